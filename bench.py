@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- `bigseqkit stats` on the BASELINE C2 workload (100 GB synthetic FASTQ,
+150 bp reads, 317 B/record), HBM-resident, through the C ABI of libbsk.so.
+
+One step == one complete Stats over the whole file:
+    zero the stats vector -> bsk_stats_run (k_prep + k_stats, one pass over the shard)
+    -> StatsReduce across ranks (ONE sum all-reduce of the stats vector over RCCL, N>1 only)
+    -> bsk_stats_collect (map[int64]int64) -> Stats()/StatsString() on the host.
+The file is cut into N record-aligned shards (strong scaling: total work is fixed).
+Prints ONE JSON line (rank 0).  See DESIGN.md section 6 for how each number is defined.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+REC = 317
+FILE_BYTES = 100_000_000_000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gb", type=float, default=FILE_BYTES / 1e9, help="size of the synthetic file (GB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import bigseqkit_amd as bsk
+    from bigseqkit_amd import _lib
+    from bigseqkit_amd._lib import lib, check
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- the synthetic file, cut into record-aligned shards --------------------------
+    total_rec = int(args.gb * 1e9) // REC
+    while True:
+        lo, hi = total_rec * rank // world, total_rec * (rank + 1) // world
+        nrec = hi - lo
+        # last whole record; the very last shard drops the final '\n' (a file need not end with one)
+        nbytes = nrec * REC
+        try:
+            shard = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            break
+        except RuntimeError:
+            if world > 1:
+                raise
+            total_rec //= 2  # smaller HBM than an MI355X: say so in config.workload
+    check(lib.bsk_synth_device(_lib.SYNTH_FASTQ150, 42, 0, lo, C.c_void_p(shard.data_ptr()), nbytes, local, None))
+    torch.cuda.synchronize()
+
+    def make_op(all_):
+        o = bsk.SeqKitStatsOptions().Tabular(True).All(all_)
+        op = bsk.Operator("Stats", o.to_json(), local)
+        vlen = lib.bsk_stats_vector_len(op.ctx)
+        vec = torch.zeros(vlen, dtype=torch.int64, device=dev)
+        return op, vec
+
+    def one_step(op, vec):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        vec.zero_()
+        check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nbytes, 1, bsk.FORMAT_FASTQ, rank,
+                                C.c_void_p(vec.data_ptr()), st), op.ctx)
+        if world > 1:
+            dist.all_reduce(vec)  # StatsReduce: sum of the dense maps (RCCL)
+        m = bsk.api._collect_map(op, C.c_void_p(vec.data_ptr()))
+        info = bsk.api._finalize(op, m)
+        buf = C.create_string_buffer(4096)
+        check(lib.bsk_stats_string(op.ctx, b"input0", b"N/A", C.byref(info), buf, len(buf)), op.ctx)
+        return m, buf.value.decode()
+
+    def timed(op, vec, steps, warmup):
+        for _ in range(warmup):
+            one_step(op, vec)
+        lib.bsk_profile_reset(op.ctx)
+        lib.bsk_profile_enable(op.ctx, 1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m, text = one_step(op, vec)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        lib.bsk_profile_enable(op.ctx, 0)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ms, n = C.c_double(), C.c_uint64()
+        lib.bsk_profile_read(op.ctx, b"k_stats", C.byref(ms), C.byref(n))
+        k_ms = ms.value / max(1, n.value)
+        lib.bsk_profile_read(op.ctx, b"k_prep", C.byref(ms), C.byref(n))
+        p_ms = ms.value / max(1, n.value)
+        return dt, m, text, k_ms, p_ms
+
+    op, vec = make_op(False)
+    dt, m, text, k_ms, p_ms = timed(op, vec, args.steps, args.warmup)
+    want_row = "input0\tN/A\tDNA\t%d\t%d\t150\t150.0\t150" % (total_rec, total_rec * 150)
+    verified = (m.get(150) == total_rec) and text.splitlines()[1] == want_row
+    op.close()
+
+    # secondary line: stats -a (Q20/Q30/gap counters on top), same timing recipe
+    op, vec = make_op(True)
+    dta, ma, texta, ka_ms, _ = timed(op, vec, max(3, args.steps // 2), 1)
+    stepsa = max(3, args.steps // 2)
+    verified_a = ma.get(150) == total_rec and ma.get(-3) == 0 and abs(ma.get(-1, 0) / (150 * total_rec) - 21 / 39) < 1e-3
+    op.close()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_bytes = total_rec * REC
+    ms_per_step = dt / args.steps * 1e3
+    out = {
+        "metric": "M records/s + GB/s (vs HBM roofline) on 100GB FASTQ stats",
+        "value": round(total_rec * args.steps / dt / 1e6, 3),
+        "unit": "M records/s",
+        "gb_per_s": round(total_bytes * args.steps / dt / 1e9, 2),
+        "frac_of_hbm_peak": round(total_bytes * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "bigseqkit stats on %.1f GB synthetic FASTQ-150 (BASELINE C2: %d records x 317 B), "
+                               "HBM-resident, %d record-aligned shard(s)" % (total_bytes / 1e9, total_rec, world),
+                   "command": "stats", "records": total_rec, "bytes": total_bytes, "seed": 42},
+        "bit_exact_vs_expected_row": bool(verified),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_stats<FASTQ,default>",
+            "achieved": round(nbytes / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_ms": round(k_ms, 4),
+            "k_prep_avg_launch_ms": round(p_ms, 4),
+        },
+        "stats_all": {
+            "value": round(total_rec * stepsa / dta / 1e6, 3), "unit": "M records/s",
+            "gb_per_s": round(total_bytes * stepsa / dta / 1e9, 2), "ms_per_step": round(dta / stepsa * 1e3, 4),
+            "k_stats_avg_launch_ms": round(ka_ms, 4),
+            "roofline_frac": round(nbytes / (ka_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ka_ms > 0 else None,
+            "verified": bool(verified_a),
+        },
+    }
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+        pilot = bytes(shard[:REC * 200_000].cpu().numpy().tobytes())
+        t0 = time.perf_counter()
+        oracle.stats_map(pilot, True, "{}")
+        rate = len(pilot) / (time.perf_counter() - t0)  # bytes/s
+        srec = int(min(args.cpu_seconds * rate, 4e9, nbytes)) // REC
+        sample = bytes(shard[:REC * srec].cpu().numpy().tobytes())
+        t0 = time.perf_counter()
+        cm = oracle.stats_map(sample, True, "{}")
+        ct = time.perf_counter() - t0
+        assert cm.get(150) == srec
+        out["cpu_baseline"] = {
+            "value": round(srec / ct / 1e6, 4), "unit": "M records/s", "gb_per_s": round(srec * REC / ct / 1e9, 4),
+            "cores": 1, "kind": "port",
+            "sample": "oracle/ (C++ restatement of ReadFixer+SeqParser+Stats, NOT IgnisHPC/Go) on the first %d "
+                      "records (%.2f GB) of the same file, %.1f s, 1 thread of %d host cores"
+                      % (srec, srec * REC / 1e9, ct, os.cpu_count()),
+        }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

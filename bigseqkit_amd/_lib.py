@@ -1,0 +1,85 @@
+"""ctypes binding of libbsk.so -- the C ABI declared in include/bsk.h.
+
+The HIP library is the product; there is no Python/CPU fallback.  Importing this
+module fails loudly when the shared library has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``./build.sh``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("BSK_LIB", os.path.join(_HERE, "lib", "libbsk.so"))
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"libbsk.so not found at {LIB_PATH}: build it with ./build.sh "
+        "(hipcc --offload-arch=gfx950); bigseqkit_amd has no CPU fallback")
+
+lib = C.CDLL(LIB_PATH)
+
+BSK_OK, BSK_ERR_INVALID_ARG, BSK_ERR_OPTS, BSK_ERR_FORMAT, BSK_ERR_UNSUPPORTED, BSK_ERR_HIP, \
+    BSK_ERR_NO_DEVICE, BSK_ERR_CAPACITY = range(8)
+FORMAT_FASTA, FORMAT_FASTQ = 0, 1
+STATS_HDR = 8
+SYNTH_FASTQ150, SYNTH_FASTA1K, SYNTH_FASTA5K_CDS = 0, 1, 2
+SYNTH_FLAG_MOTIF, SYNTH_FLAG_DUPS = 1, 2
+
+
+class StatInfo(C.Structure):
+    _fields_ = [("type", C.c_char * 16),
+                ("num", C.c_uint64), ("len_sum", C.c_uint64), ("gap_sum", C.c_uint64),
+                ("len_min", C.c_uint64), ("len_max", C.c_uint64), ("n50", C.c_uint64),
+                ("l50", C.c_int64),
+                ("len_avg", C.c_double), ("q1", C.c_double), ("q2", C.c_double), ("q3", C.c_double),
+                ("q20", C.c_double), ("q30", C.c_double)]
+
+
+_vp, _sz, _i, _i64, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_uint64
+_p = C.POINTER
+
+# every symbol include/bsk.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "bsk_version": (_i, []),
+    "bsk_device_count": (_i, []),
+    "bsk_global_error": (C.c_char_p, []),
+    "bsk_last_error": (C.c_char_p, [_vp]),
+    "bsk_create": (_i, [C.c_char_p, C.c_char_p, _i, _p(_vp)]),
+    "bsk_destroy": (None, [_vp]),
+    "bsk_opts_json": (C.c_char_p, [_vp]),
+    "bsk_find_record_start": (_i, [_vp, _sz, _sz, _i, _p(_sz)]),
+    "bsk_stats_vector_len": (_sz, [_vp]),
+    "bsk_stats_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _vp]),
+    "bsk_stats_reset": (_i, [_vp, _vp]),
+    "bsk_stats_collect": (_i, [_vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
+    "bsk_stats_merge": (_i, [_p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_sz)]),
+    "bsk_stats_finalize": (_i, [_vp, _p(_i64), _p(_i64), _sz, _p(StatInfo)]),
+    "bsk_stats_string": (_i, [_vp, C.c_char_p, C.c_char_p, _p(StatInfo), C.c_char_p, _sz]),
+    "bsk_synth_record_bytes": (_sz, [_i]),
+    "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),
+    "bsk_synth_device": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz, _i, _vp]),
+    "bsk_event_create": (_i, [_p(_vp)]),
+    "bsk_event_record": (_i, [_vp, _vp]),
+    "bsk_event_elapsed_ms": (_i, [_vp, _vp, _p(C.c_float)]),
+    "bsk_event_destroy": (_i, [_vp]),
+    "bsk_profile_enable": (_i, [_vp, _i]),
+    "bsk_profile_read": (_i, [_vp, C.c_char_p, _p(C.c_double), _p(_u64)]),
+    "bsk_profile_reset": (_i, [_vp]),
+    "bsk_selftest_scan": (_i, [_i, _p(C.c_uint32), _p(C.c_uint32)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)  # AttributeError here == symbol missing from the build
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class BskError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def check(rc, ctx=None):
+    if rc != BSK_OK:
+        msg = lib.bsk_last_error(ctx) if ctx else lib.bsk_global_error()
+        raise BskError(rc, (msg or b"").decode("utf-8", "replace"))

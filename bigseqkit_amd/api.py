@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's driver library for the hot path.
+
+Same entry points, argument meaning and error behaviour as
+/root/reference/bigseqkit/{helper,stats}.go, but the dataflow
+``MapPartitions(libSource("Stats")) -> Reduce(libSource("StatsReduce"))`` is a
+sequence of C-ABI calls into libbsk.so (include/bsk.h) instead of IgnisHPC tasks.
+"""
+import ctypes as C
+import os
+
+from . import _lib
+from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
+from .options import SeqKitStatsOptions
+
+
+class SeqFrame:
+    """What ``*api.IDataFrame[string]`` is to the reference: the records of one input,
+    held as shards (partitions) of raw FASTA/FASTQ text that begin on a record.
+    A shard is ``(buffer, nbytes, on_device)``; device buffers are anything with
+    ``data_ptr()`` (a torch uint8 tensor), host buffers are bytes-like."""
+
+    def __init__(self, fmt, shards):
+        self.format = fmt
+        self.shards = list(shards)
+
+    @staticmethod
+    def _ptr(buf):
+        if hasattr(buf, "data_ptr"):
+            return C.c_void_p(buf.data_ptr()), int(buf.numel()), bool(buf.is_cuda)
+        mv = memoryview(buf)
+        if mv.readonly:
+            arr = (C.c_char * len(mv)).from_buffer_copy(mv)  # keeps a private copy alive
+        else:
+            arr = (C.c_char * len(mv)).from_buffer(mv)
+        return C.cast(arr, C.c_void_p), len(mv), False, arr
+
+    def partitions(self):
+        for pid, buf in enumerate(self.shards):
+            r = self._ptr(buf)
+            yield pid, r[0], r[1], r[2], r  # keep r alive while the pointer is in use
+
+
+def _read(path_or_bytes, fmt, min_partitions=1):
+    if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) or hasattr(path_or_bytes, "data_ptr"):
+        data = path_or_bytes
+    else:
+        with open(os.fspath(path_or_bytes), "rb") as f:
+            data = f.read()
+    if hasattr(data, "data_ptr") or min_partitions <= 1:
+        return SeqFrame(fmt, [data])
+    # PlainFileN(path, minPartitions, delim) + ReadFixer: cut on record starts
+    n = len(data)
+    arr = (C.c_char * n).from_buffer_copy(data)
+    cuts = [0]
+    for k in range(1, min_partitions):
+        out = C.c_size_t()
+        check(lib.bsk_find_record_start(C.cast(arr, C.c_void_p), n, n * k // min_partitions, fmt, C.byref(out)))
+        if out.value > cuts[-1]:
+            cuts.append(out.value)
+    cuts.append(n)
+    return SeqFrame(fmt, [bytes(data[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a])
+
+
+def ReadFASTA(path, worker=None):
+    """bigseqkit/helper.go:148-154"""
+    return _read(path, FORMAT_FASTA)
+
+
+def ReadFASTAN(path, minPartitions, worker=None):
+    """bigseqkit/helper.go:156-162"""
+    return _read(path, FORMAT_FASTA, minPartitions)
+
+
+def ReadFASTQ(path, worker=None):
+    """bigseqkit/helper.go:164-170"""
+    return _read(path, FORMAT_FASTQ)
+
+
+def ReadFASTQN(path, minPartitions, worker=None):
+    """bigseqkit/helper.go:172-178"""
+    return _read(path, FORMAT_FASTQ, minPartitions)
+
+
+class Operator:
+    """One plugin operator between Before() and After() (bsk_create .. bsk_destroy)."""
+
+    def __init__(self, name, opts_json, device=0):
+        self.ctx = C.c_void_p()
+        if isinstance(opts_json, str):
+            opts_json = opts_json.encode()
+        check(lib.bsk_create(name.encode(), opts_json, device, C.byref(self.ctx)))
+
+    def close(self):
+        if self.ctx:
+            lib.bsk_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def opts_json(self):
+        return lib.bsk_opts_json(self.ctx).decode()
+
+
+def _collect_map(op, d_vec=None):
+    cap = 1024
+    while True:
+        n = C.c_size_t()
+        keys = (C.c_int64 * cap)()
+        vals = (C.c_int64 * cap)()
+        rc = lib.bsk_stats_collect(op.ctx, d_vec, keys, vals, cap, C.byref(n))
+        if rc == _lib.BSK_ERR_CAPACITY and n.value > cap:
+            cap = n.value
+            continue
+        check(rc, op.ctx)
+        return dict(zip(keys[:n.value], vals[:n.value]))
+
+
+def stats_map(input, o=None, device=0, stream=None):
+    """MapPartitions(Stats) + Reduce(StatsReduce) (bigseqkit/stats.go:81-94): the merged
+    map[int64]int64.  Returns (map, operator) -- the operator carries the first record
+    the driver needs for the type column."""
+    o = o or SeqKitStatsOptions()
+    op = Operator("Stats", o.to_json(), device)
+    try:
+        for pid, ptr, n, on_dev, keep in input.partitions():
+            check(lib.bsk_stats_run(op.ctx, ptr, n, 1 if on_dev else 0, input.format, pid, None, stream), op.ctx)
+        return _collect_map(op), op
+    except Exception:
+        op.close()
+        raise
+
+
+def _finalize(op, m):
+    ks = sorted(m)
+    keys = (C.c_int64 * len(ks))(*ks)
+    vals = (C.c_int64 * len(ks))(*[m[k] for k in ks])
+    info = _lib.StatInfo()
+    check(lib.bsk_stats_finalize(op.ctx, keys, vals, len(ks), C.byref(info)), op.ctx)
+    return info
+
+
+def Stats(name, format, input, o=None, device=0):
+    """bigseqkit/stats.go:75-166 -> StatInfo"""
+    m, op = stats_map(input, o, device)
+    with op:
+        return _finalize(op, m)
+
+
+def StatsString(name, format, input, o=None, device=0):
+    """bigseqkit/stats.go:168-288"""
+    m, op = stats_map(input, o, device)
+    with op:
+        info = _finalize(op, m)
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.bsk_stats_string(op.ctx, name.encode(), format.encode(), C.byref(info), buf, len(buf)), op.ctx)
+        return buf.value.decode()

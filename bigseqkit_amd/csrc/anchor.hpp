@@ -1,0 +1,106 @@
+// Record-boundary repair: find the first record start at or after a byte offset.
+// This is the job IgnisHPC's PlainFile(path, delim) + ReadFixer do for the
+// reference (/root/reference/bigseqkit/helper.go:148-178,
+// bigseqkit-lib/helper.go:41-66): every partition must begin on a record.
+// One rule, compiled for host (shard cutting) and device (range anchors).
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define BSK_HD __host__ __device__ __forceinline__
+#else
+#ifndef BSK_HD
+#define BSK_HD inline
+#endif
+#endif
+
+namespace bsk {
+
+// first index >= from with buf[idx] == c, else n
+BSK_HD uint64_t find_byte(const uint8_t* buf, uint64_t n, uint64_t from, uint8_t c) {
+    uint64_t i = from;
+    // head: up to 8-byte alignment
+    while (i < n && ((uintptr_t)(buf + i) & 7)) {
+        if (buf[i] == c) return i;
+        ++i;
+    }
+    const uint64_t rep = 0x0101010101010101ull * c;
+    while (i + 8 <= n) {
+        uint64_t x = *(const uint64_t*)(buf + i) ^ rep;
+        // exact zero-byte detector
+        uint64_t z = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);
+        if (z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            return i + ((uint64_t)(__ffsll((long long)z) - 1) >> 3);
+#else
+            return i + ((uint64_t)__builtin_ctzll(z) >> 3);
+#endif
+        }
+        i += 8;
+    }
+    while (i < n) {
+        if (buf[i] == c) return i;
+        ++i;
+    }
+    return n;
+}
+
+// FASTA: a record starts at a '>' that is the first byte of a line (PARITY.md SPLIT).
+BSK_HD uint64_t find_fasta_start(const uint8_t* buf, uint64_t n, uint64_t from) {
+    if (from >= n) return n;
+    if (from == 0 && buf[0] == '>') return 0;
+    uint64_t j = from == 0 ? find_byte(buf, n, 0, '\n') : find_byte(buf, n, from - 1, '\n');
+    while (j < n) {
+        if (j + 1 < n && buf[j + 1] == '>') return j + 1;
+        j = find_byte(buf, n, j + 1, '\n');
+    }
+    return n;
+}
+
+// FASTQ (strict 4-line layout): line p is a record start iff it begins with
+// '@', the line two below begins with '+', the sequence line does not begin
+// with '+', and len(line p+1) == len(line p+3).  A quality line that begins
+// with '@' fails the test because the line two below it is a sequence line.
+BSK_HD bool fastq_record_at(const uint8_t* buf, uint64_t n, uint64_t p) {
+    if (p >= n || buf[p] != '@') return false;
+    uint64_t e0 = find_byte(buf, n, p, '\n');
+    if (e0 >= n) return false;
+    uint64_t s0 = e0 + 1;
+    uint64_t e1 = find_byte(buf, n, s0, '\n');
+    if (e1 >= n) return false;
+    if (e1 > s0 && buf[s0] == '+') return false;
+    uint64_t p0 = e1 + 1;
+    if (p0 >= n || buf[p0] != '+') return false;
+    uint64_t e2 = find_byte(buf, n, p0, '\n');
+    if (e2 >= n) return false;
+    uint64_t q0 = e2 + 1;
+    uint64_t e3 = find_byte(buf, n, q0, '\n');  // may be n: last line without '\n'
+    if (e3 - q0 != e1 - s0) return false;
+    if (e3 + 1 < n) {
+        uint8_t c = buf[e3 + 1];
+        if (c != '@' && c != '\n') return false;
+    }
+    return true;
+}
+
+BSK_HD uint64_t find_fastq_start(const uint8_t* buf, uint64_t n, uint64_t from) {
+    if (from >= n) return n;
+    if (from == 0 && fastq_record_at(buf, n, 0)) return 0;
+    uint64_t j = from == 0 ? find_byte(buf, n, 0, '\n') : find_byte(buf, n, from - 1, '\n');
+    while (j < n) {
+        if (fastq_record_at(buf, n, j + 1)) return j + 1;
+        j = find_byte(buf, n, j + 1, '\n');
+    }
+    return n;
+}
+
+// end of the shard once trailing blank lines are dropped: at most one '\n'
+// is kept after the last non-newline byte; a buffer of only newlines is empty.
+BSK_HD uint64_t effective_end(const uint8_t* buf, uint64_t n) {
+    uint64_t e = n;
+    while (e >= 2 && buf[e - 1] == '\n' && buf[e - 2] == '\n') --e;
+    if (e == 1 && buf[0] == '\n') e = 0;
+    return e;
+}
+
+}  // namespace bsk

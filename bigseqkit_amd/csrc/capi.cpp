@@ -1,0 +1,557 @@
+// C ABI of libbsk.so (see include/bsk.h for the reference interface each entry
+// point replaces).  Host code only; kernels live in the .hip files.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/bsk.h"
+#include "anchor.hpp"
+#include "ctx.hpp"
+#include "stats_host.hpp"
+#include "stream_stats.hpp"
+#include "synth.hpp"
+
+namespace bsk {
+hipError_t launch_synth(int kind, uint64_t seed, unsigned flags, uint64_t first_record, uint8_t* dst, uint64_t n,
+                        hipStream_t st);
+}
+
+using namespace bsk;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail_global(int code, const std::string& m) {
+    g_error = m;
+    return code;
+}
+int fail(const bsk_ctx* c, int code, const std::string& m) {
+    if (c) c->set_error(m);
+    g_error = m;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail(ctx, BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+constexpr uint64_t MIN_RANGE_BYTES = 64 * 1024;  // BSK_MIN_RANGE_BYTES overrides (tests stress tiny ranges)
+constexpr int RANGES_PER_WAVE = 4;
+
+struct Timed {  // optional HIP-event bracket around one launch
+    bsk_ctx* c;
+    const char* name;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(bsk_ctx* c_, const char* n, hipStream_t s) : c(c_), name(n), st(s) {
+        if (c->profile) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, st);
+        }
+    }
+    ~Timed() {
+        if (c->profile && a) {
+            hipEventRecord(b, st);
+            c->pending.push_back({name, a, b});
+        }
+    }
+};
+
+// ---- Before() of each operator: option validation with the reference's texts ----
+void validate_stats(bsk_ctx* c) {  // bigseqkit-lib/stats.go:27-46
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    const std::string& g = o.s("GapLetters");
+    if (g.empty()) throw OptError("value of flag -G (--gap-letters) should not be empty");
+    for (unsigned char ch : g)
+        if (ch > 127) throw OptError("value of -G (--gap-letters) contains non-ASCII characters");
+    c->qual_offset = quality_offset(o.s("FqEncoding"));  // stats.go:58-62 (raised in Call there)
+    std::string uniq;
+    for (char ch : g)
+        if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
+    if ((int)uniq.size() > MAX_GAP_LETTERS)
+        throw OptError("libbsk: at most 8 distinct gap letters are supported by the HIP path");
+}
+
+int ensure_ranges(bsk_ctx* c, uint32_t nranges) {
+    if (nranges <= c->cap_ranges && c->d_anchors) return BSK_OK;
+    if (c->d_anchors) HIP_TRY(c, hipFree(c->d_anchors));
+    c->d_anchors = nullptr;
+    // anchors[nranges + 1] followed by the queue word
+    HIP_TRY(c, hipMalloc((void**)&c->d_anchors, ((size_t)nranges + 2) * sizeof(uint64_t)));
+    c->cap_ranges = nranges;
+    return BSK_OK;
+}
+
+int init_device(bsk_ctx* c) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(c, BSK_ERR_NO_DEVICE, "libbsk: no HIP device visible (this library has no CPU fallback)");
+    if (c->device >= ndev) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: device index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipDeviceProp_t p;
+    HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
+    c->num_cus = p.multiProcessorCount;
+    const char* sc = getenv("BSK_SCAN");
+    c->use_dpp = !(sc && strcmp(sc, "shfl") == 0);
+    const char* mr = getenv("BSK_MIN_RANGE_BYTES");
+    c->min_range_bytes = mr && atoll(mr) > 0 ? (uint64_t)atoll(mr) : MIN_RANGE_BYTES;
+    HIP_TRY(c, hipMalloc((void**)&c->d_status, 2 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMemset(c->d_status, 0, 2 * sizeof(uint64_t)));
+    if (c->op == Op::Stats) {
+        const size_t len = (size_t)STATS_HDR + c->hist_cap;
+        HIP_TRY(c, hipMalloc((void**)&c->d_vec, len * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemset(c->d_vec, 0, len * sizeof(uint64_t)));
+    }
+    return BSK_OK;
+}
+
+// sequence bytes of the first record in `b` (up to `limit` bytes)
+std::vector<uint8_t> first_record_seq(const std::vector<uint8_t>& b, int format, size_t limit) {
+    std::vector<uint8_t> s;
+    const size_t n = b.size();
+    size_t p = 0;
+    while (p < n && b[p] != '\n') ++p;  // header
+    ++p;
+    if (format == BSK_FORMAT_FASTQ) {
+        while (p < n && b[p] != '\n' && s.size() < limit) s.push_back(b[p++]);
+        return s;
+    }
+    while (p < n && s.size() < limit) {
+        if (b[p] == '>' && b[p - 1] == '\n') break;
+        if (b[p] != '\n') s.push_back(b[p]);
+        ++p;
+    }
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsk_version(void) { return 100; }
+
+int bsk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* bsk_global_error(void) { return g_error.c_str(); }
+
+const char* bsk_last_error(const bsk_ctx* c) {
+    if (!c) return g_error.c_str();
+    std::lock_guard<std::mutex> g(c->mu);
+    // stable storage for the caller
+    thread_local std::string copy;
+    copy = c->last_error;
+    return copy.c_str();
+}
+
+int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx** out) {
+    if (!op_name_ || !out) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null argument");
+    *out = nullptr;
+    Op op;
+    if (!op_from_name(op_name_, &op))
+        return fail_global(BSK_ERR_INVALID_ARG, std::string("libbsk: unknown operator: ") + op_name_);
+    bsk_ctx* c = new (std::nothrow) bsk_ctx();
+    if (!c) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: out of memory");
+    c->op = op;
+    c->device = device;
+    try {
+        c->opts = Options::from_json(op, opts_json && *opts_json ? opts_json : "{}");
+        c->opts_json = c->opts.to_json();
+        switch (op) {
+            case Op::Stats: validate_stats(c); break;
+            default: break;  // validated by the op's own module once it is built
+        }
+    } catch (const std::exception& e) {
+        std::string m = e.what();
+        delete c;
+        return fail_global(BSK_ERR_OPTS, m);
+    }
+    if (device >= 0) {
+        int rc = init_device(c);
+        if (rc != BSK_OK) {
+            std::string m = c->last_error;
+            bsk_destroy(c);
+            return fail_global(rc, m);
+        }
+    }
+    *out = c;
+    return BSK_OK;
+}
+
+void bsk_destroy(bsk_ctx* c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        hipSetDevice(c->device);
+        hipDeviceSynchronize();
+        for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+        if (c->d_anchors) hipFree(c->d_anchors);
+        if (c->d_vec) hipFree(c->d_vec);
+        if (c->d_status) hipFree(c->d_status);
+        if (c->d_overflow) hipFree(c->d_overflow);
+        for (int i = 0; i < 2; ++i) {
+            if (c->d_stage[i]) hipFree(c->d_stage[i]);
+            if (c->pinned[i]) hipHostFree(c->pinned[i]);
+            if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
+            if (c->stage_done[i]) hipEventDestroy(c->stage_done[i]);
+        }
+    }
+    delete c;
+}
+
+const char* bsk_opts_json(const bsk_ctx* c) { return c ? c->opts_json.c_str() : ""; }
+
+int bsk_find_record_start(const uint8_t* buf, size_t n, size_t from, int format, size_t* out) {
+    if (!buf || !out) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null argument");
+    *out = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_start(buf, n, from) : (size_t)find_fasta_start(buf, n, from);
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Stats
+// ---------------------------------------------------------------------------
+size_t bsk_stats_vector_len(const bsk_ctx* c) { return c ? (size_t)STATS_HDR + c->hist_cap : 0; }
+
+int bsk_stats_reset(bsk_ctx* c, void* stream) {
+    if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_vec, 0, ((size_t)STATS_HDR + c->hist_cap) * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    return BSK_OK;
+}
+
+static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, uint64_t* d_vec, hipStream_t st) {
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    const bool all = c->opts.b("All");
+    const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp);
+    const int blocks = std::max(1, c->num_cus * per_cu);
+    const uint64_t waves = (uint64_t)blocks * 4;
+    uint64_t nr = n / c->min_range_bytes;
+    nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, waves * RANGES_PER_WAVE));
+    const uint32_t nranges = (uint32_t)nr;
+    // 16-byte aligned nominal chunk so that most range starts keep tile alignment cheap
+    uint64_t chunk = (n + nranges - 1) / nranges;
+    chunk = (chunk + 15) & ~(uint64_t)15;
+    int rc = ensure_ranges(c, nranges);
+    if (rc != BSK_OK) return rc;
+    // overflow list for lengths >= hist_cap
+    const uint64_t need = n / c->hist_cap + 1024;
+    if (need > c->overflow_cap) {
+        // keep what earlier runs appended
+        uint64_t* nb = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&nb, need * sizeof(uint64_t)));
+        if (c->d_overflow) {
+            HIP_TRY(c, hipMemcpyAsync(nb, c->d_overflow, c->overflow_cap * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            HIP_TRY(c, hipFree(c->d_overflow));
+        }
+        c->d_overflow = nb;
+        c->overflow_cap = need;
+    }
+    StatsDev D;
+    D.vec = d_vec ? d_vec : c->d_vec;
+    D.status = c->d_status;
+    D.overflow = c->d_overflow;
+    D.overflow_cap = c->overflow_cap;
+    D.hist_cap = c->hist_cap;
+    const uint32_t t20 = (uint32_t)(c->qual_offset + 20), t30 = (uint32_t)(c->qual_offset + 30);
+    D.k20 = (0x80u - t20) * 0x01010101u;
+    D.k30 = (0x80u - t30) * 0x01010101u;
+    D.ngap = 0;
+    for (int k = 0; k < MAX_GAP_LETTERS; ++k) D.gap_rep[k] = 0;
+    {
+        std::string uniq;
+        for (char ch : c->opts.s("GapLetters"))
+            if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
+        for (char ch : uniq) D.gap_rep[D.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;
+    }
+    uint64_t* anchors = c->d_anchors;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
+    {
+        Timed t(c, "k_prep", st);
+        HIP_TRY(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st));
+    }
+    {
+        Timed t(c, "k_stats", st);
+        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+    }
+    return BSK_OK;
+}
+
+int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* d_vec,
+                  void* stream) {
+    if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    if (format != BSK_FORMAT_FASTA && format != BSK_FORMAT_FASTQ)
+        return fail(c, BSK_ERR_INVALID_ARG, "libbsk: format must be BSK_FORMAT_FASTA or BSK_FORMAT_FASTQ");
+    if (n == 0) return BSK_OK;
+    if (!shard) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null shard");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+
+    // head of the lowest-pid shard: type guess (stats.go:106-114) and Take(1) (bigseqkit/stats.go:117)
+    if (pid < c->first_pid) {
+        const int64_t thr = c->opts.ci("AlphabetGuessSeqLength");
+        size_t want = (size_t)std::max<int64_t>(thr, 10000) * 2 + 65536;
+        want = std::min(want, n);
+        c->first_bytes.resize(want);
+        if (on_device) HIP_TRY(c, hipMemcpy(c->first_bytes.data(), shard, want, hipMemcpyDeviceToHost));
+        else memcpy(c->first_bytes.data(), shard, want);
+        c->first_pid = pid;
+        c->first_format = format;
+    }
+    if (on_device) return stats_run_device(c, (const uint8_t*)shard, n, format, (uint64_t*)d_vec, st);
+
+    // host-resident shard: stage through a device buffer
+    if (n > c->stage_cap) {
+        if (c->d_stage[0]) HIP_TRY(c, hipFree(c->d_stage[0]));
+        c->d_stage[0] = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&c->d_stage[0], n + 16));
+        c->stage_cap = n;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage[0], shard, n, hipMemcpyHostToDevice, st));
+    int rc = stats_run_device(c, c->d_stage[0], n, format, (uint64_t*)d_vec, st);
+    if (rc != BSK_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(st));  // the staging buffer is reused by the next call
+    return BSK_OK;
+}
+
+static std::string describe_kernel_errors(uint64_t f, int* code) {
+    *code = BSK_ERR_FORMAT;
+    if (f & ERR_LEN_MISMATCH) return "unmatched length of sequence and quality";
+    if (f & ERR_BAD_HEADER) {
+        *code = BSK_ERR_UNSUPPORTED;
+        return "record does not start with '>' / '@' at a line start (leading blank lines, multi-line FASTQ and "
+               "blank lines between records are not accepted by the HIP path)";
+    }
+    if (f & ERR_BAD_PLUS) {
+        *code = BSK_ERR_UNSUPPORTED;
+        return "FASTQ is not in the strict 4-line layout (third line must start with '+')";
+    }
+    if (f & ERR_TRUNCATED) return "FASTQ ends inside a record";
+    if (f & ERR_ANCHOR) {
+        *code = BSK_ERR_UNSUPPORTED;
+        return "FASTQ is not in the strict 4-line layout (a range did not end on a record boundary)";
+    }
+    if (f & ERR_LINE_TOO_LONG) {
+        *code = BSK_ERR_UNSUPPORTED;
+        return "a line longer than 2^31 bytes";
+    }
+    return "unknown kernel error";
+}
+
+int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
+    if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    if (!n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_out");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    uint64_t status[2];
+    HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+    if (status[0]) {
+        int code;
+        std::string m = describe_kernel_errors(status[0], &code);
+        return fail(c, code, m);
+    }
+    const size_t len = (size_t)STATS_HDR + c->hist_cap;
+    std::vector<uint64_t> v(len);
+    HIP_TRY(c, hipMemcpy(v.data(), d_vec ? d_vec : (const void*)c->d_vec, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    StatsMap m;
+    for (uint32_t L = 0; L < c->hist_cap; ++L)
+        if (v[STATS_HDR + L]) m[(int64_t)L] = (int64_t)v[STATS_HDR + L];
+    if (status[1]) {
+        if (status[1] > c->overflow_cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow length list exhausted");
+        std::vector<uint64_t> ov(status[1]);
+        HIP_TRY(c, hipMemcpy(ov.data(), c->d_overflow, status[1] * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (uint64_t L : ov) m[(int64_t)L] += 1;
+    }
+    const bool all = c->opts.b("All");
+    const uint64_t nrec = v[3];
+    if (all && nrec > 0) {
+        if (v[0]) m[KEY_Q20] = (int64_t)v[0];
+        if (v[1]) m[KEY_Q30] = (int64_t)v[1];
+        m[KEY_GAP] = (int64_t)v[2];
+    }
+    // key -4 (bigseqkit-lib/stats.go:106-114): alphabet forced by -t, else guessed
+    // from the first record of the lowest partition seen
+    Alphabet ab = c->alphabet;
+    std::vector<uint8_t> seq;
+    if (nrec > 0 && !c->first_bytes.empty()) {
+        const int64_t thr = c->opts.ci("AlphabetGuessSeqLength");
+        seq = first_record_seq(c->first_bytes, c->first_format, (size_t)std::max<int64_t>(thr, 10000));
+        if (ab == AB_NONE) ab = guess_alphabet_less_conservatively(seq.data(), seq.size(), thr);
+    }
+    if (ab == AB_NONE) ab = AB_UNLIMIT;  // SeqParser.Alphabet() with t == nil
+    int64_t T;
+    if (ab == AB_DNAredundant) T = 'D';
+    else if (ab == AB_RNAredundant) T = 'R';
+    else if (nrec == 0 && ab == AB_UNLIMIT) T = 'U';
+    else T = 'F';
+    m[KEY_TYPE] = T;
+    // what the driver would find with Take(1) + a fresh fastx reader (bio default threshold)
+    c->type_if_F = alphabet_name(guess_alphabet_less_conservatively(seq.data(), seq.size(), 10000));
+    *n_out = m.size();
+    if (m.size() > cap || !keys || !vals) {
+        if (cap == 0) return BSK_OK;  // size query
+        return fail(c, BSK_ERR_CAPACITY, "libbsk: output map does not fit the caller's buffers");
+    }
+    size_t i = 0;
+    for (auto& kv : m) {
+        keys[i] = kv.first;
+        vals[i] = kv.second;
+        ++i;
+    }
+    return BSK_OK;
+}
+
+int bsk_stats_merge(const int64_t* ka, const int64_t* va, size_t na, const int64_t* kb, const int64_t* vb, size_t nb,
+                    int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
+    if (!n_out) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null n_out");
+    StatsMap a, b;
+    for (size_t i = 0; i < na; ++i) a[ka[i]] = va[i];
+    for (size_t i = 0; i < nb; ++i) b[kb[i]] = vb[i];
+    StatsMap r = stats_merge(a, b);
+    *n_out = r.size();
+    if (r.size() > cap) return fail_global(BSK_ERR_CAPACITY, "libbsk: output map does not fit the caller's buffers");
+    size_t i = 0;
+    for (auto& kv : r) {
+        keys[i] = kv.first;
+        vals[i] = kv.second;
+        ++i;
+    }
+    return BSK_OK;
+}
+
+int bsk_stats_finalize(const bsk_ctx* c, const int64_t* keys, const int64_t* vals, size_t n, bsk_statinfo* out) {
+    if (!c || c->op != Op::Stats || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    StatsMap m;
+    for (size_t i = 0; i < n; ++i) m[keys[i]] = vals[i];
+    stats_finalize(m, c->opts.b("All"), c->type_if_F, out);
+    return BSK_OK;
+}
+
+int bsk_stats_string(const bsk_ctx* c, const char* name, const char* format, const bsk_statinfo* info, char* out,
+                     size_t cap) {
+    if (!c || c->op != Op::Stats || !info || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    std::string s = stats_string(name ? name : "", format ? format : "", *info, c->opts.b("Tabular"), c->opts.b("All"));
+    if (s.size() + 1 > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
+    memcpy(out, s.c_str(), s.size() + 1);
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic inputs
+// ---------------------------------------------------------------------------
+size_t bsk_synth_record_bytes(int kind) { return synth::record_bytes(kind); }
+
+int bsk_synth_host(int kind, uint64_t seed, unsigned flags, uint64_t first_record, uint8_t* dst, size_t n) {
+    if (!dst && n) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null dst");
+    const uint32_t rb = synth::record_bytes(kind);
+    uint64_t i = first_record;
+    uint32_t k = 0;
+    for (size_t p = 0; p < n; ++p) {
+        dst[p] = synth::byte_at(kind, seed, flags, i, k);
+        if (++k == rb) { k = 0; ++i; }
+    }
+    return BSK_OK;
+}
+
+int bsk_synth_device(int kind, uint64_t seed, unsigned flags, uint64_t first_record, void* d_dst, size_t n, int device,
+                     void* stream) {
+    if (!d_dst && n) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null dst");
+    if (n == 0) return BSK_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev)
+        return fail_global(BSK_ERR_NO_DEVICE, "libbsk: no HIP device visible");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, launch_synth(kind, seed, flags, first_record, (uint8_t*)d_dst, n, (hipStream_t)stream));
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// events / profiling
+// ---------------------------------------------------------------------------
+int bsk_event_create(void** ev) {
+    hipEvent_t e;
+    HIP_TRY(nullptr, hipEventCreate(&e));
+    *ev = e;
+    return BSK_OK;
+}
+int bsk_event_record(void* ev, void* stream) {
+    HIP_TRY(nullptr, hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return BSK_OK;
+}
+int bsk_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIP_TRY(nullptr, hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(nullptr, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return BSK_OK;
+}
+int bsk_event_destroy(void* ev) {
+    HIP_TRY(nullptr, hipEventDestroy((hipEvent_t)ev));
+    return BSK_OK;
+}
+
+int bsk_profile_enable(bsk_ctx* c, int on) {
+    if (!c) return BSK_ERR_INVALID_ARG;
+    c->profile = on != 0;
+    return BSK_OK;
+}
+
+int bsk_profile_read(bsk_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
+    if (!c || !kernel) return BSK_ERR_INVALID_ARG;
+    if (c->device >= 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        for (auto& p : c->pending) {
+            HIP_TRY(c, hipEventSynchronize(p.b));
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
+            auto& pr = c->prof[p.name];
+            pr.ms += ms;
+            pr.launches += 1;
+            hipEventDestroy(p.a);
+            hipEventDestroy(p.b);
+        }
+        c->pending.clear();
+    }
+    auto it = c->prof.find(kernel);
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    return BSK_OK;
+}
+
+int bsk_profile_reset(bsk_ctx* c) {
+    if (!c) return BSK_ERR_INVALID_ARG;
+    double d;
+    uint64_t l;
+    bsk_profile_read(c, "", &d, &l);
+    c->prof.clear();
+    return BSK_OK;
+}
+
+// wave-scan self test (tests/test_gpu_primitives.py)
+int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64) {
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(nullptr, hipMalloc((void**)&d_in, 64 * 4));
+    HIP_TRY(nullptr, hipMalloc((void**)&d_out, 64 * 4));
+    HIP_TRY(nullptr, hipMemcpy(d_in, in64, 64 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(nullptr, launch_scan_selftest(use_dpp != 0, d_in, d_out, nullptr));
+    HIP_TRY(nullptr, hipMemcpy(out64, d_out, 64 * 4, hipMemcpyDeviceToHost));
+    hipFree(d_in);
+    hipFree(d_out);
+    return BSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Operator context == one instance of a reference plugin operator between
+// Before() and After() (see include/bsk.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "opts.hpp"
+
+struct bsk_ctx {
+    bsk::Op op;
+    bsk::Options opts;
+    std::string opts_json;
+    int device = -1;  // < 0: options only
+    mutable std::mutex mu;
+    mutable std::string last_error;
+
+    // ---- device state shared by the ops -----------------------------------
+    int num_cus = 0;
+    uint64_t min_range_bytes = 64 * 1024;
+    bool use_dpp = true;          // BSK_SCAN=shfl selects the ds_bpermute scan
+    uint64_t* d_anchors = nullptr;  // [cap_ranges + 1] + queue word
+    uint32_t cap_ranges = 0;
+    hipStream_t own_stream = nullptr;
+
+    // ---- Stats ----------------------------------------------------------------
+    bsk::Alphabet alphabet = bsk::AB_NONE;  // forced by -t, else AB_NONE
+    uint32_t hist_cap = 1u << 16;
+    uint64_t* d_vec = nullptr;       // ctx-owned stats vector
+    uint64_t* d_status = nullptr;    // [0] err flags [1] overflow count
+    uint64_t* d_overflow = nullptr;
+    uint64_t overflow_cap = 0;
+    int qual_offset = 33;
+    std::vector<uint8_t> first_bytes;  // head of the lowest-pid shard (type guess, Take(1))
+    int64_t first_pid = INT64_MAX;
+    int first_format = -1;
+    std::string type_if_F;  // alphabet name the driver would guess from Take(1) (bigseqkit/stats.go:117-129)
+
+    // ---- staging for host-resident shards ------------------------------------
+    uint8_t* pinned[2] = {nullptr, nullptr};
+    uint8_t* d_stage[2] = {nullptr, nullptr};
+    size_t stage_cap = 0;
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+
+    // ---- profiling (bench.py roofline leg) -----------------------------------
+    bool profile = false;
+    struct Prof { double ms = 0; uint64_t launches = 0; };
+    std::map<std::string, Prof> prof;
+    struct PendingEv { const char* name; hipEvent_t a, b; };
+    std::vector<PendingEv> pending;  // event pairs recorded around launches, not yet read
+
+    void set_error(const std::string& m) const {
+        std::lock_guard<std::mutex> g(mu);
+        last_error = m;
+    }
+};

@@ -1,0 +1,156 @@
+/* ============================================================================
+ * bsk.h -- C ABI of libbsk.so, the MI355X (gfx950) engine behind BigSeqKit's
+ * per-record map/filter hot path.
+ *
+ * Every entry point replaces one executor-side operator of the reference's Go
+ * plugin (bigseqkit.so, looked up as "New"+Name by IgnisHPC; see
+ * /root/reference/bigseqkit/helper.go:21-23).  Citations are file:line relative
+ * to /root/reference/.  The lifecycle of the reference operators
+ *     Before(ctx)  ->  Call(partition)...  ->  After(ctx)
+ * maps to
+ *     bsk_create() ->  bsk_<op>_run()...   ->  bsk_destroy().
+ * Options travel exactly as in the reference: the JSON text produced by
+ * bigseqkit.OptionsToString (bigseqkit/helper.go:47-55), i.e. the Go struct of
+ * the command with exported field names and a nested "Config" (KitConfig).
+ *
+ * Plain C: pointers and sizes only; no torch / HIP types in any signature
+ * (streams are passed as void* = hipStream_t, device buffers as void*).
+ * All functions return 0 (BSK_OK) on success, else a BSK_ERR_* code; the
+ * message (the reference's own error text where one exists) is available from
+ * bsk_last_error(ctx) or, for failures that have no ctx, bsk_global_error().
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails with BSK_ERR_NO_DEVICE.
+ * ==========================================================================*/
+#ifndef BSK_H
+#define BSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSK_OK 0
+#define BSK_ERR_INVALID_ARG 1 /* bad pointer / size / op name                         */
+#define BSK_ERR_OPTS 2        /* option validation failed (reference's Before() error) */
+#define BSK_ERR_FORMAT 3      /* malformed record (reference's Call() error)           */
+#define BSK_ERR_UNSUPPORTED 4 /* input layout the HIP path does not accept (PARITY.md) */
+#define BSK_ERR_HIP 5         /* HIP runtime error                                     */
+#define BSK_ERR_NO_DEVICE 6   /* no gfx950 device visible                              */
+#define BSK_ERR_CAPACITY 7    /* caller-provided output buffer too small               */
+
+#define BSK_FORMAT_FASTA 0
+#define BSK_FORMAT_FASTQ 1
+
+typedef struct bsk_ctx bsk_ctx;
+
+/* ---- library ------------------------------------------------------------ */
+int bsk_version(void);
+/* number of visible HIP devices (0 when none); never fails */
+int bsk_device_count(void);
+const char* bsk_global_error(void);         /* thread-local */
+const char* bsk_last_error(const bsk_ctx*); /* per context  */
+
+/* ---- operator lifecycle ---------------------------------------------------
+ * op_name is the reference's plugin symbol without "New":
+ *   "Stats"            NewStats            bigseqkit-lib/stats.go:16
+ *   "SeqTransform"     NewSeqTransform     bigseqkit-lib/seq.go:17
+ *   "Grep"             NewGrep             bigseqkit-lib/grep.go:24
+ *   "Locate"           NewLocate           bigseqkit-lib/locate.go:19
+ *   "SubseqTransform"  NewSubseqTransform  bigseqkit-lib/subseq.go:22
+ *   "Translate"        NewTranslate        bigseqkit-lib/translate.go:21
+ *   "RmDup"            NewRmDupPrepare + NewRmDupCheck  bigseqkit-lib/rmdup.go:23,92
+ * bsk_create == Before(): decodes opts_json (StringToOptions, helper.go:57-66),
+ * fills defaults (setDefaults of the command), validates with the reference's
+ * messages, uploads pattern / codon tables.  device < 0: options are parsed and
+ * validated only (no HIP call is made; usable without a GPU). */
+int bsk_create(const char* op_name, const char* opts_json, int device, bsk_ctx** out);
+void bsk_destroy(bsk_ctx* ctx); /* == After() */
+/* canonical JSON of the options after defaults (the text the reference's
+ * executor would see); returned pointer lives as long as ctx */
+const char* bsk_opts_json(const bsk_ctx* ctx);
+
+/* ---- record boundaries: PlainFile(path, delim) + ReadFixer ---------------
+ * bigseqkit/helper.go:148-178, bigseqkit-lib/helper.go:41-66.
+ * Finds, on the HOST, the first record start at or after `from` in a window of
+ * file bytes (used to cut a file into per-GPU shards that begin on a record).
+ * Returns n if there is none. */
+int bsk_find_record_start(const uint8_t* buf, size_t n, size_t from, int format, size_t* out);
+
+/* ---- Stats  (bigseqkit-lib/stats.go:27-117, StatsReduce :128-137) ---------
+ * The per-partition result of Stats.Call -- a map[int64]int64 of
+ * length -> count plus keys -1 (Q20), -2 (Q30), -3 (gap sum), -4 (type) --
+ * is kept DEVICE-RESIDENT as one flat vector of uint64 ("stats vector"):
+ *     [0]=q20 [1]=q30 [2]=gap_sum [3]=num_records [4]=error flags
+ *     [5]=number of overflow lengths [6]=sum of lengths [7]=reserved
+ *     [8 + L] = count of records with sequence length L, 0 <= L < hist_cap
+ * so that StatsReduce across GPUs is ONE sum all-reduce (RCCL) on that vector.
+ * Lengths >= hist_cap go to a ctx-owned overflow list merged by
+ * bsk_stats_collect().  Slots [4] and [5] are per-shard diagnostics. */
+#define BSK_STATS_HDR 8
+size_t bsk_stats_vector_len(const bsk_ctx* ctx);
+/* One Stats.Call over a shard.  `shard` holds n bytes of FASTA/FASTQ text
+ * starting on a record; on_device != 0: device pointer (HBM-resident, the
+ * measured path), else host pointer (staged through a pinned double buffer).
+ * d_vec: device stats vector to ACCUMULATE into (caller zeroes it once, e.g. a
+ * torch tensor), or NULL to use the ctx-owned vector.  stream: hipStream_t or
+ * NULL.  Asynchronous w.r.t. the host when on_device; errors detected by the
+ * kernels are reported by bsk_stats_collect(). */
+int bsk_stats_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* d_vec,
+                  void* stream);
+int bsk_stats_reset(bsk_ctx* ctx, void* stream); /* zero the ctx-owned vector */
+/* Synchronise, check the kernels' error flags (BSK_ERR_FORMAT /
+ * BSK_ERR_UNSUPPORTED) and convert a stats vector (d_vec or the ctx-owned one)
+ * into the reference's map form, sorted by key.  Key -4 is computed from the
+ * first record seen by this ctx (bigseqkit-lib/stats.go:106-114). */
+int bsk_stats_collect(bsk_ctx* ctx, const void* d_vec, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out);
+/* StatsReduce.Call on two host maps (sums; PARITY.md Q2) */
+int bsk_stats_merge(const int64_t* ka, const int64_t* va, size_t na, const int64_t* kb, const int64_t* vb, size_t nb,
+                    int64_t* keys, int64_t* vals, size_t cap, size_t* n_out);
+
+/* driver side: Stats() bigseqkit/stats.go:75-166 and StatInfo :290-311 */
+typedef struct {
+    char type[16]; /* "DNA" "RNA" "Protein" "Unlimit" "" ... */
+    uint64_t num, len_sum, gap_sum, len_min, len_max, n50;
+    int64_t l50;
+    double len_avg, q1, q2, q3, q20, q30;
+} bsk_statinfo;
+int bsk_stats_finalize(const bsk_ctx* ctx, const int64_t* keys, const int64_t* vals, size_t n, bsk_statinfo* out);
+/* StatsString() bigseqkit/stats.go:168-288 ; out is NUL-terminated */
+int bsk_stats_string(const bsk_ctx* ctx, const char* name, const char* format, const bsk_statinfo* info, char* out,
+                     size_t cap);
+
+/* ---- synthetic inputs (bench + tests only) --------
+ * Deterministic, counter-based: byte k of record i depends on (seed, i, k)
+ * only, so any shard can be produced on the host or directly in HBM. */
+#define BSK_SYNTH_FASTQ150 0 /* 317 B/record                          */
+#define BSK_SYNTH_FASTA1K 1  /* 1027 B/record, 60-column lines        */
+#define BSK_SYNTH_FASTA5K_CDS 2
+#define BSK_SYNTH_FLAG_MOTIF 1u /* C3: plant ACGTTGCAAGCT / its revcomp */
+#define BSK_SYNTH_FLAG_DUPS 2u  /* C5: 20 % sequence duplicates         */
+size_t bsk_synth_record_bytes(int kind);
+/* fill dst[0..n) with the bytes [first_record*record_bytes, ...+n) of the
+ * synthetic file; n need not be a whole number of records */
+int bsk_synth_host(int kind, uint64_t seed, unsigned flags, uint64_t first_record, uint8_t* dst, size_t n);
+int bsk_synth_device(int kind, uint64_t seed, unsigned flags, uint64_t first_record, void* d_dst, size_t n, int device,
+                     void* stream);
+
+/* ---- timing helper for bench.py: HIP events on the stream the kernels use */
+int bsk_event_create(void** ev);
+int bsk_event_record(void* ev, void* stream);
+int bsk_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int bsk_event_destroy(void* ev);
+/* accumulated device time of the dominant kernel of the last run(s), measured
+ * with HIP events around each launch when profiling is enabled */
+int bsk_profile_enable(bsk_ctx* ctx, int on);
+int bsk_profile_read(bsk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+int bsk_profile_reset(bsk_ctx* ctx);
+
+/* ---- device self tests used by tests/ (-m gpu) ---------------------------- */
+int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSK_H */

@@ -1,0 +1,179 @@
+// TEST INFRASTRUCTURE -- C entry points of the CPU oracle (ctypes-friendly).
+// See oracle_core.hpp for the parity status ("parity unpinned") and PARITY.md.
+#include <cstdio>
+#include <cstring>
+
+#include "oracle_core.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+typedef struct {
+    const char* SeqType;
+    int LineWidth;
+    const char* IDRegexp;
+    int IDNCBI;
+    int Quiet;
+    int AlphabetGuessSeqLength;
+    int ValidateSeqLength;
+} orc_kitconfig;
+
+typedef struct {
+    orc_kitconfig Config;
+    int Tabular;
+    const char* GapLetters;
+    int All;
+    int SkipErr;
+    const char* FqEncoding;
+    int Basename;
+} orc_stats_opts;
+
+}  // extern "C"
+
+static KitConfig conv(const orc_kitconfig& c) {
+    KitConfig k;
+    if (c.SeqType) k.SeqType = c.SeqType;
+    k.LineWidth = c.LineWidth;
+    if (c.IDRegexp) k.IDRegexp = c.IDRegexp;
+    k.IDNCBI = c.IDNCBI != 0;
+    if (k.IDNCBI) k.IDRegexp = "\\|([^\\|]+)\\| ";  // bigseqkit/helper.go:97-100
+    k.Quiet = c.Quiet != 0;
+    k.AlphabetGuessSeqLength = c.AlphabetGuessSeqLength;
+    k.ValidateSeqLength = c.ValidateSeqLength;
+    return k;
+}
+
+static StatsOptions conv(const orc_stats_opts& c) {
+    StatsOptions o;
+    o.Config = conv(c.Config);
+    o.Tabular = c.Tabular != 0;
+    if (c.GapLetters) o.GapLetters = c.GapLetters;
+    o.All = c.All != 0;
+    o.SkipErr = c.SkipErr != 0;
+    if (c.FqEncoding) o.FqEncoding = c.FqEncoding;
+    o.Basename = c.Basename != 0;
+    return o;
+}
+
+static int fail(char* err, size_t cap, const std::exception& e) {
+    if (err && cap) snprintf(err, cap, "%s", e.what());
+    return 1;
+}
+
+// Split [buf, buf+n) into `nparts` contiguous groups of whole records
+// (IgnisHPC partitions), run Stats.Call on each and fold with StatsReduce.
+static std::map<int64_t, int64_t> stats_over_parts(std::string_view buf, bool fastq, const StatsOptions& o, int nparts,
+                                                   std::string_view* first) {
+    auto recs = split_records(buf, fastq);
+    if (first) *first = recs.empty() ? std::string_view() : recs[0];
+    if (nparts < 1) nparts = 1;
+    std::map<int64_t, int64_t> acc;
+    bool have = false;
+    for (int p = 0; p < nparts; ++p) {
+        size_t a = recs.size() * (size_t)p / (size_t)nparts, b = recs.size() * (size_t)(p + 1) / (size_t)nparts;
+        std::vector<std::string_view> part(recs.begin() + a, recs.begin() + b);
+        auto m = stats_call(part, o);
+        acc = have ? stats_reduce(acc, m) : m;
+        have = true;
+    }
+    return acc;
+}
+
+extern "C" {
+
+// number of records and strictness probes
+int orc_count_records(const uint8_t* buf, size_t n, int fastq, uint64_t* out, char* err, size_t errcap) {
+    try {
+        *out = split_records(std::string_view((const char*)buf, n), fastq != 0).size();
+        return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+int orc_is_strict_4line_fastq(const uint8_t* buf, size_t n) {
+    return is_strict_4line_fastq(std::string_view((const char*)buf, n)) ? 1 : 0;
+}
+
+// record boundaries (start offsets of each element and its length) -- used to
+// check the HIP index kernels.
+int orc_record_spans(const uint8_t* buf, size_t n, int fastq, uint64_t* starts, uint64_t* lens, size_t cap,
+                     size_t* nout, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        *nout = recs.size();
+        for (size_t i = 0; i < recs.size() && i < cap; ++i) {
+            starts[i] = (uint64_t)(recs[i].data() - (const char*)buf);
+            lens[i] = recs[i].size();
+        }
+        return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+// Stats.Call (+StatsReduce over nparts partitions) -> sorted (key,value) pairs
+int orc_stats_map(const uint8_t* buf, size_t n, int fastq, const orc_stats_opts* o, int nparts, int64_t* keys,
+                  int64_t* vals, size_t cap, size_t* nout, char* err, size_t errcap) {
+    try {
+        auto m = stats_over_parts(std::string_view((const char*)buf, n), fastq != 0, conv(*o), nparts, nullptr);
+        *nout = m.size();
+        size_t i = 0;
+        for (auto& kv : m) {
+            if (i >= cap) break;
+            keys[i] = kv.first;
+            vals[i] = kv.second;
+            ++i;
+        }
+        return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+// driver Stats() + StatsString()
+int orc_stats_string(const uint8_t* buf, size_t n, int fastq, const orc_stats_opts* o, int nparts, const char* name,
+                     const char* format, char* out, size_t cap, char* err, size_t errcap) {
+    try {
+        StatsOptions so = conv(*o);
+        std::string_view first;
+        auto m = stats_over_parts(std::string_view((const char*)buf, n), fastq != 0, so, nparts, &first);
+        StatInfo info = stats_finalize(name, format, m, first, so);
+        std::string s = stats_string(info, so);
+        snprintf(out, cap, "%s", s.c_str());
+        return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+// Finalise a map that came from elsewhere (e.g. the HIP path) -- lets a test
+// compare the driver-side arithmetic in isolation.
+int orc_stats_string_from_map(const int64_t* keys, const int64_t* vals, size_t nkv, const uint8_t* first_rec,
+                              size_t first_len, const orc_stats_opts* o, const char* name, const char* format,
+                              char* out, size_t cap, char* err, size_t errcap) {
+    try {
+        StatsOptions so = conv(*o);
+        std::map<int64_t, int64_t> m;
+        for (size_t i = 0; i < nkv; ++i) m[keys[i]] = vals[i];
+        StatInfo info = stats_finalize(name, format, m, std::string_view((const char*)first_rec, first_len), so);
+        std::string s = stats_string(info, so);
+        snprintf(out, cap, "%s", s.c_str());
+        return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+int orc_wrap(const uint8_t* s, size_t n, int width, uint8_t* out, size_t cap, size_t* nout) {
+    std::string w = wrap_byte_slice(std::string_view((const char*)s, n), width);
+    *nout = w.size();
+    memcpy(out, w.data(), std::min(cap, w.size()));
+    return 0;
+}
+
+int orc_parse_head(const char* head, const char* re, char* id, size_t idcap, char* desc, size_t desccap) {
+    try {
+        std::string i, d, r = re ? re : "";
+        bool def = r.empty() || r == "^(\\S+)\\s?";
+        parse_head_id_desc(head, def, r, i, d);
+        snprintf(id, idcap, "%s", i.c_str());
+        snprintf(desc, desccap, "%s", d.c_str());
+        return 0;
+    } catch (const std::exception&) { return 1; }
+}
+
+double orc_go_round(double f, int n) { return go_round(f, n); }
+
+}  // extern "C"

@@ -1,0 +1,678 @@
+// TEST INFRASTRUCTURE -- see the header of oracle_core.hpp ("parity unpinned").
+// CPU restatement of bigseqkit-lib parser + stats.  Citations: /root/reference/.
+#include "oracle_core.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+
+namespace orc {
+
+// ---------------------------------------------------------------------------
+// Alphabets  [upstream-memory: shenwei356/bio v0.7.0 seq/alphabet.go]
+// ---------------------------------------------------------------------------
+namespace {
+struct LetterSet {
+    bool has[256];
+    explicit LetterSet(const char* s) {
+        memset(has, 0, sizeof(has));
+        for (; *s; ++s) has[(unsigned char)*s] = true;
+    }
+    bool subset(std::string_view v) const {
+        for (unsigned char c : v)
+            if (!has[c]) return false;
+        return true;
+    }
+};
+// AllLetters() = letters + gap + ambiguous
+const LetterSet kDNA("acgtACGT -.nN");
+const LetterSet kRNA("acguACGU -.nN");
+const LetterSet kDNAr("acgtryswkmbdhvACGTRYSWKMBDHV -.nN");
+const LetterSet kRNAr("acguryswkmbdhvACGURYSWKMBDHV -.nN");
+const LetterSet kProt("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ -xX*_.");
+}  // namespace
+
+const char* alphabet_name(Alphabet a) {
+    switch (a) {
+        case AB_DNA: return "DNA";
+        case AB_DNAredundant: return "DNAredundant";
+        case AB_RNA: return "RNA";
+        case AB_RNAredundant: return "RNAredundant";
+        case AB_PROTEIN: return "Protein";
+        case AB_UNLIMIT: return "Unlimit";
+        default: return "";
+    }
+}
+
+static Alphabet guess_alphabet(std::string_view s, int thr) {
+    if (s.empty()) return AB_UNLIMIT;
+    if (thr != 0 && (int64_t)s.size() > thr) s = s.substr(0, thr);
+    if (kDNA.subset(s)) return AB_DNA;
+    if (kRNA.subset(s)) return AB_RNA;
+    if (kDNAr.subset(s)) return AB_DNAredundant;
+    if (kRNAr.subset(s)) return AB_RNAredundant;
+    if (kProt.subset(s)) return AB_PROTEIN;
+    return AB_UNLIMIT;
+}
+
+Alphabet guess_alphabet_less_conservatively(std::string_view s, int thr) {
+    Alphabet ab = guess_alphabet(s, thr);
+    if (ab == AB_DNA) return AB_DNAredundant;
+    if (ab == AB_RNA) return AB_RNAredundant;
+    return ab;
+}
+
+static std::string lower(std::string s) {
+    for (auto& c : s)
+        if (c >= 'A' && c <= 'Z') c += 32;
+    return s;
+}
+
+// bigseqkit/helper.go:68-84
+Alphabet alphabet_from_seqtype(const std::string& t) {
+    std::string v = lower(t);
+    if (v == "dna") return AB_DNAredundant;
+    if (v == "rna") return AB_RNAredundant;
+    if (v == "protein") return AB_PROTEIN;
+    if (v == "unlimit") return AB_UNLIMIT;
+    if (v == "auto") return AB_NONE;
+    throw Error("invalid sequence type: " + t + ", available value: dna|rna|protein|unlimit|auto");
+}
+
+bool alphabet_is_valid(Alphabet a, std::string_view s) {
+    switch (a) {
+        case AB_DNA: return kDNA.subset(s);
+        case AB_RNA: return kRNA.subset(s);
+        case AB_DNAredundant: return kDNAr.subset(s);
+        case AB_RNAredundant: return kRNAr.subset(s);
+        case AB_PROTEIN: return kProt.subset(s);
+        default: return true;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Record splitting.  PARITY.md "SPLIT": FASTA records start at a '>' that is
+// the first byte of a line; FASTQ records are read sequentially the way seqkit's
+// own reader does (header '@', sequence lines until a non-empty line starting
+// with '+', then quality lines -- at least one -- until len(qual) >= len(seq)).
+// Then ReadFixer (bigseqkit-lib/helper.go:41-66): drop empty elements, strip
+// ONE trailing '\n', make sure the element starts with the marker.
+// ---------------------------------------------------------------------------
+std::vector<std::string_view> split_records(std::string_view buf, bool fastq) {
+    std::vector<std::string_view> out;
+    const size_t n = buf.size();
+    size_t p = 0;
+    // leading blank lines are not records
+    while (p < n && buf[p] == '\n') ++p;
+    if (!fastq) {
+        if (p < n && buf[p] != '>') throw Error("invalid FASTA: data before the first '>'");
+        while (p < n) {
+            size_t q = p + 1;
+            // next '>' at line start
+            for (;;) {
+                const void* f = memchr(buf.data() + q, '>', n - q);
+                if (!f) { q = n; break; }
+                q = (const char*)f - buf.data();
+                if (buf[q - 1] == '\n') break;
+                ++q;
+            }
+            std::string_view e = buf.substr(p, q - p);
+            if (!e.empty() && e.back() == '\n') e.remove_suffix(1);  // helper.go:51-56
+            if (!e.empty()) out.push_back(e);
+            p = q;
+        }
+        return out;
+    }
+    auto line_end = [&](size_t s) {  // index of '\n' or n
+        const void* f = s < n ? memchr(buf.data() + s, '\n', n - s) : nullptr;
+        return f ? (size_t)((const char*)f - buf.data()) : n;
+    };
+    while (p < n) {
+        // trailing blank lines at EOF are ignored
+        size_t t = p;
+        while (t < n && buf[t] == '\n') ++t;
+        if (t == n) break;
+        if (buf[p] != '@') throw Error("invalid FASTQ: record does not start with '@'");
+        size_t s = p;
+        size_t e = line_end(s);  // header
+        size_t cur = e < n ? e + 1 : n;
+        size_t seqlen = 0, quallen = 0;
+        bool isQual = false, any_qual_line = false;
+        size_t rec_end = n;
+        while (cur < n) {
+            size_t le = line_end(cur);
+            size_t k = le - cur;
+            if (!isQual) {
+                if (k > 0 && buf[cur] == '+') isQual = true;  // helper.go:255
+                else seqlen += k;
+            } else {
+                quallen += k;
+                any_qual_line = true;
+            }
+            cur = le < n ? le + 1 : n;
+            if (isQual && any_qual_line && quallen >= seqlen) { rec_end = cur; break; }
+            // quality shorter than the sequence and the next line looks like a header:
+            // the reference's "\n@" split ends the record here and SeqParser then
+            // reports the length mismatch (bigseqkit-lib/helper.go:308-311)
+            if (isQual && any_qual_line && cur < n && buf[cur] == '@') { rec_end = cur; break; }
+        }
+        std::string_view el = buf.substr(s, rec_end - s);
+        if (!el.empty() && el.back() == '\n') el.remove_suffix(1);
+        if (!el.empty()) out.push_back(el);
+        p = rec_end;
+    }
+    return out;
+}
+
+// Strict 4-line FASTQ == what the HIP path accepts (PARITY.md "STRICT4"):
+// every record is exactly: '@' line, sequence line not starting with '+' unless
+// empty... (a non-empty sequence line starting with '+' is rejected), '+' line,
+// quality line with len == len(seq).  Optional missing final '\n'.  Trailing
+// empty lines at EOF are tolerated.
+bool is_strict_4line_fastq(std::string_view buf) {
+    const size_t n = buf.size();
+    size_t p = 0;
+    auto line_end = [&](size_t s) {
+        const void* f = s < n ? memchr(buf.data() + s, '\n', n - s) : nullptr;
+        return f ? (size_t)((const char*)f - buf.data()) : n;
+    };
+    if (n > 0 && buf[0] == '\n') return false;  // leading blank lines unsupported
+    while (p < n) {
+        size_t t = p;
+        while (t < n && buf[t] == '\n') ++t;
+        if (t == n) return true;
+        if (buf[p] != '@') return false;
+        size_t h = line_end(p);
+        if (h >= n) return false;
+        size_t s0 = h + 1, s1 = line_end(s0);
+        if (s1 >= n) return false;
+        if (s1 > s0 && buf[s0] == '+') return false;
+        size_t p0 = s1 + 1, p1 = line_end(p0);
+        if (p1 >= n) return false;
+        if (p1 == p0 || buf[p0] != '+') return false;
+        size_t q0 = p1 + 1, q1 = line_end(q0);
+        if (q1 - q0 != s1 - s0) return false;
+        p = q1 < n ? q1 + 1 : n;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// SeqParser  bigseqkit-lib/helper.go:179-325
+// ---------------------------------------------------------------------------
+SeqParser::SeqParser(Alphabet t_, const std::vector<std::string_view>* it_, const std::string& idRegexp, int thr)
+    : it(it_), t(t_), guess_thr(thr), id_regexp(idRegexp) {
+    // helper.go:182-197
+    default_id_regexp = idRegexp.empty() || idRegexp == "^(\\S+)\\s?";
+    if (!default_id_regexp && idRegexp.find('(') == std::string::npos)
+        throw Error("fastx: regular expression must contain \"(\" and \")\" to capture matched ID. default: ^(\\S+)\\s?");
+}
+
+// bigseqkit-lib/helper.go:329-369 ; custom regexps: only the NCBI one
+// (bigseqkit/helper.go:97-100, `\|([^\|]+)\| `) is restated natively.
+void parse_head_id_desc(const std::string& head, bool default_re, const std::string& re, std::string& id,
+                        std::string& desc) {
+    id.clear();
+    desc.clear();
+    if (default_re) {
+        for (char sep : {' ', '\t'}) {
+            size_t i = head.find(sep);
+            if (i != std::string::npos && i > 0) {
+                size_t e = head.size();
+                size_t j = i + 1;
+                for (; j < e; j++) {
+                    if (head[j] == ' ' || head[j] == '\t') j++;  // sic: skips two per iteration (helper.go:335-339)
+                    else break;
+                }
+                id = head.substr(0, i);
+                if (j >= e) return;
+                desc = head.substr(j);
+                return;
+            }
+        }
+        id = head;
+        return;
+    }
+    if (re == "\\|([^\\|]+)\\| ") {
+        // leftmost match of  '|' [^|]+ '|' ' '
+        for (size_t a = head.find('|'); a != std::string::npos; a = head.find('|', a + 1)) {
+            size_t b = head.find('|', a + 1);
+            if (b == std::string::npos) break;
+            if (b > a + 1 && b + 1 < head.size() && head[b + 1] == ' ') {
+                id = head.substr(a + 1, b - a - 1);
+                return;
+            }
+        }
+        id = head;  // not match -> whole head (helper.go:365-367)
+        return;
+    }
+    throw Error("oracle: custom --id-regexp other than the NCBI one is not restated");
+}
+
+bool SeqParser::Read() {
+    if (pos >= it->size()) return false;  // io.EOF
+    std::string_view p = (*it)[pos++];
+    if (firstseq) IsFastq = !p.empty() && p[0] == '@';  // helper.go:228-230
+    std::string head;
+    rec.seq.clear();
+    rec.qual.clear();
+    size_t j = p.find('\n');
+    if (j != std::string_view::npos && j > 0) {
+        head = std::string(p.substr(0, j));
+        size_t r = j + 1;
+        if (!IsFastq) {  // helper.go:240-250
+            for (;;) {
+                size_t k = p.find('\n', r);
+                if (k != std::string_view::npos) {
+                    rec.seq.append(p.substr(r, k - r));
+                    r = k + 1;
+                    continue;
+                }
+                rec.seq.append(p.substr(r));
+                break;
+            }
+        } else {  // helper.go:251-273
+            bool isQual = false;
+            for (;;) {
+                size_t kk = p.find('\n', r);
+                if (kk != std::string_view::npos) {
+                    size_t k = kk - r;
+                    if (k > 0 && p[r] == '+' && !isQual) isQual = true;
+                    else if (isQual) rec.qual.append(p.substr(r, k));
+                    else rec.seq.append(p.substr(r, k));
+                    r = kk + 1;
+                    continue;
+                }
+                if (isQual) rec.qual.append(p.substr(r));
+                break;  // sic: an unterminated non-quality last line is dropped
+            }
+        }
+    } else {  // helper.go:275-283
+        if (!p.empty() && p.back() == '\n') head = std::string(p.substr(0, p.size() - 1));
+        else head = std::string(p);
+    }
+    if (firstseq) {  // helper.go:286-291
+        if (t == AB_NONE) t = guess_alphabet_less_conservatively(rec.seq, guess_thr);
+        firstseq = false;
+    }
+    if (head.empty() && rec.seq.empty()) return false;  // helper.go:293-295
+    // PARITY.md Q1: the marker byte is not part of the name.
+    if (!head.empty() && (head[0] == '>' || head[0] == '@')) head.erase(0, 1);
+    rec.name = head;
+    parse_head_id_desc(head, default_id_regexp, id_regexp, rec.id, rec.desc);
+    if (IsFastq && rec.seq.size() != rec.qual.size()) {  // helper.go:308-311
+        char b[256];
+        snprintf(b, sizeof b, "seq('%s'): unmatched length of sequence (%zu) and quality (%zu)", rec.name.c_str(),
+                 rec.seq.size(), rec.qual.size());
+        throw Error(b);
+    }
+    return true;
+}
+
+// bigseqkit-lib/helper.go:81-117
+std::string wrap_byte_slice(std::string_view s, int width) {
+    if (width < 1) return std::string(s);
+    size_t l = s.size();
+    if (l == 0) return std::string();
+    size_t w = (size_t)width;
+    size_t lines = (l % w == 0) ? l / w - 1 : l / w;
+    std::string out;
+    out.reserve(l + lines);
+    for (size_t i = 0; i <= lines; i++) {
+        size_t start = i * w, end = std::min((i + 1) * w, l);
+        out.append(s.substr(start, end - start));
+        if (i < lines) out.push_back('\n');
+    }
+    return out;
+}
+
+std::string record_format(const Record& r, bool fastq, int width) {
+    std::string o;
+    o.push_back(fastq ? '@' : '>');
+    o += r.name;
+    o.push_back('\n');
+    o += wrap_byte_slice(r.seq, width);
+    o.push_back('\n');
+    if (fastq) {
+        o += "+\n";
+        o += wrap_byte_slice(r.qual, width);
+        o.push_back('\n');
+    }
+    return o;
+}
+
+// bigseqkit-lib/helper.go:119-136 + bio QualityEncoding.Offset [upstream-memory]
+int quality_offset(const std::string& enc) {
+    std::string s = lower(enc);
+    if (s == "sanger" || s == "illumina-1.8+") return 33;
+    if (s == "solexa" || s == "illumina-1.3+" || s == "illumina-1.5+") return 64;
+    if (s == "") return 0;
+    throw Error("unsupported quality encoding: " + enc +
+                ". available values: 'sanger', 'solexa', 'illumina-1.3+', 'illumina-1.5+', 'illumina-1.8+'");
+}
+
+// ---------------------------------------------------------------------------
+// Stats  bigseqkit-lib/stats.go
+// ---------------------------------------------------------------------------
+static void check_gap_letters(const std::string& g) {  // stats.go:36-43
+    if (g.empty()) throw Error("value of flag -G (--gap-letters) should not be empty");
+    for (unsigned char c : g)
+        if (c > 127) throw Error("value of -G (--gap-letters) contains non-ASCII characters");
+}
+
+std::map<int64_t, int64_t> stats_call(const std::vector<std::string_view>& part, const StatsOptions& o) {
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    check_gap_letters(o.GapLetters);
+    SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    bool gap[256] = {false};
+    for (unsigned char c : o.GapLetters) gap[c] = true;
+    const int off = quality_offset(o.FqEncoding);
+    std::string seqFormat;
+    std::map<int64_t, int64_t> result;
+    const int64_t Q20 = -1, Q30 = -2, GAP_SUM = -3, T = -4;
+    while (rd.Read()) {
+        const Record& r = rd.rec;
+        if (seqFormat.empty()) seqFormat = r.qual.empty() ? "FASTA" : "FASTQ";  // stats.go:80-86
+        result[(int64_t)r.seq.size()]++;                                        // stats.go:88
+        if (o.All) {
+            if (rd.IsFastq) {
+                for (unsigned char q : r.qual) {  // stats.go:91-100
+                    if ((int)q - off >= 20) {
+                        result[Q20]++;
+                        if ((int)q - off >= 30) result[Q30]++;
+                    }
+                }
+            }
+            int64_t g = 0;
+            for (unsigned char c : r.seq) g += gap[c];
+            result[GAP_SUM] += g;  // stats.go:102
+        }
+    }
+    Alphabet fa = rd.GetAlphabet();  // stats.go:106-114
+    if (fa == AB_DNAredundant) result[T] = 'D';
+    else if (fa == AB_RNAredundant) result[T] = 'R';
+    else if (seqFormat.empty() && fa == AB_UNLIMIT) result[T] = 'U';
+    else result[T] = 'F';
+    return result;
+}
+
+// stats.go:128-137 restated with PARITY.md Q2: counts are summed; the type key
+// (-4) keeps the value of the lower-index partition.
+std::map<int64_t, int64_t> stats_reduce(const std::map<int64_t, int64_t>& a, const std::map<int64_t, int64_t>& b) {
+    std::map<int64_t, int64_t> r = a;
+    for (auto& kv : b) {
+        if (kv.first == -4) {
+            if (!r.count(-4) || r[-4] == 'U') r[-4] = kv.second;
+        } else {
+            r[kv.first] += kv.second;
+        }
+    }
+    return r;
+}
+
+// shenwei356/util/math.Round [upstream-memory]:
+//   pow10_n := math.Pow10(n); return math.Trunc((f+0.5/pow10_n)*pow10_n) / pow10_n
+double go_round(double f, int n) {
+    double p = std::pow(10.0, n);
+    return std::trunc((f + 0.5 / p) * p) / p;
+}
+
+// go-humanize Comma [upstream-memory]
+std::string humanize_comma(int64_t v) {
+    bool neg = v < 0;
+    uint64_t u = neg ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
+    std::string d = std::to_string(u), o;
+    int c = 0;
+    for (int i = (int)d.size() - 1; i >= 0; --i) {
+        o.push_back(d[i]);
+        if (++c % 3 == 0 && i > 0) o.push_back(',');
+    }
+    if (neg) o.push_back('-');
+    std::reverse(o.begin(), o.end());
+    return o;
+}
+
+// strconv.FormatFloat(v, 'f', -1, 64): shortest decimal that round-trips.
+static std::string format_float_shortest(double v) {
+    char b[64];
+    for (int prec = 1; prec <= 17; ++prec) {
+        snprintf(b, sizeof b, "%.*g", prec, v);
+        if (strtod(b, nullptr) == v) break;
+    }
+    // %g may give exponent form; re-render as plain decimal
+    std::string s(b);
+    if (s.find('e') != std::string::npos || s.find('E') != std::string::npos) {
+        // digits after the point needed: derive from exponent
+        int dec = 0;
+        for (; dec < 340; ++dec) {
+            snprintf(b, sizeof b, "%.*f", dec, v);
+            if (strtod(b, nullptr) == v) break;
+        }
+        s = b;
+    }
+    return s;
+}
+
+// go-humanize Commaf [upstream-memory]
+std::string humanize_commaf(double v) {
+    std::string s = format_float_shortest(std::fabs(v));
+    size_t dot = s.find('.');
+    std::string ip = s.substr(0, dot), fp = dot == std::string::npos ? "" : s.substr(dot);
+    std::string o;
+    int c = 0;
+    for (int i = (int)ip.size() - 1; i >= 0; --i) {
+        o.push_back(ip[i]);
+        if (++c % 3 == 0 && i > 0) o.push_back(',');
+    }
+    std::reverse(o.begin(), o.end());
+    if (v < 0) o = "-" + o;
+    return o + fp;
+}
+
+// ---------------------------------------------------------------------------
+// util.LengthStats  [upstream-memory: shenwei356/bio v0.7.0 util/length-stats.go]
+// Built from (length,count) pairs; the reference calls Add(k) v times
+// (bigseqkit/stats.go:134-138) which yields the same multiset.
+// ---------------------------------------------------------------------------
+namespace {
+struct LengthStats {
+    std::vector<std::pair<uint64_t, uint64_t>> counts;  // sorted by length
+    uint64_t count = 0, sum = 0, mn = 0, mx = 0;
+    explicit LengthStats(const std::map<int64_t, int64_t>& m) {
+        for (auto& kv : m) {
+            if (kv.second <= 0) continue;
+            counts.emplace_back((uint64_t)kv.first, (uint64_t)kv.second);
+            count += (uint64_t)kv.second;
+            sum += (uint64_t)kv.first * (uint64_t)kv.second;
+        }
+        if (!counts.empty()) {
+            mn = counts.front().first;
+            mx = counts.back().first;
+        }
+    }
+    double Mean() const { return (double)sum / (double)count; }
+    uint64_t N50(int* l50) const {
+        if (counts.empty()) { *l50 = 0; return 0; }
+        double sumLen = 0, half = (double)sum / 2;
+        uint64_t n = 0;
+        for (size_t i = counts.size(); i-- > 0;) {
+            // the reference adds one sequence at a time from the longest
+            double need = half - sumLen;
+            double len = (double)counts[i].first;
+            double tot = len * (double)counts[i].second;
+            if (sumLen + tot >= half) {
+                uint64_t k = len > 0 ? (uint64_t)std::ceil(need / len) : 1;
+                if (k < 1) k = 1;
+                if (k > counts[i].second) k = counts[i].second;
+                *l50 = (int)(n + k);
+                return counts[i].first;
+            }
+            sumLen += tot;
+            n += counts[i].second;
+        }
+        *l50 = (int)n;
+        return counts.front().first;
+    }
+    double value_at(uint64_t idx) const {  // 0-based in the expanded sorted multiset
+        uint64_t acc = 0;
+        for (auto& c : counts) {
+            acc += c.second;
+            if (idx < acc) return (double)c.first;
+        }
+        return (double)mx;
+    }
+    double get(bool even, uint64_t l, uint64_t r) const {
+        return even ? (value_at(l) + value_at(r)) / 2 : value_at(l);
+    }
+    double Q2() const {
+        if (count == 0) return 0;
+        if (count == 1) return (double)counts[0].first;
+        bool even = (count & 1) == 0;
+        return even ? get(true, count / 2 - 1, count / 2) : get(false, count / 2, 0);
+    }
+    double Q1() const {
+        if (count == 0) return 0;
+        if (count == 1) return (double)counts[0].first;
+        uint64_t n = (count % 2 == 0) ? count / 2 : (count + 1) / 2;
+        bool even = n % 2 == 0;
+        return even ? get(true, n / 2 - 1, n / 2) : get(false, n / 2, 0);
+    }
+    double Q3() const {
+        if (count == 0) return 0;
+        if (count == 1) return (double)counts[0].first;
+        uint64_t n, mean;
+        if (count % 2 == 0) { n = count / 2; mean = n; }
+        else { n = (count + 1) / 2; mean = n - 1; }
+        bool even = n % 2 == 0;
+        return even ? get(true, mean + n / 2 - 1, mean + n / 2) : get(false, mean + n / 2, 0);
+    }
+};
+}  // namespace
+
+// bigseqkit/stats.go:75-166
+StatInfo stats_finalize(const std::string& name, const std::string& format, std::map<int64_t, int64_t> stats,
+                        std::string_view first_record, const StatsOptions& o) {
+    auto pop = [&](int64_t k) {
+        int64_t v = 0;
+        auto it = stats.find(k);
+        if (it != stats.end()) { v = it->second; stats.erase(it); }
+        return v;
+    };
+    int64_t q20 = pop(-1), q30 = pop(-2);
+    uint64_t gapSum = (uint64_t)pop(-3);
+    int64_t ti = pop(-4);
+    std::string t;
+    if (ti == 'D') t = "DNA";
+    else if (ti == 'R') t = "RNA";
+    else if (ti == 'U') t = "";
+    else {
+        // stats.go:117-129: fastx reader over the first record, alphabet guessed
+        // from its sequence with the bio default threshold (10000).
+        std::vector<std::string_view> one{first_record};
+        SeqParser rd(AB_NONE, &one, o.Config.IDRegexp, 10000);
+        if (!rd.Read()) throw Error("EOF");
+        t = alphabet_name(rd.GetAlphabet());
+    }
+    LengthStats ls(stats);
+    StatInfo info;
+    info.file = name;
+    info.format = format;
+    info.t = t;
+    if (ls.count > 0) {
+        if (o.All) {
+            info.N50 = ls.N50(&info.L50);
+            info.Q1 = ls.Q1();
+            info.Q2 = ls.Q2();
+            info.Q3 = ls.Q3();
+        }
+        info.num = ls.count;
+        info.lenSum = ls.sum;
+        info.gapSum = gapSum;
+        info.lenMin = ls.mn;
+        info.lenAvg = go_round(ls.Mean(), 1);
+        info.lenMax = ls.mx;
+        info.q20 = go_round((double)q20 / (double)ls.sum * 100, 2);
+        info.q30 = go_round((double)q30 / (double)ls.sum * 100, 2);
+    }
+    return info;
+}
+
+static std::string sprintf_s(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+static std::string sprintf_s(const char* fmt, ...) {
+    char b[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(b, sizeof b, fmt, ap);
+    va_end(ap);
+    return b;
+}
+
+// go-prettytable rendering [upstream-memory]: each cell padded to its column's
+// maximum width (left-aligned unless AlignRight), cells joined by the default
+// separator " ", one '\n' per row, header row first.
+static std::string pretty_table(const std::vector<std::string>& hdr, const std::vector<bool>& right,
+                                const std::vector<std::string>& row) {
+    std::string out;
+    std::vector<size_t> w(hdr.size());
+    for (size_t i = 0; i < hdr.size(); ++i) w[i] = std::max(hdr[i].size(), row[i].size());
+    for (const auto* r : {&hdr, &row}) {
+        for (size_t i = 0; i < hdr.size(); ++i) {
+            if (i) out.push_back(' ');
+            const std::string& c = (*r)[i];
+            if (right[i]) out.append(w[i] - c.size(), ' ').append(c);
+            else out.append(c).append(w[i] - c.size(), ' ');
+        }
+        out.push_back('\n');
+    }
+    return out;
+}
+
+// bigseqkit/stats.go:168-288
+std::string stats_string(const StatInfo& info, const StatsOptions& o) {
+    std::string result;
+    if (o.Tabular) {
+        result += "file\tformat\ttype\tnum_seqs\tsum_len\tmin_len\tavg_len\tmax_len";
+        if (o.All) result += "\tQ1\tQ2\tQ3\tsum_gap\tN50\tQ20(%)\tQ30(%)";
+        result += "\n";
+        if (!o.All) {
+            result += sprintf_s("%s\t%s\t%s\t%llu\t%llu\t%llu\t%.1f\t%llu\n", info.file.c_str(), info.format.c_str(),
+                                info.t.c_str(), (unsigned long long)info.num, (unsigned long long)info.lenSum,
+                                (unsigned long long)info.lenMin, info.lenAvg, (unsigned long long)info.lenMax);
+        } else {
+            result += sprintf_s("%s\t%s\t%s\t%llu\t%llu\t%llu\t%.1f\t%llu\t%.1f\t%.1f\t%.1f\t%llu\t%llu\t%.2f\t%.2f\n",
+                                info.file.c_str(), info.format.c_str(), info.t.c_str(), (unsigned long long)info.num,
+                                (unsigned long long)info.lenSum, (unsigned long long)info.lenMin, info.lenAvg,
+                                (unsigned long long)info.lenMax, info.Q1, info.Q2, info.Q3,
+                                (unsigned long long)info.gapSum, (unsigned long long)info.N50, info.q20, info.q30);
+        }
+        return result;
+    }
+    std::vector<std::string> hdr{"file", "format", "type", "num_seqs", "sum_len", "min_len", "avg_len", "max_len"};
+    std::vector<bool> right{false, false, false, true, true, true, true, true};
+    std::vector<std::string> row{info.file,
+                                 info.format,
+                                 info.t,
+                                 humanize_comma((int64_t)info.num),
+                                 humanize_comma((int64_t)info.lenSum),
+                                 humanize_comma((int64_t)info.lenMin),
+                                 humanize_commaf(info.lenAvg),
+                                 humanize_comma((int64_t)info.lenMax)};
+    if (o.All) {
+        for (const char* h : {"Q1", "Q2", "Q3", "sum_gap", "N50", "Q20(%)", "Q30(%)"}) {
+            hdr.push_back(h);
+            right.push_back(true);
+        }
+        row.push_back(humanize_commaf(info.Q1));
+        row.push_back(humanize_commaf(info.Q2));
+        row.push_back(humanize_commaf(info.Q3));
+        row.push_back(humanize_comma((int64_t)info.gapSum));
+        row.push_back(humanize_comma((int64_t)info.N50));
+        row.push_back(humanize_commaf(info.q20));
+        row.push_back(humanize_commaf(info.q30));
+    }
+    return pretty_table(hdr, right, row);
+}
+
+}  // namespace orc

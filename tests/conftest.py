@@ -1,0 +1,40 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    lib = os.path.join(ROOT, "bigseqkit_amd", "lib", "libbsk.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        subprocess.check_call([os.path.join(ROOT, "build.sh")], cwd=ROOT)
+
+
+_ensure_built()
+
+
+def has_gpu():
+    try:
+        from bigseqkit_amd import lib
+        return lib.bsk_device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

@@ -1,0 +1,119 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE."""
+import ctypes as C
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+
+
+class KitConfig(C.Structure):
+    _fields_ = [("SeqType", C.c_char_p), ("LineWidth", C.c_int), ("IDRegexp", C.c_char_p), ("IDNCBI", C.c_int),
+                ("Quiet", C.c_int), ("AlphabetGuessSeqLength", C.c_int), ("ValidateSeqLength", C.c_int)]
+
+
+class StatsOpts(C.Structure):
+    _fields_ = [("Config", KitConfig), ("Tabular", C.c_int), ("GapLetters", C.c_char_p), ("All", C.c_int),
+                ("SkipErr", C.c_int), ("FqEncoding", C.c_char_p), ("Basename", C.c_int)]
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _cfg(d):
+    c = d.get("Config") or {}
+    g = lambda k, dv: dv if c.get(k) is None else c[k]
+    return KitConfig(g("SeqType", "auto").encode(), g("LineWidth", 60), g("IDRegexp", r"^(\S+)\s?").encode(),
+                     int(g("IDNCBI", False)), int(g("Quiet", False)), g("AlphabetGuessSeqLength", 10000),
+                     g("ValidateSeqLength", 10000))
+
+
+def stats_opts(opts_json):
+    """Fill the oracle's plain struct from the same JSON the product eats (defaults per
+    /root/reference/bigseqkit/stats.go:28-38)."""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    return StatsOpts(_cfg(d), int(g("Tabular", False)), g("GapLetters", "- .").encode(), int(g("All", False)),
+                     int(g("SkipErr", False)), g("FqEncoding", "sanger").encode(), int(g("Basename", False)))
+
+
+def _buf(data):
+    return (C.c_char * len(data)).from_buffer_copy(data) if len(data) else (C.c_char * 1)()
+
+
+_ERR = 1024
+
+
+def count_records(data, fastq):
+    out, err = C.c_uint64(), C.create_string_buffer(_ERR)
+    if _lib.orc_count_records(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(out), err, _ERR):
+        raise OracleError(err.value.decode())
+    return out.value
+
+
+def is_strict_4line_fastq(data):
+    return bool(_lib.orc_is_strict_4line_fastq(_buf(data), C.c_size_t(len(data))))
+
+
+def record_spans(data, fastq):
+    cap = max(16, len(data) // 2 + 2)
+    st, ln = (C.c_uint64 * cap)(), (C.c_uint64 * cap)()
+    n, err = C.c_size_t(), C.create_string_buffer(_ERR)
+    if _lib.orc_record_spans(_buf(data), C.c_size_t(len(data)), int(fastq), st, ln, C.c_size_t(cap), C.byref(n), err, _ERR):
+        raise OracleError(err.value.decode())
+    return list(zip(st[:n.value], ln[:n.value]))
+
+
+def stats_map(data, fastq, opts_json="{}", nparts=1):
+    o = stats_opts(opts_json)
+    cap = 1 << 20
+    keys, vals = (C.c_int64 * cap)(), (C.c_int64 * cap)()
+    n, err = C.c_size_t(), C.create_string_buffer(_ERR)
+    if _lib.orc_stats_map(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), nparts, keys, vals,
+                          C.c_size_t(cap), C.byref(n), err, _ERR):
+        raise OracleError(err.value.decode())
+    return dict(zip(keys[:n.value], vals[:n.value]))
+
+
+def stats_string(data, fastq, opts_json="{}", nparts=1, name="input0", fmt="N/A"):
+    o = stats_opts(opts_json)
+    out, err = C.create_string_buffer(1 << 16), C.create_string_buffer(_ERR)
+    if _lib.orc_stats_string(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), nparts, name.encode(),
+                             fmt.encode(), out, C.c_size_t(len(out)), err, _ERR):
+        raise OracleError(err.value.decode())
+    return out.value.decode()
+
+
+def stats_string_from_map(m, first_record, opts_json="{}", name="input0", fmt="N/A"):
+    o = stats_opts(opts_json)
+    ks = sorted(m)
+    keys, vals = (C.c_int64 * len(ks))(*ks), (C.c_int64 * len(ks))(*[m[k] for k in ks])
+    out, err = C.create_string_buffer(1 << 16), C.create_string_buffer(_ERR)
+    if _lib.orc_stats_string_from_map(keys, vals, C.c_size_t(len(ks)), _buf(first_record),
+                                      C.c_size_t(len(first_record)), C.byref(o), name.encode(), fmt.encode(), out,
+                                      C.c_size_t(len(out)), err, _ERR):
+        raise OracleError(err.value.decode())
+    return out.value.decode()
+
+
+def wrap(s, width):
+    out = C.create_string_buffer(2 * len(s) + 16)
+    n = C.c_size_t()
+    _lib.orc_wrap(_buf(s), C.c_size_t(len(s)), width, out, C.c_size_t(len(out)), C.byref(n))
+    return out.raw[:n.value]
+
+
+def parse_head(head, regexp=""):
+    i, d = C.create_string_buffer(4096), C.create_string_buffer(4096)
+    if _lib.orc_parse_head(head.encode(), regexp.encode(), i, C.c_size_t(4096), d, C.c_size_t(4096)):
+        raise OracleError("parse_head")
+    return i.value.decode(), d.value.decode()
+
+
+_lib.orc_go_round.restype = C.c_double
+_lib.orc_go_round.argtypes = [C.c_double, C.c_int]
+
+
+def go_round(f, n):
+    return _lib.orc_go_round(f, n)

@@ -1,0 +1,237 @@
+"""Parity of the HIP `stats` path against the CPU oracle -- through the C ABI, on a GPU.
+Integer work: every map entry must be bit-exact; the driver-side text must be identical."""
+import ctypes as C
+import json
+import os
+import random
+
+import pytest
+
+import oracle
+import seqgen
+import bigseqkit_amd as bsk
+from bigseqkit_amd import _lib
+from bigseqkit_amd._lib import lib
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(data):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    return t.cuda()
+
+
+def gpu_map(data, fastq, opts, on_device=True):
+    fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+    frame = bsk.SeqFrame(fmt, [dev(data) if on_device else data])
+    m, op = bsk.stats_map(frame, _Opts(opts))
+    op.close()
+    return m
+
+
+class _Opts:
+    def __init__(self, d):
+        self.d = d
+
+    def to_json(self):
+        return json.dumps(self.d)
+
+
+def check_parity(data, fastq, opts=None, **kw):
+    opts = opts or {}
+    want = oracle.stats_map(data, fastq, json.dumps(opts))
+    got = gpu_map(data, fastq, opts, **kw)
+    assert got == want
+
+
+@pytest.mark.parametrize("use_dpp", [1, 0])
+def test_wave_scan_primitive(use_dpp):
+    rng = random.Random(3)
+    for _ in range(4):
+        vals = [rng.randint(0, 1 << 20) for _ in range(64)]
+        i, o = (C.c_uint32 * 64)(*vals), (C.c_uint32 * 64)()
+        assert lib.bsk_selftest_scan(use_dpp, i, o) == 0
+        acc, want = 0, []
+        for v in vals:
+            acc += v
+            want.append(acc & 0xFFFFFFFF)
+        assert list(o) == want
+
+
+def test_synth_device_equals_host():
+    import torch
+    for kind in (0, 1, 2):
+        rb = lib.bsk_synth_record_bytes(kind)
+        n = rb * 1000 + 123
+        t = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert lib.bsk_synth_device(kind, 42, 3, 5, C.c_void_p(t.data_ptr()), n, 0, None) == 0
+        torch.cuda.synchronize()
+        h = C.create_string_buffer(n)
+        lib.bsk_synth_host(kind, 42, 3, 5, h, n)
+        assert bytes(t.cpu().numpy().tobytes()) == h.raw
+
+
+HAND = [
+    b"@r1 d\nACGT\n+\nIIII\n@r2\nAC-N\n+\n5#5I\n",
+    b"@a\nAC\n+\n@+\n@b\nGT\n+a\n+@",                 # '@'/'+' leading quality, no final newline
+    b"@a\n\n+\n\n@b\nA\n+\nI\n\n\n",                  # empty sequence, trailing blank lines
+    b"@a\n\n+\n",                                     # ends inside an empty quality line
+    b"@only\nACGTACGT\n+\nIIIIIIII",
+    b"",
+]
+
+
+@pytest.mark.parametrize("all_", [False, True])
+@pytest.mark.parametrize("i", range(len(HAND)))
+def test_fastq_hand_cases(i, all_):
+    check_parity(HAND[i], True, {"All": all_})
+
+
+HAND_FA = [
+    b">s1 a>b\nAC\nGT\n>s2\n\n>s3",
+    b">x\nACGT\n",
+    b">x\nAC-GT\nA. T\n>y\n>z\nNNNN",
+    b">p\nMKVLAAGIVGLLLAQ\n",
+    b">r\nACGUACGU\n",
+    b">lonely",
+    b">a\n\n\n\n",
+]
+
+
+@pytest.mark.parametrize("all_", [False, True])
+@pytest.mark.parametrize("i", range(len(HAND_FA)))
+def test_fasta_hand_cases(i, all_):
+    check_parity(HAND_FA[i], False, {"All": all_})
+
+
+@pytest.mark.parametrize("all_", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_fastq_random_parity(seed, all_, monkeypatch):
+    # tiny ranges: many anchors, records straddling every range and tile boundary
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", str([256, 1000, 4096, 65536][seed % 4]))
+    rng = random.Random(seed)
+    data = seqgen.random_fastq(rng, 3000, 0, [40, 300, 3000][seed % 3], final_newline=seed % 2 == 0,
+                               trailing_blank=seed % 3)
+    assert oracle.is_strict_4line_fastq(data)
+    check_parity(data, True, {"All": all_})
+
+
+@pytest.mark.parametrize("all_", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_fasta_random_parity(seed, all_, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", str([256, 1000, 4096, 65536][seed % 4]))
+    rng = random.Random(100 + seed)
+    data = seqgen.random_fasta(rng, 1500, 0, [100, 1500, 9000][seed % 3], width=[60, 70, 0, 13][seed % 4],
+                               final_newline=seed % 2 == 0, trailing_blank=seed % 3, gt_in_header=True)
+    check_parity(data, False, {"All": all_})
+
+
+def test_shfl_scan_variant_gives_same_result(monkeypatch):
+    rng = random.Random(9)
+    data = seqgen.random_fastq(rng, 2000, 0, 200)
+    monkeypatch.setenv("BSK_SCAN", "shfl")
+    check_parity(data, True, {"All": True})
+
+
+def test_newline_dense_input_takes_several_event_batches(monkeypatch):
+    # more than 128 newlines per 4 KiB tile: records of 1-base reads
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "2048")
+    rng = random.Random(4)
+    data = seqgen.random_fastq(rng, 5000, 0, 2, name_space=False)
+    check_parity(data, True, {"All": True})
+    fa = b"".join(b">%d\nA\n\nC\n" % i for i in range(3000))
+    check_parity(fa, False, {"All": True})
+
+
+def test_long_reads_and_histogram_overflow():
+    rng = random.Random(8)
+    recs = []
+    for L in [2047, 2048, 2049, 65535, 65536, 70000, 200000, 5, 200000]:
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        recs.append(f"@r{L}\n{s}\n+\n{'I' * L}\n")
+    data = "".join(recs).encode()
+    check_parity(data, True, {"All": True})
+    fa = b">chr1 one line\n" + b"ACGT" * 100000 + b"\n>chr2\n" + (b"ACGTN" * 12 + b"\n") * 5000
+    check_parity(fa, False, {"All": True})
+
+
+def test_gap_letters_and_encoding_options():
+    rng = random.Random(12)
+    data = seqgen.random_fastq(rng, 500, 1, 100, qual_lo=64, qual_hi=104)
+    check_parity(data, True, {"All": True, "FqEncoding": "solexa"})
+    check_parity(data, True, {"All": True, "FqEncoding": "illumina-1.8+", "GapLetters": "N-"})
+    check_parity(data, True, {"All": True, "Config": {"SeqType": "dna"}})
+
+
+def test_host_resident_shard():
+    rng = random.Random(13)
+    data = seqgen.random_fastq(rng, 800, 0, 150)
+    check_parity(data, True, {"All": True}, on_device=False)
+
+
+def test_partitions_are_reduced():
+    rng = random.Random(14)
+    data = seqgen.random_fastq(rng, 1000, 0, 150)
+    frame = bsk.ReadFASTQN(data, 5)
+    assert len(frame.shards) >= 4
+    m, op = bsk.stats_map(frame, bsk.SeqKitStatsOptions().All(True))
+    op.close()
+    assert m == oracle.stats_map(data, True, '{"All": true}', nparts=5)
+
+
+@pytest.mark.parametrize("data,code,msg", [
+    (b"@a\nACGT\n+\nIII\n@b\nA\n+\nI\n", _lib.BSK_ERR_FORMAT, "unmatched length"),
+    (b"@a\nACGT\nAC\n+\nIIII\nII\n", _lib.BSK_ERR_UNSUPPORTED, "4-line"),      # multi-line FASTQ
+    (b"\n@a\nACGT\n+\nIIII\n", _lib.BSK_ERR_UNSUPPORTED, "does not start"),
+    (b"@a\nACGT\n+\nIIII\n@b\nAC\n", _lib.BSK_ERR_FORMAT, None),               # truncated
+])
+def test_malformed_fastq_is_an_error_not_a_wrong_answer(data, code, msg):
+    assert not oracle.is_strict_4line_fastq(data)
+    with pytest.raises(bsk.BskError) as e:
+        gpu_map(data, True, {"All": True})
+    assert e.value.code in (code, _lib.BSK_ERR_FORMAT, _lib.BSK_ERR_UNSUPPORTED)
+    if msg:
+        assert msg in str(e.value)
+
+
+def test_stats_string_end_to_end():
+    rng = random.Random(15)
+    data = seqgen.random_fastq(rng, 1234, 0, 250)
+    for opts in ({"All": True, "Tabular": True}, {"All": True}, {"Tabular": True}, {}):
+        o = bsk.SeqKitStatsOptions()
+        for k, v in opts.items():
+            getattr(o, k)(v)
+        got = bsk.StatsString("input0", "N/A", bsk.SeqFrame(bsk.FORMAT_FASTQ, [dev(data)]), o)
+        assert got == oracle.stats_string(data, True, json.dumps(opts))
+    prot = b">p1\nMKVLAAGIVGLLLAQW\n>p2\nMKV\n"
+    got = bsk.StatsString("input0", "N/A", bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(prot)]),
+                          bsk.SeqKitStatsOptions().Tabular(True))
+    assert got == oracle.stats_string(prot, False, '{"Tabular": true}')
+
+
+def test_synthetic_fastq150_full_size_properties():
+    """BASELINE C2 layout at a size the oracle cannot touch: size-independent properties."""
+    import torch
+    rb = 317
+    nrec = 20_000_000  # 6.3 GB in HBM
+    n = rb * nrec - 1  # drop the final newline
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert lib.bsk_synth_device(0, 42, 0, 0, C.c_void_p(t.data_ptr()), n, 0, None) == 0
+    m, op = bsk.stats_map(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), bsk.SeqKitStatsOptions().All(True))
+    op.close()
+    assert m[150] == nrec and m[-3] == 0 and m[-4] == ord("D")
+    assert set(m) == {150, -1, -2, -3, -4}
+    # uniform quals in '#'..'I' (Phred 2..40): P(q>=20) = 21/39, P(q>=30) = 11/39
+    tot = 150 * nrec
+    assert abs(m[-1] / tot - 21 / 39) < 1e-3
+    assert abs(m[-2] / tot - 11 / 39) < 1e-3
+    # linearity: a prefix shard and the rest sum to the whole
+    cut = rb * 7_000_001
+    a, op = bsk.stats_map(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t[:cut], t[cut:]]), bsk.SeqKitStatsOptions().All(True))
+    op.close()
+    assert a == m
+    # the oracle agrees on a 10 MB prefix
+    head = bytes(t[:rb * 30000].cpu().numpy().tobytes())
+    g = gpu_map(head, True, {"All": True})
+    assert g == oracle.stats_map(head, True, '{"All": true}')
