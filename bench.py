@@ -124,7 +124,7 @@ def main():
     op, vec = make_op(True)
     dta, ma, texta, ka_ms, _ = timed(op, vec, max(3, args.steps // 2), 1)
     stepsa = max(3, args.steps // 2)
-    verified_a = ma.get(150) == total_rec and ma.get(-3) == 0 and abs(ma.get(-1, 0) / (150 * total_rec) - 21 / 39) < 1e-3
+    verified_a = ma.get(150) == total_rec and ma.get(-3) == 0 and abs(ma.get(-1, 0) / (150 * total_rec) - 137 / 256) < 1e-3
     op.close()
 
     if rank != 0:

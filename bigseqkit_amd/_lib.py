@@ -15,6 +15,30 @@ if not os.path.exists(LIB_PATH):
         f"libbsk.so not found at {LIB_PATH}: build it with ./build.sh "
         "(hipcc --offload-arch=gfx950); bigseqkit_amd has no CPU fallback")
 
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch ships its own libamdhip64.so (same SONAME,
+    libamdhip64.so.7, as /opt/rocm's).  If libbsk.so were loaded first it would bind to
+    /opt/rocm's copy and a later `import torch` would bring a second runtime into the
+    process (observed: "No HIP GPUs are available", and streams / device pointers could not
+    be shared).  Loading torch's copy first -- without importing torch -- makes both bind
+    to it.  Without torch installed, libbsk.so uses /opt/rocm's runtime via its RUNPATH."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+_preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 BSK_OK, BSK_ERR_INVALID_ARG, BSK_ERR_OPTS, BSK_ERR_FORMAT, BSK_ERR_UNSUPPORTED, BSK_ERR_HIP, \

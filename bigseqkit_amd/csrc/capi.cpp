@@ -331,7 +331,6 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
 
 static std::string describe_kernel_errors(uint64_t f, int* code) {
     *code = BSK_ERR_FORMAT;
-    if (f & ERR_LEN_MISMATCH) return "unmatched length of sequence and quality";
     if (f & ERR_BAD_HEADER) {
         *code = BSK_ERR_UNSUPPORTED;
         return "record does not start with '>' / '@' at a line start (leading blank lines, multi-line FASTQ and "
@@ -341,6 +340,7 @@ static std::string describe_kernel_errors(uint64_t f, int* code) {
         *code = BSK_ERR_UNSUPPORTED;
         return "FASTQ is not in the strict 4-line layout (third line must start with '+')";
     }
+    if (f & ERR_LEN_MISMATCH) return "unmatched length of sequence and quality";
     if (f & ERR_TRUNCATED) return "FASTQ ends inside a record";
     if (f & ERR_ANCHOR) {
         *code = BSK_ERR_UNSUPPORTED;

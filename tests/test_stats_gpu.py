@@ -222,10 +222,10 @@ def test_synthetic_fastq150_full_size_properties():
     op.close()
     assert m[150] == nrec and m[-3] == 0 and m[-4] == ord("D")
     assert set(m) == {150, -1, -2, -3, -4}
-    # uniform quals in '#'..'I' (Phred 2..40): P(q>=20) = 21/39, P(q>=30) = 11/39
+    # qual = '#' + (u8 * 39 >> 8): Phred >= 20 <=> u8 >= 119, Phred >= 30 <=> u8 >= 184
     tot = 150 * nrec
-    assert abs(m[-1] / tot - 21 / 39) < 1e-3
-    assert abs(m[-2] / tot - 11 / 39) < 1e-3
+    assert abs(m[-1] / tot - 137 / 256) < 1e-4
+    assert abs(m[-2] / tot - 72 / 256) < 1e-4
     # linearity: a prefix shard and the rest sum to the whole
     cut = rb * 7_000_001
     a, op = bsk.stats_map(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t[:cut], t[cut:]]), bsk.SeqKitStatsOptions().All(True))
