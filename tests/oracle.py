@@ -76,6 +76,18 @@ def stats_map(data, fastq, opts_json="{}", nparts=1):
     return dict(zip(keys[:n.value], vals[:n.value]))
 
 
+def stats_map_ptr(ptr, n, fastq, opts_json="{}", nparts=1):
+    """Same as stats_map but on a raw host pointer (no copy; bench.py's cpu_baseline leg)."""
+    o = stats_opts(opts_json)
+    cap = 1 << 16
+    keys, vals = (C.c_int64 * cap)(), (C.c_int64 * cap)()
+    nn, err = C.c_size_t(), C.create_string_buffer(_ERR)
+    if _lib.orc_stats_map(C.c_void_p(ptr), C.c_size_t(n), int(fastq), C.byref(o), nparts, keys, vals,
+                          C.c_size_t(cap), C.byref(nn), err, _ERR):
+        raise OracleError(err.value.decode())
+    return dict(zip(keys[:nn.value], vals[:nn.value]))
+
+
 def stats_string(data, fastq, opts_json="{}", nparts=1, name="input0", fmt="N/A"):
     o = stats_opts(opts_json)
     out, err = C.create_string_buffer(1 << 16), C.create_string_buffer(_ERR)
