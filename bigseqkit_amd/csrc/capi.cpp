@@ -541,6 +541,41 @@ int bsk_profile_reset(bsk_ctx* c) {
     return BSK_OK;
 }
 
+// Streaming-read calibration: reads d_buf[0..n) once with k_stats' access pattern,
+// `reps` times; returns the average launch time (HIP events).
+int bsk_selftest_stream_read(const void* d_buf, size_t n, int reps, int blocks_per_cu, float* avg_ms) {
+    if (!d_buf || !avg_ms || reps < 1) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    int dev = 0;
+    HIP_TRY(nullptr, hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&p, dev));
+    const int blocks = p.multiProcessorCount * (blocks_per_cu > 0 ? blocks_per_cu : 8);
+    uint64_t nr = std::max<uint64_t>(1, std::min<uint64_t>(n / MIN_RANGE_BYTES, (uint64_t)blocks * 4 * RANGES_PER_WAVE));
+    uint64_t chunk = ((n + nr - 1) / nr + 4095) & ~(uint64_t)4095;
+    nr = (n + chunk - 1) / chunk;
+    uint32_t* d = nullptr;
+    HIP_TRY(nullptr, hipMalloc((void**)&d, 8));
+    hipEvent_t a, b;
+    HIP_TRY(nullptr, hipEventCreate(&a));
+    HIP_TRY(nullptr, hipEventCreate(&b));
+    float total = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        HIP_TRY(nullptr, hipMemsetAsync(d, 0, 8, nullptr));
+        HIP_TRY(nullptr, hipEventRecord(a, nullptr));
+        HIP_TRY(nullptr, launch_stream_read(blocks, (const uint8_t*)d_buf, n, chunk, (uint32_t)nr, d, d + 1, nullptr));
+        HIP_TRY(nullptr, hipEventRecord(b, nullptr));
+        HIP_TRY(nullptr, hipEventSynchronize(b));
+        float ms = 0;
+        HIP_TRY(nullptr, hipEventElapsedTime(&ms, a, b));
+        if (r > 0) total += ms;  // first launch is warm-up
+    }
+    *avg_ms = total / reps;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipFree(d);
+    return BSK_OK;
+}
+
 // wave-scan self test (tests/test_gpu_primitives.py)
 int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64) {
     uint32_t *d_in = nullptr, *d_out = nullptr;

@@ -34,6 +34,8 @@ hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
                         hipStream_t st);
 int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp);
+hipError_t launch_stream_read(int blocks, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
+                              uint32_t* queue, uint32_t* sink, hipStream_t st);
 hipError_t launch_scan_selftest(bool dpp, const uint32_t* in, uint32_t* out, hipStream_t st);
 
 }  // namespace bsk

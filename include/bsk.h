@@ -149,6 +149,9 @@ int bsk_profile_reset(bsk_ctx* ctx);
 
 /* ---- device self tests used by tests/ (-m gpu) ---------------------------- */
 int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64);
+/* streaming read of d_buf[0..n) with k_stats' tile/queue pattern and no per-byte work:
+ * the read ceiling of that pattern and the FETCH_SIZE calibration run */
+int bsk_selftest_stream_read(const void* d_buf, size_t n, int reps, int blocks_per_cu, float* avg_ms);
 
 #ifdef __cplusplus
 }
