@@ -58,6 +58,10 @@ class StatInfo(C.Structure):
                 ("q20", C.c_double), ("q30", C.c_double)]
 
 
+class Out(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("len", C.c_size_t), ("records", C.c_uint64)]
+
+
 _vp, _sz, _i, _i64, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_uint64
 _p = C.POINTER
 
@@ -78,6 +82,10 @@ SIGNATURES = {
     "bsk_stats_merge": (_i, [_p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_stats_finalize": (_i, [_vp, _p(_i64), _p(_i64), _sz, _p(StatInfo)]),
     "bsk_stats_string": (_i, [_vp, C.c_char_p, C.c_char_p, _p(StatInfo), C.c_char_p, _sz]),
+    "bsk_out_to_host": (_i, [_vp, _p(Out), _vp, _sz]),
+    "bsk_index_build": (_i, [_vp, _vp, _sz, _i, _i, _vp, _p(_u64)]),
+    "bsk_index_copy": (_i, [_vp, _p(_u64), _p(C.c_uint32), _p(C.c_uint32), _p(C.c_uint32), _sz]),
+    "bsk_seq_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),
     "bsk_synth_device": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz, _i, _vp]),

@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions
 
 
 class SeqFrame:
@@ -164,3 +164,36 @@ def StatsString(name, format, input, o=None, device=0):
         buf = C.create_string_buffer(1 << 16)
         check(lib.bsk_stats_string(op.ctx, name.encode(), format.encode(), C.byref(info), buf, len(buf)), op.ctx)
         return buf.value.decode()
+
+
+def _run_records(op_name, run_fn, input, o, device=0, stream=None):
+    """MapPartitions(libSource(op_name)) over the shards of `input`: the concatenated
+    FileStore bytes (element + newline per output record) and the number of elements."""
+    chunks, nrec = [], 0
+    with Operator(op_name, o.to_json(), device) as op:
+        for pid, ptr, n, on_dev, keep in input.partitions():
+            out = _lib.Out()
+            check(run_fn(op.ctx, ptr, n, 1 if on_dev else 0, input.format, pid, stream, C.byref(out)), op.ctx)
+            buf = C.create_string_buffer(max(1, out.len))
+            check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+            chunks.append(buf.raw[:out.len])
+            nrec += out.records
+    return b"".join(chunks), nrec
+
+
+def Seq(input, o=None, device=0):
+    """bigseqkit/seq.go:157-170 -- returns the bytes StoreFASTX would write"""
+    return _run_records("SeqTransform", lib.bsk_seq_run, input, o or SeqKitSeqOptions(), device)[0]
+
+
+def build_index(input, device=0):
+    """Record table of the first shard (tests): list of (start, head_len, seq_len, aux)."""
+    with Operator("SeqTransform", "{}", device) as op:
+        for pid, ptr, n, on_dev, keep in input.partitions():
+            nrec = C.c_uint64()
+            check(lib.bsk_index_build(op.ctx, ptr, n, 1 if on_dev else 0, input.format, None, C.byref(nrec)), op.ctx)
+            k = nrec.value
+            st, hl, sl, ax = (C.c_uint64 * k)(), (C.c_uint32 * k)(), (C.c_uint32 * k)(), (C.c_uint32 * k)()
+            check(lib.bsk_index_copy(op.ctx, st, hl, sl, ax, k), op.ctx)
+            return list(zip(st, hl, sl, ax))
+    return []

@@ -11,6 +11,7 @@
 #include "../../include/bsk.h"
 #include "anchor.hpp"
 #include "ctx.hpp"
+#include "ops_host.hpp"
 #include "stats_host.hpp"
 #include "stream_stats.hpp"
 #include "synth.hpp"
@@ -171,6 +172,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
         c->opts_json = c->opts.to_json();
         switch (op) {
             case Op::Stats: validate_stats(c); break;
+            case Op::Seq: validate_seq_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
     } catch (const std::exception& e) {
@@ -200,6 +202,11 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_vec) hipFree(c->d_vec);
         if (c->d_status) hipFree(c->d_status);
         if (c->d_overflow) hipFree(c->d_overflow);
+        for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux,
+                        (void*)c->d_range_count, (void*)c->d_range_base, (void*)c->d_out_len, (void*)c->d_out_off,
+                        (void*)c->d_scan_tmp, (void*)c->d_out, (void*)c->d_lut, (void*)c->d_qual_err,
+                        (void*)c->d_counter})
+            if (p) hipFree(p);
         for (int i = 0; i < 2; ++i) {
             if (c->d_stage[i]) hipFree(c->d_stage[i]);
             if (c->pinned[i]) hipHostFree(c->pinned[i]);
@@ -268,15 +275,15 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     D.overflow_cap = c->overflow_cap;
     D.hist_cap = c->hist_cap;
     const uint32_t t20 = (uint32_t)(c->qual_offset + 20), t30 = (uint32_t)(c->qual_offset + 30);
-    D.k20 = (0x80u - t20) * 0x01010101u;
-    D.k30 = (0x80u - t30) * 0x01010101u;
-    D.ngap = 0;
-    for (int k = 0; k < MAX_GAP_LETTERS; ++k) D.gap_rep[k] = 0;
+    D.pred.k20 = (0x80u - t20) * 0x01010101u;
+    D.pred.k30 = (0x80u - t30) * 0x01010101u;
+    D.pred.ngap = 0;
+    for (int k = 0; k < MAX_GAP_LETTERS; ++k) D.pred.gap_rep[k] = 0;
     {
         std::string uniq;
         for (char ch : c->opts.s("GapLetters"))
             if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
-        for (char ch : uniq) D.gap_rep[D.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;
+        for (char ch : uniq) D.pred.gap_rep[D.pred.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;
     }
     uint64_t* anchors = c->d_anchors;
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
@@ -450,6 +457,90 @@ int bsk_stats_string(const bsk_ctx* c, const char* name, const char* format, con
     if (s.size() + 1 > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
     memcpy(out, s.c_str(), s.size() + 1);
     return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// record table and record-producing operators
+// ---------------------------------------------------------------------------
+static int stage_shard(bsk_ctx* c, const void* shard, size_t n, int on_device, hipStream_t st, const uint8_t** d) {
+    if (on_device) { *d = (const uint8_t*)shard; return BSK_OK; }
+    if (n > c->stage_cap || !c->d_stage[0]) {
+        if (c->d_stage[0]) HIP_TRY(c, hipFree(c->d_stage[0]));
+        c->d_stage[0] = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&c->d_stage[0], n + 16));
+        c->stage_cap = n;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage[0], shard, n, hipMemcpyHostToDevice, st));
+    *d = c->d_stage[0];
+    return BSK_OK;
+}
+
+static int check_run_args(bsk_ctx* c, const void* shard, size_t n, int format) {
+    if (!c) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null context");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    if (format != BSK_FORMAT_FASTA && format != BSK_FORMAT_FASTQ)
+        return fail(c, BSK_ERR_INVALID_ARG, "libbsk: format must be BSK_FORMAT_FASTA or BSK_FORMAT_FASTQ");
+    if (n && !shard) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null shard");
+    return BSK_OK;
+}
+
+int bsk_out_to_host(bsk_ctx* c, const bsk_out* out, void* dst, size_t cap) {
+    if (!c || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null argument");
+    if (out->len > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (out->len) HIP_TRY(c, hipMemcpy(dst, out->d_data, out->len, hipMemcpyDeviceToHost));
+    return BSK_OK;
+}
+
+int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, void* stream,
+                    uint64_t* n_records) {
+    int rc = check_run_args(c, shard, n, format);
+    if (rc != BSK_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    const uint8_t* d = nullptr;
+    rc = stage_shard(c, shard, n, on_device, st, &d);
+    if (rc != BSK_OK) return rc;
+    rc = build_index(c, d, n, format, st);
+    if (rc != BSK_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    uint64_t status = 0;
+    HIP_TRY(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    if (n_records) *n_records = c->table.n;
+    return BSK_OK;
+}
+
+int bsk_index_copy(bsk_ctx* c, uint64_t* starts, uint32_t* head_len, uint32_t* seq_len, uint32_t* aux, size_t cap) {
+    if (!c || c->device < 0) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad context");
+    const uint64_t n = c->table.n;
+    if (n > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (n == 0) return BSK_OK;
+    if (starts) HIP_TRY(c, hipMemcpy(starts, c->table.start, n * 8, hipMemcpyDeviceToHost));
+    if (head_len) HIP_TRY(c, hipMemcpy(head_len, c->table.l_head, n * 4, hipMemcpyDeviceToHost));
+    if (seq_len) HIP_TRY(c, hipMemcpy(seq_len, c->table.l_seq, n * 4, hipMemcpyDeviceToHost));
+    if (aux) HIP_TRY(c, hipMemcpy(aux, c->table.aux, n * 4, hipMemcpyDeviceToHost));
+    return BSK_OK;
+}
+
+int bsk_seq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                bsk_out* out) {
+    (void)pid;
+    int rc = check_run_args(c, shard, n, format);
+    if (rc != BSK_OK) return rc;
+    if (c->op != Op::Seq || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a SeqTransform context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    const uint8_t* d = nullptr;
+    rc = stage_shard(c, shard, n, on_device, st, &d);
+    if (rc != BSK_OK) return rc;
+    return seq_run_device(c, d, n, format, st, out);
 }
 
 // ---------------------------------------------------------------------------

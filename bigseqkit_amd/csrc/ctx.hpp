@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "index.hpp"
 #include "opts.hpp"
 
 struct bsk_ctx {
@@ -39,6 +40,21 @@ struct bsk_ctx {
     int64_t first_pid = INT64_MAX;
     int first_format = -1;
     std::string type_if_F;  // alphabet name the driver would guess from Take(1) (bigseqkit/stats.go:117-129)
+
+    // ---- record table + per-record scratch (seq, grep, ...) ---------------------
+    bsk::RecordTable table;          // ctx-owned arrays, grown on demand
+    uint64_t* d_range_count = nullptr;  // [cap_ranges]
+    uint64_t* d_range_base = nullptr;   // [cap_ranges + 1]
+    uint32_t* d_out_len = nullptr;      // [table.cap]
+    uint64_t* d_out_off = nullptr;      // [table.cap + 1]
+    uint64_t* d_scan_tmp = nullptr;
+    uint64_t scan_tmp_cap = 0;
+    uint64_t out_len_cap = 0;
+    uint8_t* d_out = nullptr;           // output text of the last run
+    uint64_t out_cap = 0;
+    uint8_t* d_lut = nullptr;           // 256-byte byte map (seq)
+    double* d_qual_err = nullptr;       // 256 doubles (seq -Q/-R)
+    uint64_t* d_counter = nullptr;      // scratch counter
 
     // ---- staging for host-resident shards ------------------------------------
     uint8_t* pinned[2] = {nullptr, nullptr};

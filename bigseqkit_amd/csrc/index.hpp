@@ -1,0 +1,45 @@
+// Record table ("SoA columnarisation"): what SeqParser.Read
+// (/root/reference/bigseqkit-lib/helper.go:219-325) yields per record -- head,
+// seq, qual -- kept as offsets into the shard text that stays where it is in HBM.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "stream_stats.hpp"
+
+namespace bsk {
+
+// SoA, device memory.  Record i:
+//   header line   = [start[i], start[i] + l_head[i])            (marker byte included)
+//   FASTQ: seq    = [start + l_head + 1, +l_seq)                 plus line = aux bytes, qual = same length as seq
+//          qual   = [start + l_head + 1 + l_seq + 1 + aux + 1, +l_seq)
+//   FASTA: sequence region = [start + l_head + 1, +aux) (may contain '\n'), l_seq = bases in it
+//   start[n] = end of the last record
+struct RecordTable {
+    uint64_t* start = nullptr;
+    uint32_t* l_head = nullptr;
+    uint32_t* l_seq = nullptr;
+    uint32_t* aux = nullptr;
+    uint64_t n = 0;
+    uint64_t cap = 0;
+};
+
+struct IndexDev {
+    RecordTable t;
+    uint64_t* range_count;       // [nranges] records per range (count pass writes, write pass reads base)
+    const uint64_t* range_base;  // [nranges + 1] exclusive scan of range_count (write pass)
+    uint64_t* status;            // [0] error flags
+    int write;                   // 0: count pass, 1: write pass
+};
+
+hipError_t launch_index(bool fastq, bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
+                        uint32_t nranges, uint32_t* queue, const IndexDev& D, hipStream_t st);
+int index_max_blocks_per_cu(bool fastq, bool dpp);
+// exclusive scan of u64 counts (n <= a few 10^4; one block): out[0..n], out[n] = total
+hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st);
+// exclusive scan u32 -> u64 over N items (N up to 2^32): out[0..N], out[N] = total; tmp: u64[(N + 2047) / 2048 + 1]
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st);
+hipError_t launch_reset_queue(uint32_t* queue, hipStream_t st);
+
+}  // namespace bsk

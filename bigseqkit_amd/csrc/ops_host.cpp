@@ -1,0 +1,322 @@
+// Host side of the record-table operators: index construction and `seq`
+// (SeqTransform, /root/reference/bigseqkit-lib/seq.go).  C-ABI in include/bsk.h.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/bsk.h"
+#include "ctx.hpp"
+#include "ops_host.hpp"
+#include "ops_seq.hpp"
+#include "stream_stats.hpp"
+
+namespace bsk {
+
+#define HIP_TRYX(ctx, expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(e__));           \
+            return BSK_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+template <class T>
+static int grow(bsk_ctx* c, T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
+    if (need <= *cap && *p) return BSK_OK;
+    if (*p) HIP_TRYX(c, hipFree(*p));
+    *p = nullptr;
+    const uint64_t n = need + slack;
+    HIP_TRYX(c, hipMalloc((void**)p, std::max<uint64_t>(n, 1) * sizeof(T)));
+    *cap = n;
+    return BSK_OK;
+}
+
+int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
+    if (!f) return BSK_OK;
+    int code = BSK_ERR_FORMAT;
+    std::string m;
+    if (f & ERR_BAD_HEADER) {
+        code = BSK_ERR_UNSUPPORTED;
+        m = "record does not start with '>' / '@' at a line start (leading blank lines, multi-line FASTQ and "
+            "blank lines between records are not accepted by the HIP path)";
+    } else if (f & ERR_BAD_PLUS) {
+        code = BSK_ERR_UNSUPPORTED;
+        m = "FASTQ is not in the strict 4-line layout (third line must start with '+')";
+    } else if (f & ERR_LEN_MISMATCH) m = "unmatched length of sequence and quality";
+    else if (f & ERR_TRUNCATED) m = "FASTQ ends inside a record";
+    else if (f & ERR_ANCHOR) {
+        code = BSK_ERR_UNSUPPORTED;
+        m = "FASTQ is not in the strict 4-line layout (a range did not end on a record boundary)";
+    } else if (f & ERR_LINE_TOO_LONG) {
+        code = BSK_ERR_UNSUPPORTED;
+        m = "a line longer than 2^31 bytes (or a FASTA record longer than 2^32 bytes)";
+    } else if (f & ERR_INVALID_LETTER) m = "seq: invalid letter for the sequence alphabet";
+    else if (f & ERR_CAPACITY) { code = BSK_ERR_CAPACITY; m = "libbsk: internal table capacity exceeded"; }
+    else m = "unknown kernel error";
+    c->set_error(m);
+    return code;
+}
+
+// ---------------------------------------------------------------------------
+// record table of one device-resident shard (count pass, scan, write pass)
+// ---------------------------------------------------------------------------
+int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st) {
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    c->table.n = 0;
+    if (n == 0) return BSK_OK;
+    const int per_cu = index_max_blocks_per_cu(fastq, c->use_dpp);
+    const int blocks = std::max(1, c->num_cus * per_cu);
+    const uint64_t waves = (uint64_t)blocks * 4;
+    uint64_t nr = n / c->min_range_bytes;
+    nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, waves * 4));
+    const uint32_t nranges = (uint32_t)nr;
+    uint64_t chunk = (n + nranges - 1) / nranges;
+    chunk = (chunk + 15) & ~(uint64_t)15;
+    if (nranges > c->cap_ranges || !c->d_anchors || !c->d_range_count) {
+        if (c->d_anchors) HIP_TRYX(c, hipFree(c->d_anchors));
+        if (c->d_range_count) HIP_TRYX(c, hipFree(c->d_range_count));
+        if (c->d_range_base) HIP_TRYX(c, hipFree(c->d_range_base));
+        c->d_anchors = nullptr; c->d_range_count = nullptr; c->d_range_base = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_anchors, ((size_t)nranges + 2) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_range_count, ((size_t)nranges + 1) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_range_base, ((size_t)nranges + 2) * sizeof(uint64_t)));
+        c->cap_ranges = nranges;
+    }
+    uint64_t* anchors = c->d_anchors;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
+    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st));
+    IndexDev D;
+    D.t = c->table;
+    D.range_count = c->d_range_count;
+    D.range_base = c->d_range_base;
+    D.status = c->d_status;
+    D.write = 0;
+    HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+    HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
+    uint64_t total = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (total + 1 > c->table.cap) {
+        for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux})
+            if (p) HIP_TRYX(c, hipFree(p));
+        c->table = RecordTable();
+        const uint64_t cap = total + total / 8 + 16;
+        HIP_TRYX(c, hipMalloc((void**)&c->table.start, (cap + 1) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->table.l_head, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->table.l_seq, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->table.aux, cap * sizeof(uint32_t)));
+        c->table.cap = cap;
+    }
+    c->table.n = total;
+    if (total == 0) return BSK_OK;
+    D.t = c->table;
+    D.write = 1;
+    HIP_TRYX(c, launch_reset_queue(queue, st));
+    HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+    // start[n] = effective end of the shard (anchors[nranges])
+    HIP_TRYX(c, hipMemcpyAsync(c->table.start + total, anchors + nranges, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// seq
+// ---------------------------------------------------------------------------
+static void set_bits(uint32_t* set, const std::string& letters) {
+    for (int k = 0; k < 8; ++k) set[k] = 0;
+    for (unsigned char ch : letters) set[ch >> 5] |= 1u << (ch & 31);
+}
+
+static const char* alphabet_letters(Alphabet a) {
+    switch (a) {
+        case AB_DNA: return "acgtACGT -.nN";
+        case AB_RNA: return "acguACGU -.nN";
+        case AB_DNAredundant: return "acgtryswkmbdhvACGTRYSWKMBDHV -.nN";
+        case AB_RNAredundant: return "acguryswkmbdhvACGURYSWKMBDHV -.nN";
+        case AB_PROTEIN: return "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ -xX*_.";
+        default: return nullptr;
+    }
+}
+
+void validate_seq_opts(bsk_ctx* c) {  // SeqTransform.Before, seq.go:28-79
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    const std::string& g = o.s("GapLetters");
+    if (g.empty()) throw OptError("value of flag -G (--gap-letters) should not be empty");
+    for (unsigned char ch : g)
+        if (ch > 127) throw OptError("value of -G (--gap-letters) contains non-ASCII characters");
+    if (o.i("MinLen") >= 0 && o.i("MaxLen") >= 0 && o.i("MinLen") > o.i("MaxLen"))
+        throw OptError("value of flag -m (--min-len) should be >= value of flag -M (--max-len)");
+    if (o.f("MinQual") >= 0 && o.f("MaxQual") >= 0 && o.f("MinQual") > o.f("MaxQual"))
+        throw OptError("value of flag -Q (--min-qual) should be <= value of flag -R (--max-qual)");
+    if (o.b("LowerCase") && o.b("UpperCase"))
+        throw OptError("could not give both flags -l (--lower-case) and -u (--upper-case)");
+    const std::string& re = o.cs("IDRegexp");
+    if (!(re.empty() || re == "^(\\S+)\\s?" || re == "\\|([^\\|]+)\\| "))
+        throw OptError("libbsk: --id-regexp other than the default and the --id-ncbi one is not supported by the HIP path");
+}
+
+// sequence bytes of the first record of a shard head (type guess, helper.go:286-291)
+static std::vector<uint8_t> head_first_seq(const std::vector<uint8_t>& b, int format, size_t limit) {
+    std::vector<uint8_t> s;
+    const size_t n = b.size();
+    size_t p = 0;
+    while (p < n && b[p] != '\n') ++p;
+    ++p;
+    if (format == BSK_FORMAT_FASTQ) {
+        while (p < n && b[p] != '\n' && s.size() < limit) s.push_back(b[p++]);
+        return s;
+    }
+    while (p < n && s.size() < limit) {
+        if (b[p] == '>' && b[p - 1] == '\n') break;
+        if (b[p] != '\n') s.push_back(b[p]);
+        ++p;
+    }
+    return s;
+}
+
+Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc) {
+    *rc = BSK_OK;
+    if (c->alphabet != AB_NONE) return c->alphabet;
+    const int64_t thr = c->opts.ci("AlphabetGuessSeqLength");
+    size_t want = (size_t)std::max<int64_t>(thr, 10000) * 2 + 65536;
+    want = std::min(want, n);
+    std::vector<uint8_t> h(want);
+    if (want) {
+        hipError_t e = hipMemcpyAsync(h.data(), d_buf, want, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            c->set_error(std::string("hipMemcpy: ") + hipGetErrorString(e));
+            *rc = BSK_ERR_HIP;
+            return AB_UNLIMIT;
+        }
+    }
+    std::vector<uint8_t> s = head_first_seq(h, format, (size_t)std::max<int64_t>(thr, 1) );
+    if (thr == 0) s = head_first_seq(h, format, h.size());
+    return guess_alphabet_less_conservatively(s.data(), s.size(), thr);
+}
+
+int ensure_out(bsk_ctx* c, uint64_t bytes) { return grow(c, &c->d_out, &c->out_cap, bytes, bytes / 8 + 256); }
+
+int ensure_record_scratch(bsk_ctx* c) {
+    const uint64_t n = c->table.n;
+    int rc = BSK_OK;
+    if (n + 1 > c->out_len_cap || !c->d_out_len) {
+        if (c->d_out_len) HIP_TRYX(c, hipFree(c->d_out_len));
+        if (c->d_out_off) HIP_TRYX(c, hipFree(c->d_out_off));
+        c->d_out_len = nullptr; c->d_out_off = nullptr;
+        const uint64_t cap = n + n / 8 + 16;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_out_len, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_out_off, (cap + 1) * sizeof(uint64_t)));
+        c->out_len_cap = cap;
+    }
+    const uint64_t need = 2 * ((n + 2047) / 2048) + 4;
+    rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, need, 16);
+    if (rc != BSK_OK) return rc;
+    if (!c->d_counter) HIP_TRYX(c, hipMalloc((void**)&c->d_counter, 4 * sizeof(uint64_t)));
+    return BSK_OK;
+}
+
+int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    // ---- per-partition decisions of SeqTransform.Call (seq.go:94-125)
+    Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);  // parser.t after the first record
+    if (rc != BSK_OK) return rc;
+    if (ab == AB_NONE) ab = AB_UNLIMIT;
+    SeqParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    bool printName = true, printSeq = true, printQual = fastq;
+    if (o.b("Name") && o.b("Seq")) { /* both on; printQual as is */ }
+    else if (o.b("Name")) { printSeq = false; printQual = false; }
+    else if (o.b("Seq")) { printName = false; printQual = false; }
+    else if (o.b("Qual")) {
+        if (!fastq && c->table.n > 0) {
+            c->set_error("FASTA format has no quality. So do not just use flag -q (--qual)");
+            return BSK_ERR_FORMAT;
+        }
+        printName = false; printSeq = false; printQual = true;
+    }
+    P.print_name = printName; P.print_seq = printSeq; P.print_qual = printQual;
+    P.qual_only = o.b("Qual");
+    P.only_id = o.b("OnlyId");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.reverse = o.b("Reverse");
+    P.remove_gaps = o.b("RemoveGaps");
+    set_bits(P.gap_set, o.s("GapLetters"));
+    P.line_width = (fastq || o.b("Seq") || o.b("Qual")) ? 0 : (int)o.ci("LineWidth");
+    P.min_len = (int)o.i("MinLen"); P.max_len = (int)o.i("MaxLen");
+    P.min_qual = o.f("MinQual"); P.max_qual = o.f("MaxQual");
+    P.qual_base = (int)o.i("QualAsciiBase");
+    bool validate = o.b("ValidateSeq");
+    if (!validate && !(c->alphabet == AB_NONE || c->alphabet == AB_UNLIMIT)) validate = true;  // seq.go:66-72
+    const char* letters = alphabet_letters(ab);
+    P.validate = validate && letters != nullptr;
+    P.validate_len = (int)o.i("ValidateSeqLength");
+    if (letters) set_bits(P.valid_set, letters);
+    // one byte map for complement -> dna2rna -> rna2dna -> case (seq.go:191-239)
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i;
+    bool use_lut = false;
+    auto apply = [&](const char* from, const char* to) {
+        uint8_t m[256];
+        for (int i = 0; i < 256; ++i) m[i] = (uint8_t)i;
+        for (size_t k = 0; from[k]; ++k) m[(uint8_t)from[k]] = (uint8_t)to[k];
+        for (int i = 0; i < 256; ++i) lut[i] = m[lut[i]];
+        use_lut = true;
+    };
+    if (o.b("Complement")) {
+        if (ab == AB_DNA || ab == AB_DNAredundant) apply("acgtryswkmbdhvACGTRYSWKMBDHV", "tgcayrswmkvhdbTGCAYRSWMKVHDB");
+        else if (ab == AB_RNA || ab == AB_RNAredundant) apply("acguryswkmbdhvACGURYSWKMBDHV", "ugcayrswmkvhdbUGCAYRSWMKVHDB");
+    }
+    if (o.b("Dna2rna") && !(ab == AB_RNA || ab == AB_RNAredundant)) apply("tT", "uU");
+    if (o.b("Rna2dna") && !(ab == AB_DNA || ab == AB_DNAredundant)) apply("uU", "tT");
+    if (o.b("LowerCase")) apply("ABCDEFGHIJKLMNOPQRSTUVWXYZ", "abcdefghijklmnopqrstuvwxyz");
+    else if (o.b("UpperCase")) apply("abcdefghijklmnopqrstuvwxyz", "ABCDEFGHIJKLMNOPQRSTUVWXYZ");
+    P.use_lut = use_lut;
+    if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
+    if (!c->d_qual_err) HIP_TRYX(c, hipMalloc((void**)&c->d_qual_err, 256 * sizeof(double)));
+    HIP_TRYX(c, hipMemcpyAsync(c->d_lut, lut, 256, hipMemcpyHostToDevice, st));
+    double qe[256];
+    for (int q = 0; q < 256; ++q) qe[q] = std::pow(10.0, (double)(q - P.qual_base) / -10.0);
+    HIP_TRYX(c, hipMemcpyAsync(c->d_qual_err, qe, sizeof qe, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // lut / qe live on the host stack
+    P.lut = c->d_lut;
+    P.qual_err = c->d_qual_err;
+
+    if (c->table.n == 0) {
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        return kernel_error_to_status(c, status);
+    }
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
+    uint64_t total = 0, kept = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&kept, c->d_counter, sizeof kept, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
+}  // namespace bsk

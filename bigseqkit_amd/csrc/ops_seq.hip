@@ -1,0 +1,268 @@
+// ============================================================================
+// ops_seq.hip -- SeqTransform.Call (/root/reference/bigseqkit-lib/seq.go:81-269)
+// on the record table.
+//   k_seq_size : one thread per record -> bytes the record contributes (0 = filtered)
+//   (exclusive scan of the sizes, stream_index.hip)
+//   k_seq_emit : 16 lanes per record; every output byte is a pure function of
+//                (record, output offset): header / wrapped sequence / "+" / quality,
+//                reverse as an index map, complement + dna<->rna + case as ONE
+//                256-byte lookup.  Gap removal and multi-line FASTA sources take a
+//                sequential per-record path.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ops_seq.hpp"
+
+namespace bsk {
+
+namespace {
+
+__device__ __forceinline__ bool in_set(const uint32_t* set, uint8_t c) { return (set[c >> 5] >> (c & 31)) & 1u; }
+
+// ID length inside a header (marker excluded), parseHeadIDAndDesc (helper.go:329-369)
+__device__ uint32_t id_span(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off) {
+    *id_off = 0;
+    if (id_mode == 0) {
+        for (uint32_t i = 0; i < n; ++i)
+            if (h[i] == ' ') { if (i > 0) return i; break; }
+        for (uint32_t i = 0; i < n; ++i)
+            if (h[i] == '\t') { if (i > 0) return i; break; }
+        return n;
+    }
+    // --id-ncbi: leftmost match of  '|' [^|]+ '|' ' '
+    uint32_t a = 0;
+    while (a < n && h[a] != '|') ++a;
+    while (a < n) {
+        uint32_t b = a + 1;
+        while (b < n && h[b] != '|') ++b;
+        if (b >= n) break;
+        if (b > a + 1 && b + 1 < n && h[b + 1] == ' ') { *id_off = a + 1; return b - a - 1; }
+        a = b;
+    }
+    return n;
+}
+
+struct RecView {
+    const uint8_t* head;  // after the marker
+    uint32_t head_len;
+    const uint8_t* seq;   // FASTQ: contiguous; FASTA: region that may contain '\n'
+    uint32_t seq_len;     // bases
+    uint32_t region;      // FASTA: bytes of the region
+    const uint8_t* qual;
+    bool contiguous;      // sequence bytes are contiguous in memory
+};
+
+__device__ __forceinline__ RecView view(const uint8_t* buf, const RecordTable& t, uint64_t i, int fastq) {
+    RecView r;
+    const uint64_t s = t.start[i];
+    const uint32_t lh = t.l_head[i];
+    r.head = buf + s + 1;
+    r.head_len = lh > 0 ? lh - 1 : 0;
+    r.seq = buf + s + lh + 1;
+    r.seq_len = t.l_seq[i];
+    if (fastq) {
+        r.region = r.seq_len;
+        r.qual = r.seq + r.seq_len + 1 + t.aux[i] + 1;
+        r.contiguous = true;
+    } else {
+        r.region = t.aux[i];
+        r.qual = nullptr;
+        r.contiguous = r.region <= r.seq_len + 1;  // no interior newline
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t wrapped_len(uint32_t L, int w) {
+    if (w < 1 || L == 0) return L;
+    return L + (L - 1) / (uint32_t)w;
+}
+
+__global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
+                                                  uint32_t* __restrict__ out_len, uint64_t* __restrict__ status) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const RecView r = view(buf, t, i, P.fastq);
+    uint32_t L = r.seq_len;
+    uint32_t err = 0;
+    if (P.validate) {
+        uint32_t seen = 0;
+        for (uint32_t k = 0; k < r.region && (P.validate_len <= 0 || seen < (uint32_t)P.validate_len); ++k) {
+            const uint8_t c = r.seq[k];
+            if (c == '\n' && !P.fastq) continue;
+            ++seen;
+            if (!in_set(P.valid_set, c)) { err |= ERR_INVALID_LETTER; break; }
+        }
+    }
+    uint32_t kept = L;
+    if (P.remove_gaps) {
+        kept = 0;
+        for (uint32_t k = 0; k < r.region; ++k) {
+            const uint8_t c = r.seq[k];
+            if (c == '\n' && !P.fastq) continue;
+            if (!in_set(P.gap_set, c)) ++kept;
+        }
+    }
+    bool keep = true;
+    if (P.min_len > 0 && (int64_t)kept < P.min_len) keep = false;
+    if (P.max_len > 0 && (int64_t)kept > P.max_len) keep = false;
+    if (keep && (P.min_qual > 0 || P.max_qual > 0)) {
+        // Seq.AvgQual: mean error probability, summed sequentially in float64
+        double aq = 0;
+        if (P.fastq && kept > 0) {
+            double sum = 0;
+            for (uint32_t k = 0; k < L; ++k) {
+                if (P.remove_gaps && in_set(P.gap_set, r.seq[k])) continue;
+                sum += P.qual_err[r.qual[k]];
+            }
+            aq = -10.0 * log10(sum / (double)kept);
+        }
+        if (P.min_qual > 0 && aq < P.min_qual) keep = false;
+        if (P.max_qual > 0 && aq >= P.max_qual) keep = false;
+    }
+    uint32_t n = 0;
+    if (keep) {
+        if (P.print_name) {
+            uint32_t hl = r.head_len, off;
+            if (P.only_id) hl = id_span(r.head, r.head_len, P.id_mode, &off);
+            n += (P.print_seq ? 1u : 0u) + hl + 1u;
+        }
+        if (P.print_seq) n += wrapped_len(kept, P.line_width) + 1u;
+        if (P.print_qual) n += (P.qual_only ? 0u : 2u) + kept + 1u;
+    }
+    out_len[i] = n;
+    if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
+}
+
+constexpr int GROUP = 16;
+
+__global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
+                                                  const uint32_t* __restrict__ out_len,
+                                                  const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    if (g >= t.n) return;
+    const uint32_t n = out_len[g];
+    if (n == 0) return;
+    uint8_t* o = out + out_off[g];
+    const RecView r = view(buf, t, g, P.fastq);
+    uint32_t hl = r.head_len, hoff = 0;
+    if (P.print_name && P.only_id) hl = id_span(r.head, r.head_len, P.id_mode, &hoff);
+    const uint32_t a = P.print_name ? (P.print_seq ? 1u : 0u) + hl + 1u : 0u;
+    const bool fast = r.contiguous && !P.remove_gaps;
+    if (fast) {
+        const uint32_t L = r.seq_len;
+        const uint32_t W = wrapped_len(L, P.line_width);
+        const uint32_t b = P.print_seq ? W + 1u : 0u;
+        const uint32_t w1 = (uint32_t)(P.line_width > 0 ? P.line_width + 1 : 0);
+        for (uint32_t x = gl; x < n; x += GROUP) {
+            uint8_t c;
+            if (x < a) {
+                const uint32_t m = P.print_seq ? 1u : 0u;
+                if (x < m) c = P.fastq ? '@' : '>';
+                else if (x == a - 1) c = '\n';
+                else c = r.head[hoff + x - m];
+            } else if (x < a + b) {
+                uint32_t q = x - a;
+                if (q == W) c = '\n';
+                else {
+                    bool nl = false;
+                    if (w1) {
+                        const uint32_t line = q / w1, col = q - line * w1;
+                        if (col == w1 - 1) nl = true;
+                        q = line * (w1 - 1) + col;
+                    }
+                    if (nl) c = '\n';
+                    else {
+                        c = r.seq[P.reverse ? L - 1 - q : q];
+                        if (P.use_lut) c = P.lut[c];
+                    }
+                }
+            } else {
+                uint32_t q = x - a - b;
+                if (!P.qual_only) {
+                    if (q == 0) { o[x] = '+'; continue; }
+                    if (q == 1) { o[x] = '\n'; continue; }
+                    q -= 2;
+                }
+                c = q == L ? (uint8_t)'\n' : r.qual[P.reverse ? L - 1 - q : q];
+            }
+            o[x] = c;
+        }
+        return;
+    }
+    // sequential path: gap removal and / or a multi-line FASTA source
+    if (gl != 0) return;
+    uint32_t x = 0;
+    if (P.print_name) {
+        if (P.print_seq) o[x++] = P.fastq ? '@' : '>';
+        for (uint32_t k = 0; k < hl; ++k) o[x++] = r.head[hoff + k];
+        o[x++] = '\n';
+    }
+    const uint32_t R = r.region;
+    if (P.print_seq) {
+        uint32_t col = 0;
+        bool first = true;
+        for (uint32_t k = 0; k < R; ++k) {
+            const uint8_t c0 = r.seq[P.reverse ? R - 1 - k : k];
+            if (c0 == '\n' && !P.fastq) continue;
+            if (P.remove_gaps && in_set(P.gap_set, c0)) continue;
+            if (P.line_width > 0 && !first && col == (uint32_t)P.line_width) { o[x++] = '\n'; col = 0; }
+            o[x++] = P.use_lut ? P.lut[c0] : c0;
+            ++col;
+            first = false;
+        }
+        o[x++] = '\n';
+    }
+    if (P.print_qual) {
+        if (!P.qual_only) { o[x++] = '+'; o[x++] = '\n'; }
+        const uint32_t L = r.seq_len;
+        for (uint32_t k = 0; k < L; ++k) {
+            const uint32_t j = P.reverse ? L - 1 - k : k;
+            if (P.remove_gaps && in_set(P.gap_set, r.seq[j])) continue;
+            o[x++] = r.qual[j];
+        }
+        o[x++] = '\n';
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t* __restrict__ v, uint64_t n, uint64_t* counter) {
+    uint64_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        c += v[i] != 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)c, d, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(c >> 32), d, 64);
+        c += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long*)counter, (unsigned long long)c);
+}
+
+}  // namespace
+
+hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqParams& P, uint32_t* out_len,
+                           uint64_t* status, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    const uint64_t blocks = (t.n + 255) / 256;
+    hipLaunchKernelGGL(k_seq_size, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& P, const uint32_t* out_len,
+                           const uint64_t* out_off, uint8_t* out, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    const uint64_t blocks = (t.n * GROUP + 255) / 256;
+    hipLaunchKernelGGL(k_seq_emit, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_nonzero(const uint32_t* v, uint64_t n, uint64_t* counter, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)blocks), dim3(256), 0, st, v, n, counter);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

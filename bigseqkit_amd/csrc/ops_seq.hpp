@@ -1,0 +1,40 @@
+// `seq` on the record table: size pass -> exclusive scan -> emit pass.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+
+namespace bsk {
+
+struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go:28-79), device-friendly
+    int fastq;
+    int print_name, print_seq, print_qual;  // seq.go:151-163 (constant per partition)
+    int qual_only;                          // opts.Qual: no "+\n" before the quality
+    int only_id;                            // -i
+    int id_mode;                            // 0 default regexp (helper.go:329-357), 1 --id-ncbi
+    int reverse;
+    int use_lut;                            // complement / dna2rna / rna2dna / case folded into one 256-byte map
+    int remove_gaps;
+    uint32_t gap_set[8];                    // 256-bit set
+    int line_width;                         // effective (0 for FASTQ, -s, -q)
+    int min_len, max_len;                   // > 0 enables (seq.go:88-89)
+    double min_qual, max_qual;              // > 0 enables (seq.go:90-91)
+    int qual_base;
+    int validate;                           // SeqParser validation (helper.go:304-306)
+    int validate_len;
+    uint32_t valid_set[8];
+    const uint8_t* lut;                     // device, 256 bytes
+    const double* qual_err;                 // device, 256 doubles: 10^(-(q-base)/10) indexed by the raw byte
+};
+
+constexpr uint32_t ERR_INVALID_LETTER = 128u;
+
+hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqParams& P, uint32_t* out_len,
+                           uint64_t* status, hipStream_t st);
+hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& P, const uint32_t* out_len,
+                           const uint64_t* out_off, uint8_t* out, hipStream_t st);
+hipError_t launch_count_nonzero(const uint32_t* v, uint64_t n, uint64_t* counter, hipStream_t st);
+
+}  // namespace bsk

@@ -1,157 +1,28 @@
 // ============================================================================
-// stream_stats.hip -- single-pass streaming kernels for `stats` on gfx950.
+// stream_stats.hip -- `stats` on gfx950: the StatsSink of the streaming skeleton
+// (stream_core.cuh) + k_prep (range anchors) + launchers.
 //
 // Replaces, for one shard resident in HBM, the reference's
-//   ReadFixer.Call   /root/reference/bigseqkit-lib/helper.go:41-66
-//   SeqParser.Read   bigseqkit-lib/helper.go:219-325   (line structure only)
-//   Stats.Call       bigseqkit-lib/stats.go:48-117
-// Design:
-//   * the shard is cut into `nranges` byte ranges that begin on a record
-//     (k_prep: anchor search, the ReadFixer equivalent);
-//   * persistent 64-lane waves pull ranges from an atomic queue and stream them
-//     in 4 KiB tiles of coalesced 16-byte loads; every byte is read ONCE;
-//   * per tile: SWAR newline / quality-threshold / gap masks, one packed DPP
-//     prefix scan per 1 KiB piece, newline EVENTS (position + running counters)
-//     scattered into a per-wave LDS window, then one lane per event derives
-//     line lengths and per-line counter differences.  No per-byte state machine.
-//   * lengths go to an LDS histogram (bins < 2048) flushed once per block.
-// HBM-bound integer/byte work: no MFMA anywhere.
+//   ReadFixer.Call   /root/reference/bigseqkit-lib/helper.go:41-66   (k_prep)
+//   SeqParser.Read   bigseqkit-lib/helper.go:219-325   (line structure, stream_core.cuh)
+//   Stats.Call       bigseqkit-lib/stats.go:48-117     (StatsSink)
+// One pass, every byte read once; lengths go to an LDS histogram (bins < 2048)
+// flushed once per block; Q20/Q30/gap are differences of running counters taken
+// at newline events.  See DESIGN.md section 3.
 // ============================================================================
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
 #include "anchor.hpp"
+#include "stream_core.cuh"
 #include "stream_stats.hpp"
 
 namespace bsk {
 
 namespace {
 
-constexpr int WAVE = 64;
-constexpr int NPIECE = 4;                 // 16-byte pieces per lane per tile
-constexpr int PIECE_BYTES = WAVE * 16;    // 1 KiB per wave-piece
-constexpr int TILE = PIECE_BYTES * NPIECE;  // 4 KiB per wave-tile
-constexpr int CAP = 128;                  // newline events per LDS batch
-constexpr int HISTORY = 4;                // events kept from the previous batch
-constexpr int SLOTS = HISTORY + CAP;
-constexpr int LDS_HIST = 2048;
-constexpr int WAVES_PER_BLOCK = 4;
-
-// ---------------------------------------------------------------------------
-// wave primitives
-// ---------------------------------------------------------------------------
-template <bool DPP>
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    if constexpr (DPP) {
-        // Hillis-Steele inside each row of 16 lanes (row_shr 1,2,4,8; lanes
-        // without a source read 0 via bound_ctrl), then row_bcast:15 into rows
-        // 1 and 3, then row_bcast:31 into rows 2 and 3.
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-        return v;
-    } else {
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
-            if (lane >= d) v += t;
-        }
-        return v;
-    }
-}
-
-__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
-__device__ __forceinline__ uint32_t wave_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
-}
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
-        uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// make one wave's LDS writes visible to its other lanes (DS ops of a wave are
-// executed in order; this only stops the compiler from reordering them)
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---------------------------------------------------------------------------
-// SWAR byte predicates on a dword -> 4-bit mask (bit b = byte b matches)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {  // exact: 0x80 in every zero byte
-    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-}
-__device__ __forceinline__ uint32_t nibble(uint32_t t) {  // 0x80-per-byte mask -> 4 bits
-    return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu;
-}
-__device__ __forceinline__ uint32_t eq_mask16(const uint4& v, uint32_t rep) {
-    return nibble(zero_bytes(v.x ^ rep)) | (nibble(zero_bytes(v.y ^ rep)) << 4) | (nibble(zero_bytes(v.z ^ rep)) << 8) |
-           (nibble(zero_bytes(v.w ^ rep)) << 12);
-}
-// bytes >= thr (unsigned compare, thr in 1..128): k = (0x80 - thr) replicated
-__device__ __forceinline__ uint32_t ge_bytes(uint32_t x, uint32_t k) {
-    return (((x & 0x7F7F7F7Fu) + k) | x) & 0x80808080u;
-}
-__device__ __forceinline__ uint32_t ge_mask16(const uint4& v, uint32_t k) {
-    return nibble(ge_bytes(v.x, k)) | (nibble(ge_bytes(v.y, k)) << 4) | (nibble(ge_bytes(v.z, k)) << 8) |
-           (nibble(ge_bytes(v.w, k)) << 12);
-}
-
-// 16 bytes at buf[idx..idx+16) with idx % 16 == 0; bytes outside [0, n) read as 0
-__device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ buf, uint64_t n, uint64_t idx) {
-    if (idx + 16 <= n) return *reinterpret_cast<const uint4*>(buf + idx);
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (int b = 0; b < 16; ++b)
-        if (idx + b < n) w[b >> 2] |= (uint32_t)buf[idx + b] << ((b & 3) * 8);
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-struct Acc {  // per-lane accumulators, reduced once per wave at kernel end
-    uint64_t q20 = 0, q30 = 0, gap = 0, nrec = 0, sumlen = 0;
-    uint32_t err = 0;
-};
-
-struct Piece {  // what a lane keeps of one 16-byte piece
-    uint32_t m_nl_a;  // nl16 | a16 << 16      (a = q>=20 for FASTQ, gap for FASTA)
-    uint32_t m_b_c;   // b16 | c16 << 16       (b = q>=30, c = gap; FASTQ -a only)
-    uint32_t ex_lo;   // exclusive prefix: nl | a << 16
-    uint32_t ex_hi;   // exclusive prefix: b  | c << 16
-};
-
-template <bool FASTQ, bool ALL>
-struct Lds {
-    uint32_t pos[SLOTS];
-    uint32_t a[(ALL) ? SLOTS : 1];
-    uint32_t b[(ALL && FASTQ) ? SLOTS : 1];
-    uint32_t c[(ALL && FASTQ) ? SLOTS : 1];
-    uint8_t flag[(!FASTQ) ? SLOTS : 4];
-};
+using namespace stream;
 
 // length histogram update with wave-level aggregation of the common case
 // "every active lane saw the same length" (fixed-length reads)
@@ -185,285 +56,101 @@ __device__ __forceinline__ void add_length(bool has, uint32_t len, uint32_t* s_h
     }
 }
 
-// ---------------------------------------------------------------------------
-// one batch of E newline events sitting in LDS slots [HISTORY, HISTORY+E);
-// `wb` = rank (0-based line index inside the range) of the first of them;
-// `tile_idx` / `tile_rel` locate the tile so that a relative position can be
-// turned back into an absolute byte index without 32-bit wrap problems.
-// ---------------------------------------------------------------------------
-template <bool FASTQ, bool ALL>
-__device__ __forceinline__ void process_batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
-                                              uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf,
-                                              uint32_t* s_hist, const StatsDev& D, Acc& acc, uint32_t& open_key,
-                                              uint32_t& open_sg) {
-    const int lane = threadIdx.x & 63;
-    uint64_t best = 0;  // FASTA: (rank+1) << 32 | lane of the last header-end event seen by this lane
-    uint32_t best_key = 0, best_sg = 0;
-    for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
-        const uint32_t e = e0 + lane;
-        const bool on = e < E;
-        const uint32_t s = HISTORY + (on ? e : 0);
-        const uint32_t rank = wb + e;
-        const uint32_t p = L.pos[s];
-        const uint64_t abs_next = tile_idx + (uint64_t)(uint32_t)(p - tile_rel) + 1;  // byte after the newline
-        if constexpr (FASTQ) {
-            const uint32_t role = rank & 3u;
-            const uint32_t p1 = L.pos[s - 1];
-            const uint32_t len = p - p1 - 1u;
-            const bool is_seq = on && role == 1u;
-            add_length(is_seq, len, s_hist, D);
-            if (on) {
-                if (role == 1u) {
-                    acc.sumlen += len;
-                    if constexpr (ALL) acc.gap += (uint32_t)(L.c[s] - L.c[s - 1]);
-                    if (abs_next >= re || buf[abs_next] != '+') acc.err |= ERR_BAD_PLUS;
-                } else if (role == 3u) {
-                    const uint32_t slen = L.pos[s - 2] - L.pos[s - 3] - 1u;
-                    if (len != slen) acc.err |= ERR_LEN_MISMATCH;
-                    if constexpr (ALL) {
-                        acc.q20 += (uint32_t)(L.a[s] - L.a[s - 1]);
-                        acc.q30 += (uint32_t)(L.b[s] - L.b[s - 1]);
-                    }
-                    acc.nrec += 1;
-                    if (abs_next < re && buf[abs_next] != '@') acc.err |= ERR_BAD_HEADER;
-                } else if (role == 0u) {
-                    // a non-empty sequence line must not start with '+'
-                    if (abs_next < re && buf[abs_next] == '+') acc.err |= ERR_BAD_PLUS;
-                }
-            }
-        } else {
-            const bool closing = on && L.flag[s] != 0;
-            uint32_t seqlen = 0;
-            if (on) {
-                // is this event the end of a header line?
-                if (L.flag[s - 1]) {
-                    best = ((uint64_t)(rank + 1u) << 32) | (uint32_t)lane;
-                    best_key = p - rank;
-                    if constexpr (ALL) best_sg = L.a[s];
-                }
-            }
-            if (closing) {
-                // walk back to the header-end event of this record
-                uint32_t t = s;
-                while (t > 0 && !L.flag[t - 1]) --t;
-                uint32_t key_i, sg_i = 0;
-                if (t > 0) {
-                    key_i = L.pos[t] - (wb + (t - HISTORY));
-                    if constexpr (ALL) sg_i = L.a[t];
-                } else {
-                    key_i = open_key;
-                    sg_i = open_sg;
-                }
-                seqlen = (p - rank) - key_i;
-                acc.sumlen += seqlen;
-                acc.nrec += 1;
-                if constexpr (ALL) acc.gap += (uint32_t)(L.a[s] - sg_i);
-            }
-            add_length(closing, seqlen, s_hist, D);
-        }
-    }
-    if constexpr (!FASTQ) {
-        // carry the header-end of the record that is open at the end of the batch
-        const uint64_t w = wave_max_u64(best);
-        if (w != 0) {
-            const int src = (int)(uint32_t)w;
-            open_key = (uint32_t)__builtin_amdgcn_readlane((int)best_key, src);
-            if constexpr (ALL) open_sg = (uint32_t)__builtin_amdgcn_readlane((int)best_sg, src);
-        }
-    }
-    // keep the last HISTORY events for the next batch
-    wave_lds_fence();
-    uint32_t hp = 0, ha = 0, hb = 0, hc = 0;
-    uint8_t hf = 0;
-    if (lane < HISTORY) {
-        hp = L.pos[E + lane];
-        if constexpr (ALL) ha = L.a[E + lane];
-        if constexpr (ALL && FASTQ) { hb = L.b[E + lane]; hc = L.c[E + lane]; }
-        if constexpr (!FASTQ) hf = L.flag[E + lane];
-    }
-    wave_lds_fence();
-    if (lane < HISTORY) {
-        L.pos[lane] = hp;
-        if constexpr (ALL) L.a[lane] = ha;
-        if constexpr (ALL && FASTQ) { L.b[lane] = hb; L.c[lane] = hc; }
-        if constexpr (!FASTQ) L.flag[lane] = hf;
-    }
-    wave_lds_fence();
-}
 
 // ---------------------------------------------------------------------------
-// stream one range [rs, re) of the shard
+// StatsSink: Stats.Call (bigseqkit-lib/stats.go:48-117) on newline events
 // ---------------------------------------------------------------------------
-template <bool FASTQ, bool ALL, bool DPP>
-__device__ __forceinline__ void process_range(Lds<FASTQ, ALL>& L, const uint8_t* __restrict__ buf, uint64_t n,
-                                              uint64_t rs, uint64_t re, bool is_last, uint32_t* s_hist,
-                                              const StatsDev& D, Acc& acc) {
-    const int lane = threadIdx.x & 63;
-    // virtual events before the range: a newline at relative position -1
-    if (lane < HISTORY) {
-        L.pos[lane] = 0xFFFFFFFFu;
-        if constexpr (ALL) L.a[lane] = 0;
-        if constexpr (ALL && FASTQ) { L.b[lane] = 0; L.c[lane] = 0; }
-        if constexpr (!FASTQ) L.flag[lane] = 1;
-    }
-    wave_lds_fence();
-    if (lane == 0) {
-        const uint8_t c0 = buf[rs];
-        if (c0 != (FASTQ ? '@' : '>')) acc.err |= ERR_BAD_HEADER;
-    }
-    uint32_t line_base = 0;                // newlines seen so far in this range
-    uint32_t run_a = 0, run_b = 0, run_c = 0;  // running counters (mod 2^32)
+struct StatsSink {
+    uint32_t* s_hist;
+    StatsDev D;
+    // per-lane accumulators, reduced once per wave at kernel end
+    uint64_t q20 = 0, q30 = 0, gap = 0, nrec = 0, sumlen = 0;
+    uint32_t err = 0;
+    // FASTA: header-end of the record that is open at the start of a batch
     uint32_t open_key = 0, open_sg = 0;
-    uint32_t quiet_tiles = 0;              // consecutive tiles without a newline
 
-    const uint64_t idx0 = rs & ~(uint64_t)15;
-    const uint64_t ntiles = (re - idx0 + TILE - 1) / TILE;
+    __device__ __forceinline__ void begin_range() { open_key = 0; open_sg = 0; }
 
-    uint4 cur[NPIECE], nxt[NPIECE];
-#pragma unroll
-    for (int p = 0; p < NPIECE; ++p) cur[p] = load16(buf, n, idx0 + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
-
-    for (uint64_t t = 0; t < ntiles; ++t) {
-        const uint64_t tile_idx = idx0 + t * TILE;
-        const uint32_t tile_rel = (uint32_t)(tile_idx - rs);
-        // prefetch the next tile while this one is processed
-        if (t + 1 < ntiles) {
-#pragma unroll
-            for (int p = 0; p < NPIECE; ++p)
-                nxt[p] = load16(buf, n, tile_idx + TILE + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
-        }
-        const bool edge = (tile_idx < rs) || (tile_idx + TILE > re);  // wave-uniform
-
-        Piece pc[NPIECE];
-        uint32_t base_nl[NPIECE], base_a[NPIECE], base_b[NPIECE], base_c[NPIECE];
-        const uint32_t tile_rank_base = line_base;
-#pragma unroll
-        for (int p = 0; p < NPIECE; ++p) {
-            const uint4 v = cur[p];
-            uint32_t nl = eq_mask16(v, 0x0A0A0A0Au);
-            uint32_t ma = 0, mb = 0, mc = 0;
-            if constexpr (ALL) {
-                uint32_t g = 0;
-#pragma unroll
-                for (int k = 0; k < MAX_GAP_LETTERS; ++k)
-                    if (k < D.ngap) g |= eq_mask16(v, D.gap_rep[k]);
-                if constexpr (FASTQ) {
-                    ma = ge_mask16(v, D.k20);
-                    mb = ge_mask16(v, D.k30);
-                    mc = g;
-                } else {
-                    ma = g;
-                }
-            }
-            if (edge) {
-                const uint64_t I = tile_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16;
-                int64_t lo = (int64_t)rs - (int64_t)I, hi = (int64_t)re - (int64_t)I;
-                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-                const uint32_t valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-                nl &= valid; ma &= valid; mb &= valid; mc &= valid;
-            }
-            pc[p].m_nl_a = nl | (ma << 16);
-            pc[p].m_b_c = mb | (mc << 16);
-            const uint32_t lo_cnt = (uint32_t)__popc(nl) | ((uint32_t)__popc(ma) << 16);
-            const uint32_t incl_lo = wave_incl_scan<DPP>(lo_cnt);
-            pc[p].ex_lo = incl_lo - lo_cnt;
-            const uint32_t tot_lo = wave_last(incl_lo);
-            base_nl[p] = line_base;
-            base_a[p] = run_a;
-            line_base += tot_lo & 0xFFFFu;
-            run_a += tot_lo >> 16;
-            if constexpr (ALL && FASTQ) {
-                const uint32_t hi_cnt = (uint32_t)__popc(mb) | ((uint32_t)__popc(mc) << 16);
-                const uint32_t incl_hi = wave_incl_scan<DPP>(hi_cnt);
-                pc[p].ex_hi = incl_hi - hi_cnt;
-                const uint32_t tot_hi = wave_last(incl_hi);
-                base_b[p] = run_b;
-                base_c[p] = run_c;
-                run_b += tot_hi & 0xFFFFu;
-                run_c += tot_hi >> 16;
-            } else {
-                pc[p].ex_hi = 0;
-                base_b[p] = 0;
-                base_c[p] = 0;
-            }
-        }
-        const uint32_t tile_events = line_base - tile_rank_base;
-        if (tile_events == 0) {
-            // lines longer than 2^31 bytes cannot be measured with 32-bit relative positions
-            if (++quiet_tiles >= (1u << 31) / TILE) acc.err |= ERR_LINE_TOO_LONG;
-        } else {
-            quiet_tiles = 0;
-        }
-
-        // events of this tile, CAP at a time (one batch for ordinary data)
-        for (uint32_t wb = tile_rank_base; wb < line_base; wb += CAP) {
-#pragma unroll
-            for (int p = 0; p < NPIECE; ++p) {
-                uint32_t m = pc[p].m_nl_a & 0xFFFFu;
-                const uint32_t ma = pc[p].m_nl_a >> 16;
-                const uint32_t rank0 = base_nl[p] + (pc[p].ex_lo & 0xFFFFu);
-                uint32_t k = 0;
-                while (m) {
-                    const uint32_t bpos = (uint32_t)__ffs((int)m) - 1u;
-                    m &= m - 1u;
-                    const uint32_t rank = rank0 + k;
-                    ++k;
-                    const uint32_t w = rank - wb;
-                    if (w < (uint32_t)CAP) {
-                        const uint32_t s = HISTORY + w;
-                        const uint32_t below = (1u << bpos) - 1u;
-                        const uint32_t off = (uint32_t)p * PIECE_BYTES + (uint32_t)lane * 16u + bpos;
-                        L.pos[s] = tile_rel + off;
-                        if constexpr (ALL) L.a[s] = base_a[p] + (pc[p].ex_lo >> 16) + (uint32_t)__popc(ma & below);
-                        if constexpr (ALL && FASTQ) {
-                            L.b[s] = base_b[p] + (pc[p].ex_hi & 0xFFFFu) + (uint32_t)__popc((pc[p].m_b_c & 0xFFFFu) & below);
-                            L.c[s] = base_c[p] + (pc[p].ex_hi >> 16) + (uint32_t)__popc((pc[p].m_b_c >> 16) & below);
+    template <bool FASTQ, bool ALL>
+    __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
+                                          uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
+        const int lane = threadIdx.x & 63;
+        uint64_t best = 0;  // FASTA: (rank+1) << 32 | lane of the last header-end event seen by this lane
+        uint32_t best_key = 0, best_sg = 0;
+        for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
+            const uint32_t e = e0 + lane;
+            const bool on = e < E;
+            const uint32_t s = HISTORY + (on ? e : 0);
+            const uint32_t rank = wb + e;
+            const uint32_t p = L.pos[s];
+            const uint64_t abs_next = tile_idx + (uint64_t)(uint32_t)(p - tile_rel) + 1;  // byte after the newline
+            if constexpr (FASTQ) {
+                const uint32_t role = rank & 3u;
+                const uint32_t p1 = L.pos[s - 1];
+                const uint32_t len = p - p1 - 1u;
+                const bool is_seq = on && role == 1u;
+                add_length(is_seq, len, s_hist, D);
+                if (on) {
+                    if (role == 1u) {
+                        sumlen += len;
+                        if constexpr (ALL) gap += (uint32_t)(L.c[s] - L.c[s - 1]);
+                        if (abs_next >= re || buf[abs_next] != '+') err |= ERR_BAD_PLUS;
+                    } else if (role == 3u) {
+                        const uint32_t slen = L.pos[s - 2] - L.pos[s - 3] - 1u;
+                        if (len != slen) err |= ERR_LEN_MISMATCH;
+                        if constexpr (ALL) {
+                            q20 += (uint32_t)(L.a[s] - L.a[s - 1]);
+                            q30 += (uint32_t)(L.b[s] - L.b[s - 1]);
                         }
-                        if constexpr (!FASTQ) {
-                            const uint64_t an = tile_idx + off + 1;  // byte after the newline
-                            L.flag[s] = (an >= re || buf[an] == '>') ? 1 : 0;
-                        }
+                        nrec += 1;
+                        if (abs_next < re && buf[abs_next] != '@') err |= ERR_BAD_HEADER;
+                    } else if (role == 0u) {
+                        // a non-empty sequence line must not start with '+'
+                        if (abs_next < re && buf[abs_next] == '+') err |= ERR_BAD_PLUS;
                     }
                 }
+            } else {
+                const bool closing = on && L.flag[s] != 0;
+                uint32_t seqlen = 0;
+                if (on) {
+                    // is this event the end of a header line?
+                    if (L.flag[s - 1]) {
+                        best = ((uint64_t)(rank + 1u) << 32) | (uint32_t)lane;
+                        best_key = p - rank;
+                        if constexpr (ALL) best_sg = L.a[s];
+                    }
+                }
+                if (closing) {
+                    // walk back to the header-end event of this record
+                    uint32_t t = s;
+                    while (t > 0 && !L.flag[t - 1]) --t;
+                    uint32_t key_i, sg_i = 0;
+                    if (t > 0) {
+                        key_i = L.pos[t] - (wb + (t - HISTORY));
+                        if constexpr (ALL) sg_i = L.a[t];
+                    } else {
+                        key_i = open_key;
+                        sg_i = open_sg;
+                    }
+                    seqlen = (p - rank) - key_i;
+                    sumlen += seqlen;
+                    nrec += 1;
+                    if constexpr (ALL) gap += (uint32_t)(L.a[s] - sg_i);
+                }
+                add_length(closing, seqlen, s_hist, D);
             }
-            wave_lds_fence();
-            const uint32_t E = (line_base - wb) < (uint32_t)CAP ? (line_base - wb) : (uint32_t)CAP;
-            process_batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf, s_hist, D, acc, open_key, open_sg);
         }
-        if (t + 1 < ntiles) {
-#pragma unroll
-            for (int p = 0; p < NPIECE; ++p) cur[p] = nxt[p];
+        if constexpr (!FASTQ) {
+            // carry the header-end of the record that is open at the end of the batch
+            const uint64_t w = wave_max_u64(best);
+            if (w != 0) {
+                const int src = (int)(uint32_t)w;
+                open_key = (uint32_t)__builtin_amdgcn_readlane((int)best_key, src);
+                if constexpr (ALL) open_sg = (uint32_t)__builtin_amdgcn_readlane((int)best_sg, src);
+            }
         }
     }
-
-    // end of range --------------------------------------------------------
-    const uint32_t end_rel = (uint32_t)(re - rs);
-    const uint64_t end_tile = re & ~(uint64_t)(TILE - 1);
-    bool virt = false;
-    if constexpr (FASTQ) {
-        // EOF inside a quality line (no final '\n', or an empty last quality line)
-        virt = is_last && (line_base & 3u) == 3u;
-    } else {
-        virt = is_last && buf[re - 1] != '\n';
-    }
-    if (virt) {
-        if (lane == 0) {
-            L.pos[HISTORY] = end_rel;
-            if constexpr (ALL) L.a[HISTORY] = run_a;
-            if constexpr (ALL && FASTQ) { L.b[HISTORY] = run_b; L.c[HISTORY] = run_c; }
-            if constexpr (!FASTQ) L.flag[HISTORY] = 1;
-        }
-        wave_lds_fence();
-        // place the pseudo tile so that (pos - tile_rel) stays small
-        const uint32_t vt_rel = (uint32_t)(end_tile - rs);
-        process_batch<FASTQ, ALL>(L, 1u, line_base, end_tile, vt_rel, re + 1, buf, s_hist, D, acc, open_key, open_sg);
-        line_base += 1;
-    }
-    if constexpr (FASTQ) {
-        if ((line_base & 3u) != 0u) acc.err |= is_last ? ERR_TRUNCATED : ERR_ANCHOR;
-    }
-}
+};
 
 template <bool FASTQ, bool ALL, bool DPP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void k_stats(const uint8_t* __restrict__ buf, uint64_t n,
@@ -478,7 +165,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void k_stats(const uint8_t*
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     Lds<FASTQ, ALL>& L = s_l[wave];
-    Acc acc;
+    StatsSink sink;
+    sink.s_hist = s_hist;
+    sink.D = D;
     const uint64_t n_eff = anchors[nranges];
     for (;;) {
         uint32_t r = 0;
@@ -489,12 +178,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void k_stats(const uint8_t*
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) continue;
-        process_range<FASTQ, ALL, DPP>(L, buf, n, rs, re, re == n_eff, s_hist, D, acc);
+        sink.begin_range();
+        stream_range<FASTQ, ALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink);
     }
     // flush ---------------------------------------------------------------
-    const uint64_t q20 = wave_sum_u64(acc.q20), q30 = wave_sum_u64(acc.q30), gap = wave_sum_u64(acc.gap);
-    const uint64_t nrec = wave_sum_u64(acc.nrec), sumlen = wave_sum_u64(acc.sumlen);
-    const uint32_t err = wave_or_u32(acc.err);
+    const uint64_t q20 = wave_sum_u64(sink.q20), q30 = wave_sum_u64(sink.q30), gap = wave_sum_u64(sink.gap);
+    const uint64_t nrec = wave_sum_u64(sink.nrec), sumlen = wave_sum_u64(sink.sumlen);
+    const uint32_t err = wave_or_u32(sink.err);
     if (lane == 0) {
         if (q20) atomicAdd((unsigned long long*)&D.vec[0], (unsigned long long)q20);
         if (q30) atomicAdd((unsigned long long*)&D.vec[1], (unsigned long long)q30);

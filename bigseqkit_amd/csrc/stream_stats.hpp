@@ -9,13 +9,21 @@ namespace bsk {
 constexpr int STATS_HDR = 8;  // == BSK_STATS_HDR in include/bsk.h
 constexpr int MAX_GAP_LETTERS = 8;
 
-// error flags raised by the kernels (status[0])
+// error flags raised by the kernels (status[0]); mirrored in stream_core.cuh
 constexpr uint32_t ERR_BAD_HEADER = 1u;     // record does not start with '@' / '>'
 constexpr uint32_t ERR_BAD_PLUS = 2u;       // FASTQ: third line does not start with '+' (or sequence line does)
 constexpr uint32_t ERR_LEN_MISMATCH = 4u;   // FASTQ: len(seq) != len(qual)
 constexpr uint32_t ERR_TRUNCATED = 8u;      // FASTQ: shard ends inside a record
 constexpr uint32_t ERR_ANCHOR = 16u;        // a range did not end on a record boundary
 constexpr uint32_t ERR_LINE_TOO_LONG = 32u; // a line longer than 2^31 bytes
+constexpr uint32_t ERR_CAPACITY = 64u;      // an output table was too small
+
+// constants of the byte predicates (only read by the -a kernels)
+struct PredConsts {
+    uint32_t k20, k30;  // (0x80 - threshold) replicated in the 4 bytes
+    uint32_t gap_rep[MAX_GAP_LETTERS];
+    int ngap;
+};
 
 struct StatsDev {
     uint64_t* vec;       // stats vector (see include/bsk.h)
@@ -23,9 +31,7 @@ struct StatsDev {
     uint64_t* overflow;  // lengths >= hist_cap
     uint64_t overflow_cap;
     uint32_t hist_cap;
-    uint32_t k20, k30;   // (0x80 - threshold) replicated in the 4 bytes
-    uint32_t gap_rep[MAX_GAP_LETTERS];
-    int ngap;
+    PredConsts pred;
 };
 
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,

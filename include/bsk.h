@@ -121,6 +121,33 @@ int bsk_stats_finalize(const bsk_ctx* ctx, const int64_t* keys, const int64_t* v
 int bsk_stats_string(const bsk_ctx* ctx, const char* name, const char* format, const bsk_statinfo* info, char* out,
                      size_t cap);
 
+/* ---- record-producing operators ------------------------------------------
+ * The reference operators return []string, one element per output record,
+ * which FileStore writes as element + "\n" (bigseqkit-lib/helper.go:447).
+ * Here the result of one Call() is that byte stream, left in a ctx-owned DEVICE
+ * buffer (valid until the next run on the same ctx or bsk_destroy). */
+typedef struct {
+    void* d_data;     /* device pointer, `len` bytes */
+    size_t len;
+    uint64_t records; /* number of elements (output records) */
+} bsk_out;
+/* copy an operator result to host memory (synchronises) */
+int bsk_out_to_host(bsk_ctx* ctx, const bsk_out* out, void* dst, size_t cap);
+
+/* ---- record table: SeqParser.Read (bigseqkit-lib/helper.go:219-325) --------
+ * Builds, for a device- or host-resident shard, the SoA table of record slices the
+ * per-record operators work on.  Exposed for tests and for callers that want the
+ * offsets (faidx-style); the operators below build it themselves.
+ * starts[i] = offset of the marker byte, head_len[i] = header line length incl.
+ * the marker, seq_len[i] = bases.  Any output pointer may be NULL. */
+int bsk_index_build(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, void* stream,
+                    uint64_t* n_records);
+int bsk_index_copy(bsk_ctx* ctx, uint64_t* starts, uint32_t* head_len, uint32_t* seq_len, uint32_t* aux, size_t cap);
+
+/* ---- SeqTransform (bigseqkit-lib/seq.go:28-269) --------------------------- */
+int bsk_seq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                bsk_out* out);
+
 /* ---- synthetic inputs (bench + tests only) --------
  * Deterministic, counter-based: byte k of record i depends on (seed, i, k)
  * only, so any shard can be produced on the host or directly in HBM. */

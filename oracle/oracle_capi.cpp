@@ -29,6 +29,14 @@ typedef struct {
     int Basename;
 } orc_stats_opts;
 
+typedef struct {
+    orc_kitconfig Config;
+    int Reverse, Complement, Name, Seq, Qual, OnlyId, RemoveGaps;
+    const char* GapLetters;
+    int LowerCase, UpperCase, Dna2rna, Rna2dna, ValidateSeq, ValidateSeqLength, MaxLen, MinLen, QualAsciiBase;
+    double MinQual, MaxQual;
+} orc_seq_opts;
+
 }  // extern "C"
 
 static KitConfig conv(const orc_kitconfig& c) {
@@ -54,6 +62,35 @@ static StatsOptions conv(const orc_stats_opts& c) {
     if (c.FqEncoding) o.FqEncoding = c.FqEncoding;
     o.Basename = c.Basename != 0;
     return o;
+}
+
+static SeqOptions conv(const orc_seq_opts& c) {
+    SeqOptions o;
+    o.Config = conv(c.Config);
+    o.Reverse = c.Reverse; o.Complement = c.Complement; o.Name = c.Name; o.Seq = c.Seq; o.Qual = c.Qual;
+    o.OnlyId = c.OnlyId; o.RemoveGaps = c.RemoveGaps;
+    if (c.GapLetters) o.GapLetters = c.GapLetters;
+    o.LowerCase = c.LowerCase; o.UpperCase = c.UpperCase; o.Dna2rna = c.Dna2rna; o.Rna2dna = c.Rna2dna;
+    o.ValidateSeq = c.ValidateSeq; o.ValidateSeqLength = c.ValidateSeqLength;
+    o.MaxLen = c.MaxLen; o.MinLen = c.MinLen; o.QualAsciiBase = c.QualAsciiBase;
+    o.MinQual = c.MinQual; o.MaxQual = c.MaxQual;
+    return o;
+}
+
+// elements joined the way FileStore writes them (bigseqkit-lib/helper.go:447): e + "\n"
+static int emit(const std::vector<std::string>& els, uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec) {
+    size_t tot = 0;
+    for (auto& e : els) tot += e.size() + 1;
+    *nout = tot;
+    if (nrec) *nrec = els.size();
+    if (tot > cap) return 2;
+    size_t p = 0;
+    for (auto& e : els) {
+        memcpy(out + p, e.data(), e.size());
+        p += e.size();
+        out[p++] = '\n';
+    }
+    return 0;
 }
 
 static int fail(char* err, size_t cap, const std::exception& e) {
@@ -153,6 +190,24 @@ int orc_stats_string_from_map(const int64_t* keys, const int64_t* vals, size_t n
         std::string s = stats_string(info, so);
         snprintf(out, cap, "%s", s.c_str());
         return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+// SeqTransform over nparts partitions (each partition re-decides FASTQ-ness / alphabet from its first record)
+int orc_seq(const uint8_t* buf, size_t n, int fastq, const orc_seq_opts* o, int nparts, uint8_t* out, size_t cap,
+            size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        if (nparts < 1) nparts = 1;
+        std::vector<std::string> all;
+        SeqOptions so = conv(*o);
+        for (int p = 0; p < nparts; ++p) {
+            size_t a = recs.size() * (size_t)p / (size_t)nparts, b = recs.size() * (size_t)(p + 1) / (size_t)nparts;
+            std::vector<std::string_view> part(recs.begin() + a, recs.begin() + b);
+            auto r = seq_call(part, so);
+            all.insert(all.end(), r.begin(), r.end());
+        }
+        return emit(all, out, cap, nout, nrec);
     } catch (const std::exception& e) { return fail(err, errcap, e); }
 }
 

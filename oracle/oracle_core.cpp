@@ -412,6 +412,132 @@ std::map<int64_t, int64_t> stats_reduce(const std::map<int64_t, int64_t>& a, con
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// SeqTransform  bigseqkit-lib/seq.go
+// ---------------------------------------------------------------------------
+// seq.Seq.ComplementInplace [upstream-memory]: PairLetter per byte, letters that
+// are not in the alphabet stay as they are; Unlimit/Protein are identities.
+void complement_inplace(std::string& s, Alphabet a) {
+    const char *from, *to;
+    if (a == AB_DNA || a == AB_DNAredundant) {
+        from = "acgtryswkmbdhvACGTRYSWKMBDHV";
+        to = "tgcayrswmkvhdbTGCAYRSWMKVHDB";
+    } else if (a == AB_RNA || a == AB_RNAredundant) {
+        from = "acguryswkmbdhvACGURYSWKMBDHV";
+        to = "ugcayrswmkvhdbUGCAYRSWMKVHDB";
+    } else {
+        return;
+    }
+    unsigned char lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (unsigned char)i;
+    for (size_t i = 0; from[i]; ++i) lut[(unsigned char)from[i]] = (unsigned char)to[i];
+    for (auto& c : s) c = (char)lut[(unsigned char)c];
+}
+
+// seq.Seq.AvgQual [upstream-memory]: mean error probability, sequential float64 sum
+double avg_qual(const std::string& qual, int base) {
+    if (qual.empty()) return 0;
+    double sum = 0;
+    for (unsigned char q : qual) sum += std::pow(10.0, (double)((int)q - base) / -10.0);
+    return -10.0 * std::log10(sum / (double)qual.size());
+}
+
+std::vector<std::string> seq_call(const std::vector<std::string_view>& part, const SeqOptions& oin) {
+    SeqOptions o = oin;
+    // ---- Before (seq.go:28-79)
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    if (o.GapLetters.empty()) throw Error("value of flag -G (--gap-letters) should not be empty");
+    for (unsigned char c : o.GapLetters)
+        if (c > 127) throw Error("value of -G (--gap-letters) contains non-ASCII characters");
+    if (o.MinLen >= 0 && o.MaxLen >= 0 && o.MinLen > o.MaxLen)
+        throw Error("value of flag -m (--min-len) should be >= value of flag -M (--max-len)");
+    if (o.MinQual >= 0 && o.MaxQual >= 0 && o.MinQual > o.MaxQual)
+        throw Error("value of flag -Q (--min-qual) should be <= value of flag -R (--max-qual)");
+    bool validate = o.ValidateSeq;
+    if (!validate && !(ab == AB_NONE || ab == AB_UNLIMIT)) validate = true;  // seq.go:66-72
+    if (o.LowerCase && o.UpperCase) throw Error("could not give both flags -l (--lower-case) and -u (--upper-case)");
+    // ---- Call (seq.go:81-269)
+    SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    const bool filterMinLen = o.MinLen > 0, filterMaxLen = o.MaxLen > 0;
+    const bool filterMinQual = o.MinQual > 0, filterMaxQual = o.MaxQual > 0;
+    bool isFastq = false, printName, printSeq, printQual = false, checkSeqType = true;
+    int lineWidth = o.Config.LineWidth;
+    if (o.Seq || o.Qual) lineWidth = 0;  // seq.go:106-108
+    bool gapset[256] = {false};
+    for (unsigned char c : o.GapLetters) gapset[c] = true;
+    std::vector<std::string> result;
+    while (rd.Read()) {
+        Record& r = rd.rec;
+        if (validate) {  // SeqParser validates with parser.t (helper.go:304-306,318-320)
+            std::string_view v = r.seq;
+            if (o.ValidateSeqLength > 0 && (int64_t)v.size() > o.ValidateSeqLength) v = v.substr(0, o.ValidateSeqLength);
+            if (!alphabet_is_valid(rd.GetAlphabet(), v)) throw Error("seq: invalid " + std::string(alphabet_name(rd.GetAlphabet())) + " letter");
+        }
+        if (checkSeqType) {
+            isFastq = rd.IsFastq;
+            if (isFastq) { lineWidth = 0; printQual = true; }
+            checkSeqType = false;
+        }
+        if (o.RemoveGaps) {  // Seq.RemoveGapsInplace [upstream-memory]: seq and qual together
+            std::string s2, q2;
+            for (size_t i = 0; i < r.seq.size(); ++i)
+                if (!gapset[(unsigned char)r.seq[i]]) {
+                    s2.push_back(r.seq[i]);
+                    if (i < r.qual.size()) q2.push_back(r.qual[i]);
+                }
+            r.seq.swap(s2);
+            if (!r.qual.empty()) r.qual.swap(q2);
+        }
+        if (filterMinLen && (int64_t)r.seq.size() < o.MinLen) continue;
+        if (filterMaxLen && (int64_t)r.seq.size() > o.MaxLen) continue;
+        if (filterMinQual || filterMaxQual) {
+            double aq = avg_qual(r.qual, o.QualAsciiBase);
+            if (filterMinQual && aq < o.MinQual) continue;
+            if (filterMaxQual && aq >= o.MaxQual) continue;
+        }
+        printName = true; printSeq = true;
+        if (o.Name && o.Seq) { printName = true; printSeq = true; }
+        else if (o.Name) { printName = true; printSeq = false; printQual = false; }
+        else if (o.Seq) { printName = false; printSeq = true; printQual = false; }
+        else if (o.Qual) {
+            if (!isFastq) throw Error("FASTA format has no quality. So do not just use flag -q (--qual)");
+            printName = false; printSeq = false; printQual = true;
+        }
+        std::string out;
+        if (printName) {
+            const std::string& head = o.OnlyId ? r.id : r.name;
+            if (printSeq) out.push_back(isFastq ? '@' : '>');
+            out += head;
+            out.push_back('\n');
+        }
+        if (o.Reverse) {  // ReverseInplace: sequence and quality
+            std::reverse(r.seq.begin(), r.seq.end());
+            std::reverse(r.qual.begin(), r.qual.end());
+        }
+        if (o.Complement) complement_inplace(r.seq, rd.GetAlphabet());
+        if (printSeq) {
+            Alphabet fa = rd.GetAlphabet();
+            if (o.Dna2rna && !(fa == AB_RNA || fa == AB_RNAredundant))
+                for (auto& c : r.seq) { if (c == 't') c = 'u'; else if (c == 'T') c = 'U'; }
+            if (o.Rna2dna && !(fa == AB_DNA || fa == AB_DNAredundant))
+                for (auto& c : r.seq) { if (c == 'u') c = 't'; else if (c == 'U') c = 'T'; }
+            if (o.LowerCase) { for (auto& c : r.seq) if (c >= 'A' && c <= 'Z') c += 32; }
+            else if (o.UpperCase) { for (auto& c : r.seq) if (c >= 'a' && c <= 'z') c -= 32; }
+            if (isFastq) out += r.seq;
+            else out += wrap_byte_slice(r.seq, lineWidth);
+            out.push_back('\n');
+        }
+        if (printQual) {
+            if (!o.Qual) out += "+\n";
+            out += r.qual;
+            out.push_back('\n');
+        }
+        if (!out.empty() && out.back() == '\n') out.pop_back();  // seq.go:261-265
+        result.push_back(out);
+    }
+    return result;
+}
+
 // shenwei356/util/math.Round [upstream-memory]:
 //   pow10_n := math.Pow10(n); return math.Trunc((f+0.5/pow10_n)*pow10_n) / pow10_n
 double go_round(double f, int n) {

@@ -134,6 +134,22 @@ StatInfo stats_finalize(const std::string& name, const std::string& format, std:
 // StatsString  bigseqkit/stats.go:168-288
 std::string stats_string(const StatInfo& info, const StatsOptions& o);
 
+struct SeqOptions {  // bigseqkit/seq.go:9-55
+    KitConfig Config;
+    bool Reverse = false, Complement = false, Name = false, Seq = false, Qual = false, OnlyId = false;
+    bool RemoveGaps = false;
+    std::string GapLetters = "- \t.";
+    bool LowerCase = false, UpperCase = false, Dna2rna = false, Rna2dna = false, ValidateSeq = false;
+    int ValidateSeqLength = 10000, MaxLen = -1, MinLen = -1, QualAsciiBase = 33;
+    double MinQual = -1, MaxQual = -1;
+};
+// SeqTransform.Before + Call  bigseqkit-lib/seq.go:28-269 -> elements (no trailing '\n')
+std::vector<std::string> seq_call(const std::vector<std::string_view>& part, const SeqOptions& o);
+
+// bio seq.Seq helpers [upstream-memory, shenwei356/bio v0.7.0]
+void complement_inplace(std::string& s, Alphabet a);
+double avg_qual(const std::string& qual, int base);
+
 double go_round(double f, int n);          // shenwei356/util/math.Round [upstream-memory]
 std::string humanize_comma(int64_t v);     // go-humanize Comma
 std::string humanize_commaf(double v);     // go-humanize Commaf

@@ -17,6 +17,14 @@ class StatsOpts(C.Structure):
                 ("SkipErr", C.c_int), ("FqEncoding", C.c_char_p), ("Basename", C.c_int)]
 
 
+class SeqOpts(C.Structure):
+    _fields_ = [("Config", KitConfig)] + [(k, C.c_int) for k in
+                ("Reverse", "Complement", "Name", "Seq", "Qual", "OnlyId", "RemoveGaps")] + \
+               [("GapLetters", C.c_char_p)] + [(k, C.c_int) for k in
+                ("LowerCase", "UpperCase", "Dna2rna", "Rna2dna", "ValidateSeq", "ValidateSeqLength", "MaxLen",
+                 "MinLen", "QualAsciiBase")] + [("MinQual", C.c_double), ("MaxQual", C.c_double)]
+
+
 class OracleError(RuntimeError):
     pass
 
@@ -36,6 +44,36 @@ def stats_opts(opts_json):
     g = lambda k, dv: dv if d.get(k) is None else d[k]
     return StatsOpts(_cfg(d), int(g("Tabular", False)), g("GapLetters", "- .").encode(), int(g("All", False)),
                      int(g("SkipErr", False)), g("FqEncoding", "sanger").encode(), int(g("Basename", False)))
+
+
+def seq_opts(opts_json):
+    """defaults per /root/reference/bigseqkit/seq.go:32-55"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    b = lambda k: int(bool(g(k, False)))
+    return SeqOpts(_cfg(d), b("Reverse"), b("Complement"), b("Name"), b("Seq"), b("Qual"), b("OnlyId"),
+                   b("RemoveGaps"), g("GapLetters", "- \t.").encode(), b("LowerCase"), b("UpperCase"), b("Dna2rna"),
+                   b("Rna2dna"), b("ValidateSeq"), g("ValidateSeqLength", 10000), g("MaxLen", -1), g("MinLen", -1),
+                   g("QualAsciiBase", 33), float(g("MinQual", -1)), float(g("MaxQual", -1)))
+
+
+def _run_text(fn, data, fastq, o, nparts):
+    cap = 4 * len(data) + 4096
+    while True:
+        out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = fn(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), nparts, out, C.c_size_t(cap), C.byref(n),
+                C.byref(nrec), err, _ERR)
+        if rc == 2:
+            cap = n.value + 16
+            continue
+        if rc:
+            raise OracleError(err.value.decode())
+        return out.raw[:n.value], nrec.value
+
+
+def seq(data, fastq, opts_json="{}", nparts=1):
+    """SeqTransform -> the bytes FileStore would write (each element + newline)."""
+    return _run_text(_lib.orc_seq, data, fastq, seq_opts(opts_json), nparts)[0]
 
 
 def _buf(data):
