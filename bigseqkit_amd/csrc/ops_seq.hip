@@ -69,7 +69,9 @@ __device__ __forceinline__ RecView view(const uint8_t* buf, const RecordTable& t
     } else {
         r.region = t.aux[i];
         r.qual = nullptr;
-        r.contiguous = r.region <= r.seq_len + 1;  // no interior newline
+        // contiguous iff the region holds no newline except an optional final one
+        const uint32_t tail_nl = (r.region > 0 && r.seq[r.region - 1] == '\n') ? 1u : 0u;
+        r.contiguous = r.region == r.seq_len + tail_nl;
     }
     return r;
 }

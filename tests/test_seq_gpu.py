@@ -40,6 +40,12 @@ def check_index(data, fastq):
             assert sl == len(lines[1]) and ax == len(lines[2])
         else:
             assert sl == sum(len(x) for x in lines[1:])
+            body = s0 + len(lines[0]) + 1
+            end = min(len(data), s0 + ln + 1)  # the element has lost its final newline
+            region = data[body:end]
+            if region.endswith(b"\n"):          # blank lines at EOF are not part of the shard
+                region = region.rstrip(b"\n") + b"\n"
+            assert ax == len(region), (s0, ln, ax, len(region))
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -56,6 +62,14 @@ def test_record_table_fasta(seed, monkeypatch):
     rng = random.Random(50 + seed)
     check_index(seqgen.random_fasta(rng, 1200, 0, [100, 1500, 9000][seed % 3], width=[60, 70, 0, 13][seed % 4],
                                     final_newline=seed % 2 == 0, trailing_blank=seed % 3, gt_in_header=True), False)
+
+
+def test_record_table_fasta_regression(monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "2048")
+    rng = random.Random(2001)
+    data = seqgen.random_fasta(rng, 300, 0, 1200, width=60, final_newline=False, alphabet="ACGTNacgtu",
+                               gt_in_header=True)
+    check_index(data, False)
 
 
 def check_seq(data, fastq, opts, on_device=True):
