@@ -86,6 +86,9 @@ SIGNATURES = {
     "bsk_index_build": (_i, [_vp, _vp, _sz, _i, _i, _vp, _p(_u64)]),
     "bsk_index_copy": (_i, [_vp, _p(_u64), _p(C.c_uint32), _p(C.c_uint32), _p(C.c_uint32), _sz]),
     "bsk_seq_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
+    "bsk_grep_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
+    "bsk_grep_last_count": (_i, [_vp, _p(_u64)]),
+    "bsk_subseq_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),
     "bsk_synth_device": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz, _i, _vp]),

@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions
 
 
 class SeqFrame:
@@ -184,6 +184,31 @@ def _run_records(op_name, run_fn, input, o, device=0, stream=None):
 def Seq(input, o=None, device=0):
     """bigseqkit/seq.go:157-170 -- returns the bytes StoreFASTX would write"""
     return _run_records("SeqTransform", lib.bsk_seq_run, input, o or SeqKitSeqOptions(), device)[0]
+
+
+def Grep(input, o, device=0):
+    """bigseqkit/grep.go:130-159 (Count forced off, :136-137)"""
+    o._v["Count"] = False
+    return _run_records("Grep", lib.bsk_grep_run, input, o, device)[0]
+
+
+def GrepCount(input, o, device=0):
+    """bigseqkit/grep.go:161-180: per-partition counts summed (GrepReduceCount)"""
+    o._v["Count"] = True
+    total = 0
+    with Operator("Grep", o.to_json(), device) as op:
+        for pid, ptr, n, on_dev, keep in input.partitions():
+            out = _lib.Out()
+            check(lib.bsk_grep_run(op.ctx, ptr, n, 1 if on_dev else 0, input.format, pid, None, C.byref(out)), op.ctx)
+            cnt = C.c_uint64()
+            check(lib.bsk_grep_last_count(op.ctx, C.byref(cnt)), op.ctx)
+            total += cnt.value
+    return total
+
+
+def Subseq(input, o, device=0):
+    """bigseqkit/subseq.go:86-100"""
+    return _run_records("SubseqTransform", lib.bsk_subseq_run, input, o, device)[0]
 
 
 def build_index(input, device=0):

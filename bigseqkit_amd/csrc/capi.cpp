@@ -173,6 +173,8 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
         switch (op) {
             case Op::Stats: validate_stats(c); break;
             case Op::Seq: validate_seq_opts(c); break;
+            case Op::Grep: validate_grep_opts(c); break;
+            case Op::Subseq: validate_subseq_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
     } catch (const std::exception& e) {
@@ -202,6 +204,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_vec) hipFree(c->d_vec);
         if (c->d_status) hipFree(c->d_status);
         if (c->d_overflow) hipFree(c->d_overflow);
+        if (c->d_pat) hipFree(c->d_pat);
+        if (c->d_pat_off) hipFree(c->d_pat_off);
         for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux,
                         (void*)c->d_range_count, (void*)c->d_range_base, (void*)c->d_out_len, (void*)c->d_out_off,
                         (void*)c->d_scan_tmp, (void*)c->d_out, (void*)c->d_lut, (void*)c->d_qual_err,
@@ -541,6 +545,39 @@ int bsk_seq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int form
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
     return seq_run_device(c, d, n, format, st, out);
+}
+
+typedef int (*run_fn)(bsk_ctx*, const uint8_t*, size_t, int, hipStream_t, bsk_out*);
+static int run_record_op(bsk_ctx* c, Op want, const char* what, run_fn fn, const void* shard, size_t n, int on_device,
+                         int format, void* stream, bsk_out* out) {
+    int rc = check_run_args(c, shard, n, format);
+    if (rc != BSK_OK) return rc;
+    if (c->op != want || !out) return fail(c, BSK_ERR_INVALID_ARG, std::string("libbsk: not a ") + what + " context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    const uint8_t* d = nullptr;
+    rc = stage_shard(c, shard, n, on_device, st, &d);
+    if (rc != BSK_OK) return rc;
+    return fn(c, d, n, format, st, out);
+}
+
+int bsk_grep_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                 bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::Grep, "Grep", grep_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_grep_last_count(const bsk_ctx* c, uint64_t* count) {
+    if (!c || !count) return BSK_ERR_INVALID_ARG;
+    *count = c->last_count;
+    return BSK_OK;
+}
+
+int bsk_subseq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                   bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::Subseq, "SubseqTransform", subseq_run_device, shard, n, on_device, format, stream, out);
 }
 
 // ---------------------------------------------------------------------------

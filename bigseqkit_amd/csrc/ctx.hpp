@@ -55,6 +55,14 @@ struct bsk_ctx {
     uint8_t* d_lut = nullptr;           // 256-byte byte map (seq)
     double* d_qual_err = nullptr;       // 256 doubles (seq -Q/-R)
     uint64_t* d_counter = nullptr;      // scratch counter
+    // grep / locate: patterns after Before() (CLI order, duplicates removed, lower-cased with -i)
+    std::vector<std::string> patterns;
+    uint8_t* d_pat = nullptr;
+    uint32_t* d_pat_off = nullptr;
+    uint64_t pat_cap = 0, pat_off_cap = 0;
+    int region_start = 0, region_end = 0;  // parsed -R / -r
+    bool region_on = false;
+    uint64_t last_count = 0;               // grep -C result of the last run
 
     // ---- staging for host-resident shards ------------------------------------
     uint8_t* pinned[2] = {nullptr, nullptr};

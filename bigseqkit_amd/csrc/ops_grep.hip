@@ -1,0 +1,243 @@
+// ============================================================================
+// ops_grep.hip -- Grep.grepGeneral (/root/reference/bigseqkit-lib/grep.go:367-542)
+// for exact patterns, on the record table.
+//   by sequence (-s): 16 lanes per record test the start positions in parallel;
+//     the '-' strand is searched as reverse-complemented PATTERNS on the forward
+//     text (RevCom is an involution on bytes, so  P in RevCom(S)  <=>  RevCom(P) in S),
+//     which halves the traffic of the reference's RevCom(seq) copy (grep.go:445-448).
+//     Regions (-R) and --circular are index maps on the same text.
+//   by ID / name: one thread per record, exact comparison against the pattern set.
+// Output of the kernel: bytes the record contributes (0 = not selected); the record
+// itself is emitted by k_seq_emit after the scan.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ops_grep.hpp"
+#include "ops_seq.hpp"
+
+namespace bsk {
+
+namespace {
+
+constexpr int GROUP = 16;
+
+__device__ __forceinline__ uint8_t lower8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
+
+// Sequence text of a record as a random-access array of bases.
+struct Text {
+    const uint8_t* p;
+    uint32_t L;      // bases
+    uint32_t W;      // FASTA: line width of a uniformly wrapped region, 0 = contiguous
+    __device__ __forceinline__ uint8_t at(uint32_t i) const { return W ? p[i + i / W] : p[i]; }
+};
+
+// formatted length of the whole record, fastx.Record.Format(width)
+__device__ __forceinline__ uint32_t format_len(uint32_t name_len, uint32_t L, int fastq, int width) {
+    uint32_t w = L;
+    if (width > 0 && L > 0) w += (L - 1) / (uint32_t)width;
+    uint32_t n = 1 + name_len + 1 + w + 1;
+    if (fastq) n += 2 + w + 1;
+    return n;
+}
+
+__device__ uint32_t id_span2(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off) {
+    *id_off = 0;
+    if (id_mode == 0) {
+        for (uint32_t i = 0; i < n; ++i)
+            if (h[i] == ' ') { if (i > 0) return i; break; }
+        for (uint32_t i = 0; i < n; ++i)
+            if (h[i] == '\t') { if (i > 0) return i; break; }
+        return n;
+    }
+    uint32_t a = 0;
+    while (a < n && h[a] != '|') ++a;
+    while (a < n) {
+        uint32_t b = a + 1;
+        while (b < n && h[b] != '|') ++b;
+        if (b >= n) break;
+        if (b > a + 1 && b + 1 < n && h[b + 1] == ' ') { *id_off = a + 1; return b - a - 1; }
+        a = b;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ buf, RecordTable t, GrepParams P,
+                                                  uint32_t* __restrict__ out_len) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;  // position of this group inside the wave
+    const bool live = g < t.n;
+    const uint64_t gi = live ? g : 0;
+    const uint64_t s = t.start[gi];
+    const uint32_t lh = t.l_head[gi];
+    const uint32_t L = live ? t.l_seq[gi] : 0;
+    Text T;
+    T.p = buf + s + lh + 1;
+    T.L = L;
+    T.W = 0;
+    bool sequential = false;
+    if (!P.fastq && live) {
+        // multi-line FASTA: usable as an array iff every line but the last has the same width
+        const uint32_t region = t.aux[gi];
+        const uint32_t tail_nl = (region > 0 && T.p[region - 1] == '\n') ? 1u : 0u;
+        const uint32_t nnl = region - L;  // newlines in the region
+        if (nnl > tail_nl) {
+            uint32_t W = 0;
+            while (W < region && T.p[W] != '\n') ++W;  // first line
+            const uint32_t lines = W ? (L + W - 1) / W : 0;
+            bool ok = W > 0 && nnl == lines - 1 + tail_nl;
+            if (ok)
+                for (uint32_t k = gl; k + 1 < lines; k += GROUP)
+                    if (T.p[(uint64_t)k * (W + 1) + W] != '\n') ok = false;
+            const uint64_t bad = __ballot(!ok);
+            if ((bad >> gshift) & 0xFFFFull) sequential = true;
+            else T.W = W;
+        }
+    }
+    bool hit = false;
+    const int nstr = P.both_strands ? 2 : 1;
+    if (live && !sequential) {
+        for (int strand = 0; strand < nstr && !hit; ++strand) {
+            // window of the forward text that the strand's target covers
+            uint32_t wb = 0, we = L;
+            if (P.region_on) {
+                uint32_t b, e;
+                sub_location(L, P.region_start, P.region_end, &b, &e);
+                if (strand == 0) { wb = b; we = e; }
+                else { wb = L - e; we = L - b; }  // SubSeq of RevCom(S) mirrored onto S
+            }
+            const uint32_t wl = we - wb;
+            const uint32_t tl = P.circular ? 2 * wl : wl;  // --circular doubles the target (grep.go:449-454)
+            for (int k = 0; k < P.npat && !hit; ++k) {
+                const int pk = strand * P.npat + k;
+                const uint8_t* pp = P.pat + P.pat_off[pk];
+                const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
+                if (m == 0) { hit = true; break; }  // bytes.Contains(x, "") is true
+                if (m > tl) continue;
+                const uint32_t npos = tl - m + 1;
+                const uint8_t p0 = pp[0];
+                for (uint32_t i0 = 0; i0 < npos; i0 += GROUP) {
+                    const uint32_t i = i0 + gl;
+                    bool ok = false;
+                    if (i < npos) {
+                        uint32_t j = i >= wl ? i - wl : i;  // circular wrap
+                        uint8_t c = T.at(wb + j);
+                        if (P.ignore_case) c = lower8(c);
+                        if (c == p0) {
+                            ok = true;
+                            for (uint32_t q = 1; q < m; ++q) {
+                                uint32_t jj = i + q;
+                                if (jj >= wl) jj -= wl;  // only reachable when circular (jj < 2 wl)
+                                uint8_t cc = T.at(wb + jj);
+                                if (P.ignore_case) cc = lower8(cc);
+                                if (cc != pp[q]) { ok = false; break; }
+                            }
+                        }
+                    }
+                    const uint64_t any = __ballot(ok);
+                    if ((any >> gshift) & 0xFFFFull) { hit = true; break; }
+                }
+            }
+        }
+    } else if (live && gl == 0) {
+        // irregularly wrapped FASTA: one lane walks the region, newlines skipped
+        const uint32_t region = t.aux[gi];
+        for (int strand = 0; strand < nstr && !hit; ++strand) {
+            uint32_t wb = 0, we = L;
+            if (P.region_on) {
+                uint32_t b, e;
+                sub_location(L, P.region_start, P.region_end, &b, &e);
+                if (strand == 0) { wb = b; we = e; }
+                else { wb = L - e; we = L - b; }
+            }
+            const uint32_t wl = we - wb, tl = P.circular ? 2 * wl : wl;
+            for (int k = 0; k < P.npat && !hit; ++k) {
+                const int pk = strand * P.npat + k;
+                const uint8_t* pp = P.pat + P.pat_off[pk];
+                const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
+                if (m == 0) { hit = true; break; }
+                if (m > tl) continue;
+                // raw offset of base wb (newlines skipped)
+                uint32_t raw0 = 0, bi = 0;
+                for (;;) {
+                    while (raw0 < region && T.p[raw0] == '\n') ++raw0;
+                    if (bi == wb) break;
+                    ++raw0;
+                    ++bi;
+                }
+                uint32_t r = raw0;  // raw offset of window base (i mod wl)
+                for (uint32_t i = 0; i + m <= tl && !hit; ++i) {
+                    if (i == wl) r = raw0;  // second copy of a circular target
+                    uint32_t cur = r, pos = i >= wl ? i - wl : i;
+                    bool ok = true;
+                    for (uint32_t q = 0; q < m; ++q) {
+                        if (pos == wl) { pos = 0; cur = raw0; }  // wrap (circular only)
+                        while (T.p[cur] == '\n') ++cur;
+                        uint8_t c = T.p[cur];
+                        if (P.ignore_case) c = lower8(c);
+                        if (c != pp[q]) { ok = false; break; }
+                        ++cur;
+                        ++pos;
+                    }
+                    if (ok) hit = true;
+                    ++r;
+                    while (r < region && T.p[r] == '\n') ++r;
+                }
+            }
+        }
+    }
+    if (sequential) {
+        const uint64_t any = __ballot(hit);
+        hit = ((any >> gshift) & 0xFFFFull) != 0;
+    }
+    if (live && gl == 0) {
+        const bool sel = P.invert ? !hit : hit;
+        out_len[g] = sel ? format_len(lh > 0 ? lh - 1 : 0, L, P.fastq, P.line_width) : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ buf, RecordTable t, GrepParams P,
+                                                   uint32_t* __restrict__ out_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint64_t s = t.start[i];
+    const uint32_t lh = t.l_head[i];
+    const uint8_t* h = buf + s + 1;
+    uint32_t hl = lh > 0 ? lh - 1 : 0, off = 0;
+    uint32_t tl = hl;
+    if (!P.by_name) tl = id_span2(h, hl, P.id_mode, &off);
+    bool hit = false;
+    for (int k = 0; k < P.npat && !hit; ++k) {
+        const uint8_t* pp = P.pat + P.pat_off[k];
+        const uint32_t m = P.pat_off[k + 1] - P.pat_off[k];
+        if (m != tl) continue;
+        bool ok = true;
+        for (uint32_t q = 0; q < m; ++q) {
+            uint8_t c = h[off + q];
+            if (P.ignore_case) c = lower8(c);
+            if (c != pp[q]) { ok = false; break; }
+        }
+        hit = ok;
+    }
+    const bool sel = P.invert ? !hit : hit;
+    out_len[i] = sel ? format_len(hl, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
+}  // namespace
+
+hipError_t launch_grep_match(const uint8_t* buf, const RecordTable& t, const GrepParams& P, uint32_t* out_len,
+                             hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    if (P.by_seq) {
+        const uint64_t blocks = (t.n * GROUP + 255) / 256;
+        hipLaunchKernelGGL(k_grep_seq, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len);
+    } else {
+        const uint64_t blocks = (t.n + 255) / 256;
+        hipLaunchKernelGGL(k_grep_name, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace bsk

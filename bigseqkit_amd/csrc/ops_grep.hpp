@@ -1,0 +1,26 @@
+// `grep` on the record table: match kernel -> sizes -> scan -> k_seq_emit (full record).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+
+namespace bsk {
+
+struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-253), exact patterns
+    int fastq;
+    int by_seq, by_name, invert, ignore_case, circular;
+    int region_on, region_start, region_end;
+    int both_strands;        // search the reverse complement too (grep.go:432-448)
+    int id_mode;             // 0 default ID regexp, 1 --id-ncbi
+    int line_width;          // of the emitted record (0 for FASTQ)
+    int npat;                // patterns; with both_strands the reverse-complemented copies follow
+    const uint8_t* pat;      // concatenated pattern bytes (already lower-cased when ignore_case)
+    const uint32_t* pat_off; // [npat_total + 1]
+};
+
+hipError_t launch_grep_match(const uint8_t* buf, const RecordTable& t, const GrepParams& P, uint32_t* out_len,
+                             hipStream_t st);
+
+}  // namespace bsk

@@ -3,12 +3,15 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/bsk.h"
 #include "ctx.hpp"
 #include "ops_host.hpp"
+#include "ops_grep.hpp"
 #include "ops_seq.hpp"
 #include "stream_stats.hpp"
 
@@ -216,6 +219,267 @@ int ensure_record_scratch(bsk_ctx* c) {
     rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, need, 16);
     if (rc != BSK_OK) return rc;
     if (!c->d_counter) HIP_TRYX(c, hipMalloc((void**)&c->d_counter, 4 * sizeof(uint64_t)));
+    return BSK_OK;
+}
+
+// size array -> scan -> total / kept / kernel status; then the caller emits
+static int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
+    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(total, c->d_out_off + c->table.n, sizeof *total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(kept, c->d_counter, sizeof *kept, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    return kernel_error_to_status(c, status);
+}
+
+static int empty_result(bsk_ctx* c, bsk_out* out) {
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+    return kernel_error_to_status(c, status);
+}
+
+// SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
+static SeqParams format_params(bsk_ctx* c, bool fastq) {
+    SeqParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.print_name = 1;
+    P.print_seq = 1;
+    P.print_qual = fastq;
+    P.line_width = fastq ? 0 : (int)c->opts.ci("LineWidth");
+    P.id_mode = c->opts.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    return P;
+}
+
+static void parse_region_opt(const std::string& region, const char* cmd, int* start, int* end) {
+    // reRegion `\-?\d+:\-?\d+` (bigseqkit-lib/helper.go:20) + grep.go:103-118 / subseq.go:83-97
+    bool ok = false;
+    for (size_t i = 0; i < region.size() && !ok; ++i) {
+        size_t p = i;
+        if (region[p] == '-') ++p;
+        size_t d0 = p;
+        while (p < region.size() && isdigit((unsigned char)region[p])) ++p;
+        if (p == d0 || p >= region.size() || region[p] != ':') continue;
+        ++p;
+        if (p < region.size() && region[p] == '-') ++p;
+        size_t d1 = p;
+        while (p < region.size() && isdigit((unsigned char)region[p])) ++p;
+        if (p > d1) ok = true;
+    }
+    if (!ok) throw OptError("invalid region: " + region + ". type \"seqkit " + cmd + " -h\" for more examples");
+    const size_t c = region.find(':');
+    const std::string a = region.substr(0, c), b = region.substr(c + 1);
+    char* endp = nullptr;
+    const long sa = strtol(a.c_str(), &endp, 10);
+    if (a.empty() || *endp) throw OptError("strconv.Atoi: parsing \"" + a + "\": invalid syntax");
+    const long sb = strtol(b.c_str(), &endp, 10);
+    if (b.empty() || *endp) throw OptError("strconv.Atoi: parsing \"" + b + "\": invalid syntax");
+    if (sa == 0 || sb == 0) throw OptError("both start and end should not be 0");
+    if (sa < 0 && sb > 0) throw OptError("when start < 0, end should not > 0");
+    *start = (int)sa;
+    *end = (int)sb;
+}
+
+static void check_id_regexp(const Options& o) {
+    const std::string& re = o.cs("IDRegexp");
+    if (!(re.empty() || re == "^(\\S+)\\s?" || re == "\\|([^\\|]+)\\| "))
+        throw OptError("libbsk: --id-regexp other than the default and the --id-ncbi one is not supported by the HIP path");
+}
+
+// ---------------------------------------------------------------------------
+// grep  (Grep.Before, bigseqkit-lib/grep.go:41-253)
+// ---------------------------------------------------------------------------
+void validate_grep_opts(bsk_ctx* c) {
+    Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    bool any = !o.s("PatternFile").empty();
+    for (auto& p : o.sl("Pattern")) if (!p.empty()) any = true;
+    // PARITY.md Q17: the default Pattern [""] must not defeat this guard (grep.go:53)
+    if (!any) throw OptError("one of flags -p (--pattern) and -f (--pattern-file) needed");
+    if (o.b("Degenerate")) o.mut("BySeq").b = true;
+    if (o.i("MaxMismatch") > 0) {
+        if (o.b("UseRegexp") || o.b("Degenerate"))
+            throw OptError("flag -r (--use-regexp) or -d (--degenerate) not allowed when giving flag -m (--max-mismatch)");
+        o.mut("BySeq").b = true;
+    }
+    if (o.b("UseRegexp") && o.b("Degenerate"))
+        throw OptError("could not give both flags -d (--degenerate) and -r (--use-regexp)");
+    c->region_on = false;
+    if (!o.s("Region").empty()) {
+        c->region_on = true;
+        o.mut("BySeq").b = true;
+        parse_region_opt(o.s("Region"), "grep", &c->region_start, &c->region_end);
+    }
+    if (o.b("UseRegexp") || o.b("Degenerate") || o.i("MaxMismatch") > 0 || o.b("DeleteMatched") ||
+        !o.s("PatternFile").empty())
+        throw OptError("libbsk: regexp (-r), degenerate (-d), mismatch (-m), --delete-matched and pattern files (-f) "
+                       "are not supported by the HIP path yet");
+    c->patterns.clear();
+    for (std::string p : o.sl("Pattern")) {
+        if (p.empty()) continue;
+        if (o.b("BySeq")) {
+            const uint8_t* b = (const uint8_t*)p.data();
+            if (!(alphabet_valid_letters(AB_DNAredundant, b, p.size()) || alphabet_valid_letters(AB_RNAredundant, b, p.size()) ||
+                  alphabet_valid_letters(AB_PROTEIN, b, p.size())))
+                throw OptError("illegal DNA/RNA/Protein sequence: " + p);
+        }
+        if (o.b("IgnoreCase"))
+            for (auto& ch : p) if (ch >= 'A' && ch <= 'Z') ch += 32;
+        if (std::find(c->patterns.begin(), c->patterns.end(), p) == c->patterns.end()) c->patterns.push_back(p);
+    }
+}
+
+static std::string revcom_pattern(const std::string& p, Alphabet ab) {
+    uint8_t m[256];
+    for (int i = 0; i < 256; ++i) m[i] = (uint8_t)i;
+    const char *from = nullptr, *to = nullptr;
+    if (ab == AB_DNA || ab == AB_DNAredundant) { from = "acgtryswkmbdhvACGTRYSWKMBDHV"; to = "tgcayrswmkvhdbTGCAYRSWMKVHDB"; }
+    else if (ab == AB_RNA || ab == AB_RNAredundant) { from = "acguryswkmbdhvACGURYSWKMBDHV"; to = "ugcayrswmkvhdbUGCAYRSWMKVHDB"; }
+    if (from) for (size_t k = 0; from[k]; ++k) m[(uint8_t)from[k]] = (uint8_t)to[k];
+    std::string r(p.rbegin(), p.rend());
+    for (auto& ch : r) ch = (char)m[(uint8_t)ch];
+    return r;
+}
+
+static int upload_patterns(bsk_ctx* c, const std::vector<std::string>& all, hipStream_t st) {
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off{0};
+    for (auto& p : all) {
+        bytes.insert(bytes.end(), p.begin(), p.end());
+        off.push_back((uint32_t)bytes.size());
+    }
+    int rc = grow(c, &c->d_pat, &c->pat_cap, bytes.size() + 16);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_pat_off, &c->pat_off_cap, off.size());
+    if (rc != BSK_OK) return rc;
+    if (!bytes.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_pat, bytes.data(), bytes.size(), hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipMemcpyAsync(c->d_pat_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    return BSK_OK;
+}
+
+int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    c->last_count = 0;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    uint64_t total = 0, kept = 0;
+    if (c->table.n > 0) {
+        Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+        if (rc != BSK_OK) return rc;
+        if (ab == AB_NONE) ab = AB_UNLIMIT;
+        GrepParams G;
+        memset(&G, 0, sizeof G);
+        G.fastq = fastq;
+        G.by_seq = o.b("BySeq");
+        G.by_name = o.b("ByName");
+        G.invert = o.b("InvertMatch");
+        G.ignore_case = o.b("IgnoreCase");
+        G.circular = o.b("Circular") && !c->region_on;  // the region branch wins (grep.go:447-456)
+        G.region_on = c->region_on;
+        G.region_start = c->region_start;
+        G.region_end = c->region_end;
+        // grep.go:404-409: protein / unlimit sequences are searched on the '+' strand only
+        const bool only_pos = o.b("OnlyPositiveStrand") || ab == AB_UNLIMIT || ab == AB_PROTEIN;
+        G.both_strands = G.by_seq && !only_pos;
+        G.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+        G.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+        G.npat = (int)c->patterns.size();
+        std::vector<std::string> all = c->patterns;
+        if (G.both_strands)
+            for (auto& p : c->patterns) all.push_back(revcom_pattern(p, ab));
+        rc = upload_patterns(c, all, st);
+        if (rc != BSK_OK) return rc;
+        G.pat = c->d_pat;
+        G.pat_off = c->d_pat_off;
+        rc = ensure_record_scratch(c);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_grep_match(d_buf, c->table, G, c->d_out_len, st));
+        rc = finish_sizes(c, st, &total, &kept);
+        if (rc != BSK_OK) return rc;
+    } else {
+        rc = empty_result(c, out);
+        if (rc != BSK_OK) return rc;
+    }
+    c->last_count = kept;
+    if (o.b("Count")) {  // grep.go:526-540: one element holding the decimal count
+        const std::string txt = std::to_string(kept) + "\n";
+        rc = ensure_out(c, txt.size());
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, hipMemcpy(c->d_out, txt.data(), txt.size(), hipMemcpyHostToDevice));
+        out->d_data = c->d_out;
+        out->len = txt.size();
+        out->records = 1;
+        return BSK_OK;
+    }
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    if (total == 0) return BSK_OK;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    const SeqParams P = format_params(c, fastq);
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// subseq by region  (SubseqTransform, bigseqkit-lib/subseq.go:36-165, 314-317)
+// ---------------------------------------------------------------------------
+void validate_subseq_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    if (o.b("OnlyFlank")) {
+        if (o.i("UpStream") > 0 && o.i("DownStream") > 0)
+            throw OptError("when flag -f (--only-flank) given, only one of flags -u (--up-stream) and -d (--down-stream) is allowed");
+        else if (o.i("UpStream") == 0 && o.i("DownStream") == 0)
+            throw OptError("when flag -f (--only-flank) given, one of flags -u (--up-stream) and -d (--down-stream) should be given");
+    }
+    if (!o.s("Region").empty()) {
+        if (o.i("UpStream") > 0 || o.i("DownStream") > 0 || o.b("OnlyFlank"))
+            throw OptError("when flag -r (--region) given, any of flags -u (--up-stream), -d (--down-stream) and -f (--only-flank) is not allowed");
+        c->region_on = true;
+        parse_region_opt(o.s("Region"), "subseq", &c->region_start, &c->region_end);
+    } else if (!o.s("Gtf").empty() || !o.s("Bed").empty()) {
+        throw OptError("libbsk: subseq --gtf / --bed are not supported by the HIP path yet");
+    } else {
+        throw OptError("one of the options needed: -r/--region, --bed, --gtf");
+    }
+}
+
+int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    SeqParams P = format_params(c, fastq);
+    P.region_on = 1;
+    P.region_start = c->region_start;
+    P.region_end = c->region_end;
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
     return BSK_OK;
 }
 

@@ -9,6 +9,10 @@ int kernel_error_to_status(bsk_ctx* c, uint64_t flags);
 int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st);
 void validate_seq_opts(bsk_ctx* c);
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
+void validate_grep_opts(bsk_ctx* c);
+int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
+void validate_subseq_opts(bsk_ctx* c);
+int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 int ensure_out(bsk_ctx* c, uint64_t bytes);
 int ensure_record_scratch(bsk_ctx* c);
 Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc);

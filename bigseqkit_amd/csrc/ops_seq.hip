@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
             if (!in_set(P.gap_set, c)) ++kept;
         }
     }
+    if (P.region_on) {
+        uint32_t b, e;
+        sub_location(L, P.region_start, P.region_end, &b, &e);
+        kept = e - b;
+    }
     bool keep = true;
     if (P.min_len > 0 && (int64_t)kept < P.min_len) keep = false;
     if (P.max_len > 0 && (int64_t)kept > P.max_len) keep = false;
@@ -152,9 +157,13 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     uint32_t hl = r.head_len, hoff = 0;
     if (P.print_name && P.only_id) hl = id_span(r.head, r.head_len, P.id_mode, &hoff);
     const uint32_t a = P.print_name ? (P.print_seq ? 1u : 0u) + hl + 1u : 0u;
+    uint32_t sub_b = 0, sub_e = r.seq_len;
+    if (P.region_on) sub_location(r.seq_len, P.region_start, P.region_end, &sub_b, &sub_e);
     const bool fast = r.contiguous && !P.remove_gaps;
     if (fast) {
-        const uint32_t L = r.seq_len;
+        const uint32_t L = sub_e - sub_b;
+        const uint8_t* rseq = r.seq + sub_b;
+        const uint8_t* rqual = r.qual ? r.qual + sub_b : nullptr;
         const uint32_t W = wrapped_len(L, P.line_width);
         const uint32_t b = P.print_seq ? W + 1u : 0u;
         const uint32_t w1 = (uint32_t)(P.line_width > 0 ? P.line_width + 1 : 0);
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                     }
                     if (nl) c = '\n';
                     else {
-                        c = r.seq[P.reverse ? L - 1 - q : q];
+                        c = rseq[P.reverse ? L - 1 - q : q];
                         if (P.use_lut) c = P.lut[c];
                     }
                 }
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                     if (q == 1) { o[x] = '\n'; continue; }
                     q -= 2;
                 }
-                c = q == L ? (uint8_t)'\n' : r.qual[P.reverse ? L - 1 - q : q];
+                c = q == L ? (uint8_t)'\n' : rqual[P.reverse ? L - 1 - q : q];
             }
             o[x] = c;
         }
@@ -204,11 +213,14 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     }
     const uint32_t R = r.region;
     if (P.print_seq) {
-        uint32_t col = 0;
+        uint32_t col = 0, base_i = 0;
         bool first = true;
         for (uint32_t k = 0; k < R; ++k) {
             const uint8_t c0 = r.seq[P.reverse ? R - 1 - k : k];
             if (c0 == '\n' && !P.fastq) continue;
+            const uint32_t bi = P.reverse ? r.seq_len - 1 - base_i : base_i;  // index in the forward sequence
+            ++base_i;
+            if (bi < sub_b || bi >= sub_e) continue;
             if (P.remove_gaps && in_set(P.gap_set, c0)) continue;
             if (P.line_width > 0 && !first && col == (uint32_t)P.line_width) { o[x++] = '\n'; col = 0; }
             o[x++] = P.use_lut ? P.lut[c0] : c0;
@@ -222,6 +234,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         const uint32_t L = r.seq_len;
         for (uint32_t k = 0; k < L; ++k) {
             const uint32_t j = P.reverse ? L - 1 - k : k;
+            if (j < sub_b || j >= sub_e) continue;
             if (P.remove_gaps && in_set(P.gap_set, r.seq[j])) continue;
             o[x++] = r.qual[j];
         }

@@ -25,11 +25,31 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     int validate;                           // SeqParser validation (helper.go:304-306)
     int validate_len;
     uint32_t valid_set[8];
+    int region_on, region_start, region_end; // Seq.SubSeq(start, end) applied to seq and qual (subseq -r)
     const uint8_t* lut;                     // device, 256 bytes
     const double* qual_err;                 // device, 256 doubles: 10^(-(q-base)/10) indexed by the raw byte
 };
 
 constexpr uint32_t ERR_INVALID_LETTER = 128u;
+
+// Seq.SubSeq / SubLocation (shenwei356/bio, not in tree; pinned by the region table at
+// /root/reference/bigseqkit-cli/helper.go:348-361): 1-based inclusive, negative = from the end.
+// Returns the 0-based half-open [b, e); b == e when empty.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void sub_location(uint32_t length, int start, int end, uint32_t* b, uint32_t* e) {
+    *b = *e = 0;
+    if (length == 0) return;
+    long long L = (long long)length, s = start, t = end;
+    if (s < 0) { s = L + s + 1; if (s < 1) s = 1; }
+    if (s == 0) s = 1;
+    if (t < 0) t = L + t + 1;
+    if (t > L) t = L;
+    if (s > L || t < 1 || s > t) return;
+    *b = (uint32_t)(s - 1);
+    *e = (uint32_t)t;
+}
 
 hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqParams& P, uint32_t* out_len,
                            uint64_t* status, hipStream_t st);

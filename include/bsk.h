@@ -148,6 +148,19 @@ int bsk_index_copy(bsk_ctx* ctx, uint64_t* starts, uint32_t* head_len, uint32_t*
 int bsk_seq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                 bsk_out* out);
 
+/* ---- Grep (bigseqkit-lib/grep.go:24-549; exact patterns: by ID, by name -n, by
+ * sequence -s on both strands, -i, -v, -R region, --circular, -C count).
+ * With Count set the single element is the decimal count (GrepReduceCount sums
+ * them across partitions, grep.go:598-611); bsk_grep_last_count returns it as a
+ * number for a 1-word all-reduce. */
+int bsk_grep_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                 bsk_out* out);
+int bsk_grep_last_count(const bsk_ctx* ctx, uint64_t* count);
+
+/* ---- SubseqTransform by region (bigseqkit-lib/subseq.go:22-225, 314-317) -- */
+int bsk_subseq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                   bsk_out* out);
+
 /* ---- synthetic inputs (bench + tests only) --------
  * Deterministic, counter-based: byte k of record i depends on (seed, i, k)
  * only, so any shard can be produced on the host or directly in HBM. */

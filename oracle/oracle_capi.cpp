@@ -37,6 +37,23 @@ typedef struct {
     double MinQual, MaxQual;
 } orc_seq_opts;
 
+typedef struct {
+    orc_kitconfig Config;
+    const char* const* Pattern;  // npattern entries
+    int npattern;
+    int InvertMatch, ByName, BySeq, OnlyPositiveStrand, IgnoreCase;
+    const char* Region;
+    int Circular, Count, UseRegexp, Degenerate, MaxMismatch, DeleteMatched;
+} orc_grep_opts;
+
+typedef struct {
+    orc_kitconfig Config;
+    const char* Region;
+    int UpStream, DownStream, OnlyFlank;
+    const char* Gtf;
+    const char* Bed;
+} orc_subseq_opts;
+
 }  // extern "C"
 
 static KitConfig conv(const orc_kitconfig& c) {
@@ -74,6 +91,29 @@ static SeqOptions conv(const orc_seq_opts& c) {
     o.ValidateSeq = c.ValidateSeq; o.ValidateSeqLength = c.ValidateSeqLength;
     o.MaxLen = c.MaxLen; o.MinLen = c.MinLen; o.QualAsciiBase = c.QualAsciiBase;
     o.MinQual = c.MinQual; o.MaxQual = c.MaxQual;
+    return o;
+}
+
+static GrepOptions conv(const orc_grep_opts& c) {
+    GrepOptions o;
+    o.Config = conv(c.Config);
+    o.Pattern.clear();
+    for (int i = 0; i < c.npattern; ++i) o.Pattern.push_back(c.Pattern[i]);
+    o.InvertMatch = c.InvertMatch; o.ByName = c.ByName; o.BySeq = c.BySeq;
+    o.OnlyPositiveStrand = c.OnlyPositiveStrand; o.IgnoreCase = c.IgnoreCase;
+    if (c.Region) o.Region = c.Region;
+    o.Circular = c.Circular; o.Count = c.Count; o.UseRegexp = c.UseRegexp; o.Degenerate = c.Degenerate;
+    o.MaxMismatch = c.MaxMismatch; o.DeleteMatched = c.DeleteMatched;
+    return o;
+}
+
+static SubseqOptions conv(const orc_subseq_opts& c) {
+    SubseqOptions o;
+    o.Config = conv(c.Config);
+    if (c.Region) o.Region = c.Region;
+    o.UpStream = c.UpStream; o.DownStream = c.DownStream; o.OnlyFlank = c.OnlyFlank;
+    if (c.Gtf) o.Gtf = c.Gtf;
+    if (c.Bed) o.Bed = c.Bed;
     return o;
 }
 
@@ -115,6 +155,26 @@ static std::map<int64_t, int64_t> stats_over_parts(std::string_view buf, bool fa
         have = true;
     }
     return acc;
+}
+
+template <class Opt, class Fn>
+static int run_parts(const uint8_t* buf, size_t n, int fastq, const Opt& so, int nparts, Fn fn, bool sum_counts,
+                     uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        if (nparts < 1) nparts = 1;
+        std::vector<std::string> all;
+        int64_t total = 0;
+        for (int p = 0; p < nparts; ++p) {
+            size_t a = recs.size() * (size_t)p / (size_t)nparts, b = recs.size() * (size_t)(p + 1) / (size_t)nparts;
+            std::vector<std::string_view> part(recs.begin() + a, recs.begin() + b);
+            auto r = fn(part, so);
+            if (sum_counts) total += strtoll(r.at(0).c_str(), nullptr, 10);  // GrepReduceCount (grep.go:598-611)
+            else all.insert(all.end(), r.begin(), r.end());
+        }
+        if (sum_counts) all.push_back(std::to_string(total));
+        return emit(all, out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
 }
 
 extern "C" {
@@ -209,6 +269,24 @@ int orc_seq(const uint8_t* buf, size_t n, int fastq, const orc_seq_opts* o, int 
         }
         return emit(all, out, cap, nout, nrec);
     } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
+int orc_grep(const uint8_t* buf, size_t n, int fastq, const orc_grep_opts* o, int nparts, uint8_t* out, size_t cap,
+             size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    GrepOptions so = conv(*o);
+    return run_parts(buf, n, fastq, so, nparts, grep_call, so.Count, out, cap, nout, nrec, err, errcap);
+}
+
+int orc_subseq(const uint8_t* buf, size_t n, int fastq, const orc_subseq_opts* o, int nparts, uint8_t* out, size_t cap,
+               size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    SubseqOptions so = conv(*o);
+    return run_parts(buf, n, fastq, so, nparts, subseq_call, false, out, cap, nout, nrec, err, errcap);
+}
+
+// region table probe: 0-based [b, e)
+int orc_sub_location(size_t length, int start, int end, size_t* b, size_t* e) {
+    sub_location(length, start, end, b, e);
+    return 0;
 }
 
 int orc_wrap(const uint8_t* s, size_t n, int width, uint8_t* out, size_t cap, size_t* nout) {

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -534,6 +535,176 @@ std::vector<std::string> seq_call(const std::vector<std::string_view>& part, con
         }
         if (!out.empty() && out.back() == '\n') out.pop_back();  // seq.go:261-265
         result.push_back(out);
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// regions  (Seq.SubSeq / SubLocation [upstream-memory]; KATs bigseqkit-cli/helper.go:348-361)
+// ---------------------------------------------------------------------------
+void sub_location(size_t length, int start, int end, size_t* b, size_t* e) {
+    *b = *e = 0;
+    if (length == 0) return;
+    long L = (long)length, s = start, t = end;
+    if (s < 0) { s = L + s + 1; if (s < 1) s = 1; }
+    if (s == 0) s = 1;
+    if (t < 0) t = L + t + 1;
+    if (t > L) t = L;
+    if (s > L || t < 1 || s > t) return;
+    *b = (size_t)(s - 1);
+    *e = (size_t)t;
+}
+
+// reRegion `\-?\d+:\-?\d+` + the checks at bigseqkit-lib/grep.go:103-118, subseq.go:83-97
+void parse_region(const std::string& region, const char* cmd, int* start, int* end) {
+    // leftmost match of -?digits:-?digits anywhere in the string (MatchString), then Split(":")
+    bool ok = false;
+    for (size_t i = 0; i < region.size() && !ok; ++i) {
+        size_t p = i;
+        if (p < region.size() && region[p] == '-') ++p;
+        size_t d0 = p;
+        while (p < region.size() && isdigit((unsigned char)region[p])) ++p;
+        if (p == d0 || p >= region.size() || region[p] != ':') continue;
+        ++p;
+        if (p < region.size() && region[p] == '-') ++p;
+        size_t d1 = p;
+        while (p < region.size() && isdigit((unsigned char)region[p])) ++p;
+        if (p > d1) ok = true;
+    }
+    if (!ok) throw Error("invalid region: " + region + ". type \"seqkit " + cmd + " -h\" for more examples");
+    size_t c = region.find(':');
+    char* endp = nullptr;
+    std::string a = region.substr(0, c), b = region.substr(c + 1);
+    long sa = strtol(a.c_str(), &endp, 10);
+    if (a.empty() || *endp) throw Error("strconv.Atoi: parsing \"" + a + "\": invalid syntax");
+    long sb = strtol(b.c_str(), &endp, 10);
+    if (b.empty() || *endp) throw Error("strconv.Atoi: parsing \"" + b + "\": invalid syntax");
+    if (sa == 0 || sb == 0) throw Error("both start and end should not be 0");
+    if (sa < 0 && sb > 0) throw Error("when start < 0, end should not > 0");
+    *start = (int)sa;
+    *end = (int)sb;
+}
+
+std::string rev_com(const std::string& s, Alphabet a) {
+    std::string r(s.rbegin(), s.rend());
+    complement_inplace(r, a);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Grep  bigseqkit-lib/grep.go (exact patterns: no -r, -d, -m, --delete-matched)
+// ---------------------------------------------------------------------------
+std::vector<std::string> grep_call(const std::vector<std::string_view>& part, const GrepOptions& oin) {
+    GrepOptions o = oin;
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    // PARITY.md Q17: the default Pattern [""] must not defeat the guard at grep.go:53
+    bool any = !o.PatternFile.empty();
+    for (auto& p : o.Pattern) if (!p.empty()) any = true;
+    if (!any) throw Error("one of flags -p (--pattern) and -f (--pattern-file) needed");
+    if (o.Degenerate) o.BySeq = true;
+    if (o.MaxMismatch > 0) {
+        if (o.UseRegexp || o.Degenerate)
+            throw Error("flag -r (--use-regexp) or -d (--degenerate) not allowed when giving flag -m (--max-mismatch)");
+        o.BySeq = true;
+    }
+    if (o.UseRegexp && o.Degenerate) throw Error("could not give both flags -d (--degenerate) and -r (--use-regexp)");
+    bool limitRegion = false;
+    int start = 0, end = 0;
+    if (!o.Region.empty()) {
+        limitRegion = true;
+        o.BySeq = true;
+        parse_region(o.Region, "grep", &start, &end);
+    }
+    if (o.UseRegexp || o.Degenerate || o.MaxMismatch > 0 || o.DeleteMatched || !o.PatternFile.empty())
+        throw Error("oracle: regexp / degenerate / mismatch / delete-matched / pattern-file grep is not restated");
+    std::vector<std::string> patterns;  // PARITY.md Q11: CLI order instead of Go map order
+    for (auto p : o.Pattern) {
+        if (p.empty()) continue;
+        if (o.BySeq) {
+            if (!(alphabet_is_valid(AB_DNAredundant, p) || alphabet_is_valid(AB_RNAredundant, p) ||
+                  alphabet_is_valid(AB_PROTEIN, p)))
+                throw Error("illegal DNA/RNA/Protein sequence: " + p);
+        }
+        if (o.IgnoreCase) p = lower(p);
+        if (std::find(patterns.begin(), patterns.end(), p) == patterns.end()) patterns.push_back(p);
+    }
+    SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    std::vector<std::string> result;
+    bool checkAlphabet = true, onlyPos = o.OnlyPositiveStrand;
+    int lineWidth = o.Config.LineWidth;
+    int64_t count = 0;
+    while (rd.Read()) {
+        Record& r = rd.rec;
+        if (checkAlphabet) {  // grep.go:403-409
+            if (rd.GetAlphabet() == AB_UNLIMIT || rd.GetAlphabet() == AB_PROTEIN) onlyPos = true;
+            checkAlphabet = false;
+        }
+        if (rd.IsFastq) lineWidth = 0;
+        bool hit = false;
+        for (int strand = 0; strand < 2 && !hit; ++strand) {
+            if (strand == 1 && (!o.BySeq || onlyPos)) break;
+            std::string target;
+            if (o.BySeq) {
+                std::string sq = strand == 0 ? r.seq : rev_com(r.seq, rd.GetAlphabet());
+                if (limitRegion) {
+                    size_t b, e;
+                    sub_location(sq.size(), start, end, &b, &e);
+                    target = sq.substr(b, e - b);
+                } else if (o.Circular) target = sq + sq;
+                else target = sq;
+                if (o.IgnoreCase) target = lower(target);
+                for (auto& k : patterns)
+                    if (target.find(k) != std::string::npos) { hit = true; break; }
+            } else {
+                target = o.ByName ? r.name : r.id;
+                if (o.IgnoreCase) target = lower(target);
+                hit = std::find(patterns.begin(), patterns.end(), target) != patterns.end();
+            }
+        }
+        if (o.InvertMatch ? hit : !hit) continue;
+        if (o.Count) { ++count; continue; }
+        std::string bb = record_format(r, rd.IsFastq, lineWidth);
+        bb.pop_back();  // grep.go:531-533
+        result.push_back(bb);
+    }
+    if (o.Count) result.push_back(std::to_string(count));
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// SubseqTransform by region  bigseqkit-lib/subseq.go
+// ---------------------------------------------------------------------------
+std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, const SubseqOptions& o) {
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    if (o.OnlyFlank) {  // subseq.go:63-71
+        if (o.UpStream > 0 && o.DownStream > 0)
+            throw Error("when flag -f (--only-flank) given, only one of flags -u (--up-stream) and -d (--down-stream) is allowed");
+        else if (o.UpStream == 0 && o.DownStream == 0)
+            throw Error("when flag -f (--only-flank) given, one of flags -u (--up-stream) and -d (--down-stream) should be given");
+    }
+    int start = 0, end = 0;
+    if (!o.Region.empty()) {
+        if (o.UpStream > 0 || o.DownStream > 0 || o.OnlyFlank)
+            throw Error("when flag -r (--region) given, any of flags -u (--up-stream), -d (--down-stream) and -f (--only-flank) is not allowed");
+        parse_region(o.Region, "subseq", &start, &end);
+    } else if (!o.Gtf.empty() || !o.Bed.empty()) {
+        throw Error("oracle: subseq --gtf/--bed is not restated");
+    } else {
+        throw Error("one of the options needed: -r/--region, --bed, --gtf");
+    }
+    SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    std::vector<std::string> result;
+    int lineWidth = o.Config.LineWidth;
+    while (rd.Read()) {
+        Record& r = rd.rec;
+        if (rd.IsFastq) lineWidth = 0;
+        size_t b, e;
+        sub_location(r.seq.size(), start, end, &b, &e);
+        r.seq = r.seq.substr(b, e - b);
+        if (!r.qual.empty()) r.qual = r.qual.substr(b, e - b);
+        std::string bb = record_format(r, rd.IsFastq, lineWidth);
+        bb.pop_back();  // PARITY.md Q6: no blank line between records
+        result.push_back(bb);
     }
     return result;
 }

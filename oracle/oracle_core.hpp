@@ -146,6 +146,36 @@ struct SeqOptions {  // bigseqkit/seq.go:9-55
 // SeqTransform.Before + Call  bigseqkit-lib/seq.go:28-269 -> elements (no trailing '\n')
 std::vector<std::string> seq_call(const std::vector<std::string_view>& part, const SeqOptions& o);
 
+struct GrepOptions {  // bigseqkit/grep.go:13-49
+    KitConfig Config;
+    std::vector<std::string> Pattern = {""};
+    std::string PatternFile;
+    bool UseRegexp = false, DeleteMatched = false, InvertMatch = false, ByName = false, BySeq = false;
+    bool OnlyPositiveStrand = false;
+    int MaxMismatch = 0;
+    bool IgnoreCase = false, Degenerate = false;
+    std::string Region;
+    bool Circular = false, Count = false;
+};
+// Grep.Before + grepGeneral  bigseqkit-lib/grep.go:41-253, 367-542  (exact patterns only)
+std::vector<std::string> grep_call(const std::vector<std::string_view>& part, const GrepOptions& o);
+
+struct SubseqOptions {  // bigseqkit/subseq.go:9-35 (region mode)
+    KitConfig Config;
+    std::string Region;
+    int UpStream = 0, DownStream = 0;
+    bool OnlyFlank = false;
+    std::string Gtf, Bed;
+};
+// SubseqTransform.Before + Call (by region)  bigseqkit-lib/subseq.go:36-165, 167-225, 314-317
+std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, const SubseqOptions& o);
+
+// seq.SubLocation / Seq.SubSeq [upstream-memory]; pinned by the region table
+// bigseqkit-cli/helper.go:348-361.  Returns 0-based [begin, end) or begin == end for empty.
+void sub_location(size_t length, int start, int end, size_t* b, size_t* e);
+void parse_region(const std::string& region, const char* cmd, int* start, int* end);
+std::string rev_com(const std::string& s, Alphabet a);
+
 // bio seq.Seq helpers [upstream-memory, shenwei356/bio v0.7.0]
 void complement_inplace(std::string& s, Alphabet a);
 double avg_qual(const std::string& qual, int base);

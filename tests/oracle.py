@@ -25,6 +25,18 @@ class SeqOpts(C.Structure):
                  "MinLen", "QualAsciiBase")] + [("MinQual", C.c_double), ("MaxQual", C.c_double)]
 
 
+class GrepOpts(C.Structure):
+    _fields_ = [("Config", KitConfig), ("Pattern", C.POINTER(C.c_char_p)), ("npattern", C.c_int)] + \
+               [(k, C.c_int) for k in ("InvertMatch", "ByName", "BySeq", "OnlyPositiveStrand", "IgnoreCase")] + \
+               [("Region", C.c_char_p)] + [(k, C.c_int) for k in
+                ("Circular", "Count", "UseRegexp", "Degenerate", "MaxMismatch", "DeleteMatched")]
+
+
+class SubseqOpts(C.Structure):
+    _fields_ = [("Config", KitConfig), ("Region", C.c_char_p), ("UpStream", C.c_int), ("DownStream", C.c_int),
+                ("OnlyFlank", C.c_int), ("Gtf", C.c_char_p), ("Bed", C.c_char_p)]
+
+
 class OracleError(RuntimeError):
     pass
 
@@ -74,6 +86,41 @@ def _run_text(fn, data, fastq, o, nparts):
 def seq(data, fastq, opts_json="{}", nparts=1):
     """SeqTransform -> the bytes FileStore would write (each element + newline)."""
     return _run_text(_lib.orc_seq, data, fastq, seq_opts(opts_json), nparts)[0]
+
+
+def grep_opts(opts_json):
+    """defaults per /root/reference/bigseqkit/grep.go:31-49"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    b = lambda k: int(bool(g(k, False)))
+    pats = [p.encode() for p in g("Pattern", [""])]
+    arr = (C.c_char_p * max(1, len(pats)))(*pats)
+    o = GrepOpts(_cfg(d), arr, len(pats), b("InvertMatch"), b("ByName"), b("BySeq"), b("OnlyPositiveStrand"),
+                 b("IgnoreCase"), g("Region", "").encode(), b("Circular"), b("Count"), b("UseRegexp"),
+                 b("Degenerate"), g("MaxMismatch", 0), b("DeleteMatched"))
+    o._keep = (arr, pats)
+    return o
+
+
+def grep(data, fastq, opts_json="{}", nparts=1):
+    return _run_text(_lib.orc_grep, data, fastq, grep_opts(opts_json), nparts)[0]
+
+
+def subseq_opts(opts_json):
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    return SubseqOpts(_cfg(d), g("Region", "").encode(), g("UpStream", 0), g("DownStream", 0),
+                      int(bool(g("OnlyFlank", False))), g("Gtf", "").encode(), g("Bed", "").encode())
+
+
+def subseq(data, fastq, opts_json="{}", nparts=1):
+    return _run_text(_lib.orc_subseq, data, fastq, subseq_opts(opts_json), nparts)[0]
+
+
+def sub_location(length, start, end):
+    b, e = C.c_size_t(), C.c_size_t()
+    _lib.orc_sub_location(C.c_size_t(length), start, end, C.byref(b), C.byref(e))
+    return b.value, e.value
 
 
 def _buf(data):

@@ -51,20 +51,22 @@ def test_options_json_defaults_match_reference_schema():
 
 @pytest.mark.parametrize("name,cls,probe", [
     ("SeqTransform", bsk.SeqKitSeqOptions, {"GapLetters": "- \t.", "MinLen": -1, "MaxQual": -1, "QualAsciiBase": 33}),
-    ("Grep", bsk.SeqKitGrepOptions, {"Pattern": [""], "MaxMismatch": 0, "Region": ""}),
+    ("Grep", lambda: bsk.SeqKitGrepOptions().Pattern(["id1"]), {"Pattern": ["id1"], "MaxMismatch": 0, "Region": ""}),
     ("Locate", bsk.SeqKitLocateOptions, {"Pattern": [""], "ValidateSeqLength": 10000, "NonGreedy": False}),
-    ("SubseqTransform", bsk.SeqKitSubseqOptions, {"Chr": [], "Feature": [], "UpStream": 0, "GtfTag": ""}),
+    ("SubseqTransform", lambda: bsk.SeqKitSubseqOptions().Region("1:2"),
+     {"Chr": [], "Feature": [], "UpStream": 0, "GtfTag": "", "Region": "1:2"}),
     ("Translate", bsk.SeqKitTranslateOptions, {"TranslTable": 1, "Frame": ["1"], "ListTranslTable": -1}),
     ("RmDup", bsk.SeqKitRmDupOptions, {"BySeq": False, "DupNumFile": ""}),
 ])
 def test_defaults_of_every_hot_path_command(name, cls, probe):
-    op = bsk.Operator(name, cls().to_json(), -1)
+    o = cls()
+    op = bsk.Operator(name, o.to_json(), -1)
     d = json.loads(op.opts_json())
     for k, v in probe.items():
         assert d[k] == v
     assert list(d)[0] == "Config" and d["Config"]["LineWidth"] == 60
     # field order == Go declaration order
-    assert list(d)[1:] == list(cls._fields)
+    assert list(d)[1:] == list(o._fields)
 
 
 def test_idncbi_overrides_idregexp():

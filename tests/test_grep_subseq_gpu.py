@@ -1,0 +1,213 @@
+"""Parity of `grep` (exact patterns) and `subseq -r` against the CPU oracle, through the C ABI."""
+import ctypes as C
+import json
+import random
+
+import pytest
+
+import oracle
+import seqgen
+import bigseqkit_amd as bsk
+from bigseqkit_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(data):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    return t.cuda()
+
+
+class _Opts:
+    def __init__(self, d):
+        self.d = dict(d)
+        self._v = self.d
+
+    def to_json(self):
+        return json.dumps(self.d)
+
+
+def frame(data, fastq, on_device=True):
+    return bsk.SeqFrame(bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA, [dev(data) if on_device else data])
+
+
+def check_grep(data, fastq, opts):
+    want = oracle.grep(data, fastq, json.dumps(dict(opts, Count=False)))
+    got = bsk.Grep(frame(data, fastq), _Opts(opts))
+    assert got == want, (opts, len(got), len(want))
+    wantc = int(oracle.grep(data, fastq, json.dumps(dict(opts, Count=True))))
+    assert bsk.GrepCount(frame(data, fastq), _Opts(opts)) == wantc
+    return wantc
+
+
+MOTIF = "ACGTTGCAAGCT"
+
+
+def planted_fastq(rng, n, L=150):
+    out = []
+    for i in range(n):
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if i % 7 == 0:
+            p = rng.randrange(L - 12 + 1)
+            s[p:p + 12] = MOTIF
+        elif i % 7 == 3:
+            p = rng.randrange(L - 12 + 1)
+            s[p:p + 12] = "AGCTTGCAACGT"  # reverse complement
+        elif i % 7 == 5:
+            s[-6:] = MOTIF[:6]
+            s[:6] = MOTIF[6:]            # only a circular target contains the motif
+        s = "".join(s)
+        if i % 11 == 0:
+            s = s.lower()
+        out.append(f"@r{i} d{i % 5}\n{s}\n+\n{'I' * L}\n")
+    return "".join(out).encode()
+
+
+GREP_SEQ_OPTS = [
+    {"BySeq": True, "Pattern": [MOTIF]},
+    {"BySeq": True, "Pattern": [MOTIF], "OnlyPositiveStrand": True},
+    {"BySeq": True, "Pattern": [MOTIF], "IgnoreCase": True},
+    {"BySeq": True, "Pattern": [MOTIF], "InvertMatch": True},
+    {"BySeq": True, "Pattern": [MOTIF], "Circular": True},
+    {"BySeq": True, "Pattern": [MOTIF.lower(), "GGGGGGGG", "TTTTTTTTT"], "IgnoreCase": True},
+    {"Pattern": [MOTIF], "Region": "1:40"},
+    {"Pattern": [MOTIF], "Region": "-40:-1"},
+    {"Pattern": [MOTIF], "Region": "20:-20", "OnlyPositiveStrand": True},
+    {"BySeq": True, "Pattern": ["ACG"]},
+    {"BySeq": True, "Pattern": ["A" * 200]},
+    {"BySeq": True, "Pattern": ["ACGTN", "RYRY"], "Config": {"SeqType": "dna"}},
+]
+
+
+@pytest.mark.parametrize("i", range(len(GREP_SEQ_OPTS)))
+def test_grep_by_seq_fastq(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(300 + i)
+    data = planted_fastq(rng, 900)
+    n = check_grep(data, True, GREP_SEQ_OPTS[i])
+    if i == 0:
+        assert n >= 900 // 7 * 2 * 9 // 11 - 5   # every 11th read is lower case
+
+
+@pytest.mark.parametrize("width", [60, 0, 13])
+@pytest.mark.parametrize("i", [0, 2, 3, 4, 6, 7])
+def test_grep_by_seq_fasta(i, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(400 + i)
+    recs = []
+    for k in range(250):
+        L = rng.randint(0, 700)
+        s = [rng.choice("ACGTacgt") for _ in range(L)]
+        if L >= 12 and k % 3 == 0:
+            p = rng.randrange(L - 11)
+            s[p:p + 12] = MOTIF if k % 2 else "AGCTTGCAACGT"
+        s = "".join(s)
+        w = width if width else max(1, L)
+        recs.append(f">s{k} x\n" + "".join(s[j:j + w] + "\n" for j in range(0, L, w)))
+    data = "".join(recs).encode()
+    check_grep(data, False, GREP_SEQ_OPTS[i])
+
+
+def test_grep_irregularly_wrapped_fasta():
+    rng = random.Random(5)
+    recs = []
+    for k in range(120):
+        L = rng.randint(20, 400)
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if k % 2 == 0:
+            p = rng.randrange(L - 11)
+            s[p:p + 12] = MOTIF
+        s = "".join(s)
+        lines, j = [], 0
+        while j < L:
+            w = rng.randint(1, 50)
+            lines.append(s[j:j + w])
+            j += w
+        recs.append(f">s{k}\n" + "\n".join(lines) + "\n")
+    data = "".join(recs).encode()
+    for o in ({"BySeq": True, "Pattern": [MOTIF]}, {"BySeq": True, "Pattern": [MOTIF], "Circular": True},
+              {"Pattern": [MOTIF], "Region": "5:-5"}):
+        check_grep(data, False, o)
+
+
+GREP_NAME_OPTS = [
+    {"Pattern": ["r3", "r10", "r899", "nope"]},
+    {"Pattern": ["r3", "R10"], "IgnoreCase": True},
+    {"Pattern": ["r3 d3", "r10 d0", "r4"], "ByName": True},
+    {"Pattern": ["r3"], "InvertMatch": True},
+]
+
+
+@pytest.mark.parametrize("i", range(len(GREP_NAME_OPTS)))
+def test_grep_by_id_and_name(i):
+    rng = random.Random(500 + i)
+    data = planted_fastq(rng, 900, L=30)
+    n = check_grep(data, True, GREP_NAME_OPTS[i])
+    assert n > 0
+
+
+def test_grep_option_errors():
+    for opts, msg in [({}, "one of flags -p (--pattern) and -f (--pattern-file) needed"),
+                      ({"Pattern": ["ACGT"], "Region": "0:5"}, "both start and end should not be 0"),
+                      ({"Pattern": ["ACGT"], "Region": "-5:5"}, "when start < 0, end should not > 0"),
+                      ({"Pattern": ["ACGT"], "Region": "abc"}, "invalid region: abc"),
+                      ({"Pattern": ["AC!T"], "BySeq": True}, "illegal DNA/RNA/Protein sequence: AC!T")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("Grep", json.dumps(opts), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.grep(b"@a\nA\n+\nI\n", True, json.dumps(opts))
+        assert msg in str(oe.value)
+
+
+def test_grep_c3_synthetic_motif_count():
+    """BASELINE C3 planting rule: motif on '+' when i%100==0, reverse complement when i%100==50."""
+    import torch
+    rb, nrec = 317, 3_000_000
+    t = torch.empty(rb * nrec, dtype=torch.uint8, device="cuda")
+    assert _lib.lib.bsk_synth_device(0, 42, _lib.SYNTH_FLAG_MOTIF, 0, C.c_void_p(t.data_ptr()), rb * nrec, 0, None) == 0
+    o = {"BySeq": True, "Pattern": [MOTIF]}
+    n = bsk.GrepCount(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), _Opts(o))
+    assert nrec // 50 <= n <= nrec // 50 + 400          # 2 % planted + ~1.7e-5 * 2 background
+    npos = bsk.GrepCount(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), _Opts(dict(o, OnlyPositiveStrand=True)))
+    assert nrec // 100 <= npos <= nrec // 100 + 200
+    head = bytes(t[:rb * 40000].cpu().numpy().tobytes())
+    assert bsk.Grep(frame(head, True), _Opts(o)) == oracle.grep(head, True, json.dumps(o))
+
+
+SUBSEQ_REGIONS = ["1:1", "2:4", "-4:-2", "-4:-1", "-1:-1", "2:-2", "1:-1", "1:12", "-12:-1", "50:60", "100:90", "-3:-9"]
+
+
+def test_subseq_region_table_kat():
+    # bigseqkit-cli/helper.go:348-361
+    fa = b">s\nACGTNacgtn\n"
+    want = {"1:1": "A", "2:4": "CGT", "-4:-2": "cgt", "-4:-1": "cgtn", "-1:-1": "n", "2:-2": "CGTNacgt",
+            "1:-1": "ACGTNacgtn", "1:12": "ACGTNacgtn", "-12:-1": "ACGTNacgtn"}
+    for r, w in want.items():
+        got = bsk.Subseq(frame(fa, False), _Opts({"Region": r}))
+        assert got == b">s\n" + w.encode() + b"\n"
+        assert got == oracle.subseq(fa, False, json.dumps({"Region": r}))
+
+
+@pytest.mark.parametrize("fastq", [True, False])
+@pytest.mark.parametrize("r", SUBSEQ_REGIONS)
+def test_subseq_region_random(r, fastq, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(hash(r) & 0xFFFF)
+    data = seqgen.random_fastq(rng, 400, 0, 120) if fastq else seqgen.random_fasta(rng, 200, 0, 300, width=60)
+    for lw in ([60] if fastq else [60, 0, 17]):
+        o = {"Region": r, "Config": {"LineWidth": lw}}
+        assert bsk.Subseq(frame(data, fastq), _Opts(o)) == oracle.subseq(data, fastq, json.dumps(o))
+
+
+def test_subseq_option_errors():
+    for opts, msg in [({}, "one of the options needed: -r/--region, --bed, --gtf"),
+                      ({"Region": "1:5", "UpStream": 3}, "when flag -r (--region) given"),
+                      ({"OnlyFlank": True, "Region": "1:2"}, "when flag -f (--only-flank) given")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("SubseqTransform", json.dumps(opts), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.subseq(b">a\nA\n", False, json.dumps(opts))
+        assert msg in str(oe.value)
