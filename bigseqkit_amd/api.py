@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions
 
 
 class SeqFrame:
@@ -209,6 +209,16 @@ def GrepCount(input, o, device=0):
 def Subseq(input, o, device=0):
     """bigseqkit/subseq.go:86-100"""
     return _run_records("SubseqTransform", lib.bsk_subseq_run, input, o, device)[0]
+
+
+def Translate(input, o=None, device=0):
+    """bigseqkit/translate.go:87-100"""
+    return _run_records("Translate", lib.bsk_translate_run, input, o or SeqKitTranslateOptions(), device)[0]
+
+
+def RmDup(input, o=None, device=0):
+    """bigseqkit/rmdup.go:70-108 (duplicates are global: the input must be one shard per rank)"""
+    return _run_records("RmDup", lib.bsk_rmdup_run, input, o or SeqKitRmDupOptions(), device)[0]
 
 
 def build_index(input, device=0):

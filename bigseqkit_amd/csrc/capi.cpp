@@ -175,6 +175,8 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
             case Op::Seq: validate_seq_opts(c); break;
             case Op::Grep: validate_grep_opts(c); break;
             case Op::Subseq: validate_subseq_opts(c); break;
+            case Op::Translate: validate_translate_opts(c); break;
+            case Op::RmDup: validate_rmdup_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
     } catch (const std::exception& e) {
@@ -204,6 +206,9 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_vec) hipFree(c->d_vec);
         if (c->d_status) hipFree(c->d_status);
         if (c->d_overflow) hipFree(c->d_overflow);
+        for (void* p : {(void*)c->d_text_w, (void*)c->d_lin_off, (void*)c->d_lin, (void*)c->d_codon, (void*)c->d_keys,
+                        (void*)c->d_table})
+            if (p) hipFree(p);
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_pat_off) hipFree(c->d_pat_off);
         for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux,
@@ -578,6 +583,18 @@ int bsk_subseq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int f
                    bsk_out* out) {
     (void)pid;
     return run_record_op(c, Op::Subseq, "SubseqTransform", subseq_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_translate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                      bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::Translate, "Translate", translate_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_rmdup_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                  bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::RmDup, "RmDup", rmdup_run_device, shard, n, on_device, format, stream, out);
 }
 
 // ---------------------------------------------------------------------------

@@ -55,6 +55,20 @@ struct bsk_ctx {
     uint8_t* d_lut = nullptr;           // 256-byte byte map (seq)
     double* d_qual_err = nullptr;       // 256 doubles (seq -Q/-R)
     uint64_t* d_counter = nullptr;      // scratch counter
+    // FASTA text view (text.cuh)
+    uint32_t* d_text_w = nullptr;
+    uint64_t* d_lin_off = nullptr;
+    uint8_t* d_lin = nullptr;
+    uint64_t text_cap = 0, lin_cap = 0;
+    bool text_ready = false;
+    // translate
+    uint8_t* d_codon = nullptr;   // 4096 + 4096 bytes (aa table, start table)
+    std::vector<int> frames;
+    // rmdup
+    uint64_t* d_keys = nullptr;
+    uint64_t keys_cap = 0;
+    uint64_t* d_table = nullptr;  // table_keys[cap] ++ table_first[cap]
+    uint64_t table_cap = 0;
     // grep / locate: patterns after Before() (CLI order, duplicates removed, lower-cased with -i)
     std::vector<std::string> patterns;
     uint8_t* d_pat = nullptr;

@@ -12,6 +12,9 @@
 #include "ctx.hpp"
 #include "ops_host.hpp"
 #include "ops_grep.hpp"
+#include "ops_rmdup.hpp"
+#include "ops_text.hpp"
+#include "ops_translate.hpp"
 #include "ops_seq.hpp"
 #include "stream_stats.hpp"
 
@@ -477,6 +480,248 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FASTA text view: classify every record, linearise the irregularly wrapped ones
+// ---------------------------------------------------------------------------
+static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt) {
+    tt->text_w = nullptr;
+    tt->lin_off = nullptr;
+    tt->lin = nullptr;
+    if (format == BSK_FORMAT_FASTQ || c->table.n == 0) return BSK_OK;
+    const uint64_t n = c->table.n;
+    if (n + 1 > c->text_cap || !c->d_text_w) {
+        if (c->d_text_w) HIP_TRYX(c, hipFree(c->d_text_w));
+        if (c->d_lin_off) HIP_TRYX(c, hipFree(c->d_lin_off));
+        c->d_text_w = nullptr; c->d_lin_off = nullptr;
+        const uint64_t cap = n + n / 8 + 16;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_text_w, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_lin_off, (cap + 1) * sizeof(uint64_t)));
+        c->text_cap = cap;
+    }
+    int rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_text_classify(d_buf, c->table, c->d_text_w, c->d_out_len, st));
+    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_lin_off, n, c->d_scan_tmp, st));
+    uint64_t total = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_lin_off + n, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (total) {
+        rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_text_linearise(d_buf, c->table, c->d_text_w, c->d_lin_off, c->d_lin, st));
+    }
+    tt->text_w = c->d_text_w;
+    tt->lin_off = c->d_lin_off;
+    tt->lin = c->d_lin;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// translate  (Translate.Before, bigseqkit-lib/translate.go:33-64)
+// ---------------------------------------------------------------------------
+#include "genetic_codes.inc"
+
+static const GeneticCode* find_code(int id) {
+    for (auto& g : kGeneticCodes)
+        if (g.id == id) return &g;
+    return nullptr;
+}
+
+void validate_translate_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    if (!find_code((int)o.i("TranslTable"))) throw OptError("invalid translate table: " + std::to_string(o.i("TranslTable")));
+    c->frames.clear();
+    for (auto& f : o.sl("Frame")) {
+        char* endp = nullptr;
+        const long v = strtol(f.c_str(), &endp, 10);
+        if (f.empty() || *endp)
+            throw OptError("invalid frame(s): " + f + ". available: 1, 2, 3, -1, -2, -3, and 6 for all. multiple frames should be separated by comma");
+        if (!(v == 1 || v == 2 || v == 3 || v == -1 || v == -2 || v == -3 || v == 6))
+            throw OptError("invalid frame: " + std::to_string(v) + ". available: 1, 2, 3, -1, -2, -3, and 6 for all");
+        if (v == 6) { c->frames = {1, 2, 3, -1, -2, -3}; break; }
+        c->frames.push_back((int)v);
+    }
+    if (c->frames.size() > 6) throw OptError("libbsk: at most 6 frames per call");
+    if (o.i("ListTranslTable") >= 0 || o.i("ListTranslTableWithAmbCodons") >= 0)
+        throw OptError("libbsk: translate -l / -L table listings are not supported by the HIP path");
+}
+
+// 4096-entry tables over 4-bit IUPAC codes (A=1 C=2 G=4 T=8): amino acid common to all
+// expansions of the codon ('X' when they disagree), and the exact start codons
+static void build_codon_tables(const GeneticCode& g, uint8_t* aa, uint8_t* start) {
+    static const int tcag[4] = {8, 2, 1, 4};  // code of T, C, A, G
+    auto idx64 = [&](int b1, int b2, int b3) {
+        int i[3] = {b1, b2, b3}, r = 0;
+        for (int k = 0; k < 3; ++k) {
+            int j = 0;
+            while (tcag[j] != i[k]) ++j;
+            r = r * 4 + j;
+        }
+        return r;
+    };
+    memset(aa, 0, 4096);
+    memset(start, 0, 4096);
+    for (int c1 = 1; c1 < 16; ++c1)
+        for (int c2 = 1; c2 < 16; ++c2)
+            for (int c3 = 1; c3 < 16; ++c3) {
+                char r = 0;
+                for (int b1 = 1; b1 <= 8; b1 <<= 1) {
+                    if (!(c1 & b1)) continue;
+                    for (int b2 = 1; b2 <= 8; b2 <<= 1) {
+                        if (!(c2 & b2)) continue;
+                        for (int b3 = 1; b3 <= 8; b3 <<= 1) {
+                            if (!(c3 & b3)) continue;
+                            const char a = g.aa[idx64(b1, b2, b3)];
+                            if (r == 0) r = a;
+                            else if (r != a) r = 'X';
+                        }
+                    }
+                }
+                aa[(c1 << 8) | (c2 << 4) | c3] = (uint8_t)r;
+            }
+    for (int b1 = 1; b1 <= 8; b1 <<= 1)
+        for (int b2 = 1; b2 <= 8; b2 <<= 1)
+            for (int b3 = 1; b3 <= 8; b3 <<= 1)
+                if (g.starts[idx64(b1, b2, b3)] == 'M') start[(b1 << 8) | (b2 << 4) | b3] = 1;
+}
+
+int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+    if (rc != BSK_OK) return rc;
+    if (!(ab == AB_DNA || ab == AB_DNAredundant || ab == AB_RNA || ab == AB_RNAredundant)) {  // translate.go:116-122
+        c->set_error("command 'seqkit translate' only apply to DNA/RNA sequences");
+        return BSK_ERR_FORMAT;
+    }
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    TranslateParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = format == BSK_FORMAT_FASTQ;
+    P.nframes = (int)c->frames.size();
+    for (int k = 0; k < P.nframes; ++k) P.frames[k] = c->frames[k];
+    P.trim = o.b("Trim"); P.clean = o.b("Clean"); P.allow_unknown = o.b("AllowUnknownCodon");
+    P.init_m = o.b("InitCodonAsM"); P.append_frame = o.b("AppendFrame");
+    P.line_width = (int)o.ci("LineWidth");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 8192));
+    {
+        std::vector<uint8_t> tab(8192);
+        build_codon_tables(*find_code((int)o.i("TranslTable")), tab.data(), tab.data() + 4096);
+        HIP_TRYX(c, hipMemcpyAsync(c->d_codon, tab.data(), 8192, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+    }
+    P.codon = c->d_codon;
+    P.start = c->d_codon + 4096;
+    // per-element scratch: nframes elements per record
+    const uint64_t ne = c->table.n * (uint64_t)P.nframes;
+    const uint64_t saved_n = c->table.n;
+    c->table.n = ne;  // size the scratch for elements
+    rc = ensure_record_scratch(c);
+    c->table.n = saved_n;
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_translate_size(d_buf, c->table, tt, P, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, ne, c->d_scan_tmp, st));
+    uint64_t total = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + ne, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_translate_emit(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status, st));
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_UNKNOWN_CODON) {
+        c->set_error("seq: unknown codon (use flag -x/--allow-unknown-codon to translate it to 'X')");
+        return BSK_ERR_FORMAT;
+    }
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = ne;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rmdup  (bigseqkit/rmdup.go:70-108 + bigseqkit-lib/rmdup.go)
+// ---------------------------------------------------------------------------
+void validate_rmdup_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    if (o.b("BySeq") && o.b("ByName"))  // bigseqkit/rmdup.go:79-81
+        throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
+    if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :83-85
+        throw OptError("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
+    if (!o.s("DupSeqsFile").empty() || !o.s("DupNumFile").empty())
+        throw OptError("libbsk: rmdup -d / -D side files are not supported by the HIP path yet");
+}
+
+int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.by_seq = o.b("BySeq");
+    P.by_name = o.b("ByName");
+    P.ignore_case = o.b("IgnoreCase");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    const uint64_t N = c->table.n;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    if (2 * cap > c->table_cap || !c->d_table) {
+        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+        c->d_table = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+        c->table_cap = 2 * cap;
+    }
+    uint64_t* tk = c->d_table;
+    uint64_t* tf = c->d_table + cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, c->table, tt, P, c->d_keys, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc == BSK_OK) {
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        if (status & ERR_HASH_COLLISION) {
+            c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+            return BSK_ERR_UNSUPPORTED;
+        }
+    }
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    const SeqParams F = format_params(c, fastq);
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st));
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;

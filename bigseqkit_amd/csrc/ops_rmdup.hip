@@ -1,0 +1,203 @@
+// ============================================================================
+// ops_rmdup.hip -- RmDupPrepare / RmDupCheck (/root/reference/bigseqkit-lib/rmdup.go)
+// on the record table.
+//   k_rmdup_hash    : XXH64(seed 0) of the subject (sequence | name | ID, lower-cased
+//                     with -i) == int64(xxhash.Sum64(subject)) (rmdup.go:67-84)
+//   k_rmdup_insert  : the reference's GroupByKey (bigseqkit/rmdup.go:97) shuffles whole
+//                     records; here only (hash, record index) goes into an
+//                     open-addressing table, atomicMin keeps the FIRST record of a key
+//   k_rmdup_resolve : a record survives iff it is the first of its key; every later one
+//                     is byte-compared with the survivor (RmDupCheck's exact test,
+//                     rmdup.go:193-199); a true 64-bit collision raises an error flag
+//                     instead of a wrong answer.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ops_rmdup.hpp"
+#include "text.cuh"
+
+namespace bsk {
+
+namespace {
+
+__device__ __forceinline__ uint8_t lower8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
+
+// the subject of a record as a byte accessor
+struct Subject {
+    Text T;  // by sequence (W may be > 0)
+    const uint8_t* h;
+    uint32_t len;
+    bool seq, fold;
+    __device__ __forceinline__ uint8_t at(uint32_t i) const {
+        const uint8_t c = seq ? T.at(i) : h[i];
+        return fold ? lower8(c) : c;
+    }
+};
+
+__device__ __forceinline__ Subject subject_of(const uint8_t* buf, const RecordTable& t, const TextTable& tt,
+                                              const RmDupParams& P, uint64_t i) {
+    Subject s;
+    s.fold = P.ignore_case;
+    s.seq = P.by_seq;
+    if (P.by_seq) {
+        s.T = text_of(buf, t, tt, i);
+        s.h = nullptr;
+        s.len = s.T.L;
+    } else {
+        const uint32_t lh = t.l_head[i];
+        const uint8_t* h = buf + t.start[i] + 1;
+        uint32_t hl = lh > 0 ? lh - 1 : 0, off = 0;
+        if (!P.by_name) hl = id_span_of(h, hl, P.id_mode, &off);
+        s.h = h + off;
+        s.len = hl;
+        s.T.p = nullptr; s.T.L = 0; s.T.W = 0;
+    }
+    return s;
+}
+
+constexpr uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull,
+                   P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) { return rotl64(acc + in * P2, 31) * P1; }
+__device__ __forceinline__ uint64_t xmerge(uint64_t acc, uint64_t v) { return (acc ^ xround(0, v)) * P1 + P4; }
+
+__device__ __forceinline__ uint64_t word64(const Subject& s, uint32_t i) {
+    if (s.seq ? (s.T.W == 0 && !s.fold) : !s.fold) {
+        const uint8_t* p = (s.seq ? s.T.p : s.h) + i;
+        uint64_t v;
+        __builtin_memcpy(&v, p, 8);  // unaligned 8-byte load
+        return v;
+    }
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v |= (uint64_t)s.at(i + k) << (8 * k);
+    return v;
+}
+
+__device__ uint64_t xxh64_subject(const Subject& s) {
+    const uint32_t len = s.len;
+    uint32_t p = 0;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0ull - P1;
+        do {
+            v1 = xround(v1, word64(s, p));
+            v2 = xround(v2, word64(s, p + 8));
+            v3 = xround(v3, word64(s, p + 16));
+            v4 = xround(v4, word64(s, p + 24));
+            p += 32;
+        } while (p + 32 <= len);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= len) { h ^= xround(0, word64(s, p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= len) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; ++k) w |= (uint32_t)s.at(p + k) << (8 * k);
+        h ^= (uint64_t)w * P1;
+        h = rotl64(h, 23) * P2 + P3;
+        p += 4;
+    }
+    while (p < len) { h ^= (uint64_t)s.at(p) * P5; h = rotl64(h, 11) * P1; ++p; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                    RmDupParams P, uint64_t* __restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    keys[i] = xxh64_subject(subject_of(buf, t, tt, P, i));
+}
+
+__device__ __forceinline__ uint64_t slot_key(uint64_t k) { return k ? k : 0x9E3779B97F4A7C15ull; }  // 0 == empty
+__device__ __forceinline__ uint64_t slot_of(uint64_t k, uint64_t mask) {
+    k ^= k >> 32; k *= 0xD6E8FEB86659FD93ull; k ^= k >> 32;
+    return k & mask;
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_insert(const uint64_t* __restrict__ keys, uint64_t n, uint64_t base,
+                                                      uint64_t* table_keys, uint64_t* table_first, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = slot_key(keys[i]);
+    const uint64_t mask = cap - 1;
+    uint64_t s = slot_of(k, mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&table_keys[s], 0ull, (unsigned long long)k);
+        if (old == 0ull || old == k) {
+            atomicMin((unsigned long long*)&table_first[s], (unsigned long long)(base + i));
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t format_len(uint32_t name_len, uint32_t L, int fastq, int width) {
+    uint32_t w = L;
+    if (width > 0 && L > 0) w += (L - 1) / (uint32_t)width;
+    uint32_t n = 1 + name_len + 1 + w + 1;
+    if (fastq) n += 2 + w + 1;
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                       RmDupParams P, const uint64_t* __restrict__ keys,
+                                                       const uint64_t* __restrict__ table_keys,
+                                                       const uint64_t* __restrict__ table_first, uint64_t cap,
+                                                       uint32_t* __restrict__ out_len, uint64_t* __restrict__ status) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint64_t k = slot_key(keys[i]);
+    const uint64_t mask = cap - 1;
+    uint64_t s = slot_of(k, mask);
+    while (table_keys[s] != k) s = (s + 1) & mask;
+    const uint64_t first = table_first[s];
+    bool keep = first == i;
+    if (!keep) {
+        const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
+        bool same = a.len == b.len;
+        for (uint32_t q = 0; same && q < a.len; ++q) same = a.at(q) == b.at(q);
+        if (!same) {  // distinct subjects under one 64-bit key: refuse rather than guess
+            atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
+            keep = true;
+        }
+    }
+    const uint32_t lh = t.l_head[i];
+    out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
+}  // namespace
+
+hipError_t launch_rmdup_hash(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                             uint64_t* keys, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_rmdup_hash, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table_keys,
+                               uint64_t* table_first, uint64_t cap, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, base_index,
+                       table_keys, table_first, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                                const uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
+                                uint64_t cap, uint32_t* out_len, uint64_t* status, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_rmdup_resolve, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys,
+                       table_keys, table_first, cap, out_len, status);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

@@ -1,0 +1,31 @@
+// `rmdup`: XXH64 key per record -> open-addressing table keyed by the hash (first
+// occurrence wins) -> exact verification -> survivors emitted in file order.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+#include "ops_translate.hpp"  // TextTableH
+
+namespace bsk {
+
+struct RmDupParams {  // RmDupPrepare / RmDupCheck options (bigseqkit-lib/rmdup.go:23-90)
+    int fastq;
+    int by_seq, by_name, ignore_case;
+    int id_mode;
+    int line_width;
+};
+
+constexpr uint32_t ERR_HASH_COLLISION = 512u;
+
+hipError_t launch_rmdup_hash(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                             uint64_t* keys, hipStream_t st);
+// table_keys / table_first: `cap` slots (power of two), zero / 0xFF initialised by the caller
+hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table_keys,
+                               uint64_t* table_first, uint64_t cap, hipStream_t st);
+hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                                const uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
+                                uint64_t cap, uint32_t* out_len, uint64_t* status, hipStream_t st);
+
+}  // namespace bsk

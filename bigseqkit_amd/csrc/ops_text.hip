@@ -1,0 +1,80 @@
+// ops_text.hip -- classify FASTA sequence regions (contiguous / uniformly wrapped /
+// irregular) and linearise the irregular ones.  See text.cuh.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ops_text.hpp"
+#include "text.cuh"
+
+namespace bsk {
+
+namespace {
+
+constexpr int GROUP = 16;
+
+__global__ __launch_bounds__(256) void k_text_classify(const uint8_t* __restrict__ buf, RecordTable t,
+                                                       uint32_t* __restrict__ text_w, uint32_t* __restrict__ lin_len) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;
+    const bool live = g < t.n;
+    const uint64_t gi = live ? g : 0;
+    const uint8_t* p = buf + t.start[gi] + t.l_head[gi] + 1;
+    const uint32_t L = t.l_seq[gi], region = t.aux[gi];
+    const uint32_t tail_nl = (region > 0 && p[region - 1] == '\n') ? 1u : 0u;
+    const uint32_t nnl = region - L;
+    uint32_t w = 0;
+    bool ok = true;
+    if (live && nnl > tail_nl) {
+        uint32_t W = 0;
+        while (W < region && p[W] != '\n') ++W;
+        const uint32_t lines = W ? (L + W - 1) / W : 0;
+        ok = W > 0 && nnl == lines - 1 + tail_nl;
+        if (ok)
+            for (uint32_t k = gl; k + 1 < lines; k += GROUP)
+                if (p[(uint64_t)k * (W + 1) + W] != '\n') ok = false;
+        w = W;
+    }
+    const uint64_t bad = __ballot(!ok);
+    if ((bad >> gshift) & 0xFFFFull) w = TEXT_IRREGULAR;
+    if (live && gl == 0) {
+        text_w[g] = w;
+        lin_len[g] = w == TEXT_IRREGULAR ? L : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_text_linearise(const uint8_t* __restrict__ buf, RecordTable t,
+                                                        const uint32_t* __restrict__ text_w,
+                                                        const uint64_t* __restrict__ lin_off, uint8_t* __restrict__ lin) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n || text_w[i] != TEXT_IRREGULAR) return;
+    const uint8_t* p = buf + t.start[i] + t.l_head[i] + 1;
+    const uint32_t region = t.aux[i];
+    uint8_t* o = lin + lin_off[i];
+    uint32_t x = 0;
+    for (uint32_t k = 0; k < region; ++k) {
+        const uint8_t c = p[k];
+        if (c != '\n') o[x++] = c;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_text_classify(const uint8_t* buf, const RecordTable& t, uint32_t* text_w, uint32_t* lin_len,
+                                hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    const uint64_t blocks = (t.n * GROUP + 255) / 256;
+    hipLaunchKernelGGL(k_text_classify, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, text_w, lin_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_linearise(const uint8_t* buf, const RecordTable& t, const uint32_t* text_w,
+                                 const uint64_t* lin_off, uint8_t* lin, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    const uint64_t blocks = (t.n + 255) / 256;
+    hipLaunchKernelGGL(k_text_linearise, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, text_w, lin_off, lin);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

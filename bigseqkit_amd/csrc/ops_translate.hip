@@ -1,0 +1,213 @@
+// ============================================================================
+// ops_translate.hip -- Translate.Call (/root/reference/bigseqkit-lib/translate.go:66-145)
+// with CodonTable.Translate (shenwei356/bio, not in tree) on the record table.
+// One element per (record, frame) (PARITY.md Q5).  Bases are mapped to 4-bit IUPAC
+// codes (A=1 C=2 G=4 T/U=8, unions for ambiguity codes); complement is a 4-bit
+// reversal; the amino acid of any (possibly ambiguous) codon is ONE lookup in a
+// 4 KiB table that every block stages in LDS.  Negative frames read the forward
+// text backwards -- the reverse complement is never materialised.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ops_translate.hpp"
+#include "text.cuh"
+
+namespace bsk {
+
+namespace {
+
+constexpr int GROUP = 16;
+
+__device__ __forceinline__ uint32_t iupac_code(uint8_t c) {
+    switch (c | 0x20) {  // ASCII lower-case fold
+        case 'a': return 1; case 'c': return 2; case 'g': return 4; case 't': case 'u': return 8;
+        case 'r': return 5; case 'y': return 10; case 's': return 6; case 'w': return 9;
+        case 'k': return 12; case 'm': return 3; case 'b': return 14; case 'd': return 13;
+        case 'h': return 11; case 'v': return 7; case 'n': return 15;
+        default: return 0;
+    }
+}
+__device__ __forceinline__ uint32_t comp_code(uint32_t c) {  // A<->T, C<->G on the bit set
+    return ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
+}
+
+// IUPAC-coded codon index of amino acid j of `frame`
+__device__ __forceinline__ uint32_t codon_index(const Text& T, int frame, uint32_t j) {
+    uint32_t c1, c2, c3;
+    if (frame > 0) {
+        const uint32_t p = (uint32_t)(frame - 1) + 3u * j;
+        c1 = iupac_code(T.at(p)); c2 = iupac_code(T.at(p + 1)); c3 = iupac_code(T.at(p + 2));
+    } else {
+        const uint32_t p = (uint32_t)(-frame - 1) + 3u * j;  // position in the reverse complement
+        c1 = comp_code(iupac_code(T.at(T.L - 1 - p)));
+        c2 = comp_code(iupac_code(T.at(T.L - 2 - p)));
+        c3 = comp_code(iupac_code(T.at(T.L - 3 - p)));
+    }
+    if (c1 == 0 || c2 == 0 || c3 == 0) return 0xFFFFFFFFu;  // not an IUPAC codon
+    return (c1 << 8) | (c2 << 4) | c3;
+}
+
+__device__ __forceinline__ uint32_t num_aa(uint32_t L, int frame) {
+    const uint32_t f = (uint32_t)(frame > 0 ? frame : -frame) - 1u;
+    return L >= f + 3u ? (L - f) / 3u : 0u;
+}
+
+// amino acid j after the unknown / init-codon / clean rules; 0 = unknown codon without -x
+__device__ __forceinline__ uint8_t aa_at(const Text& T, const TranslateParams& P, const uint8_t* s_codon, int frame,
+                                         uint32_t j) {
+    const uint32_t ci = codon_index(T, frame, j);
+    uint8_t aa = ci == 0xFFFFFFFFu ? 0 : s_codon[ci];
+    if (aa == 0) {
+        if (!P.allow_unknown) return 0;
+        aa = 'X';
+    }
+    if (j == 0 && P.init_m && ci != 0xFFFFFFFFu && P.start[ci]) aa = 'M';
+    if (P.clean && aa == '*') aa = 'X';
+    return aa;
+}
+
+__device__ __forceinline__ uint32_t dec_len(int v) {
+    uint32_t n = v < 0 ? 1u : 0u;
+    uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    do { ++n; a /= 10; } while (a);
+    return n;
+}
+
+// header of an element: ">Name" or ">ID_frame=N Desc" (translate.go:133-137), without the '\n'
+__device__ uint32_t header_len(const uint8_t* h, uint32_t hl, const TranslateParams& P, int frame) {
+    if (!P.append_frame) return 1 + hl;
+    uint32_t ioff, doff;
+    const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+    const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
+    return 1 + il + 7 + dec_len(frame) + 1 + dl;  // '>' id "_frame=" N ' ' desc
+}
+
+__global__ __launch_bounds__(256) void k_translate_size(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                        TranslateParams P, uint32_t* __restrict__ out_len,
+                                                        uint64_t* __restrict__ status) {
+    __shared__ uint8_t s_codon[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_codon[i] = P.codon[i];
+    __syncthreads();
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.n * (uint64_t)P.nframes) return;
+    const uint64_t i = e / (uint64_t)P.nframes;
+    const int frame = P.frames[e % (uint64_t)P.nframes];
+    const Text T = text_of(buf, t, tt, i);
+    uint32_t naa = num_aa(T.L, frame);
+    if (P.trim) {  // bytes.TrimRight(aas, "X*"): walk back over the tail
+        while (naa > 0) {
+            const uint8_t aa = aa_at(T, P, s_codon, frame, naa - 1);
+            if (aa == 'X' || aa == '*') --naa;
+            else break;  // (an unknown codon is reported by the emit pass)
+        }
+    }
+    const uint32_t lh = t.l_head[i];
+    uint32_t n = header_len(buf + t.start[i] + 1, lh > 0 ? lh - 1 : 0, P, frame) + 1;
+    n += naa + ((P.line_width > 0 && naa > 0) ? (naa - 1) / (uint32_t)P.line_width : 0u);
+    n += 1;  // FileStore's newline after the element
+    out_len[e] = n;
+    (void)status;
+}
+
+__device__ __forceinline__ uint32_t put_dec(uint8_t* o, int v) {
+    uint32_t n = 0;
+    if (v < 0) { o[n++] = '-'; v = -v; }
+    char tmp[12];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) o[n++] = (uint8_t)tmp[--k];
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_translate_emit(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                        TranslateParams P, const uint32_t* __restrict__ out_len,
+                                                        const uint64_t* __restrict__ out_off,
+                                                        uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
+    __shared__ uint8_t s_codon[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_codon[i] = P.codon[i];
+    __syncthreads();
+    const uint64_t e = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    if (e >= t.n * (uint64_t)P.nframes) return;
+    const uint64_t i = e / (uint64_t)P.nframes;
+    const int frame = P.frames[e % (uint64_t)P.nframes];
+    const Text T = text_of(buf, t, tt, i);
+    const uint32_t n = out_len[e];
+    uint8_t* o = out + out_off[e];
+    const uint8_t* h = buf + t.start[i] + 1;
+    const uint32_t lh = t.l_head[i];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    uint32_t hdr = 0;
+    if (gl == 0) {
+        o[hdr++] = '>';
+        if (!P.append_frame) {
+            for (uint32_t k = 0; k < hl; ++k) o[hdr++] = h[k];
+        } else {
+            uint32_t ioff, doff;
+            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
+            for (uint32_t k = 0; k < il; ++k) o[hdr++] = h[ioff + k];
+            const char* f = "_frame=";
+            for (int k = 0; k < 7; ++k) o[hdr++] = (uint8_t)f[k];
+            hdr += put_dec(o + hdr, frame);
+            o[hdr++] = ' ';
+            for (uint32_t k = 0; k < dl; ++k) o[hdr++] = h[doff + k];
+        }
+        o[hdr++] = '\n';
+        o[n - 1] = '\n';
+    }
+    const uint32_t H = header_len(h, hl, P, frame) + 1;
+    // body: wrapped amino acids; the trimmed length follows from the element size
+    const uint32_t body = n - H - 1;
+    const uint32_t w1 = P.line_width > 0 ? (uint32_t)P.line_width + 1u : 0u;
+    uint32_t err = 0;
+    for (uint32_t x = gl; x < body; x += GROUP) {
+        uint32_t j = x;
+        bool nl = false;
+        if (w1) {
+            const uint32_t line = x / w1, col = x - line * w1;
+            if (col == w1 - 1) nl = true;
+            j = line * (w1 - 1) + col;
+        }
+        uint8_t c = '\n';
+        if (!nl) {
+            c = aa_at(T, P, s_codon, frame, j);
+            if (c == 0) { err = ERR_UNKNOWN_CODON; c = 'X'; }
+        }
+        o[H + x] = c;
+    }
+    // codons dropped by --trim are still translated by the reference (errors included)
+    if (P.trim && !P.allow_unknown) {
+        const uint32_t total = num_aa(T.L, frame);
+        const uint32_t kept = body - ((w1 && body) ? (body - 1) / w1 : 0u);
+        for (uint32_t j = kept + gl; j < total; j += GROUP)
+            if (aa_at(T, P, s_codon, frame, j) == 0) err = ERR_UNKNOWN_CODON;
+    }
+    if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
+}
+
+}  // namespace
+
+hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                                 const TranslateParams& P, uint32_t* out_len, uint64_t* status, hipStream_t st) {
+    const uint64_t ne = t.n * (uint64_t)P.nframes;
+    if (ne == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_translate_size, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_translate_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                                  const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
+                                  uint8_t* out, uint64_t* status, hipStream_t st) {
+    const uint64_t ne = t.n * (uint64_t)P.nframes;
+    if (ne == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_translate_emit, dim3((unsigned)((ne * GROUP + 255) / 256)), dim3(256), 0, st, buf, t, d, P,
+                       out_len, out_off, out, status);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

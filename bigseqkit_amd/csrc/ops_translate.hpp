@@ -1,0 +1,37 @@
+// `translate`: per (record, frame) element.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+
+namespace bsk {
+
+struct TextTableH {  // host-visible mirror of TextTable (text.cuh)
+    const uint32_t* text_w;
+    const uint64_t* lin_off;
+    const uint8_t* lin;
+};
+
+struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/translate.go:33-64)
+    int fastq;
+    int nframes;
+    int frames[6];
+    int trim, clean, allow_unknown, init_m, append_frame;
+    int line_width;
+    int id_mode;
+    const uint8_t* codon;   // device, 4096 bytes: aa of the IUPAC-coded codon (c1 << 8 | c2 << 4 | c3); 0 = unknown
+    const uint8_t* start;   // device, 4096 bytes: 1 when the codon is a start codon of the table
+};
+
+constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
+
+// elements are numbered record * nframes + f
+hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                                 const TranslateParams& P, uint32_t* out_len, uint64_t* status, hipStream_t st);
+hipError_t launch_translate_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                                 const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
+                                 uint8_t* out, uint64_t* status, hipStream_t st);
+
+}  // namespace bsk

@@ -1,0 +1,79 @@
+// Random-access view of a record's sequence (device code).
+// FASTQ sequences are contiguous in the shard.  A multi-line FASTA sequence is used in
+// place when all of its lines but the last have one width W (base i lives at i + i / W);
+// irregularly wrapped records are copied once into a linear side buffer (ops_text.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+
+namespace bsk {
+
+constexpr uint32_t TEXT_IRREGULAR = 0xFFFFFFFFu;
+
+struct TextTable {            // device arrays; null for FASTQ
+    const uint32_t* text_w;   // [n] 0 contiguous, W uniform width, TEXT_IRREGULAR -> linear copy
+    const uint64_t* lin_off;  // [n + 1]
+    const uint8_t* lin;
+};
+
+struct Text {
+    const uint8_t* p;
+    uint32_t L;
+    uint32_t W;
+    __device__ __forceinline__ uint8_t at(uint32_t i) const { return W ? p[i + i / W] : p[i]; }
+};
+
+__device__ __forceinline__ Text text_of(const uint8_t* buf, const RecordTable& t, const TextTable& tt, uint64_t i) {
+    Text T;
+    T.p = buf + t.start[i] + t.l_head[i] + 1;
+    T.L = t.l_seq[i];
+    T.W = 0;
+    if (tt.text_w) {
+        const uint32_t w = tt.text_w[i];
+        if (w == TEXT_IRREGULAR) T.p = tt.lin + tt.lin_off[i];
+        else T.W = w;
+    }
+    return T;
+}
+
+// ID length inside a header (marker excluded): parseHeadIDAndDesc,
+// /root/reference/bigseqkit-lib/helper.go:329-369 (default regexp and --id-ncbi)
+__device__ inline uint32_t id_span_of(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off) {
+    *id_off = 0;
+    if (id_mode == 0) {
+        for (uint32_t i = 0; i < n; ++i)
+            if (h[i] == ' ') { if (i > 0) return i; break; }
+        for (uint32_t i = 0; i < n; ++i)
+            if (h[i] == '\t') { if (i > 0) return i; break; }
+        return n;
+    }
+    uint32_t a = 0;
+    while (a < n && h[a] != '|') ++a;
+    while (a < n) {
+        uint32_t b = a + 1;
+        while (b < n && h[b] != '|') ++b;
+        if (b >= n) break;
+        if (b > a + 1 && b + 1 < n && h[b + 1] == ' ') { *id_off = a + 1; return b - a - 1; }
+        a = b;
+    }
+    return n;
+}
+
+// description after the ID (default regexp only; helper.go:331-345, incl. its skip-two loop)
+__device__ inline uint32_t desc_of(const uint8_t* h, uint32_t n, int id_mode, uint32_t id_len, uint32_t* desc_off) {
+    *desc_off = n;
+    if (id_mode != 0 || id_len >= n) return 0;
+    uint32_t j = id_len + 1;
+    for (; j < n; j++) {
+        if (h[j] == ' ' || h[j] == '\t') j++;
+        else break;
+    }
+    if (j >= n) return 0;
+    *desc_off = j;
+    return n - j;
+}
+
+}  // namespace bsk

@@ -161,6 +161,17 @@ int bsk_grep_last_count(const bsk_ctx* ctx, uint64_t* count);
 int bsk_subseq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                    bsk_out* out);
 
+/* ---- Translate (bigseqkit-lib/translate.go:21-145): one element per (record, frame),
+ * ">Name" or ">ID_frame=N Desc" + the protein wrapped at Config.LineWidth. */
+int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                      bsk_out* out);
+
+/* ---- RmDup (RmDupPrepare + GroupByKey + RmDupCheck, bigseqkit-lib/rmdup.go:23-242):
+ * duplicates are global, so ONE call must see the whole input of a rank; the first
+ * record of every subject (file order) survives. */
+int bsk_rmdup_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                  bsk_out* out);
+
 /* ---- synthetic inputs (bench + tests only) --------
  * Deterministic, counter-based: byte k of record i depends on (seed, i, k)
  * only, so any shard can be produced on the host or directly in HBM. */

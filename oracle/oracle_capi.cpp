@@ -54,6 +54,19 @@ typedef struct {
     const char* Bed;
 } orc_subseq_opts;
 
+typedef struct {
+    orc_kitconfig Config;
+    int TranslTable;
+    const char* const* Frame;
+    int nframe;
+    int Trim, Clean, AllowUnknownCodon, InitCodonAsM, ListTranslTable, ListTranslTableWithAmbCodons, AppendFrame;
+} orc_translate_opts;
+
+typedef struct {
+    orc_kitconfig Config;
+    int ByName, BySeq, IgnoreCase, OnlyPositiveStrand;
+} orc_rmdup_opts;
+
 }  // extern "C"
 
 static KitConfig conv(const orc_kitconfig& c) {
@@ -114,6 +127,25 @@ static SubseqOptions conv(const orc_subseq_opts& c) {
     o.UpStream = c.UpStream; o.DownStream = c.DownStream; o.OnlyFlank = c.OnlyFlank;
     if (c.Gtf) o.Gtf = c.Gtf;
     if (c.Bed) o.Bed = c.Bed;
+    return o;
+}
+
+static TranslateOptions conv(const orc_translate_opts& c) {
+    TranslateOptions o;
+    o.Config = conv(c.Config);
+    o.TranslTable = c.TranslTable;
+    o.Frame.clear();
+    for (int i = 0; i < c.nframe; ++i) o.Frame.push_back(c.Frame[i]);
+    o.Trim = c.Trim; o.Clean = c.Clean; o.AllowUnknownCodon = c.AllowUnknownCodon; o.InitCodonAsM = c.InitCodonAsM;
+    o.ListTranslTable = c.ListTranslTable; o.ListTranslTableWithAmbCodons = c.ListTranslTableWithAmbCodons;
+    o.AppendFrame = c.AppendFrame;
+    return o;
+}
+
+static RmDupOptions conv(const orc_rmdup_opts& c) {
+    RmDupOptions o;
+    o.Config = conv(c.Config);
+    o.ByName = c.ByName; o.BySeq = c.BySeq; o.IgnoreCase = c.IgnoreCase; o.OnlyPositiveStrand = c.OnlyPositiveStrand;
     return o;
 }
 
@@ -281,6 +313,33 @@ int orc_subseq(const uint8_t* buf, size_t n, int fastq, const orc_subseq_opts* o
                size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
     SubseqOptions so = conv(*o);
     return run_parts(buf, n, fastq, so, nparts, subseq_call, false, out, cap, nout, nrec, err, errcap);
+}
+
+int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_opts* o, int nparts, uint8_t* out,
+                  size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    TranslateOptions so = conv(*o);
+    return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
+}
+
+// rmdup is global (GroupByKey): nparts is ignored, the whole input is one group space
+int orc_rmdup(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, int nparts, uint8_t* out, size_t cap,
+              size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    (void)nparts;
+    RmDupOptions so = conv(*o);
+    return run_parts(buf, n, fastq, so, 1, rmdup_call, false, out, cap, nout, nrec, err, errcap);
+}
+
+uint64_t orc_xxh64(const uint8_t* p, size_t n) { return xxh64(p, n, 0); }
+
+int orc_translate_seq(const char* seq, int table, int frame, int trim, int clean, int allow_unknown, int init_m,
+                      char* out, size_t cap) {
+    try {
+        bool unknown = false;
+        std::string aa = translate_seq(seq, table, frame, trim, clean, allow_unknown, init_m, &unknown);
+        if (unknown) return 3;
+        snprintf(out, cap, "%s", aa.c_str());
+        return 0;
+    } catch (const std::exception&) { return 1; }
 }
 
 // region table probe: 0-based [b, e)

@@ -709,6 +709,226 @@ std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, 
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// Translate  bigseqkit-lib/translate.go + bio CodonTable.Translate [upstream-memory]
+// ---------------------------------------------------------------------------
+#include "genetic_codes.inc"
+
+static const char* iupac_set(char c) {  // upper-case, U == T
+    switch (c) {
+        case 'A': return "A"; case 'C': return "C"; case 'G': return "G"; case 'T': case 'U': return "T";
+        case 'R': return "AG"; case 'Y': return "CT"; case 'S': return "CG"; case 'W': return "AT";
+        case 'K': return "GT"; case 'M': return "AC"; case 'B': return "CGT"; case 'D': return "AGT";
+        case 'H': return "ACT"; case 'V': return "ACG"; case 'N': return "ACGT";
+        default: return nullptr;
+    }
+}
+
+static const GeneticCode* find_code(int id) {
+    for (auto& g : kGeneticCodes)
+        if (g.id == id) return &g;
+    return nullptr;
+}
+
+// amino acid of a (possibly ambiguous) codon: the common translation of all its
+// expansions, 'X' when they disagree, 0 when a letter is not an IUPAC base.
+static char codon_aa(const GeneticCode& g, const char* c3) {
+    const char* s[3];
+    for (int k = 0; k < 3; ++k) {
+        char c = c3[k];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        s[k] = iupac_set(c);
+        if (!s[k]) return 0;
+    }
+    static const char order[] = "TCAG";
+    char aa = 0;
+    for (const char* a = s[0]; *a; ++a)
+        for (const char* b = s[1]; *b; ++b)
+            for (const char* c = s[2]; *c; ++c) {
+                int i = (int)(strchr(order, *a) - order) * 16 + (int)(strchr(order, *b) - order) * 4 +
+                        (int)(strchr(order, *c) - order);
+                if (aa == 0) aa = g.aa[i];
+                else if (aa != g.aa[i]) return 'X';
+            }
+    return aa;
+}
+
+static bool codon_is_start(const GeneticCode& g, const char* c3) {
+    static const char order[] = "TCAG";
+    int idx = 0;
+    for (int k = 0; k < 3; ++k) {
+        char c = c3[k];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        if (c == 'U') c = 'T';
+        const char* q = strchr(order, c);
+        if (!q || !c) return false;
+        idx = idx * 4 + (int)(q - order);
+    }
+    return g.starts[idx] == 'M';
+}
+
+std::string translate_seq(const std::string& seq_in, int table, int frame, bool trim, bool clean, bool allow_unknown,
+                          bool init_m, bool* unknown) {
+    *unknown = false;
+    const GeneticCode* g = find_code(table);
+    if (!g) throw Error("invalid translate table: " + std::to_string(table));
+    std::string sq = seq_in;
+    if (frame < 0) {  // reverse complement over the IUPAC letters, case kept, others unchanged
+        sq = rev_com(seq_in, AB_DNAredundant);
+        for (auto& c : sq) { if (c == 'u') c = 'a'; else if (c == 'U') c = 'A'; }  // RNA input: U pairs with A
+        frame = -frame;
+    }
+    std::string aas;
+    bool first = true;
+    for (size_t i = (size_t)frame - 1; i + 2 < sq.size(); i += 3) {
+        char aa = codon_aa(*g, sq.data() + i);
+        if (aa == 0) {
+            if (allow_unknown) aa = 'X';
+            else { *unknown = true; return std::string(); }
+        }
+        if (first) {
+            first = false;
+            if (init_m && codon_is_start(*g, sq.data() + i)) aa = 'M';
+        }
+        if (clean && aa == '*') aa = 'X';
+        aas.push_back(aa);
+    }
+    if (trim)
+        while (!aas.empty() && (aas.back() == 'X' || aas.back() == '*')) aas.pop_back();
+    return aas;
+}
+
+std::vector<std::string> translate_call(const std::vector<std::string_view>& part, const TranslateOptions& o) {
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    if (!find_code(o.TranslTable)) throw Error("invalid translate table: " + std::to_string(o.TranslTable));
+    std::vector<int> frames;
+    for (auto& f : o.Frame) {  // translate.go:46-61
+        char* endp = nullptr;
+        long v = strtol(f.c_str(), &endp, 10);
+        if (f.empty() || *endp)
+            throw Error("invalid frame(s): " + f + ". available: 1, 2, 3, -1, -2, -3, and 6 for all. multiple frames should be separated by comma");
+        if (!(v == 1 || v == 2 || v == 3 || v == -1 || v == -2 || v == -3 || v == 6))
+            throw Error("invalid frame: " + std::to_string(v) + ". available: 1, 2, 3, -1, -2, -3, and 6 for all");
+        if (v == 6) { frames = {1, 2, 3, -1, -2, -3}; break; }
+        frames.push_back((int)v);
+    }
+    if (o.ListTranslTable >= 0 || o.ListTranslTableWithAmbCodons >= 0)
+        throw Error("oracle: translate -l / -L table listings are not restated");
+    SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    std::vector<std::string> result;
+    bool once = true;
+    while (rd.Read()) {
+        Record& r = rd.rec;
+        if (once) {
+            Alphabet a = rd.GetAlphabet();
+            if (!(a == AB_DNA || a == AB_DNAredundant || a == AB_RNA || a == AB_RNAredundant))
+                throw Error("command 'seqkit translate' only apply to DNA/RNA sequences");
+            once = false;
+        }
+        for (int frame : frames) {
+            bool unknown = false;
+            std::string aa = translate_seq(r.seq, o.TranslTable, frame, o.Trim, o.Clean, o.AllowUnknownCodon,
+                                           o.InitCodonAsM, &unknown);
+            if (unknown) throw Error("seq: unknown codon");
+            std::string out;
+            if (o.AppendFrame) out = ">" + r.id + "_frame=" + std::to_string(frame) + " " + r.desc + "\n";
+            else out = ">" + r.name + "\n";
+            out += wrap_byte_slice(aa, o.Config.LineWidth);
+            result.push_back(out);
+        }
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// XXH64 (public algorithm; cespare/xxhash/v2 Sum64 == XXH64 with seed 0),
+// pinned by tests/golden/xxh64_vectors.json
+// ---------------------------------------------------------------------------
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+uint64_t xxh64(const void* data, size_t len, uint64_t seed) {
+    const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull,
+                   P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+    const uint8_t* p = (const uint8_t*)data;
+    const uint8_t* end = p + len;
+    uint64_t h;
+    auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; };
+    auto merge = [&](uint64_t acc, uint64_t v) { acc ^= round(0, v); return acc * P1 + P4; };
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24));
+            p += 32;
+        } while (p + 32 <= end);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= round(0, rd64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p) * P5; h = rotl64(h, 11) * P1; ++p; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// ---------------------------------------------------------------------------
+// RmDup  bigseqkit-lib/rmdup.go.  RmDupPrepare keys every record by
+// int64(xxhash.Sum64(subject)); GroupByKey gathers equal keys; RmDupCheck keeps,
+// inside a group, the first record of every distinct subject (and, with -s and
+// without -P, drops a record whose reverse complement was already seen IN THE SAME
+// hash group -- PARITY.md Q8).  Elements leave in first-occurrence file order.
+// ---------------------------------------------------------------------------
+std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, const RmDupOptions& o) {
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    if (o.BySeq && o.ByName) throw Error("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
+    if (o.OnlyPositiveStrand && !o.BySeq) throw Error("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
+    SeqParser rd(ab, &all, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    struct Item { std::string subject, text; uint64_t key; bool fastq; std::string seq; };
+    std::vector<Item> items;
+    int lineWidth = o.Config.LineWidth;
+    while (rd.Read()) {
+        Record& r = rd.rec;
+        if (rd.IsFastq) lineWidth = 0;
+        Item it;
+        it.subject = o.BySeq ? r.seq : (o.ByName ? r.name : r.id);
+        if (o.IgnoreCase) it.subject = lower(it.subject);
+        it.key = xxh64(it.subject.data(), it.subject.size(), 0);
+        it.text = record_format(r, rd.IsFastq, lineWidth);
+        it.seq = r.seq;
+        items.push_back(std::move(it));
+    }
+    const Alphabet fa = rd.GetAlphabet();
+    const bool revcom = o.BySeq && !o.OnlyPositiveStrand;
+    // groups in first-occurrence order
+    std::map<uint64_t, std::vector<size_t>> groups;
+    for (size_t i = 0; i < items.size(); ++i) groups[items[i].key].push_back(i);
+    std::vector<char> keep(items.size(), 0);
+    for (auto& kv : groups) {
+        auto& g = kv.second;
+        if (g.size() == 1) { keep[g[0]] = 1; continue; }
+        std::map<std::string, int> counter;
+        for (size_t i : g) {
+            const std::string& subject = items[i].subject;
+            if (counter.count(subject)) { counter[subject]++; continue; }
+            if (revcom) {
+                std::string rc = rev_com(items[i].seq, fa);
+                if (o.IgnoreCase) rc = lower(rc);
+                if (counter.count(rc)) { counter[rc]++; continue; }
+            }
+            counter[subject]++;
+            keep[i] = 1;
+        }
+    }
+    std::vector<std::string> result;
+    for (size_t i = 0; i < items.size(); ++i)
+        if (keep[i]) { std::string t = items[i].text; t.pop_back(); result.push_back(t); }
+    return result;
+}
+
 // shenwei356/util/math.Round [upstream-memory]:
 //   pow10_n := math.Pow10(n); return math.Trunc((f+0.5/pow10_n)*pow10_n) / pow10_n
 double go_round(double f, int n) {

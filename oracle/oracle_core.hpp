@@ -170,6 +170,29 @@ struct SubseqOptions {  // bigseqkit/subseq.go:9-35 (region mode)
 // SubseqTransform.Before + Call (by region)  bigseqkit-lib/subseq.go:36-165, 167-225, 314-317
 std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, const SubseqOptions& o);
 
+struct TranslateOptions {  // bigseqkit/translate.go:9-35
+    KitConfig Config;
+    int TranslTable = 1;
+    std::vector<std::string> Frame = {"1"};
+    bool Trim = false, Clean = false, AllowUnknownCodon = false, InitCodonAsM = false, AppendFrame = false;
+    int ListTranslTable = -1, ListTranslTableWithAmbCodons = -1;
+};
+// Translate.Before + Call  bigseqkit-lib/translate.go:33-145 (one element per frame, PARITY.md Q5)
+std::vector<std::string> translate_call(const std::vector<std::string_view>& part, const TranslateOptions& o);
+// CodonTable.Translate [upstream-memory, shenwei356/bio v0.7.0 seq/codon_table.go]
+std::string translate_seq(const std::string& seq, int table, int frame, bool trim, bool clean, bool allow_unknown,
+                          bool init_m, bool* unknown);
+
+struct RmDupOptions {  // bigseqkit/rmdup.go:13-33
+    KitConfig Config;
+    bool ByName = false, BySeq = false, IgnoreCase = false, OnlyPositiveStrand = false;
+    std::string DupSeqsFile, DupNumFile;
+};
+// RmDupPrepare + GroupByKey + RmDupCheck over the WHOLE input (bigseqkit-lib/rmdup.go:43-242);
+// survivor = first record in file order (PARITY.md Q10)
+std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, const RmDupOptions& o);
+uint64_t xxh64(const void* data, size_t len, uint64_t seed);  // cespare/xxhash Sum64 == XXH64 seed 0
+
 // seq.SubLocation / Seq.SubSeq [upstream-memory]; pinned by the region table
 // bigseqkit-cli/helper.go:348-361.  Returns 0-based [begin, end) or begin == end for empty.
 void sub_location(size_t length, int start, int end, size_t* b, size_t* e);

@@ -37,6 +37,16 @@ class SubseqOpts(C.Structure):
                 ("OnlyFlank", C.c_int), ("Gtf", C.c_char_p), ("Bed", C.c_char_p)]
 
 
+class TranslateOpts(C.Structure):
+    _fields_ = [("Config", KitConfig), ("TranslTable", C.c_int), ("Frame", C.POINTER(C.c_char_p)), ("nframe", C.c_int)] + \
+               [(k, C.c_int) for k in ("Trim", "Clean", "AllowUnknownCodon", "InitCodonAsM", "ListTranslTable",
+                                       "ListTranslTableWithAmbCodons", "AppendFrame")]
+
+
+class RmDupOpts(C.Structure):
+    _fields_ = [("Config", KitConfig)] + [(k, C.c_int) for k in ("ByName", "BySeq", "IgnoreCase", "OnlyPositiveStrand")]
+
+
 class OracleError(RuntimeError):
     pass
 
@@ -115,6 +125,52 @@ def subseq_opts(opts_json):
 
 def subseq(data, fastq, opts_json="{}", nparts=1):
     return _run_text(_lib.orc_subseq, data, fastq, subseq_opts(opts_json), nparts)[0]
+
+
+def translate_opts(opts_json):
+    """defaults per /root/reference/bigseqkit/translate.go:22-35"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    b = lambda k: int(bool(g(k, False)))
+    fr = [f.encode() for f in g("Frame", ["1"])]
+    arr = (C.c_char_p * max(1, len(fr)))(*fr)
+    o = TranslateOpts(_cfg(d), g("TranslTable", 1), arr, len(fr), b("Trim"), b("Clean"), b("AllowUnknownCodon"),
+                      b("InitCodonAsM"), g("ListTranslTable", -1), g("ListTranslTableWithAmbCodons", -1),
+                      b("AppendFrame"))
+    o._keep = (arr, fr)
+    return o
+
+
+def translate(data, fastq, opts_json="{}", nparts=1):
+    return _run_text(_lib.orc_translate, data, fastq, translate_opts(opts_json), nparts)[0]
+
+
+def translate_seq(seq, table=1, frame=1, trim=False, clean=False, allow_unknown=False, init_m=False):
+    out = C.create_string_buffer(len(seq) + 8)
+    rc = _lib.orc_translate_seq(seq.encode(), table, frame, int(trim), int(clean), int(allow_unknown), int(init_m),
+                                out, C.c_size_t(len(out)))
+    if rc == 3:
+        raise OracleError("unknown codon")
+    if rc:
+        raise OracleError("translate")
+    return out.value.decode()
+
+
+def rmdup_opts(opts_json):
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    b = lambda k: int(bool(d.get(k)))
+    return RmDupOpts(_cfg(d), b("ByName"), b("BySeq"), b("IgnoreCase"), b("OnlyPositiveStrand"))
+
+
+def rmdup(data, fastq, opts_json="{}"):
+    return _run_text(_lib.orc_rmdup, data, fastq, rmdup_opts(opts_json), 1)[0]
+
+
+_lib.orc_xxh64.restype = C.c_uint64
+
+
+def xxh64(b):
+    return _lib.orc_xxh64(_buf(b), C.c_size_t(len(b)))
 
 
 def sub_location(length, start, end):

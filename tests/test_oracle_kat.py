@@ -131,3 +131,58 @@ def test_solexa_offset():
     fq = b"@a\nACGT\n+\nTT^^\n"  # 'T'=84 -> 20 at offset 64, '^'=94 -> 30
     assert oracle.stats_map(fq, True, '{"All": true, "FqEncoding": "solexa"}') == {4: 1, -1: 4, -2: 2, -3: 0, -4: ord("D")}
     assert oracle.stats_map(fq, True, '{"All": true}')[-2] == 4
+
+
+def test_xxh64_golden_vectors():
+    # tests/golden/xxh64_vectors.json: generated with python-xxhash (make_xxh64_vectors.py);
+    # xxh64("") = ef46db3751d8e999, xxh64("ACGT") = f40a8ecfa26af897
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxh64_vectors.json")))
+    assert len(g["vectors"]) > 80
+    for v in g["vectors"]:
+        assert "%016x" % oracle.xxh64(bytes.fromhex(v["hex"])) == v["xxh64"]
+    assert "%016x" % oracle.xxh64(b"") == "ef46db3751d8e999"
+    assert "%016x" % oracle.xxh64(b"ACGT") == "f40a8ecfa26af897"
+
+
+def test_region_table_kat():
+    # bigseqkit-cli/helper.go:348-361
+    s = b"ACGTNacgtn"
+    for r, w in [("1:1", "A"), ("2:4", "CGT"), ("-4:-2", "cgt"), ("-4:-1", "cgtn"), ("-1:-1", "n"),
+                 ("2:-2", "CGTNacgt"), ("1:-1", "ACGTNacgtn"), ("1:12", "ACGTNacgtn"), ("-12:-1", "ACGTNacgtn")]:
+        a, b = map(int, r.split(":"))
+        x, y = oracle.sub_location(10, a, b)
+        assert s[x:y].decode() == w, r
+        assert oracle.subseq(b">s\n" + s + b"\n", False, '{"Region": "%s"}' % r) == b">s\n" + w.encode() + b"\n"
+
+
+def test_ambiguous_codon_kat_and_frames():
+    # bigseqkit-cli/translate.go:42-52
+    for c, a in [("ACN", "T"), ("CCN", "P"), ("CGN", "R"), ("CTN", "L"), ("GCN", "A"), ("GGN", "G"), ("GTN", "V"),
+                 ("TCN", "S"), ("MGR", "R"), ("YTR", "L")]:
+        assert oracle.translate_seq(c) == a
+    assert oracle.translate_seq("ATGGCCTAAGG") == "MA*"
+    assert oracle.translate_seq("ATGGCCTAAGG", frame=2) == "WPK"
+    assert oracle.translate_seq("ATGGCCTAAGG", frame=-1) == "P*A"
+    assert oracle.translate_seq("AUGGCCUAA") == "MA*"          # RNA: U == T
+    assert oracle.translate_seq("atggcctaa") == "MA*"
+    assert oracle.translate_seq("ATGNNNTAA", clean=True) == "MXX"
+    assert oracle.translate_seq("ATGTAATAA", trim=True) == "M"
+    assert oracle.translate_seq("TTGGCC", init_m=True) == "MA"   # TTG is a start codon of table 1
+    assert oracle.translate_seq("TGA", table=2) == "W" and oracle.translate_seq("TGA", table=1) == "*"
+    with pytest.raises(oracle.OracleError):
+        oracle.translate_seq("AT-GCC")
+    assert oracle.translate_seq("AT-GCC", allow_unknown=True) == "XA"
+    fa = b">s1 d\nATGGCCTAAGGA\n"
+    out = oracle.translate(fa, False, '{"Frame": ["6"], "AppendFrame": true}')
+    assert out == (b">s1_frame=1 d\nMA*G\n>s1_frame=2 d\nWPK\n>s1_frame=3 d\nGLR\n"
+                   b">s1_frame=-1 d\nSLGH\n>s1_frame=-2 d\nP*A\n>s1_frame=-3 d\nLRP\n")
+
+
+def test_rmdup_hand_cases():
+    fa = b">a\nACGT\n>b\nacgt\n>c\nACGT\n>d\nTTTT\n"
+    assert oracle.rmdup(fa, False, '{"BySeq": true}') == b">a\nACGT\n>b\nacgt\n>d\nTTTT\n"
+    assert oracle.rmdup(fa, False, '{"BySeq": true, "IgnoreCase": true}') == b">a\nACGT\n>d\nTTTT\n"
+    assert oracle.rmdup(b">a x\nA\n>a y\nC\n>b\nG\n", False, "{}") == b">a x\nA\n>b\nG\n"
+    assert oracle.rmdup(b">a x\nA\n>a y\nC\n>a x\nG\n", False, '{"ByName": true}') == b">a x\nA\n>a y\nC\n"

@@ -1,0 +1,206 @@
+"""Parity of `translate` and `rmdup` against the CPU oracle, through the C ABI."""
+import ctypes as C
+import json
+import random
+
+import pytest
+
+import oracle
+import seqgen
+import bigseqkit_amd as bsk
+from bigseqkit_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(data):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    return t.cuda()
+
+
+class _Opts:
+    def __init__(self, d):
+        self.d = dict(d)
+        self._v = self.d
+
+    def to_json(self):
+        return json.dumps(self.d)
+
+
+def frame(data, fastq):
+    return bsk.SeqFrame(bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA, [dev(data)])
+
+
+def check_translate(data, fastq, opts):
+    want = oracle.translate(data, fastq, json.dumps(opts))
+    got = bsk.Translate(frame(data, fastq), _Opts(opts))
+    assert got == want, (opts, got[:200], want[:200])
+
+
+TR_OPTS = [
+    {},
+    {"Frame": ["6"]},
+    {"Frame": ["6"], "AppendFrame": True},
+    {"Frame": ["2", "-3"], "Config": {"LineWidth": 0}},
+    {"Frame": ["6"], "Trim": True},
+    {"Frame": ["1", "-1"], "Clean": True, "Config": {"LineWidth": 17}},
+    {"Frame": ["6"], "InitCodonAsM": True, "TranslTable": 11},
+    {"Frame": ["6"], "TranslTable": 2, "Trim": True, "Clean": True},
+    {"Frame": ["3"], "TranslTable": 4, "AppendFrame": True},
+]
+
+
+@pytest.mark.parametrize("alphabet", ["ACGT", "ACGTNRYacgtu"])
+@pytest.mark.parametrize("width", [60, 0, 11])
+@pytest.mark.parametrize("i", range(len(TR_OPTS)))
+def test_translate_fasta(i, width, alphabet, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(700 + i)
+    data = seqgen.random_fasta(rng, 150, 0, 700, width=width, alphabet=alphabet, final_newline=i % 2 == 0)
+    data = data.replace(b"-", b"A").replace(b".", b"C").replace(b" ", b"G")  # no gap letters here
+    check_translate(data, False, TR_OPTS[i])
+
+
+def test_translate_fastq_and_irregular_fasta():
+    rng = random.Random(9)
+    fq = seqgen.random_fastq(rng, 300, 0, 160, alphabet="ACGT")
+    fq = fq  # gap letters may appear: handled below with -x
+    check_translate(fq, True, {"Frame": ["6"], "AllowUnknownCodon": True})
+    recs = []
+    for k in range(80):
+        L = rng.randint(0, 500)
+        s = "".join(rng.choice("ACGTN") for _ in range(L))
+        lines, j = [], 0
+        while j < L:
+            w = rng.randint(1, 40)
+            lines.append(s[j:j + w])
+            j += w
+        recs.append(f">s{k} d\n" + "".join(l + "\n" for l in lines))
+    check_translate("".join(recs).encode(), False, {"Frame": ["6"], "AppendFrame": True})
+
+
+def test_translate_unknown_codon_and_errors():
+    bad = b">a\nATG-CCTAA\n"
+    with pytest.raises(bsk.BskError, match="unknown codon"):
+        bsk.Translate(frame(bad, False), _Opts({}))
+    with pytest.raises(oracle.OracleError, match="unknown codon"):
+        oracle.translate(bad, False, "{}")
+    check_translate(bad, False, {"AllowUnknownCodon": True})
+    prot = b">p\nMKVLAAGIVGLLLAQ\n"
+    with pytest.raises(bsk.BskError, match="only apply to DNA/RNA"):
+        bsk.Translate(frame(prot, False), _Opts({}))
+    with pytest.raises(oracle.OracleError, match="only apply to DNA/RNA"):
+        oracle.translate(prot, False, "{}")
+    for opts, msg in [({"TranslTable": 7}, "invalid translate table: 7"), ({"Frame": ["4"]}, "invalid frame: 4"),
+                      ({"Frame": ["x"]}, "invalid frame(s): x")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("Translate", json.dumps(opts), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.translate(b">a\nATG\n", False, json.dumps(opts))
+        assert msg in str(oe.value)
+
+
+def test_translate_c4_synthetic_cds():
+    """BASELINE C4 layout: every frame-1 protein is M + 1665 residues + '*'."""
+    import torch
+    rb, nrec = 5107, 20000
+    t = torch.empty(rb * nrec, dtype=torch.uint8, device="cuda")
+    assert _lib.lib.bsk_synth_device(2, 42, 0, 0, C.c_void_p(t.data_ptr()), rb * nrec, 0, None) == 0
+    got = bsk.Translate(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts({"Frame": ["1"], "Config": {"LineWidth": 0}}))
+    recs = got.split(b"\n")[:-1]
+    assert len(recs) == 2 * nrec
+    assert all(len(p) == 1667 and p[:1] == b"M" and p[-1:] == b"*" and b"*" not in p[:-1] for p in recs[1::2])
+    head = bytes(t[:rb * 300].cpu().numpy().tobytes())
+    o = {"Frame": ["6"]}
+    assert bsk.Translate(frame(head, False), _Opts(o)) == oracle.translate(head, False, json.dumps(o))
+
+
+def check_rmdup(data, fastq, opts):
+    want = oracle.rmdup(data, fastq, json.dumps(opts))
+    got = bsk.RmDup(frame(data, fastq), _Opts(opts))
+    assert got == want, (opts, len(got), len(want))
+    return got
+
+
+def dup_fastq(rng, n, L=100):
+    seqs, out = [], []
+    for i in range(n):
+        if i > 5 and rng.random() < 0.3:
+            s = seqs[rng.randrange(len(seqs))]
+            if rng.random() < 0.3:
+                s = s.lower()
+        else:
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, L)))
+        seqs.append(s)
+        name = f"r{i % (n // 2) if rng.random() < 0.2 else i} c{rng.randint(0, 3)}"
+        out.append(f"@{name}\n{s}\n+\n{'I' * len(s)}\n")
+    return "".join(out).encode()
+
+
+RMDUP_OPTS = [{"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {"BySeq": True, "OnlyPositiveStrand": True},
+              {}, {"ByName": True}, {"ByName": True, "IgnoreCase": True}]
+
+
+@pytest.mark.parametrize("i", range(len(RMDUP_OPTS)))
+def test_rmdup_fastq(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(800 + i)
+    data = dup_fastq(rng, 1500)
+    got = check_rmdup(data, True, RMDUP_OPTS[i])
+    assert 0 < got.count(b"\n") // 4 < 1500
+
+
+@pytest.mark.parametrize("width", [60, 0])
+def test_rmdup_fasta(width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(31)
+    seqs, recs = [], []
+    for k in range(400):
+        s = seqs[rng.randrange(len(seqs))] if (k > 3 and rng.random() < 0.4) else \
+            "".join(rng.choice("ACGTacgt") for _ in range(rng.randint(0, 400)))
+        seqs.append(s)
+        w = width if width else max(1, len(s))
+        if k % 5 == 0 and len(s) > 3:  # same sequence, different wrapping
+            w = rng.randint(1, 30)
+        recs.append(f">s{k}\n" + "".join(s[j:j + w] + "\n" for j in range(0, len(s), w)))
+    data = "".join(recs).encode()
+    for o in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}):
+        check_rmdup(data, False, o)
+
+
+def test_rmdup_hash_matches_golden_xxh64():
+    """The survivors of `-s` are decided by XXH64 keys: feed the golden vectors as sequences."""
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxh64_vectors.json")))
+    seqs = [bytes.fromhex(v["hex"]) for v in g["vectors"]]
+    fa = b"".join(b">v%d\n%s\n" % (i, s) for i, s in enumerate(seqs + seqs[::-1]))
+    check_rmdup(fa, False, {"BySeq": True, "Config": {"LineWidth": 0}})
+
+
+def test_rmdup_option_errors():
+    for opts, msg in [({"BySeq": True, "ByName": True}, "only one/none of the flags"),
+                      ({"OnlyPositiveStrand": True}, "flag -s (--by-seq) needed")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("RmDup", json.dumps(opts), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.rmdup(b">a\nA\n", False, json.dumps(opts))
+        assert msg in str(oe.value)
+
+
+def test_rmdup_c5_synthetic_duplicates():
+    """BASELINE C5 rule: record i with i%5==4 copies an earlier sequence -> 20 % removed."""
+    import torch
+    rb, nrec = 317, 2_000_000
+    t = torch.empty(rb * nrec, dtype=torch.uint8, device="cuda")
+    assert _lib.lib.bsk_synth_device(0, 42, _lib.SYNTH_FLAG_DUPS, 0, C.c_void_p(t.data_ptr()), rb * nrec, 0, None) == 0
+    got = bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), _Opts({"BySeq": True}))
+    kept = len(got) // rb
+    assert len(got) == kept * rb and kept == nrec - nrec // 5
+    # idempotence: a second pass removes nothing
+    again = bsk.RmDup(frame(got[:rb * 50000], True), _Opts({"BySeq": True}))
+    assert again == got[:rb * 50000]
+    head = bytes(t[:rb * 30000].cpu().numpy().tobytes())
+    assert bsk.RmDup(frame(head, True), _Opts({"BySeq": True})) == oracle.rmdup(head, True, '{"BySeq": true}')
