@@ -51,7 +51,7 @@ TR_OPTS = [
 ]
 
 
-@pytest.mark.parametrize("alphabet", ["ACGT", "ACGTNRYacgtu"])
+@pytest.mark.parametrize("alphabet", ["ACGT", "ACGTNRYacgt", "ACGUNacgu"])
 @pytest.mark.parametrize("width", [60, 0, 11])
 @pytest.mark.parametrize("i", range(len(TR_OPTS)))
 def test_translate_fasta(i, width, alphabet, monkeypatch):
