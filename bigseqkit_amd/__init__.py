@@ -8,4 +8,4 @@ from ._lib import BskError, FORMAT_FASTA, FORMAT_FASTQ, lib  # noqa: F401  (fail
 from .options import (SeqKitConfig, SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions,  # noqa: F401
                       SeqKitLocateOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions)
 from .api import (SeqFrame, ReadFASTA, ReadFASTAN, ReadFASTQ, ReadFASTQN, Operator, Stats, StatsString,  # noqa: F401
-                  stats_map, Seq, build_index, Grep, GrepCount, Subseq, Translate, RmDup)
+                  stats_map, Seq, build_index, Grep, GrepCount, Subseq, Translate, RmDup, Locate)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "bsk_grep_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_grep_last_count": (_i, [_vp, _p(_u64)]),
     "bsk_subseq_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
+    "bsk_locate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_translate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_rmdup_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_synth_record_bytes": (_sz, [_i]),

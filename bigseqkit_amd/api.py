@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions
 
 
 class SeqFrame:
@@ -209,6 +209,11 @@ def GrepCount(input, o, device=0):
 def Subseq(input, o, device=0):
     """bigseqkit/subseq.go:86-100"""
     return _run_records("SubseqTransform", lib.bsk_subseq_run, input, o, device)[0]
+
+
+def Locate(input, o, device=0):
+    """bigseqkit/locate.go:122-134 (MapPartitionsWithIndex: partition 0 carries the header row)"""
+    return _run_records("Locate", lib.bsk_locate_run, input, o, device)[0]
 
 
 def Translate(input, o=None, device=0):

@@ -176,6 +176,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
             case Op::Grep: validate_grep_opts(c); break;
             case Op::Subseq: validate_subseq_opts(c); break;
             case Op::Translate: validate_translate_opts(c); break;
+            case Op::Locate: validate_locate_opts(c); break;
             case Op::RmDup: validate_rmdup_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
@@ -209,6 +210,8 @@ void bsk_destroy(bsk_ctx* c) {
         for (void* p : {(void*)c->d_text_w, (void*)c->d_lin_off, (void*)c->d_lin, (void*)c->d_codon, (void*)c->d_keys,
                         (void*)c->d_table})
             if (p) hipFree(p);
+        if (c->d_names) hipFree(c->d_names);
+        if (c->d_names_off) hipFree(c->d_names_off);
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_pat_off) hipFree(c->d_pat_off);
         for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux,
@@ -583,6 +586,12 @@ int bsk_subseq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int f
                    bsk_out* out) {
     (void)pid;
     return run_record_op(c, Op::Subseq, "SubseqTransform", subseq_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_locate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                   bsk_out* out) {
+    if (c) c->cur_pid = pid;
+    return run_record_op(c, Op::Locate, "Locate", locate_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_translate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

@@ -74,6 +74,11 @@ struct bsk_ctx {
     uint8_t* d_pat = nullptr;
     uint32_t* d_pat_off = nullptr;
     uint64_t pat_cap = 0, pat_off_cap = 0;
+    std::vector<std::string> pattern_names;  // locate: names as given (== the -p text)
+    uint8_t* d_names = nullptr;
+    uint32_t* d_names_off = nullptr;
+    uint64_t names_cap = 0, names_off_cap = 0;
+    int64_t cur_pid = 0;                   // partition index of the running Call()
     int region_start = 0, region_end = 0;  // parsed -R / -r
     bool region_on = false;
     uint64_t last_count = 0;               // grep -C result of the last run

@@ -12,6 +12,7 @@
 #include "ctx.hpp"
 #include "ops_host.hpp"
 #include "ops_grep.hpp"
+#include "ops_locate.hpp"
 #include "ops_rmdup.hpp"
 #include "ops_text.hpp"
 #include "ops_translate.hpp"
@@ -39,6 +40,8 @@ static int grow(bsk_ctx* c, T** p, uint64_t* cap, uint64_t need, uint64_t slack 
     *cap = n;
     return BSK_OK;
 }
+
+static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
 
 int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
     if (!f) return BSK_OK;
@@ -434,6 +437,129 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// locate  (Locate.Before, bigseqkit-lib/locate.go:33-193; exact patterns)
+// ---------------------------------------------------------------------------
+void validate_locate_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    bool any = !o.s("PatternFile").empty();
+    for (auto& p : o.sl("Pattern")) if (!p.empty()) any = true;
+    if (!any) throw OptError("one of flags -p (--pattern) and -f (--pattern-file) needed");  // PARITY.md Q17
+    if (o.i("MaxMismatch") > 0) {
+        if (o.b("Degenerate")) throw OptError("flag -d (--degenerate) not allowed when giving flag -m (--max-mismatch)");
+        if (o.b("UseRegexp")) throw OptError("flag -r (--use-regexp) not allowed when giving flag -m (--use-regexp)");
+    }
+    if (o.b("UseFmi")) {
+        if (o.b("Degenerate")) throw OptError("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
+        if (o.b("UseRegexp")) throw OptError("flag -r (--use-regexp) ignored when giving flag -F (--use-fmi)");
+    }
+    if (o.b("Degenerate") || o.b("UseRegexp") || o.b("UseFmi") || o.i("MaxMismatch") > 0 || !o.s("PatternFile").empty())
+        throw OptError("libbsk: degenerate (-d), regexp (-r), FM-index (-F), mismatch (-m) and pattern files (-f) are not "
+                       "supported by the HIP path yet");
+    c->patterns.clear();
+    c->pattern_names.clear();
+    for (const std::string& p : o.sl("Pattern")) {
+        if (p.empty()) continue;
+        std::string eff = p;
+        if (o.b("IgnoreCase"))
+            for (auto& ch : eff) if (ch >= 'A' && ch <= 'Z') ch += 32;
+        const uint8_t* b = (const uint8_t*)eff.data();
+        if (eff.find('.') != std::string::npos ||
+            !(alphabet_valid_letters(AB_DNAredundant, b, eff.size()) || alphabet_valid_letters(AB_RNAredundant, b, eff.size()) ||
+              alphabet_valid_letters(AB_PROTEIN, b, eff.size())))
+            throw OptError("illegal DNA/RNA/Protein sequence: " + p + ", you may switch on -d/--degenerate or -r/--use-regexp");
+        if (std::find(c->pattern_names.begin(), c->pattern_names.end(), p) != c->pattern_names.end()) continue;
+        c->pattern_names.push_back(p);
+        c->patterns.push_back(eff);
+    }
+}
+
+int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    // header row of partition 0 (locate.go:198-204)
+    std::string header;
+    const bool tsv = !(o.b("Gtf") || o.b("Bed"));
+    if (tsv && c->cur_pid == 0)
+        header = o.b("HideMatched") ? "seqID\tpatternName\tpattern\tstrand\tstart\tend\n"
+                                    : "seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched\n";
+    uint64_t total = 0, nrows = 0;
+    LocateParams P;
+    memset(&P, 0, sizeof P);
+    TextTableH tt{nullptr, nullptr, nullptr};
+    if (c->table.n > 0) {
+        Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+        if (rc != BSK_OK) return rc;
+        if (ab == AB_NONE) ab = AB_UNLIMIT;
+        rc = prepare_text(c, d_buf, format, st, &tt);
+        if (rc != BSK_OK) return rc;
+        P.fastq = format == BSK_FORMAT_FASTQ;
+        P.ignore_case = o.b("IgnoreCase");
+        P.circular = o.b("Circular");
+        P.non_greedy = o.b("NonGreedy");
+        P.both_strands = !o.b("OnlyPositiveStrand");  // sic: locate.go:669 tests the option, not the alphabet
+        P.format = o.b("Gtf") ? 2 : (o.b("Bed") ? 3 : (o.b("HideMatched") ? 1 : 0));
+        P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+        P.npat = (int)c->patterns.size();
+        std::vector<std::string> all = c->patterns;
+        for (auto& p : c->patterns) all.push_back(revcom_pattern(p, ab));
+        rc = upload_patterns(c, all, st);
+        if (rc != BSK_OK) return rc;
+        P.pat = c->d_pat;
+        P.pat_off = c->d_pat_off;
+        {
+            std::vector<uint8_t> bytes;
+            std::vector<uint32_t> off{0};
+            for (auto& p : c->pattern_names) {
+                bytes.insert(bytes.end(), p.begin(), p.end());
+                off.push_back((uint32_t)bytes.size());
+            }
+            rc = grow(c, &c->d_names, &c->names_cap, bytes.size() + 16);
+            if (rc != BSK_OK) return rc;
+            rc = grow(c, &c->d_names_off, &c->names_off_cap, off.size());
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemcpyAsync(c->d_names, bytes.data(), bytes.size(), hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipMemcpyAsync(c->d_names_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+        }
+        P.name = c->d_names;
+        P.name_off = c->d_names_off;
+        rc = ensure_record_scratch(c);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_locate(false, d_buf, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
+        HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipMemcpyAsync(&nrows, c->d_counter + 1, sizeof nrows, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        rc = kernel_error_to_status(c, status);
+        if (rc != BSK_OK) return rc;
+    } else {
+        rc = empty_result(c, out);
+        if (rc != BSK_OK) return rc;
+    }
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    if (total + header.size() == 0) return BSK_OK;
+    rc = ensure_out(c, total + header.size());
+    if (rc != BSK_OK) return rc;
+    if (!header.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_out, header.data(), header.size(), hipMemcpyHostToDevice, st));
+    if (total)
+        HIP_TRYX(c, launch_locate(true, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out + header.size(),
+                                  c->d_counter + 1, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // header lives on the host stack
+    out->d_data = c->d_out;
+    out->len = total + header.size();
+    out->records = nrows + (header.empty() ? 0 : 1);
     return BSK_OK;
 }
 

@@ -17,6 +17,8 @@ void validate_translate_opts(bsk_ctx* c);
 int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_rmdup_opts(bsk_ctx* c);
 int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
+void validate_locate_opts(bsk_ctx* c);
+int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 int ensure_out(bsk_ctx* c, uint64_t bytes);
 int ensure_record_scratch(bsk_ctx* c);
 Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc);

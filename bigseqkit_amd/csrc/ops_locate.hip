@@ -1,0 +1,232 @@
+// ============================================================================
+// ops_locate.hip -- Locate.Call, exact path (/root/reference/bigseqkit-lib/locate.go:575-767).
+// 16 lanes per record test 16 start positions at a time; the '-' strand is searched as the
+// reverse-complemented pattern on the forward text (no RevCom(seq) copy, locate.go:673) and
+// visited in the order of RevCom coordinates, so rows leave in the reference's order:
+// per record, per pattern (CLI order), '+' hits ascending, then '-' hits ascending in the
+// reverse-complement frame.  Exact matching makes the "matched" column equal to the pattern.
+// Two passes of the same kernel: row bytes per record -> scan -> rows written in place.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ops_locate.hpp"
+#include "text.cuh"
+
+namespace bsk {
+
+namespace {
+
+constexpr int GROUP = 16;
+
+__device__ __forceinline__ uint8_t lower8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
+
+__device__ __forceinline__ uint32_t dec_len(uint64_t v) {
+    uint32_t n = 0;
+    do { ++n; v /= 10; } while (v);
+    return n;
+}
+__device__ __forceinline__ uint32_t put_dec(uint8_t* o, uint64_t v) {
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    uint32_t n = 0;
+    while (k) o[n++] = (uint8_t)tmp[--k];
+    return n;
+}
+__device__ __forceinline__ uint32_t put_bytes(uint8_t* o, const uint8_t* s, uint32_t n) {
+    for (uint32_t k = 0; k < n; ++k) o[k] = s[k];
+    return n;
+}
+__device__ __forceinline__ uint32_t put_str(uint8_t* o, const char* s) {
+    uint32_t n = 0;
+    while (s[n]) { o[n] = (uint8_t)s[n]; ++n; }
+    return n;
+}
+
+struct RowCtx {
+    const uint8_t* id; uint32_t id_len;
+    const uint8_t* name; uint32_t name_len;
+    const uint8_t* pat; uint32_t pat_len;
+    int format;
+};
+
+__device__ __forceinline__ uint32_t row_len(const RowCtx& r, uint64_t begin, uint64_t end) {
+    switch (r.format) {
+        case 2:  // "%s\tSeqKit\tlocation\t%d\t%d\t0\t%c\t.\tgene_id \"%s\"; \n"
+            return r.id_len + 17 + dec_len(begin) + 1 + dec_len(end) + 3 + 2 + 2 + 9 + r.name_len + 3 + 1;
+        case 3:  // "%s\t%d\t%d\t%s\t0\t%c\n"
+            return r.id_len + 1 + dec_len(begin - 1) + 1 + dec_len(end) + 1 + r.name_len + 3 + 1 + 1;
+        default: {
+            uint32_t n = r.id_len + 1 + r.name_len + 1 + r.pat_len + 1 + 1 + 1 + dec_len(begin) + 1 + dec_len(end);
+            if (r.format == 0) n += 1 + r.pat_len;
+            return n + 1;
+        }
+    }
+}
+
+__device__ uint32_t row_put(uint8_t* o, const RowCtx& r, char strand, uint64_t begin, uint64_t end) {
+    uint32_t n = 0;
+    n += put_bytes(o + n, r.id, r.id_len);
+    if (r.format == 2) {
+        n += put_str(o + n, "\tSeqKit\tlocation\t");
+        n += put_dec(o + n, begin); o[n++] = '\t';
+        n += put_dec(o + n, end);
+        n += put_str(o + n, "\t0\t");
+        o[n++] = (uint8_t)strand;
+        n += put_str(o + n, "\t.\tgene_id \"");
+        n += put_bytes(o + n, r.name, r.name_len);
+        n += put_str(o + n, "\"; \n");
+    } else if (r.format == 3) {
+        o[n++] = '\t';
+        n += put_dec(o + n, begin - 1); o[n++] = '\t';
+        n += put_dec(o + n, end); o[n++] = '\t';
+        n += put_bytes(o + n, r.name, r.name_len);
+        n += put_str(o + n, "\t0\t");
+        o[n++] = (uint8_t)strand;
+        o[n++] = '\n';
+    } else {
+        o[n++] = '\t';
+        n += put_bytes(o + n, r.name, r.name_len); o[n++] = '\t';
+        n += put_bytes(o + n, r.pat, r.pat_len); o[n++] = '\t';
+        o[n++] = (uint8_t)strand; o[n++] = '\t';
+        n += put_dec(o + n, begin); o[n++] = '\t';
+        n += put_dec(o + n, end);
+        if (r.format == 0) { o[n++] = '\t'; n += put_bytes(o + n, r.pat, r.pat_len); }
+        o[n++] = '\n';
+    }
+    return n;
+}
+
+// does pattern pp (length m) occur at forward position f of the (possibly circular) text?
+__device__ __forceinline__ bool match_at(const Text& T, uint32_t l, bool fold, const uint8_t* pp, uint32_t m, uint64_t f) {
+    for (uint32_t q = 0; q < m; ++q) {
+        uint64_t j = f + q;
+        if (j >= l) j -= l;  // second copy of a circular text
+        uint8_t c = T.at((uint32_t)j);
+        if (fold) c = lower8(c);
+        if (c != pp[q]) return false;
+    }
+    return true;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                LocateParams P, uint32_t* __restrict__ out_len,
+                                                const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                uint64_t* __restrict__ rows) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;
+    const bool live = g < t.n;
+    const uint64_t gi = live ? g : 0;
+    const Text T = text_of(buf, t, tt, gi);
+    const uint32_t l = live ? T.L : 0;
+    const uint64_t n = P.circular ? 2ull * l : l;  // len(record.Seq.Seq) after the doubling
+    RowCtx R;
+    {
+        const uint32_t lh = t.l_head[gi];
+        const uint8_t* h = buf + t.start[gi] + 1;
+        uint32_t off;
+        R.id_len = id_span_of(h, lh > 0 ? lh - 1 : 0, P.id_mode, &off);
+        R.id = h + off;
+        R.format = P.format;
+    }
+    uint64_t bytes = 0;  // running row bytes of this record (group-uniform)
+    uint32_t nrows = 0;
+    uint8_t* o = EMIT ? out + out_off[gi] : nullptr;
+    const int nstr = P.both_strands ? 2 : 1;
+    for (int k = 0; k < P.npat; ++k) {
+        R.name = P.name + P.name_off[k];
+        R.name_len = P.name_off[k + 1] - P.name_off[k];
+        R.pat = P.pat + P.pat_off[k];
+        R.pat_len = P.pat_off[k + 1] - P.pat_off[k];
+        const uint32_t m = R.pat_len;
+        for (int strand = 0; strand < nstr; ++strand) {
+            const uint8_t* pp = P.pat + P.pat_off[strand * P.npat + k];
+            if (!live || m == 0 || m > n) continue;
+            // candidate start positions a (in the strand's own frame): a + m <= n, and a < l when circular
+            uint64_t npos = n - m + 1;
+            if (P.circular && npos > l) npos = l;
+            const char sc = strand ? '-' : '+';
+            if (!P.non_greedy) {
+                for (uint64_t a0 = 0; a0 < npos; a0 += GROUP) {
+                    const uint64_t a = a0 + gl;
+                    bool hit = false;
+                    uint64_t begin = 0, end = 0;
+                    if (a < npos) {
+                        const uint64_t f = strand ? n - a - m : a;  // forward position of the occurrence
+                        hit = match_at(T, l, P.ignore_case, pp, m, f);
+                        if (strand == 0) { begin = a + 1; end = a + m; }
+                        else {
+                            begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a;  // locate.go:698-703
+                            if (a + m > l) { begin += l; end += l; }
+                        }
+                    }
+                    const uint32_t mask = (uint32_t)((__ballot(hit) >> gshift) & 0xFFFFull);
+                    if (mask == 0) continue;
+                    uint32_t mine = hit ? row_len(R, begin, end) : 0u;
+                    // exclusive prefix of row sizes inside the group
+                    uint32_t incl = mine;
+#pragma unroll
+                    for (int d = 1; d < GROUP; d <<= 1) {
+                        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, GROUP);
+                        if ((int)gl >= d) incl += v;
+                    }
+                    const uint32_t tot = (uint32_t)__shfl((int)incl, GROUP - 1, GROUP);
+                    if (EMIT && hit) row_put(o + bytes + (incl - mine), R, sc, begin, end);
+                    bytes += tot;
+                    nrows += (uint32_t)__popc(mask);
+                }
+            } else if (gl == 0) {
+                // --non-greedy (locate.go:659-663): the search resumes one base AFTER the match end
+                uint64_t a = 0;
+                while (a < npos) {
+                    const uint64_t f = strand ? n - a - m : a;
+                    if (match_at(T, l, P.ignore_case, pp, m, f)) {
+                        uint64_t begin, end;
+                        if (strand == 0) { begin = a + 1; end = a + m; }
+                        else {
+                            begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a;
+                            if (a + m > l) { begin += l; end += l; }
+                        }
+                        if (EMIT) row_put(o + bytes, R, sc, begin, end);
+                        bytes += row_len(R, begin, end);
+                        ++nrows;
+                        a += (uint64_t)m + 1;
+                    } else {
+                        ++a;
+                    }
+                }
+            }
+        }
+    }
+    if (P.non_greedy) {  // lane 0 did the work
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)bytes, 0, GROUP);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(bytes >> 32), 0, GROUP);
+        bytes = ((uint64_t)hi << 32) | lo;
+        nrows = (uint32_t)__shfl((int)nrows, 0, GROUP);
+    }
+    if (live && gl == 0) {
+        if (!EMIT) {
+            out_len[g] = (uint32_t)bytes;  // rows of one record beyond 4 GiB are not representable
+            if (nrows) atomicAdd((unsigned long long*)rows, (unsigned long long)nrows);
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_locate(bool emit, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                         const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
+                         uint64_t* rows, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    const uint64_t blocks = (t.n * GROUP + 255) / 256;
+    if (emit) hipLaunchKernelGGL(k_locate<true>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len, out_off, out, rows);
+    else hipLaunchKernelGGL(k_locate<false>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len, out_off, out, rows);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

@@ -1,0 +1,29 @@
+// `locate`: all match positions of exact patterns, both strands, as text rows.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+#include "ops_translate.hpp"  // TextTableH
+
+namespace bsk {
+
+struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go:33-193), exact patterns
+    int fastq;
+    int ignore_case, circular, non_greedy, both_strands;
+    int format;              // 0 TSV, 1 TSV without the matched column (-M), 2 GTF, 3 BED
+    int id_mode;
+    int npat;
+    const uint8_t* pat;      // effective pattern bytes: npat forward, then npat reverse-complemented
+    const uint32_t* pat_off; // [2 * npat + 1]
+    const uint8_t* name;     // pattern names as given (npat)
+    const uint32_t* name_off;
+};
+
+// count pass: out_len[i] = bytes of all rows of record i; emit pass writes them at out_off[i]
+hipError_t launch_locate(bool emit, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                         const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
+                         uint64_t* rows, hipStream_t st);
+
+}  // namespace bsk

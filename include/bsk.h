@@ -161,6 +161,12 @@ int bsk_grep_last_count(const bsk_ctx* ctx, uint64_t* count);
 int bsk_subseq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                    bsk_out* out);
 
+/* ---- Locate (bigseqkit-lib/locate.go:19-772; exact patterns on both strands, -i, -P,
+ * --circular, -G non-greedy, TSV / -M / --gtf / --bed rows).  pid == 0 emits the header
+ * row first (locate.go:198-204), exactly as MapPartitionsWithIndex does. */
+int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                   bsk_out* out);
+
 /* ---- Translate (bigseqkit-lib/translate.go:21-145): one element per (record, frame),
  * ">Name" or ">ID_frame=N Desc" + the protein wrapped at Config.LineWidth. */
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

@@ -56,6 +56,14 @@ typedef struct {
 
 typedef struct {
     orc_kitconfig Config;
+    const char* const* Pattern;
+    int npattern;
+    int IgnoreCase, OnlyPositiveStrand, NonGreedy, Gtf, Bed, HideMatched, Circular;
+    int Degenerate, UseRegexp, UseFmi, MaxMismatch;
+} orc_locate_opts;
+
+typedef struct {
+    orc_kitconfig Config;
     int TranslTable;
     const char* const* Frame;
     int nframe;
@@ -139,6 +147,17 @@ static TranslateOptions conv(const orc_translate_opts& c) {
     o.Trim = c.Trim; o.Clean = c.Clean; o.AllowUnknownCodon = c.AllowUnknownCodon; o.InitCodonAsM = c.InitCodonAsM;
     o.ListTranslTable = c.ListTranslTable; o.ListTranslTableWithAmbCodons = c.ListTranslTableWithAmbCodons;
     o.AppendFrame = c.AppendFrame;
+    return o;
+}
+
+static LocateOptions conv(const orc_locate_opts& c) {
+    LocateOptions o;
+    o.Config = conv(c.Config);
+    o.Pattern.clear();
+    for (int i = 0; i < c.npattern; ++i) o.Pattern.push_back(c.Pattern[i]);
+    o.IgnoreCase = c.IgnoreCase; o.OnlyPositiveStrand = c.OnlyPositiveStrand; o.NonGreedy = c.NonGreedy;
+    o.Gtf = c.Gtf; o.Bed = c.Bed; o.HideMatched = c.HideMatched; o.Circular = c.Circular;
+    o.Degenerate = c.Degenerate; o.UseRegexp = c.UseRegexp; o.UseFmi = c.UseFmi; o.MaxMismatch = c.MaxMismatch;
     return o;
 }
 
@@ -327,6 +346,24 @@ int orc_rmdup(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, 
     (void)nparts;
     RmDupOptions so = conv(*o);
     return run_parts(buf, n, fastq, so, 1, rmdup_call, false, out, cap, nout, nrec, err, errcap);
+}
+
+// Locate over nparts partitions: MapPartitionsWithIndex, the header row comes from partition 0
+int orc_locate(const uint8_t* buf, size_t n, int fastq, const orc_locate_opts* o, int nparts, uint8_t* out, size_t cap,
+               size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        if (nparts < 1) nparts = 1;
+        LocateOptions so = conv(*o);
+        std::vector<std::string> all;
+        for (int p = 0; p < nparts; ++p) {
+            size_t a = recs.size() * (size_t)p / (size_t)nparts, b = recs.size() * (size_t)(p + 1) / (size_t)nparts;
+            std::vector<std::string_view> part(recs.begin() + a, recs.begin() + b);
+            auto r = locate_call(part, so, p);
+            all.insert(all.end(), r.begin(), r.end());
+        }
+        return emit(all, out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
 }
 
 uint64_t orc_xxh64(const uint8_t* p, size_t n) { return xxh64(p, n, 0); }

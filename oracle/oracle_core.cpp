@@ -841,6 +841,97 @@ std::vector<std::string> translate_call(const std::vector<std::string_view>& par
 }
 
 // ---------------------------------------------------------------------------
+// Locate  bigseqkit-lib/locate.go (exact patterns: no -d, -r, -m, -F, -f)
+// ---------------------------------------------------------------------------
+std::vector<std::string> locate_call(const std::vector<std::string_view>& part, const LocateOptions& o, int64_t pid) {
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    bool any = !o.PatternFile.empty();
+    for (auto& p : o.Pattern) if (!p.empty()) any = true;
+    if (!any) throw Error("one of flags -p (--pattern) and -f (--pattern-file) needed");  // PARITY.md Q17
+    if (o.MaxMismatch > 0) {
+        if (o.Degenerate) throw Error("flag -d (--degenerate) not allowed when giving flag -m (--max-mismatch)");
+        if (o.UseRegexp) throw Error("flag -r (--use-regexp) not allowed when giving flag -m (--use-regexp)");
+    }
+    if (o.UseFmi) {
+        if (o.Degenerate) throw Error("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
+        if (o.UseRegexp) throw Error("flag -r (--use-regexp) ignored when giving flag -F (--use-fmi)");
+    }
+    if (o.Degenerate || o.UseRegexp || o.UseFmi || o.MaxMismatch > 0 || !o.PatternFile.empty())
+        throw Error("oracle: degenerate / regexp / FM-index / mismatch / pattern-file locate is not restated");
+    std::vector<std::pair<std::string, std::string>> pats;  // (name, bytes) in CLI order (PARITY.md Q11)
+    for (auto& p : o.Pattern) {
+        if (p.empty()) continue;
+        std::string eff = o.IgnoreCase ? lower(p) : p;
+        if (eff.find('.') != std::string::npos ||
+            !(alphabet_is_valid(AB_DNAredundant, eff) || alphabet_is_valid(AB_RNAredundant, eff) || alphabet_is_valid(AB_PROTEIN, eff)))
+            throw Error("illegal DNA/RNA/Protein sequence: " + p + ", you may switch on -d/--degenerate or -r/--use-regexp");
+        bool dup = false;
+        for (auto& q : pats) if (q.first == p) dup = true;
+        if (!dup) pats.emplace_back(p, eff);
+    }
+    std::vector<std::string> result;
+    if (!(o.Gtf || o.Bed) && pid == 0)  // locate.go:198-204
+        result.push_back(o.HideMatched ? "seqID\tpatternName\tpattern\tstrand\tstart\tend"
+                                       : "seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched");
+    SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    auto row = [&](const Record& r, const std::pair<std::string, std::string>& pt, char strand, long begin, long end,
+                   const std::string& matched) {
+        char b[64];
+        std::string s;
+        if (o.Gtf) {
+            snprintf(b, sizeof b, "%ld\t%ld\t%d\t%c\t", begin, end, 0, strand);
+            s = r.id + "\tSeqKit\tlocation\t" + b + ".\tgene_id \"" + pt.first + "\"; ";
+        } else if (o.Bed) {
+            snprintf(b, sizeof b, "\t%ld\t%ld\t", begin - 1, end);
+            s = r.id + b + pt.first + "\t0\t" + strand;
+        } else {
+            snprintf(b, sizeof b, "%c\t%ld\t%ld", strand, begin, end);
+            s = r.id + "\t" + pt.first + "\t" + pt.second + "\t" + b;
+            if (!o.HideMatched) s += "\t" + matched;
+        }
+        result.push_back(s);
+    };
+    while (rd.Read()) {
+        Record& r = rd.rec;
+        if (o.IgnoreCase) r.seq = lower(r.seq);  // locate.go:424-426
+        const long l = (long)r.seq.size();
+        if (o.Circular) r.seq += r.seq;
+        const long n = (long)r.seq.size();
+        for (auto& pt : pats) {
+            const std::string& p = pt.second;
+            const long lp = (long)p.size();
+            long offset = 0;
+            for (;;) {  // locate.go:583-667
+                size_t f = r.seq.find(p, (size_t)offset);
+                if (f == std::string::npos) break;
+                const long i = (long)f - offset;
+                const long begin = offset + i + 1;
+                if (o.Circular && begin > l) break;
+                const long end = offset + i + lp;
+                row(r, pt, '+', begin, end, r.seq.substr((size_t)begin - 1, (size_t)(end - begin + 1)));
+                offset = o.NonGreedy ? offset + i + lp + 1 : offset + i + 1;
+                if (offset >= n) break;
+            }
+            if (o.OnlyPositiveStrand) continue;  // sic: the protein/unlimit auto-switch is not consulted here
+            const std::string rp = rev_com(r.seq, rd.GetAlphabet());
+            offset = 0;
+            for (;;) {  // locate.go:679-766
+                size_t f = rp.find(p, (size_t)offset);
+                if (f == std::string::npos) break;
+                const long i = (long)f - offset;
+                if (o.Circular && offset + i + 1 > l) break;
+                long begin = l - offset - (i + lp) + 1, end = l - offset - i;
+                if (offset + i + lp > l) { begin += l; end += l; }
+                row(r, pt, '-', begin, end, rp.substr((size_t)(offset + i), (size_t)lp));
+                offset = o.NonGreedy ? offset + i + lp + 1 : offset + i + 1;
+                if (offset >= n) break;
+            }
+        }
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------
 // XXH64 (public algorithm; cespare/xxhash/v2 Sum64 == XXH64 with seed 0),
 // pinned by tests/golden/xxh64_vectors.json
 // ---------------------------------------------------------------------------

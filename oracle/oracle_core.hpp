@@ -183,6 +183,20 @@ std::vector<std::string> translate_call(const std::vector<std::string_view>& par
 std::string translate_seq(const std::string& seq, int table, int frame, bool trim, bool clean, bool allow_unknown,
                           bool init_m, bool* unknown);
 
+struct LocateOptions {  // bigseqkit/locate.go:9-45
+    KitConfig Config;
+    std::vector<std::string> Pattern = {""};
+    std::string PatternFile;
+    bool Degenerate = false, UseRegexp = false, UseFmi = false, IgnoreCase = false, OnlyPositiveStrand = false;
+    int ValidateSeqLength = 10000;
+    bool NonGreedy = false, Gtf = false, Bed = false;
+    int MaxMismatch = 0;
+    bool HideMatched = false, Circular = false;
+};
+// Locate.Before + Call, exact patterns  bigseqkit-lib/locate.go:33-193, 195-204, 392-772
+// rows WITHOUT their trailing newline (PARITY.md Q6); header row when pid == 0
+std::vector<std::string> locate_call(const std::vector<std::string_view>& part, const LocateOptions& o, int64_t pid);
+
 struct RmDupOptions {  // bigseqkit/rmdup.go:13-33
     KitConfig Config;
     bool ByName = false, BySeq = false, IgnoreCase = false, OnlyPositiveStrand = false;

@@ -37,6 +37,12 @@ class SubseqOpts(C.Structure):
                 ("OnlyFlank", C.c_int), ("Gtf", C.c_char_p), ("Bed", C.c_char_p)]
 
 
+class LocateOpts(C.Structure):
+    _fields_ = [("Config", KitConfig), ("Pattern", C.POINTER(C.c_char_p)), ("npattern", C.c_int)] + \
+               [(k, C.c_int) for k in ("IgnoreCase", "OnlyPositiveStrand", "NonGreedy", "Gtf", "Bed", "HideMatched",
+                                       "Circular", "Degenerate", "UseRegexp", "UseFmi", "MaxMismatch")]
+
+
 class TranslateOpts(C.Structure):
     _fields_ = [("Config", KitConfig), ("TranslTable", C.c_int), ("Frame", C.POINTER(C.c_char_p)), ("nframe", C.c_int)] + \
                [(k, C.c_int) for k in ("Trim", "Clean", "AllowUnknownCodon", "InitCodonAsM", "ListTranslTable",
@@ -125,6 +131,24 @@ def subseq_opts(opts_json):
 
 def subseq(data, fastq, opts_json="{}", nparts=1):
     return _run_text(_lib.orc_subseq, data, fastq, subseq_opts(opts_json), nparts)[0]
+
+
+def locate_opts(opts_json):
+    """defaults per /root/reference/bigseqkit/locate.go:27-45"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    b = lambda k: int(bool(g(k, False)))
+    pats = [p.encode() for p in g("Pattern", [""])]
+    arr = (C.c_char_p * max(1, len(pats)))(*pats)
+    o = LocateOpts(_cfg(d), arr, len(pats), b("IgnoreCase"), b("OnlyPositiveStrand"), b("NonGreedy"), b("Gtf"),
+                   b("Bed"), b("HideMatched"), b("Circular"), b("Degenerate"), b("UseRegexp"), b("UseFmi"),
+                   g("MaxMismatch", 0))
+    o._keep = (arr, pats)
+    return o
+
+
+def locate(data, fastq, opts_json="{}", nparts=1):
+    return _run_text(_lib.orc_locate, data, fastq, locate_opts(opts_json), nparts)[0]
 
 
 def translate_opts(opts_json):

@@ -52,7 +52,8 @@ def test_options_json_defaults_match_reference_schema():
 @pytest.mark.parametrize("name,cls,probe", [
     ("SeqTransform", bsk.SeqKitSeqOptions, {"GapLetters": "- \t.", "MinLen": -1, "MaxQual": -1, "QualAsciiBase": 33}),
     ("Grep", lambda: bsk.SeqKitGrepOptions().Pattern(["id1"]), {"Pattern": ["id1"], "MaxMismatch": 0, "Region": ""}),
-    ("Locate", bsk.SeqKitLocateOptions, {"Pattern": [""], "ValidateSeqLength": 10000, "NonGreedy": False}),
+    ("Locate", lambda: bsk.SeqKitLocateOptions().Pattern(["ACGT"]),
+     {"Pattern": ["ACGT"], "ValidateSeqLength": 10000, "NonGreedy": False}),
     ("SubseqTransform", lambda: bsk.SeqKitSubseqOptions().Region("1:2"),
      {"Chr": [], "Feature": [], "UpStream": 0, "GtfTag": "", "Region": "1:2"}),
     ("Translate", bsk.SeqKitTranslateOptions, {"TranslTable": 1, "Frame": ["1"], "ListTranslTable": -1}),

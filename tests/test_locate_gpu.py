@@ -1,0 +1,109 @@
+"""Parity of `locate` (exact patterns) against the CPU oracle, through the C ABI."""
+import json
+import random
+
+import pytest
+
+import oracle
+import seqgen
+import bigseqkit_amd as bsk
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(data):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    return t.cuda()
+
+
+class _Opts:
+    def __init__(self, d):
+        self.d = dict(d)
+        self._v = self.d
+
+    def to_json(self):
+        return json.dumps(self.d)
+
+
+def check(data, fastq, opts):
+    fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+    want = oracle.locate(data, fastq, json.dumps(opts))
+    got = bsk.Locate(bsk.SeqFrame(fmt, [dev(data)]), _Opts(opts))
+    assert got == want, (opts, got[:400], want[:400])
+    return got
+
+
+def test_locate_hand_cases_overlap_and_strands():
+    fa = b">s1 d\nAAAATTTTGGAAAA\n>s2\nACGTTGCAAGCT\n"
+    got = check(fa, False, {"Pattern": ["AA"]})
+    assert got.startswith(b"seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched\ns1\tAA\tAA\t+\t1\t2\tAA\n")
+    assert b"s1\tAA\tAA\t-\t7\t8\tAA\n" in got
+    check(fa, False, {"Pattern": ["AA"], "NonGreedy": True})
+    check(fa, False, {"Pattern": ["AA"], "NonGreedy": True, "OnlyPositiveStrand": True, "HideMatched": True})
+    check(fa, False, {"Pattern": ["AAAA", "TGCA"], "Bed": True})
+    check(fa, False, {"Pattern": ["AAAA", "TGCA", "AAAA"], "Gtf": True})
+    check(fa, False, {"Pattern": ["aaaa"], "IgnoreCase": True})
+    check(fa, False, {"Pattern": ["AAAAAAAA"], "Circular": True})
+    check(fa, False, {"Pattern": ["GCTAC"], "Circular": True})   # wraps around the end of s2
+    check(b"", False, {"Pattern": ["AA"]})
+
+
+LOC_OPTS = [
+    {"Pattern": ["ACG"]},
+    {"Pattern": ["ACG", "TTT", "GGCC"], "HideMatched": True},
+    {"Pattern": ["AAA"], "NonGreedy": True},
+    {"Pattern": ["ACGT"], "Circular": True},
+    {"Pattern": ["ACGT"], "Circular": True, "NonGreedy": True, "Bed": True},
+    {"Pattern": ["acg", "TTt"], "IgnoreCase": True, "Gtf": True},
+    {"Pattern": ["TGCATG"], "OnlyPositiveStrand": True},
+    {"Pattern": ["A" * 40]},
+    {"Pattern": ["NNN", "RY"], "Config": {"SeqType": "dna"}},
+]
+
+
+@pytest.mark.parametrize("i", range(len(LOC_OPTS)))
+def test_locate_fastq(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(900 + i)
+    data = seqgen.random_fastq(rng, 400, 0, 120, alphabet="ACGTNacgt")
+    check(data, True, LOC_OPTS[i])
+
+
+@pytest.mark.parametrize("width", [60, 0, 7])
+@pytest.mark.parametrize("i", range(len(LOC_OPTS)))
+def test_locate_fasta(i, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(950 + i)
+    data = seqgen.random_fasta(rng, 120, 0, 500, width=width, alphabet="ACGTacgtN", final_newline=i % 2 == 0)
+    check(data, False, LOC_OPTS[i])
+
+
+def test_locate_protein_minus_strand_is_searched_as_written():
+    # locate.go:669 consults the option, not the guessed alphabet: the reverse of a protein is searched too
+    prot = b">p\nMKVLAAGIVKM\n"
+    got = check(prot, False, {"Pattern": ["MK"]})
+    assert b"\t-\t" in got
+
+
+def test_locate_option_errors():
+    for opts, msg in [({}, "one of flags -p (--pattern) and -f (--pattern-file) needed"),
+                      ({"Pattern": ["AC.T"]}, "illegal DNA/RNA/Protein sequence: AC.T, you may switch on"),
+                      ({"Pattern": ["AC!"]}, "illegal DNA/RNA/Protein sequence: AC!")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("Locate", json.dumps(opts), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.locate(b">a\nA\n", False, json.dumps(opts))
+        assert msg in str(oe.value)
+
+
+def test_locate_header_only_on_partition_zero():
+    rng = random.Random(3)
+    data = seqgen.random_fastq(rng, 300, 10, 80, alphabet="ACGT")
+    fr = bsk.ReadFASTQN(data, 3)
+    assert len(fr.shards) == 3
+    fr = bsk.SeqFrame(fr.format, [dev(s) for s in fr.shards])
+    got = bsk.Locate(fr, _Opts({"Pattern": ["ACG"]}))
+    assert got == oracle.locate(data, True, '{"Pattern": ["ACG"]}', nparts=1)
+    assert got.count(b"seqID\t") == 1
