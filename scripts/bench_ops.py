@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Secondary measurements (1 GPU, HBM-resident): the other hot-path commands at the sizes of
+BASELINE.json configs 2-5 (per-GPU shard where the config is an 8-GPU one).  Prints one JSON
+object; algorithmic bytes per BASELINE.md section 4.  Not the driver's bench (that is bench.py)."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bigseqkit_amd as bsk
+from bigseqkit_amd import _lib
+from bigseqkit_amd._lib import lib, check
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+
+
+def synth(kind, flags, nbytes):
+    rb = lib.bsk_synth_record_bytes(kind)
+    n = int(nbytes) // rb * rb
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    check(lib.bsk_synth_device(kind, 42, flags, 0, C.c_void_p(t.data_ptr()), n, 0, None))
+    torch.cuda.synchronize()
+    return t, n // rb
+
+
+def run(op_name, fn, opts, t, fmt):
+    out = _lib.Out()
+    with bsk.Operator(op_name, json.dumps(opts), 0) as op:
+        check(fn(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, fmt, 0, None, C.byref(out)), op.ctx)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            check(fn(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, fmt, 0, None, C.byref(out)), op.ctx)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        return dt, out.len, out.records
+
+
+res = {}
+
+
+def report(name, nrec, in_bytes, dt, out_len, note=""):
+    alg = in_bytes + out_len
+    res[name] = {"records": nrec, "in_GB": round(in_bytes / 1e9, 2), "out_GB": round(out_len / 1e9, 3),
+                 "ms": round(dt * 1e3, 2), "M_records_per_s": round(nrec / dt / 1e6, 1),
+                 "algorithmic_GBps": round(alg / dt / 1e9, 1), "frac_of_8TBps": round(alg / dt / 8e12, 4), "note": note}
+
+
+# C2: seq -n on 100 GB FASTQ-150
+t, nrec = synth(0, 0, 100e9 * scale)
+dt, ol, k = run("SeqTransform", lib.bsk_seq_run, {"Name": True}, t, 1)
+assert ol == 12 * nrec
+report("seq -n (C2, 100 GB FASTQ)", nrec, t.numel(), dt, ol)
+dt, ol, k = run("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, t[:317 * (nrec // 4)], 1)
+report("subseq -r 1:50 (25 GB FASTQ)", nrec // 4, 317 * (nrec // 4), dt, ol)
+del t
+# C3: grep -s -p motif, one GPU's 12.5 GB shard
+t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)
+dt, ol, k = run("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t, 1)
+report("grep -s -p 12-mer (C3 shard, 12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "hits=%d" % k)
+dt, ol, k = run("Locate", lib.bsk_locate_run, {"Pattern": ["ACGTTGCAAGCT"]}, t, 1)
+report("locate -p 12-mer (12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "rows=%d" % k)
+del t
+# C5: rmdup -s, one GPU's 25 GB shard
+t, nrec = synth(0, _lib.SYNTH_FLAG_DUPS, 25e9 * scale)
+dt, ol, k = run("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, 1)
+assert k == nrec - nrec // 5
+report("rmdup -s (C5 shard, 25 GB FASTQ, 20% dups)", nrec, t.numel(), dt, ol, "survivors=%d" % k)
+del t
+# C4: translate --frame 6 on 50 GB FASTA (5 kb CDS)
+t, nrec = synth(2, 0, 50e9 * scale)
+dt, ol, k = run("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, 0)
+report("translate -f 6 (C4, 50 GB FASTA-5k)", nrec, t.numel(), dt, ol)
+del t
+print(json.dumps(res))
