@@ -37,7 +37,7 @@ def main():
     import torch
     import torch.distributed as dist
     import bigseqkit_amd as bsk
-    from bigseqkit_amd import _lib
+    from bigseqkit_amd import _lib, dist as bdist
     from bigseqkit_amd._lib import lib, check
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,8 +79,7 @@ def main():
         vec.zero_()
         check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nbytes, 1, bsk.FORMAT_FASTQ, rank,
                                 C.c_void_p(vec.data_ptr()), st), op.ctx)
-        if world > 1:
-            dist.all_reduce(vec)  # StatsReduce: sum of the dense maps (RCCL)
+        bdist.all_reduce_stats_vector(vec)  # StatsReduce: one sum all-reduce of the dense map (RCCL), no-op at N=1
         m = bsk.api._collect_map(op, C.c_void_p(vec.data_ptr()))
         info = bsk.api._finalize(op, m)
         buf = C.create_string_buffer(4096)

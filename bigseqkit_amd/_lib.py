@@ -79,6 +79,7 @@ SIGNATURES = {
     "bsk_stats_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _vp]),
     "bsk_stats_reset": (_i, [_vp, _vp]),
     "bsk_stats_collect": (_i, [_vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
+    "bsk_stats_collect_host": (_i, [_vp, _p(_u64), _sz, _vp, _sz, _i, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_stats_merge": (_i, [_p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_stats_finalize": (_i, [_vp, _p(_i64), _p(_i64), _sz, _p(StatInfo)]),
     "bsk_stats_string": (_i, [_vp, C.c_char_p, C.c_char_p, _p(StatInfo), C.c_char_p, _sz]),

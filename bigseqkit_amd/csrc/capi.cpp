@@ -372,31 +372,12 @@ static std::string describe_kernel_errors(uint64_t f, int* code) {
     return "unknown kernel error";
 }
 
-int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
-    if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
-    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
-    if (!n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_out");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipDeviceSynchronize());
-    uint64_t status[2];
-    HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
-    if (status[0]) {
-        int code;
-        std::string m = describe_kernel_errors(status[0], &code);
-        return fail(c, code, m);
-    }
-    const size_t len = (size_t)STATS_HDR + c->hist_cap;
-    std::vector<uint64_t> v(len);
-    HIP_TRY(c, hipMemcpy(v.data(), d_vec ? d_vec : (const void*)c->d_vec, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
+static int stats_vector_to_map(bsk_ctx* c, const std::vector<uint64_t>& v, const std::vector<uint64_t>& overflow,
+                               int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
     StatsMap m;
     for (uint32_t L = 0; L < c->hist_cap; ++L)
         if (v[STATS_HDR + L]) m[(int64_t)L] = (int64_t)v[STATS_HDR + L];
-    if (status[1]) {
-        if (status[1] > c->overflow_cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow length list exhausted");
-        std::vector<uint64_t> ov(status[1]);
-        HIP_TRY(c, hipMemcpy(ov.data(), c->d_overflow, status[1] * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        for (uint64_t L : ov) m[(int64_t)L] += 1;
-    }
+    for (uint64_t L : overflow) m[(int64_t)L] += 1;
     const bool all = c->opts.b("All");
     const uint64_t nrec = v[3];
     if (all && nrec > 0) {
@@ -434,6 +415,45 @@ int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* val
         ++i;
     }
     return BSK_OK;
+}
+
+int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
+    if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    if (!n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_out");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    uint64_t status[2];
+    HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+    if (status[0]) {
+        int code;
+        std::string m = describe_kernel_errors(status[0], &code);
+        return fail(c, code, m);
+    }
+    const size_t len = (size_t)STATS_HDR + c->hist_cap;
+    std::vector<uint64_t> v(len);
+    HIP_TRY(c, hipMemcpy(v.data(), d_vec ? d_vec : (const void*)c->d_vec, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> ov;
+    if (status[1]) {
+        if (status[1] > c->overflow_cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow length list exhausted");
+        ov.resize(status[1]);
+        HIP_TRY(c, hipMemcpy(ov.data(), c->d_overflow, status[1] * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return stats_vector_to_map(c, v, ov, keys, vals, cap, n_out);
+}
+
+int bsk_stats_collect_host(bsk_ctx* c, const uint64_t* h_vec, size_t vec_len, const uint8_t* first_record,
+                           size_t first_len, int format, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
+    if (!c || c->op != Op::Stats || !h_vec || !n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    if (vec_len != (size_t)STATS_HDR + c->hist_cap) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: wrong stats vector length");
+    if (first_record && first_len) {
+        c->first_bytes.assign(first_record, first_record + first_len);
+        c->first_bytes.push_back((uint8_t)'\n');
+        c->first_format = format;
+        c->first_pid = 0;
+    }
+    std::vector<uint64_t> v(h_vec, h_vec + vec_len);
+    return stats_vector_to_map(c, v, {}, keys, vals, cap, n_out);
 }
 
 int bsk_stats_merge(const int64_t* ka, const int64_t* va, size_t na, const int64_t* kb, const int64_t* vb, size_t nb,

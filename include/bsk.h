@@ -105,6 +105,11 @@ int bsk_stats_reset(bsk_ctx* ctx, void* stream); /* zero the ctx-owned vector */
  * into the reference's map form, sorted by key.  Key -4 is computed from the
  * first record seen by this ctx (bigseqkit-lib/stats.go:106-114). */
 int bsk_stats_collect(bsk_ctx* ctx, const void* d_vec, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out);
+/* Same conversion for a stats vector that already lives in HOST memory (e.g. after a
+ * reduction done elsewhere); needs no device.  first_record (may be NULL) is the text of
+ * the first record of partition 0, used for the type column exactly like Take(1). */
+int bsk_stats_collect_host(bsk_ctx* ctx, const uint64_t* h_vec, size_t vec_len, const uint8_t* first_record,
+                           size_t first_len, int format, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out);
 /* StatsReduce.Call on two host maps (sums; PARITY.md Q2) */
 int bsk_stats_merge(const int64_t* ka, const int64_t* va, size_t na, const int64_t* kb, const int64_t* vb, size_t nb,
                     int64_t* keys, int64_t* vals, size_t cap, size_t* n_out);

@@ -1,0 +1,113 @@
+"""The N>1 path on CPU: world_size 2 over gloo.  Record-aligned shard cutting and the two
+reductions of the hot path (StatsReduce as one all-reduce of the dense stats vector,
+GrepReduceCount as one int64).  The per-shard maps come from the oracle here (no GPU in this
+container); on the GPU box the same vectors come out of k_stats (tests -m gpu, bench.py)."""
+import ctypes as C
+import json
+import os
+import random
+import socket
+
+import pytest
+
+import oracle
+import seqgen
+import bigseqkit_amd as bsk
+from bigseqkit_amd import _lib, dist as bdist
+from bigseqkit_amd._lib import lib
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, data, fastq, opts, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+        lo, hi = bdist.shard_bounds(data, world, fmt)[rank]
+        shard = data[lo:hi]
+        op = bsk.Operator("Stats", json.dumps(opts), -1)
+        vlen = lib.bsk_stats_vector_len(op.ctx)
+        # dense stats vector of this rank's shard (layout of include/bsk.h)
+        m = oracle.stats_map(shard, fastq, json.dumps(opts))
+        vec = torch.zeros(vlen, dtype=torch.int64)
+        nrec = 0
+        for k, v in m.items():
+            if k >= 0:
+                vec[_lib.STATS_HDR + k] = v
+                nrec += v
+        vec[0], vec[1], vec[2], vec[3] = m.get(-1, 0), m.get(-2, 0), m.get(-3, 0), nrec
+        bdist.all_reduce_stats_vector(vec)
+        # grep -C on the same shards
+        gopts = {"BySeq": True, "Pattern": ["ACG"], "Count": True}
+        cnt = int(oracle.grep(shard, fastq, json.dumps(gopts))) if len(shard) else 0
+        total = bdist.all_reduce_count(cnt)
+        if rank == 0:
+            first = oracle.record_spans(data, fastq)
+            fr = data[first[0][0]:first[0][0] + first[0][1]] if first else b""
+            h = (C.c_uint64 * vlen)(*[int(x) for x in vec.tolist()])
+            keys, vals, n = (C.c_int64 * 4096)(), (C.c_int64 * 4096)(), C.c_size_t()
+            rc = lib.bsk_stats_collect_host(op.ctx, h, vlen, fr, len(fr), fmt, keys, vals, 4096, C.byref(n))
+            assert rc == 0, lib.bsk_last_error(op.ctx)
+            got = dict(zip(keys[:n.value], vals[:n.value]))
+            info = _lib.StatInfo()
+            assert lib.bsk_stats_finalize(op.ctx, keys, vals, n.value, C.byref(info)) == 0
+            out = C.create_string_buffer(4096)
+            assert lib.bsk_stats_string(op.ctx, b"input0", b"N/A", C.byref(info), out, 4096) == 0
+            q.put((got, out.value.decode(), total, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fastq", [True, False])
+def test_two_ranks_gloo_stats_and_grep_count(fastq):
+    import torch.multiprocessing as mp
+    rng = random.Random(21 + fastq)
+    data = seqgen.random_fastq(rng, 500, 0, 120) if fastq else seqgen.random_fasta(rng, 300, 0, 400, gt_in_header=True)
+    opts = {"All": True, "Tabular": True}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, data, fastq, opts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, text, total, (lo, hi) = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert 0 < hi < len(data)  # a real cut
+    assert got == oracle.stats_map(data, fastq, json.dumps(opts))
+    assert text == oracle.stats_string(data, fastq, json.dumps(opts))
+    assert total == int(oracle.grep(data, fastq, json.dumps({"BySeq": True, "Pattern": ["ACG"], "Count": True})))
+
+
+def test_shard_bounds_are_record_aligned_and_cover_the_file():
+    rng = random.Random(5)
+    for fastq in (True, False):
+        data = seqgen.random_fastq(rng, 300, 0, 90) if fastq else seqgen.random_fasta(rng, 200, 0, 300)
+        starts = {s for s, _ in oracle.record_spans(data, fastq)} | {len(data)}
+        for world in (1, 2, 3, 8):
+            b = bdist.shard_bounds(data, world, int(fastq))
+            assert b[0][0] == 0 and b[-1][1] == len(data)
+            assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert all(lo in starts for lo, _ in b)
+            # per-shard results reduce to the whole (StatsReduce sums, PARITY.md Q2)
+            whole = oracle.stats_map(data, fastq, '{"All": true}')
+            acc = {}
+            for lo, hi in b:
+                for k, v in oracle.stats_map(data[lo:hi], fastq, '{"All": true}').items():
+                    if k != -4:
+                        acc[k] = acc.get(k, 0) + v
+            acc[-4] = whole[-4]
+            if -3 not in whole:
+                acc.pop(-3, None)
+            assert {k: v for k, v in acc.items() if v or k in whole} == whole
