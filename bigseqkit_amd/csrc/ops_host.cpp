@@ -742,15 +742,31 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     P.init_m = o.b("InitCodonAsM"); P.append_frame = o.b("AppendFrame");
     P.line_width = (int)o.ci("LineWidth");
     P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 8192));
+    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 4 * 4096 + 256));
     {
-        std::vector<uint8_t> tab(8192);
-        build_codon_tables(*find_code((int)o.i("TranslTable")), tab.data(), tab.data() + 4096);
-        HIP_TRYX(c, hipMemcpyAsync(c->d_codon, tab.data(), 8192, hipMemcpyHostToDevice, st));
+        std::vector<uint8_t> tab(4 * 4096 + 256);
+        uint8_t *fw = tab.data(), *stt = fw + 4096, *rcw = fw + 8192, *rcs = fw + 12288, *iu = fw + 16384;
+        build_codon_tables(*find_code((int)o.i("TranslTable")), fw, stt);
+        auto comp = [](int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); };
+        for (int c0 = 0; c0 < 16; ++c0)
+            for (int c1 = 0; c1 < 16; ++c1)
+                for (int c2 = 0; c2 < 16; ++c2) {
+                    const int i = (c0 << 8) | (c1 << 4) | c2, r = (comp(c2) << 8) | (comp(c1) << 4) | comp(c0);
+                    rcw[i] = fw[r];
+                    rcs[i] = stt[r];
+                }
+        memset(iu, 0, 256);
+        const char* letters = "acgturyswkmbdhvn";
+        const int codes[] = {1, 2, 4, 8, 8, 5, 10, 6, 9, 12, 3, 14, 13, 11, 7, 15};
+        for (int k = 0; letters[k]; ++k) { iu[(uint8_t)letters[k]] = (uint8_t)codes[k]; iu[(uint8_t)(letters[k] - 32)] = (uint8_t)codes[k]; }
+        HIP_TRYX(c, hipMemcpyAsync(c->d_codon, tab.data(), tab.size(), hipMemcpyHostToDevice, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
     }
     P.codon = c->d_codon;
     P.start = c->d_codon + 4096;
+    P.codon_rc = c->d_codon + 8192;
+    P.start_rc = c->d_codon + 12288;
+    P.iupac = c->d_codon + 16384;
     // per-element scratch: nframes elements per record
     const uint64_t ne = c->table.n * (uint64_t)P.nframes;
     const uint64_t saved_n = c->table.n;
@@ -765,7 +781,18 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     HIP_TRYX(c, hipStreamSynchronize(st));
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_translate_emit(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status, st));
+    {
+        // wave per record for long sequences, 16 lanes per record for reads; BSK_TRANSLATE=legacy keeps
+        // the per-(record, frame) kernel (used by tests to cross-check the two implementations)
+        const char* mode = getenv("BSK_TRANSLATE");
+        if (mode && strcmp(mode, "legacy") == 0) {
+            HIP_TRYX(c, launch_translate_emit(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status, st));
+        } else {
+            const uint64_t avg = n / std::max<uint64_t>(1, c->table.n);
+            HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
+                                                c->d_out, c->d_status, st));
+        }
+    }
     uint64_t status = 0;
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));

@@ -188,6 +188,159 @@ __global__ __launch_bounds__(256) void k_translate_emit(const uint8_t* __restric
     if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
 }
 
+
+// ---------------------------------------------------------------------------
+// k_translate_frames<G>: G lanes per record, every base read once.
+// A window is G x 48 bases (a multiple of 3, so base k of a lane always belongs to forward
+// frame (k % 3) + 1).  Bases -> 4-bit IUPAC codes via an LDS table, codes staged in LDS,
+// then every position q yields two amino acids from the same three codes:
+//   forward frame (q % 3) + 1, index q / 3            -> s_fw[c0 c1 c2]
+//   reverse frame -(((L-3-q) % 3) + 1), index (L-3-q)/3 -> s_rc[c0 c1 c2]  (table of the
+//   reverse-complemented codon, so the reverse complement is never formed)
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                          TranslateParams P, const uint32_t* __restrict__ out_len,
+                                                          const uint64_t* __restrict__ out_off,
+                                                          uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
+    constexpr int WIN = G * 48;
+    constexpr int NG = 256 / G;
+    __shared__ uint8_t s_fw[4096];
+    __shared__ uint8_t s_rc[4096];
+    __shared__ uint8_t s_iu[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_codes[NG][WIN + 16];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) { s_fw[i] = P.codon[i]; s_rc[i] = P.codon_rc[i]; }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
+    __syncthreads();
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint32_t gl = threadIdx.x % G;
+    if (g >= t.n) return;  // no block-level barrier below
+    uint8_t* codes = s_codes[threadIdx.x / G];
+    const Text T = text_of(buf, t, tt, g);
+    const uint32_t L = T.L;
+    const uint8_t* h = buf + t.start[g] + 1;
+    const uint32_t lh = t.l_head[g];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
+
+    // element slots: forward frames 1..3 -> fb[0..2], reverse frames -1..-3 -> rb[0..2]
+    uint8_t* fb[3] = {nullptr, nullptr, nullptr};
+    uint8_t* rbq[3] = {nullptr, nullptr, nullptr};
+    uint32_t fk[3] = {0, 0, 0}, rkq[3] = {0, 0, 0};  // amino acids kept (after --trim) per slot
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k >= P.nframes) break;
+        const int frame = P.frames[k];
+        const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
+        const uint32_t n = out_len[e];
+        uint8_t* o = out + out_off[e];
+        const uint32_t H = header_len(h, hl, P, frame) + 1;
+        const uint32_t body = n - H - 1;
+        const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
+        // header and the element's final newline
+        if (!P.append_frame) {
+            for (uint32_t x = gl; x < H; x += G) o[x] = x == 0 ? (uint8_t)'>' : (x == H - 1 ? (uint8_t)'\n' : h[x - 1]);
+        } else if (gl == 0) {
+            uint32_t hdr = 0, ioff, doff;
+            o[hdr++] = '>';
+            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
+            for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
+            const char* fs = "_frame=";
+            for (int q = 0; q < 7; ++q) o[hdr++] = (uint8_t)fs[q];
+            hdr += put_dec(o + hdr, frame);
+            o[hdr++] = ' ';
+            for (uint32_t q = 0; q < dl; ++q) o[hdr++] = h[doff + q];
+            o[hdr++] = '\n';
+        }
+        if (gl == 0) o[n - 1] = '\n';
+        // line breaks inside the body: one every lw amino acids
+        if (lw) for (uint32_t x = lw + gl * (lw + 1); x < body; x += G * (lw + 1)) o[H + x] = '\n';
+        uint8_t* bodyp = o + H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (frame == c + 1) { fb[c] = bodyp; fk[c] = kept; }
+            if (frame == -(c + 1)) { rbq[c] = bodyp; rkq[c] = kept; }
+        }
+    }
+    // a base at position q (class c = q % 3) feeds reverse frame -(((L - 3 - q) % 3) + 1):
+    // rotate the reverse slots once per record so that the class index is static in the loop
+    const uint32_t Lm = (L + 3u * 1024u * 1024u - 3u) % 3u;  // (L - 3) mod 3 without underflow
+    uint8_t* rb[3];
+    uint32_t rk[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t s = (Lm + 3u - (uint32_t)c) % 3u;  // reverse slot of class c
+        rb[c] = s == 0 ? rbq[0] : (s == 1 ? rbq[1] : rbq[2]);
+        rk[c] = s == 0 ? rkq[0] : (s == 1 ? rkq[1] : rkq[2]);
+    }
+    uint32_t err = 0;
+    for (uint32_t q0 = 0; q0 < L; q0 += WIN) {
+        // ---- stage: 48 bases per lane -> codes
+        {
+            const uint32_t qs = q0 + gl * 48u;
+            uint32_t raw = qs, col = 0;
+            if (T.W) { raw = qs + qs / T.W; col = qs % T.W; }
+            for (uint32_t k = 0; k < 48u; ++k) {
+                uint8_t code = 0;
+                if (qs + k < L) {
+                    code = s_iu[T.p[raw]];
+                    ++raw;
+                    if (T.W && ++col == T.W) { ++raw; col = 0; }
+                }
+                codes[gl * 48u + k] = code;
+            }
+            if (gl < 2) {  // two bases of overlap into the next window
+                const uint32_t q = q0 + WIN + gl;
+                codes[WIN + gl] = q < L ? s_iu[T.at(q)] : (uint8_t)0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- translate
+        const uint32_t qs = q0 + gl * 48u;
+        const uint8_t* cp = codes + gl * 48u;
+        uint32_t c0 = cp[0], c1 = cp[1];
+#pragma unroll 4
+        for (uint32_t kk = 0; kk < 16u; ++kk) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t k = kk * 3u + (uint32_t)c;
+                const uint32_t c2 = cp[k + 2];
+                const uint32_t q = qs + k;
+                if (q + 2 < L) {
+                    const bool bad = c0 == 0 || c1 == 0 || c2 == 0;
+                    const uint32_t idx = (c0 << 8) | (c1 << 4) | c2;
+                    // forward frame c + 1, amino acid (q - c) / 3 == qs / 3 + kk
+                    if (fb[c]) {
+                        const uint32_t j = qs / 3u + kk;
+                        uint8_t aa = bad ? (uint8_t)0 : s_fw[idx];
+                        if (aa == 0) { if (P.allow_unknown) aa = 'X'; else err = ERR_UNKNOWN_CODON; }
+                        if (j == 0 && P.init_m && !bad && P.start[idx]) aa = 'M';
+                        if (P.clean && aa == '*') aa = 'X';
+                        if (j < fk[c]) fb[c][j + (lw ? j / lw : 0u)] = aa;
+                    }
+                    if (rb[c]) {
+                        const uint32_t j = (L - 3u - q) / 3u;
+                        uint8_t aa = bad ? (uint8_t)0 : s_rc[idx];
+                        if (aa == 0) { if (P.allow_unknown) aa = 'X'; else err = ERR_UNKNOWN_CODON; }
+                        if (j == 0 && P.init_m && !bad && P.start_rc[idx]) aa = 'M';
+                        if (P.clean && aa == '*') aa = 'X';
+                        if (j < rk[c]) rb[c][j + (lw ? j / lw : 0u)] = aa;
+                    }
+                }
+                c0 = c1;
+                c1 = c2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
+}
+
 }  // namespace
 
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
@@ -196,6 +349,21 @@ hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const
     if (ne == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     hipLaunchKernelGGL(k_translate_size, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                                   const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
+                                   uint8_t* out, uint64_t* status, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    if (lanes_per_record == 64) {
+        hipLaunchKernelGGL(k_translate_frames<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, t, d,
+                           P, out_len, out_off, out, status);
+    } else {
+        hipLaunchKernelGGL(k_translate_frames<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t, d,
+                           P, out_len, out_off, out, status);
+    }
     return hipGetLastError();
 }
 

@@ -23,6 +23,9 @@ struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/tra
     int id_mode;
     const uint8_t* codon;   // device, 4096 bytes: aa of the IUPAC-coded codon (c1 << 8 | c2 << 4 | c3); 0 = unknown
     const uint8_t* start;   // device, 4096 bytes: 1 when the codon is a start codon of the table
+    const uint8_t* codon_rc; // device, 4096 bytes: aa of the REVERSE COMPLEMENT of the codon with that index
+    const uint8_t* start_rc; // device, 4096 bytes
+    const uint8_t* iupac;    // device, 256 bytes: byte -> 4-bit IUPAC code (0 = not a base)
 };
 
 constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
@@ -30,6 +33,10 @@ constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
 // elements are numbered record * nframes + f
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                  const TranslateParams& P, uint32_t* out_len, uint64_t* status, hipStream_t st);
+// all requested frames of a record from ONE read of its bases (G lanes per record)
+hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+                                   const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
+                                   uint8_t* out, uint64_t* status, hipStream_t st);
 hipError_t launch_translate_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                  const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                  uint8_t* out, uint64_t* status, hipStream_t st);
