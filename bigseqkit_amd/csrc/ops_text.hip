@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void k_text_classify(const uint8_t* __restrict
             for (uint32_t k = gl; k + 1 < lines; k += GROUP)
                 if (p[(uint64_t)k * (W + 1) + W] != '\n') ok = false;
         w = W;
+        // very narrow lines are cheaper to linearise than to index (and keep the raw-window
+        // kernels' LDS budget bounded): treat them as irregular
+        if (W < 16) ok = false;
     }
     const uint64_t bad = __ballot(!ok);
     if ((bad >> gshift) & 0xFFFFull) w = TEXT_IRREGULAR;

@@ -192,11 +192,14 @@ __global__ __launch_bounds__(256) void k_translate_emit(const uint8_t* __restric
 // ---------------------------------------------------------------------------
 // k_translate_frames<G>: G lanes per record, every base read once.
 // A window is G x 48 bases (a multiple of 3, so base k of a lane always belongs to forward
-// frame (k % 3) + 1).  Bases -> 4-bit IUPAC codes via an LDS table, codes staged in LDS,
-// then every position q yields two amino acids from the same three codes:
-//   forward frame (q % 3) + 1, index q / 3            -> s_fw[c0 c1 c2]
+// frame (k % 3) + 1).  The window's RAW text (bases + the newlines of a wrapped FASTA record)
+// is copied once into LDS with coalesced 16-byte loads; each lane then walks its 48 bases,
+// skipping newlines by column counting, mapping bytes to 4-bit IUPAC codes through an LDS
+// table.  Every position q yields two amino acids from the same three codes:
+//   forward frame (q % 3) + 1, index q / 3              -> s_fw[c0 c1 c2]
 //   reverse frame -(((L-3-q) % 3) + 1), index (L-3-q)/3 -> s_rc[c0 c1 c2]  (table of the
 //   reverse-complemented codon, so the reverse complement is never formed)
+// Output offsets (index + line breaks) are advanced incrementally: no division per residue.
 // ---------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
@@ -204,26 +207,30 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
                                                           const uint64_t* __restrict__ out_off,
                                                           uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
     constexpr int WIN = G * 48;
+    constexpr int RAWCAP = WIN + WIN / 16 + 64;  // line width >= 16 (narrower records are linearised)
     constexpr int NG = 256 / G;
     __shared__ uint8_t s_fw[4096];
     __shared__ uint8_t s_rc[4096];
     __shared__ uint8_t s_iu[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_codes[NG][WIN + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[NG][RAWCAP];
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) { s_fw[i] = P.codon[i]; s_rc[i] = P.codon_rc[i]; }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
     __syncthreads();
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (g >= t.n) return;  // no block-level barrier below
-    uint8_t* codes = s_codes[threadIdx.x / G];
+    uint8_t* raw = s_raw[threadIdx.x / G];
     const Text T = text_of(buf, t, tt, g);
     const uint32_t L = T.L;
+    const uint32_t W = T.W;
+    // bytes of text that may be read: bases plus one newline per full line
+    const uint32_t raw_total = W ? L + (L ? (L - 1) / W : 0u) : L;
     const uint8_t* h = buf + t.start[g] + 1;
     const uint32_t lh = t.l_head[g];
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
     const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
 
-    // element slots: forward frames 1..3 -> fb[0..2], reverse frames -1..-3 -> rb[0..2]
+    // element slots: forward frames 1..3 -> fb[0..2], reverse frames -1..-3 -> rbq[0..2]
     uint8_t* fb[3] = {nullptr, nullptr, nullptr};
     uint8_t* rbq[3] = {nullptr, nullptr, nullptr};
     uint32_t fk[3] = {0, 0, 0}, rkq[3] = {0, 0, 0};  // amino acids kept (after --trim) per slot
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
     }
     // a base at position q (class c = q % 3) feeds reverse frame -(((L - 3 - q) % 3) + 1):
     // rotate the reverse slots once per record so that the class index is static in the loop
-    const uint32_t Lm = (L + 3u * 1024u * 1024u - 3u) % 3u;  // (L - 3) mod 3 without underflow
+    const uint32_t Lm = (L % 3u);  // (L - 3) mod 3 == L mod 3
     uint8_t* rb[3];
     uint32_t rk[3];
 #pragma unroll
@@ -275,64 +282,94 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
         rk[c] = s == 0 ? rkq[0] : (s == 1 ? rkq[1] : rkq[2]);
     }
     uint32_t err = 0;
+    // Lane l of the group owns codon slot l of every 3G-base step: bases q, q+1, q+2 with
+    // q = step_base + 3l give one residue to each forward frame (index step_base/3 + l) and one
+    // to each reverse slot, so consecutive lanes write consecutive output bytes.
+    // Per-lane constants for walking a wrapped FASTA line without divisions in the loop:
+    const uint32_t l3 = gl * 3u;
+    const uint32_t la = W ? l3 / W : 0u, lb = W ? l3 % W : 0u;  // 3l = la * W + lb
+    const uint32_t stepb = 3u * G;                                  // bases per step
+    const uint32_t sd = W ? stepb / W : 0u, sm = W ? stepb % W : 0u;
+    // forward cursor of this lane: residue index, line-break offset, column (shared by the 3 frames)
+    uint32_t fj = gl, fo = 0, fc = gl;
+    if (lw) { fo = fj / lw; fc = fj - fo * lw; }
+    const uint32_t gd = lw ? (uint32_t)G / lw : 0u, gm = lw ? (uint32_t)G % lw : 0u;
+    // reverse cursors (one per class): residue index Rc - l - G * step; valid while >= 0
+    int64_t rj[3];
+    uint32_t ro[3], rcc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rj[c] = L >= 3u + (uint32_t)c ? (int64_t)((L - 3u - (uint32_t)c) / 3u) - (int64_t)gl : -1;
+        ro[c] = 0; rcc[c] = 0;
+        if (lw && rj[c] >= 0) { ro[c] = (uint32_t)rj[c] / lw; rcc[c] = (uint32_t)rj[c] - ro[c] * lw; }
+    }
     for (uint32_t q0 = 0; q0 < L; q0 += WIN) {
-        // ---- stage: 48 bases per lane -> codes
-        {
-            const uint32_t qs = q0 + gl * 48u;
-            uint32_t raw = qs, col = 0;
-            if (T.W) { raw = qs + qs / T.W; col = qs % T.W; }
-            for (uint32_t k = 0; k < 48u; ++k) {
-                uint8_t code = 0;
-                if (qs + k < L) {
-                    code = s_iu[T.p[raw]];
-                    ++raw;
-                    if (T.W && ++col == T.W) { ++raw; col = 0; }
-                }
-                codes[gl * 48u + k] = code;
-            }
-            if (gl < 2) {  // two bases of overlap into the next window
-                const uint32_t q = q0 + WIN + gl;
-                codes[WIN + gl] = q < L ? s_iu[T.at(q)] : (uint8_t)0;
+        // ---- stage the window's raw text in LDS (coalesced 16-byte loads)
+        const uint32_t rawbase = W ? q0 + q0 / W : q0;
+        uint32_t span = raw_total - rawbase;
+        if (span > (uint32_t)RAWCAP) span = RAWCAP;
+        for (uint32_t off = gl * 16u; off < span; off += G * 16u) {
+            if (off + 16u <= span) {
+                uint4 v;
+                __builtin_memcpy(&v, T.p + rawbase + off, 16);
+                *reinterpret_cast<uint4*>(raw + off) = v;
+            } else {
+                for (uint32_t bq = off; bq < span; ++bq) raw[bq] = T.p[rawbase + bq];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- translate
-        const uint32_t qs = q0 + gl * 48u;
-        const uint8_t* cp = codes + gl * 48u;
-        uint32_t c0 = cp[0], c1 = cp[1];
-#pragma unroll 4
-        for (uint32_t kk = 0; kk < 16u; ++kk) {
+        // ---- 16 steps of 3G bases
+        uint32_t colbase = W ? q0 % W : 0u, lines = 0;  // column of the step's first base, newlines since q0
+        for (uint32_t it = 0; it < 16u; ++it) {
+            const uint32_t sb = q0 + it * stepb;  // first base of the step
+            if (sb >= L) break;
+            const uint32_t q = sb + l3;
+            // raw position and column of base q
+            uint32_t col = colbase + lb, rp = (sb - q0) + lines + l3 + la;
+            if (W && col >= W) { col -= W; ++rp; }
+            uint32_t cd[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t adj = (W && col + (uint32_t)k >= W) ? 1u : 0u;  // W >= 16 > 5: at most one break
+                cd[k] = (q + (uint32_t)k < L) ? (uint32_t)s_iu[raw[rp + (uint32_t)k + adj]] : 0u;
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const uint32_t k = kk * 3u + (uint32_t)c;
-                const uint32_t c2 = cp[k + 2];
-                const uint32_t q = qs + k;
-                if (q + 2 < L) {
+                if (q + (uint32_t)c + 2u < L) {
+                    const uint32_t c0 = cd[c], c1 = cd[c + 1], c2 = cd[c + 2];
                     const bool bad = c0 == 0 || c1 == 0 || c2 == 0;
                     const uint32_t idx = (c0 << 8) | (c1 << 4) | c2;
-                    // forward frame c + 1, amino acid (q - c) / 3 == qs / 3 + kk
-                    if (fb[c]) {
-                        const uint32_t j = qs / 3u + kk;
+                    if (fb[c]) {  // forward frame c + 1, residue fj
                         uint8_t aa = bad ? (uint8_t)0 : s_fw[idx];
                         if (aa == 0) { if (P.allow_unknown) aa = 'X'; else err = ERR_UNKNOWN_CODON; }
-                        if (j == 0 && P.init_m && !bad && P.start[idx]) aa = 'M';
+                        if (fj == 0 && P.init_m && !bad && P.start[idx]) aa = 'M';
                         if (P.clean && aa == '*') aa = 'X';
-                        if (j < fk[c]) fb[c][j + (lw ? j / lw : 0u)] = aa;
+                        if (fj < fk[c]) fb[c][fj + fo] = aa;
                     }
-                    if (rb[c]) {
-                        const uint32_t j = (L - 3u - q) / 3u;
+                    if (rb[c]) {  // reverse slot of class c, residue rj[c]
+                        const uint32_t j = (uint32_t)rj[c];
                         uint8_t aa = bad ? (uint8_t)0 : s_rc[idx];
                         if (aa == 0) { if (P.allow_unknown) aa = 'X'; else err = ERR_UNKNOWN_CODON; }
                         if (j == 0 && P.init_m && !bad && P.start_rc[idx]) aa = 'M';
                         if (P.clean && aa == '*') aa = 'X';
-                        if (j < rk[c]) rb[c][j + (lw ? j / lw : 0u)] = aa;
+                        if (j < rk[c]) rb[c][j + ro[c]] = aa;
                     }
                 }
-                c0 = c1;
-                c1 = c2;
             }
+            // advance the cursors by one step (G residues per frame)
+            fj += G;
+            if (lw) { fo += gd; fc += gm; if (fc >= lw) { fc -= lw; ++fo; } }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rj[c] -= G;
+                if (lw && rj[c] >= 0) {
+                    ro[c] -= gd;
+                    if (rcc[c] < gm) { rcc[c] += lw - gm; --ro[c]; } else rcc[c] -= gm;
+                }
+            }
+            if (W) { lines += sd; colbase += sm; if (colbase >= W) { colbase -= W; ++lines; } }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

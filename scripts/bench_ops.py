@@ -17,6 +17,11 @@ from bigseqkit_amd._lib import lib, check
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None   # subset: seq,subseq,grep,locate,rmdup,translate
+
+
+def want(name):
+    return only is None or name in only
 
 
 def synth(kind, flags, nbytes):
@@ -52,29 +57,37 @@ def report(name, nrec, in_bytes, dt, out_len, note=""):
 
 
 # C2: seq -n on 100 GB FASTQ-150
-t, nrec = synth(0, 0, 100e9 * scale)
-dt, ol, k = run("SeqTransform", lib.bsk_seq_run, {"Name": True}, t, 1)
-assert ol == 12 * nrec
-report("seq -n (C2, 100 GB FASTQ)", nrec, t.numel(), dt, ol)
-dt, ol, k = run("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, t[:317 * (nrec // 4)], 1)
-report("subseq -r 1:50 (25 GB FASTQ)", nrec // 4, 317 * (nrec // 4), dt, ol)
-del t
+if want("seq") or want("subseq"):
+    t, nrec = synth(0, 0, 100e9 * scale)
+    if want("seq"):
+        dt, ol, k = run("SeqTransform", lib.bsk_seq_run, {"Name": True}, t, 1)
+        assert ol == 12 * nrec
+        report("seq -n (C2, 100 GB FASTQ)", nrec, t.numel(), dt, ol)
+    if want("subseq"):
+        dt, ol, k = run("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, t[:317 * (nrec // 4)], 1)
+        report("subseq -r 1:50 (25 GB FASTQ)", nrec // 4, 317 * (nrec // 4), dt, ol)
+    del t
 # C3: grep -s -p motif, one GPU's 12.5 GB shard
-t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)
-dt, ol, k = run("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t, 1)
-report("grep -s -p 12-mer (C3 shard, 12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "hits=%d" % k)
-dt, ol, k = run("Locate", lib.bsk_locate_run, {"Pattern": ["ACGTTGCAAGCT"]}, t, 1)
-report("locate -p 12-mer (12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "rows=%d" % k)
-del t
+if want("grep") or want("locate"):
+    t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)
+    if want("grep"):
+        dt, ol, k = run("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t, 1)
+        report("grep -s -p 12-mer (C3 shard, 12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "hits=%d" % k)
+    if want("locate"):
+        dt, ol, k = run("Locate", lib.bsk_locate_run, {"Pattern": ["ACGTTGCAAGCT"]}, t, 1)
+        report("locate -p 12-mer (12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "rows=%d" % k)
+    del t
 # C5: rmdup -s, one GPU's 25 GB shard
-t, nrec = synth(0, _lib.SYNTH_FLAG_DUPS, 25e9 * scale)
-dt, ol, k = run("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, 1)
-assert k == nrec - nrec // 5
-report("rmdup -s (C5 shard, 25 GB FASTQ, 20% dups)", nrec, t.numel(), dt, ol, "survivors=%d" % k)
-del t
+if want("rmdup"):
+    t, nrec = synth(0, _lib.SYNTH_FLAG_DUPS, 25e9 * scale)
+    dt, ol, k = run("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, 1)
+    assert k == nrec - nrec // 5
+    report("rmdup -s (C5 shard, 25 GB FASTQ, 20% dups)", nrec, t.numel(), dt, ol, "survivors=%d" % k)
+    del t
 # C4: translate --frame 6 on 50 GB FASTA (5 kb CDS)
-t, nrec = synth(2, 0, 50e9 * scale)
-dt, ol, k = run("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, 0)
-report("translate -f 6 (C4, 50 GB FASTA-5k)", nrec, t.numel(), dt, ol)
-del t
+if want("translate"):
+    t, nrec = synth(2, 0, 50e9 * scale)
+    dt, ol, k = run("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, 0)
+    report("translate -f 6 (C4, 50 GB FASTA-5k)", nrec, t.numel(), dt, ol)
+    del t
 print(json.dumps(res))
