@@ -214,6 +214,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_names_off) hipFree(c->d_names_off);
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_pat_off) hipFree(c->d_pat_off);
+        for (void* p : {(void*)c->sparse.start, (void*)c->sparse.l_head, (void*)c->sparse.l_seq, (void*)c->sparse.aux})
+            if (p) hipFree(p);
         for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux,
                         (void*)c->d_range_count, (void*)c->d_range_base, (void*)c->d_out_len, (void*)c->d_out_off,
                         (void*)c->d_scan_tmp, (void*)c->d_out, (void*)c->d_lut, (void*)c->d_qual_err,

@@ -43,6 +43,7 @@ struct bsk_ctx {
 
     // ---- record table + per-record scratch (seq, grep, ...) ---------------------
     bsk::RecordTable table;          // ctx-owned arrays, grown on demand
+    bsk::RecordTable sparse;         // one-pass index: per-range slices, compacted into `table`
     uint64_t* d_range_count = nullptr;  // [cap_ranges]
     uint64_t* d_range_base = nullptr;   // [cap_ranges + 1]
     uint32_t* d_out_len = nullptr;      // [table.cap]

@@ -30,7 +30,8 @@ struct IndexDev {
     uint64_t* range_count;       // [nranges] records per range (count pass writes, write pass reads base)
     const uint64_t* range_base;  // [nranges + 1] exclusive scan of range_count (write pass)
     uint64_t* status;            // [0] error flags
-    int write;                   // 0: count pass, 1: write pass
+    int write;                   // 0: count pass, 1: write pass (exact bases), 2: one-pass sparse write
+    uint64_t sparse_cap;         // mode 2: slots reserved per range (range r writes at r * sparse_cap)
 };
 
 hipError_t launch_index(bool fastq, bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
@@ -41,5 +42,8 @@ hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipS
 // exclusive scan u32 -> u64 over N items (N up to 2^32): out[0..N], out[N] = total; tmp: u64[(N + 2047) / 2048 + 1]
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st);
 hipError_t launch_reset_queue(uint32_t* queue, hipStream_t st);
+// gather the per-range slices of a sparse table (mode 2) into a dense one
+hipError_t launch_index_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
+                                const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, hipStream_t st);
 
 }  // namespace bsk

@@ -98,33 +98,84 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
     HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st));
     IndexDev D;
-    D.t = c->table;
     D.range_count = c->d_range_count;
     D.range_base = c->d_range_base;
     D.status = c->d_status;
-    D.write = 0;
-    HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
-    HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
-    uint64_t total = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    if (total + 1 > c->table.cap) {
-        for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux})
+    D.sparse_cap = 0;
+    auto alloc_table = [&](RecordTable& t, uint64_t cap) -> int {
+        if (cap <= t.cap && t.start) return BSK_OK;
+        for (void* p : {(void*)t.start, (void*)t.l_head, (void*)t.l_seq, (void*)t.aux})
             if (p) HIP_TRYX(c, hipFree(p));
-        c->table = RecordTable();
-        const uint64_t cap = total + total / 8 + 16;
-        HIP_TRYX(c, hipMalloc((void**)&c->table.start, (cap + 1) * sizeof(uint64_t)));
-        HIP_TRYX(c, hipMalloc((void**)&c->table.l_head, cap * sizeof(uint32_t)));
-        HIP_TRYX(c, hipMalloc((void**)&c->table.l_seq, cap * sizeof(uint32_t)));
-        HIP_TRYX(c, hipMalloc((void**)&c->table.aux, cap * sizeof(uint32_t)));
-        c->table.cap = cap;
+        t = RecordTable();
+        HIP_TRYX(c, hipMalloc((void**)&t.start, (cap + 1) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.l_head, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.l_seq, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.aux, cap * sizeof(uint32_t)));
+        t.cap = cap;
+        return BSK_OK;
+    };
+    uint64_t total = 0;
+    bool done = false;
+    // ---- one-pass path: every range writes into its own slice of a sparse table sized from the
+    // record density of the shard head; slices are then gathered (6 % of the data volume).
+    // Falls back to the exact count + write passes when a slice overflows.
+    const char* ix = getenv("BSK_INDEX");
+    if (!(ix && strcmp(ix, "twopass") == 0)) {
+        const size_t hb = std::min<size_t>(n, 256 * 1024);
+        std::vector<uint8_t> head(hb);
+        HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        uint64_t recs = 0;
+        if (fastq) { for (size_t i = 0; i < hb; ++i) recs += head[i] == '\n'; recs /= 4; }
+        else { for (size_t i = 0; i + 1 < hb; ++i) recs += (head[i] == '\n' && head[i + 1] == '>'); recs += 1; }
+        const double avg = (double)hb / (double)std::max<uint64_t>(recs, 1);
+        const uint64_t sparse_cap = (uint64_t)((double)chunk / std::max(avg * 0.5, 6.0)) + 64;
+        const uint64_t need = sparse_cap * nranges;
+        if (need * 20 <= (uint64_t)n + (64ull << 20)) {  // never reserve more than the shard itself
+            int rc2 = alloc_table(c->sparse, need);
+            if (rc2 != BSK_OK) return rc2;
+            D.t = c->sparse;
+            D.write = 2;
+            D.sparse_cap = sparse_cap;
+            HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+            HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
+            uint64_t status = 0;
+            HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (status & ERR_CAPACITY) {
+                status &= ~(uint64_t)ERR_CAPACITY;  // retry exactly
+                HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                HIP_TRYX(c, launch_reset_queue(queue, st));
+            } else {
+                int rc3 = alloc_table(c->table, total + total / 8 + 16);
+                if (rc3 != BSK_OK) return rc3;
+                c->table.n = total;
+                if (total)
+                    HIP_TRYX(c, launch_index_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges,
+                                                     c->table, st));
+                done = true;
+            }
+        }
     }
-    c->table.n = total;
+    if (!done) {
+        D.t = c->table;
+        D.write = 0;
+        HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+        HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
+        HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        int rc4 = alloc_table(c->table, total + total / 8 + 16);
+        if (rc4 != BSK_OK) return rc4;
+        c->table.n = total;
+        if (total == 0) return BSK_OK;
+        D.t = c->table;
+        D.write = 1;
+        HIP_TRYX(c, launch_reset_queue(queue, st));
+        HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+    }
     if (total == 0) return BSK_OK;
-    D.t = c->table;
-    D.write = 1;
-    HIP_TRYX(c, launch_reset_queue(queue, st));
-    HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
     // start[n] = effective end of the shard (anchors[nranges])
     HIP_TRYX(c, hipMemcpyAsync(c->table.start + total, anchors + nranges, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     return BSK_OK;

@@ -22,14 +22,16 @@ using namespace stream;
 struct IndexSink {
     IndexDev D;
     uint64_t base = 0;   // global index of the first record of the range (wave-uniform)
+    uint64_t limit = 0;  // first index this range must not write (table capacity or end of its sparse slice)
     uint32_t nrec = 0;   // FASTA: records closed so far in this range (wave-uniform)
     uint32_t err = 0;
     // FASTA: the record that is open at the start of a batch
     uint64_t open_start = 0;  // absolute offset of its '>'
     uint32_t open_lhead = 0, open_key = 0;
 
-    __device__ __forceinline__ void begin_range(uint64_t b, uint64_t rs) {
+    __device__ __forceinline__ void begin_range(uint64_t b, uint64_t lim, uint64_t rs) {
         base = b;
+        limit = lim;
         nrec = 0;
         open_start = rs;
         open_lhead = 0;
@@ -64,7 +66,7 @@ struct IndexSink {
                         if (lq != ls) err |= ERR_LEN_MISMATCH;
                         if (abs_next < re && buf[abs_next] != '@') err |= ERR_BAD_HEADER;
                         const uint64_t g = base + (rank >> 2);
-                        if (g < D.t.cap) {
+                        if (g < limit) {
                             D.t.start[g] = abs_of(p4, tile_idx, tile_rel) + 1;
                             D.t.l_head[g] = lh;
                             D.t.l_seq[g] = ls;
@@ -103,7 +105,7 @@ struct IndexSink {
                     const uint64_t region = rec_end - (start + lhead + 1 < rec_end ? start + lhead + 1 : rec_end);
                     if (region > 0xFFFFFFFFull) err |= ERR_LINE_TOO_LONG;
                     const uint64_t g = base + local;
-                    if (g < D.t.cap) {
+                    if (g < limit) {
                         D.t.start[g] = start;
                         D.t.l_head[g] = lhead;
                         D.t.l_seq[g] = seqlen;
@@ -153,12 +155,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void k_index(const uint8_t*
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) {
-            if (!D.write && lane == 0) D.range_count[r] = 0;
+            if (D.write != 1 && lane == 0) D.range_count[r] = 0;
             continue;
         }
-        sink.begin_range(D.write ? D.range_base[r] : 0, rs);
+        uint64_t b = 0, lim = D.t.cap;
+        if (D.write == 1) b = D.range_base[r];
+        else if (D.write == 2) { b = (uint64_t)r * D.sparse_cap; lim = b + D.sparse_cap; if (lim > D.t.cap) lim = D.t.cap; }
+        sink.begin_range(b, lim, rs);
         const uint32_t lines = stream_range<FASTQ, false, DPP>(L, buf, n, rs, re, re == n_eff, P, sink);
-        if (!D.write && lane == 0) D.range_count[r] = FASTQ ? (uint64_t)(lines >> 2) : (uint64_t)sink.nrec;
+        if (D.write != 1 && lane == 0) D.range_count[r] = FASTQ ? (uint64_t)(lines >> 2) : (uint64_t)sink.nrec;
     }
     const uint32_t err = wave_or_u32(sink.err);
     if (lane == 0 && err) atomicOr((unsigned long long*)&D.status[0], (unsigned long long)err);
@@ -250,6 +255,20 @@ __global__ void k_set_total(const uint64_t* __restrict__ block_off, uint64_t nbl
 
 __global__ void k_reset_queue(uint32_t* q) { *q = 0; }
 
+// one block per range: copy its slice of the sparse table to its dense position
+__global__ __launch_bounds__(256) void k_index_compact(RecordTable sp, uint64_t sparse_cap,
+                                                       const uint64_t* __restrict__ range_count,
+                                                       const uint64_t* __restrict__ range_base, RecordTable dn) {
+    const uint32_t r = blockIdx.x;
+    const uint64_t cnt = range_count[r], src = (uint64_t)r * sparse_cap, dst = range_base[r];
+    for (uint64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        dn.start[dst + i] = sp.start[src + i];
+        dn.l_head[dst + i] = sp.l_head[src + i];
+        dn.l_seq[dst + i] = sp.l_seq[src + i];
+        dn.aux[dst + i] = sp.aux[src + i];
+    }
+}
+
 }  // namespace
 
 hipError_t launch_index(bool fastq, bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
@@ -291,6 +310,12 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint64_t*)sums, offs, (uint32_t)nb);
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(256), 0, st, in, n, (const uint64_t*)offs, out);
     hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, st, (const uint64_t*)offs, nb, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_index_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
+                                const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_compact, dim3(nranges), dim3(256), 0, st, sparse, sparse_cap, range_count, range_base, dense);
     return hipGetLastError();
 }
 
