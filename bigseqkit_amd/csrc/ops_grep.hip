@@ -63,8 +63,32 @@ __device__ uint32_t id_span2(const uint8_t* h, uint32_t n, int id_mode, uint32_t
     return n;
 }
 
-__global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ buf, RecordTable t, GrepParams P,
-                                                  uint32_t* __restrict__ out_len) {
+
+// ---------------------------------------------------------------------------
+// fast path for contiguous text: a lane tests 16 consecutive start positions from two
+// unaligned 16-byte loads; the first min(m, 4) pattern bytes are compared as one dword taken
+// with v_alignbyte at a static shift, the (rare) survivors are verified byte by byte.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fold_dword(uint32_t x) {  // ASCII lower-case, 4 bytes at once
+    const uint32_t ge_a = (x & 0x7F7F7F7Fu) + 0x3F3F3F3Fu;   // bit 7 set where byte >= 'A'
+    const uint32_t ge_z1 = (x & 0x7F7F7F7Fu) + 0x25252525u;  // bit 7 set where byte >= '[' 
+    const uint32_t up = ge_a & ~ge_z1 & ~x & 0x80808080u;      // 'A'..'Z' (and byte < 0x80)
+    return x | (up >> 2);
+}
+
+__device__ __forceinline__ uint32_t window_candidates(const uint32_t (&dw)[8], uint32_t p32, uint32_t pmask) {
+    uint32_t cand = 0;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int d = b >> 2, sft = b & 3;
+        const uint32_t w = sft == 0 ? dw[d] : __builtin_amdgcn_alignbyte(dw[d + 1], dw[d], sft);
+        cand |= (((w ^ p32) & pmask) == 0u ? 1u : 0u) << b;
+    }
+    return cand;
+}
+
+__global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+                                                  GrepParams P, uint32_t* __restrict__ out_len) {
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
     const uint32_t gl = threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;  // position of this group inside the wave
@@ -98,7 +122,74 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
     }
     bool hit = false;
     const int nstr = P.both_strands ? 2 : 1;
-    if (live && !sequential) {
+    const bool fast = live && !sequential && T.W == 0 && !P.circular;
+    if (fast) {
+        const uint8_t* const buf_end = buf + buf_n;
+        for (int strand = 0; strand < nstr && !hit; ++strand) {
+            uint32_t wb = 0, we = L;
+            if (P.region_on) {
+                uint32_t b, e;
+                sub_location(L, P.region_start, P.region_end, &b, &e);
+                if (strand == 0) { wb = b; we = e; }
+                else { wb = L - e; we = L - b; }
+            }
+            const uint32_t wl = we - wb;
+            for (int k = 0; k < P.npat && !hit; ++k) {
+                const int pk = strand * P.npat + k;
+                const uint8_t* pp = P.pat + P.pat_off[pk];
+                const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
+                if (m == 0) { hit = true; break; }
+                if (m > wl) continue;
+                const uint32_t npos = wl - m + 1;
+                uint32_t p32 = 0;
+                for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
+                const uint32_t pmask = m >= 4 ? 0xFFFFFFFFu : ((1u << (8 * m)) - 1u);
+                for (uint32_t i0 = 0; i0 < npos; i0 += GROUP * 16) {
+                    const uint32_t ib = i0 + gl * 16u;  // first start position of this lane
+                    bool ok = false;
+                    if (ib < npos) {
+                        const uint8_t* src = T.p + wb + ib;
+                        uint32_t dw[8];
+                        if (src + 32 <= buf_end) {
+                            uint4 a, b2;
+                            __builtin_memcpy(&a, src, 16);
+                            __builtin_memcpy(&b2, src + 16, 16);
+                            dw[0] = a.x; dw[1] = a.y; dw[2] = a.z; dw[3] = a.w;
+                            dw[4] = b2.x; dw[5] = b2.y; dw[6] = b2.z; dw[7] = b2.w;
+                        } else {
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                uint32_t w = 0;
+                                for (int q = 0; q < 4; ++q)
+                                    if (src + d * 4 + q < buf_end) w |= (uint32_t)src[d * 4 + q] << (8 * q);
+                                dw[d] = w;
+                            }
+                        }
+                        if (P.ignore_case) {
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) dw[d] = fold_dword(dw[d]);
+                        }
+                        uint32_t cand = window_candidates(dw, p32, pmask);
+                        const uint32_t left = npos - ib;  // valid start positions from ib
+                        if (left < 16u) cand &= (1u << left) - 1u;
+                        while (cand && !ok) {
+                            const uint32_t b = (uint32_t)__ffs((int)cand) - 1u;
+                            cand &= cand - 1u;
+                            bool all = true;
+                            for (uint32_t q = 4; q < m; ++q) {
+                                uint8_t cc = src[b + q];
+                                if (P.ignore_case) cc = lower8(cc);
+                                if (cc != pp[q]) { all = false; break; }
+                            }
+                            ok = all;
+                        }
+                    }
+                    const uint64_t any = __ballot(ok);
+                    if ((any >> gshift) & 0xFFFFull) { hit = true; break; }
+                }
+            }
+        }
+    } else if (live && !sequential) {
         for (int strand = 0; strand < nstr && !hit; ++strand) {
             // window of the forward text that the strand's target covers
             uint32_t wb = 0, we = L;
@@ -227,12 +318,12 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
 
 }  // namespace
 
-hipError_t launch_grep_match(const uint8_t* buf, const RecordTable& t, const GrepParams& P, uint32_t* out_len,
-                             hipStream_t st) {
+hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const GrepParams& P,
+                             uint32_t* out_len, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     if (P.by_seq) {
         const uint64_t blocks = (t.n * GROUP + 255) / 256;
-        hipLaunchKernelGGL(k_grep_seq, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len);
+        hipLaunchKernelGGL(k_grep_seq, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, P, out_len);
     } else {
         const uint64_t blocks = (t.n + 255) / 256;
         hipLaunchKernelGGL(k_grep_name, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len);

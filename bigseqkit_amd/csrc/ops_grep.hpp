@@ -20,7 +20,7 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     const uint32_t* pat_off; // [npat_total + 1]
 };
 
-hipError_t launch_grep_match(const uint8_t* buf, const RecordTable& t, const GrepParams& P, uint32_t* out_len,
-                             hipStream_t st);
+hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const GrepParams& P,
+                             uint32_t* out_len, hipStream_t st);
 
 }  // namespace bsk

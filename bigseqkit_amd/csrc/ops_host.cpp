@@ -459,7 +459,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.pat_off = c->d_pat_off;
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
-        HIP_TRYX(c, launch_grep_match(d_buf, c->table, G, c->d_out_len, st));
+        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, G, c->d_out_len, st));
         rc = finish_sizes(c, st, &total, &kept);
         if (rc != BSK_OK) return rc;
     } else {
@@ -584,7 +584,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
-        HIP_TRYX(c, launch_locate(false, d_buf, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
+        HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
         HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
         uint64_t status = 0;
         HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
@@ -605,7 +605,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (rc != BSK_OK) return rc;
     if (!header.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_out, header.data(), header.size(), hipMemcpyHostToDevice, st));
     if (total)
-        HIP_TRYX(c, launch_locate(true, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out + header.size(),
+        HIP_TRYX(c, launch_locate(true, d_buf, n, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out + header.size(),
                                   c->d_counter + 1, st));
     HIP_TRYX(c, hipStreamSynchronize(st));  // header lives on the host stack
     out->d_data = c->d_out;

@@ -111,8 +111,65 @@ __device__ __forceinline__ bool match_at(const Text& T, uint32_t l, bool fold, c
     return true;
 }
 
+
+__device__ __forceinline__ uint32_t fold_dword(uint32_t x) {  // ASCII lower-case, 4 bytes at once
+    const uint32_t ge_a = (x & 0x7F7F7F7Fu) + 0x3F3F3F3Fu;
+    const uint32_t ge_z1 = (x & 0x7F7F7F7Fu) + 0x25252525u;
+    const uint32_t up = ge_a & ~ge_z1 & ~x & 0x80808080u;
+    return x | (up >> 2);
+}
+
+// 16 consecutive start positions from a 32-byte window: first min(m,4) bytes as one dword
+// (v_alignbyte at static shifts), survivors verified byte by byte -> 16-bit hit mask
+__device__ __forceinline__ uint32_t window_hits(const uint8_t* src, const uint8_t* buf_end, bool fold, const uint8_t* pp,
+                                                uint32_t m) {
+    uint32_t dw[8];
+    if (src + 32 <= buf_end) {
+        uint4 a, b2;
+        __builtin_memcpy(&a, src, 16);
+        __builtin_memcpy(&b2, src + 16, 16);
+        dw[0] = a.x; dw[1] = a.y; dw[2] = a.z; dw[3] = a.w;
+        dw[4] = b2.x; dw[5] = b2.y; dw[6] = b2.z; dw[7] = b2.w;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t w = 0;
+            for (int q = 0; q < 4; ++q)
+                if (src + d * 4 + q < buf_end) w |= (uint32_t)src[d * 4 + q] << (8 * q);
+            dw[d] = w;
+        }
+    }
+    if (fold) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dw[d] = fold_dword(dw[d]);
+    }
+    uint32_t p32 = 0;
+    for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
+    const uint32_t pmask = m >= 4 ? 0xFFFFFFFFu : ((1u << (8 * m)) - 1u);
+    uint32_t cand = 0;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int d = b >> 2, sft = b & 3;
+        const uint32_t w = sft == 0 ? dw[d] : __builtin_amdgcn_alignbyte(dw[d + 1], dw[d], sft);
+        cand |= (((w ^ p32) & pmask) == 0u ? 1u : 0u) << b;
+    }
+    uint32_t hits = 0;
+    while (cand) {
+        const uint32_t b = (uint32_t)__ffs((int)cand) - 1u;
+        cand &= cand - 1u;
+        bool all = true;
+        for (uint32_t q = 4; q < m; ++q) {
+            uint8_t cc = src[b + q];
+            if (fold) cc = lower8(cc);
+            if (cc != pp[q]) { all = false; break; }
+        }
+        if (all) hits |= 1u << b;
+    }
+    return hits;
+}
+
 template <bool EMIT>
-__global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+__global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                 LocateParams P, uint32_t* __restrict__ out_len,
                                                 const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                 uint64_t* __restrict__ rows) {
@@ -150,7 +207,61 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
             uint64_t npos = n - m + 1;
             if (P.circular && npos > l) npos = l;
             const char sc = strand ? '-' : '+';
-            if (!P.non_greedy) {
+            // contiguous text inside the shard, plain greedy search: 16 positions per lane and step
+            const bool fastp = !P.non_greedy && !P.circular && T.W == 0 && T.p >= buf && T.p < buf + buf_n;
+            if (fastp) {
+                const uint8_t* const buf_end = buf + buf_n;
+                for (uint64_t a0 = 0; a0 < npos; a0 += GROUP * 16) {
+                    const uint64_t ib = a0 + (uint64_t)gl * 16u;  // first position of this lane, strand frame
+                    uint32_t hits = 0;                           // bit k <-> position ib + k (ascending)
+                    if (ib < npos) {
+                        if (strand == 0) {
+                            hits = window_hits(T.p + ib, buf_end, P.ignore_case, pp, m);
+                        } else if (ib + 15u + m <= n) {
+                            // forward window [n-m-ib-15, n-m-ib]: bit b is position ib + 15 - b
+                            const uint32_t h = window_hits(T.p + (n - m - ib - 15u), buf_end, P.ignore_case, pp, m);
+                            hits = __brev(h) >> 16;
+                        } else {
+                            for (uint32_t k2 = 0; k2 < 16u && ib + k2 < npos; ++k2)
+                                if (match_at(T, l, P.ignore_case, pp, m, n - (ib + k2) - m)) hits |= 1u << k2;
+                        }
+                        const uint64_t left = npos - ib;
+                        if (left < 16u) hits &= (1u << left) - 1u;
+                    }
+                    const uint32_t gmask = (uint32_t)((__ballot(hits != 0) >> gshift) & 0xFFFFull);
+                    if (gmask == 0) continue;
+                    uint32_t mine = 0, cnt = 0;
+                    for (uint32_t hm = hits; hm; hm &= hm - 1u) {
+                        const uint64_t a = ib + ((uint32_t)__ffs((int)hm) - 1u);
+                        uint64_t begin, end;
+                        if (strand == 0) { begin = a + 1; end = a + m; }
+                        else { begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a; }
+                        mine += row_len(R, begin, end);
+                        ++cnt;
+                    }
+                    uint32_t incl = mine, icnt = cnt;
+#pragma unroll
+                    for (int d = 1; d < GROUP; d <<= 1) {
+                        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, GROUP);
+                        const uint32_t vc = (uint32_t)__shfl_up((int)icnt, d, GROUP);
+                        if ((int)gl >= d) { incl += v; icnt += vc; }
+                    }
+                    const uint32_t tot = (uint32_t)__shfl((int)incl, GROUP - 1, GROUP);
+                    const uint32_t totc = (uint32_t)__shfl((int)icnt, GROUP - 1, GROUP);
+                    if (EMIT && hits) {
+                        uint64_t at = bytes + (incl - mine);
+                        for (uint32_t hm = hits; hm; hm &= hm - 1u) {
+                            const uint64_t a = ib + ((uint32_t)__ffs((int)hm) - 1u);
+                            uint64_t begin, end;
+                            if (strand == 0) { begin = a + 1; end = a + m; }
+                            else { begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a; }
+                            at += row_put(o + at, R, sc, begin, end);
+                        }
+                    }
+                    bytes += tot;
+                    nrows += totc;
+                }
+            } else if (!P.non_greedy) {
                 for (uint64_t a0 = 0; a0 < npos; a0 += GROUP) {
                     const uint64_t a = a0 + gl;
                     bool hit = false;
@@ -218,14 +329,14 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
 
 }  // namespace
 
-hipError_t launch_locate(bool emit, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
                          uint64_t* rows, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     const uint64_t blocks = (t.n * GROUP + 255) / 256;
-    if (emit) hipLaunchKernelGGL(k_locate<true>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len, out_off, out, rows);
-    else hipLaunchKernelGGL(k_locate<false>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len, out_off, out, rows);
+    if (emit) hipLaunchKernelGGL(k_locate<true>, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+    else hipLaunchKernelGGL(k_locate<false>, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go
 };
 
 // count pass: out_len[i] = bytes of all rows of record i; emit pass writes them at out_off[i]
-hipError_t launch_locate(bool emit, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
+hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
                          uint64_t* rows, hipStream_t st);
 
