@@ -181,15 +181,21 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     const Text T = text_of(buf, t, tt, gi);
     const uint32_t l = live ? T.L : 0;
     const uint64_t n = P.circular ? 2ull * l : l;  // len(record.Seq.Seq) after the doubling
+    if (EMIT && (!live || out_len[gi] == 0)) return;  // the count pass found no row for this record
     RowCtx R;
-    {
+    R.id = nullptr;
+    R.id_len = 0;
+    R.format = P.format;
+    bool have_id = false;  // the ID is only parsed once a record has a hit (group-uniform)
+    auto need_id = [&]() {
+        if (have_id) return;
         const uint32_t lh = t.l_head[gi];
         const uint8_t* h = buf + t.start[gi] + 1;
         uint32_t off;
         R.id_len = id_span_of(h, lh > 0 ? lh - 1 : 0, P.id_mode, &off);
         R.id = h + off;
-        R.format = P.format;
-    }
+        have_id = true;
+    };
     uint64_t bytes = 0;  // running row bytes of this record (group-uniform)
     uint32_t nrows = 0;
     uint8_t* o = EMIT ? out + out_off[gi] : nullptr;
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                     }
                     const uint32_t gmask = (uint32_t)((__ballot(hits != 0) >> gshift) & 0xFFFFull);
                     if (gmask == 0) continue;
+                    need_id();
                     uint32_t mine = 0, cnt = 0;
                     for (uint32_t hm = hits; hm; hm &= hm - 1u) {
                         const uint64_t a = ib + ((uint32_t)__ffs((int)hm) - 1u);
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                     }
                     const uint32_t mask = (uint32_t)((__ballot(hit) >> gshift) & 0xFFFFull);
                     if (mask == 0) continue;
+                    need_id();
                     uint32_t mine = hit ? row_len(R, begin, end) : 0u;
                     // exclusive prefix of row sizes inside the group
                     uint32_t incl = mine;
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                     nrows += (uint32_t)__popc(mask);
                 }
             } else if (gl == 0) {
+                need_id();
                 // --non-greedy (locate.go:659-663): the search resumes one base AFTER the match end
                 uint64_t a = 0;
                 while (a < npos) {
