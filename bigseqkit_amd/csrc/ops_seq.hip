@@ -160,6 +160,24 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     uint32_t sub_b = 0, sub_e = r.seq_len;
     if (P.region_on) sub_location(r.seq_len, P.region_start, P.region_end, &sub_b, &sub_e);
     const bool fast = r.contiguous && !P.remove_gaps;
+    // Whole FASTQ record printed unchanged (grep / rmdup / plain seq): Format() reproduces the
+    // record text byte for byte when the '+' line is bare, so copy it 16 bytes per lane.
+    if (fast && P.fastq && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id && !P.reverse &&
+        !P.use_lut && !P.region_on && t.aux[g] == 1) {
+        const uint8_t* src = buf + t.start[g];
+        const uint32_t body = n - 1;  // everything but the final newline, which the shard may lack
+        for (uint32_t x = gl * 16u; x < body; x += GROUP * 16u) {
+            if (x + 16u <= body) {
+                uint4 v;
+                __builtin_memcpy(&v, src + x, 16);
+                __builtin_memcpy(o + x, &v, 16);
+            } else {
+                for (uint32_t k = x; k < body; ++k) o[k] = src[k];
+            }
+        }
+        if (gl == 0) o[body] = '\n';
+        return;
+    }
     if (fast) {
         const uint32_t L = sub_e - sub_b;
         const uint8_t* rseq = r.seq + sub_b;
