@@ -152,8 +152,17 @@ struct StatsSink {
     }
 };
 
+#ifndef BSK_STATS_WAVES
+#define BSK_STATS_WAVES 0
+#endif
+#if BSK_STATS_WAVES
+#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu(BSK_STATS_WAVES, 8)))
+#else
+#define BSK_STATS_ATTR
+#endif
+
 template <bool FASTQ, bool ALL, bool DPP>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void k_stats(const uint8_t* __restrict__ buf, uint64_t n,
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats(const uint8_t* __restrict__ buf, uint64_t n,
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
                                                                    StatsDev D) {
