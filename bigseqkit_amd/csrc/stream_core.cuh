@@ -148,6 +148,9 @@ struct Lds {
     uint32_t b[(ALL && FASTQ) ? SLOTS : 1];
     uint32_t c[(ALL && FASTQ) ? SLOTS : 1];
     uint8_t flag[(!FASTQ) ? SLOTS : 4];
+    // sparse path (ALL == false): the 16-byte pieces that contain a newline, compacted in byte order
+    __attribute__((aligned(16))) uint4 sdata[(ALL) ? 1 : WAVE];
+    uint16_t stag[(ALL) ? 2 : WAVE];  // piece * 64 + lane of the owner
 };
 
 
@@ -228,125 +231,218 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
         }
         const bool edge = (tile_idx < rs) || (tile_idx + TILE > re);  // wave-uniform
 
-        Piece pc[NPIECE];
-        uint32_t base_nl[NPIECE], base_a[NPIECE], base_b[NPIECE], base_c[NPIECE];
-        const uint32_t tile_rank_base = line_base;
+        if constexpr (!ALL) {
+            // ---- sparse path -------------------------------------------------------------
+            // Only ~1 piece in 5 holds a newline (4 per 317 B).  Every lane runs a cheap exact
+            // "does my piece contain one" filter; the flagged pieces are compacted in byte order
+            // into LDS and only they pay for exact byte masks, the prefix scan and the events.
+            const uint32_t tile_rank_base = line_base;
+            uint32_t slot_p[NPIECE];
+            bool flagged[NPIECE];
+            uint32_t tot_slots = 0;
 #pragma unroll
-        for (int p = 0; p < NPIECE; ++p) {
-            const uint4 v = cur[p];
-            uint32_t nl = eq_mask16(v, 0x0A0A0A0Au);
-            uint32_t ma = 0, mb = 0, mc = 0;
-            if constexpr (ALL) {
-                uint32_t g = 0;
+            for (int p = 0; p < NPIECE; ++p) {
+                const uint4 v = cur[p];
+                const uint32_t y0 = v.x ^ 0x0A0A0A0Au, y1 = v.y ^ 0x0A0A0A0Au, y2 = v.z ^ 0x0A0A0A0Au,
+                               y3 = v.w ^ 0x0A0A0A0Au;
+                // (y - 0x01..) & ~y has bit 7 set in every zero byte; a false positive needs a true
+                // zero byte below it in the same dword, so "any newline in these 16 bytes" is exact
+                const uint32_t h = (((y0 - 0x01010101u) & ~y0) | ((y1 - 0x01010101u) & ~y1) |
+                                    ((y2 - 0x01010101u) & ~y2) | ((y3 - 0x01010101u) & ~y3)) & 0x80808080u;
+                const bool f = h != 0u;
+                const uint64_t bal = __ballot(f);
+                flagged[p] = f;
+                slot_p[p] = tot_slots + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                tot_slots += (uint32_t)__popcll(bal);
+            }
+            for (uint32_t sbase = 0; sbase < tot_slots; sbase += WAVE) {
+                // owners publish their flagged pieces of this round
 #pragma unroll
-                for (int k = 0; k < MAX_GAP_LETTERS; ++k)
-                    if (k < P.ngap) g |= eq_mask16(v, P.gap_rep[k]);
-                if constexpr (FASTQ) {
-                    ma = ge_mask16(v, P.k20);
-                    mb = ge_mask16(v, P.k30);
-                    mc = g;
+                for (int p = 0; p < NPIECE; ++p) {
+                    const uint32_t sl = slot_p[p] - sbase;
+                    if (flagged[p] && sl < (uint32_t)WAVE) {
+                        L.sdata[sl] = cur[p];
+                        L.stag[sl] = (uint16_t)(p * WAVE + lane);
+                    }
+                }
+                wave_lds_fence();
+                const bool have = sbase + (uint32_t)lane < tot_slots;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                uint32_t tag = 0;
+                if (have) { v = L.sdata[lane]; tag = L.stag[lane]; }
+                const uint32_t off0 = (tag >> 6) * (uint32_t)PIECE_BYTES + (tag & 63u) * 16u;
+                uint32_t nl = have ? eq_mask16(v, 0x0A0A0A0Au) : 0u;
+                if (edge) {
+                    const uint64_t I = tile_idx + off0;
+                    int64_t lo = (int64_t)rs - (int64_t)I, hi = (int64_t)re - (int64_t)I;
+                    lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+                    hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                    nl &= hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                }
+                const uint32_t cnt = (uint32_t)__popc(nl);
+                const uint32_t incl = wave_incl_scan<DPP>(cnt);
+                const uint32_t round_base = line_base;
+                const uint32_t rank0 = round_base + incl - cnt;
+                line_base += wave_last(incl);
+                for (uint32_t wb = round_base; wb < line_base; wb += CAP) {
+                    uint32_t m = nl, k = 0;
+                    while (m) {
+                        const uint32_t bpos = (uint32_t)__ffs((int)m) - 1u;
+                        m &= m - 1u;
+                        const uint32_t w = rank0 + k - wb;
+                        ++k;
+                        if (w < (uint32_t)CAP) {
+                            const uint32_t s = HISTORY + w;
+                            const uint32_t off = off0 + bpos;
+                            L.pos[s] = tile_rel + off;
+                            if constexpr (!FASTQ) {
+                                const uint64_t an = tile_idx + off + 1;  // byte after the newline
+                                uint8_t nc;
+                                if (bpos < 15u) {
+                                    const uint32_t d = (bpos + 1u) >> 2, sh8 = ((bpos + 1u) & 3u) * 8u;
+                                    const uint32_t wd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
+                                    nc = (uint8_t)(wd >> sh8);
+                                } else {
+                                    nc = an < n ? buf[an] : (uint8_t)0;
+                                }
+                                L.flag[s] = (an >= re || nc == '>') ? 1 : 0;
+                            }
+                        }
+                    }
+                    wave_lds_fence();
+                    const uint32_t E = (line_base - wb) < (uint32_t)CAP ? (line_base - wb) : (uint32_t)CAP;
+                    sink.template batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf);
+                    keep_history<FASTQ, ALL>(L, E);
+                }
+                wave_lds_fence();  // the next round overwrites sdata / stag
+            }
+            if (line_base == tile_rank_base) {
+                // lines longer than 2^31 bytes cannot be measured with 32-bit relative positions
+                if (++quiet_tiles >= (1u << 31) / TILE) sink.err |= ERR_LINE_TOO_LONG;
+            } else {
+                quiet_tiles = 0;
+            }
+        } else {
+            Piece pc[NPIECE];
+            uint32_t base_nl[NPIECE], base_a[NPIECE], base_b[NPIECE], base_c[NPIECE];
+            const uint32_t tile_rank_base = line_base;
+    #pragma unroll
+            for (int p = 0; p < NPIECE; ++p) {
+                const uint4 v = cur[p];
+                uint32_t nl = eq_mask16(v, 0x0A0A0A0Au);
+                uint32_t ma = 0, mb = 0, mc = 0;
+                if constexpr (ALL) {
+                    uint32_t g = 0;
+    #pragma unroll
+                    for (int k = 0; k < MAX_GAP_LETTERS; ++k)
+                        if (k < P.ngap) g |= eq_mask16(v, P.gap_rep[k]);
+                    if constexpr (FASTQ) {
+                        ma = ge_mask16(v, P.k20);
+                        mb = ge_mask16(v, P.k30);
+                        mc = g;
+                    } else {
+                        ma = g;
+                    }
+                }
+                if (edge) {
+                    const uint64_t I = tile_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16;
+                    int64_t lo = (int64_t)rs - (int64_t)I, hi = (int64_t)re - (int64_t)I;
+                    lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+                    hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                    const uint32_t valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    nl &= valid; ma &= valid; mb &= valid; mc &= valid;
+                }
+                pc[p].m_nl_a = nl | (ma << 16);
+                pc[p].m_b_c = mb | (mc << 16);
+                const uint32_t lo_cnt = (uint32_t)__popc(nl) | ((uint32_t)__popc(ma) << 16);
+                const uint32_t incl_lo = wave_incl_scan<DPP>(lo_cnt);
+                pc[p].ex_lo = incl_lo - lo_cnt;
+                const uint32_t tot_lo = wave_last(incl_lo);
+                base_nl[p] = line_base;
+                base_a[p] = run_a;
+                line_base += tot_lo & 0xFFFFu;
+                run_a += tot_lo >> 16;
+                if constexpr (ALL && FASTQ) {
+                    const uint32_t hi_cnt = (uint32_t)__popc(mb) | ((uint32_t)__popc(mc) << 16);
+                    const uint32_t incl_hi = wave_incl_scan<DPP>(hi_cnt);
+                    pc[p].ex_hi = incl_hi - hi_cnt;
+                    const uint32_t tot_hi = wave_last(incl_hi);
+                    base_b[p] = run_b;
+                    base_c[p] = run_c;
+                    run_b += tot_hi & 0xFFFFu;
+                    run_c += tot_hi >> 16;
                 } else {
-                    ma = g;
+                    pc[p].ex_hi = 0;
+                    base_b[p] = 0;
+                    base_c[p] = 0;
                 }
             }
-            if (edge) {
-                const uint64_t I = tile_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16;
-                int64_t lo = (int64_t)rs - (int64_t)I, hi = (int64_t)re - (int64_t)I;
-                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-                const uint32_t valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-                nl &= valid; ma &= valid; mb &= valid; mc &= valid;
-            }
-            pc[p].m_nl_a = nl | (ma << 16);
-            pc[p].m_b_c = mb | (mc << 16);
-            const uint32_t lo_cnt = (uint32_t)__popc(nl) | ((uint32_t)__popc(ma) << 16);
-            const uint32_t incl_lo = wave_incl_scan<DPP>(lo_cnt);
-            pc[p].ex_lo = incl_lo - lo_cnt;
-            const uint32_t tot_lo = wave_last(incl_lo);
-            base_nl[p] = line_base;
-            base_a[p] = run_a;
-            line_base += tot_lo & 0xFFFFu;
-            run_a += tot_lo >> 16;
-            if constexpr (ALL && FASTQ) {
-                const uint32_t hi_cnt = (uint32_t)__popc(mb) | ((uint32_t)__popc(mc) << 16);
-                const uint32_t incl_hi = wave_incl_scan<DPP>(hi_cnt);
-                pc[p].ex_hi = incl_hi - hi_cnt;
-                const uint32_t tot_hi = wave_last(incl_hi);
-                base_b[p] = run_b;
-                base_c[p] = run_c;
-                run_b += tot_hi & 0xFFFFu;
-                run_c += tot_hi >> 16;
+            const uint32_t tile_events = line_base - tile_rank_base;
+            if (tile_events == 0) {
+                // lines longer than 2^31 bytes cannot be measured with 32-bit relative positions
+                if (++quiet_tiles >= (1u << 31) / TILE) sink.err |= ERR_LINE_TOO_LONG;
             } else {
-                pc[p].ex_hi = 0;
-                base_b[p] = 0;
-                base_c[p] = 0;
+                quiet_tiles = 0;
             }
-        }
-        const uint32_t tile_events = line_base - tile_rank_base;
-        if (tile_events == 0) {
-            // lines longer than 2^31 bytes cannot be measured with 32-bit relative positions
-            if (++quiet_tiles >= (1u << 31) / TILE) sink.err |= ERR_LINE_TOO_LONG;
-        } else {
-            quiet_tiles = 0;
-        }
 
-        // events of this tile, CAP at a time (one batch for ordinary data).  The newline masks of
-        // the pieces are merged into one 64-bit word so that ONE loop visits every newline of the
-        // lane (~3 iterations per tile for 150 bp reads instead of ~2 per piece).
-        static_assert(NPIECE <= 4, "merged emission packs at most four 16-bit masks");
-        uint64_t m64 = 0, a64 = 0, b64 = 0, c64 = 0;
-#pragma unroll
-        for (int p = 0; p < NPIECE; ++p) {
-            m64 |= (uint64_t)(pc[p].m_nl_a & 0xFFFFu) << (16 * p);
-            if constexpr (ALL) a64 |= (uint64_t)(pc[p].m_nl_a >> 16) << (16 * p);
-            if constexpr (ALL && FASTQ) {
-                b64 |= (uint64_t)(pc[p].m_b_c & 0xFFFFu) << (16 * p);
-                c64 |= (uint64_t)(pc[p].m_b_c >> 16) << (16 * p);
+            // events of this tile, CAP at a time (one batch for ordinary data).  The newline masks of
+            // the pieces are merged into one 64-bit word so that ONE loop visits every newline of the
+            // lane (~3 iterations per tile for 150 bp reads instead of ~2 per piece).
+            static_assert(NPIECE <= 4, "merged emission packs at most four 16-bit masks");
+            uint64_t m64 = 0, a64 = 0, b64 = 0, c64 = 0;
+    #pragma unroll
+            for (int p = 0; p < NPIECE; ++p) {
+                m64 |= (uint64_t)(pc[p].m_nl_a & 0xFFFFu) << (16 * p);
+                if constexpr (ALL) a64 |= (uint64_t)(pc[p].m_nl_a >> 16) << (16 * p);
+                if constexpr (ALL && FASTQ) {
+                    b64 |= (uint64_t)(pc[p].m_b_c & 0xFFFFu) << (16 * p);
+                    c64 |= (uint64_t)(pc[p].m_b_c >> 16) << (16 * p);
+                }
             }
-        }
-        for (uint32_t wb = tile_rank_base; wb < line_base; wb += CAP) {
-            uint64_t m = m64;
-            while (m) {
-                const uint32_t q = (uint32_t)__ffsll((long long)m) - 1u;
-                m &= m - 1ull;
-                const uint32_t p = q >> 4, bpos = q & 15u, sh = q & 48u;
-                const uint32_t below = (1u << bpos) - 1u;
-                // per-piece values selected by p (static unrolled compare chain keeps them in registers)
-                uint32_t r0 = base_nl[0] + (pc[0].ex_lo & 0xFFFFu);
-                uint32_t sa = base_a[0] + (pc[0].ex_lo >> 16), sb = base_b[0] + (pc[0].ex_hi & 0xFFFFu),
-                         sc = base_c[0] + (pc[0].ex_hi >> 16);
-#pragma unroll
-                for (int pp = 1; pp < NPIECE; ++pp) {
-                    if (p == (uint32_t)pp) {
-                        r0 = base_nl[pp] + (pc[pp].ex_lo & 0xFFFFu);
-                        if constexpr (ALL) sa = base_a[pp] + (pc[pp].ex_lo >> 16);
+            for (uint32_t wb = tile_rank_base; wb < line_base; wb += CAP) {
+                uint64_t m = m64;
+                while (m) {
+                    const uint32_t q = (uint32_t)__ffsll((long long)m) - 1u;
+                    m &= m - 1ull;
+                    const uint32_t p = q >> 4, bpos = q & 15u, sh = q & 48u;
+                    const uint32_t below = (1u << bpos) - 1u;
+                    // per-piece values selected by p (static unrolled compare chain keeps them in registers)
+                    uint32_t r0 = base_nl[0] + (pc[0].ex_lo & 0xFFFFu);
+                    uint32_t sa = base_a[0] + (pc[0].ex_lo >> 16), sb = base_b[0] + (pc[0].ex_hi & 0xFFFFu),
+                             sc = base_c[0] + (pc[0].ex_hi >> 16);
+    #pragma unroll
+                    for (int pp = 1; pp < NPIECE; ++pp) {
+                        if (p == (uint32_t)pp) {
+                            r0 = base_nl[pp] + (pc[pp].ex_lo & 0xFFFFu);
+                            if constexpr (ALL) sa = base_a[pp] + (pc[pp].ex_lo >> 16);
+                            if constexpr (ALL && FASTQ) {
+                                sb = base_b[pp] + (pc[pp].ex_hi & 0xFFFFu);
+                                sc = base_c[pp] + (pc[pp].ex_hi >> 16);
+                            }
+                        }
+                    }
+                    const uint32_t rank = r0 + (uint32_t)__popc((uint32_t)(m64 >> sh) & below);
+                    const uint32_t w = rank - wb;
+                    if (w < (uint32_t)CAP) {
+                        const uint32_t s = HISTORY + w;
+                        const uint32_t off = p * (uint32_t)PIECE_BYTES + (uint32_t)lane * 16u + bpos;
+                        L.pos[s] = tile_rel + off;
+                        if constexpr (ALL) L.a[s] = sa + (uint32_t)__popc((uint32_t)(a64 >> sh) & below);
                         if constexpr (ALL && FASTQ) {
-                            sb = base_b[pp] + (pc[pp].ex_hi & 0xFFFFu);
-                            sc = base_c[pp] + (pc[pp].ex_hi >> 16);
+                            L.b[s] = sb + (uint32_t)__popc((uint32_t)(b64 >> sh) & below);
+                            L.c[s] = sc + (uint32_t)__popc((uint32_t)(c64 >> sh) & below);
+                        }
+                        if constexpr (!FASTQ) {
+                            const uint64_t an = tile_idx + off + 1;  // byte after the newline
+                            L.flag[s] = (an >= re || buf[an] == '>') ? 1 : 0;
                         }
                     }
                 }
-                const uint32_t rank = r0 + (uint32_t)__popc((uint32_t)(m64 >> sh) & below);
-                const uint32_t w = rank - wb;
-                if (w < (uint32_t)CAP) {
-                    const uint32_t s = HISTORY + w;
-                    const uint32_t off = p * (uint32_t)PIECE_BYTES + (uint32_t)lane * 16u + bpos;
-                    L.pos[s] = tile_rel + off;
-                    if constexpr (ALL) L.a[s] = sa + (uint32_t)__popc((uint32_t)(a64 >> sh) & below);
-                    if constexpr (ALL && FASTQ) {
-                        L.b[s] = sb + (uint32_t)__popc((uint32_t)(b64 >> sh) & below);
-                        L.c[s] = sc + (uint32_t)__popc((uint32_t)(c64 >> sh) & below);
-                    }
-                    if constexpr (!FASTQ) {
-                        const uint64_t an = tile_idx + off + 1;  // byte after the newline
-                        L.flag[s] = (an >= re || buf[an] == '>') ? 1 : 0;
-                    }
-                }
+                wave_lds_fence();
+                const uint32_t E = (line_base - wb) < (uint32_t)CAP ? (line_base - wb) : (uint32_t)CAP;
+                sink.template batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf);
+                keep_history<FASTQ, ALL>(L, E);
             }
-            wave_lds_fence();
-            const uint32_t E = (line_base - wb) < (uint32_t)CAP ? (line_base - wb) : (uint32_t)CAP;
-            sink.template batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf);
-            keep_history<FASTQ, ALL>(L, E);
         }
         if (t + 1 < ntiles) {
 #pragma unroll
