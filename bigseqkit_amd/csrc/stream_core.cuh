@@ -388,7 +388,9 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
             // events of this tile, CAP at a time (one batch for ordinary data).  The newline masks of
             // the pieces are merged into one 64-bit word so that ONE loop visits every newline of the
             // lane (~3 iterations per tile for 150 bp reads instead of ~2 per piece).
+    #ifndef BSK_EXPERIMENT
             static_assert(NPIECE <= 4, "merged emission packs at most four 16-bit masks");
+#endif
             uint64_t m64 = 0, a64 = 0, b64 = 0, c64 = 0;
     #pragma unroll
             for (int p = 0; p < NPIECE; ++p) {
