@@ -148,6 +148,9 @@ struct Lds {
     uint32_t b[(ALL && FASTQ) ? SLOTS : 1];
     uint32_t c[(ALL && FASTQ) ? SLOTS : 1];
     uint8_t flag[(!FASTQ) ? SLOTS : 4];
+    // FASTQ: the byte that follows the newline when the emitting lane had it in registers
+    // (0x100 | byte), 0 = unknown -> the sink probes memory (1 event in 16 on the sparse path)
+    uint16_t nc[(FASTQ) ? SLOTS : 4];
     // sparse path (ALL == false): the 16-byte pieces that contain a newline, compacted in byte order
     __attribute__((aligned(16))) uint4 sdata[(ALL) ? 1 : WAVE];
     uint16_t stag[(ALL) ? 2 : WAVE];  // piece * 64 + lane of the owner
@@ -161,8 +164,10 @@ __device__ __forceinline__ void keep_history(Lds<FASTQ, ALL>& L, uint32_t E) {
     wave_lds_fence();
     uint32_t hp = 0, ha = 0, hb = 0, hc = 0;
     uint8_t hf = 0;
+    uint16_t hn = 0;
     if (lane < HISTORY) {
         hp = L.pos[E + lane];
+        if constexpr (FASTQ) hn = L.nc[E + lane];
         if constexpr (ALL) ha = L.a[E + lane];
         if constexpr (ALL && FASTQ) { hb = L.b[E + lane]; hc = L.c[E + lane]; }
         if constexpr (!FASTQ) hf = L.flag[E + lane];
@@ -170,11 +175,24 @@ __device__ __forceinline__ void keep_history(Lds<FASTQ, ALL>& L, uint32_t E) {
     wave_lds_fence();
     if (lane < HISTORY) {
         L.pos[lane] = hp;
+        if constexpr (FASTQ) L.nc[lane] = hn;
         if constexpr (ALL) L.a[lane] = ha;
         if constexpr (ALL && FASTQ) { L.b[lane] = hb; L.c[lane] = hc; }
         if constexpr (!FASTQ) L.flag[lane] = hf;
     }
     wave_lds_fence();
+}
+
+// the byte after newline event `s` (its absolute index is abs_next); 0 when past the range
+template <bool FASTQ, bool ALL>
+__device__ __forceinline__ uint8_t next_char(const Lds<FASTQ, ALL>& L, uint32_t s, uint64_t abs_next, uint64_t re,
+                                             const uint8_t* __restrict__ buf) {
+    if (abs_next >= re) return 0;
+    if constexpr (FASTQ) {
+        const uint32_t v = L.nc[s];
+        if (v & 0x100u) return (uint8_t)v;
+    }
+    return buf[abs_next];
 }
 
 // absolute byte index of an event from its range-relative position; valid for
@@ -200,6 +218,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
     // virtual events before the range: a newline at relative position -1
     if (lane < HISTORY) {
         L.pos[lane] = 0xFFFFFFFFu;
+        if constexpr (FASTQ) L.nc[lane] = 0;
         if constexpr (ALL) L.a[lane] = 0;
         if constexpr (ALL && FASTQ) { L.b[lane] = 0; L.c[lane] = 0; }
         if constexpr (!FASTQ) L.flag[lane] = 1;
@@ -295,16 +314,18 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                             const uint32_t s = HISTORY + w;
                             const uint32_t off = off0 + bpos;
                             L.pos[s] = tile_rel + off;
-                            if constexpr (!FASTQ) {
-                                const uint64_t an = tile_idx + off + 1;  // byte after the newline
-                                uint8_t nc;
-                                if (bpos < 15u) {
-                                    const uint32_t d = (bpos + 1u) >> 2, sh8 = ((bpos + 1u) & 3u) * 8u;
-                                    const uint32_t wd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
-                                    nc = (uint8_t)(wd >> sh8);
-                                } else {
-                                    nc = an < n ? buf[an] : (uint8_t)0;
-                                }
+                            // the byte after the newline sits in the same 16 bytes 15 times out of 16
+                            uint32_t nc16 = 0;
+                            if (bpos < 15u) {
+                                const uint32_t d = (bpos + 1u) >> 2, sh8 = ((bpos + 1u) & 3u) * 8u;
+                                const uint32_t wd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
+                                nc16 = 0x100u | ((wd >> sh8) & 0xFFu);
+                            }
+                            if constexpr (FASTQ) {
+                                L.nc[s] = (uint16_t)nc16;
+                            } else {
+                                const uint64_t an = tile_idx + off + 1;
+                                const uint8_t nc = nc16 ? (uint8_t)nc16 : (an < n ? buf[an] : (uint8_t)0);
                                 L.flag[s] = (an >= re || nc == '>') ? 1 : 0;
                             }
                         }
@@ -429,6 +450,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                         const uint32_t s = HISTORY + w;
                         const uint32_t off = p * (uint32_t)PIECE_BYTES + (uint32_t)lane * 16u + bpos;
                         L.pos[s] = tile_rel + off;
+                        if constexpr (FASTQ) L.nc[s] = 0;  // dense path: the sink probes memory
                         if constexpr (ALL) L.a[s] = sa + (uint32_t)__popc((uint32_t)(a64 >> sh) & below);
                         if constexpr (ALL && FASTQ) {
                             L.b[s] = sb + (uint32_t)__popc((uint32_t)(b64 >> sh) & below);
@@ -467,6 +489,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
     if (virt) {
         if (lane == 0) {
             L.pos[HISTORY] = end_rel;
+            if constexpr (FASTQ) L.nc[HISTORY] = 0;
             if constexpr (ALL) L.a[HISTORY] = run_a;
             if constexpr (ALL && FASTQ) { L.b[HISTORY] = run_b; L.c[HISTORY] = run_c; }
             if constexpr (!FASTQ) L.flag[HISTORY] = 1;

@@ -57,14 +57,14 @@ struct IndexSink {
                 if (on && D.write) {
                     // same structural validation as the stats kernel (strict 4-line FASTQ)
                     if (role == 1u) {
-                        if (abs_next >= re || buf[abs_next] != '+') err |= ERR_BAD_PLUS;
+                        if (next_char(L, s, abs_next, re, buf) != '+') err |= ERR_BAD_PLUS;
                     } else if (role == 0u) {
-                        if (abs_next < re && buf[abs_next] == '+') err |= ERR_BAD_PLUS;
+                        if (next_char(L, s, abs_next, re, buf) == '+') err |= ERR_BAD_PLUS;
                     } else if (role == 3u) {
                         const uint32_t p1 = L.pos[s - 1], p2 = L.pos[s - 2], p3 = L.pos[s - 3], p4 = L.pos[s - 4];
                         const uint32_t lq = p - p1 - 1u, lp = p1 - p2 - 1u, ls = p2 - p3 - 1u, lh = p3 - p4 - 1u;
                         if (lq != ls) err |= ERR_LEN_MISMATCH;
-                        if (abs_next < re && buf[abs_next] != '@') err |= ERR_BAD_HEADER;
+                        if (abs_next < re && next_char(L, s, abs_next, re, buf) != '@') err |= ERR_BAD_HEADER;
                         const uint64_t g = base + (rank >> 2);
                         if (g < limit) {
                             D.t.start[g] = abs_of(p4, tile_idx, tile_rel) + 1;

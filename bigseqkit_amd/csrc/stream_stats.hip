@@ -94,7 +94,7 @@ struct StatsSink {
                     if (role == 1u) {
                         sumlen += len;
                         if constexpr (ALL) gap += (uint32_t)(L.c[s] - L.c[s - 1]);
-                        if (abs_next >= re || buf[abs_next] != '+') err |= ERR_BAD_PLUS;
+                        if (next_char(L, s, abs_next, re, buf) != '+') err |= ERR_BAD_PLUS;
                     } else if (role == 3u) {
                         const uint32_t slen = L.pos[s - 2] - L.pos[s - 3] - 1u;
                         if (len != slen) err |= ERR_LEN_MISMATCH;
@@ -103,10 +103,10 @@ struct StatsSink {
                             q30 += (uint32_t)(L.b[s] - L.b[s - 1]);
                         }
                         nrec += 1;
-                        if (abs_next < re && buf[abs_next] != '@') err |= ERR_BAD_HEADER;
+                        if (abs_next < re && next_char(L, s, abs_next, re, buf) != '@') err |= ERR_BAD_HEADER;
                     } else if (role == 0u) {
                         // a non-empty sequence line must not start with '+'
-                        if (abs_next < re && buf[abs_next] == '+') err |= ERR_BAD_PLUS;
+                        if (next_char(L, s, abs_next, re, buf) == '+') err |= ERR_BAD_PLUS;
                     }
                 }
             } else {
