@@ -133,6 +133,17 @@ def main():
 
     total_bytes = total_rec * REC
     ms_per_step = dt / args.steps * 1e3
+    # HBM bytes per k_stats launch from the PMC passes (rocprofv3 cannot wrap itself: the counters come from the
+    # committed profile of this same command, scripts/gpu_round.sh + scripts/pmc_traffic.py); only valid for the
+    # full single-GPU workload it was collected on.
+    traffic, traffic_src = None, None
+    pmc = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if pmc and world == 1 and total_bytes > 99e9:
+        try:
+            traffic = json.load(open(pmc[-1]))["per_launch"]["stats"]["traffic_bytes"]
+            traffic_src = "profiles/" + os.path.basename(pmc[-1]) + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, gfx950-corrected)"
+        except (KeyError, ValueError):
+            pass
     out = {
         "metric": "M records/s + GB/s (vs HBM roofline) on 100GB FASTQ stats",
         "value": round(total_rec * args.steps / dt / 1e6, 3),
@@ -159,7 +170,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": nbytes,
             "avg_launch_ms": round(k_ms, 4),
             "k_prep_avg_launch_ms": round(p_ms, 4),

@@ -16,5 +16,7 @@ for f in $SRC/*.hip $SRC/*.cpp; do
   OBJS+=("$o")
 done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbsk.so" "${OBJS[@]}"
+mkdir -p bigseqkit_amd/bin
+${CXX:-g++} $FLAGS -o bigseqkit_amd/bin/bigseqkit cli/bigseqkit.cpp -L"$OUT" -lbsk -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 make -s -C oracle
 echo "built $OUT/libbsk.so and oracle/_build/liboracle.so"

@@ -1,0 +1,158 @@
+"""The `bigseqkit` command line (cli/bigseqkit.cpp): cobra flag tables -> option JSON (CPU, --dry-run) and
+end-to-end runs on files compared with the CPU oracle driven by the SAME option JSON (GPU).
+Flag tables: /root/reference/bigseqkit-cli/{helper.go:161-173,seq.go:54-73,stats.go:61-65,grep.go:81-96,
+locate.go:61-74,subseq.go:56-67,translate.go:86-94,rmdup.go:45-51}."""
+import json
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+import oracle
+import seqgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bigseqkit_amd", "bin", "bigseqkit")
+
+
+def run(*args, ok=True):
+    p = subprocess.run([CLI, *args], capture_output=True, timeout=600)
+    if ok:
+        assert p.returncode == 0, p.stderr.decode()
+    return p
+
+
+def dry(*args):
+    out = run(*args, "--dry-run").stdout.decode().split("\n")
+    return out[0], json.loads(out[1]), [f for f in out[2:] if f]
+
+
+def test_persistent_flag_defaults_match_reference_cli():
+    op, js, files = dry("seq", "a.fa", "b.fa")
+    assert op == "SeqTransform" and files == ["a.fa", "b.fa"]
+    assert js["Config"] == {"SeqType": "auto", "LineWidth": 60, "IDRegexp": "^(\\S+)\\s?", "IDNCBI": False,
+                            "Quiet": False, "AlphabetGuessSeqLength": 10000}
+    assert js["GapLetters"] == "- \t." and js["ValidateSeqLength"] == 10000 and js["QualAsciiBase"] == 33
+    assert js["MinLen"] == -1 and js["MaxQual"] == -1
+
+
+def test_shorthand_clusters_values_and_slices():
+    op, js, files = dry("grep", "-sic", "-p", "ACGT,TTT", "-p", '"A,C"', "-R", "1:30", "-m1", "--max-mismatch=2", "x.fq")
+    assert op == "Grep" and files == ["x.fq"]
+    assert js["Pattern"] == ["ACGT", "TTT", "A,C"]
+    assert js["BySeq"] and js["IgnoreCase"] and js["Circular"] and not js["ByName"]
+    assert js["Region"] == "1:30" and js["MaxMismatch"] == 2
+    op, js, _ = dry("translate", "-f", "1,2,-1", "-T11", "-xMF", "--trim")
+    assert op == "Translate" and js["Frame"] == ["1", "2", "-1"] and js["TranslTable"] == 11
+    assert js["AllowUnknownCodon"] and js["InitCodonAsM"] and js["AppendFrame"] and js["Trim"] and not js["Clean"]
+    assert dry("translate")[1]["Frame"] == ["1"]
+    op, js, _ = dry("subseq", "-r", "2:-3", "-u", "5", "-f")
+    assert op == "SubseqTransform" and js["Region"] == "2:-3" and js["UpStream"] == 5 and js["OnlyFlank"]
+    assert js["GtfTag"] == "gene_id" and js["Chr"] == []
+    op, js, _ = dry("stats", "-aT", "-G", "-.", "-E", "illumina-1.3+")
+    assert op == "Stats" and js["All"] and js["Tabular"] and js["GapLetters"] == "-." and js["FqEncoding"] == "illumina-1.3+"
+    op, js, _ = dry("rmdup", "-s", "-i", "-P")
+    assert op == "RmDup" and js["BySeq"] and js["IgnoreCase"] and js["OnlyPositiveStrand"] and not js["ByName"]
+    op, js, _ = dry("locate", "-p", "AA", "-GMP", "-w", "0")
+    assert op == "Locate" and js["NonGreedy"] and js["HideMatched"] and js["OnlyPositiveStrand"] and js["Config"]["LineWidth"] == 0
+
+
+def test_id_ncbi_replaces_the_id_regexp():
+    assert dry("seq", "--id-ncbi")[1]["Config"]["IDRegexp"] == r"\|([^\|]+)\| "
+
+
+def test_flag_value_checks_use_the_reference_messages(tmp_path):
+    for args, msg in [(("seq", "-w", "-1"), "value of flag --line-width should be greater than 0"),
+                      (("seq", "-V", "10"), "value of flag --validate-seq-length too small, should >= 1000"),
+                      (("seq", "-b", "0"), "value of flag --qual-ascii-base should be greater than 0"),
+                      (("translate", "-T", "0"), "value of flag --transl-table should be greater than 0"),
+                      (("grep", "-m", "-2"), "value of flag --max-mismatch should be greater than 0"),
+                      (("seq", "--alphabet-guess-seq-length", "5"), "value of flag --alphabet-guess-seq-length too small, should >= 1000"),
+                      (("seq", "--nope"), "unknown flag: --nope"),
+                      (("seq", "-w", "x"), 'invalid argument "x" for "--line-width" flag'),
+                      (("frobnicate",), 'unknown command "frobnicate" for "bigseqkit"')]:
+        p = run(*args, "--dry-run", ok=False)
+        assert p.returncode == 1 and msg in p.stderr.decode(), (args, p.stderr)
+
+
+def test_infile_list(tmp_path):
+    lst = tmp_path / "files.txt"
+    lst.write_text("c.fa\nd.fq\n")
+    assert dry("seq", "a.fa", "--infile-list", str(lst))[2] == ["a.fa", "c.fa", "d.fq"]
+
+
+# ------------------------------------------------------------------ GPU: files in, files out
+def _write(tmp_path, name, data):
+    p = tmp_path / name
+    p.write_bytes(data)
+    return str(p)
+
+
+CASES = [
+    ("seq", ["-rp", "-w", "50"], "fa"), ("seq", ["-n", "-i"], "fq"), ("seq", ["-m", "100", "-M", "400", "-u"], "fa"),
+    ("seq", ["-Q", "20"], "fq"),
+    ("grep", ["-s", "-p", "ACGTAC,GGATCC", "-i"], "fa"), ("grep", ["-n", "-p", "r3 x", "-v"], "fq"),
+    ("subseq", ["-r", "3:-4"], "fa"), ("subseq", ["-r", "-20:-1"], "fq"),
+    ("locate", ["-p", "ACG,TTGA", "-i"], "fa"), ("locate", ["-p", "GATC", "-P", "-M"], "fq"),
+    ("translate", ["-f", "1,-2", "-x"], "fa"), ("translate", ["-T", "11", "-F", "--trim", "-x"], "fa"),
+    ("rmdup", ["-s"], "fa"), ("rmdup", ["-n"], "fq"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cmd,flags,kind", CASES)
+def test_cli_output_equals_oracle(tmp_path, cmd, flags, kind):
+    rng = random.Random(zlib.crc32(repr((cmd, flags)).encode()))
+    fastq = kind == "fq"
+    data = seqgen.random_fastq(rng, 300, min_len=1) if fastq else seqgen.random_fasta(rng, 300, min_len=1)
+    if cmd == "rmdup":
+        data = data + data[:len(data)]  # every record twice
+    path = _write(tmp_path, "in." + kind, data)
+    op, js, _ = dry(cmd, *flags, path)
+    fn = {"seq": oracle.seq, "grep": oracle.grep, "subseq": oracle.subseq, "locate": oracle.locate,
+          "translate": oracle.translate, "rmdup": oracle.rmdup}[cmd]
+    want = fn(data, fastq, json.dumps(js))
+    want = want[0] if isinstance(want, tuple) else want
+    assert run(cmd, *flags, path, "-o", "-").stdout == want
+    # default store: <file>-out directory of parts; --merge: one file
+    run(cmd, *flags, path, "--partitions", "3")
+    parts = sorted(os.listdir(path + "-out"))
+    assert parts == ["part00000", "part00001", "part00002"]
+    assert b"".join(open(os.path.join(path + "-out", p), "rb").read() for p in parts) == want
+    merged = str(tmp_path / "merged.out")
+    run(cmd, *flags, path, "--merge", "-o", merged)
+    assert open(merged, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_cli_stats_two_inputs_and_grep_count(tmp_path):
+    rng = random.Random(5)
+    fq = seqgen.random_fastq(rng, 500, min_len=1)
+    fa = seqgen.random_fasta(rng, 200, min_len=1)
+    a, b = _write(tmp_path, "a.fastq", fq), _write(tmp_path, "b.fna", fa)
+    for flags in (["-a"], ["-T"], ["-a", "-T"], []):
+        _, js, _ = dry("stats", *flags)
+        t0 = oracle.stats_string(fq, True, json.dumps(js), name="input0")
+        t1 = oracle.stats_string(fa, False, json.dumps(js), name="input1")
+        head = t1.split("\n")[0] + "\n"
+        body = "\n".join(t0.split("\n")[1:]) + "\n" + "\n".join(t1.split("\n")[1:]) + "\n"
+        assert run("stats", *flags, a, b).stdout.decode() == head + body
+    _, js, _ = dry("grep", "-s", "-p", "ACG", "-C")
+    js["Count"] = True
+    want = int(oracle.grep(fa, False, json.dumps(js)).strip() or 0)
+    assert run("grep", "-s", "-p", "ACG", "-C", b).stdout == str(want).encode()
+
+
+@pytest.mark.gpu
+def test_cli_sniffs_format_from_first_byte_and_reports_kernel_errors(tmp_path):
+    rng = random.Random(9)
+    fa = seqgen.random_fasta(rng, 50, min_len=1)
+    p = _write(tmp_path, "noext", fa)
+    assert run("seq", p, "-o", "-").stdout == oracle.seq(fa, False, json.dumps(dry("seq")[1]))
+    bad = _write(tmp_path, "bad.txt", b"hello\n")
+    r = run("seq", bad, ok=False)
+    assert r.returncode == 1 and b"must be fasta or fastq" in r.stderr
+    r = run("grep", p, ok=False)
+    assert r.returncode == 1 and b"one of flags -p (--pattern) and -f (--pattern-file) needed" in r.stderr
