@@ -213,6 +213,9 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_names) hipFree(c->d_names);
         if (c->d_names_off) hipFree(c->d_names_off);
         if (c->d_pat) hipFree(c->d_pat);
+        if (c->d_cls) hipFree(c->d_cls);
+        if (c->d_set_keys) hipFree(c->d_set_keys);
+        if (c->d_set_idx) hipFree(c->d_set_idx);
         if (c->d_pat_off) hipFree(c->d_pat_off);
         for (void* p : {(void*)c->sparse.start, (void*)c->sparse.l_head, (void*)c->sparse.l_seq, (void*)c->sparse.aux})
             if (p) hipFree(p);

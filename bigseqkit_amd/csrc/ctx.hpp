@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <array>
 #include <cstdint>
 #include <map>
 #include <mutex>
@@ -75,7 +76,19 @@ struct bsk_ctx {
     uint8_t* d_pat = nullptr;
     uint32_t* d_pat_off = nullptr;
     uint64_t pat_cap = 0, pat_off_cap = 0;
-    std::vector<std::string> pattern_names;  // locate: names as given (== the -p text)
+    std::vector<std::string> pattern_names;  // locate: names as given (== the -p text, or the FASTA name with -f)
+    // class patterns (-d, -m, -F): one 256-bit accept set per pattern position (pattern_match.cuh)
+    std::vector<std::vector<std::array<uint32_t, 8>>> pattern_cls;
+    bool general = false;     // match through pattern_cls instead of the exact byte compare
+    int max_mm = 0;           // -m
+    bool fmi_order = false;   // locate -m / -F: all patterns on '+', then all on '-' (locate.go:208-391)
+    uint32_t* d_cls = nullptr;
+    uint64_t cls_cap = 0;
+    // grep by ID / name with many patterns: hash set on the device
+    uint64_t* d_set_keys = nullptr;
+    uint32_t* d_set_idx = nullptr;
+    uint64_t set_keys_cap = 0, set_idx_cap = 0, set_slots = 0;
+    bool patterns_uploaded = false;  // exact patterns + set do not depend on the shard's alphabet when by name
     uint8_t* d_names = nullptr;
     uint32_t* d_names_off = nullptr;
     uint64_t names_cap = 0, names_off_cap = 0;

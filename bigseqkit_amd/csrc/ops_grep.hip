@@ -16,6 +16,8 @@
 
 #include "ops_grep.hpp"
 #include "ops_seq.hpp"
+#include "ops_translate.hpp"  // TextTableH
+#include "pattern_match.cuh"
 
 namespace bsk {
 
@@ -25,13 +27,6 @@ constexpr int GROUP = 16;
 
 __device__ __forceinline__ uint8_t lower8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
 
-// Sequence text of a record as a random-access array of bases.
-struct Text {
-    const uint8_t* p;
-    uint32_t L;      // bases
-    uint32_t W;      // FASTA: line width of a uniformly wrapped region, 0 = contiguous
-    __device__ __forceinline__ uint8_t at(uint32_t i) const { return W ? p[i + i / W] : p[i]; }
-};
 
 // formatted length of the whole record, fastx.Record.Format(width)
 __device__ __forceinline__ uint32_t format_len(uint32_t name_len, uint32_t L, int fastq, int width) {
@@ -289,6 +284,66 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
     }
 }
 
+// ---------------------------------------------------------------------------
+// class patterns (-d / -m): 16 lanes per record, one start position per lane and step; the text is
+// seen through the Text view (uniform-width FASTA in place, irregular FASTA linearised)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grep_seq_gen(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                      GrepParams P, uint32_t* __restrict__ out_len) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;
+    const bool live = g < t.n;
+    const uint64_t gi = live ? g : 0;
+    const Text T = text_of(buf, t, tt, gi);
+    const uint32_t L = live ? T.L : 0;
+    bool hit = false;
+    const int nstr = P.both_strands ? 2 : 1;
+    for (int strand = 0; strand < nstr && !hit; ++strand) {
+        uint32_t wb = 0, we = L;
+        if (P.region_on) {
+            uint32_t b, e;
+            sub_location(L, P.region_start, P.region_end, &b, &e);
+            if (strand == 0) { wb = b; we = e; }
+            else { wb = L - e; we = L - b; }
+        }
+        const uint32_t wl = we - wb;
+        const uint64_t tl = P.circular ? 2ull * wl : wl;
+        Text V = T;  // the window as its own text (contiguous or linearised) or via an offset (wrapped FASTA)
+        for (int k = 0; k < P.npat && !hit; ++k) {
+            const int pk = strand * P.npat + k;
+            const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
+            const uint32_t* cls = P.cls + (uint64_t)P.pat_off[pk] * 8u;
+            if (m == 0) { hit = true; break; }
+            if (m > tl) continue;
+            const uint64_t npos = tl - m + 1;
+            for (uint64_t i0 = 0; i0 < npos; i0 += GROUP) {
+                const uint64_t i = i0 + gl;
+                bool ok = false;
+                if (i < npos) {
+                    int mm = 0;
+                    ok = true;
+                    for (uint32_t q = 0; q < m; ++q) {
+                        uint64_t j = i + q;
+                        if (j >= wl) j -= wl;
+                        if (j >= wl) j -= wl;  // i < 2 wl and q < m <= 2 wl
+                        const uint8_t c = V.at(wb + (uint32_t)j);
+                        if (!((cls[q * 8u + (c >> 5)] >> (c & 31u)) & 1u))
+                            if (++mm > P.max_mm) { ok = false; break; }
+                    }
+                }
+                const uint64_t any = __ballot(ok);
+                if ((any >> gshift) & 0xFFFFull) { hit = true; break; }
+            }
+        }
+    }
+    if (live && gl == 0) {
+        const uint32_t lh = t.l_head[gi];
+        const bool sel = P.invert ? !hit : hit;
+        out_len[g] = sel ? format_len(lh > 0 ? lh - 1 : 0, L, P.fastq, P.line_width) : 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ buf, RecordTable t, GrepParams P,
                                                    uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,7 +355,25 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
     uint32_t tl = hl;
     if (!P.by_name) tl = id_span2(h, hl, P.id_mode, &off);
     bool hit = false;
-    for (int k = 0; k < P.npat && !hit; ++k) {
+    if (P.set_keys) {  // pattern set: probe by hash, verify by bytes (patterns[k] is a map key in the reference, grep.go:501-511)
+        const uint64_t key = fnv1a64(h + off, tl, P.ignore_case);
+        for (uint64_t slot = key & P.set_mask;; slot = (slot + 1) & P.set_mask) {
+            const uint64_t sk = P.set_keys[slot];
+            if (sk == 0) break;
+            if (sk != key) continue;
+            const uint32_t k = P.set_idx[slot];
+            const uint8_t* pp = P.pat + P.pat_off[k];
+            if (P.pat_off[k + 1] - P.pat_off[k] != tl) continue;
+            bool ok = true;
+            for (uint32_t q = 0; q < tl; ++q) {
+                uint8_t c = h[off + q];
+                if (P.ignore_case) c = lower8(c);
+                if (c != pp[q]) { ok = false; break; }
+            }
+            if (ok) { hit = true; break; }
+        }
+    }
+    for (int k = 0; !P.set_keys && k < P.npat && !hit; ++k) {
         const uint8_t* pp = P.pat + P.pat_off[k];
         const uint32_t m = P.pat_off[k + 1] - P.pat_off[k];
         if (m != tl) continue;
@@ -318,10 +391,14 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
 
 }  // namespace
 
-hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const GrepParams& P,
-                             uint32_t* out_len, hipStream_t st) {
+hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH* tt,
+                             const GrepParams& P, uint32_t* out_len, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    if (P.by_seq) {
+    if (P.by_seq && P.general) {
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
+        const uint64_t blocks = (t.n * GROUP + 255) / 256;
+        hipLaunchKernelGGL(k_grep_seq_gen, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len);
+    } else if (P.by_seq) {
         const uint64_t blocks = (t.n * GROUP + 255) / 256;
         hipLaunchKernelGGL(k_grep_seq, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, P, out_len);
     } else {

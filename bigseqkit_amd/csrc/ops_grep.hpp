@@ -18,9 +18,18 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     int npat;                // patterns; with both_strands the reverse-complemented copies follow
     const uint8_t* pat;      // concatenated pattern bytes (already lower-cased when ignore_case)
     const uint32_t* pat_off; // [npat_total + 1]
+    // class patterns (-d, -m): 8 dwords per pattern position, same offsets as `pat` (pattern_match.cuh)
+    int general;
+    int max_mm;
+    const uint32_t* cls;
+    // ID / name pattern set (many patterns, e.g. -f ids.txt): open addressing on fnv1a64, verified by bytes
+    const uint64_t* set_keys;  // null: linear scan over the patterns
+    const uint32_t* set_idx;
+    uint64_t set_mask;
 };
 
-hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const GrepParams& P,
-                             uint32_t* out_len, hipStream_t st);
+struct TextTableH;
+hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH* tt,
+                             const GrepParams& P, uint32_t* out_len, hipStream_t st);
 
 }  // namespace bsk

@@ -7,6 +7,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
 
 #include "../../include/bsk.h"
 #include "ctx.hpp"
@@ -350,6 +353,131 @@ static void check_id_regexp(const Options& o) {
 }
 
 // ---------------------------------------------------------------------------
+// pattern helpers shared by grep and locate
+// ---------------------------------------------------------------------------
+using ByteSet = std::array<uint32_t, 8>;
+static inline void set_add(ByteSet& s, uint8_t b) { s[b >> 5] |= 1u << (b & 31); }
+static inline bool set_has(const ByteSet& s, uint8_t b) { return (s[b >> 5] >> (b & 31)) & 1u; }
+
+// Seq.Degenerate2Regexp [shenwei356/bio v0.7.0, not in tree; PARITY.md DEG]: the letters a degenerate
+// base / residue stands for; nullptr = the byte stays a literal of the regular expression
+static std::string degenerate_letters(char c, bool protein) {
+    const bool low = c >= 'a' && c <= 'z';
+    const char u = low ? (char)(c - 32) : c;
+    std::string r;
+    if (!protein) {
+        switch (u) {
+            case 'A': case 'C': case 'G': case 'T': case 'U': r = std::string(1, u); break;
+            case 'R': r = "AG"; break; case 'Y': r = "CT"; break; case 'M': r = "AC"; break; case 'K': r = "GT"; break;
+            case 'S': r = "CG"; break; case 'W': r = "AT"; break; case 'H': r = "ACT"; break; case 'B': r = "CGT"; break;
+            case 'V': r = "ACG"; break; case 'D': r = "AGT"; break; case 'N': r = "ACGT"; break;
+            default: return "";
+        }
+    } else {
+        if (u < 'A' || u > 'Z') return "";
+        switch (u) {
+            case 'B': r = "DN"; break; case 'Z': r = "EQ"; break; case 'J': r = "IL"; break;
+            case 'X': r = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"; break;
+            default: r = std::string(1, u);
+        }
+    }
+    if (low) for (auto& ch : r) ch = (char)(ch + 32);
+    return r;
+}
+
+static std::vector<ByteSet> class_sets(const std::string& p, bool degenerate, bool protein, bool icase) {
+    std::vector<ByteSet> out;
+    for (char ch : p) {
+        ByteSet s{};
+        std::string letters = degenerate ? degenerate_letters(ch, protein) : std::string();
+        if (letters.empty()) {
+            if (degenerate && !((ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z')))
+                throw OptError("libbsk: with -d the HIP path takes patterns made of letters only (regular-expression "
+                               "syntax is not supported): " + p);
+            letters = std::string(1, ch);
+        }
+        for (char l : letters) {
+            set_add(s, (uint8_t)l);
+            if (icase && l >= 'A' && l <= 'Z') set_add(s, (uint8_t)(l + 32));
+            if (icase && l >= 'a' && l <= 'z') set_add(s, (uint8_t)(l - 32));
+        }
+        out.push_back(s);
+    }
+    return out;
+}
+
+static void complement_table(Alphabet ab, uint8_t m[256]) {
+    for (int i = 0; i < 256; ++i) m[i] = (uint8_t)i;
+    const char *from = nullptr, *to = nullptr;
+    if (ab == AB_DNA || ab == AB_DNAredundant) { from = "acgtryswkmbdhvACGTRYSWKMBDHV"; to = "tgcayrswmkvhdbTGCAYRSWMKVHDB"; }
+    else if (ab == AB_RNA || ab == AB_RNAredundant) { from = "acguryswkmbdhvACGURYSWKMBDHV"; to = "ugcayrswmkvhdbUGCAYRSWMKVHDB"; }
+    if (from) for (size_t k = 0; from[k]; ++k) m[(uint8_t)from[k]] = (uint8_t)to[k];
+}
+
+// class pattern that matches on the forward text exactly where the original matches on RevCom(text)
+static std::vector<ByteSet> revcom_sets(const std::vector<ByteSet>& s, Alphabet ab) {
+    uint8_t comp[256];
+    complement_table(ab, comp);
+    std::vector<ByteSet> out(s.size());
+    for (size_t q = 0; q < s.size(); ++q)
+        for (int b = 0; b < 256; ++b)
+            if (set_has(s[s.size() - 1 - q], comp[b])) set_add(out[q], (uint8_t)b);
+    return out;
+}
+
+static std::string read_whole_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw OptError("open " + path + ": no such file or directory");
+    std::string s;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+
+// breader.NewDefaultBufferedReader: one pattern per line, line ends trimmed (grep.go:126-140)
+static std::vector<std::string> read_pattern_lines(const std::string& path) {
+    std::vector<std::string> out;
+    const std::string s = read_whole_file(path);
+    for (size_t i = 0; i < s.size();) {
+        size_t j = s.find('\n', i);
+        if (j == std::string::npos) j = s.size();
+        size_t e = j;
+        while (e > i && (s[e - 1] == '\r' || s[e - 1] == '\n')) --e;
+        out.emplace_back(s, i, e - i);
+        i = j + 1;
+    }
+    return out;
+}
+
+// fastx.GetSeqsMap(file, seq.Unlimit, ...) (locate.go:86): full name -> sequence, file order (PARITY.md Q11);
+// a repeated name keeps the later sequence, like the Go map assignment
+static std::vector<std::pair<std::string, std::string>> read_pattern_fasta(const std::string& path) {
+    std::vector<std::pair<std::string, std::string>> out;
+    const std::string s = read_whole_file(path);
+    bool have = false;
+    for (size_t i = 0; i < s.size();) {
+        size_t j = s.find('\n', i);
+        if (j == std::string::npos) j = s.size();
+        size_t e = j;
+        while (e > i && s[e - 1] == '\r') --e;
+        if (e > i && s[i] == '>') {
+            const std::string name(s, i + 1, e - i - 1);
+            have = true;
+            size_t k = 0;
+            for (; k < out.size(); ++k) if (out[k].first == name) break;
+            if (k < out.size()) out.erase(out.begin() + (long)k);
+            out.emplace_back(name, "");
+        } else if (have) {
+            out.back().second.append(s, i, e - i);
+        }
+        i = j + 1;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
 // grep  (Grep.Before, bigseqkit-lib/grep.go:41-253)
 // ---------------------------------------------------------------------------
 void validate_grep_opts(bsk_ctx* c) {
@@ -374,14 +502,27 @@ void validate_grep_opts(bsk_ctx* c) {
         o.mut("BySeq").b = true;
         parse_region_opt(o.s("Region"), "grep", &c->region_start, &c->region_end);
     }
-    if (o.b("UseRegexp") || o.b("Degenerate") || o.i("MaxMismatch") > 0 || o.b("DeleteMatched") ||
-        !o.s("PatternFile").empty())
-        throw OptError("libbsk: regexp (-r), degenerate (-d), mismatch (-m), --delete-matched and pattern files (-f) "
-                       "are not supported by the HIP path yet");
+    if (o.b("UseRegexp") || o.b("DeleteMatched"))
+        throw OptError("libbsk: regexp (-r) and --delete-matched are not supported by the HIP path yet");
     c->patterns.clear();
-    for (std::string p : o.sl("Pattern")) {
+    c->pattern_cls.clear();
+    c->max_mm = (int)o.i("MaxMismatch");
+    c->general = o.b("Degenerate") || c->max_mm > 0;
+    c->patterns_uploaded = false;
+    // grep.go:122-252: the pattern file replaces -p when given
+    const std::vector<std::string> given = !o.s("PatternFile").empty() ? read_pattern_lines(o.s("PatternFile")) : o.sl("Pattern");
+    std::unordered_set<std::string> seen;
+    for (std::string p : given) {
         if (p.empty()) continue;
+        if (o.b("Degenerate")) {
+            // Degenerate2Regexp with the alphabet of -t (nil for auto => nucleotide map), "(?i)" with -i
+            if (!seen.insert(p).second) continue;
+            c->pattern_cls.push_back(class_sets(p, true, c->alphabet == AB_PROTEIN, o.b("IgnoreCase")));
+            c->patterns.push_back(p);
+            continue;
+        }
         if (o.b("BySeq")) {
+            if (c->max_mm > 0 && c->max_mm > (int)p.size()) throw OptError("mismatch should be <= length of sequence: " + p);
             const uint8_t* b = (const uint8_t*)p.data();
             if (!(alphabet_valid_letters(AB_DNAredundant, b, p.size()) || alphabet_valid_letters(AB_RNAredundant, b, p.size()) ||
                   alphabet_valid_letters(AB_PROTEIN, b, p.size())))
@@ -389,20 +530,60 @@ void validate_grep_opts(bsk_ctx* c) {
         }
         if (o.b("IgnoreCase"))
             for (auto& ch : p) if (ch >= 'A' && ch <= 'Z') ch += 32;
-        if (std::find(c->patterns.begin(), c->patterns.end(), p) == c->patterns.end()) c->patterns.push_back(p);
+        if (!seen.insert(p).second) continue;
+        if (c->general) c->pattern_cls.push_back(class_sets(p, false, false, o.b("IgnoreCase")));
+        c->patterns.push_back(p);
     }
 }
 
 static std::string revcom_pattern(const std::string& p, Alphabet ab) {
     uint8_t m[256];
-    for (int i = 0; i < 256; ++i) m[i] = (uint8_t)i;
-    const char *from = nullptr, *to = nullptr;
-    if (ab == AB_DNA || ab == AB_DNAredundant) { from = "acgtryswkmbdhvACGTRYSWKMBDHV"; to = "tgcayrswmkvhdbTGCAYRSWMKVHDB"; }
-    else if (ab == AB_RNA || ab == AB_RNAredundant) { from = "acguryswkmbdhvACGURYSWKMBDHV"; to = "ugcayrswmkvhdbUGCAYRSWMKVHDB"; }
-    if (from) for (size_t k = 0; from[k]; ++k) m[(uint8_t)from[k]] = (uint8_t)to[k];
+    complement_table(ab, m);
     std::string r(p.rbegin(), p.rend());
     for (auto& ch : r) ch = (char)m[(uint8_t)ch];
     return r;
+}
+
+// class sets of all patterns (forward, then reverse-complemented when `rc`), 8 dwords per position
+static int upload_classes(bsk_ctx* c, bool rc, Alphabet ab, hipStream_t st) {
+    std::vector<uint32_t> flat;
+    for (int pass = 0; pass < (rc ? 2 : 1); ++pass)
+        for (auto& sets : c->pattern_cls) {
+            const std::vector<ByteSet> use = pass ? revcom_sets(sets, ab) : sets;
+            for (auto& s : use) flat.insert(flat.end(), s.begin(), s.end());
+        }
+    int r = grow(c, &c->d_cls, &c->cls_cap, flat.size() + 8);
+    if (r != BSK_OK) return r;
+    if (!flat.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_cls, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    return BSK_OK;
+}
+
+// open-addressing set of the ID / name patterns keyed by fnv1a64 (pattern_match.cuh)
+static int upload_pattern_set(bsk_ctx* c, hipStream_t st) {
+    uint64_t slots = 16;
+    while (slots < 2 * c->patterns.size()) slots <<= 1;
+    std::vector<uint64_t> keys(slots, 0);
+    std::vector<uint32_t> idx(slots, 0);
+    for (size_t k = 0; k < c->patterns.size(); ++k) {
+        const std::string& p = c->patterns[k];
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char ch : p) h = (h ^ ch) * 1099511628211ull;  // patterns are already lower-cased with -i
+        if (!h) h = 1;
+        uint64_t s = h & (slots - 1);
+        while (keys[s]) s = (s + 1) & (slots - 1);
+        keys[s] = h;
+        idx[s] = (uint32_t)k;
+    }
+    int r = grow(c, &c->d_set_keys, &c->set_keys_cap, slots);
+    if (r != BSK_OK) return r;
+    r = grow(c, &c->d_set_idx, &c->set_idx_cap, slots);
+    if (r != BSK_OK) return r;
+    HIP_TRYX(c, hipMemcpyAsync(c->d_set_keys, keys.data(), slots * 8, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipMemcpyAsync(c->d_set_idx, idx.data(), slots * 4, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    c->set_slots = slots;
+    return BSK_OK;
 }
 
 static int upload_patterns(bsk_ctx* c, const std::vector<std::string>& all, hipStream_t st) {
@@ -450,16 +631,40 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
         G.line_width = fastq ? 0 : (int)o.ci("LineWidth");
         G.npat = (int)c->patterns.size();
-        std::vector<std::string> all = c->patterns;
-        if (G.both_strands)
-            for (auto& p : c->patterns) all.push_back(revcom_pattern(p, ab));
-        rc = upload_patterns(c, all, st);
-        if (rc != BSK_OK) return rc;
+        TextTableH tt{nullptr, nullptr, nullptr};
+        if (!G.by_seq) {
+            // ID / name: the patterns do not depend on the shard, upload once per context
+            if (!c->patterns_uploaded) {
+                rc = upload_patterns(c, c->patterns, st);
+                if (rc != BSK_OK) return rc;
+                if (c->patterns.size() > 8) {
+                    rc = upload_pattern_set(c, st);
+                    if (rc != BSK_OK) return rc;
+                } else c->set_slots = 0;
+                c->patterns_uploaded = true;
+            }
+            if (c->set_slots) { G.set_keys = c->d_set_keys; G.set_idx = c->d_set_idx; G.set_mask = c->set_slots - 1; }
+        } else {
+            std::vector<std::string> all = c->patterns;
+            if (G.both_strands)
+                for (auto& p : c->patterns) all.push_back(revcom_pattern(p, ab));
+            rc = upload_patterns(c, all, st);
+            if (rc != BSK_OK) return rc;
+            if (c->general) {
+                rc = upload_classes(c, G.both_strands, ab, st);
+                if (rc != BSK_OK) return rc;
+                rc = prepare_text(c, d_buf, format, st, &tt);
+                if (rc != BSK_OK) return rc;
+                G.general = 1;
+                G.max_mm = c->max_mm;
+                G.cls = c->d_cls;
+            }
+        }
         G.pat = c->d_pat;
         G.pat_off = c->d_pat_off;
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
-        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, G, c->d_out_len, st));
+        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st));
         rc = finish_sizes(c, st, &total, &kept);
         if (rc != BSK_OK) return rc;
     } else {
@@ -509,23 +714,40 @@ void validate_locate_opts(bsk_ctx* c) {
         if (o.b("Degenerate")) throw OptError("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
         if (o.b("UseRegexp")) throw OptError("flag -r (--use-regexp) ignored when giving flag -F (--use-fmi)");
     }
-    if (o.b("Degenerate") || o.b("UseRegexp") || o.b("UseFmi") || o.i("MaxMismatch") > 0 || !o.s("PatternFile").empty())
-        throw OptError("libbsk: degenerate (-d), regexp (-r), FM-index (-F), mismatch (-m) and pattern files (-f) are not "
-                       "supported by the HIP path yet");
+    if (o.b("UseRegexp")) throw OptError("libbsk: regexp (-r) is not supported by the HIP path yet");
     c->patterns.clear();
     c->pattern_names.clear();
-    for (const std::string& p : o.sl("Pattern")) {
-        if (p.empty()) continue;
-        std::string eff = p;
-        if (o.b("IgnoreCase"))
+    c->pattern_cls.clear();
+    c->max_mm = (int)o.i("MaxMismatch");
+    c->fmi_order = c->max_mm > 0 || o.b("UseFmi");
+    c->general = o.b("Degenerate") || c->fmi_order;
+    std::vector<std::pair<std::string, std::string>> given;  // (name, sequence)
+    const bool from_file = !o.s("PatternFile").empty();
+    if (from_file) {
+        given = read_pattern_fasta(o.s("PatternFile"));
+        if (given.empty()) throw OptError("no FASTA sequences found in pattern file: " + o.s("PatternFile"));
+    } else {
+        for (const std::string& p : o.sl("Pattern")) if (!p.empty()) given.emplace_back(p, p);
+    }
+    for (auto& g : given) {  // locate.go:86-190
+        std::string eff = g.second;
+        if (!o.b("Degenerate") && o.b("IgnoreCase"))
             for (auto& ch : eff) if (ch >= 'A' && ch <= 'Z') ch += 32;
         const uint8_t* b = (const uint8_t*)eff.data();
-        if (eff.find('.') != std::string::npos ||
-            !(alphabet_valid_letters(AB_DNAredundant, b, eff.size()) || alphabet_valid_letters(AB_RNAredundant, b, eff.size()) ||
-              alphabet_valid_letters(AB_PROTEIN, b, eff.size())))
-            throw OptError("illegal DNA/RNA/Protein sequence: " + p + ", you may switch on -d/--degenerate or -r/--use-regexp");
-        if (std::find(c->pattern_names.begin(), c->pattern_names.end(), p) != c->pattern_names.end()) continue;
-        c->pattern_names.push_back(p);
+        const bool legal = alphabet_valid_letters(AB_DNAredundant, b, eff.size()) || alphabet_valid_letters(AB_RNAredundant, b, eff.size()) ||
+                           alphabet_valid_letters(AB_PROTEIN, b, eff.size());
+        if (c->max_mm > 0) {
+            if (c->max_mm > (int)eff.size()) throw OptError("mismatch should be <= length of sequence: " + g.second);
+            if (!legal) throw OptError("illegal DNA/RNA/Protein sequence: " + g.first);
+        } else if (!o.b("Degenerate") && (eff.find('.') != std::string::npos || !legal)) {
+            throw OptError("illegal DNA/RNA/Protein sequence: " + g.first + ", you may switch on -d/--degenerate or -r/--use-regexp");
+        }
+        if (std::find(c->pattern_names.begin(), c->pattern_names.end(), g.first) != c->pattern_names.end()) continue;
+        if (c->general)
+            // -d: Degenerate2Regexp with the alphabet of -t (records of a pattern file are seq.Unlimit => nucleotide map)
+            c->pattern_cls.push_back(class_sets(eff, o.b("Degenerate"), !from_file && c->alphabet == AB_PROTEIN,
+                                                o.b("IgnoreCase")));
+        c->pattern_names.push_back(g.first);
         c->patterns.push_back(eff);
     }
 }
@@ -555,6 +777,10 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         P.circular = o.b("Circular");
         P.non_greedy = o.b("NonGreedy");
         P.both_strands = !o.b("OnlyPositiveStrand");  // sic: locate.go:669 tests the option, not the alphabet
+        if (c->fmi_order) {  // the FM-index branch does consult the alphabet (locate.go:222-227, 308-310)
+            P.both_strands = !(o.b("OnlyPositiveStrand") || ab == AB_UNLIMIT || ab == AB_PROTEIN);
+            P.non_greedy = 0;  // "flag -G (--non-greedy) ignored when giving flag -m" (locate.go:67-69)
+        }
         P.format = o.b("Gtf") ? 2 : (o.b("Bed") ? 3 : (o.b("HideMatched") ? 1 : 0));
         P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
         P.npat = (int)c->patterns.size();
@@ -564,6 +790,21 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         if (rc != BSK_OK) return rc;
         P.pat = c->d_pat;
         P.pat_off = c->d_pat_off;
+        if (c->general) {
+            rc = upload_classes(c, true, ab, st);
+            if (rc != BSK_OK) return rc;
+            uint8_t comp[256];
+            complement_table(ab, comp);
+            if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
+            HIP_TRYX(c, hipMemcpyAsync(c->d_lut, comp, 256, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));  // comp lives on the host stack
+            P.general = 1;
+            P.max_mm = c->max_mm;
+            P.cls = c->d_cls;
+            P.fmi_order = c->fmi_order;
+            P.matched_lower = !o.b("Degenerate") && o.b("IgnoreCase");  // locate.go:430-432 lower-cases the text
+            P.comp = c->d_lut;
+        }
         {
             std::vector<uint8_t> bytes;
             std::vector<uint32_t> off{0};

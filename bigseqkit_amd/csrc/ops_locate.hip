@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "ops_locate.hpp"
+#include "pattern_match.cuh"
 #include "text.cuh"
 
 namespace bsk {
@@ -35,6 +36,12 @@ __device__ __forceinline__ uint32_t put_dec(uint8_t* o, uint64_t v) {
     while (k) o[n++] = (uint8_t)tmp[--k];
     return n;
 }
+// coordinates of the FM-index branch can be <= 0 on a circular '-' hit (locate.go:330-331 has no +l shift): %d
+__device__ __forceinline__ uint32_t dec_len_s(int64_t v) { return v < 0 ? 1u + dec_len((uint64_t)(-v)) : dec_len((uint64_t)v); }
+__device__ __forceinline__ uint32_t put_dec_s(uint8_t* o, int64_t v) {
+    if (v < 0) { o[0] = '-'; return 1u + put_dec(o + 1, (uint64_t)(-v)); }
+    return put_dec(o, (uint64_t)v);
+}
 __device__ __forceinline__ uint32_t put_bytes(uint8_t* o, const uint8_t* s, uint32_t n) {
     for (uint32_t k = 0; k < n; ++k) o[k] = s[k];
     return n;
@@ -50,29 +57,47 @@ struct RowCtx {
     const uint8_t* name; uint32_t name_len;
     const uint8_t* pat; uint32_t pat_len;
     int format;
+    // matched column taken from the text (class patterns): m letters from forward position f, reverse-complemented on '-'
+    bool from_text, rc, lower;
+    Text T; uint32_t l; uint64_t f;
+    const uint8_t* comp;
 };
 
-__device__ __forceinline__ uint32_t row_len(const RowCtx& r, uint64_t begin, uint64_t end) {
+__device__ uint32_t put_matched(uint8_t* o, const RowCtx& r) {
+    if (!r.from_text) return put_bytes(o, r.pat, r.pat_len);
+    const uint32_t m = r.pat_len;
+    for (uint32_t q = 0; q < m; ++q) {
+        uint64_t j = r.f + (r.rc ? m - 1 - q : q);
+        if (j >= r.l) j -= r.l;
+        uint8_t c = r.T.at((uint32_t)j);
+        if (r.rc) c = r.comp[c];
+        if (r.lower) c = lower8(c);
+        o[q] = c;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t row_len(const RowCtx& r, int64_t begin, int64_t end) {
     switch (r.format) {
         case 2:  // "%s\tSeqKit\tlocation\t%d\t%d\t0\t%c\t.\tgene_id \"%s\"; \n"
-            return r.id_len + 17 + dec_len(begin) + 1 + dec_len(end) + 3 + 2 + 2 + 9 + r.name_len + 3 + 1;
+            return r.id_len + 17 + dec_len_s(begin) + 1 + dec_len_s(end) + 3 + 2 + 2 + 9 + r.name_len + 3 + 1;
         case 3:  // "%s\t%d\t%d\t%s\t0\t%c\n"
-            return r.id_len + 1 + dec_len(begin - 1) + 1 + dec_len(end) + 1 + r.name_len + 3 + 1 + 1;
+            return r.id_len + 1 + dec_len_s(begin - 1) + 1 + dec_len_s(end) + 1 + r.name_len + 3 + 1 + 1;
         default: {
-            uint32_t n = r.id_len + 1 + r.name_len + 1 + r.pat_len + 1 + 1 + 1 + dec_len(begin) + 1 + dec_len(end);
+            uint32_t n = r.id_len + 1 + r.name_len + 1 + r.pat_len + 1 + 1 + 1 + dec_len_s(begin) + 1 + dec_len_s(end);
             if (r.format == 0) n += 1 + r.pat_len;
             return n + 1;
         }
     }
 }
 
-__device__ uint32_t row_put(uint8_t* o, const RowCtx& r, char strand, uint64_t begin, uint64_t end) {
+__device__ uint32_t row_put(uint8_t* o, const RowCtx& r, char strand, int64_t begin, int64_t end) {
     uint32_t n = 0;
     n += put_bytes(o + n, r.id, r.id_len);
     if (r.format == 2) {
         n += put_str(o + n, "\tSeqKit\tlocation\t");
-        n += put_dec(o + n, begin); o[n++] = '\t';
-        n += put_dec(o + n, end);
+        n += put_dec_s(o + n, begin); o[n++] = '\t';
+        n += put_dec_s(o + n, end);
         n += put_str(o + n, "\t0\t");
         o[n++] = (uint8_t)strand;
         n += put_str(o + n, "\t.\tgene_id \"");
@@ -80,8 +105,8 @@ __device__ uint32_t row_put(uint8_t* o, const RowCtx& r, char strand, uint64_t b
         n += put_str(o + n, "\"; \n");
     } else if (r.format == 3) {
         o[n++] = '\t';
-        n += put_dec(o + n, begin - 1); o[n++] = '\t';
-        n += put_dec(o + n, end); o[n++] = '\t';
+        n += put_dec_s(o + n, begin - 1); o[n++] = '\t';
+        n += put_dec_s(o + n, end); o[n++] = '\t';
         n += put_bytes(o + n, r.name, r.name_len);
         n += put_str(o + n, "\t0\t");
         o[n++] = (uint8_t)strand;
@@ -91,9 +116,9 @@ __device__ uint32_t row_put(uint8_t* o, const RowCtx& r, char strand, uint64_t b
         n += put_bytes(o + n, r.name, r.name_len); o[n++] = '\t';
         n += put_bytes(o + n, r.pat, r.pat_len); o[n++] = '\t';
         o[n++] = (uint8_t)strand; o[n++] = '\t';
-        n += put_dec(o + n, begin); o[n++] = '\t';
-        n += put_dec(o + n, end);
-        if (r.format == 0) { o[n++] = '\t'; n += put_bytes(o + n, r.pat, r.pat_len); }
+        n += put_dec_s(o + n, begin); o[n++] = '\t';
+        n += put_dec_s(o + n, end);
+        if (r.format == 0) { o[n++] = '\t'; n += put_matched(o + n, r); }
         o[n++] = '\n';
     }
     return n;
@@ -168,7 +193,7 @@ __device__ __forceinline__ uint32_t window_hits(const uint8_t* src, const uint8_
     return hits;
 }
 
-template <bool EMIT>
+template <bool EMIT, bool GEN>
 __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                 LocateParams P, uint32_t* __restrict__ out_len,
                                                 const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
@@ -186,6 +211,13 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     R.id = nullptr;
     R.id_len = 0;
     R.format = P.format;
+    R.from_text = GEN;
+    R.lower = P.matched_lower != 0;
+    R.T = T;
+    R.l = l;
+    R.comp = P.comp;
+    R.rc = false;
+    R.f = 0;
     bool have_id = false;  // the ID is only parsed once a record has a hit (group-uniform)
     auto need_id = [&]() {
         if (have_id) return;
@@ -200,21 +232,39 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     uint32_t nrows = 0;
     uint8_t* o = EMIT ? out + out_off[gi] : nullptr;
     const int nstr = P.both_strands ? 2 : 1;
-    for (int k = 0; k < P.npat; ++k) {
+    const int niter = P.npat * nstr;
+    for (int it = 0; it < niter; ++it) {
+        // reference loop order: per pattern both strands (locate.go:575-767); FM-index branch: per strand all patterns
+        const int k = P.fmi_order ? it % P.npat : it / nstr;
+        const int strand = P.fmi_order ? it / P.npat : it % nstr;
         R.name = P.name + P.name_off[k];
         R.name_len = P.name_off[k + 1] - P.name_off[k];
         R.pat = P.pat + P.pat_off[k];
         R.pat_len = P.pat_off[k + 1] - P.pat_off[k];
+        R.rc = strand != 0;
         const uint32_t m = R.pat_len;
-        for (int strand = 0; strand < nstr; ++strand) {
+        {
             const uint8_t* pp = P.pat + P.pat_off[strand * P.npat + k];
+            const uint32_t* cls = GEN ? P.cls + (uint64_t)P.pat_off[strand * P.npat + k] * 8u : nullptr;
+            auto matches = [&](uint64_t f) -> bool {
+                if (GEN) return class_match_at(T, l, cls, m, f, P.max_mm);
+                return match_at(T, l, P.ignore_case, pp, m, f);
+            };
+            // '-' coordinates in the original frame (locate.go:698-703); the FM-index branch has no +l shift (:330-331)
+            auto coords = [&](uint64_t a, int64_t* begin, int64_t* end) {
+                if (strand == 0) { *begin = (int64_t)a + 1; *end = (int64_t)(a + m); }
+                else {
+                    *begin = (int64_t)l - (int64_t)a - (int64_t)m + 1; *end = (int64_t)l - (int64_t)a;
+                    if (!P.fmi_order && a + m > l) { *begin += l; *end += l; }
+                }
+            };
             if (!live || m == 0 || m > n) continue;
             // candidate start positions a (in the strand's own frame): a + m <= n, and a < l when circular
             uint64_t npos = n - m + 1;
             if (P.circular && npos > l) npos = l;
             const char sc = strand ? '-' : '+';
             // contiguous text inside the shard, plain greedy search: 16 positions per lane and step
-            const bool fastp = !P.non_greedy && !P.circular && T.W == 0 && T.p >= buf && T.p < buf + buf_n;
+            const bool fastp = !GEN && !P.non_greedy && !P.circular && T.W == 0 && T.p >= buf && T.p < buf + buf_n;
             if (fastp) {
                 const uint8_t* const buf_end = buf + buf_n;
                 for (uint64_t a0 = 0; a0 < npos; a0 += GROUP * 16) {
@@ -240,9 +290,8 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                     uint32_t mine = 0, cnt = 0;
                     for (uint32_t hm = hits; hm; hm &= hm - 1u) {
                         const uint64_t a = ib + ((uint32_t)__ffs((int)hm) - 1u);
-                        uint64_t begin, end;
-                        if (strand == 0) { begin = a + 1; end = a + m; }
-                        else { begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a; }
+                        int64_t begin, end;
+                        coords(a, &begin, &end);
                         mine += row_len(R, begin, end);
                         ++cnt;
                     }
@@ -259,9 +308,8 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                         uint64_t at = bytes + (incl - mine);
                         for (uint32_t hm = hits; hm; hm &= hm - 1u) {
                             const uint64_t a = ib + ((uint32_t)__ffs((int)hm) - 1u);
-                            uint64_t begin, end;
-                            if (strand == 0) { begin = a + 1; end = a + m; }
-                            else { begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a; }
+                            int64_t begin, end;
+                            coords(a, &begin, &end);
                             at += row_put(o + at, R, sc, begin, end);
                         }
                     }
@@ -272,15 +320,12 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                 for (uint64_t a0 = 0; a0 < npos; a0 += GROUP) {
                     const uint64_t a = a0 + gl;
                     bool hit = false;
-                    uint64_t begin = 0, end = 0;
+                    int64_t begin = 0, end = 0;
                     if (a < npos) {
                         const uint64_t f = strand ? n - a - m : a;  // forward position of the occurrence
-                        hit = match_at(T, l, P.ignore_case, pp, m, f);
-                        if (strand == 0) { begin = a + 1; end = a + m; }
-                        else {
-                            begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a;  // locate.go:698-703
-                            if (a + m > l) { begin += l; end += l; }
-                        }
+                        hit = matches(f);
+                        coords(a, &begin, &end);
+                        R.f = f;
                     }
                     const uint32_t mask = (uint32_t)((__ballot(hit) >> gshift) & 0xFFFFull);
                     if (mask == 0) continue;
@@ -304,13 +349,10 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                 uint64_t a = 0;
                 while (a < npos) {
                     const uint64_t f = strand ? n - a - m : a;
-                    if (match_at(T, l, P.ignore_case, pp, m, f)) {
-                        uint64_t begin, end;
-                        if (strand == 0) { begin = a + 1; end = a + m; }
-                        else {
-                            begin = (uint64_t)l - a - m + 1; end = (uint64_t)l - a;
-                            if (a + m > l) { begin += l; end += l; }
-                        }
+                    if (matches(f)) {
+                        int64_t begin, end;
+                        coords(a, &begin, &end);
+                        R.f = f;
                         if (EMIT) row_put(o + bytes, R, sc, begin, end);
                         bytes += row_len(R, begin, end);
                         ++nrows;
@@ -344,8 +386,14 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     const uint64_t blocks = (t.n * GROUP + 255) / 256;
-    if (emit) hipLaunchKernelGGL(k_locate<true>, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
-    else hipLaunchKernelGGL(k_locate<false>, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+    const dim3 gr((unsigned)blocks), bl(256);
+    if (P.general) {
+        if (emit) hipLaunchKernelGGL((k_locate<true, true>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+        else hipLaunchKernelGGL((k_locate<false, true>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+    } else {
+        if (emit) hipLaunchKernelGGL((k_locate<true, false>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+        else hipLaunchKernelGGL((k_locate<false, false>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+    }
     return hipGetLastError();
 }
 

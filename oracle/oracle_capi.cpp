@@ -44,6 +44,7 @@ typedef struct {
     int InvertMatch, ByName, BySeq, OnlyPositiveStrand, IgnoreCase;
     const char* Region;
     int Circular, Count, UseRegexp, Degenerate, MaxMismatch, DeleteMatched;
+    const char* PatternFile;
 } orc_grep_opts;
 
 typedef struct {
@@ -60,6 +61,7 @@ typedef struct {
     int npattern;
     int IgnoreCase, OnlyPositiveStrand, NonGreedy, Gtf, Bed, HideMatched, Circular;
     int Degenerate, UseRegexp, UseFmi, MaxMismatch;
+    const char* PatternFile;
 } orc_locate_opts;
 
 typedef struct {
@@ -125,6 +127,7 @@ static GrepOptions conv(const orc_grep_opts& c) {
     if (c.Region) o.Region = c.Region;
     o.Circular = c.Circular; o.Count = c.Count; o.UseRegexp = c.UseRegexp; o.Degenerate = c.Degenerate;
     o.MaxMismatch = c.MaxMismatch; o.DeleteMatched = c.DeleteMatched;
+    if (c.PatternFile) o.PatternFile = c.PatternFile;
     return o;
 }
 
@@ -158,6 +161,7 @@ static LocateOptions conv(const orc_locate_opts& c) {
     o.IgnoreCase = c.IgnoreCase; o.OnlyPositiveStrand = c.OnlyPositiveStrand; o.NonGreedy = c.NonGreedy;
     o.Gtf = c.Gtf; o.Bed = c.Bed; o.HideMatched = c.HideMatched; o.Circular = c.Circular;
     o.Degenerate = c.Degenerate; o.UseRegexp = c.UseRegexp; o.UseFmi = c.UseFmi; o.MaxMismatch = c.MaxMismatch;
+    if (c.PatternFile) o.PatternFile = c.PatternFile;
     return o;
 }
 

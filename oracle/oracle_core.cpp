@@ -592,7 +592,121 @@ std::string rev_com(const std::string& s, Alphabet a) {
 }
 
 // ---------------------------------------------------------------------------
-// Grep  bigseqkit-lib/grep.go (exact patterns: no -r, -d, -m, --delete-matched)
+// Pattern helpers shared by grep and locate
+//   Seq.Degenerate2Regexp           [shenwei356/bio v0.7.0, not in tree; upstream-memory, PARITY.md DEG]
+//   regexp.Regexp (Go RE2)          only the subset Degenerate2Regexp can emit: literals and [..] classes, (?i)
+//   fmi.FMIndex.Match / Locate      [shenwei356/bwt v0.6.0, not in tree]: Hamming distance <= k, no indels,
+//                                   locations ascending (PARITY.md FMI)
+//   breader / fastx.GetSeqsMap      pattern files
+// ---------------------------------------------------------------------------
+static const char* degenerate_nucl(char c) {
+    switch (c) {
+        case 'A': return "A"; case 'T': return "T"; case 'U': return "U"; case 'C': return "C"; case 'G': return "G";
+        case 'R': return "AG"; case 'Y': return "CT"; case 'M': return "AC"; case 'K': return "GT"; case 'S': return "CG";
+        case 'W': return "AT"; case 'H': return "ACT"; case 'B': return "CGT"; case 'V': return "ACG"; case 'D': return "AGT";
+        case 'N': return "ACGT";
+        case 'a': return "a"; case 't': return "t"; case 'u': return "u"; case 'c': return "c"; case 'g': return "g";
+        case 'r': return "ag"; case 'y': return "ct"; case 'm': return "ac"; case 'k': return "gt"; case 's': return "cg";
+        case 'w': return "at"; case 'h': return "act"; case 'b': return "cgt"; case 'v': return "acg"; case 'd': return "agt";
+        case 'n': return "acgt";
+    }
+    return nullptr;
+}
+static const char* degenerate_prot(char c) {
+    static char one[128][2];
+    switch (c) {
+        case 'B': return "DN"; case 'Z': return "EQ"; case 'J': return "IL"; case 'X': return "ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+        case 'b': return "dn"; case 'z': return "eq"; case 'j': return "il"; case 'x': return "abcdefghijklmnopqrstuvwxyz";
+    }
+    if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')) { one[(int)c][0] = c; one[(int)c][1] = 0; return one[(int)c]; }
+    return nullptr;
+}
+
+std::string degenerate2regexp(const std::string& p, Alphabet a) {
+    std::string s;
+    for (char c : p) {
+        const char* m = a == AB_PROTEIN ? degenerate_prot(c) : degenerate_nucl(c);
+        if (!m) s.push_back(c);
+        else if (m[1] == 0) s += m;
+        else s += std::string("[") + m + "]";
+    }
+    return s;
+}
+
+MiniRe MiniRe::compile(const std::string& re_in) {
+    MiniRe r;
+    std::string re = re_in;
+    if (re.rfind("(?i)", 0) == 0) { r.icase = true; re = re.substr(4); }
+    for (size_t i = 0; i < re.size(); ++i) {
+        std::bitset<256> set;
+        unsigned char c = (unsigned char)re[i];
+        if (c == '[') {
+            size_t j = re.find(']', i + 1);
+            if (j == std::string::npos) throw Error("error parsing regexp: missing closing ]: `" + re.substr(i) + "`");
+            for (size_t k = i + 1; k < j; ++k) set.set((unsigned char)re[k]);
+            i = j;
+        } else if (isalpha(c)) {
+            set.set(c);
+        } else {
+            throw Error("oracle: regexp syntax beyond literals and [..] classes is not restated: " + re_in);
+        }
+        if (r.icase)
+            for (int b = 0; b < 256; ++b)
+                if (set[b] && isalpha(b)) { set.set(tolower(b)); set.set(toupper(b)); }
+        r.atoms.push_back(set);
+    }
+    return r;
+}
+
+long MiniRe::find(const std::string& t, size_t from) const {  // leftmost match at or after `from`, -1 if none
+    const size_t m = atoms.size();
+    for (size_t i = from; i + m <= t.size(); ++i) {
+        size_t q = 0;
+        while (q < m && atoms[q][(unsigned char)t[i + q]]) ++q;
+        if (q == m) return (long)i;
+    }
+    return -1;
+}
+
+std::vector<long> fmi_locate(const std::string& text, const std::string& pat, int k) {
+    std::vector<long> loc;
+    const size_t m = pat.size();
+    for (size_t i = 0; m > 0 && i + m <= text.size(); ++i) {
+        int mm = 0;
+        for (size_t q = 0; q < m && mm <= k; ++q) mm += text[i + q] != pat[q];
+        if (mm <= k) loc.push_back((long)i);
+    }
+    return loc;
+}
+
+static std::string read_text_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw Error("open " + path + ": no such file or directory");
+    std::string s;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+
+std::vector<std::string> read_pattern_lines(const std::string& path) {  // breader: one pattern per line, CR/LF trimmed
+    std::vector<std::string> out;
+    const std::string s = read_text_file(path);
+    size_t i = 0;
+    while (i < s.size()) {
+        size_t j = s.find('\n', i);
+        if (j == std::string::npos) j = s.size();
+        std::string line = s.substr(i, j - i);
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        out.push_back(line);
+        i = j + 1;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// Grep  bigseqkit-lib/grep.go (no -r, no --delete-matched)
 // ---------------------------------------------------------------------------
 std::vector<std::string> grep_call(const std::vector<std::string_view>& part, const GrepOptions& oin) {
     GrepOptions o = oin;
@@ -615,12 +729,24 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
         o.BySeq = true;
         parse_region(o.Region, "grep", &start, &end);
     }
-    if (o.UseRegexp || o.Degenerate || o.MaxMismatch > 0 || o.DeleteMatched || !o.PatternFile.empty())
-        throw Error("oracle: regexp / degenerate / mismatch / delete-matched / pattern-file grep is not restated");
-    std::vector<std::string> patterns;  // PARITY.md Q11: CLI order instead of Go map order
-    for (auto p : o.Pattern) {
+    if (o.UseRegexp || o.DeleteMatched)
+        throw Error("oracle: regexp / delete-matched grep is not restated");
+    std::vector<std::string> patterns;  // PARITY.md Q11: CLI / file order instead of Go map order
+    std::vector<MiniRe> regexps;        // -d
+    // grep.go:122-252: the file replaces -p when given
+    const std::vector<std::string> given = !o.PatternFile.empty() ? read_pattern_lines(o.PatternFile) : o.Pattern;
+    for (auto p : given) {
         if (p.empty()) continue;
+        if (o.Degenerate) {
+            p = degenerate2regexp(p, ab);
+            if (o.IgnoreCase) p = "(?i)" + p;
+            if (std::find(patterns.begin(), patterns.end(), p) != patterns.end()) continue;
+            regexps.push_back(MiniRe::compile(p));
+            patterns.push_back(p);
+            continue;
+        }
         if (o.BySeq) {
+            if (o.MaxMismatch > 0 && o.MaxMismatch > (int)p.size()) throw Error("mismatch should be <= length of sequence: " + p);
             if (!(alphabet_is_valid(AB_DNAredundant, p) || alphabet_is_valid(AB_RNAredundant, p) ||
                   alphabet_is_valid(AB_PROTEIN, p)))
                 throw Error("illegal DNA/RNA/Protein sequence: " + p);
@@ -635,7 +761,7 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
     int64_t count = 0;
     while (rd.Read()) {
         Record& r = rd.rec;
-        if (checkAlphabet) {  // grep.go:403-409
+        if (checkAlphabet) {  // grep.go:403-409, :276-281
             if (rd.GetAlphabet() == AB_UNLIMIT || rd.GetAlphabet() == AB_PROTEIN) onlyPos = true;
             checkAlphabet = false;
         }
@@ -652,9 +778,19 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
                     target = sq.substr(b, e - b);
                 } else if (o.Circular) target = sq + sq;
                 else target = sq;
+                if (o.Degenerate) {  // grep.go:459-468: re.Match on the un-lowered target
+                    for (auto& re : regexps)
+                        if (re.find(target, 0) >= 0) { hit = true; break; }
+                    continue;
+                }
                 if (o.IgnoreCase) target = lower(target);
-                for (auto& k : patterns)
-                    if (target.find(k) != std::string::npos) { hit = true; break; }
+                for (auto& k : patterns) {
+                    if (o.MaxMismatch == 0 ? target.find(k) != std::string::npos
+                                           : !fmi_locate(target, k, o.MaxMismatch).empty()) {  // grep.go:327-339, 484-497
+                        hit = true;
+                        break;
+                    }
+                }
             } else {
                 target = o.ByName ? r.name : r.id;
                 if (o.IgnoreCase) target = lower(target);
@@ -664,7 +800,7 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
         if (o.InvertMatch ? hit : !hit) continue;
         if (o.Count) { ++count; continue; }
         std::string bb = record_format(r, rd.IsFastq, lineWidth);
-        bb.pop_back();  // grep.go:531-533
+        bb.pop_back();  // grep.go:531-533 (grepBySeqMismatches keeps it, :356 -- PARITY.md Q6: one newline everywhere)
         result.push_back(bb);
     }
     if (o.Count) result.push_back(std::to_string(count));
@@ -841,8 +977,43 @@ std::vector<std::string> translate_call(const std::vector<std::string_view>& par
 }
 
 // ---------------------------------------------------------------------------
-// Locate  bigseqkit-lib/locate.go (exact patterns: no -d, -r, -m, -F, -f)
+// Locate  bigseqkit-lib/locate.go (no -r)
 // ---------------------------------------------------------------------------
+std::vector<std::pair<std::string, std::string>> read_pattern_fasta(const std::string& path) {
+    // fastx.GetSeqsMap(file, seq.Unlimit, ...): full name -> sequence; file order kept (PARITY.md Q11)
+    std::vector<std::pair<std::string, std::string>> out;
+    const std::string s = [&] {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) throw Error("open " + path + ": no such file or directory");
+        std::string t;
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) t.append(buf, n);
+        fclose(f);
+        return t;
+    }();
+    size_t i = 0;
+    bool have = false;
+    while (i < s.size()) {
+        size_t j = s.find('\n', i);
+        if (j == std::string::npos) j = s.size();
+        std::string line = s.substr(i, j - i);
+        while (!line.empty() && line.back() == '\r') line.pop_back();
+        i = j + 1;
+        if (!line.empty() && line[0] == '>') {
+            const std::string name = line.substr(1);
+            have = true;
+            size_t k = 0;
+            for (; k < out.size(); ++k) if (out[k].first == name) break;
+            if (k == out.size()) out.emplace_back(name, "");
+            else { auto e = out[k]; out.erase(out.begin() + (long)k); e.second.clear(); out.push_back(e); }
+        } else if (have) {
+            out.back().second += line;
+        }
+    }
+    return out;
+}
+
 std::vector<std::string> locate_call(const std::vector<std::string_view>& part, const LocateOptions& o, int64_t pid) {
     Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
     bool any = !o.PatternFile.empty();
@@ -856,55 +1027,102 @@ std::vector<std::string> locate_call(const std::vector<std::string_view>& part, 
         if (o.Degenerate) throw Error("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
         if (o.UseRegexp) throw Error("flag -r (--use-regexp) ignored when giving flag -F (--use-fmi)");
     }
-    if (o.Degenerate || o.UseRegexp || o.UseFmi || o.MaxMismatch > 0 || !o.PatternFile.empty())
-        throw Error("oracle: degenerate / regexp / FM-index / mismatch / pattern-file locate is not restated");
-    std::vector<std::pair<std::string, std::string>> pats;  // (name, bytes) in CLI order (PARITY.md Q11)
-    for (auto& p : o.Pattern) {
-        if (p.empty()) continue;
-        std::string eff = o.IgnoreCase ? lower(p) : p;
-        if (eff.find('.') != std::string::npos ||
-            !(alphabet_is_valid(AB_DNAredundant, eff) || alphabet_is_valid(AB_RNAredundant, eff) || alphabet_is_valid(AB_PROTEIN, eff)))
-            throw Error("illegal DNA/RNA/Protein sequence: " + p + ", you may switch on -d/--degenerate or -r/--use-regexp");
+    if (o.UseRegexp) throw Error("oracle: regexp locate is not restated");
+    struct Pat { std::string name, bytes; MiniRe re; };
+    std::vector<Pat> pats;  // CLI / file order (PARITY.md Q11)
+    std::vector<std::pair<std::string, std::string>> given;
+    if (!o.PatternFile.empty()) {
+        given = read_pattern_fasta(o.PatternFile);
+        if (given.empty()) throw Error("no FASTA sequences found in pattern file: " + o.PatternFile);
+    } else {
+        for (auto& p : o.Pattern) if (!p.empty()) given.emplace_back(p, p);
+    }
+    for (auto& g : given) {  // locate.go:86-190
+        Pat pt;
+        pt.name = g.first;
+        pt.bytes = g.second;
+        std::string re;
+        if (o.Degenerate) re = degenerate2regexp(g.second, !o.PatternFile.empty() ? AB_UNLIMIT : ab);
+        else if (o.IgnoreCase) pt.bytes = lower(pt.bytes);
+        if (o.MaxMismatch > 0) {
+            if (o.MaxMismatch > (int)pt.bytes.size()) throw Error("mismatch should be <= length of sequence: " + g.second);
+            if (!(alphabet_is_valid(AB_DNAredundant, pt.bytes) || alphabet_is_valid(AB_RNAredundant, pt.bytes) ||
+                  alphabet_is_valid(AB_PROTEIN, pt.bytes)))
+                throw Error("illegal DNA/RNA/Protein sequence: " + g.first);
+        } else if (o.Degenerate) {
+            if (o.IgnoreCase) re = "(?i)" + re;
+            pt.re = MiniRe::compile(re);
+        } else if (pt.bytes.find('.') != std::string::npos ||
+                   !(alphabet_is_valid(AB_DNAredundant, pt.bytes) || alphabet_is_valid(AB_RNAredundant, pt.bytes) ||
+                     alphabet_is_valid(AB_PROTEIN, pt.bytes))) {
+            throw Error("illegal DNA/RNA/Protein sequence: " + g.first + ", you may switch on -d/--degenerate or -r/--use-regexp");
+        }
         bool dup = false;
-        for (auto& q : pats) if (q.first == p) dup = true;
-        if (!dup) pats.emplace_back(p, eff);
+        for (auto& q : pats) if (q.name == pt.name) dup = true;
+        if (!dup) pats.push_back(pt);
     }
     std::vector<std::string> result;
     if (!(o.Gtf || o.Bed) && pid == 0)  // locate.go:198-204
         result.push_back(o.HideMatched ? "seqID\tpatternName\tpattern\tstrand\tstart\tend"
                                        : "seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched");
     SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
-    auto row = [&](const Record& r, const std::pair<std::string, std::string>& pt, char strand, long begin, long end,
-                   const std::string& matched) {
+    auto row = [&](const Record& r, const Pat& pt, char strand, long begin, long end, const std::string& matched) {
         char b[64];
         std::string s;
         if (o.Gtf) {
             snprintf(b, sizeof b, "%ld\t%ld\t%d\t%c\t", begin, end, 0, strand);
-            s = r.id + "\tSeqKit\tlocation\t" + b + ".\tgene_id \"" + pt.first + "\"; ";
+            s = r.id + "\tSeqKit\tlocation\t" + b + ".\tgene_id \"" + pt.name + "\"; ";
         } else if (o.Bed) {
             snprintf(b, sizeof b, "\t%ld\t%ld\t", begin - 1, end);
-            s = r.id + b + pt.first + "\t0\t" + strand;
+            s = r.id + b + pt.name + "\t0\t" + strand;
         } else {
             snprintf(b, sizeof b, "%c\t%ld\t%ld", strand, begin, end);
-            s = r.id + "\t" + pt.first + "\t" + pt.second + "\t" + b;
+            s = r.id + "\t" + pt.name + "\t" + pt.bytes + "\t" + b;
             if (!o.HideMatched) s += "\t" + matched;
         }
         result.push_back(s);
     };
+    bool checkAlphabet = true, onlyPosAuto = o.OnlyPositiveStrand;
     while (rd.Read()) {
         Record& r = rd.rec;
-        if (o.IgnoreCase) r.seq = lower(r.seq);  // locate.go:424-426
+        if (checkAlphabet) {  // locate.go:222-227, 423-428
+            if (rd.GetAlphabet() == AB_UNLIMIT || rd.GetAlphabet() == AB_PROTEIN) onlyPosAuto = true;
+            checkAlphabet = false;
+        }
+        if (!o.Degenerate && o.IgnoreCase) r.seq = lower(r.seq);  // locate.go:430-432
         const long l = (long)r.seq.size();
         if (o.Circular) r.seq += r.seq;
         const long n = (long)r.seq.size();
+        if (o.MaxMismatch > 0 || o.UseFmi) {  // locate.go:208-391: every pattern on '+', then every pattern on '-'
+            for (int strand = 0; strand < 2; ++strand) {
+                if (strand == 1 && onlyPosAuto) break;
+                const std::string text = strand == 0 ? r.seq : rev_com(r.seq, rd.GetAlphabet());
+                for (auto& pt : pats) {
+                    const long lp = (long)pt.bytes.size();
+                    for (long i : fmi_locate(text, pt.bytes, o.MaxMismatch)) {
+                        if (o.Circular && i + 1 > l) continue;
+                        if (i + lp > n) continue;
+                        const long begin = strand == 0 ? i + 1 : l - i - lp + 1;
+                        const long end = strand == 0 ? i + lp : l - i;
+                        row(r, pt, strand == 0 ? '+' : '-', begin, end, text.substr((size_t)i, (size_t)lp));
+                    }
+                }
+            }
+            continue;
+        }
         for (auto& pt : pats) {
-            const std::string& p = pt.second;
-            const long lp = (long)p.size();
+            const std::string& p = pt.bytes;
+            const long lp = (long)p.size();  // a degenerate pattern matches exactly len(p) letters
+            auto find_from = [&](const std::string& text, long offset) -> long {
+                if (o.Degenerate) return pt.re.find(text, (size_t)offset);
+                size_t f = text.find(p, (size_t)offset);
+                return f == std::string::npos ? -1 : (long)f;
+            };
             long offset = 0;
-            for (;;) {  // locate.go:583-667
-                size_t f = r.seq.find(p, (size_t)offset);
-                if (f == std::string::npos) break;
-                const long i = (long)f - offset;
+            for (;;) {  // locate.go:583-667 (the containment check at :604-614 cannot fire for fixed-length matches)
+                const long f = find_from(r.seq, offset);
+                if (f < 0) break;
+                const long i = f - offset;
                 const long begin = offset + i + 1;
                 if (o.Circular && begin > l) break;
                 const long end = offset + i + lp;
@@ -916,9 +1134,9 @@ std::vector<std::string> locate_call(const std::vector<std::string_view>& part, 
             const std::string rp = rev_com(r.seq, rd.GetAlphabet());
             offset = 0;
             for (;;) {  // locate.go:679-766
-                size_t f = rp.find(p, (size_t)offset);
-                if (f == std::string::npos) break;
-                const long i = (long)f - offset;
+                const long f = find_from(rp, offset);
+                if (f < 0) break;
+                const long i = f - offset;
                 if (o.Circular && offset + i + 1 > l) break;
                 long begin = l - offset - (i + lp) + 1, end = l - offset - i;
                 if (offset + i + lp > l) { begin += l; end += l; }

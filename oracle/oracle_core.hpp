@@ -20,6 +20,7 @@
 // Deliberate deviations from the reference *as written* are listed in PARITY.md.
 // ============================================================================
 #pragma once
+#include <bitset>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -157,7 +158,17 @@ struct GrepOptions {  // bigseqkit/grep.go:13-49
     std::string Region;
     bool Circular = false, Count = false;
 };
-// Grep.Before + grepGeneral  bigseqkit-lib/grep.go:41-253, 367-542  (exact patterns only)
+// Degenerate2Regexp + the regexp subset it emits; Hamming search standing in for the FM-index (see oracle_core.cpp)
+std::string degenerate2regexp(const std::string& p, Alphabet a);
+struct MiniRe {
+    bool icase = false;
+    std::vector<std::bitset<256>> atoms;
+    static MiniRe compile(const std::string& re);
+    long find(const std::string& text, size_t from) const;
+};
+std::vector<long> fmi_locate(const std::string& text, const std::string& pat, int k);
+std::vector<std::string> read_pattern_lines(const std::string& path);
+// Grep.Before + grepGeneral + grepBySeqMismatches  bigseqkit-lib/grep.go:41-253, 255-365, 367-542  (no -r, --delete-matched)
 std::vector<std::string> grep_call(const std::vector<std::string_view>& part, const GrepOptions& o);
 
 struct SubseqOptions {  // bigseqkit/subseq.go:9-35 (region mode)
@@ -193,7 +204,7 @@ struct LocateOptions {  // bigseqkit/locate.go:9-45
     int MaxMismatch = 0;
     bool HideMatched = false, Circular = false;
 };
-// Locate.Before + Call, exact patterns  bigseqkit-lib/locate.go:33-193, 195-204, 392-772
+// Locate.Before + Call (exact, -d, -m, -F, -f; no -r)  bigseqkit-lib/locate.go:33-193, 195-772
 // rows WITHOUT their trailing newline (PARITY.md Q6); header row when pid == 0
 std::vector<std::string> locate_call(const std::vector<std::string_view>& part, const LocateOptions& o, int64_t pid);
 

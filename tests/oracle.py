@@ -29,7 +29,8 @@ class GrepOpts(C.Structure):
     _fields_ = [("Config", KitConfig), ("Pattern", C.POINTER(C.c_char_p)), ("npattern", C.c_int)] + \
                [(k, C.c_int) for k in ("InvertMatch", "ByName", "BySeq", "OnlyPositiveStrand", "IgnoreCase")] + \
                [("Region", C.c_char_p)] + [(k, C.c_int) for k in
-                ("Circular", "Count", "UseRegexp", "Degenerate", "MaxMismatch", "DeleteMatched")]
+                ("Circular", "Count", "UseRegexp", "Degenerate", "MaxMismatch", "DeleteMatched")] + \
+               [("PatternFile", C.c_char_p)]
 
 
 class SubseqOpts(C.Structure):
@@ -40,7 +41,8 @@ class SubseqOpts(C.Structure):
 class LocateOpts(C.Structure):
     _fields_ = [("Config", KitConfig), ("Pattern", C.POINTER(C.c_char_p)), ("npattern", C.c_int)] + \
                [(k, C.c_int) for k in ("IgnoreCase", "OnlyPositiveStrand", "NonGreedy", "Gtf", "Bed", "HideMatched",
-                                       "Circular", "Degenerate", "UseRegexp", "UseFmi", "MaxMismatch")]
+                                       "Circular", "Degenerate", "UseRegexp", "UseFmi", "MaxMismatch")] + \
+               [("PatternFile", C.c_char_p)]
 
 
 class TranslateOpts(C.Structure):
@@ -113,7 +115,7 @@ def grep_opts(opts_json):
     arr = (C.c_char_p * max(1, len(pats)))(*pats)
     o = GrepOpts(_cfg(d), arr, len(pats), b("InvertMatch"), b("ByName"), b("BySeq"), b("OnlyPositiveStrand"),
                  b("IgnoreCase"), g("Region", "").encode(), b("Circular"), b("Count"), b("UseRegexp"),
-                 b("Degenerate"), g("MaxMismatch", 0), b("DeleteMatched"))
+                 b("Degenerate"), g("MaxMismatch", 0), b("DeleteMatched"), g("PatternFile", "").encode())
     o._keep = (arr, pats)
     return o
 
@@ -142,7 +144,7 @@ def locate_opts(opts_json):
     arr = (C.c_char_p * max(1, len(pats)))(*pats)
     o = LocateOpts(_cfg(d), arr, len(pats), b("IgnoreCase"), b("OnlyPositiveStrand"), b("NonGreedy"), b("Gtf"),
                    b("Bed"), b("HideMatched"), b("Circular"), b("Degenerate"), b("UseRegexp"), b("UseFmi"),
-                   g("MaxMismatch", 0))
+                   g("MaxMismatch", 0), g("PatternFile", "").encode())
     o._keep = (arr, pats)
     return o
 

@@ -211,3 +211,97 @@ def test_subseq_option_errors():
         with pytest.raises(oracle.OracleError) as oe:
             oracle.subseq(b">a\nA\n", False, json.dumps(opts))
         assert msg in str(oe.value)
+
+
+# ---------------------------------------------------------------- -d, -m, -f (class patterns, pattern files)
+GREP_GEN_OPTS = [
+    {"Pattern": ["ACGTTGCAAGCT"], "MaxMismatch": 1},
+    {"Pattern": ["ACGTTGCAAGCT"], "MaxMismatch": 3, "OnlyPositiveStrand": True},
+    {"Pattern": ["acgttgcaagct"], "MaxMismatch": 2, "IgnoreCase": True},
+    {"Pattern": ["ACGTTGCAAGCT", "GGGGGGGGGG"], "MaxMismatch": 2, "InvertMatch": True},
+    {"Pattern": ["ACGTTGCAAGCT"], "MaxMismatch": 1, "Circular": True},
+    {"Pattern": ["ACGTTGCAAGCT"], "MaxMismatch": 2, "Region": "1:60"},
+    {"Pattern": ["ACGTTGCAAGCT"], "MaxMismatch": 2, "Region": "-60:-1"},
+    {"Pattern": ["ACGNTGCRAGYT"], "Degenerate": True},
+    {"Pattern": ["acgnnnnaagct"], "Degenerate": True, "IgnoreCase": True},
+    {"Pattern": ["acgnnnnaagct"], "Degenerate": True},                       # lower-case classes only
+    {"Pattern": ["WSWSWSWSWS", "ACGNTGCRAGYT"], "Degenerate": True, "Circular": True},
+    {"Pattern": ["ACGNTGCRAGYT"], "Degenerate": True, "Region": "10:-10", "OnlyPositiveStrand": True},
+    {"Pattern": ["BBBBBBHHHHDDDDVVVV"], "Degenerate": True},
+]
+
+
+@pytest.mark.parametrize("i", range(len(GREP_GEN_OPTS)))
+def test_grep_mismatch_and_degenerate_fastq(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1300 + i)
+    n = check_grep(planted_fastq(rng, 600), True, GREP_GEN_OPTS[i])
+    assert n > 0
+
+
+@pytest.mark.parametrize("width", [60, 0, 13, -1])
+@pytest.mark.parametrize("i", [0, 2, 4, 6, 7, 8, 10])
+def test_grep_mismatch_and_degenerate_fasta(i, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1400 + i)
+    recs = []
+    for k in range(200):
+        L = rng.randint(0, 500)
+        s = [rng.choice("ACGTacgtN") for _ in range(L)]
+        if L >= 12 and k % 3 == 0:
+            p = rng.randrange(L - 11)
+            s[p:p + 12] = MOTIF if k % 2 else "AGCTTGCAACGT"
+            if k % 4 == 0:
+                s[p + 5] = "T" if s[p + 5] != "T" else "A"   # one mismatch
+        s = "".join(s)
+        if width < 0:  # irregular wrapping
+            lines, j = [], 0
+            while j < L:
+                w = rng.randint(1, 40)
+                lines.append(s[j:j + w])
+                j += w
+            recs.append(f">s{k} x\n" + "".join(l + "\n" for l in lines))
+        else:
+            w = width if width else max(1, L)
+            recs.append(f">s{k} x\n" + "".join(s[j:j + w] + "\n" for j in range(0, L, w)))
+    check_grep("".join(recs).encode(), False, GREP_GEN_OPTS[i])
+
+
+def test_grep_protein_degenerate_with_seqtype_protein():
+    prot = b">p1\nMKVLAAGIVDMEE\n>p2\nMKVLAAGIVNMQE\n>p3\nMKVLAAGIVAMAE\n"
+    o = {"Pattern": ["VBMZE"], "Degenerate": True, "Config": {"SeqType": "protein"}}
+    assert check_grep(prot, False, o) == 2
+    assert check_grep(prot, False, {"Pattern": ["GIVXM"], "Degenerate": True, "Config": {"SeqType": "protein"}}) == 3
+
+
+def test_grep_pattern_file_and_large_id_set(tmp_path):
+    rng = random.Random(77)
+    data = planted_fastq(rng, 3000, L=20)
+    ids = [f"r{i}" for i in rng.sample(range(6000), 2500)] + ["", "r5", "r5"]
+    f = tmp_path / "ids.txt"
+    f.write_text("\r\n".join(ids) + "\n")
+    n = check_grep(data, True, {"PatternFile": str(f)})
+    assert 800 < n < 2000
+    check_grep(data, True, {"PatternFile": str(f), "InvertMatch": True})
+    names = tmp_path / "names.txt"
+    names.write_text("".join(f"R{i} D{i % 5}\n" for i in range(0, 3000, 3)))
+    assert check_grep(data, True, {"PatternFile": str(names), "ByName": True, "IgnoreCase": True}) == 1000
+    seqs = tmp_path / "seqs.txt"
+    seqs.write_text(MOTIF + "\nGGGGGGGGGGGG\n")
+    check_grep(data, True, {"PatternFile": str(seqs), "BySeq": True})
+    check_grep(planted_fastq(rng, 500), True, {"PatternFile": str(seqs), "MaxMismatch": 1})
+    # many patterns given with -p take the same set path
+    many = [f"r{i}" for i in range(0, 3000, 7)]
+    assert check_grep(data, True, {"Pattern": many}) == len(many)
+
+
+def test_grep_general_option_errors():
+    for opts, msg in [({"Pattern": ["ACGT"], "MaxMismatch": 5}, "mismatch should be <= length of sequence: ACGT"),
+                      ({"Pattern": ["ACGT"], "MaxMismatch": 1, "Degenerate": True}, "not allowed when giving flag -m"),
+                      ({"PatternFile": "/nonexistent/ids.txt"}, "no such file or directory")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("Grep", json.dumps(opts), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.grep(b"@a\nA\n+\nI\n", True, json.dumps(opts))
+        assert msg in str(oe.value)

@@ -107,3 +107,67 @@ def test_locate_header_only_on_partition_zero():
     got = bsk.Locate(fr, _Opts({"Pattern": ["ACG"]}))
     assert got == oracle.locate(data, True, '{"Pattern": ["ACG"]}', nparts=1)
     assert got.count(b"seqID\t") == 1
+
+
+# ---------------------------------------------------------------- -d, -m, -F, -f
+LOC_GEN_OPTS = [
+    {"Pattern": ["ACGT"], "MaxMismatch": 1},
+    {"Pattern": ["ACGTAC", "TTTTT"], "MaxMismatch": 2, "HideMatched": True},
+    {"Pattern": ["acgtac"], "MaxMismatch": 1, "IgnoreCase": True},
+    {"Pattern": ["ACGTAC"], "MaxMismatch": 1, "Circular": True},
+    {"Pattern": ["ACGTAC"], "MaxMismatch": 1, "Circular": True, "Bed": True},
+    {"Pattern": ["ACGTAC"], "MaxMismatch": 2, "Gtf": True, "OnlyPositiveStrand": True},
+    {"Pattern": ["ACGTAC"], "MaxMismatch": 1, "NonGreedy": True},
+    {"Pattern": ["ACG", "GGCC"], "UseFmi": True},
+    {"Pattern": ["acg"], "UseFmi": True, "IgnoreCase": True, "Circular": True},
+    {"Pattern": ["ANNT"], "Degenerate": True},
+    {"Pattern": ["RYRY", "ACGN"], "Degenerate": True, "HideMatched": True},
+    {"Pattern": ["acgn"], "Degenerate": True, "IgnoreCase": True},
+    {"Pattern": ["ACNNGT"], "Degenerate": True, "NonGreedy": True},
+    {"Pattern": ["ACNNGT"], "Degenerate": True, "Circular": True, "Bed": True},
+    {"Pattern": ["WSWS"], "Degenerate": True, "Circular": True, "NonGreedy": True, "Gtf": True},
+    {"Pattern": ["NNNNNNNN"], "Degenerate": True, "OnlyPositiveStrand": True},
+]
+
+
+@pytest.mark.parametrize("i", range(len(LOC_GEN_OPTS)))
+def test_locate_general_fastq(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1900 + i)
+    data = seqgen.random_fastq(rng, 300, 0, 100, alphabet="ACGT" * 5 + "acgtN")
+    got = check(data, True, LOC_GEN_OPTS[i])
+    assert got.count(b"\n") > 10
+
+
+@pytest.mark.parametrize("width", [60, 0, 7])
+@pytest.mark.parametrize("i", range(len(LOC_GEN_OPTS)))
+def test_locate_general_fasta(i, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1950 + i)
+    data = seqgen.random_fasta(rng, 80, 0, 300, width=width, alphabet="ACGT" * 5 + "acgtN", final_newline=i % 2 == 0)
+    check(data, False, LOC_GEN_OPTS[i])
+
+
+def test_locate_fm_index_branch_consults_the_alphabet_and_keeps_raw_minus_coordinates():
+    prot = b">p\nMKVLAAGIVKM\n"
+    assert b"\t-\t" not in check(prot, False, {"Pattern": ["MK"], "UseFmi": True})
+    # circular '-' hit that wraps: begin = l - i - len + 1 without the +l shift of the exact branch (locate.go:330)
+    got = check(b">c\nGTTTTGAC\n", False, {"Pattern": ["ACGTCA"], "MaxMismatch": 1, "Circular": True})
+    assert b"c\tACGTCA\tACGTCA\t-\t-3\t2\tACGTCA\n" in got
+    check(b">c\nAAAAAAAC\n", False, {"Pattern": ["TTTT"], "UseFmi": True, "Circular": True, "Bed": True})
+
+
+def test_locate_pattern_file(tmp_path):
+    rng = random.Random(8)
+    data = seqgen.random_fasta(rng, 100, 0, 400, alphabet="ACGT")
+    f = tmp_path / "motifs.fa"
+    f.write_text(">m1 first motif\nACGT\n>m2\nTTG\nCA\n>m1 first motif\nGGCC\n>deg\nANNT\n")
+    got = check(data, False, {"PatternFile": str(f)})
+    assert b"\tm1 first motif\tGGCC\t" in got and b"\tm2\tTTGCA\t" in got
+    check(data, False, {"PatternFile": str(f), "Degenerate": True, "HideMatched": True})
+    check(data, False, {"PatternFile": str(f), "MaxMismatch": 1})
+    empty = tmp_path / "empty.fa"
+    empty.write_text("\n")
+    with pytest.raises(bsk.BskError) as e:
+        bsk.Operator("Locate", json.dumps({"PatternFile": str(empty)}), -1)
+    assert "no FASTA sequences found in pattern file" in str(e.value)
