@@ -214,6 +214,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_names_off) hipFree(c->d_names_off);
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_cls) hipFree(c->d_cls);
+        if (c->d_feat) hipFree(c->d_feat);
         if (c->d_set_keys) hipFree(c->d_set_keys);
         if (c->d_set_idx) hipFree(c->d_set_idx);
         if (c->d_pat_off) hipFree(c->d_pat_off);

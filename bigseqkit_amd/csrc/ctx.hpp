@@ -92,6 +92,14 @@ struct bsk_ctx {
     uint8_t* d_names = nullptr;
     uint32_t* d_names_off = nullptr;
     uint64_t names_cap = 0, names_off_cap = 0;
+    // subseq --gtf / --bed: the first feature of every (lower-cased) sequence name (subseq.go:319-526)
+    struct Feature { std::string name_lower, suffix; int64_t s, e; bool minus; };
+    std::vector<Feature> features;
+    bool features_uploaded = false;
+    uint8_t* d_feat = nullptr;             // one allocation holding all feature arrays
+    uint64_t feat_cap = 0;
+    uint64_t feat_off[9] = {0};            // byte offsets of the arrays inside d_feat
+    uint64_t feat_slots = 0;
     int64_t cur_pid = 0;                   // partition index of the running Call()
     int region_start = 0, region_end = 0;  // parsed -R / -r
     bool region_on = false;

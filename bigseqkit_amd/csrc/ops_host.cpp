@@ -45,6 +45,8 @@ static int grow(bsk_ctx* c, T** p, uint64_t* cap, uint64_t need, uint64_t slack 
 }
 
 static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
+static void complement_table(Alphabet ab, uint8_t m[256]);
+static std::vector<std::string> read_pattern_lines(const std::string& path);
 
 int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
     if (!f) return BSK_OK;
@@ -610,6 +612,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     int rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
     uint64_t total = 0, kept = 0;
+    TextTableH tt{nullptr, nullptr, nullptr};
     if (c->table.n > 0) {
         Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
         if (rc != BSK_OK) return rc;
@@ -631,7 +634,8 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
         G.line_width = fastq ? 0 : (int)o.ci("LineWidth");
         G.npat = (int)c->patterns.size();
-        TextTableH tt{nullptr, nullptr, nullptr};
+        rc = prepare_text(c, d_buf, format, st, &tt);  // uses d_out_len as scratch: before the match kernel
+        if (rc != BSK_OK) return rc;
         if (!G.by_seq) {
             // ID / name: the patterns do not depend on the shard, upload once per context
             if (!c->patterns_uploaded) {
@@ -652,8 +656,6 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             if (rc != BSK_OK) return rc;
             if (c->general) {
                 rc = upload_classes(c, G.both_strands, ab, st);
-                if (rc != BSK_OK) return rc;
-                rc = prepare_text(c, d_buf, format, st, &tt);
                 if (rc != BSK_OK) return rc;
                 G.general = 1;
                 G.max_mm = c->max_mm;
@@ -688,7 +690,8 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     if (total == 0) return BSK_OK;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    const SeqParams P = format_params(c, fastq);
+    SeqParams P = format_params(c, fastq);
+    P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
     out->d_data = c->d_out;
     out->len = total;
@@ -856,6 +859,115 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
 }
 
 // ---------------------------------------------------------------------------
+// subseq --gtf / --bed: feature files (host side of SubseqTransform.Before, subseq.go:100-165)
+//   ReadBedFilteredFeatures  bigseqkit-lib/subseq.go:242-310 (in tree)
+//   gtf.ReadFilteredFeatures shenwei356/bio featio/gtf (not in tree; PARITY.md GTF)
+// Only the FIRST feature of a sequence name is ever used (subseq.go:426, 523 return inside the loop, Q7), so that
+// is all the context keeps: name -> (flank-adjusted start, end, strand, header suffix).
+// ---------------------------------------------------------------------------
+static std::vector<std::string> split_tabs(const std::string& line) {
+    std::vector<std::string> items;
+    for (size_t i = 0;;) {
+        size_t j = line.find('\t', i);
+        if (j == std::string::npos) { items.emplace_back(line, i); break; }
+        items.emplace_back(line, i, j - i);
+        i = j + 1;
+    }
+    return items;
+}
+
+static bool atoi_strict(const std::string& s, long long* v) {
+    if (s.empty() || isspace((unsigned char)s[0])) return false;
+    char* e = nullptr;
+    *v = strtoll(s.c_str(), &e, 10);
+    return *e == 0;
+}
+
+static std::string lower_str(std::string s) {
+    for (auto& ch : s) if (ch >= 'A' && ch <= 'Z') ch += 32;
+    return s;
+}
+
+static void load_features(bsk_ctx* c) {
+    const Options& o = c->opts;
+    const bool gtf = !o.s("Gtf").empty();
+    const std::vector<std::string>& chrs = o.sl("Chr");
+    std::vector<std::string> feats;
+    for (auto& f : o.sl("Feature")) feats.push_back(lower_str(f));
+    if (!gtf && !feats.empty()) throw OptError("when given flag -b (--bed), flag -f (--feature) is not allowed");
+    const int64_t up = o.i("UpStream"), down = o.i("DownStream");
+    const bool only = o.b("OnlyFlank");
+    std::string flank;
+    if (up > 0) {
+        if (only) flank = "_usf:" + std::to_string(up);
+        else if (down > 0) flank = "_us:" + std::to_string(up) + "_ds:" + std::to_string(down);
+        else flank = "_us:" + std::to_string(up);
+    } else if (down > 0) {
+        flank = only ? "_dsf:" + std::to_string(down) : "_ds:" + std::to_string(down);
+    }
+    c->features.clear();
+    c->features_uploaded = false;
+    std::unordered_set<std::string> seen;
+    for (const std::string& line : read_pattern_lines(gtf ? o.s("Gtf") : o.s("Bed"))) {
+        if (line.empty() || line[0] == '#') continue;
+        if (!gtf && ((line.size() > 7 && line.compare(0, 7, "browser") == 0) || (line.size() > 5 && line.compare(0, 5, "track") == 0)))
+            continue;
+        const auto items = split_tabs(line);
+        if (gtf ? items.size() != 9 : items.size() < 3) continue;
+        if (!chrs.empty() && std::find(chrs.begin(), chrs.end(), items[0]) == chrs.end()) continue;
+        if (gtf && !feats.empty() && std::find(feats.begin(), feats.end(), lower_str(items[2])) == feats.end()) continue;
+        long long st, en;
+        const std::string &sst = items[gtf ? 3 : 1], &sen = items[gtf ? 4 : 2];
+        if (!atoi_strict(sst, &st)) throw OptError(items[0] + ": bad start: " + sst);
+        if (!atoi_strict(sen, &en)) throw OptError(items[0] + ": bad end: " + sen);
+        std::string strand = ".", label;
+        if (gtf) {
+            if (st > en) throw OptError(items[0] + ": start (" + std::to_string(st) + ") must be < end (" + std::to_string(en) + ")");
+            if (items[6] != "+" && items[6] != "-" && items[6] != ".") throw OptError("bad strand: " + items[6]);
+            strand = items[6];
+            const std::string& at = items[8];  // tag "value"; tag "value";
+            for (size_t i = 0; i < at.size();) {
+                size_t j = at.find(';', i);
+                if (j == std::string::npos) j = at.size();
+                std::string item(at, i, j - i);
+                i = j + 1;
+                const size_t a0 = item.find_first_not_of(' ');
+                if (a0 == std::string::npos) continue;
+                item.erase(0, a0);
+                const size_t sp = item.find(' ');
+                if (sp == std::string::npos) continue;
+                std::string v(item, sp + 1);
+                while (!v.empty() && v.back() == ' ') v.pop_back();
+                if (v.size() >= 2 && v.front() == '"' && v.back() == '"') v = v.substr(1, v.size() - 2);
+                if (item.compare(0, sp, o.s("GtfTag")) == 0 && sp == o.s("GtfTag").size()) { label = v; break; }
+            }
+        } else {
+            if (st >= en) throw OptError(items[0] + ": start (" + std::to_string(st) + ") must be <= end (" + std::to_string(en) + ")");
+            st += 1;  // BED start is 0-based (subseq.go:294)
+            if (items.size() >= 4) label = items[3];
+            if (items.size() >= 6) {
+                if (items[5] != "+" && items[5] != "-" && items[5] != ".") throw OptError("bad strand: " + items[5]);
+                strand = items[5];
+            }
+        }
+        const std::string key = lower_str(items[0]);
+        if (!seen.insert(key).second) continue;  // a later feature of the same name is never reached
+        bsk_ctx::Feature f;
+        f.name_lower = key;
+        f.minus = strand == "-";
+        if (f.minus) {  // subseq.go:340-352
+            if (only) { if (up > 0) { f.s = en + 1; f.e = en + up; } else { f.s = st - down; f.e = st - 1; } }
+            else { f.s = st - down; f.e = en + up; }
+        } else {        // subseq.go:359-371
+            if (only) { if (up > 0) { f.s = st - up; f.e = st - 1; } else { f.s = en + 1; f.e = en + down; } }
+            else { f.s = st - up; f.e = en + down; }
+        }
+        f.suffix = "_" + std::to_string(st) + "-" + std::to_string(en) + ":" + strand + flank + " " + label;
+        c->features.push_back(f);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // subseq by region  (SubseqTransform, bigseqkit-lib/subseq.go:36-165, 314-317)
 // ---------------------------------------------------------------------------
 void validate_subseq_opts(bsk_ctx* c) {
@@ -874,10 +986,56 @@ void validate_subseq_opts(bsk_ctx* c) {
         c->region_on = true;
         parse_region_opt(o.s("Region"), "subseq", &c->region_start, &c->region_end);
     } else if (!o.s("Gtf").empty() || !o.s("Bed").empty()) {
-        throw OptError("libbsk: subseq --gtf / --bed are not supported by the HIP path yet");
+        load_features(c);
     } else {
         throw OptError("one of the options needed: -r/--region, --bed, --gtf");
     }
+}
+
+static int upload_features(bsk_ctx* c, hipStream_t st) {
+    const size_t nf = c->features.size();
+    uint64_t slots = 16;
+    while (slots < 2 * nf) slots <<= 1;
+    std::vector<uint64_t> keys(slots, 0);
+    std::vector<uint32_t> idx(slots, 0), name_off{0}, suf_off{0};
+    std::vector<int64_t> fs(nf), fe(nf);
+    std::vector<uint8_t> minus(nf), names, sufs;
+    for (size_t k = 0; k < nf; ++k) {
+        const auto& f = c->features[k];
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char ch : f.name_lower) h = (h ^ ch) * 1099511628211ull;
+        if (!h) h = 1;
+        uint64_t s = h & (slots - 1);
+        while (keys[s]) s = (s + 1) & (slots - 1);
+        keys[s] = h;
+        idx[s] = (uint32_t)k;
+        names.insert(names.end(), f.name_lower.begin(), f.name_lower.end());
+        name_off.push_back((uint32_t)names.size());
+        sufs.insert(sufs.end(), f.suffix.begin(), f.suffix.end());
+        suf_off.push_back((uint32_t)sufs.size());
+        fs[k] = f.s; fe[k] = f.e; minus[k] = f.minus;
+    }
+    // one allocation, every array 16-byte aligned
+    const void* src[8] = {keys.data(), idx.data(), name_off.data(), suf_off.data(), fs.data(), fe.data(), minus.data(), nullptr};
+    const uint64_t bytes[8] = {slots * 8, slots * 4, name_off.size() * 4, suf_off.size() * 4, nf * 8, nf * 8, nf, 0};
+    uint64_t off = 0;
+    for (int a = 0; a < 7; ++a) { c->feat_off[a] = off; off += (bytes[a] + 15) & ~15ull; }
+    const uint64_t names_at = off;
+    off += (names.size() + 15) & ~15ull;
+    const uint64_t sufs_at = off;
+    off += (sufs.size() + 15) & ~15ull;
+    c->feat_off[7] = names_at;
+    int rc = grow(c, &c->d_feat, &c->feat_cap, off + 16);
+    if (rc != BSK_OK) return rc;
+    for (int a = 0; a < 7; ++a)
+        if (bytes[a]) HIP_TRYX(c, hipMemcpyAsync(c->d_feat + c->feat_off[a], src[a], bytes[a], hipMemcpyHostToDevice, st));
+    if (!names.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_feat + names_at, names.data(), names.size(), hipMemcpyHostToDevice, st));
+    if (!sufs.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_feat + sufs_at, sufs.data(), sufs.size(), hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    c->feat_slots = slots;
+    c->feat_off[8] = sufs_at;
+    c->features_uploaded = true;
+    return BSK_OK;
 }
 
 int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
@@ -886,9 +1044,43 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     SeqParams P = format_params(c, fastq);
-    P.region_on = 1;
-    P.region_start = c->region_start;
-    P.region_end = c->region_end;
+    if (c->region_on) {
+        P.region_on = 1;
+        P.region_start = c->region_start;
+        P.region_end = c->region_end;
+    } else {
+        if (c->features.empty()) return empty_result(c, out);  // no record can have a feature
+        if (!c->features_uploaded) {
+            rc = upload_features(c, st);
+            if (rc != BSK_OK) return rc;
+        }
+        Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+        if (rc != BSK_OK) return rc;
+        uint8_t comp[256];
+        complement_table(ab, comp);
+        if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
+        HIP_TRYX(c, hipMemcpyAsync(c->d_lut, comp, 256, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));  // comp lives on the host stack
+        const uint8_t* base = c->d_feat;
+        P.feat_on = 1;
+        P.fset_keys = (const uint64_t*)(base + c->feat_off[0]);
+        P.fset_idx = (const uint32_t*)(base + c->feat_off[1]);
+        P.fset_mask = c->feat_slots - 1;
+        P.fname_off = (const uint32_t*)(base + c->feat_off[2]);
+        P.fsuffix_off = (const uint32_t*)(base + c->feat_off[3]);
+        P.f_s = (const int64_t*)(base + c->feat_off[4]);
+        P.f_e = (const int64_t*)(base + c->feat_off[5]);
+        P.f_minus = base + c->feat_off[6];
+        P.fname = base + c->feat_off[7];
+        P.fsuffix = base + c->feat_off[8];
+        P.comp = c->d_lut;
+    }
+    {   // wrapped FASTA: random access through the text view instead of the sequential per-record walk
+        TextTableH tt{nullptr, nullptr, nullptr};
+        rc = prepare_text(c, d_buf, format, st, &tt);
+        if (rc != BSK_OK) return rc;
+        P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
+    }
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
@@ -1165,7 +1357,8 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    const SeqParams F = format_params(c, fastq);
+    SeqParams F = format_params(c, fastq);
+    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st));
     out->d_data = c->d_out;
     out->len = total;
@@ -1250,6 +1443,12 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
         uint64_t status = 0;
         HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
         return kernel_error_to_status(c, status);
+    }
+    if (!P.remove_gaps) {  // wrapped FASTA: random access through the text view (gap removal walks the record anyway)
+        TextTableH tt{nullptr, nullptr, nullptr};
+        rc = prepare_text(c, d_buf, format, st, &tt);
+        if (rc != BSK_OK) return rc;
+        P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
     }
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;

@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "ops_seq.hpp"
+#include "pattern_match.cuh"  // fnv1a64, TEXT_IRREGULAR (text.cuh)
 
 namespace bsk {
 
@@ -81,6 +82,37 @@ __device__ __forceinline__ uint32_t wrapped_len(uint32_t L, int w) {
     return L + (L - 1) / (uint32_t)w;
 }
 
+// feature of a record (subseq --gtf/--bed): index into the f_* arrays or -1
+__device__ int feature_of(const SeqParams& P, const uint8_t* id, uint32_t id_len) {
+    const uint64_t key = fnv1a64(id, id_len, true);
+    for (uint64_t slot = key & P.fset_mask;; slot = (slot + 1) & P.fset_mask) {
+        const uint64_t sk = P.fset_keys[slot];
+        if (sk == 0) return -1;
+        if (sk != key) continue;
+        const uint32_t f = P.fset_idx[slot];
+        const uint32_t o = P.fname_off[f];
+        if (P.fname_off[f + 1] - o != id_len) continue;
+        bool ok = true;
+        for (uint32_t q = 0; q < id_len; ++q) {
+            uint8_t c = id[q];
+            if (c >= 'A' && c <= 'Z') c += 32;
+            if (c != P.fname[o + q]) { ok = false; break; }
+        }
+        if (ok) return (int)f;
+    }
+}
+
+// region of the feature on a record of length L: subseq.go:339-376 then Seq.SubSeq; [b, e) 0-based
+__device__ __forceinline__ void feature_region(const SeqParams& P, int f, uint32_t L, uint32_t* b, uint32_t* e) {
+    int64_t s = P.f_s[f], t = P.f_e[f];
+    if (s < 1) s = 1;
+    if (t > (int64_t)L) t = L;
+    *b = *e = 0;
+    if (t < 1 || s > (int64_t)L || s > t) return;  // SubSeq of positive bounds; t < 1: empty (PARITY.md SUB0)
+    *b = (uint32_t)(s - 1);
+    *e = (uint32_t)t;
+}
+
 __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
                                                   uint32_t* __restrict__ out_len, uint64_t* __restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,6 +142,18 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
         uint32_t b, e;
         sub_location(L, P.region_start, P.region_end, &b, &e);
         kept = e - b;
+    }
+    if (P.feat_on) {
+        uint32_t off;
+        const uint32_t il = id_span(r.head, r.head_len, P.id_mode, &off);
+        const int f = feature_of(P, r.head + off, il);
+        if (f < 0) { out_len[i] = 0; return; }
+        uint32_t b, e;
+        feature_region(P, f, L, &b, &e);
+        kept = e - b;
+        const uint32_t hl = il + (P.fsuffix_off[f + 1] - P.fsuffix_off[f]);
+        out_len[i] = 1u + hl + 1u + wrapped_len(kept, P.line_width) + 1u + (P.print_qual ? 2u + kept + 1u : 0u);
+        return;
     }
     bool keep = true;
     if (P.min_len > 0 && (int64_t)kept < P.min_len) keep = false;
@@ -156,14 +200,36 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     const RecView r = view(buf, t, g, P.fastq);
     uint32_t hl = r.head_len, hoff = 0;
     if (P.print_name && P.only_id) hl = id_span(r.head, r.head_len, P.id_mode, &hoff);
-    const uint32_t a = P.print_name ? (P.print_seq ? 1u : 0u) + hl + 1u : 0u;
     uint32_t sub_b = 0, sub_e = r.seq_len;
     if (P.region_on) sub_location(r.seq_len, P.region_start, P.region_end, &sub_b, &sub_e);
-    const bool fast = r.contiguous && !P.remove_gaps;
+    bool reverse = P.reverse != 0, use_lut = P.use_lut != 0;
+    const uint8_t* lut = P.lut;
+    const uint8_t* suffix = nullptr;  // feature mode: header = ID + suffix
+    uint32_t id_len = hl;
+    if (P.feat_on) {
+        id_len = id_span(r.head, r.head_len, P.id_mode, &hoff);
+        const int f = feature_of(P, r.head + hoff, id_len);
+        feature_region(P, f, r.seq_len, &sub_b, &sub_e);
+        suffix = P.fsuffix + P.fsuffix_off[f];
+        hl = id_len + (P.fsuffix_off[f + 1] - P.fsuffix_off[f]);
+        if (P.f_minus[f]) { reverse = true; use_lut = true; lut = P.comp; }
+    }
+    const uint32_t a = P.print_name ? (P.print_seq ? 1u : 0u) + hl + 1u : 0u;
+    // random access to the bases: contiguous text, or a wrapped FASTA record through the text view
+    const uint8_t* sp = r.seq;
+    uint32_t TW = 0;
+    bool random_access = r.contiguous;
+    if (!random_access && P.text_w) {
+        const uint32_t w = P.text_w[g];
+        if (w == TEXT_IRREGULAR) sp = P.lin + P.lin_off[g];
+        else TW = w;
+        random_access = true;
+    }
+    const bool fast = random_access && !P.remove_gaps;
     // Whole FASTQ record printed unchanged (grep / rmdup / plain seq): Format() reproduces the
     // record text byte for byte when the '+' line is bare, so copy it 16 bytes per lane.
-    if (fast && P.fastq && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id && !P.reverse &&
-        !P.use_lut && !P.region_on && t.aux[g] == 1) {
+    if (fast && P.fastq && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id && !reverse &&
+        !use_lut && !P.region_on && !P.feat_on && t.aux[g] == 1) {
         const uint8_t* src = buf + t.start[g];
         const uint32_t body = n - 1;  // everything but the final newline, which the shard may lack
         for (uint32_t x = gl * 16u; x < body; x += GROUP * 16u) {
@@ -180,7 +246,6 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     }
     if (fast) {
         const uint32_t L = sub_e - sub_b;
-        const uint8_t* rseq = r.seq + sub_b;
         const uint8_t* rqual = r.qual ? r.qual + sub_b : nullptr;
         const uint32_t W = wrapped_len(L, P.line_width);
         const uint32_t b = P.print_seq ? W + 1u : 0u;
@@ -191,6 +256,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 if (x < m) c = P.fastq ? '@' : '>';
                 else if (x == a - 1) c = '\n';
+                else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
                 else c = r.head[hoff + x - m];
             } else if (x < a + b) {
                 uint32_t q = x - a;
@@ -204,8 +270,9 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                     }
                     if (nl) c = '\n';
                     else {
-                        c = rseq[P.reverse ? L - 1 - q : q];
-                        if (P.use_lut) c = P.lut[c];
+                        const uint32_t bi = sub_b + (reverse ? L - 1 - q : q);
+                        c = TW ? sp[bi + bi / TW] : sp[bi];
+                        if (use_lut) c = lut[c];
                     }
                 }
             } else {
@@ -215,18 +282,18 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                     if (q == 1) { o[x] = '\n'; continue; }
                     q -= 2;
                 }
-                c = q == L ? (uint8_t)'\n' : rqual[P.reverse ? L - 1 - q : q];
+                c = q == L ? (uint8_t)'\n' : rqual[reverse ? L - 1 - q : q];
             }
             o[x] = c;
         }
         return;
     }
-    // sequential path: gap removal and / or a multi-line FASTA source
+    // sequential path: gap removal and / or a multi-line FASTA source without a text view
     if (gl != 0) return;
     uint32_t x = 0;
     if (P.print_name) {
         if (P.print_seq) o[x++] = P.fastq ? '@' : '>';
-        for (uint32_t k = 0; k < hl; ++k) o[x++] = r.head[hoff + k];
+        for (uint32_t k = 0; k < hl; ++k) o[x++] = (suffix && k >= id_len) ? suffix[k - id_len] : r.head[hoff + k];
         o[x++] = '\n';
     }
     const uint32_t R = r.region;
@@ -234,14 +301,14 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         uint32_t col = 0, base_i = 0;
         bool first = true;
         for (uint32_t k = 0; k < R; ++k) {
-            const uint8_t c0 = r.seq[P.reverse ? R - 1 - k : k];
+            const uint8_t c0 = r.seq[reverse ? R - 1 - k : k];
             if (c0 == '\n' && !P.fastq) continue;
-            const uint32_t bi = P.reverse ? r.seq_len - 1 - base_i : base_i;  // index in the forward sequence
+            const uint32_t bi = reverse ? r.seq_len - 1 - base_i : base_i;  // index in the forward sequence
             ++base_i;
             if (bi < sub_b || bi >= sub_e) continue;
             if (P.remove_gaps && in_set(P.gap_set, c0)) continue;
             if (P.line_width > 0 && !first && col == (uint32_t)P.line_width) { o[x++] = '\n'; col = 0; }
-            o[x++] = P.use_lut ? P.lut[c0] : c0;
+            o[x++] = use_lut ? lut[c0] : c0;
             ++col;
             first = false;
         }
@@ -251,7 +318,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         if (!P.qual_only) { o[x++] = '+'; o[x++] = '\n'; }
         const uint32_t L = r.seq_len;
         for (uint32_t k = 0; k < L; ++k) {
-            const uint32_t j = P.reverse ? L - 1 - k : k;
+            const uint32_t j = reverse ? L - 1 - k : k;
             if (j < sub_b || j >= sub_e) continue;
             if (P.remove_gaps && in_set(P.gap_set, r.seq[j])) continue;
             o[x++] = r.qual[j];

@@ -28,6 +28,25 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     int region_on, region_start, region_end; // Seq.SubSeq(start, end) applied to seq and qual (subseq -r)
     const uint8_t* lut;                     // device, 256 bytes
     const double* qual_err;                 // device, 256 doubles: 10^(-(q-base)/10) indexed by the raw byte
+    // FASTA text view (text.cuh): random access into wrapped sequences; null = contiguous records only on the
+    // parallel path (others take the sequential per-record walk)
+    const uint32_t* text_w;
+    const uint64_t* lin_off;
+    const uint8_t* lin;
+    // subseq --gtf / --bed (bigseqkit-lib/subseq.go:319-526): the record's lower-cased ID selects ONE feature
+    // (the first of that name); region, strand and the new header come from it
+    int feat_on;
+    const uint64_t* fset_keys;              // open-addressing set of lower-cased names (fnv1a64), 0 = empty
+    const uint32_t* fset_idx;
+    uint64_t fset_mask;
+    const uint8_t* fname;                   // lower-cased names, for verification
+    const uint32_t* fname_off;
+    const int64_t* f_s;                     // flank-adjusted 1-based start / end, not yet clamped to the record
+    const int64_t* f_e;
+    const uint8_t* f_minus;                 // feature on the '-' strand: reverse complement (qualities reversed)
+    const uint8_t* fsuffix;                 // "_<start>-<end>:<strand><flank> <label>" appended to the ID
+    const uint32_t* fsuffix_off;
+    const uint8_t* comp;                    // complement map of the shard's alphabet
 };
 
 constexpr uint32_t ERR_INVALID_LETTER = 128u;

@@ -53,6 +53,9 @@ typedef struct {
     int UpStream, DownStream, OnlyFlank;
     const char* Gtf;
     const char* Bed;
+    const char* Chr;      /* newline-joined lists */
+    const char* Feature;
+    const char* GtfTag;
 } orc_subseq_opts;
 
 typedef struct {
@@ -138,6 +141,22 @@ static SubseqOptions conv(const orc_subseq_opts& c) {
     o.UpStream = c.UpStream; o.DownStream = c.DownStream; o.OnlyFlank = c.OnlyFlank;
     if (c.Gtf) o.Gtf = c.Gtf;
     if (c.Bed) o.Bed = c.Bed;
+    auto split = [](const char* s) {
+        std::vector<std::string> v;
+        if (!s || !*s) return v;
+        std::string t = s;
+        size_t i = 0;
+        for (;;) {
+            size_t j = t.find('\n', i);
+            if (j == std::string::npos) { v.push_back(t.substr(i)); break; }
+            v.push_back(t.substr(i, j - i));
+            i = j + 1;
+        }
+        return v;
+    };
+    o.Chr = split(c.Chr);
+    o.Feature = split(c.Feature);
+    if (c.GtfTag) o.GtfTag = c.GtfTag;
     return o;
 }
 

@@ -808,10 +808,111 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
 }
 
 // ---------------------------------------------------------------------------
-// SubseqTransform by region  bigseqkit-lib/subseq.go
+// SubseqTransform  bigseqkit-lib/subseq.go
+//   gtf.ReadFilteredFeatures [shenwei356/bio v0.7.0 featio/gtf, not in tree; PARITY.md GTF]
+//   ReadBedFilteredFeatures  subseq.go:242-310 (in tree)
 // ---------------------------------------------------------------------------
+struct FeatureRow {  // what subseqByGTFFile / subSeqByBEDFile use of a feature
+    std::string chr, type;
+    long start = 0, end = 0;  // 1-based, end included
+    std::string strand;       // "+", "-", "." ("." also when the column is absent)
+    std::string label;        // BED name column / value of the --gtf-tag attribute
+};
+
+static std::vector<std::string> split_tab(const std::string& line) {
+    std::vector<std::string> items;
+    size_t i = 0;
+    for (;;) {
+        size_t j = line.find('\t', i);
+        if (j == std::string::npos) { items.push_back(line.substr(i)); break; }
+        items.push_back(line.substr(i, j - i));
+        i = j + 1;
+    }
+    return items;
+}
+
+static bool go_atoi(const std::string& s, long* v) {
+    if (s.empty()) return false;
+    char* e = nullptr;
+    *v = strtol(s.c_str(), &e, 10);
+    return *e == 0 && !isspace((unsigned char)s[0]);
+}
+
+static std::vector<FeatureRow> read_bed(const std::string& file, const std::vector<std::string>& chrs) {
+    std::vector<FeatureRow> out;
+    for (std::string line : read_pattern_lines(file)) {  // lines with "\r\n" trimmed (subseq.go:251)
+        if (line.empty() || line[0] == '#' || (line.size() > 7 && line.compare(0, 7, "browser") == 0) ||
+            (line.size() > 5 && line.compare(0, 5, "track") == 0))
+            continue;
+        auto items = split_tab(line);
+        if (items.size() < 3) continue;
+        if (!chrs.empty() && std::find(chrs.begin(), chrs.end(), items[0]) == chrs.end()) continue;
+        FeatureRow f;
+        long st, en;
+        if (!go_atoi(items[1], &st)) throw Error(items[0] + ": bad start: " + items[1]);
+        if (!go_atoi(items[2], &en)) throw Error(items[0] + ": bad end: " + items[2]);
+        if (st >= en) throw Error(items[0] + ": start (" + std::to_string(st) + ") must be <= end (" + std::to_string(en) + ")");
+        f.chr = items[0];
+        f.start = st + 1;
+        f.end = en;
+        if (items.size() >= 4) f.label = items[3];
+        f.strand = ".";
+        if (items.size() >= 6) {
+            if (items[5] != "+" && items[5] != "-" && items[5] != ".") throw Error("bad strand: " + items[5]);
+            f.strand = items[5];
+        }
+        out.push_back(f);
+    }
+    return out;
+}
+
+static std::vector<FeatureRow> read_gtf(const std::string& file, const std::vector<std::string>& chrs,
+                                        const std::vector<std::string>& feats_lower, const std::string& tag) {
+    std::vector<FeatureRow> out;
+    for (std::string line : read_pattern_lines(file)) {
+        if (line.empty() || line[0] == '#') continue;
+        auto items = split_tab(line);
+        if (items.size() != 9) continue;
+        if (!chrs.empty() && std::find(chrs.begin(), chrs.end(), items[0]) == chrs.end()) continue;
+        if (!feats_lower.empty() && std::find(feats_lower.begin(), feats_lower.end(), lower(items[2])) == feats_lower.end()) continue;
+        FeatureRow f;
+        long st, en;
+        if (!go_atoi(items[3], &st)) throw Error(items[0] + ": bad start: " + items[3]);
+        if (!go_atoi(items[4], &en)) throw Error(items[0] + ": bad end: " + items[4]);
+        if (st > en) throw Error(items[0] + ": start (" + std::to_string(st) + ") must be < end (" + std::to_string(en) + ")");
+        if (items[6] != "+" && items[6] != "-" && items[6] != ".") throw Error("bad strand: " + items[6]);
+        f.chr = items[0];
+        f.type = items[2];
+        f.start = st;
+        f.end = en;
+        f.strand = items[6];
+        // attributes: `tag "value"; tag "value";`  -> first attribute named `tag`
+        const std::string& at = items[8];
+        size_t i = 0;
+        while (i < at.size()) {
+            size_t j = at.find(';', i);
+            if (j == std::string::npos) j = at.size();
+            std::string item = at.substr(i, j - i);
+            i = j + 1;
+            size_t a0 = item.find_first_not_of(' ');
+            if (a0 == std::string::npos) continue;
+            item = item.substr(a0);
+            size_t sp = item.find(' ');
+            if (sp == std::string::npos) continue;
+            std::string t = item.substr(0, sp), v = item.substr(sp + 1);
+            while (!v.empty() && v.back() == ' ') v.pop_back();
+            if (v.size() >= 2 && v.front() == '"' && v.back() == '"') v = v.substr(1, v.size() - 2);
+            if (t == tag) { f.label = v; break; }
+        }
+        out.push_back(f);
+    }
+    return out;
+}
+
 std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, const SubseqOptions& o) {
     Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    std::vector<std::string> feats_lower;
+    for (auto& f : o.Feature) feats_lower.push_back(lower(f));
     if (o.OnlyFlank) {  // subseq.go:63-71
         if (o.UpStream > 0 && o.DownStream > 0)
             throw Error("when flag -f (--only-flank) given, only one of flags -u (--up-stream) and -d (--down-stream) is allowed");
@@ -819,12 +920,17 @@ std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, 
             throw Error("when flag -f (--only-flank) given, one of flags -u (--up-stream) and -d (--down-stream) should be given");
     }
     int start = 0, end = 0;
+    std::vector<FeatureRow> features;
+    const bool byFeature = o.Region.empty();
     if (!o.Region.empty()) {
         if (o.UpStream > 0 || o.DownStream > 0 || o.OnlyFlank)
             throw Error("when flag -r (--region) given, any of flags -u (--up-stream), -d (--down-stream) and -f (--only-flank) is not allowed");
         parse_region(o.Region, "subseq", &start, &end);
-    } else if (!o.Gtf.empty() || !o.Bed.empty()) {
-        throw Error("oracle: subseq --gtf/--bed is not restated");
+    } else if (!o.Gtf.empty()) {
+        features = read_gtf(o.Gtf, o.Chr, feats_lower, o.GtfTag);
+    } else if (!o.Bed.empty()) {
+        if (!o.Feature.empty()) throw Error("when given flag -b (--bed), flag -f (--feature) is not allowed");
+        features = read_bed(o.Bed, o.Chr);
     } else {
         throw Error("one of the options needed: -r/--region, --bed, --gtf");
     }
@@ -834,12 +940,61 @@ std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, 
     while (rd.Read()) {
         Record& r = rd.rec;
         if (rd.IsFastq) lineWidth = 0;
-        size_t b, e;
-        sub_location(r.seq.size(), start, end, &b, &e);
-        r.seq = r.seq.substr(b, e - b);
-        if (!r.qual.empty()) r.qual = r.qual.substr(b, e - b);
-        std::string bb = record_format(r, rd.IsFastq, lineWidth);
-        bb.pop_back();  // PARITY.md Q6: no blank line between records
+        if (!byFeature) {
+            size_t b, e;
+            sub_location(r.seq.size(), start, end, &b, &e);
+            r.seq = r.seq.substr(b, e - b);
+            if (!r.qual.empty()) r.qual = r.qual.substr(b, e - b);
+            std::string bb = record_format(r, rd.IsFastq, lineWidth);
+            bb.pop_back();  // PARITY.md Q6: no blank line between records
+            result.push_back(bb);
+            continue;
+        }
+        // subseq.go:319-526: the FIRST feature of the record's (lower-cased) ID, then return (Q7 as written);
+        // "first" = file order (the Go map over feature types has no order; PARITY.md GTF)
+        const std::string seqname = lower(r.id);
+        const FeatureRow* f = nullptr;
+        for (auto& cand : features)
+            if (lower(cand.chr) == seqname) { f = &cand; break; }
+        if (!f) continue;
+        long s = f->start, e = f->end;
+        const long L = (long)r.seq.size();
+        const bool minus = f->strand == "-";
+        if (minus) {
+            if (o.OnlyFlank) {
+                if (o.UpStream > 0) { s = f->end + 1; e = f->end + o.UpStream; }
+                else { s = f->start - o.DownStream; e = f->start - 1; }
+            } else { s = f->start - o.DownStream; e = f->end + o.UpStream; }
+        } else {
+            if (o.OnlyFlank) {
+                if (o.UpStream > 0) { s = f->start - o.UpStream; e = f->start - 1; }
+                else { s = e + 1; e = e + o.DownStream; }
+            } else { s = f->start - o.UpStream; e = f->end + o.DownStream; }
+        }
+        if (s < 1) s = 1;
+        if (e > L) e = L;
+        size_t b0 = 0, e0 = 0;
+        if (e >= 1) sub_location(r.seq.size(), (int)s, (int)e, &b0, &e0);  // e < 1: empty (PARITY.md SUB0)
+        Record nr;
+        nr.seq = r.seq.substr(b0, e0 - b0);
+        if (!r.qual.empty()) nr.qual = r.qual.substr(b0, e0 - b0);
+        if (minus) {  // RevComInplace reverses the qualities too
+            nr.seq = rev_com(nr.seq, rd.GetAlphabet());
+            std::reverse(nr.qual.begin(), nr.qual.end());
+        }
+        std::string flank;
+        if (o.UpStream > 0) {
+            if (o.OnlyFlank) flank = "_usf:" + std::to_string(o.UpStream);
+            else if (o.DownStream > 0) flank = "_us:" + std::to_string(o.UpStream) + "_ds:" + std::to_string(o.DownStream);
+            else flank = "_us:" + std::to_string(o.UpStream);
+        } else if (o.DownStream > 0) {
+            if (o.OnlyFlank) flank = "_dsf:" + std::to_string(o.DownStream);
+            else flank = "_ds:" + std::to_string(o.DownStream);
+        }
+        nr.name = r.id + "_" + std::to_string(f->start) + "-" + std::to_string(f->end) + ":" + f->strand + flank + " " + f->label;
+        nr.id = nr.name;
+        std::string bb = record_format(nr, rd.IsFastq, lineWidth);
+        bb.pop_back();  // Q6
         result.push_back(bb);
     }
     return result;

@@ -177,8 +177,10 @@ struct SubseqOptions {  // bigseqkit/subseq.go:9-35 (region mode)
     int UpStream = 0, DownStream = 0;
     bool OnlyFlank = false;
     std::string Gtf, Bed;
+    std::vector<std::string> Chr, Feature;
+    std::string GtfTag;  // library default "" (bigseqkit/subseq.go:33); the CLI passes gene_id
 };
-// SubseqTransform.Before + Call (by region)  bigseqkit-lib/subseq.go:36-165, 167-225, 314-317
+// SubseqTransform.Before + Call (-r, --gtf, --bed)  bigseqkit-lib/subseq.go:36-165, 167-225, 242-526
 std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, const SubseqOptions& o);
 
 struct TranslateOptions {  // bigseqkit/translate.go:9-35

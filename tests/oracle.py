@@ -35,7 +35,8 @@ class GrepOpts(C.Structure):
 
 class SubseqOpts(C.Structure):
     _fields_ = [("Config", KitConfig), ("Region", C.c_char_p), ("UpStream", C.c_int), ("DownStream", C.c_int),
-                ("OnlyFlank", C.c_int), ("Gtf", C.c_char_p), ("Bed", C.c_char_p)]
+                ("OnlyFlank", C.c_int), ("Gtf", C.c_char_p), ("Bed", C.c_char_p), ("Chr", C.c_char_p),
+                ("Feature", C.c_char_p), ("GtfTag", C.c_char_p)]
 
 
 class LocateOpts(C.Structure):
@@ -128,7 +129,9 @@ def subseq_opts(opts_json):
     d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
     g = lambda k, dv: dv if d.get(k) is None else d[k]
     return SubseqOpts(_cfg(d), g("Region", "").encode(), g("UpStream", 0), g("DownStream", 0),
-                      int(bool(g("OnlyFlank", False))), g("Gtf", "").encode(), g("Bed", "").encode())
+                      int(bool(g("OnlyFlank", False))), g("Gtf", "").encode(), g("Bed", "").encode(),
+                      "\n".join(g("Chr", [])).encode(), "\n".join(g("Feature", [])).encode(),
+                      g("GtfTag", "").encode())
 
 
 def subseq(data, fastq, opts_json="{}", nparts=1):

@@ -305,3 +305,107 @@ def test_grep_general_option_errors():
         with pytest.raises(oracle.OracleError) as oe:
             oracle.grep(b"@a\nA\n+\nI\n", True, json.dumps(opts))
         assert msg in str(oe.value)
+
+
+# ---------------------------------------------------------------- subseq --bed / --gtf
+def check_subseq(data, fastq, opts):
+    want = oracle.subseq(data, fastq, json.dumps(opts))
+    got = bsk.Subseq(frame(data, fastq), _Opts(opts))
+    assert got == want, (opts, got[:300], want[:300])
+    return got
+
+
+def feature_files(tmp_path, rng, nrec, prefix):
+    bed, gtf = [], []
+    bed.append("track name=test\n")
+    bed.append("#comment\n")
+    for k in rng.sample(range(nrec + 20), nrec // 2):
+        for _ in range(rng.randint(1, 2)):   # a second feature of the same name is never used
+            st = rng.randint(0, 300)
+            en = st + rng.randint(1, 200)
+            strand = rng.choice("+-.")
+            name = f"{prefix}{k}" if rng.random() < 0.7 else f"{prefix.upper()}{k}"
+            cols = [name, str(st), str(en)]
+            if rng.random() < 0.8:
+                cols += [f"gene{k}", "0", strand]
+            elif rng.random() < 0.5:
+                cols += [f"only name {k}"]
+            bed.append("\t".join(cols) + "\n")
+            typ = rng.choice(["gene", "CDS", "exon"])
+            gtf.append(f'{name}\tsrc\t{typ}\t{st + 1}\t{en}\t.\t{strand}\t.\tgene_id "G{k}"; transcript_id "T{k}.1";\n')
+    b, g = tmp_path / "f.bed", tmp_path / "f.gtf"
+    b.write_text("".join(bed))
+    g.write_text("#!gtf\n" + "".join(gtf))
+    return str(b), str(g)
+
+
+FEATURE_FLAGS = [{}, {"UpStream": 5}, {"DownStream": 7}, {"UpStream": 3, "DownStream": 4},
+                 {"UpStream": 6, "OnlyFlank": True}, {"DownStream": 6, "OnlyFlank": True}]
+
+
+@pytest.mark.parametrize("width", [60, 0, 17, -1])
+@pytest.mark.parametrize("fi", range(len(FEATURE_FLAGS)))
+def test_subseq_bed_and_gtf_fasta(tmp_path, fi, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(2100 + fi)
+    recs = []
+    for k in range(150):
+        L = rng.randint(0, 600)
+        s = "".join(rng.choice("ACGTacgtNRY") for _ in range(L))
+        if width < 0:
+            lines, j = [], 0
+            while j < L:
+                w = rng.randint(1, 40)
+                lines.append(s[j:j + w])
+                j += w
+            recs.append(f">s{k} desc\n" + "".join(l + "\n" for l in lines))
+        else:
+            w = width if width else max(1, L)
+            recs.append(f">s{k} desc\n" + "".join(s[j:j + w] + "\n" for j in range(0, L, w)))
+    data = "".join(recs).encode()
+    bed, gtf = feature_files(tmp_path, rng, 150, "s")
+    flags = FEATURE_FLAGS[fi]
+    got = check_subseq(data, False, dict(flags, Bed=bed))
+    assert got.count(b">") > 30
+    check_subseq(data, False, dict(flags, Gtf=gtf, GtfTag="gene_id"))
+    check_subseq(data, False, dict(flags, Gtf=gtf, GtfTag="transcript_id", Feature=["cds", "Exon"]))
+    check_subseq(data, False, dict(flags, Bed=bed, Chr=["s3", "s10", "S11", "s12"]))
+    check_subseq(data, False, dict(flags, Gtf=gtf, Config={"LineWidth": 0}))
+
+
+@pytest.mark.parametrize("fi", range(len(FEATURE_FLAGS)))
+def test_subseq_bed_and_gtf_fastq(tmp_path, fi):
+    rng = random.Random(2200 + fi)
+    data = seqgen.random_fastq(rng, 300, 0, 400, alphabet="ACGTN")
+    bed, gtf = feature_files(tmp_path, rng, 300, "r")
+    got = check_subseq(data, True, dict(FEATURE_FLAGS[fi], Bed=bed))
+    assert got.count(b"\n+\n") > 50
+    check_subseq(data, True, dict(FEATURE_FLAGS[fi], Gtf=gtf, GtfTag="gene_id"))
+
+
+def test_subseq_feature_edge_cases(tmp_path):
+    fa = b">chr1 d\nAAAATTTTGGAAAACCCC\n>Chr2\nACGTTGCAAGCT\n>chr3\nACGT\n>chr4\n\n"
+    bed = tmp_path / "a.bed"
+    bed.write_text("browser position\nchr1\t0\t8\tfirst\t0\t+\nchr1\t3\t8\tnever\t0\t-\nCHR2\t100\t105\tbeyond\nchr3\t1\t3\nchr4\t0\t5\tx\t0\t-\n"
+                   "chr9\t1\t3\nshort\t1\n")
+    got = check_subseq(fa, False, {"Bed": str(bed)})
+    assert got.startswith(b">chr1_1-8:+ first\nAAAATTTT\n") and b"never" not in got
+    assert b">Chr2_101-105:. beyond\n\n" in got                                  # feature past the end: empty sequence
+    check_subseq(fa, False, {"Bed": str(bed), "UpStream": 4, "OnlyFlank": True})   # flank of a feature at position 1 is empty
+    check_subseq(fa, False, {"Bed": str(bed), "DownStream": 50})
+    empty = tmp_path / "none.bed"
+    empty.write_text("#nothing\n")
+    assert check_subseq(fa, False, {"Bed": str(empty)}) == b""
+    for text, msg in [("chr1\tx\t5\n", "chr1: bad start: x"), ("chr1\t5\t5\n", "chr1: start (5) must be <= end (5)"),
+                      ("chr1\t1\t5\tn\t0\t*\n", "bad strand: *")]:
+        bad = tmp_path / "bad.bed"
+        bad.write_text(text)
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("SubseqTransform", json.dumps({"Bed": str(bad)}), -1)
+        assert msg in str(e.value)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.subseq(fa, False, json.dumps({"Bed": str(bad)}))
+        assert msg in str(oe.value)
+    with pytest.raises(bsk.BskError) as e:
+        bsk.Operator("SubseqTransform", json.dumps({"Bed": str(bed), "Feature": ["gene"]}), -1)
+    assert "when given flag -b (--bed), flag -f (--feature) is not allowed" in str(e.value)
