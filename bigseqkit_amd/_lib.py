@@ -93,6 +93,7 @@ SIGNATURES = {
     "bsk_locate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_translate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_rmdup_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
+    "bsk_rmdup_finish": (_i, [_vp]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),
     "bsk_synth_device": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz, _i, _vp]),

@@ -166,7 +166,7 @@ def StatsString(name, format, input, o=None, device=0):
         return buf.value.decode()
 
 
-def _run_records(op_name, run_fn, input, o, device=0, stream=None):
+def _run_records(op_name, run_fn, input, o, device=0, stream=None, finish=None):
     """MapPartitions(libSource(op_name)) over the shards of `input`: the concatenated
     FileStore bytes (element + newline per output record) and the number of elements."""
     chunks, nrec = [], 0
@@ -178,6 +178,8 @@ def _run_records(op_name, run_fn, input, o, device=0, stream=None):
             check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
             chunks.append(buf.raw[:out.len])
             nrec += out.records
+        if finish is not None:  # After() with an error return
+            check(finish(op.ctx), op.ctx)
     return b"".join(chunks), nrec
 
 
@@ -223,7 +225,8 @@ def Translate(input, o=None, device=0):
 
 def RmDup(input, o=None, device=0):
     """bigseqkit/rmdup.go:70-108 (duplicates are global: the input must be one shard per rank)"""
-    return _run_records("RmDup", lib.bsk_rmdup_run, input, o or SeqKitRmDupOptions(), device)[0]
+    return _run_records("RmDup", lib.bsk_rmdup_run, input, o or SeqKitRmDupOptions(), device,
+                        finish=lib.bsk_rmdup_finish)[0]
 
 
 def build_index(input, device=0):

@@ -197,8 +197,15 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
     return BSK_OK;
 }
 
+int bsk_rmdup_finish(bsk_ctx* c) {
+    if (!c) return BSK_ERR_INVALID_ARG;
+    if (c->op != bsk::Op::RmDup) return BSK_OK;
+    return bsk::rmdup_finish(c);
+}
+
 void bsk_destroy(bsk_ctx* c) {
     if (!c) return;
+    if (c->op == bsk::Op::RmDup) bsk::rmdup_finish(c);
     if (c->device >= 0) {
         hipSetDevice(c->device);
         hipDeviceSynchronize();

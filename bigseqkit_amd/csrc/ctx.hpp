@@ -71,6 +71,10 @@ struct bsk_ctx {
     uint64_t keys_cap = 0;
     uint64_t* d_table = nullptr;  // table_keys[cap] ++ table_first[cap]
     uint64_t table_cap = 0;
+    // -d / -D: what RmDupCheck accumulates until After() (rmdup.go:100-104, 224-238)
+    std::string dup_seqs, dup_nums;
+    uint64_t removed = 0;
+    bool side_written = false;
     // grep / locate: patterns after Before() (CLI order, duplicates removed, lower-cased with -i)
     std::vector<std::string> patterns;
     uint8_t* d_pat = nullptr;

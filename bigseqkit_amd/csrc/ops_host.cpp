@@ -1,6 +1,8 @@
 // Host side of the record-table operators: index construction and `seq`
 // (SeqTransform, /root/reference/bigseqkit-lib/seq.go).  C-ABI in include/bsk.h.
 #include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
+#include <cerrno>
 
 #include <algorithm>
 #include <cctype>
@@ -8,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -1303,8 +1306,39 @@ void validate_rmdup_opts(bsk_ctx* c) {
         throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
     if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :83-85
         throw OptError("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
-    if (!o.s("DupSeqsFile").empty() || !o.s("DupNumFile").empty())
-        throw OptError("libbsk: rmdup -d / -D side files are not supported by the HIP path yet");
+}
+
+// RmDupCheck.After (rmdup.go:244-279) with the swapped directory names of Q9 put right: the removed records go to
+// <DupSeqsFile>/<executor id>, the duplicate-number lines to <DupNumFile>/<executor id>; nothing is written when no
+// record was removed.  The executor id is the device index of the context.
+int rmdup_finish(bsk_ctx* c) {
+    if (c->side_written) return BSK_OK;
+    c->side_written = true;
+    if (c->removed == 0) return BSK_OK;
+    const Options& o = c->opts;
+    auto write = [&](const std::string& dir, const std::string& text) -> int {
+        if (dir.empty()) return BSK_OK;
+        std::string acc;
+        for (size_t i = 0; i <= dir.size(); ++i) {  // os.MkdirAll
+            if (i == dir.size() || dir[i] == '/') {
+                if (!acc.empty() && mkdir(acc.c_str(), 0777) != 0 && errno != EEXIST) {
+                    c->set_error("mkdir " + acc + ": " + strerror(errno));
+                    return BSK_ERR_INVALID_ARG;
+                }
+            }
+            if (i < dir.size()) acc.push_back(dir[i]);
+        }
+        const std::string path = dir + "/" + std::to_string(c->device < 0 ? 0 : c->device);
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) { c->set_error("open " + path + ": " + strerror(errno)); return BSK_ERR_INVALID_ARG; }
+        const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+        fclose(f);
+        if (!ok) { c->set_error("write " + path + " failed"); return BSK_ERR_INVALID_ARG; }
+        return BSK_OK;
+    };
+    int rc = write(o.s("DupSeqsFile"), c->dup_seqs);
+    if (rc != BSK_OK) return rc;
+    return write(o.s("DupNumFile"), c->dup_nums);
 }
 
 int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
@@ -1363,6 +1397,65 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
+    if (!o.s("DupSeqsFile").empty() || !o.s("DupNumFile").empty()) {
+        // side outputs, after the main emit on the same stream (d_out_len / d_out_off are free again)
+        c->removed += N - kept;
+        c->side_written = false;
+        uint8_t* d_has = nullptr;
+        uint32_t* d_row_len = nullptr;
+        uint64_t* d_row_off = nullptr;
+        uint8_t* d_side = nullptr;
+        auto cleanup = [&]() {
+            for (void* p : {(void*)d_has, (void*)d_row_len, (void*)d_row_off, (void*)d_side}) if (p) hipFree(p);
+        };
+        int src = BSK_OK;
+        do {
+            if (hipMalloc((void**)&d_has, N) != hipSuccess || hipMalloc((void**)&d_row_len, N * 4) != hipSuccess ||
+                hipMalloc((void**)&d_row_off, (N + 1) * 8) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (hipMemsetAsync(d_has, 0, N, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_rmdup_side_sizes(d_buf, c->table, P, c->d_keys, d_has, c->d_out_len, d_row_len, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_scan_u32(d_row_len, d_row_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            uint64_t dup_total = 0, row_total = 0;
+            hipMemcpyAsync(&dup_total, c->d_out_off + N, 8, hipMemcpyDeviceToHost, st);
+            hipMemcpyAsync(&row_total, d_row_off + N, 8, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (hipMalloc((void**)&d_side, std::max<uint64_t>(1, std::max(dup_total, row_total))) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (!o.s("DupSeqsFile").empty() && dup_total) {
+                if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, d_side, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                const size_t at = c->dup_seqs.size();
+                c->dup_seqs.resize(at + dup_total);
+                if (hipMemcpyAsync(&c->dup_seqs[at], d_side, dup_total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            }
+            if (!o.s("DupNumFile").empty() && row_total) {
+                if (launch_rmdup_rows(d_buf, c->table, P, c->d_keys, d_row_len, d_row_off, d_side, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                std::string rows(row_total, '\0');
+                if (hipMemcpyAsync(&rows[0], d_side, row_total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                // rows are in file order: group them by survivor, groups in the order of their survivor
+                std::vector<std::pair<uint64_t, std::string>> groups;  // survivor -> "id, id, ..."
+                std::unordered_map<uint64_t, size_t> where;
+                std::vector<uint32_t> count;
+                for (size_t i = 0; i < rows.size();) {
+                    const size_t e = rows.find('\n', i);
+                    const uint64_t g = strtoull(rows.substr(i, 20).c_str(), nullptr, 10);
+                    const std::string id = rows.substr(i + 21, e - i - 21);
+                    auto it = where.find(g);
+                    if (it == where.end()) { where[g] = groups.size(); groups.emplace_back(g, id); count.push_back(1); }
+                    else { groups[it->second].second += ", " + id; ++count[it->second]; }
+                    i = e + 1;
+                }
+                std::vector<size_t> order(groups.size());
+                for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return groups[a].first < groups[b].first; });
+                for (size_t k : order) c->dup_nums += std::to_string(count[k]) + "\t" + groups[k].second + "\n";
+            }
+        } while (false);
+        cleanup();
+        if (src != BSK_OK) { c->set_error("libbsk: rmdup side outputs (-d / -D) failed on the device"); return src; }
+    }
     return BSK_OK;
 }
 

@@ -16,6 +16,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
 void validate_translate_opts(bsk_ctx* c);
 int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_rmdup_opts(bsk_ctx* c);
+int rmdup_finish(bsk_ctx* c);
 int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_locate_opts(bsk_ctx* c);
 int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);

@@ -172,6 +172,63 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict
     out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
 }
 
+// ---------------------------------------------------------------------------
+// -d / -D side outputs (rmdup.go:179-186, 224-238).  keys[i] is replaced by the record's group = index of its
+// survivor; has_dup marks survivors that lost a duplicate.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rmdup_group(uint64_t n, uint64_t* __restrict__ keys,
+                                                     const uint64_t* __restrict__ table_keys,
+                                                     const uint64_t* __restrict__ table_first, uint64_t cap,
+                                                     uint8_t* __restrict__ has_dup) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = slot_key(keys[i]);
+    const uint64_t mask = cap - 1;
+    uint64_t s = slot_of(k, mask);
+    while (table_keys[s] != k) s = (s + 1) & mask;
+    const uint64_t first = table_first[s];
+    keys[i] = first;
+    if (first != i) has_dup[first] = 1;
+}
+
+// dup_len[i]: Format() bytes of a removed record, else 0;  row_len[i]: bytes of "<20-digit group>\t<ID>\n" for every
+// member of a group of two or more, else 0
+__global__ __launch_bounds__(256) void k_rmdup_side_sizes(const uint8_t* __restrict__ buf, RecordTable t, RmDupParams P,
+                                                          const uint64_t* __restrict__ group,
+                                                          const uint8_t* __restrict__ has_dup,
+                                                          uint32_t* __restrict__ dup_len, uint32_t* __restrict__ row_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const bool removed = group[i] != i;
+    const uint32_t lh = t.l_head[i];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    dup_len[i] = removed ? format_len(hl, t.l_seq[i], P.fastq, P.line_width) : 0u;
+    uint32_t r = 0;
+    if (removed || has_dup[i]) {
+        uint32_t off;
+        r = 20u + 1u + id_span_of(buf + t.start[i] + 1, hl, P.id_mode, &off) + 1u;
+    }
+    row_len[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_rows(const uint8_t* __restrict__ buf, RecordTable t, RmDupParams P,
+                                                    const uint64_t* __restrict__ group,
+                                                    const uint32_t* __restrict__ row_len,
+                                                    const uint64_t* __restrict__ row_off, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n || row_len[i] == 0) return;
+    uint8_t* o = out + row_off[i];
+    uint64_t g = group[i];
+    for (int d = 19; d >= 0; --d) { o[d] = (uint8_t)('0' + g % 10); g /= 10; }
+    o[20] = '\t';
+    const uint32_t lh = t.l_head[i];
+    uint32_t off;
+    const uint8_t* h = buf + t.start[i] + 1;
+    const uint32_t il = id_span_of(h, lh > 0 ? lh - 1 : 0, P.id_mode, &off);
+    for (uint32_t q = 0; q < il; ++q) o[21 + q] = h[off + q];
+    o[21 + il] = '\n';
+}
+
 }  // namespace
 
 hipError_t launch_rmdup_hash(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
@@ -197,6 +254,30 @@ hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const 
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     hipLaunchKernelGGL(k_rmdup_resolve, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys,
                        table_keys, table_first, cap, out_len, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
+                              uint64_t cap, uint8_t* has_dup, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, keys, table_keys,
+                       table_first, cap, has_dup);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_side_sizes(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
+                                   const uint8_t* has_dup, uint32_t* dup_len, uint32_t* row_len, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_side_sizes, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, P, group,
+                       has_dup, dup_len, row_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
+                             const uint32_t* row_len, const uint64_t* row_off, uint8_t* out, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_rows, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, P, group, row_len,
+                       row_off, out);
     return hipGetLastError();
 }
 

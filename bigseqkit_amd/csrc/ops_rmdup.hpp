@@ -28,4 +28,13 @@ hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const 
                                 const uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
                                 uint64_t cap, uint32_t* out_len, uint64_t* status, hipStream_t st);
 
+// -d / -D side outputs: keys[i] := survivor index of record i; sizes of the removed records' text and of the
+// "<20-digit group>\t<ID>\n" rows of all members of groups of two or more; the rows themselves
+hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
+                              uint64_t cap, uint8_t* has_dup, hipStream_t st);
+hipError_t launch_rmdup_side_sizes(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
+                                   const uint8_t* has_dup, uint32_t* dup_len, uint32_t* row_len, hipStream_t st);
+hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
+                             const uint32_t* row_len, const uint64_t* row_off, uint8_t* out, hipStream_t st);
+
 }  // namespace bsk

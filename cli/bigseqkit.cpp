@@ -395,6 +395,7 @@ int main(int argc, char** argv) {
         out_text.resize(at + out.len);
         if (bsk_out_to_host(ctx, &out, out_text.data() + at, out.len) != BSK_OK) die(bsk_last_error(ctx));
     }
+    if (use == "rmdup" && bsk_rmdup_finish(ctx) != BSK_OK) die(bsk_last_error(ctx));
     bsk_destroy(ctx);
     if (use == "stats") { std::cout << stats_head << stats_body; return 0; }
     if (grep_count) { std::cout << grep_total; return 0; }  // fmt.Print: no newline (cli/grep.go:14)

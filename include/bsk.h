@@ -182,6 +182,10 @@ int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, 
  * record of every subject (file order) survives. */
 int bsk_rmdup_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                   bsk_out* out);
+/* RmDupCheck.After() (bigseqkit-lib/rmdup.go:244-279): writes what the runs of this context accumulated for
+ * -d (--dup-seqs-file: text of the removed records) and -D (--dup-num-file: "<n>\t<id>, <id>, ...") to
+ * <file>/<device index>, nothing when no record was removed.  bsk_destroy() calls it if the caller did not. */
+int bsk_rmdup_finish(bsk_ctx* ctx);
 
 /* ---- synthetic inputs (bench + tests only) --------
  * Deterministic, counter-based: byte k of record i depends on (seed, i, k)

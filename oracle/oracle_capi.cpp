@@ -364,6 +364,21 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
 }
 
 // rmdup is global (GroupByKey): nparts is ignored, the whole input is one group space
+// which: 1 = text of the removed records (-d), 2 = duplicate-number lines (-D)
+int orc_rmdup_side(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, int which, uint8_t* out, size_t cap,
+                   size_t* nout, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        std::string seqs, nums;
+        rmdup_call_side(recs, conv(*o), &seqs, &nums);
+        const std::string& r = which == 1 ? seqs : nums;
+        *nout = r.size();
+        if (r.size() > cap) return 2;
+        memcpy(out, r.data(), r.size());
+        return 0;
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 int orc_rmdup(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, int nparts, uint8_t* out, size_t cap,
               size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
     (void)nparts;

@@ -1347,11 +1347,19 @@ uint64_t xxh64(const void* data, size_t len, uint64_t seed) {
 // hash group -- PARITY.md Q8).  Elements leave in first-occurrence file order.
 // ---------------------------------------------------------------------------
 std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, const RmDupOptions& o) {
+    return rmdup_call_side(all, o, nullptr, nullptr);
+}
+
+// dup_seqs: Format() text of every removed record (rmdup.go:181-183, written by After() :246-261);
+// dup_nums: "%d\t%s\n" = group size and ", "-joined IDs, survivor first (rmdup.go:229-236).  Removed records in file
+// order; groups in the file order of their survivor (the reference iterates Go maps; PARITY.md Q9/Q10)
+std::vector<std::string> rmdup_call_side(const std::vector<std::string_view>& all, const RmDupOptions& o,
+                                         std::string* dup_seqs, std::string* dup_nums) {
     Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
     if (o.BySeq && o.ByName) throw Error("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
     if (o.OnlyPositiveStrand && !o.BySeq) throw Error("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
     SeqParser rd(ab, &all, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
-    struct Item { std::string subject, text; uint64_t key; bool fastq; std::string seq; };
+    struct Item { std::string subject, text; uint64_t key; bool fastq; std::string seq, id; };
     std::vector<Item> items;
     int lineWidth = o.Config.LineWidth;
     while (rd.Read()) {
@@ -1363,6 +1371,7 @@ std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, co
         it.key = xxh64(it.subject.data(), it.subject.size(), 0);
         it.text = record_format(r, rd.IsFastq, lineWidth);
         it.seq = r.seq;
+        it.id = r.id;
         items.push_back(std::move(it));
     }
     const Alphabet fa = rd.GetAlphabet();
@@ -1371,22 +1380,34 @@ std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, co
     std::map<uint64_t, std::vector<size_t>> groups;
     for (size_t i = 0; i < items.size(); ++i) groups[items[i].key].push_back(i);
     std::vector<char> keep(items.size(), 0);
+    std::map<size_t, std::vector<size_t>> members;  // survivor index -> [survivor, removed...]
     for (auto& kv : groups) {
         auto& g = kv.second;
         if (g.size() == 1) { keep[g[0]] = 1; continue; }
-        std::map<std::string, int> counter;
+        std::map<std::string, size_t> counter;  // subject -> its survivor
         for (size_t i : g) {
             const std::string& subject = items[i].subject;
-            if (counter.count(subject)) { counter[subject]++; continue; }
+            if (counter.count(subject)) { members[counter[subject]].push_back(i); continue; }
             if (revcom) {
                 std::string rc = rev_com(items[i].seq, fa);
                 if (o.IgnoreCase) rc = lower(rc);
-                if (counter.count(rc)) { counter[rc]++; continue; }
+                if (counter.count(rc)) { members[counter[rc]].push_back(i); continue; }
             }
-            counter[subject]++;
+            counter[subject] = i;
+            members[i].push_back(i);
             keep[i] = 1;
         }
     }
+    if (dup_seqs)
+        for (size_t i = 0; i < items.size(); ++i)
+            if (!keep[i]) *dup_seqs += items[i].text;
+    if (dup_nums)
+        for (auto& kv : members) {
+            if (kv.second.size() < 2) continue;
+            std::string l;
+            for (size_t k = 0; k < kv.second.size(); ++k) l += (k ? ", " : "") + items[kv.second[k]].id;
+            *dup_nums += std::to_string(kv.second.size()) + "\t" + l + "\n";
+        }
     std::vector<std::string> result;
     for (size_t i = 0; i < items.size(); ++i)
         if (keep[i]) { std::string t = items[i].text; t.pop_back(); result.push_back(t); }

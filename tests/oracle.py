@@ -195,6 +195,18 @@ def rmdup(data, fastq, opts_json="{}"):
     return _run_text(_lib.orc_rmdup, data, fastq, rmdup_opts(opts_json), 1)[0]
 
 
+def rmdup_side(data, fastq, opts_json="{}", which=1):
+    """which=1: text of the removed records (-d); which=2: the duplicate-number lines (-D)"""
+    o = rmdup_opts(opts_json)
+    cap = 4 * len(data) + 4096
+    out, n, err = C.create_string_buffer(cap), C.c_size_t(), C.create_string_buffer(_ERR)
+    rc = _lib.orc_rmdup_side(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), which, out, C.c_size_t(cap),
+                             C.byref(n), err, _ERR)
+    if rc:
+        raise OracleError(err.value.decode() or "rmdup_side failed")
+    return out.raw[:n.value]
+
+
 _lib.orc_xxh64.restype = C.c_uint64
 
 

@@ -204,3 +204,33 @@ def test_rmdup_c5_synthetic_duplicates():
     assert again == got[:rb * 50000]
     head = bytes(t[:rb * 30000].cpu().numpy().tobytes())
     assert bsk.RmDup(frame(head, True), _Opts({"BySeq": True})) == oracle.rmdup(head, True, '{"BySeq": true}')
+
+
+@pytest.mark.parametrize("i", range(len(RMDUP_OPTS)))
+def test_rmdup_side_files(tmp_path, i, monkeypatch):
+    """-d / -D: text of the removed records and the duplicate-number lines (rmdup.go:179-186, 224-279)."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1800 + i)
+    data = dup_fastq(rng, 1200)
+    d, D = tmp_path / "dups" / "seqs", tmp_path / "nums"
+    opts = dict(RMDUP_OPTS[i], DupSeqsFile=str(d), DupNumFile=str(D))
+    check_rmdup(data, True, opts)
+    assert (d / "0").read_bytes() == oracle.rmdup_side(data, True, json.dumps(opts), 1)
+    nums = (D / "0").read_bytes()
+    assert nums == oracle.rmdup_side(data, True, json.dumps(opts), 2)
+    assert nums.count(b"\n") > 10 and all(int(l.split(b"\t")[0]) == l.count(b", ") + 1 for l in nums.splitlines())
+
+
+def test_rmdup_side_files_fasta_and_nothing_removed(tmp_path):
+    rng = random.Random(4)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 300))) for _ in range(60)]
+    fa = "".join(f">s{k} d\n" + "".join(s[j:j + 50] + "\n" for j in range(0, len(s), 50))
+                 for k, s in enumerate(seqs + seqs[:25] + seqs[:5])).encode()
+    d = tmp_path / "d"
+    opts = {"BySeq": True, "DupSeqsFile": str(d), "Config": {"LineWidth": 70}}
+    check_rmdup(fa, False, opts)
+    assert (d / "0").read_bytes() == oracle.rmdup_side(fa, False, json.dumps(opts), 1)
+    uniq = "".join(f">u{k}\n{s}\n" for k, s in enumerate(seqs)).encode()
+    e = tmp_path / "e"
+    check_rmdup(uniq, False, {"BySeq": True, "DupSeqsFile": str(e), "DupNumFile": str(e)})
+    assert not e.exists()        # After() writes nothing when no record was removed (rmdup.go:245)
