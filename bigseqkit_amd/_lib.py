@@ -94,6 +94,10 @@ SIGNATURES = {
     "bsk_translate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_rmdup_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_rmdup_finish": (_i, [_vp]),
+    "bsk_rmdup_dist_keys": (_i, [_vp, _vp, _sz, _i, _vp, _p(C.c_uint64)]),
+    "bsk_rmdup_dist_pack": (_i, [_vp, C.c_uint64, _i, _vp, _p(C.c_uint64), _vp]),
+    "bsk_rmdup_dist_resolve": (_i, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "bsk_rmdup_dist_emit": (_i, [_vp, _vp, _vp, C.c_uint64, _vp, _p(Out)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),
     "bsk_synth_device": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz, _i, _vp]),

@@ -222,6 +222,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_cls) hipFree(c->d_cls);
         if (c->d_feat) hipFree(c->d_feat);
+        if (c->d_keys2) hipFree(c->d_keys2);
+        if (c->d_own) hipFree(c->d_own);
         if (c->d_set_keys) hipFree(c->d_set_keys);
         if (c->d_set_idx) hipFree(c->d_set_idx);
         if (c->d_pat_off) hipFree(c->d_pat_off);
@@ -637,6 +639,47 @@ int bsk_rmdup_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
                   bsk_out* out) {
     (void)pid;
     return run_record_op(c, Op::RmDup, "RmDup", rmdup_run_device, shard, n, on_device, format, stream, out);
+}
+
+// ---- rmdup across ranks: the phases between which the caller runs the all-to-all exchanges (include/bsk.h)
+static int dist_enter(bsk_ctx* c, const char* what) {
+    if (!c) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null context");
+    if (c->op != Op::RmDup) return fail(c, BSK_ERR_INVALID_ARG, std::string("libbsk: ") + what + " needs a RmDup context");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context has no device (options only)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return BSK_OK;
+}
+
+int bsk_rmdup_dist_keys(bsk_ctx* c, const void* d_shard, size_t n, int format, void* stream, uint64_t* n_records) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_keys");
+    if (rc != BSK_OK) return rc;
+    rc = check_run_args(c, d_shard, n, format);
+    if (rc != BSK_OK) return rc;
+    if (!n_records) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_records");
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), (hipStream_t)stream));
+    return rmdup_dist_keys(c, (const uint8_t*)d_shard, n, format, (hipStream_t)stream, n_records);
+}
+
+int bsk_rmdup_dist_pack(bsk_ctx* c, uint64_t base_index, int world, void* d_send, uint64_t* counts, void* stream) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_pack");
+    if (rc != BSK_OK) return rc;
+    if (world < 1 || world > 64 || !counts || (!d_send && c->table.n)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad pack arguments");
+    return rmdup_dist_pack(c, base_index, world, (uint64_t*)d_send, counts, (hipStream_t)stream);
+}
+
+int bsk_rmdup_dist_resolve(bsk_ctx* c, const void* d_tuples, uint64_t m, void* d_keep, void* stream) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_resolve");
+    if (rc != BSK_OK) return rc;
+    if (m && (!d_tuples || !d_keep)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null tuples / keep");
+    return rmdup_dist_resolve(c, (const uint64_t*)d_tuples, m, (uint8_t*)d_keep, (hipStream_t)stream);
+}
+
+int bsk_rmdup_dist_emit(bsk_ctx* c, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
+                        bsk_out* out) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_emit");
+    if (rc != BSK_OK) return rc;
+    if (!out || (c->table.n && (!d_send || !d_reply))) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null send / reply / out");
+    return rmdup_dist_emit(c, (const uint64_t*)d_send, (const uint8_t*)d_reply, base_index, (hipStream_t)stream, out);
 }
 
 // ---------------------------------------------------------------------------

@@ -71,6 +71,14 @@ struct bsk_ctx {
     uint64_t keys_cap = 0;
     uint64_t* d_table = nullptr;  // table_keys[cap] ++ table_first[cap]
     uint64_t table_cap = 0;
+    // multi-GPU rmdup: second keys, owner-side table, the shard the keys phase indexed
+    uint64_t* d_keys2 = nullptr;
+    uint64_t keys2_cap = 0;
+    uint64_t* d_own = nullptr;   // table_keys[cap] ++ table_first[cap] ++ table_k2[cap]
+    uint64_t own_cap = 0;
+    const uint8_t* dist_buf = nullptr;
+    size_t dist_n = 0;
+    int dist_format = -1;
     // -d / -D: what RmDupCheck accumulates until After() (rmdup.go:100-104, 224-238)
     std::string dup_seqs, dup_nums;
     uint64_t removed = 0;

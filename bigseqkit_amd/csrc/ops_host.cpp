@@ -1459,6 +1459,119 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     return BSK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// rmdup across ranks.  One call sequence per rank, the caller runs the collectives in between:
+//   keys  -> [all-gather of record counts]      -> pack -> [all-to-all of tuples]
+//   resolve (owner side)                        -> [all-to-all of keep bytes, reversed]
+//   emit
+// The context keeps the record table of the shard between keys and emit.
+// ---------------------------------------------------------------------------
+static RmDupParams rmdup_params(bsk_ctx* c, bool fastq) {
+    const Options& o = c->opts;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.by_seq = o.b("BySeq");
+    P.by_name = o.b("ByName");
+    P.ignore_case = o.b("IgnoreCase");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    return P;
+}
+
+int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, uint64_t* n_records) {
+    if (!c->opts.s("DupSeqsFile").empty() || !c->opts.s("DupNumFile").empty()) {
+        c->set_error("libbsk: -d / -D side files are not available on the multi-GPU rmdup path");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    c->dist_buf = d_buf;
+    c->dist_n = n;
+    c->dist_format = format;
+    const uint64_t N = c->table.n;
+    *n_records = N;
+    uint64_t status = 0;
+    if (N == 0) {
+        HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        return kernel_error_to_status(c, status);
+    }
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_keys2, &c->keys2_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_rmdup_hash2(d_buf, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    return kernel_error_to_status(c, status);
+}
+
+int rmdup_dist_pack(bsk_ctx* c, uint64_t base, int world, uint64_t* d_send, uint64_t* counts, hipStream_t st) {
+    const uint64_t N = c->table.n;
+    for (int r = 0; r < world; ++r) counts[r] = 0;
+    if (N == 0) return BSK_OK;
+    int rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, 64 + 16, 16);  // [0..63] counts, then cursors
+    if (rc != BSK_OK) return rc;
+    uint64_t* d_counts = c->d_scan_tmp;
+    HIP_TRYX(c, hipMemsetAsync(d_counts, 0, 64 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_rmdup_count_owner(c->d_keys, N, (uint32_t)world, d_counts, st));
+    HIP_TRYX(c, hipMemcpyAsync(counts, d_counts, world * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    uint64_t cursor[64], acc = 0;
+    for (int r = 0; r < world; ++r) { cursor[r] = acc; acc += counts[r]; }
+    HIP_TRYX(c, hipMemcpyAsync(d_counts, cursor, world * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, launch_rmdup_pack(c->d_keys, c->d_keys2, N, base, (uint32_t)world, d_counts, d_send, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // cursor lives on the host stack
+    return BSK_OK;
+}
+
+int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t* d_keep, hipStream_t st) {
+    if (m == 0) return BSK_OK;
+    uint64_t cap = 1024;
+    while (cap < 2 * m) cap <<= 1;
+    int rc = grow(c, &c->d_own, &c->own_cap, 3 * cap);
+    if (rc != BSK_OK) return rc;
+    uint64_t *tk = c->d_own, *tf = c->d_own + cap, *t2 = c->d_own + 2 * cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(t2, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_rmdup_own(d_tuples, m, tk, tf, t2, cap, d_keep, c->d_status, st));
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_HASH_COLLISION) {
+        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    return BSK_OK;
+}
+
+int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, uint64_t base, hipStream_t st, bsk_out* out) {
+    const uint64_t N = c->table.n;
+    if (N == 0) return empty_result(c, out);
+    const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
+    int rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_rmdup_apply(c->table, rmdup_params(c, fastq), d_send, d_reply, base, c->d_out_len, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    SeqParams F = format_params(c, fastq);
+    if (!fastq) { F.text_w = c->d_text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
+    HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     out->d_data = nullptr;

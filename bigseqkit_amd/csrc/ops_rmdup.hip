@@ -76,12 +76,12 @@ __device__ __forceinline__ uint64_t word64(const Subject& s, uint32_t i) {
     return v;
 }
 
-__device__ uint64_t xxh64_subject(const Subject& s) {
+__device__ uint64_t xxh64_subject(const Subject& s, uint64_t seed = 0) {
     const uint32_t len = s.len;
     uint32_t p = 0;
     uint64_t h;
     if (len >= 32) {
-        uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0ull - P1;
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
         do {
             v1 = xround(v1, word64(s, p));
             v2 = xround(v2, word64(s, p + 8));
@@ -92,7 +92,7 @@ __device__ uint64_t xxh64_subject(const Subject& s) {
         h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
         h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
     } else {
-        h = P5;
+        h = seed + P5;
     }
     h += (uint64_t)len;
     while (p + 8 <= len) { h ^= xround(0, word64(s, p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
@@ -229,6 +229,106 @@ __global__ __launch_bounds__(256) void k_rmdup_rows(const uint8_t* __restrict__ 
     o[21 + il] = '\n';
 }
 
+// ---------------------------------------------------------------------------
+// multi-GPU rmdup: the reference's GroupByKey shuffles whole records (bigseqkit/rmdup.go:97);
+// here a record travels as the 24-byte tuple (XXH64 key, second XXH64 with another seed, global record index).
+//   k_rmdup_hash2   : both keys of every record of the shard
+//   k_rmdup_pack    : tuples bucketed by owner = key % world into the send buffer (wave-aggregated cursors)
+//   k_rmdup_own_*   : the owner keeps, per key, the LOWEST global index (first in file order) and checks that equal
+//                     keys carry equal second keys (else ERR_HASH_COLLISION); reply = one keep byte per tuple
+//   k_rmdup_apply   : the sender turns the reply into the per-record output sizes
+// ---------------------------------------------------------------------------
+constexpr uint64_t SEED2 = 0x9E3779B97F4A7C15ull;
+
+__global__ __launch_bounds__(256) void k_rmdup_hash2(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                     RmDupParams P, uint64_t* __restrict__ keys,
+                                                     uint64_t* __restrict__ keys2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const Subject s = subject_of(buf, t, tt, P, i);
+    keys[i] = xxh64_subject(s, 0);
+    keys2[i] = xxh64_subject(s, SEED2);
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_count_owner(const uint64_t* __restrict__ keys, uint64_t n, uint32_t world,
+                                                           unsigned long long* __restrict__ counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const uint32_t owner = live ? (uint32_t)(keys[i] % world) : world;
+    for (uint32_t o = 0; o < world; ++o) {
+        const uint64_t m = __ballot(owner == o);
+        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&counts[o], (unsigned long long)__popcll(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_pack(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys2,
+                                                    uint64_t n, uint64_t base, uint32_t world,
+                                                    unsigned long long* __restrict__ cursor, uint64_t* __restrict__ send) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const uint64_t k = live ? keys[i] : 0;
+    const uint32_t owner = live ? (uint32_t)(k % world) : world;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t o = 0; o < world; ++o) {
+        const uint64_t m = __ballot(owner == o);
+        if (!m) continue;
+        const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
+        unsigned long long at = 0;
+        if (lane == leader) at = atomicAdd(&cursor[o], (unsigned long long)__popcll(m));
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)at, (int)leader, 64);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(at >> 32), (int)leader, 64);
+        if (owner == o) {
+            const uint64_t pos = (((uint64_t)hi << 32) | lo) + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            send[3 * pos] = k;
+            send[3 * pos + 1] = keys2[i];
+            send[3 * pos + 2] = base + i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_own_insert(const uint64_t* __restrict__ tuples, uint64_t m,
+                                                          uint64_t* table_keys, uint64_t* table_first, uint64_t* table_k2,
+                                                          uint64_t cap, uint64_t* __restrict__ status) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const uint64_t k = slot_key(tuples[3 * p]), k2 = slot_key(tuples[3 * p + 1]);
+    const uint64_t mask = cap - 1;
+    uint64_t s = slot_of(k, mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&table_keys[s], 0ull, (unsigned long long)k);
+        if (old == 0ull || old == k) {
+            atomicMin((unsigned long long*)&table_first[s], (unsigned long long)tuples[3 * p + 2]);
+            const unsigned long long o2 = atomicCAS((unsigned long long*)&table_k2[s], 0ull, (unsigned long long)k2);
+            if (o2 != 0ull && o2 != k2) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_own_keep(const uint64_t* __restrict__ tuples, uint64_t m,
+                                                        const uint64_t* __restrict__ table_keys,
+                                                        const uint64_t* __restrict__ table_first, uint64_t cap,
+                                                        uint8_t* __restrict__ keep) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const uint64_t k = slot_key(tuples[3 * p]);
+    const uint64_t mask = cap - 1;
+    uint64_t s = slot_of(k, mask);
+    while (table_keys[s] != k) s = (s + 1) & mask;
+    keep[p] = table_first[s] == tuples[3 * p + 2] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_apply(RecordTable t, RmDupParams P, const uint64_t* __restrict__ send,
+                                                     const uint8_t* __restrict__ reply, uint64_t base,
+                                                     uint32_t* __restrict__ out_len) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= t.n) return;
+    const uint64_t i = send[3 * p + 2] - base;
+    const uint32_t lh = t.l_head[i];
+    out_len[i] = reply[p] ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
 }  // namespace
 
 hipError_t launch_rmdup_hash(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
@@ -278,6 +378,46 @@ hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmD
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_rmdup_rows, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, P, group, row_len,
                        row_off, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_hash2(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                              uint64_t* keys, uint64_t* keys2, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_rmdup_hash2, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys, keys2);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_count_owner(const uint64_t* keys, uint64_t n, uint32_t world, uint64_t* counts, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_count_owner, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, world,
+                       (unsigned long long*)counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_pack(const uint64_t* keys, const uint64_t* keys2, uint64_t n, uint64_t base, uint32_t world,
+                             uint64_t* cursor, uint64_t* send, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, keys2, n, base, world,
+                       (unsigned long long*)cursor, send);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_own(const uint64_t* tuples, uint64_t m, uint64_t* table_keys, uint64_t* table_first,
+                            uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    const dim3 g((unsigned)((m + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_rmdup_own_insert, g, b, 0, st, tuples, m, table_keys, table_first, table_k2, cap, status);
+    hipLaunchKernelGGL(k_rmdup_own_keep, g, b, 0, st, tuples, m, table_keys, table_first, cap, keep);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_apply(const RecordTable& t, const RmDupParams& P, const uint64_t* send, const uint8_t* reply,
+                              uint64_t base, uint32_t* out_len, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_apply, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, t, P, send, reply, base,
+                       out_len);
     return hipGetLastError();
 }
 

@@ -37,4 +37,16 @@ hipError_t launch_rmdup_side_sizes(const uint8_t* buf, const RecordTable& t, con
 hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
                              const uint32_t* row_len, const uint64_t* row_off, uint8_t* out, hipStream_t st);
 
+// multi-GPU rmdup: tuples (key, second key, global index) routed to owner = key % world (ops_rmdup.hip)
+hipError_t launch_rmdup_hash2(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                              uint64_t* keys, uint64_t* keys2, hipStream_t st);
+hipError_t launch_rmdup_count_owner(const uint64_t* keys, uint64_t n, uint32_t world, uint64_t* counts, hipStream_t st);
+hipError_t launch_rmdup_pack(const uint64_t* keys, const uint64_t* keys2, uint64_t n, uint64_t base, uint32_t world,
+                             uint64_t* cursor, uint64_t* send, hipStream_t st);
+// table_keys / table_k2 zeroed, table_first 0xFF-filled by the caller; keep[p] = tuple p is the first of its key
+hipError_t launch_rmdup_own(const uint64_t* tuples, uint64_t m, uint64_t* table_keys, uint64_t* table_first,
+                            uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st);
+hipError_t launch_rmdup_apply(const RecordTable& t, const RmDupParams& P, const uint64_t* send, const uint8_t* reply,
+                              uint64_t base, uint32_t* out_len, hipStream_t st);
+
 }  // namespace bsk

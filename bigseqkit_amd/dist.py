@@ -41,3 +41,84 @@ def all_reduce_count(count, device="cpu"):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+# ---------------------------------------------------------------------------
+# rmdup across ranks: duplicates are global, so this is the one command with a real exchange step.
+# The reference shuffles whole records (GroupByKey, bigseqkit/rmdup.go:97); here 24-byte tuples travel to
+# owner = key % world and one keep byte per tuple travels back (include/bsk.h, "rmdup across ranks").
+# ---------------------------------------------------------------------------
+class HipRmDupBackend:
+    """The four device phases of libbsk for one rank's HBM-resident shard (a torch uint8 CUDA tensor)."""
+
+    def __init__(self, opts_json, device=0):
+        from .api import Operator
+        self.op = Operator("RmDup", opts_json, device)
+        self.device = device
+        self.n = 0
+
+    def close(self):
+        self.op.close()
+
+    def keys(self, shard, fmt):
+        n = C.c_uint64()
+        self._keep = shard
+        check(lib.bsk_rmdup_dist_keys(self.op.ctx, C.c_void_p(shard.data_ptr()), shard.numel(), fmt, None, C.byref(n)),
+              self.op.ctx)
+        self.n = n.value
+        return self.n
+
+    def pack(self, base, world):
+        import torch
+        send = torch.empty((self.n, 3), dtype=torch.int64, device=self._keep.device)
+        counts = (C.c_uint64 * world)()
+        check(lib.bsk_rmdup_dist_pack(self.op.ctx, base, world, C.c_void_p(send.data_ptr()), counts, None), self.op.ctx)
+        return send, [int(x) for x in counts]
+
+    def resolve(self, tuples):
+        import torch
+        keep = torch.empty(tuples.shape[0], dtype=torch.uint8, device=tuples.device)
+        check(lib.bsk_rmdup_dist_resolve(self.op.ctx, C.c_void_p(tuples.data_ptr()), tuples.shape[0],
+                                         C.c_void_p(keep.data_ptr()), None), self.op.ctx)
+        return keep
+
+    def emit(self, send, reply, base):
+        from . import _lib
+        out = _lib.Out()
+        check(lib.bsk_rmdup_dist_emit(self.op.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(reply.data_ptr()), base, None,
+                                      C.byref(out)), self.op.ctx)
+        buf = C.create_string_buffer(max(1, out.len))
+        check(lib.bsk_out_to_host(self.op.ctx, C.byref(out), buf, out.len), self.op.ctx)
+        return buf.raw[:out.len]
+
+
+def rmdup_distributed(shard, fmt, backend, group=None):
+    """RmDup over the shards of all ranks of `group`; returns the survivors of THIS rank's shard (bytes, file
+    order), so that the concatenation over ranks equals the single-GPU output.  Collectives: one all_gather of
+    the record counts, one all_to_all of split sizes, one all_to_all of tuples, one all_to_all of keep bytes."""
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    n = backend.keys(shard, fmt)
+    dev = shard.device
+    if multi:
+        counts_all = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts_all, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+        base = int(sum(int(c.item()) for c in counts_all[:rank]))
+    else:
+        base = 0
+    send, in_splits = backend.pack(base, world)
+    if not multi:
+        return backend.emit(send, backend.resolve(send), base)
+    t_in = torch.tensor(in_splits, dtype=torch.int64, device=dev)
+    t_out = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(t_out, t_in, group=group)
+    out_splits = [int(x) for x in t_out.tolist()]
+    recv = torch.empty((sum(out_splits), 3), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+    keep = backend.resolve(recv)
+    reply = torch.empty(n, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(reply, keep, in_splits, out_splits, group=group)
+    return backend.emit(send, reply, base)

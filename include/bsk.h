@@ -187,6 +187,25 @@ int bsk_rmdup_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int 
  * <file>/<device index>, nothing when no record was removed.  bsk_destroy() calls it if the caller did not. */
 int bsk_rmdup_finish(bsk_ctx* ctx);
 
+/* ---- rmdup across ranks (one process per GPU).  Duplicates are global, so the reference shuffles whole records
+ * with GroupByKey (bigseqkit/rmdup.go:97).  Here a record travels as a 24-byte tuple
+ *     (XXH64 key, second XXH64 with another seed, global record index)
+ * to its owner rank = key % world; the owner keeps the lowest global index of every key (first in file order,
+ * PARITY.md Q10) and answers one keep byte per tuple; equal keys with different second keys raise
+ * BSK_ERR_UNSUPPORTED instead of a guess.  The caller runs the collectives between the phases
+ * (bigseqkit_amd/dist.py: all_gather of counts, all_to_all_single of tuples, all_to_all_single of keep bytes):
+ *   keys    : record table + both keys of the HBM-resident shard            -> *n_records
+ *   pack    : tuples bucketed by owner into d_send (u64[3 * n_records]), counts[world] on the host;
+ *             base_index = number of records on lower ranks
+ *   resolve : owner side, d_tuples = the m tuples received (u64[3 * m])       -> d_keep (u8[m], 1 = first of its key)
+ *   emit    : d_reply (u8[n_records]) = keep bytes in the order of d_send    -> survivors of this shard, file order
+ * keys ... emit must run on the same context without another run in between (it holds the record table). */
+int bsk_rmdup_dist_keys(bsk_ctx* ctx, const void* d_shard, size_t n, int format, void* stream, uint64_t* n_records);
+int bsk_rmdup_dist_pack(bsk_ctx* ctx, uint64_t base_index, int world, void* d_send, uint64_t* counts, void* stream);
+int bsk_rmdup_dist_resolve(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void* d_keep, void* stream);
+int bsk_rmdup_dist_emit(bsk_ctx* ctx, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
+                        bsk_out* out);
+
 /* ---- synthetic inputs (bench + tests only) --------
  * Deterministic, counter-based: byte k of record i depends on (seed, i, k)
  * only, so any shard can be produced on the host or directly in HBM. */

@@ -111,3 +111,49 @@ def test_shard_bounds_are_record_aligned_and_cover_the_file():
             if -3 not in whole:
                 acc.pop(-3, None)
             assert {k: v for k, v in acc.items() if v or k in whole} == whole
+
+
+# ---------------------------------------------------------------- rmdup: the one command with an exchange step
+def _rmdup_worker(rank, world, port, data, opts, q):
+    import torch
+    import torch.distributed as dist
+    from rmdup_cpu_backend import OracleRmDupBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = bdist.shard_bounds(data, world, bsk.FORMAT_FASTQ)[rank]
+        shard = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.empty(0, dtype=torch.uint8)
+        out = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("opts", [{"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}])
+def test_two_ranks_gloo_rmdup_exchange(opts):
+    """all_gather(counts) + all_to_all(tuples) + all_to_all(keep bytes): the concatenated per-rank survivors equal the
+    single-shard result, i.e. the first occurrence in FILE order survives even when it lives on the other rank."""
+    import torch.multiprocessing as mp
+    rng = random.Random(77)
+    seqs, recs = [], []
+    for i in range(600):
+        s = seqs[rng.randrange(len(seqs))] if (i > 5 and rng.random() < 0.35) else "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 60)))
+        if rng.random() < 0.2:
+            s = s.lower()
+        seqs.append(s)
+        recs.append(f"@r{i % 400} c\n{s}\n+\n{'I' * len(s)}\n")
+    data = "".join(recs).encode()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rmdup_worker, args=(r, 2, port, data, opts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = oracle.rmdup(data, True, json.dumps(opts))
+    assert outs[0] + outs[1] == want
+    assert 0 < len(want) < len(data)

@@ -234,3 +234,79 @@ def test_rmdup_side_files_fasta_and_nothing_removed(tmp_path):
     e = tmp_path / "e"
     check_rmdup(uniq, False, {"BySeq": True, "DupSeqsFile": str(e), "DupNumFile": str(e)})
     assert not e.exists()        # After() writes nothing when no record was removed (rmdup.go:245)
+
+
+# ---------------------------------------------------------------- rmdup across ranks (device phases)
+def _virtual_ranks(data, fastq, opts, world):
+    """Drive `world` HipRmDupBackend contexts in ONE process on one GPU, doing by hand the exchanges that
+    dist.rmdup_distributed does with all_gather / all_to_all_single (the collectives themselves are covered by the
+    world_size-2 gloo test).  Returns the concatenated survivors."""
+    import torch
+    from bigseqkit_amd import dist as bdist
+    fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+    bounds = bdist.shard_bounds(data, world, fmt)
+    shards = [dev(data[lo:hi]) for lo, hi in bounds]
+    backs = [bdist.HipRmDupBackend(json.dumps(opts), 0) for _ in range(world)]
+    try:
+        ns = [b.keys(s, fmt) for b, s in zip(backs, shards)]
+        bases = [sum(ns[:r]) for r in range(world)]
+        packed = [b.pack(bases[r], world) for r, b in enumerate(backs)]
+        assert all(sum(c) == n for (_, c), n in zip(packed, ns))
+        # tuples for owner o: the o-th bucket of every sender, in sender order
+        def bucket(r, o):
+            send, counts = packed[r]
+            a = sum(counts[:o])
+            return send[a:a + counts[o]]
+        keeps = []
+        for o in range(world):
+            recv = torch.cat([bucket(r, o) for r in range(world)]) if world > 1 else packed[0][0]
+            keeps.append(backs[o].resolve(recv.contiguous()))
+        outs = []
+        for r in range(world):
+            parts = []
+            for o in range(world):
+                a = sum(packed[s][1][o] for s in range(r))
+                parts.append(keeps[o][a:a + packed[r][1][o]])
+            reply = torch.cat(parts).contiguous() if parts else torch.empty(0, dtype=torch.uint8, device="cuda")
+            outs.append(backs[r].emit(packed[r][0], reply, bases[r]))
+        return b"".join(outs)
+    finally:
+        for b in backs:
+            b.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("i", [0, 1, 3, 5])
+def test_rmdup_across_virtual_ranks_fastq(i, world, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(2800 + i)
+    data = dup_fastq(rng, 2000)
+    want = oracle.rmdup(data, True, json.dumps(RMDUP_OPTS[i]))
+    assert _virtual_ranks(data, True, RMDUP_OPTS[i], world) == want
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_rmdup_across_virtual_ranks_fasta(world):
+    rng = random.Random(41)
+    seqs, recs = [], []
+    for k in range(500):
+        s = seqs[rng.randrange(len(seqs))] if (k > 3 and rng.random() < 0.4) else \
+            "".join(rng.choice("ACGTacgt") for _ in range(rng.randint(0, 300)))
+        seqs.append(s)
+        w = rng.choice([60, 60, 60, 17, max(1, len(s))])
+        recs.append(f">s{k}\n" + "".join(s[j:j + w] + "\n" for j in range(0, len(s), w)))
+    data = "".join(recs).encode()
+    for o in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}):
+        assert _virtual_ranks(data, False, o, world) == oracle.rmdup(data, False, json.dumps(o))
+
+
+def test_rmdup_distributed_single_rank_equals_rmdup():
+    from bigseqkit_amd import dist as bdist
+    rng = random.Random(9)
+    data = dup_fastq(rng, 3000)
+    b = bdist.HipRmDupBackend(json.dumps({"BySeq": True}), 0)
+    try:
+        got = bdist.rmdup_distributed(dev(data), bsk.FORMAT_FASTQ, b)
+    finally:
+        b.close()
+    assert got == bsk.RmDup(frame(data, True), _Opts({"BySeq": True})) == oracle.rmdup(data, True, '{"BySeq": true}')
