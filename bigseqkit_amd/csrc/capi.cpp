@@ -222,6 +222,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_cls) hipFree(c->d_cls);
         if (c->d_feat) hipFree(c->d_feat);
+        if (c->d_hit_list) hipFree(c->d_hit_list);
         if (c->d_keys2) hipFree(c->d_keys2);
         if (c->d_own) hipFree(c->d_own);
         if (c->d_set_keys) hipFree(c->d_set_keys);

@@ -112,6 +112,8 @@ struct bsk_ctx {
     uint64_t feat_cap = 0;
     uint64_t feat_off[9] = {0};            // byte offsets of the arrays inside d_feat
     uint64_t feat_slots = 0;
+    uint32_t* d_hit_list = nullptr;        // locate: records with rows
+    uint64_t hit_list_cap = 0;
     int64_t cur_pid = 0;                   // partition index of the running Call()
     int region_start = 0, region_end = 0;  // parsed -R / -r
     bool region_on = false;

@@ -830,12 +830,17 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         P.name_off = c->d_names_off;
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
+        rc = grow(c, &c->d_hit_list, &c->hit_list_cap, c->table.n, c->table.n / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        P.hit_list = c->d_hit_list;
+        P.hit_count = c->d_counter;
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
         HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
         HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
         uint64_t status = 0;
         HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
         HIP_TRYX(c, hipMemcpyAsync(&nrows, c->d_counter + 1, sizeof nrows, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipMemcpyAsync(&P.nhit, c->d_counter, sizeof P.nhit, hipMemcpyDeviceToHost, st));
         HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
         rc = kernel_error_to_status(c, status);
@@ -1229,9 +1234,9 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     P.init_m = o.b("InitCodonAsM"); P.append_frame = o.b("AppendFrame");
     P.line_width = (int)o.ci("LineWidth");
     P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 4 * 4096 + 256));
+    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 6 * 4096 + 256));
     {
-        std::vector<uint8_t> tab(4 * 4096 + 256);
+        std::vector<uint8_t> tab(6 * 4096 + 256);
         uint8_t *fw = tab.data(), *stt = fw + 4096, *rcw = fw + 8192, *rcs = fw + 12288, *iu = fw + 16384;
         build_codon_tables(*find_code((int)o.i("TranslTable")), fw, stt);
         auto comp = [](int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); };
@@ -1246,9 +1251,16 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
         const char* letters = "acgturyswkmbdhvn";
         const int codes[] = {1, 2, 4, 8, 8, 5, 10, 6, 9, 12, 3, 14, 13, 11, 7, 15};
         for (int k = 0; letters[k]; ++k) { iu[(uint8_t)letters[k]] = (uint8_t)codes[k]; iu[(uint8_t)(letters[k] - 32)] = (uint8_t)codes[k]; }
+        for (int i = 0; i < 8192; ++i) {  // tables as the frames kernel wants them: -x and --clean folded in
+            uint8_t a = i < 4096 ? fw[i] : rcw[i - 4096];
+            if (P.allow_unknown && a == 0) a = 'X';
+            if (P.clean && a == '*') a = 'X';
+            tab[16384 + 256 + i] = a;
+        }
         HIP_TRYX(c, hipMemcpyAsync(c->d_codon, tab.data(), tab.size(), hipMemcpyHostToDevice, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
     }
+    P.baked = c->d_codon + 16384 + 256;
     P.codon = c->d_codon;
     P.start = c->d_codon + 4096;
     P.codon_rc = c->d_codon + 8192;

@@ -198,10 +198,11 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                                                 LocateParams P, uint32_t* __restrict__ out_len,
                                                 const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                 uint64_t* __restrict__ rows) {
-    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint64_t slot = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
     const uint32_t gl = threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;
-    const bool live = g < t.n;
+    const bool live = EMIT ? slot < P.nhit : slot < t.n;
+    const uint64_t g = EMIT ? (live ? (uint64_t)P.hit_list[slot] : 0) : slot;
     const uint64_t gi = live ? g : 0;
     const Text T = text_of(buf, t, tt, gi);
     const uint32_t l = live ? T.L : 0;
@@ -373,7 +374,10 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     if (live && gl == 0) {
         if (!EMIT) {
             out_len[g] = (uint32_t)bytes;  // rows of one record beyond 4 GiB are not representable
-            if (nrows) atomicAdd((unsigned long long*)rows, (unsigned long long)nrows);
+            if (nrows) {
+                atomicAdd((unsigned long long*)rows, (unsigned long long)nrows);
+                P.hit_list[atomicAdd((unsigned long long*)P.hit_count, 1ull)] = (uint32_t)g;
+            }
         }
     }
 }
@@ -385,7 +389,9 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
                          uint64_t* rows, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    const uint64_t blocks = (t.n * GROUP + 255) / 256;
+    const uint64_t groups = emit ? P.nhit : t.n;
+    if (groups == 0) return hipSuccess;
+    const uint64_t blocks = (groups * GROUP + 255) / 256;
     const dim3 gr((unsigned)blocks), bl(256);
     if (P.general) {
         if (emit) hipLaunchKernelGGL((k_locate<true, true>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);

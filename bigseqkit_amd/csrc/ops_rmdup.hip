@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict
     if (!keep) {
         const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
         bool same = a.len == b.len;
-        for (uint32_t q = 0; same && q < a.len; ++q) same = a.at(q) == b.at(q);
+        uint32_t q = 0;
+        for (; same && q + 8 <= a.len; q += 8) same = word64(a, q) == word64(b, q);  // 8 subject bytes per step
+        for (; same && q < a.len; ++q) same = a.at(q) == b.at(q);
         if (!same) {  // distinct subjects under one 64-bit key: refuse rather than guess
             atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
             keep = true;

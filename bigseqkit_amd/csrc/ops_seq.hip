@@ -250,6 +250,47 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         const uint32_t W = wrapped_len(L, P.line_width);
         const uint32_t b = P.print_seq ? W + 1u : 0u;
         const uint32_t w1 = (uint32_t)(P.line_width > 0 ? P.line_width + 1 : 0);
+        // The source bytes already have the output layout when nothing is transformed and either no newline has to
+        // be inserted (contiguous source) or the source is wrapped at the output width and the region starts at
+        // base 0: header byte-wise, sequence and quality as 16-byte copies.
+        const bool verbatim = !reverse && !use_lut &&
+                              ((TW == 0 && W == L) || (TW != 0 && (int)TW == P.line_width && sub_b == 0));
+        if (verbatim) {
+            for (uint32_t x = gl; x < a; x += GROUP) {
+                const uint32_t m = P.print_seq ? 1u : 0u;
+                uint8_t c;
+                if (x < m) c = P.fastq ? '@' : '>';
+                else if (x == a - 1) c = '\n';
+                else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
+                else c = r.head[hoff + x - m];
+                o[x] = c;
+            }
+            auto group_copy = [&](uint8_t* dst, const uint8_t* src, uint32_t nb) {
+                for (uint32_t x = gl * 16u; x < nb; x += GROUP * 16u) {
+                    if (x + 16u <= nb) {
+                        uint4 v;
+                        __builtin_memcpy(&v, src + x, 16);
+                        __builtin_memcpy(dst + x, &v, 16);
+                    } else {
+                        for (uint32_t k = x; k < nb; ++k) dst[k] = src[k];
+                    }
+                }
+            };
+            if (P.print_seq) {
+                group_copy(o + a, sp + (TW ? 0u : sub_b), W);
+                if (gl == 0) o[a + W] = '\n';
+            }
+            if (P.print_qual) {
+                uint32_t q0 = a + b;
+                if (!P.qual_only) {
+                    if (gl == 0) { o[q0] = '+'; o[q0 + 1] = '\n'; }
+                    q0 += 2;
+                }
+                group_copy(o + q0, rqual, L);
+                if (gl == 0) o[q0 + L] = '\n';
+            }
+            return;
+        }
         for (uint32_t x = gl; x < n; x += GROUP) {
             uint8_t c;
             if (x < a) {

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #include "ops_translate.hpp"
 #include "text.cuh"
@@ -378,6 +380,270 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
     if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
 }
 
+// ---------------------------------------------------------------------------
+// k_translate_frames4<G>: like k_translate_frames, but a lane owns FOUR consecutive codon slots (12 bases) of a
+// step, so every frame gets four consecutive residues per lane and step.  The previous kernel was VALU-bound
+// (~36 vector instructions per residue, profiles/r01d_ops_kernel_breakdown.json + SQ counters); here
+//   * the lane fetches its 16 raw bytes with five LDS dword reads + v_alignbyte, drops the (at most one) newline of a
+//     wrapped FASTA line with four v_bfi merges, and maps 14 bytes to IUPAC codes through the LDS table;
+//   * four residues are packed into one dword and leave as ONE store unless a line break falls between them
+//     (then four byte stores) -- interior steps carry no bounds checks at all;
+//   * --clean and -x are folded into the LDS copies of the codon tables, an unknown codon is detected from the AND of
+//     all packed dwords once per record, -M patches residue 0 of each frame after the loop.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t byte_of(const uint32_t (&w)[4], int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; }
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// four residues at `at` = position of the first one; `first` = residues before the line break (>= 4: none inside)
+__device__ __forceinline__ void put4(uint8_t* at, uint32_t packed, uint32_t first) {
+    if (first >= 4u) {
+        *reinterpret_cast<u32_unaligned*>(at) = packed;
+    } else {
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) at[(uint32_t)tq + ((uint32_t)tq >= first ? 1u : 0u)] = (uint8_t)(packed >> (8 * tq));
+    }
+}
+
+// the same, cut by the start / end of the element (first and last step of a record).  o / col: line-break offset and
+// column of residue jlow when jlow >= 0; a group that starts before residue 0 lies on the first line
+__device__ __forceinline__ void put4_edge(uint8_t* body, int64_t jlow, uint32_t packed, uint32_t lw, uint32_t kept,
+                                          uint32_t o, uint32_t col) {
+    if (jlow + 3 < 0 || jlow >= (int64_t)kept) return;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        const int64_t jj = jlow + tq;
+        if (jj >= 0 && (uint64_t)jj < kept) {
+            uint32_t oo = 0;
+            if (lw >= 4u) oo = jlow >= 0 ? o + (col + (uint32_t)tq >= lw ? 1u : 0u) : 0u;  // at most one break inside
+            else if (lw) oo = (uint32_t)jj / lw;
+            body[jj + oo] = (uint8_t)(packed >> (8 * tq));
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_translate_frames4(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                           TranslateParams P, const uint32_t* __restrict__ out_len,
+                                                           const uint64_t* __restrict__ out_off,
+                                                           uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
+    constexpr int STEPB = G * 12;      // bases per step
+    constexpr int STEPS = 4;           // steps per window
+    constexpr int WIN = STEPB * STEPS; // bases per window
+    constexpr int RAWCAP = WIN + WIN / 16 + 64;  // source lines are >= 16 wide (narrower records are linearised)
+    constexpr int NG = 256 / G;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tab[8192];  // codon table ++ reverse-complement-indexed table
+    __shared__ uint8_t s_iu[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[NG][RAWCAP];
+    const uint8_t* s_fw = s_tab;
+    const uint8_t* s_rc = s_tab + 4096;
+    for (int i = threadIdx.x * 16; i < 8192; i += blockDim.x * 16)
+        *reinterpret_cast<uint4*>(s_tab + i) = *reinterpret_cast<const uint4*>(P.baked + i);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
+    __syncthreads();
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint32_t gl = threadIdx.x % G;
+    if (g >= t.n) return;  // no block-level barrier below
+    uint8_t* raw = s_raw[threadIdx.x / G];
+    const Text T = text_of(buf, t, tt, g);
+    const uint32_t L = T.L;
+    const uint32_t W = T.W;
+    const uint32_t raw_total = W ? L + (L ? (L - 1) / W : 0u) : L;
+    const uint8_t* h = buf + t.start[g] + 1;
+    const uint32_t lh = t.l_head[g];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
+
+    constexpr uint64_t NONE = ~0ull;
+    uint64_t fb[3] = {NONE, NONE, NONE};   // body offsets from `out` (keeps the global address space)
+    uint64_t rbq[3] = {NONE, NONE, NONE};
+    uint32_t fk[3] = {0, 0, 0}, rkq[3] = {0, 0, 0};
+#pragma unroll 1
+    for (int k = 0; k < P.nframes; ++k) {
+        const int frame = P.frames[k];
+        const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
+        const uint32_t n = out_len[e];
+        uint8_t* o = out + out_off[e];
+        const uint32_t H = header_len(h, hl, P, frame) + 1;
+        const uint32_t body = n - H - 1;
+        const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
+        if (!P.append_frame) {
+            for (uint32_t x = gl; x < H; x += G) o[x] = x == 0 ? (uint8_t)'>' : (x == H - 1 ? (uint8_t)'\n' : h[x - 1]);
+        } else if (gl == 0) {
+            uint32_t hdr = 0, ioff, doff;
+            o[hdr++] = '>';
+            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
+            for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
+            const char* fs = "_frame=";
+            for (int q = 0; q < 7; ++q) o[hdr++] = (uint8_t)fs[q];
+            hdr += put_dec(o + hdr, frame);
+            o[hdr++] = ' ';
+            for (uint32_t q = 0; q < dl; ++q) o[hdr++] = h[doff + q];
+            o[hdr++] = '\n';
+        }
+        if (gl == 0) o[n - 1] = '\n';
+        if (lw) for (uint32_t x = lw + gl * (lw + 1); x < body; x += G * (lw + 1)) o[H + x] = '\n';
+        const uint64_t bodyp = out_off[e] + H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (frame == c + 1) { fb[c] = bodyp; fk[c] = kept; }
+            if (frame == -(c + 1)) { rbq[c] = bodyp; rkq[c] = kept; }
+        }
+    }
+    const uint32_t Lm = (L % 3u);
+    uint64_t rb[3];
+    uint32_t rk[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t sl = (Lm + 3u - (uint32_t)c) % 3u;  // reverse slot of class c
+        rb[c] = sl == 0 ? rbq[0] : (sl == 1 ? rbq[1] : rbq[2]);
+        rk[c] = sl == 0 ? rkq[0] : (sl == 1 ? rkq[1] : rkq[2]);
+    }
+    // unknown codon == a 0 byte among the existing residues.  Every real residue ('*', 'A'..'Z') has bit 5 or bit 6
+    // set, so bit 6 of (pk | pk << 1) is 1 for a residue and 0 for the unknown marker: AND-accumulate that bit.
+    uint32_t andacc = 0xFFFFFFFFu;
+    const uint32_t g4 = 4u * G;
+    const uint32_t gd = lw ? g4 / lw : 0u, gm = lw ? g4 % lw : 0u;
+    // forward cursor (shared by the forward frames): first residue of the lane's group of four
+    uint32_t fj = 4u * gl, fo = 0, fc = fj;
+    if (lw) { fo = fj / lw; fc = fj - fo * lw; }
+    // reverse cursors: LOWEST residue of the lane's group (the one of its 4th codon); descending by 4G per step
+    int64_t rj[3];
+    uint32_t ro[3], rcc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rj[c] = (L >= 3u + (uint32_t)c ? (int64_t)((L - 3u - (uint32_t)c) / 3u) : -1) - 4 * (int64_t)gl - 3;
+        ro[c] = 0; rcc[c] = 0;
+        if (lw && rj[c] >= 0) { ro[c] = (uint32_t)rj[c] / lw; rcc[c] = (uint32_t)rj[c] - ro[c] * lw; }
+    }
+    // raw cursor of the lane's first base (wrapped source): newlines before it and its column
+    uint32_t rnl = 0, rcol = 0;
+    if (W) { rnl = (12u * gl) / W; rcol = 12u * gl - rnl * W; }
+    const uint32_t sdq = W ? (uint32_t)STEPB / W : 0u, smq = W ? (uint32_t)STEPB % W : 0u;
+
+    for (uint32_t q0 = 0; q0 < L; q0 += WIN) {
+        // ---- stage the window's raw text (bases + newlines) in LDS: coalesced 16-byte copies
+        const uint32_t rawbase = W ? q0 + q0 / W : q0;
+        uint32_t span = raw_total - rawbase;
+        if (span > (uint32_t)RAWCAP) span = RAWCAP;
+        for (uint32_t off = gl * 16u; off < span; off += G * 16u) {
+            if (off + 16u <= span) {
+                uint4 v;
+                __builtin_memcpy(&v, T.p + rawbase + off, 16);
+                *reinterpret_cast<uint4*>(raw + off) = v;
+            } else {
+                for (uint32_t bq = off; bq < span; ++bq) raw[bq] = T.p[rawbase + bq];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (uint32_t it = 0; it < (uint32_t)STEPS; ++it) {
+            const uint32_t sb = q0 + it * (uint32_t)STEPB;
+            if (sb >= L) break;
+            const uint32_t q = sb + 12u * gl;  // first base of the lane
+            // ---- 16 raw bytes from the lane's first base
+            const uint32_t rp = W ? (q + rnl) - rawbase : q - q0;
+            uint32_t w[4];
+            {
+                const uint32_t* a = reinterpret_cast<const uint32_t*>(raw + (rp & ~3u));
+                const uint32_t sh = rp & 3u;
+                const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+                w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            }
+            if (W) {
+                // the line's newline sits k bytes after the first base; bytes above it move down by one
+                const uint32_t k = W - rcol;
+                if (k < 16u) {
+                    const uint32_t s0 = __builtin_amdgcn_alignbyte(w[1], w[0], 1), s1 = __builtin_amdgcn_alignbyte(w[2], w[1], 1),
+                                   s2 = __builtin_amdgcn_alignbyte(w[3], w[2], 1), s3 = w[3] >> 8;
+                    const uint32_t sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int32_t km = (int32_t)k - 4 * i;  // bytes of dword i that stay
+                        const uint32_t m = km >= 4 ? 0xFFFFFFFFu : (km <= 0 ? 0u : ((1u << (8 * km)) - 1u));
+                        w[i] = (w[i] & m) | (sv[i] & ~m);
+                    }
+                }
+            }
+            uint32_t cd[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) cd[i] = s_iu[byte_of(w, i)];
+            const bool interior = sb + (uint32_t)STEPB + 2u <= L;  // every codon of every lane is complete
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (fb[c] == NONE && rb[c] == NONE) continue;
+                uint32_t idx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) idx[k] = (cd[3 * k + c] << 8) | (cd[3 * k + c + 1] << 4) | cd[3 * k + c + 2];
+                uint32_t nv = 4;  // complete codons of the lane in this class
+                if (!interior) {
+                    nv = 0;
+                    if (q + (uint32_t)c + 2u < L) { nv = (L - q - (uint32_t)c - 3u) / 3u + 1u; if (nv > 4u) nv = 4u; }
+                }
+                if (fb[c] != NONE) {
+                    const uint32_t pk = (uint32_t)s_fw[idx[0]] | ((uint32_t)s_fw[idx[1]] << 8) | ((uint32_t)s_fw[idx[2]] << 16) |
+                                        ((uint32_t)s_fw[idx[3]] << 24);
+                    if (interior) andacc &= pk | (pk << 1);
+                    else andacc &= pk | (pk << 1) | (nv >= 4u ? 0u : ~((1u << (8 * nv)) - 1u));
+                    uint8_t* body = out + fb[c];
+                    if ((uint64_t)sb / 3u + g4 <= fk[c]) put4(body + fj + fo, pk, lw ? lw - fc : 4u);
+                    else put4_edge(body, (int64_t)fj, pk, lw, fk[c], fo, fc);
+                }
+                if (rb[c] != NONE) {
+                    // descending residues: codon slot 3 is the lowest residue = byte 0
+                    const uint32_t pk = (uint32_t)s_rc[idx[3]] | ((uint32_t)s_rc[idx[2]] << 8) | ((uint32_t)s_rc[idx[1]] << 16) |
+                                        ((uint32_t)s_rc[idx[0]] << 24);
+                    if (interior) andacc &= pk | (pk << 1);
+                    else andacc &= pk | (pk << 1) | (nv >= 4u ? 0u : (nv == 0u ? 0xFFFFFFFFu : ((1u << (8 * (4u - nv))) - 1u)));
+                    uint8_t* body = out + rb[c];
+                    // lane 0 holds the highest residues of the step, lane G-1 the lowest
+                    const int64_t hi0 = rj[c] + 4 * (int64_t)gl + 3, lo0 = hi0 - 4 * (int64_t)G + 1;
+                    if (lo0 >= 0 && (uint64_t)hi0 < rk[c]) put4(body + rj[c] + ro[c], pk, lw ? lw - rcc[c] : 4u);
+                    else put4_edge(body, rj[c], pk, lw, rk[c], ro[c], rcc[c]);
+                }
+            }
+            // ---- advance the cursors by one step
+            fj += g4;
+            if (lw) { fo += gd; fc += gm; if (fc >= lw) { fc -= lw; ++fo; } }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rj[c] -= g4;
+                if (lw && rj[c] >= 0) {
+                    ro[c] -= gd;
+                    if (rcc[c] < gm) { rcc[c] += lw - gm; --ro[c]; } else rcc[c] -= gm;
+                }
+            }
+            if (W) { rnl += sdq; rcol += smq; if (rcol >= W) { rcol -= W; ++rnl; } }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (!P.allow_unknown && (andacc & 0x40404040u) != 0x40404040u)
+        atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_UNKNOWN_CODON);
+    // ---- -M: residue 0 of a frame becomes 'M' when its codon is a start codon (after every other store)
+    if (P.init_m && gl == 0) {
+        __threadfence();
+        for (int k = 0; k < P.nframes; ++k) {
+            const int frame = P.frames[k];
+            const uint32_t f = (uint32_t)(frame < 0 ? -frame : frame);
+            if (L < f + 2u) continue;
+            const uint32_t p0 = frame > 0 ? f - 1u : L - f - 2u;  // first base of the codon (forward coordinates)
+            const uint32_t ix = ((uint32_t)s_iu[T.at(p0)] << 8) | ((uint32_t)s_iu[T.at(p0 + 1)] << 4) | (uint32_t)s_iu[T.at(p0 + 2)];
+            const bool st = frame > 0 ? P.start[ix] != 0 : P.start_rc[ix] != 0;
+            const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
+            const uint32_t H = header_len(h, hl, P, frame) + 1;
+            if (st && out_len[e] > H + 1u) out[out_off[e] + H] = 'M';
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
@@ -394,6 +660,16 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
                                    uint8_t* out, uint64_t* status, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    static const bool v3 = [] { const char* e = getenv("BSK_TRANSLATE"); return e && !strcmp(e, "v3"); }();
+    if (!v3) {
+        if (lanes_per_record == 64)
+            hipLaunchKernelGGL(k_translate_frames4<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, t,
+                               d, P, out_len, out_off, out, status);
+        else
+            hipLaunchKernelGGL(k_translate_frames4<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t,
+                               d, P, out_len, out_off, out, status);
+        return hipGetLastError();
+    }
     if (lanes_per_record == 64) {
         hipLaunchKernelGGL(k_translate_frames<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, t, d,
                            P, out_len, out_off, out, status);

@@ -26,6 +26,7 @@ struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/tra
     const uint8_t* codon_rc; // device, 4096 bytes: aa of the REVERSE COMPLEMENT of the codon with that index
     const uint8_t* start_rc; // device, 4096 bytes
     const uint8_t* iupac;    // device, 256 bytes: byte -> 4-bit IUPAC code (0 = not a base)
+    const uint8_t* baked;    // device, 8192 bytes, 16-byte aligned: codon ++ codon_rc with -x (0 -> 'X') and --clean ('*' -> 'X') applied
 };
 
 constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
