@@ -197,6 +197,15 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
     return BSK_OK;
 }
 
+int bsk_regex_match(const char* expr, const uint8_t* text, size_t n, int* matched) {
+    if (!expr || (!text && n) || !matched) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null argument");
+    try {
+        const bsk::RegexProgram p = bsk::compile_regex(expr);
+        *matched = bsk::regex_match(p, text, n) ? 1 : 0;
+        return BSK_OK;
+    } catch (const std::exception& e) { return fail_global(BSK_ERR_OPTS, e.what()); }
+}
+
 int bsk_rmdup_finish(bsk_ctx* c) {
     if (!c) return BSK_ERR_INVALID_ARG;
     if (c->op != bsk::Op::RmDup) return BSK_OK;
@@ -222,6 +231,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_cls) hipFree(c->d_cls);
         if (c->d_feat) hipFree(c->d_feat);
+        if (c->d_regex) hipFree(c->d_regex);
         if (c->d_hit_list) hipFree(c->d_hit_list);
         if (c->d_keys2) hipFree(c->d_keys2);
         if (c->d_own) hipFree(c->d_own);

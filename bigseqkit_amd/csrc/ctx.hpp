@@ -12,6 +12,7 @@
 
 #include "index.hpp"
 #include "opts.hpp"
+#include "regex_nfa.hpp"
 
 struct bsk_ctx {
     bsk::Op op;
@@ -100,6 +101,10 @@ struct bsk_ctx {
     uint64_t* d_set_keys = nullptr;
     uint32_t* d_set_idx = nullptr;
     uint64_t set_keys_cap = 0, set_idx_cap = 0, set_slots = 0;
+    // -r: compiled position automata (regex_nfa.hpp)
+    std::vector<bsk::RegexProgram> regexes;
+    bsk::RegexProgram* d_regex = nullptr;
+    uint64_t regex_cap = 0;
     bool patterns_uploaded = false;  // exact patterns + set do not depend on the shard's alphabet when by name
     uint8_t* d_names = nullptr;
     uint32_t* d_names_off = nullptr;

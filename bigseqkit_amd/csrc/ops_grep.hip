@@ -18,6 +18,7 @@
 #include "ops_seq.hpp"
 #include "ops_translate.hpp"  // TextTableH
 #include "pattern_match.cuh"
+#include "regex_nfa.hpp"
 
 namespace bsk {
 
@@ -344,6 +345,67 @@ __global__ __launch_bounds__(256) void k_grep_seq_gen(const uint8_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// -r: re.Match(target) (grep.go:459-468) as a bit-parallel position automaton, one lane per record.
+// State = 64-bit set of active positions; per byte: S = (follow(S) | first) & accept[byte]; follow(S) is the OR of
+// one table entry per 8 state bits.  The search is unanchored (first is injected before every byte); ^ and $ are
+// positions that accept the virtual BEGIN / END symbols fed before the first and after the last byte.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool re_step(const RegexProgram& p, uint32_t nchunk, uint64_t& S, int sym) {
+    uint64_t f = p.first;
+    for (uint32_t k = 0; k < nchunk; ++k) f |= p.follow[k][(S >> (8u * k)) & 255u];
+    S = f & p.accept[sym];
+    return (S & p.last) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_grep_regex(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                    GrepParams P, uint32_t* __restrict__ out_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t lh = t.l_head[i];
+    const uint8_t* h = buf + t.start[i] + 1;
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    bool hit = false;
+    if (P.by_seq) {
+        const Text T = text_of(buf, t, tt, i);
+        const uint32_t L = T.L;
+        const int nstr = P.both_strands ? 2 : 1;
+        for (int strand = 0; strand < nstr && !hit; ++strand) {
+            uint32_t wb = 0, we = L;  // window in the strand's own coordinates
+            if (P.region_on) sub_location(L, P.region_start, P.region_end, &wb, &we);
+            const uint32_t wl = we - wb;
+            const uint64_t tl = P.circular ? 2ull * wl : wl;
+            for (int k = 0; k < P.npat && !hit; ++k) {
+                const RegexProgram& p = P.regex[k];
+                if (p.nullable) { hit = true; break; }
+                const uint32_t nchunk = (p.npos + 7u) >> 3;
+                uint64_t S = 0;
+                hit = re_step(p, nchunk, S, RE_SYM_BEGIN);
+                for (uint64_t x = 0; x < tl && !hit; ++x) {
+                    uint32_t j = (uint32_t)(x >= wl ? x - wl : x) + wb;
+                    const uint8_t c = strand == 0 ? T.at(j) : P.comp[T.at(L - 1u - j)];
+                    hit = re_step(p, nchunk, S, c);
+                }
+                if (!hit) hit = re_step(p, nchunk, S, RE_SYM_END);
+            }
+        }
+    } else {
+        uint32_t off = 0, tl = hl;
+        if (!P.by_name) tl = id_span2(h, hl, P.id_mode, &off);
+        for (int k = 0; k < P.npat && !hit; ++k) {
+            const RegexProgram& p = P.regex[k];
+            if (p.nullable) { hit = true; break; }
+            const uint32_t nchunk = (p.npos + 7u) >> 3;
+            uint64_t S = 0;
+            hit = re_step(p, nchunk, S, RE_SYM_BEGIN);
+            for (uint32_t x = 0; x < tl && !hit; ++x) hit = re_step(p, nchunk, S, h[off + x]);
+            if (!hit) hit = re_step(p, nchunk, S, RE_SYM_END);
+        }
+    }
+    const bool sel = P.invert ? !hit : hit;
+    out_len[i] = sel ? format_len(hl, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ buf, RecordTable t, GrepParams P,
                                                    uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,7 +456,10 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
 hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH* tt,
                              const GrepParams& P, uint32_t* out_len, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    if (P.by_seq && P.general) {
+    if (P.regex) {
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
+        hipLaunchKernelGGL(k_grep_regex, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len);
+    } else if (P.by_seq && P.general) {
         TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
         const uint64_t blocks = (t.n * GROUP + 255) / 256;
         hipLaunchKernelGGL(k_grep_seq_gen, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len);

@@ -23,6 +23,9 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     int max_mm;
     const uint32_t* cls;
     // ID / name pattern set (many patterns, e.g. -f ids.txt): open addressing on fnv1a64, verified by bytes
+    // -r: Glushkov programs (regex_nfa.hpp), `npat` of them, in device memory; comp: complement map for the '-' strand
+    const struct RegexProgram* regex;
+    const uint8_t* comp;
     const uint64_t* set_keys;  // null: linear scan over the patterns
     const uint32_t* set_idx;
     uint64_t set_mask;

@@ -507,9 +507,9 @@ void validate_grep_opts(bsk_ctx* c) {
         o.mut("BySeq").b = true;
         parse_region_opt(o.s("Region"), "grep", &c->region_start, &c->region_end);
     }
-    if (o.b("UseRegexp") || o.b("DeleteMatched"))
-        throw OptError("libbsk: regexp (-r) and --delete-matched are not supported by the HIP path yet");
+    if (o.b("DeleteMatched")) throw OptError("libbsk: --delete-matched is not supported by the HIP path yet");
     c->patterns.clear();
+    c->regexes.clear();
     c->pattern_cls.clear();
     c->max_mm = (int)o.i("MaxMismatch");
     c->general = o.b("Degenerate") || c->max_mm > 0;
@@ -519,6 +519,13 @@ void validate_grep_opts(bsk_ctx* c) {
     std::unordered_set<std::string> seen;
     for (std::string p : given) {
         if (p.empty()) continue;
+        if (o.b("UseRegexp")) {  // grep.go:148-153, 211-225: "(?i)" + p with -i, then regexp.Compile
+            if (o.b("IgnoreCase")) p = "(?i)" + p;
+            if (!seen.insert(p).second) continue;
+            c->regexes.push_back(compile_regex(p));
+            c->patterns.push_back(p);
+            continue;
+        }
         if (o.b("Degenerate")) {
             // Degenerate2Regexp with the alphabet of -t (nil for auto => nucleotide map), "(?i)" with -i
             if (!seen.insert(p).second) continue;
@@ -639,7 +646,23 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.npat = (int)c->patterns.size();
         rc = prepare_text(c, d_buf, format, st, &tt);  // uses d_out_len as scratch: before the match kernel
         if (rc != BSK_OK) return rc;
-        if (!G.by_seq) {
+        if (!c->regexes.empty()) {
+            if (!c->patterns_uploaded) {
+                rc = grow(c, &c->d_regex, &c->regex_cap, c->regexes.size());
+                if (rc != BSK_OK) return rc;
+                HIP_TRYX(c, hipMemcpyAsync(c->d_regex, c->regexes.data(), c->regexes.size() * sizeof(RegexProgram),
+                                           hipMemcpyHostToDevice, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                c->patterns_uploaded = true;
+            }
+            uint8_t comp[256];
+            complement_table(ab, comp);
+            if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
+            HIP_TRYX(c, hipMemcpyAsync(c->d_lut, comp, 256, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));  // comp lives on the host stack
+            G.regex = c->d_regex;
+            G.comp = c->d_lut;
+        } else if (!G.by_seq) {
             // ID / name: the patterns do not depend on the shard, upload once per context
             if (!c->patterns_uploaded) {
                 rc = upload_patterns(c, c->patterns, st);

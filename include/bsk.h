@@ -161,6 +161,10 @@ int bsk_seq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int fo
 int bsk_grep_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                  bsk_out* out);
 int bsk_grep_last_count(const bsk_ctx* ctx, uint64_t* count);
+/* grep -r: the regular expression compiler of the HIP path (Go regexp / RE2 syntax subset -> position automaton,
+ * bigseqkit_amd/csrc/regex_nfa.hpp) run on the HOST against one target: *matched = re.Match(text).  Needs no device;
+ * lets callers (and the CPU tests) check an expression before creating a Grep context. */
+int bsk_regex_match(const char* expr, const uint8_t* text, size_t n, int* matched);
 
 /* ---- SubseqTransform by region (bigseqkit-lib/subseq.go:22-225, 314-317) -- */
 int bsk_subseq_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

@@ -2,6 +2,8 @@
 // CPU restatement of bigseqkit-lib parser + stats.  Citations: /root/reference/.
 #include "oracle_core.hpp"
 
+#include <regex>
+
 #include <algorithm>
 #include <cmath>
 #include <cctype>
@@ -729,14 +731,24 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
         o.BySeq = true;
         parse_region(o.Region, "grep", &start, &end);
     }
-    if (o.UseRegexp || o.DeleteMatched)
-        throw Error("oracle: regexp / delete-matched grep is not restated");
+    if (o.DeleteMatched) throw Error("oracle: delete-matched grep is not restated");
     std::vector<std::string> patterns;  // PARITY.md Q11: CLI / file order instead of Go map order
     std::vector<MiniRe> regexps;        // -d
+    // -r: Go regexp (RE2) is not in this image; std::regex (ECMAScript grammar) stands in for it -- the two agree on
+    // the syntax the tests use (classes, escapes, groups, alternation, quantifiers, ^ $).  "(?i)" becomes the icase flag.
+    std::vector<std::regex> stdres;
     // grep.go:122-252: the file replaces -p when given
     const std::vector<std::string> given = !o.PatternFile.empty() ? read_pattern_lines(o.PatternFile) : o.Pattern;
     for (auto p : given) {
         if (p.empty()) continue;
+        if (o.UseRegexp) {  // grep.go:148-153
+            if (std::find(patterns.begin(), patterns.end(), p) != patterns.end()) continue;
+            try {
+                stdres.emplace_back(p, o.IgnoreCase ? std::regex::ECMAScript | std::regex::icase : std::regex::ECMAScript);
+            } catch (const std::regex_error& e) { throw Error(std::string("error parsing regexp: ") + e.what() + ": `" + p + "`"); }
+            patterns.push_back(p);
+            continue;
+        }
         if (o.Degenerate) {
             p = degenerate2regexp(p, ab);
             if (o.IgnoreCase) p = "(?i)" + p;
@@ -778,6 +790,11 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
                     target = sq.substr(b, e - b);
                 } else if (o.Circular) target = sq + sq;
                 else target = sq;
+                if (o.UseRegexp) {
+                    for (auto& re : stdres)
+                        if (std::regex_search(target, re)) { hit = true; break; }
+                    continue;
+                }
                 if (o.Degenerate) {  // grep.go:459-468: re.Match on the un-lowered target
                     for (auto& re : regexps)
                         if (re.find(target, 0) >= 0) { hit = true; break; }
@@ -793,6 +810,11 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
                 }
             } else {
                 target = o.ByName ? r.name : r.id;
+                if (o.UseRegexp) {  // grep.go:459-468: the regexp sees the un-lowered ID / name
+                    for (auto& re : stdres)
+                        if (std::regex_search(target, re)) { hit = true; break; }
+                    continue;
+                }
                 if (o.IgnoreCase) target = lower(target);
                 hit = std::find(patterns.begin(), patterns.end(), target) != patterns.end();
             }

@@ -98,6 +98,9 @@ CASES = [
     ("locate", ["-p", "ACG,TTGA", "-i"], "fa"), ("locate", ["-p", "GATC", "-P", "-M"], "fq"),
     ("translate", ["-f", "1,-2", "-x"], "fa"), ("translate", ["-T", "11", "-F", "--trim", "-x"], "fa"),
     ("rmdup", ["-s"], "fa"), ("rmdup", ["-n"], "fq"),
+    ("grep", ["-r", "-p", "^r1\\d$", "-i"], "fq"), ("grep", ["-s", "-d", "-p", "ACGNNT"], "fa"),
+    ("grep", ["-s", "-m", "1", "-p", "ACGTACGTAC"], "fa"), ("locate", ["-d", "-p", "ACNNT", "--bed"], "fa"),
+    ("locate", ["-m", "1", "-p", "ACGTAC", "-i"], "fq"), ("locate", ["-F", "-p", "ACG"], "fa"),
 ]
 
 

@@ -409,3 +409,66 @@ def test_subseq_feature_edge_cases(tmp_path):
     with pytest.raises(bsk.BskError) as e:
         bsk.Operator("SubseqTransform", json.dumps({"Bed": str(bed), "Feature": ["gene"]}), -1)
     assert "when given flag -b (--bed), flag -f (--feature) is not allowed" in str(e.value)
+
+
+# ---------------------------------------------------------------- grep -r (regular expressions on the device)
+GREP_RE_OPTS = [
+    {"Pattern": ["^r1[0-9]$"], "UseRegexp": True},
+    {"Pattern": ["^r\\d+ d[03]$"], "UseRegexp": True, "ByName": True},
+    {"Pattern": ["R1", "^r2\\d\\d$"], "UseRegexp": True, "IgnoreCase": True},
+    {"Pattern": ["7$"], "UseRegexp": True, "InvertMatch": True},
+    {"Pattern": ["ACGTT[GA]CAAGCT"], "UseRegexp": True, "BySeq": True},
+    {"Pattern": ["ACGTTGCA{2}GCT"], "UseRegexp": True, "BySeq": True, "OnlyPositiveStrand": True},
+    {"Pattern": ["^A.*T$"], "UseRegexp": True, "BySeq": True},
+    {"Pattern": ["acgttg(ca|gg)agct"], "UseRegexp": True, "BySeq": True, "IgnoreCase": True},
+    {"Pattern": ["GCAAGCT.*ACGTTG|TTTTTTTT"], "UseRegexp": True, "BySeq": True, "Circular": True},
+    {"Pattern": ["^ACG"], "UseRegexp": True, "Region": "5:60"},
+    {"Pattern": ["(AC){3,}G+T"], "UseRegexp": True, "Region": "-50:-1", "InvertMatch": True},
+    {"Pattern": ["A[TU]G(?:.{3})+?[TU](?:AG|AA|GA)"], "UseRegexp": True, "BySeq": True},
+]
+
+
+@pytest.mark.parametrize("i", range(len(GREP_RE_OPTS)))
+def test_grep_regexp_fastq(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(3300 + i)
+    n = check_grep(planted_fastq(rng, 700), True, GREP_RE_OPTS[i])
+    assert 0 < n < 700
+
+
+@pytest.mark.parametrize("width", [60, 0, -1])
+@pytest.mark.parametrize("i", [4, 6, 7, 8, 9])
+def test_grep_regexp_fasta(i, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(3400 + i)
+    recs = []
+    for k in range(200):
+        L = rng.randint(0, 400)
+        s = [rng.choice("ACGTacgt") for _ in range(L)]
+        if L >= 12 and k % 3 == 0:
+            p = rng.randrange(L - 11)
+            s[p:p + 12] = MOTIF if k % 2 else "AGCTTGCAACGT"
+        s = "".join(s)
+        if width < 0:
+            lines, j = [], 0
+            while j < L:
+                w = rng.randint(1, 40)
+                lines.append(s[j:j + w])
+                j += w
+            recs.append(f">s{k} x\n" + "".join(l + "\n" for l in lines))
+        else:
+            w = width if width else max(1, L)
+            recs.append(f">s{k} x\n" + "".join(s[j:j + w] + "\n" for j in range(0, L, w)))
+    check_grep("".join(recs).encode(), False, GREP_RE_OPTS[i])
+
+
+def test_grep_regexp_errors_and_pattern_file(tmp_path):
+    for opts, msg in [({"Pattern": ["a(b"], "UseRegexp": True}, "missing closing )"),
+                      ({"Pattern": ["ACGT"], "UseRegexp": True, "Degenerate": True}, "could not give both flags -d")]:
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("Grep", json.dumps(opts), -1)
+        assert msg in str(e.value)
+    f = tmp_path / "re.txt"
+    f.write_text("^r1\\d$\n^r2\\d\\d$\n")
+    rng = random.Random(8)
+    assert check_grep(planted_fastq(rng, 400, L=20), True, {"PatternFile": str(f), "UseRegexp": True}) == 110
