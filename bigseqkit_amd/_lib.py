@@ -93,6 +93,8 @@ SIGNATURES = {
     "bsk_locate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_translate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_rmdup_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
+    "bsk_host_alloc": (_vp, [_sz]),
+    "bsk_host_free": (None, [_vp]),
     "bsk_regex_match": (_i, [C.c_char_p, _vp, _sz, _p(C.c_int)]),
     "bsk_rmdup_finish": (_i, [_vp]),
     "bsk_rmdup_dist_keys": (_i, [_vp, _vp, _sz, _i, _vp, _p(C.c_uint64)]),

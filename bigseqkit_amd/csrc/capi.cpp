@@ -250,6 +250,7 @@ void bsk_destroy(bsk_ctx* c) {
             if (c->pinned[i]) hipHostFree(c->pinned[i]);
             if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
             if (c->stage_done[i]) hipEventDestroy(c->stage_done[i]);
+            if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
         }
     }
     delete c;
@@ -360,18 +361,54 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     }
     if (on_device) return stats_run_device(c, (const uint8_t*)shard, n, format, (uint64_t*)d_vec, st);
 
-    // host-resident shard: stage through a device buffer
-    if (n > c->stage_cap) {
-        if (c->d_stage[0]) HIP_TRY(c, hipFree(c->d_stage[0]));
-        c->d_stage[0] = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&c->d_stage[0], n + 16));
-        c->stage_cap = n;
+    // host-resident shard: record-aligned chunks through two device buffers; the copy of chunk i+1 (copy stream)
+    // overlaps the kernels of chunk i (caller's stream).  Pinned host memory (bsk_host_alloc / hipHostMalloc /
+    // hipHostRegister) makes the copies true DMA at PCIe rate; pageable memory works but is staged by the runtime.
+    const char* chunk_env = getenv("BSK_STAGE_BYTES");
+    const size_t chunk = chunk_env && strtoull(chunk_env, nullptr, 10) ? (size_t)strtoull(chunk_env, nullptr, 10) : ((size_t)256 << 20);
+    const uint8_t* h = (const uint8_t*)shard;
+    if (!c->copy_stream[0]) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        if (!c->stage_done[b]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming));
+        if (!c->stage_free[b]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_stage[0], shard, n, hipMemcpyHostToDevice, st));
-    int rc = stats_run_device(c, c->d_stage[0], n, format, (uint64_t*)d_vec, st);
-    if (rc != BSK_OK) return rc;
-    HIP_TRY(c, hipStreamSynchronize(st));  // the staging buffer is reused by the next call
+    size_t lo = 0;
+    for (int i = 0; lo < n; ++i) {
+        size_t hi = n;
+        if (n - lo > chunk) {  // cut on the first record start at or after lo + chunk (a chunk holds whole records)
+            hi = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_start(h, n, lo + chunk) : (size_t)find_fasta_start(h, n, lo + chunk);
+            if (hi <= lo || hi > n) hi = n;
+        }
+        const int b = i & 1;
+        const size_t len = hi - lo;
+        if (len > c->stage_cap_b[b]) {
+            HIP_TRY(c, hipStreamSynchronize(st));  // nothing may still read the buffer that is replaced
+            if (c->d_stage[b]) HIP_TRY(c, hipFree(c->d_stage[b]));
+            c->d_stage[b] = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&c->d_stage[b], len + len / 16 + 4096));
+            c->stage_cap_b[b] = len + len / 16;
+        }
+        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream[0], c->stage_free[b], 0));
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage[b], h + lo, len, hipMemcpyHostToDevice, c->copy_stream[0]));
+        HIP_TRY(c, hipEventRecord(c->stage_done[b], c->copy_stream[0]));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->stage_done[b], 0));
+        int rc = stats_run_device(c, c->d_stage[b], len, format, (uint64_t*)d_vec, st);
+        if (rc != BSK_OK) return rc;
+        HIP_TRY(c, hipEventRecord(c->stage_free[b], st));
+        lo = hi;
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));  // the staging buffers are reused by the next call
     return BSK_OK;
+}
+
+void* bsk_host_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void bsk_host_free(void* p) {
+    if (p) hipHostFree(p);
 }
 
 static std::string describe_kernel_errors(uint64_t f, int* code) {

@@ -129,7 +129,9 @@ struct bsk_ctx {
     uint8_t* d_stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;
     hipStream_t copy_stream[2] = {nullptr, nullptr};
-    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};  // copy of buffer b finished
+    hipEvent_t stage_free[2] = {nullptr, nullptr};  // kernels reading buffer b finished
+    size_t stage_cap_b[2] = {0, 0};
 
     // ---- profiling (bench.py roofline leg) -----------------------------------
     bool profile = false;

@@ -99,6 +99,11 @@ size_t bsk_stats_vector_len(const bsk_ctx* ctx);
  * kernels are reported by bsk_stats_collect(). */
 int bsk_stats_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* d_vec,
                   void* stream);
+/* Pinned (page-locked) host memory for host-resident shards: read the file into such a buffer and the H2D copies of
+ * bsk_stats_run(on_device = 0) are DMA at PCIe rate, overlapped with the kernels chunk by chunk (256 MiB record-aligned
+ * chunks, two device buffers; BSK_STAGE_BYTES overrides the chunk size).  NULL when the allocation fails. */
+void* bsk_host_alloc(size_t n);
+void bsk_host_free(void* p);
 int bsk_stats_reset(bsk_ctx* ctx, void* stream); /* zero the ctx-owned vector */
 /* Synchronise, check the kernels' error flags (BSK_ERR_FORMAT /
  * BSK_ERR_UNSUPPORTED) and convert a stats vector (d_vec or the ctx-owned one)

@@ -235,3 +235,33 @@ def test_synthetic_fastq150_full_size_properties():
     head = bytes(t[:rb * 30000].cpu().numpy().tobytes())
     g = gpu_map(head, True, {"All": True})
     assert g == oracle.stats_map(head, True, '{"All": true}')
+
+
+def test_stats_host_shard_chunked_pipeline_matches_device_path(monkeypatch):
+    """on_device = 0: record-aligned chunks through two device buffers (copy of chunk i+1 overlaps the kernels of
+    chunk i).  Tiny chunks force many cuts, in pinned (bsk_host_alloc) and pageable memory."""
+    import ctypes as C
+    import json
+    import random
+    import oracle
+    import seqgen
+    from bigseqkit_amd._lib import lib, check
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_STAGE_BYTES", "30000")
+    for fastq in (True, False):
+        rng = random.Random(91 + fastq)
+        data = seqgen.random_fastq(rng, 4000, 0, 200) if fastq else seqgen.random_fasta(rng, 1500, 0, 900)
+        want = oracle.stats_map(data, fastq, json.dumps({"All": True}))
+        p = lib.bsk_host_alloc(len(data))
+        assert p
+        try:
+            C.memmove(p, data, len(data))
+            for ptr in (p, C.cast(C.create_string_buffer(data, len(data)), C.c_void_p).value):
+                with bsk.Operator("Stats", json.dumps({"All": True}), 0) as op:
+                    keys, vals, n = (C.c_int64 * 8192)(), (C.c_int64 * 8192)(), C.c_size_t()
+                    check(lib.bsk_stats_run(op.ctx, C.c_void_p(ptr), len(data), 0, bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA,
+                                            0, None, None), op.ctx)
+                    check(lib.bsk_stats_collect(op.ctx, None, keys, vals, 8192, C.byref(n)), op.ctx)
+                    assert dict(zip(keys[:n.value], vals[:n.value])) == want
+        finally:
+            lib.bsk_host_free(p)
