@@ -238,9 +238,9 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_set_keys) hipFree(c->d_set_keys);
         if (c->d_set_idx) hipFree(c->d_set_idx);
         if (c->d_pat_off) hipFree(c->d_pat_off);
-        for (void* p : {(void*)c->sparse.start, (void*)c->sparse.l_head, (void*)c->sparse.l_seq, (void*)c->sparse.aux})
+        for (void* p : {(void*)c->sparse.start, (void*)c->sparse.l_head, (void*)c->sparse.l_seq, (void*)c->sparse.aux, (void*)c->sparse.text_w})
             if (p) hipFree(p);
-        for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux,
+        for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux, (void*)c->table.text_w,
                         (void*)c->d_range_count, (void*)c->d_range_base, (void*)c->d_out_len, (void*)c->d_out_off,
                         (void*)c->d_scan_tmp, (void*)c->d_out, (void*)c->d_lut, (void*)c->d_qual_err,
                         (void*)c->d_counter})

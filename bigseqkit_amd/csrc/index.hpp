@@ -21,6 +21,9 @@ struct RecordTable {
     uint32_t* l_head = nullptr;
     uint32_t* l_seq = nullptr;
     uint32_t* aux = nullptr;
+    // FASTA only (written by the index pass): 0 = the sequence is one line (or empty), W = every line but the last has
+    // W >= 16 bases and the last 1..W (base i sits at i + i / W), 0xFFFFFFFF = irregular wrapping (text.cuh)
+    uint32_t* text_w = nullptr;
     uint64_t n = 0;
     uint64_t cap = 0;
 };

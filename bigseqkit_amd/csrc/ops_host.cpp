@@ -112,13 +112,14 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
     D.sparse_cap = 0;
     auto alloc_table = [&](RecordTable& t, uint64_t cap) -> int {
         if (cap <= t.cap && t.start) return BSK_OK;
-        for (void* p : {(void*)t.start, (void*)t.l_head, (void*)t.l_seq, (void*)t.aux})
+        for (void* p : {(void*)t.start, (void*)t.l_head, (void*)t.l_seq, (void*)t.aux, (void*)t.text_w})
             if (p) HIP_TRYX(c, hipFree(p));
         t = RecordTable();
         HIP_TRYX(c, hipMalloc((void**)&t.start, (cap + 1) * sizeof(uint64_t)));
         HIP_TRYX(c, hipMalloc((void**)&t.l_head, cap * sizeof(uint32_t)));
         HIP_TRYX(c, hipMalloc((void**)&t.l_seq, cap * sizeof(uint32_t)));
         HIP_TRYX(c, hipMalloc((void**)&t.aux, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.text_w, cap * sizeof(uint32_t)));
         t.cap = cap;
         return BSK_OK;
     };
@@ -1136,7 +1137,7 @@ static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_
     tt->lin = nullptr;
     if (format == BSK_FORMAT_FASTQ || c->table.n == 0) return BSK_OK;
     const uint64_t n = c->table.n;
-    if (n + 1 > c->text_cap || !c->d_text_w) {
+    if (n + 1 > c->text_cap || !c->d_lin_off) {
         if (c->d_text_w) HIP_TRYX(c, hipFree(c->d_text_w));
         if (c->d_lin_off) HIP_TRYX(c, hipFree(c->d_lin_off));
         c->d_text_w = nullptr; c->d_lin_off = nullptr;
@@ -1147,7 +1148,16 @@ static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_
     }
     int rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_text_classify(d_buf, c->table, c->d_text_w, c->d_out_len, st));
+    // The line layout of every record comes out of the index pass (RecordTable::text_w); BSK_TEXT=classify keeps the
+    // separate pass over the line ends (tests cross-check the two).
+    const char* mode = getenv("BSK_TEXT");
+    const uint32_t* text_w = c->table.text_w;
+    if (mode && strcmp(mode, "classify") == 0) {
+        HIP_TRYX(c, launch_text_classify(d_buf, c->table, c->d_text_w, c->d_out_len, st));
+        text_w = c->d_text_w;
+    } else {
+        HIP_TRYX(c, launch_lin_len(c->table, c->d_out_len, st));
+    }
     HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_lin_off, n, c->d_scan_tmp, st));
     uint64_t total = 0;
     HIP_TRYX(c, hipMemcpyAsync(&total, c->d_lin_off + n, sizeof total, hipMemcpyDeviceToHost, st));
@@ -1155,9 +1165,9 @@ static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_
     if (total) {
         rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
         if (rc != BSK_OK) return rc;
-        HIP_TRYX(c, launch_text_linearise(d_buf, c->table, c->d_text_w, c->d_lin_off, c->d_lin, st));
+        HIP_TRYX(c, launch_text_linearise(d_buf, c->table, text_w, c->d_lin_off, c->d_lin, st));
     }
-    tt->text_w = c->d_text_w;
+    tt->text_w = text_w;
     tt->lin_off = c->d_lin_off;
     tt->lin = c->d_lin;
     return BSK_OK;
@@ -1599,7 +1609,7 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     SeqParams F = format_params(c, fastq);
-    if (!fastq) { F.text_w = c->d_text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
+    if (!fastq) { F.text_w = c->table.text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
     HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st));
     out->d_data = c->d_out;
     out->len = total;

@@ -62,7 +62,19 @@ __global__ __launch_bounds__(256) void k_text_linearise(const uint8_t* __restric
     }
 }
 
+// bytes each record needs in the linear side buffer, from the layout the index pass recorded (RecordTable::text_w)
+__global__ __launch_bounds__(256) void k_lin_len(RecordTable t, uint32_t* __restrict__ lin_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.n) lin_len[i] = t.text_w[i] == TEXT_IRREGULAR ? t.l_seq[i] : 0u;
+}
+
 }  // namespace
+
+hipError_t launch_lin_len(const RecordTable& t, uint32_t* lin_len, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lin_len, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, t, lin_len);
+    return hipGetLastError();
+}
 
 hipError_t launch_text_classify(const uint8_t* buf, const RecordTable& t, uint32_t* text_w, uint32_t* lin_len,
                                 hipStream_t st) {

@@ -28,6 +28,10 @@ struct IndexSink {
     // FASTA: the record that is open at the start of a batch
     uint64_t open_start = 0;  // absolute offset of its '>'
     uint32_t open_lhead = 0, open_key = 0;
+    // FASTA line layout of the open record (text.cuh): length of its first sequence line, any line seen so far that
+    // breaks "all lines but the last are equally long, the last is 1..W"
+    uint32_t open_w = 0;
+    bool open_irr = false;
 
     __device__ __forceinline__ void begin_range(uint64_t b, uint64_t lim, uint64_t rs) {
         base = b;
@@ -36,6 +40,8 @@ struct IndexSink {
         open_start = rs;
         open_lhead = 0;
         open_key = 0;
+        open_w = 0;
+        open_irr = false;
     }
 
     template <bool FASTQ, bool ALL>
@@ -85,6 +91,41 @@ struct IndexSink {
                     best_start = abs_of(L.pos[s - 1], tile_idx, tile_rel) + 1;
                 }
                 const uint64_t cm = __ballot(closing);
+                // ---- line layout (replaces a separate pass over every line end): an event is a header end (H), the
+                // first sequence line of its record (F), or a later sequence line, which must be as long as the line
+                // before it (the last one: 1..that length)
+                const bool H = on && L.flag[s - 1] != 0;
+                const bool F = on && !H && L.flag[s - 2] != 0;
+                const uint32_t len = p - L.pos[s - 1] - 1u;
+                bool viol = false;
+                if (on && !H) {
+                    if (F) viol = !closing && len == 0u;
+                    else {
+                        const uint32_t plen = L.pos[s - 1] - L.pos[s - 2] - 1u;
+                        viol = closing ? (len > plen || len == 0u) : (len != plen);
+                    }
+                }
+                const uint64_t hb = __ballot(H), fb = __ballot(F), vb = __ballot(viol);
+                uint32_t tw = 0;  // text_w of the record this lane closes
+                {
+                    // every lane takes part in the shuffle (a ds_bpermute reads nothing from inactive lanes)
+                    const uint64_t upto = (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                    const uint64_t hh = hb & upto, ff = fb & upto;
+                    bool irr;
+                    int src = lane;
+                    if (hh) {
+                        const int hpos = 63 - __clzll((long long)hh);
+                        const uint64_t seg = upto & ~((hpos == 63) ? ~0ull : ((2ull << hpos) - 1ull));
+                        irr = (vb & seg) != 0;
+                        src = (hpos + 1) & 63;  // the event after a header end is the first sequence line
+                    } else {
+                        irr = open_irr || (vb & upto) != 0;
+                        if (ff) src = (int)__ffsll((long long)ff) - 1;
+                    }
+                    const uint32_t wsh = (uint32_t)__shfl((int)len, src, 64);
+                    const uint32_t W = (hh || ff) ? wsh : open_w;
+                    if (closing && !H && !F) tw = (irr || W < 16u) ? 0xFFFFFFFFu : W;
+                }
                 if (closing && D.write) {
                     const uint32_t local = nrec + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
                     uint32_t t = s;
@@ -110,11 +151,22 @@ struct IndexSink {
                         D.t.l_head[g] = lhead;
                         D.t.l_seq[g] = seqlen;
                         D.t.aux[g] = (uint32_t)region;
+                        D.t.text_w[g] = tw;
                     } else {
                         err |= ERR_CAPACITY;
                     }
                 }
                 nrec += (uint32_t)__popcll(cm);
+                // layout state of the record that stays open after these 64 events (wave-uniform)
+                if (hb) {
+                    const int hl = 63 - __clzll((long long)hb);
+                    const uint64_t above = hl == 63 ? 0ull : ~((2ull << hl) - 1ull);
+                    open_irr = (vb & above) != 0;
+                    open_w = (fb & above) ? (uint32_t)__builtin_amdgcn_readlane((int)len, hl + 1) : 0u;
+                } else {
+                    open_irr = open_irr || vb != 0;
+                    if (fb) open_w = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)__ffsll((long long)fb) - 1);
+                }
             }
         }
         if constexpr (!FASTQ) {
@@ -266,6 +318,7 @@ __global__ __launch_bounds__(256) void k_index_compact(RecordTable sp, uint64_t 
         dn.l_head[dst + i] = sp.l_head[src + i];
         dn.l_seq[dst + i] = sp.l_seq[src + i];
         dn.aux[dst + i] = sp.aux[src + i];
+        dn.text_w[dst + i] = sp.text_w[src + i];
     }
 }
 

@@ -186,3 +186,41 @@ def test_seq_n_on_synthetic_c2_layout():
     assert got[-12:] == b"S%010d\n" % (nrec - 1)
     head = bytes(t[:rb * 20000].cpu().numpy().tobytes())
     assert got[:12 * 20000] == oracle.seq(head, True, '{"Name": true}')
+
+
+def test_fasta_layout_from_index_pass_equals_separate_classification(monkeypatch):
+    """RecordTable::text_w is produced by the index pass (line lengths seen by the event sink); BSK_TEXT=classify
+    keeps the older separate pass over the line ends.  Same operator output either way, on every kind of wrapping."""
+    import json
+    import random
+    import oracle
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(123)
+    recs = []
+    for k in range(400):
+        L = rng.randint(0, 900)
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        kind = k % 6
+        if kind == 0:
+            lines = [s[j:j + 60] for j in range(0, L, 60)]
+        elif kind == 1:
+            lines = [s] if L else []
+        elif kind == 2:
+            lines = [s[j:j + 17] for j in range(0, L, 17)]
+        elif kind == 3:
+            lines = [s[j:j + 11] for j in range(0, L, 11)]       # narrower than 16: linearised
+        elif kind == 4:                                            # one line too long / too short somewhere
+            lines = [s[j:j + 60] for j in range(0, L, 60)]
+            if len(lines) > 2:
+                i = rng.randrange(len(lines) - 1)
+                lines[i], lines[-1] = lines[i][:-3], lines[-1] + lines[i][-3:]
+        else:                                                      # last line longer than the others
+            lines = [s[j:j + 40] for j in range(0, max(0, L - 70), 40)] + ([s[max(0, L - 70) // 40 * 40:]] if L else [])
+        recs.append(f">s{k} d\n" + "".join(l + "\n" for l in lines))
+    data = "".join(recs).encode()
+    opts = {"Reverse": True, "Complement": True, "Config": {"LineWidth": 50}}
+    want = oracle.seq(data, False, json.dumps(opts))
+    t = dev(data)
+    for mode in ("", "classify"):
+        monkeypatch.setenv("BSK_TEXT", mode)
+        assert bsk.Seq(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts(opts)) == want, mode
