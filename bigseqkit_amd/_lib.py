@@ -93,6 +93,9 @@ SIGNATURES = {
     "bsk_locate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_translate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_rmdup_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
+    "bsk_device_alloc": (_vp, [_sz]),
+    "bsk_device_free": (None, [_vp]),
+    "bsk_device_copy": (_i, [_vp, _vp, _sz, _i]),
     "bsk_host_alloc": (_vp, [_sz]),
     "bsk_host_free": (None, [_vp]),
     "bsk_regex_match": (_i, [C.c_char_p, _vp, _sz, _p(C.c_int)]),

@@ -401,6 +401,25 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     return BSK_OK;
 }
 
+void* bsk_device_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n ? n : 1) != hipSuccess) { fail_global(BSK_ERR_HIP, "libbsk: device allocation failed"); return nullptr; }
+    return p;
+}
+
+void bsk_device_free(void* p) {
+    if (p) hipFree(p);
+}
+
+int bsk_device_copy(void* dst, const void* src, size_t n, int kind) {
+    if (n == 0) return BSK_OK;
+    if (!dst || !src) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null pointer");
+    const hipMemcpyKind k = kind == BSK_COPY_H2D ? hipMemcpyHostToDevice : kind == BSK_COPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (kind < BSK_COPY_H2D || kind > BSK_COPY_D2D) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: bad copy kind");
+    if (hipMemcpy(dst, src, n, k) != hipSuccess) return fail_global(BSK_ERR_HIP, "libbsk: device copy failed");
+    return BSK_OK;
+}
+
 void* bsk_host_alloc(size_t n) {
     void* p = nullptr;
     if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr;

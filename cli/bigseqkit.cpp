@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../include/bsk.h"
+#include "../bigseqkit_amd/csrc/json.hpp"
 
 namespace {
 
@@ -195,20 +196,37 @@ void usage() {
                  "  --alphabet-guess-seq-length --infile-list --merge --partitions --order --device --dry-run\n";
 }
 
-}  // namespace
-
-int main(int argc, char** argv) {
-    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage(); return argc < 2; }
+// one parsed command line: `args[0]` is the command, the rest flags and input files
+struct Invocation {
     const Command* cmd = nullptr;
-    for (auto& c : kCommands)
-        if (!strcmp(argv[1], c.use)) cmd = &c;
-    if (!cmd) die(std::string("unknown command \"") + argv[1] + "\" for \"bigseqkit\"");
-
     Values val;
     std::vector<std::string> files;
-    for (int i = 2; i < argc; ++i) {
-        std::string a = argv[i];
-        if (a == "--") { for (int k = i + 1; k < argc; ++k) files.push_back(argv[k]); break; }
+    std::string js;  // option JSON of the operator
+    std::string pget(const char* name) const {
+        auto it = val.scalar.find(name);
+        if (it != val.scalar.end()) return it->second;
+        for (auto& f : kPersistent)
+            if (!strcmp(f.name, name)) return f.def;
+        if (cmd)
+            for (auto& f : cmd->flags)
+                if (!strcmp(f.name, name)) return f.def;
+        return "";
+    }
+};
+
+Invocation parse_invocation(const std::vector<std::string>& args) {
+    Invocation inv;
+    const int argc = (int)args.size();
+    auto argv = [&](int i) -> const std::string& { return args[(size_t)i]; };
+    for (auto& c : kCommands)
+        if (args[0] == c.use) inv.cmd = &c;
+    if (!inv.cmd) die(std::string("unknown command \"") + args[0] + "\" for \"bigseqkit\"");
+    const Command* cmd = inv.cmd;
+    Values& val = inv.val;
+    std::vector<std::string>& files = inv.files;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv(i);
+        if (a == "--") { for (int k = i + 1; k < argc; ++k) files.push_back(argv(k)); break; }
         if (a.size() < 2 || a[0] != '-' || a == "-") { files.push_back(a); continue; }
         std::vector<std::pair<const Flag*, std::string>> parsed;  // flag, inline value ("\x01" = none)
         if (a[1] == '-') {
@@ -242,7 +260,7 @@ int main(int argc, char** argv) {
             }
             if (v == "\x01") {
                 if (i + 1 >= argc) die(std::string("flag needs an argument: --") + f->name);
-                v = argv[++i];
+                v = argv(++i);
             }
             if (f->kind == SLICE) {
                 auto parts = split_csv(v);
@@ -310,7 +328,8 @@ int main(int argc, char** argv) {
         if (f.kind == STR) js += jquote(v);
         else js += v;
     };
-    std::string js = "{\"Config\":{";
+    std::string& js = inv.js;
+    js = "{\"Config\":{";
     bool first = true;
     for (auto& f : kPersistent) {
         if (strncmp(f.field, "Config.", 7)) continue;
@@ -336,30 +355,88 @@ int main(int argc, char** argv) {
                 if (!line.empty()) files.push_back(line);
         }
     }
-    const bool dry = pget("dry-run") == "true";
-    if (dry) {
-        std::cout << cmd->op << "\n" << js << "\n";
-        for (auto& f : files) std::cout << f << "\n";
-        return 0;
+    return inv;
+}
+
+// ---------------------------------------------------------------------------
+// execution: inputs are PARTS (the reference's dataframe partitions): the text of a file on the host, or the
+// device-resident output of an upstream command of a `pipe` job (it never leaves HBM)
+// ---------------------------------------------------------------------------
+struct Part {
+    int fmt = BSK_FORMAT_FASTA;
+    std::string host;        // file text (when dptr == nullptr)
+    void* dptr = nullptr;    // device text of `n` bytes
+    size_t n = 0;
+    bsk_ctx* owner = nullptr;  // context whose output buffer dptr is (destroyed with the part)
+    bool owned_alloc = false;  // dptr came from bsk_device_alloc
+    const void* ptr() const { return dptr ? dptr : (const void*)host.data(); }
+    size_t size() const { return dptr ? n : host.size(); }
+    int on_device() const { return dptr ? 1 : 0; }
+};
+
+void release(std::vector<Part>& parts) {
+    for (auto& p : parts) {
+        if (p.owner) bsk_destroy(p.owner);
+        else if (p.owned_alloc && p.dptr) bsk_device_free(p.dptr);
+        p.owner = nullptr; p.dptr = nullptr;
     }
-    if (files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
+    parts.clear();
+}
 
-    const int device = (int)strtol(pget("device").c_str(), nullptr, 10);
-    bsk_ctx* ctx = nullptr;
-    if (bsk_create(cmd->op, js.c_str(), device, &ctx) != BSK_OK) die(bsk_global_error());
+struct Output {
+    std::vector<Part> parts;  // FASTA / FASTQ records (device-resident when keep_on_device)
+    std::string text;         // everything else: stats table, grep -C count, locate rows, or the host copy of the records
+    bool is_text = false;     // `text` is the result (not record text)
+    int fmt = -1;             // format of the record text in `text` (-1: line oriented)
+};
 
-    const std::string use = cmd->use;
-    std::string out_text;  // records of all inputs, in input order (union, cli/helper.go:134-141)
-    std::string stats_head, stats_body;
-    uint64_t grep_total = 0;
-    const bool grep_count = use == "grep" && val.scalar.count("count") && val.scalar["count"] == "true";
-    for (size_t fi = 0; fi < files.size(); ++fi) {
-        const std::string data = read_file(files[fi]);
-        const int fmt = sniff_format(files[fi], data);
-        if (use == "stats") {
+int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, bsk_out* out) {
+    const void* p = in.ptr();
+    const size_t n = in.size();
+    const int dev = in.on_device();
+    if (use == "seq") return bsk_seq_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "grep") return bsk_grep_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "locate") return bsk_locate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "subseq") return bsk_subseq_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "translate") return bsk_translate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    return bsk_rmdup_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+}
+
+// keep_on_device: the caller is an inner node of a pipe job; record outputs stay in HBM (one context per part)
+Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_device) {
+    const std::string use = inv.cmd->use;
+    const std::string& js = inv.js;
+    const int device = (int)strtol(inv.pget("device").c_str(), nullptr, 10);
+    Output res;
+    // rmdup is global over the union of its inputs (bigseqkit/rmdup.go:97 groups the whole dataframe): one shard
+    if (use == "rmdup" && inputs.size() > 1) {
+        size_t total = 0;
+        for (auto& p : inputs) {
+            if (p.fmt != inputs[0].fmt) die("rmdup: inputs of different formats");
+            total += p.size();
+        }
+        Part all;
+        all.fmt = inputs[0].fmt;
+        all.dptr = bsk_device_alloc(total ? total : 1);
+        if (!all.dptr) die(bsk_global_error());
+        all.n = total;
+        all.owned_alloc = true;
+        size_t at = 0;
+        for (auto& p : inputs) {
+            if (p.size() && bsk_device_copy((char*)all.dptr + at, p.ptr(), p.size(), p.on_device() ? BSK_COPY_D2D : BSK_COPY_H2D) != BSK_OK)
+                die(bsk_global_error());
+            at += p.size();
+        }
+        release(inputs);
+        inputs.push_back(all);
+    }
+    if (use == "stats") {
+        std::string head, body;
+        for (size_t fi = 0; fi < inputs.size(); ++fi) {
+            const Part& in = inputs[fi];
             bsk_ctx* sc = nullptr;  // one Stats per input (cli/stats.go:16-21)
             if (bsk_create("Stats", js.c_str(), device, &sc) != BSK_OK) die(bsk_global_error());
-            if (bsk_stats_run(sc, data.data(), data.size(), 0, fmt, 0, nullptr, nullptr) != BSK_OK) die(bsk_last_error(sc));
+            if (bsk_stats_run(sc, in.ptr(), in.size(), in.on_device(), in.fmt, 0, nullptr, nullptr) != BSK_OK) die(bsk_last_error(sc));
             std::vector<int64_t> keys(1 << 20), vals(1 << 20);
             size_t n = 0;
             if (bsk_stats_collect(sc, nullptr, keys.data(), vals.data(), keys.size(), &n) != BSK_OK) die(bsk_last_error(sc));
@@ -370,60 +447,167 @@ int main(int argc, char** argv) {
             if (bsk_stats_string(sc, name.c_str(), "N/A", &info, buf.data(), buf.size()) != BSK_OK) die(bsk_last_error(sc));
             std::string table = buf.data();
             size_t nl = table.find('\n');
-            stats_head = table.substr(0, nl + 1);
-            stats_body += table.substr(nl + 1) + "\n";  // Join(lines[1:]) + "\n": a blank line per input, as written
+            head = table.substr(0, nl + 1);
+            body += table.substr(nl + 1) + "\n";  // Join(lines[1:]) + "\n": a blank line per input, as written
             bsk_destroy(sc);
-            continue;
         }
-        bsk_out out;
-        int rc;
-        const int64_t pid = (int64_t)fi;
-        if (use == "seq") rc = bsk_seq_run(ctx, data.data(), data.size(), 0, fmt, pid, nullptr, &out);
-        else if (use == "grep") rc = bsk_grep_run(ctx, data.data(), data.size(), 0, fmt, pid, nullptr, &out);
-        else if (use == "locate") rc = bsk_locate_run(ctx, data.data(), data.size(), 0, fmt, pid, nullptr, &out);
-        else if (use == "subseq") rc = bsk_subseq_run(ctx, data.data(), data.size(), 0, fmt, pid, nullptr, &out);
-        else if (use == "translate") rc = bsk_translate_run(ctx, data.data(), data.size(), 0, fmt, pid, nullptr, &out);
-        else rc = bsk_rmdup_run(ctx, data.data(), data.size(), 0, fmt, pid, nullptr, &out);
-        if (rc != BSK_OK) die(bsk_last_error(ctx));
-        if (grep_count) {
-            uint64_t c = 0;
-            bsk_grep_last_count(ctx, &c);
-            grep_total += c;
-            continue;
-        }
-        const size_t at = out_text.size();
-        out_text.resize(at + out.len);
-        if (bsk_out_to_host(ctx, &out, out_text.data() + at, out.len) != BSK_OK) die(bsk_last_error(ctx));
+        res.is_text = true;
+        res.text = head + body;
+        return res;
     }
-    if (use == "rmdup" && bsk_rmdup_finish(ctx) != BSK_OK) die(bsk_last_error(ctx));
-    bsk_destroy(ctx);
-    if (use == "stats") { std::cout << stats_head << stats_body; return 0; }
-    if (grep_count) { std::cout << grep_total; return 0; }  // fmt.Print: no newline (cli/grep.go:14)
+    const bool grep_count = use == "grep" && inv.pget("count") == "true";
+    const bool records_out = !(use == "locate" || grep_count);
+    uint64_t grep_total = 0;
+    bsk_ctx* ctx = nullptr;
+    auto fresh = [&]() {
+        bsk_ctx* c = nullptr;
+        if (bsk_create(inv.cmd->op, js.c_str(), device, &c) != BSK_OK) die(bsk_global_error());
+        return c;
+    };
+    if (!(keep_on_device && records_out)) ctx = fresh();
+    for (size_t fi = 0; fi < inputs.size(); ++fi) {
+        const Part& in = inputs[fi];
+        bsk_out out;
+        bsk_ctx* c = ctx ? ctx : fresh();
+        if (run_op(use, c, in, (int64_t)fi, &out) != BSK_OK) die(bsk_last_error(c));
+        if (use == "rmdup" && bsk_rmdup_finish(c) != BSK_OK) die(bsk_last_error(c));
+        if (grep_count) {
+            uint64_t cnt = 0;
+            bsk_grep_last_count(c, &cnt);
+            grep_total += cnt;
+            continue;
+        }
+        const int ofmt = use == "translate" ? BSK_FORMAT_FASTA : in.fmt;
+        if (!ctx) {  // device-resident part owned by its context
+            Part o;
+            o.fmt = ofmt;
+            o.dptr = out.d_data;
+            o.n = out.len;
+            o.owner = c;
+            res.parts.push_back(o);
+            continue;
+        }
+        res.fmt = use == "locate" ? -1 : ofmt;
+        const size_t at = res.text.size();
+        res.text.resize(at + out.len);
+        if (bsk_out_to_host(c, &out, res.text.data() + at, out.len) != BSK_OK) die(bsk_last_error(c));
+    }
+    if (ctx) bsk_destroy(ctx);
+    if (grep_count) { res.is_text = true; res.text = std::to_string(grep_total); }  // fmt.Print: no newline (cli/grep.go:14)
+    if (use == "locate") res.is_text = keep_on_device;  // rows cannot feed another command
+    return res;
+}
 
-    // ---- store (cli/helper.go:105-127)
-    std::string outp = pget("out-file");
+std::vector<Part> read_parts(const std::vector<std::string>& files) {
+    std::vector<Part> parts;
+    for (auto& f : files) {
+        Part p;
+        p.host = read_file(f);
+        p.fmt = sniff_format(f, p.host);
+        parts.push_back(std::move(p));
+    }
+    return parts;
+}
+
+// `pipe` job (bigseqkit-cli/pipe.go:12-40): {"pipe": [job, ...], "cmd": ["grep", "-s", ...]} -- the outputs of the
+// jobs under "pipe" become inputs of "cmd", ahead of the files named in it.  ("sh" hooks are not run.)
+Output run_job(const bsk::json::Value& j, bool root) {
+    std::vector<Part> inputs;
+    if (const auto* deps = j.get("pipe")) {
+        if (deps->kind == bsk::json::Value::Array)
+            for (auto& d : deps->arr) {
+                Output o = run_job(*d, false);
+                if (o.is_text) die("bad execution dependency");  // pipe.go:26-28: the job produced no dataframe
+                for (auto& p : o.parts) inputs.push_back(p);
+            }
+    }
+    const auto* cmd = j.get("cmd");
+    if (!cmd || cmd->kind != bsk::json::Value::Array || cmd->arr.empty()) die("incorrect job format");
+    std::vector<std::string> args;
+    for (auto& a : cmd->arr) args.push_back(a->str);
+    Invocation inv = parse_invocation(args);
+    for (auto& p : read_parts(inv.files)) inputs.push_back(std::move(p));
+    if (inputs.empty()) die("no input for job command " + args[0]);
+    Output o = execute(inv, inputs, !root);
+    release(inputs);
+    return o;
+}
+
+void store(const Invocation& inv, const Output& out, const std::vector<std::string>& files) {
+    if (out.is_text) { std::cout << out.text; return; }
+    const std::string& out_text = out.text;
+    // ---- cli/helper.go:105-127
+    std::string outp = inv.pget("out-file");
     if (outp.empty()) outp = files.size() == 1 ? files[0] + "-out" : (getenv("IGNIS_JOB_NAME") ? std::string(getenv("IGNIS_JOB_NAME")) + "-out" : std::string());
     if (outp.empty()) die("out file -o required");
-    if (outp == "-") { fwrite(out_text.data(), 1, out_text.size(), stdout); return 0; }
-    if (pget("merge") == "true") {  // StoreFASTX: one file
+    if (outp == "-") { fwrite(out_text.data(), 1, out_text.size(), stdout); return; }
+    if (inv.pget("merge") == "true") {  // StoreFASTX: one file
         std::ofstream f(outp, std::ios::binary);
         if (!f) die("cannot create " + outp);
         f.write(out_text.data(), (std::streamsize)out_text.size());
-        return 0;
+        return;
     }
-    // StoreFASTXN == SaveAsTextFile: a directory of part files (records never split)
-    long parts = strtol(pget("partitions").c_str(), nullptr, 10);
+    // StoreFASTXN == SaveAsTextFile: a directory of part files; a record is never split between two parts
+    long parts = strtol(inv.pget("partitions").c_str(), nullptr, 10);
     if (parts < 1) parts = 1;
     if (!is_dir(outp) && mkdir(outp.c_str(), 0755) != 0) die("cannot create directory " + outp);
     size_t pos = 0;
     for (long p = 0; p < parts; ++p) {
         size_t end = p + 1 == parts ? out_text.size() : out_text.size() * (size_t)(p + 1) / (size_t)parts;
-        while (end < out_text.size() && end > 0 && out_text[end - 1] != '\n') ++end;  // line granularity
+        if (end < pos) end = pos;
+        if (p + 1 < parts && end < out_text.size()) {
+            if (out.fmt >= 0) {  // next record start (the anchor rule of the library)
+                size_t cut = out_text.size();
+                if (bsk_find_record_start((const uint8_t*)out_text.data(), out_text.size(), end, out.fmt, &cut) == BSK_OK) end = cut;
+                else end = out_text.size();
+            } else {
+                while (end < out_text.size() && end > 0 && out_text[end - 1] != '\n') ++end;  // line granularity
+            }
+        }
         char nm[64];
         snprintf(nm, sizeof nm, "/part%05ld", p);
         std::ofstream f(outp + nm, std::ios::binary);
         f.write(out_text.data() + pos, (std::streamsize)(end - pos));
         pos = end;
     }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage(); return argc < 2; }
+    std::vector<std::string> args(argv + 1, argv + argc);
+    if (args[0] == "pipe") {
+        // bigseqkit pipe --job job.json [files...] [-o out] [--merge] ...   (bigseqkit-cli/pipe.go:42-67)
+        std::string job;
+        std::vector<std::string> rest{"seq"};  // the persistent flags are parsed with any command table
+        for (size_t i = 1; i < args.size(); ++i) {
+            if (args[i] == "--job" && i + 1 < args.size()) job = args[++i];
+            else if (args[i].rfind("--job=", 0) == 0) job = args[i].substr(6);
+            else rest.push_back(args[i]);
+        }
+        if (job.empty()) die("job not defined");
+        Invocation inv = parse_invocation(rest);
+        bsk::json::ValuePtr j;
+        try {
+            const std::string text = read_file(job);
+            j = bsk::json::Parser(text).parse();
+        } catch (const std::exception&) { die("incorrect job format"); }
+        Output o = run_job(*j, true);
+        // the files given to `pipe` itself are appended unchanged (pipe.go:61-66)
+        for (auto& p : read_parts(inv.files)) o.text += p.host;
+        store(inv, o, inv.files);
+        return 0;
+    }
+    Invocation inv = parse_invocation(args);
+    if (inv.pget("dry-run") == "true") {
+        std::cout << inv.cmd->op << "\n" << inv.js << "\n";
+        for (auto& f : inv.files) std::cout << f << "\n";
+        return 0;
+    }
+    if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
+    std::vector<Part> inputs = read_parts(inv.files);
+    Output o = execute(inv, inputs, false);
+    store(inv, o, inv.files);
     return 0;
 }

@@ -99,6 +99,17 @@ size_t bsk_stats_vector_len(const bsk_ctx* ctx);
  * kernels are reported by bsk_stats_collect(). */
 int bsk_stats_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* d_vec,
                   void* stream);
+/* Device-buffer plumbing for callers that do not link the HIP runtime themselves (the cgo shim, the C++ CLI):
+ * shards and operator outputs can be chained on the device (the output text of seq / grep / subseq / rmdup / translate
+ * is FASTA / FASTQ again) without a host round trip.  Buffers live on the current device of the calling thread
+ * (device 0 unless a context of another device ran last). */
+#define BSK_COPY_H2D 1
+#define BSK_COPY_D2H 2
+#define BSK_COPY_D2D 3
+void* bsk_device_alloc(size_t n);
+void bsk_device_free(void* p);
+int bsk_device_copy(void* dst, const void* src, size_t n, int kind); /* synchronous */
+
 /* Pinned (page-locked) host memory for host-resident shards: read the file into such a buffer and the H2D copies of
  * bsk_stats_run(on_device = 0) are DMA at PCIe rate, overlapped with the kernels chunk by chunk (256 MiB record-aligned
  * chunks, two device buffers; BSK_STAGE_BYTES overrides the chunk size).  NULL when the allocation fails. */

@@ -159,3 +159,55 @@ def test_cli_sniffs_format_from_first_byte_and_reports_kernel_errors(tmp_path):
     assert r.returncode == 1 and b"must be fasta or fastq" in r.stderr
     r = run("grep", p, ok=False)
     assert r.returncode == 1 and b"one of flags -p (--pattern) and -f (--pattern-file) needed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_pipe_chains_commands_in_hbm(tmp_path):
+    """`pipe --job job.json` (bigseqkit-cli/pipe.go): outputs of the jobs under "pipe" feed "cmd" without leaving HBM.
+    seq (length filter) -> grep -s -> rmdup -s, plus a second branch, checked against the oracle applied step by step."""
+    rng = random.Random(31)
+    recs = []
+    for i in range(600):
+        s = "".join(rng.choice("ACGT") for _ in range(rng.randint(20, 200)))
+        if i % 4 == 0 and i > 8:
+            s = recs[rng.randrange(len(recs))][1]
+        recs.append((f"r{i} d", s))
+    fq1 = "".join(f"@{n}\n{s}\n+\n{'I' * len(s)}\n" for n, s in recs[:350]).encode()
+    fq2 = "".join(f"@{n}\n{s}\n+\n{'I' * len(s)}\n" for n, s in recs[350:]).encode()
+    a, b = _write(tmp_path, "a.fq", fq1), _write(tmp_path, "b.fq", fq2)
+    job = {"pipe": [{"pipe": [{"cmd": ["seq", "-m", "60", a]}], "cmd": ["grep", "-s", "-p", "ACG"]},
+                    {"cmd": ["seq", "-M", "120", b]}],
+           "cmd": ["rmdup", "-s"]}
+    jf = tmp_path / "job.json"
+    jf.write_text(json.dumps(job))
+    got = run("pipe", "--job", str(jf), "-o", "-").stdout
+    o_seq = json.dumps(dry("seq", "-m", "60")[1])
+    o_grep = json.dumps(dry("grep", "-s", "-p", "ACG")[1])
+    o_seq2 = json.dumps(dry("seq", "-M", "120")[1])
+    o_rm = json.dumps(dry("rmdup", "-s")[1])
+    step1 = oracle.grep(oracle.seq(fq1, True, o_seq), True, o_grep)
+    step2 = oracle.seq(fq2, True, o_seq2)
+    want = oracle.rmdup(step1 + step2, True, o_rm)
+    assert got == want and 0 < len(want) < len(fq1) + len(fq2)
+    # a stats table at the end of a chain
+    job2 = {"pipe": [{"cmd": ["seq", "-m", "60", a]}], "cmd": ["stats", "-T"]}
+    jf.write_text(json.dumps(job2))
+    t = oracle.stats_string(oracle.seq(fq1, True, o_seq), True, json.dumps(dry("stats", "-T")[1]), name="input0")
+    assert run("pipe", "--job", str(jf)).stdout.decode() == t.split("\n")[0] + "\n" + "\n".join(t.split("\n")[1:]) + "\n"
+
+
+@pytest.mark.gpu
+def test_cli_rmdup_is_global_over_several_input_files_and_parts_never_split_records(tmp_path):
+    rng = random.Random(32)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(30, 90))) for _ in range(200)]
+    f1 = "".join(f"@a{i}\n{s}\n+\n{'@' * len(s)}\n" for i, s in enumerate(seqs)).encode()
+    f2 = "".join(f"@b{i}\n{s}\n+\n{'@' * len(s)}\n" for i, s in enumerate(seqs[::2])).encode()   # all duplicates of file 1
+    a, b = _write(tmp_path, "a.fq", f1), _write(tmp_path, "b.fq", f2)
+    out = tmp_path / "o"
+    run("rmdup", "-s", a, b, "-o", str(out), "--partitions", "4")
+    parts = sorted(os.listdir(out))
+    assert len(parts) == 4
+    texts = [open(os.path.join(out, p), "rb").read() for p in parts]
+    assert b"".join(texts) == f1                     # every record of b.fq is a duplicate of one in a.fq
+    for t in texts:                                  # quality lines start with '@': a line-based cut would split records
+        assert t == b"" or (t.startswith(b"@a") and oracle.is_strict_4line_fastq(t))
