@@ -122,3 +122,36 @@ def rmdup_distributed(shard, fmt, backend, group=None):
     reply = torch.empty(n, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(reply, keep, in_splits, out_splits, group=group)
     return backend.emit(send, reply, base)
+
+
+def store_fastx(path, payload, group=None):
+    """StoreFASTX (`--merge`, one output file) across ranks.  The reference's FileStore passes an MPI token from
+    executor to executor so that partitions append in order (bigseqkit-lib/helper.go:378-460); here every rank learns
+    its byte offset from one all_gather of the payload sizes and writes its part with a single pwrite -- all ranks
+    write concurrently, the file equals the single-GPU output (rank order == file order)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        with open(path, "wb") as f:
+            f.write(payload)
+        return len(payload)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(payload)], dtype=torch.int64), group=group)
+    sizes = [int(s.item()) for s in sizes]
+    total, off = sum(sizes), sum(sizes[:rank])
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.truncate(total)
+    dist.barrier(group=group)
+    fd = os.open(path, os.O_WRONLY)
+    try:
+        done = 0
+        while done < len(payload):
+            done += os.pwrite(fd, payload[done:], off + done)
+    finally:
+        os.close(fd)
+    dist.barrier(group=group)
+    return total

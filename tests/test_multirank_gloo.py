@@ -114,7 +114,7 @@ def test_shard_bounds_are_record_aligned_and_cover_the_file():
 
 
 # ---------------------------------------------------------------- rmdup: the one command with an exchange step
-def _rmdup_worker(rank, world, port, data, opts, q):
+def _rmdup_worker(rank, world, port, data, opts, q, store=None):
     import torch
     import torch.distributed as dist
     from rmdup_cpu_backend import OracleRmDupBackend
@@ -125,13 +125,15 @@ def _rmdup_worker(rank, world, port, data, opts, q):
         lo, hi = bdist.shard_bounds(data, world, bsk.FORMAT_FASTQ)[rank]
         shard = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.empty(0, dtype=torch.uint8)
         out = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts))
+        if store:
+            bdist.store_fastx(store, out)   # scan of sizes + one pwrite per rank (FileStore's ordered single-file merge)
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("opts", [{"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}])
-def test_two_ranks_gloo_rmdup_exchange(opts):
+def test_two_ranks_gloo_rmdup_exchange(opts, tmp_path):
     """all_gather(counts) + all_to_all(tuples) + all_to_all(keep bytes): the concatenated per-rank survivors equal the
     single-shard result, i.e. the first occurrence in FILE order survives even when it lives on the other rank."""
     import torch.multiprocessing as mp
@@ -147,7 +149,8 @@ def test_two_ranks_gloo_rmdup_exchange(opts):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rmdup_worker, args=(r, 2, port, data, opts, q)) for r in range(2)]
+    merged = str(tmp_path / "merged.fq")
+    procs = [ctx.Process(target=_rmdup_worker, args=(r, 2, port, data, opts, q, merged)) for r in range(2)]
     for p in procs:
         p.start()
     outs = dict(q.get(timeout=120) for _ in range(2))
@@ -157,3 +160,4 @@ def test_two_ranks_gloo_rmdup_exchange(opts):
     want = oracle.rmdup(data, True, json.dumps(opts))
     assert outs[0] + outs[1] == want
     assert 0 < len(want) < len(data)
+    assert open(merged, "rb").read() == want
