@@ -719,7 +719,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     if (rc != BSK_OK) return rc;
     SeqParams P = format_params(c, fastq);
     P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -1121,7 +1121,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -1420,7 +1420,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, c->table, tt, P, c->d_keys, st));
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
     HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
     HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
     uint64_t total = 0, kept = 0;
@@ -1438,7 +1438,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return rc;
     SeqParams F = format_params(c, fastq);
     F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st));
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -1548,7 +1548,7 @@ int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     if (rc != BSK_OK) return rc;
     rc = grow(c, &c->d_keys2, &c->keys2_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_rmdup_hash2(d_buf, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
     return kernel_error_to_status(c, status);
@@ -1610,7 +1610,7 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     if (rc != BSK_OK) return rc;
     SeqParams F = format_params(c, fastq);
     if (!fastq) { F.text_w = c->table.text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
-    HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st));
+    HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -1716,7 +1716,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st));
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;

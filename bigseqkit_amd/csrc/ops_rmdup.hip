@@ -108,11 +108,122 @@ __device__ uint64_t xxh64_subject(const Subject& s, uint64_t seed = 0) {
     return h;
 }
 
-__global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
-                                                    RmDupParams P, uint64_t* __restrict__ keys) {
+// ---------------------------------------------------------------------------
+// Short subjects (reads, IDs): one lane per record reading its own subject 8 bytes at a time touches 64 different
+// cache lines per load instruction.  Instead the wave first copies the 64 subjects into LDS with 16-byte loads that
+// are contiguous inside a record (16 lanes per record, 4 records per step), then every lane hashes its subject from
+// LDS.  Slots are 164 bytes apart (41 dwords, odd: the 64 lanes hit 64 different banks).
+// ---------------------------------------------------------------------------
+constexpr uint64_t SEED2 = 0x9E3779B97F4A7C15ull;  // seed of the second key (multi-GPU verification)
+constexpr uint32_t STAGE_MAX = 160;   // longest subject staged
+constexpr uint32_t STAGE_STRIDE = 164;
+
+struct LdsSubject {
+    const uint8_t* p;  // LDS
+    uint32_t len;
+    bool fold;
+    __device__ __forceinline__ uint8_t at(uint32_t i) const { const uint8_t c = p[i]; return fold ? lower8(c) : c; }
+    __device__ __forceinline__ uint64_t word64(uint32_t i) const {  // i is a multiple of 8
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p + i);
+        uint32_t lo = w[0], hi = w[1];
+        if (fold) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v |= (uint64_t)lower8((uint8_t)(lo >> (8 * k))) << (8 * k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v |= (uint64_t)lower8((uint8_t)(hi >> (8 * k))) << (32 + 8 * k);
+            return v;
+        }
+        return ((uint64_t)hi << 32) | lo;
+    }
+};
+
+__device__ uint64_t xxh64_lds(const LdsSubject& s, uint64_t seed) {
+    const uint32_t len = s.len;
+    uint32_t p = 0;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = xround(v1, s.word64(p));
+            v2 = xround(v2, s.word64(p + 8));
+            v3 = xround(v3, s.word64(p + 16));
+            v4 = xround(v4, s.word64(p + 24));
+            p += 32;
+        } while (p + 32 <= len);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= len) { h ^= xround(0, s.word64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= len) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; ++k) w |= (uint32_t)s.at(p + k) << (8 * k);
+        h ^= (uint64_t)w * P1;
+        h = rotl64(h, 23) * P2 + P3;
+        p += 4;
+    }
+    while (p < len) { h ^= (uint64_t)s.at(p) * P5; h = rotl64(h, 11) * P1; ++p; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// copy the subjects of the wave's 64 records into `slot` (64 x STAGE_STRIDE bytes of LDS); false = not applicable
+__device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_end, uint8_t* slot) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool contiguous = s.seq ? s.T.W == 0 : true;
+    const bool ok = !live || (contiguous && s.len <= STAGE_MAX);
+    if (__ballot(ok) != ~0ull) return false;
+    const uint8_t* src = s.seq ? s.T.p : s.h;
+    const uint64_t a = (uint64_t)(uintptr_t)src;
+    const uint32_t q = lane >> 4, gl = lane & 15u;
+    for (uint32_t j = 0; j < 16u; ++j) {
+        const int r = (int)(4u * j + q);
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a, r, 64), hi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), r, 64);
+        const uint32_t len_r = (uint32_t)__shfl((int)(live ? s.len : 0u), r, 64);
+        const uint8_t* pr = (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+        const uint32_t off = gl * 16u;
+        if (off < len_r) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (pr + off + 16 <= buf_end) {
+                uint4 v;
+                __builtin_memcpy(&v, pr + off, 16);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+                for (uint32_t b = 0; off + b < len_r; ++b) w[b >> 2] |= (uint32_t)pr[off + b] << (8 * (b & 3));
+            }
+            uint32_t* d = reinterpret_cast<uint32_t*>(slot + (uint32_t)r * STAGE_STRIDE + off);
+            d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+                                                    RmDupParams P, uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][64 * STAGE_STRIDE];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.n) return;
-    keys[i] = xxh64_subject(subject_of(buf, t, tt, P, i));
+    const bool live = i < t.n;
+    const Subject s = subject_of(buf, t, tt, P, live ? i : 0);
+    uint8_t* slot = s_stage[threadIdx.x >> 6];
+    uint64_t k1, k2 = 0;
+    if (stage_subjects(s, live, buf + buf_n, slot)) {
+        LdsSubject ls{slot + (threadIdx.x & 63u) * STAGE_STRIDE, s.len, s.fold};
+        k1 = xxh64_lds(ls, 0);
+        if (keys2) k2 = xxh64_lds(ls, SEED2);
+    } else {
+        k1 = xxh64_subject(s, 0);
+        if (keys2) k2 = xxh64_subject(s, SEED2);
+    }
+    if (live) {
+        keys[i] = k1;
+        if (keys2) keys2[i] = k2;
+    }
 }
 
 __device__ __forceinline__ uint64_t slot_key(uint64_t k) { return k ? k : 0x9E3779B97F4A7C15ull; }  // 0 == empty
@@ -240,17 +351,6 @@ __global__ __launch_bounds__(256) void k_rmdup_rows(const uint8_t* __restrict__ 
 //                     keys carry equal second keys (else ERR_HASH_COLLISION); reply = one keep byte per tuple
 //   k_rmdup_apply   : the sender turns the reply into the per-record output sizes
 // ---------------------------------------------------------------------------
-constexpr uint64_t SEED2 = 0x9E3779B97F4A7C15ull;
-
-__global__ __launch_bounds__(256) void k_rmdup_hash2(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
-                                                     RmDupParams P, uint64_t* __restrict__ keys,
-                                                     uint64_t* __restrict__ keys2) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.n) return;
-    const Subject s = subject_of(buf, t, tt, P, i);
-    keys[i] = xxh64_subject(s, 0);
-    keys2[i] = xxh64_subject(s, SEED2);
-}
 
 __global__ __launch_bounds__(256) void k_rmdup_count_owner(const uint64_t* __restrict__ keys, uint64_t n, uint32_t world,
                                                            unsigned long long* __restrict__ counts) {
@@ -333,11 +433,11 @@ __global__ __launch_bounds__(256) void k_rmdup_apply(RecordTable t, RmDupParams 
 
 }  // namespace
 
-hipError_t launch_rmdup_hash(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
-                             uint64_t* keys, hipStream_t st) {
+hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
+                             const RmDupParams& P, uint64_t* keys, uint64_t* keys2, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    hipLaunchKernelGGL(k_rmdup_hash, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys);
+    hipLaunchKernelGGL(k_rmdup_hash, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, keys, keys2);
     return hipGetLastError();
 }
 
@@ -380,14 +480,6 @@ hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmD
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_rmdup_rows, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, P, group, row_len,
                        row_off, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_rmdup_hash2(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
-                              uint64_t* keys, uint64_t* keys2, hipStream_t st) {
-    if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    hipLaunchKernelGGL(k_rmdup_hash2, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys, keys2);
     return hipGetLastError();
 }
 

@@ -19,8 +19,9 @@ struct RmDupParams {  // RmDupPrepare / RmDupCheck options (bigseqkit-lib/rmdup.
 
 constexpr uint32_t ERR_HASH_COLLISION = 512u;
 
-hipError_t launch_rmdup_hash(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
-                             uint64_t* keys, hipStream_t st);
+// keys[i] = XXH64(subject i, seed 0); keys2 (may be null) = the same with another seed (multi-GPU verification key)
+hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
+                             const RmDupParams& P, uint64_t* keys, uint64_t* keys2, hipStream_t st);
 // table_keys / table_first: `cap` slots (power of two), zero / 0xFF initialised by the caller
 hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table_keys,
                                uint64_t* table_first, uint64_t cap, hipStream_t st);
@@ -38,8 +39,6 @@ hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmD
                              const uint32_t* row_len, const uint64_t* row_off, uint8_t* out, hipStream_t st);
 
 // multi-GPU rmdup: tuples (key, second key, global index) routed to owner = key % world (ops_rmdup.hip)
-hipError_t launch_rmdup_hash2(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
-                              uint64_t* keys, uint64_t* keys2, hipStream_t st);
 hipError_t launch_rmdup_count_owner(const uint64_t* keys, uint64_t n, uint32_t world, uint64_t* counts, hipStream_t st);
 hipError_t launch_rmdup_pack(const uint64_t* keys, const uint64_t* keys2, uint64_t n, uint64_t base, uint32_t world,
                              uint64_t* cursor, uint64_t* send, hipStream_t st);

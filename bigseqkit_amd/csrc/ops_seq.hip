@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
     if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
 }
 
-constexpr int GROUP = 16;
-
+// GROUP lanes per record: 16 for long records, 4 when the average output record is small (a 16-lane group would sit
+// idle on a 120-byte `subseq` record or a 317-byte read: 4x the waves for the same bytes)
+template <int GROUP>
 __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
                                                   const uint32_t* __restrict__ out_len,
                                                   const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
@@ -391,10 +392,17 @@ hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqPa
 }
 
 hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& P, const uint32_t* out_len,
-                           const uint64_t* out_off, uint8_t* out, hipStream_t st) {
+                           const uint64_t* out_off, uint8_t* out, hipStream_t st, uint64_t total_bytes, uint64_t records) {
     if (t.n == 0) return hipSuccess;
-    const uint64_t blocks = (t.n * GROUP + 255) / 256;
-    hipLaunchKernelGGL(k_seq_emit, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
+    // tiny records (names only) are written by the per-byte path: one pass of 16 lanes beats three of 4
+    const bool small = records > 0 && total_bytes / records < 1024 && total_bytes / records >= 48;
+    if (small) {
+        const uint64_t blocks = (t.n * 4 + 255) / 256;
+        hipLaunchKernelGGL(k_seq_emit<4>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
+    } else {
+        const uint64_t blocks = (t.n * 16 + 255) / 256;
+        hipLaunchKernelGGL(k_seq_emit<16>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
+    }
     return hipGetLastError();
 }
 

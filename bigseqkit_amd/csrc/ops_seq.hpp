@@ -72,8 +72,10 @@ inline void sub_location(uint32_t length, int start, int end, uint32_t* b, uint3
 
 hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqParams& P, uint32_t* out_len,
                            uint64_t* status, hipStream_t st);
+// total_bytes / records (of the output, when known) pick the lanes per record: 4 for small records, else 16
 hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& P, const uint32_t* out_len,
-                           const uint64_t* out_off, uint8_t* out, hipStream_t st);
+                           const uint64_t* out_off, uint8_t* out, hipStream_t st, uint64_t total_bytes = 0,
+                           uint64_t records = 0);
 hipError_t launch_count_nonzero(const uint32_t* v, uint64_t n, uint64_t* counter, hipStream_t st);
 
 }  // namespace bsk
