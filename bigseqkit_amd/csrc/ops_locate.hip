@@ -233,11 +233,12 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     uint32_t nrows = 0;
     uint8_t* o = EMIT ? out + out_off[gi] : nullptr;
     const int nstr = P.both_strands ? 2 : 1;
-    const int niter = P.npat * nstr;
-    for (int it = 0; it < niter; ++it) {
-        // reference loop order: per pattern both strands (locate.go:575-767); FM-index branch: per strand all patterns
-        const int k = P.fmi_order ? it % P.npat : it / nstr;
-        const int strand = P.fmi_order ? it / P.npat : it % nstr;
+    // reference loop order: per pattern both strands (locate.go:575-767); FM-index branch: per strand all patterns
+    const int n_outer = P.fmi_order ? nstr : P.npat, n_inner = P.fmi_order ? P.npat : nstr;
+    for (int lo_ = 0; lo_ < n_outer; ++lo_)
+    for (int li_ = 0; li_ < n_inner; ++li_) {
+        const int k = P.fmi_order ? li_ : lo_;
+        const int strand = P.fmi_order ? lo_ : li_;
         R.name = P.name + P.name_off[k];
         R.name_len = P.name_off[k + 1] - P.name_off[k];
         R.pat = P.pat + P.pat_off[k];
@@ -268,21 +269,22 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
             const bool fastp = !GEN && !P.non_greedy && !P.circular && T.W == 0 && T.p >= buf && T.p < buf + buf_n;
             if (fastp) {
                 const uint8_t* const buf_end = buf + buf_n;
-                for (uint64_t a0 = 0; a0 < npos; a0 += GROUP * 16) {
-                    const uint64_t ib = a0 + (uint64_t)gl * 16u;  // first position of this lane, strand frame
+                const uint32_t npos32 = (uint32_t)npos, n32 = (uint32_t)n;  // not circular: n == l < 2^32
+                for (uint32_t a0 = 0; a0 < npos32; a0 += GROUP * 16) {
+                    const uint32_t ib = a0 + gl * 16u;  // first position of this lane, strand frame
                     uint32_t hits = 0;                           // bit k <-> position ib + k (ascending)
-                    if (ib < npos) {
+                    if (ib < npos32) {
                         if (strand == 0) {
                             hits = window_hits(T.p + ib, buf_end, P.ignore_case, pp, m);
-                        } else if (ib + 15u + m <= n) {
+                        } else if (ib + 15u + m <= n32) {
                             // forward window [n-m-ib-15, n-m-ib]: bit b is position ib + 15 - b
-                            const uint32_t h = window_hits(T.p + (n - m - ib - 15u), buf_end, P.ignore_case, pp, m);
+                            const uint32_t h = window_hits(T.p + (n32 - m - ib - 15u), buf_end, P.ignore_case, pp, m);
                             hits = __brev(h) >> 16;
                         } else {
-                            for (uint32_t k2 = 0; k2 < 16u && ib + k2 < npos; ++k2)
-                                if (match_at(T, l, P.ignore_case, pp, m, n - (ib + k2) - m)) hits |= 1u << k2;
+                            for (uint32_t k2 = 0; k2 < 16u && ib + k2 < npos32; ++k2)
+                                if (match_at(T, l, P.ignore_case, pp, m, n32 - (ib + k2) - m)) hits |= 1u << k2;
                         }
-                        const uint64_t left = npos - ib;
+                        const uint32_t left = npos32 - ib;
                         if (left < 16u) hits &= (1u << left) - 1u;
                     }
                     const uint32_t gmask = (uint32_t)((__ballot(hits != 0) >> gshift) & 0xFFFFull);

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void k_translate_frames4(const uint8_t* __rest
     // unknown codon == a 0 byte among the existing residues.  Every real residue ('*', 'A'..'Z') has bit 5 or bit 6
     // set, so bit 6 of (pk | pk << 1) is 1 for a residue and 0 for the unknown marker: AND-accumulate that bit.
     uint32_t andacc = 0xFFFFFFFFu;
+    const bool wide = lw == 0u || lw >= 4u;  // put4 assumes at most one line break among four residues
     const uint32_t g4 = 4u * G;
     const uint32_t gd = lw ? g4 / lw : 0u, gm = lw ? g4 % lw : 0u;
     // forward cursor (shared by the forward frames): first residue of the lane's group of four
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void k_translate_frames4(const uint8_t* __rest
                     if (interior) andacc &= pk | (pk << 1);
                     else andacc &= pk | (pk << 1) | (nv >= 4u ? 0u : ~((1u << (8 * nv)) - 1u));
                     uint8_t* body = out + fb[c];
-                    if ((uint64_t)sb / 3u + g4 <= fk[c]) put4(body + fj + fo, pk, lw ? lw - fc : 4u);
+                    if (wide && (uint64_t)sb / 3u + g4 <= fk[c]) put4(body + fj + fo, pk, lw ? lw - fc : 4u);
                     else put4_edge(body, (int64_t)fj, pk, lw, fk[c], fo, fc);
                 }
                 if (rb[c] != NONE) {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256) void k_translate_frames4(const uint8_t* __rest
                     uint8_t* body = out + rb[c];
                     // lane 0 holds the highest residues of the step, lane G-1 the lowest
                     const int64_t hi0 = rj[c] + 4 * (int64_t)gl + 3, lo0 = hi0 - 4 * (int64_t)G + 1;
-                    if (lo0 >= 0 && (uint64_t)hi0 < rk[c]) put4(body + rj[c] + ro[c], pk, lw ? lw - rcc[c] : 4u);
+                    if (wide && lo0 >= 0 && (uint64_t)hi0 < rk[c]) put4(body + rj[c] + ro[c], pk, lw ? lw - rcc[c] : 4u);
                     else put4_edge(body, rj[c], pk, lw, rk[c], ro[c], rcc[c]);
                 }
             }

@@ -1,0 +1,179 @@
+"""Randomised cross-check of every command against the oracle: random small FASTA / FASTQ inputs with awkward
+features (empty sequences, no final newline, '>' and '@' inside headers and quality lines, mixed case, IUPAC letters,
+every kind of line wrapping) x random option combinations.  Either both sides produce the same bytes or both fail."""
+import json
+import random
+
+import pytest
+
+import oracle
+import bigseqkit_amd as bsk
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(data):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    return t.cuda()
+
+
+class _Opts:
+    def __init__(self, d):
+        self.d = dict(d)
+        self._v = self.d
+
+    def to_json(self):
+        return json.dumps(self.d)
+
+
+def rand_seq(rng, L, alphabet):
+    return "".join(rng.choice(alphabet) for _ in range(L))
+
+
+def rand_fasta(rng):
+    alphabet = rng.choice(["ACGT", "ACGTN", "ACGTacgt", "ACGTRYKMSWN", "ACGUacgu"])
+    style = rng.choice(["w60", "w1line", "w17", "w7", "irregular", "mixed"])
+    recs = []
+    for k in range(rng.randint(1, 60)):
+        L = rng.choice([0, 1, 2, 3, 15, 16, 17, 59, 60, 61, 120, rng.randint(0, 400), rng.randint(0, 2000)])
+        s = rand_seq(rng, L, alphabet)
+        st = style if style != "mixed" else rng.choice(["w60", "w1line", "w17", "w7", "irregular"])
+        if st == "irregular":
+            lines, j = [], 0
+            while j < L:
+                w = rng.randint(1, 70)
+                lines.append(s[j:j + w])
+                j += w
+        else:
+            w = {"w60": 60, "w1line": max(1, L), "w17": 17, "w7": 7}[st]
+            lines = [s[j:j + w] for j in range(0, L, w)]
+        name = f"s{k}" + rng.choice(["", " desc", "\tx y", " a>b", "  two  spaces", "|gi|123|ref| z"])
+        recs.append(f">{name}\n" + "".join(l + "\n" for l in lines))
+    data = "".join(recs)
+    if rng.random() < 0.3 and data.endswith("\n"):
+        data = data[:-1]
+    return data.encode()
+
+
+def rand_fastq(rng):
+    alphabet = rng.choice(["ACGT", "ACGTN", "ACGTacgtN"])
+    recs = []
+    for k in range(rng.randint(1, 80)):
+        L = rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 150, rng.randint(0, 300)])
+        s = rand_seq(rng, L, alphabet)
+        q = "".join(chr(rng.randint(33, 74)) for _ in range(L))
+        if L and rng.random() < 0.3:
+            q = rng.choice("@+") + q[1:]
+        name = f"r{k % 50}" + rng.choice(["", " d", " @x +y", "\tt"])
+        recs.append(f"@{name}\n{s}\n+{name if rng.random() < 0.1 else ''}\n{q}\n")
+    data = "".join(recs)
+    if rng.random() < 0.3:
+        data = data[:-1]
+    return data.encode()
+
+
+def rand_opts(rng, op, fastq):
+    cfg = {"LineWidth": rng.choice([60, 0, 1, 13, 70])}
+    if rng.random() < 0.15:
+        cfg["IDNCBI"] = True
+    o = {"Config": cfg}
+    pat = lambda: rand_seq(rng, rng.randint(1, 8), "ACGT")
+    if op == "seq":
+        for k in ("Reverse", "Complement", "OnlyId", "LowerCase", "UpperCase", "RemoveGaps", "Dna2rna", "Rna2dna"):
+            if rng.random() < 0.25:
+                o[k] = True
+        r = rng.random()
+        if r < 0.15: o["Name"] = True
+        elif r < 0.3: o["Seq"] = True
+        elif r < 0.4 and fastq: o["Qual"] = True
+        if rng.random() < 0.3: o["MinLen"] = rng.randint(0, 100)
+        if rng.random() < 0.3: o["MaxLen"] = rng.randint(50, 400)
+        if fastq and rng.random() < 0.3: o["MinQual"] = rng.choice([5.0, 15.0, 20.5])
+    elif op == "grep":
+        mode = rng.choice(["id", "name", "seq", "seq", "deg", "mm", "re", "re_seq"])
+        if mode == "id": o["Pattern"] = [f"s{rng.randint(0, 30)}", f"r{rng.randint(0, 30)}"]
+        elif mode == "name": o.update(Pattern=[f"s{rng.randint(0, 9)} desc", f"r{rng.randint(0, 9)} d"], ByName=True)
+        elif mode == "seq": o.update(Pattern=[pat(), pat()], BySeq=True)
+        elif mode == "deg": o.update(Pattern=[rand_seq(rng, rng.randint(2, 7), "ACGTNRY")], Degenerate=True)
+        elif mode == "mm": o.update(Pattern=[rand_seq(rng, rng.randint(4, 9), "ACGT")], MaxMismatch=rng.randint(1, 2))
+        elif mode == "re": o.update(Pattern=[rng.choice(["^s[0-9]$", "1$", "^r\\d\\d", "s(1|2)+"])], UseRegexp=True, ByName=rng.random() < 0.5)
+        else: o.update(Pattern=[rng.choice(["AC+G", "^A.*T$", "(AC|GT){2}", "T[AG]A"])], UseRegexp=True, BySeq=True)
+        for k in ("InvertMatch", "IgnoreCase", "OnlyPositiveStrand"):
+            if rng.random() < 0.3:
+                o[k] = True
+        if o.get("OnlyPositiveStrand") and not (o.get("BySeq") or o.get("Degenerate") or o.get("MaxMismatch")):
+            o.pop("OnlyPositiveStrand")
+        if (o.get("BySeq") or o.get("Degenerate") or o.get("MaxMismatch")) and rng.random() < 0.3:
+            o["Circular"] = True
+        if (o.get("BySeq") or o.get("Degenerate")) and rng.random() < 0.25:
+            o["Region"] = rng.choice(["1:20", "-30:-1", "5:-5", "100:200"])
+    elif op == "locate":
+        mode = rng.choice(["exact", "exact", "deg", "mm", "fmi"])
+        o["Pattern"] = [rand_seq(rng, rng.randint(1, 6), "ACGT") for _ in range(rng.randint(1, 3))]
+        if mode == "deg": o.update(Pattern=[rand_seq(rng, rng.randint(2, 6), "ACGTNRYW")], Degenerate=True)
+        elif mode == "mm": o.update(Pattern=[rand_seq(rng, rng.randint(4, 8), "ACGT")], MaxMismatch=1)
+        elif mode == "fmi": o["UseFmi"] = True
+        for k in ("IgnoreCase", "OnlyPositiveStrand", "NonGreedy", "Circular", "HideMatched"):
+            if rng.random() < 0.3:
+                o[k] = True
+        r = rng.random()
+        if r < 0.15: o["Gtf"] = True
+        elif r < 0.3: o["Bed"] = True
+    elif op == "subseq":
+        o["Region"] = rng.choice(["1:1", "2:-2", "-10:-1", "1:100", "50:60", "-3:-9", "7:7"])
+    elif op == "translate":
+        o["Frame"] = rng.choice([["1"], ["6"], ["2", "-1"], ["-3"], ["3", "1", "-2"]])
+        o["TranslTable"] = rng.choice([1, 2, 4, 11])
+        o["AllowUnknownCodon"] = rng.random() < 0.8
+        for k in ("Trim", "Clean", "InitCodonAsM", "AppendFrame"):
+            if rng.random() < 0.3:
+                o[k] = True
+    elif op == "rmdup":
+        r = rng.random()
+        if r < 0.5: o["BySeq"] = True
+        elif r < 0.7: o["ByName"] = True
+        if rng.random() < 0.3: o["IgnoreCase"] = True
+    return o
+
+
+OPS = {"seq": (oracle.seq, bsk.Seq), "grep": (oracle.grep, bsk.Grep), "locate": (oracle.locate, bsk.Locate),
+       "subseq": (oracle.subseq, bsk.Subseq), "translate": (oracle.translate, bsk.Translate),
+       "rmdup": (oracle.rmdup, bsk.RmDup)}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "12"))))
+def test_fuzz_every_command(seed, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(5000 + seed)
+    agree = errors = 0
+    for it in range(60):
+        op = rng.choice(list(OPS))
+        fastq = rng.random() < 0.5
+        data = rand_fastq(rng) if fastq else rand_fasta(rng)
+        if op == "translate" and rng.random() < 0.8:
+            data = data.replace(b"-", b"A")
+        opts = rand_opts(rng, op, fastq)
+        fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+        ofn, gfn = OPS[op]
+        try:
+            want = ofn(data, fastq, json.dumps(opts))
+            werr = None
+        except oracle.OracleError as e:
+            want, werr = None, str(e)
+        try:
+            got = gfn(bsk.SeqFrame(fmt, [dev(data)]), _Opts(opts))
+            gerr = None
+        except bsk.BskError as e:
+            got, gerr = None, str(e)
+        ctx = (op, fastq, opts, data[:300])
+        if werr is not None or gerr is not None:
+            # both fail, or the HIP path declines something it documents as unsupported -- never a different answer
+            assert gerr is not None, ("oracle failed, HIP path answered", werr, ctx)
+            if werr is None:
+                assert "not supported" in gerr or "not accepted" in gerr or "libbsk" in gerr, (gerr, ctx)
+            errors += 1
+            continue
+        assert got == want, ctx
+        agree += 1
+    assert agree > 30
