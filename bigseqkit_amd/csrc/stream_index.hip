@@ -183,8 +183,17 @@ struct IndexSink {
     }
 };
 
+#ifndef BSK_INDEX_WAVES
+#define BSK_INDEX_WAVES 0
+#endif
+#if BSK_INDEX_WAVES
+#define BSK_INDEX_ATTR __attribute__((amdgpu_waves_per_eu(BSK_INDEX_WAVES, 8)))
+#else
+#define BSK_INDEX_ATTR
+#endif
+
 template <bool FASTQ, bool DPP>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void k_index(const uint8_t* __restrict__ buf, uint64_t n,
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index(const uint8_t* __restrict__ buf, uint64_t n,
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
                                                                    IndexDev D) {

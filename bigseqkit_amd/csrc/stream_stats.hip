@@ -152,8 +152,10 @@ struct StatsSink {
     }
 };
 
+// 7 waves per SIMD (<= 72 VGPRs): measured 18.27 -> 17.72 ms (stats) and 55.1 -> 49.8 ms (stats -a) against the
+// compiler's own choice (74 VGPRs, 6 waves); asking for 8 spills the -a kernel (96.8 ms)
 #ifndef BSK_STATS_WAVES
-#define BSK_STATS_WAVES 0
+#define BSK_STATS_WAVES 7
 #endif
 #if BSK_STATS_WAVES
 #define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu(BSK_STATS_WAVES, 8)))
