@@ -208,6 +208,34 @@ def main():
                       "first %d records (%.2f GB) of the same file, %.1f s, 1 thread of %d host cores"
                       % (passes, srec, srec * REC / 1e9, ct, os.cpu_count()),
         }
+        # the same port on every host core (one thread per record-aligned slice of the sample; ctypes releases the
+        # GIL): the fairer "what would the CPU path do on this box" number, still a reported baseline only
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(os.cpu_count() or 1, 256))
+            per = srec // nthr
+            if per > 0:
+                base = sample.data_ptr()
+                def work(k):
+                    lo = k * per
+                    cnt = per if k + 1 < nthr else srec - lo
+                    m = oracle.stats_map_ptr(base + lo * REC, cnt * REC, True, "{}")
+                    return m.get(150, 0)
+                reps = 8
+                with ThreadPoolExecutor(nthr) as ex:
+                    list(ex.map(work, range(nthr)))  # warm-up: threads started, pages touched
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        got = sum(ex.map(work, range(nthr)))
+                    ct = (time.perf_counter() - t0) / reps
+                assert got == srec
+                out["cpu_baseline_all_cores"] = {
+                    "value": round(srec / ct / 1e6, 2), "unit": "M records/s", "gb_per_s": round(srec * REC / ct / 1e9, 2),
+                    "cores": nthr, "kind": "port",
+                    "sample": "the same oracle, %d threads, mean of %d passes over the same %.2f GB sample, %.2f s per pass" % (nthr, reps, srec * REC / 1e9, ct),
+                }
+        except Exception as e:  # never let the extra baseline break the bench line
+            out["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
