@@ -19,7 +19,6 @@ namespace bsk {
 
 namespace {
 
-constexpr int GROUP = 16;
 
 __device__ __forceinline__ uint8_t lower8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
 
@@ -147,7 +146,7 @@ __device__ __forceinline__ uint32_t fold_dword(uint32_t x) {  // ASCII lower-cas
 // 16 consecutive start positions from a 32-byte window: first min(m,4) bytes as one dword
 // (v_alignbyte at static shifts), survivors verified byte by byte -> 16-bit hit mask
 __device__ __forceinline__ uint32_t window_hits(const uint8_t* src, const uint8_t* buf_end, bool fold, const uint8_t* pp,
-                                                uint32_t m) {
+                                                uint32_t m, uint32_t p32, uint32_t pmask) {
     uint32_t dw[8];
     if (src + 32 <= buf_end) {
         uint4 a, b2;
@@ -168,16 +167,16 @@ __device__ __forceinline__ uint32_t window_hits(const uint8_t* src, const uint8_
 #pragma unroll
         for (int d = 0; d < 8; ++d) dw[d] = fold_dword(dw[d]);
     }
-    uint32_t p32 = 0;
-    for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
-    const uint32_t pmask = m >= 4 ? 0xFFFFFFFFu : ((1u << (8 * m)) - 1u);
-    uint32_t cand = 0;
+    uint32_t miss = 0;  // mismatch bit per start position: alignbyte, xor, and, min(.,1), lshl_or (no compares)
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
         const int d = b >> 2, sft = b & 3;
         const uint32_t w = sft == 0 ? dw[d] : __builtin_amdgcn_alignbyte(dw[d + 1], dw[d], sft);
-        cand |= (((w ^ p32) & pmask) == 0u ? 1u : 0u) << b;
+        uint32_t t = (w ^ p32) & pmask;
+        t = t < 1u ? t : 1u;
+        miss |= t << b;
     }
+    uint32_t cand = ~miss & 0xFFFFu;
     uint32_t hits = 0;
     while (cand) {
         const uint32_t b = (uint32_t)__ffs((int)cand) - 1u;
@@ -193,7 +192,9 @@ __device__ __forceinline__ uint32_t window_hits(const uint8_t* src, const uint8_
     return hits;
 }
 
-template <bool EMIT, bool GEN>
+// GROUP lanes per record (4 for reads: the kernel is bound by dependent-load latency per wave, not by lanes; 16 for
+// long sequences)
+template <bool EMIT, bool GEN, int GROUP>
 __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                 LocateParams P, uint32_t* __restrict__ out_len,
                                                 const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     const uint64_t slot = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
     const uint32_t gl = threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;
+    constexpr uint64_t GMASK = (1ull << GROUP) - 1ull;
     const bool live = EMIT ? slot < P.nhit : slot < t.n;
     const uint64_t g = EMIT ? (live ? (uint64_t)P.hit_list[slot] : 0) : slot;
     const uint64_t gi = live ? g : 0;
@@ -270,15 +272,18 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
             if (fastp) {
                 const uint8_t* const buf_end = buf + buf_n;
                 const uint32_t npos32 = (uint32_t)npos, n32 = (uint32_t)n;  // not circular: n == l < 2^32
+                uint32_t p32 = 0;  // first min(m, 4) pattern bytes, loaded once per (record, pattern, strand)
+                for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
+                const uint32_t pmask = m >= 4 ? 0xFFFFFFFFu : ((1u << (8 * m)) - 1u);
                 for (uint32_t a0 = 0; a0 < npos32; a0 += GROUP * 16) {
                     const uint32_t ib = a0 + gl * 16u;  // first position of this lane, strand frame
                     uint32_t hits = 0;                           // bit k <-> position ib + k (ascending)
                     if (ib < npos32) {
                         if (strand == 0) {
-                            hits = window_hits(T.p + ib, buf_end, P.ignore_case, pp, m);
+                            hits = window_hits(T.p + ib, buf_end, P.ignore_case, pp, m, p32, pmask);
                         } else if (ib + 15u + m <= n32) {
                             // forward window [n-m-ib-15, n-m-ib]: bit b is position ib + 15 - b
-                            const uint32_t h = window_hits(T.p + (n32 - m - ib - 15u), buf_end, P.ignore_case, pp, m);
+                            const uint32_t h = window_hits(T.p + (n32 - m - ib - 15u), buf_end, P.ignore_case, pp, m, p32, pmask);
                             hits = __brev(h) >> 16;
                         } else {
                             for (uint32_t k2 = 0; k2 < 16u && ib + k2 < npos32; ++k2)
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                         const uint32_t left = npos32 - ib;
                         if (left < 16u) hits &= (1u << left) - 1u;
                     }
-                    const uint32_t gmask = (uint32_t)((__ballot(hits != 0) >> gshift) & 0xFFFFull);
+                    const uint32_t gmask = (uint32_t)((__ballot(hits != 0) >> gshift) & GMASK);
                     if (gmask == 0) continue;
                     need_id();
                     uint32_t mine = 0, cnt = 0;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                         coords(a, &begin, &end);
                         R.f = f;
                     }
-                    const uint32_t mask = (uint32_t)((__ballot(hit) >> gshift) & 0xFFFFull);
+                    const uint32_t mask = (uint32_t)((__ballot(hit) >> gshift) & GMASK);
                     if (mask == 0) continue;
                     need_id();
                     uint32_t mine = hit ? row_len(R, begin, end) : 0u;
@@ -393,15 +398,19 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     const uint64_t groups = emit ? P.nhit : t.n;
     if (groups == 0) return hipSuccess;
-    const uint64_t blocks = (groups * GROUP + 255) / 256;
+    const bool small = buf_n / t.n < 1024;  // bytes per record
+    const int G = small ? 4 : 16;
+    const uint64_t blocks = (groups * G + 255) / 256;
     const dim3 gr((unsigned)blocks), bl(256);
-    if (P.general) {
-        if (emit) hipLaunchKernelGGL((k_locate<true, true>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
-        else hipLaunchKernelGGL((k_locate<false, true>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+#define BSK_LAUNCH_LOCATE(E, GE, GG) hipLaunchKernelGGL((k_locate<E, GE, GG>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows)
+    if (small) {
+        if (P.general) { if (emit) BSK_LAUNCH_LOCATE(true, true, 4); else BSK_LAUNCH_LOCATE(false, true, 4); }
+        else { if (emit) BSK_LAUNCH_LOCATE(true, false, 4); else BSK_LAUNCH_LOCATE(false, false, 4); }
     } else {
-        if (emit) hipLaunchKernelGGL((k_locate<true, false>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
-        else hipLaunchKernelGGL((k_locate<false, false>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows);
+        if (P.general) { if (emit) BSK_LAUNCH_LOCATE(true, true, 16); else BSK_LAUNCH_LOCATE(false, true, 16); }
+        else { if (emit) BSK_LAUNCH_LOCATE(true, false, 16); else BSK_LAUNCH_LOCATE(false, false, 16); }
     }
+#undef BSK_LAUNCH_LOCATE
     return hipGetLastError();
 }
 
