@@ -181,13 +181,7 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
                         while (cand && !ok) {
                             const uint32_t b = (uint32_t)__ffs((int)cand) - 1u;
                             cand &= cand - 1u;
-                            bool all = true;
-                            for (uint32_t q = 4; q < m; ++q) {
-                                uint8_t cc = src[b + q];
-                                if (P.ignore_case) cc = lower8(cc);
-                                if (cc != pp[q]) { all = false; break; }
-                            }
-                            ok = all;
+                            ok = verify_from4(src + b, buf_end, P.ignore_case, pp, m);
                         }
                     }
                     const uint64_t any = __ballot(ok);

@@ -36,4 +36,7 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
                          uint64_t* rows, hipStream_t st);
 
+// hit_list := indices of the records with out_len != 0 (any order), *hit_count := how many (zeroed by the caller)
+hipError_t launch_compact_hits(const uint32_t* out_len, uint64_t n, uint32_t* hit_list, uint64_t* hit_count, hipStream_t st);
+
 }  // namespace bsk

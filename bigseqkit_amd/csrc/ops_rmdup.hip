@@ -352,39 +352,46 @@ __global__ __launch_bounds__(256) void k_rmdup_rows(const uint8_t* __restrict__ 
 //   k_rmdup_apply   : the sender turns the reply into the per-record output sizes
 // ---------------------------------------------------------------------------
 
+// Both kernels give every block a contiguous chunk of records and touch the per-owner global counters ONCE per block
+// (a few thousand atomics): one atomic per wave and owner on `world` addresses serialises in the L2 atomic unit.
+constexpr int PACK_MAX_WORLD = 64;
+
 __global__ __launch_bounds__(256) void k_rmdup_count_owner(const uint64_t* __restrict__ keys, uint64_t n, uint32_t world,
                                                            unsigned long long* __restrict__ counts) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    const uint32_t owner = live ? (uint32_t)(keys[i] % world) : world;
-    for (uint32_t o = 0; o < world; ++o) {
-        const uint64_t m = __ballot(owner == o);
-        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&counts[o], (unsigned long long)__popcll(m));
-    }
+    __shared__ unsigned int s_cnt[PACK_MAX_WORLD];
+    for (uint32_t o = threadIdx.x; o < world; o += blockDim.x) s_cnt[o] = 0;
+    __syncthreads();
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&s_cnt[(uint32_t)(keys[i] % world)], 1u);
+    __syncthreads();
+    for (uint32_t o = threadIdx.x; o < world; o += blockDim.x)
+        if (s_cnt[o]) atomicAdd(&counts[o], (unsigned long long)s_cnt[o]);
 }
 
 __global__ __launch_bounds__(256) void k_rmdup_pack(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys2,
                                                     uint64_t n, uint64_t base, uint32_t world,
                                                     unsigned long long* __restrict__ cursor, uint64_t* __restrict__ send) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    const uint64_t k = live ? keys[i] : 0;
-    const uint32_t owner = live ? (uint32_t)(k % world) : world;
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t o = 0; o < world; ++o) {
-        const uint64_t m = __ballot(owner == o);
-        if (!m) continue;
-        const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
-        unsigned long long at = 0;
-        if (lane == leader) at = atomicAdd(&cursor[o], (unsigned long long)__popcll(m));
-        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)at, (int)leader, 64);
-        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(at >> 32), (int)leader, 64);
-        if (owner == o) {
-            const uint64_t pos = (((uint64_t)hi << 32) | lo) + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-            send[3 * pos] = k;
-            send[3 * pos + 1] = keys2[i];
-            send[3 * pos + 2] = base + i;
-        }
+    __shared__ unsigned int s_cnt[PACK_MAX_WORLD];
+    __shared__ unsigned long long s_base[PACK_MAX_WORLD];
+    for (uint32_t o = threadIdx.x; o < world; o += blockDim.x) s_cnt[o] = 0;
+    __syncthreads();
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&s_cnt[(uint32_t)(keys[i] % world)], 1u);
+    __syncthreads();
+    for (uint32_t o = threadIdx.x; o < world; o += blockDim.x) {
+        s_base[o] = s_cnt[o] ? atomicAdd(&cursor[o], (unsigned long long)s_cnt[o]) : 0ull;  // reserve the block's slots
+        s_cnt[o] = 0;
+    }
+    __syncthreads();
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint64_t k = keys[i];
+        const uint32_t o = (uint32_t)(k % world);
+        const uint64_t pos = s_base[o] + atomicAdd(&s_cnt[o], 1u);  // order inside a bucket is irrelevant (tuples carry their index)
+        send[3 * pos] = k;
+        send[3 * pos + 1] = keys2[i];
+        send[3 * pos + 2] = base + i;
     }
 }
 
@@ -483,17 +490,21 @@ hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmD
     return hipGetLastError();
 }
 
+static unsigned pack_blocks(uint64_t n) {
+    uint64_t b = (n + 8191) / 8192;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
 hipError_t launch_rmdup_count_owner(const uint64_t* keys, uint64_t n, uint32_t world, uint64_t* counts, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rmdup_count_owner, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, world,
-                       (unsigned long long*)counts);
+    hipLaunchKernelGGL(k_rmdup_count_owner, dim3(pack_blocks(n)), dim3(256), 0, st, keys, n, world, (unsigned long long*)counts);
     return hipGetLastError();
 }
 
 hipError_t launch_rmdup_pack(const uint64_t* keys, const uint64_t* keys2, uint64_t n, uint64_t base, uint32_t world,
                              uint64_t* cursor, uint64_t* send, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rmdup_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, keys2, n, base, world,
+    hipLaunchKernelGGL(k_rmdup_pack, dim3(pack_blocks(n)), dim3(256), 0, st, keys, keys2, n, base, world,
                        (unsigned long long*)cursor, send);
     return hipGetLastError();
 }

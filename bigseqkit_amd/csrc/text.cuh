@@ -39,15 +39,42 @@ __device__ __forceinline__ Text text_of(const uint8_t* buf, const RecordTable& t
     return T;
 }
 
+// index of the first byte `c` in h[0, n), or n.  With `lim` (one past the last readable byte of the buffer) the search
+// takes 16 bytes per load and finds the byte with SWAR instead of one dependent byte load per character.
+__device__ inline uint32_t find_byte_in(const uint8_t* h, uint32_t n, uint8_t c, const uint8_t* lim) {
+    uint32_t i = 0;
+    const uint32_t rep = 0x01010101u * c;
+    while (i < n) {
+        if (lim && h + i + 16 <= lim) {
+            uint4 v;
+            __builtin_memcpy(&v, h + i, 16);
+            const uint32_t w[4] = {v.x ^ rep, v.y ^ rep, v.z ^ rep, v.w ^ rep};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t z = ~(((w[d] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[d] | 0x7F7F7F7Fu);  // 0x80 in every zero byte
+                if (z) {
+                    const uint32_t at = i + 4u * d + (((uint32_t)__ffs((int)z) - 1u) >> 3);
+                    return at < n ? at : n;
+                }
+            }
+            i += 16;
+        } else {
+            if (h[i] == c) return i;
+            ++i;
+        }
+    }
+    return n;
+}
+
 // ID length inside a header (marker excluded): parseHeadIDAndDesc,
 // /root/reference/bigseqkit-lib/helper.go:329-369 (default regexp and --id-ncbi)
-__device__ inline uint32_t id_span_of(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off) {
+__device__ inline uint32_t id_span_of(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off, const uint8_t* lim = nullptr) {
     *id_off = 0;
     if (id_mode == 0) {
-        for (uint32_t i = 0; i < n; ++i)
-            if (h[i] == ' ') { if (i > 0) return i; break; }
-        for (uint32_t i = 0; i < n; ++i)
-            if (h[i] == '\t') { if (i > 0) return i; break; }
+        const uint32_t s = find_byte_in(h, n, ' ', lim);   // up to the first ' ' (a leading one falls through), else '\t'
+        if (s < n && s > 0) return s;
+        const uint32_t tb = find_byte_in(h, n, '\t', lim);
+        if (tb < n && tb > 0) return tb;
         return n;
     }
     uint32_t a = 0;
