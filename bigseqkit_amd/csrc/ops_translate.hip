@@ -422,8 +422,17 @@ __device__ __forceinline__ void put4_edge(uint8_t* body, int64_t jlow, uint32_t 
     }
 }
 
+#ifndef BSK_TR_WAVES
+#define BSK_TR_WAVES 0
+#endif
+#if BSK_TR_WAVES
+#define BSK_TR_ATTR __attribute__((amdgpu_waves_per_eu(BSK_TR_WAVES, 8)))
+#else
+#define BSK_TR_ATTR
+#endif
+
 template <int G>
-__global__ __launch_bounds__(256) void k_translate_frames4(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+__global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
                                                            TranslateParams P, const uint32_t* __restrict__ out_len,
                                                            const uint64_t* __restrict__ out_off,
                                                            uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
