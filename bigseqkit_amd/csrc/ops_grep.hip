@@ -41,28 +41,6 @@ __device__ __forceinline__ uint32_t format_len(uint32_t name_len, uint32_t L, in
     return n;
 }
 
-__device__ uint32_t id_span2(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off) {
-    *id_off = 0;
-    if (id_mode == 0) {
-        for (uint32_t i = 0; i < n; ++i)
-            if (h[i] == ' ') { if (i > 0) return i; break; }
-        for (uint32_t i = 0; i < n; ++i)
-            if (h[i] == '\t') { if (i > 0) return i; break; }
-        return n;
-    }
-    uint32_t a = 0;
-    while (a < n && h[a] != '|') ++a;
-    while (a < n) {
-        uint32_t b = a + 1;
-        while (b < n && h[b] != '|') ++b;
-        if (b >= n) break;
-        if (b > a + 1 && b + 1 < n && h[b + 1] == ' ') { *id_off = a + 1; return b - a - 1; }
-        a = b;
-    }
-    return n;
-}
-
-
 // ---------------------------------------------------------------------------
 // fast path for contiguous text: a lane tests 16 consecutive start positions from two
 // unaligned 16-byte loads; the first min(m, 4) pattern bytes are compared as one dword taken
@@ -395,7 +373,7 @@ __global__ __launch_bounds__(256) void k_grep_regex(const uint8_t* __restrict__ 
         }
     } else {
         uint32_t off = 0, tl = hl;
-        if (!P.by_name) tl = id_span2(h, hl, P.id_mode, &off);
+        if (!P.by_name) tl = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
         for (int k = 0; k < P.npat && !hit; ++k) {
             const RegexProgram& p = P.regex[k];
             if (p.nullable) { hit = true; break; }
@@ -419,7 +397,7 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
     const uint8_t* h = buf + s + 1;
     uint32_t hl = lh > 0 ? lh - 1 : 0, off = 0;
     uint32_t tl = hl;
-    if (!P.by_name) tl = id_span2(h, hl, P.id_mode, &off);
+    if (!P.by_name) tl = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
     bool hit = false;
     if (P.set_keys) {  // pattern set: probe by hash, verify by bytes (patterns[k] is a map key in the reference, grep.go:501-511)
         const uint64_t key = fnv1a64(h + off, tl, P.ignore_case);
@@ -458,8 +436,10 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
 }  // namespace
 
 hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH* tt,
-                             const GrepParams& P, uint32_t* out_len, hipStream_t st) {
+                             const GrepParams& Pin, uint32_t* out_len, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
+    GrepParams P = Pin;
+    P.buf_end = buf + buf_n;
     if (P.regex) {
         TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
         hipLaunchKernelGGL(k_grep_regex, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len);

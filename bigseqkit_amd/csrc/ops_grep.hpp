@@ -26,6 +26,7 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     // -r: Glushkov programs (regex_nfa.hpp), `npat` of them, in device memory; comp: complement map for the '-' strand
     const struct RegexProgram* regex;
     const uint8_t* comp;
+    const uint8_t* buf_end;    // one past the shard (lets the ID search read 16 bytes at a time)
     const uint64_t* set_keys;  // null: linear scan over the patterns
     const uint32_t* set_idx;
     uint64_t set_mask;

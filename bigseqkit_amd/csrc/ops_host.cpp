@@ -1077,6 +1077,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     SeqParams P = format_params(c, fastq);
+    P.buf_end = d_buf + n;
     if (c->region_on) {
         P.region_on = 1;
         P.region_start = c->region_start;
@@ -1404,6 +1405,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     P.ignore_case = o.b("IgnoreCase");
     P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
     rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
@@ -1522,6 +1524,7 @@ static RmDupParams rmdup_params(bsk_ctx* c, bool fastq) {
     P.ignore_case = o.b("IgnoreCase");
     P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = c->dist_buf ? c->dist_buf + c->dist_n : nullptr;
     return P;
 }
 
@@ -1647,6 +1650,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     P.print_name = printName; P.print_seq = printSeq; P.print_qual = printQual;
     P.qual_only = o.b("Qual");
     P.only_id = o.b("OnlyId");
+    P.buf_end = d_buf + n;
     P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
     P.reverse = o.b("Reverse");
     P.remove_gaps = o.b("RemoveGaps");

@@ -49,7 +49,7 @@ __device__ __forceinline__ Subject subject_of(const uint8_t* buf, const RecordTa
         const uint32_t lh = t.l_head[i];
         const uint8_t* h = buf + t.start[i] + 1;
         uint32_t hl = lh > 0 ? lh - 1 : 0, off = 0;
-        if (!P.by_name) hl = id_span_of(h, hl, P.id_mode, &off);
+        if (!P.by_name) hl = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
         s.h = h + off;
         s.len = hl;
         s.T.p = nullptr; s.T.L = 0; s.T.W = 0;

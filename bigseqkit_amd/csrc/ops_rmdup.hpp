@@ -15,6 +15,7 @@ struct RmDupParams {  // RmDupPrepare / RmDupCheck options (bigseqkit-lib/rmdup.
     int by_seq, by_name, ignore_case;
     int id_mode;
     int line_width;
+    const uint8_t* buf_end;  // one past the shard, or null
 };
 
 constexpr uint32_t ERR_HASH_COLLISION = 512u;

@@ -22,29 +22,6 @@ namespace {
 
 __device__ __forceinline__ bool in_set(const uint32_t* set, uint8_t c) { return (set[c >> 5] >> (c & 31)) & 1u; }
 
-// ID length inside a header (marker excluded), parseHeadIDAndDesc (helper.go:329-369)
-__device__ uint32_t id_span(const uint8_t* h, uint32_t n, int id_mode, uint32_t* id_off) {
-    *id_off = 0;
-    if (id_mode == 0) {
-        for (uint32_t i = 0; i < n; ++i)
-            if (h[i] == ' ') { if (i > 0) return i; break; }
-        for (uint32_t i = 0; i < n; ++i)
-            if (h[i] == '\t') { if (i > 0) return i; break; }
-        return n;
-    }
-    // --id-ncbi: leftmost match of  '|' [^|]+ '|' ' '
-    uint32_t a = 0;
-    while (a < n && h[a] != '|') ++a;
-    while (a < n) {
-        uint32_t b = a + 1;
-        while (b < n && h[b] != '|') ++b;
-        if (b >= n) break;
-        if (b > a + 1 && b + 1 < n && h[b + 1] == ' ') { *id_off = a + 1; return b - a - 1; }
-        a = b;
-    }
-    return n;
-}
-
 struct RecView {
     const uint8_t* head;  // after the marker
     uint32_t head_len;
@@ -145,7 +122,7 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
     }
     if (P.feat_on) {
         uint32_t off;
-        const uint32_t il = id_span(r.head, r.head_len, P.id_mode, &off);
+        const uint32_t il = id_span_of(r.head, r.head_len, P.id_mode, &off, P.buf_end);
         const int f = feature_of(P, r.head + off, il);
         if (f < 0) { out_len[i] = 0; return; }
         uint32_t b, e;
@@ -176,7 +153,7 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
     if (keep) {
         if (P.print_name) {
             uint32_t hl = r.head_len, off;
-            if (P.only_id) hl = id_span(r.head, r.head_len, P.id_mode, &off);
+            if (P.only_id) hl = id_span_of(r.head, r.head_len, P.id_mode, &off, P.buf_end);
             n += (P.print_seq ? 1u : 0u) + hl + 1u;
         }
         if (P.print_seq) n += wrapped_len(kept, P.line_width) + 1u;
@@ -200,7 +177,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     uint8_t* o = out + out_off[g];
     const RecView r = view(buf, t, g, P.fastq);
     uint32_t hl = r.head_len, hoff = 0;
-    if (P.print_name && P.only_id) hl = id_span(r.head, r.head_len, P.id_mode, &hoff);
+    if (P.print_name && P.only_id) hl = id_span_of(r.head, r.head_len, P.id_mode, &hoff, P.buf_end);
     uint32_t sub_b = 0, sub_e = r.seq_len;
     if (P.region_on) sub_location(r.seq_len, P.region_start, P.region_end, &sub_b, &sub_e);
     bool reverse = P.reverse != 0, use_lut = P.use_lut != 0;
@@ -208,7 +185,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     const uint8_t* suffix = nullptr;  // feature mode: header = ID + suffix
     uint32_t id_len = hl;
     if (P.feat_on) {
-        id_len = id_span(r.head, r.head_len, P.id_mode, &hoff);
+        id_len = id_span_of(r.head, r.head_len, P.id_mode, &hoff, P.buf_end);
         const int f = feature_of(P, r.head + hoff, id_len);
         feature_region(P, f, r.seq_len, &sub_b, &sub_e);
         suffix = P.fsuffix + P.fsuffix_off[f];

@@ -47,6 +47,7 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     const uint8_t* fsuffix;                 // "_<start>-<end>:<strand><flank> <label>" appended to the ID
     const uint32_t* fsuffix_off;
     const uint8_t* comp;                    // complement map of the shard's alphabet
+    const uint8_t* buf_end;                 // one past the shard, or null (the ID search then reads byte by byte)
 };
 
 constexpr uint32_t ERR_INVALID_LETTER = 128u;

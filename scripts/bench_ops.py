@@ -68,11 +68,19 @@ if want("seq") or want("subseq"):
         report("subseq -r 1:50 (25 GB FASTQ)", nrec // 4, 317 * (nrec // 4), dt, ol)
     del t
 # C3: grep -s -p motif, one GPU's 12.5 GB shard
-if want("grep") or want("locate"):
+if want("grep") or want("locate") or want("grepid"):
     t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)
     if want("grep"):
         dt, ol, k = run("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t, 1)
         report("grep -s -p 12-mer (C3 shard, 12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "hits=%d" % k)
+    if want("grepid"):
+        # seqkit's most common grep: a list of IDs (here 100 000 of them, every 300th record) -> device hash set
+        import tempfile
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write("".join("S%010d\n" % i for i in range(0, 30_000_000, 300)))
+        dt, ol, k = run("Grep", lib.bsk_grep_run, {"PatternFile": f.name}, t, 1)
+        os.unlink(f.name)
+        report("grep -f 100k IDs (12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "hits=%d" % k)
     if want("locate"):
         dt, ol, k = run("Locate", lib.bsk_locate_run, {"Pattern": ["ACGTTGCAAGCT"]}, t, 1)
         report("locate -p 12-mer (12.5 GB FASTQ)", nrec, t.numel(), dt, ol, "rows=%d" % k)
