@@ -169,6 +169,13 @@ template <int GROUP>
 __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
                                                   const uint32_t* __restrict__ out_len,
                                                   const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
+    // byte map (complement / case / dna<->rna) in LDS for the 16-bytes-per-step transform path
+    __shared__ uint8_t s_lut[256];
+    if (P.use_lut || P.feat_on) {
+        const uint8_t* src = P.use_lut ? P.lut : P.comp;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = src ? src[i] : (uint8_t)i;
+        __syncthreads();
+    }
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
     const uint32_t gl = threadIdx.x % GROUP;
     if (g >= t.n) return;
@@ -265,6 +272,63 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                     q0 += 2;
                 }
                 group_copy(o + q0, rqual, L);
+                if (gl == 0) o[q0 + L] = '\n';
+            }
+            return;
+        }
+        // Transformed but not re-wrapped (reverse and / or the byte map on a contiguous source, no newline to insert):
+        // 16 output bytes per lane and step -- one 16-byte load, a byte reversal with v_perm, the map through LDS.
+        // (The LDS map holds P.lut, or the complement of a '-' strand feature; both are never active together.)
+        const bool lut_in_lds = use_lut && (lut == P.lut ? P.use_lut != 0 : true);
+        if (TW == 0 && W == L && (!use_lut || lut_in_lds)) {
+            for (uint32_t x = gl; x < a; x += GROUP) {
+                const uint32_t m = P.print_seq ? 1u : 0u;
+                uint8_t c;
+                if (x < m) c = P.fastq ? '@' : '>';
+                else if (x == a - 1) c = '\n';
+                else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
+                else c = r.head[hoff + x - m];
+                o[x] = c;
+            }
+            auto xform_copy = [&](uint8_t* dst, const uint8_t* src, uint32_t nb, bool map) {
+                for (uint32_t x = gl * 16u; x < nb; x += GROUP * 16u) {
+                    if (x + 16u <= nb) {
+                        uint4 v;
+                        __builtin_memcpy(&v, src + (reverse ? nb - 16u - x : x), 16);
+                        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        if (reverse) {
+                            const uint32_t r0 = __builtin_bswap32(w[3]), r1 = __builtin_bswap32(w[2]), r2 = __builtin_bswap32(w[1]),
+                                           r3 = __builtin_bswap32(w[0]);
+                            w[0] = r0; w[1] = r1; w[2] = r2; w[3] = r3;
+                        }
+                        if (map) {
+#pragma unroll
+                            for (int d = 0; d < 4; ++d)
+                                w[d] = (uint32_t)s_lut[w[d] & 0xFFu] | ((uint32_t)s_lut[(w[d] >> 8) & 0xFFu] << 8) |
+                                       ((uint32_t)s_lut[(w[d] >> 16) & 0xFFu] << 16) | ((uint32_t)s_lut[w[d] >> 24] << 24);
+                        }
+                        const uint4 ov = make_uint4(w[0], w[1], w[2], w[3]);
+                        __builtin_memcpy(dst + x, &ov, 16);
+                    } else {
+                        for (uint32_t k = x; k < nb; ++k) {
+                            uint8_t c = src[reverse ? nb - 1u - k : k];
+                            if (map) c = s_lut[c];
+                            dst[k] = c;
+                        }
+                    }
+                }
+            };
+            if (P.print_seq) {
+                xform_copy(o + a, sp + sub_b, L, use_lut);
+                if (gl == 0) o[a + L] = '\n';
+            }
+            if (P.print_qual) {
+                uint32_t q0 = a + b;
+                if (!P.qual_only) {
+                    if (gl == 0) { o[q0] = '+'; o[q0 + 1] = '\n'; }
+                    q0 += 2;
+                }
+                xform_copy(o + q0, rqual, L, false);
                 if (gl == 0) o[q0 + L] = '\n';
             }
             return;

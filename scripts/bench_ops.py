@@ -67,6 +67,12 @@ if want("seq") or want("subseq"):
         dt, ol, k = run("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, t[:317 * (nrec // 4)], 1)
         report("subseq -r 1:50 (25 GB FASTQ)", nrec // 4, 317 * (nrec // 4), dt, ol)
     del t
+# full re-emit with a transformation: reverse complement of 25 GB FASTQ (algorithmic bytes = 2 x in)
+if want("seqrc"):
+    t, nrec = synth(0, 0, 25e9 * scale)
+    dt, ol, k = run("SeqTransform", lib.bsk_seq_run, {"Reverse": True, "Complement": True}, t, 1)
+    report("seq -r -p (25 GB FASTQ)", nrec, t.numel(), dt, ol)
+    del t
 # C3: grep -s -p motif, one GPU's 12.5 GB shard
 if want("grep") or want("locate") or want("grepid"):
     t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)
