@@ -45,6 +45,14 @@ BSK_HD uint64_t find_byte(const uint8_t* buf, uint64_t n, uint64_t from, uint8_t
     return n;
 }
 
+// first line start at or after `from` (n if none): where a FASTA range may begin even inside a record
+BSK_HD uint64_t find_line_start(const uint8_t* buf, uint64_t n, uint64_t from) {
+    if (from == 0) return 0;
+    if (from >= n) return n;
+    const uint64_t j = find_byte(buf, n, from - 1, '\n');
+    return j < n ? j + 1 : n;
+}
+
 // FASTA: a record starts at a '>' that is the first byte of a line (PARITY.md SPLIT).
 BSK_HD uint64_t find_fasta_start(const uint8_t* buf, uint64_t n, uint64_t from) {
     if (from >= n) return n;

@@ -220,6 +220,7 @@ void bsk_destroy(bsk_ctx* c) {
         hipDeviceSynchronize();
         for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
         if (c->d_anchors) hipFree(c->d_anchors);
+        if (c->d_rng) hipFree(c->d_rng);
         if (c->d_vec) hipFree(c->d_vec);
         if (c->d_status) hipFree(c->d_status);
         if (c->d_overflow) hipFree(c->d_overflow);
@@ -326,14 +327,30 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     }
     uint64_t* anchors = c->d_anchors;
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
+    D.r_head = D.r_tail = nullptr;
+    D.r_flags = nullptr;
+    if (!fastq) {
+        // FASTA ranges begin on line starts (a chromosome spans many ranges): per-range parts for the stitch kernel
+        if (nranges > c->rng_cap || !c->d_rng) {
+            if (c->d_rng) HIP_TRY(c, hipFree(c->d_rng));
+            c->d_rng = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&c->d_rng, (size_t)nranges * 20 + 64));
+            c->rng_cap = nranges;
+        }
+        D.r_head = c->d_rng;
+        D.r_tail = c->d_rng + nranges;
+        D.r_flags = reinterpret_cast<uint32_t*>(c->d_rng + 2 * (size_t)nranges);
+        HIP_TRY(c, hipMemsetAsync(c->d_rng, 0, (size_t)nranges * 20, st));
+    }
     {
         Timed t(c, "k_prep", st);
-        HIP_TRY(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st));
+        HIP_TRY(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st, /*line_mode=*/!fastq));
     }
     {
         Timed t(c, "k_stats", st);
         HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
     }
+    if (!fastq) HIP_TRY(c, launch_stats_stitch(nranges, D, st));
     return BSK_OK;
 }
 

@@ -29,6 +29,8 @@ struct bsk_ctx {
     uint64_t* d_anchors = nullptr;  // [cap_ranges + 1] + queue word
     uint32_t cap_ranges = 0;
     hipStream_t own_stream = nullptr;
+    uint64_t* d_rng = nullptr;       // FASTA stats: r_head[cap] ++ r_tail[cap] ++ (u32) r_flags[cap]
+    uint32_t rng_cap = 0;
 
     // ---- Stats ----------------------------------------------------------------
     bsk::Alphabet alphabet = bsk::AB_NONE;  // forced by -t, else AB_NONE

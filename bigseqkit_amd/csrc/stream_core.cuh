@@ -221,12 +221,15 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
         if constexpr (FASTQ) L.nc[lane] = 0;
         if constexpr (ALL) L.a[lane] = 0;
         if constexpr (ALL && FASTQ) { L.b[lane] = 0; L.c[lane] = 0; }
-        if constexpr (!FASTQ) L.flag[lane] = 1;
+        // FASTA ranges may begin inside a record (on any line start): the virtual event before the range closed a
+        // record only if the range begins with a header
+        if constexpr (!FASTQ) L.flag[lane] = buf[rs] == '>' ? 1 : 0;
     }
     wave_lds_fence();
     if (lane == 0) {
         const uint8_t c0 = buf[rs];
-        if (c0 != (FASTQ ? '@' : '>')) sink.err |= ERR_BAD_HEADER;
+        if constexpr (FASTQ) { if (c0 != '@') sink.err |= ERR_BAD_HEADER; }
+        else { if (rs == 0 && c0 != '>') sink.err |= ERR_BAD_HEADER; }
     }
     uint32_t line_base = 0;                    // newlines seen so far in this range
     uint32_t run_a = 0, run_b = 0, run_c = 0;  // running counters (mod 2^32)
@@ -324,9 +327,10 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                             if constexpr (FASTQ) {
                                 L.nc[s] = (uint16_t)nc16;
                             } else {
+                                // the line closes a record when a header follows, or at the end of the shard
                                 const uint64_t an = tile_idx + off + 1;
                                 const uint8_t nc = nc16 ? (uint8_t)nc16 : (an < n ? buf[an] : (uint8_t)0);
-                                L.flag[s] = (an >= re || nc == '>') ? 1 : 0;
+                                L.flag[s] = (nc == '>' || (an >= re && is_last) || an >= n) ? 1 : 0;
                             }
                         }
                     }
@@ -458,7 +462,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                         }
                         if constexpr (!FASTQ) {
                             const uint64_t an = tile_idx + off + 1;  // byte after the newline
-                            L.flag[s] = (an >= re || buf[an] == '>') ? 1 : 0;
+                            L.flag[s] = (an >= n || buf[an] == '>' || (an >= re && is_last)) ? 1 : 0;
                         }
                     }
                 }

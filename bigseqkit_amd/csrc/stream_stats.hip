@@ -83,8 +83,33 @@ struct StatsSink {
     uint32_t err = 0;
     // FASTA: header-end of the record that is open at the start of a batch
     uint32_t open_key = 0, open_sg = 0;
+    // FASTA: ranges begin on line starts, possibly inside a record (see StatsDev::r_head)
+    uint32_t range_id = 0;
+    bool open_is_header = false;  // open_key belongs to a header of THIS range (else: to the range start)
+    bool any_event = false, last_closing = true;
+    uint32_t last_key = 0, last_a = 0;
 
-    __device__ __forceinline__ void begin_range() { open_key = 0; open_sg = 0; }
+    __device__ __forceinline__ void begin_range(uint32_t r) {
+        open_key = 0; open_sg = 0;
+        range_id = r;
+        open_is_header = false;
+        any_event = false; last_closing = true;
+        last_key = 0; last_a = 0;
+    }
+
+    // FASTA: what this range leaves open (lane 0 records it for k_stats_stitch)
+    template <bool ALL>
+    __device__ __forceinline__ void end_range() {
+        if ((threadIdx.x & 63) != 0) return;
+        uint32_t f = RF_VISITED | (open_is_header ? RF_HAS_HEADER : 0u);
+        if (any_event && !last_closing) {
+            const uint64_t bases = (uint64_t)(uint32_t)(last_key - (open_is_header ? open_key : 0u));
+            if (open_is_header) { D.r_tail[range_id] = bases; f |= RF_TAIL_OPEN; }
+            else D.r_head[range_id] = bases;  // no header and no closing line: the whole range is inside one record
+            if constexpr (ALL) gap += (uint32_t)(last_a - (open_is_header ? open_sg : 0u));
+        }
+        atomicOr(&D.r_flags[range_id], f);
+    }
 
     template <bool FASTQ, bool ALL>
     __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
@@ -127,6 +152,7 @@ struct StatsSink {
             } else {
                 const bool closing = on && L.flag[s] != 0;
                 uint32_t seqlen = 0;
+                bool whole = true;  // header and closing line of the record are both in this range
                 if (on) {
                     // is this event the end of a header line?
                     if (L.flag[s - 1]) {
@@ -146,13 +172,19 @@ struct StatsSink {
                     } else {
                         key_i = open_key;
                         sg_i = open_sg;
+                        whole = open_is_header;  // else the record began in an earlier range: only its tail is here
                     }
                     seqlen = (p - rank) - key_i;
-                    sumlen += seqlen;
-                    nrec += 1;
+                    if (whole) {
+                        sumlen += seqlen;
+                        nrec += 1;
+                    } else {
+                        D.r_head[range_id] = seqlen;
+                        atomicOr(&D.r_flags[range_id], RF_HEAD_CLOSED);
+                    }
                     if constexpr (ALL) gap += (uint32_t)(L.a[s] - sg_i);
                 }
-                add_length(closing, seqlen, s_hist, D);
+                add_length(closing && whole, seqlen, s_hist, D);
             }
         }
         if constexpr (!FASTQ) {
@@ -162,6 +194,14 @@ struct StatsSink {
                 const int src = (int)(uint32_t)w;
                 open_key = (uint32_t)__builtin_amdgcn_readlane((int)best_key, src);
                 if constexpr (ALL) open_sg = (uint32_t)__builtin_amdgcn_readlane((int)best_sg, src);
+                open_is_header = true;
+            }
+            if (E > 0) {  // the last event of the batch (uniform LDS reads)
+                const uint32_t sl = HISTORY + (E - 1u);
+                last_key = L.pos[sl] - (wb + (E - 1u));
+                last_closing = L.flag[sl] != 0;
+                if constexpr (ALL) last_a = L.a[sl];
+                any_event = true;
             }
         }
     }
@@ -205,8 +245,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) continue;
-        sink.begin_range();
+        sink.begin_range(r);
         stream_range<FASTQ, ALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink);
+        if constexpr (!FASTQ) sink.template end_range<ALL>();
     }
     // flush ---------------------------------------------------------------
     const uint64_t q20 = wave_sum_u64(sink.q20), q30 = wave_sum_u64(sink.q30), gap = wave_sum_u64(sink.gap);
@@ -237,7 +278,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
 // ---------------------------------------------------------------------------
 template <bool FASTQ>
 __global__ void k_prep(const uint8_t* __restrict__ buf, uint64_t n, uint64_t chunk, uint32_t nranges,
-                       uint64_t* __restrict__ anchors, uint32_t* __restrict__ queue) {
+                       uint64_t* __restrict__ anchors, uint32_t* __restrict__ queue, int line_mode) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nranges) return;
     if (r == 0) {
@@ -250,7 +291,38 @@ __global__ void k_prep(const uint8_t* __restrict__ buf, uint64_t n, uint64_t chu
         return;
     }
     const uint64_t from = (uint64_t)r * chunk;
-    anchors[r] = FASTQ ? find_fastq_start(buf, n, from) : find_fasta_start(buf, n, from);
+    anchors[r] = FASTQ ? find_fastq_start(buf, n, from) : (line_mode ? find_line_start(buf, n, from) : find_fasta_start(buf, n, from));
+}
+
+// Records that cross range boundaries (FASTA, line-start ranges): one thread walks the ranges in file order and adds up
+// the parts; a few 10^4 iterations.
+__global__ void k_stats_stitch(uint32_t nranges, StatsDev D) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t carry = 0, nrec = 0, sumlen = 0;
+    bool open = false;
+    auto emit = [&](uint64_t len) {
+        ++nrec;
+        sumlen += len;
+        if (len < D.hist_cap) D.vec[STATS_HDR + len] += 1;
+        else {
+            const uint64_t i = D.status[1]++;
+            if (i < D.overflow_cap) D.overflow[i] = len;
+        }
+    };
+    for (uint32_t r = 0; r < nranges; ++r) {
+        const uint32_t f = D.r_flags[r];
+        if (!(f & RF_VISITED)) continue;
+        if (f & RF_HAS_HEADER) {
+            if (open) { emit(carry + D.r_head[r]); carry = 0; open = false; }  // the open record ends before this range's first header
+            if (f & RF_TAIL_OPEN) { carry = D.r_tail[r]; open = true; }
+        } else {
+            carry += D.r_head[r];
+            if (f & RF_HEAD_CLOSED) { if (open) emit(carry); carry = 0; open = false; }
+        }
+    }
+    if (open) emit(carry);
+    D.vec[3] += nrec;
+    D.vec[6] += sumlen;
 }
 
 // Pure streaming read with the access pattern of k_stats (same tiles, same queue, no
@@ -293,11 +365,16 @@ __global__ void k_scan_selftest(const uint32_t* in, uint32_t* out) {
 // host launchers
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
-                       uint64_t* anchors, uint32_t* queue, hipStream_t st) {
+                       uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode) {
     const int threads = 64;
     const int blocks = (int)((nranges + 1 + threads - 1) / threads);
-    if (fastq) hipLaunchKernelGGL(k_prep<true>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue);
-    else hipLaunchKernelGGL(k_prep<false>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue);
+    if (fastq) hipLaunchKernelGGL(k_prep<true>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, 0);
+    else hipLaunchKernelGGL(k_prep<false>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, line_mode ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st) {
+    hipLaunchKernelGGL(k_stats_stitch, dim3(1), dim3(1), 0, st, nranges, D);
     return hipGetLastError();
 }
 

@@ -32,10 +32,20 @@ struct StatsDev {
     uint64_t overflow_cap;
     uint32_t hist_cap;
     PredConsts pred;
+    // FASTA ranges begin on LINE starts, so a record (a chromosome) may span many ranges.  Per range: bases of the part
+    // before its first header (r_head), bases after its last header when that record is still open at the range end
+    // (r_tail), and flags; k_stats_stitch adds up the records that cross range boundaries.
+    uint64_t* r_head;
+    uint64_t* r_tail;
+    uint32_t* r_flags;
 };
 
+constexpr uint32_t RF_VISITED = 1u, RF_HAS_HEADER = 2u, RF_HEAD_CLOSED = 4u, RF_TAIL_OPEN = 8u;
+
+// line_mode (FASTA only): anchors are line starts, not record starts
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
-                       uint64_t* anchors, uint32_t* queue, hipStream_t st);
+                       uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode = false);
+hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st);
 hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_t* buf, uint64_t n,
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
                         hipStream_t st);

@@ -265,3 +265,21 @@ def test_stats_host_shard_chunked_pipeline_matches_device_path(monkeypatch):
                     assert dict(zip(keys[:n.value], vals[:n.value])) == want
         finally:
             lib.bsk_host_free(p)
+
+
+@pytest.mark.parametrize("all_", [False, True])
+@pytest.mark.parametrize("final_newline", [True, False])
+def test_fasta_records_much_longer_than_a_range(all_, final_newline, monkeypatch):
+    """FASTA ranges begin on line starts, so a chromosome-sized record is cut into many ranges whose parts are added up
+    by k_stats_stitch: lengths, record count, gap sums and the histogram overflow list must still be exact."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(77 + all_)
+    recs = []
+    for k, L in enumerate([3, 250_000, 0, 70_001, 59, 60, 61, 1_200_000, 17, 66_000, 5000, 5000, 5000]):
+        s = "".join(rng.choice("ACGTN-.") for _ in range(L))
+        w = [60, 70, 80][k % 3]
+        recs.append(f">chr{k} len={L}\n" + "".join(s[j:j + w] + "\n" for j in range(0, L, w)))
+    data = "".join(recs)
+    if not final_newline:
+        data = data[:-1]
+    check_parity(data.encode(), False, {"All": all_})
