@@ -221,6 +221,7 @@ void bsk_destroy(bsk_ctx* c) {
         for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
         if (c->d_anchors) hipFree(c->d_anchors);
         if (c->d_rng) hipFree(c->d_rng);
+        if (c->d_parts) hipFree(c->d_parts);
         if (c->d_vec) hipFree(c->d_vec);
         if (c->d_status) hipFree(c->d_status);
         if (c->d_overflow) hipFree(c->d_overflow);

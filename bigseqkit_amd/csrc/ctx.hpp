@@ -50,6 +50,8 @@ struct bsk_ctx {
     bsk::RecordTable sparse;         // one-pass index: per-range slices, compacted into `table`
     uint64_t* d_range_count = nullptr;  // [cap_ranges]
     uint64_t* d_range_base = nullptr;   // [cap_ranges + 1]
+    bsk::RangePart* d_parts = nullptr;  // [parts_cap] FASTA: parts of records that span ranges
+    uint32_t parts_cap = 0;
     uint32_t* d_out_len = nullptr;      // [table.cap]
     uint64_t* d_out_off = nullptr;      // [table.cap + 1]
     uint64_t* d_scan_tmp = nullptr;

@@ -28,8 +28,21 @@ struct RecordTable {
     uint64_t cap = 0;
 };
 
+// FASTA ranges begin on line starts: what a range knows about the record that is open at its start (head part) and
+// about its own last record when that one is still open at the range end (tail part); k_index_stitch joins them.
+struct RangePart {
+    uint64_t head_bases, head_end_abs;  // bases before the first header; one past the last byte of that record (if closed here)
+    uint64_t tail_bases;
+    uint32_t head_nlines, head_first, head_last;  // sequence lines of the head part, length of the first / last one
+    uint32_t tail_nlines, tail_first, tail_last;
+    uint32_t flags;                               // IP_*
+    uint32_t pad;
+};
+constexpr uint32_t IP_VISITED = 1u, IP_HAS_HEADER = 2u, IP_HEAD_CLOSED = 4u, IP_TAIL_OPEN = 8u, IP_HEAD_IRR = 16u, IP_TAIL_IRR = 32u;
+
 struct IndexDev {
     RecordTable t;
+    RangePart* parts;            // [nranges] FASTA with line-start ranges, else null
     uint64_t* range_count;       // [nranges] records per range (count pass writes, write pass reads base)
     const uint64_t* range_base;  // [nranges + 1] exclusive scan of range_count (write pass)
     uint64_t* status;            // [0] error flags
@@ -46,6 +59,9 @@ hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipS
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st);
 hipError_t launch_reset_queue(uint32_t* queue, hipStream_t st);
 // gather the per-range slices of a sparse table (mode 2) into a dense one
+// FASTA, line-start ranges: complete l_seq / aux / text_w of the records that span ranges (dense table, exact bases)
+hipError_t launch_index_stitch(const RecordTable& dense, const RangePart* parts, const uint64_t* range_count,
+                               const uint64_t* range_base, uint32_t nranges, hipStream_t st);
 hipError_t launch_index_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
                                 const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, hipStream_t st);
 

@@ -104,8 +104,21 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
     }
     uint64_t* anchors = c->d_anchors;
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
-    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st));
+    // FASTA ranges begin on line starts (a chromosome spans many ranges); the records that cross range boundaries are
+    // completed by k_index_stitch from the per-range parts
+    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st, /*line_mode=*/!fastq));
     IndexDev D;
+    D.parts = nullptr;
+    if (!fastq) {
+        if (nranges > c->parts_cap || !c->d_parts) {
+            if (c->d_parts) HIP_TRYX(c, hipFree(c->d_parts));
+            c->d_parts = nullptr;
+            HIP_TRYX(c, hipMalloc((void**)&c->d_parts, (size_t)nranges * sizeof(RangePart)));
+            c->parts_cap = nranges;
+        }
+        HIP_TRYX(c, hipMemsetAsync(c->d_parts, 0, (size_t)nranges * sizeof(RangePart), st));
+        D.parts = c->d_parts;
+    }
     D.range_count = c->d_range_count;
     D.range_base = c->d_range_base;
     D.status = c->d_status;
@@ -157,6 +170,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
                 HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
                 HIP_TRYX(c, hipStreamSynchronize(st));
                 HIP_TRYX(c, launch_reset_queue(queue, st));
+                if (D.parts) HIP_TRYX(c, hipMemsetAsync(c->d_parts, 0, (size_t)nranges * sizeof(RangePart), st));
             } else {
                 int rc3 = alloc_table(c->table, total + total / 8 + 16);
                 if (rc3 != BSK_OK) return rc3;
@@ -185,6 +199,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
         HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
     }
     if (total == 0) return BSK_OK;
+    if (D.parts) HIP_TRYX(c, launch_index_stitch(c->table, c->d_parts, c->d_range_count, c->d_range_base, nranges, st));
     // start[n] = effective end of the shard (anchors[nranges])
     HIP_TRYX(c, hipMemcpyAsync(c->table.start + total, anchors + nranges, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     return BSK_OK;

@@ -32,8 +32,18 @@ struct IndexSink {
     // breaks "all lines but the last are equally long, the last is 1..W"
     uint32_t open_w = 0;
     bool open_irr = false;
+    // FASTA with line-start ranges (D.parts != null): a range may begin inside a record
+    uint32_t range_id = 0, nhdr = 0;      // headers seen so far in this range == records it owns
+    bool mid_start = false;               // the range begins inside a record
+    bool open_is_header = false;          // open_* describe a header of THIS range
+    uint32_t open_hdr_rank = 0;           // line index of that header
+    uint32_t part_first = 0;              // length of the first line of a mid-record range
+    bool any_event = false, last_closing = true;
+    uint32_t last_key = 0, last_rank = 0, last_len = 0;
+    uint64_t range_end = 0;
 
-    __device__ __forceinline__ void begin_range(uint64_t b, uint64_t lim, uint64_t rs) {
+    __device__ __forceinline__ void begin_range(uint64_t b, uint64_t lim, uint64_t rs, uint64_t re = 0, uint32_t r = 0,
+                                                bool mid = false) {
         base = b;
         limit = lim;
         nrec = 0;
@@ -42,6 +52,46 @@ struct IndexSink {
         open_key = 0;
         open_w = 0;
         open_irr = false;
+        range_id = r; nhdr = 0; mid_start = mid; open_is_header = false; open_hdr_rank = 0; part_first = 0;
+        any_event = false; last_closing = true; last_key = 0; last_rank = 0; last_len = 0;
+        range_end = re;
+    }
+
+    // FASTA: the parts this range leaves to k_index_stitch (lane 0)
+    __device__ __forceinline__ void end_range() {
+        if ((threadIdx.x & 63) != 0 || !D.parts || !D.write) return;
+        RangePart& Q = D.parts[range_id];
+        uint32_t f = IP_VISITED | (open_is_header ? IP_HAS_HEADER : 0u);
+        if (any_event && !last_closing) {
+            if (open_is_header) {
+                // the last record of the range is still open: its table entry holds what is known so far
+                const uint64_t g = base + nhdr - 1u;
+                const uint32_t bases = last_key - open_key;
+                if (g < limit) {
+                    D.t.start[g] = open_start;
+                    D.t.l_head[g] = open_lhead;
+                    D.t.l_seq[g] = bases;
+                    D.t.aux[g] = 0;
+                    D.t.text_w[g] = 0;
+                } else {
+                    err |= ERR_CAPACITY;
+                }
+                Q.tail_bases = bases;
+                Q.tail_nlines = last_rank - open_hdr_rank;
+                Q.tail_first = open_w;
+                Q.tail_last = last_len;
+                f |= IP_TAIL_OPEN | (open_irr ? IP_TAIL_IRR : 0u);
+            } else {
+                // no header and no closing line: the whole range is inside one record
+                Q.head_bases = last_key;
+                Q.head_end_abs = range_end;
+                Q.head_nlines = last_rank + 1u;
+                Q.head_first = part_first;
+                Q.head_last = last_len;
+                f |= open_irr ? IP_HEAD_IRR : 0u;
+            }
+        }
+        atomicOr(&Q.flags, f);
     }
 
     template <bool FASTQ, bool ALL>
@@ -90,15 +140,15 @@ struct IndexSink {
                     best_lhead = p - L.pos[s - 1] - 1u;
                     best_start = abs_of(L.pos[s - 1], tile_idx, tile_rel) + 1;
                 }
-                const uint64_t cm = __ballot(closing);
                 // ---- line layout (replaces a separate pass over every line end): an event is a header end (H), the
                 // first sequence line of its record (F), or a later sequence line, which must be as long as the line
                 // before it (the last one: 1..that length)
                 const bool H = on && L.flag[s - 1] != 0;
                 const bool F = on && !H && L.flag[s - 2] != 0;
                 const uint32_t len = p - L.pos[s - 1] - 1u;
-                bool viol = false;
-                if (on && !H) {
+                const bool cont_first = mid_start && rank == 0u;  // first line of a range that begins inside a record:
+                bool viol = false;                                // its predecessor is in another range (k_index_stitch)
+                if (on && !H && !cont_first) {
                     if (F) viol = !closing && len == 0u;
                     else {
                         const uint32_t plen = L.pos[s - 1] - L.pos[s - 2] - 1u;
@@ -106,10 +156,16 @@ struct IndexSink {
                     }
                 }
                 const uint64_t hb = __ballot(H), fb = __ballot(F), vb = __ballot(viol);
+                if (mid_start && wb == 0u && e0 == 0u && E > 0u) part_first = (uint32_t)__builtin_amdgcn_readlane((int)len, 0);
+                const uint64_t upto = (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                // records owned by this range are numbered by their headers; a closing line before the first header
+                // of the range ends a record that began in an earlier range
+                const uint32_t hdrs = nhdr + (uint32_t)__popcll(hb & upto);
+                const bool whole = hdrs > 0u;
                 uint32_t tw = 0;  // text_w of the record this lane closes
+                bool irr_here = false;
                 {
                     // every lane takes part in the shuffle (a ds_bpermute reads nothing from inactive lanes)
-                    const uint64_t upto = (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
                     const uint64_t hh = hb & upto, ff = fb & upto;
                     bool irr;
                     int src = lane;
@@ -124,10 +180,10 @@ struct IndexSink {
                     }
                     const uint32_t wsh = (uint32_t)__shfl((int)len, src, 64);
                     const uint32_t W = (hh || ff) ? wsh : open_w;
+                    irr_here = irr;
                     if (closing && !H && !F) tw = (irr || W < 16u) ? 0xFFFFFFFFu : W;
                 }
                 if (closing && D.write) {
-                    const uint32_t local = nrec + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
                     uint32_t t = s;
                     while (t > 0 && !L.flag[t - 1]) --t;
                     uint32_t key_i, lhead;
@@ -143,20 +199,32 @@ struct IndexSink {
                     }
                     const uint32_t seqlen = (p - rank) - key_i;
                     const uint64_t rec_end = abs_next > re ? re : abs_next;  // the virtual event sits at re
-                    const uint64_t region = rec_end - (start + lhead + 1 < rec_end ? start + lhead + 1 : rec_end);
-                    if (region > 0xFFFFFFFFull) err |= ERR_LINE_TOO_LONG;
-                    const uint64_t g = base + local;
-                    if (g < limit) {
-                        D.t.start[g] = start;
-                        D.t.l_head[g] = lhead;
-                        D.t.l_seq[g] = seqlen;
-                        D.t.aux[g] = (uint32_t)region;
-                        D.t.text_w[g] = tw;
-                    } else {
-                        err |= ERR_CAPACITY;
+                    if (whole) {
+                        const uint64_t region = rec_end - (start + lhead + 1 < rec_end ? start + lhead + 1 : rec_end);
+                        if (region > 0xFFFFFFFFull) err |= ERR_LINE_TOO_LONG;
+                        const uint64_t g = base + (hdrs - 1u);
+                        if (g < limit) {
+                            D.t.start[g] = start;
+                            D.t.l_head[g] = lhead;
+                            D.t.l_seq[g] = seqlen;
+                            D.t.aux[g] = (uint32_t)region;
+                            D.t.text_w[g] = tw;
+                        } else {
+                            err |= ERR_CAPACITY;
+                        }
+                    } else if (D.parts) {
+                        // end of the record that was open when the range began
+                        RangePart& Q = D.parts[range_id];
+                        Q.head_bases = seqlen;  // open_key == 0: bases since the range start
+                        Q.head_end_abs = rec_end;
+                        Q.head_nlines = rank + 1u;
+                        Q.head_first = rank == 0u ? len : part_first;
+                        Q.head_last = len;
+                        atomicOr(&Q.flags, IP_HEAD_CLOSED | (irr_here ? IP_HEAD_IRR : 0u));
                     }
                 }
-                nrec += (uint32_t)__popcll(cm);
+                nrec = nhdr + (uint32_t)__popcll(hb);  // records owned so far (k_index reads it after the range)
+                nhdr = nrec;
                 // layout state of the record that stays open after these 64 events (wave-uniform)
                 if (hb) {
                     const int hl = 63 - __clzll((long long)hb);
@@ -178,6 +246,16 @@ struct IndexSink {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)best_start, src);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(best_start >> 32), src);
                 open_start = ((uint64_t)hi << 32) | lo;
+                open_is_header = true;
+                open_hdr_rank = (uint32_t)(w >> 32) - 1u;
+            }
+            if (E > 0) {  // the last event of the batch (uniform LDS reads)
+                const uint32_t sl = HISTORY + (E - 1u);
+                last_rank = wb + (E - 1u);
+                last_key = L.pos[sl] - last_rank;
+                last_len = L.pos[sl] - L.pos[sl - 1] - 1u;
+                last_closing = L.flag[sl] != 0;
+                any_event = true;
             }
         }
     }
@@ -222,8 +300,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index
         uint64_t b = 0, lim = D.t.cap;
         if (D.write == 1) b = D.range_base[r];
         else if (D.write == 2) { b = (uint64_t)r * D.sparse_cap; lim = b + D.sparse_cap; if (lim > D.t.cap) lim = D.t.cap; }
-        sink.begin_range(b, lim, rs);
+        sink.begin_range(b, lim, rs, re, r, !FASTQ && buf[rs] != '>');
         const uint32_t lines = stream_range<FASTQ, false, DPP>(L, buf, n, rs, re, re == n_eff, P, sink);
+        if constexpr (!FASTQ) sink.end_range();
         if (D.write != 1 && lane == 0) D.range_count[r] = FASTQ ? (uint64_t)(lines >> 2) : (uint64_t)sink.nrec;
     }
     const uint32_t err = wave_or_u32(sink.err);
@@ -316,6 +395,52 @@ __global__ void k_set_total(const uint64_t* __restrict__ block_off, uint64_t nbl
 
 __global__ void k_reset_queue(uint32_t* q) { *q = 0; }
 
+// FASTA, line-start ranges: records that span ranges.  One thread walks the ranges in file order; the open record's
+// bases, region and line layout are completed from the head parts of the following ranges.
+__global__ void k_index_stitch(RecordTable t, const RangePart* __restrict__ parts, const uint64_t* __restrict__ range_count,
+                               const uint64_t* __restrict__ range_base, uint32_t nranges) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    bool open = false;
+    uint64_t g = 0, bases = 0;
+    uint32_t nl = 0, W = 0, last = 0;
+    bool irr = false;
+    auto finish = [&](uint64_t end_abs) {
+        const uint64_t seq0 = t.start[g] + t.l_head[g] + 1;
+        t.l_seq[g] = (uint32_t)bases;
+        t.aux[g] = (uint32_t)(end_abs > seq0 ? end_abs - seq0 : 0);
+        t.text_w[g] = nl <= 1u ? 0u : ((irr || W < 16u) ? 0xFFFFFFFFu : W);
+    };
+    for (uint32_t r = 0; r < nranges; ++r) {
+        const RangePart& Q = parts[r];
+        const uint32_t f = Q.flags;
+        if (!(f & IP_VISITED)) continue;
+        const bool has_head_part = open && (!(f & IP_HAS_HEADER) || (f & IP_HEAD_CLOSED));
+        if (has_head_part) {
+            const bool closed = (f & IP_HEAD_CLOSED) != 0;
+            if (Q.head_nlines > 0u) {
+                if (nl == 0u) W = Q.head_first;          // the record's first sequence line
+                else {
+                    // the line that ended the previous part is no longer the last one: the next line is compared with it
+                    const bool only_line_is_last = closed && Q.head_nlines == 1u;
+                    if (only_line_is_last) irr |= !(Q.head_first >= 1u && Q.head_first <= last);
+                    else irr |= Q.head_first != last;
+                }
+                nl += Q.head_nlines;
+                last = Q.head_last;
+                irr |= (f & IP_HEAD_IRR) != 0;
+            }
+            bases += Q.head_bases;
+            if (closed) { finish(Q.head_end_abs); open = false; }
+        }
+        if (f & IP_TAIL_OPEN) {
+            g = range_base[r] + range_count[r] - 1;
+            bases = Q.tail_bases;
+            nl = Q.tail_nlines; W = Q.tail_first; last = Q.tail_last; irr = (f & IP_TAIL_IRR) != 0;
+            open = true;
+        }
+    }
+}
+
 // one block per range: copy its slice of the sparse table to its dense position
 __global__ __launch_bounds__(256) void k_index_compact(RecordTable sp, uint64_t sparse_cap,
                                                        const uint64_t* __restrict__ range_count,
@@ -372,6 +497,12 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint64_t*)sums, offs, (uint32_t)nb);
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(256), 0, st, in, n, (const uint64_t*)offs, out);
     hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, st, (const uint64_t*)offs, nb, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_index_stitch(const RecordTable& dense, const RangePart* parts, const uint64_t* range_count,
+                               const uint64_t* range_base, uint32_t nranges, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_stitch, dim3(1), dim3(1), 0, st, dense, parts, range_count, range_base, nranges);
     return hipGetLastError();
 }
 

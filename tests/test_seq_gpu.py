@@ -224,3 +224,59 @@ def test_fasta_layout_from_index_pass_equals_separate_classification(monkeypatch
     for mode in ("", "classify"):
         monkeypatch.setenv("BSK_TEXT", mode)
         assert bsk.Seq(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts(opts)) == want, mode
+
+
+def test_records_much_longer_than_a_range_through_every_operator(monkeypatch):
+    """FASTA ranges begin on line starts: a record spans many ranges and k_index_stitch completes its table entry
+    (bases, region, line layout).  Every operator must see exactly the oracle's records."""
+    import json
+    import random
+    import oracle
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(321)
+    recs = []
+    specs = [(150_000, 60), (10, 60), (70_000, -1), (0, 60), (33_333, 11), (90_001, 80), (4096, 4096), (50_000, 16),
+             (25_000, -2), (61, 60)]
+    for k, (L, w) in enumerate(specs):
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        if w == -1:      # irregular wrapping
+            lines, j = [], 0
+            while j < L:
+                ww = rng.randint(1, 200)
+                lines.append(s[j:j + ww])
+                j += ww
+        elif w == -2:    # regular except one short line in the middle
+            lines = [s[j:j + 60] for j in range(0, L, 60)]
+            lines[len(lines) // 2] = lines[len(lines) // 2][:-7]
+        else:
+            lines = [s[j:j + w] for j in range(0, L, w)]
+        recs.append(f">chr{k} test record\n" + "".join(l + "\n" for l in lines))
+    data = "".join(recs).encode()
+    t = dev(data)
+    fr = lambda: bsk.SeqFrame(bsk.FORMAT_FASTA, [t])
+
+    class _Opts:  # the option object the operators mutate (Grep forces Count off)
+        def __init__(self, d):
+            self.d = dict(d)
+            self._v = self.d
+
+        def to_json(self):
+            return json.dumps(self.d)
+
+    for mode in ("", "classify"):
+        monkeypatch.setenv("BSK_TEXT", mode)
+        o = {"Reverse": True, "Complement": True, "Config": {"LineWidth": 50}}
+        assert bsk.Seq(fr(), _Opts(o)) == oracle.seq(data, False, json.dumps(o)), mode
+    monkeypatch.setenv("BSK_TEXT", "")
+    o = {}
+    assert bsk.Seq(fr(), _Opts(o)) == oracle.seq(data, False, json.dumps(o))
+    o = {"Region": "1000:-1000"}
+    assert bsk.Subseq(fr(), _Opts(o)) == oracle.subseq(data, False, json.dumps(o))
+    o = {"Pattern": ["ACGTACGTAC", "GGGGGGGGGGGG"], "BySeq": True}
+    assert bsk.Grep(fr(), _Opts(o)) == oracle.grep(data, False, json.dumps(o))
+    o = {"Pattern": ["ACGTACGT"]}
+    assert bsk.Locate(fr(), _Opts(o)) == oracle.locate(data, False, json.dumps(o))
+    o = {"Frame": ["6"], "AllowUnknownCodon": True}
+    assert bsk.Translate(fr(), _Opts(o)) == oracle.translate(data, False, json.dumps(o))
+    o = {"BySeq": True}
+    assert bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data + data)]), _Opts(o)) == oracle.rmdup(data + data, False, json.dumps(o))
