@@ -121,6 +121,10 @@ struct bsk_ctx {
     uint64_t feat_cap = 0;
     uint64_t feat_off[9] = {0};            // byte offsets of the arrays inside d_feat
     uint64_t feat_slots = 0;
+    uint32_t long_thresh = 1u << 20;        // BSK_LONG_BYTES overrides (tests)
+    uint64_t long_count = 0, long_max = 0;  // records with >= SEQ_LONG_THRESH output bytes in the last finish_sizes()
+    uint32_t* d_long_list = nullptr;
+    uint64_t long_list_cap = 0;
     uint32_t* d_hit_list = nullptr;        // locate: records with rows
     uint64_t hit_list_cap = 0;
     int64_t cur_pid = 0;                   // partition index of the running Call()

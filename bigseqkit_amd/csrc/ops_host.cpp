@@ -306,14 +306,34 @@ int ensure_record_scratch(bsk_ctx* c) {
 // size array -> scan -> total / kept / kernel status; then the caller emits
 static int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
     HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
-    uint64_t status = 0;
+    // records with a very large output are written by whole blocks (k_seq_emit<.., LONG>): list them now, the
+    // synchronisation below is needed anyway
+    int rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    {
+        const char* e = getenv("BSK_LONG_BYTES");
+        c->long_thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+    }
+    HIP_TRYX(c, launch_find_long(c->d_out_len, c->table.n, c->long_thresh, c->d_long_list, c->d_counter + 2, st));
+    uint64_t status = 0, lc[2] = {0, 0};
     HIP_TRYX(c, hipMemcpyAsync(total, c->d_out_off + c->table.n, sizeof *total, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipMemcpyAsync(kept, c->d_counter, sizeof *kept, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
+    c->long_count = lc[0];
+    c->long_max = lc[1];
     return kernel_error_to_status(c, status);
+}
+
+// tell the emit kernel which records it must leave to the block-per-chunk launch
+static void apply_long(const bsk_ctx* c, SeqParams* P) {
+    P->long_list = c->long_count ? c->d_long_list : nullptr;
+    P->long_count = c->long_count;
+    P->long_max = c->long_max;
+    P->long_thresh = c->long_count ? c->long_thresh : 0u;
 }
 
 static int empty_result(bsk_ctx* c, bsk_out* out) {
@@ -734,6 +754,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     if (rc != BSK_OK) return rc;
     SeqParams P = format_params(c, fastq);
     P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
+    apply_long(c, &P);
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
@@ -1138,6 +1159,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
+    apply_long(c, &P);
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
@@ -1456,6 +1478,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return rc;
     SeqParams F = format_params(c, fastq);
     F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
+    apply_long(c, &F);
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
@@ -1486,7 +1509,9 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             if (hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (hipMalloc((void**)&d_side, std::max<uint64_t>(1, std::max(dup_total, row_total))) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (!o.s("DupSeqsFile").empty() && dup_total) {
-                if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, d_side, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                SeqParams F2 = F;  // other sizes than the main output: every record goes through the per-record kernel
+                F2.long_list = nullptr; F2.long_count = 0;
+                if (launch_seq_emit(d_buf, c->table, F2, c->d_out_len, c->d_out_off, d_side, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
                 const size_t at = c->dup_seqs.size();
                 c->dup_seqs.resize(at + dup_total);
                 if (hipMemcpyAsync(&c->dup_seqs[at], d_side, dup_total, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1629,6 +1654,7 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     if (rc != BSK_OK) return rc;
     SeqParams F = format_params(c, fastq);
     if (!fastq) { F.text_w = c->table.text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
+    apply_long(c, &F);
     HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;
@@ -1724,18 +1750,12 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
-    uint64_t total = 0, kept = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&kept, c->d_counter, sizeof kept, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    rc = kernel_error_to_status(c, status);
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
+    apply_long(c, &P);
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     out->d_data = c->d_out;
     out->len = total;

@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
 
 // GROUP lanes per record: 16 for long records, 4 when the average output record is small (a 16-lane group would sit
 // idle on a 120-byte `subseq` record or a 317-byte read: 4x the waves for the same bytes)
-template <int GROUP>
+// LONG: records whose output is at least P.long_thresh bytes (chromosomes) are skipped by the per-record kernel and
+// written by whole blocks instead, one block per LONG_CH output bytes of one record (grid = chunks x long records).
+constexpr uint32_t LONG_CH = 64u * 1024u;
+
+template <int GROUP, bool LONG>
 __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
                                                   const uint32_t* __restrict__ out_len,
                                                   const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
@@ -176,11 +180,21 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = src ? src[i] : (uint8_t)i;
         __syncthreads();
     }
-    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
-    const uint32_t gl = threadIdx.x % GROUP;
+    constexpr uint32_t LANES = LONG ? 256u : (uint32_t)GROUP;  // lanes that share one record (or one chunk of it)
+    const uint64_t g = LONG ? (uint64_t)P.long_list[blockIdx.y] : ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = LONG ? threadIdx.x : threadIdx.x % GROUP;
     if (g >= t.n) return;
     const uint32_t n = out_len[g];
     if (n == 0) return;
+    if (!LONG && P.long_thresh && n >= P.long_thresh) return;  // written by the LONG launch
+    const uint32_t clo = LONG ? blockIdx.x * LONG_CH : 0u;       // this block's slice [clo, chi) of the record's output
+    if (clo >= n) return;
+    const uint32_t chi = LONG ? (n - clo < LONG_CH ? n : clo + LONG_CH) : n;
+    // 16-byte steps of a segment that sits at output offset `off`, restricted to the slice (a step that straddles a
+    // slice boundary is written by both neighbours with the same bytes)
+    auto first_step = [&](uint32_t off) -> uint32_t { return clo > off ? ((clo - off) & ~15u) : 0u; };
+    auto last_byte = [&](uint32_t off, uint32_t nb) -> uint32_t { return chi < off ? 0u : (chi - off < nb ? chi - off : nb); };
+    auto mine = [&](uint32_t x) -> bool { return x >= clo && x < chi; };  // single bytes
     uint8_t* o = out + out_off[g];
     const RecView r = view(buf, t, g, P.fastq);
     uint32_t hl = r.head_len, hoff = 0;
@@ -217,7 +231,8 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         !use_lut && !P.region_on && !P.feat_on && t.aux[g] == 1) {
         const uint8_t* src = buf + t.start[g];
         const uint32_t body = n - 1;  // everything but the final newline, which the shard may lack
-        for (uint32_t x = gl * 16u; x < body; x += GROUP * 16u) {
+        const uint32_t hi = last_byte(0, body);
+        for (uint32_t x = first_step(0) + gl * 16u; x < hi; x += LANES * 16u) {
             if (x + 16u <= body) {
                 uint4 v;
                 __builtin_memcpy(&v, src + x, 16);
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 for (uint32_t k = x; k < body; ++k) o[k] = src[k];
             }
         }
-        if (gl == 0) o[body] = '\n';
+        if (gl == 0 && mine(body)) o[body] = '\n';
         return;
     }
     if (fast) {
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         const bool verbatim = !reverse && !use_lut &&
                               ((TW == 0 && W == L) || (TW != 0 && (int)TW == P.line_width && sub_b == 0));
         if (verbatim) {
-            for (uint32_t x = gl; x < a; x += GROUP) {
+            for (uint32_t x = clo + gl; x < (a < chi ? a : chi); x += LANES) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 uint8_t c;
                 if (x < m) c = P.fastq ? '@' : '>';
@@ -250,8 +265,10 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 else c = r.head[hoff + x - m];
                 o[x] = c;
             }
-            auto group_copy = [&](uint8_t* dst, const uint8_t* src, uint32_t nb) {
-                for (uint32_t x = gl * 16u; x < nb; x += GROUP * 16u) {
+            auto group_copy = [&](uint32_t off, const uint8_t* src, uint32_t nb) {
+                uint8_t* dst = o + off;
+                const uint32_t hi = last_byte(off, nb);
+                for (uint32_t x = first_step(off) + gl * 16u; x < hi; x += LANES * 16u) {
                     if (x + 16u <= nb) {
                         uint4 v;
                         __builtin_memcpy(&v, src + x, 16);
@@ -262,17 +279,18 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 }
             };
             if (P.print_seq) {
-                group_copy(o + a, sp + (TW ? 0u : sub_b), W);
-                if (gl == 0) o[a + W] = '\n';
+                group_copy(a, sp + (TW ? 0u : sub_b), W);
+                if (gl == 0 && mine(a + W)) o[a + W] = '\n';
             }
             if (P.print_qual) {
                 uint32_t q0 = a + b;
                 if (!P.qual_only) {
-                    if (gl == 0) { o[q0] = '+'; o[q0 + 1] = '\n'; }
+                    if (gl == 0 && mine(q0)) o[q0] = '+';
+                    if (gl == 0 && mine(q0 + 1)) o[q0 + 1] = '\n';
                     q0 += 2;
                 }
-                group_copy(o + q0, rqual, L);
-                if (gl == 0) o[q0 + L] = '\n';
+                group_copy(q0, rqual, L);
+                if (gl == 0 && mine(q0 + L)) o[q0 + L] = '\n';
             }
             return;
         }
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         // (The LDS map holds P.lut, or the complement of a '-' strand feature; both are never active together.)
         const bool lut_in_lds = use_lut && (lut == P.lut ? P.use_lut != 0 : true);
         if (TW == 0 && W == L && (!use_lut || lut_in_lds)) {
-            for (uint32_t x = gl; x < a; x += GROUP) {
+            for (uint32_t x = clo + gl; x < (a < chi ? a : chi); x += LANES) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 uint8_t c;
                 if (x < m) c = P.fastq ? '@' : '>';
@@ -290,8 +308,10 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 else c = r.head[hoff + x - m];
                 o[x] = c;
             }
-            auto xform_copy = [&](uint8_t* dst, const uint8_t* src, uint32_t nb, bool map) {
-                for (uint32_t x = gl * 16u; x < nb; x += GROUP * 16u) {
+            auto xform_copy = [&](uint32_t off, const uint8_t* src, uint32_t nb, bool map) {
+                uint8_t* dst = o + off;
+                const uint32_t hi = last_byte(off, nb);
+                for (uint32_t x = first_step(off) + gl * 16u; x < hi; x += LANES * 16u) {
                     if (x + 16u <= nb) {
                         uint4 v;
                         __builtin_memcpy(&v, src + (reverse ? nb - 16u - x : x), 16);
@@ -319,21 +339,22 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 }
             };
             if (P.print_seq) {
-                xform_copy(o + a, sp + sub_b, L, use_lut);
-                if (gl == 0) o[a + L] = '\n';
+                xform_copy(a, sp + sub_b, L, use_lut);
+                if (gl == 0 && mine(a + L)) o[a + L] = '\n';
             }
             if (P.print_qual) {
                 uint32_t q0 = a + b;
                 if (!P.qual_only) {
-                    if (gl == 0) { o[q0] = '+'; o[q0 + 1] = '\n'; }
+                    if (gl == 0 && mine(q0)) o[q0] = '+';
+                    if (gl == 0 && mine(q0 + 1)) o[q0 + 1] = '\n';
                     q0 += 2;
                 }
-                xform_copy(o + q0, rqual, L, false);
-                if (gl == 0) o[q0 + L] = '\n';
+                xform_copy(q0, rqual, L, false);
+                if (gl == 0 && mine(q0 + L)) o[q0 + L] = '\n';
             }
             return;
         }
-        for (uint32_t x = gl; x < n; x += GROUP) {
+        for (uint32_t x = clo + gl; x < chi; x += LANES) {
             uint8_t c;
             if (x < a) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         return;
     }
     // sequential path: gap removal and / or a multi-line FASTA source without a text view
-    if (gl != 0) return;
+    if (gl != 0 || clo != 0) return;  // (LONG: the first chunk's lane walks the whole record)
     uint32_t x = 0;
     if (P.print_name) {
         if (P.print_seq) o[x++] = P.fastq ? '@' : '>';
@@ -432,18 +453,47 @@ hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqPa
     return hipGetLastError();
 }
 
-hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& P, const uint32_t* out_len,
+hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& Pin, const uint32_t* out_len,
                            const uint64_t* out_off, uint8_t* out, hipStream_t st, uint64_t total_bytes, uint64_t records) {
     if (t.n == 0) return hipSuccess;
+    SeqParams P = Pin;
+    if (!(P.long_list && P.long_count)) P.long_thresh = 0u;
     // tiny records (names only) are written by the per-byte path: one pass of 16 lanes beats three of 4
     const bool small = records > 0 && total_bytes / records < 1024 && total_bytes / records >= 48;
     if (small) {
         const uint64_t blocks = (t.n * 4 + 255) / 256;
-        hipLaunchKernelGGL(k_seq_emit<4>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
+        hipLaunchKernelGGL((k_seq_emit<4, false>), dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
     } else {
         const uint64_t blocks = (t.n * 16 + 255) / 256;
-        hipLaunchKernelGGL(k_seq_emit<16>, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
+        hipLaunchKernelGGL((k_seq_emit<16, false>), dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);
     }
+    if (P.long_thresh) {
+        const unsigned chunks = (unsigned)((P.long_max + LONG_CH - 1) / LONG_CH);
+        hipLaunchKernelGGL((k_seq_emit<16, true>), dim3(chunks, (unsigned)P.long_count), dim3(256), 0, st, buf, t, P, out_len,
+                           out_off, out);
+    }
+    return hipGetLastError();
+}
+
+// indices of the records whose output is at least `thresh` bytes (any order), their number and the largest size
+__global__ __launch_bounds__(256) void k_find_long(const uint32_t* __restrict__ out_len, uint64_t n, uint32_t thresh,
+                                                   uint32_t* __restrict__ list, unsigned long long* __restrict__ count_max) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = out_len[i];
+        if (v >= thresh) {  // rare by construction (a record of a MiB or more)
+            list[atomicAdd(&count_max[0], 1ull)] = (uint32_t)i;
+            atomicMax(&count_max[1], (unsigned long long)v);
+        }
+    }
+}
+
+hipError_t launch_find_long(const uint32_t* out_len, uint64_t n, uint32_t thresh, uint32_t* list, uint64_t* count_max,
+                            hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_find_long, dim3((unsigned)blocks), dim3(256), 0, st, out_len, n, thresh, list,
+                       (unsigned long long*)count_max);
     return hipGetLastError();
 }
 

@@ -48,7 +48,13 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     const uint32_t* fsuffix_off;
     const uint8_t* comp;                    // complement map of the shard's alphabet
     const uint8_t* buf_end;                 // one past the shard, or null (the ID search then reads byte by byte)
+    // records with a very large output (chromosomes): written by whole blocks, see k_seq_emit<.., LONG>
+    const uint32_t* long_list;              // their indices (launch_find_long), or null
+    uint64_t long_count, long_max;          // how many, and the largest output size
+    uint32_t long_thresh;                   // output bytes from which a record is 'long' (0: none are)
 };
+
+constexpr uint32_t SEQ_LONG_THRESH = 1u << 20;  // output bytes from which a record is 'long'
 
 constexpr uint32_t ERR_INVALID_LETTER = 128u;
 
@@ -77,6 +83,10 @@ hipError_t launch_seq_size(const uint8_t* buf, const RecordTable& t, const SeqPa
 hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqParams& P, const uint32_t* out_len,
                            const uint64_t* out_off, uint8_t* out, hipStream_t st, uint64_t total_bytes = 0,
                            uint64_t records = 0);
+// list := indices of the records with out_len >= thresh; count_max[0] := their number, [1] := max out_len
+// (both zeroed by the caller).  At most 2^32 / SEQ_LONG_THRESH... the list needs one slot per such record.
+hipError_t launch_find_long(const uint32_t* out_len, uint64_t n, uint32_t thresh, uint32_t* list, uint64_t* count_max,
+                            hipStream_t st);
 hipError_t launch_count_nonzero(const uint32_t* v, uint64_t n, uint64_t* counter, hipStream_t st);
 
 }  // namespace bsk

@@ -233,6 +233,7 @@ def test_records_much_longer_than_a_range_through_every_operator(monkeypatch):
     import random
     import oracle
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_LONG_BYTES", "30000")   # records above 30 kB of output take the block-per-chunk emit
     rng = random.Random(321)
     recs = []
     specs = [(150_000, 60), (10, 60), (70_000, -1), (0, 60), (33_333, 11), (90_001, 80), (4096, 4096), (50_000, 16),
