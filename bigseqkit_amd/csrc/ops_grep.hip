@@ -69,44 +69,30 @@ __device__ __forceinline__ uint32_t window_candidates(const uint32_t (&dw)[8], u
 
 // GROUP lanes per record: the kernel is bound by the chain of dependent loads per wave (record table -> window -> verify),
 // so short reads use 4 lanes (16 records per wave in flight), long sequences 16.
-template <int GROUP>
-__global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+// LONG: sequences of at least P.long_thresh bases (chromosomes) are skipped here and searched by whole blocks,
+// GREP_LONG_CH start positions per block (grid = chunks x long records); a hit sets P.long_hit[record slot] and
+// k_grep_long_finish turns the flags into output sizes.
+constexpr uint32_t GREP_LONG_CH = 256u * 1024u;
+
+template <int GROUP, bool LONG>
+__global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                   GrepParams P, uint32_t* __restrict__ out_len) {
-    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
-    const uint32_t gl = threadIdx.x % GROUP;
+    constexpr uint32_t LANES = LONG ? 256u : (uint32_t)GROUP;
+    const uint64_t g = LONG ? (uint64_t)P.long_list[blockIdx.y] : ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = LONG ? threadIdx.x : threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;  // position of this group inside the wave
     constexpr uint64_t GMASK = (1ull << GROUP) - 1ull;
     const bool live = g < t.n;
     const uint64_t gi = live ? g : 0;
-    const uint64_t s = t.start[gi];
+    const Text T = text_of(buf, t, tt, gi);  // wrapped FASTA in place (W), irregular FASTA linearised
+    const uint32_t L = live ? T.L : 0;
     const uint32_t lh = t.l_head[gi];
-    const uint32_t L = live ? t.l_seq[gi] : 0;
-    Text T;
-    T.p = buf + s + lh + 1;
-    T.L = L;
-    T.W = 0;
-    bool sequential = false;
-    if (!P.fastq && live) {
-        // multi-line FASTA: usable as an array iff every line but the last has the same width
-        const uint32_t region = t.aux[gi];
-        const uint32_t tail_nl = (region > 0 && T.p[region - 1] == '\n') ? 1u : 0u;
-        const uint32_t nnl = region - L;  // newlines in the region
-        if (nnl > tail_nl) {
-            uint32_t W = 0;
-            while (W < region && T.p[W] != '\n') ++W;  // first line
-            const uint32_t lines = W ? (L + W - 1) / W : 0;
-            bool ok = W > 0 && nnl == lines - 1 + tail_nl;
-            if (ok)
-                for (uint32_t k = gl; k + 1 < lines; k += GROUP)
-                    if (T.p[(uint64_t)k * (W + 1) + W] != '\n') ok = false;
-            const uint64_t bad = __ballot(!ok);
-            if ((bad >> gshift) & GMASK) sequential = true;
-            else T.W = W;
-        }
-    }
+    if (!LONG && P.long_thresh && L >= P.long_thresh) return;  // searched by the LONG launch (whole groups leave)
+    const uint64_t plo = LONG ? (uint64_t)blockIdx.x * GREP_LONG_CH : 0ull;  // this block's start positions [plo, phi)
+    const uint64_t phi = LONG ? plo + GREP_LONG_CH : ~0ull;
     bool hit = false;
     const int nstr = P.both_strands ? 2 : 1;
-    const bool fast = live && !sequential && T.W == 0 && !P.circular;
+    const bool fast = live && T.W == 0 && !P.circular && T.p >= buf && T.p < buf + buf_n;
     if (fast) {
         const uint8_t* const buf_end = buf + buf_n;
         for (int strand = 0; strand < nstr && !hit; ++strand) {
@@ -128,10 +114,11 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
                 uint32_t p32 = 0;
                 for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
                 const uint32_t pmask = m >= 4 ? 0xFFFFFFFFu : ((1u << (8 * m)) - 1u);
-                for (uint32_t i0 = 0; i0 < npos; i0 += GROUP * 16) {
+                const uint32_t iend = phi < npos ? (uint32_t)phi : npos;
+                for (uint32_t i0 = (uint32_t)(plo < npos ? plo : npos); i0 < iend; i0 += LANES * 16) {
                     const uint32_t ib = i0 + gl * 16u;  // first start position of this lane
                     bool ok = false;
-                    if (ib < npos) {
+                    if (ib < iend) {
                         const uint8_t* src = T.p + wb + ib;
                         uint32_t dw[8];
                         if (src + 32 <= buf_end) {
@@ -162,12 +149,15 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
                             ok = verify_from4(src + b, buf_end, P.ignore_case, pp, m);
                         }
                     }
-                    const uint64_t any = __ballot(ok);
-                    if ((any >> gshift) & GMASK) { hit = true; break; }
+                    if (LONG) { if (ok) hit = true; }
+                    else {
+                        const uint64_t any = __ballot(ok);
+                        if ((any >> gshift) & GMASK) { hit = true; break; }
+                    }
                 }
             }
         }
-    } else if (live && !sequential) {
+    } else if (live) {
         for (int strand = 0; strand < nstr && !hit; ++strand) {
             // window of the forward text that the strand's target covers
             uint32_t wb = 0, we = L;
@@ -178,93 +168,62 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
                 else { wb = L - e; we = L - b; }  // SubSeq of RevCom(S) mirrored onto S
             }
             const uint32_t wl = we - wb;
-            const uint32_t tl = P.circular ? 2 * wl : wl;  // --circular doubles the target (grep.go:449-454)
+            const uint64_t tl = P.circular ? 2ull * wl : wl;  // --circular doubles the target (grep.go:449-454)
             for (int k = 0; k < P.npat && !hit; ++k) {
                 const int pk = strand * P.npat + k;
                 const uint8_t* pp = P.pat + P.pat_off[pk];
                 const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
                 if (m == 0) { hit = true; break; }  // bytes.Contains(x, "") is true
                 if (m > tl) continue;
-                const uint32_t npos = tl - m + 1;
+                const uint64_t npos = tl - m + 1;
                 const uint8_t p0 = pp[0];
-                for (uint32_t i0 = 0; i0 < npos; i0 += GROUP) {
-                    const uint32_t i = i0 + gl;
+                const uint64_t iend = phi < npos ? phi : npos;
+                for (uint64_t i0 = plo < npos ? plo : npos; i0 < iend; i0 += LANES) {
+                    const uint64_t i = i0 + gl;
                     bool ok = false;
-                    if (i < npos) {
-                        uint32_t j = i >= wl ? i - wl : i;  // circular wrap
-                        uint8_t c = T.at(wb + j);
+                    if (i < iend) {
+                        uint64_t j = i >= wl ? i - wl : i;  // circular wrap
+                        uint8_t c = T.at(wb + (uint32_t)j);
                         if (P.ignore_case) c = lower8(c);
                         if (c == p0) {
                             ok = true;
                             for (uint32_t q = 1; q < m; ++q) {
-                                uint32_t jj = i + q;
+                                uint64_t jj = i + q;
                                 if (jj >= wl) jj -= wl;  // only reachable when circular (jj < 2 wl)
-                                uint8_t cc = T.at(wb + jj);
+                                uint8_t cc = T.at(wb + (uint32_t)jj);
                                 if (P.ignore_case) cc = lower8(cc);
                                 if (cc != pp[q]) { ok = false; break; }
                             }
                         }
                     }
-                    const uint64_t any = __ballot(ok);
-                    if ((any >> gshift) & GMASK) { hit = true; break; }
-                }
-            }
-        }
-    } else if (live && gl == 0) {
-        // irregularly wrapped FASTA: one lane walks the region, newlines skipped
-        const uint32_t region = t.aux[gi];
-        for (int strand = 0; strand < nstr && !hit; ++strand) {
-            uint32_t wb = 0, we = L;
-            if (P.region_on) {
-                uint32_t b, e;
-                sub_location(L, P.region_start, P.region_end, &b, &e);
-                if (strand == 0) { wb = b; we = e; }
-                else { wb = L - e; we = L - b; }
-            }
-            const uint32_t wl = we - wb, tl = P.circular ? 2 * wl : wl;
-            for (int k = 0; k < P.npat && !hit; ++k) {
-                const int pk = strand * P.npat + k;
-                const uint8_t* pp = P.pat + P.pat_off[pk];
-                const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
-                if (m == 0) { hit = true; break; }
-                if (m > tl) continue;
-                // raw offset of base wb (newlines skipped)
-                uint32_t raw0 = 0, bi = 0;
-                for (;;) {
-                    while (raw0 < region && T.p[raw0] == '\n') ++raw0;
-                    if (bi == wb) break;
-                    ++raw0;
-                    ++bi;
-                }
-                uint32_t r = raw0;  // raw offset of window base (i mod wl)
-                for (uint32_t i = 0; i + m <= tl && !hit; ++i) {
-                    if (i == wl) r = raw0;  // second copy of a circular target
-                    uint32_t cur = r, pos = i >= wl ? i - wl : i;
-                    bool ok = true;
-                    for (uint32_t q = 0; q < m; ++q) {
-                        if (pos == wl) { pos = 0; cur = raw0; }  // wrap (circular only)
-                        while (T.p[cur] == '\n') ++cur;
-                        uint8_t c = T.p[cur];
-                        if (P.ignore_case) c = lower8(c);
-                        if (c != pp[q]) { ok = false; break; }
-                        ++cur;
-                        ++pos;
+                    if (LONG) { if (ok) hit = true; }
+                    else {
+                        const uint64_t any = __ballot(ok);
+                        if ((any >> gshift) & GMASK) { hit = true; break; }
                     }
-                    if (ok) hit = true;
-                    ++r;
-                    while (r < region && T.p[r] == '\n') ++r;
                 }
             }
         }
     }
-    if (sequential) {
-        const uint64_t any = __ballot(hit);
-        hit = ((any >> gshift) & GMASK) != 0;
+    if (LONG) {
+        if (hit) atomicOr(&P.long_hit[blockIdx.y], 1u);
+        return;
     }
     if (live && gl == 0) {
         const bool sel = P.invert ? !hit : hit;
         out_len[g] = sel ? format_len(lh > 0 ? lh - 1 : 0, L, P.fastq, P.line_width) : 0u;
     }
+}
+
+// output sizes of the long records from the flags the LONG search left
+__global__ void k_grep_long_finish(RecordTable t, GrepParams P, uint32_t* __restrict__ out_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.long_count) return;
+    const uint64_t g = P.long_list[i];
+    const bool hit = P.long_hit[i] != 0;
+    const bool sel = P.invert ? !hit : hit;
+    const uint32_t lh = t.l_head[g];
+    out_len[g] = sel ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[g], P.fastq, P.line_width) : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -448,11 +407,17 @@ hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTab
         const uint64_t blocks = (t.n * GROUP + 255) / 256;
         hipLaunchKernelGGL(k_grep_seq_gen, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len);
     } else if (P.by_seq) {
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
         const uint64_t avg = buf_n / t.n;  // bytes per record
         if (avg < 1024) {
-            hipLaunchKernelGGL(k_grep_seq<BSK_GREP_LANES>, dim3((unsigned)((t.n * BSK_GREP_LANES + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, P, out_len);
+            hipLaunchKernelGGL((k_grep_seq<BSK_GREP_LANES, false>), dim3((unsigned)((t.n * BSK_GREP_LANES + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);
         } else {
-            hipLaunchKernelGGL(k_grep_seq<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, P, out_len);
+            hipLaunchKernelGGL((k_grep_seq<16, false>), dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);
+        }
+        if (P.long_thresh && P.long_count) {
+            const unsigned chunks = (unsigned)(((uint64_t)P.long_max * (P.circular ? 2 : 1) + GREP_LONG_CH - 1) / GREP_LONG_CH);
+            hipLaunchKernelGGL((k_grep_seq<16, true>), dim3(chunks, (unsigned)P.long_count), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);
+            hipLaunchKernelGGL(k_grep_long_finish, dim3((unsigned)((P.long_count + 255) / 256)), dim3(256), 0, st, t, P, out_len);
         }
     } else {
         const uint64_t blocks = (t.n + 255) / 256;

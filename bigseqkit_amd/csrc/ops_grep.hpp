@@ -26,6 +26,11 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     // -r: Glushkov programs (regex_nfa.hpp), `npat` of them, in device memory; comp: complement map for the '-' strand
     const struct RegexProgram* regex;
     const uint8_t* comp;
+    // sequences of at least long_thresh bases are searched by whole blocks (k_grep_seq<.., LONG>)
+    const uint32_t* long_list;  // their record indices
+    uint32_t* long_hit;         // one flag per entry of long_list (zeroed by the caller)
+    uint64_t long_count, long_max;
+    uint32_t long_thresh;
     const uint8_t* buf_end;    // one past the shard (lets the ID search read 16 bytes at a time)
     const uint64_t* set_keys;  // null: linear scan over the patterns
     const uint32_t* set_idx;

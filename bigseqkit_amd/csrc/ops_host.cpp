@@ -728,6 +728,28 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.pat_off = c->d_pat_off;
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
+        if (G.by_seq && !G.general && !G.regex) {
+            // chromosome-sized sequences are searched by whole blocks (k_grep_seq<.., LONG>): list them
+            const char* e = getenv("BSK_LONG_BYTES");
+            const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+            rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+            HIP_TRYX(c, launch_find_long(c->table.l_seq, c->table.n, thresh, c->d_long_list, c->d_counter + 2, st));
+            uint64_t lc[2] = {0, 0};
+            HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (lc[0]) {
+                rc = grow(c, &c->d_hit_list, &c->hit_list_cap, lc[0], 64);
+                if (rc != BSK_OK) return rc;
+                HIP_TRYX(c, hipMemsetAsync(c->d_hit_list, 0, lc[0] * sizeof(uint32_t), st));
+                G.long_list = c->d_long_list;
+                G.long_hit = c->d_hit_list;
+                G.long_count = lc[0];
+                G.long_max = lc[1];
+                G.long_thresh = thresh;
+            }
+        }
         HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st));
         rc = finish_sizes(c, st, &total, &kept);
         if (rc != BSK_OK) return rc;
