@@ -235,6 +235,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_feat) hipFree(c->d_feat);
         if (c->d_regex) hipFree(c->d_regex);
         if (c->d_hit_list) hipFree(c->d_hit_list);
+        if (c->d_cells) hipFree(c->d_cells);
+        if (c->d_cellmeta) hipFree(c->d_cellmeta);
         if (c->d_long_list) hipFree(c->d_long_list);
         if (c->d_keys2) hipFree(c->d_keys2);
         if (c->d_own) hipFree(c->d_own);

@@ -125,6 +125,10 @@ struct bsk_ctx {
     uint64_t long_count = 0, long_max = 0;  // records with >= SEQ_LONG_THRESH output bytes in the last finish_sizes()
     uint32_t* d_long_list = nullptr;
     uint64_t long_list_cap = 0;
+    // locate, long records: cells (pattern, strand, chunk) -- see LocateParams
+    uint8_t* d_cellmeta = nullptr;         // cell counts[count] ++ cellbase[count + 1]
+    uint8_t* d_cells = nullptr;            // cell_bytes[cells] ++ cell_off[cells + 1]
+    uint64_t cells_cap = 0, cellmeta_cap = 0;
     uint32_t* d_hit_list = nullptr;        // locate: records with rows
     uint64_t hit_list_cap = 0;
     int64_t cur_pid = 0;                   // partition index of the running Call()

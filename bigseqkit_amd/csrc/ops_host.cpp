@@ -916,8 +916,55 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         if (rc != BSK_OK) return rc;
         P.hit_list = c->d_hit_list;
         P.hit_count = c->d_counter;
+        // chromosome-sized sequences: one wave per (pattern, strand, chunk) cell instead of one group per record
+        // (not with --non-greedy, whose search position depends on the previous match)
+        uint64_t ncells_total = 0;
+        const uint64_t per_cells = (uint64_t)P.npat * (P.both_strands ? 2 : 1);
+        if (!P.non_greedy && per_cells < 32768) {  // (cells of one record are counted in 32 bits: chunks <= 2^17)
+            const char* e = getenv("BSK_LONG_BYTES");
+            const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+            rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+            HIP_TRYX(c, launch_find_long(c->table.l_seq, c->table.n, thresh, c->d_long_list, c->d_counter + 2, st));
+            uint64_t lc[2] = {0, 0};
+            HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (lc[0]) {
+                const uint64_t nl = lc[0];
+                auto al = [](uint64_t b) { return (b + 15) & ~15ull; };
+                // cell counts -> cellbase (record order does not matter: every record has its own rows)
+                const uint64_t o_nc = 0, o_cb = al(nl * 4), meta = o_cb + al((nl + 1) * 8);
+                rc = grow(c, &c->d_cellmeta, &c->cellmeta_cap, meta, meta / 8 + 64);
+                if (rc != BSK_OK) return rc;
+                rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, 2 * ((nl + 2047) / 2048) + 4, 16);
+                if (rc != BSK_OK) return rc;
+                P.long_list = c->d_long_list;
+                P.long_count = nl;
+                P.cellbase = (const uint64_t*)(c->d_cellmeta + o_cb);
+                HIP_TRYX(c, launch_locate_long_cells(c->table, P, (uint32_t*)(c->d_cellmeta + o_nc), st));
+                HIP_TRYX(c, launch_scan_u32((const uint32_t*)(c->d_cellmeta + o_nc), const_cast<uint64_t*>(P.cellbase), nl,
+                                            c->d_scan_tmp, st));
+                HIP_TRYX(c, hipMemcpyAsync(&ncells_total, P.cellbase + nl, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                const uint64_t o_off = al(ncells_total * 4), need = o_off + al((ncells_total + 1) * 8);
+                rc = grow(c, &c->d_cells, &c->cells_cap, need, need / 8 + 64);
+                if (rc != BSK_OK) return rc;
+                rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, 2 * ((ncells_total + 2047) / 2048) + 4, 16);
+                if (rc != BSK_OK) return rc;
+                P.cell_bytes = (uint32_t*)c->d_cells;
+                P.cell_off = (const uint64_t*)(c->d_cells + o_off);
+                P.long_cells = ncells_total;
+                P.long_thresh = thresh;
+            }
+        }
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
         HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
+        if (P.long_count) {
+            // place every cell inside its record's rows, then the record sizes
+            HIP_TRYX(c, launch_scan_u32(P.cell_bytes, const_cast<uint64_t*>(P.cell_off), ncells_total, c->d_scan_tmp, st));
+            HIP_TRYX(c, launch_locate_long_sizes(P, c->d_out_len, st));
+        }
         HIP_TRYX(c, launch_compact_hits(c->d_out_len, c->table.n, c->d_hit_list, c->d_counter, st));
         HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
         uint64_t status = 0;

@@ -198,17 +198,48 @@ __device__ __forceinline__ uint32_t window_hits(const uint8_t* src, const uint8_
 
 // GROUP lanes per record (4 for reads: the kernel is bound by dependent-load latency per wave, not by lanes; 16 for
 // long sequences)
-template <bool EMIT, bool GEN, int GROUP>
+// LONG (GROUP == 64): one wave per cell (pattern, strand, chunk of start positions) of a chromosome-sized record, see
+// LocateParams::long_list; the per-record launches leave those records alone.
+template <bool EMIT, bool GEN, int GROUP, bool LONG>
 __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                 LocateParams P, uint32_t* __restrict__ out_len,
                                                 const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                 uint64_t* __restrict__ rows) {
-    const uint64_t slot = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint64_t slot = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;  // LONG: cell index inside the record
     const uint32_t gl = threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & 63) / GROUP * GROUP;
-    constexpr uint64_t GMASK = (1ull << GROUP) - 1ull;
-    const bool live = EMIT ? slot < P.nhit : slot < t.n;
-    const uint64_t g = EMIT ? (live ? (uint64_t)P.hit_list[slot] : 0) : slot;
+    constexpr uint64_t GMASK = GROUP >= 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    const int nstr = P.both_strands ? 2 : 1;
+    bool live;
+    uint64_t g;
+    int cell_k = 0, cell_strand = 0;
+    uint64_t a_lo = 0, a_hi = ~0ull;  // start positions this group searches (strand frame)
+    uint64_t cell_at = 0;             // LONG: index of this cell in cell_bytes / cell_off
+    uint64_t cell_rec0 = 0;           // LONG: first cell of this cell's record
+    if constexpr (LONG) {
+        cell_at = slot;  // one flat grid over the cells of all long records
+        live = cell_at < P.long_cells;
+        // the record of this cell: last y with cellbase[y] <= cell_at   (wave-uniform)
+        uint64_t ylo = 0, yhi = P.long_count;
+        while (live && yhi - ylo > 1) {
+            const uint64_t mid = (ylo + yhi) >> 1;
+            if (P.cellbase[mid] <= cell_at) ylo = mid; else yhi = mid;
+        }
+        g = live ? P.long_list[ylo] : 0;
+        cell_rec0 = live ? P.cellbase[ylo] : 0;
+        const uint64_t ln = live ? (P.circular ? 2ull * t.l_seq[g] : (uint64_t)t.l_seq[g]) : 1;
+        const uint32_t nch = (uint32_t)((ln + LOCATE_LONG_CH - 1) / LOCATE_LONG_CH);
+        const uint64_t cell = live ? cell_at - cell_rec0 : 0;
+        const uint32_t per = (uint32_t)(cell / nch), c = (uint32_t)(cell % nch);  // cells are numbered in row order
+        if (P.fmi_order) { cell_strand = (int)(per / (uint32_t)P.npat); cell_k = (int)(per % (uint32_t)P.npat); }
+        else { cell_k = (int)(per / (uint32_t)nstr); cell_strand = (int)(per % (uint32_t)nstr); }
+        a_lo = (uint64_t)c * LOCATE_LONG_CH;
+        a_hi = a_lo + LOCATE_LONG_CH;
+    } else {
+        live = EMIT ? slot < P.nhit : slot < t.n;
+        g = EMIT ? (live ? (uint64_t)P.hit_list[slot] : 0) : slot;
+        if (live && P.long_thresh && t.l_seq[g] >= P.long_thresh) live = false;  // a cell launch handles this record
+    }
     const uint64_t gi = live ? g : 0;
     const Text T = text_of(buf, t, tt, gi);
     const uint32_t l = live ? T.L : 0;
@@ -238,11 +269,13 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     uint64_t bytes = 0;  // running row bytes of this record (group-uniform)
     uint32_t nrows = 0;
     uint8_t* o = EMIT ? out + out_off[gi] : nullptr;
-    const int nstr = P.both_strands ? 2 : 1;
+    if constexpr (LONG && EMIT) { if (live) o += P.cell_off[cell_at] - P.cell_off[cell_rec0]; }
     // reference loop order: per pattern both strands (locate.go:575-767); FM-index branch: per strand all patterns
     const int n_outer = P.fmi_order ? nstr : P.npat, n_inner = P.fmi_order ? P.npat : nstr;
-    for (int lo_ = 0; lo_ < n_outer; ++lo_)
-    for (int li_ = 0; li_ < n_inner; ++li_) {
+    // (a cell is one iteration of this nest)
+    const int lo_0 = LONG ? (P.fmi_order ? cell_strand : cell_k) : 0, li_0 = LONG ? (P.fmi_order ? cell_k : cell_strand) : 0;
+    for (int lo_ = lo_0; lo_ < (LONG ? lo_0 + 1 : n_outer); ++lo_)
+    for (int li_ = li_0; li_ < (LONG ? li_0 + 1 : n_inner); ++li_) {
         const int k = P.fmi_order ? li_ : lo_;
         const int strand = P.fmi_order ? lo_ : li_;
         R.name = P.name + P.name_off[k];
@@ -279,11 +312,12 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                 uint32_t p32 = 0;  // first min(m, 4) pattern bytes, loaded once per (record, pattern, strand)
                 for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
                 const uint32_t pmask = m >= 4 ? 0xFFFFFFFFu : ((1u << (8 * m)) - 1u);
-                for (uint32_t a0 = 0; a0 < npos32; a0 += GROUP * 16) {
+                const uint32_t aend32 = a_hi < npos32 ? (uint32_t)a_hi : npos32;
+                for (uint32_t a0 = a_lo < npos32 ? (uint32_t)a_lo : npos32; a0 < aend32; a0 += GROUP * 16) {
                     const uint32_t ib = a0 + gl * 16u;  // first position of this lane, strand frame
                     uint32_t hits = 0;                           // bit k <-> position ib + k (ascending)
-                    if (ib < npos32) {
-                        const uint32_t left0 = npos32 - ib;
+                    if (ib < aend32) {
+                        const uint32_t left0 = aend32 - ib;
                         const uint32_t valid = left0 < 16u ? (1u << left0) - 1u : 0xFFFFu;  // positions ib .. ib + 15 that exist
                         if (strand == 0) {
                             hits = window_hits(T.p + ib, buf_end, P.ignore_case, pp, m, p32, pmask, valid);
@@ -298,10 +332,10 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                             const uint32_t h = window_hits(T.p, buf_end, P.ignore_case, pp, m, p32, pmask, (2u << D) - 1u);
                             hits = __brev(h) >> (31u - D);
                         }
-                        const uint32_t left = npos32 - ib;
+                        const uint32_t left = aend32 - ib;
                         if (left < 16u) hits &= (1u << left) - 1u;
                     }
-                    const uint32_t gmask = (uint32_t)((__ballot(hits != 0) >> gshift) & GMASK);
+                    const uint64_t gmask = (__ballot(hits != 0) >> gshift) & GMASK;
                     if (gmask == 0) continue;
                     need_id();
                     uint32_t mine = 0, cnt = 0;
@@ -334,17 +368,18 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                     nrows += totc;
                 }
             } else if (!P.non_greedy) {
-                for (uint64_t a0 = 0; a0 < npos; a0 += GROUP) {
+                const uint64_t aend = a_hi < npos ? a_hi : npos;
+                for (uint64_t a0 = a_lo < npos ? a_lo : npos; a0 < aend; a0 += GROUP) {
                     const uint64_t a = a0 + gl;
                     bool hit = false;
                     int64_t begin = 0, end = 0;
-                    if (a < npos) {
+                    if (a < aend) {
                         const uint64_t f = strand ? n - a - m : a;  // forward position of the occurrence
                         hit = matches(f);
                         coords(a, &begin, &end);
                         R.f = f;
                     }
-                    const uint32_t mask = (uint32_t)((__ballot(hit) >> gshift) & GMASK);
+                    const uint64_t mask = (__ballot(hit) >> gshift) & GMASK;
                     if (mask == 0) continue;
                     need_id();
                     uint32_t mine = hit ? row_len(R, begin, end) : 0u;
@@ -358,7 +393,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
                     const uint32_t tot = (uint32_t)__shfl((int)incl, GROUP - 1, GROUP);
                     if (EMIT && hit) row_put(o + bytes + (incl - mine), R, sc, begin, end);
                     bytes += tot;
-                    nrows += (uint32_t)__popc(mask);
+                    nrows += (uint32_t)__popcll(mask);
                 }
             } else if (gl == 0) {
                 need_id();
@@ -396,6 +431,10 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
         __syncthreads();
         if (threadIdx.x == 0 && s_rows) atomicAdd((unsigned long long*)rows, (unsigned long long)s_rows);
     }
+    if constexpr (LONG && !EMIT) {
+        if (live && gl == 0) P.cell_bytes[cell_at] = (uint32_t)bytes;
+        return;
+    }
     if (live && gl == 0) {
         if (!EMIT) {
             // no global atomics here: 2 % of 39 M records hitting one counter cost more than the whole search
@@ -426,7 +465,34 @@ __global__ __launch_bounds__(256) void k_compact_hits(const uint32_t* __restrict
         if (out_len[i] != 0) hit_list[s_base + atomicAdd(&s_cnt, 1u)] = (uint32_t)i;
 }
 
+// out_len of a long record = bytes of all its cells
+__global__ void k_locate_long_sizes(LocateParams P, uint32_t* __restrict__ out_len) {
+    const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= P.long_count) return;
+    out_len[P.long_list[y]] = (uint32_t)(P.cell_off[P.cellbase[y + 1]] - P.cell_off[P.cellbase[y]]);
+}
+
+__global__ void k_locate_long_cells(RecordTable t, LocateParams P, uint32_t* __restrict__ ncells) {
+    const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= P.long_count) return;
+    const uint64_t l = t.l_seq[P.long_list[y]];
+    const uint64_t n = P.circular ? 2ull * l : l;
+    ncells[y] = (uint32_t)((n + LOCATE_LONG_CH - 1) / LOCATE_LONG_CH) * (uint32_t)(P.npat * (P.both_strands ? 2 : 1));
+}
+
 }  // namespace
+
+hipError_t launch_locate_long_cells(const RecordTable& t, const LocateParams& P, uint32_t* ncells, hipStream_t st) {
+    if (!P.long_count) return hipSuccess;
+    hipLaunchKernelGGL(k_locate_long_cells, dim3((unsigned)((P.long_count + 255) / 256)), dim3(256), 0, st, t, P, ncells);
+    return hipGetLastError();
+}
+
+hipError_t launch_locate_long_sizes(const LocateParams& P, uint32_t* out_len, hipStream_t st) {
+    if (!P.long_count) return hipSuccess;
+    hipLaunchKernelGGL(k_locate_long_sizes, dim3((unsigned)((P.long_count + 255) / 256)), dim3(256), 0, st, P, out_len);
+    return hipGetLastError();
+}
 
 hipError_t launch_compact_hits(const uint32_t* out_len, uint64_t n, uint32_t* hit_list, uint64_t* hit_count, hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -442,20 +508,29 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     const uint64_t groups = emit ? P.nhit : t.n;
-    if (groups == 0) return hipSuccess;
     const bool small = buf_n / t.n < 1024;  // bytes per record
     const int G = small ? 4 : 16;
     const uint64_t blocks = (groups * G + 255) / 256;
     const dim3 gr((unsigned)blocks), bl(256);
-#define BSK_LAUNCH_LOCATE(E, GE, GG) hipLaunchKernelGGL((k_locate<E, GE, GG>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows)
-    if (small) {
-        if (P.general) { if (emit) BSK_LAUNCH_LOCATE(true, true, 4); else BSK_LAUNCH_LOCATE(false, true, 4); }
-        else { if (emit) BSK_LAUNCH_LOCATE(true, false, 4); else BSK_LAUNCH_LOCATE(false, false, 4); }
-    } else {
-        if (P.general) { if (emit) BSK_LAUNCH_LOCATE(true, true, 16); else BSK_LAUNCH_LOCATE(false, true, 16); }
-        else { if (emit) BSK_LAUNCH_LOCATE(true, false, 16); else BSK_LAUNCH_LOCATE(false, false, 16); }
+#define BSK_LAUNCH_LOCATE(E, GE, GG) hipLaunchKernelGGL((k_locate<E, GE, GG, false>), gr, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows)
+    if (groups) {
+        if (small) {
+            if (P.general) { if (emit) BSK_LAUNCH_LOCATE(true, true, 4); else BSK_LAUNCH_LOCATE(false, true, 4); }
+            else { if (emit) BSK_LAUNCH_LOCATE(true, false, 4); else BSK_LAUNCH_LOCATE(false, false, 4); }
+        } else {
+            if (P.general) { if (emit) BSK_LAUNCH_LOCATE(true, true, 16); else BSK_LAUNCH_LOCATE(false, true, 16); }
+            else { if (emit) BSK_LAUNCH_LOCATE(true, false, 16); else BSK_LAUNCH_LOCATE(false, false, 16); }
+        }
     }
 #undef BSK_LAUNCH_LOCATE
+    if (P.long_thresh && P.long_count && P.long_cells) {
+        // one wave per cell of every long record: 4 cells per block
+        const dim3 lg((unsigned)((P.long_cells + 3u) / 4u));
+#define BSK_LAUNCH_LONG(E, GE) hipLaunchKernelGGL((k_locate<E, GE, 64, true>), lg, bl, 0, st, buf, buf_n, t, d, P, out_len, out_off, out, rows)
+        if (P.general) { if (emit) BSK_LAUNCH_LONG(true, true); else BSK_LAUNCH_LONG(false, true); }
+        else { if (emit) BSK_LAUNCH_LONG(true, false); else BSK_LAUNCH_LONG(false, false); }
+#undef BSK_LAUNCH_LONG
+    }
     return hipGetLastError();
 }
 

@@ -29,7 +29,18 @@ struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go
     uint32_t* hit_list;
     uint64_t* hit_count;
     uint64_t nhit;
+    // sequences of at least long_thresh bases (chromosomes): one WAVE per cell = (pattern, strand, chunk of LOCATE_LONG_CH
+    // start positions); the cells of a record are numbered in the reference's row order, so a scan of their byte counts
+    // gives every cell its place inside the record's rows
+    const uint32_t* long_list;    // record indices of the long records (any order)
+    const uint64_t* cellbase;     // [long_count + 1] first cell of each long record (scan of their cell counts)
+    uint32_t* cell_bytes;         // [total cells] written by the count pass
+    const uint64_t* cell_off;     // [total cells + 1] exclusive scan of cell_bytes
+    uint64_t long_count, long_cells;  // long records, cells of all of them
+    uint32_t long_thresh;
 };
+
+constexpr uint32_t LOCATE_LONG_CH = 64u * 1024u;
 
 // count pass: out_len[i] = bytes of all rows of record i; emit pass writes them at out_off[i]
 hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
@@ -37,6 +48,10 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
                          uint64_t* rows, hipStream_t st);
 
 // hit_list := indices of the records with out_len != 0 (any order), *hit_count := how many (zeroed by the caller)
+// out_len of the long records := sum of their cells' bytes (after the scan of cell_bytes)
+hipError_t launch_locate_long_sizes(const LocateParams& P, uint32_t* out_len, hipStream_t st);
+// ncells[y] = chunks x patterns x strands of long record long_list[y]
+hipError_t launch_locate_long_cells(const RecordTable& t, const LocateParams& P, uint32_t* ncells, hipStream_t st);
 hipError_t launch_compact_hits(const uint32_t* out_len, uint64_t n, uint32_t* hit_list, uint64_t* hit_count, hipStream_t st);
 
 }  // namespace bsk

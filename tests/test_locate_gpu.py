@@ -171,3 +171,38 @@ def test_locate_pattern_file(tmp_path):
     with pytest.raises(bsk.BskError) as e:
         bsk.Operator("Locate", json.dumps({"PatternFile": str(empty)}), -1)
     assert "no FASTA sequences found in pattern file" in str(e.value)
+
+
+# ---------------------------------------------------------------- chromosome-sized records (cells of 64 Ki start positions)
+def _long_fasta(seed):
+    rng = random.Random(seed)
+    recs = []
+    for k, (L, w) in enumerate([(200_000, 60), (50, 60), (140_000, 0), (70_001, 11), (0, 60), (65_536, 80), (131_073, 60)]):
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        if k == 0:   # matches that straddle the chunk boundary at 65536 and the end of the record
+            s = s[:65530] + "ACGTACGTACGT" + s[65542:-6] + "ACGTAC"
+        if w:
+            body = "".join(s[j:j + w] + "\n" for j in range(0, L, w))
+        else:
+            body = s + "\n"
+        recs.append(f">chr{k} long\n{body}")
+    return "".join(recs).encode()
+
+
+@pytest.mark.parametrize("i", range(len(LOC_OPTS) + len(LOC_GEN_OPTS)))
+def test_locate_long_records(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_LONG_BYTES", "60000")
+    opts = (LOC_OPTS + LOC_GEN_OPTS)[i]
+    if len(opts["Pattern"][0]) < 4 and not opts.get("NonGreedy"):
+        opts = dict(opts, Pattern=[p * 2 for p in opts["Pattern"]])  # keep the row count of the oracle run reasonable
+    check(_long_fasta(11 + i), False, opts)
+
+
+def test_locate_every_record_is_long(monkeypatch):
+    # threshold below every sequence: all rows come from cell launches, the per-record kernel has nothing to do
+    monkeypatch.setenv("BSK_LONG_BYTES", "1")
+    fa = seqgen.random_fasta(random.Random(5), 40, 0, 400, width=60, alphabet="ACGT")
+    for opts in ({"Pattern": ["ACG", "TT"]}, {"Pattern": ["ACGT"], "Circular": True, "Bed": True},
+                 {"Pattern": ["ACNT"], "Degenerate": True}, {"Pattern": ["ACG", "GGCC"], "UseFmi": True}):
+        check(fa, False, opts)
