@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions
 
 
 class SeqFrame:
@@ -227,6 +227,61 @@ def RmDup(input, o=None, device=0):
     """bigseqkit/rmdup.go:70-108 (duplicates are global: the input must be one shard per rank)"""
     return _run_records("RmDup", lib.bsk_rmdup_run, input, o or SeqKitRmDupOptions(), device,
                         finish=lib.bsk_rmdup_finish)[0]
+
+
+def Fq2Fa(input, o=None, device=0):
+    """bigseqkit/fq2fa.go:25-37"""
+    return _run_records("Fq2Fa", lib.bsk_fq2fa_run, input, o or SeqKitFq2FaOptions(), device)[0]
+
+
+def Duplicate(input, o=None, device=0):
+    """bigseqkit/duplicate.go:31-43 (Flatmap: the copies of a record are adjacent)"""
+    return _run_records("Duplicate", lib.bsk_duplicate_run, input, o or SeqKitDuplicateOptions(), device)[0]
+
+
+def Count(input, device=0):
+    """input.Count(): records per shard (the record table of every shard is built once)"""
+    counts = []
+    with Operator("SeqTransform", "{}", device) as op:
+        for pid, ptr, n, on_dev, keep in input.partitions():
+            nrec = C.c_uint64()
+            check(lib.bsk_index_build(op.ctx, ptr, n, 1 if on_dev else 0, input.format, None, C.byref(nrec)), op.ctx)
+            counts.append(nrec.value)
+    return counts
+
+
+def _range(op_name, input, o, device):
+    """bigseqkit/range.go:36-103: MapWithIndex(RangePrepare) + Filter(RangeFilter); the index of a record is its
+    position in the whole input, so every shard is told where it starts.  The counts cost one index pass per shard,
+    which is what IgnisHPC's MapWithIndex (and input.Count() for negative positions) also pay."""
+    chunks = []
+    with Operator(op_name, o.to_json(), device) as op:
+        counts = Count(input, device) if len(input.shards) > 1 else [0]
+        needs = C.c_int()
+        check(lib.bsk_range_needs_count(op.ctx, C.byref(needs)), op.ctx)
+        if needs.value:
+            if len(input.shards) == 1:
+                counts = Count(input, device)
+            check(lib.bsk_range_set_count(op.ctx, sum(counts)), op.ctx)
+        first = 0
+        for (pid, ptr, n, on_dev, keep), cnt in zip(input.partitions(), counts):
+            out = _lib.Out()
+            check(lib.bsk_range_run(op.ctx, ptr, n, 1 if on_dev else 0, input.format, pid, first, None, C.byref(out)), op.ctx)
+            buf = C.create_string_buffer(max(1, out.len))
+            check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+            chunks.append(buf.raw[:out.len])
+            first += cnt
+    return b"".join(chunks)
+
+
+def Range(input, o, device=0):
+    """bigseqkit/range.go:36-103"""
+    return _range("Range", input, o, device)
+
+
+def Head(input, o=None, device=0):
+    """bigseqkit/head.go:34-44: Range("1:N")"""
+    return _range("Head", input, o or SeqKitHeadOptions(), device)
 
 
 def build_index(input, device=0):

@@ -178,6 +178,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
             case Op::Translate: validate_translate_opts(c); break;
             case Op::Locate: validate_locate_opts(c); break;
             case Op::RmDup: validate_rmdup_opts(c); break;
+            case Op::Fq2Fa: case Op::Range: case Op::Head: case Op::Duplicate: validate_records_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
     } catch (const std::exception& e) {
@@ -237,6 +238,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_hit_list) hipFree(c->d_hit_list);
         if (c->d_cells) hipFree(c->d_cells);
         if (c->d_cellmeta) hipFree(c->d_cellmeta);
+        if (c->d_tile_first) hipFree(c->d_tile_first);
         if (c->d_long_list) hipFree(c->d_long_list);
         if (c->d_keys2) hipFree(c->d_keys2);
         if (c->d_own) hipFree(c->d_own);
@@ -709,6 +711,38 @@ int bsk_subseq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int f
                    bsk_out* out) {
     (void)pid;
     return run_record_op(c, Op::Subseq, "SubseqTransform", subseq_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_fq2fa_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                  bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::Fq2Fa, "Fq2Fa", fq2fa_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_range_needs_count(const bsk_ctx* c, int* needs) {
+    if (!c || !needs || (c->op != Op::Range && c->op != Op::Head)) return BSK_ERR_INVALID_ARG;
+    *needs = c->range_needs_count && !c->range_resolved ? 1 : 0;
+    return BSK_OK;
+}
+
+int bsk_range_set_count(bsk_ctx* c, uint64_t n_records) {
+    if (!c || (c->op != Op::Range && c->op != Op::Head)) return BSK_ERR_INVALID_ARG;
+    return range_resolve(c, (int64_t)n_records);
+}
+
+int bsk_range_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t first_record,
+                  void* stream, bsk_out* out) {
+    (void)pid;
+    if (!c) return BSK_ERR_INVALID_ARG;
+    c->cur_first_record = (int64_t)first_record;
+    return run_record_op(c, c->op == Op::Head ? Op::Head : Op::Range, "Range", records_run_device, shard, n, on_device,
+                         format, stream, out);
+}
+
+int bsk_duplicate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                      bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::Duplicate, "Duplicate", records_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_locate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

@@ -132,6 +132,12 @@ struct bsk_ctx {
     uint32_t* d_hit_list = nullptr;        // locate: records with rows
     uint64_t hit_list_cap = 0;
     int64_t cur_pid = 0;                   // partition index of the running Call()
+    // range / head / duplicate (ops_records.hpp)
+    int64_t range_start = 0, range_end = 0;  // as the driver computes them (bigseqkit/range.go:46-86)
+    bool range_needs_count = false, range_resolved = false;
+    int64_t cur_first_record = 0;          // index of the shard's first record in the whole input
+    uint32_t* d_tile_first = nullptr;      // record of the first byte of every output tile (k_records_copy)
+    uint64_t tile_first_cap = 0;
     int region_start = 0, region_end = 0;  // parsed -R / -r
     bool region_on = false;
     uint64_t last_count = 0;               // grep -C result of the last run

@@ -19,6 +19,7 @@
 #include "ops_host.hpp"
 #include "ops_grep.hpp"
 #include "ops_locate.hpp"
+#include "ops_records.hpp"
 #include "ops_rmdup.hpp"
 #include "ops_text.hpp"
 #include "ops_translate.hpp"
@@ -71,6 +72,7 @@ int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
         code = BSK_ERR_UNSUPPORTED;
         m = "a line longer than 2^31 bytes (or a FASTA record longer than 2^32 bytes)";
     } else if (f & ERR_INVALID_LETTER) m = "seq: invalid letter for the sequence alphabet";
+    else if (f & ERR_RECORD_TOO_LARGE) { code = BSK_ERR_UNSUPPORTED; m = "duplicate: the copies of one record exceed 4 GiB"; }
     else if (f & ERR_CAPACITY) { code = BSK_ERR_CAPACITY; m = "libbsk: internal table capacity exceeded"; }
     else m = "unknown kernel error";
     c->set_error(m);
@@ -1829,6 +1831,162 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fq2fa, range / head, duplicate
+// ---------------------------------------------------------------------------
+// Go strconv.ParseInt(s, 10, 64) with its error text
+static int64_t go_parse_int(const std::string& s) {
+    const std::string err = "strconv.ParseInt: parsing \"" + s + "\": invalid syntax";
+    size_t i = 0;
+    bool neg = false;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) neg = s[i++] == '-';
+    if (i >= s.size()) throw OptError(err);
+    unsigned long long v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') throw OptError(err);
+        if (v > (0x7FFFFFFFFFFFFFFFull - (unsigned)(s[i] - '0')) / 10ull)
+            throw OptError("strconv.ParseInt: parsing \"" + s + "\": value out of range");
+        v = v * 10ull + (unsigned)(s[i] - '0');
+    }
+    return neg ? -(int64_t)v : (int64_t)v;
+}
+
+// Before() of Fq2Fa (bigseqkit-lib/fq2fa.go:26-33) and the driver side of Range / Head / Duplicate
+// (bigseqkit/range.go:36-66, head.go:34-44, duplicate.go:31-43)
+void validate_records_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    if (c->op == Op::Fq2Fa) { check_id_regexp(o); return; }
+    if (c->op == Op::Duplicate) {
+        // make([]string, times) panics for a negative count; zero copies is an empty result
+        if (o.i("Times") < 0) throw OptError("value of -n (--times) should not be negative");
+        if (o.i("Times") > 0xFFFFFFFFll) throw OptError("value of -n (--times) too large");
+        return;
+    }
+    std::string range = c->op == Op::Head ? "1:" + std::to_string(o.i("N")) : o.s("Range");
+    if (range.empty()) throw OptError("flag -r (--range) needed");
+    std::vector<std::string> r;  // strings.Split(range, ":")
+    for (size_t a = 0;;) {
+        const size_t b = range.find(':', a);
+        r.push_back(range.substr(a, b == std::string::npos ? std::string::npos : b - a));
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    int64_t start = go_parse_int(r[0]);
+    int64_t end = -1;
+    if (r.size() > 1) end = go_parse_int(r[1]);
+    if (start == 0 || end == 0) throw OptError("either start and end should not be 0");
+    if (start > 0) --start;
+    if (end == -1) end = INT64_MAX;
+    c->range_start = start;
+    c->range_end = end;
+    c->range_needs_count = start < -1 || end < -1;  // range.go:69
+    c->range_resolved = false;
+    if (!c->range_needs_count) {
+        const int rc = range_resolve(c, 0);
+        if (rc != BSK_OK) throw OptError(c->last_error);
+    }
+}
+
+// bigseqkit/range.go:69-86: negative positions count from the end.  PARITY.md RNG: the reference's final check reads
+// `if start <= end { error }`, which rejects every non-empty range; the evident intent (an empty or inverted range is
+// the error) is what runs here, the arithmetic above it is kept as written.
+int range_resolve(bsk_ctx* c, int64_t n_records) {
+    if (c->range_resolved) return BSK_OK;
+    if (c->range_needs_count) {
+        if (c->range_start < 0) c->range_start += n_records;
+        if (c->range_end < 0) c->range_end += n_records;
+    }
+    if (c->range_start >= c->range_end) {
+        c->set_error("start must be > than end");
+        return BSK_ERR_OPTS;
+    }
+    c->range_resolved = true;
+    return BSK_OK;
+}
+
+// Fq2Fa.Call (bigseqkit-lib/fq2fa.go:35-59): record.Seq.Qual = []; record.Format(0) -- '>' + name, the sequence on one line
+int fq2fa_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    SeqParams P = format_params(c, fastq);
+    P.print_qual = 0;
+    P.line_width = 0;
+    P.fasta_out = 1;
+    P.buf_end = d_buf + n;
+    TextTableH tt{nullptr, nullptr, nullptr};
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    apply_long(c, &P);
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
+// RangePrepare + RangeFilter (bigseqkit-lib/range.go:26-43), Duplicate.Call (duplicate.go:24-30)
+int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    RecordsParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = format == BSK_FORMAT_FASTQ;
+    P.first_record = c->cur_first_record;
+    if (c->op == Op::Duplicate) {
+        P.lo = INT64_MIN;
+        P.hi = INT64_MAX;
+        P.times = (uint32_t)c->opts.i("Times");
+        if (P.times == 0) return empty_result(c, out);
+    } else {
+        if (!c->range_resolved) {
+            c->set_error("libbsk: a range with negative positions needs the record count first (bsk_range_set_count)");
+            return BSK_ERR_INVALID_ARG;
+        }
+        P.lo = c->range_start;
+        P.hi = c->range_end;
+        P.times = 1;
+    }
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_records_size(d_buf, n, c->table, P, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
+    uint64_t total = 0, kept = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&kept, c->d_counter, sizeof kept, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    if (total == 0) return BSK_OK;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_tile_first, &c->tile_first_cap, records_copy_tiles(total), 64);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_records_copy(d_buf, c->table, P, c->d_out_off, c->d_tile_first, c->d_out, total, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept * P.times;
     return BSK_OK;
 }
 

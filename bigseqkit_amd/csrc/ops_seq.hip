@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
             for (uint32_t x = clo + gl; x < (a < chi ? a : chi); x += LANES) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 uint8_t c;
-                if (x < m) c = P.fastq ? '@' : '>';
+                if (x < m) c = (P.fastq && !P.fasta_out) ? '@' : '>';
                 else if (x == a - 1) c = '\n';
                 else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
                 else c = r.head[hoff + x - m];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
             for (uint32_t x = clo + gl; x < (a < chi ? a : chi); x += LANES) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 uint8_t c;
-                if (x < m) c = P.fastq ? '@' : '>';
+                if (x < m) c = (P.fastq && !P.fasta_out) ? '@' : '>';
                 else if (x == a - 1) c = '\n';
                 else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
                 else c = r.head[hoff + x - m];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
             uint8_t c;
             if (x < a) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
-                if (x < m) c = P.fastq ? '@' : '>';
+                if (x < m) c = (P.fastq && !P.fasta_out) ? '@' : '>';
                 else if (x == a - 1) c = '\n';
                 else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
                 else c = r.head[hoff + x - m];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     if (gl != 0 || clo != 0) return;  // (LONG: the first chunk's lane walks the whole record)
     uint32_t x = 0;
     if (P.print_name) {
-        if (P.print_seq) o[x++] = P.fastq ? '@' : '>';
+        if (P.print_seq) o[x++] = (P.fastq && !P.fasta_out) ? '@' : '>';
         for (uint32_t k = 0; k < hl; ++k) o[x++] = (suffix && k >= id_len) ? suffix[k - id_len] : r.head[hoff + k];
         o[x++] = '\n';
     }

@@ -10,6 +10,7 @@ namespace bsk {
 
 struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go:28-79), device-friendly
     int fastq;
+    int fasta_out;                          // fq2fa: a FASTQ record is written as FASTA ('>' marker; print_qual is 0)
     int print_name, print_seq, print_qual;  // seq.go:151-163 (constant per partition)
     int qual_only;                          // opts.Qual: no "+\n" before the quality
     int only_id;                            // -i

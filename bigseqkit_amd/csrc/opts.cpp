@@ -63,6 +63,10 @@ Options Options::defaults(Op op) {
             o.fields = {fb("ByName", false), fb("BySeq", false), fb("IgnoreCase", false), fs("DupSeqsFile", ""),
                         fs("DupNumFile", ""), fb("OnlyPositiveStrand", false)};
             break;
+        case Op::Fq2Fa: break;                                      // bigseqkit/fq2fa.go:15-18
+        case Op::Range: o.fields = {fs("Range", "")}; break;        // bigseqkit/range.go:19-24
+        case Op::Head: o.fields = {fi("N", 10)}; break;             // bigseqkit/head.go:17-22
+        case Op::Duplicate: o.fields = {fi("Times", 1)}; break;     // bigseqkit/duplicate.go:14-19
     }
     return o;
 }
@@ -200,7 +204,9 @@ bool op_from_name(const std::string& name, Op* out) {
     struct { const char* n; Op op; } tbl[] = {
         {"Stats", Op::Stats}, {"SeqTransform", Op::Seq}, {"Seq", Op::Seq}, {"Grep", Op::Grep},
         {"Locate", Op::Locate}, {"SubseqTransform", Op::Subseq}, {"Subseq", Op::Subseq},
-        {"Translate", Op::Translate}, {"RmDup", Op::RmDup}, {"RmDupPrepare", Op::RmDup}, {"RmDupCheck", Op::RmDup}};
+        {"Translate", Op::Translate}, {"RmDup", Op::RmDup}, {"RmDupPrepare", Op::RmDup}, {"RmDupCheck", Op::RmDup},
+        {"Fq2Fa", Op::Fq2Fa}, {"Range", Op::Range}, {"RangePrepare", Op::Range}, {"Head", Op::Head},
+        {"Duplicate", Op::Duplicate}};
     for (auto& t : tbl)
         if (name == t.n) { *out = t.op; return true; }
     return false;
@@ -215,6 +221,10 @@ const char* op_name(Op op) {
         case Op::Subseq: return "SubseqTransform";
         case Op::Translate: return "Translate";
         case Op::RmDup: return "RmDup";
+        case Op::Fq2Fa: return "Fq2Fa";
+        case Op::Range: return "Range";
+        case Op::Head: return "Head";
+        case Op::Duplicate: return "Duplicate";
     }
     return "";
 }

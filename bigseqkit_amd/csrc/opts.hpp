@@ -8,6 +8,8 @@
 //   SubseqOptions     bigseqkit/subseq.go:9-20,    defaults :22-35
 //   TranslateOptions  bigseqkit/translate.go:9-20, defaults :22-35
 //   RmDupOptions      bigseqkit/rmdup.go:13-21,    defaults :23-33
+//   Fq2FaOptions      bigseqkit/fq2fa.go:11-18;  RangeOptions bigseqkit/range.go:14-24;  HeadOptions bigseqkit/head.go:12-22;
+//   DuplicateOptions  bigseqkit/duplicate.go:9-19
 #pragma once
 #include <cstdint>
 #include <stdexcept>
@@ -33,7 +35,7 @@ struct Field {
     std::vector<std::string> sl;
 };
 
-enum class Op { Stats, Seq, Grep, Locate, Subseq, Translate, RmDup };
+enum class Op { Stats, Seq, Grep, Locate, Subseq, Translate, RmDup, Fq2Fa, Range, Head, Duplicate };
 
 class Options {
    public:

@@ -24,6 +24,10 @@ _FIELDS = {
     "Translate": ["TranslTable", "Frame", "Trim", "Clean", "AllowUnknownCodon", "InitCodonAsM", "ListTranslTable",
                   "ListTranslTableWithAmbCodons", "AppendFrame"],
     "RmDup": ["ByName", "BySeq", "IgnoreCase", "DupSeqsFile", "DupNumFile", "OnlyPositiveStrand"],
+    "Fq2Fa": [],              # bigseqkit/fq2fa.go:11-13
+    "Range": ["Range"],       # bigseqkit/range.go:14-17
+    "Head": ["N"],            # bigseqkit/head.go:12-15
+    "Duplicate": ["Times"],   # bigseqkit/duplicate.go:9-12
 }
 
 
@@ -92,3 +96,7 @@ SeqKitLocateOptions = _make("Locate")
 SeqKitSubseqOptions = type("SeqKitSubseqOptions", (_CmdOptions,), {"op": "SubseqTransform", "_fields": tuple(_FIELDS["SubseqTransform"])})
 SeqKitTranslateOptions = _make("Translate")
 SeqKitRmDupOptions = _make("RmDup")
+SeqKitFq2FaOptions = _make("Fq2Fa")
+SeqKitRangeOptions = _make("Range")
+SeqKitHeadOptions = _make("Head")
+SeqKitDuplicateOptions = _make("Duplicate")

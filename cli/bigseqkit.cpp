@@ -105,6 +105,10 @@ const Command kCommands[] = {
       {"list-transl-table", 'l', INT, "ListTranslTable", "-1"},
       {"list-transl-table-with-amb-codons", 'L', INT, "ListTranslTableWithAmbCodons", "-1"},
       {"append-frame", 'F', BOOL, "AppendFrame", "false"}}},
+    {"fq2fa", "Fq2Fa", {}},                                                          // cli/fq2fa.go:27
+    {"range", "Range", {{"range", 'r', STR, "Range", ""}}},                            // cli/range.go:48
+    {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
+    {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
     {"rmdup", "RmDup",
      {{"by-name", 'n', BOOL, "ByName", "false"}, {"by-seq", 's', BOOL, "BySeq", "false"},
       {"ignore-case", 'i', BOOL, "IgnoreCase", "false"}, {"dup-seqs-file", 'd', STR, "DupSeqsFile", ""},
@@ -219,7 +223,7 @@ Invocation parse_invocation(const std::vector<std::string>& args) {
     const int argc = (int)args.size();
     auto argv = [&](int i) -> const std::string& { return args[(size_t)i]; };
     for (auto& c : kCommands)
-        if (args[0] == c.use) inv.cmd = &c;
+        if (args[0] == c.use || (args[0] == "dup" && !strcmp(c.use, "duplicate"))) inv.cmd = &c;
     if (!inv.cmd) die(std::string("unknown command \"") + args[0] + "\" for \"bigseqkit\"");
     const Command* cmd = inv.cmd;
     Values& val = inv.val;
@@ -390,7 +394,7 @@ struct Output {
     int fmt = -1;             // format of the record text in `text` (-1: line oriented)
 };
 
-int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, bsk_out* out) {
+int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, uint64_t first_record, bsk_out* out) {
     const void* p = in.ptr();
     const size_t n = in.size();
     const int dev = in.on_device();
@@ -399,6 +403,9 @@ int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, bs
     if (use == "locate") return bsk_locate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "subseq") return bsk_subseq_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "translate") return bsk_translate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "fq2fa") return bsk_fq2fa_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "duplicate") return bsk_duplicate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "range" || use == "head") return bsk_range_run(ctx, p, n, dev, in.fmt, pid, first_record, nullptr, out);
     return bsk_rmdup_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
 }
 
@@ -465,11 +472,33 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
         return c;
     };
     if (!(keep_on_device && records_out)) ctx = fresh();
+    // range / head: the record index runs over the union of the inputs (cli/helper.go unions the files into one
+    // dataframe); negative positions need the total (bigseqkit/range.go:69-80)
+    std::vector<uint64_t> first(inputs.size(), 0);
+    uint64_t n_records = 0;
+    bool range_needs = false;
+    if (use == "range" || use == "head") {
+        bsk_ctx* probe = fresh();
+        int needs = 0;
+        bsk_range_needs_count(probe, &needs);
+        range_needs = needs != 0;
+        if (range_needs || inputs.size() > 1)
+            for (size_t fi = 0; fi < inputs.size(); ++fi) {
+                uint64_t k = 0;
+                if (bsk_index_build(probe, inputs[fi].ptr(), inputs[fi].size(), inputs[fi].on_device(), inputs[fi].fmt, nullptr, &k) != BSK_OK)
+                    die(bsk_last_error(probe));
+                first[fi] = n_records;
+                n_records += k;
+            }
+        bsk_destroy(probe);
+        if (ctx && range_needs && bsk_range_set_count(ctx, n_records) != BSK_OK) die(bsk_last_error(ctx));
+    }
     for (size_t fi = 0; fi < inputs.size(); ++fi) {
         const Part& in = inputs[fi];
         bsk_out out;
         bsk_ctx* c = ctx ? ctx : fresh();
-        if (run_op(use, c, in, (int64_t)fi, &out) != BSK_OK) die(bsk_last_error(c));
+        if (!ctx && range_needs && bsk_range_set_count(c, n_records) != BSK_OK) die(bsk_last_error(c));
+        if (run_op(use, c, in, (int64_t)fi, first[fi], &out) != BSK_OK) die(bsk_last_error(c));
         if (use == "rmdup" && bsk_rmdup_finish(c) != BSK_OK) die(bsk_last_error(c));
         if (grep_count) {
             uint64_t cnt = 0;
@@ -477,7 +506,7 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
             grep_total += cnt;
             continue;
         }
-        const int ofmt = use == "translate" ? BSK_FORMAT_FASTA : in.fmt;
+        const int ofmt = use == "translate" || use == "fq2fa" ? BSK_FORMAT_FASTA : in.fmt;
         if (!ctx) {  // device-resident part owned by its context
             Part o;
             o.fmt = ofmt;

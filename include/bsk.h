@@ -197,6 +197,25 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Fq2Fa (bigseqkit-lib/fq2fa.go:16-59): every record as FASTA, the sequence on one line (Format(0)). */
+int bsk_fq2fa_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                  bsk_out* out);
+
+/* ---- Range / Head (driver: bigseqkit/range.go:36-103, head.go:34-44; executor: RangePrepare + RangeFilter,
+ * bigseqkit-lib/range.go:14-43).  A context is created from RangeOptions {"Range": "a:b"} or HeadOptions {"N": n}; the
+ * records whose index in the WHOLE input lies in the range come back unchanged.  first_record = index of the shard's
+ * first record (what MapWithIndex hands to RangePrepare.Call).  Ranges with a position below -1 need input.Count()
+ * (range.go:69-80): bsk_range_needs_count says so, bsk_range_set_count supplies it before the first run. */
+int bsk_range_needs_count(const bsk_ctx* ctx, int* needs);
+int bsk_range_set_count(bsk_ctx* ctx, uint64_t n_records);
+int bsk_range_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t first_record,
+                  void* stream, bsk_out* out);
+
+/* ---- Duplicate (bigseqkit/duplicate.go:31-43, bigseqkit-lib/duplicate.go:13-30): every record Times times, copies
+ * adjacent. */
+int bsk_duplicate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                      bsk_out* out);
+
 /* ---- RmDup (RmDupPrepare + GroupByKey + RmDupCheck, bigseqkit-lib/rmdup.go:23-242):
  * duplicates are global, so ONE call must see the whole input of a rank; the first
  * record of every subject (file order) survives. */

@@ -363,6 +363,31 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+// which: 0 fq2fa, 1 range (Range), 2 head (N), 3 duplicate (Times)
+int orc_records(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int which, const char* range,
+                long long num, int nparts, uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err,
+                size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        if (nparts < 1) nparts = 1;
+        std::vector<std::string> all;
+        int64_t start = 0, end = 0;
+        if (which == 1 || which == 2)
+            range_bounds(which == 2 ? "1:" + std::to_string(num) : std::string(range ? range : ""), (int64_t)recs.size(),
+                         &start, &end);
+        for (int p = 0; p < nparts; ++p) {
+            size_t a = recs.size() * (size_t)p / (size_t)nparts, b = recs.size() * (size_t)(p + 1) / (size_t)nparts;
+            std::vector<std::string_view> part(recs.begin() + a, recs.begin() + b);
+            std::vector<std::string> r;
+            if (which == 0) r = fq2fa_call(part, conv(*cfg));
+            else if (which == 3) r = duplicate_call(part, num);
+            else r = range_call(part, (int64_t)a, start, end);
+            all.insert(all.end(), r.begin(), r.end());
+        }
+        return emit(all, out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // rmdup is global (GroupByKey): nparts is ignored, the whole input is one group space
 // which: 1 = text of the removed records (-d), 2 = duplicate-number lines (-D)
 int orc_rmdup_side(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, int which, uint8_t* out, size_t cap,

@@ -1699,4 +1699,81 @@ std::string stats_string(const StatInfo& info, const StatsOptions& o) {
     return pretty_table(hdr, right, row);
 }
 
+// ---------------------------------------------------------------------------
+// fq2fa, range / head, duplicate
+// ---------------------------------------------------------------------------
+// bigseqkit-lib/fq2fa.go:35-59
+std::vector<std::string> fq2fa_call(const std::vector<std::string_view>& part, const KitConfig& cfg) {
+    Alphabet ab = alphabet_from_seqtype(cfg.SeqType);  // :28
+    SeqParser rd(ab, &part, cfg.IDRegexp, cfg.AlphabetGuessSeqLength);
+    std::vector<std::string> result;
+    while (rd.Read()) {
+        Record r = rd.rec;
+        r.qual.clear();                                  // :52
+        std::string bb = record_format(r, false, 0);     // :53  (no quality -> FASTA layout)
+        bb.pop_back();                                   // :55
+        result.push_back(bb);
+    }
+    return result;
+}
+
+static int64_t parse_int_go(const std::string& s) {  // strconv.ParseInt(s, 10, 64)
+    size_t i = 0;
+    bool neg = false;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) neg = s[i++] == '-';
+    if (i >= s.size()) throw Error("strconv.ParseInt: parsing \"" + s + "\": invalid syntax");
+    int64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') throw Error("strconv.ParseInt: parsing \"" + s + "\": invalid syntax");
+        v = v * 10 + (s[i] - '0');
+    }
+    return neg ? -v : v;
+}
+
+// bigseqkit/range.go:43-86
+void range_bounds(const std::string& range, int64_t n_records, int64_t* pstart, int64_t* pend) {
+    if (range.empty()) throw Error("flag -r (--range) needed");                     // :43-45
+    std::vector<std::string> r;                                                      // :47
+    for (size_t a = 0;;) {
+        size_t b = range.find(':', a);
+        r.push_back(range.substr(a, b == std::string::npos ? std::string::npos : b - a));
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    int64_t start = parse_int_go(r[0]);                                              // :48-51
+    int64_t end = -1;                                                                // :52
+    if (r.size() > 1) end = parse_int_go(r[1]);                                      // :53-58
+    if (start == 0 || end == 0) throw Error("either start and end should not be 0"); // :60-62
+    if (start > 0) start--;                                                          // :64-66
+    if (end == -1) end = INT64_MAX;                                                  // :67-69
+    if (start < -1 || end < -1) {                                                    // :71-83
+        if (start < 0) start += n_records;
+        if (end < 0) end += n_records;
+    }
+    // :85-87 reads `if start <= end { error }` -- every non-empty range would be refused (PARITY.md RNG)
+    if (start >= end) throw Error("start must be > than end");
+    *pstart = start;
+    *pend = end;
+}
+
+// bigseqkit-lib/range.go:33-43
+std::vector<std::string> range_call(const std::vector<std::string_view>& part, int64_t first, int64_t start, int64_t end) {
+    std::vector<std::string> result;
+    for (size_t i = 0; i < part.size(); ++i) {
+        const int64_t v1 = first + (int64_t)i;
+        std::string v = start <= v1 && v1 < end ? std::string(part[i]) : std::string();  // :33-38
+        if (!v.empty()) result.push_back(v);                                              // :41-43
+    }
+    return result;
+}
+
+// bigseqkit-lib/duplicate.go:24-30
+std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times) {
+    if (times < 0) throw Error("value of -n (--times) should not be negative");  // make([]string, times) would panic
+    std::vector<std::string> result;
+    for (auto& v : part)
+        for (int64_t i = 0; i < times; ++i) result.push_back(std::string(v));
+    return result;
+}
+
 }  // namespace orc

@@ -222,6 +222,16 @@ std::vector<std::string> rmdup_call_side(const std::vector<std::string_view>& al
                                          std::string* dup_seqs, std::string* dup_nums);
 uint64_t xxh64(const void* data, size_t len, uint64_t seed);  // cespare/xxhash Sum64 == XXH64 seed 0
 
+// Fq2Fa.Call  bigseqkit-lib/fq2fa.go:35-59: Qual dropped, Format(0)
+std::vector<std::string> fq2fa_call(const std::vector<std::string_view>& part, const KitConfig& cfg);
+// driver Range()  bigseqkit/range.go:36-86 (Head: head.go:34-44 builds "1:N"): 0-based [start, end) over the record
+// indices of the whole input.  PARITY.md RNG: the final check is the evident intent, not the inverted one as written.
+void range_bounds(const std::string& range, int64_t n_records, int64_t* start, int64_t* end);
+// RangePrepare.Call + RangeFilter.Call  bigseqkit-lib/range.go:33-43 (first = index of part[0] in the whole input)
+std::vector<std::string> range_call(const std::vector<std::string_view>& part, int64_t first, int64_t start, int64_t end);
+// Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
+std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
+
 // seq.SubLocation / Seq.SubSeq [upstream-memory]; pinned by the region table
 // bigseqkit-cli/helper.go:348-361.  Returns 0-based [begin, end) or begin == end for empty.
 void sub_location(size_t length, int start, int end, size_t* b, size_t* e);

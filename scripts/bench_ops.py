@@ -73,6 +73,19 @@ if want("seqrc"):
     dt, ol, k = run("SeqTransform", lib.bsk_seq_run, {"Reverse": True, "Complement": True}, t, 1)
     report("seq -r -p (25 GB FASTQ)", nrec, t.numel(), dt, ol)
     del t
+# whole-record operators on 25 GB FASTQ
+if want("records"):
+    t, nrec = synth(0, 0, 25e9 * scale)
+    dt, ol, k = run("Fq2Fa", lib.bsk_fq2fa_run, {}, t, 1)
+    report("fq2fa (25 GB FASTQ)", nrec, t.numel(), dt, ol)
+    dt, ol, k = run("Duplicate", lib.bsk_duplicate_run, {"Times": 2}, t, 1)
+    report("duplicate -n 2 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
+    rng = lambda ctx, p, n, dev, fmt, pid, st, out: lib.bsk_range_run(ctx, p, n, dev, fmt, pid, 0, st, out)
+    dt, ol, k = run("Range", rng, {"Range": "1000001:%d" % (nrec - 1000000)}, t, 1)
+    report("range -r 1000001:-1000001 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
+    dt, ol, k = run("Head", rng, {"N": 1000}, t, 1)
+    report("head -n 1000 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
+    del t
 # C3: grep -s -p motif, one GPU's 12.5 GB shard
 if want("grep") or want("locate") or want("grepid"):
     t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)

@@ -3,8 +3,8 @@
 SCALE=${1:-1.0}; TAG=${2:-r01d}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for OP in seq subseq grep locate rmdup translate; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_$OP -o ops -- python $R/scripts/bench_ops.py $SCALE 2 $OP > $O/prof_${TAG}_$OP.out 2>&1
+for OP in ${3:-seq subseq grep locate rmdup translate}; do
+  timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_$OP -o ops -- python $R/scripts/bench_ops.py $SCALE 2 $OP > $O/prof_${TAG}_$OP.out 2>&1
   echo "== $OP"; tail -1 $O/prof_${TAG}_$OP.out | head -c 1500; echo
   python - <<PY
 import csv

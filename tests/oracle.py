@@ -311,3 +311,38 @@ _lib.orc_go_round.argtypes = [C.c_double, C.c_int]
 
 def go_round(f, n):
     return _lib.orc_go_round(f, n)
+
+
+def _records(data, fastq, opts_json, which, nparts):
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    cfg = _cfg(d)
+    num = {0: 0, 1: 0, 2: g("N", 10), 3: g("Times", 1)}[which]
+    rng = g("Range", "").encode()
+    cap = 4 * len(data) * max(1, num if which == 3 else 1) + 4096
+    while True:
+        out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = _lib.orc_records(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(cfg), which, rng,
+                              C.c_longlong(num), nparts, out, C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+        if rc == 2:
+            cap = n.value + 16
+            continue
+        if rc:
+            raise OracleError(err.value.decode())
+        return out.raw[:n.value]
+
+
+def fq2fa(data, fastq, opts_json="{}", nparts=1):
+    return _records(data, fastq, opts_json, 0, nparts)
+
+
+def range_(data, fastq, opts_json, nparts=1):
+    return _records(data, fastq, opts_json, 1, nparts)
+
+
+def head(data, fastq, opts_json="{}", nparts=1):
+    return _records(data, fastq, opts_json, 2, nparts)
+
+
+def duplicate(data, fastq, opts_json="{}", nparts=1):
+    return _records(data, fastq, opts_json, 3, nparts)

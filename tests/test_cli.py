@@ -55,6 +55,9 @@ def test_shorthand_clusters_values_and_slices():
     assert op == "Stats" and js["All"] and js["Tabular"] and js["GapLetters"] == "-." and js["FqEncoding"] == "illumina-1.3+"
     op, js, _ = dry("rmdup", "-s", "-i", "-P")
     assert op == "RmDup" and js["BySeq"] and js["IgnoreCase"] and js["OnlyPositiveStrand"] and not js["ByName"]
+    assert dry("fq2fa", "x.fq")[0] == "Fq2Fa" and dry("range", "-r", "1:12")[1]["Range"] == "1:12"
+    assert dry("head")[0:2] == ("Head", dict(dry("head")[1], N=10)) and dry("head", "-n", "3")[1]["N"] == 3
+    assert dry("dup", "-n", "4")[0] == "Duplicate" and dry("duplicate", "--times", "4")[1]["Times"] == 4
     op, js, _ = dry("locate", "-p", "AA", "-GMP", "-w", "0")
     assert op == "Locate" and js["NonGreedy"] and js["HideMatched"] and js["OnlyPositiveStrand"] and js["Config"]["LineWidth"] == 0
 
@@ -101,6 +104,8 @@ CASES = [
     ("grep", ["-r", "-p", "^r1\\d$", "-i"], "fq"), ("grep", ["-s", "-d", "-p", "ACGNNT"], "fa"),
     ("grep", ["-s", "-m", "1", "-p", "ACGTACGTAC"], "fa"), ("locate", ["-d", "-p", "ACNNT", "--bed"], "fa"),
     ("locate", ["-m", "1", "-p", "ACGTAC", "-i"], "fq"), ("locate", ["-F", "-p", "ACG"], "fa"),
+    ("fq2fa", [], "fq"), ("fq2fa", [], "fa"), ("range", ["-r", "5:40"], "fq"), ("range", ["-r", "-30:-1"], "fa"),
+    ("head", [], "fa"), ("head", ["-n", "77"], "fq"), ("duplicate", ["-n", "3"], "fq"), ("dup", [], "fa"),
 ]
 
 
@@ -115,7 +120,8 @@ def test_cli_output_equals_oracle(tmp_path, cmd, flags, kind):
     path = _write(tmp_path, "in." + kind, data)
     op, js, _ = dry(cmd, *flags, path)
     fn = {"seq": oracle.seq, "grep": oracle.grep, "subseq": oracle.subseq, "locate": oracle.locate,
-          "translate": oracle.translate, "rmdup": oracle.rmdup}[cmd]
+          "translate": oracle.translate, "rmdup": oracle.rmdup, "fq2fa": oracle.fq2fa, "range": oracle.range_,
+          "head": oracle.head, "duplicate": oracle.duplicate, "dup": oracle.duplicate}[cmd]
     want = fn(data, fastq, json.dumps(js))
     want = want[0] if isinstance(want, tuple) else want
     assert run(cmd, *flags, path, "-o", "-").stdout == want
@@ -194,6 +200,25 @@ def test_cli_pipe_chains_commands_in_hbm(tmp_path):
     jf.write_text(json.dumps(job2))
     t = oracle.stats_string(oracle.seq(fq1, True, o_seq), True, json.dumps(dry("stats", "-T")[1]), name="input0")
     assert run("pipe", "--job", str(jf)).stdout.decode() == t.split("\n")[0] + "\n" + "\n".join(t.split("\n")[1:]) + "\n"
+
+
+@pytest.mark.gpu
+def test_cli_range_indexes_the_union_of_its_inputs_and_chains_in_a_pipe(tmp_path):
+    rng = random.Random(8)
+    d1, d2 = seqgen.random_fastq(rng, 120, min_len=1), seqgen.random_fastq(rng, 90, min_len=1)
+    a, b = _write(tmp_path, "a.fq", d1), _write(tmp_path, "b.fq", d2)
+    for r in ("100:150", "-100:-1", "1:5", "130"):
+        want = oracle.range_(d1 + d2, True, json.dumps({"Range": r}))
+        assert run("range", "-r", r, a, b, "-o", "-").stdout == want, r
+    assert run("head", "-n", "125", a, b, "-o", "-").stdout == oracle.head(d1 + d2, True, '{"N": 125}')
+    p = run("range", "-r", "9:3", a, ok=False)
+    assert p.returncode != 0 and b"start must be > than end" in p.stderr
+    # fq2fa -> duplicate -> head without leaving HBM
+    job = {"pipe": [{"pipe": [{"cmd": ["fq2fa", a]}], "cmd": ["dup", "-n", "2"]}], "cmd": ["head", "-n", "7"]}
+    jf = tmp_path / "job.json"
+    jf.write_text(json.dumps(job))
+    want = oracle.head(oracle.duplicate(oracle.fq2fa(d1, True), False, '{"Times": 2}'), False, '{"N": 7}')
+    assert run("pipe", "--job", str(jf), "-o", "-").stdout == want and want.count(b">") == 7
 
 
 @pytest.mark.gpu
