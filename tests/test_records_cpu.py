@@ -1,0 +1,81 @@
+"""fq2fa / range / head / duplicate without a GPU: the oracle against hand-written expectations (the reference has no
+tests for them; the arithmetic follows bigseqkit/range.go:43-86 line by line, PARITY.md RNG) and the host-side option
+handling of libbsk (bsk_create on device -1)."""
+import json
+
+import pytest
+
+import oracle
+import bigseqkit_amd as bsk
+
+FA = b">a x\nACGT\nAC\n>b\nGG\n\n>c\nT"
+FQ = b"@r1 d\nACGT\n+\nIIII\n@r2\nGG\n+r2\n##\n@r3\nT\n+\n@\n"
+RECS = [b">%d\nA\n" % i for i in range(1, 21)]
+MANY = b"".join(RECS)
+
+
+def pick(lo, hi):  # 1-based inclusive
+    return b"".join(RECS[lo - 1:hi])
+
+
+def test_fq2fa_drops_the_quality_and_unwraps():
+    assert oracle.fq2fa(FQ, True) == b">r1 d\nACGT\n>r2\nGG\n>r3\nT\n"
+    assert oracle.fq2fa(FA, False) == b">a x\nACGTAC\n>b\nGG\n>c\nT\n"
+    assert oracle.fq2fa(FA, False, json.dumps({"Config": {"LineWidth": 2}})) == b">a x\nACGTAC\n>b\nGG\n>c\nT\n"  # Format(0)
+    with pytest.raises(oracle.OracleError):
+        oracle.fq2fa(FA, False, json.dumps({"Config": {"SeqType": "bogus"}}))
+
+
+@pytest.mark.parametrize("rng,lo,hi", [("1:12", 1, 12), ("5:5", 5, 5), ("3", 3, 20), ("19:40", 19, 20),
+                                       ("-12:-1", 9, 20), ("-1:-1", 1, 20), ("-1:5", 1, 5), ("-10:-3", 11, 17),
+                                       ("2:-2", 2, 18), ("-3", 18, 20)])
+def test_range_arithmetic_as_written(rng, lo, hi):
+    want = pick(lo, hi)
+    assert oracle.range_(MANY, False, json.dumps({"Range": rng})) == want
+    assert oracle.range_(MANY, False, json.dumps({"Range": rng}), nparts=3) == want  # the index is global
+
+
+@pytest.mark.parametrize("rng,msg", [("", "flag -r (--range) needed"), ("0:3", "either start and end should not be 0"),
+                                     ("3:0", "either start and end should not be 0"), ("9:3", "start must be > than end"),
+                                     ("17:", 'strconv.ParseInt: parsing "": invalid syntax'),
+                                     ("x:2", 'strconv.ParseInt: parsing "x": invalid syntax'),
+                                     ("-3:-8", "start must be > than end")])
+def test_range_errors(rng, msg):
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.range_(MANY, False, json.dumps({"Range": rng}))
+    assert msg in str(e.value)
+    if rng != "-3:-8":  # needs the record count: reported by bsk_range_set_count, not by bsk_create
+        with pytest.raises(bsk.BskError) as e2:
+            bsk.Operator("Range", json.dumps({"Range": rng}), -1)
+        assert msg in str(e2.value)
+
+
+def test_head_is_range_1_to_n_and_duplicate_keeps_copies_adjacent():
+    assert oracle.head(MANY, False) == pick(1, 10)
+    assert oracle.head(MANY, False, '{"N": 3}') == pick(1, 3)
+    assert oracle.head(FQ, True, '{"N": 2}') == b"@r1 d\nACGT\n+\nIIII\n@r2\nGG\n+r2\n##\n"
+    assert oracle.duplicate(FA, False, '{"Times": 2}') == b">a x\nACGT\nAC\n>a x\nACGT\nAC\n>b\nGG\n\n>b\nGG\n\n>c\nT\n>c\nT\n"
+    assert oracle.duplicate(FQ, True) == FQ
+    assert oracle.duplicate(FQ, True, '{"Times": 0}') == b""
+    with pytest.raises(oracle.OracleError):
+        oracle.duplicate(FQ, True, '{"Times": -2}')
+
+
+def test_libbsk_option_handling_of_the_record_operators():
+    with bsk.Operator("Head", "{}", -1) as op:
+        assert json.loads(op.opts_json())["N"] == 10
+    with bsk.Operator("Duplicate", '{"Times": null}', -1) as op:
+        assert json.loads(op.opts_json())["Times"] == 1
+    with bsk.Operator("Range", '{"Range": "-12:-1"}', -1) as op:
+        import ctypes as C
+        needs = C.c_int()
+        assert bsk.lib.bsk_range_needs_count(op.ctx, C.byref(needs)) == 0 and needs.value == 1
+        assert bsk.lib.bsk_range_set_count(op.ctx, 5) == 0   # start -7: nothing before record 0 exists, all 5 are kept
+        assert bsk.lib.bsk_range_needs_count(op.ctx, C.byref(needs)) == 0 and needs.value == 0
+    with bsk.Operator("Range", '{"Range": "-3:-8"}', -1) as op:
+        assert bsk.lib.bsk_range_set_count(op.ctx, 20) != 0  # start 17 >= end 12
+        assert "start must be > than end" in bsk.lib.bsk_last_error(op.ctx).decode()
+    with pytest.raises(bsk.BskError):
+        bsk.Operator("Duplicate", '{"Times": -1}', -1)
+    with pytest.raises(bsk.BskError):
+        bsk.Operator("Fq2Fa", '{"Config": {"SeqType": "bogus"}}', -1)
