@@ -395,27 +395,25 @@ __global__ void k_set_total(const uint64_t* __restrict__ block_off, uint64_t nbl
 
 __global__ void k_reset_queue(uint32_t* q) { *q = 0; }
 
-// FASTA, line-start ranges: records that span ranges.  One thread walks the ranges in file order; the open record's
-// bases, region and line layout are completed from the head parts of the following ranges.
-__global__ void k_index_stitch(RecordTable t, const RangePart* __restrict__ parts, const uint64_t* __restrict__ range_count,
-                               const uint64_t* __restrict__ range_base, uint32_t nranges) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    bool open = false;
-    uint64_t g = 0, bases = 0;
-    uint32_t nl = 0, W = 0, last = 0;
-    bool irr = false;
-    auto finish = [&](uint64_t end_abs) {
-        const uint64_t seq0 = t.start[g] + t.l_head[g] + 1;
-        t.l_seq[g] = (uint32_t)bases;
-        t.aux[g] = (uint32_t)(end_abs > seq0 ? end_abs - seq0 : 0);
-        t.text_w[g] = nl <= 1u ? 0u : ((irr || W < 16u) ? 0xFFFFFFFFu : W);
-    };
-    for (uint32_t r = 0; r < nranges; ++r) {
+// FASTA, line-start ranges: records that span ranges.  The thread of range r finishes the record that is open at the
+// end of r: bases, region and line layout are completed from the head parts of the following ranges, up to the range
+// that closes it.  Chains are disjoint (see k_stats_stitch).
+__global__ __launch_bounds__(256) void k_index_stitch(RecordTable t, const RangePart* __restrict__ parts,
+                                                      const uint64_t* __restrict__ range_count,
+                                                      const uint64_t* __restrict__ range_base, uint32_t nranges) {
+    const uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r0 >= nranges) return;
+    const uint32_t f0 = parts[r0].flags;
+    if ((f0 & (IP_VISITED | IP_TAIL_OPEN)) != (IP_VISITED | IP_TAIL_OPEN)) return;
+    const uint64_t g = range_base[r0] + range_count[r0] - 1;
+    uint64_t bases = parts[r0].tail_bases;
+    uint32_t nl = parts[r0].tail_nlines, W = parts[r0].tail_first, last = parts[r0].tail_last;
+    bool irr = (f0 & IP_TAIL_IRR) != 0;
+    for (uint32_t r = r0 + 1; r < nranges; ++r) {
         const RangePart& Q = parts[r];
         const uint32_t f = Q.flags;
         if (!(f & IP_VISITED)) continue;
-        const bool has_head_part = open && (!(f & IP_HAS_HEADER) || (f & IP_HEAD_CLOSED));
-        if (has_head_part) {
+        if (!(f & IP_HAS_HEADER) || (f & IP_HEAD_CLOSED)) {  // this range holds a part of the open record
             const bool closed = (f & IP_HEAD_CLOSED) != 0;
             if (Q.head_nlines > 0u) {
                 if (nl == 0u) W = Q.head_first;          // the record's first sequence line
@@ -430,14 +428,15 @@ __global__ void k_index_stitch(RecordTable t, const RangePart* __restrict__ part
                 irr |= (f & IP_HEAD_IRR) != 0;
             }
             bases += Q.head_bases;
-            if (closed) { finish(Q.head_end_abs); open = false; }
+            if (closed) {
+                const uint64_t seq0 = t.start[g] + t.l_head[g] + 1;
+                t.l_seq[g] = (uint32_t)bases;
+                t.aux[g] = (uint32_t)(Q.head_end_abs > seq0 ? Q.head_end_abs - seq0 : 0);
+                t.text_w[g] = nl <= 1u ? 0u : ((irr || W < 16u) ? 0xFFFFFFFFu : W);
+                return;
+            }
         }
-        if (f & IP_TAIL_OPEN) {
-            g = range_base[r] + range_count[r] - 1;
-            bases = Q.tail_bases;
-            nl = Q.tail_nlines; W = Q.tail_first; last = Q.tail_last; irr = (f & IP_TAIL_IRR) != 0;
-            open = true;
-        }
+        if (f & IP_TAIL_OPEN) return;  // another record is open from here on
     }
 }
 
@@ -502,7 +501,7 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64
 
 hipError_t launch_index_stitch(const RecordTable& dense, const RangePart* parts, const uint64_t* range_count,
                                const uint64_t* range_base, uint32_t nranges, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_stitch, dim3(1), dim3(1), 0, st, dense, parts, range_count, range_base, nranges);
+    hipLaunchKernelGGL(k_index_stitch, dim3((nranges + 255u) / 256u), dim3(256), 0, st, dense, parts, range_count, range_base, nranges);
     return hipGetLastError();
 }
 

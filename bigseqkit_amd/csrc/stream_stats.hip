@@ -294,35 +294,42 @@ __global__ void k_prep(const uint8_t* __restrict__ buf, uint64_t n, uint64_t chu
     anchors[r] = FASTQ ? find_fastq_start(buf, n, from) : (line_mode ? find_line_start(buf, n, from) : find_fasta_start(buf, n, from));
 }
 
-// Records that cross range boundaries (FASTA, line-start ranges): one thread walks the ranges in file order and adds up
-// the parts; a few 10^4 iterations.
-__global__ void k_stats_stitch(uint32_t nranges, StatsDev D) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint64_t carry = 0, nrec = 0, sumlen = 0;
-    bool open = false;
-    auto emit = [&](uint64_t len) {
-        ++nrec;
-        sumlen += len;
-        if (len < D.hist_cap) D.vec[STATS_HDR + len] += 1;
+// Records that cross range boundaries (FASTA, line-start ranges).  A record that is open at the end of range r (its
+// header is in r) is finished by the thread of r: it walks the following ranges, adding the parts that have no header
+// of their own, up to the range where the record ends.  The chains are disjoint, so reads (every range leaves one short
+// chain) run fully parallel and a chromosome costs one thread a walk over the ranges it spans.  (A single thread over
+// all ranges cost 6 ms for 15 000 ranges -- more than the 1 GB pass it followed.)
+__global__ __launch_bounds__(256) void k_stats_stitch(uint32_t nranges, StatsDev D) {
+    __shared__ uint32_t s_hist[2048];
+    __shared__ unsigned long long s_nrec, s_sum;
+    for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) s_hist[k] = 0;
+    if (threadIdx.x == 0) { s_nrec = 0; s_sum = 0; }
+    __syncthreads();
+    const uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r0 < nranges && (D.r_flags[r0] & (RF_VISITED | RF_TAIL_OPEN)) == (RF_VISITED | RF_TAIL_OPEN)) {
+        uint64_t len = D.r_tail[r0];
+        for (uint32_t r = r0 + 1; r < nranges; ++r) {
+            const uint32_t f = D.r_flags[r];
+            if (!(f & RF_VISITED)) continue;
+            len += D.r_head[r];  // has a header: the bases before it; no header: the whole range
+            if (f & (RF_HAS_HEADER | RF_HEAD_CLOSED)) break;
+        }
+        atomicAdd(&s_nrec, 1ull);
+        atomicAdd(&s_sum, (unsigned long long)len);
+        if (len < 2048u) atomicAdd(&s_hist[len], 1u);
+        else if (len < D.hist_cap) atomicAdd((unsigned long long*)&D.vec[STATS_HDR + len], 1ull);
         else {
-            const uint64_t i = D.status[1]++;
+            const uint64_t i = atomicAdd((unsigned long long*)&D.status[1], 1ull);
             if (i < D.overflow_cap) D.overflow[i] = len;
         }
-    };
-    for (uint32_t r = 0; r < nranges; ++r) {
-        const uint32_t f = D.r_flags[r];
-        if (!(f & RF_VISITED)) continue;
-        if (f & RF_HAS_HEADER) {
-            if (open) { emit(carry + D.r_head[r]); carry = 0; open = false; }  // the open record ends before this range's first header
-            if (f & RF_TAIL_OPEN) { carry = D.r_tail[r]; open = true; }
-        } else {
-            carry += D.r_head[r];
-            if (f & RF_HEAD_CLOSED) { if (open) emit(carry); carry = 0; open = false; }
-        }
     }
-    if (open) emit(carry);
-    D.vec[3] += nrec;
-    D.vec[6] += sumlen;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x)
+        if (s_hist[k] && k < D.hist_cap) atomicAdd((unsigned long long*)&D.vec[STATS_HDR + k], (unsigned long long)s_hist[k]);
+    if (threadIdx.x == 0 && s_nrec) {
+        atomicAdd((unsigned long long*)&D.vec[3], s_nrec);
+        atomicAdd((unsigned long long*)&D.vec[6], s_sum);
+    }
 }
 
 // Pure streaming read with the access pattern of k_stats (same tiles, same queue, no
@@ -374,7 +381,7 @@ hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chun
 }
 
 hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st) {
-    hipLaunchKernelGGL(k_stats_stitch, dim3(1), dim3(1), 0, st, nranges, D);
+    hipLaunchKernelGGL(k_stats_stitch, dim3((nranges + 255u) / 256u), dim3(256), 0, st, nranges, D);
     return hipGetLastError();
 }
 
