@@ -98,9 +98,6 @@ struct IndexSink {
     __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
         const int lane = threadIdx.x & 63;
-        uint64_t best = 0;
-        uint32_t best_key = 0, best_lhead = 0;
-        uint64_t best_start = 0;
         for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
             const uint32_t e = e0 + lane;
             const bool on = e < E;
@@ -134,12 +131,11 @@ struct IndexSink {
                 }
             } else {
                 const bool closing = on && L.flag[s] != 0;
-                if (on && L.flag[s - 1]) {  // this event ends a header line
-                    best = ((uint64_t)(rank + 1u) << 32) | (uint32_t)lane;
-                    best_key = p - rank;
-                    best_lhead = p - L.pos[s - 1] - 1u;
-                    best_start = abs_of(L.pos[s - 1], tile_idx, tile_rel) + 1;
-                }
+                // what a header-end event knows about its record (every lane computes it: the closing lane of a record
+                // fetches it with a shuffle instead of walking back through the events)
+                const uint32_t key = p - rank;
+                const uint32_t my_lhead = p - L.pos[s - 1] - 1u;
+                const uint64_t my_start = abs_of(L.pos[s - 1], tile_idx, tile_rel) + 1;
                 // ---- line layout (replaces a separate pass over every line end): an event is a header end (H), the
                 // first sequence line of its record (F), or a later sequence line, which must be as long as the line
                 // before it (the last one: 1..that length)
@@ -183,15 +179,19 @@ struct IndexSink {
                     irr_here = irr;
                     if (closing && !H && !F) tw = (irr || W < 16u) ? 0xFFFFFFFFu : W;
                 }
+                // header-end event of the record a lane closes: the last H at or below it in these 64 events
+                const int hsrc = (hb & upto) ? 63 - __clzll((long long)(hb & upto)) : lane;
+                const uint32_t key_h = (uint32_t)__shfl((int)key, hsrc, 64);
+                const uint32_t lhead_h = (uint32_t)__shfl((int)my_lhead, hsrc, 64);
+                const uint32_t start_lo = (uint32_t)__shfl((int)(uint32_t)my_start, hsrc, 64);
+                const uint32_t start_hi = (uint32_t)__shfl((int)(uint32_t)(my_start >> 32), hsrc, 64);
                 if (closing && D.write) {
-                    uint32_t t = s;
-                    while (t > 0 && !L.flag[t - 1]) --t;
                     uint32_t key_i, lhead;
                     uint64_t start;
-                    if (t > 0) {
-                        key_i = L.pos[t] - (wb + (t - HISTORY));
-                        lhead = L.pos[t] - L.pos[t - 1] - 1u;
-                        start = abs_of(L.pos[t - 1], tile_idx, tile_rel) + 1;
+                    if (hb & upto) {
+                        key_i = key_h;
+                        lhead = lhead_h;
+                        start = ((uint64_t)start_hi << 32) | start_lo;
                     } else {
                         key_i = open_key;
                         lhead = open_lhead;
@@ -225,12 +225,19 @@ struct IndexSink {
                 }
                 nrec = nhdr + (uint32_t)__popcll(hb);  // records owned so far (k_index reads it after the range)
                 nhdr = nrec;
-                // layout state of the record that stays open after these 64 events (wave-uniform)
+                // state of the record that stays open after these 64 events (wave-uniform)
                 if (hb) {
                     const int hl = 63 - __clzll((long long)hb);
                     const uint64_t above = hl == 63 ? 0ull : ~((2ull << hl) - 1ull);
                     open_irr = (vb & above) != 0;
                     open_w = (fb & above) ? (uint32_t)__builtin_amdgcn_readlane((int)len, hl + 1) : 0u;
+                    open_key = (uint32_t)__builtin_amdgcn_readlane((int)key, hl);
+                    open_lhead = (uint32_t)__builtin_amdgcn_readlane((int)my_lhead, hl);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_start, hl);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_start >> 32), hl);
+                    open_start = ((uint64_t)hi << 32) | lo;
+                    open_is_header = true;
+                    open_hdr_rank = wb + e0 + (uint32_t)hl;
                 } else {
                     open_irr = open_irr || vb != 0;
                     if (fb) open_w = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)__ffsll((long long)fb) - 1);
@@ -238,17 +245,6 @@ struct IndexSink {
             }
         }
         if constexpr (!FASTQ) {
-            const uint64_t w = wave_max_u64(best);
-            if (w != 0) {
-                const int src = (int)(uint32_t)w;
-                open_key = (uint32_t)__builtin_amdgcn_readlane((int)best_key, src);
-                open_lhead = (uint32_t)__builtin_amdgcn_readlane((int)best_lhead, src);
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)best_start, src);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(best_start >> 32), src);
-                open_start = ((uint64_t)hi << 32) | lo;
-                open_is_header = true;
-                open_hdr_rank = (uint32_t)(w >> 32) - 1u;
-            }
             if (E > 0) {  // the last event of the batch (uniform LDS reads)
                 const uint32_t sl = HISTORY + (E - 1u);
                 last_rank = wb + (E - 1u);

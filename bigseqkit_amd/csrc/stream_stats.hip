@@ -115,8 +115,6 @@ struct StatsSink {
     __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
         const int lane = threadIdx.x & 63;
-        uint64_t best = 0;  // FASTA: (rank+1) << 32 | lane of the last header-end event seen by this lane
-        uint32_t best_key = 0, best_sg = 0;
         for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
             const uint32_t e = e0 + lane;
             const bool on = e < E;
@@ -151,30 +149,33 @@ struct StatsSink {
                 }
             } else {
                 const bool closing = on && L.flag[s] != 0;
+                const bool hdr_end = on && L.flag[s - 1] != 0;  // the line after a closing line is a header
+                const uint32_t key = p - rank;                  // bases before this newline
+                uint32_t sg = 0;
+                if constexpr (ALL) sg = L.a[s];
+                // the header-end event of the record a lane closes: the last one at or below it in this group of 64
+                // events (ballot + shuffle), else the one carried in open_key (a walk back through the LDS events cost
+                // a 5 kb record ~85 dependent reads on one lane)
+                const uint64_t hb = __ballot(hdr_end);
+                const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+                const uint64_t hh = hb & upto;
+                const int src = hh ? 63 - __clzll((long long)hh) : lane;
+                const uint32_t key_h = (uint32_t)__shfl((int)key, src, 64);
+                uint32_t sg_h = 0;
+                if constexpr (ALL) sg_h = (uint32_t)__shfl((int)sg, src, 64);
                 uint32_t seqlen = 0;
                 bool whole = true;  // header and closing line of the record are both in this range
-                if (on) {
-                    // is this event the end of a header line?
-                    if (L.flag[s - 1]) {
-                        best = ((uint64_t)(rank + 1u) << 32) | (uint32_t)lane;
-                        best_key = p - rank;
-                        if constexpr (ALL) best_sg = L.a[s];
-                    }
-                }
                 if (closing) {
-                    // walk back to the header-end event of this record
-                    uint32_t t = s;
-                    while (t > 0 && !L.flag[t - 1]) --t;
                     uint32_t key_i, sg_i = 0;
-                    if (t > 0) {
-                        key_i = L.pos[t] - (wb + (t - HISTORY));
-                        if constexpr (ALL) sg_i = L.a[t];
+                    if (hh) {
+                        key_i = key_h;
+                        sg_i = sg_h;
                     } else {
                         key_i = open_key;
                         sg_i = open_sg;
                         whole = open_is_header;  // else the record began in an earlier range: only its tail is here
                     }
-                    seqlen = (p - rank) - key_i;
+                    seqlen = key - key_i;
                     if (whole) {
                         sumlen += seqlen;
                         nrec += 1;
@@ -182,20 +183,18 @@ struct StatsSink {
                         D.r_head[range_id] = seqlen;
                         atomicOr(&D.r_flags[range_id], RF_HEAD_CLOSED);
                     }
-                    if constexpr (ALL) gap += (uint32_t)(L.a[s] - sg_i);
+                    if constexpr (ALL) gap += (uint32_t)(sg - sg_i);
                 }
                 add_length(closing && whole, seqlen, s_hist, D);
+                if (hb) {  // carry the last header end of this group (wave-uniform)
+                    const int last = 63 - __clzll((long long)hb);
+                    open_key = (uint32_t)__builtin_amdgcn_readlane((int)key, last);
+                    if constexpr (ALL) open_sg = (uint32_t)__builtin_amdgcn_readlane((int)sg, last);
+                    open_is_header = true;
+                }
             }
         }
         if constexpr (!FASTQ) {
-            // carry the header-end of the record that is open at the end of the batch
-            const uint64_t w = wave_max_u64(best);
-            if (w != 0) {
-                const int src = (int)(uint32_t)w;
-                open_key = (uint32_t)__builtin_amdgcn_readlane((int)best_key, src);
-                if constexpr (ALL) open_sg = (uint32_t)__builtin_amdgcn_readlane((int)best_sg, src);
-                open_is_header = true;
-            }
             if (E > 0) {  // the last event of the batch (uniform LDS reads)
                 const uint32_t sl = HISTORY + (E - 1u);
                 last_key = L.pos[sl] - (wb + (E - 1u));
