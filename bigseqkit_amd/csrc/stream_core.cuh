@@ -125,6 +125,29 @@ __device__ __forceinline__ uint32_t ge_mask16(const uint4& v, uint32_t k) {
            (nibble(ge_bytes(v.w, k)) << 12);
 }
 
+// ---- packed flags of a 16-byte piece (dense path) -------------------------------------------------------------
+// The 0x80-per-byte flag words of the four dwords are merged WITHOUT being compressed to one bit per byte in byte
+// order (that compression was half of the VALU work of `stats -a`): byte k of dword d lands on bit 8k + d, so a piece
+// uses the low nibble of every byte of one word and a second predicate fits in the high nibbles.
+__device__ __forceinline__ uint32_t pack_flags(uint32_t tx, uint32_t ty, uint32_t tz, uint32_t tw) {
+    return (tx >> 7) | (ty >> 6) | (tz >> 5) | (tw >> 4);
+}
+// "byte != rep" as 0x80 flags plus garbage below (AND-accumulate over several letters, then zero_from_nonzero)
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; }
+__device__ __forceinline__ uint32_t zero_from_nonzero(uint32_t nz) { return ~nz & 0x80808080u; }
+// packed positions of the bytes j' < j of a piece (j = 4 d + k)
+__device__ __forceinline__ uint32_t packed_below(uint32_t j) {
+    const uint32_t d = j >> 2, k = j & 3u;
+    return (0x01010101u * ((1u << d) - 1u)) | ((0x00010101u & ((1u << (8u * k)) - 1u)) << d);
+}
+// 16-bit byte-order mask -> packed positions (edge tiles only)
+__device__ __forceinline__ uint32_t packed_from_mask16(uint32_t m16) {
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < 16u; ++j)
+        if ((m16 >> j) & 1u) r |= 1u << (8u * (j & 3u) + (j >> 2));
+    return r;
+}
+
 // 16 bytes at buf[idx..idx+16) with idx % 16 == 0; bytes outside [0, n) read as 0
 __device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ buf, uint64_t n, uint64_t idx) {
     if (idx + 16 <= n) return *reinterpret_cast<const uint4*>(buf + idx);
@@ -134,9 +157,9 @@ __device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ buf, uint64_
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-struct Piece {  // what a lane keeps of one 16-byte piece
-    uint32_t m_nl_a;  // nl16 | a16 << 16      (a = q>=20 for FASTQ, gap for FASTA)
-    uint32_t m_b_c;   // b16 | c16 << 16       (b = q>=30, c = gap; FASTQ -a only)
+struct Piece {  // what a lane keeps of one 16-byte piece (dense path; packed flags, see pack_flags)
+    uint32_t m_nl_a;  // newlines in the low nibbles, a in the high nibbles   (a = q>=20 for FASTQ, gap for FASTA)
+    uint32_t m_b_c;   // b in the low nibbles, c in the high nibbles          (b = q>=30, c = gap; FASTQ -a only)
     uint32_t ex_lo;   // exclusive prefix: nl | a << 16
     uint32_t ex_hi;   // exclusive prefix: b  | c << 16
 };
@@ -354,16 +377,24 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
     #pragma unroll
             for (int p = 0; p < NPIECE; ++p) {
                 const uint4 v = cur[p];
-                uint32_t nl = eq_mask16(v, 0x0A0A0A0Au);
+                uint32_t nl = pack_flags(zero_bytes(v.x ^ 0x0A0A0A0Au), zero_bytes(v.y ^ 0x0A0A0A0Au),
+                                         zero_bytes(v.z ^ 0x0A0A0A0Au), zero_bytes(v.w ^ 0x0A0A0A0Au));
                 uint32_t ma = 0, mb = 0, mc = 0;
                 if constexpr (ALL) {
-                    uint32_t g = 0;
+                    // gap letters: AND the "differs" words of all letters, one pack for the set
+                    uint32_t n0 = ~0u, n1 = ~0u, n2 = ~0u, n3 = ~0u;
     #pragma unroll
                     for (int k = 0; k < MAX_GAP_LETTERS; ++k)
-                        if (k < P.ngap) g |= eq_mask16(v, P.gap_rep[k]);
+                        if (k < P.ngap) {
+                            const uint32_t rep = P.gap_rep[k];
+                            n0 &= nonzero_bytes(v.x ^ rep); n1 &= nonzero_bytes(v.y ^ rep);
+                            n2 &= nonzero_bytes(v.z ^ rep); n3 &= nonzero_bytes(v.w ^ rep);
+                        }
+                    const uint32_t g = pack_flags(zero_from_nonzero(n0), zero_from_nonzero(n1), zero_from_nonzero(n2),
+                                                  zero_from_nonzero(n3));
                     if constexpr (FASTQ) {
-                        ma = ge_mask16(v, P.k20);
-                        mb = ge_mask16(v, P.k30);
+                        ma = pack_flags(ge_bytes(v.x, P.k20), ge_bytes(v.y, P.k20), ge_bytes(v.z, P.k20), ge_bytes(v.w, P.k20));
+                        mb = pack_flags(ge_bytes(v.x, P.k30), ge_bytes(v.y, P.k30), ge_bytes(v.z, P.k30), ge_bytes(v.w, P.k30));
                         mc = g;
                     } else {
                         ma = g;
@@ -374,11 +405,11 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                     int64_t lo = (int64_t)rs - (int64_t)I, hi = (int64_t)re - (int64_t)I;
                     lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
                     hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-                    const uint32_t valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    const uint32_t valid = packed_from_mask16(hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u);
                     nl &= valid; ma &= valid; mb &= valid; mc &= valid;
                 }
-                pc[p].m_nl_a = nl | (ma << 16);
-                pc[p].m_b_c = mb | (mc << 16);
+                pc[p].m_nl_a = nl | (ma << 4);
+                pc[p].m_b_c = mb | (mc << 4);
                 const uint32_t lo_cnt = (uint32_t)__popc(nl) | ((uint32_t)__popc(ma) << 16);
                 const uint32_t incl_lo = wave_incl_scan<DPP>(lo_cnt);
                 pc[p].ex_lo = incl_lo - lo_cnt;
@@ -416,23 +447,33 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
     #ifndef BSK_EXPERIMENT
             static_assert(NPIECE <= 4, "merged emission packs at most four 16-bit masks");
 #endif
-            uint64_t m64 = 0, a64 = 0, b64 = 0, c64 = 0;
-    #pragma unroll
-            for (int p = 0; p < NPIECE; ++p) {
-                m64 |= (uint64_t)(pc[p].m_nl_a & 0xFFFFu) << (16 * p);
-                if constexpr (ALL) a64 |= (uint64_t)(pc[p].m_nl_a >> 16) << (16 * p);
-                if constexpr (ALL && FASTQ) {
-                    b64 |= (uint64_t)(pc[p].m_b_c & 0xFFFFu) << (16 * p);
-                    c64 |= (uint64_t)(pc[p].m_b_c >> 16) << (16 * p);
-                }
+            // word h of a merged mask holds pieces 2h (low nibbles) and 2h + 1 (high nibbles)
+            static_assert(NPIECE == 4, "the dense path merges exactly four pieces");
+            constexpr uint32_t LOW = 0x0F0F0F0Fu;
+            const uint32_t nl_w[2] = {(pc[0].m_nl_a & LOW) | ((pc[1].m_nl_a & LOW) << 4), (pc[2].m_nl_a & LOW) | ((pc[3].m_nl_a & LOW) << 4)};
+            uint32_t a_w[2] = {0, 0}, b_w[2] = {0, 0}, c_w[2] = {0, 0};
+            if constexpr (ALL) {
+                a_w[0] = ((pc[0].m_nl_a >> 4) & LOW) | (pc[1].m_nl_a & ~LOW);
+                a_w[1] = ((pc[2].m_nl_a >> 4) & LOW) | (pc[3].m_nl_a & ~LOW);
             }
+            if constexpr (ALL && FASTQ) {
+                b_w[0] = (pc[0].m_b_c & LOW) | ((pc[1].m_b_c & LOW) << 4);
+                b_w[1] = (pc[2].m_b_c & LOW) | ((pc[3].m_b_c & LOW) << 4);
+                c_w[0] = ((pc[0].m_b_c >> 4) & LOW) | (pc[1].m_b_c & ~LOW);
+                c_w[1] = ((pc[2].m_b_c >> 4) & LOW) | (pc[3].m_b_c & ~LOW);
+            }
+            const uint64_t m64 = (uint64_t)nl_w[0] | ((uint64_t)nl_w[1] << 32);
             for (uint32_t wb = tile_rank_base; wb < line_base; wb += CAP) {
                 uint64_t m = m64;
                 while (m) {
+                    // (the newlines of a lane are visited in bit order, not byte order: every event computes its own rank)
                     const uint32_t q = (uint32_t)__ffsll((long long)m) - 1u;
                     m &= m - 1ull;
-                    const uint32_t p = q >> 4, bpos = q & 15u, sh = q & 48u;
-                    const uint32_t below = (1u << bpos) - 1u;
+                    const uint32_t h = q >> 5, rbit = q & 31u;
+                    const uint32_t psel = (rbit >> 2) & 1u;
+                    const uint32_t p = 2u * h + psel;
+                    const uint32_t bpos = 4u * (rbit & 3u) + (rbit >> 3);  // byte of the piece
+                    const uint32_t below = packed_below(bpos) << (4u * psel);
                     // per-piece values selected by p (static unrolled compare chain keeps them in registers)
                     uint32_t r0 = base_nl[0] + (pc[0].ex_lo & 0xFFFFu);
                     uint32_t sa = base_a[0] + (pc[0].ex_lo >> 16), sb = base_b[0] + (pc[0].ex_hi & 0xFFFFu),
@@ -448,17 +489,17 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                             }
                         }
                     }
-                    const uint32_t rank = r0 + (uint32_t)__popc((uint32_t)(m64 >> sh) & below);
+                    const uint32_t rank = r0 + (uint32_t)__popc((h ? nl_w[1] : nl_w[0]) & below);
                     const uint32_t w = rank - wb;
                     if (w < (uint32_t)CAP) {
                         const uint32_t s = HISTORY + w;
                         const uint32_t off = p * (uint32_t)PIECE_BYTES + (uint32_t)lane * 16u + bpos;
                         L.pos[s] = tile_rel + off;
                         if constexpr (FASTQ) L.nc[s] = 0;  // dense path: the sink probes memory
-                        if constexpr (ALL) L.a[s] = sa + (uint32_t)__popc((uint32_t)(a64 >> sh) & below);
+                        if constexpr (ALL) L.a[s] = sa + (uint32_t)__popc((h ? a_w[1] : a_w[0]) & below);
                         if constexpr (ALL && FASTQ) {
-                            L.b[s] = sb + (uint32_t)__popc((uint32_t)(b64 >> sh) & below);
-                            L.c[s] = sc + (uint32_t)__popc((uint32_t)(c64 >> sh) & below);
+                            L.b[s] = sb + (uint32_t)__popc((h ? b_w[1] : b_w[0]) & below);
+                            L.c[s] = sc + (uint32_t)__popc((h ? c_w[1] : c_w[0]) & below);
                         }
                         if constexpr (!FASTQ) {
                             const uint64_t an = tile_idx + off + 1;  // byte after the newline
