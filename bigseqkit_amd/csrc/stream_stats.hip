@@ -206,13 +206,17 @@ struct StatsSink {
     }
 };
 
-// 7 waves per SIMD (<= 72 VGPRs): measured 18.27 -> 17.72 ms (stats) and 55.1 -> 49.8 ms (stats -a) against the
-// compiler's own choice (74 VGPRs, 6 waves); asking for 8 spills the -a kernel (96.8 ms)
+// 7 waves per SIMD (<= 72 VGPRs): measured 18.27 -> 17.72 ms (stats) against the compiler's own choice (74 VGPRs,
+// 6 waves).  The FASTQ -a kernel needs ~90 VGPRs: at 7 waves it spills 17 of them (24 GB of scratch writes per 100 GB
+// pass, PMC) -- 5 waves without spills: 40.7 -> 37.4 ms.
 #ifndef BSK_STATS_WAVES
 #define BSK_STATS_WAVES 7
 #endif
+#ifndef BSK_STATS_WAVES_ALL
+#define BSK_STATS_WAVES_ALL 5
+#endif
 #if BSK_STATS_WAVES
-#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu(BSK_STATS_WAVES, 8)))
+#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu((ALL && FASTQ) ? BSK_STATS_WAVES_ALL : BSK_STATS_WAVES, 8)))
 #else
 #define BSK_STATS_ATTR
 #endif
