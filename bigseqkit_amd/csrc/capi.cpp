@@ -292,8 +292,7 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
-    uint64_t nr = n / c->min_range_bytes;
-    nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, waves * RANGES_PER_WAVE));
+    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
     const uint32_t nranges = (uint32_t)nr;
     // 16-byte aligned nominal chunk so that most range starts keep tile alignment cheap
     uint64_t chunk = (n + nranges - 1) / nranges;

@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstdint>
 #include <map>
 #include <mutex>
@@ -163,3 +165,22 @@ struct bsk_ctx {
         last_error = m;
     }
 };
+
+// Ranges of the persistent streaming kernels (k_stats, k_index): about 512 KiB each -- measured on 3-100 GB shards,
+// ranges below ~200 KiB pay their start-up (anchor, LDS window, validation) and fewer than ~4 ranges per wave leave a
+// tail: 100 GB 17.7 -> 17.1 ms with 16 ranges per wave instead of 4, small shards unchanged (scripts/sweep_ranges.sh).
+// min_range_bytes (BSK_MIN_RANGE_BYTES, tests) bounds the range size from below; BSK_RANGES_PER_WAVE pins the count.
+inline uint64_t pick_nranges(uint64_t n, uint64_t waves, uint64_t min_range_bytes) {
+    static const int pinned = [] { const char* e = getenv("BSK_RANGES_PER_WAVE"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    uint64_t nr;
+    if (pinned) nr = waves * (uint64_t)pinned;
+    else {
+        nr = n / (512u * 1024u);
+        const uint64_t lo = std::min<uint64_t>(waves * 2, n / (128u * 1024u));  // at least two ranges per wave while they stay >= 128 KiB
+        nr = std::max(nr, lo);
+        nr = std::min<uint64_t>(nr, waves * 16);
+    }
+    nr = std::min<uint64_t>(nr, n / std::max<uint64_t>(1, min_range_bytes));
+    return std::max<uint64_t>(1, nr);
+}
+

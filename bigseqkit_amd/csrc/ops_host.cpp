@@ -89,8 +89,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
     const int per_cu = index_max_blocks_per_cu(fastq, c->use_dpp);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
-    uint64_t nr = n / c->min_range_bytes;
-    nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, waves * 4));
+    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
     const uint32_t nranges = (uint32_t)nr;
     uint64_t chunk = (n + nranges - 1) / nranges;
     chunk = (chunk + 15) & ~(uint64_t)15;
