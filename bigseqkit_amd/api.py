@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions
 
 
 class SeqFrame:
@@ -237,6 +237,11 @@ def Fq2Fa(input, o=None, device=0):
 def Duplicate(input, o=None, device=0):
     """bigseqkit/duplicate.go:31-43 (Flatmap: the copies of a record are adjacent)"""
     return _run_records("Duplicate", lib.bsk_duplicate_run, input, o or SeqKitDuplicateOptions(), device)[0]
+
+
+def Rename(input, o=None, device=0):
+    """bigseqkit/rename.go:34-60 (groups are global: the input must be one shard per rank, like RmDup)"""
+    return _run_records("Rename", lib.bsk_rename_run, input, o or SeqKitRenameOptions(), device)[0]
 
 
 def Count(input, device=0):

@@ -18,6 +18,7 @@
 #include "ctx.hpp"
 #include "ops_host.hpp"
 #include "ops_grep.hpp"
+#include "ops_group.hpp"
 #include "ops_locate.hpp"
 #include "ops_records.hpp"
 #include "ops_rmdup.hpp"
@@ -1858,7 +1859,7 @@ static int64_t go_parse_int(const std::string& s) {
 void validate_records_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (c->op == Op::Fq2Fa) { check_id_regexp(o); return; }
+    if (c->op == Op::Fq2Fa || c->op == Op::Rename) { check_id_regexp(o); return; }
     if (c->op == Op::Duplicate) {
         // make([]string, times) panics for a negative count; zero copies is an empty result
         if (o.i("Times") < 0) throw OptError("value of -n (--times) should not be negative");
@@ -1986,6 +1987,115 @@ int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, h
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept * P.times;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rename: RenamePrepare + GroupByKey + Rename (bigseqkit-lib/rename.go:39-131).
+// The k-th further record (k >= 1, file order) of an ID -- or of a whole name with ByName -- is printed as
+// "<ID>_<k> <Desc>"; everything is re-formatted with Format(LineWidth).  Global like rmdup: one call sees the whole
+// input.  Output in file order (the reference's group order is whatever GroupByKey yields); PARITY.md REN.
+// ---------------------------------------------------------------------------
+int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.by_name = o.b("ByName");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = d_buf + n;
+    const uint64_t N = c->table.n;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    if (2 * cap > c->table_cap || !c->d_table) {
+        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+        c->d_table = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+        c->table_cap = 2 * cap;
+    }
+    uint64_t* tk = c->d_table;
+    uint64_t* tf = c->d_table + cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    // groups: the rmdup machinery (XXH64 of the ID / name, first occurrence wins, exact verification of every other one)
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    uint8_t* d_has = nullptr;   // (launch_rmdup_group also marks the groups of two or more; not needed here)
+    uint32_t* d_ord = nullptr;
+    uint64_t* d_list = nullptr;
+    void* d_tmp = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)d_has, (void*)d_ord, (void*)d_list, d_tmp}) if (p) hipFree(p);
+    };
+    auto fail = [&](int code) { cleanup(); return code; };
+    if (hipMalloc((void**)&d_has, N) != hipSuccess || hipMalloc((void**)&d_ord, N * 4) != hipSuccess) {
+        c->set_error("libbsk: out of device memory (rename)");
+        return fail(BSK_ERR_HIP);
+    }
+    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
+    HIP_TRYX(c, hipMemsetAsync(d_ord, 0, N * 4, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));  // d_keys[i] := first record of i's group
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+    // how many records are not the first of their group
+    uint64_t status = 0, m = 0;
+    {
+        // count first (the list is allocated to size): out_len of resolve is 0 exactly for the dropped records
+        HIP_TRYX(c, launch_count_nonzero(c->d_out_len, N, c->d_counter, st));
+        uint64_t firsts = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&firsts, c->d_counter, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (status & ERR_HASH_COLLISION) {
+            c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+            return fail(BSK_ERR_UNSUPPORTED);
+        }
+        rc = kernel_error_to_status(c, status);
+        if (rc != BSK_OK) return fail(rc);
+        m = N - firsts;
+    }
+    if (m) {
+        size_t tmp_bytes = 0;
+        if (group_sort_temp_bytes(m, &tmp_bytes) != hipSuccess || hipMalloc((void**)&d_list, 2 * m * 8) != hipSuccess ||
+            hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) {
+            c->set_error("libbsk: out of device memory (rename)");
+            return fail(BSK_ERR_HIP);
+        }
+        HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 8, st));
+        HIP_TRYX(c, launch_group_compact(c->d_keys, N, d_list, c->d_counter, st));
+        HIP_TRYX(c, launch_group_sort(d_tmp, tmp_bytes, d_list, d_list + m, m, st));
+        HIP_TRYX(c, launch_group_ordinals(d_list + m, m, d_ord, st));
+    }
+    SeqParams F = format_params(c, fastq);
+    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
+    F.buf_end = d_buf + n;
+    F.ren_ord = d_ord;
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, F, c->d_out_len, c->d_status, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return fail(rc);
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return fail(rc);
+    apply_long(c, &F);
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // d_ord is read by the emit
+    cleanup();
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
     return BSK_OK;
 }
 

@@ -90,6 +90,50 @@ __device__ __forceinline__ void feature_region(const SeqParams& P, int f, uint32
     *e = (uint32_t)t;
 }
 
+// Where the bytes of an output header come from: the record's own head (whole, or the ID only), the ID followed by a
+// feature suffix (subseq --gtf / --bed), or the ID followed by "_<ord> " and the description (rename).
+struct HeadSrc {
+    const uint8_t* head;     // after the marker
+    const uint8_t* suffix;   // feature mode
+    uint32_t hoff, id_len;   // ID span inside head
+    uint32_t ord, ndig;      // rename: ordinal (0: header unchanged) and its decimal digits
+    uint32_t desc_off;       // rename: first byte of the description inside head
+    uint32_t len;            // header bytes
+    __device__ __forceinline__ uint8_t at(uint32_t k) const {
+        if (k < id_len) return head[hoff + k];
+        if (suffix) return suffix[k - id_len];
+        if (ord) {
+            const uint32_t q = k - id_len;
+            if (q == 0) return '_';
+            if (q <= ndig) {
+                uint32_t v = ord;
+                for (uint32_t z = ndig - q; z; --z) v /= 10u;
+                return (uint8_t)('0' + v % 10u);
+            }
+            if (q == ndig + 1u) return ' ';
+            return head[desc_off + (q - ndig - 2u)];
+        }
+        return head[hoff + k];
+    }
+};
+
+// rename: header of record g (ord > 0); returns false when the header stays as it is
+__device__ __forceinline__ bool rename_head(const SeqParams& P, uint64_t g, const uint8_t* head, uint32_t head_len,
+                                            HeadSrc* H) {
+    if (!P.ren_ord) return false;
+    const uint32_t ord = P.ren_ord[g];
+    if (!ord) return false;
+    uint32_t hoff, doff;
+    const uint32_t il = id_span_of(head, head_len, P.id_mode, &hoff, P.buf_end);
+    // Desc of parseHeadIDAndDesc (helper.go:329-369): only the default regexp yields one
+    const uint32_t dl = hoff == 0 ? desc_of(head, head_len, P.id_mode, il, &doff) : 0u;
+    uint32_t nd = 1;
+    for (uint32_t v = ord; v >= 10u; v /= 10u) ++nd;
+    H->hoff = hoff; H->id_len = il; H->ord = ord; H->ndig = nd; H->desc_off = doff;
+    H->len = il + 1u + nd + 1u + dl;  // ID '_' digits ' ' Desc   (fmt.Sprintf("%s %s", newID, record.Desc))
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ buf, RecordTable t, SeqParams P,
                                                   uint32_t* __restrict__ out_len, uint64_t* __restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +198,8 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
         if (P.print_name) {
             uint32_t hl = r.head_len, off;
             if (P.only_id) hl = id_span_of(r.head, r.head_len, P.id_mode, &off, P.buf_end);
+            HeadSrc H;
+            if (rename_head(P, i, r.head, r.head_len, &H)) hl = H.len;
             n += (P.print_seq ? 1u : 0u) + hl + 1u;
         }
         if (P.print_seq) n += wrapped_len(kept, P.line_width) + 1u;
@@ -213,6 +259,10 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         hl = id_len + (P.fsuffix_off[f + 1] - P.fsuffix_off[f]);
         if (P.f_minus[f]) { reverse = true; use_lut = true; lut = P.comp; }
     }
+    HeadSrc HS;
+    HS.head = r.head; HS.suffix = suffix; HS.hoff = hoff; HS.id_len = id_len; HS.ord = 0; HS.ndig = 0; HS.desc_off = 0;
+    if (rename_head(P, g, r.head, r.head_len, &HS)) hl = HS.len;
+    HS.len = hl;
     const uint32_t a = P.print_name ? (P.print_seq ? 1u : 0u) + hl + 1u : 0u;
     // random access to the bases: contiguous text, or a wrapped FASTA record through the text view
     const uint8_t* sp = r.seq;
@@ -228,7 +278,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     // Whole FASTQ record printed unchanged (grep / rmdup / plain seq): Format() reproduces the
     // record text byte for byte when the '+' line is bare, so copy it 16 bytes per lane.
     if (fast && P.fastq && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id && !reverse &&
-        !use_lut && !P.region_on && !P.feat_on && t.aux[g] == 1) {
+        !use_lut && !P.region_on && !P.feat_on && t.aux[g] == 1 && HS.ord == 0) {
         const uint8_t* src = buf + t.start[g];
         const uint32_t body = n - 1;  // everything but the final newline, which the shard may lack
         const uint32_t hi = last_byte(0, body);
@@ -261,8 +311,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 uint8_t c;
                 if (x < m) c = (P.fastq && !P.fasta_out) ? '@' : '>';
                 else if (x == a - 1) c = '\n';
-                else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
-                else c = r.head[hoff + x - m];
+                else c = HS.at(x - m);
                 o[x] = c;
             }
             auto group_copy = [&](uint32_t off, const uint8_t* src, uint32_t nb) {
@@ -304,8 +353,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 uint8_t c;
                 if (x < m) c = (P.fastq && !P.fasta_out) ? '@' : '>';
                 else if (x == a - 1) c = '\n';
-                else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
-                else c = r.head[hoff + x - m];
+                else c = HS.at(x - m);
                 o[x] = c;
             }
             auto xform_copy = [&](uint32_t off, const uint8_t* src, uint32_t nb, bool map) {
@@ -360,8 +408,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 if (x < m) c = (P.fastq && !P.fasta_out) ? '@' : '>';
                 else if (x == a - 1) c = '\n';
-                else if (suffix && x - m >= id_len) c = suffix[x - m - id_len];
-                else c = r.head[hoff + x - m];
+                else c = HS.at(x - m);
             } else if (x < a + b) {
                 uint32_t q = x - a;
                 if (q == W) c = '\n';
@@ -397,7 +444,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     uint32_t x = 0;
     if (P.print_name) {
         if (P.print_seq) o[x++] = (P.fastq && !P.fasta_out) ? '@' : '>';
-        for (uint32_t k = 0; k < hl; ++k) o[x++] = (suffix && k >= id_len) ? suffix[k - id_len] : r.head[hoff + k];
+        for (uint32_t k = 0; k < hl; ++k) o[x++] = HS.at(k);
         o[x++] = '\n';
     }
     const uint32_t R = r.region;

@@ -48,6 +48,8 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     const uint8_t* fsuffix;                 // "_<start>-<end>:<strand><flank> <label>" appended to the ID
     const uint32_t* fsuffix_off;
     const uint8_t* comp;                    // complement map of the shard's alphabet
+    // rename (bigseqkit-lib/rename.go:118-121): ord[i] > 0 => header = ID + "_" + ord + " " + Desc
+    const uint32_t* ren_ord;
     const uint8_t* buf_end;                 // one past the shard, or null (the ID search then reads byte by byte)
     // records with a very large output (chromosomes): written by whole blocks, see k_seq_emit<.., LONG>
     const uint32_t* long_list;              // their indices (launch_find_long), or null

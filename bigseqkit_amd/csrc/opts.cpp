@@ -67,6 +67,7 @@ Options Options::defaults(Op op) {
         case Op::Range: o.fields = {fs("Range", "")}; break;        // bigseqkit/range.go:19-24
         case Op::Head: o.fields = {fi("N", 10)}; break;             // bigseqkit/head.go:17-22
         case Op::Duplicate: o.fields = {fi("Times", 1)}; break;     // bigseqkit/duplicate.go:14-19
+        case Op::Rename: o.fields = {fb("ByName", false)}; break;   // bigseqkit/rename.go:17-22
     }
     return o;
 }
@@ -206,7 +207,7 @@ bool op_from_name(const std::string& name, Op* out) {
         {"Locate", Op::Locate}, {"SubseqTransform", Op::Subseq}, {"Subseq", Op::Subseq},
         {"Translate", Op::Translate}, {"RmDup", Op::RmDup}, {"RmDupPrepare", Op::RmDup}, {"RmDupCheck", Op::RmDup},
         {"Fq2Fa", Op::Fq2Fa}, {"Range", Op::Range}, {"RangePrepare", Op::Range}, {"Head", Op::Head},
-        {"Duplicate", Op::Duplicate}};
+        {"Duplicate", Op::Duplicate}, {"Rename", Op::Rename}, {"RenamePrepare", Op::Rename}};
     for (auto& t : tbl)
         if (name == t.n) { *out = t.op; return true; }
     return false;
@@ -225,6 +226,7 @@ const char* op_name(Op op) {
         case Op::Range: return "Range";
         case Op::Head: return "Head";
         case Op::Duplicate: return "Duplicate";
+        case Op::Rename: return "Rename";
     }
     return "";
 }

@@ -28,6 +28,7 @@ _FIELDS = {
     "Range": ["Range"],       # bigseqkit/range.go:14-17
     "Head": ["N"],            # bigseqkit/head.go:12-15
     "Duplicate": ["Times"],   # bigseqkit/duplicate.go:9-12
+    "Rename": ["ByName"],     # bigseqkit/rename.go:12-15
 }
 
 
@@ -100,3 +101,4 @@ SeqKitFq2FaOptions = _make("Fq2Fa")
 SeqKitRangeOptions = _make("Range")
 SeqKitHeadOptions = _make("Head")
 SeqKitDuplicateOptions = _make("Duplicate")
+SeqKitRenameOptions = _make("Rename")

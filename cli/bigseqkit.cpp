@@ -109,6 +109,7 @@ const Command kCommands[] = {
     {"range", "Range", {{"range", 'r', STR, "Range", ""}}},                            // cli/range.go:48
     {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
     {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
+    {"rename", "Rename", {{"by-name", 'n', BOOL, "ByName", "false"}}},                  // cli/rename.go
     {"rmdup", "RmDup",
      {{"by-name", 'n', BOOL, "ByName", "false"}, {"by-seq", 's', BOOL, "BySeq", "false"},
       {"ignore-case", 'i', BOOL, "IgnoreCase", "false"}, {"dup-seqs-file", 'd', STR, "DupSeqsFile", ""},
@@ -404,6 +405,7 @@ int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, ui
     if (use == "subseq") return bsk_subseq_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "translate") return bsk_translate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "fq2fa") return bsk_fq2fa_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "rename") return bsk_rename_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "duplicate") return bsk_duplicate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "range" || use == "head") return bsk_range_run(ctx, p, n, dev, in.fmt, pid, first_record, nullptr, out);
     return bsk_rmdup_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
@@ -416,10 +418,10 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
     const int device = (int)strtol(inv.pget("device").c_str(), nullptr, 10);
     Output res;
     // rmdup is global over the union of its inputs (bigseqkit/rmdup.go:97 groups the whole dataframe): one shard
-    if (use == "rmdup" && inputs.size() > 1) {
+    if ((use == "rmdup" || use == "rename") && inputs.size() > 1) {
         size_t total = 0;
         for (auto& p : inputs) {
-            if (p.fmt != inputs[0].fmt) die("rmdup: inputs of different formats");
+            if (p.fmt != inputs[0].fmt) die(use + ": inputs of different formats");
             total += p.size();
         }
         Part all;

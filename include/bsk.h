@@ -197,6 +197,12 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Rename (RenamePrepare + GroupByKey + Rename, bigseqkit/rename.go:34-60, bigseqkit-lib/rename.go:39-131):
+ * the k-th further record of an ID (of a whole name with ByName) becomes "<ID>_<k> <Desc>".  Global like rmdup:
+ * ONE call must see the whole input of a rank; output in file order. */
+int bsk_rename_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                   bsk_out* out);
+
 /* ---- Fq2Fa (bigseqkit-lib/fq2fa.go:16-59): every record as FASTA, the sequence on one line (Format(0)). */
 int bsk_fq2fa_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                   bsk_out* out);

@@ -363,6 +363,15 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+// rename is global (GroupByKey)
+int orc_rename(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int by_name, uint8_t* out, size_t cap,
+               size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        return emit(rename_call(recs, conv(*cfg), by_name != 0), out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // which: 0 fq2fa, 1 range (Range), 2 head (N), 3 duplicate (Times)
 int orc_records(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int which, const char* range,
                 long long num, int nparts, uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err,

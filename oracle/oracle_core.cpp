@@ -1776,4 +1776,30 @@ std::vector<std::string> duplicate_call(const std::vector<std::string_view>& par
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// rename  (bigseqkit-lib/rename.go)
+// ---------------------------------------------------------------------------
+std::vector<std::string> rename_call(const std::vector<std::string_view>& all, const KitConfig& cfg, bool by_name) {
+    Alphabet ab = alphabet_from_seqtype(cfg.SeqType);  // :32
+    SeqParser rd(ab, &all, cfg.IDRegexp, cfg.AlphabetGuessSeqLength);
+    std::map<std::string, int64_t> numbers;  // per group, in arrival (file) order  (:106)
+    std::vector<std::string> result;
+    int lineWidth = cfg.LineWidth;
+    while (rd.Read()) {
+        Record r = rd.rec;
+        if (rd.IsFastq) lineWidth = 0;                       // :56-59, :113-116
+        const std::string k = by_name ? r.name : r.id;       // :61-65
+        int64_t& n = numbers[k];
+        if (n > 0) {                                         // :118-121
+            const std::string newID = r.id + "_" + std::to_string(n);
+            r.name = newID + " " + r.desc;
+        }
+        ++n;                                                 // :123
+        std::string bb = record_format(r, rd.IsFastq, lineWidth);
+        bb.pop_back();                                       // :125
+        result.push_back(bb);
+    }
+    return result;
+}
+
 }  // namespace orc

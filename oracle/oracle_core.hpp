@@ -232,6 +232,10 @@ std::vector<std::string> range_call(const std::vector<std::string_view>& part, i
 // Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
 std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
 
+// RenamePrepare + GroupByKey + Rename over the WHOLE input (bigseqkit-lib/rename.go:39-131), elements in file order,
+// without the stray newline the reference leaves on singleton groups (PARITY.md REN)
+std::vector<std::string> rename_call(const std::vector<std::string_view>& all, const KitConfig& cfg, bool by_name);
+
 // seq.SubLocation / Seq.SubSeq [upstream-memory]; pinned by the region table
 // bigseqkit-cli/helper.go:348-361.  Returns 0-based [begin, end) or begin == end for empty.
 void sub_location(size_t length, int start, int end, size_t* b, size_t* e);

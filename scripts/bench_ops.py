@@ -86,6 +86,17 @@ if want("records"):
     dt, ol, k = run("Head", rng, {"N": 1000}, t, 1)
     report("head -n 1000 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
     del t
+if want("rename"):
+    # 25 GB with 20 % duplicated sequences but unique names: nothing to rename; and 12.5 GB given twice: every ID twice
+    t, nrec = synth(0, 0, 25e9 * scale)
+    dt, ol, k = run("Rename", lib.bsk_rename_run, {}, t, 1)
+    report("rename, unique IDs (25 GB FASTQ)", nrec, t.numel(), dt, ol)
+    half = t[:317 * (nrec // 2)]
+    t2 = torch.cat([half, half])
+    del t, half
+    dt, ol, k = run("Rename", lib.bsk_rename_run, {}, t2, 1)
+    report("rename, every ID twice (25 GB FASTQ)", 2 * (nrec // 2), t2.numel(), dt, ol)
+    del t2
 # C3: grep -s -p motif, one GPU's 12.5 GB shard
 if want("grep") or want("locate") or want("grepid"):
     t, nrec = synth(0, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * scale)

@@ -106,6 +106,7 @@ CASES = [
     ("locate", ["-m", "1", "-p", "ACGTAC", "-i"], "fq"), ("locate", ["-F", "-p", "ACG"], "fa"),
     ("fq2fa", [], "fq"), ("fq2fa", [], "fa"), ("range", ["-r", "5:40"], "fq"), ("range", ["-r", "-30:-1"], "fa"),
     ("head", [], "fa"), ("head", ["-n", "77"], "fq"), ("duplicate", ["-n", "3"], "fq"), ("dup", [], "fa"),
+    ("rename", [], "fq"), ("rename", ["-n"], "fa"),
 ]
 
 
@@ -115,13 +116,13 @@ def test_cli_output_equals_oracle(tmp_path, cmd, flags, kind):
     rng = random.Random(zlib.crc32(repr((cmd, flags)).encode()))
     fastq = kind == "fq"
     data = seqgen.random_fastq(rng, 300, min_len=1) if fastq else seqgen.random_fasta(rng, 300, min_len=1)
-    if cmd == "rmdup":
+    if cmd in ("rmdup", "rename"):
         data = data + data[:len(data)]  # every record twice
     path = _write(tmp_path, "in." + kind, data)
     op, js, _ = dry(cmd, *flags, path)
     fn = {"seq": oracle.seq, "grep": oracle.grep, "subseq": oracle.subseq, "locate": oracle.locate,
           "translate": oracle.translate, "rmdup": oracle.rmdup, "fq2fa": oracle.fq2fa, "range": oracle.range_,
-          "head": oracle.head, "duplicate": oracle.duplicate, "dup": oracle.duplicate}[cmd]
+          "head": oracle.head, "duplicate": oracle.duplicate, "dup": oracle.duplicate, "rename": oracle.rename}[cmd]
     want = fn(data, fastq, json.dumps(js))
     want = want[0] if isinstance(want, tuple) else want
     assert run(cmd, *flags, path, "-o", "-").stdout == want

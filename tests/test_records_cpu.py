@@ -79,3 +79,17 @@ def test_libbsk_option_handling_of_the_record_operators():
         bsk.Operator("Duplicate", '{"Times": -1}', -1)
     with pytest.raises(bsk.BskError):
         bsk.Operator("Fq2Fa", '{"Config": {"SeqType": "bogus"}}', -1)
+
+
+def test_rename_numbers_further_records_of_an_id_in_file_order():
+    fa = b">a x y\nACGT\n>b\nGG\n>a\tz\nTT\n>a\nC\n>b q\nA\n"
+    assert oracle.rename(fa, False) == b">a x y\nACGT\n>b\nGG\n>a_1 z\nTT\n>a_2 \nC\n>b_1 q\nA\n"
+    assert oracle.rename(fa, False, '{"ByName": true}') == fa   # all five headers differ
+    fa2 = b">a x\nAC\n>a x\nGT\n>a y\nTT\n"
+    assert oracle.rename(fa2, False, '{"ByName": true}') == b">a x\nAC\n>a_1 x\nGT\n>a y\nTT\n"
+    fq = b"@r1 d\nAC\n+\nII\n@r1\nG\n+\n#\n"
+    assert oracle.rename(fq, True) == b"@r1 d\nAC\n+\nII\n@r1_1 \nG\n+\n#\n"
+    wrapped = b">s\nACGTACGT\n>s\nAAAA\n"
+    assert oracle.rename(wrapped, False, '{"Config": {"LineWidth": 3}}') == b">s\nACG\nTAC\nGT\n>s_1 \nAAA\nA\n"
+    with bsk.Operator("Rename", "{}", -1) as op:
+        assert json.loads(op.opts_json())["ByName"] is False
