@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions
 
 
 class SeqFrame:
@@ -242,6 +242,11 @@ def Duplicate(input, o=None, device=0):
 def Rename(input, o=None, device=0):
     """bigseqkit/rename.go:34-60 (groups are global: the input must be one shard per rank, like RmDup)"""
     return _run_records("Rename", lib.bsk_rename_run, input, o or SeqKitRenameOptions(), device)[0]
+
+
+def Sort(input, o=None, device=0):
+    """bigseqkit/sort.go:91-147 (global: the input must be one shard per rank)"""
+    return _run_records("Sort", lib.bsk_sort_run, input, o or SeqKitSortOptions(), device)[0]
 
 
 def Count(input, device=0):

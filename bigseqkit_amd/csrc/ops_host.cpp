@@ -25,6 +25,7 @@
 #include "ops_text.hpp"
 #include "ops_translate.hpp"
 #include "ops_seq.hpp"
+#include "ops_sort.hpp"
 #include "stream_stats.hpp"
 
 namespace bsk {
@@ -2092,6 +2093,109 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     apply_long(c, &F);
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
     HIP_TRYX(c, hipStreamSynchronize(st));  // d_ord is read by the emit
+    cleanup();
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sort: driver bigseqkit/sort.go:91-147, executor bigseqkit-lib/sort.go:38-166
+// ---------------------------------------------------------------------------
+void validate_sort_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    int k = 0;  // sort.go:105-119 (ByBases implies ByLength)
+    if (o.b("BySeq")) ++k;
+    if (o.b("ByName")) ++k;
+    if (o.b("ByLength") || o.b("ByBases")) ++k;
+    if (k > 1) throw OptError("only one of the options (byLength), (byName) and (bySeq) is allowed");
+    if (o.i("SeqPrefixLength") < 0) throw OptError("value of flag -L (--seq-prefix-length) should be >= 0");
+    if (o.b("InNaturalOrder") && !o.b("BySeq") && !(o.b("ByLength") || o.b("ByBases")))
+        throw OptError("libbsk: sort in natural order (-N) is not provided by the HIP path");
+}
+
+int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    const uint64_t N = c->table.n;
+    SortParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.mode = o.b("ByBases") ? 4 : o.b("ByLength") ? 3 : o.b("BySeq") ? 2 : o.b("ByName") ? 1 : 0;
+    P.ignore_case = o.b("IgnoreCase");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.prefix_len = (uint32_t)std::min<int64_t>(o.i("SeqPrefixLength"), 0xFFFFFFFFll);
+    set_bits(P.gap_set, o.s("GapLetters"));
+    P.buf_end = d_buf + n;
+    const bool desc = o.b("Reverse");  // SortByKey(!reverse, ...)
+    // scratch: keys x2, perm x2, key lengths, rocPRIM temporary storage
+    uint64_t* d_keys2 = nullptr;   // [2 N]
+    uint32_t* d_perm2 = nullptr;   // [2 N]
+    uint32_t* d_klen = nullptr;    // [N + 1]   (last: max)
+    void* d_tmp = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)d_keys2, (void*)d_perm2, (void*)d_klen, d_tmp}) if (p) hipFree(p);
+    };
+    auto fail = [&](int code) { cleanup(); return code; };
+    size_t tmp_bytes = 0;
+    if (sort_pairs_temp_bytes(N, &tmp_bytes) != hipSuccess || hipMalloc((void**)&d_keys2, 2 * N * 8) != hipSuccess ||
+        hipMalloc((void**)&d_perm2, 2 * N * 4) != hipSuccess || hipMalloc((void**)&d_klen, (N + 1) * 4) != hipSuccess ||
+        hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) {
+        c->set_error("libbsk: out of device memory (sort)");
+        return fail(BSK_ERR_HIP);
+    }
+    uint64_t* kin = d_keys2;
+    uint64_t* kout = d_keys2 + N;
+    uint32_t* pin = d_perm2;
+    uint32_t* pout = d_perm2 + N;
+    if (launch_sort_iota(pin, N, st) != hipSuccess) return fail(BSK_ERR_HIP);
+    if (P.mode >= 3) {
+        if (launch_sort_intkeys(d_buf, c->table, tt, P, kin, st) != hipSuccess ||
+            launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 32, st) != hipSuccess) return fail(BSK_ERR_HIP);
+        std::swap(pin, pout);
+    } else {
+        uint32_t maxlen = 0;
+        if (hipMemsetAsync(d_klen + N, 0, 4, st) != hipSuccess ||
+            launch_sort_keylen(d_buf, c->table, P, d_klen, d_klen + N, st) != hipSuccess ||
+            hipMemcpyAsync(&maxlen, d_klen + N, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+        // LSD over the 8-byte chunks of the keys, last chunk first; every pass is stable
+        for (uint32_t ch = (maxlen + 7) / 8; ch-- > 0;) {
+            if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, pin, ch, kin, st) != hipSuccess ||
+                launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 64, st) != hipSuccess) return fail(BSK_ERR_HIP);
+            std::swap(pin, pout);
+        }
+    }
+    // sizes in file order, offsets in sorted order
+    SeqParams F = format_params(c, fastq);
+    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
+    F.buf_end = d_buf + n;
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return fail(rc);
+    if (launch_seq_size(d_buf, c->table, F, c->d_out_len, c->d_status, st) != hipSuccess) return fail(BSK_ERR_HIP);
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return fail(rc);
+    uint32_t* len_perm = pout;  // the other permutation buffer is free now
+    uint64_t* off_perm = kin;   // [N + 1] fits: kin and kout are adjacent (2 N entries)
+    if (kin != d_keys2) off_perm = d_keys2;
+    if (launch_sort_gather(c->d_out_len, pin, N, len_perm, st) != hipSuccess ||
+        launch_scan_u32(len_perm, off_perm, N, c->d_scan_tmp, st) != hipSuccess ||
+        launch_sort_scatter(off_perm, pin, N, c->d_out_off, st) != hipSuccess) return fail(BSK_ERR_HIP);
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return fail(rc);
+    apply_long(c, &F);
+    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
     cleanup();
     out->d_data = c->d_out;
     out->len = total;

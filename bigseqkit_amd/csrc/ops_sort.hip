@@ -1,0 +1,173 @@
+// see ops_sort.hpp
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ops_sort.hpp"
+#include "text.cuh"
+
+namespace bsk {
+namespace {
+
+__device__ __forceinline__ bool in_set256(const uint32_t* s, uint8_t b) { return (s[b >> 5] >> (b & 31)) & 1u; }
+
+__global__ void k_iota(uint32_t* __restrict__ perm, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = (uint32_t)i;
+}
+
+// where the string key of record i lives: head bytes [off, off + len) for modes 0 / 1, the sequence for mode 2
+__device__ __forceinline__ uint32_t key_span(const uint8_t* __restrict__ buf, const RecordTable& t, const SortParams& P,
+                                             uint64_t i, uint32_t* off) {
+    *off = 0;
+    if (P.mode == 2) {
+        const uint32_t L = t.l_seq[i];
+        return (P.prefix_len == 0 || L <= P.prefix_len) ? L : P.prefix_len;  // sort.go:74-87
+    }
+    const uint8_t* h = buf + t.start[i] + 1;
+    const uint32_t lh = t.l_head[i];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    if (P.mode == 1) return hl;                                  // record.Name
+    return id_span_of(h, hl, P.id_mode, off, P.buf_end);         // record.ID
+}
+
+__global__ __launch_bounds__(256) void k_sort_keylen(const uint8_t* __restrict__ buf, RecordTable t, SortParams P,
+                                                     uint32_t* __restrict__ key_len, uint32_t* __restrict__ max_len) {
+    __shared__ unsigned int s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.n) {
+        uint32_t off;
+        const uint32_t l = key_span(buf, t, P, i, &off);
+        key_len[i] = l;
+        atomicMax(&s_max, l);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(max_len, s_max);
+}
+
+__global__ __launch_bounds__(256) void k_sort_chunk(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                    SortParams P, const uint32_t* __restrict__ key_len,
+                                                    const uint32_t* __restrict__ perm, uint32_t chunk,
+                                                    uint64_t* __restrict__ keys) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= t.n) return;
+    const uint64_t i = perm[j];
+    const uint32_t len = key_len[i];
+    const uint32_t b0 = chunk * 8u;
+    uint64_t key = 0;
+    if (b0 < len) {
+        const uint32_t nb = len - b0 < 8u ? len - b0 : 8u;
+        if (P.mode == 2) {
+            const Text T = text_of(buf, t, tt, i);
+            for (uint32_t k = 0; k < nb; ++k) {
+                uint8_t c = T.at(b0 + k);
+                if (P.ignore_case && c >= 'A' && c <= 'Z') c += 32;
+                key |= (uint64_t)c << (56u - 8u * k);
+            }
+        } else {
+            uint32_t off;
+            key_span(buf, t, P, i, &off);
+            const uint8_t* h = buf + t.start[i] + 1 + off + b0;
+            for (uint32_t k = 0; k < nb; ++k) {
+                uint8_t c = h[k];
+                if (P.ignore_case && c >= 'A' && c <= 'Z') c += 32;
+                key |= (uint64_t)c << (56u - 8u * k);
+            }
+        }
+    }
+    keys[j] = key;
+}
+
+// 16 lanes per record for the gap count of -b
+__global__ __launch_bounds__(256) void k_sort_intkeys(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                      SortParams P, uint64_t* __restrict__ keys) {
+    constexpr int G = 16;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint32_t gl = threadIdx.x % G;
+    const bool live = i < t.n;
+    const uint64_t ii = live ? i : 0;
+    const uint32_t L = live ? t.l_seq[ii] : 0;
+    uint32_t gaps = 0;
+    if (P.mode == 4) {
+        const Text T = text_of(buf, t, tt, ii);
+        for (uint32_t k = gl; k < L; k += G) gaps += in_set256(P.gap_set, T.at(k)) ? 1u : 0u;
+#pragma unroll
+        for (int d = G / 2; d >= 1; d >>= 1) gaps += (uint32_t)__shfl_xor((int)gaps, d, G);
+    }
+    if (live && gl == 0) keys[i] = (uint64_t)(L - gaps);  // Seq.Bases(gapLetters) = len - gaps
+}
+
+__global__ void k_sort_gather(const uint32_t* __restrict__ out_len, const uint32_t* __restrict__ perm, uint64_t n,
+                              uint32_t* __restrict__ len_perm) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) len_perm[j] = out_len[perm[j]];
+}
+
+__global__ void k_sort_scatter(const uint64_t* __restrict__ off_perm, const uint32_t* __restrict__ perm, uint64_t n,
+                               uint64_t* __restrict__ out_off) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out_off[perm[j]] = off_perm[j];
+    if (j == 0) out_off[n] = off_perm[n];
+}
+
+inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+hipError_t launch_sort_iota(uint32_t* perm, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, st, perm, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_keylen(const uint8_t* buf, const RecordTable& t, const SortParams& P, uint32_t* key_len,
+                              uint32_t* max_len, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_keylen, grid_for(t.n), dim3(256), 0, st, buf, t, P, key_len, max_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_chunk(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const SortParams& P,
+                             const uint32_t* key_len, const uint32_t* perm, uint32_t chunk, uint64_t* keys, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_sort_chunk, grid_for(t.n), dim3(256), 0, st, buf, t, d, P, key_len, perm, chunk, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_intkeys(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const SortParams& P,
+                               uint64_t* keys, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_sort_intkeys, grid_for(t.n * 16), dim3(256), 0, st, buf, t, d, P, keys);
+    return hipGetLastError();
+}
+
+hipError_t sort_pairs_temp_bytes(uint64_t n, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (size_t)n, 0, 64, (hipStream_t)0);
+}
+
+hipError_t launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                             uint32_t* vout, uint64_t n, bool descending, int end_bit, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (descending) return rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, st);
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, st);
+}
+
+hipError_t launch_sort_gather(const uint32_t* out_len, const uint32_t* perm, uint64_t n, uint32_t* len_perm, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_gather, grid_for(n), dim3(256), 0, st, out_len, perm, n, len_perm);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_scatter(const uint64_t* off_perm, const uint32_t* perm, uint64_t n, uint64_t* out_off, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_scatter, grid_for(n), dim3(256), 0, st, off_perm, perm, n, out_off);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

@@ -29,6 +29,8 @@ _FIELDS = {
     "Head": ["N"],            # bigseqkit/head.go:12-15
     "Duplicate": ["Times"],   # bigseqkit/duplicate.go:9-12
     "Rename": ["ByName"],     # bigseqkit/rename.go:12-15
+    "Sort": ["InNaturalOrder", "BySeq", "ByName", "ByLength", "ByBases", "GapLetters", "Reverse", "IgnoreCase",
+             "SeqPrefixLength"],   # bigseqkit/sort.go:13-24
 }
 
 
@@ -102,3 +104,4 @@ SeqKitRangeOptions = _make("Range")
 SeqKitHeadOptions = _make("Head")
 SeqKitDuplicateOptions = _make("Duplicate")
 SeqKitRenameOptions = _make("Rename")
+SeqKitSortOptions = _make("Sort")

@@ -110,6 +110,13 @@ const Command kCommands[] = {
     {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
     {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
     {"rename", "Rename", {{"by-name", 'n', BOOL, "ByName", "false"}}},                  // cli/rename.go
+    {"sort", "Sort",                                                                   // cli/sort.go:50-61
+     {{"natural-order", 'N', BOOL, "InNaturalOrder", "false"}, {"by-name", 'n', BOOL, "ByName", "false"},
+      {"by-seq", 's', BOOL, "BySeq", "false"}, {"by-length", 'l', BOOL, "ByLength", "false"},
+      {"by-bases", 'b', BOOL, "ByBases", "false"}, {"gap-letters", 'G', STR, "GapLetters", "- \t."},
+      {"reverse", 'r', BOOL, "Reverse", "false"}, {"ignore-case", 'i', BOOL, "IgnoreCase", "false"},
+      {"two-pass", '2', BOOL, "", "false"}, {"keep-temp", 'k', BOOL, "", "false"},
+      {"seq-prefix-length", 'L', INT, "SeqPrefixLength", "10000"}}},
     {"rmdup", "RmDup",
      {{"by-name", 'n', BOOL, "ByName", "false"}, {"by-seq", 's', BOOL, "BySeq", "false"},
       {"ignore-case", 'i', BOOL, "IgnoreCase", "false"}, {"dup-seqs-file", 'd', STR, "DupSeqsFile", ""},
@@ -406,6 +413,7 @@ int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, ui
     if (use == "translate") return bsk_translate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "fq2fa") return bsk_fq2fa_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "rename") return bsk_rename_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "sort") return bsk_sort_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "duplicate") return bsk_duplicate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "range" || use == "head") return bsk_range_run(ctx, p, n, dev, in.fmt, pid, first_record, nullptr, out);
     return bsk_rmdup_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
@@ -418,7 +426,7 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
     const int device = (int)strtol(inv.pget("device").c_str(), nullptr, 10);
     Output res;
     // rmdup is global over the union of its inputs (bigseqkit/rmdup.go:97 groups the whole dataframe): one shard
-    if ((use == "rmdup" || use == "rename") && inputs.size() > 1) {
+    if ((use == "rmdup" || use == "rename" || use == "sort") && inputs.size() > 1) {
         size_t total = 0;
         for (auto& p : inputs) {
             if (p.fmt != inputs[0].fmt) die(use + ": inputs of different formats");

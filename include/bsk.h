@@ -197,6 +197,13 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Sort (bigseqkit/sort.go:91-147; SortParseInputString / SortParseInputInt + SortByKey, bigseqkit-lib/sort.go):
+ * by ID (default), full name (ByName), sequence prefix (BySeq, SeqPrefixLength), length (ByLength) or non-gap bases
+ * (ByBases); IgnoreCase, Reverse.  Records with equal keys keep file order.  Global: ONE call sees the whole input of
+ * a rank.  InNaturalOrder is rejected at bsk_create. */
+int bsk_sort_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                 bsk_out* out);
+
 /* ---- Rename (RenamePrepare + GroupByKey + Rename, bigseqkit/rename.go:34-60, bigseqkit-lib/rename.go:39-131):
  * the k-th further record of an ID (of a whole name with ByName) becomes "<ID>_<k> <Desc>".  Global like rmdup:
  * ONE call must see the whole input of a rank; output in file order. */

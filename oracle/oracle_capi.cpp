@@ -363,6 +363,29 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+typedef struct {
+    orc_kitconfig Config;
+    int InNaturalOrder, BySeq, ByName, ByLength, ByBases;
+    const char* GapLetters;
+    int Reverse, IgnoreCase;
+    long long SeqPrefixLength;
+} orc_sort_opts;
+
+int orc_sort(const uint8_t* buf, size_t n, int fastq, const orc_sort_opts* o, uint8_t* out, size_t cap, size_t* nout,
+             uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        SortOptions so;
+        so.Config = conv(o->Config);
+        so.InNaturalOrder = o->InNaturalOrder != 0; so.BySeq = o->BySeq != 0; so.ByName = o->ByName != 0;
+        so.ByLength = o->ByLength != 0; so.ByBases = o->ByBases != 0;
+        if (o->GapLetters) so.GapLetters = o->GapLetters;
+        so.Reverse = o->Reverse != 0; so.IgnoreCase = o->IgnoreCase != 0;
+        so.SeqPrefixLength = o->SeqPrefixLength;
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        return emit(sort_call(recs, so), out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // rename is global (GroupByKey)
 int orc_rename(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int by_name, uint8_t* out, size_t cap,
                size_t* nout, uint64_t* nrec, char* err, size_t errcap) {

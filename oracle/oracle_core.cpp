@@ -1802,4 +1802,59 @@ std::vector<std::string> rename_call(const std::vector<std::string_view>& all, c
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// sort  (bigseqkit/sort.go, bigseqkit-lib/sort.go)
+// ---------------------------------------------------------------------------
+std::vector<std::string> sort_call(const std::vector<std::string_view>& all, const SortOptions& o) {
+    bool byLength = o.ByLength;
+    if (o.ByBases) byLength = true;                                   // sort.go:105-108
+    int n = (o.BySeq ? 1 : 0) + (o.ByName ? 1 : 0) + (byLength ? 1 : 0);
+    if (n > 1) throw Error("only one of the options (byLength), (byName) and (bySeq) is allowed");  // :110-122
+    if (!byLength && !o.BySeq && o.InNaturalOrder) throw Error("natural order: natsort is not in the reference tree");
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    SeqParser rd(ab, &all, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    std::bitset<256> gaps;
+    for (unsigned char ch : o.GapLetters) gaps.set(ch);
+    struct Item { std::string skey; int32_t ikey; std::string text; };
+    std::vector<Item> items;
+    int lineWidth = o.Config.LineWidth;
+    while (rd.Read()) {
+        const Record& r = rd.rec;
+        if (rd.IsFastq) lineWidth = 0;                                // lib/sort.go:58-61, 140-143
+        Item it;
+        it.text = record_format(r, rd.IsFastq, lineWidth);
+        if (!it.text.empty() && it.text.back() == '\n') it.text.pop_back();  // :62-67
+        it.ikey = 0;
+        if (byLength) {                                               // :152-156
+            if (o.ByBases) {
+                int32_t b = 0;
+                for (unsigned char ch : r.seq) b += gaps.test(ch) ? 0 : 1;   // Seq.Bases(gapLetters)
+                it.ikey = b;
+            } else {
+                it.ikey = (int32_t)r.seq.size();
+            }
+        } else if (o.ByName) {                                        // :69-74
+            it.skey = o.IgnoreCase ? lower(r.name) : r.name;
+        } else if (o.BySeq) {                                         // :75-88
+            std::string s = (o.SeqPrefixLength == 0 || (int64_t)r.seq.size() <= o.SeqPrefixLength)
+                                ? r.seq : r.seq.substr(0, (size_t)o.SeqPrefixLength);
+            it.skey = o.IgnoreCase ? lower(s) : s;
+        } else {                                                      // :89-95
+            it.skey = o.IgnoreCase ? lower(r.id) : r.id;
+        }
+        items.push_back(std::move(it));
+    }
+    // SortByKey(ascending = !reverse, less)
+    if (byLength) {
+        if (!o.Reverse) std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ikey < b.ikey; });
+        else std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ikey > b.ikey; });
+    } else {
+        if (!o.Reverse) std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.skey < b.skey; });
+        else std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.skey > b.skey; });
+    }
+    std::vector<std::string> result;
+    for (auto& it : items) result.push_back(std::move(it.text));
+    return result;
+}
+
 }  // namespace orc

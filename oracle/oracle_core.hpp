@@ -232,6 +232,17 @@ std::vector<std::string> range_call(const std::vector<std::string_view>& part, i
 // Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
 std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
 
+struct SortOptions {  // bigseqkit/sort.go:13-39
+    KitConfig Config;
+    bool InNaturalOrder = false, BySeq = false, ByName = false, ByLength = false, ByBases = false;
+    std::string GapLetters = "- \t.";
+    bool Reverse = false, IgnoreCase = false;
+    int64_t SeqPrefixLength = 10000;
+};
+// driver Sort() + SortParseInputString / SortParseInputInt + SortByKey(!reverse) over the WHOLE input
+// (bigseqkit/sort.go:91-147, bigseqkit-lib/sort.go:38-166); equal keys keep file order (PARITY.md SORT); no -N
+std::vector<std::string> sort_call(const std::vector<std::string_view>& all, const SortOptions& o);
+
 // RenamePrepare + GroupByKey + Rename over the WHOLE input (bigseqkit-lib/rename.go:39-131), elements in file order,
 // without the stray newline the reference leaves on singleton groups (PARITY.md REN)
 std::vector<std::string> rename_call(const std::vector<std::string_view>& all, const KitConfig& cfg, bool by_name);

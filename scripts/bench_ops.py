@@ -86,6 +86,16 @@ if want("records"):
     dt, ol, k = run("Head", rng, {"N": 1000}, t, 1)
     report("head -n 1000 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
     del t
+if want("sort"):
+    t, nrec = synth(0, 0, 25e9 * scale)
+    dt, ol, k = run("Sort", lib.bsk_sort_run, {"ByLength": True, "Reverse": True}, t, 1)
+    report("sort -l -r (25 GB FASTQ, all lengths equal)", nrec, t.numel(), dt, ol)
+    dt, ol, k = run("Sort", lib.bsk_sort_run, {"Reverse": True}, t, 1)
+    report("sort -r by ID (25 GB FASTQ, 11-byte IDs)", nrec, t.numel(), dt, ol)
+    half = t[:317 * (nrec // 8)]
+    dt, ol, k = run("Sort", lib.bsk_sort_run, {"BySeq": True}, half, 1)
+    report("sort -s (3.1 GB FASTQ, 150-base keys)", nrec // 8, half.numel(), dt, ol)
+    del t, half
 if want("rename"):
     # 25 GB with 20 % duplicated sequences but unique names: nothing to rename; and 12.5 GB given twice: every ID twice
     t, nrec = synth(0, 0, 25e9 * scale)

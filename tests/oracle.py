@@ -362,3 +362,28 @@ def rename(data, fastq, opts_json="{}"):
         if rc:
             raise OracleError(err.value.decode())
         return out.raw[:n.value]
+
+
+class SortOpts(C.Structure):
+    _fields_ = [("Config", KitConfig)] + [(k, C.c_int) for k in ("InNaturalOrder", "BySeq", "ByName", "ByLength", "ByBases")] + \
+               [("GapLetters", C.c_char_p), ("Reverse", C.c_int), ("IgnoreCase", C.c_int), ("SeqPrefixLength", C.c_longlong)]
+
+
+def sort(data, fastq, opts_json="{}"):
+    """defaults per /root/reference/bigseqkit/sort.go:26-39"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    g = lambda k, dv: dv if d.get(k) is None else d[k]
+    b = lambda k: int(bool(g(k, False)))
+    o = SortOpts(_cfg(d), b("InNaturalOrder"), b("BySeq"), b("ByName"), b("ByLength"), b("ByBases"),
+                 g("GapLetters", "- \t.").encode(), b("Reverse"), b("IgnoreCase"), g("SeqPrefixLength", 10000))
+    cap = 2 * len(data) + 4096
+    while True:
+        out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = _lib.orc_sort(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), out, C.c_size_t(cap), C.byref(n),
+                           C.byref(nrec), err, _ERR)
+        if rc == 2:
+            cap = n.value + 16
+            continue
+        if rc:
+            raise OracleError(err.value.decode())
+        return out.raw[:n.value]

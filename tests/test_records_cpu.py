@@ -93,3 +93,21 @@ def test_rename_numbers_further_records_of_an_id_in_file_order():
     assert oracle.rename(wrapped, False, '{"Config": {"LineWidth": 3}}') == b">s\nACG\nTAC\nGT\n>s_1 \nAAA\nA\n"
     with bsk.Operator("Rename", "{}", -1) as op:
         assert json.loads(op.opts_json())["ByName"] is False
+
+
+def test_sort_keys_ties_and_errors():
+    fa = b">b x\nACGT\n>A\nGG\n>c\nTTTTT\n>a\nC\n>B q\nA-\n"
+    assert oracle.sort(fa, False) == b">A\nGG\n>B q\nA-\n>a\nC\n>b x\nACGT\n>c\nTTTTT\n"
+    assert oracle.sort(fa, False, '{"IgnoreCase": true}') == b">A\nGG\n>a\nC\n>b x\nACGT\n>B q\nA-\n>c\nTTTTT\n"  # ties: file order
+    assert oracle.sort(fa, False, '{"ByLength": true, "Reverse": true}') == b">c\nTTTTT\n>b x\nACGT\n>A\nGG\n>B q\nA-\n>a\nC\n"
+    assert oracle.sort(fa, False, '{"ByBases": true}') == b">a\nC\n>B q\nA-\n>A\nGG\n>b x\nACGT\n>c\nTTTTT\n"
+    assert oracle.sort(fa, False, '{"BySeq": true}') == b">B q\nA-\n>b x\nACGT\n>a\nC\n>A\nGG\n>c\nTTTTT\n"
+    with pytest.raises(oracle.OracleError):
+        oracle.sort(fa, False, '{"BySeq": true, "ByLength": true}')
+    for o, msg in (('{"BySeq": true, "ByName": true}', "only one of the options"), ('{"InNaturalOrder": true}', "natural order")):
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Operator("Sort", o, -1)
+        assert msg in str(e.value)
+    with bsk.Operator("Sort", "{}", -1) as op:
+        d = json.loads(op.opts_json())
+        assert d["GapLetters"] == "- \t." and d["SeqPrefixLength"] == 10000 and d["Reverse"] is False
