@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions
 
 
 class SeqFrame:
@@ -247,6 +247,20 @@ def Rename(input, o=None, device=0):
 def Sort(input, o=None, device=0):
     """bigseqkit/sort.go:91-147 (global: the input must be one shard per rank)"""
     return _run_records("Sort", lib.bsk_sort_run, input, o or SeqKitSortOptions(), device)[0]
+
+
+def Faidx(input, o=None, device=0):
+    """bigseqkit/faidx.go:61-95 (index rows only): the FaidxOffset pass is the running sum of the shard sizes"""
+    chunks, base = [], 0
+    with Operator("Faidx", (o or SeqKitFaidxOptions()).to_json(), device) as op:
+        for pid, ptr, n, on_dev, keep in input.partitions():
+            out = _lib.Out()
+            check(lib.bsk_faidx_run(op.ctx, ptr, n, 1 if on_dev else 0, input.format, pid, base, None, C.byref(out)), op.ctx)
+            buf = C.create_string_buffer(max(1, out.len))
+            check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+            chunks.append(buf.raw[:out.len])
+            base += n
+    return b"".join(chunks)
 
 
 def Count(input, device=0):

@@ -180,6 +180,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
             case Op::RmDup: validate_rmdup_opts(c); break;
             case Op::Fq2Fa: case Op::Range: case Op::Head: case Op::Duplicate: case Op::Rename: validate_records_opts(c); break;
             case Op::Sort: validate_sort_opts(c); break;
+            case Op::Faidx: validate_faidx_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
     } catch (const std::exception& e) {
@@ -711,6 +712,14 @@ int bsk_subseq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int f
                    bsk_out* out) {
     (void)pid;
     return run_record_op(c, Op::Subseq, "SubseqTransform", subseq_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_faidx_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t base_offset,
+                  void* stream, bsk_out* out) {
+    (void)pid;
+    if (!c) return BSK_ERR_INVALID_ARG;
+    c->cur_base_offset = base_offset;
+    return run_record_op(c, Op::Faidx, "Faidx", faidx_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_sort_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

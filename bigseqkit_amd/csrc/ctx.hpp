@@ -138,6 +138,7 @@ struct bsk_ctx {
     int64_t range_start = 0, range_end = 0;  // as the driver computes them (bigseqkit/range.go:46-86)
     bool range_needs_count = false, range_resolved = false;
     int64_t cur_first_record = 0;          // index of the shard's first record in the whole input
+    uint64_t cur_base_offset = 0;          // faidx: file offset of the shard
     uint32_t* d_tile_first = nullptr;      // record of the first byte of every output tile (k_records_copy)
     uint64_t tile_first_cap = 0;
     int region_start = 0, region_end = 0;  // parsed -R / -r

@@ -17,6 +17,7 @@
 #include "../../include/bsk.h"
 #include "ctx.hpp"
 #include "ops_host.hpp"
+#include "ops_faidx.hpp"
 #include "ops_grep.hpp"
 #include "ops_group.hpp"
 #include "ops_locate.hpp"
@@ -74,6 +75,7 @@ int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
         code = BSK_ERR_UNSUPPORTED;
         m = "a line longer than 2^31 bytes (or a FASTA record longer than 2^32 bytes)";
     } else if (f & ERR_INVALID_LETTER) m = "seq: invalid letter for the sequence alphabet";
+    else if (f & ERR_LINE_LENGTHS) m = "different line length in sequence";  // the caller adds the ID
     else if (f & ERR_RECORD_TOO_LARGE) { code = BSK_ERR_UNSUPPORTED; m = "duplicate: the copies of one record exceed 4 GiB"; }
     else if (f & ERR_CAPACITY) { code = BSK_ERR_CAPACITY; m = "libbsk: internal table capacity exceeded"; }
     else m = "unknown kernel error";
@@ -2200,6 +2202,72 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// faidx index rows: Faidx.Before / Call, bigseqkit-lib/faidx.go:63-229.  PARITY.md FAI.
+// ---------------------------------------------------------------------------
+void validate_faidx_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    if (!o.b("FullHead")) check_id_regexp(o);  // -f swaps the ID regexp for ^(.+)$ (faidx.go:69-73)
+    if (!o.sl("Regions").empty() || !o.s("RegionFile").empty())
+        throw OptError("libbsk: faidx region queries are not provided by the HIP path (index rows only; use subseq / grep)");
+}
+
+int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    FaidxParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = format == BSK_FORMAT_FASTQ;
+    P.full_head = o.b("FullHead");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.base_offset = c->cur_base_offset;
+    P.buf_end = d_buf + n;
+    const uint64_t N = c->table.n;
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    uint32_t* d_lb = nullptr;
+    if (hipMalloc((void**)&d_lb, N * 4) != hipSuccess) { c->set_error("libbsk: out of device memory (faidx)"); return BSK_ERR_HIP; }
+    auto fail = [&](int code) { hipFree(d_lb); return code; };
+    if (hipMemsetAsync(c->d_status + 1, 0xFF, 8, st) != hipSuccess ||
+        launch_faidx_size(d_buf, c->table, P, c->d_out_len, d_lb, c->d_status, st) != hipSuccess ||
+        launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) return fail(BSK_ERR_HIP);
+    uint64_t total = 0, status[2] = {0, 0};
+    if (hipMemcpyAsync(&total, c->d_out_off + N, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(status, c->d_status, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+    if (status[0] & ERR_LINE_LENGTHS) {
+        // the first offending record names the error (faidx.go:131)
+        uint64_t start = 0;
+        uint32_t lh = 0;
+        hipMemcpy(&start, c->table.start + status[1], 8, hipMemcpyDeviceToHost);
+        hipMemcpy(&lh, c->table.l_head + status[1], 4, hipMemcpyDeviceToHost);
+        std::string head(lh > 0 ? lh - 1 : 0, '\0');
+        if (!head.empty()) hipMemcpy(&head[0], d_buf + start + 1, head.size(), hipMemcpyDeviceToHost);
+        std::string id = head;
+        if (!P.full_head && P.id_mode == 0) {
+            size_t sp = head.find(' ');
+            if (sp != std::string::npos && sp > 0) id = head.substr(0, sp);
+            else { sp = head.find('\t'); if (sp != std::string::npos && sp > 0) id = head.substr(0, sp); }
+        }
+        c->set_error("different line length in sequence: " + id + ". Please format the file with 'seqkit seq'");
+        return fail(BSK_ERR_FORMAT);
+    }
+    rc = kernel_error_to_status(c, status[0]);
+    if (rc != BSK_OK) return fail(rc);
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return fail(rc);
+    if (launch_faidx_rows(d_buf, c->table, P, d_lb, c->d_out_off, c->d_out, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+    hipFree(d_lb);
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = N;
     return BSK_OK;
 }
 

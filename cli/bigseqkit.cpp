@@ -110,6 +110,10 @@ const Command kCommands[] = {
     {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
     {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
     {"rename", "Rename", {{"by-name", 'n', BOOL, "ByName", "false"}}},                  // cli/rename.go
+    {"faidx", "Faidx",                                                                 // cli/faidx.go:68-72
+     {{"use-regexp", 'r', BOOL, "UseRegexp", "false"}, {"ignore-case", 'i', BOOL, "IgnoreCase", "false"},
+      {"full-head", 'f', BOOL, "FullHead", "false"}, {"region-file", 'l', STR, "RegionFile", ""},
+      {"index-file", 'd', STR, "", ""}}},
     {"sort", "Sort",                                                                   // cli/sort.go:50-61
      {{"natural-order", 'N', BOOL, "InNaturalOrder", "false"}, {"by-name", 'n', BOOL, "ByName", "false"},
       {"by-seq", 's', BOOL, "BySeq", "false"}, {"by-length", 'l', BOOL, "ByLength", "false"},
@@ -414,6 +418,7 @@ int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, ui
     if (use == "fq2fa") return bsk_fq2fa_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "rename") return bsk_rename_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "sort") return bsk_sort_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "faidx") return bsk_faidx_run(ctx, p, n, dev, in.fmt, pid, first_record /* = byte offset here */, nullptr, out);
     if (use == "duplicate") return bsk_duplicate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "range" || use == "head") return bsk_range_run(ctx, p, n, dev, in.fmt, pid, first_record, nullptr, out);
     return bsk_rmdup_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
@@ -473,7 +478,8 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
         return res;
     }
     const bool grep_count = use == "grep" && inv.pget("count") == "true";
-    const bool records_out = !(use == "locate" || grep_count);
+    const bool rows_out = use == "locate" || use == "faidx";  // line-oriented text, not records
+    const bool records_out = !(rows_out || grep_count);
     uint64_t grep_total = 0;
     bsk_ctx* ctx = nullptr;
     auto fresh = [&]() {
@@ -526,14 +532,14 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
             res.parts.push_back(o);
             continue;
         }
-        res.fmt = use == "locate" ? -1 : ofmt;
+        res.fmt = rows_out ? -1 : ofmt;
         const size_t at = res.text.size();
         res.text.resize(at + out.len);
         if (bsk_out_to_host(c, &out, res.text.data() + at, out.len) != BSK_OK) die(bsk_last_error(c));
     }
     if (ctx) bsk_destroy(ctx);
     if (grep_count) { res.is_text = true; res.text = std::to_string(grep_total); }  // fmt.Print: no newline (cli/grep.go:14)
-    if (use == "locate") res.is_text = keep_on_device;  // rows cannot feed another command
+    if (rows_out) res.is_text = keep_on_device;  // rows cannot feed another command
     return res;
 }
 

@@ -197,6 +197,14 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Faidx index rows (FaidxOffset + Faidx, bigseqkit/faidx.go:61-95, bigseqkit-lib/faidx.go:29-229): one row per
+ * record, "<ID>\t<length>\t<offset>\t<linebases>\t<linewidth>[\t<qualoffset>]" (the .fai columns; FullHead prints the
+ * whole header as the name).  base_offset = file offset of the shard's first byte (what the FaidxOffset pass
+ * accumulates per partition).  Records whose sequence lines do not have the .fai shape fail with the reference's
+ * "different line length in sequence: <ID>" error.  Region queries (Regions / RegionFile) are rejected at bsk_create. */
+int bsk_faidx_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t base_offset,
+                  void* stream, bsk_out* out);
+
 /* ---- Sort (bigseqkit/sort.go:91-147; SortParseInputString / SortParseInputInt + SortByKey, bigseqkit-lib/sort.go):
  * by ID (default), full name (ByName), sequence prefix (BySeq, SeqPrefixLength), length (ByLength) or non-gap bases
  * (ByBases); IgnoreCase, Reverse.  Records with equal keys keep file order.  Global: ONE call sees the whole input of

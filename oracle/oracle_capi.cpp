@@ -363,6 +363,26 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+// faidx index rows over nparts partitions (offsets = prefix sums of the partition sizes)
+int orc_faidx(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int full_head, int nparts, uint8_t* out,
+              size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        if (nparts < 1) nparts = 1;
+        std::vector<std::string> all;
+        uint64_t base = 0;
+        for (int p = 0; p < nparts; ++p) {
+            size_t a = recs.size() * (size_t)p / (size_t)nparts, b = recs.size() * (size_t)(p + 1) / (size_t)nparts;
+            std::vector<std::string_view> part(recs.begin() + a, recs.begin() + b);
+            uint64_t bytes = 0;
+            auto r = faidx_call(part, base, full_head != 0, conv(*cfg), &bytes);
+            base += bytes;
+            all.insert(all.end(), r.begin(), r.end());
+        }
+        return emit(all, out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 typedef struct {
     orc_kitconfig Config;
     int InNaturalOrder, BySeq, ByName, ByLength, ByBases;

@@ -1857,4 +1857,75 @@ std::vector<std::string> sort_call(const std::vector<std::string_view>& all, con
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// faidx index rows  (bigseqkit-lib/faidx.go:91-229)
+// ---------------------------------------------------------------------------
+std::vector<std::string> faidx_call(const std::vector<std::string_view>& part, uint64_t base, bool full_head,
+                                    const KitConfig& cfg, uint64_t* bytes) {
+    std::vector<std::string> result;
+    uint64_t at = base;  // file offset of the current element
+    const bool default_re = cfg.IDRegexp == "^(\\S+)\\s?";
+    for (auto elem : part) {
+        // lines of the element (bytes.Split(seqBlock, "\n"), :110)
+        std::vector<std::string_view> lines;
+        for (size_t a = 0;;) {
+            size_t b = elem.find('\n', a);
+            lines.push_back(elem.substr(a, b == std::string_view::npos ? std::string_view::npos : b - a));
+            if (b == std::string_view::npos) break;
+            a = b + 1;
+        }
+        const std::string head(lines[0].substr(1));
+        std::string id, desc;
+        if (full_head) id = head;                                       // ^(.+)$  (:69-73)
+        else if (default_re) {                                          // parseHeadID :434-444
+            size_t i = head.find(' ');
+            if (i != std::string::npos && i > 0) id = head.substr(0, i);
+            else { i = head.find('\t'); id = (i != std::string::npos && i > 0) ? head.substr(0, i) : head; }
+        } else parse_head_id_desc(head, false, cfg.IDRegexp, id, desc);
+        const uint64_t seq_start = at + lines[0].size() + 1;            // lastStart :159-160
+        std::vector<uint64_t> lineWidths, seqWidths;
+        uint64_t seqLen = 0, cur = seq_start, iqual = 0;
+        bool fastq = lines[0][0] == '@', qline = false, have_qual = false;
+        for (size_t k = 1; k < lines.size(); ++k) {
+            const std::string_view line = lines[k];
+            if (fastq && !qline && !have_qual && !line.empty() && line[0] == '+') {  // :111-114
+                iqual = cur + line.size() + 1;
+                qline = true;
+            } else if (qline) {                                         // the quality line :169-171
+                qline = false;
+                have_qual = true;
+            } else if (!have_qual) {                                    // :163-168
+                seqLen += line.size();
+                lineWidths.push_back(line.size() + 1);
+                seqWidths.push_back(line.size());
+            }
+            cur += line.size() + 1;
+        }
+        // check lineWidths :117-137
+        long long lastLineWidth = -1;
+        int chances = 2;
+        bool seenSeqs = false;
+        for (size_t i = lineWidths.size(); i-- > 0;) {
+            if (!seenSeqs && seqWidths[i] == 0) continue;
+            seenSeqs = true;
+            if (lastLineWidth == -1) { lastLineWidth = (long long)lineWidths[i]; continue; }
+            if ((long long)lineWidths[i] != lastLineWidth) {
+                chances--;
+                if (chances == 0 || (long long)lineWidths[i] < lastLineWidth)
+                    throw Error("different line length in sequence: " + id + ". Please format the file with 'seqkit seq'");
+            }
+            lastLineWidth = (long long)lineWidths[i];
+        }
+        const uint64_t lineWidth = lineWidths.empty() ? 0 : lineWidths[0];   // :139-146 (stale values of the previous
+        const uint64_t seqWidth = seqWidths.empty() ? 0 : seqWidths[0];      //  record as written; FAI)
+        std::string row = id + "\t" + std::to_string(seqLen) + "\t" + std::to_string(seq_start) + "\t" +
+                          std::to_string(seqWidth) + "\t" + std::to_string(lineWidth);
+        if (fastq) row += "\t" + std::to_string(iqual);                // :148-152
+        result.push_back(row);
+        at += elem.size() + 1;                                          // FaidxOffset: len(elem) + 1
+    }
+    if (bytes) *bytes = at - base;
+    return result;
+}
+
 }  // namespace orc

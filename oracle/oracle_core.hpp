@@ -232,6 +232,12 @@ std::vector<std::string> range_call(const std::vector<std::string_view>& part, i
 // Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
 std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
 
+// Faidx.Call  bigseqkit-lib/faidx.go:91-229: .fai rows of one partition whose first byte sits at file offset `base`
+// (FaidxOffset :38-48).  PARITY.md FAI: true byte offsets (the line loop as written advances a sequence line by
+// len(line) instead of len(line)+1), widths of a record without sequence lines are 0, '+' line of any length.
+std::vector<std::string> faidx_call(const std::vector<std::string_view>& part, uint64_t base, bool full_head,
+                                    const KitConfig& cfg, uint64_t* bytes);
+
 struct SortOptions {  // bigseqkit/sort.go:13-39
     KitConfig Config;
     bool InNaturalOrder = false, BySeq = false, ByName = false, ByLength = false, ByBases = false;

@@ -86,6 +86,12 @@ if want("records"):
     dt, ol, k = run("Head", rng, {"N": 1000}, t, 1)
     report("head -n 1000 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
     del t
+if want("faidx"):
+    t, nrec = synth(2, 0, 50e9 * scale)
+    fai = lambda ctx, p, n, dev, fmt, pid, st, out: lib.bsk_faidx_run(ctx, p, n, dev, fmt, pid, 0, st, out)
+    dt, ol, k = run("Faidx", fai, {}, t, 0)
+    report("faidx index rows (C4 input, 50 GB FASTA-5k)", nrec, t.numel(), dt, ol)
+    del t
 if want("sort"):
     t, nrec = synth(0, 0, 25e9 * scale)
     dt, ol, k = run("Sort", lib.bsk_sort_run, {"ByLength": True, "Reverse": True}, t, 1)

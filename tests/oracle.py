@@ -387,3 +387,19 @@ def sort(data, fastq, opts_json="{}"):
         if rc:
             raise OracleError(err.value.decode())
         return out.raw[:n.value]
+
+
+def faidx(data, fastq, opts_json="{}", nparts=1):
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    cfg = _cfg(d)
+    cap = 2 * len(data) + 4096
+    while True:
+        out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = _lib.orc_faidx(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(cfg), int(bool(d.get("FullHead"))), nparts,
+                            out, C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+        if rc == 2:
+            cap = n.value + 16
+            continue
+        if rc:
+            raise OracleError(err.value.decode())
+        return out.raw[:n.value]

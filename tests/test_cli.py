@@ -107,6 +107,7 @@ CASES = [
     ("fq2fa", [], "fq"), ("fq2fa", [], "fa"), ("range", ["-r", "5:40"], "fq"), ("range", ["-r", "-30:-1"], "fa"),
     ("head", [], "fa"), ("head", ["-n", "77"], "fq"), ("duplicate", ["-n", "3"], "fq"), ("dup", [], "fa"),
     ("rename", [], "fq"), ("rename", ["-n"], "fa"), ("sort", ["-l", "-r"], "fa"), ("sort", ["-s", "-i"], "fq"), ("sort", [], "fa"),
+    ("faidx", [], "fa"), ("faidx", ["-f"], "fq"),
 ]
 
 
@@ -122,7 +123,7 @@ def test_cli_output_equals_oracle(tmp_path, cmd, flags, kind):
     op, js, _ = dry(cmd, *flags, path)
     fn = {"seq": oracle.seq, "grep": oracle.grep, "subseq": oracle.subseq, "locate": oracle.locate,
           "translate": oracle.translate, "rmdup": oracle.rmdup, "fq2fa": oracle.fq2fa, "range": oracle.range_,
-          "head": oracle.head, "duplicate": oracle.duplicate, "dup": oracle.duplicate, "rename": oracle.rename, "sort": oracle.sort}[cmd]
+          "head": oracle.head, "duplicate": oracle.duplicate, "dup": oracle.duplicate, "rename": oracle.rename, "sort": oracle.sort, "faidx": oracle.faidx}[cmd]
     want = fn(data, fastq, json.dumps(js))
     want = want[0] if isinstance(want, tuple) else want
     assert run(cmd, *flags, path, "-o", "-").stdout == want

@@ -1,0 +1,77 @@
+"""Parity of the `faidx` index rows against the CPU oracle, through the C ABI."""
+import json
+import random
+
+import pytest
+
+import oracle
+import seqgen
+import bigseqkit_amd as bsk
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(data):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    return t.cuda()
+
+
+class _Opts:
+    def __init__(self, d):
+        self.d = dict(d)
+        self._v = self.d
+
+    def to_json(self):
+        return json.dumps(self.d)
+
+
+def frame(data, fastq, nshards=1):
+    fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+    if nshards == 1:
+        return bsk.SeqFrame(fmt, [dev(data)])
+    fr = (bsk.ReadFASTQN if fastq else bsk.ReadFASTAN)(data, nshards)
+    return bsk.SeqFrame(fr.format, [dev(s) for s in fr.shards])
+
+
+def test_faidx_hand_cases():
+    fa = b">a x\nACGTACGT\nACGTACGT\nACG\n>b\nGG\n>c\n>d q\nTTTT\nTT"
+    assert bsk.Faidx(frame(fa, False)) == b"a\t19\t5\t8\t9\nb\t2\t30\t2\t3\nc\t0\t36\t0\t0\nd\t6\t41\t4\t5\n" == oracle.faidx(fa, False)
+    assert bsk.Faidx(frame(fa, False), _Opts({"FullHead": True})).startswith(b"a x\t19\t5\t8\t9\n")
+    fq = b"@r1 d\nACGT\n+\nIIII\n@r2\nGG\n+r2\n##\n"
+    assert bsk.Faidx(frame(fq, True)) == b"r1\t4\t6\t4\t5\t13\nr2\t2\t22\t2\t3\t29\n" == oracle.faidx(fq, True)
+    assert bsk.Faidx(frame(b"", False)) == b""
+    for bad in (b">ok\nAC\n>a\nACGT\nACGTAC\nAC\n", b">a z\nACGTAC\nACGT\nAC\n", b">a\nAC\nACGT\n"):
+        with pytest.raises(oracle.OracleError) as e1:
+            oracle.faidx(bad, False)
+        with pytest.raises(bsk.BskError) as e2:
+            bsk.Faidx(frame(bad, False))
+        assert str(e1.value) in str(e2.value) and "different line length in sequence: a." in str(e2.value)
+    # one change of width, downwards, is what the reference accepts (also in the middle)
+    ok = b">a\nACGTAC\nACGTAC\nACG\nACG\n"
+    assert bsk.Faidx(frame(ok, False)) == oracle.faidx(ok, False) == b"a\t18\t3\t6\t7\n"
+    with pytest.raises(bsk.BskError) as e:
+        bsk.Faidx(frame(fa, False), _Opts({"Regions": ["a:1-5"]}))
+    assert "region queries" in str(e.value)
+
+
+@pytest.mark.parametrize("width", [60, 0, 7, 16])
+def test_faidx_fasta(width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(width)
+    data = seqgen.random_fasta(rng, 400, 0, 900, width=width, final_newline=width != 7)
+    for o in ({}, {"FullHead": True}, {"Config": {"IDNCBI": True}}):
+        assert bsk.Faidx(frame(data, False), _Opts(o)) == oracle.faidx(data, False, json.dumps(o)), o
+    # shards: the offsets are file offsets
+    assert bsk.Faidx(frame(data, False, 3)) == oracle.faidx(data, False)
+
+
+def test_faidx_fastq_and_long_records(monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(3)
+    fq = seqgen.random_fastq(rng, 500, 0, 200)
+    assert bsk.Faidx(frame(fq, True)) == oracle.faidx(fq, True)
+    assert bsk.Faidx(frame(fq, True, 4)) == oracle.faidx(fq, True)
+    big = "".join(rng.choice("ACGT") for _ in range(400_000))
+    fa = (">chr1 x\n" + "".join(big[j:j + 60] + "\n" for j in range(0, len(big), 60)) + ">chr2\nACGT\n").encode()
+    assert bsk.Faidx(frame(fa, False)) == oracle.faidx(fa, False) == b"chr1\t400000\t8\t60\t61\nchr2\t4\t406681\t4\t5\n"

@@ -111,3 +111,17 @@ def test_sort_keys_ties_and_errors():
     with bsk.Operator("Sort", "{}", -1) as op:
         d = json.loads(op.opts_json())
         assert d["GapLetters"] == "- \t." and d["SeqPrefixLength"] == 10000 and d["Reverse"] is False
+
+
+def test_faidx_rows_are_the_fai_columns_with_true_offsets():
+    fa = b">a x\nACGTACGT\nACGTACGT\nACG\n>b\nGG\n>c\n>d q\nTTTT\nTT"
+    assert oracle.faidx(fa, False) == b"a\t19\t5\t8\t9\nb\t2\t30\t2\t3\nc\t0\t36\t0\t0\nd\t6\t41\t4\t5\n"
+    assert oracle.faidx(fa, False, nparts=3) == oracle.faidx(fa, False)   # partition offsets accumulate
+    assert oracle.faidx(fa, False, '{"FullHead": true}').split(b"\n")[3] == b"d q\t6\t41\t4\t5"
+    fq = b"@r1 d\nACGT\n+\nIIII\n@r2\nGG\n+r2\n##\n"
+    assert oracle.faidx(fq, True) == b"r1\t4\t6\t4\t5\t13\nr2\t2\t22\t2\t3\t29\n"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.faidx(b">a\nACGT\nACGTAC\nAC\n", False)
+    assert "different line length in sequence: a." in str(e.value)
+    with pytest.raises(bsk.BskError):
+        bsk.Operator("Faidx", '{"Regions": ["chr1:1-10"]}', -1)
