@@ -241,6 +241,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_cells) hipFree(c->d_cells);
         if (c->d_cellmeta) hipFree(c->d_cellmeta);
         if (c->d_tile_first) hipFree(c->d_tile_first);
+        if (c->d_arena) hipFree(c->d_arena);
         if (c->d_long_list) hipFree(c->d_long_list);
         if (c->d_keys2) hipFree(c->d_keys2);
         if (c->d_own) hipFree(c->d_own);

@@ -139,6 +139,8 @@ struct bsk_ctx {
     bool range_needs_count = false, range_resolved = false;
     int64_t cur_first_record = 0;          // index of the shard's first record in the whole input
     uint64_t cur_base_offset = 0;          // faidx: file offset of the shard
+    uint8_t* d_arena = nullptr;            // grow-only scratch of sort / rename / faidx (carved per call)
+    uint64_t arena_cap = 0;
     uint32_t* d_tile_first = nullptr;      // record of the first byte of every output tile (k_records_copy)
     uint64_t tile_first_cap = 0;
     int region_start = 0, region_end = 0;  // parsed -R / -r

@@ -51,6 +51,20 @@ static int grow(bsk_ctx* c, T** p, uint64_t* cap, uint64_t need, uint64_t slack 
     return BSK_OK;
 }
 
+// Scratch of the global operators (sort, rename, faidx): ONE grow-only allocation per context, carved per call.
+// (hipMalloc / hipFree of gigabytes per call cost 110 of the 144 ms of `sort -l` on 25 GB.)
+struct Arena {
+    uint8_t* base = nullptr;
+    uint64_t used = 0;
+    uint64_t take(uint64_t bytes) { const uint64_t at = used; used = (used + bytes + 255) & ~255ull; return at; }
+    template <class T> T* at(uint64_t off) const { return reinterpret_cast<T*>(base + off); }
+};
+static int arena_reserve(bsk_ctx* c, Arena* a) {
+    int rc = grow(c, &c->d_arena, &c->arena_cap, a->used, a->used / 8 + 256);
+    a->base = c->d_arena;
+    return rc;
+}
+
 static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
 static void complement_table(Alphabet ab, uint8_t m[256]);
 static std::vector<std::string> read_pattern_lines(const std::string& path);
@@ -2036,18 +2050,16 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
     HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
     HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
-    uint8_t* d_has = nullptr;   // (launch_rmdup_group also marks the groups of two or more; not needed here)
-    uint32_t* d_ord = nullptr;
+    Arena A;
+    const uint64_t o_has = A.take(N), o_ord = A.take(N * 4);
+    rc = arena_reserve(c, &A);
+    if (rc != BSK_OK) return rc;
+    uint8_t* d_has = A.at<uint8_t>(o_has);   // (launch_rmdup_group also marks the groups of two or more; not needed here)
+    uint32_t* d_ord = A.at<uint32_t>(o_ord);
     uint64_t* d_list = nullptr;
     void* d_tmp = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)d_has, (void*)d_ord, (void*)d_list, d_tmp}) if (p) hipFree(p);
-    };
-    auto fail = [&](int code) { cleanup(); return code; };
-    if (hipMalloc((void**)&d_has, N) != hipSuccess || hipMalloc((void**)&d_ord, N * 4) != hipSuccess) {
-        c->set_error("libbsk: out of device memory (rename)");
-        return fail(BSK_ERR_HIP);
-    }
+    auto cleanup = [&]() {};
+    auto fail = [&](int code) { return code; };
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
     HIP_TRYX(c, hipMemsetAsync(d_ord, 0, N * 4, st));
     HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));  // d_keys[i] := first record of i's group
@@ -2071,11 +2083,25 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     }
     if (m) {
         size_t tmp_bytes = 0;
-        if (group_sort_temp_bytes(m, &tmp_bytes) != hipSuccess || hipMalloc((void**)&d_list, 2 * m * 8) != hipSuccess ||
-            hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) {
-            c->set_error("libbsk: out of device memory (rename)");
-            return fail(BSK_ERR_HIP);
+        if (group_sort_temp_bytes(m, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
+        // the arena may move when it grows: d_ord has to survive, so it is re-derived after the reservation
+        const uint64_t o_list = A.take(2 * m * 8), o_tmp = A.take(tmp_bytes ? tmp_bytes : 16);
+        if (A.used > c->arena_cap) {
+            // grow by hand, keeping the first part (has / ord)
+            uint8_t* nb = nullptr;
+            const uint64_t cap = A.used + A.used / 8 + 256;
+            if (hipMalloc((void**)&nb, cap) != hipSuccess) { c->set_error("libbsk: out of device memory (rename)"); return BSK_ERR_HIP; }
+            HIP_TRYX(c, hipMemcpyAsync(nb, c->d_arena, o_list, hipMemcpyDeviceToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            hipFree(c->d_arena);
+            c->d_arena = nb;
+            c->arena_cap = cap;
         }
+        A.base = c->d_arena;
+        d_has = A.at<uint8_t>(o_has);
+        d_ord = A.at<uint32_t>(o_ord);
+        d_list = A.at<uint64_t>(o_list);
+        d_tmp = A.at<uint8_t>(o_tmp);
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 8, st));
         HIP_TRYX(c, launch_group_compact(c->d_keys, N, d_list, c->d_counter, st));
         HIP_TRYX(c, launch_group_sort(d_tmp, tmp_bytes, d_list, d_list + m, m, st));
@@ -2094,7 +2120,6 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (rc != BSK_OK) return fail(rc);
     apply_long(c, &F);
     HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
-    HIP_TRYX(c, hipStreamSynchronize(st));  // d_ord is read by the emit
     cleanup();
     out->d_data = c->d_out;
     out->len = total;
@@ -2140,21 +2165,19 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     P.buf_end = d_buf + n;
     const bool desc = o.b("Reverse");  // SortByKey(!reverse, ...)
     // scratch: keys x2, perm x2, key lengths, rocPRIM temporary storage
-    uint64_t* d_keys2 = nullptr;   // [2 N]
-    uint32_t* d_perm2 = nullptr;   // [2 N]
-    uint32_t* d_klen = nullptr;    // [N + 1]   (last: max)
-    void* d_tmp = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)d_keys2, (void*)d_perm2, (void*)d_klen, d_tmp}) if (p) hipFree(p);
-    };
-    auto fail = [&](int code) { cleanup(); return code; };
     size_t tmp_bytes = 0;
-    if (sort_pairs_temp_bytes(N, &tmp_bytes) != hipSuccess || hipMalloc((void**)&d_keys2, 2 * N * 8) != hipSuccess ||
-        hipMalloc((void**)&d_perm2, 2 * N * 4) != hipSuccess || hipMalloc((void**)&d_klen, (N + 1) * 4) != hipSuccess ||
-        hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) {
-        c->set_error("libbsk: out of device memory (sort)");
-        return fail(BSK_ERR_HIP);
-    }
+    if (sort_pairs_temp_bytes(N, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
+    Arena A;
+    const uint64_t o_keys = A.take(2 * N * 8), o_perm = A.take(2 * N * 4), o_klen = A.take((N + 1) * 4),
+                   o_tmp = A.take(tmp_bytes ? tmp_bytes : 16);
+    rc = arena_reserve(c, &A);
+    if (rc != BSK_OK) return rc;
+    uint64_t* d_keys2 = A.at<uint64_t>(o_keys);   // [2 N]
+    uint32_t* d_perm2 = A.at<uint32_t>(o_perm);   // [2 N]
+    uint32_t* d_klen = A.at<uint32_t>(o_klen);    // [N + 1]   (last: max)
+    void* d_tmp = A.at<uint8_t>(o_tmp);
+    auto cleanup = [&]() {};
+    auto fail = [&](int code) { return code; };
     uint64_t* kin = d_keys2;
     uint64_t* kout = d_keys2 + N;
     uint32_t* pin = d_perm2;
@@ -2196,8 +2219,7 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return fail(rc);
     apply_long(c, &F);
-    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess) return fail(BSK_ERR_HIP);
     cleanup();
     out->d_data = c->d_out;
     out->len = total;
@@ -2231,9 +2253,12 @@ int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     const uint64_t N = c->table.n;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
-    uint32_t* d_lb = nullptr;
-    if (hipMalloc((void**)&d_lb, N * 4) != hipSuccess) { c->set_error("libbsk: out of device memory (faidx)"); return BSK_ERR_HIP; }
-    auto fail = [&](int code) { hipFree(d_lb); return code; };
+    Arena A;
+    const uint64_t o_lb = A.take(N * 4);
+    rc = arena_reserve(c, &A);
+    if (rc != BSK_OK) return rc;
+    uint32_t* d_lb = A.at<uint32_t>(o_lb);
+    auto fail = [&](int code) { return code; };
     if (hipMemsetAsync(c->d_status + 1, 0xFF, 8, st) != hipSuccess ||
         launch_faidx_size(d_buf, c->table, P, c->d_out_len, d_lb, c->d_status, st) != hipSuccess ||
         launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) return fail(BSK_ERR_HIP);
@@ -2262,9 +2287,7 @@ int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return fail(rc);
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return fail(rc);
-    if (launch_faidx_rows(d_buf, c->table, P, d_lb, c->d_out_off, c->d_out, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
-    hipFree(d_lb);
+    if (launch_faidx_rows(d_buf, c->table, P, d_lb, c->d_out_off, c->d_out, st) != hipSuccess) return fail(BSK_ERR_HIP);
     out->d_data = c->d_out;
     out->len = total;
     out->records = N;
