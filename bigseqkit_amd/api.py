@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions
 
 
 class SeqFrame:
@@ -261,6 +261,30 @@ def Faidx(input, o=None, device=0):
             chunks.append(buf.raw[:out.len])
             base += n
     return b"".join(chunks)
+
+
+def Pair(inputA, inputB, o=None, device=0):
+    """bigseqkit/pair.go:68-100 -> (paired.1, paired.2, unpaired.1, unpaired.2) as the bytes SaveAsTextFile would write.
+    Both inputs are one device-resident shard each; they are joined (file 1, then file 2) for the one call."""
+    import torch
+    a, b = inputA.shards[0], inputB.shards[0]
+    if not (hasattr(a, "data_ptr") and hasattr(b, "data_ptr")):
+        raise ValueError("Pair: both inputs must be device tensors")
+    parts = [a]
+    if a.numel() and int(a[-1]) != 10:
+        parts.append(torch.tensor([10], dtype=torch.uint8, device=a.device))
+    n_first = sum(p.numel() for p in parts)
+    both = torch.cat(parts + [b]) if b.numel() or len(parts) > 1 else a
+    outs = (_lib.Out * 4)()
+    res = []
+    with Operator("Pair", (o or SeqKitPairOptions()).to_json(), device) as op:
+        check(lib.bsk_pair_run(op.ctx, C.c_void_p(both.data_ptr()) if both.numel() else None, both.numel(), n_first, 1,
+                               inputA.format, None, outs), op.ctx)
+        for k in range(4):
+            buf = C.create_string_buffer(max(1, outs[k].len))
+            check(lib.bsk_out_to_host(op.ctx, C.byref(outs[k]), buf, outs[k].len), op.ctx)
+            res.append(buf.raw[:outs[k].len])
+    return tuple(res)
 
 
 def Count(input, device=0):

@@ -40,7 +40,154 @@ __global__ __launch_bounds__(256) void k_group_ordinals(const uint64_t* __restri
     ord[(uint32_t)e] = (uint32_t)(p - lo) + 1u;
 }
 
+__global__ void k_group_all(const uint64_t* __restrict__ group, uint64_t n, uint64_t* __restrict__ list) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) list[i] = (group[i] << 32) | i;
+}
+
+__global__ __launch_bounds__(256) void k_count_below(const uint64_t* __restrict__ start, uint64_t n, uint64_t x,
+                                                     unsigned long long* __restrict__ count) {
+    __shared__ unsigned int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        mine += start[i] < x;
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(count, (unsigned long long)s_cnt);
+}
+
+__device__ __forceinline__ uint64_t lower_bound64(const uint64_t* __restrict__ a, uint64_t lo, uint64_t hi, uint64_t v) {
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One thread per sorted entry.  Groups are almost always two records (a read and its mate): the segment is found by a
+// short walk, the binary searches are for the rare large groups.
+__global__ __launch_bounds__(256) void k_pair_classify(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t first2,
+                                                       uint8_t* __restrict__ state, uint32_t* __restrict__ partner) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t e = sorted[p], g = e >> 32;
+    const uint32_t i = (uint32_t)e;
+    uint64_t s = p, end = p + 1;
+    int steps = 0;
+    while (s > 0 && (sorted[s - 1] >> 32) == g && steps < 8) { --s; ++steps; }
+    if (s > 0 && (sorted[s - 1] >> 32) == g) s = lower_bound64(sorted, 0, s, g << 32);
+    steps = 0;
+    while (end < n && (sorted[end] >> 32) == g && steps < 8) { ++end; ++steps; }
+    if (end < n && (sorted[end] >> 32) == g) end = lower_bound64(sorted, end, n, (g + 1) << 32);
+    uint64_t m1;  // members of file 1 (they sort first: their indices are below first2)
+    if (end - s <= 16) {
+        m1 = 0;
+        for (uint64_t q = s; q < end; ++q) m1 += (uint32_t)sorted[q] < first2;
+    } else {
+        m1 = lower_bound64(sorted, s, end, (g << 32) | first2) - s;
+    }
+    const uint64_t m2 = end - s - m1;
+    if (i < first2) {
+        const uint64_t ord = p - s;
+        if (ord < m2) { state[i] = 1; partner[i] = (uint32_t)sorted[s + m1 + ord]; }
+        else state[i] = 3;
+    } else {
+        const uint64_t ord = p - s - m1;
+        if (ord < m1) { state[i] = 2; partner[i] = (uint32_t)sorted[s + ord]; }
+        else state[i] = 4;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_totals(const uint8_t* __restrict__ state, const uint32_t* __restrict__ fmt_len,
+                                                     uint64_t n, unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long s_b[4];
+    __shared__ unsigned int s_c[4];
+    if (threadIdx.x < 4) { s_b[threadIdx.x] = 0; s_c[threadIdx.x] = 0; }
+    __syncthreads();
+    unsigned long long b[4] = {0, 0, 0, 0};
+    unsigned int c[4] = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = state[i];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+            if (k == q + 1u) { b[q] += fmt_len[i]; ++c[q]; }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q)
+        if (c[q]) { atomicAdd(&s_b[q], b[q]); atomicAdd(&s_c[q], c[q]); }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_c[threadIdx.x]) {
+        atomicAdd(&totals[threadIdx.x], s_b[threadIdx.x]);
+        atomicAdd(&totals[4 + threadIdx.x], (unsigned long long)s_c[threadIdx.x]);
+    }
+}
+
+__global__ void k_pair_select(const uint8_t* __restrict__ state, const uint32_t* __restrict__ fmt_len, uint64_t n, uint8_t k,
+                              uint32_t* __restrict__ len_k) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) len_k[i] = state[i] == k ? fmt_len[i] : 0u;
+}
+
+__global__ void k_pair_partner_len(const uint8_t* __restrict__ state, const uint32_t* __restrict__ partner,
+                                   const uint32_t* __restrict__ fmt_len, uint64_t n, uint32_t* __restrict__ w) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = state[i] == 1 ? fmt_len[partner[i]] : 0u;
+}
+
+__global__ void k_pair_partner_off(const uint8_t* __restrict__ state, const uint32_t* __restrict__ partner,
+                                   const uint64_t* __restrict__ offw, uint64_t n, uint64_t* __restrict__ off2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && state[i] == 1) off2[partner[i]] = offw[i];
+}
+
 }  // namespace
+
+#define BSK_GRID(n) dim3((unsigned)(((n) + 255) / 256))
+hipError_t launch_group_all(const uint64_t* group, uint64_t n, uint64_t* list, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_group_all, BSK_GRID(n), dim3(256), 0, st, group, n, list);
+    return hipGetLastError();
+}
+hipError_t launch_count_below(const uint64_t* start, uint64_t n, uint64_t x, uint64_t* count, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 4095) / 4096;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_count_below, dim3((unsigned)blocks), dim3(256), 0, st, start, n, x, (unsigned long long*)count);
+    return hipGetLastError();
+}
+hipError_t launch_pair_classify(const uint64_t* sorted, uint64_t n, uint32_t first2, uint8_t* state, uint32_t* partner,
+                                hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair_classify, BSK_GRID(n), dim3(256), 0, st, sorted, n, first2, state, partner);
+    return hipGetLastError();
+}
+hipError_t launch_pair_totals(const uint8_t* state, const uint32_t* fmt_len, uint64_t n, uint64_t* totals, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 4095) / 4096;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pair_totals, dim3((unsigned)blocks), dim3(256), 0, st, state, fmt_len, n, (unsigned long long*)totals);
+    return hipGetLastError();
+}
+hipError_t launch_pair_select(const uint8_t* state, const uint32_t* fmt_len, uint64_t n, uint8_t k, uint32_t* len_k, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair_select, BSK_GRID(n), dim3(256), 0, st, state, fmt_len, n, k, len_k);
+    return hipGetLastError();
+}
+hipError_t launch_pair_partner_len(const uint8_t* state, const uint32_t* partner, const uint32_t* fmt_len, uint64_t n,
+                                   uint32_t* w, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair_partner_len, BSK_GRID(n), dim3(256), 0, st, state, partner, fmt_len, n, w);
+    return hipGetLastError();
+}
+hipError_t launch_pair_partner_off(const uint8_t* state, const uint32_t* partner, const uint64_t* offw, uint64_t n,
+                                   uint64_t* off2, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair_partner_off, BSK_GRID(n), dim3(256), 0, st, state, partner, offw, n, off2);
+    return hipGetLastError();
+}
+#undef BSK_GRID
 
 hipError_t launch_group_compact(const uint64_t* group, uint64_t n, uint64_t* list, uint64_t* count, hipStream_t st) {
     if (n == 0) return hipSuccess;

@@ -17,4 +17,24 @@ hipError_t launch_group_sort(void* tmp, size_t tmp_bytes, const uint64_t* in, ui
 // ord[i] := 1 + number of earlier records of the same group, for the m sorted entries (ord is zero elsewhere)
 hipError_t launch_group_ordinals(const uint64_t* sorted, uint64_t m, uint32_t* ord, hipStream_t st);
 
+// ---- pair (bigseqkit-lib/pair.go:86-121): records of two files grouped by ID; the k-th record of an ID in file 1
+// goes with the k-th of file 2.  Records [0, first2) belong to file 1.
+// list[i] = group[i] << 32 | i for every record
+hipError_t launch_group_all(const uint64_t* group, uint64_t n, uint64_t* list, hipStream_t st);
+// *count += records whose start is below x (zeroed by the caller)
+hipError_t launch_count_below(const uint64_t* start, uint64_t n, uint64_t x, uint64_t* count, hipStream_t st);
+// state[i]: 1 paired (file 1), 2 paired (file 2), 3 unpaired (file 1), 4 unpaired (file 2); partner[i] for 1 and 2
+hipError_t launch_pair_classify(const uint64_t* sorted, uint64_t n, uint32_t first2, uint8_t* state, uint32_t* partner,
+                                hipStream_t st);
+// totals[k] += bytes, totals[4 + k] += records of state k + 1 (zeroed by the caller)
+hipError_t launch_pair_totals(const uint8_t* state, const uint32_t* fmt_len, uint64_t n, uint64_t* totals, hipStream_t st);
+// len_k[i] = state[i] == k ? fmt_len[i] : 0
+hipError_t launch_pair_select(const uint8_t* state, const uint32_t* fmt_len, uint64_t n, uint8_t k, uint32_t* len_k, hipStream_t st);
+// w[i] = state[i] == 1 ? fmt_len[partner[i]] : 0   (file order of the paired file-1 records = order of both outputs)
+hipError_t launch_pair_partner_len(const uint8_t* state, const uint32_t* partner, const uint32_t* fmt_len, uint64_t n,
+                                   uint32_t* w, hipStream_t st);
+// off2[partner[i]] = offw[i] for state[i] == 1
+hipError_t launch_pair_partner_off(const uint8_t* state, const uint32_t* partner, const uint64_t* offw, uint64_t n,
+                                   uint64_t* off2, hipStream_t st);
+
 }  // namespace bsk

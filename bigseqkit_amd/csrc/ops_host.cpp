@@ -1876,7 +1876,7 @@ static int64_t go_parse_int(const std::string& s) {
 void validate_records_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (c->op == Op::Fq2Fa || c->op == Op::Rename) { check_id_regexp(o); return; }
+    if (c->op == Op::Fq2Fa || c->op == Op::Rename || c->op == Op::Pair) { check_id_regexp(o); return; }
     if (c->op == Op::Duplicate) {
         // make([]string, times) panics for a negative count; zero copies is an empty result
         if (o.i("Times") < 0) throw OptError("value of -n (--times) should not be negative");
@@ -2291,6 +2291,125 @@ int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     out->d_data = c->d_out;
     out->len = total;
     out->records = N;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pair: PairPrepare x2 + Union + GroupByKey + Pair (bigseqkit/pair.go:34-100,
+// bigseqkit-lib/pair.go:37-121).  The shard is file 1 followed by file 2; the k-th record of an ID in file 1 is paired
+// with the k-th of file 2.  outs[0] / outs[1]: the pairs, both in the file-1 order of their first mates; outs[2] /
+// outs[3]: the records without a mate (SaveUnpaired), file order.  PARITY.md PAIR.
+// ---------------------------------------------------------------------------
+int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* outs) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    for (int k = 0; k < 4; ++k) { outs[k].d_data = nullptr; outs[k].len = 0; outs[k].records = 0; }
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) {
+        bsk_out tmp;
+        return empty_result(c, &tmp);
+    }
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    const uint64_t N = c->table.n;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = d_buf + n;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    if (2 * cap > c->table_cap || !c->d_table) {
+        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+        c->d_table = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+        c->table_cap = 2 * cap;
+    }
+    uint64_t* tk = c->d_table;
+    uint64_t* tf = c->d_table + cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    size_t tmp_bytes = 0;
+    if (group_sort_temp_bytes(N, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
+    Arena A;
+    const uint64_t o_has = A.take(N), o_list = A.take(2 * N * 8), o_tmp = A.take(tmp_bytes ? tmp_bytes : 16),
+                   o_state = A.take(N), o_partner = A.take(N * 4), o_fmt = A.take(N * 4), o_len = A.take(N * 4),
+                   o_off = A.take((N + 1) * 8), o_offw = A.take((N + 1) * 8), o_tot = A.take(8 * 8);
+    rc = arena_reserve(c, &A);
+    if (rc != BSK_OK) return rc;
+    uint8_t* d_has = A.at<uint8_t>(o_has);
+    uint64_t* d_list = A.at<uint64_t>(o_list);
+    uint8_t* d_state = A.at<uint8_t>(o_state);
+    uint32_t* d_partner = A.at<uint32_t>(o_partner);
+    uint32_t* d_fmt = A.at<uint32_t>(o_fmt);
+    uint32_t* d_len = A.at<uint32_t>(o_len);
+    uint64_t* d_off = A.at<uint64_t>(o_off);
+    uint64_t* d_offw = A.at<uint64_t>(o_offw);
+    uint64_t* d_tot = A.at<uint64_t>(o_tot);
+    // groups by ID (XXH64, first occurrence, exact verification of every other member)
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
+    HIP_TRYX(c, hipMemsetAsync(d_tot, 0, 8 * 8, st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
+    uint64_t first2 = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&first2, c->d_counter, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_HASH_COLLISION) {
+        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_group_all(c->d_keys, N, d_list, st));
+    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st));
+    HIP_TRYX(c, launch_pair_classify(d_list + N, N, (uint32_t)first2, d_state, d_partner, st));
+    // formatted size of every record, totals per output
+    SeqParams F = format_params(c, fastq);
+    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
+    F.buf_end = d_buf + n;
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, F, d_fmt, c->d_status, st));
+    HIP_TRYX(c, launch_pair_totals(d_state, d_fmt, N, d_tot, st));
+    uint64_t tot[8];
+    HIP_TRYX(c, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    const bool unpaired = o.b("SaveUnpaired");
+    uint64_t base[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) base[k + 1] = base[k] + ((k < 2 || unpaired) ? ((tot[k] + 255) & ~255ull) : 0);
+    rc = ensure_out(c, base[4]);
+    if (rc != BSK_OK) return rc;
+    for (int k = 0; k < 4; ++k) {
+        if (!(k < 2 || unpaired) || tot[k] == 0) continue;
+        HIP_TRYX(c, launch_pair_select(d_state, d_fmt, N, (uint8_t)(k + 1), d_len, st));
+        if (k == 1) {
+            // the second mates follow the order of the first ones
+            uint32_t* d_w = c->d_out_len;  // free scratch of N entries
+            HIP_TRYX(c, launch_pair_partner_len(d_state, d_partner, d_fmt, N, d_w, st));
+            HIP_TRYX(c, launch_scan_u32(d_w, d_offw, N, c->d_scan_tmp, st));
+            HIP_TRYX(c, launch_pair_partner_off(d_state, d_partner, d_offw, N, d_off, st));
+        } else {
+            HIP_TRYX(c, launch_scan_u32(d_len, d_off, N, c->d_scan_tmp, st));
+        }
+        HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, d_len, d_off, c->d_out + base[k], st, tot[k], tot[4 + k]));
+        outs[k].d_data = c->d_out + base[k];
+        outs[k].len = tot[k];
+        outs[k].records = tot[4 + k];
+    }
     return BSK_OK;
 }
 

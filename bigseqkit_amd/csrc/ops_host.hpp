@@ -33,6 +33,7 @@ void validate_sort_opts(bsk_ctx* c);
 int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_faidx_opts(bsk_ctx* c);
 int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
+int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* outs);
 int ensure_out(bsk_ctx* c, uint64_t bytes);
 int ensure_record_scratch(bsk_ctx* c);
 Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc);

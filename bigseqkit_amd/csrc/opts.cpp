@@ -68,6 +68,7 @@ Options Options::defaults(Op op) {
         case Op::Head: o.fields = {fi("N", 10)}; break;             // bigseqkit/head.go:17-22
         case Op::Duplicate: o.fields = {fi("Times", 1)}; break;     // bigseqkit/duplicate.go:14-19
         case Op::Rename: o.fields = {fb("ByName", false)}; break;   // bigseqkit/rename.go:17-22
+        case Op::Pair: o.fields = {fb("SaveUnpaired", false)}; break;   // bigseqkit/pair.go:17-22
         case Op::Faidx:  // bigseqkit/faidx.go:20-29
             o.fields = {fb("UseRegexp", false), fb("IgnoreCase", false), fb("FullHead", false), fs("RegionFile", ""),
                         fl("Regions", {})};
@@ -217,7 +218,8 @@ bool op_from_name(const std::string& name, Op* out) {
         {"Translate", Op::Translate}, {"RmDup", Op::RmDup}, {"RmDupPrepare", Op::RmDup}, {"RmDupCheck", Op::RmDup},
         {"Fq2Fa", Op::Fq2Fa}, {"Range", Op::Range}, {"RangePrepare", Op::Range}, {"Head", Op::Head},
         {"Duplicate", Op::Duplicate}, {"Rename", Op::Rename}, {"RenamePrepare", Op::Rename},
-        {"Sort", Op::Sort}, {"Faidx", Op::Faidx}};
+        {"Sort", Op::Sort}, {"Faidx", Op::Faidx}, {"Pair", Op::Pair},
+        {"PairPrepare", Op::Pair}};
     for (auto& t : tbl)
         if (name == t.n) { *out = t.op; return true; }
     return false;
@@ -239,6 +241,7 @@ const char* op_name(Op op) {
         case Op::Rename: return "Rename";
         case Op::Sort: return "Sort";
         case Op::Faidx: return "Faidx";
+        case Op::Pair: return "Pair";
     }
     return "";
 }

@@ -29,6 +29,7 @@ _FIELDS = {
     "Head": ["N"],            # bigseqkit/head.go:12-15
     "Duplicate": ["Times"],   # bigseqkit/duplicate.go:9-12
     "Rename": ["ByName"],     # bigseqkit/rename.go:12-15
+    "Pair": ["SaveUnpaired"], # bigseqkit/pair.go:12-15
     "Faidx": ["UseRegexp", "IgnoreCase", "FullHead", "RegionFile", "Regions"],   # bigseqkit/faidx.go:11-18
     "Sort": ["InNaturalOrder", "BySeq", "ByName", "ByLength", "ByBases", "GapLetters", "Reverse", "IgnoreCase",
              "SeqPrefixLength"],   # bigseqkit/sort.go:13-24
@@ -107,3 +108,4 @@ SeqKitDuplicateOptions = _make("Duplicate")
 SeqKitRenameOptions = _make("Rename")
 SeqKitSortOptions = _make("Sort")
 SeqKitFaidxOptions = _make("Faidx")
+SeqKitPairOptions = _make("Pair")

@@ -109,6 +109,9 @@ const Command kCommands[] = {
     {"range", "Range", {{"range", 'r', STR, "Range", ""}}},                            // cli/range.go:48
     {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
     {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
+    {"pair", "Pair",                                                                   // cli/pair.go (flags of its init())
+     {{"read1", '1', STR, "", ""}, {"read2", '2', STR, "", ""}, {"out-dir", 'O', STR, "", ""}, {"force", 'f', BOOL, "", "false"},
+      {"save-unpaired", 'u', BOOL, "SaveUnpaired", "false"}}},
     {"rename", "Rename", {{"by-name", 'n', BOOL, "ByName", "false"}}},                  // cli/rename.go
     {"faidx", "Faidx",                                                                 // cli/faidx.go:68-72
      {{"use-regexp", 'r', BOOL, "UseRegexp", "false"}, {"ignore-case", 'i', BOOL, "IgnoreCase", "false"},
@@ -439,16 +442,25 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
         }
         Part all;
         all.fmt = inputs[0].fmt;
-        all.dptr = bsk_device_alloc(total ? total : 1);
+        all.dptr = bsk_device_alloc(total + inputs.size() + 1);  // room for a newline after every part
         if (!all.dptr) die(bsk_global_error());
-        all.n = total;
         all.owned_alloc = true;
         size_t at = 0;
         for (auto& p : inputs) {
-            if (p.size() && bsk_device_copy((char*)all.dptr + at, p.ptr(), p.size(), p.on_device() ? BSK_COPY_D2D : BSK_COPY_H2D) != BSK_OK)
+            if (!p.size()) continue;
+            if (bsk_device_copy((char*)all.dptr + at, p.ptr(), p.size(), p.on_device() ? BSK_COPY_D2D : BSK_COPY_H2D) != BSK_OK)
                 die(bsk_global_error());
             at += p.size();
+            // a file that does not end in a newline must not run into the next file's first header
+            char last = 0;
+            if (bsk_device_copy(&last, (char*)all.dptr + at - 1, 1, BSK_COPY_D2H) != BSK_OK) die(bsk_global_error());
+            if (last != '\n') {
+                const char nl = '\n';
+                if (bsk_device_copy((char*)all.dptr + at, &nl, 1, BSK_COPY_H2D) != BSK_OK) die(bsk_global_error());
+                ++at;
+            }
         }
+        all.n = at;
         release(inputs);
         inputs.push_back(all);
     }
@@ -652,6 +664,34 @@ int main(int argc, char** argv) {
     }
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
     std::vector<Part> inputs = read_parts(inv.files);
+    if (std::string(inv.cmd->use) == "pair") {
+        // cli/pair.go:13-66: two files; <out-dir>/paired.1, paired.2 and, with -u, unpaired.1, unpaired.2
+        if (inputs.size() < 2) die("2 files needed");
+        const std::string outdir = inv.pget("out-dir");
+        if (outdir.empty()) die("out-dir required");
+        if (inputs[0].fmt != inputs[1].fmt) die("pair: inputs of different formats");
+        if (!is_dir(outdir) && mkdir(outdir.c_str(), 0755) != 0) die("cannot create directory " + outdir);
+        std::string both = inputs[0].host;
+        if (!both.empty() && both.back() != '\n') both += '\n';
+        const size_t n_first = both.size();
+        both += inputs[1].host;
+        bsk_ctx* c = nullptr;
+        const int device = (int)strtol(inv.pget("device").c_str(), nullptr, 10);
+        if (bsk_create("Pair", inv.js.c_str(), device, &c) != BSK_OK) die(bsk_global_error());
+        bsk_out outs[4];
+        if (bsk_pair_run(c, both.data(), both.size(), n_first, 0, inputs[0].fmt, nullptr, outs) != BSK_OK) die(bsk_last_error(c));
+        const char* names[4] = {"paired.1", "paired.2", "unpaired.1", "unpaired.2"};
+        const bool unp = inv.pget("save-unpaired") == "true";
+        for (int k = 0; k < (unp ? 4 : 2); ++k) {
+            std::string text(outs[k].len, '\0');
+            if (outs[k].len && bsk_out_to_host(c, &outs[k], &text[0], text.size()) != BSK_OK) die(bsk_last_error(c));
+            std::ofstream f(outdir + "/" + names[k], std::ios::binary);
+            if (!f) die("cannot create " + outdir + "/" + names[k]);
+            f.write(text.data(), (std::streamsize)text.size());
+        }
+        bsk_destroy(c);
+        return 0;
+    }
     Output o = execute(inv, inputs, false);
     store(inv, o, inv.files);
     return 0;

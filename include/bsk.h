@@ -197,6 +197,13 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Pair (bigseqkit/pair.go:34-100; PairPrepare + Union + GroupByKey + Pair, bigseqkit-lib/pair.go:37-121): match up
+ * the reads of two files by ID.  `shard` holds file 1 followed by file 2, n_first = bytes of file 1 (ending in a
+ * newline).  outs[0], outs[1]: the paired records of file 1 / file 2, line for line in the same pair order (= PairIndex
+ * 0 / 1); outs[2], outs[3]: the records without a mate (= UnpairedId "1" / "2"), filled with SaveUnpaired only. */
+int bsk_pair_run(bsk_ctx* ctx, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
+                 bsk_out outs[4]);
+
 /* ---- Faidx index rows (FaidxOffset + Faidx, bigseqkit/faidx.go:61-95, bigseqkit-lib/faidx.go:29-229): one row per
  * record, "<ID>\t<length>\t<offset>\t<linebases>\t<linewidth>[\t<qualoffset>]" (the .fai columns; FullHead prints the
  * whole header as the name).  base_offset = file offset of the shard's first byte (what the FaidxOffset pass

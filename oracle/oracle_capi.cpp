@@ -363,6 +363,18 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+// which: 0 paired.1, 1 paired.2, 2 unpaired.1, 3 unpaired.2
+int orc_pair(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int fastq, const orc_kitconfig* cfg, int which,
+             uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto ra = split_records(std::string_view((const char*)a, na), fastq != 0);
+        auto rb = split_records(std::string_view((const char*)b, nb), fastq != 0);
+        std::vector<std::string> outs[4];
+        pair_call(ra, rb, conv(*cfg), outs);
+        return emit(outs[which & 3], out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // faidx index rows over nparts partitions (offsets = prefix sums of the partition sizes)
 int orc_faidx(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int full_head, int nparts, uint8_t* out,
               size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {

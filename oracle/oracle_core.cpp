@@ -1928,4 +1928,43 @@ std::vector<std::string> faidx_call(const std::vector<std::string_view>& part, u
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// pair  (bigseqkit-lib/pair.go)
+// ---------------------------------------------------------------------------
+void pair_call(const std::vector<std::string_view>& a, const std::vector<std::string_view>& b, const KitConfig& cfg,
+               std::vector<std::string> out[4]) {
+    Alphabet ab = alphabet_from_seqtype(cfg.SeqType);
+    struct Rec { std::string id, text; };
+    auto prepare = [&](const std::vector<std::string_view>& part) {  // PairPrepare.Call :37-65
+        std::vector<Rec> v;
+        SeqParser rd(ab, &part, cfg.IDRegexp, cfg.AlphabetGuessSeqLength);
+        int lineWidth = cfg.LineWidth;
+        while (rd.Read()) {
+            if (rd.IsFastq) lineWidth = 0;
+            std::string t = record_format(rd.rec, rd.IsFastq, lineWidth);
+            t.pop_back();
+            v.push_back({rd.rec.id, t});
+        }
+        return v;
+    };
+    const std::vector<Rec> ra = prepare(a), rb = prepare(b);
+    std::map<std::string, std::vector<size_t>> f2;  // ID -> its records in file 2, in order
+    for (size_t j = 0; j < rb.size(); ++j) f2[rb[j].id].push_back(j);
+    std::map<std::string, size_t> used;             // ID -> records of file 1 seen so far
+    std::vector<char> b_paired(rb.size(), 0);
+    for (size_t i = 0; i < ra.size(); ++i) {        // Pair.Call :86-121, groups visited in file-1 order
+        const size_t k = used[ra[i].id]++;
+        auto it = f2.find(ra[i].id);
+        if (it != f2.end() && k < it->second.size()) {
+            out[0].push_back(ra[i].text);
+            out[1].push_back(rb[it->second[k]].text);
+            b_paired[it->second[k]] = 1;
+        } else {
+            out[2].push_back(ra[i].text);
+        }
+    }
+    for (size_t j = 0; j < rb.size(); ++j)
+        if (!b_paired[j]) out[3].push_back(rb[j].text);
+}
+
 }  // namespace orc

@@ -232,6 +232,12 @@ std::vector<std::string> range_call(const std::vector<std::string_view>& part, i
 // Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
 std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
 
+// Pair(): PairPrepare x2 + Union + GroupByKey + Pair.Call (bigseqkit/pair.go:34-100, bigseqkit-lib/pair.go:37-121).
+// out[0] / out[1]: first / second mates, pairs ordered by the file-1 position of the first mate; out[2] / out[3]: the
+// records without a mate, file order (PARITY.md PAIR: element order, no stray newline)
+void pair_call(const std::vector<std::string_view>& a, const std::vector<std::string_view>& b, const KitConfig& cfg,
+               std::vector<std::string> out[4]);
+
 // Faidx.Call  bigseqkit-lib/faidx.go:91-229: .fai rows of one partition whose first byte sits at file offset `base`
 // (FaidxOffset :38-48).  PARITY.md FAI: true byte offsets (the line loop as written advances a sequence line by
 // len(line) instead of len(line)+1), widths of a record without sequence lines are 0, '+' line of any length.

@@ -86,6 +86,22 @@ if want("records"):
     dt, ol, k = run("Head", rng, {"N": 1000}, t, 1)
     report("head -n 1000 (25 GB FASTQ)", nrec, t.numel(), dt, ol)
     del t
+if want("pair"):
+    # two files of 12.5 GB with the same IDs in the same order (the usual paired-end layout)
+    t, nrec = synth(0, 0, 12.5e9 * scale)
+    both = torch.cat([t, t])
+    del t
+    outs = (_lib.Out * 4)()
+    with bsk.Operator("Pair", "{}", 0) as op:
+        for i in range(reps + 1):
+            if i == 1:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            check(lib.bsk_pair_run(op.ctx, C.c_void_p(both.data_ptr()), both.numel(), both.numel() // 2, 1, 1, None, outs), op.ctx)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert outs[0].records == nrec and outs[1].records == nrec
+        report("pair (2 x 12.5 GB FASTQ, all reads paired)", 2 * nrec, both.numel(), dt, outs[0].len + outs[1].len)
+    del both
 if want("faidx"):
     t, nrec = synth(2, 0, 50e9 * scale)
     fai = lambda ctx, p, n, dev, fmt, pid, st, out: lib.bsk_faidx_run(ctx, p, n, dev, fmt, pid, 0, st, out)

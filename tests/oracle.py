@@ -403,3 +403,19 @@ def faidx(data, fastq, opts_json="{}", nparts=1):
         if rc:
             raise OracleError(err.value.decode())
         return out.raw[:n.value]
+
+
+def pair(a, b, fastq, opts_json="{}"):
+    """-> (paired.1, paired.2, unpaired.1, unpaired.2)"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    cfg = _cfg(d)
+    res = []
+    for which in range(4):
+        cap = 2 * (len(a) + len(b)) + 4096
+        out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = _lib.orc_pair(_buf(a), C.c_size_t(len(a)), _buf(b), C.c_size_t(len(b)), int(fastq), C.byref(cfg), which, out,
+                           C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+        if rc:
+            raise OracleError(err.value.decode())
+        res.append(out.raw[:n.value])
+    return tuple(res)

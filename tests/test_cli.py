@@ -205,6 +205,16 @@ def test_cli_pipe_chains_commands_in_hbm(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_global_commands_join_files_that_lack_a_final_newline(tmp_path):
+    a = _write(tmp_path, "a.fa", b">x 1\nACGT\n>y\nGG")          # no newline at the end
+    b = _write(tmp_path, "b.fa", b">x 2\nTTTT\n>z\nC\n")
+    union = b">x 1\nACGT\n>y\nGG\n>x 2\nTTTT\n>z\nC\n"
+    assert run("rename", a, b, "-o", "-").stdout == oracle.rename(union, False) == b">x 1\nACGT\n>y\nGG\n>x_1 2\nTTTT\n>z\nC\n"
+    assert run("sort", "-l", a, b, "-o", "-").stdout == oracle.sort(union, False, '{"ByLength": true}')
+    assert run("rmdup", a, b, "-o", "-").stdout == oracle.rmdup(union, False)
+
+
+@pytest.mark.gpu
 def test_cli_range_indexes_the_union_of_its_inputs_and_chains_in_a_pipe(tmp_path):
     rng = random.Random(8)
     d1, d2 = seqgen.random_fastq(rng, 120, min_len=1), seqgen.random_fastq(rng, 90, min_len=1)

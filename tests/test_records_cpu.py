@@ -125,3 +125,13 @@ def test_faidx_rows_are_the_fai_columns_with_true_offsets():
     assert "different line length in sequence: a." in str(e.value)
     with pytest.raises(bsk.BskError):
         bsk.Operator("Faidx", '{"Regions": ["chr1:1-10"]}', -1)
+
+
+def test_pair_kth_with_kth_and_the_rest_unpaired():
+    a = b"@r1 1\nAC\n+\nII\n@r2 1\nGG\n+\nII\n@r1 1b\nTT\n+\nII\n@r5\nA\n+\nI\n"
+    b = b"@r2 2\nCC\n+\nII\n@r9\nT\n+\nI\n@r1 2\nGT\n+\nII\n"
+    p1, p2, u1, u2 = oracle.pair(a, b, True)
+    assert p1 == b"@r1 1\nAC\n+\nII\n@r2 1\nGG\n+\nII\n" and p2 == b"@r1 2\nGT\n+\nII\n@r2 2\nCC\n+\nII\n"
+    assert u1 == b"@r1 1b\nTT\n+\nII\n@r5\nA\n+\nI\n" and u2 == b"@r9\nT\n+\nI\n"
+    with bsk.Operator("Pair", "{}", -1) as op:
+        assert json.loads(op.opts_json())["SaveUnpaired"] is False
