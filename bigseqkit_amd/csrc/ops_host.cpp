@@ -1440,6 +1440,28 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     HIP_TRYX(c, hipStreamSynchronize(st));
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
+    // chromosome-sized records leave the per-record kernels (one wave would translate 10^8 bases alone)
+    uint64_t long_max = 0;
+    {
+        const char* e = getenv("BSK_LONG_BYTES");
+        const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+        const char* mode = getenv("BSK_TRANSLATE");
+        if (!(mode && strcmp(mode, "legacy") == 0)) {
+            rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+            HIP_TRYX(c, launch_find_long(c->table.l_seq, c->table.n, thresh, c->d_long_list, c->d_counter + 2, st));
+            uint64_t lc[2] = {0, 0};
+            HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (lc[0] && lc[0] * (uint64_t)P.nframes <= 65535) {  // (grid.y; more long records than that stay per record)
+                P.long_list = c->d_long_list;
+                P.long_count = lc[0];
+                P.long_thresh = thresh;
+                long_max = lc[1];
+            }
+        }
+    }
     {
         // wave per record for long sequences, 16 lanes per record for reads; BSK_TRANSLATE=legacy keeps
         // the per-(record, frame) kernel (used by tests to cross-check the two implementations)
@@ -1450,6 +1472,8 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             const uint64_t avg = n / std::max<uint64_t>(1, c->table.n);
             HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
                                                 c->d_out, c->d_status, st));
+            HIP_TRYX(c, launch_translate_long(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status,
+                                              long_max, st));
         }
     }
     uint64_t status = 0;

@@ -191,6 +191,77 @@ __global__ __launch_bounds__(256) void k_translate_emit(const uint8_t* __restric
 }
 
 
+// Chromosome-sized records: every output byte of an element is computed from its position (aa_at), so an element's
+// body is cut into chunks of LONG_BODY bytes, one block each: grid = (chunks, long records x frames).
+constexpr uint32_t LONG_BODY = 16u * 1024u;
+__global__ __launch_bounds__(256) void k_translate_long(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                        TranslateParams P, const uint32_t* __restrict__ out_len,
+                                                        const uint64_t* __restrict__ out_off,
+                                                        uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
+    __shared__ uint8_t s_codon[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_codon[i] = P.codon[i];
+    __syncthreads();
+    const uint64_t i = P.long_list[blockIdx.y / (uint32_t)P.nframes];
+    const int k = (int)(blockIdx.y % (uint32_t)P.nframes);
+    const int frame = P.frames[k];
+    const uint64_t e = i * (uint64_t)P.nframes + (uint64_t)k;
+    const Text T = text_of(buf, t, tt, i);
+    const uint32_t n = out_len[e];
+    uint8_t* o = out + out_off[e];
+    const uint8_t* h = buf + t.start[i] + 1;
+    const uint32_t lh = t.l_head[i];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    const uint32_t H = header_len(h, hl, P, frame) + 1;
+    const uint32_t body = n - H - 1;
+    const uint32_t x_lo = blockIdx.x * LONG_BODY;
+    if (x_lo >= body && blockIdx.x != 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // header and the element's final newline
+        uint32_t hdr = 0;
+        o[hdr++] = '>';
+        if (!P.append_frame) {
+            for (uint32_t q = 0; q < hl; ++q) o[hdr++] = h[q];
+        } else {
+            uint32_t ioff, doff;
+            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
+            for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
+            const char* f = "_frame=";
+            for (int q = 0; q < 7; ++q) o[hdr++] = (uint8_t)f[q];
+            hdr += put_dec(o + hdr, frame);
+            o[hdr++] = ' ';
+            for (uint32_t q = 0; q < dl; ++q) o[hdr++] = h[doff + q];
+        }
+        o[hdr++] = '\n';
+        o[n - 1] = '\n';
+    }
+    const uint32_t w1 = P.line_width > 0 ? (uint32_t)P.line_width + 1u : 0u;
+    const uint32_t x_hi = x_lo + LONG_BODY < body ? x_lo + LONG_BODY : body;
+    uint32_t err = 0;
+    for (uint32_t x = x_lo + threadIdx.x; x < x_hi; x += blockDim.x) {
+        uint32_t j = x;
+        bool nl = false;
+        if (w1) {
+            const uint32_t line = x / w1, col = x - line * w1;
+            if (col == w1 - 1) nl = true;
+            j = line * (w1 - 1) + col;
+        }
+        uint8_t c = '\n';
+        if (!nl) {
+            c = aa_at(T, P, s_codon, frame, j);
+            if (c == 0) { err = ERR_UNKNOWN_CODON; c = 'X'; }
+        }
+        o[H + x] = c;
+    }
+    // codons dropped by --trim are still translated by the reference (errors included)
+    if (blockIdx.x == 0 && P.trim && !P.allow_unknown) {
+        const uint32_t total = num_aa(T.L, frame);
+        const uint32_t kept = body - ((w1 && body) ? (body - 1) / w1 : 0u);
+        for (uint32_t j = kept + threadIdx.x; j < total; j += blockDim.x)
+            if (aa_at(T, P, s_codon, frame, j) == 0) err = ERR_UNKNOWN_CODON;
+    }
+    if (err) atomicOr((unsigned long long*)&status[0], (unsigned long long)err);
+}
+
 // ---------------------------------------------------------------------------
 // k_translate_frames<G>: G lanes per record, every base read once.
 // A window is G x 48 bases (a multiple of 3, so base k of a lane always belongs to forward
@@ -221,6 +292,8 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (g >= t.n) return;  // no block-level barrier below
+    if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;
+    if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
     uint8_t* raw = s_raw[threadIdx.x / G];
     const Text T = text_of(buf, t, tt, g);
     const uint32_t L = T.L;
@@ -453,6 +526,7 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (g >= t.n) return;  // no block-level barrier below
+    if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
     uint8_t* raw = s_raw[threadIdx.x / G];
     const Text T = text_of(buf, t, tt, g);
     const uint32_t L = T.L;
@@ -687,6 +761,18 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
         hipLaunchKernelGGL(k_translate_frames<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t, d,
                            P, out_len, out_off, out, status);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_translate_long(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const TranslateParams& P,
+                                 const uint32_t* out_len, const uint64_t* out_off, uint8_t* out, uint64_t* status,
+                                 uint64_t max_len, hipStream_t st) {
+    if (!P.long_count) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    uint64_t body = max_len / 3 + 2;
+    if (P.line_width > 0) body += body / (uint64_t)P.line_width + 1;
+    const dim3 grid((unsigned)((body + LONG_BODY - 1) / LONG_BODY), (unsigned)(P.long_count * (uint64_t)P.nframes));
+    hipLaunchKernelGGL(k_translate_long, grid, dim3(256), 0, st, buf, t, d, P, out_len, out_off, out, status);
     return hipGetLastError();
 }
 

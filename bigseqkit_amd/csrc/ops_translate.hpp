@@ -27,6 +27,11 @@ struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/tra
     const uint8_t* start_rc; // device, 4096 bytes
     const uint8_t* iupac;    // device, 256 bytes: byte -> 4-bit IUPAC code (0 = not a base)
     const uint8_t* baked;    // device, 8192 bytes, 16-byte aligned: codon ++ codon_rc with -x (0 -> 'X') and --clean ('*' -> 'X') applied
+    // chromosome-sized records (l_seq >= long_thresh): skipped by the per-record kernels, translated by whole blocks
+    // (launch_translate_long: one block per 16 KiB of an element's body)
+    const uint32_t* long_list;
+    uint64_t long_count;
+    uint32_t long_thresh;
 };
 
 constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
@@ -38,6 +43,10 @@ hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const
 hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                    uint8_t* out, uint64_t* status, hipStream_t st);
+// elements of the records in P.long_list; max_len = longest of those sequences
+hipError_t launch_translate_long(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const TranslateParams& P,
+                                 const uint32_t* out_len, const uint64_t* out_off, uint8_t* out, uint64_t* status,
+                                 uint64_t max_len, hipStream_t st);
 hipError_t launch_translate_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                  const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                  uint8_t* out, uint64_t* status, hipStream_t st);

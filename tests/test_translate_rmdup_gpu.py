@@ -310,3 +310,23 @@ def test_rmdup_distributed_single_rank_equals_rmdup():
     finally:
         b.close()
     assert got == bsk.RmDup(frame(data, True), _Opts({"BySeq": True})) == oracle.rmdup(data, True, '{"BySeq": true}')
+
+
+@pytest.mark.parametrize("i", range(len(TR_OPTS)))
+def test_translate_long_records_take_the_block_per_chunk_kernel(i, monkeypatch):
+    """records above BSK_LONG_BYTES bases are translated by k_translate_long (16 KiB of an element's body per block)"""
+    import random
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_LONG_BYTES", "20000")
+    rng = random.Random(50 + i)
+    recs = []
+    for k, (L, w) in enumerate([(120_001, 60), (12, 60), (70_000, 0), (50_003, 11), (19_999, 60), (65_536, 80)]):
+        s = "".join(rng.choice("ACGTacgtN") for _ in range(L))
+        if k == 0:
+            s = s[:-3] + "TAA"   # a stop codon at the very end (for --trim)
+        body = "".join(s[j:j + w] + "\n" for j in range(0, L, w)) if w else s + "\n"
+        recs.append(f">chr{k} some description\n{body}")
+    data = "".join(recs).encode()
+    o = dict(TR_OPTS[i], AllowUnknownCodon=True)
+    got = bsk.Translate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)]), _Opts(o))
+    assert got == oracle.translate(data, False, json.dumps(o)), o
