@@ -2303,6 +2303,13 @@ int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             size_t sp = head.find(' ');
             if (sp != std::string::npos && sp > 0) id = head.substr(0, sp);
             else { sp = head.find('\t'); if (sp != std::string::npos && sp > 0) id = head.substr(0, sp); }
+        } else if (!P.full_head) {  // --id-ncbi: first match of \|([^\|]+)\|<space>
+            for (size_t i = 0; i < head.size(); ++i) {
+                if (head[i] != '|') continue;
+                size_t j = i + 1;
+                while (j < head.size() && head[j] != '|') ++j;
+                if (j > i + 1 && j + 1 < head.size() && head[j + 1] == ' ') { id = head.substr(i + 1, j - i - 1); break; }
+            }
         }
         c->set_error("different line length in sequence: " + id + ". Please format the file with 'seqkit seq'");
         return fail(BSK_ERR_FORMAT);

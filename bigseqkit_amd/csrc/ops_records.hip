@@ -11,7 +11,15 @@ namespace {
 //   FASTA: everything up to the next record start / the shard end, minus ONE trailing '\n' (helper.go:51-56)
 __device__ __forceinline__ uint64_t record_text_len(const uint8_t* __restrict__ buf, uint64_t buf_n, const RecordTable& t,
                                                     int fastq, uint64_t i) {
-    if (fastq) return (uint64_t)t.l_head[i] + 1u + t.l_seq[i] + 1u + t.aux[i] + 1u + t.l_seq[i];
+    if (fastq) {
+        uint64_t T = (uint64_t)t.l_head[i] + 1u + t.l_seq[i] + 1u + t.aux[i] + 1u + t.l_seq[i];
+        const uint64_t s = t.start[i], avail = buf_n - s;
+        if (avail <= T) {  // the shard ends with this record and without a final newline: an EMPTY quality line then
+            T = avail;     // leaves the newline of the '+' line at the end of the element, and ReadFixer strips it
+            if (T && buf[s + T - 1] == '\n') --T;
+        }
+        return T;
+    }
     const uint64_t s = t.start[i];
     uint64_t e = i + 1 == t.n ? buf_n : t.start[i + 1];  // (start[n] stops before blank lines at the end of the shard)
     if (e > s && buf[e - 1] == '\n') --e;

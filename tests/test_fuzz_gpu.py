@@ -134,20 +134,41 @@ def rand_opts(rng, op, fastq):
         if r < 0.5: o["BySeq"] = True
         elif r < 0.7: o["ByName"] = True
         if rng.random() < 0.3: o["IgnoreCase"] = True
+    elif op == "range":
+        o["Range"] = rng.choice(["1:3", "2:2", "-5:-1", "-1:-1", "4", "-20:-3", "3:1", "0:2", "7:1000", "-2"])
+    elif op == "head":
+        o["N"] = rng.choice([1, 2, 10, 1000])
+    elif op == "duplicate":
+        o["Times"] = rng.choice([0, 1, 2, 3, 7])
+    elif op == "rename":
+        if rng.random() < 0.4: o["ByName"] = True
+    elif op == "sort":
+        r = rng.random()
+        if r < 0.2: o["ByLength"] = True
+        elif r < 0.35: o["ByBases"] = True
+        elif r < 0.55: o.update(BySeq=True, SeqPrefixLength=rng.choice([0, 3, 10, 10000]))
+        elif r < 0.7: o["ByName"] = True
+        for k in ("Reverse", "IgnoreCase"):
+            if rng.random() < 0.4:
+                o[k] = True
+    elif op == "faidx":
+        if rng.random() < 0.3: o["FullHead"] = True
     return o
 
 
 OPS = {"seq": (oracle.seq, bsk.Seq), "grep": (oracle.grep, bsk.Grep), "locate": (oracle.locate, bsk.Locate),
        "subseq": (oracle.subseq, bsk.Subseq), "translate": (oracle.translate, bsk.Translate),
-       "rmdup": (oracle.rmdup, bsk.RmDup)}
+       "rmdup": (oracle.rmdup, bsk.RmDup), "fq2fa": (oracle.fq2fa, bsk.Fq2Fa), "range": (oracle.range_, bsk.Range),
+       "head": (oracle.head, bsk.Head), "duplicate": (oracle.duplicate, bsk.Duplicate), "rename": (oracle.rename, bsk.Rename),
+       "sort": (oracle.sort, bsk.Sort), "faidx": (oracle.faidx, bsk.Faidx)}
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24"))))
 def test_fuzz_every_command(seed, monkeypatch):
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
     rng = random.Random(5000 + seed)
     agree = errors = 0
-    for it in range(60):
+    for it in range(90):
         op = rng.choice(list(OPS))
         fastq = rng.random() < 0.5
         data = rand_fastq(rng) if fastq else rand_fasta(rng)
@@ -172,8 +193,10 @@ def test_fuzz_every_command(seed, monkeypatch):
             assert gerr is not None, ("oracle failed, HIP path answered", werr, ctx)
             if werr is None:
                 assert "not supported" in gerr or "not accepted" in gerr or "libbsk" in gerr, (gerr, ctx)
+            elif op in ("range", "head", "duplicate", "faidx", "sort", "rename"):
+                assert werr in gerr, (werr, gerr, ctx)   # the reference's own message
             errors += 1
             continue
         assert got == want, ctx
         agree += 1
-    assert agree > 30
+    assert agree > 45
