@@ -142,6 +142,29 @@ __global__ void k_pair_partner_off(const uint8_t* __restrict__ state, const uint
     if (i < n && state[i] == 1) off2[partner[i]] = offw[i];
 }
 
+__global__ void k_mask_u32(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !b[i]) a[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_first_nonzero(const uint32_t* __restrict__ a, uint64_t n,
+                                                       unsigned long long* __restrict__ first) {
+    __shared__ unsigned long long s_min;
+    if (threadIdx.x == 0) s_min = ~0ull;
+    __syncthreads();
+    unsigned long long mine = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (a[i]) { mine = i; break; }  // indices grow along the loop: the first one found is this thread's smallest
+    if (mine != ~0ull) atomicMin(&s_min, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_min != ~0ull) atomicMin(first, s_min);
+}
+
+__global__ void k_keep_only(uint32_t* __restrict__ a, uint64_t n, const uint64_t* __restrict__ first) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && i != *first) a[i] = 0;
+}
+
 }  // namespace
 
 #define BSK_GRID(n) dim3((unsigned)(((n) + 255) / 256))
@@ -185,6 +208,23 @@ hipError_t launch_pair_partner_off(const uint8_t* state, const uint32_t* partner
                                    uint64_t* off2, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_pair_partner_off, BSK_GRID(n), dim3(256), 0, st, state, partner, offw, n, off2);
+    return hipGetLastError();
+}
+hipError_t launch_mask_u32(uint32_t* a, const uint32_t* b, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mask_u32, BSK_GRID(n), dim3(256), 0, st, a, b, n);
+    return hipGetLastError();
+}
+hipError_t launch_first_nonzero(const uint32_t* a, uint64_t n, uint64_t* first, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 4095) / 4096;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_first_nonzero, dim3((unsigned)blocks), dim3(256), 0, st, a, n, (unsigned long long*)first);
+    return hipGetLastError();
+}
+hipError_t launch_keep_only(uint32_t* a, uint64_t n, const uint64_t* first, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_keep_only, BSK_GRID(n), dim3(256), 0, st, a, n, first);
     return hipGetLastError();
 }
 #undef BSK_GRID

@@ -37,4 +37,10 @@ hipError_t launch_pair_partner_len(const uint8_t* state, const uint32_t* partner
 hipError_t launch_pair_partner_off(const uint8_t* state, const uint32_t* partner, const uint64_t* offw, uint64_t n,
                                    uint64_t* off2, hipStream_t st);
 
+// ---- grep --delete-matched: a[i] = b[i] ? a[i] : 0;  keep only the first non-zero entry of a
+hipError_t launch_mask_u32(uint32_t* a, const uint32_t* b, uint64_t n, hipStream_t st);
+// *first = min index with a[i] != 0 (set to ~0 by the caller), then every other entry is zeroed
+hipError_t launch_first_nonzero(const uint32_t* a, uint64_t n, uint64_t* first, hipStream_t st);
+hipError_t launch_keep_only(uint32_t* a, uint64_t n, const uint64_t* first, hipStream_t st);
+
 }  // namespace bsk

@@ -562,7 +562,6 @@ void validate_grep_opts(bsk_ctx* c) {
         o.mut("BySeq").b = true;
         parse_region_opt(o.s("Region"), "grep", &c->region_start, &c->region_end);
     }
-    if (o.b("DeleteMatched")) throw OptError("libbsk: --delete-matched is not supported by the HIP path yet");
     c->patterns.clear();
     c->regexes.clear();
     c->pattern_cls.clear();
@@ -600,6 +599,14 @@ void validate_grep_opts(bsk_ctx* c) {
         if (!seen.insert(p).second) continue;
         if (c->general) c->pattern_cls.push_back(class_sets(p, false, false, o.b("IgnoreCase")));
         c->patterns.push_back(p);
+    }
+    if (o.b("DeleteMatched") && !o.b("InvertMatch")) {  // PARITY.md DEL
+        if (o.b("BySeq") && c->max_mm > 0)
+            throw OptError("libbsk: --delete-matched with -m: the reference returns its internal key/partition strings there; not provided");
+        const size_t np = o.b("UseRegexp") ? c->regexes.size() : c->patterns.size();
+        if ((o.b("BySeq") || o.b("UseRegexp")) && np > 1)
+            throw OptError("libbsk: --delete-matched with several sequence / regexp patterns follows Go's map iteration order in "
+                           "the reference; provided for one pattern, or for ID / name patterns");
     }
 }
 
@@ -770,7 +777,60 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             }
         }
         HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st));
+        if (o.b("DeleteMatched") && !G.invert) {
+            // grep.go:463-511 + bigseqkit/grep.go:144-156: a pattern is dropped at its first hit and the driver keeps
+            // the lowest partition per pattern, so every pattern selects its FIRST record in file order (PARITY.md DEL)
+            const uint64_t N = c->table.n;
+            const bool exact_key = !G.by_seq && !o.b("UseRegexp");
+            if (exact_key) {
+                // all records with the ID / name of a hit are hits: "first per pattern" = hit AND first of its key group
+                RmDupParams R;
+                memset(&R, 0, sizeof R);
+                R.fastq = fastq;
+                R.by_name = G.by_name;
+                R.ignore_case = G.ignore_case;
+                R.id_mode = G.id_mode;
+                R.line_width = G.line_width;
+                R.buf_end = d_buf + n;
+                rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+                if (rc != BSK_OK) return rc;
+                uint64_t cap = 1024;
+                while (cap < 2 * N) cap <<= 1;
+                if (2 * cap > c->table_cap || !c->d_table) {
+                    if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+                    c->d_table = nullptr;
+                    HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+                    c->table_cap = 2 * cap;
+                }
+                uint64_t* tk = c->d_table;
+                uint64_t* tf = c->d_table + cap;
+                HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+                HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+                Arena A;
+                const uint64_t o_first = A.take(N * 4);
+                rc = arena_reserve(c, &A);
+                if (rc != BSK_OK) return rc;
+                uint32_t* d_firsts = A.at<uint32_t>(o_first);
+                HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, R, c->d_keys, nullptr, st));
+                HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
+                HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, R, c->d_keys, tk, tf, cap, d_firsts, c->d_status, st));
+                HIP_TRYX(c, launch_mask_u32(c->d_out_len, d_firsts, N, st));
+            } else {
+                // one pattern (checked at create time): only its first hit survives
+                HIP_TRYX(c, hipMemsetAsync(c->d_counter + 3, 0xFF, 8, st));
+                HIP_TRYX(c, launch_first_nonzero(c->d_out_len, N, c->d_counter + 3, st));
+                HIP_TRYX(c, launch_keep_only(c->d_out_len, N, c->d_counter + 3, st));
+            }
+        }
         rc = finish_sizes(c, st, &total, &kept);
+        if (rc == BSK_OK && o.b("DeleteMatched") && !G.invert) {
+            uint64_t status = 0;
+            HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+            if (status & ERR_HASH_COLLISION) {
+                c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+                return BSK_ERR_UNSUPPORTED;
+            }
+        }
         if (rc != BSK_OK) return rc;
     } else {
         rc = empty_result(c, out);

@@ -708,7 +708,7 @@ std::vector<std::string> read_pattern_lines(const std::string& path) {  // bread
 }
 
 // ---------------------------------------------------------------------------
-// Grep  bigseqkit-lib/grep.go (no -r, no --delete-matched)
+// Grep  bigseqkit-lib/grep.go (--delete-matched: grep.go:463-511 + the driver's reduce, bigseqkit/grep.go:144-156)
 // ---------------------------------------------------------------------------
 std::vector<std::string> grep_call(const std::vector<std::string_view>& part, const GrepOptions& oin) {
     GrepOptions o = oin;
@@ -731,7 +731,10 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
         o.BySeq = true;
         parse_region(o.Region, "grep", &start, &end);
     }
-    if (o.DeleteMatched) throw Error("oracle: delete-matched grep is not restated");
+    // --delete-matched (with -v it does nothing, grep.go:463): a pattern is dropped at its first hit, so every pattern
+    // selects at most its FIRST record in file order (the driver's ReduceByKey keeps the lowest partition, PARITY.md DEL)
+    const bool del = o.DeleteMatched && !o.InvertMatch;
+    if (del && o.BySeq && o.MaxMismatch > 0) throw Error("delete-matched with mismatches: the reference returns its internal key\\0pid\\0 strings");
     std::vector<std::string> patterns;  // PARITY.md Q11: CLI / file order instead of Go map order
     std::vector<MiniRe> regexps;        // -d
     // -r: Go regexp (RE2) is not in this image; std::regex (ECMAScript grammar) stands in for it -- the two agree on
@@ -766,6 +769,12 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
         if (o.IgnoreCase) p = lower(p);
         if (std::find(patterns.begin(), patterns.end(), p) == patterns.end()) patterns.push_back(p);
     }
+    auto drop = [&](size_t idx) {
+        if (!del) return;
+        patterns.erase(patterns.begin() + (long)idx);
+        if (!regexps.empty()) regexps.erase(regexps.begin() + (long)idx);
+        if (!stdres.empty()) stdres.erase(stdres.begin() + (long)idx);
+    };
     SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
     std::vector<std::string> result;
     bool checkAlphabet = true, onlyPos = o.OnlyPositiveStrand;
@@ -791,32 +800,36 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
                 } else if (o.Circular) target = sq + sq;
                 else target = sq;
                 if (o.UseRegexp) {
-                    for (auto& re : stdres)
-                        if (std::regex_search(target, re)) { hit = true; break; }
+                    for (size_t q = 0; q < stdres.size(); ++q)
+                        if (std::regex_search(target, stdres[q])) { hit = true; drop(q); break; }
                     continue;
                 }
                 if (o.Degenerate) {  // grep.go:459-468: re.Match on the un-lowered target
-                    for (auto& re : regexps)
-                        if (re.find(target, 0) >= 0) { hit = true; break; }
+                    for (size_t q = 0; q < regexps.size(); ++q)
+                        if (regexps[q].find(target, 0) >= 0) { hit = true; drop(q); break; }
                     continue;
                 }
                 if (o.IgnoreCase) target = lower(target);
-                for (auto& k : patterns) {
+                for (size_t q = 0; q < patterns.size(); ++q) {
+                    const std::string& k = patterns[q];
                     if (o.MaxMismatch == 0 ? target.find(k) != std::string::npos
                                            : !fmi_locate(target, k, o.MaxMismatch).empty()) {  // grep.go:327-339, 484-497
                         hit = true;
+                        drop(q);
                         break;
                     }
                 }
             } else {
                 target = o.ByName ? r.name : r.id;
                 if (o.UseRegexp) {  // grep.go:459-468: the regexp sees the un-lowered ID / name
-                    for (auto& re : stdres)
-                        if (std::regex_search(target, re)) { hit = true; break; }
+                    for (size_t q = 0; q < stdres.size(); ++q)
+                        if (std::regex_search(target, stdres[q])) { hit = true; drop(q); break; }
                     continue;
                 }
                 if (o.IgnoreCase) target = lower(target);
-                hit = std::find(patterns.begin(), patterns.end(), target) != patterns.end();
+                auto it = std::find(patterns.begin(), patterns.end(), target);
+                hit = it != patterns.end();
+                if (hit) drop((size_t)(it - patterns.begin()));
             }
         }
         if (o.InvertMatch ? hit : !hit) continue;

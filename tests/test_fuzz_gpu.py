@@ -108,6 +108,8 @@ def rand_opts(rng, op, fastq):
             o["Circular"] = True
         if (o.get("BySeq") or o.get("Degenerate")) and rng.random() < 0.25:
             o["Region"] = rng.choice(["1:20", "-30:-1", "5:-5", "100:200"])
+        if rng.random() < 0.2 and not o.get("MaxMismatch") and (len(o["Pattern"]) == 1 or not (o.get("BySeq") or o.get("UseRegexp") or o.get("Degenerate"))):
+            o["DeleteMatched"] = True
     elif op == "locate":
         mode = rng.choice(["exact", "exact", "deg", "mm", "fmi"])
         o["Pattern"] = [rand_seq(rng, rng.randint(1, 6), "ACGT") for _ in range(rng.randint(1, 3))]

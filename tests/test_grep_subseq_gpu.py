@@ -472,3 +472,34 @@ def test_grep_regexp_errors_and_pattern_file(tmp_path):
     f.write_text("^r1\\d$\n^r2\\d\\d$\n")
     rng = random.Random(8)
     assert check_grep(planted_fastq(rng, 400, L=20), True, {"PatternFile": str(f), "UseRegexp": True}) == 110
+
+
+# ---------------------------------------------------------------- --delete-matched (PARITY.md DEL)
+def test_grep_delete_matched_keeps_the_first_record_of_every_pattern(tmp_path, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    fa = b">a 1\nACGT\n>b\nGG\n>a 2\nTT\n>c\nACGA\n>b x\nAA\n>A 3\nCC\n"
+    def both(data, fastq, o):
+        check_grep(data, fastq, o)   # bytes and count against the oracle
+        return bsk.Grep(frame(data, fastq), _Opts(o))
+    assert both(fa, False, {"Pattern": ["a", "b"], "DeleteMatched": True}) == b">a 1\nACGT\n>b\nGG\n"
+    assert both(fa, False, {"Pattern": ["a"], "DeleteMatched": True, "IgnoreCase": True}) == b">a 1\nACGT\n"
+    assert both(fa, False, {"Pattern": ["a 2", "A 3", "zz"], "ByName": True, "DeleteMatched": True}) == b">a 2\nTT\n>A 3\nCC\n"
+    assert both(fa, False, {"Pattern": ["ACG"], "BySeq": True, "DeleteMatched": True}) == b">a 1\nACGT\n"
+    assert both(fa, False, {"Pattern": ["^[ab]$"], "UseRegexp": True, "DeleteMatched": True}) == b">a 1\nACGT\n"
+    assert both(fa, False, {"Pattern": ["ACN"], "Degenerate": True, "DeleteMatched": True}) == b">a 1\nACGT\n"
+    # with -v it changes nothing (grep.go:463)
+    assert both(fa, False, {"Pattern": ["a"], "DeleteMatched": True, "InvertMatch": True}) == b">b\nGG\n>c\nACGA\n>b x\nAA\n>A 3\nCC\n"
+    # a large ID list against reads with repeated IDs
+    rng = random.Random(6)
+    ids = [f"r{rng.randrange(300)}" for _ in range(2000)]
+    fq = "".join(f"@{i} n{k}\nACGT\n+\nIIII\n" for k, i in enumerate(ids)).encode()
+    pf = tmp_path / "ids.txt"
+    pf.write_text("".join(f"r{k}\n" for k in range(0, 300, 2)))
+    got = both(fq, True, {"PatternFile": str(pf), "DeleteMatched": True})
+    assert got.count(b"@") == len({i for i in ids if int(i[1:]) % 2 == 0})
+    assert bsk.GrepCount(frame(fq, True), _Opts({"PatternFile": str(pf), "DeleteMatched": True})) == got.count(b"@")
+    for o, msg in (({"Pattern": ["AC", "GG"], "BySeq": True, "DeleteMatched": True}, "several sequence"),
+                   ({"Pattern": ["ACGT"], "MaxMismatch": 1, "DeleteMatched": True}, "with -m")):
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Grep(frame(fa, False), _Opts(o))
+        assert msg in str(e.value)
