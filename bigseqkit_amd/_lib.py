@@ -102,6 +102,7 @@ SIGNATURES = {
     "bsk_range_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, C.c_uint64, _vp, _p(Out)]),
     "bsk_range_needs_count": (_i, [_vp, _p(C.c_int)]),
     "bsk_range_set_count": (_i, [_vp, C.c_uint64]),
+    "bsk_range_bounds": (_i, [_vp, _p(_i64), _p(_i64)]),
     "bsk_device_alloc": (_vp, [_sz]),
     "bsk_device_free": (None, [_vp]),
     "bsk_device_copy": (_i, [_vp, _vp, _sz, _i]),

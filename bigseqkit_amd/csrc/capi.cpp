@@ -766,6 +766,13 @@ int bsk_range_set_count(bsk_ctx* c, uint64_t n_records) {
     return range_resolve(c, (int64_t)n_records);
 }
 
+int bsk_range_bounds(const bsk_ctx* c, int64_t* start, int64_t* end) {
+    if (!c || !start || !end || (c->op != Op::Range && c->op != Op::Head) || !c->range_resolved) return BSK_ERR_INVALID_ARG;
+    *start = c->range_start;
+    *end = c->range_end;
+    return BSK_OK;
+}
+
 int bsk_range_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t first_record,
                   void* stream, bsk_out* out) {
     (void)pid;

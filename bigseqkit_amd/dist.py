@@ -4,6 +4,9 @@ ROCm; "gloo" in the CPU tests).  The path shards by records -- the reference's o
 collectives are the two small reductions the reference performs with IgnisHPC Reduce:
     StatsReduce      (bigseqkit/stats.go:91)   -> all_reduce(sum) of the dense stats vector
     GrepReduceCount  (bigseqkit/grep.go:175)   -> all_reduce(sum) of one int64
+plus the exchange of rmdup (GroupByKey) and the two prefix sums that MapWithIndex / FaidxOffset imply:
+    Range / Head     (bigseqkit/range.go:69-103) -> all_gather of the record counts
+    Faidx            (bigseqkit/faidx.go:69-80)  -> all_gather of the shard sizes
 """
 import ctypes as C
 
@@ -122,6 +125,64 @@ def rmdup_distributed(shard, fmt, backend, group=None):
     reply = torch.empty(n, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(reply, keep, in_splits, out_splits, group=group)
     return backend.emit(send, reply, base)
+
+
+def _all_gather_int(value, device, group=None):
+    """[value of rank 0, ..., value of rank world-1] (a list of one element without a process group)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return [int(value)], 0
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, torch.tensor([int(value)], dtype=torch.int64, device=device), group=group)
+    return [int(p.item()) for p in parts], rank
+
+
+class HipRangeBackend:
+    """Range / Head for one rank's HBM-resident shard: count (record table), then the run with the global index base."""
+
+    def __init__(self, op_name, opts_json, device=0):
+        from .api import Operator
+        self.op = Operator(op_name, opts_json, device)
+
+    def close(self):
+        self.op.close()
+
+    def count(self, shard, fmt):
+        n = C.c_uint64()
+        self._shard, self._fmt = shard, fmt
+        check(lib.bsk_index_build(self.op.ctx, C.c_void_p(shard.data_ptr()), shard.numel(), 1, fmt, None, C.byref(n)), self.op.ctx)
+        return n.value
+
+    def run(self, first_record, total):
+        from . import _lib
+        needs = C.c_int()
+        check(lib.bsk_range_needs_count(self.op.ctx, C.byref(needs)), self.op.ctx)
+        if needs.value:
+            check(lib.bsk_range_set_count(self.op.ctx, total), self.op.ctx)
+        out = _lib.Out()
+        s = self._shard
+        check(lib.bsk_range_run(self.op.ctx, C.c_void_p(s.data_ptr()), s.numel(), 1, self._fmt, 0, first_record, None,
+                                C.byref(out)), self.op.ctx)
+        buf = C.create_string_buffer(max(1, out.len))
+        check(lib.bsk_out_to_host(self.op.ctx, C.byref(out), buf, out.len), self.op.ctx)
+        return buf.raw[:out.len]
+
+
+def range_distributed(shard, fmt, backend, group=None):
+    """Range / Head over the shards of all ranks: the record index of MapWithIndex is global, so every rank learns the
+    number of records before its shard (and the total, for negative positions) from ONE all_gather of the counts.
+    Returns this rank's selected records; the concatenation over ranks equals the single-GPU output."""
+    counts, rank = _all_gather_int(backend.count(shard, fmt), shard.device, group)
+    return backend.run(sum(counts[:rank]), sum(counts))
+
+
+def faidx_distributed(shard, fmt, run, group=None):
+    """faidx index rows over the shards of all ranks: the FaidxOffset pass (bigseqkit/faidx.go:69-80) is ONE all_gather
+    of the shard sizes; `run(base_offset)` produces this rank's rows (HIP: bsk_faidx_run)."""
+    sizes, rank = _all_gather_int(shard.numel(), shard.device, group)
+    return run(sum(sizes[:rank]))
 
 
 def store_fastx(path, payload, group=None):

@@ -236,6 +236,8 @@ int bsk_fq2fa_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int 
  * (range.go:69-80): bsk_range_needs_count says so, bsk_range_set_count supplies it before the first run. */
 int bsk_range_needs_count(const bsk_ctx* ctx, int* needs);
 int bsk_range_set_count(bsk_ctx* ctx, uint64_t n_records);
+/* the resolved 0-based half-open record range [start, end) (after bsk_range_set_count when that was needed) */
+int bsk_range_bounds(const bsk_ctx* ctx, int64_t* start, int64_t* end);
 int bsk_range_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t first_record,
                   void* stream, bsk_out* out);
 

@@ -161,3 +161,93 @@ def test_two_ranks_gloo_rmdup_exchange(opts, tmp_path):
     assert outs[0] + outs[1] == want
     assert 0 < len(want) < len(data)
     assert open(merged, "rb").read() == want
+
+
+# ---------------------------------------------------------------- range / head / faidx: one all_gather each
+class _CpuRangeBackend:
+    """TEST stand-in for HipRangeBackend: libbsk's host-side range arithmetic (bsk_create on device -1,
+    bsk_range_set_count, bsk_range_bounds) + a record split by the oracle's rule."""
+
+    def __init__(self, op_name, opts_json):
+        self.op = bsk.Operator(op_name, opts_json, -1)
+
+    def count(self, shard, fmt):
+        data = bytes(shard.numpy().tobytes())
+        b = bdist.shard_bounds(data, 1, fmt)  # (exercises the anchor search; one shard)
+        assert b == [(0, len(data))]
+        # records of this shard: cut at every record start the library finds
+        self.records, pos = [], 0
+        import ctypes as C
+        arr = (C.c_char * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+        while pos < len(data):
+            out = C.c_size_t()
+            bsk.lib.bsk_find_record_start(C.cast(arr, C.c_void_p), len(data), pos + 1, fmt, C.byref(out))
+            nxt = min(out.value, len(data)) if out.value > pos else len(data)
+            self.records.append(data[pos:nxt])
+            pos = nxt
+        return len(self.records)
+
+    def run(self, first_record, total):
+        import ctypes as C
+        needs = C.c_int()
+        assert bsk.lib.bsk_range_needs_count(self.op.ctx, C.byref(needs)) == 0
+        if needs.value:
+            assert bsk.lib.bsk_range_set_count(self.op.ctx, total) == 0
+        lo, hi = C.c_int64(), C.c_int64()
+        assert bsk.lib.bsk_range_bounds(self.op.ctx, C.byref(lo), C.byref(hi)) == 0
+        keep = [r for k, r in enumerate(self.records) if lo.value <= first_record + k < hi.value]
+        return b"".join(r if r.endswith(b"\n") else r + b"\n" for r in keep)
+
+
+def _range_worker(rank, world, port, data, fmt, op_name, opts, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = bdist.shard_bounds(data, world, fmt)[rank]
+        shard = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.empty(0, dtype=torch.uint8)
+        got = bdist.range_distributed(shard, fmt, _CpuRangeBackend(op_name, json.dumps(opts)))
+        # faidx: rows of this shard from the oracle, shifted by the base offset the collective delivers
+        def rows(base):
+            out = []
+            for line in oracle.faidx(data[lo:hi], fmt == bsk.FORMAT_FASTQ).decode().splitlines():
+                f = line.split("\t")
+                f[2] = str(int(f[2]) + base)
+                if len(f) > 5:
+                    f[5] = str(int(f[5]) + base)
+                out.append("\t".join(f))
+            return ("\n".join(out) + "\n").encode() if out else b""
+        fai = bdist.faidx_distributed(shard, fmt, rows)
+        q.put((rank, got, fai))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fastq", [True, False])
+@pytest.mark.parametrize("op_name,opts", [("Range", {"Range": "120:480"}), ("Range", {"Range": "-90:-1"}), ("Head", {"N": 333}),
+                                          ("Range", {"Range": "2:5"})])
+def test_two_ranks_gloo_range_head_and_faidx(fastq, op_name, opts):
+    """the record index is global (all_gather of the counts), the .fai offsets are file offsets (all_gather of the
+    shard sizes): the concatenated per-rank results equal the single-shard oracle result"""
+    import torch.multiprocessing as mp
+    rng = random.Random(5)
+    data = seqgen.random_fastq(rng, 600, 1, 80) if fastq else seqgen.random_fasta(rng, 600, 1, 200, width=60)
+    fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_range_worker, args=(r, 2, port, data, fmt, op_name, opts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, got, fai = q.get(timeout=120)
+        res[rank] = (got, fai)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = oracle.head(data, fastq, json.dumps(opts)) if op_name == "Head" else oracle.range_(data, fastq, json.dumps(opts))
+    assert res[0][0] + res[1][0] == want and len(want) > 0
+    assert res[0][1] + res[1][1] == oracle.faidx(data, fastq)

@@ -108,3 +108,21 @@ def test_records_option_errors_and_empty_input():
     assert "invalid sequence type" in str(ei.value)
     for fn, o in ((bsk.Fq2Fa, {}), (bsk.Duplicate, {"Times": 2}), (bsk.Range, {"Range": "1:5"}), (bsk.Head, {})):
         assert fn(frame(b"", True), _Opts(o)) == b""
+
+
+def test_range_backend_of_the_multi_gpu_path_with_virtual_ranks():
+    """dist.HipRangeBackend is what every rank runs between the all_gather of the counts and the store: emulate three
+    ranks on one GPU (the collective itself is covered by the world_size-2 gloo test)"""
+    from bigseqkit_amd import dist as bdist
+    rng = random.Random(2)
+    data = seqgen.random_fastq(rng, 700, 0, 90)
+    bounds = bdist.shard_bounds(data, 3, bsk.FORMAT_FASTQ)
+    for op_name, o in (("Range", {"Range": "-250:-20"}), ("Head", {"N": 400}), ("Range", {"Range": "30:31"})):
+        backs = [bdist.HipRangeBackend(op_name, json.dumps(o), 0) for _ in bounds]
+        shards = [dev(data[lo:hi]) for lo, hi in bounds]
+        counts = [b.count(s, bsk.FORMAT_FASTQ) for b, s in zip(backs, shards)]
+        got = b"".join(b.run(sum(counts[:r]), sum(counts)) for r, b in enumerate(backs))
+        want = oracle.head(data, True, json.dumps(o)) if op_name == "Head" else oracle.range_(data, True, json.dumps(o))
+        assert got == want and len(want) > 0
+        for b in backs:
+            b.close()
