@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions, SeqKitCommonOptions
 
 
 class SeqFrame:
@@ -285,6 +285,34 @@ def Pair(inputA, inputB, o=None, device=0):
             check(lib.bsk_out_to_host(op.ctx, C.byref(outs[k]), buf, outs[k].len), op.ctx)
             res.append(buf.raw[:outs[k].len])
     return tuple(res)
+
+
+def _join_files(tensors):
+    """device tensors back to back, a newline added to a file that lacks the final one -> (tensor, [end offsets])"""
+    import torch
+    parts, ends, at = [], [], 0
+    for t in tensors:
+        parts.append(t)
+        at += t.numel()
+        if t.numel() and int(t[-1]) != 10:
+            parts.append(torch.tensor([10], dtype=torch.uint8, device=t.device))
+            at += 1
+        ends.append(at)
+    return (torch.cat(parts) if len(parts) > 1 else parts[0]), ends
+
+
+def Common(inputA, inputB, o=None, *inputN, device=0):
+    """bigseqkit/common.go:68-109 -> the records of inputA common to all inputs (one device-resident shard each)"""
+    frames = [inputA, inputB, *inputN]
+    both, ends = _join_files([f.shards[0] for f in frames])
+    arr = (C.c_uint64 * len(ends))(*ends)
+    out = _lib.Out()
+    with Operator("Common", (o or SeqKitCommonOptions()).to_json(), device) as op:
+        check(lib.bsk_common_run(op.ctx, C.c_void_p(both.data_ptr()) if both.numel() else None, both.numel(), arr, len(ends), 1,
+                                 inputA.format, None, C.byref(out)), op.ctx)
+        buf = C.create_string_buffer(max(1, out.len))
+        check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+        return buf.raw[:out.len]
 
 
 def Count(input, device=0):

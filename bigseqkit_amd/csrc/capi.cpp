@@ -181,6 +181,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
             case Op::Fq2Fa: case Op::Range: case Op::Head: case Op::Duplicate: case Op::Rename: case Op::Pair: validate_records_opts(c); break;
             case Op::Sort: validate_sort_opts(c); break;
             case Op::Faidx: validate_faidx_opts(c); break;
+            case Op::Common: validate_common_opts(c); break;
             default: break;  // validated by the op's own module once it is built
         }
     } catch (const std::exception& e) {
@@ -721,6 +722,21 @@ int bsk_faidx_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     if (!c) return BSK_ERR_INVALID_ARG;
     c->cur_base_offset = base_offset;
     return run_record_op(c, Op::Faidx, "Faidx", faidx_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file_ends, uint32_t n_files, int on_device,
+                   int format, void* stream, bsk_out* out) {
+    int rc = check_run_args(c, shard, n, format);
+    if (rc != BSK_OK) return rc;
+    if (c->op != Op::Common || !out || !file_ends || n_files < 2 || n_files > 64 || file_ends[n_files - 1] != n)
+        return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Common context / bad argument (2..64 files, file_ends[last] == n)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    const uint8_t* d = nullptr;
+    rc = stage_shard(c, shard, n, on_device, st, &d);
+    if (rc != BSK_OK) return rc;
+    return common_run_device(c, d, n, file_ends, n_files, format, st, out);
 }
 
 int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,

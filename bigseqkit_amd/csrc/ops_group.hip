@@ -142,6 +142,28 @@ __global__ void k_pair_partner_off(const uint8_t* __restrict__ state, const uint
     if (i < n && state[i] == 1) off2[partner[i]] = offw[i];
 }
 
+__device__ __forceinline__ uint32_t file_of(uint64_t pos, const uint64_t* __restrict__ ends, uint32_t k) {
+    uint32_t f = 0;
+    while (f + 1 < k && pos >= ends[f]) ++f;  // k <= 64 files, mostly 2
+    return f;
+}
+
+__global__ void k_common_masks(const uint64_t* __restrict__ group, const uint64_t* __restrict__ start, uint64_t n,
+                               const uint64_t* __restrict__ ends, uint32_t k, unsigned long long* __restrict__ masks) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicOr(&masks[group[i]], 1ull << file_of(start[i], ends, k));
+}
+
+__global__ void k_common_select(const uint64_t* __restrict__ group, const uint64_t* __restrict__ start, uint64_t n,
+                                const uint64_t* __restrict__ ends, uint32_t k, const uint64_t* __restrict__ masks,
+                                uint32_t* __restrict__ len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t full = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    if (!(group[i] == i && start[i] < ends[0] && masks[i] == full)) len[i] = 0;
+}
+
 __global__ void k_mask_u32(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !b[i]) a[i] = 0;
@@ -208,6 +230,18 @@ hipError_t launch_pair_partner_off(const uint8_t* state, const uint32_t* partner
                                    uint64_t* off2, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_pair_partner_off, BSK_GRID(n), dim3(256), 0, st, state, partner, offw, n, off2);
+    return hipGetLastError();
+}
+hipError_t launch_common_masks(const uint64_t* group, const uint64_t* start, uint64_t n, const uint64_t* file_ends, uint32_t k,
+                               uint64_t* masks, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_common_masks, BSK_GRID(n), dim3(256), 0, st, group, start, n, file_ends, k, (unsigned long long*)masks);
+    return hipGetLastError();
+}
+hipError_t launch_common_select(const uint64_t* group, const uint64_t* start, uint64_t n, const uint64_t* file_ends, uint32_t k,
+                                const uint64_t* masks, uint32_t* len, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_common_select, BSK_GRID(n), dim3(256), 0, st, group, start, n, file_ends, k, masks, len);
     return hipGetLastError();
 }
 hipError_t launch_mask_u32(uint32_t* a, const uint32_t* b, uint64_t n, hipStream_t st) {

@@ -37,6 +37,14 @@ hipError_t launch_pair_partner_len(const uint8_t* state, const uint32_t* partner
 hipError_t launch_pair_partner_off(const uint8_t* state, const uint32_t* partner, const uint64_t* offw, uint64_t n,
                                    uint64_t* off2, hipStream_t st);
 
+// ---- common: the shard is k files back to back, file_ends[f] = one past the last byte of file f (device array).
+// masks[g] |= 1 << file(i) for g = group[i] (masks zeroed by the caller, k <= 64)
+hipError_t launch_common_masks(const uint64_t* group, const uint64_t* start, uint64_t n, const uint64_t* file_ends, uint32_t k,
+                               uint64_t* masks, hipStream_t st);
+// len[i] = fmt_len[i] when i is the first record of its group, lies in file 0 and the group has members in all k files
+hipError_t launch_common_select(const uint64_t* group, const uint64_t* start, uint64_t n, const uint64_t* file_ends, uint32_t k,
+                                const uint64_t* masks, uint32_t* len, hipStream_t st);
+
 // ---- grep --delete-matched: a[i] = b[i] ? a[i] : 0;  keep only the first non-zero entry of a
 hipError_t launch_mask_u32(uint32_t* a, const uint32_t* b, uint64_t n, hipStream_t st);
 // *first = min index with a[i] != 0 (set to ~0 by the caller), then every other entry is zeroed

@@ -2504,4 +2504,104 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     return BSK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// common: the records of the first file whose key occurs in every file.  The reference's
+// CommonPrepare / CommonJoin (bigseqkit-lib/common.go:31-212) cannot run as written; PARITY.md COMMON states what is
+// kept (keys, options, error texts) and what follows seqkit's documented behaviour instead.
+// ---------------------------------------------------------------------------
+void validate_common_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(o);
+    if (o.b("BySeq") && o.b("ByName"))  // common.go:37-39
+        throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
+    if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :43-45
+        throw OptError("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
+    if (o.b("OnlyPositiveStrand"))
+        throw OptError("libbsk: common -s -P: the reference hashes nothing on that branch (every record gets key 0); not provided");
+}
+
+int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t* file_ends, uint32_t nfiles, int format,
+                      hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    const uint64_t N = c->table.n;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.by_seq = o.b("BySeq");
+    P.by_name = o.b("ByName");
+    P.ignore_case = o.b("IgnoreCase");
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = d_buf + n;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    if (2 * cap > c->table_cap || !c->d_table) {
+        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+        c->d_table = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+        c->table_cap = 2 * cap;
+    }
+    uint64_t* tk = c->d_table;
+    uint64_t* tf = c->d_table + cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    Arena A;
+    const uint64_t o_has = A.take(N), o_masks = A.take(N * 8), o_ends = A.take((uint64_t)nfiles * 8);
+    rc = arena_reserve(c, &A);
+    if (rc != BSK_OK) return rc;
+    uint8_t* d_has = A.at<uint8_t>(o_has);
+    uint64_t* d_masks = A.at<uint64_t>(o_masks);
+    uint64_t* d_ends = A.at<uint64_t>(o_ends);
+    HIP_TRYX(c, hipMemcpyAsync(d_ends, file_ends, (size_t)nfiles * 8, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
+    HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 8, st));
+    HIP_TRYX(c, launch_common_masks(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, st));
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // (file_ends is the caller's memory)
+    if (status & ERR_HASH_COLLISION) {
+        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    SeqParams F = format_params(c, fastq);
+    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
+    F.buf_end = d_buf + n;
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, F, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_common_select(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, c->d_out_len, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return rc;
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    if (total == 0) return BSK_OK;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    apply_long(c, &F);
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
 }  // namespace bsk

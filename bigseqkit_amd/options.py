@@ -30,6 +30,7 @@ _FIELDS = {
     "Duplicate": ["Times"],   # bigseqkit/duplicate.go:9-12
     "Rename": ["ByName"],     # bigseqkit/rename.go:12-15
     "Pair": ["SaveUnpaired"], # bigseqkit/pair.go:12-15
+    "Common": ["ByName", "BySeq", "IgnoreCase", "OnlyPositiveStrand"],   # bigseqkit/common.go:13-19
     "Faidx": ["UseRegexp", "IgnoreCase", "FullHead", "RegionFile", "Regions"],   # bigseqkit/faidx.go:11-18
     "Sort": ["InNaturalOrder", "BySeq", "ByName", "ByLength", "ByBases", "GapLetters", "Reverse", "IgnoreCase",
              "SeqPrefixLength"],   # bigseqkit/sort.go:13-24
@@ -109,3 +110,4 @@ SeqKitRenameOptions = _make("Rename")
 SeqKitSortOptions = _make("Sort")
 SeqKitFaidxOptions = _make("Faidx")
 SeqKitPairOptions = _make("Pair")
+SeqKitCommonOptions = _make("Common")

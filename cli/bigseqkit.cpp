@@ -109,6 +109,9 @@ const Command kCommands[] = {
     {"range", "Range", {{"range", 'r', STR, "Range", ""}}},                            // cli/range.go:48
     {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
     {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
+    {"common", "Common",                                                               // cli/common.go:52-56
+     {{"by-name", 'n', BOOL, "ByName", "false"}, {"by-seq", 's', BOOL, "BySeq", "false"},
+      {"ignore-case", 'i', BOOL, "IgnoreCase", "false"}, {"only-positive-strand", 'P', BOOL, "OnlyPositiveStrand", "false"}}},
     {"pair", "Pair",                                                                   // cli/pair.go (flags of its init())
      {{"read1", '1', STR, "", ""}, {"read2", '2', STR, "", ""}, {"out-dir", 'O', STR, "", ""}, {"force", 'f', BOOL, "", "false"},
       {"save-unpaired", 'u', BOOL, "SaveUnpaired", "false"}}},
@@ -664,6 +667,31 @@ int main(int argc, char** argv) {
     }
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
     std::vector<Part> inputs = read_parts(inv.files);
+    if (std::string(inv.cmd->use) == "common") {
+        // cli/common.go: at least two files; the records of the first one that are common to all
+        if (inputs.size() < 2) die("at least 2 files needed");
+        std::string all;
+        std::vector<uint64_t> ends;
+        for (auto& p : inputs) {
+            if (p.fmt != inputs[0].fmt) die("common: inputs of different formats");
+            all += p.host;
+            if (!p.host.empty() && p.host.back() != '\n') all += '\n';
+            ends.push_back(all.size());
+        }
+        bsk_ctx* c = nullptr;
+        const int device = (int)strtol(inv.pget("device").c_str(), nullptr, 10);
+        if (bsk_create("Common", inv.js.c_str(), device, &c) != BSK_OK) die(bsk_global_error());
+        bsk_out out;
+        if (bsk_common_run(c, all.data(), all.size(), ends.data(), (uint32_t)ends.size(), 0, inputs[0].fmt, nullptr, &out) != BSK_OK)
+            die(bsk_last_error(c));
+        Output o;
+        o.fmt = inputs[0].fmt;
+        o.text.resize(out.len);
+        if (out.len && bsk_out_to_host(c, &out, &o.text[0], out.len) != BSK_OK) die(bsk_last_error(c));
+        bsk_destroy(c);
+        store(inv, o, inv.files);
+        return 0;
+    }
     if (std::string(inv.cmd->use) == "pair") {
         // cli/pair.go:13-66: two files; <out-dir>/paired.1, paired.2 and, with -u, unpaired.1, unpaired.2
         if (inputs.size() < 2) die("2 files needed");

@@ -197,6 +197,13 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Common (bigseqkit/common.go:56-109; CommonPrepare + Union + GroupByKey + CommonJoin, bigseqkit-lib/common.go): the
+ * records of the FIRST file whose ID (full name with ByName, sequence with BySeq; IgnoreCase) occurs in every file --
+ * one record per key, file order.  `shard` holds the n_files files back to back (every file ends in a newline),
+ * file_ends[f] = offset one past file f (host array, file_ends[n_files - 1] == n). */
+int bsk_common_run(bsk_ctx* ctx, const void* shard, size_t n, const uint64_t* file_ends, uint32_t n_files, int on_device,
+                   int format, void* stream, bsk_out* out);
+
 /* ---- Pair (bigseqkit/pair.go:34-100; PairPrepare + Union + GroupByKey + Pair, bigseqkit-lib/pair.go:37-121): match up
  * the reads of two files by ID.  `shard` holds file 1 followed by file 2, n_first = bytes of file 1 (ending in a
  * newline).  outs[0], outs[1]: the paired records of file 1 / file 2, line for line in the same pair order (= PairIndex

@@ -363,6 +363,23 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+// common over nfiles files given back to back; ends[f] = offset one past file f
+int orc_common(const uint8_t* buf, const uint64_t* ends, int nfiles, int fastq, const orc_kitconfig* cfg, int by_name, int by_seq,
+               int ignore_case, int only_pos, uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        std::vector<std::vector<std::string_view>> files;
+        uint64_t lo = 0;
+        for (int f = 0; f < nfiles; ++f) {
+            files.push_back(split_records(std::string_view((const char*)buf + lo, ends[f] - lo), fastq != 0));
+            lo = ends[f];
+        }
+        CommonOptions o;
+        o.Config = conv(*cfg);
+        o.ByName = by_name != 0; o.BySeq = by_seq != 0; o.IgnoreCase = ignore_case != 0; o.OnlyPositiveStrand = only_pos != 0;
+        return emit(common_call(files, o), out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // which: 0 paired.1, 1 paired.2, 2 unpaired.1, 3 unpaired.2
 int orc_pair(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int fastq, const orc_kitconfig* cfg, int which,
              uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {

@@ -5,6 +5,7 @@
 #include <regex>
 
 #include <algorithm>
+#include <set>
 #include <cmath>
 #include <cctype>
 #include <cstdarg>
@@ -1978,6 +1979,41 @@ void pair_call(const std::vector<std::string_view>& a, const std::vector<std::st
     }
     for (size_t j = 0; j < rb.size(); ++j)
         if (!b_paired[j]) out[3].push_back(rb[j].text);
+}
+
+// ---------------------------------------------------------------------------
+// common  (bigseqkit/common.go:56-109, bigseqkit-lib/common.go:31-212; PARITY.md COMMON)
+// ---------------------------------------------------------------------------
+std::vector<std::string> common_call(const std::vector<std::vector<std::string_view>>& files, const CommonOptions& o) {
+    if (o.BySeq && o.ByName) throw Error("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");  // :37-39
+    if (o.OnlyPositiveStrand && !o.BySeq) throw Error("flag -s (--by-seq) needed when using -P (--only-positive-strand)");  // :43-45
+    if (o.OnlyPositiveStrand) throw Error("common -s -P: every record gets key 0 in the reference");
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    auto key_of = [&](const Record& r) {
+        std::string k = o.BySeq ? r.seq : (o.ByName ? r.name : r.id);  // :76-100 (the revcom of both sides == same strand)
+        return o.IgnoreCase ? lower(k) : k;
+    };
+    std::vector<std::set<std::string>> present(files.size());
+    for (size_t f = 1; f < files.size(); ++f) {
+        SeqParser rd(ab, &files[f], o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+        while (rd.Read()) present[f].insert(key_of(rd.rec));
+    }
+    std::vector<std::string> result;
+    std::set<std::string> done;
+    SeqParser rd(ab, &files[0], o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+    int lineWidth = o.Config.LineWidth;
+    while (rd.Read()) {
+        if (rd.IsFastq) lineWidth = 0;
+        const std::string k = key_of(rd.rec);
+        if (!done.insert(k).second) continue;
+        bool all = true;
+        for (size_t f = 1; f < files.size() && all; ++f) all = present[f].count(k) != 0;
+        if (!all) continue;
+        std::string bb = record_format(rd.rec, rd.IsFastq, lineWidth);
+        bb.pop_back();
+        result.push_back(bb);
+    }
+    return result;
 }
 
 }  // namespace orc

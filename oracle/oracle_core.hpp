@@ -232,6 +232,13 @@ std::vector<std::string> range_call(const std::vector<std::string_view>& part, i
 // Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
 std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
 
+struct CommonOptions {  // bigseqkit/common.go:13-29
+    KitConfig Config;
+    bool ByName = false, BySeq = false, IgnoreCase = false, OnlyPositiveStrand = false;
+};
+// Common(): the records of files[0] whose key occurs in every file, one per key, file order (PARITY.md COMMON)
+std::vector<std::string> common_call(const std::vector<std::vector<std::string_view>>& files, const CommonOptions& o);
+
 // Pair(): PairPrepare x2 + Union + GroupByKey + Pair.Call (bigseqkit/pair.go:34-100, bigseqkit-lib/pair.go:37-121).
 // out[0] / out[1]: first / second mates, pairs ordered by the file-1 position of the first mate; out[2] / out[3]: the
 // records without a mate, file order (PARITY.md PAIR: element order, no stray newline)

@@ -419,3 +419,23 @@ def pair(a, b, fastq, opts_json="{}"):
             raise OracleError(err.value.decode())
         res.append(out.raw[:n.value])
     return tuple(res)
+
+
+def common(files, fastq, opts_json="{}"):
+    """files: list of bytes (every one ending in a newline) -> records of files[0] common to all"""
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    cfg = _cfg(d)
+    data = b"".join(files)
+    ends, at = [], 0
+    for f in files:
+        at += len(f)
+        ends.append(at)
+    arr = (C.c_uint64 * len(ends))(*ends)
+    cap = 2 * len(data) + 4096
+    out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+    b = lambda k: int(bool(d.get(k)))
+    rc = _lib.orc_common(_buf(data), arr, len(files), int(fastq), C.byref(cfg), b("ByName"), b("BySeq"), b("IgnoreCase"),
+                         b("OnlyPositiveStrand"), out, C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+    if rc:
+        raise OracleError(err.value.decode())
+    return out.raw[:n.value]

@@ -135,3 +135,16 @@ def test_pair_kth_with_kth_and_the_rest_unpaired():
     assert u1 == b"@r1 1b\nTT\n+\nII\n@r5\nA\n+\nI\n" and u2 == b"@r9\nT\n+\nI\n"
     with bsk.Operator("Pair", "{}", -1) as op:
         assert json.loads(op.opts_json())["SaveUnpaired"] is False
+
+
+def test_common_first_file_records_present_in_every_file():
+    a = b">x 1\nACGT\n>y\nGG\n>x 2\nTT\n>z\nAC\n"
+    b = b">z q\nAA\n>x\nC\n"
+    c = b">X\nA\n>z\nT\n"
+    assert oracle.common([a, b], False) == b">x 1\nACGT\n>z\nAC\n"          # one record per key: the first x
+    assert oracle.common([a, b, c], False) == b">z\nAC\n"
+    assert oracle.common([a, b, c], False, '{"IgnoreCase": true}') == b">x 1\nACGT\n>z\nAC\n"
+    assert oracle.common([a, b"" + b], False, '{"BySeq": true}') == b""
+    assert oracle.common([a, b">q\nacgt\n"], False, '{"BySeq": true, "IgnoreCase": true}') == b">x 1\nACGT\n"
+    with pytest.raises(bsk.BskError):
+        bsk.Operator("Common", '{"BySeq": true, "ByName": true}', -1)
