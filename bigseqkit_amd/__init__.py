@@ -7,7 +7,7 @@ driver library used by tests and bench.py; it has no CPU fallback.
 from ._lib import BskError, FORMAT_FASTA, FORMAT_FASTQ, lib  # noqa: F401  (fails loudly if libbsk.so is missing)
 from .options import (SeqKitConfig, SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions,  # noqa: F401
                       SeqKitLocateOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions,
-                      SeqKitFq2FaOptions, SeqKitRangeOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions, SeqKitCommonOptions)
+                      SeqKitFq2FaOptions, SeqKitRangeOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions, SeqKitCommonOptions, SeqKitConcatOptions)
 from .api import (SeqFrame, ReadFASTA, ReadFASTAN, ReadFASTQ, ReadFASTQN, Operator, Stats, StatsString,  # noqa: F401
                   stats_map, Seq, build_index, Grep, GrepCount, Subseq, Translate, RmDup, Locate, Fq2Fa, Range, Head,
-                  Duplicate, Count, Rename, Sort, Faidx, Pair, Common)
+                  Duplicate, Count, Rename, Sort, Faidx, Pair, Common, Concat)

@@ -10,7 +10,7 @@ import os
 
 from . import _lib
 from ._lib import lib, check, BskError, FORMAT_FASTA, FORMAT_FASTQ
-from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions, SeqKitCommonOptions
+from .options import SeqKitStatsOptions, SeqKitSeqOptions, SeqKitGrepOptions, SeqKitSubseqOptions, SeqKitTranslateOptions, SeqKitRmDupOptions, SeqKitLocateOptions, SeqKitFq2FaOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions, SeqKitCommonOptions, SeqKitConcatOptions
 
 
 class SeqFrame:
@@ -309,6 +309,18 @@ def Common(inputA, inputB, o=None, *inputN, device=0):
     out = _lib.Out()
     with Operator("Common", (o or SeqKitCommonOptions()).to_json(), device) as op:
         check(lib.bsk_common_run(op.ctx, C.c_void_p(both.data_ptr()) if both.numel() else None, both.numel(), arr, len(ends), 1,
+                                 inputA.format, None, C.byref(out)), op.ctx)
+        buf = C.create_string_buffer(max(1, out.len))
+        check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+        return buf.raw[:out.len]
+
+
+def Concat(inputA, inputB, o=None, device=0):
+    """bigseqkit/concat.go:53-90 (one device-resident shard per input)"""
+    both, ends = _join_files([inputA.shards[0], inputB.shards[0]])
+    out = _lib.Out()
+    with Operator("Concat", (o or SeqKitConcatOptions()).to_json(), device) as op:
+        check(lib.bsk_concat_run(op.ctx, C.c_void_p(both.data_ptr()) if both.numel() else None, both.numel(), ends[0], 1,
                                  inputA.format, None, C.byref(out)), op.ctx)
         buf = C.create_string_buffer(max(1, out.len))
         check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)

@@ -178,7 +178,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
             case Op::Translate: validate_translate_opts(c); break;
             case Op::Locate: validate_locate_opts(c); break;
             case Op::RmDup: validate_rmdup_opts(c); break;
-            case Op::Fq2Fa: case Op::Range: case Op::Head: case Op::Duplicate: case Op::Rename: case Op::Pair: validate_records_opts(c); break;
+            case Op::Fq2Fa: case Op::Range: case Op::Head: case Op::Duplicate: case Op::Rename: case Op::Pair: case Op::Concat: validate_records_opts(c); break;
             case Op::Sort: validate_sort_opts(c); break;
             case Op::Faidx: validate_faidx_opts(c); break;
             case Op::Common: validate_common_opts(c); break;
@@ -722,6 +722,20 @@ int bsk_faidx_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     if (!c) return BSK_ERR_INVALID_ARG;
     c->cur_base_offset = base_offset;
     return run_record_op(c, Op::Faidx, "Faidx", faidx_run_device, shard, n, on_device, format, stream, out);
+}
+
+int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
+                   bsk_out* out) {
+    int rc = check_run_args(c, shard, n, format);
+    if (rc != BSK_OK) return rc;
+    if (c->op != Op::Concat || !out || n_first > n) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Concat context / bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    const uint8_t* d = nullptr;
+    rc = stage_shard(c, shard, n, on_device, st, &d);
+    if (rc != BSK_OK) return rc;
+    return concat_run_device(c, d, n, n_first, format, st, out);
 }
 
 int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file_ends, uint32_t n_files, int on_device,

@@ -17,6 +17,7 @@
 #include "../../include/bsk.h"
 #include "ctx.hpp"
 #include "ops_host.hpp"
+#include "ops_concat.hpp"
 #include "ops_faidx.hpp"
 #include "ops_grep.hpp"
 #include "ops_group.hpp"
@@ -1960,7 +1961,7 @@ static int64_t go_parse_int(const std::string& s) {
 void validate_records_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (c->op == Op::Fq2Fa || c->op == Op::Rename || c->op == Op::Pair) { check_id_regexp(o); return; }
+    if (c->op == Op::Fq2Fa || c->op == Op::Rename || c->op == Op::Pair || c->op == Op::Concat) { check_id_regexp(o); return; }
     if (c->op == Op::Duplicate) {
         // make([]string, times) panics for a negative count; zero copies is an empty result
         if (o.i("Times") < 0) throw OptError("value of -n (--times) should not be negative");
@@ -2601,6 +2602,106 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// concat: ConcatPrepare x2 + Union + GroupByKey + ConcatJoin (bigseqkit/concat.go:41-90,
+// bigseqkit-lib/concat.go:39-165).  PARITY.md CONCAT.
+// ---------------------------------------------------------------------------
+int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    const uint64_t N = c->table.n;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = d_buf + n;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    if (2 * cap > c->table_cap || !c->d_table) {
+        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+        c->d_table = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+        c->table_cap = 2 * cap;
+    }
+    uint64_t* tk = c->d_table;
+    uint64_t* tf = c->d_table + cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    size_t tmp_bytes = 0;
+    if (group_sort_temp_bytes(N, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
+    Arena A;
+    const uint64_t o_has = A.take(N), o_list = A.take(2 * N * 8), o_tmp = A.take(tmp_bytes ? tmp_bytes : 16),
+                   o_seg = A.take(3 * N * 4), o_cnt = A.take(N * 4), o_cntoff = A.take((N + 1) * 8);
+    rc = arena_reserve(c, &A);
+    if (rc != BSK_OK) return rc;
+    uint8_t* d_has = A.at<uint8_t>(o_has);
+    uint64_t* d_list = A.at<uint64_t>(o_list);
+    uint32_t* d_seg = A.at<uint32_t>(o_seg);
+    uint32_t* d_cnt = A.at<uint32_t>(o_cnt);
+    uint64_t* d_cntoff = A.at<uint64_t>(o_cntoff);
+    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
+    uint64_t first2 = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&first2, c->d_counter, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_HASH_COLLISION) {
+        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_group_all(c->d_keys, N, d_list, st));
+    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st));
+    HIP_TRYX(c, launch_concat_segments(d_list + N, N, (uint32_t)first2, d_seg, st));
+    ConcatParams Q;
+    memset(&Q, 0, sizeof Q);
+    Q.fastq = fastq;
+    Q.full = o.b("Full");
+    Q.id_mode = P.id_mode;
+    Q.line_width = P.line_width;
+    Q.first2 = (uint32_t)first2;
+    Q.buf_end = d_buf + n;
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_concat_size(d_buf, c->table, Q, d_list + N, d_seg, c->d_out_len, d_cnt, c->d_status, st));
+    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st));
+    HIP_TRYX(c, launch_scan_u32(d_cnt, d_cntoff, N, c->d_scan_tmp, st));
+    uint64_t total = 0, elements = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + N, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&elements, d_cntoff + N, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    rc = kernel_error_to_status(c, status);
+    if (rc != BSK_OK) return rc;
+    out->d_data = nullptr;
+    out->len = 0;
+    out->records = 0;
+    if (total == 0) return BSK_OK;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_concat_emit(d_buf, c->table, tt, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, c->d_out, st));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = elements;
     return BSK_OK;
 }
 

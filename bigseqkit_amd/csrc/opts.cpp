@@ -69,6 +69,7 @@ Options Options::defaults(Op op) {
         case Op::Duplicate: o.fields = {fi("Times", 1)}; break;     // bigseqkit/duplicate.go:14-19
         case Op::Rename: o.fields = {fb("ByName", false)}; break;   // bigseqkit/rename.go:17-22
         case Op::Pair: o.fields = {fb("SaveUnpaired", false)}; break;   // bigseqkit/pair.go:17-22
+        case Op::Concat: o.fields = {fb("Full", false), fs("Separator", "|")}; break;   // bigseqkit/concat.go:18-24
         case Op::Common:  // bigseqkit/common.go:21-29
             o.fields = {fb("ByName", false), fb("BySeq", false), fb("IgnoreCase", false), fb("OnlyPositiveStrand", false)};
             break;
@@ -222,7 +223,8 @@ bool op_from_name(const std::string& name, Op* out) {
         {"Fq2Fa", Op::Fq2Fa}, {"Range", Op::Range}, {"RangePrepare", Op::Range}, {"Head", Op::Head},
         {"Duplicate", Op::Duplicate}, {"Rename", Op::Rename}, {"RenamePrepare", Op::Rename},
         {"Sort", Op::Sort}, {"Faidx", Op::Faidx}, {"Pair", Op::Pair},
-        {"PairPrepare", Op::Pair}, {"Common", Op::Common}, {"CommonPrepare", Op::Common}};
+        {"PairPrepare", Op::Pair}, {"Common", Op::Common}, {"CommonPrepare", Op::Common},
+        {"Concat", Op::Concat}, {"ConcatPrepare", Op::Concat}};
     for (auto& t : tbl)
         if (name == t.n) { *out = t.op; return true; }
     return false;
@@ -246,6 +248,7 @@ const char* op_name(Op op) {
         case Op::Faidx: return "Faidx";
         case Op::Pair: return "Pair";
         case Op::Common: return "Common";
+        case Op::Concat: return "Concat";
     }
     return "";
 }

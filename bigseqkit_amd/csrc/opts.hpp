@@ -35,7 +35,7 @@ struct Field {
     std::vector<std::string> sl;
 };
 
-enum class Op { Stats, Seq, Grep, Locate, Subseq, Translate, RmDup, Fq2Fa, Range, Head, Duplicate, Rename, Sort, Faidx, Pair, Common };
+enum class Op { Stats, Seq, Grep, Locate, Subseq, Translate, RmDup, Fq2Fa, Range, Head, Duplicate, Rename, Sort, Faidx, Pair, Common, Concat };
 
 class Options {
    public:

@@ -30,6 +30,7 @@ _FIELDS = {
     "Duplicate": ["Times"],   # bigseqkit/duplicate.go:9-12
     "Rename": ["ByName"],     # bigseqkit/rename.go:12-15
     "Pair": ["SaveUnpaired"], # bigseqkit/pair.go:12-15
+    "Concat": ["Full", "Separator"],   # bigseqkit/concat.go:12-16
     "Common": ["ByName", "BySeq", "IgnoreCase", "OnlyPositiveStrand"],   # bigseqkit/common.go:13-19
     "Faidx": ["UseRegexp", "IgnoreCase", "FullHead", "RegionFile", "Regions"],   # bigseqkit/faidx.go:11-18
     "Sort": ["InNaturalOrder", "BySeq", "ByName", "ByLength", "ByBases", "GapLetters", "Reverse", "IgnoreCase",
@@ -111,3 +112,4 @@ SeqKitSortOptions = _make("Sort")
 SeqKitFaidxOptions = _make("Faidx")
 SeqKitPairOptions = _make("Pair")
 SeqKitCommonOptions = _make("Common")
+SeqKitConcatOptions = _make("Concat")

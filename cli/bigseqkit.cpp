@@ -109,6 +109,7 @@ const Command kCommands[] = {
     {"range", "Range", {{"range", 'r', STR, "Range", ""}}},                            // cli/range.go:48
     {"head", "Head", {{"number", 'n', INT, "N", "10"}}},                               // cli/head.go:40
     {"duplicate", "Duplicate", {{"times", 'n', INT, "Times", "1"}}},                   // cli/duplicate.go:28-40 (alias dup)
+    {"concat", "Concat", {{"full", 'f', BOOL, "Full", "false"}, {"separator", 's', STR, "Separator", "|"}}},   // cli/concat.go:51-52
     {"common", "Common",                                                               // cli/common.go:52-56
      {{"by-name", 'n', BOOL, "ByName", "false"}, {"by-seq", 's', BOOL, "BySeq", "false"},
       {"ignore-case", 'i', BOOL, "IgnoreCase", "false"}, {"only-positive-strand", 'P', BOOL, "OnlyPositiveStrand", "false"}}},
@@ -667,6 +668,26 @@ int main(int argc, char** argv) {
     }
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
     std::vector<Part> inputs = read_parts(inv.files);
+    if (std::string(inv.cmd->use) == "concat") {
+        if (inputs.size() != 2) die("2 files needed");
+        if (inputs[0].fmt != inputs[1].fmt) die("concat: inputs of different formats");
+        std::string both = inputs[0].host;
+        if (!both.empty() && both.back() != '\n') both += '\n';
+        const size_t n_first = both.size();
+        both += inputs[1].host;
+        bsk_ctx* c = nullptr;
+        const int device = (int)strtol(inv.pget("device").c_str(), nullptr, 10);
+        if (bsk_create("Concat", inv.js.c_str(), device, &c) != BSK_OK) die(bsk_global_error());
+        bsk_out out;
+        if (bsk_concat_run(c, both.data(), both.size(), n_first, 0, inputs[0].fmt, nullptr, &out) != BSK_OK) die(bsk_last_error(c));
+        Output o;
+        o.fmt = inputs[0].fmt;
+        o.text.resize(out.len);
+        if (out.len && bsk_out_to_host(c, &out, &o.text[0], out.len) != BSK_OK) die(bsk_last_error(c));
+        bsk_destroy(c);
+        store(inv, o, inv.files);
+        return 0;
+    }
     if (std::string(inv.cmd->use) == "common") {
         // cli/common.go: at least two files; the records of the first one that are common to all
         if (inputs.size() < 2) die("at least 2 files needed");

@@ -197,6 +197,13 @@ int bsk_locate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int
 int bsk_translate_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out);
 
+/* ---- Concat (bigseqkit/concat.go:41-90; ConcatPrepare + Union + GroupByKey + ConcatJoin, bigseqkit-lib/concat.go): for
+ * every ID of both files, each record of file 1 joined with each record of file 2 of that ID: header = the ID, sequence
+ * and quality = A followed by B.  With Full the records of IDs present in one file only are kept unchanged.  `shard` holds
+ * file 1 followed by file 2, n_first = bytes of file 1 (ending in a newline). */
+int bsk_concat_run(bsk_ctx* ctx, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
+                   bsk_out* out);
+
 /* ---- Common (bigseqkit/common.go:56-109; CommonPrepare + Union + GroupByKey + CommonJoin, bigseqkit-lib/common.go): the
  * records of the FIRST file whose ID (full name with ByName, sequence with BySeq; IgnoreCase) occurs in every file --
  * one record per key, file order.  `shard` holds the n_files files back to back (every file ends in a newline),

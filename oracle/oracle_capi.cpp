@@ -363,6 +363,15 @@ int orc_translate(const uint8_t* buf, size_t n, int fastq, const orc_translate_o
     return run_parts(buf, n, fastq, so, nparts, translate_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+int orc_concat(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int fastq, const orc_kitconfig* cfg, int full,
+               uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto ra = split_records(std::string_view((const char*)a, na), fastq != 0);
+        auto rb = split_records(std::string_view((const char*)b, nb), fastq != 0);
+        return emit(concat_call(ra, rb, conv(*cfg), full != 0), out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // common over nfiles files given back to back; ends[f] = offset one past file f
 int orc_common(const uint8_t* buf, const uint64_t* ends, int nfiles, int fastq, const orc_kitconfig* cfg, int by_name, int by_seq,
                int ignore_case, int only_pos, uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {

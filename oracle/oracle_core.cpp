@@ -2016,4 +2016,52 @@ std::vector<std::string> common_call(const std::vector<std::vector<std::string_v
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// concat  (bigseqkit-lib/concat.go)
+// ---------------------------------------------------------------------------
+std::vector<std::string> concat_call(const std::vector<std::string_view>& a, const std::vector<std::string_view>& b,
+                                     const KitConfig& cfg, bool full) {
+    Alphabet ab = alphabet_from_seqtype(cfg.SeqType);
+    struct Rec { Record r; bool fastq; };
+    int lineWidth = cfg.LineWidth;
+    auto parse = [&](const std::vector<std::string_view>& part) {
+        std::vector<Rec> v;
+        SeqParser rd(ab, &part, cfg.IDRegexp, cfg.AlphabetGuessSeqLength);
+        while (rd.Read()) {
+            if (rd.IsFastq) lineWidth = 0;               // :59-62
+            v.push_back({rd.rec, rd.IsFastq});
+        }
+        return v;
+    };
+    const std::vector<Rec> ra = parse(a), rb = parse(b);
+    std::map<std::string, std::vector<size_t>> f2;
+    std::set<std::string> ids1;
+    for (size_t j = 0; j < rb.size(); ++j) f2[rb[j].r.id].push_back(j);
+    for (auto& x : ra) ids1.insert(x.r.id);
+    std::vector<std::string> result;
+    auto keep = [&](const Rec& x) {                      // :112-127 (one side only, Full)
+        std::string t = record_format(x.r, x.fastq, lineWidth);
+        t.pop_back();
+        result.push_back(t);
+    };
+    for (auto& x : ra) {
+        auto it = f2.find(x.r.id);
+        if (it == f2.end()) { if (full) keep(x); continue; }
+        for (size_t j : it->second) {                    // :129-146: every A with every B
+            Record n;
+            n.id = x.r.id;
+            n.name = x.r.id;                             // Name: recordA.ID -- the description is not printed
+            n.seq = x.r.seq + rb[j].r.seq;
+            n.qual = x.r.qual + rb[j].r.qual;
+            std::string t = record_format(n, x.fastq, lineWidth);
+            t.pop_back();
+            result.push_back(t);
+        }
+    }
+    if (full)
+        for (auto& y : rb)
+            if (!ids1.count(y.r.id)) keep(y);
+    return result;
+}
+
 }  // namespace orc

@@ -232,6 +232,11 @@ std::vector<std::string> range_call(const std::vector<std::string_view>& part, i
 // Duplicate.Call  bigseqkit-lib/duplicate.go:24-30 under Flatmap
 std::vector<std::string> duplicate_call(const std::vector<std::string_view>& part, int64_t times);
 
+// Concat(): ConcatPrepare x2 + Union + GroupByKey + ConcatJoin (bigseqkit-lib/concat.go:39-165; PARITY.md CONCAT):
+// file-1 order (joined records, and with `full` the unmatched ones in place), then the unmatched records of file 2
+std::vector<std::string> concat_call(const std::vector<std::string_view>& a, const std::vector<std::string_view>& b,
+                                     const KitConfig& cfg, bool full);
+
 struct CommonOptions {  // bigseqkit/common.go:13-29
     KitConfig Config;
     bool ByName = false, BySeq = false, IgnoreCase = false, OnlyPositiveStrand = false;

@@ -439,3 +439,19 @@ def common(files, fastq, opts_json="{}"):
     if rc:
         raise OracleError(err.value.decode())
     return out.raw[:n.value]
+
+
+def concat(a, b, fastq, opts_json="{}"):
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    cfg = _cfg(d)
+    cap = 4 * (len(a) + len(b)) + 4096
+    while True:
+        out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = _lib.orc_concat(_buf(a), C.c_size_t(len(a)), _buf(b), C.c_size_t(len(b)), int(fastq), C.byref(cfg),
+                             int(bool(d.get("Full"))), out, C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+        if rc == 2:
+            cap = n.value + 16
+            continue
+        if rc:
+            raise OracleError(err.value.decode())
+        return out.raw[:n.value]

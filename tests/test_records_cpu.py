@@ -148,3 +148,14 @@ def test_common_first_file_records_present_in_every_file():
     assert oracle.common([a, b">q\nacgt\n"], False, '{"BySeq": true, "IgnoreCase": true}') == b">x 1\nACGT\n"
     with pytest.raises(bsk.BskError):
         bsk.Operator("Common", '{"BySeq": true, "ByName": true}', -1)
+
+
+def test_concat_joins_every_a_with_every_b_of_an_id():
+    a = b">x 1\nACGT\n>y\nGG\n>x 2\nTT\n"
+    b = b">z q\nAA\n>x d\nCCC\n>x e\nG\n"
+    assert oracle.concat(a, b, False) == b">x\nACGTCCC\n>x\nACGTG\n>x\nTTCCC\n>x\nTTG\n"
+    assert oracle.concat(a, b, False, '{"Full": true, "Config": {"LineWidth": 3}}') == \
+        b">x\nACG\nTCC\nC\n>x\nACG\nTG\n>y\nGG\n>x\nTTC\nCC\n>x\nTTG\n>z q\nAA\n"
+    assert oracle.concat(b"@r1 a\nAC\n+\nII\n", b"@r1 b\nGGG\n+\n###\n", True) == b"@r1\nACGGG\n+\nII###\n"
+    with bsk.Operator("Concat", "{}", -1) as op:
+        assert json.loads(op.opts_json())["Separator"] == "|"
