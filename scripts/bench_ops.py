@@ -102,6 +102,33 @@ if want("pair"):
         assert outs[0].records == nrec and outs[1].records == nrec
         report("pair (2 x 12.5 GB FASTQ, all reads paired)", 2 * nrec, both.numel(), dt, outs[0].len + outs[1].len)
     del both
+if want("common") or want("concat"):
+    t, nrec = synth(0, 0, 12.5e9 * scale)
+    both = torch.cat([t, t])
+    del t
+    out = _lib.Out()
+    if want("common"):
+        ends = (C.c_uint64 * 2)(both.numel() // 2, both.numel())
+        with bsk.Operator("Common", "{}", 0) as op:
+            for i in range(reps + 1):
+                if i == 1:
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                check(lib.bsk_common_run(op.ctx, C.c_void_p(both.data_ptr()), both.numel(), ends, 2, 1, 1, None, C.byref(out)), op.ctx)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            assert out.records == nrec
+            report("common (2 x 12.5 GB FASTQ, same IDs)", 2 * nrec, both.numel(), dt, out.len)
+    if want("concat"):
+        with bsk.Operator("Concat", "{}", 0) as op:
+            for i in range(reps + 1):
+                if i == 1:
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                check(lib.bsk_concat_run(op.ctx, C.c_void_p(both.data_ptr()), both.numel(), both.numel() // 2, 1, 1, None, C.byref(out)), op.ctx)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            assert out.records == nrec
+            report("concat (2 x 12.5 GB FASTQ, same IDs)", 2 * nrec, both.numel(), dt, out.len)
+    del both
 if want("faidx"):
     t, nrec = synth(2, 0, 50e9 * scale)
     fai = lambda ctx, p, n, dev, fmt, pid, st, out: lib.bsk_faidx_run(ctx, p, n, dev, fmt, pid, 0, st, out)
