@@ -17,6 +17,7 @@
 #include "../../include/bsk.h"
 #include "ctx.hpp"
 #include "ops_host.hpp"
+#include "ops_host_internal.hpp"
 #include "ops_concat.hpp"
 #include "ops_faidx.hpp"
 #include "ops_grep.hpp"
@@ -32,41 +33,27 @@
 
 namespace bsk {
 
-#define HIP_TRYX(ctx, expr)                                                                  \
-    do {                                                                                     \
-        hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess) {                                                             \
-            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(e__));           \
-            return BSK_ERR_HIP;                                                              \
-        }                                                                                    \
-    } while (0)
-
-template <class T>
-static int grow(bsk_ctx* c, T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
-    if (need <= *cap && *p) return BSK_OK;
-    if (*p) HIP_TRYX(c, hipFree(*p));
-    *p = nullptr;
-    const uint64_t n = need + slack;
-    HIP_TRYX(c, hipMalloc((void**)p, std::max<uint64_t>(n, 1) * sizeof(T)));
-    *cap = n;
+// Open-addressing table of the key-grouping operators (rmdup, rename, pair, common, concat, grep --delete-matched):
+// d_keys for N records, `cap` slots (a power of two >= 2 N) of keys (zeroed) and first-record indices (0xFF-filled).
+int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, uint64_t** tf, hipStream_t st) {
+    int rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    if (2 * cap > c->table_cap || !c->d_table) {
+        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
+        c->d_table = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
+        c->table_cap = 2 * cap;
+    }
+    *tk = c->d_table;
+    *tf = c->d_table + cap;
+    *cap_out = cap;
+    HIP_TRYX(c, hipMemsetAsync(*tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(*tf, 0xFF, cap * sizeof(uint64_t), st));
     return BSK_OK;
 }
 
-// Scratch of the global operators (sort, rename, faidx): ONE grow-only allocation per context, carved per call.
-// (hipMalloc / hipFree of gigabytes per call cost 110 of the 144 ms of `sort -l` on 25 GB.)
-struct Arena {
-    uint8_t* base = nullptr;
-    uint64_t used = 0;
-    uint64_t take(uint64_t bytes) { const uint64_t at = used; used = (used + bytes + 255) & ~255ull; return at; }
-    template <class T> T* at(uint64_t off) const { return reinterpret_cast<T*>(base + off); }
-};
-static int arena_reserve(bsk_ctx* c, Arena* a) {
-    int rc = grow(c, &c->d_arena, &c->arena_cap, a->used, a->used / 8 + 256);
-    a->base = c->d_arena;
-    return rc;
-}
-
-static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
 static void complement_table(Alphabet ab, uint8_t m[256]);
 static std::vector<std::string> read_pattern_lines(const std::string& path);
 
@@ -228,7 +215,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
 // ---------------------------------------------------------------------------
 // seq
 // ---------------------------------------------------------------------------
-static void set_bits(uint32_t* set, const std::string& letters) {
+void set_bits(uint32_t* set, const std::string& letters) {
     for (int k = 0; k < 8; ++k) set[k] = 0;
     for (unsigned char ch : letters) set[ch >> 5] |= 1u << (ch & 31);
 }
@@ -324,7 +311,7 @@ int ensure_record_scratch(bsk_ctx* c) {
 }
 
 // size array -> scan -> total / kept / kernel status; then the caller emits
-static int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
+int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
     HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
@@ -349,14 +336,14 @@ static int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* k
 }
 
 // tell the emit kernel which records it must leave to the block-per-chunk launch
-static void apply_long(const bsk_ctx* c, SeqParams* P) {
+void apply_long(const bsk_ctx* c, SeqParams* P) {
     P->long_list = c->long_count ? c->d_long_list : nullptr;
     P->long_count = c->long_count;
     P->long_max = c->long_max;
     P->long_thresh = c->long_count ? c->long_thresh : 0u;
 }
 
-static int empty_result(bsk_ctx* c, bsk_out* out) {
+int empty_result(bsk_ctx* c, bsk_out* out) {
     out->d_data = nullptr;
     out->len = 0;
     out->records = 0;
@@ -366,7 +353,7 @@ static int empty_result(bsk_ctx* c, bsk_out* out) {
 }
 
 // SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
-static SeqParams format_params(bsk_ctx* c, bool fastq) {
+SeqParams format_params(bsk_ctx* c, bool fastq) {
     SeqParams P;
     memset(&P, 0, sizeof P);
     P.fastq = fastq;
@@ -407,7 +394,7 @@ static void parse_region_opt(const std::string& region, const char* cmd, int* st
     *end = (int)sb;
 }
 
-static void check_id_regexp(const Options& o) {
+void check_id_regexp(const Options& o) {
     const std::string& re = o.cs("IDRegexp");
     if (!(re.empty() || re == "^(\\S+)\\s?" || re == "\\|([^\\|]+)\\| "))
         throw OptError("libbsk: --id-regexp other than the default and the --id-ncbi one is not supported by the HIP path");
@@ -793,20 +780,10 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 R.id_mode = G.id_mode;
                 R.line_width = G.line_width;
                 R.buf_end = d_buf + n;
-                rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+                uint64_t cap = 0;
+                uint64_t *tk = nullptr, *tf = nullptr;
+                rc = key_table(c, N, &cap, &tk, &tf, st);
                 if (rc != BSK_OK) return rc;
-                uint64_t cap = 1024;
-                while (cap < 2 * N) cap <<= 1;
-                if (2 * cap > c->table_cap || !c->d_table) {
-                    if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
-                    c->d_table = nullptr;
-                    HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
-                    c->table_cap = 2 * cap;
-                }
-                uint64_t* tk = c->d_table;
-                uint64_t* tf = c->d_table + cap;
-                HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
-                HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
                 Arena A;
                 const uint64_t o_first = A.take(N * 4);
                 rc = arena_reserve(c, &A);
@@ -1319,7 +1296,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
 // ---------------------------------------------------------------------------
 // FASTA text view: classify every record, linearise the irregularly wrapped ones
 // ---------------------------------------------------------------------------
-static int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt) {
+int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt) {
     tt->text_w = nullptr;
     tt->lin_off = nullptr;
     tt->lin = nullptr;
@@ -1617,20 +1594,10 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
-    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    uint64_t cap = 0;
+    uint64_t *tk = nullptr, *tf = nullptr;
+    rc = key_table(c, N, &cap, &tk, &tf, st);
     if (rc != BSK_OK) return rc;
-    uint64_t cap = 1024;
-    while (cap < 2 * N) cap <<= 1;
-    if (2 * cap > c->table_cap || !c->d_table) {
-        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
-        c->d_table = nullptr;
-        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
-        c->table_cap = 2 * cap;
-    }
-    uint64_t* tk = c->d_table;
-    uint64_t* tf = c->d_table + cap;
-    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
-    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
@@ -1933,775 +1900,6 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// fq2fa, range / head, duplicate
-// ---------------------------------------------------------------------------
-// Go strconv.ParseInt(s, 10, 64) with its error text
-static int64_t go_parse_int(const std::string& s) {
-    const std::string err = "strconv.ParseInt: parsing \"" + s + "\": invalid syntax";
-    size_t i = 0;
-    bool neg = false;
-    if (i < s.size() && (s[i] == '+' || s[i] == '-')) neg = s[i++] == '-';
-    if (i >= s.size()) throw OptError(err);
-    unsigned long long v = 0;
-    for (; i < s.size(); ++i) {
-        if (s[i] < '0' || s[i] > '9') throw OptError(err);
-        if (v > (0x7FFFFFFFFFFFFFFFull - (unsigned)(s[i] - '0')) / 10ull)
-            throw OptError("strconv.ParseInt: parsing \"" + s + "\": value out of range");
-        v = v * 10ull + (unsigned)(s[i] - '0');
-    }
-    return neg ? -(int64_t)v : (int64_t)v;
-}
-
-// Before() of Fq2Fa (bigseqkit-lib/fq2fa.go:26-33) and the driver side of Range / Head / Duplicate
-// (bigseqkit/range.go:36-66, head.go:34-44, duplicate.go:31-43)
-void validate_records_opts(bsk_ctx* c) {
-    const Options& o = c->opts;
-    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (c->op == Op::Fq2Fa || c->op == Op::Rename || c->op == Op::Pair || c->op == Op::Concat) { check_id_regexp(o); return; }
-    if (c->op == Op::Duplicate) {
-        // make([]string, times) panics for a negative count; zero copies is an empty result
-        if (o.i("Times") < 0) throw OptError("value of -n (--times) should not be negative");
-        if (o.i("Times") > 0xFFFFFFFFll) throw OptError("value of -n (--times) too large");
-        return;
-    }
-    std::string range = c->op == Op::Head ? "1:" + std::to_string(o.i("N")) : o.s("Range");
-    if (range.empty()) throw OptError("flag -r (--range) needed");
-    std::vector<std::string> r;  // strings.Split(range, ":")
-    for (size_t a = 0;;) {
-        const size_t b = range.find(':', a);
-        r.push_back(range.substr(a, b == std::string::npos ? std::string::npos : b - a));
-        if (b == std::string::npos) break;
-        a = b + 1;
-    }
-    int64_t start = go_parse_int(r[0]);
-    int64_t end = -1;
-    if (r.size() > 1) end = go_parse_int(r[1]);
-    if (start == 0 || end == 0) throw OptError("either start and end should not be 0");
-    if (start > 0) --start;
-    if (end == -1) end = INT64_MAX;
-    c->range_start = start;
-    c->range_end = end;
-    c->range_needs_count = start < -1 || end < -1;  // range.go:69
-    c->range_resolved = false;
-    if (!c->range_needs_count) {
-        const int rc = range_resolve(c, 0);
-        if (rc != BSK_OK) throw OptError(c->last_error);
-    }
-}
-
-// bigseqkit/range.go:69-86: negative positions count from the end.  PARITY.md RNG: the reference's final check reads
-// `if start <= end { error }`, which rejects every non-empty range; the evident intent (an empty or inverted range is
-// the error) is what runs here, the arithmetic above it is kept as written.
-int range_resolve(bsk_ctx* c, int64_t n_records) {
-    if (c->range_resolved) return BSK_OK;
-    if (c->range_needs_count) {
-        if (c->range_start < 0) c->range_start += n_records;
-        if (c->range_end < 0) c->range_end += n_records;
-    }
-    if (c->range_start >= c->range_end) {
-        c->set_error("start must be > than end");
-        return BSK_ERR_OPTS;
-    }
-    c->range_resolved = true;
-    return BSK_OK;
-}
-
-// Fq2Fa.Call (bigseqkit-lib/fq2fa.go:35-59): record.Seq.Qual = []; record.Format(0) -- '>' + name, the sequence on one line
-int fq2fa_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    SeqParams P = format_params(c, fastq);
-    P.print_qual = 0;
-    P.line_width = 0;
-    P.fasta_out = 1;
-    P.buf_end = d_buf + n;
-    TextTableH tt{nullptr, nullptr, nullptr};
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
-    P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
-    uint64_t total = 0, kept = 0;
-    rc = finish_sizes(c, st, &total, &kept);
-    if (rc != BSK_OK) return rc;
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return rc;
-    apply_long(c, &P);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = kept;
-    return BSK_OK;
-}
-
-// RangePrepare + RangeFilter (bigseqkit-lib/range.go:26-43), Duplicate.Call (duplicate.go:24-30)
-int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
-    RecordsParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = format == BSK_FORMAT_FASTQ;
-    P.first_record = c->cur_first_record;
-    if (c->op == Op::Duplicate) {
-        P.lo = INT64_MIN;
-        P.hi = INT64_MAX;
-        P.times = (uint32_t)c->opts.i("Times");
-        if (P.times == 0) return empty_result(c, out);
-    } else {
-        if (!c->range_resolved) {
-            c->set_error("libbsk: a range with negative positions needs the record count first (bsk_range_set_count)");
-            return BSK_ERR_INVALID_ARG;
-        }
-        P.lo = c->range_start;
-        P.hi = c->range_end;
-        P.times = 1;
-    }
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_records_size(d_buf, n, c->table, P, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
-    uint64_t total = 0, kept = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&kept, c->d_counter, sizeof kept, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
-    out->d_data = nullptr;
-    out->len = 0;
-    out->records = 0;
-    if (total == 0) return BSK_OK;
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return rc;
-    rc = grow(c, &c->d_tile_first, &c->tile_first_cap, records_copy_tiles(total), 64);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_records_copy(d_buf, c->table, P, c->d_out_off, c->d_tile_first, c->d_out, total, st));
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = kept * P.times;
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// rename: RenamePrepare + GroupByKey + Rename (bigseqkit-lib/rename.go:39-131).
-// The k-th further record (k >= 1, file order) of an ID -- or of a whole name with ByName -- is printed as
-// "<ID>_<k> <Desc>"; everything is re-formatted with Format(LineWidth).  Global like rmdup: one call sees the whole
-// input.  Output in file order (the reference's group order is whatever GroupByKey yields); PARITY.md REN.
-// ---------------------------------------------------------------------------
-int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
-    const Options& o = c->opts;
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
-    RmDupParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = fastq;
-    P.by_name = o.b("ByName");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
-    P.buf_end = d_buf + n;
-    const uint64_t N = c->table.n;
-    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
-    if (rc != BSK_OK) return rc;
-    uint64_t cap = 1024;
-    while (cap < 2 * N) cap <<= 1;
-    if (2 * cap > c->table_cap || !c->d_table) {
-        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
-        c->d_table = nullptr;
-        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
-        c->table_cap = 2 * cap;
-    }
-    uint64_t* tk = c->d_table;
-    uint64_t* tf = c->d_table + cap;
-    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
-    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    // groups: the rmdup machinery (XXH64 of the ID / name, first occurrence wins, exact verification of every other one)
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
-    Arena A;
-    const uint64_t o_has = A.take(N), o_ord = A.take(N * 4);
-    rc = arena_reserve(c, &A);
-    if (rc != BSK_OK) return rc;
-    uint8_t* d_has = A.at<uint8_t>(o_has);   // (launch_rmdup_group also marks the groups of two or more; not needed here)
-    uint32_t* d_ord = A.at<uint32_t>(o_ord);
-    uint64_t* d_list = nullptr;
-    void* d_tmp = nullptr;
-    auto cleanup = [&]() {};
-    auto fail = [&](int code) { return code; };
-    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, hipMemsetAsync(d_ord, 0, N * 4, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));  // d_keys[i] := first record of i's group
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
-    // how many records are not the first of their group
-    uint64_t status = 0, m = 0;
-    {
-        // count first (the list is allocated to size): out_len of resolve is 0 exactly for the dropped records
-        HIP_TRYX(c, launch_count_nonzero(c->d_out_len, N, c->d_counter, st));
-        uint64_t firsts = 0;
-        HIP_TRYX(c, hipMemcpyAsync(&firsts, c->d_counter, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRYX(c, hipStreamSynchronize(st));
-        if (status & ERR_HASH_COLLISION) {
-            c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
-            return fail(BSK_ERR_UNSUPPORTED);
-        }
-        rc = kernel_error_to_status(c, status);
-        if (rc != BSK_OK) return fail(rc);
-        m = N - firsts;
-    }
-    if (m) {
-        size_t tmp_bytes = 0;
-        if (group_sort_temp_bytes(m, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
-        // the arena may move when it grows: d_ord has to survive, so it is re-derived after the reservation
-        const uint64_t o_list = A.take(2 * m * 8), o_tmp = A.take(tmp_bytes ? tmp_bytes : 16);
-        if (A.used > c->arena_cap) {
-            // grow by hand, keeping the first part (has / ord)
-            uint8_t* nb = nullptr;
-            const uint64_t cap = A.used + A.used / 8 + 256;
-            if (hipMalloc((void**)&nb, cap) != hipSuccess) { c->set_error("libbsk: out of device memory (rename)"); return BSK_ERR_HIP; }
-            HIP_TRYX(c, hipMemcpyAsync(nb, c->d_arena, o_list, hipMemcpyDeviceToDevice, st));
-            HIP_TRYX(c, hipStreamSynchronize(st));
-            hipFree(c->d_arena);
-            c->d_arena = nb;
-            c->arena_cap = cap;
-        }
-        A.base = c->d_arena;
-        d_has = A.at<uint8_t>(o_has);
-        d_ord = A.at<uint32_t>(o_ord);
-        d_list = A.at<uint64_t>(o_list);
-        d_tmp = A.at<uint8_t>(o_tmp);
-        HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 8, st));
-        HIP_TRYX(c, launch_group_compact(c->d_keys, N, d_list, c->d_counter, st));
-        HIP_TRYX(c, launch_group_sort(d_tmp, tmp_bytes, d_list, d_list + m, m, st));
-        HIP_TRYX(c, launch_group_ordinals(d_list + m, m, d_ord, st));
-    }
-    SeqParams F = format_params(c, fastq);
-    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
-    F.buf_end = d_buf + n;
-    F.ren_ord = d_ord;
-    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_seq_size(d_buf, c->table, F, c->d_out_len, c->d_status, st));
-    uint64_t total = 0, kept = 0;
-    rc = finish_sizes(c, st, &total, &kept);
-    if (rc != BSK_OK) return fail(rc);
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return fail(rc);
-    apply_long(c, &F);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
-    cleanup();
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = kept;
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// sort: driver bigseqkit/sort.go:91-147, executor bigseqkit-lib/sort.go:38-166
-// ---------------------------------------------------------------------------
-void validate_sort_opts(bsk_ctx* c) {
-    const Options& o = c->opts;
-    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
-    int k = 0;  // sort.go:105-119 (ByBases implies ByLength)
-    if (o.b("BySeq")) ++k;
-    if (o.b("ByName")) ++k;
-    if (o.b("ByLength") || o.b("ByBases")) ++k;
-    if (k > 1) throw OptError("only one of the options (byLength), (byName) and (bySeq) is allowed");
-    if (o.i("SeqPrefixLength") < 0) throw OptError("value of flag -L (--seq-prefix-length) should be >= 0");
-    if (o.b("InNaturalOrder") && !o.b("BySeq") && !(o.b("ByLength") || o.b("ByBases")))
-        throw OptError("libbsk: sort in natural order (-N) is not provided by the HIP path");
-}
-
-int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
-    const Options& o = c->opts;
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
-    const uint64_t N = c->table.n;
-    SortParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = fastq;
-    P.mode = o.b("ByBases") ? 4 : o.b("ByLength") ? 3 : o.b("BySeq") ? 2 : o.b("ByName") ? 1 : 0;
-    P.ignore_case = o.b("IgnoreCase");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    P.prefix_len = (uint32_t)std::min<int64_t>(o.i("SeqPrefixLength"), 0xFFFFFFFFll);
-    set_bits(P.gap_set, o.s("GapLetters"));
-    P.buf_end = d_buf + n;
-    const bool desc = o.b("Reverse");  // SortByKey(!reverse, ...)
-    // scratch: keys x2, perm x2, key lengths, rocPRIM temporary storage
-    size_t tmp_bytes = 0;
-    if (sort_pairs_temp_bytes(N, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
-    Arena A;
-    const uint64_t o_keys = A.take(2 * N * 8), o_perm = A.take(2 * N * 4), o_klen = A.take((N + 1) * 4),
-                   o_tmp = A.take(tmp_bytes ? tmp_bytes : 16);
-    rc = arena_reserve(c, &A);
-    if (rc != BSK_OK) return rc;
-    uint64_t* d_keys2 = A.at<uint64_t>(o_keys);   // [2 N]
-    uint32_t* d_perm2 = A.at<uint32_t>(o_perm);   // [2 N]
-    uint32_t* d_klen = A.at<uint32_t>(o_klen);    // [N + 1]   (last: max)
-    void* d_tmp = A.at<uint8_t>(o_tmp);
-    auto cleanup = [&]() {};
-    auto fail = [&](int code) { return code; };
-    uint64_t* kin = d_keys2;
-    uint64_t* kout = d_keys2 + N;
-    uint32_t* pin = d_perm2;
-    uint32_t* pout = d_perm2 + N;
-    if (launch_sort_iota(pin, N, st) != hipSuccess) return fail(BSK_ERR_HIP);
-    if (P.mode >= 3) {
-        if (launch_sort_intkeys(d_buf, c->table, tt, P, kin, st) != hipSuccess ||
-            launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 32, st) != hipSuccess) return fail(BSK_ERR_HIP);
-        std::swap(pin, pout);
-    } else {
-        uint32_t maxlen = 0;
-        if (hipMemsetAsync(d_klen + N, 0, 4, st) != hipSuccess ||
-            launch_sort_keylen(d_buf, c->table, P, d_klen, d_klen + N, st) != hipSuccess ||
-            hipMemcpyAsync(&maxlen, d_klen + N, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
-        // LSD over the 8-byte chunks of the keys, last chunk first; every pass is stable
-        for (uint32_t ch = (maxlen + 7) / 8; ch-- > 0;) {
-            if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, pin, ch, kin, st) != hipSuccess ||
-                launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 64, st) != hipSuccess) return fail(BSK_ERR_HIP);
-            std::swap(pin, pout);
-        }
-    }
-    // sizes in file order, offsets in sorted order
-    SeqParams F = format_params(c, fastq);
-    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
-    F.buf_end = d_buf + n;
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return fail(rc);
-    if (launch_seq_size(d_buf, c->table, F, c->d_out_len, c->d_status, st) != hipSuccess) return fail(BSK_ERR_HIP);
-    uint64_t total = 0, kept = 0;
-    rc = finish_sizes(c, st, &total, &kept);
-    if (rc != BSK_OK) return fail(rc);
-    uint32_t* len_perm = pout;  // the other permutation buffer is free now
-    uint64_t* off_perm = kin;   // [N + 1] fits: kin and kout are adjacent (2 N entries)
-    if (kin != d_keys2) off_perm = d_keys2;
-    if (launch_sort_gather(c->d_out_len, pin, N, len_perm, st) != hipSuccess ||
-        launch_scan_u32(len_perm, off_perm, N, c->d_scan_tmp, st) != hipSuccess ||
-        launch_sort_scatter(off_perm, pin, N, c->d_out_off, st) != hipSuccess) return fail(BSK_ERR_HIP);
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return fail(rc);
-    apply_long(c, &F);
-    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess) return fail(BSK_ERR_HIP);
-    cleanup();
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = kept;
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// faidx index rows: Faidx.Before / Call, bigseqkit-lib/faidx.go:63-229.  PARITY.md FAI.
-// ---------------------------------------------------------------------------
-void validate_faidx_opts(bsk_ctx* c) {
-    const Options& o = c->opts;
-    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (!o.b("FullHead")) check_id_regexp(o);  // -f swaps the ID regexp for ^(.+)$ (faidx.go:69-73)
-    if (!o.sl("Regions").empty() || !o.s("RegionFile").empty())
-        throw OptError("libbsk: faidx region queries are not provided by the HIP path (index rows only; use subseq / grep)");
-}
-
-int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
-    const Options& o = c->opts;
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    FaidxParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = format == BSK_FORMAT_FASTQ;
-    P.full_head = o.b("FullHead");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    P.base_offset = c->cur_base_offset;
-    P.buf_end = d_buf + n;
-    const uint64_t N = c->table.n;
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    Arena A;
-    const uint64_t o_lb = A.take(N * 4);
-    rc = arena_reserve(c, &A);
-    if (rc != BSK_OK) return rc;
-    uint32_t* d_lb = A.at<uint32_t>(o_lb);
-    auto fail = [&](int code) { return code; };
-    if (hipMemsetAsync(c->d_status + 1, 0xFF, 8, st) != hipSuccess ||
-        launch_faidx_size(d_buf, c->table, P, c->d_out_len, d_lb, c->d_status, st) != hipSuccess ||
-        launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) return fail(BSK_ERR_HIP);
-    uint64_t total = 0, status[2] = {0, 0};
-    if (hipMemcpyAsync(&total, c->d_out_off + N, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(status, c->d_status, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
-    if (status[0] & ERR_LINE_LENGTHS) {
-        // the first offending record names the error (faidx.go:131)
-        uint64_t start = 0;
-        uint32_t lh = 0;
-        hipMemcpy(&start, c->table.start + status[1], 8, hipMemcpyDeviceToHost);
-        hipMemcpy(&lh, c->table.l_head + status[1], 4, hipMemcpyDeviceToHost);
-        std::string head(lh > 0 ? lh - 1 : 0, '\0');
-        if (!head.empty()) hipMemcpy(&head[0], d_buf + start + 1, head.size(), hipMemcpyDeviceToHost);
-        std::string id = head;
-        if (!P.full_head && P.id_mode == 0) {
-            size_t sp = head.find(' ');
-            if (sp != std::string::npos && sp > 0) id = head.substr(0, sp);
-            else { sp = head.find('\t'); if (sp != std::string::npos && sp > 0) id = head.substr(0, sp); }
-        } else if (!P.full_head) {  // --id-ncbi: first match of \|([^\|]+)\|<space>
-            for (size_t i = 0; i < head.size(); ++i) {
-                if (head[i] != '|') continue;
-                size_t j = i + 1;
-                while (j < head.size() && head[j] != '|') ++j;
-                if (j > i + 1 && j + 1 < head.size() && head[j + 1] == ' ') { id = head.substr(i + 1, j - i - 1); break; }
-            }
-        }
-        c->set_error("different line length in sequence: " + id + ". Please format the file with 'seqkit seq'");
-        return fail(BSK_ERR_FORMAT);
-    }
-    rc = kernel_error_to_status(c, status[0]);
-    if (rc != BSK_OK) return fail(rc);
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return fail(rc);
-    if (launch_faidx_rows(d_buf, c->table, P, d_lb, c->d_out_off, c->d_out, st) != hipSuccess) return fail(BSK_ERR_HIP);
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = N;
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// pair: PairPrepare x2 + Union + GroupByKey + Pair (bigseqkit/pair.go:34-100,
-// bigseqkit-lib/pair.go:37-121).  The shard is file 1 followed by file 2; the k-th record of an ID in file 1 is paired
-// with the k-th of file 2.  outs[0] / outs[1]: the pairs, both in the file-1 order of their first mates; outs[2] /
-// outs[3]: the records without a mate (SaveUnpaired), file order.  PARITY.md PAIR.
-// ---------------------------------------------------------------------------
-int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* outs) {
-    const Options& o = c->opts;
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    for (int k = 0; k < 4; ++k) { outs[k].d_data = nullptr; outs[k].len = 0; outs[k].records = 0; }
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) {
-        bsk_out tmp;
-        return empty_result(c, &tmp);
-    }
-    TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
-    const uint64_t N = c->table.n;
-    RmDupParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = fastq;
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
-    P.buf_end = d_buf + n;
-    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
-    if (rc != BSK_OK) return rc;
-    uint64_t cap = 1024;
-    while (cap < 2 * N) cap <<= 1;
-    if (2 * cap > c->table_cap || !c->d_table) {
-        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
-        c->d_table = nullptr;
-        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
-        c->table_cap = 2 * cap;
-    }
-    uint64_t* tk = c->d_table;
-    uint64_t* tf = c->d_table + cap;
-    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
-    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    size_t tmp_bytes = 0;
-    if (group_sort_temp_bytes(N, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
-    Arena A;
-    const uint64_t o_has = A.take(N), o_list = A.take(2 * N * 8), o_tmp = A.take(tmp_bytes ? tmp_bytes : 16),
-                   o_state = A.take(N), o_partner = A.take(N * 4), o_fmt = A.take(N * 4), o_len = A.take(N * 4),
-                   o_off = A.take((N + 1) * 8), o_offw = A.take((N + 1) * 8), o_tot = A.take(8 * 8);
-    rc = arena_reserve(c, &A);
-    if (rc != BSK_OK) return rc;
-    uint8_t* d_has = A.at<uint8_t>(o_has);
-    uint64_t* d_list = A.at<uint64_t>(o_list);
-    uint8_t* d_state = A.at<uint8_t>(o_state);
-    uint32_t* d_partner = A.at<uint32_t>(o_partner);
-    uint32_t* d_fmt = A.at<uint32_t>(o_fmt);
-    uint32_t* d_len = A.at<uint32_t>(o_len);
-    uint64_t* d_off = A.at<uint64_t>(o_off);
-    uint64_t* d_offw = A.at<uint64_t>(o_offw);
-    uint64_t* d_tot = A.at<uint64_t>(o_tot);
-    // groups by ID (XXH64, first occurrence, exact verification of every other member)
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
-    HIP_TRYX(c, hipMemsetAsync(d_tot, 0, 8 * 8, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
-    uint64_t first2 = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&first2, c->d_counter, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    if (status & ERR_HASH_COLLISION) {
-        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
-        return BSK_ERR_UNSUPPORTED;
-    }
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_group_all(c->d_keys, N, d_list, st));
-    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st));
-    HIP_TRYX(c, launch_pair_classify(d_list + N, N, (uint32_t)first2, d_state, d_partner, st));
-    // formatted size of every record, totals per output
-    SeqParams F = format_params(c, fastq);
-    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
-    F.buf_end = d_buf + n;
-    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_seq_size(d_buf, c->table, F, d_fmt, c->d_status, st));
-    HIP_TRYX(c, launch_pair_totals(d_state, d_fmt, N, d_tot, st));
-    uint64_t tot[8];
-    HIP_TRYX(c, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
-    const bool unpaired = o.b("SaveUnpaired");
-    uint64_t base[5] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < 4; ++k) base[k + 1] = base[k] + ((k < 2 || unpaired) ? ((tot[k] + 255) & ~255ull) : 0);
-    rc = ensure_out(c, base[4]);
-    if (rc != BSK_OK) return rc;
-    for (int k = 0; k < 4; ++k) {
-        if (!(k < 2 || unpaired) || tot[k] == 0) continue;
-        HIP_TRYX(c, launch_pair_select(d_state, d_fmt, N, (uint8_t)(k + 1), d_len, st));
-        if (k == 1) {
-            // the second mates follow the order of the first ones
-            uint32_t* d_w = c->d_out_len;  // free scratch of N entries
-            HIP_TRYX(c, launch_pair_partner_len(d_state, d_partner, d_fmt, N, d_w, st));
-            HIP_TRYX(c, launch_scan_u32(d_w, d_offw, N, c->d_scan_tmp, st));
-            HIP_TRYX(c, launch_pair_partner_off(d_state, d_partner, d_offw, N, d_off, st));
-        } else {
-            HIP_TRYX(c, launch_scan_u32(d_len, d_off, N, c->d_scan_tmp, st));
-        }
-        HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, d_len, d_off, c->d_out + base[k], st, tot[k], tot[4 + k]));
-        outs[k].d_data = c->d_out + base[k];
-        outs[k].len = tot[k];
-        outs[k].records = tot[4 + k];
-    }
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// common: the records of the first file whose key occurs in every file.  The reference's
-// CommonPrepare / CommonJoin (bigseqkit-lib/common.go:31-212) cannot run as written; PARITY.md COMMON states what is
-// kept (keys, options, error texts) and what follows seqkit's documented behaviour instead.
-// ---------------------------------------------------------------------------
-void validate_common_opts(bsk_ctx* c) {
-    const Options& o = c->opts;
-    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
-    if (o.b("BySeq") && o.b("ByName"))  // common.go:37-39
-        throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
-    if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :43-45
-        throw OptError("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
-    if (o.b("OnlyPositiveStrand"))
-        throw OptError("libbsk: common -s -P: the reference hashes nothing on that branch (every record gets key 0); not provided");
-}
-
-int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t* file_ends, uint32_t nfiles, int format,
-                      hipStream_t st, bsk_out* out) {
-    const Options& o = c->opts;
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
-    const uint64_t N = c->table.n;
-    RmDupParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = fastq;
-    P.by_seq = o.b("BySeq");
-    P.by_name = o.b("ByName");
-    P.ignore_case = o.b("IgnoreCase");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
-    P.buf_end = d_buf + n;
-    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
-    if (rc != BSK_OK) return rc;
-    uint64_t cap = 1024;
-    while (cap < 2 * N) cap <<= 1;
-    if (2 * cap > c->table_cap || !c->d_table) {
-        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
-        c->d_table = nullptr;
-        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
-        c->table_cap = 2 * cap;
-    }
-    uint64_t* tk = c->d_table;
-    uint64_t* tf = c->d_table + cap;
-    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
-    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    Arena A;
-    const uint64_t o_has = A.take(N), o_masks = A.take(N * 8), o_ends = A.take((uint64_t)nfiles * 8);
-    rc = arena_reserve(c, &A);
-    if (rc != BSK_OK) return rc;
-    uint8_t* d_has = A.at<uint8_t>(o_has);
-    uint64_t* d_masks = A.at<uint64_t>(o_masks);
-    uint64_t* d_ends = A.at<uint64_t>(o_ends);
-    HIP_TRYX(c, hipMemcpyAsync(d_ends, file_ends, (size_t)nfiles * 8, hipMemcpyHostToDevice, st));
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
-    HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 8, st));
-    HIP_TRYX(c, launch_common_masks(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, st));
-    uint64_t status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));  // (file_ends is the caller's memory)
-    if (status & ERR_HASH_COLLISION) {
-        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
-        return BSK_ERR_UNSUPPORTED;
-    }
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
-    SeqParams F = format_params(c, fastq);
-    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
-    F.buf_end = d_buf + n;
-    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_seq_size(d_buf, c->table, F, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, launch_common_select(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, c->d_out_len, st));
-    uint64_t total = 0, kept = 0;
-    rc = finish_sizes(c, st, &total, &kept);
-    if (rc != BSK_OK) return rc;
-    out->d_data = nullptr;
-    out->len = 0;
-    out->records = 0;
-    if (total == 0) return BSK_OK;
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return rc;
-    apply_long(c, &F);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = kept;
-    return BSK_OK;
-}
-
-// ---------------------------------------------------------------------------
-// concat: ConcatPrepare x2 + Union + GroupByKey + ConcatJoin (bigseqkit/concat.go:41-90,
-// bigseqkit-lib/concat.go:39-165).  PARITY.md CONCAT.
-// ---------------------------------------------------------------------------
-int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* out) {
-    const Options& o = c->opts;
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
-    const uint64_t N = c->table.n;
-    RmDupParams P;
-    memset(&P, 0, sizeof P);
-    P.fastq = fastq;
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
-    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
-    P.buf_end = d_buf + n;
-    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
-    if (rc != BSK_OK) return rc;
-    uint64_t cap = 1024;
-    while (cap < 2 * N) cap <<= 1;
-    if (2 * cap > c->table_cap || !c->d_table) {
-        if (c->d_table) HIP_TRYX(c, hipFree(c->d_table));
-        c->d_table = nullptr;
-        HIP_TRYX(c, hipMalloc((void**)&c->d_table, 2 * cap * sizeof(uint64_t)));
-        c->table_cap = 2 * cap;
-    }
-    uint64_t* tk = c->d_table;
-    uint64_t* tf = c->d_table + cap;
-    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
-    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    size_t tmp_bytes = 0;
-    if (group_sort_temp_bytes(N, &tmp_bytes) != hipSuccess) { c->set_error("libbsk: rocPRIM sort size query failed"); return BSK_ERR_HIP; }
-    Arena A;
-    const uint64_t o_has = A.take(N), o_list = A.take(2 * N * 8), o_tmp = A.take(tmp_bytes ? tmp_bytes : 16),
-                   o_seg = A.take(3 * N * 4), o_cnt = A.take(N * 4), o_cntoff = A.take((N + 1) * 8);
-    rc = arena_reserve(c, &A);
-    if (rc != BSK_OK) return rc;
-    uint8_t* d_has = A.at<uint8_t>(o_has);
-    uint64_t* d_list = A.at<uint64_t>(o_list);
-    uint32_t* d_seg = A.at<uint32_t>(o_seg);
-    uint32_t* d_cnt = A.at<uint32_t>(o_cnt);
-    uint64_t* d_cntoff = A.at<uint64_t>(o_cntoff);
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
-    uint64_t first2 = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&first2, c->d_counter, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    if (status & ERR_HASH_COLLISION) {
-        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
-        return BSK_ERR_UNSUPPORTED;
-    }
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_group_all(c->d_keys, N, d_list, st));
-    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st));
-    HIP_TRYX(c, launch_concat_segments(d_list + N, N, (uint32_t)first2, d_seg, st));
-    ConcatParams Q;
-    memset(&Q, 0, sizeof Q);
-    Q.fastq = fastq;
-    Q.full = o.b("Full");
-    Q.id_mode = P.id_mode;
-    Q.line_width = P.line_width;
-    Q.first2 = (uint32_t)first2;
-    Q.buf_end = d_buf + n;
-    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_concat_size(d_buf, c->table, Q, d_list + N, d_seg, c->d_out_len, d_cnt, c->d_status, st));
-    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st));
-    HIP_TRYX(c, launch_scan_u32(d_cnt, d_cntoff, N, c->d_scan_tmp, st));
-    uint64_t total = 0, elements = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + N, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&elements, d_cntoff + N, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
-    out->d_data = nullptr;
-    out->len = 0;
-    out->records = 0;
-    if (total == 0) return BSK_OK;
-    rc = ensure_out(c, total);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_concat_emit(d_buf, c->table, tt, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, c->d_out, st));
-    out->d_data = c->d_out;
-    out->len = total;
-    out->records = elements;
     return BSK_OK;
 }
 

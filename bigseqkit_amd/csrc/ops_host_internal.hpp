@@ -1,0 +1,66 @@
+// Internal to the host side of libbsk (ops_host.cpp, ops_host_next.cpp): scratch helpers and the pieces of the
+// seq-style "size -> scan -> emit" flow that several operators share.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+
+#include "../../include/bsk.h"
+#include "ctx.hpp"
+#include "ops_host.hpp"
+#include "ops_seq.hpp"
+#include "ops_translate.hpp"  // TextTableH
+
+namespace bsk {
+
+#define HIP_TRYX(ctx, expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(e__));           \
+            return BSK_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+template <class T>
+inline int grow(bsk_ctx* c, T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
+    if (need <= *cap && *p) return BSK_OK;
+    if (*p) HIP_TRYX(c, hipFree(*p));
+    *p = nullptr;
+    const uint64_t n = need + slack;
+    HIP_TRYX(c, hipMalloc((void**)p, std::max<uint64_t>(n, 1) * sizeof(T)));
+    *cap = n;
+    return BSK_OK;
+}
+
+// Scratch of the global operators (sort, rename, faidx): ONE grow-only allocation per context, carved per call.
+// (hipMalloc / hipFree of gigabytes per call cost 110 of the 144 ms of `sort -l` on 25 GB.)
+struct Arena {
+    uint8_t* base = nullptr;
+    uint64_t used = 0;
+    uint64_t take(uint64_t bytes) { const uint64_t at = used; used = (used + bytes + 255) & ~255ull; return at; }
+    template <class T> T* at(uint64_t off) const { return reinterpret_cast<T*>(base + off); }
+};
+inline int arena_reserve(bsk_ctx* c, Arena* a) {
+    int rc = grow(c, &c->d_arena, &c->arena_cap, a->used, a->used / 8 + 256);
+    a->base = c->d_arena;
+    return rc;
+}
+
+// Open-addressing table of the key-grouping operators (rmdup, rename, pair, common, concat, grep --delete-matched):
+// d_keys for N records, `cap` slots (a power of two >= 2 N) of keys (zeroed) and first-record indices (0xFF-filled).
+int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, uint64_t** tf, hipStream_t st);
+// FASTA text view of the shard's records (text.cuh); null pointers for FASTQ
+int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
+// size array -> scan -> total / kept / kernel status (also lists the records with a very large output)
+int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept);
+void apply_long(const bsk_ctx* c, SeqParams* P);
+int empty_result(bsk_ctx* c, bsk_out* out);
+// SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
+SeqParams format_params(bsk_ctx* c, bool fastq);
+void set_bits(uint32_t* set, const std::string& letters);
+void check_id_regexp(const Options& o);
+
+}  // namespace bsk
