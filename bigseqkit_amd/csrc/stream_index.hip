@@ -257,8 +257,10 @@ struct IndexSink {
     }
 };
 
+// 7 waves per SIMD (72 VGPRs instead of the compiler's 74-75): k_index 3.20 -> 3.06 ms on 12.5 GB FASTQ, 12.7 -> 12.3 ms
+// on 50 GB FASTA (scripts/variant_index_waves.sh)
 #ifndef BSK_INDEX_WAVES
-#define BSK_INDEX_WAVES 0
+#define BSK_INDEX_WAVES 7
 #endif
 #if BSK_INDEX_WAVES
 #define BSK_INDEX_ATTR __attribute__((amdgpu_waves_per_eu(BSK_INDEX_WAVES, 8)))
