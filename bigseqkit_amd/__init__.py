@@ -10,4 +10,4 @@ from .options import (SeqKitConfig, SeqKitStatsOptions, SeqKitSeqOptions, SeqKit
                       SeqKitFq2FaOptions, SeqKitRangeOptions, SeqKitHeadOptions, SeqKitDuplicateOptions, SeqKitRenameOptions, SeqKitSortOptions, SeqKitFaidxOptions, SeqKitPairOptions, SeqKitCommonOptions, SeqKitConcatOptions)
 from .api import (SeqFrame, ReadFASTA, ReadFASTAN, ReadFASTQ, ReadFASTQN, Operator, Stats, StatsString,  # noqa: F401
                   stats_map, Seq, build_index, Grep, GrepCount, Subseq, Translate, RmDup, Locate, Fq2Fa, Range, Head,
-                  Duplicate, Count, Rename, Sort, Faidx, Pair, Common, Concat)
+                  Duplicate, Count, Rename, Sort, Faidx, Pair, Common, Concat, FaidxQuery)

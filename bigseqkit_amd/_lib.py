@@ -100,6 +100,7 @@ SIGNATURES = {
     "bsk_concat_run": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _p(Out)]),
     "bsk_common_run": (_i, [_vp, _vp, _sz, _p(C.c_uint64), C.c_uint32, _i, _i, _vp, _p(Out)]),
     "bsk_faidx_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, C.c_uint64, _vp, _p(Out)]),
+    "bsk_faidx_query_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_duplicate_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),
     "bsk_range_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, C.c_uint64, _vp, _p(Out)]),
     "bsk_range_needs_count": (_i, [_vp, _p(C.c_int)]),

@@ -327,6 +327,11 @@ def Concat(inputA, inputB, o=None, device=0):
         return buf.raw[:out.len]
 
 
+def FaidxQuery(input, o, device=0):
+    """the `queries` dataframe of bigseqkit/faidx.go:96-106 (Regions / RegionFile of the options)"""
+    return _run_records("Faidx", lib.bsk_faidx_query_run, input, o, device)[0]
+
+
 def Count(input, device=0):
     """input.Count(): records per shard (the record table of every shard is built once)"""
     counts = []

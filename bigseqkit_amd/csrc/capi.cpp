@@ -767,6 +767,12 @@ int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on
     return pair_run_device(c, d, n, n_first, format, st, outs);
 }
 
+int bsk_faidx_query_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                        bsk_out* out) {
+    (void)pid;
+    return run_record_op(c, Op::Faidx, "Faidx", faidx_query_run_device, shard, n, on_device, format, stream, out);
+}
+
 int bsk_sort_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                  bsk_out* out) {
     (void)pid;

@@ -55,7 +55,6 @@ int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, uint64_t
 }
 
 static void complement_table(Alphabet ab, uint8_t m[256]);
-static std::vector<std::string> read_pattern_lines(const std::string& path);
 
 int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
     if (!f) return BSK_OK;
@@ -485,7 +484,7 @@ static std::string read_whole_file(const std::string& path) {
 }
 
 // breader.NewDefaultBufferedReader: one pattern per line, line ends trimmed (grep.go:126-140)
-static std::vector<std::string> read_pattern_lines(const std::string& path) {
+std::vector<std::string> read_pattern_lines(const std::string& path) {
     std::vector<std::string> out;
     const std::string s = read_whole_file(path);
     for (size_t i = 0; i < s.size();) {
@@ -1233,6 +1232,36 @@ static int upload_features(bsk_ctx* c, hipStream_t st) {
     return BSK_OK;
 }
 
+// the feature set of the context (subseq --gtf / --bed, faidx region queries) on the device, bound to P
+int bind_features(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, SeqParams* P) {
+    int rc = BSK_OK;
+    if (!c->features_uploaded) {
+        rc = upload_features(c, st);
+        if (rc != BSK_OK) return rc;
+    }
+    Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+    if (rc != BSK_OK) return rc;
+    uint8_t comp[256];
+    complement_table(ab, comp);
+    if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
+    HIP_TRYX(c, hipMemcpyAsync(c->d_lut, comp, 256, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // comp lives on the host stack
+    const uint8_t* base = c->d_feat;
+    P->feat_on = 1;
+    P->fset_keys = (const uint64_t*)(base + c->feat_off[0]);
+    P->fset_idx = (const uint32_t*)(base + c->feat_off[1]);
+    P->fset_mask = c->feat_slots - 1;
+    P->fname_off = (const uint32_t*)(base + c->feat_off[2]);
+    P->fsuffix_off = (const uint32_t*)(base + c->feat_off[3]);
+    P->f_s = (const int64_t*)(base + c->feat_off[4]);
+    P->f_e = (const int64_t*)(base + c->feat_off[5]);
+    P->f_minus = base + c->feat_off[6];
+    P->fname = base + c->feat_off[7];
+    P->fsuffix = base + c->feat_off[8];
+    P->comp = c->d_lut;
+    return BSK_OK;
+}
+
 int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const bool fastq = format == BSK_FORMAT_FASTQ;
     int rc = build_index(c, d_buf, n, format, st);
@@ -1246,30 +1275,8 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         P.region_end = c->region_end;
     } else {
         if (c->features.empty()) return empty_result(c, out);  // no record can have a feature
-        if (!c->features_uploaded) {
-            rc = upload_features(c, st);
-            if (rc != BSK_OK) return rc;
-        }
-        Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+        rc = bind_features(c, d_buf, n, format, st, &P);
         if (rc != BSK_OK) return rc;
-        uint8_t comp[256];
-        complement_table(ab, comp);
-        if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
-        HIP_TRYX(c, hipMemcpyAsync(c->d_lut, comp, 256, hipMemcpyHostToDevice, st));
-        HIP_TRYX(c, hipStreamSynchronize(st));  // comp lives on the host stack
-        const uint8_t* base = c->d_feat;
-        P.feat_on = 1;
-        P.fset_keys = (const uint64_t*)(base + c->feat_off[0]);
-        P.fset_idx = (const uint32_t*)(base + c->feat_off[1]);
-        P.fset_mask = c->feat_slots - 1;
-        P.fname_off = (const uint32_t*)(base + c->feat_off[2]);
-        P.fsuffix_off = (const uint32_t*)(base + c->feat_off[3]);
-        P.f_s = (const int64_t*)(base + c->feat_off[4]);
-        P.f_e = (const int64_t*)(base + c->feat_off[5]);
-        P.f_minus = base + c->feat_off[6];
-        P.fname = base + c->feat_off[7];
-        P.fsuffix = base + c->feat_off[8];
-        P.comp = c->d_lut;
     }
     {   // wrapped FASTA: random access through the text view instead of the sequential per-record walk
         TextTableH tt{nullptr, nullptr, nullptr};

@@ -38,6 +38,7 @@ void validate_common_opts(bsk_ctx* c);
 int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t* file_ends, uint32_t nfiles, int format,
                       hipStream_t st, bsk_out* out);
 int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* out);
+int faidx_query_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 int ensure_out(bsk_ctx* c, uint64_t bytes);
 int ensure_record_scratch(bsk_ctx* c);
 Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/bsk.h"
 #include "ctx.hpp"
@@ -62,5 +63,9 @@ int empty_result(bsk_ctx* c, bsk_out* out);
 SeqParams format_params(bsk_ctx* c, bool fastq);
 void set_bits(uint32_t* set, const std::string& letters);
 void check_id_regexp(const Options& o);
+// the context's feature set (ctx.features) uploaded and bound to P: name lookup, regions, suffixes, complement map
+int bind_features(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, SeqParams* P);
+// lines of a text file ("\r\n" trimmed, empty lines skipped): pattern files, region files
+std::vector<std::string> read_pattern_lines(const std::string& path);
 
 }  // namespace bsk

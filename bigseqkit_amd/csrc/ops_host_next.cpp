@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/bsk.h"
@@ -395,12 +396,68 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
 // ---------------------------------------------------------------------------
 // faidx index rows: Faidx.Before / Call, bigseqkit-lib/faidx.go:63-229.  PARITY.md FAI.
 // ---------------------------------------------------------------------------
+// parseRegion (bigseqkit-lib/faidx.go:536-567): "id:b-e", "id:b", "id:b-", "id:-e", else the whole record; the id is
+// the shortest prefix whose remainder has one of those shapes (lazy `(.+?)`), tried shape by shape
+static void parse_faidx_region(const std::string& region, std::string* id, long long* begin, long long* end) {
+    auto number = [](const std::string& t, size_t* at, bool neg_ok, long long* v) {
+        size_t i = *at;
+        bool neg = false;
+        if (neg_ok && i < t.size() && t[i] == '-') { neg = true; ++i; }
+        const size_t d0 = i;
+        long long x = 0;
+        while (i < t.size() && t[i] >= '0' && t[i] <= '9') { x = x * 10 + (t[i] - '0'); ++i; }
+        if (i == d0) return false;
+        *v = neg ? -x : x;
+        *at = i;
+        return true;
+    };
+    for (int shape = 0; shape < 4; ++shape)
+        for (size_t c0 = 1; c0 < region.size(); ++c0) {
+            if (region[c0] != ':') continue;
+            const std::string t = region.substr(c0 + 1);
+            size_t at = 0;
+            long long b = 0, e = 0;
+            bool ok = false;
+            if (shape == 0) ok = number(t, &at, true, &b) && at < t.size() && t[at] == '-' && (++at, number(t, &at, true, &e)) && at == t.size();
+            else if (shape == 1) { ok = number(t, &at, false, &b) && at == t.size(); e = b; }
+            else if (shape == 2) { ok = number(t, &at, true, &b) && at + 1 == t.size() && t[at] == '-'; e = -1; }
+            else { ok = !t.empty() && t[0] == '-' && (at = 1, number(t, &at, true, &e)) && at == t.size(); b = 1; }
+            if (ok) { *id = region.substr(0, c0); *begin = b; *end = e; return; }
+        }
+    *id = region;
+    *begin = 1;
+    *end = -1;
+}
+
 void validate_faidx_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
     if (!o.b("FullHead")) check_id_regexp(o);  // -f swaps the ID regexp for ^(.+)$ (faidx.go:69-73)
-    if (!o.sl("Regions").empty() || !o.s("RegionFile").empty())
-        throw OptError("libbsk: faidx region queries are not provided by the HIP path (index rows only; use subseq / grep)");
+    // region queries (FaidxQuery.Before, faidx.go:246-329): the region file first, then Regions
+    c->features.clear();
+    c->features_uploaded = false;
+    std::vector<std::string> queries;
+    if (!o.s("RegionFile").empty())
+        for (auto& r : read_pattern_lines(o.s("RegionFile"))) if (!r.empty()) queries.push_back(r);
+    for (auto& r : o.sl("Regions")) queries.push_back(r);
+    if (queries.empty()) return;
+    if (o.b("UseRegexp")) throw OptError("libbsk: faidx -r (IDs as regular expressions) is not provided by the HIP path");
+    std::unordered_set<std::string> seen;
+    for (const std::string& q : queries) {
+        std::string id;
+        long long begin = 1, end = -1;
+        parse_faidx_region(q, &id, &begin, &end);
+        if (o.b("IgnoreCase")) for (auto& ch : id) if (ch >= 'A' && ch <= 'Z') ch += 32;  // strings.ToLower(id), :323
+        if (!seen.insert(id).second) continue;  // the first query of an ID is the one a record meets (:373-380)
+        bsk_ctx::Feature f;
+        f.name_lower = id;
+        const bool whole = (begin == 1 && end == -1) || (begin > 0 && end < 0);  // :388
+        f.suffix = whole ? std::string() : ":" + std::to_string(begin) + "-" + std::to_string(end);
+        f.minus = !whole && begin > end;  // :403-418, PARITY.md FAI: the region [end, begin], reverse complemented
+        f.s = f.minus ? end : begin;
+        f.e = f.minus ? begin : end;
+        c->features.push_back(f);
+    }
 }
 
 int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
@@ -752,6 +809,42 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     out->d_data = c->d_out;
     out->len = total;
     out->records = elements;
+    return BSK_OK;
+}
+
+// FaidxQuery.Call (bigseqkit-lib/faidx.go:331-432): every record whose ID has a query comes back as FASTA --
+// ">ID" or ">ID:b-e" and the region, wrapped at LineWidth; PARITY.md FAI
+int faidx_query_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    int rc = build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0 || c->features.empty()) return empty_result(c, out);
+    SeqParams P = format_params(c, fastq);
+    P.print_qual = 0;
+    P.fasta_out = 1;
+    P.line_width = (int)c->opts.ci("LineWidth");
+    P.buf_end = d_buf + n;
+    rc = bind_features(c, d_buf, n, format, st, &P);
+    if (rc != BSK_OK) return rc;
+    P.feat_query = 1;
+    P.feat_fold = c->opts.b("IgnoreCase");
+    TextTableH tt{nullptr, nullptr, nullptr};
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    apply_long(c, &P);
+    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
     return BSK_OK;
 }
 

@@ -61,7 +61,8 @@ __device__ __forceinline__ uint32_t wrapped_len(uint32_t L, int w) {
 
 // feature of a record (subseq --gtf/--bed): index into the f_* arrays or -1
 __device__ int feature_of(const SeqParams& P, const uint8_t* id, uint32_t id_len) {
-    const uint64_t key = fnv1a64(id, id_len, true);
+    const bool fold = !P.feat_query || P.feat_fold;  // subseq lower-cases the names; faidx only with -i
+    const uint64_t key = fnv1a64(id, id_len, fold);
     for (uint64_t slot = key & P.fset_mask;; slot = (slot + 1) & P.fset_mask) {
         const uint64_t sk = P.fset_keys[slot];
         if (sk == 0) return -1;
@@ -72,7 +73,7 @@ __device__ int feature_of(const SeqParams& P, const uint8_t* id, uint32_t id_len
         bool ok = true;
         for (uint32_t q = 0; q < id_len; ++q) {
             uint8_t c = id[q];
-            if (c >= 'A' && c <= 'Z') c += 32;
+            if (fold && c >= 'A' && c <= 'Z') c += 32;
             if (c != P.fname[o + q]) { ok = false; break; }
         }
         if (ok) return (int)f;
@@ -82,6 +83,7 @@ __device__ int feature_of(const SeqParams& P, const uint8_t* id, uint32_t id_len
 // region of the feature on a record of length L: subseq.go:339-376 then Seq.SubSeq; [b, e) 0-based
 __device__ __forceinline__ void feature_region(const SeqParams& P, int f, uint32_t L, uint32_t* b, uint32_t* e) {
     int64_t s = P.f_s[f], t = P.f_e[f];
+    if (P.feat_query) { sub_location(L, (int)s, (int)t, b, e); return; }  // seq.SubLocation (faidx.go:391-402)
     if (s < 1) s = 1;
     if (t > (int64_t)L) t = L;
     *b = *e = 0;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
         uint32_t b, e;
         feature_region(P, f, L, &b, &e);
         kept = e - b;
+        if (P.feat_query && kept == 0) { out_len[i] = 0; return; }  // SubLocation !ok: the record is skipped
         const uint32_t hl = il + (P.fsuffix_off[f + 1] - P.fsuffix_off[f]);
         out_len[i] = 1u + hl + 1u + wrapped_len(kept, P.line_width) + 1u + (P.print_qual ? 2u + kept + 1u : 0u);
         return;

@@ -37,6 +37,8 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     // subseq --gtf / --bed (bigseqkit-lib/subseq.go:319-526): the record's lower-cased ID selects ONE feature
     // (the first of that name); region, strand and the new header come from it
     int feat_on;
+    int feat_query;                         // faidx region queries: names compared as they are unless feat_fold, region by
+    int feat_fold;                          // SubLocation (negative positions), records whose region is empty are skipped
     const uint64_t* fset_keys;              // open-addressing set of lower-cased names (fnv1a64), 0 = empty
     const uint32_t* fset_idx;
     uint64_t fset_mask;

@@ -413,6 +413,8 @@ struct Output {
     int fmt = -1;             // format of the record text in `text` (-1: line oriented)
 };
 
+bool g_faidx_query = false;  // `faidx` with regions: records out, not index rows
+
 int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, uint64_t first_record, bsk_out* out) {
     const void* p = in.ptr();
     const size_t n = in.size();
@@ -425,6 +427,7 @@ int run_op(const std::string& use, bsk_ctx* ctx, const Part& in, int64_t pid, ui
     if (use == "fq2fa") return bsk_fq2fa_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "rename") return bsk_rename_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "sort") return bsk_sort_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
+    if (use == "faidx" && g_faidx_query) return bsk_faidx_query_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "faidx") return bsk_faidx_run(ctx, p, n, dev, in.fmt, pid, first_record /* = byte offset here */, nullptr, out);
     if (use == "duplicate") return bsk_duplicate_run(ctx, p, n, dev, in.fmt, pid, nullptr, out);
     if (use == "range" || use == "head") return bsk_range_run(ctx, p, n, dev, in.fmt, pid, first_record, nullptr, out);
@@ -494,7 +497,7 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
         return res;
     }
     const bool grep_count = use == "grep" && inv.pget("count") == "true";
-    const bool rows_out = use == "locate" || use == "faidx";  // line-oriented text, not records
+    const bool rows_out = use == "locate" || (use == "faidx" && !g_faidx_query);  // line-oriented text, not records
     const bool records_out = !(rows_out || grep_count);
     uint64_t grep_total = 0;
     bsk_ctx* ctx = nullptr;
@@ -538,7 +541,7 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
             grep_total += cnt;
             continue;
         }
-        const int ofmt = use == "translate" || use == "fq2fa" ? BSK_FORMAT_FASTA : in.fmt;
+        const int ofmt = use == "translate" || use == "fq2fa" || use == "faidx" ? BSK_FORMAT_FASTA : in.fmt;
         if (!ctx) {  // device-resident part owned by its context
             Part o;
             o.fmt = ofmt;
@@ -661,12 +664,22 @@ int main(int argc, char** argv) {
         return 0;
     }
     Invocation inv = parse_invocation(args);
+    bool faidx_query = false;
+    if (std::string(inv.cmd->use) == "faidx") {
+        // cli/faidx.go: the first argument is the file, the others are regions ("id", "id:b-e", ...)
+        std::string regions;
+        for (size_t k = 1; k < inv.files.size(); ++k) regions += (k > 1 ? "," : "") + jquote(inv.files[k]);
+        if (inv.files.size() > 1) inv.files.resize(1);
+        inv.js.insert(inv.js.rfind('}'), ",\"Regions\":[" + regions + "]");
+        faidx_query = !regions.empty() || !inv.pget("region-file").empty();
+    }
     if (inv.pget("dry-run") == "true") {
         std::cout << inv.cmd->op << "\n" << inv.js << "\n";
         for (auto& f : inv.files) std::cout << f << "\n";
         return 0;
     }
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
+    g_faidx_query = faidx_query;
     std::vector<Part> inputs = read_parts(inv.files);
     if (std::string(inv.cmd->use) == "concat") {
         if (inputs.size() != 2) die("2 files needed");

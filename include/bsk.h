@@ -222,9 +222,15 @@ int bsk_pair_run(bsk_ctx* ctx, const void* shard, size_t n, size_t n_first, int 
  * record, "<ID>\t<length>\t<offset>\t<linebases>\t<linewidth>[\t<qualoffset>]" (the .fai columns; FullHead prints the
  * whole header as the name).  base_offset = file offset of the shard's first byte (what the FaidxOffset pass
  * accumulates per partition).  Records whose sequence lines do not have the .fai shape fail with the reference's
- * "different line length in sequence: <ID>" error.  Region queries (Regions / RegionFile) are rejected at bsk_create. */
+ * "different line length in sequence: <ID>" error. */
 int bsk_faidx_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t base_offset,
                   void* stream, bsk_out* out);
+
+/* Region queries of the same context (FaidxQuery, bigseqkit-lib/faidx.go:231-432): with Regions / RegionFile in the
+ * options ("id", "id:b-e", "id:b", "id:b-", "id:-e"; negative positions count from the end; b > e = reverse complement),
+ * every record whose ID has a query comes back as FASTA: ">ID" or ">ID:b-e" and the region.  UseRegexp is rejected. */
+int bsk_faidx_query_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
+                        bsk_out* out);
 
 /* ---- Sort (bigseqkit/sort.go:91-147; SortParseInputString / SortParseInputInt + SortByKey, bigseqkit-lib/sort.go):
  * by ID (default), full name (ByName), sequence prefix (BySeq, SeqPrefixLength), length (ByLength) or non-gap bases

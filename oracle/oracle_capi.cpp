@@ -401,6 +401,23 @@ int orc_pair(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int fastq
     } catch (const std::exception& e) { return fail(err, errcap, e); }
 }
 
+// queries: newline-joined region strings
+int orc_faidx_query(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, const char* queries, int ignore_case,
+                    uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        std::vector<std::string> qs;
+        std::string all = queries ? queries : "";
+        for (size_t a = 0; a < all.size();) {
+            size_t b = all.find('\n', a);
+            if (b == std::string::npos) b = all.size();
+            if (b > a) qs.push_back(all.substr(a, b - a));
+            a = b + 1;
+        }
+        return emit(faidx_query_call(recs, qs, ignore_case != 0, conv(*cfg)), out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // faidx index rows over nparts partitions (offsets = prefix sums of the partition sizes)
 int orc_faidx(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, int full_head, int nparts, uint8_t* out,
               size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {

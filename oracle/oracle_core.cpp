@@ -2064,4 +2064,50 @@ std::vector<std::string> concat_call(const std::vector<std::string_view>& a, con
     return result;
 }
 
+// parseRegion  bigseqkit-lib/faidx.go:536-567 (the four Go regexps, lazy id)
+static void parse_faidx_region(const std::string& region, std::string* id, long* begin, long* end) {
+    static const std::regex full("^(.+?):(-?\\d+)-(-?\\d+)$"), one("^(.+?):(\\d+)$"), onlyb("^(.+?):(-?\\d+)-$"),
+        onlye("^(.+?):-(-?\\d+)$");
+    std::smatch m;
+    if (std::regex_match(region, m, full)) { *id = m[1]; *begin = atol(m[2].str().c_str()); *end = atol(m[3].str().c_str()); }
+    else if (std::regex_match(region, m, one)) { *id = m[1]; *begin = atol(m[2].str().c_str()); *end = *begin; }
+    else if (std::regex_match(region, m, onlyb)) { *id = m[1]; *begin = atol(m[2].str().c_str()); *end = -1; }
+    else if (std::regex_match(region, m, onlye)) { *id = m[1]; *begin = 1; *end = atol(m[2].str().c_str()); }
+    else { *id = region; *begin = 1; *end = -1; }
+}
+
+std::vector<std::string> faidx_query_call(const std::vector<std::string_view>& part, const std::vector<std::string>& queries,
+                                          bool ignore_case, const KitConfig& cfg) {
+    Alphabet ab = alphabet_from_seqtype(cfg.SeqType);
+    struct Q { std::string id; long b, e; };
+    std::vector<Q> qs;
+    for (auto& r : queries) {                              // :316-327
+        Q q;
+        parse_faidx_region(r, &q.id, &q.b, &q.e);
+        if (ignore_case) q.id = lower(q.id);
+        qs.push_back(q);
+    }
+    SeqParser rd(ab, &part, cfg.IDRegexp, cfg.AlphabetGuessSeqLength);
+    std::vector<std::string> result;
+    while (rd.Read()) {
+        const Record& r = rd.rec;
+        std::string id = ignore_case ? lower(r.id) : r.id;  // :369-372
+        const Q* hit = nullptr;
+        for (auto& q : qs) if (q.id == id) { hit = &q; break; }   // :373-380
+        if (!hit) continue;
+        const bool whole = (hit->b == 1 && hit->e == -1) || (hit->b > 0 && hit->e < 0);  // :388
+        const bool rc = !whole && hit->b > hit->e;
+        size_t b0, e0;
+        sub_location(r.seq.size(), (int)(rc ? hit->e : hit->b), (int)(rc ? hit->b : hit->e), &b0, &e0);
+        if (b0 == e0) continue;                              // !ok
+        std::string sub = r.seq.substr(b0, e0 - b0);
+        if (rc) sub = rev_com(sub, rd.GetAlphabet());
+        std::string head = r.id;                             // parseHeadID(record.Name)
+        std::string text = ">" + head + (whole ? "" : ":" + std::to_string(hit->b) + "-" + std::to_string(hit->e)) + "\n" +
+                           wrap_byte_slice(sub, cfg.LineWidth);
+        result.push_back(text);
+    }
+    return result;
+}
+
 }  // namespace orc

@@ -256,6 +256,11 @@ void pair_call(const std::vector<std::string_view>& a, const std::vector<std::st
 std::vector<std::string> faidx_call(const std::vector<std::string_view>& part, uint64_t base, bool full_head,
                                     const KitConfig& cfg, uint64_t* bytes);
 
+// FaidxQuery.Before + Call  bigseqkit-lib/faidx.go:246-432 (PARITY.md FAI: `ok` is reset per record, b > e is the
+// reverse complement of [e, b]); queries = region file lines then Regions; no -r
+std::vector<std::string> faidx_query_call(const std::vector<std::string_view>& part, const std::vector<std::string>& queries,
+                                          bool ignore_case, const KitConfig& cfg);
+
 struct SortOptions {  // bigseqkit/sort.go:13-39
     KitConfig Config;
     bool InNaturalOrder = false, BySeq = false, ByName = false, ByLength = false, ByBases = false;

@@ -455,3 +455,19 @@ def concat(a, b, fastq, opts_json="{}"):
         if rc:
             raise OracleError(err.value.decode())
         return out.raw[:n.value]
+
+
+def faidx_query(data, fastq, opts_json):
+    d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
+    cfg = _cfg(d)
+    qs = []
+    if d.get("RegionFile"):
+        qs += [l.rstrip("\r") for l in open(d["RegionFile"]).read().split("\n") if l.strip("\r")]
+    qs += list(d.get("Regions") or [])
+    cap = 2 * len(data) + 4096
+    out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+    rc = _lib.orc_faidx_query(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(cfg), "\n".join(qs).encode(),
+                              int(bool(d.get("IgnoreCase"))), out, C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+    if rc:
+        raise OracleError(err.value.decode())
+    return out.raw[:n.value]

@@ -215,6 +215,17 @@ def test_cli_global_commands_join_files_that_lack_a_final_newline(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_faidx_rows_and_region_queries(tmp_path):
+    fa = b">chr1 x\nACGTACGTAC\nGGGGGTTTTT\n>chr2\nAAAACCCC\n"
+    path = _write(tmp_path, "g.fa", fa)
+    assert run("faidx", path, "-o", "-").stdout == oracle.faidx(fa, False) == b"chr1\t20\t8\t10\t11\nchr2\t8\t36\t8\t9\n"
+    got = run("faidx", path, "chr1:2-5", "chr2:-3", "chr1:9-1", "-o", "-").stdout
+    assert got == b">chr1:2-5\nCGTA\n>chr2:1-3\nAAA\n" == oracle.faidx_query(fa, False, '{"Regions": ["chr1:2-5", "chr2:-3", "chr1:9-1"]}')
+    rf = _write(tmp_path, "r.txt", b"chr2:5-\nCHR1:12-15\n")
+    assert run("faidx", "-i", "-l", rf, path, "-w", "2", "-o", "-").stdout == b">chr1:12-15\nGG\nGG\n>chr2\nCC\nCC\n"
+
+
+@pytest.mark.gpu
 def test_cli_range_indexes_the_union_of_its_inputs_and_chains_in_a_pipe(tmp_path):
     rng = random.Random(8)
     d1, d2 = seqgen.random_fastq(rng, 120, min_len=1), seqgen.random_fastq(rng, 90, min_len=1)

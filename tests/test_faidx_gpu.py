@@ -50,9 +50,6 @@ def test_faidx_hand_cases():
     # one change of width, downwards, is what the reference accepts (also in the middle)
     ok = b">a\nACGTAC\nACGTAC\nACG\nACG\n"
     assert bsk.Faidx(frame(ok, False)) == oracle.faidx(ok, False) == b"a\t18\t3\t6\t7\n"
-    with pytest.raises(bsk.BskError) as e:
-        bsk.Faidx(frame(fa, False), _Opts({"Regions": ["a:1-5"]}))
-    assert "region queries" in str(e.value)
 
 
 @pytest.mark.parametrize("width", [60, 0, 7, 16])
@@ -75,3 +72,43 @@ def test_faidx_fastq_and_long_records(monkeypatch):
     big = "".join(rng.choice("ACGT") for _ in range(400_000))
     fa = (">chr1 x\n" + "".join(big[j:j + 60] + "\n" for j in range(0, len(big), 60)) + ">chr2\nACGT\n").encode()
     assert bsk.Faidx(frame(fa, False)) == oracle.faidx(fa, False) == b"chr1\t400000\t8\t60\t61\nchr2\t4\t406681\t4\t5\n"
+
+
+# ---------------------------------------------------------------- region queries (FaidxQuery)
+QUERIES = [["chr1"], ["chr1:2-5", "chr2:-3", "chr2:1-2"], ["chr1:5-2"], ["chr1:-5--1"], ["chr1:3"], ["chr1:15-"], ["chr3"], ["chr9"],
+           ["chr2:100-200"], ["Chr3:2-", "chr1:-4", "x:y:1-2"]]
+
+
+@pytest.mark.parametrize("qi", range(len(QUERIES)))
+def test_faidx_queries_hand_cases(qi, tmp_path):
+    fa = b">chr1 x\nACGTACGTAC\nGGGGGTTTTT\n>chr2\nAAAACCCC\n>Chr3\nTTTT\n>x:y d\nACGTT\n"
+    for extra in ({}, {"IgnoreCase": True}, {"Config": {"LineWidth": 3}}):
+        o = dict({"Regions": QUERIES[qi]}, **extra)
+        assert bsk.FaidxQuery(frame(fa, False), _Opts(o)) == oracle.faidx_query(fa, False, json.dumps(o)), o
+    rf = tmp_path / "regions.txt"
+    rf.write_text("\n".join(QUERIES[qi]) + "\n\n")
+    o = {"RegionFile": str(rf), "Regions": ["chr2:2-3"]}
+    assert bsk.FaidxQuery(frame(fa, False), _Opts(o)) == oracle.faidx_query(fa, False, json.dumps(o))
+
+
+def test_faidx_queries_random_and_fastq(monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(8)
+    for fastq in (False, True):
+        data = seqgen.random_fastq(rng, 300, 0, 150) if fastq else seqgen.random_fasta(rng, 300, 0, 400, width=60)
+        ids = [f"r{k}" if fastq else f"s{k}" for k in range(300)]
+        qs = []
+        for _ in range(120):
+            i = rng.choice(ids)
+            kind = rng.randrange(6)
+            b, e = rng.randint(-60, 120), rng.randint(-60, 120)
+            if b == 0: b = 1
+            if e == 0: e = -1
+            qs.append([i, f"{i}:{b}-{e}", f"{i}:{abs(b)}", f"{i}:{b}-", f"{i}:-{abs(e)}", i.upper()][kind])
+        for extra in ({}, {"IgnoreCase": True}):
+            o = dict({"Regions": qs}, **extra)
+            want = oracle.faidx_query(data, fastq, json.dumps(o))
+            assert bsk.FaidxQuery(frame(data, fastq), _Opts(o)) == want and len(want) > 100
+    with pytest.raises(bsk.BskError) as e:
+        bsk.FaidxQuery(frame(b">a\nA\n", False), _Opts({"Regions": ["a"], "UseRegexp": True}))
+    assert "not provided" in str(e.value)

@@ -124,7 +124,11 @@ def test_faidx_rows_are_the_fai_columns_with_true_offsets():
         oracle.faidx(b">a\nACGT\nACGTAC\nAC\n", False)
     assert "different line length in sequence: a." in str(e.value)
     with pytest.raises(bsk.BskError):
-        bsk.Operator("Faidx", '{"Regions": ["chr1:1-10"]}', -1)
+        bsk.Operator("Faidx", '{"Regions": ["chr1:1-10"], "UseRegexp": true}', -1)
+    fq = b">chr1 x\nACGTACGTAC\nGGGGGTTTTT\n>chr2\nAAAACCCC\n"
+    assert oracle.faidx_query(fq, False, '{"Regions": ["chr1:2-5", "chr2:-3", "chr2:1-2", "chr1:5-2"]}') == b">chr1:2-5\nCGTA\n>chr2:1-3\nAAA\n"
+    assert oracle.faidx_query(fq, False, '{"Regions": ["chr1:5-2"]}') == b">chr1:5-2\nTACG\n"
+    assert oracle.faidx_query(fq, False, '{"Regions": ["chr1:15-"]}') == b">chr1\nGTTTTT\n"
 
 
 def test_pair_kth_with_kth_and_the_rest_unpaired():
