@@ -18,6 +18,7 @@
 #include "ops_host_internal.hpp"
 #include "ops_concat.hpp"
 #include "ops_faidx.hpp"
+#include "ops_grep.hpp"
 #include "ops_group.hpp"
 #include "ops_records.hpp"
 #include "ops_rmdup.hpp"
@@ -441,7 +442,18 @@ void validate_faidx_opts(bsk_ctx* c) {
         for (auto& r : read_pattern_lines(o.s("RegionFile"))) if (!r.empty()) queries.push_back(r);
     for (auto& r : o.sl("Regions")) queries.push_back(r);
     if (queries.empty()) return;
-    if (o.b("UseRegexp")) throw OptError("libbsk: faidx -r (IDs as regular expressions) is not provided by the HIP path");
+    c->regexes.clear();
+    c->patterns_uploaded = false;
+    if (o.b("UseRegexp")) {  // :312-319: every query is a regular expression on the ID, the region is the whole record
+        for (const std::string& q : queries) {
+            try { c->regexes.push_back(compile_regex(q)); }
+            catch (const OptError& e) {
+                if (std::string(e.what()).rfind("error parsing regexp", 0) == 0) throw OptError("invalid regular expression: " + q);
+                throw;
+            }
+        }
+        return;
+    }
     std::unordered_set<std::string> seen;
     for (const std::string& q : queries) {
         std::string id;
@@ -818,12 +830,58 @@ int faidx_query_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int forma
     const bool fastq = format == BSK_FORMAT_FASTQ;
     int rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
-    if (c->table.n == 0 || c->features.empty()) return empty_result(c, out);
+    if (c->table.n == 0 || (c->features.empty() && c->regexes.empty())) return empty_result(c, out);
     SeqParams P = format_params(c, fastq);
     P.print_qual = 0;
     P.fasta_out = 1;
     P.line_width = (int)c->opts.ci("LineWidth");
     P.buf_end = d_buf + n;
+    if (!c->regexes.empty()) {
+        // -r: hits = records whose ID matches one of the expressions (the grep -r automaton), printed as ">ID" + sequence
+        const uint64_t N = c->table.n;
+        if (!c->patterns_uploaded) {
+            rc = grow(c, &c->d_regex, &c->regex_cap, c->regexes.size());
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemcpyAsync(c->d_regex, c->regexes.data(), c->regexes.size() * sizeof(RegexProgram),
+                                       hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            c->patterns_uploaded = true;
+        }
+        TextTableH tt{nullptr, nullptr, nullptr};
+        rc = prepare_text(c, d_buf, format, st, &tt);
+        if (rc != BSK_OK) return rc;
+        P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
+        P.only_id = 1;
+        P.min_len = 1;  // SubLocation of an empty sequence is not ok: the record is skipped (faidx.go:391-395)
+        rc = ensure_record_scratch(c);
+        if (rc != BSK_OK) return rc;
+        Arena A;
+        const uint64_t o_hits = A.take(N * 4);
+        rc = arena_reserve(c, &A);
+        if (rc != BSK_OK) return rc;
+        uint32_t* d_hits = A.at<uint32_t>(o_hits);
+        GrepParams G;
+        memset(&G, 0, sizeof G);
+        G.fastq = fastq;
+        G.id_mode = P.id_mode;
+        G.line_width = P.line_width;
+        G.npat = (int)c->regexes.size();
+        G.regex = c->d_regex;
+        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, d_hits, st));
+        HIP_TRYX(c, launch_seq_size(d_buf, c->table, P, c->d_out_len, c->d_status, st));
+        HIP_TRYX(c, launch_mask_u32(c->d_out_len, d_hits, N, st));
+        uint64_t total = 0, kept = 0;
+        rc = finish_sizes(c, st, &total, &kept);
+        if (rc != BSK_OK) return rc;
+        rc = ensure_out(c, total);
+        if (rc != BSK_OK) return rc;
+        apply_long(c, &P);
+        HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+        out->d_data = c->d_out;
+        out->len = total;
+        out->records = kept;
+        return BSK_OK;
+    }
     rc = bind_features(c, d_buf, n, format, st, &P);
     if (rc != BSK_OK) return rc;
     P.feat_query = 1;

@@ -228,7 +228,8 @@ int bsk_faidx_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int 
 
 /* Region queries of the same context (FaidxQuery, bigseqkit-lib/faidx.go:231-432): with Regions / RegionFile in the
  * options ("id", "id:b-e", "id:b", "id:b-", "id:-e"; negative positions count from the end; b > e = reverse complement),
- * every record whose ID has a query comes back as FASTA: ">ID" or ">ID:b-e" and the region.  UseRegexp is rejected. */
+ * every record whose ID has a query comes back as FASTA: ">ID" or ">ID:b-e" and the region.  With UseRegexp the
+ * queries are regular expressions on the ID and the hits come back whole. */
 int bsk_faidx_query_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                         bsk_out* out);
 

@@ -403,7 +403,7 @@ int orc_pair(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int fastq
 
 // queries: newline-joined region strings
 int orc_faidx_query(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig* cfg, const char* queries, int ignore_case,
-                    uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+                    int use_regexp, uint8_t* out, size_t cap, size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
     try {
         auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
         std::vector<std::string> qs;
@@ -414,7 +414,7 @@ int orc_faidx_query(const uint8_t* buf, size_t n, int fastq, const orc_kitconfig
             if (b > a) qs.push_back(all.substr(a, b - a));
             a = b + 1;
         }
-        return emit(faidx_query_call(recs, qs, ignore_case != 0, conv(*cfg)), out, cap, nout, nrec);
+        return emit(faidx_query_call(recs, qs, ignore_case != 0, conv(*cfg), use_regexp != 0), out, cap, nout, nrec);
     } catch (const std::exception& e) { return fail(err, errcap, e); }
 }
 

@@ -2077,8 +2077,24 @@ static void parse_faidx_region(const std::string& region, std::string* id, long*
 }
 
 std::vector<std::string> faidx_query_call(const std::vector<std::string_view>& part, const std::vector<std::string>& queries,
-                                          bool ignore_case, const KitConfig& cfg) {
+                                          bool ignore_case, const KitConfig& cfg, bool use_regexp) {
     Alphabet ab = alphabet_from_seqtype(cfg.SeqType);
+    if (use_regexp) {  // :312-319, :362-368: a record whose ID matches any expression comes back whole
+        std::vector<std::regex> res;
+        for (auto& q : queries) {
+            try { res.emplace_back(q, std::regex::ECMAScript); }
+            catch (const std::regex_error&) { throw Error("invalid regular expression: " + q); }
+        }
+        SeqParser rd(ab, &part, cfg.IDRegexp, cfg.AlphabetGuessSeqLength);
+        std::vector<std::string> result;
+        while (rd.Read()) {
+            bool ok = false;
+            for (auto& re : res) if (std::regex_search(rd.rec.id, re)) { ok = true; break; }
+            if (!ok || rd.rec.seq.empty()) continue;   // SubLocation of an empty sequence is not ok
+            result.push_back(">" + rd.rec.id + "\n" + wrap_byte_slice(rd.rec.seq, cfg.LineWidth));
+        }
+        return result;
+    }
     struct Q { std::string id; long b, e; };
     std::vector<Q> qs;
     for (auto& r : queries) {                              // :316-327

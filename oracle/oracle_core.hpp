@@ -257,9 +257,9 @@ std::vector<std::string> faidx_call(const std::vector<std::string_view>& part, u
                                     const KitConfig& cfg, uint64_t* bytes);
 
 // FaidxQuery.Before + Call  bigseqkit-lib/faidx.go:246-432 (PARITY.md FAI: `ok` is reset per record, b > e is the
-// reverse complement of [e, b]); queries = region file lines then Regions; no -r
+// reverse complement of [e, b]); queries = region file lines then Regions; -r: std::regex stands in for Go regexp
 std::vector<std::string> faidx_query_call(const std::vector<std::string_view>& part, const std::vector<std::string>& queries,
-                                          bool ignore_case, const KitConfig& cfg);
+                                          bool ignore_case, const KitConfig& cfg, bool use_regexp = false);
 
 struct SortOptions {  // bigseqkit/sort.go:13-39
     KitConfig Config;

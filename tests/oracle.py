@@ -467,7 +467,8 @@ def faidx_query(data, fastq, opts_json):
     cap = 2 * len(data) + 4096
     out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
     rc = _lib.orc_faidx_query(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(cfg), "\n".join(qs).encode(),
-                              int(bool(d.get("IgnoreCase"))), out, C.c_size_t(cap), C.byref(n), C.byref(nrec), err, _ERR)
+                              int(bool(d.get("IgnoreCase"))), int(bool(d.get("UseRegexp"))), out, C.c_size_t(cap), C.byref(n),
+                              C.byref(nrec), err, _ERR)
     if rc:
         raise OracleError(err.value.decode())
     return out.raw[:n.value]

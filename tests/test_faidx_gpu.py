@@ -109,6 +109,13 @@ def test_faidx_queries_random_and_fastq(monkeypatch):
             o = dict({"Regions": qs}, **extra)
             want = oracle.faidx_query(data, fastq, json.dumps(o))
             assert bsk.FaidxQuery(frame(data, fastq), _Opts(o)) == want and len(want) > 100
+    # -r: the queries are regular expressions on the ID, the hits come back whole
+    fa = seqgen.random_fasta(rng, 200, 0, 300, width=60)
+    for qs in (["^s1\\d$"], ["7$", "^s2"], ["s(3|4)5", "zzz"], ["^S1"]):
+        o = {"Regions": qs, "UseRegexp": True, "Config": {"LineWidth": 40}}
+        want = oracle.faidx_query(fa, False, json.dumps(o))
+        assert bsk.FaidxQuery(frame(fa, False), _Opts(o)) == want, qs
+    assert len(oracle.faidx_query(fa, False, json.dumps({"Regions": ["7$", "^s2"], "UseRegexp": True}))) > 500
     with pytest.raises(bsk.BskError) as e:
-        bsk.FaidxQuery(frame(b">a\nA\n", False), _Opts({"Regions": ["a"], "UseRegexp": True}))
-    assert "not provided" in str(e.value)
+        bsk.FaidxQuery(frame(b">a\nA\n", False), _Opts({"Regions": ["a("], "UseRegexp": True}))
+    assert "invalid regular expression: a(" in str(e.value)
