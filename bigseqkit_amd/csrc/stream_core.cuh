@@ -444,9 +444,6 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
             // events of this tile, CAP at a time (one batch for ordinary data).  The newline masks of
             // the pieces are merged into one 64-bit word so that ONE loop visits every newline of the
             // lane (~3 iterations per tile for 150 bp reads instead of ~2 per piece).
-    #ifndef BSK_EXPERIMENT
-            static_assert(NPIECE <= 4, "merged emission packs at most four 16-bit masks");
-#endif
             // word h of a merged mask holds pieces 2h (low nibbles) and 2h + 1 (high nibbles)
             static_assert(NPIECE == 4, "the dense path merges exactly four pieces");
             constexpr uint32_t LOW = 0x0F0F0F0Fu;
