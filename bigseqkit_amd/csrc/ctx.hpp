@@ -96,6 +96,7 @@ struct bsk_ctx {
     uint32_t* d_pat_off = nullptr;
     uint64_t pat_cap = 0, pat_off_cap = 0;
     std::vector<std::string> pattern_names;  // locate: names as given (== the -p text, or the FASTA name with -f)
+    std::vector<std::string> pattern_disp;   // locate -r: the expressions (pattern column); patterns[] then only carries the match length
     // class patterns (-d, -m, -F): one 256-bit accept set per pattern position (pattern_match.cuh)
     std::vector<std::vector<std::array<uint32_t, 8>>> pattern_cls;
     bool general = false;     // match through pattern_cls instead of the exact byte compare

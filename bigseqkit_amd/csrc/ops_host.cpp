@@ -858,13 +858,13 @@ void validate_locate_opts(bsk_ctx* c) {
         if (o.b("Degenerate")) throw OptError("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
         if (o.b("UseRegexp")) throw OptError("flag -r (--use-regexp) ignored when giving flag -F (--use-fmi)");
     }
-    if (o.b("UseRegexp")) throw OptError("libbsk: regexp (-r) is not supported by the HIP path yet");
     c->patterns.clear();
     c->pattern_names.clear();
+    c->pattern_disp.clear();
     c->pattern_cls.clear();
     c->max_mm = (int)o.i("MaxMismatch");
     c->fmi_order = c->max_mm > 0 || o.b("UseFmi");
-    c->general = o.b("Degenerate") || c->fmi_order;
+    c->general = o.b("Degenerate") || o.b("UseRegexp") || c->fmi_order;
     std::vector<std::pair<std::string, std::string>> given;  // (name, sequence)
     const bool from_file = !o.s("PatternFile").empty();
     if (from_file) {
@@ -872,6 +872,34 @@ void validate_locate_opts(bsk_ctx* c) {
         if (given.empty()) throw OptError("no FASTA sequences found in pattern file: " + o.s("PatternFile"));
     } else {
         for (const std::string& p : o.sl("Pattern")) if (!p.empty()) given.emplace_back(p, p);
+    }
+    if (o.b("UseRegexp")) {
+        // locate.go:102-121, 153-172: the regexp branch shares the search loop of -d (FindSubmatchIndex from a moving
+        // offset).  Provided for expressions that are a fixed-length chain of literals, '.', classes and escapes -- they
+        // become class patterns, for which leftmost-first matching has nothing to choose; quantifiers, alternation,
+        // groups with choices and anchors need Go's match priorities and are rejected (PARITY.md LOCRE).
+        for (auto& g : given) {
+            if (std::find(c->pattern_names.begin(), c->pattern_names.end(), g.first) != c->pattern_names.end()) continue;
+            const RegexProgram pr = compile_regex(o.b("IgnoreCase") ? "(?i)" + g.second : g.second);  // :104-106
+            bool chain = pr.npos > 0 && !pr.nullable && pr.first == 1ull && pr.last == (1ull << (pr.npos - 1)) &&
+                         pr.accept[RE_SYM_BEGIN] == 0 && pr.accept[RE_SYM_END] == 0;
+            for (uint32_t q = 0; chain && q < pr.npos; ++q)
+                chain = pr.follow[q >> 3][1u << (q & 7)] == (q + 1 < pr.npos ? (1ull << (q + 1)) : 0ull);
+            if (!chain)
+                throw OptError("libbsk: locate -r is provided for fixed-length expressions (literals, '.', [classes], escapes); `" +
+                               g.second + "` needs regexp match priorities");
+            std::vector<ByteSet> sets(pr.npos);
+            for (uint32_t q = 0; q < pr.npos; ++q) {
+                sets[q].fill(0);
+                for (int b = 0; b < 256; ++b)
+                    if ((pr.accept[b] >> q) & 1ull) set_add(sets[q], (uint8_t)b);
+            }
+            c->pattern_cls.push_back(sets);
+            c->pattern_names.push_back(g.first);
+            c->pattern_disp.push_back(g.second);
+            c->patterns.push_back(std::string(pr.npos, 'N'));  // carries the match length only
+        }
+        return;
     }
     for (auto& g : given) {  // locate.go:86-190
         std::string eff = g.second;
@@ -946,13 +974,17 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             P.max_mm = c->max_mm;
             P.cls = c->d_cls;
             P.fmi_order = c->fmi_order;
-            P.matched_lower = !o.b("Degenerate") && o.b("IgnoreCase");  // locate.go:430-432 lower-cases the text
+            P.matched_lower = !o.b("Degenerate") && !o.b("UseRegexp") && o.b("IgnoreCase");  // locate.go:430-432 lower-cases the text
             P.comp = c->d_lut;
         }
         {
             std::vector<uint8_t> bytes;
             std::vector<uint32_t> off{0};
             for (auto& p : c->pattern_names) {
+                bytes.insert(bytes.end(), p.begin(), p.end());
+                off.push_back((uint32_t)bytes.size());
+            }
+            for (auto& p : c->pattern_disp) {  // after the names: off[npat + k] .. off[npat + k + 1]
                 bytes.insert(bytes.end(), p.begin(), p.end());
                 off.push_back((uint32_t)bytes.size());
             }
@@ -966,6 +998,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         }
         P.name = c->d_names;
         P.name_off = c->d_names_off;
+        if (!c->pattern_disp.empty()) { P.disp = c->d_names; P.disp_off = c->d_names_off + c->pattern_names.size(); }
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
         rc = grow(c, &c->d_hit_list, &c->hit_list_cap, c->table.n, c->table.n / 8 + 16);

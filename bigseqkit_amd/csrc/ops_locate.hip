@@ -65,6 +65,7 @@ struct RowCtx {
     const uint8_t* id; uint32_t id_len;
     const uint8_t* name; uint32_t name_len;
     const uint8_t* pat; uint32_t pat_len;
+    const uint8_t* disp; uint32_t disp_len;  // pattern column (== pat unless the pattern is a regular expression)
     int format;
     // matched column taken from the text (class patterns): m letters from forward position f, reverse-complemented on '-'
     bool from_text, rc, lower;
@@ -93,7 +94,7 @@ __device__ __forceinline__ uint32_t row_len(const RowCtx& r, int64_t begin, int6
         case 3:  // "%s\t%d\t%d\t%s\t0\t%c\n"
             return r.id_len + 1 + dec_len_s(begin - 1) + 1 + dec_len_s(end) + 1 + r.name_len + 3 + 1 + 1;
         default: {
-            uint32_t n = r.id_len + 1 + r.name_len + 1 + r.pat_len + 1 + 1 + 1 + dec_len_s(begin) + 1 + dec_len_s(end);
+            uint32_t n = r.id_len + 1 + r.name_len + 1 + r.disp_len + 1 + 1 + 1 + dec_len_s(begin) + 1 + dec_len_s(end);
             if (r.format == 0) n += 1 + r.pat_len;
             return n + 1;
         }
@@ -123,7 +124,7 @@ __device__ uint32_t row_put(uint8_t* o, const RowCtx& r, char strand, int64_t be
     } else {
         o[n++] = '\t';
         n += put_bytes(o + n, r.name, r.name_len); o[n++] = '\t';
-        n += put_bytes(o + n, r.pat, r.pat_len); o[n++] = '\t';
+        n += put_bytes(o + n, r.disp, r.disp_len); o[n++] = '\t';
         o[n++] = (uint8_t)strand; o[n++] = '\t';
         n += put_dec_s(o + n, begin); o[n++] = '\t';
         n += put_dec_s(o + n, end);
@@ -282,6 +283,8 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
         R.name_len = P.name_off[k + 1] - P.name_off[k];
         R.pat = P.pat + P.pat_off[k];
         R.pat_len = P.pat_off[k + 1] - P.pat_off[k];
+        R.disp = P.disp ? P.disp + P.disp_off[k] : R.pat;
+        R.disp_len = P.disp ? P.disp_off[k + 1] - P.disp_off[k] : R.pat_len;
         R.rc = strand != 0;
         const uint32_t m = R.pat_len;
         {

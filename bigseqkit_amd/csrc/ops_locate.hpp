@@ -25,6 +25,9 @@ struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go
     int fmi_order;           // -m / -F: all patterns on '+', then all on '-'; no +l shift of '-' coordinates (locate.go:208-391)
     int matched_lower;       // the matched column shows the lower-cased text (-i without -d)
     const uint8_t* comp;     // 256-byte complement map of the shard's alphabet ('-' strand matched column)
+    // -r: the pattern column shows the expression, whose length is not the match length (null: the pattern itself)
+    const uint8_t* disp;
+    const uint32_t* disp_off;
     // records with at least one row: appended (any order) by the count pass, the emit pass runs over them only
     uint32_t* hit_list;
     uint64_t* hit_count;

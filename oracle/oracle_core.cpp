@@ -1218,8 +1218,8 @@ std::vector<std::string> locate_call(const std::vector<std::string_view>& part, 
         if (o.Degenerate) throw Error("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
         if (o.UseRegexp) throw Error("flag -r (--use-regexp) ignored when giving flag -F (--use-fmi)");
     }
-    if (o.UseRegexp) throw Error("oracle: regexp locate is not restated");
-    struct Pat { std::string name, bytes; MiniRe re; };
+    // -r: std::regex (ECMAScript) stands in for Go regexp, as in grep_call
+    struct Pat { std::string name, bytes; MiniRe re; std::regex sre; };
     std::vector<Pat> pats;  // CLI / file order (PARITY.md Q11)
     std::vector<std::pair<std::string, std::string>> given;
     if (!o.PatternFile.empty()) {
@@ -1234,7 +1234,17 @@ std::vector<std::string> locate_call(const std::vector<std::string_view>& part, 
         pt.bytes = g.second;
         std::string re;
         if (o.Degenerate) re = degenerate2regexp(g.second, !o.PatternFile.empty() ? AB_UNLIMIT : ab);
+        else if (o.UseRegexp) {  // locate.go:102-121
+            try { pt.sre = std::regex(g.second, o.IgnoreCase ? std::regex::ECMAScript | std::regex::icase : std::regex::ECMAScript); }
+            catch (const std::regex_error& e) { throw Error(std::string("error parsing regexp: ") + e.what() + ": `" + g.second + "`"); }
+        }
         else if (o.IgnoreCase) pt.bytes = lower(pt.bytes);
+        if (o.UseRegexp) {
+            bool dup = false;
+            for (auto& q : pats) if (q.name == pt.name) dup = true;
+            if (!dup) pats.push_back(pt);
+            continue;
+        }
         if (o.MaxMismatch > 0) {
             if (o.MaxMismatch > (int)pt.bytes.size()) throw Error("mismatch should be <= length of sequence: " + g.second);
             if (!(alphabet_is_valid(AB_DNAredundant, pt.bytes) || alphabet_is_valid(AB_RNAredundant, pt.bytes) ||
@@ -1280,7 +1290,7 @@ std::vector<std::string> locate_call(const std::vector<std::string_view>& part, 
             if (rd.GetAlphabet() == AB_UNLIMIT || rd.GetAlphabet() == AB_PROTEIN) onlyPosAuto = true;
             checkAlphabet = false;
         }
-        if (!o.Degenerate && o.IgnoreCase) r.seq = lower(r.seq);  // locate.go:430-432
+        if (!(o.Degenerate || o.UseRegexp) && o.IgnoreCase) r.seq = lower(r.seq);  // locate.go:430-432
         const long l = (long)r.seq.size();
         if (o.Circular) r.seq += r.seq;
         const long n = (long)r.seq.size();
@@ -1296,6 +1306,45 @@ std::vector<std::string> locate_call(const std::vector<std::string_view>& part, 
                         const long begin = strand == 0 ? i + 1 : l - i - lp + 1;
                         const long end = strand == 0 ? i + lp : l - i;
                         row(r, pt, strand == 0 ? '+' : '-', begin, end, text.substr((size_t)i, (size_t)lp));
+                    }
+                }
+            }
+            continue;
+        }
+        if (o.UseRegexp) {
+            // locate.go:575-767 with FindSubmatchIndex: matches of any length, the containment check :604-614 is live
+            for (auto& pt : pats) {
+                for (int strand = 0; strand < 2; ++strand) {
+                    if (strand == 1 && o.OnlyPositiveStrand) break;
+                    const std::string text = strand == 0 ? r.seq : rev_com(r.seq, rd.GetAlphabet());
+                    std::vector<std::pair<long, long>> locs;
+                    long offset = 0;
+                    for (;;) {
+                        std::smatch m;
+                        if (offset > (long)text.size()) break;
+                        const std::string tail = text.substr((size_t)offset);
+                        if (!std::regex_search(tail, m, pt.sre)) break;
+                        const long i = (long)m.position(0), len = (long)m.length(0);
+                        long begin, end;
+                        if (strand == 0) {
+                            begin = offset + i + 1;
+                            if (o.Circular && begin > l) break;
+                            end = offset + i + len;
+                        } else {
+                            if (o.Circular && offset + i + 1 > l) break;
+                            begin = l - offset - (i + len) + 1;
+                            end = l - offset - i;
+                            if (offset + i + len > l) { begin += l; end += l; }
+                        }
+                        bool flag = true;
+                        for (size_t q = locs.size(); q-- > 0;)
+                            if (locs[q].first <= begin && locs[q].second >= end) { flag = false; break; }
+                        if (flag) {
+                            row(r, pt, strand == 0 ? '+' : '-', begin, end, text.substr((size_t)(offset + i), (size_t)len));
+                            locs.emplace_back(begin, end);
+                        }
+                        offset = o.NonGreedy ? offset + i + len + 1 : offset + i + 1;
+                        if (offset >= n) break;
                     }
                 }
             }

@@ -58,7 +58,8 @@ add("translate -f 6 -F --trim table 11", "translate", oracle.translate, fasta(60
 LOC = b">s1 d\nAAAATTTTGGAAAA\n>s2\nACGTTGCAAGCT\n"
 for o in ({"Pattern": ["AA"]}, {"Pattern": ["AA"], "NonGreedy": True}, {"Pattern": ["AAAA", "TGCA"], "Bed": True},
           {"Pattern": ["AAAA", "TGCA"], "Gtf": True}, {"Pattern": ["aaaa"], "IgnoreCase": True, "OnlyPositiveStrand": True},
-          {"Pattern": ["GCTAC"], "Circular": True}, {"Pattern": ["ANNT"], "Degenerate": True}, {"Pattern": ["ACGTAG"], "MaxMismatch": 1}):
+          {"Pattern": ["GCTAC"], "Circular": True}, {"Pattern": ["ANNT"], "Degenerate": True}, {"Pattern": ["ACGTAG"], "MaxMismatch": 1},
+          {"Pattern": ["A[AT]T"], "UseRegexp": True}):
     add("locate " + json.dumps(o), "locate", oracle.locate, LOC, False, o)
 for o in ({"Pattern": ["r3", "r9"]}, {"Pattern": ["CCCC"], "BySeq": True}, {"Pattern": ["cccc"], "BySeq": True, "IgnoreCase": True, "InvertMatch": True},
           {"Pattern": ["^r1"], "UseRegexp": True}, {"Pattern": ["ACGN"], "Degenerate": True}, {"Pattern": ["r1", "r2"], "DeleteMatched": True}):

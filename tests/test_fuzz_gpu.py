@@ -111,11 +111,12 @@ def rand_opts(rng, op, fastq):
         if rng.random() < 0.2 and not o.get("MaxMismatch") and (len(o["Pattern"]) == 1 or not (o.get("BySeq") or o.get("UseRegexp") or o.get("Degenerate"))):
             o["DeleteMatched"] = True
     elif op == "locate":
-        mode = rng.choice(["exact", "exact", "deg", "mm", "fmi"])
+        mode = rng.choice(["exact", "exact", "deg", "mm", "fmi", "re"])
         o["Pattern"] = [rand_seq(rng, rng.randint(1, 6), "ACGT") for _ in range(rng.randint(1, 3))]
         if mode == "deg": o.update(Pattern=[rand_seq(rng, rng.randint(2, 6), "ACGTNRYW")], Degenerate=True)
         elif mode == "mm": o.update(Pattern=[rand_seq(rng, rng.randint(4, 8), "ACGT")], MaxMismatch=1)
         elif mode == "fmi": o["UseFmi"] = True
+        elif mode == "re": o.update(Pattern=[rng.choice(["A[CG]T", "G.A", "[^A]CG", "AC{2}", "T[AT][AT]A", "(AC)G"])], UseRegexp=True)
         for k in ("IgnoreCase", "OnlyPositiveStrand", "NonGreedy", "Circular", "HideMatched"):
             if rng.random() < 0.3:
                 o[k] = True

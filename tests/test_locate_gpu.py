@@ -206,3 +206,40 @@ def test_locate_every_record_is_long(monkeypatch):
     for opts in ({"Pattern": ["ACG", "TT"]}, {"Pattern": ["ACGT"], "Circular": True, "Bed": True},
                  {"Pattern": ["ACNT"], "Degenerate": True}, {"Pattern": ["ACG", "GGCC"], "UseFmi": True}):
         check(fa, False, opts)
+
+
+# ---------------------------------------------------------------- -r for fixed-length expressions (PARITY.md LOCRE)
+LOC_RE_OPTS = [
+    {"Pattern": ["A[AT]T"], "UseRegexp": True},
+    {"Pattern": ["g.a", "AC[^A]T"], "UseRegexp": True, "IgnoreCase": True},
+    {"Pattern": ["AC\\wT", "[ACG][ACG][ACG]TT"], "UseRegexp": True, "HideMatched": True},
+    {"Pattern": ["A.G.T"], "UseRegexp": True, "Circular": True, "Bed": True},
+    {"Pattern": ["[AG]CG[CT]"], "UseRegexp": True, "NonGreedy": True, "Gtf": True},
+    {"Pattern": ["TT[ACGT]AA"], "UseRegexp": True, "OnlyPositiveStrand": True},
+]
+
+
+@pytest.mark.parametrize("width", [60, 0, 7])
+@pytest.mark.parametrize("i", range(len(LOC_RE_OPTS)))
+def test_locate_regexp_of_fixed_length(i, width, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(900 + i)
+    data = seqgen.random_fasta(rng, 80, 0, 300, width=width, alphabet="ACGT" * 5 + "acgtN", final_newline=i % 2 == 0)
+    check(data, False, LOC_RE_OPTS[i])
+    fq = seqgen.random_fastq(rng, 200, 0, 100, alphabet="ACGT" * 5 + "acgtN")
+    check(fq, True, LOC_RE_OPTS[i])
+
+
+def test_locate_regexp_hand_case_pattern_file_and_what_is_refused(tmp_path):
+    fa = b">s1 d\nAAAATTTTGGAAAA\n>s2\nACGTTGCAAGCT\n"
+    got = check(fa, False, {"Pattern": ["A[AT]T"], "UseRegexp": True})
+    assert got == (b"seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched\ns1\tA[AT]T\tA[AT]T\t+\t3\t5\tAAT\n"
+                   b"s1\tA[AT]T\tA[AT]T\t+\t4\t6\tATT\ns1\tA[AT]T\tA[AT]T\t-\t4\t6\tAAT\ns1\tA[AT]T\tA[AT]T\t-\t3\t5\tATT\n")
+    pf = tmp_path / "pats.fa"
+    pf.write_text(">motif one\nG[GC]A\n>second\nTT.T\n")
+    check(fa, False, {"PatternFile": str(pf), "UseRegexp": True})
+    check(fa, False, {"Pattern": ["A{4}", "(TT)G"], "UseRegexp": True})   # a fixed count and a plain group are still a chain
+    for bad in ("AC+G", "A|C", "(AC)?G", "^ACG", "AC{1,2}"):
+        with pytest.raises(bsk.BskError) as e:
+            bsk.Locate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(fa)]), _Opts({"Pattern": [bad], "UseRegexp": True}))
+        assert "fixed-length expressions" in str(e.value), bad
