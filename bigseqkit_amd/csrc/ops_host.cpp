@@ -288,7 +288,8 @@ Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     return guess_alphabet_less_conservatively(s.data(), s.size(), thr);
 }
 
-int ensure_out(bsk_ctx* c, uint64_t bytes) { return grow(c, &c->d_out, &c->out_cap, bytes, bytes / 8 + 256); }
+// (slack so that a slightly larger next result does not reallocate; capped: 1/8 of a 100 GB output is 12 GB of HBM)
+int ensure_out(bsk_ctx* c, uint64_t bytes) { return grow(c, &c->d_out, &c->out_cap, bytes, std::min<uint64_t>(bytes / 8, 256ull << 20) + 256); }
 
 int ensure_record_scratch(bsk_ctx* c) {
     const uint64_t n = c->table.n;
