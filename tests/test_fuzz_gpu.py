@@ -203,3 +203,44 @@ def test_fuzz_every_command(seed, monkeypatch):
         assert got == want, ctx
         agree += 1
     assert agree > 45
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24")) // 2))
+def test_fuzz_two_input_commands(seed, monkeypatch):
+    """pair / common / concat on random pairs of files that share part of their IDs (one GPU call sees both files)"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(9000 + seed)
+    for it in range(20):
+        fastq = rng.random() < 0.5
+        files = []
+        for _ in range(2 if rng.random() < 0.7 else 3):
+            recs = []
+            for _ in range(rng.randint(0, 40)):
+                name = rng.choice(["a", "B", "c", "id"]) + str(rng.randrange(12)) + rng.choice(["", " d", "\tt x"])
+                L = rng.choice([0, 1, 16, 61, rng.randint(0, 150)])
+                s = rand_seq(rng, L, "ACGTacgtN")
+                if fastq:
+                    recs.append(f"@{name}\n{s}\n+\n{''.join(chr(rng.randint(33, 74)) for _ in range(L))}\n")
+                else:
+                    w = rng.choice([60, 7, max(1, L)])
+                    recs.append(f">{name}\n" + "".join(s[j:j + w] + "\n" for j in range(0, L, w)))
+            files.append("".join(recs).encode())
+        fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+        frames = [bsk.SeqFrame(fmt, [dev(f)]) for f in files]
+        cfg = {"Config": {"LineWidth": rng.choice([60, 0, 9])}}
+        op = rng.choice(["pair", "common", "concat"])
+        if op == "pair":
+            o = dict(cfg, SaveUnpaired=rng.random() < 0.6)
+            want = oracle.pair(files[0], files[1], fastq, json.dumps(o))
+            got = bsk.Pair(frames[0], frames[1], _Opts(o))
+            if not o["SaveUnpaired"]:
+                want = want[:2] + (b"", b"")
+        elif op == "common":
+            o = dict(cfg, **rng.choice([{}, {"ByName": True}, {"BySeq": True}, {"IgnoreCase": True}, {"BySeq": True, "IgnoreCase": True}]))
+            want = oracle.common(files, fastq, json.dumps(o))
+            got = bsk.Common(frames[0], frames[1], _Opts(o), *frames[2:])
+        else:
+            o = dict(cfg, Full=rng.random() < 0.5)
+            want = oracle.concat(files[0], files[1], fastq, json.dumps(o))
+            got = bsk.Concat(frames[0], frames[1], _Opts(o))
+        assert got == want, (op, fastq, o, [f[:200] for f in files])
