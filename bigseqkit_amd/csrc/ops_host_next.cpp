@@ -657,8 +657,8 @@ void validate_common_opts(bsk_ctx* c) {
         throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
     if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :43-45
         throw OptError("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
-    if (o.b("OnlyPositiveStrand"))
-        throw OptError("libbsk: common -s -P: the reference hashes nothing on that branch (every record gets key 0); not provided");
+    // -s -P: as written nothing is hashed on that branch (every record would get key 0); the flag's meaning -- compare the
+    // sequences as they are -- is what -s already does here (PARITY.md COMMON), so it is accepted and changes nothing
 }
 
 int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t* file_ends, uint32_t nfiles, int format,

@@ -2036,7 +2036,6 @@ void pair_call(const std::vector<std::string_view>& a, const std::vector<std::st
 std::vector<std::string> common_call(const std::vector<std::vector<std::string_view>>& files, const CommonOptions& o) {
     if (o.BySeq && o.ByName) throw Error("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");  // :37-39
     if (o.OnlyPositiveStrand && !o.BySeq) throw Error("flag -s (--by-seq) needed when using -P (--only-positive-strand)");  // :43-45
-    if (o.OnlyPositiveStrand) throw Error("common -s -P: every record gets key 0 in the reference");
     Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
     auto key_of = [&](const Record& r) {
         std::string k = o.BySeq ? r.seq : (o.ByName ? r.name : r.id);  // :76-100 (the revcom of both sides == same strand)

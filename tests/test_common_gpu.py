@@ -69,9 +69,9 @@ def test_common_hand_cases_and_cli(tmp_path):
     assert bsk.Common(fr[0], fr[1], _Opts({})) == b">x 1\nACGT\n>z\nAC\n"
     assert bsk.Common(fr[0], fr[1], _Opts({}), fr[2]) == b">z\nAC\n"
     assert bsk.Common(fr[0], fr[1], _Opts({"IgnoreCase": True}), fr[2]) == b">x 1\nACGT\n>z\nAC\n"
-    assert bsk.Common(fr[0], fr[1], _Opts({"BySeq": True})) == b""
+    assert bsk.Common(fr[0], fr[1], _Opts({"BySeq": True})) == b"" == bsk.Common(fr[0], fr[1], _Opts({"BySeq": True, "OnlyPositiveStrand": True}))
     for o, msg in (({"BySeq": True, "ByName": True}, "only one/none of the flags"), ({"OnlyPositiveStrand": True}, "flag -s (--by-seq) needed"),
-                   ({"BySeq": True, "OnlyPositiveStrand": True}, "key 0")):
+                   ):
         with pytest.raises(bsk.BskError) as e:
             bsk.Common(fr[0], fr[1], _Opts(o))
         assert msg in str(e.value)
