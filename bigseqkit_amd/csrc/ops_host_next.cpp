@@ -307,8 +307,6 @@ void validate_sort_opts(bsk_ctx* c) {
     if (o.b("ByLength") || o.b("ByBases")) ++k;
     if (k > 1) throw OptError("only one of the options (byLength), (byName) and (bySeq) is allowed");
     if (o.i("SeqPrefixLength") < 0) throw OptError("value of flag -L (--seq-prefix-length) should be >= 0");
-    if (o.b("InNaturalOrder") && !o.b("BySeq") && !(o.b("ByLength") || o.b("ByBases")))
-        throw OptError("libbsk: sort in natural order (-N) is not provided by the HIP path");
 }
 
 int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
@@ -355,6 +353,29 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 32, st) != hipSuccess) return fail(BSK_ERR_HIP);
         std::swap(pin, pout);
     } else {
+        uint8_t* d_nat = nullptr;
+        if (o.b("InNaturalOrder") && P.mode <= 1) {
+            // natural order (sort.go:130-133: IDs / names only): keys rewritten so that byte order is natural order
+            uint32_t* d_nlen = c->d_out_len;     // scratch of N entries, free until the size pass
+            uint64_t* d_noff = c->d_out_off;     // [N + 1]
+            rc = ensure_record_scratch(c);
+            if (rc != BSK_OK) return fail(rc);
+            d_nlen = c->d_out_len; d_noff = c->d_out_off;
+            uint64_t nat_bytes = 0;
+            if (launch_sort_natlen(d_buf, c->table, P, d_nlen, st) != hipSuccess ||
+                launch_scan_u32(d_nlen, d_noff, N, c->d_scan_tmp, st) != hipSuccess ||
+                hipMemcpyAsync(&nat_bytes, d_noff + N, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+            // the offsets must survive the size pass below: keep them (and the keys) in their own allocation
+            if (hipMalloc((void**)&d_nat, nat_bytes + 16 + (N + 1) * 8) != hipSuccess) { c->set_error("libbsk: out of device memory (sort -N)"); return fail(BSK_ERR_HIP); }
+            uint64_t* d_noff2 = reinterpret_cast<uint64_t*>(d_nat);
+            uint8_t* d_keys_nat = d_nat + (N + 1) * 8;
+            if (hipMemcpyAsync(d_noff2, d_noff, (N + 1) * 8, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                launch_sort_natkeys(d_buf, c->table, P, d_noff2, d_keys_nat, st) != hipSuccess) { hipFree(d_nat); return fail(BSK_ERR_HIP); }
+            P.nat = d_keys_nat;
+            P.nat_off = d_noff2;
+        }
+        struct FreeNat { uint8_t* p; ~FreeNat() { if (p) hipFree(p); } } free_nat{d_nat};
         uint32_t maxlen = 0;
         if (hipMemsetAsync(d_klen + N, 0, 4, st) != hipSuccess ||
             launch_sort_keylen(d_buf, c->table, P, d_klen, d_klen + N, st) != hipSuccess ||

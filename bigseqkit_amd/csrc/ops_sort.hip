@@ -31,6 +31,56 @@ __device__ __forceinline__ uint32_t key_span(const uint8_t* __restrict__ buf, co
     return id_span_of(h, hl, P.id_mode, off, P.buf_end);         // record.ID
 }
 
+// Natural order (natsort.Compare, PARITY.md SORT): the key is cut into runs of digits and runs of other bytes; digit runs
+// compare as integers, other runs as strings, a key that runs out first comes first.  Rewritten so that plain byte order
+// gives the same result:  digit run -> '0', number of significant digits, the significant digits;  other run -> its
+// bytes (lower-cased with -i) and a 0 terminator.  One thread per record (keys are IDs / headers: short).
+template <bool WRITE>
+__device__ __forceinline__ uint32_t natural_key(const uint8_t* __restrict__ k, uint32_t len, bool fold, uint8_t* __restrict__ o) {
+    uint32_t n = 0, i = 0;
+    while (i < len) {
+        if (k[i] >= '0' && k[i] <= '9') {
+            uint32_t j = i;
+            while (j < len && k[j] >= '0' && k[j] <= '9') ++j;
+            uint32_t z = i;
+            while (z + 1 < j && k[z] == '0') ++z;  // leading zeros do not count (an all-zero run keeps one '0')
+            const uint32_t nd = j - z;
+            if (WRITE) { o[n] = '0'; o[n + 1] = (uint8_t)(nd > 255u ? 255u : nd); for (uint32_t q = 0; q < nd; ++q) o[n + 2 + q] = k[z + q]; }
+            n += 2 + nd;
+            i = j;
+        } else {
+            while (i < len && !(k[i] >= '0' && k[i] <= '9')) {
+                uint8_t c = k[i];
+                if (fold && c >= 'A' && c <= 'Z') c += 32;
+                if (WRITE) o[n] = c;
+                ++n;
+                ++i;
+            }
+            if (WRITE) o[n] = 0;
+            ++n;
+        }
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_sort_natlen(const uint8_t* __restrict__ buf, RecordTable t, SortParams P,
+                                                     uint32_t* __restrict__ nat_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    uint32_t off;
+    const uint32_t l = key_span(buf, t, P, i, &off);
+    nat_len[i] = natural_key<false>(buf + t.start[i] + 1 + off, l, P.ignore_case != 0, nullptr);
+}
+
+__global__ __launch_bounds__(256) void k_sort_natkeys(const uint8_t* __restrict__ buf, RecordTable t, SortParams P,
+                                                      const uint64_t* __restrict__ nat_off, uint8_t* __restrict__ nat) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    uint32_t off;
+    const uint32_t l = key_span(buf, t, P, i, &off);
+    natural_key<true>(buf + t.start[i] + 1 + off, l, P.ignore_case != 0, nat + nat_off[i]);
+}
+
 __global__ __launch_bounds__(256) void k_sort_keylen(const uint8_t* __restrict__ buf, RecordTable t, SortParams P,
                                                      uint32_t* __restrict__ key_len, uint32_t* __restrict__ max_len) {
     __shared__ unsigned int s_max;
@@ -39,7 +89,7 @@ __global__ __launch_bounds__(256) void k_sort_keylen(const uint8_t* __restrict__
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < t.n) {
         uint32_t off;
-        const uint32_t l = key_span(buf, t, P, i, &off);
+        const uint32_t l = P.nat ? (uint32_t)(P.nat_off[i + 1] - P.nat_off[i]) : key_span(buf, t, P, i, &off);
         key_len[i] = l;
         atomicMax(&s_max, l);
     }
@@ -59,7 +109,10 @@ __global__ __launch_bounds__(256) void k_sort_chunk(const uint8_t* __restrict__ 
     uint64_t key = 0;
     if (b0 < len) {
         const uint32_t nb = len - b0 < 8u ? len - b0 : 8u;
-        if (P.mode == 2) {
+        if (P.nat) {
+            const uint8_t* h = P.nat + P.nat_off[i] + b0;  // already folded
+            for (uint32_t k = 0; k < nb; ++k) key |= (uint64_t)h[k] << (56u - 8u * k);
+        } else if (P.mode == 2) {
             const Text T = text_of(buf, t, tt, i);
             for (uint32_t k = 0; k < nb; ++k) {
                 uint8_t c = T.at(b0 + k);
@@ -115,6 +168,19 @@ __global__ void k_sort_scatter(const uint64_t* __restrict__ off_perm, const uint
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
+
+hipError_t launch_sort_natlen(const uint8_t* buf, const RecordTable& t, const SortParams& P, uint32_t* nat_len, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_natlen, grid_for(t.n), dim3(256), 0, st, buf, t, P, nat_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_natkeys(const uint8_t* buf, const RecordTable& t, const SortParams& P, const uint64_t* nat_off, uint8_t* nat,
+                               hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_natkeys, grid_for(t.n), dim3(256), 0, st, buf, t, P, nat_off, nat);
+    return hipGetLastError();
+}
 
 hipError_t launch_sort_iota(uint32_t* perm, uint64_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;

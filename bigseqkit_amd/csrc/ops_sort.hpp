@@ -2,7 +2,7 @@
 // record -- sequence length (-l), non-gap bases (-b), ID, full name (-n) or a sequence prefix (-s), lower-cased with -i
 // -- and a STABLE device radix sort (rocPRIM) of (key, record index): one pass for the integer keys, an LSD sweep over
 // the 8-byte chunks of the string keys.  The records are then emitted through the `seq` emit kernels at the offsets
-// of the sorted order.  Natural order (-N) is not provided (explicit error).
+// of the sorted order.  Natural order (-N): the keys are first rewritten so that byte order is natural order.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -21,8 +21,15 @@ struct SortParams {
     uint32_t prefix_len; // -s: bytes of the sequence that count (0: all)
     uint32_t gap_set[8]; // -b
     const uint8_t* buf_end;
+    // natural order (-N, modes 0 / 1): the keys are first rewritten so that byte order == natural order (k_sort_natkeys)
+    const uint8_t* nat;       // transformed keys, or null
+    const uint64_t* nat_off;  // [n + 1]
 };
 
+// natural order: nat_len[i] = bytes of the transformed key of record i;  then the keys themselves at nat_off[i]
+hipError_t launch_sort_natlen(const uint8_t* buf, const RecordTable& t, const SortParams& P, uint32_t* nat_len, hipStream_t st);
+hipError_t launch_sort_natkeys(const uint8_t* buf, const RecordTable& t, const SortParams& P, const uint64_t* nat_off, uint8_t* nat,
+                               hipStream_t st);
 // perm[i] = i
 hipError_t launch_sort_iota(uint32_t* perm, uint64_t n, hipStream_t st);
 // key_len[i] = bytes of the string key of record i; *max_len = max (zeroed by the caller).  Modes 0..2.

@@ -236,7 +236,7 @@ int bsk_faidx_query_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device
 /* ---- Sort (bigseqkit/sort.go:91-147; SortParseInputString / SortParseInputInt + SortByKey, bigseqkit-lib/sort.go):
  * by ID (default), full name (ByName), sequence prefix (BySeq, SeqPrefixLength), length (ByLength) or non-gap bases
  * (ByBases); IgnoreCase, Reverse.  Records with equal keys keep file order.  Global: ONE call sees the whole input of
- * a rank.  InNaturalOrder is rejected at bsk_create. */
+ * a rank.  InNaturalOrder: natural order of IDs / names (digit runs compare as numbers). */
 int bsk_sort_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                  bsk_out* out);
 

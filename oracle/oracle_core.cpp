@@ -1873,7 +1873,36 @@ std::vector<std::string> sort_call(const std::vector<std::string_view>& all, con
     if (o.ByBases) byLength = true;                                   // sort.go:105-108
     int n = (o.BySeq ? 1 : 0) + (o.ByName ? 1 : 0) + (byLength ? 1 : 0);
     if (n > 1) throw Error("only one of the options (byLength), (byName) and (bySeq) is allowed");  // :110-122
-    if (!byLength && !o.BySeq && o.InNaturalOrder) throw Error("natural order: natsort is not in the reference tree");
+    // natural order (sort.go:130-133 -> natsort.Compare of shenwei356/natsort, not in the tree [upstream-memory]): the key
+    // is cut into runs of digits and runs of other bytes; at the first differing run, two digit runs compare as
+    // integers (Atoi: runs beyond int64 fall back to string comparison), anything else as strings; a key whose runs
+    // are exhausted first comes first
+    const bool natural = !byLength && !o.BySeq && o.InNaturalOrder;
+    auto chunkify = [](const std::string& t) {
+        std::vector<std::string> ch;
+        for (size_t i = 0; i < t.size();) {
+            const bool dig = isdigit((unsigned char)t[i]) != 0;
+            size_t j = i;
+            while (j < t.size() && (isdigit((unsigned char)t[j]) != 0) == dig) ++j;
+            ch.push_back(t.substr(i, j - i));
+            i = j;
+        }
+        return ch;
+    };
+    auto nat_cmp = [&](const std::string& a, const std::string& b) {
+        const auto ca = chunkify(a), cb = chunkify(b);
+        for (size_t i = 0; i < ca.size(); ++i) {
+            if (i >= cb.size()) return 1;
+            const bool na = isdigit((unsigned char)ca[i][0]) && ca[i].size() <= 18, nb = isdigit((unsigned char)cb[i][0]) && cb[i].size() <= 18;
+            if (na && nb) {
+                const long long x = atoll(ca[i].c_str()), y = atoll(cb[i].c_str());
+                if (x != y) return x < y ? -1 : 1;
+            } else if (ca[i] != cb[i]) {
+                return ca[i] < cb[i] ? -1 : 1;
+            }
+        }
+        return ca.size() < cb.size() ? -1 : 0;
+    };
     Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
     SeqParser rd(ab, &all, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
     std::bitset<256> gaps;
@@ -1911,6 +1940,9 @@ std::vector<std::string> sort_call(const std::vector<std::string_view>& all, con
     if (byLength) {
         if (!o.Reverse) std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ikey < b.ikey; });
         else std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ikey > b.ikey; });
+    } else if (natural) {
+        if (!o.Reverse) std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nat_cmp(a.skey, b.skey) < 0; });
+        else std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nat_cmp(a.skey, b.skey) > 0; });
     } else {
         if (!o.Reverse) std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.skey < b.skey; });
         else std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.skey > b.skey; });

@@ -151,7 +151,7 @@ def rand_opts(rng, op, fastq):
         elif r < 0.35: o["ByBases"] = True
         elif r < 0.55: o.update(BySeq=True, SeqPrefixLength=rng.choice([0, 3, 10, 10000]))
         elif r < 0.7: o["ByName"] = True
-        for k in ("Reverse", "IgnoreCase"):
+        for k in ("Reverse", "IgnoreCase", "InNaturalOrder"):
             if rng.random() < 0.4:
                 o[k] = True
     elif op == "faidx":

@@ -104,7 +104,7 @@ def test_sort_keys_ties_and_errors():
     assert oracle.sort(fa, False, '{"BySeq": true}') == b">B q\nA-\n>b x\nACGT\n>a\nC\n>A\nGG\n>c\nTTTTT\n"
     with pytest.raises(oracle.OracleError):
         oracle.sort(fa, False, '{"BySeq": true, "ByLength": true}')
-    for o, msg in (('{"BySeq": true, "ByName": true}', "only one of the options"), ('{"InNaturalOrder": true}', "natural order")):
+    for o, msg in (('{"BySeq": true, "ByName": true}', "only one of the options"),):
         with pytest.raises(bsk.BskError) as e:
             bsk.Operator("Sort", o, -1)
         assert msg in str(e.value)

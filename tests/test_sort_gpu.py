@@ -49,7 +49,8 @@ def make(rng, nrec, fastq, width=60, final_newline=True):
     return text.encode()
 
 
-OPTS = [{}, {"Reverse": True}, {"IgnoreCase": True}, {"ByName": True}, {"ByName": True, "IgnoreCase": True, "Reverse": True},
+OPTS = [{"InNaturalOrder": True}, {"InNaturalOrder": True, "IgnoreCase": True, "Reverse": True}, {"InNaturalOrder": True, "ByName": True},
+        {}, {"Reverse": True}, {"IgnoreCase": True}, {"ByName": True}, {"ByName": True, "IgnoreCase": True, "Reverse": True},
         {"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {"BySeq": True, "SeqPrefixLength": 5},
         {"BySeq": True, "SeqPrefixLength": 0, "Reverse": True}, {"ByLength": True}, {"ByLength": True, "Reverse": True},
         {"ByBases": True}, {"ByBases": True, "GapLetters": "-N", "Reverse": True}, {"Config": {"LineWidth": 13}, "ByLength": True},
@@ -76,7 +77,7 @@ def test_sort_hand_cases_and_errors():
     assert bsk.Sort(fr(), _Opts({"ByBases": True})) == b">a\nC\n>B q\nA-\n>A\nGG\n>b x\nACGT\n>c\nTTTTT\n"
     assert bsk.Sort(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(b"")]), _Opts({})) == b""
     for o, msg in (({"BySeq": True, "ByName": True}, "only one of the options"), ({"ByBases": True, "BySeq": True}, "only one of the options"),
-                   ({"InNaturalOrder": True}, "natural order")):
+                   ):
         with pytest.raises(bsk.BskError) as e:
             bsk.Sort(fr(), _Opts(o))
         assert msg in str(e.value)
@@ -97,3 +98,18 @@ def test_sort_long_records(monkeypatch):
     data = "".join(recs).encode()
     for o in ({}, {"ByLength": True, "Reverse": True}, {"BySeq": True, "SeqPrefixLength": 100}):
         assert bsk.Sort(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)]), _Opts(o)) == oracle.sort(data, False, json.dumps(o)), o
+
+
+def test_sort_natural_order_hand_case():
+    ids = ["chr10", "chr2", "chr1", "chrX", "chr1_random", "chr01", "Chr3", "chr2a", "chr", "10", "9", "a-1", "a1", "s007x12", "s7x3", "s7x"]
+    data = "".join(f">{i} d\n{'ACGT' * (k + 1)}\n" for k, i in enumerate(ids)).encode()
+    fr = lambda: bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)])
+    got = bsk.Sort(fr(), _Opts({"InNaturalOrder": True}))
+    assert got == oracle.sort(data, False, '{"InNaturalOrder": true}')
+    order = [l.split()[0][1:] for l in got.decode().split("\n") if l.startswith(">")]
+    assert order == ["9", "10", "Chr3", "a1", "a-1", "chr", "chr1", "chr01", "chr1_random", "chr2", "chr2a", "chr10", "chrX", "s7x", "s7x3", "s007x12"]
+    for o in ({"InNaturalOrder": True, "Reverse": True}, {"InNaturalOrder": True, "IgnoreCase": True}, {"InNaturalOrder": True, "ByName": True}):
+        assert bsk.Sort(fr(), _Opts(o)) == oracle.sort(data, False, json.dumps(o)), o
+    # -N is ignored when sorting by sequence or length (sort.go:130-133)
+    for o in ({"InNaturalOrder": True, "BySeq": True}, {"InNaturalOrder": True, "ByLength": True}):
+        assert bsk.Sort(fr(), _Opts(o)) == oracle.sort(data, False, json.dumps(o)), o
