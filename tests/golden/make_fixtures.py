@@ -77,6 +77,9 @@ add("rename", "rename", oracle.rename, fasta(60), False, {})
 add("sort -l -r", "sort", oracle.sort, FQ10, True, {"ByLength": True, "Reverse": True})
 add("sort -s -i", "sort", oracle.sort, FQ10, True, {"BySeq": True, "IgnoreCase": True})
 add("sort by id", "sort", oracle.sort, fasta(60), False, {})
+NAT = "".join(f">{i} d\nACGT\n" for i in ["chr10", "chr2", "chr1", "chrX", "chr1_random", "chr01", "Chr3", "chr2a", "chr", "10", "9"]).encode()
+add("sort -N", "sort", oracle.sort, NAT, False, {"InNaturalOrder": True})
+add("sort -N -i -r", "sort", oracle.sort, NAT, False, {"InNaturalOrder": True, "IgnoreCase": True, "Reverse": True})
 add("faidx rows fasta", "faidx", oracle.faidx, fasta(60), False, {})
 add("faidx rows fastq", "faidx", oracle.faidx, FQ10, True, {"FullHead": True})
 add("faidx queries", "faidx_query", oracle.faidx_query, fasta(60), False, {"Regions": ["chr1:5-20", "chr2:-3", "chr1:30-21", "chr9"]})

@@ -27,4 +27,4 @@ def test_oracle_reproduces_the_golden_fixture(case):
 
 def test_fixture_set_covers_every_operator():
     assert {c["op"] for c in FIX} == set(FN)
-    assert len(FIX) >= 82
+    assert len(FIX) >= 84
