@@ -76,7 +76,7 @@ struct bsk_ctx {
     // rmdup
     uint64_t* d_keys = nullptr;
     uint64_t keys_cap = 0;
-    uint64_t* d_table = nullptr;  // table_keys[cap] ++ table_first[cap]
+    uint64_t* d_table = nullptr;  // cap slots {key, ~first record} (key_table)
     uint64_t table_cap = 0;
     // multi-GPU rmdup: second keys, owner-side table, the shard the keys phase indexed
     uint64_t* d_keys2 = nullptr;

@@ -99,6 +99,37 @@ __device__ __noinline__ uint64_t put_element(uint8_t* __restrict__ o, uint32_t g
     for (uint32_t x = gl; x < hlen + 2u; x += G)
         o[x] = x == 0 ? (uint8_t)(P.fastq ? '@' : '>') : (x == hlen + 1u ? (uint8_t)'\n' : hd[x - 1]);
     x0 = hlen + 2u;
+    // contiguous sources and no newline to insert (every FASTQ, single-line FASTA): the element is a chain of plain
+    // spans, copied 16 bytes per lane
+    if (W == L && TA.W == 0 && TB.W == 0) {
+        auto span = [&](uint64_t off, const uint8_t* src, uint32_t nb) {
+            uint8_t* dst = o + off;
+            for (uint32_t x = gl * 16u; x < nb; x += G * 16u) {
+                if (x + 16u <= nb) {
+                    uint4 v;
+                    __builtin_memcpy(&v, src + x, 16);
+                    __builtin_memcpy(dst + x, &v, 16);
+                } else {
+                    for (uint32_t k = x; k < nb; ++k) dst[k] = src[k];
+                }
+            }
+        };
+        span(x0, TA.p, LA);
+        span(x0 + LA, TB.p, TB.L);
+        x0 += L;
+        if (gl == 0) o[x0] = '\n';
+        x0 += 1;
+        if (P.fastq) {
+            if (gl == 0) { o[x0] = '+'; o[x0 + 1] = '\n'; }
+            x0 += 2;
+            span(x0, qa, LA);
+            span(x0 + LA, qb, TB.L);
+            x0 += L;
+            if (gl == 0) o[x0] = '\n';
+            x0 += 1;
+        }
+        return x0;
+    }
     for (uint32_t x = gl; x < W; x += G) {
         uint8_t c;
         if (lw && (x % (lw + 1u)) == lw) c = '\n';
@@ -122,11 +153,11 @@ __device__ __noinline__ uint64_t put_element(uint8_t* __restrict__ o, uint32_t g
     return x0;
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void k_concat_emit(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt, ConcatParams P,
                                                      const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ seg,
                                                      const uint32_t* __restrict__ out_len, const uint64_t* __restrict__ out_off,
                                                      uint8_t* __restrict__ out) {
-    constexpr int G = 16;
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (i >= t.n || out_len[i] == 0) return;
@@ -169,11 +200,16 @@ hipError_t launch_concat_size(const uint8_t* buf, const RecordTable& t, const Co
 
 hipError_t launch_concat_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const ConcatParams& P,
                               const uint64_t* sorted, const uint32_t* seg, const uint32_t* out_len, const uint64_t* out_off,
-                              uint8_t* out, hipStream_t st) {
+                              uint8_t* out, uint64_t avg_bytes, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    hipLaunchKernelGGL(k_concat_emit, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t, d, P, sorted, seg, out_len,
-                       out_off, out);
+    // short reads: 4 lanes per record (a 150-byte span is 10 steps of 16 bytes), otherwise 16
+    if (avg_bytes < 1024)
+        hipLaunchKernelGGL((k_concat_emit<4>), dim3((unsigned)((t.n * 4 + 255) / 256)), dim3(256), 0, st, buf, t, d, P, sorted, seg,
+                           out_len, out_off, out);
+    else
+        hipLaunchKernelGGL((k_concat_emit<16>), dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t, d, P, sorted, seg,
+                           out_len, out_off, out);
     return hipGetLastError();
 }
 

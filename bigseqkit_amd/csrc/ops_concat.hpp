@@ -28,6 +28,6 @@ hipError_t launch_concat_size(const uint8_t* buf, const RecordTable& t, const Co
                               const uint32_t* seg, uint32_t* out_len, uint32_t* count, uint64_t* status, hipStream_t st);
 hipError_t launch_concat_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const ConcatParams& P,
                               const uint64_t* sorted, const uint32_t* seg, const uint32_t* out_len, const uint64_t* out_off,
-                              uint8_t* out, hipStream_t st);
+                              uint8_t* out, uint64_t avg_bytes, hipStream_t st);
 
 }  // namespace bsk

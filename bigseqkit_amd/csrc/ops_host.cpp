@@ -35,7 +35,7 @@ namespace bsk {
 
 // Open-addressing table of the key-grouping operators (rmdup, rename, pair, common, concat, grep --delete-matched):
 // d_keys for N records, `cap` slots (a power of two >= 2 N) of keys (zeroed) and first-record indices (0xFF-filled).
-int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, uint64_t** tf, hipStream_t st) {
+int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, hipStream_t st) {
     int rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     uint64_t cap = 1024;
@@ -47,10 +47,8 @@ int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, uint64_t
         c->table_cap = 2 * cap;
     }
     *tk = c->d_table;
-    *tf = c->d_table + cap;
     *cap_out = cap;
-    HIP_TRYX(c, hipMemsetAsync(*tk, 0, cap * sizeof(uint64_t), st));
-    HIP_TRYX(c, hipMemsetAsync(*tf, 0xFF, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(*tk, 0, 2 * cap * sizeof(uint64_t), st));  // slot = {key, ~first}: all zero = empty
     return BSK_OK;
 }
 
@@ -781,8 +779,8 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 R.line_width = G.line_width;
                 R.buf_end = d_buf + n;
                 uint64_t cap = 0;
-                uint64_t *tk = nullptr, *tf = nullptr;
-                rc = key_table(c, N, &cap, &tk, &tf, st);
+                uint64_t* tk = nullptr;
+                rc = key_table(c, N, &cap, &tk, st);
                 if (rc != BSK_OK) return rc;
                 Arena A;
                 const uint64_t o_first = A.take(N * 4);
@@ -790,8 +788,8 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 if (rc != BSK_OK) return rc;
                 uint32_t* d_firsts = A.at<uint32_t>(o_first);
                 HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, R, c->d_keys, nullptr, st));
-                HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-                HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, R, c->d_keys, tk, tf, cap, d_firsts, c->d_status, st));
+                HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+                HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, R, c->d_keys, tk, cap, d_firsts, c->d_status, st));
                 HIP_TRYX(c, launch_mask_u32(c->d_out_len, d_firsts, N, st));
             } else {
                 // one pattern (checked at create time): only its first hit survives
@@ -1636,14 +1634,14 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
     uint64_t cap = 0;
-    uint64_t *tk = nullptr, *tf = nullptr;
-    rc = key_table(c, N, &cap, &tk, &tf, st);
+    uint64_t* tk = nullptr;
+    rc = key_table(c, N, &cap, &tk, st);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     uint64_t total = 0, kept = 0;
     rc = finish_sizes(c, st, &total, &kept);
     if (rc == BSK_OK) {
@@ -1680,7 +1678,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             if (hipMalloc((void**)&d_has, N) != hipSuccess || hipMalloc((void**)&d_row_len, N * 4) != hipSuccess ||
                 hipMalloc((void**)&d_row_off, (N + 1) * 8) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (hipMemsetAsync(d_has, 0, N, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
-            if (launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (launch_rmdup_side_sizes(d_buf, c->table, P, c->d_keys, d_has, c->d_out_len, d_row_len, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (launch_scan_u32(d_row_len, d_row_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }

@@ -208,15 +208,15 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
     uint64_t cap = 0;
-    uint64_t *tk = nullptr, *tf = nullptr;
-    rc = key_table(c, N, &cap, &tk, &tf, st);
+    uint64_t* tk = nullptr;
+    rc = key_table(c, N, &cap, &tk, st);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     // groups: the rmdup machinery (XXH64 of the ID / name, first occurrence wins, exact verification of every other one)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     Arena A;
     const uint64_t o_has = A.take(N), o_ord = A.take(N * 4);
     rc = arena_reserve(c, &A);
@@ -229,7 +229,7 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     auto fail = [&](int code) { return code; };
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
     HIP_TRYX(c, hipMemsetAsync(d_ord, 0, N * 4, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));  // d_keys[i] := first record of i's group
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));  // d_keys[i] := first record of i's group
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     // how many records are not the first of their group
     uint64_t status = 0, m = 0;
@@ -583,8 +583,8 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     uint64_t cap = 0;
-    uint64_t *tk = nullptr, *tf = nullptr;
-    rc = key_table(c, N, &cap, &tk, &tf, st);
+    uint64_t* tk = nullptr;
+    rc = key_table(c, N, &cap, &tk, st);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
@@ -607,10 +607,10 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     uint64_t* d_tot = A.at<uint64_t>(o_tot);
     // groups by ID (XXH64, first occurrence, exact verification of every other member)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(d_tot, 0, 8 * 8, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
@@ -703,8 +703,8 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     uint64_t cap = 0;
-    uint64_t *tk = nullptr, *tf = nullptr;
-    rc = key_table(c, N, &cap, &tk, &tf, st);
+    uint64_t* tk = nullptr;
+    rc = key_table(c, N, &cap, &tk, st);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
@@ -717,10 +717,10 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     uint64_t* d_ends = A.at<uint64_t>(o_ends);
     HIP_TRYX(c, hipMemcpyAsync(d_ends, file_ends, (size_t)nfiles * 8, hipMemcpyHostToDevice, st));
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 8, st));
     HIP_TRYX(c, launch_common_masks(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, st));
     uint64_t status = 0;
@@ -776,8 +776,8 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     uint64_t cap = 0;
-    uint64_t *tk = nullptr, *tf = nullptr;
-    rc = key_table(c, N, &cap, &tk, &tf, st);
+    uint64_t* tk = nullptr;
+    rc = key_table(c, N, &cap, &tk, st);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
@@ -794,10 +794,10 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     uint32_t* d_cnt = A.at<uint32_t>(o_cnt);
     uint64_t* d_cntoff = A.at<uint64_t>(o_cntoff);
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, tf, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, tf, cap, c->d_out_len, c->d_status, st));
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, tf, cap, d_has, st));
+    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
     uint64_t first2 = 0, status = 0;
@@ -838,7 +838,8 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     if (total == 0) return BSK_OK;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_concat_emit(d_buf, c->table, tt, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, c->d_out, st));
+    HIP_TRYX(c, launch_concat_emit(d_buf, c->table, tt, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, c->d_out,
+                                   elements ? total / elements : 0, st));
     out->d_data = c->d_out;
     out->len = total;
     out->records = elements;

@@ -232,17 +232,34 @@ __device__ __forceinline__ uint64_t slot_of(uint64_t k, uint64_t mask) {
     return k & mask;
 }
 
+// The table is an array of 16-byte slots {key, ~first}: one cache line per probe for both words, and an all-zero
+// slot is empty (atomicMax on ~index keeps the smallest index).
+struct Slot { uint64_t key, nfirst; };
+__device__ __forceinline__ Slot load_slot(const uint64_t* __restrict__ table, uint64_t s) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(table + 2 * s);
+    return Slot{v.x, v.y};
+}
+// first record of key k (k is in the table)
+__device__ __forceinline__ uint64_t lookup_first(const uint64_t* __restrict__ table, uint64_t k, uint64_t mask) {
+    uint64_t s = slot_of(k, mask);
+    for (;;) {
+        const Slot e = load_slot(table, s);
+        if (e.key == k) return ~e.nfirst;
+        s = (s + 1) & mask;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rmdup_insert(const uint64_t* __restrict__ keys, uint64_t n, uint64_t base,
-                                                      uint64_t* table_keys, uint64_t* table_first, uint64_t cap) {
+                                                      uint64_t* table, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = slot_key(keys[i]);
     const uint64_t mask = cap - 1;
     uint64_t s = slot_of(k, mask);
     for (;;) {
-        const unsigned long long old = atomicCAS((unsigned long long*)&table_keys[s], 0ull, (unsigned long long)k);
+        const unsigned long long old = atomicCAS((unsigned long long*)&table[2 * s], 0ull, (unsigned long long)k);
         if (old == 0ull || old == k) {
-            atomicMin((unsigned long long*)&table_first[s], (unsigned long long)(base + i));
+            atomicMax((unsigned long long*)&table[2 * s + 1], ~(unsigned long long)(base + i));
             return;
         }
         s = (s + 1) & mask;
@@ -259,16 +276,11 @@ __device__ __forceinline__ uint32_t format_len(uint32_t name_len, uint32_t L, in
 
 __global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
                                                        RmDupParams P, const uint64_t* __restrict__ keys,
-                                                       const uint64_t* __restrict__ table_keys,
-                                                       const uint64_t* __restrict__ table_first, uint64_t cap,
+                                                       const uint64_t* __restrict__ table, uint64_t cap,
                                                        uint32_t* __restrict__ out_len, uint64_t* __restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n) return;
-    const uint64_t k = slot_key(keys[i]);
-    const uint64_t mask = cap - 1;
-    uint64_t s = slot_of(k, mask);
-    while (table_keys[s] != k) s = (s + 1) & mask;
-    const uint64_t first = table_first[s];
+    const uint64_t first = lookup_first(table, slot_key(keys[i]), cap - 1);
     bool keep = first == i;
     if (!keep) {
         const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
@@ -290,16 +302,11 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict
 // survivor; has_dup marks survivors that lost a duplicate.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rmdup_group(uint64_t n, uint64_t* __restrict__ keys,
-                                                     const uint64_t* __restrict__ table_keys,
-                                                     const uint64_t* __restrict__ table_first, uint64_t cap,
+                                                     const uint64_t* __restrict__ table, uint64_t cap,
                                                      uint8_t* __restrict__ has_dup) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = slot_key(keys[i]);
-    const uint64_t mask = cap - 1;
-    uint64_t s = slot_of(k, mask);
-    while (table_keys[s] != k) s = (s + 1) & mask;
-    const uint64_t first = table_first[s];
+    const uint64_t first = lookup_first(table, slot_key(keys[i]), cap - 1);
     keys[i] = first;
     if (first != i) has_dup[first] = 1;
 }
@@ -448,29 +455,27 @@ hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTab
     return hipGetLastError();
 }
 
-hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table_keys,
-                               uint64_t* table_first, uint64_t cap, hipStream_t st) {
+hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table, uint64_t cap,
+                               hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rmdup_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, base_index,
-                       table_keys, table_first, cap);
+    hipLaunchKernelGGL(k_rmdup_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, base_index, table, cap);
     return hipGetLastError();
 }
 
 hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
-                                const uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
-                                uint64_t cap, uint32_t* out_len, uint64_t* status, hipStream_t st) {
+                                const uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
+                                uint64_t* status, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    hipLaunchKernelGGL(k_rmdup_resolve, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys,
-                       table_keys, table_first, cap, out_len, status);
+    hipLaunchKernelGGL(k_rmdup_resolve, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys, table, cap,
+                       out_len, status);
     return hipGetLastError();
 }
 
-hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
-                              uint64_t cap, uint8_t* has_dup, hipStream_t st) {
+hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table, uint64_t cap, uint8_t* has_dup,
+                              hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rmdup_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, keys, table_keys,
-                       table_first, cap, has_dup);
+    hipLaunchKernelGGL(k_rmdup_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, keys, table, cap, has_dup);
     return hipGetLastError();
 }
 

@@ -23,17 +23,17 @@ constexpr uint32_t ERR_HASH_COLLISION = 512u;
 // keys[i] = XXH64(subject i, seed 0); keys2 (may be null) = the same with another seed (multi-GPU verification key)
 hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                              const RmDupParams& P, uint64_t* keys, uint64_t* keys2, hipStream_t st);
-// table_keys / table_first: `cap` slots (power of two), zero / 0xFF initialised by the caller
-hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table_keys,
-                               uint64_t* table_first, uint64_t cap, hipStream_t st);
+// table: `cap` slots (power of two) of 16 bytes {key, ~first record}, zeroed by the caller (key_table)
+hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table, uint64_t cap,
+                               hipStream_t st);
 hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
-                                const uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
-                                uint64_t cap, uint32_t* out_len, uint64_t* status, hipStream_t st);
+                                const uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
+                                uint64_t* status, hipStream_t st);
 
 // -d / -D side outputs: keys[i] := survivor index of record i; sizes of the removed records' text and of the
 // "<20-digit group>\t<ID>\n" rows of all members of groups of two or more; the rows themselves
-hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table_keys, const uint64_t* table_first,
-                              uint64_t cap, uint8_t* has_dup, hipStream_t st);
+hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table, uint64_t cap, uint8_t* has_dup,
+                              hipStream_t st);
 hipError_t launch_rmdup_side_sizes(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
                                    const uint8_t* has_dup, uint32_t* dup_len, uint32_t* row_len, hipStream_t st);
 hipError_t launch_rmdup_rows(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint64_t* group,
