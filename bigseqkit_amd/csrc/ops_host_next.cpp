@@ -216,7 +216,6 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     // groups: the rmdup machinery (XXH64 of the ID / name, first occurrence wins, exact verification of every other one)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
     HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     Arena A;
     const uint64_t o_has = A.take(N), o_ord = A.take(N * 4);
     rc = arena_reserve(c, &A);
@@ -229,7 +228,8 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     auto fail = [&](int code) { return code; };
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
     HIP_TRYX(c, hipMemsetAsync(d_ord, 0, N * 4, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));  // d_keys[i] := first record of i's group
+    // collisions checked, and d_keys[i] := first record of i's group
+    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     // how many records are not the first of their group
     uint64_t status = 0, m = 0;
@@ -608,9 +608,8 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     // groups by ID (XXH64, first occurrence, exact verification of every other member)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
     HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));
+    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(d_tot, 0, 8 * 8, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
@@ -718,9 +717,8 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     HIP_TRYX(c, hipMemcpyAsync(d_ends, file_ends, (size_t)nfiles * 8, hipMemcpyHostToDevice, st));
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
     HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));
+    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 8, st));
     HIP_TRYX(c, launch_common_masks(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, st));
     uint64_t status = 0;
@@ -795,9 +793,8 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     uint64_t* d_cntoff = A.at<uint64_t>(o_cntoff);
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
     HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st));
+    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
     uint64_t first2 = 0, status = 0;

@@ -274,13 +274,21 @@ __device__ __forceinline__ uint32_t format_len(uint32_t name_len, uint32_t L, in
     return n;
 }
 
+// GROUP: also what k_rmdup_group does (keys[i] := first record of i's group, has_dup[first] := 1), for the operators that
+// need the groups right away (rename, pair, common, concat) -- one table lookup per record instead of two
+template <bool GROUP>
 __global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
-                                                       RmDupParams P, const uint64_t* __restrict__ keys,
+                                                       RmDupParams P, uint64_t* keys,
                                                        const uint64_t* __restrict__ table, uint64_t cap,
-                                                       uint32_t* __restrict__ out_len, uint64_t* __restrict__ status) {
+                                                       uint32_t* __restrict__ out_len, uint64_t* __restrict__ status,
+                                                       uint8_t* __restrict__ has_dup) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n) return;
     const uint64_t first = lookup_first(table, slot_key(keys[i]), cap - 1);
+    if (GROUP) {
+        keys[i] = first;
+        if (first != i) has_dup[first] = 1;
+    }
     bool keep = first == i;
     if (!keep) {
         const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
@@ -467,8 +475,18 @@ hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const 
                                 uint64_t* status, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    hipLaunchKernelGGL(k_rmdup_resolve, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys, table, cap,
-                       out_len, status);
+    hipLaunchKernelGGL(k_rmdup_resolve<false>, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P,
+                       const_cast<uint64_t*>(keys), table, cap, out_len, status, (uint8_t*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                                      uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
+                                      uint64_t* status, uint8_t* has_dup, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    hipLaunchKernelGGL(k_rmdup_resolve<true>, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys, table, cap,
+                       out_len, status, has_dup);
     return hipGetLastError();
 }
 

@@ -30,6 +30,11 @@ hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const 
                                 const uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
                                 uint64_t* status, hipStream_t st);
 
+// the same and, in the same pass, keys[i] := first record of i's group, has_dup[first] := 1 (has_dup zeroed by the caller)
+hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                                      uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
+                                      uint64_t* status, uint8_t* has_dup, hipStream_t st);
+
 // -d / -D side outputs: keys[i] := survivor index of record i; sizes of the removed records' text and of the
 // "<20-digit group>\t<ID>\n" rows of all members of groups of two or more; the rows themselves
 hipError_t launch_rmdup_group(uint64_t n, uint64_t* keys, const uint64_t* table, uint64_t cap, uint8_t* has_dup,
