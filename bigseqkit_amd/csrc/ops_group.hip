@@ -276,9 +276,18 @@ hipError_t group_sort_temp_bytes(uint64_t m, size_t* bytes) {
     return rocprim::radix_sort_keys(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)m, 0, 64, (hipStream_t)0);
 }
 
-hipError_t launch_group_sort(void* tmp, size_t tmp_bytes, const uint64_t* in, uint64_t* out, uint64_t m, hipStream_t st) {
+hipError_t launch_group_sort(void* tmp, size_t tmp_bytes, const uint64_t* in, uint64_t* out, uint64_t m, hipStream_t st,
+                             uint64_t records, bool index_ordered) {
     if (m == 0) return hipSuccess;
-    return rocprim::radix_sort_keys(tmp, tmp_bytes, in, out, (size_t)m, 0, 64, st);
+    // group < records: only the bits that can be set take part; and when the list is already in index order (the low
+    // word) the stable sort by the group alone gives the (group, index) order: 4 radix passes instead of 8
+    unsigned hi = 64;
+    if (records) {
+        unsigned b = 1;
+        while (b < 32 && (records - 1) >> b) ++b;
+        hi = 32 + b;
+    }
+    return rocprim::radix_sort_keys(tmp, tmp_bytes, in, out, (size_t)m, index_ordered ? 32u : 0u, hi, st);
 }
 
 hipError_t launch_group_ordinals(const uint64_t* sorted, uint64_t m, uint32_t* ord, hipStream_t st) {

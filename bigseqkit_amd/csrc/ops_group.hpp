@@ -13,7 +13,9 @@ namespace bsk {
 hipError_t launch_group_compact(const uint64_t* group, uint64_t n, uint64_t* list, uint64_t* count, hipStream_t st);
 // bytes of temporary storage rocprim::radix_sort_keys needs for m keys
 hipError_t group_sort_temp_bytes(uint64_t m, size_t* bytes);
-hipError_t launch_group_sort(void* tmp, size_t tmp_bytes, const uint64_t* in, uint64_t* out, uint64_t m, hipStream_t st);
+// records: number of records (groups are < records; 0 = unknown, all 64 bits); index_ordered: `in` is in index order
+hipError_t launch_group_sort(void* tmp, size_t tmp_bytes, const uint64_t* in, uint64_t* out, uint64_t m, hipStream_t st,
+                             uint64_t records = 0, bool index_ordered = false);
 // ord[i] := 1 + number of earlier records of the same group, for the m sorted entries (ord is zero elsewhere)
 hipError_t launch_group_ordinals(const uint64_t* sorted, uint64_t m, uint32_t* ord, hipStream_t st);
 

@@ -271,7 +271,7 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         d_tmp = A.at<uint8_t>(o_tmp);
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 8, st));
         HIP_TRYX(c, launch_group_compact(c->d_keys, N, d_list, c->d_counter, st));
-        HIP_TRYX(c, launch_group_sort(d_tmp, tmp_bytes, d_list, d_list + m, m, st));
+        HIP_TRYX(c, launch_group_sort(d_tmp, tmp_bytes, d_list, d_list + m, m, st, N));
         HIP_TRYX(c, launch_group_ordinals(d_list + m, m, d_ord, st));
     }
     SeqParams F = format_params(c, fastq);
@@ -624,7 +624,7 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     rc = kernel_error_to_status(c, status);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_group_all(c->d_keys, N, d_list, st));
-    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st));
+    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st, N, /*index_ordered=*/true));
     HIP_TRYX(c, launch_pair_classify(d_list + N, N, (uint32_t)first2, d_state, d_partner, st));
     // formatted size of every record, totals per output
     SeqParams F = format_params(c, fastq);
@@ -808,7 +808,7 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     rc = kernel_error_to_status(c, status);
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_group_all(c->d_keys, N, d_list, st));
-    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st));
+    HIP_TRYX(c, launch_group_sort(A.at<uint8_t>(o_tmp), tmp_bytes, d_list, d_list + N, N, st, N, /*index_ordered=*/true));
     HIP_TRYX(c, launch_concat_segments(d_list + N, N, (uint32_t)first2, d_seg, st));
     ConcatParams Q;
     memset(&Q, 0, sizeof Q);
