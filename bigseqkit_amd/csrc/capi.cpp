@@ -105,8 +105,8 @@ int init_device(bsk_ctx* c) {
     c->use_dpp = !(sc && strcmp(sc, "shfl") == 0);
     const char* mr = getenv("BSK_MIN_RANGE_BYTES");
     c->min_range_bytes = mr && atoll(mr) > 0 ? (uint64_t)atoll(mr) : MIN_RANGE_BYTES;
-    HIP_TRY(c, hipMalloc((void**)&c->d_status, 2 * sizeof(uint64_t)));
-    HIP_TRY(c, hipMemset(c->d_status, 0, 2 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_status, 4 * sizeof(uint64_t)));  // [2]: scratch of bsk_stats_collect
+    HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(uint64_t)));
     if (c->op == Op::Stats) {
         const size_t len = (size_t)STATS_HDR + c->hist_cap;
         HIP_TRY(c, hipMalloc((void**)&c->d_vec, len * sizeof(uint64_t)));
@@ -483,7 +483,7 @@ static std::string describe_kernel_errors(uint64_t f, int* code) {
 static int stats_vector_to_map(bsk_ctx* c, const std::vector<uint64_t>& v, const std::vector<uint64_t>& overflow,
                                int64_t* keys, int64_t* vals, size_t cap, size_t* n_out) {
     StatsMap m;
-    for (uint32_t L = 0; L < c->hist_cap; ++L)
+    for (size_t L = 0; STATS_HDR + L < v.size(); ++L)  // (v may hold only the used prefix of the histogram)
         if (v[STATS_HDR + L]) m[(int64_t)L] = (int64_t)v[STATS_HDR + L];
     for (uint64_t L : overflow) m[(int64_t)L] += 1;
     const bool all = c->opts.b("All");
@@ -531,16 +531,19 @@ int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* val
     if (!n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_out");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
-    uint64_t status[2];
+    // only the used part of the 512 KiB histogram crosses PCIe (short reads: a few hundred bins)
+    const uint64_t* dv = d_vec ? (const uint64_t*)d_vec : c->d_vec;
+    HIP_TRY(c, launch_hist_extent(dv + STATS_HDR, c->hist_cap, c->d_status + 2, nullptr));
+    uint64_t status[3];
     HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
     if (status[0]) {
         int code;
         std::string m = describe_kernel_errors(status[0], &code);
         return fail(c, code, m);
     }
-    const size_t len = (size_t)STATS_HDR + c->hist_cap;
+    const size_t len = (size_t)STATS_HDR + (size_t)std::min<uint64_t>(status[2], c->hist_cap);
     std::vector<uint64_t> v(len);
-    HIP_TRY(c, hipMemcpy(v.data(), d_vec ? d_vec : (const void*)c->d_vec, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(v.data(), dv, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
     std::vector<uint64_t> ov;
     if (status[1]) {
         if (status[1] > c->overflow_cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow length list exhausted");

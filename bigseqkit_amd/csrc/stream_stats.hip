@@ -383,6 +383,24 @@ hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chun
     return hipGetLastError();
 }
 
+// one past the highest non-empty bin of the length histogram (bsk_stats_collect copies only that much to the host)
+__global__ __launch_bounds__(1024) void k_hist_extent(const uint64_t* __restrict__ hist, uint32_t cap, uint64_t* __restrict__ out) {
+    __shared__ uint32_t s_hi;
+    if (threadIdx.x == 0) s_hi = 0;
+    __syncthreads();
+    uint32_t hi = 0;
+    for (uint32_t i = threadIdx.x; i < cap; i += 1024u)
+        if (hist[i]) hi = i + 1;
+    if (hi) atomicMax(&s_hi, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s_hi;
+}
+
+hipError_t launch_hist_extent(const uint64_t* hist, uint32_t cap, uint64_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_hist_extent, dim3(1), dim3(1024), 0, st, hist, cap, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st) {
     hipLaunchKernelGGL(k_stats_stitch, dim3((nranges + 255u) / 256u), dim3(256), 0, st, nranges, D);
     return hipGetLastError();

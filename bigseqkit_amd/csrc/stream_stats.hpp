@@ -46,6 +46,8 @@ constexpr uint32_t RF_VISITED = 1u, RF_HAS_HEADER = 2u, RF_HEAD_CLOSED = 4u, RF_
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
                        uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode = false);
 hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st);
+// *out := one past the highest non-zero entry of hist[0, cap)
+hipError_t launch_hist_extent(const uint64_t* hist, uint32_t cap, uint64_t* out, hipStream_t st);
 hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_t* buf, uint64_t n,
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
                         hipStream_t st);
