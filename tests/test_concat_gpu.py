@@ -59,6 +59,28 @@ def test_concat_matches_oracle(fastq, width, monkeypatch):
         assert len(want) > 100
 
 
+def test_concat_many_records():
+    # 200 k records with repeated IDs on both sides (every A of an ID with every B of it)
+    rng = random.Random(505)
+    n = 100000
+
+    def side(tag):
+        out = []
+        for _ in range(n):
+            k = rng.randrange(n // 2)
+            L = (k * 7 + tag) % 40
+            out.append(f"@id{k} {tag}\n{'ACGT' * 10}\n+\n{'I' * 40}\n".replace("ACGT" * 10, ("ACGT" * 10)[:L]).replace("I" * 40, "I" * L))
+        return "".join(out).encode()
+
+    a, b = side(1), side(2)
+    fa, fb = bsk.SeqFrame(bsk.FORMAT_FASTQ, [dev(a)]), bsk.SeqFrame(bsk.FORMAT_FASTQ, [dev(b)])
+    for o in ({}, {"Full": True}):
+        want = oracle.concat(a, b, True, json.dumps(o))
+        got = bsk.Concat(fa, fb, _Opts(o))
+        assert got == want, o
+        assert want.count(b"\n") > 4 * 100000
+
+
 def test_concat_hand_cases_and_cli(tmp_path):
     a = b">x 1\nACGT\n>y\nGG\n>x 2\nTT\n"
     b = b">z q\nAA\n>x d\nCCC\n>x e\nG"           # no newline at the end

@@ -68,6 +68,30 @@ def test_pair_matches_oracle(fastq, monkeypatch):
     assert got2[:2] == want[:2] and got2[2:] == (b"", b"")
 
 
+def many_reads(rng, ids, tag):
+    seqs = ["".join(rng.choice("ACGT") for _ in range(L)) for L in (1, 7, 16, 33, 50)]
+    out = []
+    for k in ids:
+        s = seqs[k % 5]
+        out.append(f"@r{k} {tag}\n{s}\n+\n{'F' * len(s)}\n")
+    return "".join(out).encode()
+
+
+def test_pair_many_records_shuffled_mates():
+    # 250 k records: key table of 2^19 slots, group values beyond 16 bits in the radix sort of (group, index)
+    rng = random.Random(404)
+    n = 120000
+    ids1 = [k for k in range(n) if rng.random() < 0.97] + [rng.randrange(n) for _ in range(6000)]
+    ids2 = [k for k in range(n) if rng.random() < 0.97] + [rng.randrange(n) for _ in range(6000)]
+    rng.shuffle(ids1)
+    rng.shuffle(ids2)
+    a, b = many_reads(rng, ids1, 1), many_reads(rng, ids2, 2)
+    want = oracle.pair(a, b, True, '{"SaveUnpaired": true}')
+    got = run_pair(a, b, True, {"SaveUnpaired": True})
+    assert got == want
+    assert got[0].count(b"\n") > 4 * 100000 and len(got[2]) and len(got[3])
+
+
 def test_pair_hand_cases(tmp_path):
     a = b"@r1 1\nAC\n+\nII\n@r2 1\nGG\n+\nII\n@r1 1b\nTT\n+\nII\n@r5\nA\n+\nI\n"
     b = b"@r2 2\nCC\n+\nII\n@r9\nT\n+\nI\n@r1 2\nGT\n+\nII\n"
