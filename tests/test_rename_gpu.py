@@ -66,6 +66,21 @@ def test_rename_matches_oracle(fastq, width, ids, monkeypatch):
         assert got == want, (o, got[:300], want[:300])
 
 
+def test_rename_many_records():
+    # 200 k records, IDs drawn from 70 k names: ordinals from the radix sort of (group, index) with groups beyond 16 bits
+    rng = random.Random(606)
+    out = []
+    for i in range(200000):
+        k = rng.randrange(70000)
+        L = k % 23
+        out.append(f"@n{k} d{i % 3}\n{'ACGTTGCAACGTTGCAACGTTGC'[:L]}\n+\n{'F' * L}\n")
+    data = "".join(out).encode()
+    want = oracle.rename(data, True, "{}")
+    got = bsk.Rename(bsk.SeqFrame(bsk.FORMAT_FASTQ, [dev(data)]), _Opts({}))
+    assert got == want
+    assert b"_2 " in got and b"_5 " in got
+
+
 def test_rename_hand_cases_and_ordinals_beyond_one_digit():
     fa = b">a x y\nACGT\n>b\nGG\n>a\tz\nTT\n>a\nC\n>b q\nA\n"
     got = bsk.Rename(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(fa)]), _Opts({}))
