@@ -16,6 +16,8 @@ __device__ __forceinline__ uint64_t lower_bound64(const uint64_t* __restrict__ a
     return lo;
 }
 
+constexpr uint32_t SEG_DIRECT = 0x80000000u;  // seg[3 i + 2]: seg[3 i] is the single mate, not a segment start
+
 __global__ __launch_bounds__(256) void k_concat_segments(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t first2,
                                                          uint32_t* __restrict__ seg) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,9 +32,18 @@ __global__ __launch_bounds__(256) void k_concat_segments(const uint64_t* __restr
     while (end < n && (sorted[end] >> 32) == g && steps < 8) { ++end; ++steps; }
     if (end < n && (sorted[end] >> 32) == g) end = lower_bound64(sorted, end, n, (g + 1) << 32);
     const uint64_t m1 = lower_bound64(sorted, s, end, (g << 32) | first2) - s;
-    seg[3 * (uint64_t)i] = (uint32_t)s;
+    const uint64_t m2 = end - s - m1;
+    // a record of file 1 with exactly one mate (the usual case) gets the mate itself instead of the segment start:
+    // one dependent load less before the emit can begin
+    const bool direct = i < first2 && m2 == 1;
+    seg[3 * (uint64_t)i] = direct ? (uint32_t)sorted[s + m1] : (uint32_t)s;
     seg[3 * (uint64_t)i + 1] = (uint32_t)m1;
-    seg[3 * (uint64_t)i + 2] = (uint32_t)(end - s - m1);
+    seg[3 * (uint64_t)i + 2] = direct ? (1u | SEG_DIRECT) : (uint32_t)m2;
+}
+
+// the k-th mate (file 2) of a record of file 1
+__device__ __forceinline__ uint32_t mate_of(const uint64_t* __restrict__ sorted, uint32_t s, uint32_t m1, uint32_t m2raw, uint32_t k) {
+    return (m2raw & SEG_DIRECT) ? s : (uint32_t)sorted[(uint64_t)s + m1 + k];
 }
 
 __device__ __forceinline__ uint32_t wrapped(uint32_t L, uint32_t lw) { return L + ((lw && L) ? (L - 1) / lw : 0u); }
@@ -50,7 +61,7 @@ __global__ __launch_bounds__(256) void k_concat_size(const uint8_t* __restrict__
                                                      uint64_t* __restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n) return;
-    const uint32_t s = seg[3 * i], m1 = seg[3 * i + 1], m2 = seg[3 * i + 2];
+    const uint32_t s = seg[3 * i], m1 = seg[3 * i + 1], m2raw = seg[3 * i + 2], m2 = m2raw & ~SEG_DIRECT;
     const uint8_t* h = buf + t.start[i] + 1;
     const uint32_t lh = t.l_head[i];
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(256) void k_concat_size(const uint8_t* __restrict__
             uint32_t off;
             const uint32_t il = id_span_of(h, hl, P.id_mode, &off, P.buf_end);    // Name: recordA.ID (:133)
             for (uint32_t k = 0; k < m2; ++k) {
-                const uint32_t b = (uint32_t)sorted[(uint64_t)s + m1 + k];
+                const uint32_t b = mate_of(sorted, s, m1, m2raw, k);
                 bytes += element_bytes(il, (uint64_t)t.l_seq[i] + t.l_seq[b], P);
             }
             cnt = m2;
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256) void k_concat_emit(const uint8_t* __restrict__
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (i >= t.n || out_len[i] == 0) return;
-    const uint32_t s = seg[3 * i], m1 = seg[3 * i + 1], m2 = seg[3 * i + 2];
+    const uint32_t s = seg[3 * i], m1 = seg[3 * i + 1], m2raw = seg[3 * i + 2], m2 = m2raw & ~SEG_DIRECT;
     const uint8_t* h = buf + t.start[i] + 1;
     const uint32_t lh = t.l_head[i];
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(256) void k_concat_emit(const uint8_t* __restrict__
         uint32_t off;
         const uint32_t il = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
         for (uint32_t k = 0; k < m2; ++k) {
-            const uint64_t b = (uint32_t)sorted[(uint64_t)s + m1 + k];
+            const uint64_t b = mate_of(sorted, s, m1, m2raw, k);
             const Text TB = text_of(buf, t, tt, b);
             o += put_element<G>(o, gl, h + off, il, TA, TB, qa, P.fastq ? qual_of(buf, t, b) : nullptr, P);
         }
