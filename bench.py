@@ -32,23 +32,65 @@ def main():
     ap.add_argument("--gb", type=float, default=FILE_BYTES / 1e9, help="size of the synthetic file (GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only prove that --gpus N ranks start and reduce together (backend from BSK_BENCH_BACKEND, "
+                         "default nccl; the CPU test suite runs it with gloo), print one JSON line and exit")
     args = ap.parse_args()
+    want_world = max(1, args.gpus)
+
+    # ---- self-launch: `python bench.py --gpus N` starts N ranks itself (one process per GPU); under torchrun
+    # (WORLD_SIZE set) this process IS one of the ranks.  Either way the world size must equal --gpus.
+    if "WORLD_SIZE" not in os.environ and want_world > 1:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(want_world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     import torch
     import torch.distributed as dist
-    import bigseqkit_amd as bsk
-    from bigseqkit_amd import _lib, dist as bdist
-    from bigseqkit_amd._lib import lib, check
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world != want_world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node == --gpus "
+                         "(or without torchrun: bench.py starts the ranks itself)" % (want_world, world))
+    backend = os.environ.get("BSK_BENCH_BACKEND", "nccl")
+    if args.launch_check:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            one = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        assert dist.get_world_size() == want_world and int(one.item()) == want_world
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "backend": backend,
+                              "ranks_reduced": int(one.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+
+    import bigseqkit_amd as bsk
+    from bigseqkit_amd import _lib, dist as bdist
+    from bigseqkit_amd._lib import lib, check
+
+    if lib.bsk_device_count() <= 0 or not torch.cuda.is_available():
+        raise SystemExit("bench.py: no HIP device visible: the hot path has no CPU fallback (BSK_ERR_NO_DEVICE)")
+    if torch.cuda.device_count() < (local + 1):
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+        assert dist.get_world_size() == want_world
 
     # ---- the synthetic file, cut into record-aligned shards --------------------------
     total_rec = int(args.gb * 1e9) // REC
@@ -74,12 +116,23 @@ def main():
         vec = torch.zeros(vlen, dtype=torch.int64, device=dev)
         return op, vec
 
+    reduce_s = [0.0]
+
     def one_step(op, vec):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         vec.zero_()
+        check(lib.bsk_stats_reset(op.ctx, st), op.ctx)  # error flags + overflow list of the context (the vector is ours)
         check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nbytes, 1, bsk.FORMAT_FASTQ, rank,
                                 C.c_void_p(vec.data_ptr()), st), op.ctx)
-        bdist.all_reduce_stats_vector(vec)  # StatsReduce: one sum all-reduce of the dense map (RCCL), no-op at N=1
+        if world > 1:
+            # StatsReduce (bigseqkit/stats.go:91): ONE sum all-reduce of the dense map over RCCL -- the only collective.
+            # Timed on its own (host clock around a synchronised collective; includes the wait for the slowest rank).
+            torch.cuda.synchronize()
+            t_r = time.perf_counter()
+            bdist.all_reduce_stats_vector(vec)
+            bdist.exchange_stats_overflow(op, vec)  # lengths >= 65536 of the other ranks (none for 150 bp reads)
+            torch.cuda.synchronize()
+            reduce_s[0] += time.perf_counter() - t_r
         m = bsk.api._collect_map(op, C.c_void_p(vec.data_ptr()))
         info = bsk.api._finalize(op, m)
         buf = C.create_string_buffer(4096)
@@ -94,6 +147,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        reduce_s[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
             m, text = one_step(op, vec)
@@ -115,6 +169,7 @@ def main():
 
     op, vec = make_op(False)
     dt, m, text, k_ms, p_ms = timed(op, vec, args.steps, args.warmup)
+    reduce_ms = reduce_s[0] / args.steps * 1e3
     want_row = "input0\tN/A\tDNA\t%d\t%d\t150\t150.0\t150" % (total_rec, total_rec * 150)
     verified = (m.get(150) == total_rec) and text.splitlines()[1] == want_row
     op.close()
@@ -123,8 +178,23 @@ def main():
     op, vec = make_op(True)
     dta, ma, texta, ka_ms, _ = timed(op, vec, max(3, args.steps // 2), 1)
     stepsa = max(3, args.steps // 2)
-    verified_a = ma.get(150) == total_rec and ma.get(-3) == 0 and abs(ma.get(-1, 0) / (150 * total_rec) - 137 / 256) < 1e-3
     op.close()
+    # exact expectation for -a, computed WITHOUT the parser: FASTQ-150 records are 317 bytes with the quality string at
+    # columns [166, 316), so Q20 / Q30 are plain column counts over the fixed layout (torch, chunked; untimed)
+    q20 = q30 = 0
+    view = shard.view(nrec, REC)
+    step_rows = 4_000_000
+    for r0 in range(0, nrec, step_rows):
+        q = view[r0:r0 + step_rows, 166:316]
+        q20 += int((q >= 33 + 20).sum().item())
+        q30 += int((q >= 33 + 30).sum().item())
+        del q
+    if world > 1:
+        t = torch.tensor([q20, q30], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        q20, q30 = int(t[0].item()), int(t[1].item())
+    verified_a = (ma.get(150) == total_rec and ma.get(-3) == 0 and ma.get(-1) == q20 and ma.get(-2) == q30
+                  and sum(v for k, v in ma.items() if k >= 0) == total_rec)
 
     if rank != 0:
         if world > 1:
@@ -150,7 +220,7 @@ def main():
         "unit": "M records/s",
         "gb_per_s": round(total_bytes * args.steps / dt / 1e9, 2),
         "frac_of_hbm_peak": round(total_bytes * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
-        "n_gpus": world,
+        "n_gpus": dist.get_world_size() if world > 1 else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -163,6 +233,8 @@ def main():
                                "HBM-resident, %d record-aligned shard(s)" % (total_bytes / 1e9, total_rec, world),
                    "command": "stats", "records": total_rec, "bytes": total_bytes, "seed": 42},
         "bit_exact_vs_expected_row": bool(verified),
+        "shard_bytes_per_rank": nbytes,
+        "allreduce_ms_per_step": round(reduce_ms, 4) if world > 1 else None,
         "roofline": {
             "bound": "hbm",
             "kernel": "k_stats<FASTQ,default>",
@@ -182,6 +254,7 @@ def main():
             "k_stats_avg_launch_ms": round(ka_ms, 4),
             "roofline_frac": round(nbytes / (ka_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ka_ms > 0 else None,
             "verified": bool(verified_a),
+            "expected": {"q20": q20, "q30": q30, "gap": 0, "how": "column counts over the fixed 317-byte layout (torch), exact equality"},
         },
     }
 

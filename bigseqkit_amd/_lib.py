@@ -79,6 +79,8 @@ SIGNATURES = {
     "bsk_stats_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _vp]),
     "bsk_stats_reset": (_i, [_vp, _vp]),
     "bsk_stats_collect": (_i, [_vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
+    "bsk_stats_overflow_get": (_i, [_vp, _p(_u64), _sz, _p(_sz)]),
+    "bsk_stats_overflow_add": (_i, [_vp, _p(_u64), _sz]),
     "bsk_stats_collect_host": (_i, [_vp, _p(_u64), _sz, _vp, _sz, _i, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_stats_merge": (_i, [_p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_stats_finalize": (_i, [_vp, _p(_i64), _p(_i64), _sz, _p(StatInfo)]),

@@ -183,6 +183,25 @@ def _run_records(op_name, run_fn, input, o, device=0, stream=None, finish=None):
     return b"".join(chunks), nrec
 
 
+def _one_shard(input):
+    """The operators whose result depends on ALL records (rmdup, rename, sort, grep --delete-matched: GroupByKey /
+    SortByKey / Reduce over the whole dataframe in the reference) see the input as ONE shard: the shards of `input`
+    back to back, a newline added where a shard lacks the final one (what cli/bigseqkit.cpp does with several input
+    files).  Across ranks the exchange of dist.py takes this place."""
+    if len(input.shards) <= 1:
+        return input
+    if all(hasattr(b, "data_ptr") for b in input.shards):
+        both, _ = _join_files(list(input.shards))
+        return SeqFrame(input.format, [both])
+    if any(hasattr(b, "data_ptr") for b in input.shards):
+        raise ValueError("a SeqFrame must hold either host or device shards, not both")
+    parts = []
+    for b in input.shards:
+        b = bytes(b)
+        parts.append(b if (not b or b.endswith(b"\n")) else b + b"\n")
+    return SeqFrame(input.format, [b"".join(parts)])
+
+
 def Seq(input, o=None, device=0):
     """bigseqkit/seq.go:157-170 -- returns the bytes StoreFASTX would write"""
     return _run_records("SeqTransform", lib.bsk_seq_run, input, o or SeqKitSeqOptions(), device)[0]
@@ -191,6 +210,8 @@ def Seq(input, o=None, device=0):
 def Grep(input, o, device=0):
     """bigseqkit/grep.go:130-159 (Count forced off, :136-137)"""
     o._v["Count"] = False
+    if o._v.get("DeleteMatched"):  # the driver keeps the lowest partition per pattern (bigseqkit/grep.go:144-156): global
+        input = _one_shard(input)
     return _run_records("Grep", lib.bsk_grep_run, input, o, device)[0]
 
 
@@ -224,8 +245,8 @@ def Translate(input, o=None, device=0):
 
 
 def RmDup(input, o=None, device=0):
-    """bigseqkit/rmdup.go:70-108 (duplicates are global: the input must be one shard per rank)"""
-    return _run_records("RmDup", lib.bsk_rmdup_run, input, o or SeqKitRmDupOptions(), device,
+    """bigseqkit/rmdup.go:70-108 (GroupByKey, :97: duplicates are global -- several shards are joined into one)"""
+    return _run_records("RmDup", lib.bsk_rmdup_run, _one_shard(input), o or SeqKitRmDupOptions(), device,
                         finish=lib.bsk_rmdup_finish)[0]
 
 
@@ -240,13 +261,13 @@ def Duplicate(input, o=None, device=0):
 
 
 def Rename(input, o=None, device=0):
-    """bigseqkit/rename.go:34-60 (groups are global: the input must be one shard per rank, like RmDup)"""
-    return _run_records("Rename", lib.bsk_rename_run, input, o or SeqKitRenameOptions(), device)[0]
+    """bigseqkit/rename.go:34-60 (ordinals count over the whole dataframe: several shards are joined, like RmDup)"""
+    return _run_records("Rename", lib.bsk_rename_run, _one_shard(input), o or SeqKitRenameOptions(), device)[0]
 
 
 def Sort(input, o=None, device=0):
-    """bigseqkit/sort.go:91-147 (global: the input must be one shard per rank)"""
-    return _run_records("Sort", lib.bsk_sort_run, input, o or SeqKitSortOptions(), device)[0]
+    """bigseqkit/sort.go:91-147 (SortByKey over the whole dataframe: several shards are joined)"""
+    return _run_records("Sort", lib.bsk_sort_run, _one_shard(input), o or SeqKitSortOptions(), device)[0]
 
 
 def Faidx(input, o=None, device=0):

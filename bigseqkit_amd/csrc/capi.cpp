@@ -550,7 +550,56 @@ int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* val
         ov.resize(status[1]);
         HIP_TRY(c, hipMemcpy(ov.data(), c->d_overflow, status[1] * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
+    // v[5] counts the lengths >= hist_cap that went into this vector (it is summed by the all-reduce); the list itself
+    // is per context.  A vector reduced over ranks whose lists were not exchanged would silently lose those records.
+    if (v[5] != ov.size())
+        return fail(c, BSK_ERR_INVALID_ARG,
+                    "libbsk: the stats vector counts " + std::to_string(v[5]) + " sequence lengths >= " +
+                        std::to_string(c->hist_cap) + " but this context holds " + std::to_string(ov.size()) +
+                        ": exchange the overflow lists of the other shards (bsk_stats_overflow_get / _add) before "
+                        "collecting, and reset the context together with a caller-owned vector (bsk_stats_reset)");
     return stats_vector_to_map(c, v, ov, keys, vals, cap, n_out);
+}
+
+int bsk_stats_overflow_get(bsk_ctx* c, uint64_t* lens, size_t cap, size_t* n_out) {
+    if (!c || c->op != Op::Stats || !n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    uint64_t status[2];
+    HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+    if (status[1] > c->overflow_cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow length list exhausted");
+    *n_out = (size_t)status[1];
+    if (cap == 0 && !lens) return BSK_OK;  // size query
+    if (status[1] > cap || !lens) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow list does not fit the caller's buffer");
+    if (status[1]) HIP_TRY(c, hipMemcpy(lens, c->d_overflow, status[1] * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return BSK_OK;
+}
+
+int bsk_stats_overflow_add(bsk_ctx* c, const uint64_t* lens, size_t n) {
+    if (!c || c->op != Op::Stats || (n && !lens)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    if (n == 0) return BSK_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    uint64_t status[2];
+    HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+    if (status[1] > c->overflow_cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: overflow length list exhausted");
+    const uint64_t need = status[1] + n;
+    if (need > c->overflow_cap) {
+        uint64_t* nb = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&nb, (need + 1024) * sizeof(uint64_t)));
+        if (c->d_overflow) {
+            if (status[1]) HIP_TRY(c, hipMemcpy(nb, c->d_overflow, status[1] * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+            HIP_TRY(c, hipFree(c->d_overflow));
+        }
+        c->d_overflow = nb;
+        c->overflow_cap = need + 1024;
+    }
+    HIP_TRY(c, hipMemcpy(c->d_overflow + status[1], lens, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    status[1] = need;
+    HIP_TRY(c, hipMemcpy(c->d_status + 1, &status[1], sizeof(uint64_t), hipMemcpyHostToDevice));
+    return BSK_OK;
 }
 
 int bsk_stats_collect_host(bsk_ctx* c, const uint64_t* h_vec, size_t vec_len, const uint8_t* first_record,

@@ -61,7 +61,7 @@ hipError_t launch_reset_queue(uint32_t* queue, hipStream_t st);
 // gather the per-range slices of a sparse table (mode 2) into a dense one
 // FASTA, line-start ranges: complete l_seq / aux / text_w of the records that span ranges (dense table, exact bases)
 hipError_t launch_index_stitch(const RecordTable& dense, const RangePart* parts, const uint64_t* range_count,
-                               const uint64_t* range_base, uint32_t nranges, hipStream_t st);
+                               const uint64_t* range_base, uint32_t nranges, uint64_t* status, hipStream_t st);
 hipError_t launch_index_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
                                 const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, hipStream_t st);
 

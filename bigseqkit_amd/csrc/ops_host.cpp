@@ -203,7 +203,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
         HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
     }
     if (total == 0) return BSK_OK;
-    if (D.parts) HIP_TRYX(c, launch_index_stitch(c->table, c->d_parts, c->d_range_count, c->d_range_base, nranges, st));
+    if (D.parts) HIP_TRYX(c, launch_index_stitch(c->table, c->d_parts, c->d_range_count, c->d_range_base, nranges, c->d_status, st));
     // start[n] = effective end of the shard (anchors[nranges])
     HIP_TRYX(c, hipMemcpyAsync(c->table.start + total, anchors + nranges, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     return BSK_OK;
@@ -1382,6 +1382,34 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
 // ---------------------------------------------------------------------------
 #include "genetic_codes.inc"
 
+// names of the tables as the reference lists them (bigseqkit-cli/translate.go:55-78); `translate -l 0` prints "ID\tName"
+static const struct { int id; const char* name; } kCodeNames[] = {
+    {1, "The Standard Code"},
+    {2, "The Vertebrate Mitochondrial Code"},
+    {3, "The Yeast Mitochondrial Code"},
+    {4, "The Mold, Protozoan, and Coelenterate Mitochondrial Code and the Mycoplasma/Spiroplasma Code"},
+    {5, "The Invertebrate Mitochondrial Code"},
+    {6, "The Ciliate, Dasycladacean and Hexamita Nuclear Code"},
+    {9, "The Echinoderm and Flatworm Mitochondrial Code"},
+    {10, "The Euplotid Nuclear Code"},
+    {11, "The Bacterial, Archaeal and Plant Plastid Code"},
+    {12, "The Alternative Yeast Nuclear Code"},
+    {13, "The Ascidian Mitochondrial Code"},
+    {14, "The Alternative Flatworm Mitochondrial Code"},
+    {16, "Chlorophycean Mitochondrial Code"},
+    {21, "Trematode Mitochondrial Code"},
+    {22, "Scenedesmus obliquus Mitochondrial Code"},
+    {23, "Thraustochytrium Mitochondrial Code"},
+    {24, "Pterobranchia Mitochondrial Code"},
+    {25, "Candidate Division SR1 and Gracilibacteria Code"},
+    {26, "Pachysolen tannophilus Nuclear Code"},
+    {27, "Karyorelict Nuclear"},
+    {28, "Condylostoma Nuclear"},
+    {29, "Mesodinium Nuclear"},
+    {30, "Peritrich Nuclear"},
+    {31, "Blastocrithidia Nuclear"},
+};
+
 static const GeneticCode* find_code(int id) {
     for (auto& g : kGeneticCodes)
         if (g.id == id) return &g;
@@ -1405,8 +1433,10 @@ void validate_translate_opts(bsk_ctx* c) {
         c->frames.push_back((int)v);
     }
     if (c->frames.size() > 6) throw OptError("libbsk: at most 6 frames per call");
-    if (o.i("ListTranslTable") >= 0 || o.i("ListTranslTableWithAmbCodons") >= 0)
-        throw OptError("libbsk: translate -l / -L table listings are not supported by the HIP path");
+    // translate.go:75-101: -l 0 / -L 0 list the tables; -l N / -L N print bio's CodonTable.String() /
+    // StringWithAmbiguousCodons(), whose layout lives in shenwei356/bio (not in tree) -- refused, see PARITY.md
+    if (o.i("ListTranslTable") > 0 || o.i("ListTranslTableWithAmbCodons") > 0)
+        throw OptError("libbsk: translate -l N / -L N (the codon listing of one table) is not provided; -l 0 lists the tables");
 }
 
 // 4096-entry tables over 4-bit IUPAC codes (A=1 C=2 G=4 T=8): amino acid common to all
@@ -1448,8 +1478,23 @@ static void build_codon_tables(const GeneticCode& g, uint8_t* aa, uint8_t* start
                 if (g.starts[idx64(b1, b2, b3)] == 'M') start[(b1 << 8) | (b2 << 4) | b3] = 1;
 }
 
+// translate.go:78-89: with -l 0 or -L 0 every Call returns the list of tables ("ID\tName", ascending ids) and reads no record
+static int translate_list_tables(bsk_ctx* c, bsk_out* out) {
+    std::string txt;
+    uint64_t rows = 0;
+    for (auto& e : kCodeNames) { txt += std::to_string(e.id) + "\t" + e.name + "\n"; ++rows; }
+    int rc = ensure_out(c, txt.size());
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, hipMemcpy(c->d_out, txt.data(), txt.size(), hipMemcpyHostToDevice));
+    out->d_data = c->d_out;
+    out->len = txt.size();
+    out->records = rows;
+    return BSK_OK;
+}
+
 int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
+    if (o.i("ListTranslTable") == 0 || o.i("ListTranslTableWithAmbCodons") == 0) return translate_list_tables(c, out);
     int rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);

@@ -28,6 +28,14 @@
 
 namespace bsk {
 
+// The grouping / sorting operators pack (group << 32) | record index and use 32-bit permutations: a shard of 2^32 or more
+// records (> 4 x 10^9: more than 1 TB of 317-byte reads) is refused instead of being grouped wrongly.
+static int check_u32_records(bsk_ctx* c, const char* op) {
+    if (c->table.n < (1ull << 32)) return BSK_OK;
+    c->set_error(std::string("libbsk: ") + op + ": 2^32 or more records in one shard are not supported (cut the input into more shards)");
+    return BSK_ERR_UNSUPPORTED;
+}
+
 // ---------------------------------------------------------------------------
 // fq2fa, range / head, duplicate
 // ---------------------------------------------------------------------------
@@ -194,6 +202,7 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
     int rc = build_index(c, d_buf, n, format, st);
+    if (rc == BSK_OK) rc = check_u32_records(c, "rename");  // (group << 32 | index) keys, u32 permutations
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;
@@ -313,6 +322,7 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
     int rc = build_index(c, d_buf, n, format, st);
+    if (rc == BSK_OK) rc = check_u32_records(c, "sort");  // (group << 32 | index) keys, u32 permutations
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;
@@ -567,6 +577,7 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     const bool fastq = format == BSK_FORMAT_FASTQ;
     for (int k = 0; k < 4; ++k) { outs[k].d_data = nullptr; outs[k].len = 0; outs[k].records = 0; }
     int rc = build_index(c, d_buf, n, format, st);
+    if (rc == BSK_OK) rc = check_u32_records(c, "pair");  // (group << 32 | index) keys, u32 permutations
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) {
         bsk_out tmp;
@@ -686,6 +697,7 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
     int rc = build_index(c, d_buf, n, format, st);
+    if (rc == BSK_OK) rc = check_u32_records(c, "common");  // (group << 32 | index) keys, u32 permutations
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;
@@ -761,6 +773,7 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
     int rc = build_index(c, d_buf, n, format, st);
+    if (rc == BSK_OK) rc = check_u32_records(c, "concat");  // (group << 32 | index) keys, u32 permutations
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;

@@ -411,7 +411,8 @@ __global__ void k_reset_queue(uint32_t* q) { *q = 0; }
 // that closes it.  Chains are disjoint (see k_stats_stitch).
 __global__ __launch_bounds__(256) void k_index_stitch(RecordTable t, const RangePart* __restrict__ parts,
                                                       const uint64_t* __restrict__ range_count,
-                                                      const uint64_t* __restrict__ range_base, uint32_t nranges) {
+                                                      const uint64_t* __restrict__ range_base, uint32_t nranges,
+                                                      uint64_t* __restrict__ status) {
     const uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (r0 >= nranges) return;
     const uint32_t f0 = parts[r0].flags;
@@ -441,8 +442,12 @@ __global__ __launch_bounds__(256) void k_index_stitch(RecordTable t, const Range
             bases += Q.head_bases;
             if (closed) {
                 const uint64_t seq0 = t.start[g] + t.l_head[g] + 1;
+                const uint64_t region = Q.head_end_abs > seq0 ? Q.head_end_abs - seq0 : 0;
+                // the record table keeps sequence and region lengths in 32 bits: a record of 2^32 bytes or more is
+                // refused (ERR_LINE_TOO_LONG -> BSK_ERR_UNSUPPORTED), never truncated
+                if (bases > 0xFFFFFFFFull || region > 0xFFFFFFFFull) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_LINE_TOO_LONG);
                 t.l_seq[g] = (uint32_t)bases;
-                t.aux[g] = (uint32_t)(Q.head_end_abs > seq0 ? Q.head_end_abs - seq0 : 0);
+                t.aux[g] = (uint32_t)region;
                 t.text_w[g] = nl <= 1u ? 0u : ((irr || W < 16u) ? 0xFFFFFFFFu : W);
                 return;
             }
@@ -511,8 +516,8 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64
 }
 
 hipError_t launch_index_stitch(const RecordTable& dense, const RangePart* parts, const uint64_t* range_count,
-                               const uint64_t* range_base, uint32_t nranges, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_stitch, dim3((nranges + 255u) / 256u), dim3(256), 0, st, dense, parts, range_count, range_base, nranges);
+                               const uint64_t* range_base, uint32_t nranges, uint64_t* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_stitch, dim3((nranges + 255u) / 256u), dim3(256), 0, st, dense, parts, range_count, range_base, nranges, status);
     return hipGetLastError();
 }
 

@@ -53,6 +53,7 @@ __device__ __forceinline__ void add_length(bool has, uint32_t len, uint32_t* s_h
             if (first < (uint32_t)LDS_HIST) atomicAdd(&s_hist[first], c);
             else if (first < D.hist_cap) add_big(first, c, s_hist, D);
             else {
+                atomicAdd((unsigned long long*)&D.vec[5], (unsigned long long)c);  // travels with the vector (all-reduce)
                 for (uint32_t k = 0; k < c; ++k) {
                     unsigned long long i = atomicAdd((unsigned long long*)&D.status[1], 1ull);
                     if (i < D.overflow_cap) D.overflow[i] = first;
@@ -65,6 +66,7 @@ __device__ __forceinline__ void add_length(bool has, uint32_t len, uint32_t* s_h
         if (len < (uint32_t)LDS_HIST) atomicAdd(&s_hist[len], 1u);
         else if (len < D.hist_cap) add_big(len, 1u, s_hist, D);
         else {
+            atomicAdd((unsigned long long*)&D.vec[5], 1ull);
             unsigned long long i = atomicAdd((unsigned long long*)&D.status[1], 1ull);
             if (i < D.overflow_cap) D.overflow[i] = len;
         }
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(256) void k_stats_stitch(uint32_t nranges, StatsDev
         if (len < 2048u) atomicAdd(&s_hist[len], 1u);
         else if (len < D.hist_cap) atomicAdd((unsigned long long*)&D.vec[STATS_HDR + len], 1ull);
         else {
+            atomicAdd((unsigned long long*)&D.vec[5], 1ull);
             const uint64_t i = atomicAdd((unsigned long long*)&D.status[1], 1ull);
             if (i < D.overflow_cap) D.overflow[i] = len;
         }

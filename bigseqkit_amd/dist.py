@@ -36,6 +36,40 @@ def all_reduce_stats_vector(vec):
     return vec
 
 
+def exchange_stats_overflow(op, vec, group=None):
+    """After the all-reduce, slot [5] of the stats vector is the number of sequence lengths >= hist_cap over ALL ranks,
+    but the lengths themselves sit in per-context lists (include/bsk.h).  Every rank hands its list to every other
+    (one all_gather of the counts, one of the padded lists) so that bsk_stats_collect on any rank sees all of them --
+    without this a chromosome that another rank parsed would vanish from num_seqs / sum_len / N50."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return 0
+    if int(vec[5].item()) == 0:      # nothing over the dense histogram anywhere (short reads): no exchange
+        return 0
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = C.c_size_t()
+    check(lib.bsk_stats_overflow_get(op.ctx, None, 0, C.byref(n)), op.ctx)
+    mine = (C.c_uint64 * max(1, n.value))()
+    check(lib.bsk_stats_overflow_get(op.ctx, mine, n.value, C.byref(n)), op.ctx)
+    counts, _ = _all_gather_int(n.value, vec.device, group)
+    width = max(counts)
+    pad = torch.zeros(max(1, width), dtype=torch.int64, device=vec.device)
+    if n.value:
+        pad[:n.value] = torch.tensor([int(x) for x in mine[:n.value]], dtype=torch.int64, device=vec.device)
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    added = 0
+    for r in range(world):
+        if r == rank or counts[r] == 0:
+            continue
+        vals = [int(x) for x in parts[r][:counts[r]].tolist()]
+        arr = (C.c_uint64 * len(vals))(*vals)
+        check(lib.bsk_stats_overflow_add(op.ctx, arr, len(vals)), op.ctx)
+        added += len(vals)
+    return added
+
+
 def all_reduce_count(count, device="cpu"):
     """GrepReduceCount across ranks."""
     import torch
@@ -185,11 +219,12 @@ def faidx_distributed(shard, fmt, run, group=None):
     return run(sum(sizes[:rank]))
 
 
-def store_fastx(path, payload, group=None):
+def store_fastx(path, payload, group=None, device=None):
     """StoreFASTX (`--merge`, one output file) across ranks.  The reference's FileStore passes an MPI token from
     executor to executor so that partitions append in order (bigseqkit-lib/helper.go:378-460); here every rank learns
     its byte offset from one all_gather of the payload sizes and writes its part with a single pwrite -- all ranks
-    write concurrently, the file equals the single-GPU output (rank order == file order)."""
+    write concurrently, the file equals the single-GPU output (rank order == file order).  The size tensors live on
+    `device` (default: the current GPU under the nccl backend, the host under gloo)."""
     import os
     import torch
     import torch.distributed as dist
@@ -199,9 +234,9 @@ def store_fastx(path, payload, group=None):
             f.write(payload)
         return len(payload)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([len(payload)], dtype=torch.int64), group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if device is None:  # RCCL ("nccl") only moves device tensors; gloo takes host tensors
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    sizes, _ = _all_gather_int(len(payload), device, group)
     total, off = sum(sizes), sum(sizes[:rank])
     if rank == 0:
         with open(path, "wb") as f:
@@ -209,9 +244,9 @@ def store_fastx(path, payload, group=None):
     dist.barrier(group=group)
     fd = os.open(path, os.O_WRONLY)
     try:
-        done = 0
-        while done < len(payload):
-            done += os.pwrite(fd, payload[done:], off + done)
+        done, view = 0, memoryview(payload)
+        while done < len(view):
+            done += os.pwrite(fd, view[done:], off + done)
     finally:
         os.close(fd)
     dist.barrier(group=group)

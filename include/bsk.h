@@ -87,7 +87,10 @@ int bsk_find_record_start(const uint8_t* buf, size_t n, size_t from, int format,
  *     [8 + L] = count of records with sequence length L, 0 <= L < hist_cap
  * so that StatsReduce across GPUs is ONE sum all-reduce (RCCL) on that vector.
  * Lengths >= hist_cap go to a ctx-owned overflow list merged by
- * bsk_stats_collect().  Slots [4] and [5] are per-shard diagnostics. */
+ * bsk_stats_collect(); slot [5] counts them, so after a reduction over ranks the
+ * collecting context must hold that many list entries (bsk_stats_overflow_get /
+ * _add move the lists between ranks; bsk_stats_collect fails otherwise instead of
+ * dropping chromosome-sized records).  Slot [4] is a per-shard diagnostic. */
 #define BSK_STATS_HDR 8
 size_t bsk_stats_vector_len(const bsk_ctx* ctx);
 /* One Stats.Call over a shard.  `shard` holds n bytes of FASTA/FASTQ text
@@ -115,7 +118,12 @@ int bsk_device_copy(void* dst, const void* src, size_t n, int kind); /* synchron
  * chunks, two device buffers; BSK_STAGE_BYTES overrides the chunk size).  NULL when the allocation fails. */
 void* bsk_host_alloc(size_t n);
 void bsk_host_free(void* p);
-int bsk_stats_reset(bsk_ctx* ctx, void* stream); /* zero the ctx-owned vector */
+int bsk_stats_reset(bsk_ctx* ctx, void* stream); /* zero the ctx-owned vector, error flags and overflow list */
+/* The context's list of sequence lengths >= hist_cap (the part of the reference's map[int64]int64,
+ * bigseqkit-lib/stats.go:86, that does not fit the dense vector).  _get copies it to the host (cap 0 + NULL: size
+ * query); _add appends lengths that another rank's context collected, before bsk_stats_collect on a reduced vector. */
+int bsk_stats_overflow_get(bsk_ctx* ctx, uint64_t* lens, size_t cap, size_t* n_out);
+int bsk_stats_overflow_add(bsk_ctx* ctx, const uint64_t* lens, size_t n);
 /* Synchronise, check the kernels' error flags (BSK_ERR_FORMAT /
  * BSK_ERR_UNSUPPORTED) and convert a stats vector (d_vec or the ctx-owned one)
  * into the reference's map form, sorted by key.  Key -4 is computed from the

@@ -538,6 +538,15 @@ int orc_locate(const uint8_t* buf, size_t n, int fastq, const orc_locate_opts* o
 
 uint64_t orc_xxh64(const uint8_t* p, size_t n) { return xxh64(p, n, 0); }
 
+// the 64-letter gc.prt line the oracle derived for a table (tests compare it with the product's table); 0 = unknown id
+int orc_genetic_code(int id, int which, char* out65) {
+    const char* s = genetic_code_strings(id, which);
+    if (!s) return 0;
+    memcpy(out65, s, 64);
+    out65[64] = 0;
+    return 1;
+}
+
 int orc_translate_seq(const char* seq, int table, int frame, int trim, int clean, int allow_unknown, int init_m,
                       char* out, size_t cap) {
     try {

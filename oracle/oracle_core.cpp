@@ -1039,7 +1039,60 @@ std::vector<std::string> subseq_call(const std::vector<std::string_view>& part, 
 // ---------------------------------------------------------------------------
 // Translate  bigseqkit-lib/translate.go + bio CodonTable.Translate [upstream-memory]
 // ---------------------------------------------------------------------------
-#include "genetic_codes.inc"
+#include "genetic_codes_diff.inc"
+
+// gc.prt form (ncbieaa / sncbieaa over the base order TCAG) of one table, derived from the standard code and the
+// table's documented differences (genetic_codes_diff.inc)
+struct GeneticCode { int id; std::string aa, starts; };
+
+static int tcag_index(const char* codon) {
+    static const char order[] = "TCAG";
+    int idx = 0;
+    for (int k = 0; k < 3; ++k) {
+        const char* q = strchr(order, codon[k]);
+        if (!q || !codon[k]) throw Error(std::string("oracle: bad codon in genetic_codes_diff.inc: ") + codon);
+        idx = idx * 4 + (int)(q - order);
+    }
+    return idx;
+}
+
+static std::vector<std::string> split_blank(const char* s) {
+    std::vector<std::string> v;
+    std::string cur;
+    for (const char* p = s;; ++p) {
+        if (*p == ' ' || *p == 0) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; }
+        else cur.push_back(*p);
+    }
+    return v;
+}
+
+static const std::vector<GeneticCode>& genetic_codes() {
+    static const std::vector<GeneticCode> codes = [] {
+        std::vector<GeneticCode> v;
+        for (auto& d : kCodeDiffs) {
+            GeneticCode g;
+            g.id = d.id;
+            g.aa.assign(64, '?');
+            g.starts.assign(64, '-');
+            for (auto& sc : kStandardCode) g.aa[tcag_index(sc.codon)] = sc.aa;
+            for (auto& e : split_blank(d.diffs)) {
+                if (e.size() != 5 || e[3] != '=') throw Error("oracle: bad diff entry " + e);
+                g.aa[tcag_index(e.substr(0, 3).c_str())] = e[4];
+            }
+            for (auto& e : split_blank(d.starts)) g.starts[tcag_index(e.c_str())] = 'M';
+            for (auto& e : split_blank(d.start_line_stops)) g.starts[tcag_index(e.c_str())] = '*';
+            v.push_back(g);
+        }
+        return v;
+    }();
+    return codes;
+}
+
+const char* genetic_code_strings(int id, int which) {  // tests: the derived ncbieaa (0) / sncbieaa (1) line
+    for (auto& g : genetic_codes())
+        if (g.id == id) return which ? g.starts.c_str() : g.aa.c_str();
+    return nullptr;
+}
 
 static const char* iupac_set(char c) {  // upper-case, U == T
     switch (c) {
@@ -1052,7 +1105,7 @@ static const char* iupac_set(char c) {  // upper-case, U == T
 }
 
 static const GeneticCode* find_code(int id) {
-    for (auto& g : kGeneticCodes)
+    for (auto& g : genetic_codes())
         if (g.id == id) return &g;
     return nullptr;
 }
@@ -1139,8 +1192,46 @@ std::vector<std::string> translate_call(const std::vector<std::string_view>& par
         if (v == 6) { frames = {1, 2, 3, -1, -2, -3}; break; }
         frames.push_back((int)v);
     }
-    if (o.ListTranslTable >= 0 || o.ListTranslTableWithAmbCodons >= 0)
-        throw Error("oracle: translate -l / -L table listings are not restated");
+    if (o.ListTranslTableWithAmbCodons == 0 || o.ListTranslTable == 0) {  // translate.go:78-89
+        // names: the list in the reference's own help text (bigseqkit-cli/translate.go:55-78), ids ascending
+        static const char* const help =
+            "1: The Standard Code\n"
+            "2: The Vertebrate Mitochondrial Code\n"
+            "3: The Yeast Mitochondrial Code\n"
+            "4: The Mold, Protozoan, and Coelenterate Mitochondrial Code and the Mycoplasma/Spiroplasma Code\n"
+            "5: The Invertebrate Mitochondrial Code\n"
+            "6: The Ciliate, Dasycladacean and Hexamita Nuclear Code\n"
+            "9: The Echinoderm and Flatworm Mitochondrial Code\n"
+            "10: The Euplotid Nuclear Code\n"
+            "11: The Bacterial, Archaeal and Plant Plastid Code\n"
+            "12: The Alternative Yeast Nuclear Code\n"
+            "13: The Ascidian Mitochondrial Code\n"
+            "14: The Alternative Flatworm Mitochondrial Code\n"
+            "16: Chlorophycean Mitochondrial Code\n"
+            "21: Trematode Mitochondrial Code\n"
+            "22: Scenedesmus obliquus Mitochondrial Code\n"
+            "23: Thraustochytrium Mitochondrial Code\n"
+            "24: Pterobranchia Mitochondrial Code\n"
+            "25: Candidate Division SR1 and Gracilibacteria Code\n"
+            "26: Pachysolen tannophilus Nuclear Code\n"
+            "27: Karyorelict Nuclear\n"
+            "28: Condylostoma Nuclear\n"
+            "29: Mesodinium Nuclear\n"
+            "30: Peritrich Nuclear\n"
+            "31: Blastocrithidia Nuclear\n"
+;
+        std::vector<std::string> rows;
+        for (const char* p = help; *p;) {
+            const char* e = strchr(p, '\n');
+            std::string line(p, e);
+            const size_t colon = line.find(": ");
+            rows.push_back(line.substr(0, colon) + "\t" + line.substr(colon + 2));
+            p = e + 1;
+        }
+        return rows;
+    }
+    if (o.ListTranslTable > 0 || o.ListTranslTableWithAmbCodons > 0)
+        throw Error("oracle: translate -l N / -L N (bio's CodonTable.String()) is not restated");
     SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
     std::vector<std::string> result;
     bool once = true;

@@ -193,6 +193,8 @@ struct TranslateOptions {  // bigseqkit/translate.go:9-35
 // Translate.Before + Call  bigseqkit-lib/translate.go:33-145 (one element per frame, PARITY.md Q5)
 std::vector<std::string> translate_call(const std::vector<std::string_view>& part, const TranslateOptions& o);
 // CodonTable.Translate [upstream-memory, shenwei356/bio v0.7.0 seq/codon_table.go]
+// ncbieaa (which = 0) / sncbieaa (which = 1) line of a table, derived from genetic_codes_diff.inc; null: unknown id
+const char* genetic_code_strings(int id, int which);
 std::string translate_seq(const std::string& seq, int table, int frame, bool trim, bool clean, bool allow_unknown,
                           bool init_m, bool* unknown);
 

@@ -185,6 +185,14 @@ def translate_seq(seq, table=1, frame=1, trim=False, clean=False, allow_unknown=
     return out.value.decode()
 
 
+def genetic_code(table):
+    """(ncbieaa, sncbieaa) as the oracle derives them from the standard code + NCBI's documented differences"""
+    a, b = C.create_string_buffer(65), C.create_string_buffer(65)
+    if not (_lib.orc_genetic_code(table, 0, a) and _lib.orc_genetic_code(table, 1, b)):
+        return None
+    return a.value.decode(), b.value.decode()
+
+
 def rmdup_opts(opts_json):
     d = json.loads(opts_json) if isinstance(opts_json, (str, bytes)) else dict(opts_json or {})
     b = lambda k: int(bool(d.get(k)))

@@ -7,7 +7,11 @@ import pytest
 
 import oracle
 
-FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures.json")))["cases"]
+_G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIX = json.load(open(os.path.join(_G, "fixtures.json")))["cases"]
+# expected values written BY HAND from the Go text (locate row formats, StatsString printf verbs): they pin the oracle,
+# not the other way round ("source": "hand"; the derivation of every value is in the file)
+HAND = json.load(open(os.path.join(_G, "hand_fixtures.json")))["cases"]
 FN = {"seq": oracle.seq, "subseq": oracle.subseq, "translate": oracle.translate, "locate": oracle.locate, "grep": oracle.grep,
       "rmdup": oracle.rmdup, "fq2fa": oracle.fq2fa, "range": oracle.range_, "head": oracle.head, "duplicate": oracle.duplicate,
       "rename": oracle.rename, "sort": oracle.sort, "faidx": oracle.faidx, "faidx_query": oracle.faidx_query,
@@ -23,6 +27,13 @@ def test_oracle_reproduces_the_golden_fixture(case):
         assert str(e.value) == case["error"]
     else:
         assert FN[case["op"]](data, case["fastq"], json.dumps(case["opts"])) == case["expected"].encode("latin1")
+
+
+@pytest.mark.parametrize("case", HAND, ids=[c["name"] for c in HAND])
+def test_oracle_reproduces_the_hand_derived_fixture(case):
+    assert case["source"] == "hand" and case["derivation"]
+    data = case["input"].encode("latin1")
+    assert FN[case["op"]](data, case["fastq"], json.dumps(case["opts"])) == case["expected"].encode("latin1")
 
 
 def test_fixture_set_covers_every_operator():

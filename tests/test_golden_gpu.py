@@ -8,7 +8,9 @@ import pytest
 import bigseqkit_amd as bsk
 
 pytestmark = pytest.mark.gpu
-FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures.json")))["cases"]
+_G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIX = json.load(open(os.path.join(_G, "fixtures.json")))["cases"]
+FIX = FIX + json.load(open(os.path.join(_G, "hand_fixtures.json")))["cases"]  # hand-derived from the Go text ("source": "hand")
 
 
 def dev(data):

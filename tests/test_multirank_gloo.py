@@ -251,3 +251,62 @@ def test_two_ranks_gloo_range_head_and_faidx(fastq, op_name, opts):
     want = oracle.head(data, fastq, json.dumps(opts)) if op_name == "Head" else oracle.range_(data, fastq, json.dumps(opts))
     assert res[0][0] + res[1][0] == want and len(want) > 0
     assert res[0][1] + res[1][1] == oracle.faidx(data, fastq)
+
+
+def test_bench_self_launches_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start TWO ranks that reduce together -- the
+    launcher path the driver's N>1 runs take when they call bench.py directly.  Here with gloo and the launch check
+    only (no GPU in this container); the timed path asserts the same world size before it touches a device."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BSK_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    assert got == {"launch_check": True, "n_gpus": 2, "backend": "gloo", "ranks_reduced": 2}
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BSK_BENCH_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    """No CPU fallback: on a box without a HIP device the bench exits non-zero instead of printing a line."""
+    import subprocess
+    import sys
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("a GPU is visible")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gb", "0.01", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_global_operators_see_several_shards_as_one():
+    """api._one_shard: RmDup / Rename / Sort / grep --delete-matched are global over the dataframe (GroupByKey,
+    bigseqkit/rmdup.go:97; SortByKey, sort.go) -- the shards of ReadFASTQN are joined, a missing final newline added."""
+    from bigseqkit_amd import api
+    a, b, c = b"@r1\nAC\n+\nII\n", b"@r2\nGT\n+\nII", b"@r1\nAC\n+\n##\n"
+    f = api.SeqFrame(bsk.FORMAT_FASTQ, [a, b, c])
+    one = api._one_shard(f)
+    assert len(one.shards) == 1 and bytes(one.shards[0]) == a + b + b"\n" + c
+    assert api._one_shard(api.SeqFrame(bsk.FORMAT_FASTQ, [a])).shards == [a]
+    # and the joined text is what the oracle dedups globally: r1 appears twice, once per shard
+    want = oracle.rmdup(bytes(one.shards[0]), True, json.dumps({"BySeq": True}))
+    assert want.count(b"@r1") == 1
