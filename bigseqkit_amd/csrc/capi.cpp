@@ -46,26 +46,6 @@ int fail(const bsk_ctx* c, int code, const std::string& m) {
 constexpr uint64_t MIN_RANGE_BYTES = 64 * 1024;  // BSK_MIN_RANGE_BYTES overrides (tests stress tiny ranges)
 constexpr int RANGES_PER_WAVE = 4;
 
-struct Timed {  // optional HIP-event bracket around one launch
-    bsk_ctx* c;
-    const char* name;
-    hipStream_t st;
-    hipEvent_t a = nullptr, b = nullptr;
-    Timed(bsk_ctx* c_, const char* n, hipStream_t s) : c(c_), name(n), st(s) {
-        if (c->profile) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
-            hipEventRecord(a, st);
-        }
-    }
-    ~Timed() {
-        if (c->profile && a) {
-            hipEventRecord(b, st);
-            c->pending.push_back({name, a, b});
-        }
-    }
-};
-
 // ---- Before() of each operator: option validation with the reference's texts ----
 void validate_stats(bsk_ctx* c) {  // bigseqkit-lib/stats.go:27-46
     const Options& o = c->opts;
@@ -235,6 +215,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_names) hipFree(c->d_names);
         if (c->d_names_off) hipFree(c->d_names_off);
         if (c->d_pat) hipFree(c->d_pat);
+        if (c->d_ftab) hipFree(c->d_ftab);
         if (c->d_cls) hipFree(c->d_cls);
         if (c->d_feat) hipFree(c->d_feat);
         if (c->d_regex) hipFree(c->d_regex);

@@ -49,6 +49,7 @@ struct bsk_ctx {
 
     // ---- record table + per-record scratch (seq, grep, ...) ---------------------
     bsk::RecordTable table;          // ctx-owned arrays, grown on demand
+    uint64_t avg_record_bytes = 0;   // bytes per record in the head of the last indexed shard (0: unknown)
     bsk::RecordTable sparse;         // one-pass index: per-range slices, compacted into `table`
     uint64_t* d_range_count = nullptr;  // [cap_ranges]
     uint64_t* d_range_base = nullptr;   // [cap_ranges + 1]
@@ -95,6 +96,8 @@ struct bsk_ctx {
     uint8_t* d_pat = nullptr;
     uint32_t* d_pat_off = nullptr;
     uint64_t pat_cap = 0, pat_off_cap = 0;
+    uint8_t* d_ftab = nullptr;  // pair-hash table of the fused pattern filter (stream_filter.hpp): u32 tab[slots] ++ u16 ent[slots]
+    uint64_t ftab_cap = 0;
     std::vector<std::string> pattern_names;  // locate: names as given (== the -p text, or the FASTA name with -f)
     std::vector<std::string> pattern_disp;   // locate -r: the expressions (pattern column); patterns[] then only carries the match length
     // class patterns (-d, -m, -F): one 256-bit accept set per pattern position (pattern_match.cuh)
@@ -167,6 +170,27 @@ struct bsk_ctx {
     void set_error(const std::string& m) const {
         std::lock_guard<std::mutex> g(mu);
         last_error = m;
+    }
+};
+
+// optional HIP-event bracket around one launch (bsk_profile_enable): read back by bsk_profile_read under `name`
+struct Timed {
+    bsk_ctx* c;
+    const char* name;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(bsk_ctx* c_, const char* n, hipStream_t s) : c(c_), name(n), st(s) {
+        if (c->profile) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, st);
+        }
+    }
+    ~Timed() {
+        if (c->profile && a) {
+            hipEventRecord(b, st);
+            c->pending.push_back({name, a, b});
+        }
     }
 };
 

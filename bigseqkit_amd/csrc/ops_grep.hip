@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
 }  // namespace
 
 hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH* tt,
-                             const GrepParams& Pin, uint32_t* out_len, hipStream_t st) {
+                             const GrepParams& Pin, uint32_t* out_len, hipStream_t st, uint64_t avg_record_bytes) {
     if (t.n == 0) return hipSuccess;
     GrepParams P = Pin;
     P.buf_end = buf + buf_n;
@@ -408,7 +408,7 @@ hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTab
         hipLaunchKernelGGL(k_grep_seq_gen, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len);
     } else if (P.by_seq) {
         TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
-        const uint64_t avg = buf_n / t.n;  // bytes per record
+        const uint64_t avg = avg_record_bytes ? avg_record_bytes : buf_n / t.n;  // bytes per record (a filtered table holds few of them)
         if (avg < 1024) {
             hipLaunchKernelGGL((k_grep_seq<BSK_GREP_LANES, false>), dim3((unsigned)((t.n * BSK_GREP_LANES + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);
         } else {

@@ -39,6 +39,6 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
 
 struct TextTableH;
 hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH* tt,
-                             const GrepParams& P, uint32_t* out_len, hipStream_t st);
+                             const GrepParams& P, uint32_t* out_len, hipStream_t st, uint64_t avg_record_bytes = 0);
 
 }  // namespace bsk

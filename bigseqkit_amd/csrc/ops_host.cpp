@@ -29,6 +29,7 @@
 #include "ops_translate.hpp"
 #include "ops_seq.hpp"
 #include "ops_sort.hpp"
+#include "stream_filter.hpp"
 #include "stream_stats.hpp"
 
 namespace bsk {
@@ -86,10 +87,23 @@ int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
 // record table of one device-resident shard (count pass, scan, write pass)
 // ---------------------------------------------------------------------------
 int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st) {
+    return build_index_filtered(c, d_buf, n, format, st, nullptr);
+}
+
+// With a FilterDev (FASTQ only): the table holds ONLY the records whose sequence line contains one of the filter's
+// patterns (or only the others, with invert) -- stream_filter.hip.  BSK_ERR_FILTER_FALLBACK: the filter gave up
+// (pending-hit list full); the caller then takes the unfiltered path.
+int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F) {
     const bool fastq = format == BSK_FORMAT_FASTQ;
     c->table.n = 0;
+    c->avg_record_bytes = 0;
     if (n == 0) return BSK_OK;
-    const int per_cu = index_max_blocks_per_cu(fastq, c->use_dpp);
+    if (F && !fastq) { c->set_error("libbsk: the pattern filter runs on FASTQ only"); return BSK_ERR_INVALID_ARG; }
+    auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
+        if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
+        return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st);
+    };
+    const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp) : index_max_blocks_per_cu(fastq, c->use_dpp);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
     const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
@@ -155,6 +169,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
         if (fastq) { for (size_t i = 0; i < hb; ++i) recs += head[i] == '\n'; recs /= 4; }
         else { for (size_t i = 0; i + 1 < hb; ++i) recs += (head[i] == '\n' && head[i + 1] == '>'); recs += 1; }
         const double avg = (double)hb / (double)std::max<uint64_t>(recs, 1);
+        c->avg_record_bytes = (uint64_t)avg;  // lanes per record of the per-record kernels (a filtered table is no measure)
         const uint64_t sparse_cap = (uint64_t)((double)chunk / std::max(avg * 0.5, 6.0)) + 64;
         const uint64_t need = sparse_cap * nranges;
         if (need * 20 <= (uint64_t)n + (64ull << 20)) {  // never reserve more than the shard itself
@@ -163,12 +178,21 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
             D.t = c->sparse;
             D.write = 2;
             D.sparse_cap = sparse_cap;
-            HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+            {
+                Timed t(c, F ? "k_filter" : "k_index", st);
+                HIP_TRYX(c, launch_pass(blocks, anchors, nranges, queue, D));
+            }
             HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
             uint64_t status = 0;
             HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
             HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
             HIP_TRYX(c, hipStreamSynchronize(st));
+            if (status & ERR_FILTER_OVERFLOW) {
+                status &= ~(uint64_t)(ERR_FILTER_OVERFLOW | ERR_CAPACITY);
+                HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                return BSK_ERR_FILTER_FALLBACK;
+            }
             if (status & ERR_CAPACITY) {
                 status &= ~(uint64_t)ERR_CAPACITY;  // retry exactly
                 HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
@@ -189,9 +213,20 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
     if (!done) {
         D.t = c->table;
         D.write = 0;
-        HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+        HIP_TRYX(c, launch_pass(blocks, anchors, nranges, queue, D));
         HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
         HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+        if (F) {
+            uint64_t status = 0;
+            HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (status & ERR_FILTER_OVERFLOW) {
+                status &= ~(uint64_t)(ERR_FILTER_OVERFLOW | ERR_CAPACITY);
+                HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                return BSK_ERR_FILTER_FALLBACK;
+            }
+        }
         HIP_TRYX(c, hipStreamSynchronize(st));
         int rc4 = alloc_table(c->table, total + total / 8 + 16);
         if (rc4 != BSK_OK) return rc4;
@@ -200,7 +235,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
         D.t = c->table;
         D.write = 1;
         HIP_TRYX(c, launch_reset_queue(queue, st));
-        HIP_TRYX(c, launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+        HIP_TRYX(c, launch_pass(blocks, anchors, nranges, queue, D));
     }
     if (total == 0) return BSK_OK;
     if (D.parts) HIP_TRYX(c, launch_index_stitch(c->table, c->d_parts, c->d_range_count, c->d_range_base, nranges, c->d_status, st));
@@ -663,11 +698,79 @@ static int upload_patterns(bsk_ctx* c, const std::vector<std::string>& all, hipS
     return BSK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// the fused pattern filter (stream_filter.hip): host side
+// ---------------------------------------------------------------------------
+// `all` = the pattern strings as uploaded to c->d_pat (forward, then reverse-complemented); the first `nuse` of them
+// are searched.  Builds the collision-free pair-hash table and uploads it.  false: not applicable (pattern lengths,
+// too many patterns, no collision-free table found, BSK_FILTER=off) -- the caller keeps the record-table path.
+static bool make_filter(bsk_ctx* c, const std::vector<std::string>& all, size_t nuse, bool invert, bool icase, hipStream_t st,
+                        FilterDev* F, int* rc) {
+    *rc = BSK_OK;
+    const char* env = getenv("BSK_FILTER");
+    if (env && strcmp(env, "off") == 0) return false;
+    if (nuse == 0 || nuse * 4 > FILTER_MAX_ENTRIES) return false;
+    for (size_t k = 0; k < nuse; ++k)
+        if (all[k].size() < FILTER_MIN_LEN || all[k].size() > FILTER_MAX_LEN) return false;
+    std::vector<uint32_t> tab(512, 0u);  // T1 ++ T2
+    std::vector<uint16_t> ent(FILTER_MAX_ENTRIES, 0);
+    std::vector<uint8_t> padded(FILTER_MAX_PATTERNS * FILTER_MAX_LEN, 0);
+    uint32_t e = 0;
+    for (size_t k = 0; k < nuse; ++k) {
+        memcpy(padded.data() + k * FILTER_MAX_LEN, all[k].data(), all[k].size());
+        for (uint32_t j = 0; j < 4; ++j, ++e) {
+            uint32_t first, second;
+            memcpy(&first, all[k].data() + j, 4);  // little-endian dwords, as the kernel loads the text
+            memcpy(&second, all[k].data() + j + 4, 4);
+            tab[filter_code(first)] |= 1u << e;
+            tab[256 + filter_code(second)] |= 1u << e;
+            ent[e] = (uint16_t)(k | (j << 5) | (all[k].size() << 8));  // (FILTER_MAX_LEN = 64 fits the high byte)
+        }
+    }
+    const size_t o_ent = 512 * 4, o_pat = o_ent + FILTER_MAX_ENTRIES * 2;
+    int r = grow(c, &c->d_ftab, &c->ftab_cap, o_pat + padded.size() + 64);
+    if (r != BSK_OK) { *rc = r; return false; }
+    hipError_t he = hipMemcpyAsync(c->d_ftab, tab.data(), 512 * 4, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(c->d_ftab + o_ent, ent.data(), FILTER_MAX_ENTRIES * 2, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(c->d_ftab + o_pat, padded.data(), padded.size(), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);  // the vectors live in this frame
+    if (he != hipSuccess) { c->set_error(std::string("hipMemcpy: ") + hipGetErrorString(he)); *rc = BSK_ERR_HIP; return false; }
+    F->t1 = reinterpret_cast<const uint32_t*>(c->d_ftab);
+    F->ent = reinterpret_cast<const uint16_t*>(c->d_ftab + o_ent);
+    F->pat_padded = reinterpret_cast<const uint32_t*>(c->d_ftab + o_pat);
+    F->ignore_case = icase ? 1 : 0;
+    F->invert = invert ? 1 : 0;
+    return true;
+}
+
 int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
     c->last_count = 0;
-    int rc = build_index(c, d_buf, n, format, st);
+    int rc = BSK_OK;
+    // exact sequence patterns on FASTQ: the streaming pass itself selects the records (stream_filter.hip) and the
+    // per-record kernels below run on the selected ones only.  Everything else (and any shard on which the filter gives
+    // up) goes through the table of all records.
+    bool filtered = false;
+    if (fastq && n > 0 && o.b("BySeq") && !c->general && c->regexes.empty() && !c->region_on && !o.b("Circular") &&
+        !o.b("DeleteMatched") && !c->patterns.empty()) {
+        Alphabet fab = partition_alphabet(c, d_buf, n, format, st, &rc);
+        if (rc != BSK_OK) return rc;
+        if (fab == AB_NONE) fab = AB_UNLIMIT;
+        const bool both = !(o.b("OnlyPositiveStrand") || fab == AB_UNLIMIT || fab == AB_PROTEIN);
+        std::vector<std::string> all = c->patterns;
+        if (both)
+            for (auto& p : c->patterns) all.push_back(revcom_pattern(p, fab));
+        rc = upload_patterns(c, all, st);
+        if (rc != BSK_OK) return rc;
+        FilterDev F;
+        if (make_filter(c, all, all.size(), o.b("InvertMatch"), o.b("IgnoreCase"), st, &F, &rc)) {
+            rc = build_index_filtered(c, d_buf, n, format, st, &F);
+            if (rc == BSK_OK) filtered = true;
+            else if (rc != BSK_ERR_FILTER_FALLBACK) return rc;
+        } else if (rc != BSK_OK) return rc;
+    }
+    if (!filtered) rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
     uint64_t total = 0, kept = 0;
     TextTableH tt{nullptr, nullptr, nullptr};
@@ -762,7 +865,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 G.long_thresh = thresh;
             }
         }
-        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st));
+        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st, c->avg_record_bytes));
         if (o.b("DeleteMatched") && !G.invert) {
             // grep.go:463-511 + bigseqkit/grep.go:144-156: a pattern is dropped at its first hit and the driver keeps
             // the lowest partition per pattern, so every pattern selects its FIRST record in file order (PARITY.md DEL)
@@ -925,7 +1028,28 @@ void validate_locate_opts(bsk_ctx* c) {
 
 int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
-    int rc = build_index(c, d_buf, n, format, st);
+    int rc = BSK_OK;
+    // exact patterns on FASTQ: only the records that hold an occurrence produce rows, and the streaming filter finds them
+    // (stream_filter.hip); k_locate then computes the rows of those records exactly as before
+    bool filtered = false;
+    if (format == BSK_FORMAT_FASTQ && n > 0 && !c->general && !o.b("UseRegexp") && !o.b("Circular") && !c->patterns.empty() &&
+        c->pattern_disp.empty()) {
+        Alphabet fab = partition_alphabet(c, d_buf, n, format, st, &rc);
+        if (rc != BSK_OK) return rc;
+        if (fab == AB_NONE) fab = AB_UNLIMIT;
+        std::vector<std::string> all = c->patterns;
+        for (auto& p : c->patterns) all.push_back(revcom_pattern(p, fab));
+        rc = upload_patterns(c, all, st);
+        if (rc != BSK_OK) return rc;
+        FilterDev F;
+        const size_t nuse = o.b("OnlyPositiveStrand") ? c->patterns.size() : all.size();  // locate.go:669 tests the option only
+        if (make_filter(c, all, nuse, false, o.b("IgnoreCase"), st, &F, &rc)) {
+            rc = build_index_filtered(c, d_buf, n, format, st, &F);
+            if (rc == BSK_OK) filtered = true;
+            else if (rc != BSK_ERR_FILTER_FALLBACK) return rc;
+        } else if (rc != BSK_OK) return rc;
+    }
+    if (!filtered) rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
     // header row of partition 0 (locate.go:198-204)
     std::string header;
@@ -1047,7 +1171,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             }
         }
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
-        HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
+        HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st, c->avg_record_bytes));
         if (P.long_count) {
             // place every cell inside its record's rows, then the record sizes
             HIP_TRYX(c, launch_scan_u32(P.cell_bytes, const_cast<uint64_t*>(P.cell_off), ncells_total, c->d_scan_tmp, st));
@@ -1075,7 +1199,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (!header.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_out, header.data(), header.size(), hipMemcpyHostToDevice, st));
     if (total)
         HIP_TRYX(c, launch_locate(true, d_buf, n, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out + header.size(),
-                                  c->d_counter + 1, st));
+                                  c->d_counter + 1, st, c->avg_record_bytes));
     if (total) HIP_TRYX(c, hipMemcpyAsync(&nrows, c->d_counter + 1, sizeof nrows, hipMemcpyDeviceToHost, st));  // counted by the emit pass
     HIP_TRYX(c, hipStreamSynchronize(st));  // header lives on the host stack
     out->d_data = c->d_out;

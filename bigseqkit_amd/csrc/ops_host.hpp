@@ -7,6 +7,10 @@
 namespace bsk {
 int kernel_error_to_status(bsk_ctx* c, uint64_t flags);
 int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st);
+struct FilterDev;
+// not an API status: the fused pattern filter gave up (stream_filter.hpp) and the caller must build the full table
+constexpr int BSK_ERR_FILTER_FALLBACK = -1000;
+int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
 void validate_seq_opts(bsk_ctx* c);
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_grep_opts(bsk_ctx* c);

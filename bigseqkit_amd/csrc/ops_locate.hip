@@ -507,11 +507,11 @@ hipError_t launch_compact_hits(const uint32_t* out_len, uint64_t n, uint32_t* hi
 
 hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
-                         uint64_t* rows, hipStream_t st) {
+                         uint64_t* rows, hipStream_t st, uint64_t avg_record_bytes) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     const uint64_t groups = emit ? P.nhit : t.n;
-    const bool small = buf_n / t.n < 1024;  // bytes per record
+    const bool small = (avg_record_bytes ? avg_record_bytes : buf_n / t.n) < 1024;  // bytes per record (not of a filtered table)
     const int G = small ? 4 : 16;
     const uint64_t blocks = (groups * G + 255) / 256;
     const dim3 gr((unsigned)blocks), bl(256);

@@ -48,7 +48,7 @@ constexpr uint32_t LOCATE_LONG_CH = 64u * 1024u;
 // count pass: out_len[i] = bytes of all rows of record i; emit pass writes them at out_off[i]
 hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
-                         uint64_t* rows, hipStream_t st);
+                         uint64_t* rows, hipStream_t st, uint64_t avg_record_bytes = 0);
 
 // hit_list := indices of the records with out_len != 0 (any order), *hit_count := how many (zeroed by the caller)
 // out_len of the long records := sum of their cells' bytes (after the scan of cell_bytes)

@@ -490,7 +490,14 @@ __global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t* __restric
         const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(c >> 32), d, 64);
         c += ((uint64_t)hi << 32) | lo;
     }
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long*)counter, (unsigned long long)c);
+    // one atomic per block (an atomic on one address costs ~12 ns whoever issues it: 12 000 waves were 0.15 ms)
+    __shared__ uint64_t s_c[4];
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        if (t) atomicAdd((unsigned long long*)counter, (unsigned long long)t);
+    }
 }
 
 }  // namespace
@@ -550,7 +557,7 @@ hipError_t launch_find_long(const uint32_t* out_len, uint64_t n, uint32_t thresh
 hipError_t launch_count_nonzero(const uint32_t* v, uint64_t n, uint64_t* counter, hipStream_t st) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)blocks), dim3(256), 0, st, v, n, counter);
     return hipGetLastError();
 }

@@ -227,6 +227,8 @@ __device__ __forceinline__ uint64_t abs_of(uint32_t rel, uint64_t tile_idx, uint
 // ---------------------------------------------------------------------------
 // stream one range [rs, re) of the shard through `sink`.
 //   sink.err            uint32_t error flags (per lane)
+//   Sink::TILE_HOOK     static constexpr bool; true: sink.tile(cur, tile_idx, rs, re, buf) is called once per tile
+//                       with the tile's 4 x 16 bytes per lane, before the batches of that tile
 //   sink.batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf)
 //       E events sit in LDS slots [HISTORY, HISTORY+E); wb = rank (0-based line
 //       index inside the range) of the first; slots [0, HISTORY) hold the
@@ -275,6 +277,10 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                 nxt[p] = load16(buf, n, tile_idx + TILE + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
         }
         const bool edge = (tile_idx < rs) || (tile_idx + TILE > re);  // wave-uniform
+
+        // sinks that look at the raw text of a tile (the fused pattern filter, stream_filter.hip) see it here, while
+        // it is in registers and before the newline events of the tile are handed over
+        if constexpr (Sink::TILE_HOOK) sink.tile(cur, tile_idx, rs, re, buf);
 
         if constexpr (!ALL) {
             // ---- sparse path -------------------------------------------------------------

@@ -20,6 +20,7 @@ namespace {
 using namespace stream;
 
 struct IndexSink {
+    static constexpr bool TILE_HOOK = false;
     IndexDev D;
     uint64_t base = 0;   // global index of the first record of the range (wave-uniform)
     uint64_t limit = 0;  // first index this range must not write (table capacity or end of its sparse slice)

@@ -78,6 +78,7 @@ __device__ __forceinline__ void add_length(bool has, uint32_t len, uint32_t* s_h
 // StatsSink: Stats.Call (bigseqkit-lib/stats.go:48-117) on newline events
 // ---------------------------------------------------------------------------
 struct StatsSink {
+    static constexpr bool TILE_HOOK = false;
     uint32_t* s_hist;
     StatsDev D;
     // per-lane accumulators, reduced once per wave at kernel end
