@@ -74,6 +74,8 @@ struct bsk_ctx {
     // translate
     uint8_t* d_codon = nullptr;   // 4096 + 4096 bytes (aa table, start table)
     std::vector<int> frames;
+    uint8_t* d_redo = nullptr;    // one byte per record: left by k_translate_wide to k_translate_frames4
+    uint64_t redo_cap = 0;
     // rmdup
     uint64_t* d_keys = nullptr;
     uint64_t keys_cap = 0;

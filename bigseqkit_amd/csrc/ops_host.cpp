@@ -1716,8 +1716,17 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             HIP_TRYX(c, launch_translate_emit(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status, st));
         } else {
             const uint64_t avg = n / std::max<uint64_t>(1, c->table.n);
+            static const int forced = [] { const char* e = getenv("BSK_TR_LANES"); return e ? atoi(e) : 0; }();  // measurement knob
+            // one flag byte per record for the records k_translate_wide leaves to k_translate_frames4
+            rc = grow(c, &c->d_redo, &c->redo_cap, c->table.n, c->table.n / 8 + 64);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemsetAsync(c->d_redo, 0, c->table.n, st));
+            if (!c->d_counter) HIP_TRYX(c, hipMalloc((void**)&c->d_counter, 4 * sizeof(uint64_t)));
+            HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, sizeof(uint64_t), st));
+            // wide kernel: a wave per record from ~3 k bases (a step of 64 lanes covers 3072), 16 lanes per record below
+            const int wide_lanes = forced == 16 || forced == 64 ? forced : (avg >= 3000 ? 64 : 16);
             HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
-                                                c->d_out, c->d_status, st));
+                                                c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter));
             HIP_TRYX(c, launch_translate_long(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status,
                                               long_max, st));
         }

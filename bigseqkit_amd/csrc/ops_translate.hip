@@ -468,14 +468,16 @@ __device__ __forceinline__ uint32_t byte_of(const uint32_t (&w)[4], int i) { ret
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-// four residues at `at` = position of the first one; `first` = residues before the line break (>= 4: none inside)
+// four residues at `at` = position of the first one; `first` = residues before the line break (>= 4: none inside).
+// A break inside the four is written WITH them: v_perm splices the '\n' into the dword and only the fourth residue needs
+// a byte store of its own (the first version fell back to four byte stores, each with its 64-bit address: with 60-column
+// lines one lane in fifteen straddles a break, so every wave paid for both paths -- 150 of its ~500 vector instructions
+// per step).
 __device__ __forceinline__ void put4(uint8_t* at, uint32_t packed, uint32_t first) {
-    if (first >= 4u) {
-        *reinterpret_cast<u32_unaligned*>(at) = packed;
-    } else {
-#pragma unroll
-        for (int tq = 0; tq < 4; ++tq) at[(uint32_t)tq + ((uint32_t)tq >= first ? 1u : 0u)] = (uint8_t)(packed >> (8 * tq));
-    }
+    // selector over {bytes 4..7 = '\n', bytes 0..3 = packed}
+    const uint32_t sel = first == 1u ? 0x02010400u : (first == 2u ? 0x02040100u : (first == 3u ? 0x04020100u : 0x03020100u));
+    *reinterpret_cast<u32_unaligned*>(at) = __builtin_amdgcn_perm(0x0A0A0A0Au, packed, sel);
+    if (first < 4u) at[4] = (uint8_t)(packed >> 24);
 }
 
 // the same, cut by the start / end of the element (first and last step of a record).  o / col: line-break offset and
@@ -498,6 +500,9 @@ __device__ __forceinline__ void put4_edge(uint8_t* body, int64_t jlow, uint32_t 
 #ifndef BSK_TR_WAVES
 #define BSK_TR_WAVES 0
 #endif
+#ifndef BSK_TR_FAST
+#define BSK_TR_FAST 1  // 0: IUPAC path only (measurement knob)
+#endif
 #if BSK_TR_WAVES
 #define BSK_TR_ATTR __attribute__((amdgpu_waves_per_eu(BSK_TR_WAVES, 8)))
 #else
@@ -508,7 +513,8 @@ template <int G>
 __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
                                                            TranslateParams P, const uint32_t* __restrict__ out_len,
                                                            const uint64_t* __restrict__ out_off,
-                                                           uint8_t* __restrict__ out, uint64_t* __restrict__ status) {
+                                                           uint8_t* __restrict__ out, uint64_t* __restrict__ status,
+                                                           const uint8_t* __restrict__ only) {
     constexpr int STEPB = G * 12;      // bases per step
     constexpr int STEPS = 4;           // steps per window
     constexpr int WIN = STEPB * STEPS; // bases per window
@@ -519,13 +525,29 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[NG][RAWCAP];
     const uint8_t* s_fw = s_tab;
     const uint8_t* s_rc = s_tab + 4096;
+    if (only) {  // after k_translate_wide: a block none of whose records is flagged leaves before it stages anything
+        const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+        if (!__syncthreads_or(g0 < t.n && only[g0] != 0)) return;
+    }
     for (int i = threadIdx.x * 16; i < 8192; i += blockDim.x * 16)
         *reinterpret_cast<uint4*>(s_tab + i) = *reinterpret_cast<const uint4*>(P.baked + i);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
     __syncthreads();
+    // the ACGT fast path: residue of the codon with 2-bit codes (first base in the low bits; A 0, C 1, T 2, G 3)
+    __shared__ __attribute__((aligned(64))) uint8_t s_fw64[64];
+    __shared__ __attribute__((aligned(64))) uint8_t s_rc64[64];
+    if (threadIdx.x < 64) {
+        const uint32_t iu[4] = {1u, 2u, 8u, 4u};  // IUPAC bit of code 0..3
+        const uint32_t i = threadIdx.x;
+        const uint32_t full = (iu[i & 3u] << 8) | (iu[(i >> 2) & 3u] << 4) | iu[(i >> 4) & 3u];
+        s_fw64[i] = s_fw[full];
+        s_rc64[i] = s_rc[full];
+    }
+    __syncthreads();
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (g >= t.n) return;  // no block-level barrier below
+    if (only && !only[g]) return;  // k_translate_wide ran first: only the records it flagged are left
     if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
     uint8_t* raw = s_raw[threadIdx.x / G];
     const Text T = text_of(buf, t, tt, g);
@@ -567,7 +589,10 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
         }
         if (gl == 0) o[n - 1] = '\n';
         if (lw) for (uint32_t x = lw + gl * (lw + 1); x < body; x += G * (lw + 1)) o[H + x] = '\n';
-        const uint64_t bodyp = out_off[e] + H;
+        uint64_t bodyp = out_off[e] + H;
+        if constexpr (G == 64)  // one record per wave: the six body addresses are wave-uniform -> scalar base + 32-bit offset
+            bodyp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bodyp >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bodyp);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (frame == c + 1) { fb[c] = bodyp; fk[c] = kept; }
@@ -593,11 +618,11 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
     uint32_t fj = 4u * gl, fo = 0, fc = fj;
     if (lw) { fo = fj / lw; fc = fj - fo * lw; }
     // reverse cursors: LOWEST residue of the lane's group (the one of its 4th codon); descending by 4G per step
-    int64_t rj[3];
+    int32_t rj[3];  // (a record holds < 2^32 bases, so < 2^31 residues)
     uint32_t ro[3], rcc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        rj[c] = (L >= 3u + (uint32_t)c ? (int64_t)((L - 3u - (uint32_t)c) / 3u) : -1) - 4 * (int64_t)gl - 3;
+        rj[c] = (L >= 3u + (uint32_t)c ? (int32_t)((L - 3u - (uint32_t)c) / 3u) : -1) - 4 * (int32_t)gl - 3;
         ro[c] = 0; rcc[c] = 0;
         if (lw && rj[c] >= 0) { ro[c] = (uint32_t)rj[c] / lw; rcc[c] = (uint32_t)rj[c] - ro[c] * lw; }
     }
@@ -655,40 +680,79 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
                     }
                 }
             }
-            uint32_t cd[14];
-#pragma unroll
-            for (int i = 0; i < 14; ++i) cd[i] = s_iu[byte_of(w, i)];
             const bool interior = sb + (uint32_t)STEPB + 2u <= L;  // every codon of every lane is complete
+            // ---- residues of the lane's four codon slots, per class c (codons starting at base c) and strand.
+            // FAST PATH (wave-uniform): all 14 letters of every lane are A, C, G, T (any case) and no codon is cut by the
+            // record end.  A letter's bits 1..2 are its 2-bit code (A 0, C 1, T 2, G 3); v_perm rebuilds the letter from
+            // the code for the check, v_dot4 packs four codes into a byte, the 16 codes of the lane form one dword X and
+            // a codon's 6-bit index is ONE v_bfe -- into two 64-byte tables in LDS (forward, reverse complement) whose
+            // 16 dwords sit in 16 different banks: no bank conflicts, against ~6-way conflicts of the 4 KiB IUPAC tables
+            // (the LDS pipe, not the VALU, bounded the previous version: 38 byte reads per step, 47 of its 75 ms).
+            uint32_t pkf[3] = {0, 0, 0}, pkr[3] = {0, 0, 0};
+            uint32_t nvc[3] = {4, 4, 4};
+            const uint32_t c0 = (w[0] >> 1) & 0x03030303u, c1 = (w[1] >> 1) & 0x03030303u, c2 = (w[2] >> 1) & 0x03030303u,
+                           c3 = (w[3] >> 1) & 0x03030303u;
+            constexpr uint32_t LET = 0x67746361u;  // 'a' 'c' 't' 'g' at byte 0..3 == letter of code 0..3
+            const uint32_t bad = ((w[0] | 0x20202020u) ^ __builtin_amdgcn_perm(LET, LET, c0)) |
+                                 ((w[1] | 0x20202020u) ^ __builtin_amdgcn_perm(LET, LET, c1)) |
+                                 ((w[2] | 0x20202020u) ^ __builtin_amdgcn_perm(LET, LET, c2)) |
+                                 (((w[3] | 0x20202020u) ^ __builtin_amdgcn_perm(LET, LET, c3)) & 0x0000FFFFu);
+            if (BSK_TR_FAST && __ballot(bad != 0u || !interior) == 0ull) {
+                const uint32_t X = __builtin_amdgcn_udot4(c0, 0x40100401u, 0u, false) |
+                                   (__builtin_amdgcn_udot4(c1, 0x40100401u, 0u, false) << 8) |
+                                   (__builtin_amdgcn_udot4(c2, 0x40100401u, 0u, false) << 16) |
+                                   (__builtin_amdgcn_udot4(c3, 0x40100401u, 0u, false) << 24);  // base j at bits 2j, 2j+1
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (fb[c] == NONE && rb[c] == NONE) continue;
+                    const uint32_t i0 = (X >> (2 * c)) & 63u, i1 = (X >> (2 * c + 6)) & 63u, i2 = (X >> (2 * c + 12)) & 63u,
+                                   i3 = (X >> (2 * c + 18)) & 63u;
+                    if (fb[c] != NONE)
+                        pkf[c] = (uint32_t)s_fw64[i0] | ((uint32_t)s_fw64[i1] << 8) | ((uint32_t)s_fw64[i2] << 16) | ((uint32_t)s_fw64[i3] << 24);
+                    if (rb[c] != NONE)  // descending residues: codon slot 3 is the lowest residue = byte 0
+                        pkr[c] = (uint32_t)s_rc64[i3] | ((uint32_t)s_rc64[i2] << 8) | ((uint32_t)s_rc64[i1] << 16) | ((uint32_t)s_rc64[i0] << 24);
+                }
+            } else {
+                uint32_t cd[14];
+#pragma unroll
+                for (int i = 0; i < 14; ++i) cd[i] = s_iu[byte_of(w, i)];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (fb[c] == NONE && rb[c] == NONE) continue;
+                    uint32_t idx[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) idx[k] = (cd[3 * k + c] << 8) | (cd[3 * k + c + 1] << 4) | cd[3 * k + c + 2];
+                    if (!interior) {  // complete codons of the lane in this class
+                        nvc[c] = 0;
+                        if (q + (uint32_t)c + 2u < L) { nvc[c] = (L - q - (uint32_t)c - 3u) / 3u + 1u; if (nvc[c] > 4u) nvc[c] = 4u; }
+                    }
+                    if (fb[c] != NONE)
+                        pkf[c] = (uint32_t)s_fw[idx[0]] | ((uint32_t)s_fw[idx[1]] << 8) | ((uint32_t)s_fw[idx[2]] << 16) |
+                                 ((uint32_t)s_fw[idx[3]] << 24);
+                    if (rb[c] != NONE)
+                        pkr[c] = (uint32_t)s_rc[idx[3]] | ((uint32_t)s_rc[idx[2]] << 8) | ((uint32_t)s_rc[idx[1]] << 16) |
+                                 ((uint32_t)s_rc[idx[0]] << 24);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                if (fb[c] == NONE && rb[c] == NONE) continue;
-                uint32_t idx[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) idx[k] = (cd[3 * k + c] << 8) | (cd[3 * k + c + 1] << 4) | cd[3 * k + c + 2];
-                uint32_t nv = 4;  // complete codons of the lane in this class
-                if (!interior) {
-                    nv = 0;
-                    if (q + (uint32_t)c + 2u < L) { nv = (L - q - (uint32_t)c - 3u) / 3u + 1u; if (nv > 4u) nv = 4u; }
-                }
+                const uint32_t nv = nvc[c];
                 if (fb[c] != NONE) {
-                    const uint32_t pk = (uint32_t)s_fw[idx[0]] | ((uint32_t)s_fw[idx[1]] << 8) | ((uint32_t)s_fw[idx[2]] << 16) |
-                                        ((uint32_t)s_fw[idx[3]] << 24);
+                    const uint32_t pk = pkf[c];
                     if (interior) andacc &= pk | (pk << 1);
                     else andacc &= pk | (pk << 1) | (nv >= 4u ? 0u : ~((1u << (8 * nv)) - 1u));
                     uint8_t* body = out + fb[c];
-                    if (wide && (uint64_t)sb / 3u + g4 <= fk[c]) put4(body + fj + fo, pk, lw ? lw - fc : 4u);
+                    if (wide && sb / 3u + g4 <= fk[c]) put4(body + (uint32_t)(fj + fo), pk, lw ? lw - fc : 4u);
                     else put4_edge(body, (int64_t)fj, pk, lw, fk[c], fo, fc);
                 }
                 if (rb[c] != NONE) {
-                    // descending residues: codon slot 3 is the lowest residue = byte 0
-                    const uint32_t pk = (uint32_t)s_rc[idx[3]] | ((uint32_t)s_rc[idx[2]] << 8) | ((uint32_t)s_rc[idx[1]] << 16) |
-                                        ((uint32_t)s_rc[idx[0]] << 24);
+                    const uint32_t pk = pkr[c];
                     if (interior) andacc &= pk | (pk << 1);
                     else andacc &= pk | (pk << 1) | (nv >= 4u ? 0u : (nv == 0u ? 0xFFFFFFFFu : ((1u << (8 * (4u - nv))) - 1u)));
                     uint8_t* body = out + rb[c];
                     // lane 0 holds the highest residues of the step, lane G-1 the lowest
-                    const int64_t hi0 = rj[c] + 4 * (int64_t)gl + 3, lo0 = hi0 - 4 * (int64_t)G + 1;
-                    if (wide && lo0 >= 0 && (uint64_t)hi0 < rk[c]) put4(body + rj[c] + ro[c], pk, lw ? lw - rcc[c] : 4u);
+                    const int32_t hi0 = rj[c] + 4 * (int32_t)gl + 3, lo0 = hi0 - 4 * (int32_t)G + 1;
+                    if (wide && lo0 >= 0 && (uint32_t)hi0 < rk[c]) put4(body + (uint32_t)((uint32_t)rj[c] + ro[c]), pk, lw ? lw - rcc[c] : 4u);
                     else put4_edge(body, rj[c], pk, lw, rk[c], ro[c], rcc[c]);
                 }
             }
@@ -728,6 +792,399 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_translate_wide<G>: the kernel of the common case -- plain A/C/G/T letters (any case), source lines of >= 50 bases
+// (or unwrapped), output lines of >= 16 residues (or unwrapped).  A record whose text does not fit (an N, a narrow
+// line, ...) is flagged in `redo` and translated by k_translate_frames4 afterwards; nothing here guesses.
+//
+// Why another kernel: k_translate_frames4 is bound by its WRITES, not by its instructions (measured: neither the ACGT
+// fast path nor 16 vs 64 lanes per record nor 100 M fewer store instructions moved its 77 ms; PMC WRITE_SIZE 159 GB
+// for 100.8 GB of output).  Its lanes own 4 residues per frame and step, so a store instruction covers 256 contiguous
+// bytes per frame and every 128-byte line of the output is written in pieces by several instructions.
+// Here a lane owns SIXTEEN codon slots (48 bases + 2 of look-ahead) per step:
+//   * its 64 raw bytes come straight from global memory (four 16-byte loads; neighbouring lanes overlap by 2-4 bytes,
+//     absorbed by L1/L2) -- no LDS staging, no barrier;
+//   * letters -> 2-bit codes ((b >> 1) & 3: A 0, C 1, T 2, G 3) with one shift+and per dword, checked against the
+//     letters by v_perm + v_sad_u8 (sum of |letter - letter(code)| over all bytes: 0, or exactly 57 when the lane's one
+//     line break '\n' is among them), packed by v_dot4_u32_u8 into a 128-bit string X of codes; the break's two bits are
+//     cut out of X with four v_alignbit / v_bfi -- the raw bytes are never spliced;
+//   * a codon's 6-bit index is one v_bfe / v_alignbit on X, its residue one read from a 64-byte LDS table (16 banks, no
+//     conflicts), forward and reverse-complement strand from the same index;
+//   * 16 residues leave as ONE 16-byte store per frame (the line break of the output spliced in by v_perm with selectors
+//     from a 6-entry LDS table, the 17th byte by a byte store): a wave instruction covers 1 KiB (G = 64) of contiguous
+//     output per frame, so almost every line is written whole.
+// ---------------------------------------------------------------------------
+typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+
+// codes of base slot `bit / 2` .. from the 128-bit code string (bit is a compile-time constant)
+template <int BIT>
+__device__ __forceinline__ uint32_t code6(const uint32_t (&X)[5]) {
+    constexpr int w = BIT >> 5, sh = BIT & 31;
+    if constexpr (sh <= 26) return (X[w] >> sh) & 63u;
+    else return __builtin_amdgcn_alignbit(X[w + 1], X[w], sh) & 63u;
+}
+
+template <int C, int K>
+struct Slots {  // residues of class C, slots K..15, forward ascending / reverse descending, packed into 4 dwords each
+    // s_tab64: forward residues at [0, 64), reverse-complement residues at [64, 128): both strands of a slot always (two
+    // byte reads from one address register; a branch per slot and strand cost more than the reads of an unused strand)
+    static __device__ __forceinline__ void run(const uint32_t (&X)[5], const uint8_t* s_tab64, uint32_t (&pf)[4], uint32_t (&pr)[4]) {
+        if constexpr (K < 16) {
+            const uint32_t idx = code6<2 * C + 6 * K>(X);
+            pf[K >> 2] |= (uint32_t)s_tab64[idx] << (8 * (K & 3));
+            pr[(15 - K) >> 2] |= (uint32_t)s_tab64[64 + idx] << (8 * ((15 - K) & 3));
+            Slots<C, K + 1>::run(X, s_tab64, pf, pr);
+        }
+    }
+};
+
+// 16 residues (4 dwords, ascending addresses) at `at`, `first` = residues before the line break (>= 16: none inside);
+// nbytes = how many of the 16 (17 with a break inside) bytes exist, counted from `at` (whole: 16 / 17)
+// after16: a line break follows the block's 16th residue directly (first == 16) and exists in the body (another residue
+// comes after it) -- the block writes it, so that no separate pass has to touch the lines of the output beforehand
+__device__ __forceinline__ void put16(uint8_t* at, const uint32_t (&p)[4], uint32_t first, const uint2* s_ins, uint32_t skip,
+                                      uint32_t nres, bool after16) {
+    uint32_t d[4];
+    if (first >= 16u) {
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int fm = (int)first - 4 * i;  // position of the break inside dword i
+            fm = fm < -1 ? -1 : (fm > 4 ? 4 : fm);
+            const uint2 e = s_ins[fm + 1];  // selector over {p[i] (bytes 4..7), p[i-1] (bytes 0..3)}, and the '\n' to OR in
+            d[i] = __builtin_amdgcn_perm(p[i], i ? p[i - 1] : 0u, e.x) | e.y;
+        }
+    }
+    if (skip == 0u && nres == 16u) {
+        uint4 v = make_uint4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4_unaligned*>(at) = v;
+        if (first < 16u) at[16] = (uint8_t)(p[3] >> 24);
+        else if (after16) at[16] = (uint8_t)'\n';
+    } else {
+        // a lane at the start / end of the element: residues [skip, skip + nres) of the sixteen exist, i.e. bytes [b0, b1) of
+        // the 16 / 17.  Whole dwords leave as dwords, the rest as single bytes -- straight-line, predicated (a byte loop
+        // here kept one lane busy for ~250 instructions per frame while 63 waited: 1 500 of the 2 000 per record)
+        const uint32_t b0 = skip + (first < skip ? 1u : 0u);
+        const uint32_t b1 = skip + nres + (first < skip + nres ? 1u : 0u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (b0 <= 4u * i && 4u * i + 4u <= b1) {
+                *reinterpret_cast<u32_unaligned*>(at + 4 * i) = d[i];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b0 <= 4u * i + b && 4u * i + b < b1) at[4 * i + b] = (uint8_t)(d[i] >> (8 * b));
+            }
+        }
+        if (b1 > 16u) at[16] = (uint8_t)(p[3] >> 24);
+        else if (after16 && skip + nres == 16u) at[16] = (uint8_t)'\n';
+    }
+}
+
+// the 52 raw bytes of a lane's window (50 bases and at most one line break; 13 dwords)
+__device__ __forceinline__ void load_window(const uint8_t* a, const uint8_t* buf_end, uint32_t (&r)[13]) {
+    if (a + 52 <= buf_end) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            uint4 v;
+            __builtin_memcpy(&v, a + 16 * i, 16);
+            r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+        }
+        __builtin_memcpy(&r[12], a + 48, 4);
+    } else {  // the last bytes of the shard
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            uint32_t wv = 0;
+            for (int b = 0; b < 4; ++b)
+                if (a + 4 * i + b < buf_end) wv |= (uint32_t)a[4 * i + b] << (8 * b);
+            r[i] = wv;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_translate_wide(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+                                                        TranslateParams P, const uint32_t* __restrict__ out_len,
+                                                        const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                        uint8_t* __restrict__ redo, uint64_t* __restrict__ redo_count,
+                                                        uint64_t* __restrict__ status) {
+    constexpr uint32_t LB = 48;            // bases per lane and step (16 codon slots)
+    constexpr uint32_t STEPB = G * LB;     // bases per group and step
+    __shared__ __attribute__((aligned(128))) uint8_t s_tab64[128];  // forward ++ reverse-complement residues by 2-bit codon index
+    __shared__ uint8_t s_iu[256];
+    __shared__ uint2 s_ins[6];
+    if (threadIdx.x < 64) {  // residue of the codon with 2-bit codes i (first base in the low bits) from the baked IUPAC tables
+        const uint32_t iu[4] = {1u, 2u, 8u, 4u};
+        const uint32_t i = threadIdx.x;
+        const uint32_t full = (iu[i & 3u] << 8) | (iu[(i >> 2) & 3u] << 4) | iu[(i >> 4) & 3u];
+        s_tab64[i] = P.baked[full];
+        s_tab64[64 + i] = P.baked[4096 + full];
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
+    if (threadIdx.x == 0) {
+        // break inside dword i at byte fm (index fm + 1): bytes below fm from p[i], the break, bytes above from one lower
+        s_ins[0] = make_uint2(0x06050403u, 0u);            // fm <= -1: the break came earlier, everything one byte up
+        s_ins[1] = make_uint2(0x0605040Cu, 0x0000000Au);   // fm == 0
+        s_ins[2] = make_uint2(0x06050C04u, 0x00000A00u);
+        s_ins[3] = make_uint2(0x060C0504u, 0x000A0000u);
+        s_ins[4] = make_uint2(0x0C060504u, 0x0A000000u);
+        s_ins[5] = make_uint2(0x07060504u, 0u);            // fm >= 4: the break comes later
+    }
+    __syncthreads();
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint32_t gl = threadIdx.x % G;
+    if (g >= t.n) return;  // no block-level barrier below
+    if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
+    const Text T = text_of(buf, t, tt, g);
+    const uint32_t L = T.L;
+    const uint32_t W = T.W;
+    const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
+    if ((W && W < 50u) || (lw && lw < 16u)) {  // (wave-uniform per group) not this kernel's layout
+        if (gl == 0) { redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
+        return;
+    }
+    const uint8_t* h = buf + t.start[g] + 1;
+    const uint32_t lh = t.l_head[g];
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+
+    // raw cursor of the lane's first base (wrapped source): line breaks before it and its column
+    uint32_t rnl = 0, rcol = LB * gl;
+    if (W) { rnl = rcol / W; rcol -= rnl * W; }
+    const uint32_t sdq = W ? STEPB / W : 0u, smq = W ? STEPB % W : 0u;
+    const uint8_t* const buf_end = buf + buf_n;
+    // the window of the first step is requested before anything else is done with the record, the window of step s + 1
+    // while step s is translated: the text's round trip to HBM hides behind the headers / the previous step
+    uint32_t rn[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (LB * gl < L) load_window(T.p + LB * gl + rnl, buf_end, rn);
+
+    constexpr uint64_t NONE = ~0ull;
+    uint64_t fb[3] = {NONE, NONE, NONE};   // body offsets from `out`
+    uint64_t rbq[3] = {NONE, NONE, NONE};
+    uint32_t fk[3] = {0, 0, 0}, rkq[3] = {0, 0, 0};
+    // everything the six elements need from memory is requested at once (a loop that fetched out_len / out_off / the
+    // header bytes frame by frame put six dependent round trips in front of every record: the waves of this kernel live
+    // for ~30 us, and most of that was waiting)
+    uint32_t ne[6];
+    uint64_t oe[6];
+    const uint64_t e0 = g * (uint64_t)P.nframes;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        ne[k] = k < P.nframes ? out_len[e0 + k] : 0u;
+        oe[k] = k < P.nframes ? out_off[e0 + k] : 0ull;
+    }
+    const uint8_t hbyte = (gl >= 1u && gl - 1u < hl) ? h[gl - 1u] : (uint8_t)0;  // header byte of position gl (frames share it)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k >= P.nframes) break;
+        const int frame = P.frames[k];
+        const uint32_t n = ne[k];
+        uint8_t* o = out + oe[k];
+        const uint32_t H = header_len(h, hl, P, frame) + 1;
+        const uint32_t body = n - H - 1;
+        const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
+        if (!P.append_frame) {
+            if (gl < H) o[gl] = gl == 0 ? (uint8_t)'>' : (gl == H - 1 ? (uint8_t)'\n' : hbyte);
+            for (uint32_t x = gl + G; x < H; x += G) o[x] = x == H - 1 ? (uint8_t)'\n' : h[x - 1];
+        } else if (gl == 0) {
+            uint32_t hdr = 0, ioff, doff;
+            o[hdr++] = '>';
+            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
+            for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
+            const char* fs = "_frame=";
+            for (int q = 0; q < 7; ++q) o[hdr++] = (uint8_t)fs[q];
+            hdr += put_dec(o + hdr, frame);
+            o[hdr++] = ' ';
+            for (uint32_t q = 0; q < dl; ++q) o[hdr++] = h[doff + q];
+            o[hdr++] = '\n';
+        }
+        if (gl == 0) o[n - 1] = '\n';  // (the line breaks of the body are written with the residues around them)
+        uint64_t bodyp = oe[k] + H;
+        if constexpr (G == 64)  // one record per wave: the body addresses are wave-uniform -> scalar base + 32-bit offset
+            bodyp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bodyp >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bodyp);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (frame == c + 1) { fb[c] = bodyp; fk[c] = kept; }
+            if (frame == -(c + 1)) { rbq[c] = bodyp; rkq[c] = kept; }
+        }
+    }
+    // codons of class c (starting at base c + 3 s) belong to reverse frame -(sl + 1), sl = (L % 3 + 3 - c) % 3, as its
+    // residue (L - 3 - c) / 3 - s
+    const uint32_t Lm = L % 3u;
+    uint64_t rb[3];
+    uint32_t rk[3];
+    int32_t r0[3];  // residue index of slot 0
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t sl = (Lm + 3u - (uint32_t)c) % 3u;
+        rb[c] = sl == 0 ? rbq[0] : (sl == 1 ? rbq[1] : rbq[2]);
+        rk[c] = sl == 0 ? rkq[0] : (sl == 1 ? rkq[1] : rkq[2]);
+        r0[c] = L >= 3u + (uint32_t)c ? (int32_t)((L - 3u - (uint32_t)c) / 3u) : -1;
+    }
+    const uint32_t g16 = 16u * G;  // residues per group and step
+    const uint32_t gd = lw ? g16 / lw : 0u, gm = lw ? g16 % lw : 0u;
+    // forward cursor: residue of the lane's slot 0, line breaks before it, its column
+    uint32_t fj = 16u * gl, fo = 0, fc = fj;
+    if (lw) { fo = fj / lw; fc = fj - fo * lw; }
+    // reverse cursors: LOWEST residue of the lane's sixteen (slot 15); descending by 16 G per step
+    int32_t rj[3];
+    uint32_t ro[3], rcc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rj[c] = r0[c] - (int32_t)(16u * gl) - 15;
+        ro[c] = 0; rcc[c] = 0;
+        if (lw && rj[c] >= 0) { ro[c] = (uint32_t)rj[c] / lw; rcc[c] = (uint32_t)rj[c] - ro[c] * lw; }
+    }
+    constexpr uint32_t LET = 0x67746361u;  // 'a' 'c' 't' 'g' at byte 0..3 == letter of code 0..3
+    bool give_up = false;
+
+#pragma unroll 1
+    for (uint32_t sb = 0; sb < L; sb += STEPB) {
+        const uint32_t q = sb + LB * gl;  // first base of the lane
+        const bool live = q < L;
+        uint32_t X[5] = {0, 0, 0, 0, 0};
+        bool bad = false;
+        // cursor of the next step, and its window on the way
+        uint32_t rnl2 = rnl, rcol2 = rcol;
+        if (W) { rnl2 += sdq; rcol2 += smq; if (rcol2 >= W) { rcol2 -= W; ++rnl2; } }
+        const uint32_t kbrk = W ? W - rcol : 0xFFFFu;            // raw bytes before this window's line break
+        if (live) {
+            const uint32_t nb = L - q < 50u ? L - q : 50u;     // bases of the lane's window that exist
+            const bool brk = kbrk < nb;                          // (a break after the last base needed is not read)
+            const uint32_t nraw = nb + (brk ? 1u : 0u);
+            uint32_t r[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) r[i] = rn[i];
+            // bytes past the window (the next letters, or whatever follows the record) must not take part in the check
+            if (nraw >= 48u) {
+                const uint32_t keep = nraw - 48u;  // 0..3 bytes of dword 12
+                const uint32_t m = (1u << (8u * keep)) - 1u;
+                r[12] = (r[12] & m) | (0x41414141u & ~m);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    const int keep = (int)nraw - 4 * i;
+                    const uint32_t m = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u));
+                    r[i] = (r[i] & m) | (0x41414141u & ~m);
+                }
+            }
+            uint32_t sad = 0;
+            uint32_t d8[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                const uint32_t cd = (r[i] >> 1) & 0x03030303u;
+                sad = __builtin_amdgcn_sad_u8(r[i] | 0x20202020u, __builtin_amdgcn_perm(LET, LET, cd), sad);
+                d8[i] = __builtin_amdgcn_udot4(cd, 0x40100401u, 0u, false);
+            }
+            bad = sad != (brk ? 57u : 0u);  // |('\n' | 0x20) - 'c'| = 57: the break, and nothing else, may differ
+            X[0] = d8[0] | (d8[1] << 8) | (d8[2] << 16) | (d8[3] << 24);
+            X[1] = d8[4] | (d8[5] << 8) | (d8[6] << 16) | (d8[7] << 24);
+            X[2] = d8[8] | (d8[9] << 8) | (d8[10] << 16) | (d8[11] << 24);
+            X[3] = d8[12];
+            if (q + STEPB < L) load_window(T.p + q + STEPB + rnl2, buf_end, rn);  // (r is consumed: its registers are free)
+            if (brk) {  // cut the two bits of the break (raw byte kbrk) out of the string
+                const uint32_t Y[5] = {X[0], X[1], X[2], X[3], 0u};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = 2 * (int)kbrk - 32 * i;
+                    const uint32_t up = __builtin_amdgcn_alignbit(Y[i + 1], Y[i], 2);
+                    const uint32_t m = b >= 32 ? 0xFFFFFFFFu : (b <= 0 ? 0u : ((1u << b) - 1u));
+                    X[i] = (Y[i] & m) | (up & ~m);
+                }
+            }
+        }
+        // a group that met a letter this kernel does not know leaves the record to k_translate_frames4
+        {
+            const uint64_t bb = __ballot(bad);
+            const uint32_t shift = ((threadIdx.x & 63u) / G) * G;
+            const uint64_t gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << shift);
+            if (bb & gmask) { give_up = true; break; }
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool wf = fb[c] != NONE, wr = rb[c] != NONE;
+                if (!wf && !wr) continue;
+                uint32_t pf[4] = {0, 0, 0, 0}, pr[4] = {0, 0, 0, 0};
+                if (c == 0) Slots<0, 0>::run(X, s_tab64, pf, pr);
+                else if (c == 1) Slots<1, 0>::run(X, s_tab64, pf, pr);
+                else Slots<2, 0>::run(X, s_tab64, pf, pr);
+                // complete codons among the lane's sixteen slots of this class
+                uint32_t nv = 0;
+                if (q + (uint32_t)c + 2u < L) { nv = (L - q - (uint32_t)c - 3u) / 3u + 1u; if (nv > 16u) nv = 16u; }
+                if (wf) {
+                    // residues fj .. fj + nv - 1, cut by `kept` (--trim)
+                    uint32_t nres = nv;
+                    if (fj >= fk[c]) nres = 0; else if (fj + nres > fk[c]) nres = fk[c] - fj;
+                    if (nres) {
+                        const uint32_t first = lw ? lw - fc : 17u;
+                        put16(out + fb[c] + (uint32_t)(fj + fo), pf, first, s_ins, 0u, nres, first == 16u && fj + 16u < fk[c]);
+                    }
+                }
+                if (wr) {
+                    // slot k is residue rj + 15 - k: the valid slots 0 .. nv-1 are the HIGH residues of the block
+                    // [rj, rj + 15]; below 0 nothing exists, at `kept` and above nothing is printed (--trim)
+                    int32_t lo = rj[c] + 16 - (int32_t)nv, hi = rj[c] + 16;  // residues [lo, hi)
+                    if (lo < 0) lo = 0;
+                    if (hi > (int32_t)rk[c]) hi = (int32_t)rk[c];
+                    if (hi > lo) {
+                        const uint32_t skip = (uint32_t)(lo - rj[c]);
+                        // block position: residue rj may be negative (then skip > 0): positions are relative to residue rj
+                        if (rj[c] >= 0) {
+                            const uint32_t first = lw ? lw - rcc[c] : 17u;
+                            put16(out + rb[c] + (uint32_t)((uint32_t)rj[c] + ro[c]), pr, first, s_ins, skip, (uint32_t)(hi - lo),
+                                  first == 16u && (uint32_t)rj[c] + 16u < rk[c]);
+                        } else {
+                            // the block starts before residue 0: its residues 0 .. hi-1 (< 16 <= lw) are on the first line
+                            uint8_t* base = out + rb[c];
+                            for (int32_t j = lo; j < hi; ++j) {
+                                const uint32_t kk = (uint32_t)(j - rj[c]);
+                                base[j] = (uint8_t)(pr[kk >> 2] >> (8 * (kk & 3u)));
+                            }
+                            if (lw == (uint32_t)hi && (uint32_t)hi < rk[c]) base[hi] = (uint8_t)'\n';  // (hi == 16 == lw)
+                        }
+                    }
+                }
+            }
+        }
+        // ---- advance the cursors by one step
+        fj += g16;
+        if (lw) { fo += gd; fc += gm; if (fc >= lw) { fc -= lw; ++fo; } }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rj[c] -= (int32_t)g16;
+            if (lw && rj[c] >= 0) {
+                ro[c] -= gd;
+                if (rcc[c] < gm) { rcc[c] += lw - gm; --ro[c]; } else rcc[c] -= gm;
+            }
+        }
+        rnl = rnl2; rcol = rcol2;
+    }
+    if (give_up) {
+        if (gl == 0) { redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
+        return;
+    }
+    // ---- -M: residue 0 of a frame becomes 'M' when its codon is a start codon (after every other store)
+    if (P.init_m && gl == 0) {
+        __threadfence();
+        for (int k = 0; k < P.nframes; ++k) {
+            const int frame = P.frames[k];
+            const uint32_t f = (uint32_t)(frame < 0 ? -frame : frame);
+            if (L < f + 2u) continue;
+            const uint32_t p0 = frame > 0 ? f - 1u : L - f - 2u;  // first base of the codon (forward coordinates)
+            const uint32_t ix = ((uint32_t)s_iu[T.at(p0)] << 8) | ((uint32_t)s_iu[T.at(p0 + 1)] << 4) | (uint32_t)s_iu[T.at(p0 + 2)];
+            const bool st = frame > 0 ? P.start[ix] != 0 : P.start_rc[ix] != 0;
+            const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
+            const uint32_t H = header_len(h, hl, P, frame) + 1;
+            if (st && out_len[e] > H + 1u) out[out_off[e] + H] = 'M';
+        }
+    }
+    (void)status;
+}
+
 }  // namespace
 
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
@@ -741,17 +1198,37 @@ hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const
 
 hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
-                                   uint8_t* out, uint64_t* status, hipStream_t st) {
+                                   uint8_t* out, uint64_t* status, hipStream_t st, uint64_t buf_n, uint8_t* redo, int wide_lanes,
+                                   uint64_t* redo_count) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     static const bool v3 = [] { const char* e = getenv("BSK_TRANSLATE"); return e && !strcmp(e, "v3"); }();
+    static const bool nowide = [] { const char* e = getenv("BSK_TRANSLATE"); return e && !strcmp(e, "frames4"); }();
     if (!v3) {
+        // the wide kernel first (plain A/C/G/T text in ordinary layouts), then frames4 for the records it flagged
+        const uint8_t* only = nullptr;
+        if (redo && !nowide) {
+            if (wide_lanes == 64)
+                hipLaunchKernelGGL(k_translate_wide<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
+                                   P, out_len, out_off, out, redo, redo_count, status);
+            else
+                hipLaunchKernelGGL(k_translate_wide<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
+                                   P, out_len, out_off, out, redo, redo_count, status);
+            only = redo;
+            // how many records are left for k_translate_frames4: usually none, and 2.4 M blocks that look at their flags and
+            // leave still cost 2 ms at C4 -- one small read-back instead
+            uint64_t left = 0;
+            hipError_t e = hipMemcpyAsync(&left, redo_count, sizeof left, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            if (left == 0) return hipGetLastError();
+        }
         if (lanes_per_record == 64)
             hipLaunchKernelGGL(k_translate_frames4<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, t,
-                               d, P, out_len, out_off, out, status);
+                               d, P, out_len, out_off, out, status, only);
         else
             hipLaunchKernelGGL(k_translate_frames4<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t,
-                               d, P, out_len, out_off, out, status);
+                               d, P, out_len, out_off, out, status, only);
         return hipGetLastError();
     }
     if (lanes_per_record == 64) {

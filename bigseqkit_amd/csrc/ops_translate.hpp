@@ -39,10 +39,13 @@ constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
 // elements are numbered record * nframes + f
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                  const TranslateParams& P, uint32_t* out_len, uint64_t* status, hipStream_t st);
-// all requested frames of a record from ONE read of its bases (G lanes per record)
+// all requested frames of a record from ONE read of its bases (G lanes per record).  With `redo` (one zeroed byte per
+// record) k_translate_wide<wide_lanes> translates the records of plain A/C/G/T text first and k_translate_frames4 the ones
+// it flags; buf_n = bytes in the shard (the wide kernel reads 64 bytes at a time and must not pass the end)
 hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
-                                   uint8_t* out, uint64_t* status, hipStream_t st);
+                                   uint8_t* out, uint64_t* status, hipStream_t st, uint64_t buf_n = 0, uint8_t* redo = nullptr,
+                                   int wide_lanes = 16, uint64_t* redo_count = nullptr /* zeroed device word */);
 // elements of the records in P.long_list; max_len = longest of those sequences
 hipError_t launch_translate_long(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const TranslateParams& P,
                                  const uint32_t* out_len, const uint64_t* out_off, uint8_t* out, uint64_t* status,
