@@ -91,11 +91,13 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
     const uint64_t plo = LONG ? (uint64_t)blockIdx.x * GREP_LONG_CH : 0ull;  // this block's start positions [plo, phi)
     const uint64_t phi = LONG ? plo + GREP_LONG_CH : ~0ull;
     bool hit = false;
-    const int nstr = P.both_strands ? 2 : 1;
+    // strand_only (1: '+', 2: '-'): one strand alone, for the per-(pattern, strand) hit bits of --delete-matched
+    const int nstr = P.strand_only == 1 ? 1 : (P.both_strands ? 2 : 1);
+    const int str0 = P.strand_only == 2 ? 1 : 0;
     const bool fast = live && T.W == 0 && !P.circular && T.p >= buf && T.p < buf + buf_n;
     if (fast) {
         const uint8_t* const buf_end = buf + buf_n;
-        for (int strand = 0; strand < nstr && !hit; ++strand) {
+        for (int strand = str0; strand < nstr && !hit; ++strand) {
             uint32_t wb = 0, we = L;
             if (P.region_on) {
                 uint32_t b, e;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
             }
         }
     } else if (live) {
-        for (int strand = 0; strand < nstr && !hit; ++strand) {
+        for (int strand = str0; strand < nstr && !hit; ++strand) {
             // window of the forward text that the strand's target covers
             uint32_t wb = 0, we = L;
             if (P.region_on) {
@@ -240,8 +242,10 @@ __global__ __launch_bounds__(256) void k_grep_seq_gen(const uint8_t* __restrict_
     const Text T = text_of(buf, t, tt, gi);
     const uint32_t L = live ? T.L : 0;
     bool hit = false;
-    const int nstr = P.both_strands ? 2 : 1;
-    for (int strand = 0; strand < nstr && !hit; ++strand) {
+    // strand_only (1: '+', 2: '-'): one strand alone, for the per-(pattern, strand) hit bits of --delete-matched
+    const int nstr = P.strand_only == 1 ? 1 : (P.both_strands ? 2 : 1);
+    const int str0 = P.strand_only == 2 ? 1 : 0;
+    for (int strand = str0; strand < nstr && !hit; ++strand) {
         uint32_t wb = 0, we = L;
         if (P.region_on) {
             uint32_t b, e;
@@ -310,8 +314,10 @@ __global__ __launch_bounds__(256) void k_grep_regex(const uint8_t* __restrict__ 
     if (P.by_seq) {
         const Text T = text_of(buf, t, tt, i);
         const uint32_t L = T.L;
-        const int nstr = P.both_strands ? 2 : 1;
-        for (int strand = 0; strand < nstr && !hit; ++strand) {
+        // strand_only (1: '+', 2: '-'): one strand alone, for the per-(pattern, strand) hit bits of --delete-matched
+    const int nstr = P.strand_only == 1 ? 1 : (P.both_strands ? 2 : 1);
+    const int str0 = P.strand_only == 2 ? 1 : 0;
+        for (int strand = str0; strand < nstr && !hit; ++strand) {
             uint32_t wb = 0, we = L;  // window in the strand's own coordinates
             if (P.region_on) sub_location(L, P.region_start, P.region_end, &wb, &we);
             const uint32_t wl = we - wb;

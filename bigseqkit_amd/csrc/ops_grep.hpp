@@ -13,6 +13,7 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     int by_seq, by_name, invert, ignore_case, circular;
     int region_on, region_start, region_end;
     int both_strands;        // search the reverse complement too (grep.go:432-448)
+    int strand_only;         // 0: as both_strands says; 1: '+' only; 2: '-' only (hit bits per pattern AND strand)
     int id_mode;             // 0 default ID regexp, 1 --id-ncbi
     int line_width;          // of the emitted record (0 for FASTQ)
     int npat;                // patterns; with both_strands the reverse-complemented copies follow

@@ -182,6 +182,30 @@ __global__ __launch_bounds__(256) void k_first_nonzero(const uint32_t* __restric
     if (threadIdx.x == 0 && s_min != ~0ull) atomicMin(first, s_min);
 }
 
+// grep --delete-matched with several patterns: masks[i] bit k = record i matches pattern k
+__global__ void k_or_bit(uint32_t* __restrict__ masks, const uint32_t* __restrict__ hit, uint64_t n, uint32_t bit) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && hit[i]) masks[i] |= bit;
+}
+// first record at or after `from` that matches one of the remaining patterns (same reduction as k_first_nonzero)
+__global__ __launch_bounds__(256) void k_first_masked(const uint32_t* __restrict__ masks, uint64_t n, uint32_t remaining,
+                                                      uint64_t from, unsigned long long* __restrict__ first) {
+    __shared__ unsigned long long s_min;
+    if (threadIdx.x == 0) s_min = ~0ull;
+    __syncthreads();
+    unsigned long long mine = ~0ull;
+    for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (masks[i] & remaining) { mine = i; break; }
+    if (mine != ~0ull) atomicMin(&s_min, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_min != ~0ull) atomicMin(first, s_min);
+}
+// out_len[i] := 0 unless bit 31 of masks[i] marks the record as selected
+__global__ void k_keep_selected(uint32_t* __restrict__ out_len, const uint32_t* __restrict__ masks, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(masks[i] & 0x80000000u)) out_len[i] = 0;
+}
+
 __global__ void k_keep_only(uint32_t* __restrict__ a, uint64_t n, const uint64_t* __restrict__ first) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && i != *first) a[i] = 0;
@@ -254,6 +278,23 @@ hipError_t launch_first_nonzero(const uint32_t* a, uint64_t n, uint64_t* first, 
     uint64_t blocks = (n + 4095) / 4096;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_first_nonzero, dim3((unsigned)blocks), dim3(256), 0, st, a, n, (unsigned long long*)first);
+    return hipGetLastError();
+}
+hipError_t launch_or_bit(uint32_t* masks, const uint32_t* hit, uint64_t n, uint32_t bit, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_or_bit, BSK_GRID(n), dim3(256), 0, st, masks, hit, n, bit);
+    return hipGetLastError();
+}
+hipError_t launch_first_masked(const uint32_t* masks, uint64_t n, uint32_t remaining, uint64_t from, uint64_t* first, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 4095) / 4096;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_first_masked, dim3((unsigned)blocks), dim3(256), 0, st, masks, n, remaining, from, (unsigned long long*)first);
+    return hipGetLastError();
+}
+hipError_t launch_keep_selected(uint32_t* out_len, const uint32_t* masks, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_keep_selected, BSK_GRID(n), dim3(256), 0, st, out_len, masks, n);
     return hipGetLastError();
 }
 hipError_t launch_keep_only(uint32_t* a, uint64_t n, const uint64_t* first, hipStream_t st) {

@@ -52,5 +52,10 @@ hipError_t launch_mask_u32(uint32_t* a, const uint32_t* b, uint64_t n, hipStream
 // *first = min index with a[i] != 0 (set to ~0 by the caller), then every other entry is zeroed
 hipError_t launch_first_nonzero(const uint32_t* a, uint64_t n, uint64_t* first, hipStream_t st);
 hipError_t launch_keep_only(uint32_t* a, uint64_t n, const uint64_t* first, hipStream_t st);
+// grep --delete-matched with several patterns (bigseqkit-lib/grep.go:463-511): per-pattern hit bits, the first record that
+// matches a remaining pattern, and the final mask of the selected records (bit 31)
+hipError_t launch_or_bit(uint32_t* masks, const uint32_t* hit, uint64_t n, uint32_t bit, hipStream_t st);
+hipError_t launch_first_masked(const uint32_t* masks, uint64_t n, uint32_t remaining, uint64_t from, uint64_t* first, hipStream_t st);
+hipError_t launch_keep_selected(uint32_t* out_len, const uint32_t* masks, uint64_t n, hipStream_t st);
 
 }  // namespace bsk

@@ -622,12 +622,12 @@ void validate_grep_opts(bsk_ctx* c) {
         c->patterns.push_back(p);
     }
     if (o.b("DeleteMatched") && !o.b("InvertMatch")) {  // PARITY.md DEL
-        if (o.b("BySeq") && c->max_mm > 0)
-            throw OptError("libbsk: --delete-matched with -m: the reference returns its internal key/partition strings there; not provided");
+        // with -m the reference takes grepBySeqMismatches (grep.go:255-365), which never deletes a pattern, and the driver
+        // returns its records as they are (bigseqkit/grep.go:141-143): --delete-matched is a no-op there
+        if (o.b("BySeq") && c->max_mm > 0) o.mut("DeleteMatched").b = false;
         const size_t np = o.b("UseRegexp") ? c->regexes.size() : c->patterns.size();
-        if ((o.b("BySeq") || o.b("UseRegexp")) && np > 1)
-            throw OptError("libbsk: --delete-matched with several sequence / regexp patterns follows Go's map iteration order in "
-                           "the reference; provided for one pattern, or for ID / name patterns");
+        if ((o.b("BySeq") || o.b("UseRegexp")) && np > 15)
+            throw OptError("libbsk: --delete-matched with more than 15 sequence / regexp patterns is not provided");
     }
 }
 
@@ -894,11 +894,72 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
                 HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, R, c->d_keys, tk, cap, d_firsts, c->d_status, st));
                 HIP_TRYX(c, launch_mask_u32(c->d_out_len, d_firsts, N, st));
-            } else {
-                // one pattern (checked at create time): only its first hit survives
+            } else if (G.npat == 1) {
+                // one pattern: only its first hit survives
                 HIP_TRYX(c, hipMemsetAsync(c->d_counter + 3, 0xFF, 8, st));
                 HIP_TRYX(c, launch_first_nonzero(c->d_out_len, N, c->d_counter + 3, st));
                 HIP_TRYX(c, launch_keep_only(c->d_out_len, N, c->d_counter + 3, st));
+            } else {
+                // several sequence / regexp patterns (grep.go:463-511): the records are visited in file order, a record
+                // is a hit when one of the REMAINING patterns matches it, and that pattern -- the first one in the order
+                // the patterns were given (PARITY.md Q11; the reference walks a Go map) -- is dropped.  At most one
+                // record per pattern is selected, so the walk is: hit bits of every pattern (one match launch each),
+                // then <= npat rounds of "first record after the last selected one that still matches something".
+                const int np = G.npat;
+                Arena A;
+                const uint64_t o_masks = A.take(N * 4), o_hit = A.take(N * 4);
+                rc = arena_reserve(c, &A);
+                if (rc != BSK_OK) return rc;
+                uint32_t* d_masks = A.at<uint32_t>(o_masks);
+                uint32_t* d_hit = A.at<uint32_t>(o_hit);
+                HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 4, st));
+                const std::vector<std::string> all_patterns = c->patterns;
+                const auto all_cls = c->pattern_cls;
+                // the reference asks the '+' strand about every remaining pattern before it turns to the '-' strand
+                // (grep.go:420-433): bit k = pattern k on '+', bit 16 + k = pattern k on '-'
+                const int nstrands = G.both_strands ? 2 : 1;
+                for (int k = 0; k < np; ++k) {
+                    GrepParams G1 = G;
+                    G1.npat = 1;
+                    if (G.regex) {
+                        G1.regex = c->d_regex + k;
+                    } else {
+                        c->patterns.assign(1, all_patterns[k]);
+                        if (c->general) c->pattern_cls.assign(1, all_cls[k]);
+                        std::vector<std::string> one = c->patterns;
+                        if (G.both_strands) one.push_back(revcom_pattern(all_patterns[k], ab));
+                        rc = upload_patterns(c, one, st);
+                        if (rc == BSK_OK && c->general) rc = upload_classes(c, G.both_strands, ab, st);
+                        c->patterns = all_patterns;
+                        c->pattern_cls = all_cls;
+                        if (rc != BSK_OK) return rc;
+                    }
+                    for (int sd = 0; sd < nstrands; ++sd) {
+                        G1.strand_only = sd + 1;
+                        if (G1.long_hit) HIP_TRYX(c, hipMemsetAsync(c->d_hit_list, 0, G.long_count * sizeof(uint32_t), st));
+                        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G1, d_hit, st, c->avg_record_bytes));
+                        HIP_TRYX(c, launch_or_bit(d_masks, d_hit, N, 1u << (16 * sd + k), st));
+                    }
+                }
+                uint32_t remaining = (1u << np) - 1u;  // (np <= 15)
+                uint64_t from = 0;
+                while (remaining && from < N) {
+                    uint64_t idx = ~0ull;
+                    HIP_TRYX(c, hipMemsetAsync(c->d_counter + 3, 0xFF, 8, st));
+                    HIP_TRYX(c, launch_first_masked(d_masks, N, remaining | (remaining << 16), from, c->d_counter + 3, st));
+                    HIP_TRYX(c, hipMemcpyAsync(&idx, c->d_counter + 3, 8, hipMemcpyDeviceToHost, st));
+                    HIP_TRYX(c, hipStreamSynchronize(st));
+                    if (idx == ~0ull) break;
+                    uint32_t m = 0;
+                    HIP_TRYX(c, hipMemcpy(&m, d_masks + idx, 4, hipMemcpyDeviceToHost));
+                    const uint32_t plus = m & remaining, minus = (m >> 16) & remaining;
+                    const uint32_t hitp = plus ? plus : minus;
+                    remaining &= ~(hitp & (0u - hitp));  // the first remaining pattern (in the order given) that matched
+                    m |= 0x80000000u;                    // bit 31: selected
+                    HIP_TRYX(c, hipMemcpy(d_masks + idx, &m, 4, hipMemcpyHostToDevice));
+                    from = idx + 1;
+                }
+                HIP_TRYX(c, launch_keep_selected(c->d_out_len, d_masks, N, st));
             }
         }
         rc = finish_sizes(c, st, &total, &kept);

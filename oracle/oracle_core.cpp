@@ -734,8 +734,9 @@ std::vector<std::string> grep_call(const std::vector<std::string_view>& part, co
     }
     // --delete-matched (with -v it does nothing, grep.go:463): a pattern is dropped at its first hit, so every pattern
     // selects at most its FIRST record in file order (the driver's ReduceByKey keeps the lowest partition, PARITY.md DEL)
-    const bool del = o.DeleteMatched && !o.InvertMatch;
-    if (del && o.BySeq && o.MaxMismatch > 0) throw Error("delete-matched with mismatches: the reference returns its internal key\\0pid\\0 strings");
+    // with -m the reference takes grepBySeqMismatches (grep.go:255-365), which never drops a pattern, and the driver hands
+    // its records through (bigseqkit/grep.go:141-143): --delete-matched does nothing there
+    const bool del = o.DeleteMatched && !o.InvertMatch && !(o.BySeq && o.MaxMismatch > 0);
     std::vector<std::string> patterns;  // PARITY.md Q11: CLI / file order instead of Go map order
     std::vector<MiniRe> regexps;        // -d
     // -r: Go regexp (RE2) is not in this image; std::regex (ECMAScript grammar) stands in for it -- the two agree on

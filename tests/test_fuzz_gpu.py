@@ -108,7 +108,7 @@ def rand_opts(rng, op, fastq):
             o["Circular"] = True
         if (o.get("BySeq") or o.get("Degenerate")) and rng.random() < 0.25:
             o["Region"] = rng.choice(["1:20", "-30:-1", "5:-5", "100:200"])
-        if rng.random() < 0.2 and not o.get("MaxMismatch") and (len(o["Pattern"]) == 1 or not (o.get("BySeq") or o.get("UseRegexp") or o.get("Degenerate"))):
+        if rng.random() < 0.2 and len(o["Pattern"]) <= 15:
             o["DeleteMatched"] = True
     elif op == "locate":
         mode = rng.choice(["exact", "exact", "deg", "mm", "fmi", "re"])

@@ -498,8 +498,34 @@ def test_grep_delete_matched_keeps_the_first_record_of_every_pattern(tmp_path, m
     got = both(fq, True, {"PatternFile": str(pf), "DeleteMatched": True})
     assert got.count(b"@") == len({i for i in ids if int(i[1:]) % 2 == 0})
     assert bsk.GrepCount(frame(fq, True), _Opts({"PatternFile": str(pf), "DeleteMatched": True})) == got.count(b"@")
-    for o, msg in (({"Pattern": ["AC", "GG"], "BySeq": True, "DeleteMatched": True}, "several sequence"),
-                   ({"Pattern": ["ACGT"], "MaxMismatch": 1, "DeleteMatched": True}, "with -m")):
-        with pytest.raises(bsk.BskError) as e:
-            bsk.Grep(frame(fa, False), _Opts(o))
-        assert msg in str(e.value)
+    # several sequence patterns: records in file order, a record is a hit when a REMAINING pattern matches; that pattern (the
+    # first one given, '+' strand before '-') is dropped (grep.go:463-511, PARITY.md DEL)
+    assert both(fa, False, {"Pattern": ["AC", "GG"], "BySeq": True, "DeleteMatched": True}) == b">a 1\nACGT\n>b\nGG\n"
+    assert both(fa, False, {"Pattern": ["AC", "CG"], "BySeq": True, "DeleteMatched": True}) == b">a 1\nACGT\n>c\nACGA\n"
+    assert both(fa, False, {"Pattern": ["GG", "CC"], "BySeq": True, "DeleteMatched": True}) == b">b\nGG\n>A 3\nCC\n"
+    assert both(fa, False, {"Pattern": ["GG", "CC"], "BySeq": True, "DeleteMatched": True, "OnlyPositiveStrand": True}) == b">b\nGG\n>A 3\nCC\n"
+    assert both(fa, False, {"Pattern": ["^A", "G$", "T"], "UseRegexp": True, "BySeq": True, "DeleteMatched": True}) == \
+        b">a 1\nACGT\n>b\nGG\n>a 2\nTT\n"
+    assert both(fa, False, {"Pattern": ["ACN", "GGN"], "Degenerate": True, "DeleteMatched": True}) == b">a 1\nACGT\n"
+    # with -m the reference never drops a pattern (grepBySeqMismatches, grep.go:255-365): a plain grep -m
+    assert both(fa, False, {"Pattern": ["ACGT"], "MaxMismatch": 1, "DeleteMatched": True}) == b">a 1\nACGT\n>c\nACGA\n"
+    with pytest.raises(bsk.BskError) as e:
+        bsk.Grep(frame(fa, False), _Opts({"Pattern": ["A" * k for k in range(1, 18)], "BySeq": True, "DeleteMatched": True}))
+    assert "more than 15" in str(e.value)
+
+
+def test_grep_delete_matched_many_patterns_random(monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(77)
+    for trial in range(12):
+        recs = []
+        for i in range(300):
+            L = rng.randint(20, 60)
+            recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(L)), "I" * L))
+        data = "".join(recs).encode()
+        pats = ["".join(rng.choice("ACGT") for _ in range(rng.randint(3, 5))) for _ in range(rng.randint(2, 8))]
+        o = {"Pattern": pats, "BySeq": True, "DeleteMatched": True}
+        if trial % 3 == 1: o["OnlyPositiveStrand"] = True
+        if trial % 3 == 2: o["IgnoreCase"] = True
+        check_grep(data, True, o)
+        check_grep(data, True, {"Pattern": [p[:2] + "[AC]" + p[2:] for p in pats[:4]], "UseRegexp": True, "BySeq": True, "DeleteMatched": True})
