@@ -78,7 +78,14 @@ int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
     else if (f & ERR_LINE_LENGTHS) m = "different line length in sequence";  // the caller adds the ID
     else if (f & ERR_RECORD_TOO_LARGE) { code = BSK_ERR_UNSUPPORTED; m = "duplicate: the copies of one record exceed 4 GiB"; }
     else if (f & ERR_CAPACITY) { code = BSK_ERR_CAPACITY; m = "libbsk: internal table capacity exceeded"; }
-    else m = "unknown kernel error";
+    else if (f & ERR_HASH_COLLISION) {
+        code = BSK_ERR_UNSUPPORTED;
+        m = "libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)";
+    } else {
+        char hex[32];
+        snprintf(hex, sizeof hex, "0x%llx", (unsigned long long)f);
+        m = std::string("unknown kernel error (flags ") + hex + ")";
+    }
     c->set_error(m);
     return code;
 }
@@ -1874,13 +1881,53 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     const uint64_t N = c->table.n;
     uint64_t cap = 0;
     uint64_t* tk = nullptr;
-    rc = key_table(c, N, &cap, &tk, st);
-    if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
-    HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
+    // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
+    // overflows, or with 2^32 records) keeps the one big table in HBM
+    uint32_t* d_first = nullptr;
+    bool by_buckets = N < (1ull << 32);
+    {
+        const char* e = getenv("BSK_RMDUP");
+        if (e && strcmp(e, "table") == 0) by_buckets = false;
+    }
+    if (by_buckets) {
+        size_t tmp_bytes = 0;
+        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, 16, &tmp_bytes));
+        Arena A;
+        const uint64_t o_sk = A.take(N * 8), o_vi = A.take(N * 4), o_vo = A.take(N * 4), o_first = A.take(N * 4),
+                       o_bs = A.take((65536 + 2) * 4), o_tmp = A.take(tmp_bytes + 256);
+        rc = arena_reserve(c, &A);
+        if (rc != BSK_OK) return rc;
+        uint64_t* d_sk = A.at<uint64_t>(o_sk);
+        uint32_t* d_vi = A.at<uint32_t>(o_vi);
+        uint32_t* d_vo = A.at<uint32_t>(o_vo);
+        d_first = A.at<uint32_t>(o_first);
+        HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
+        HIP_TRYX(c, launch_sort_iota(d_first, N, st));
+        HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
+        HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st));
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (status & ERR_BUCKET_OVERFLOW) {
+            status &= ~(uint64_t)ERR_BUCKET_OVERFLOW;
+            HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            by_buckets = false;
+        } else {
+            HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
+        }
+    }
+    if (!by_buckets) {
+        rc = key_table(c, N, &cap, &tk, st);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+        HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
+    }
     uint64_t total = 0, kept = 0;
     rc = finish_sizes(c, st, &total, &kept);
     if (rc == BSK_OK) {
@@ -1917,7 +1964,9 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             if (hipMalloc((void**)&d_has, N) != hipSuccess || hipMalloc((void**)&d_row_len, N * 4) != hipSuccess ||
                 hipMalloc((void**)&d_row_off, (N + 1) * 8) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (hipMemsetAsync(d_has, 0, N, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
-            if (launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (by_buckets) {  // keys[i] := survivor of record i, has_dup[survivor] := 1, from first[] (d_out_len is scratch here)
+                if (launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, c->d_keys, c->d_out_len, c->d_status, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            } else if (launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (launch_rmdup_side_sizes(d_buf, c->table, P, c->d_keys, d_has, c->d_out_len, d_row_len, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
             if (launch_scan_u32(d_row_len, d_row_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }

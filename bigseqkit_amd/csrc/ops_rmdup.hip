@@ -453,6 +453,106 @@ __global__ __launch_bounds__(256) void k_rmdup_apply(RecordTable t, RmDupParams 
     out_len[i] = reply[p] ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
 }
 
+
+// ---------------------------------------------------------------------------
+// Grouping by radix buckets (the "radix-bucket pass" of the design): instead of one open-addressing table in HBM that
+// every record probes twice at random (insert 9.8 ms + resolve 8.1 ms per 79 M records: two 64-byte lines per record and
+// pass), the (key, record) pairs are first brought into 65 536 buckets by the top 16 bits of the key (two passes of the
+// device radix sort over bits 48..63; the pairs are 12 bytes per record, read and written in streams) and every bucket
+// -- ~1 200 pairs, a few tens of KB -- is then deduplicated by ONE block in LDS:
+//   k_bucket_starts : first position of every bucket in the sorted pairs (binary search; 65 537 threads)
+//   k_bucket_dedupe : LDS table of the bucket's DISTINCT keys (atomicCAS on the 64-bit key, atomicMin on the record
+//                     index), two sweeps over the bucket's pairs (insert, then look up); first[record] := the lowest
+//                     record index with the same key, written for duplicates only (the array is iota beforehand).
+//                     Duplicates cost no table slots, so a bucket overflows only when it holds more than BUCKET_SLOTS / 2
+//                     DISTINCT keys (never for hashed keys: mean 1 200, sigma 35) -- then ERR_BUCKET_OVERFLOW and the
+//                     host takes the table path.
+//   k_rmdup_resolve_first : a record survives iff first[i] == i; a duplicate is byte-compared with its survivor
+//                     (RmDupCheck's exact test, rmdup.go:193-199) as before.
+// ---------------------------------------------------------------------------
+constexpr uint32_t BUCKET_BITS = 16;
+constexpr uint32_t BUCKET_SLOTS = 4096;  // LDS slots per bucket table (48 KB: u64 key + u32 first)
+
+__global__ __launch_bounds__(256) void k_bucket_starts(const uint64_t* __restrict__ skeys, uint64_t n, uint32_t* __restrict__ bstart) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > (1u << BUCKET_BITS)) return;
+    // first position whose bucket is >= b
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint32_t)(skeys[mid] & ((1u << BUCKET_BITS) - 1u)) < b) lo = mid + 1; else hi = mid;
+    }
+    bstart[b] = (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(256) void k_bucket_dedupe(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ sidx,
+                                                       const uint32_t* __restrict__ bstart, uint32_t* __restrict__ first,
+                                                       uint64_t* __restrict__ status) {
+    __shared__ unsigned long long s_key[BUCKET_SLOTS];
+    __shared__ uint32_t s_first[BUCKET_SLOTS];
+    __shared__ uint32_t s_used;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lo = bstart[b], hi = bstart[b + 1];
+    if (hi - lo < 2u) return;  // (block-uniform) nothing to compare
+    for (uint32_t i = threadIdx.x; i < BUCKET_SLOTS; i += blockDim.x) { s_key[i] = 0ull; s_first[i] = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) s_used = 0;
+    __syncthreads();
+    constexpr uint32_t MASK = BUCKET_SLOTS - 1;
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+        const unsigned long long k = slot_key(skeys[p]);
+        const uint32_t idx = sidx[p];
+        uint32_t s = (uint32_t)(((k >> BUCKET_BITS) * 0x9E3779B97F4A7C15ull) >> 40) & MASK;  // (the low 16 bits are the bucket's)
+        for (uint32_t tries = 0;; ++tries) {
+            const unsigned long long old = atomicCAS(&s_key[s], 0ull, k);
+            if (old == 0ull) atomicAdd(&s_used, 1u);
+            if (old == 0ull || old == k) { atomicMin(&s_first[s], idx); break; }
+            s = (s + 1) & MASK;
+            if (tries >= BUCKET_SLOTS) break;  // table full: reported below
+        }
+    }
+    __syncthreads();
+    if (s_used > BUCKET_SLOTS / 2u) {  // (block-uniform) too many distinct keys for this table: the host takes the table path
+        if (threadIdx.x == 0) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_BUCKET_OVERFLOW);
+        return;
+    }
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+        const unsigned long long k = slot_key(skeys[p]);
+        const uint32_t idx = sidx[p];
+        uint32_t s = (uint32_t)(((k >> BUCKET_BITS) * 0x9E3779B97F4A7C15ull) >> 40) & MASK;
+        while (s_key[s] != k) s = (s + 1) & MASK;
+        const uint32_t f = s_first[s];
+        if (f != idx) first[idx] = f;
+    }
+}
+
+template <bool GROUP>
+__global__ __launch_bounds__(256) void k_rmdup_resolve_first(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
+                                                             RmDupParams P, const uint32_t* __restrict__ first_of,
+                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ out_len,
+                                                             uint64_t* __restrict__ status, uint8_t* __restrict__ has_dup) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint64_t first = first_of[i];
+    if (GROUP) {
+        keys[i] = first;
+        if (first != i) has_dup[first] = 1;
+    }
+    bool keep = first == i;
+    if (!keep) {
+        const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
+        bool same = a.len == b.len;
+        uint32_t q = 0;
+        for (; same && q + 8 <= a.len; q += 8) same = word64(a, q) == word64(b, q);  // 8 subject bytes per step
+        for (; same && q < a.len; ++q) same = a.at(q) == b.at(q);
+        if (!same) {  // distinct subjects under one 64-bit key: refuse rather than guess
+            atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
+            keep = true;
+        }
+    }
+    const uint32_t lh = t.l_head[i];
+    out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
 }  // namespace
 
 hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
@@ -546,6 +646,30 @@ hipError_t launch_rmdup_apply(const RecordTable& t, const RmDupParams& P, const 
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_rmdup_apply, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, t, P, send, reply, base,
                        out_len);
+    return hipGetLastError();
+}
+
+}  // namespace bsk
+
+namespace bsk {
+
+hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
+                                uint64_t* status, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint32_t nb = (1u << BUCKET_BITS);
+    hipLaunchKernelGGL(k_bucket_starts, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, skeys, n, bstart);
+    hipLaunchKernelGGL(k_bucket_dedupe, dim3(nb), dim3(256), 0, st, skeys, sidx, bstart, first, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_resolve_first(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                                      const uint32_t* first, uint64_t* keys_group, uint32_t* out_len, uint64_t* status,
+                                      uint8_t* has_dup, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    const dim3 gr((unsigned)((t.n + 255) / 256));
+    if (keys_group) hipLaunchKernelGGL(k_rmdup_resolve_first<true>, gr, dim3(256), 0, st, buf, t, d, P, first, keys_group, out_len, status, has_dup);
+    else hipLaunchKernelGGL(k_rmdup_resolve_first<false>, gr, dim3(256), 0, st, buf, t, d, P, first, (uint64_t*)nullptr, out_len, status, (uint8_t*)nullptr);
     return hipGetLastError();
 }
 

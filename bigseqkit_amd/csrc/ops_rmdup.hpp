@@ -19,6 +19,7 @@ struct RmDupParams {  // RmDupPrepare / RmDupCheck options (bigseqkit-lib/rmdup.
 };
 
 constexpr uint32_t ERR_HASH_COLLISION = 512u;
+constexpr uint32_t ERR_BUCKET_OVERFLOW = 1u << 21;  // a radix bucket with too many distinct keys for its LDS table
 
 // keys[i] = XXH64(subject i, seed 0); keys2 (may be null) = the same with another seed (multi-GPU verification key)
 hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
@@ -34,6 +35,16 @@ hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const 
 hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
                                       uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
                                       uint64_t* status, uint8_t* has_dup, hipStream_t st);
+
+// grouping by radix buckets: skeys / sidx = the (key, record) pairs sorted by the low 16 key bits (launch_sort_pairs_bits),
+// bstart: scratch [65 537]; first[] must hold iota and receives, for every duplicate, the lowest record with its key
+hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
+                                uint64_t* status, hipStream_t st);
+// out_len from first[] (a duplicate is byte-compared with its survivor); keys_group != null: also keys_group[i] := first[i]
+// and has_dup[first] := 1 (the -d / -D side outputs)
+hipError_t launch_rmdup_resolve_first(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,
+                                      const uint32_t* first, uint64_t* keys_group, uint32_t* out_len, uint64_t* status,
+                                      uint8_t* has_dup, hipStream_t st);
 
 // -d / -D side outputs: keys[i] := survivor index of record i; sizes of the removed records' text and of the
 // "<20-digit group>\t<ID>\n" rows of all members of groups of two or more; the rows themselves

@@ -224,6 +224,18 @@ hipError_t launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* kin, u
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, st);
 }
 
+hipError_t sort_pairs_bits_temp_bytes(uint64_t n, int begin_bit, int end_bit, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (size_t)n, begin_bit, end_bit, (hipStream_t)0);
+}
+
+hipError_t launch_sort_pairs_bits(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                                  uint32_t* vout, uint64_t n, int begin_bit, int end_bit, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, begin_bit, end_bit, st);
+}
+
 hipError_t launch_sort_gather(const uint32_t* out_len, const uint32_t* perm, uint64_t n, uint32_t* len_perm, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_sort_gather, grid_for(n), dim3(256), 0, st, out_len, perm, n, len_perm);

@@ -330,3 +330,23 @@ def test_translate_long_records_take_the_block_per_chunk_kernel(i, monkeypatch):
     o = dict(TR_OPTS[i], AllowUnknownCodon=True)
     got = bsk.Translate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)]), _Opts(o))
     assert got == oracle.translate(data, False, json.dumps(o)), o
+
+
+def test_rmdup_bucket_path_heavy_duplicates_and_table_cross_check(monkeypatch):
+    """the radix-bucket grouping (default) against the oracle and against the one-table path (BSK_RMDUP=table): one
+    sequence repeated 60 000 times (a single key: one bucket, one LDS slot), many small groups, and unique records"""
+    rng = random.Random(5)
+    recs = []
+    for i in range(60000):
+        recs.append("@same%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i)
+    pool = ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 40))) for _ in range(5000)]
+    for i in range(40000):
+        s = rng.choice(pool) if i % 2 else "".join(rng.choice("ACGT") for _ in range(50))
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    rng.shuffle(recs)
+    data = "".join(recs).encode()
+    want = oracle.rmdup(data, True, json.dumps({"BySeq": True}))
+    got = bsk.RmDup(frame(data, True), _Opts({"BySeq": True}))
+    assert got == want
+    monkeypatch.setenv("BSK_RMDUP", "table")
+    assert bsk.RmDup(frame(data, True), _Opts({"BySeq": True})) == want
