@@ -126,6 +126,12 @@ SIGNATURES = {
     "bsk_event_record": (_i, [_vp, _vp]),
     "bsk_event_elapsed_ms": (_i, [_vp, _vp, _p(C.c_float)]),
     "bsk_event_destroy": (_i, [_vp]),
+    "bsk_store_open": (_i, [C.c_char_p, _i, _p(_vp)]),
+    "bsk_store_error": (C.c_char_p, [_vp]),
+    "bsk_store_put": (_i, [_vp, _vp, _u64, _vp]),
+    "bsk_store_put_host": (_i, [_vp, _u64, _vp, _sz]),
+    "bsk_store_close": (_i, [_vp, _p(_u64)]),
+    "bsk_run_to_store": (_i, [_vp, _vp, _sz, _i, _i64, _vp, _u64, _p(_u64), _p(_u64)]),
     "bsk_profile_enable": (_i, [_vp, _i]),
     "bsk_profile_read": (_i, [_vp, C.c_char_p, _p(C.c_double), _p(_u64)]),
     "bsk_profile_reset": (_i, [_vp]),

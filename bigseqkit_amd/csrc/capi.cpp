@@ -217,6 +217,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_pat) hipFree(c->d_pat);
         if (c->d_ftab) hipFree(c->d_ftab);
         if (c->d_redo) hipFree(c->d_redo);
+        if (c->d_out_alt) hipFree(c->d_out_alt);
         if (c->d_cls) hipFree(c->d_cls);
         if (c->d_feat) hipFree(c->d_feat);
         if (c->d_regex) hipFree(c->d_regex);

@@ -62,6 +62,8 @@ struct bsk_ctx {
     uint64_t out_len_cap = 0;
     uint8_t* d_out = nullptr;           // output text of the last run
     uint64_t out_cap = 0;
+    uint8_t* d_out_alt = nullptr;       // second output buffer of bsk_run_to_store (drained while the next chunk computes)
+    uint64_t out_alt_cap = 0;
     uint8_t* d_lut = nullptr;           // 256-byte byte map (seq)
     double* d_qual_err = nullptr;       // 256 doubles (seq -Q/-R)
     uint64_t* d_counter = nullptr;      // scratch counter

@@ -1,0 +1,324 @@
+// ============================================================================
+// store.cpp -- FileStore / StoreFASTXN behind the C ABI, and the pipelined host path of the record operators.
+//
+// Reference: NewFileStore (/root/reference/bigseqkit-lib/helper.go:378-460) writes the elements of every partition,
+// joined by '\n', into ONE file in partition order -- an MPI token travels from executor to executor so that partition
+// k + 1 starts where k ended; StoreFASTXN (bigseqkit/helper.go:193-195) is SaveAsTextFile: one file per partition.
+// Here the order comes from a scan of sizes instead of a token: a part that arrives before its predecessors is kept
+// in host memory until they are written (single file), or simply owns its file (directory of parts).
+//
+// bsk_run_to_store is the file -> file path for a partition that sits in HOST memory (a file read into a pinned
+// buffer): record-aligned chunks of 256 MiB go through two device buffers,
+//     H2D(chunk i+1)  ||  kernels(chunk i)  ||  D2H(output of chunk i-1) + write,
+// on three streams, so that the PCIe copies in both directions hide behind each other and behind the kernels
+// (north_star: "async hipMemcpy double-buffers host file reads against kernel execution").  Operators whose result
+// depends on the whole partition (rmdup, sort, rename, range, grep -C / --delete-matched) run on the whole shard and
+// only their output is drained in chunks.
+// ============================================================================
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+#include <future>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bsk.h"
+#include "anchor.hpp"
+#include "ctx.hpp"
+#include "ops_host.hpp"
+
+using namespace bsk;
+
+struct bsk_store {
+    std::string path;
+    bool merge = true;
+    int fd = -1;               // single file
+    std::mutex mu;
+    uint64_t next = 0;         // the part whose bytes go to the file directly
+    uint64_t offset = 0;       // end of what has been written
+    struct Pending { std::vector<uint8_t> bytes; bool done = false; int fd = -1; };
+    std::map<uint64_t, Pending> parts;  // parts that are not `next` yet (single file) / open part files (directory)
+    uint64_t total = 0;
+    std::string err;
+};
+
+namespace {
+
+int store_fail(bsk_store* s, const std::string& m) {
+    if (s) s->err = m;
+    return BSK_ERR_INVALID_ARG;
+}
+
+bool write_all(int fd, const uint8_t* p, size_t n, uint64_t at) {
+    while (n) {
+        const ssize_t w = pwrite(fd, p, n, (off_t)at);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w; at += (uint64_t)w;
+    }
+    return true;
+}
+
+// bytes of part `part`; last: the part is complete
+int store_append(bsk_store* s, uint64_t part, const uint8_t* data, size_t n, bool last) {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!s->merge) {  // a file per partition (SaveAsTextFile)
+        auto& P = s->parts[part];
+        if (P.fd < 0) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "/part%05llu", (unsigned long long)part);
+            P.fd = open((s->path + nm).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (P.fd < 0) return store_fail(s, "libbsk: cannot create " + s->path + nm + ": " + strerror(errno));
+            P.bytes.clear();
+        }
+        const off_t cur = lseek(P.fd, 0, SEEK_END);
+        if (!write_all(P.fd, data, n, (uint64_t)cur)) return store_fail(s, "libbsk: write failed: " + std::string(strerror(errno)));
+        s->total += n;
+        if (last) { close(P.fd); s->parts.erase(part); }
+        return BSK_OK;
+    }
+    if (part < s->next) return store_fail(s, "libbsk: part " + std::to_string(part) + " was already completed");
+    if (part != s->next) {  // not its turn: keep the bytes
+        auto& P = s->parts[part];
+        P.bytes.insert(P.bytes.end(), data, data + n);
+        if (last) P.done = true;
+        return BSK_OK;
+    }
+    if (!write_all(s->fd, data, n, s->offset)) return store_fail(s, "libbsk: write failed: " + std::string(strerror(errno)));
+    s->offset += n;
+    s->total += n;
+    if (!last) return BSK_OK;
+    // the next parts that are already here
+    for (;;) {
+        ++s->next;
+        auto it = s->parts.find(s->next);
+        if (it == s->parts.end()) break;
+        auto& P = it->second;
+        if (!P.bytes.empty()) {
+            if (!write_all(s->fd, P.bytes.data(), P.bytes.size(), s->offset)) return store_fail(s, "libbsk: write failed: " + std::string(strerror(errno)));
+            s->offset += P.bytes.size();
+            s->total += P.bytes.size();
+        }
+        const bool done = P.done;
+        s->parts.erase(it);
+        if (!done) break;  // that part is still being produced: it now writes directly
+    }
+    return BSK_OK;
+}
+
+int hip_fail(bsk_ctx* c, hipError_t e, const char* what) {
+    c->set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return BSK_ERR_HIP;
+}
+#define ST_TRY(c, expr)                                        \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return hip_fail(c, e__, #expr); \
+    } while (0)
+
+typedef int (*dev_fn)(bsk_ctx*, const uint8_t*, size_t, int, hipStream_t, bsk_out*);
+dev_fn fn_of(const bsk_ctx* c, bool* chunkable) {
+    *chunkable = false;
+    switch (c->op) {
+        case Op::Seq: *chunkable = true; return seq_run_device;
+        case Op::Grep: *chunkable = !c->opts.b("Count") && !(c->opts.b("DeleteMatched") && !c->opts.b("InvertMatch")); return grep_run_device;
+        case Op::Locate: *chunkable = true; return locate_run_device;
+        case Op::Subseq: *chunkable = true; return subseq_run_device;
+        case Op::Translate: *chunkable = true; return translate_run_device;
+        case Op::Fq2Fa: *chunkable = true; return fq2fa_run_device;
+        case Op::RmDup: return rmdup_run_device;
+        case Op::Rename: return rename_run_device;
+        case Op::Sort: return sort_run_device;
+        case Op::Duplicate: *chunkable = true; return records_run_device;
+        default: return nullptr;
+    }
+}
+
+// device bytes -> store, through the context's two pinned buffers: the copy of piece k+1 runs while piece k is written
+int drain_to_store(bsk_ctx* c, bsk_store* s, uint64_t part, const uint8_t* d, size_t n, bool last, hipStream_t d2h) {
+    const size_t PIECE = (size_t)64 << 20;
+    ST_TRY(c, hipSetDevice(c->device));  // (also called from the writer thread of bsk_run_to_store)
+    for (int b = 0; b < 2; ++b)
+        if (!c->pinned[b]) {
+            ST_TRY(c, hipHostMalloc((void**)&c->pinned[b], PIECE, hipHostMallocDefault));
+            if (!c->stage_done[b]) ST_TRY(c, hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming));
+        }
+    if (n == 0) return last ? store_append(s, part, nullptr, 0, true) : BSK_OK;
+    const size_t npieces = (n + PIECE - 1) / PIECE;
+    hipEvent_t ev[2];
+    for (int b = 0; b < 2; ++b) ST_TRY(c, hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    auto piece_len = [&](size_t k) { return std::min(PIECE, n - k * PIECE); };
+    ST_TRY(c, hipMemcpyAsync(c->pinned[0], d, piece_len(0), hipMemcpyDeviceToHost, d2h));
+    ST_TRY(c, hipEventRecord(ev[0], d2h));
+    int rc = BSK_OK;
+    for (size_t k = 0; k < npieces && rc == BSK_OK; ++k) {
+        const int b = (int)(k & 1);
+        if (k + 1 < npieces) {
+            ST_TRY(c, hipMemcpyAsync(c->pinned[1 - b], d + (k + 1) * PIECE, piece_len(k + 1), hipMemcpyDeviceToHost, d2h));
+            ST_TRY(c, hipEventRecord(ev[1 - b], d2h));
+        }
+        ST_TRY(c, hipEventSynchronize(ev[b]));
+        rc = store_append(s, part, c->pinned[b], piece_len(k), last && k + 1 == npieces);
+        if (rc != BSK_OK) c->set_error(s->err);
+    }
+    for (int b = 0; b < 2; ++b) hipEventDestroy(ev[b]);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsk_store_open(const char* path, int merge, bsk_store** out) {
+    if (!path || !out) return BSK_ERR_INVALID_ARG;
+    bsk_store* s = new bsk_store;
+    s->path = path;
+    s->merge = merge != 0;
+    if (s->merge) {
+        s->fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (s->fd < 0) { delete s; return BSK_ERR_INVALID_ARG; }
+    } else {
+        struct stat sb;
+        if (!(stat(path, &sb) == 0 && S_ISDIR(sb.st_mode)) && mkdir(path, 0755) != 0) { delete s; return BSK_ERR_INVALID_ARG; }
+    }
+    *out = s;
+    return BSK_OK;
+}
+
+const char* bsk_store_error(const bsk_store* s) { return s ? s->err.c_str() : ""; }
+
+int bsk_store_put_host(bsk_store* s, uint64_t part, const void* data, size_t n) {
+    if (!s || (n && !data)) return BSK_ERR_INVALID_ARG;
+    return store_append(s, part, (const uint8_t*)data, n, true);
+}
+
+int bsk_store_put(bsk_store* s, bsk_ctx* c, uint64_t part, const bsk_out* o) {
+    if (!s || !c || !o) return BSK_ERR_INVALID_ARG;
+    if (c->device < 0) { c->set_error("libbsk: context was created without a device"); return BSK_ERR_NO_DEVICE; }
+    ST_TRY(c, hipSetDevice(c->device));
+    ST_TRY(c, hipDeviceSynchronize());
+    if (!c->copy_stream[1]) ST_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking));
+    return drain_to_store(c, s, part, (const uint8_t*)o->d_data, o->len, true, c->copy_stream[1]);
+}
+
+int bsk_store_close(bsk_store* s, uint64_t* total_bytes) {
+    if (!s) return BSK_ERR_INVALID_ARG;
+    int rc = BSK_OK;
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        if (s->merge) {
+            // parts that never became `next` (a gap in the part numbers): written in part order all the same
+            for (auto& kv : s->parts) {
+                if (!kv.second.bytes.empty()) {
+                    if (!write_all(s->fd, kv.second.bytes.data(), kv.second.bytes.size(), s->offset)) rc = BSK_ERR_INVALID_ARG;
+                    s->offset += kv.second.bytes.size();
+                    s->total += kv.second.bytes.size();
+                }
+            }
+            if (s->fd >= 0) close(s->fd);
+        } else {
+            for (auto& kv : s->parts) if (kv.second.fd >= 0) close(kv.second.fd);
+        }
+        if (total_bytes) *total_bytes = s->total;
+    }
+    delete s;
+    return rc;
+}
+
+int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, int64_t pid, bsk_store* s, uint64_t part,
+                     uint64_t* out_bytes, uint64_t* out_records) {
+    if (!c || !s) return BSK_ERR_INVALID_ARG;
+    if (c->device < 0) { c->set_error("libbsk: context was created without a device"); return BSK_ERR_NO_DEVICE; }
+    if (format != BSK_FORMAT_FASTA && format != BSK_FORMAT_FASTQ) { c->set_error("libbsk: bad format"); return BSK_ERR_INVALID_ARG; }
+    if (n && !host_shard) { c->set_error("libbsk: null shard"); return BSK_ERR_INVALID_ARG; }
+    bool chunkable = false;
+    dev_fn fn = fn_of(c, &chunkable);
+    if (!fn) { c->set_error("libbsk: bsk_run_to_store: operator without a single-shard record output"); return BSK_ERR_INVALID_ARG; }
+    ST_TRY(c, hipSetDevice(c->device));
+    for (int b = 0; b < 2; ++b)
+        if (!c->copy_stream[b]) ST_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[b], hipStreamNonBlocking));
+    if (!c->own_stream) ST_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    hipStream_t st = c->own_stream, h2d = c->copy_stream[0], d2h = c->copy_stream[1];
+    hipEvent_t in_done[2] = {nullptr, nullptr}, in_free[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; ++b) {
+        ST_TRY(c, hipEventCreateWithFlags(&in_done[b], hipEventDisableTiming));
+        ST_TRY(c, hipEventCreateWithFlags(&in_free[b], hipEventDisableTiming));
+    }
+    const char* env = getenv("BSK_STAGE_BYTES");
+    const size_t want = env && strtoull(env, nullptr, 10) ? (size_t)strtoull(env, nullptr, 10) : ((size_t)256 << 20);
+    const size_t chunk = chunkable ? want : n;
+    const uint8_t* h = (const uint8_t*)host_shard;
+    // cut points: record starts (a chunk holds whole records)
+    std::vector<size_t> cuts{0};
+    while (cuts.back() < n) {
+        size_t lo = cuts.back(), hi = n;
+        if (n - lo > chunk) {
+            hi = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_start(h, n, lo + chunk) : (size_t)find_fasta_start(h, n, lo + chunk);
+            if (hi <= lo || hi > n) hi = n;
+        }
+        cuts.push_back(hi);
+    }
+    const size_t nchunks = cuts.size() - 1;
+    uint64_t bytes = 0, records = 0;
+    auto stage_in = [&](size_t i) -> int {  // H2D of chunk i into input buffer i & 1
+        const int b = (int)(i & 1);
+        const size_t len = cuts[i + 1] - cuts[i];
+        if (len > c->stage_cap_b[b] || !c->d_stage[b]) {
+            ST_TRY(c, hipStreamSynchronize(st));
+            if (c->d_stage[b]) ST_TRY(c, hipFree(c->d_stage[b]));
+            c->d_stage[b] = nullptr;
+            ST_TRY(c, hipMalloc((void**)&c->d_stage[b], len + len / 16 + 4096));
+            c->stage_cap_b[b] = len + len / 16;
+        }
+        if (i >= 2) ST_TRY(c, hipStreamWaitEvent(h2d, in_free[b], 0));
+        ST_TRY(c, hipMemcpyAsync(c->d_stage[b], h + cuts[i], len, hipMemcpyHostToDevice, h2d));
+        ST_TRY(c, hipEventRecord(in_done[b], h2d));
+        return BSK_OK;
+    };
+    int rc = BSK_OK;
+    if (nchunks == 0) rc = store_append(s, part, nullptr, 0, true);
+    else rc = stage_in(0);
+    // the output of chunk i is drained (D2H + write, on a writer thread) while chunk i+1 computes: two output buffers,
+    // swapped with the context's; the drain of chunk i must be over before chunk i+2 reuses its buffer, and before the
+    // drain of chunk i+1 starts (the bytes of a part are appended in order)
+    uint8_t* alt_out = c->d_out_alt;
+    uint64_t alt_cap = c->out_alt_cap;
+    std::future<int> writer;
+    for (size_t i = 0; i < nchunks && rc == BSK_OK; ++i) {
+        const int b = (int)(i & 1);
+        if (i + 1 < nchunks) { rc = stage_in(i + 1); if (rc != BSK_OK) break; }
+        ST_TRY(c, hipStreamWaitEvent(st, in_done[b], 0));
+        ST_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+        c->cur_pid = (pid == 0 && i == 0) ? 0 : (pid == 0 ? 1 : pid);  // locate: the header row belongs to the first chunk of partition 0
+        std::swap(c->d_out, alt_out);
+        std::swap(c->out_cap, alt_cap);
+        bsk_out o;
+        memset(&o, 0, sizeof o);
+        rc = fn(c, c->d_stage[b], cuts[i + 1] - cuts[i], format, st, &o);
+        if (rc != BSK_OK) break;
+        ST_TRY(c, hipStreamSynchronize(st));  // the output is complete (the run functions end with launches in flight)
+        ST_TRY(c, hipEventRecord(in_free[b], st));
+        if (writer.valid()) { rc = writer.get(); if (rc != BSK_OK) break; }
+        const uint8_t* od = (const uint8_t*)o.d_data;
+        const size_t ol = o.len;
+        const bool last = i + 1 == nchunks;
+        writer = std::async(std::launch::async, [=]() { return drain_to_store(c, s, part, od, ol, last, d2h); });
+        bytes += o.len;
+        records += o.records;
+    }
+    if (writer.valid()) { const int wrc = writer.get(); if (rc == BSK_OK) rc = wrc; }
+    // hand the spare output buffer back to the context
+    c->d_out_alt = alt_out;
+    c->out_alt_cap = alt_cap;
+    for (int b = 0; b < 2; ++b) { hipEventDestroy(in_done[b]); hipEventDestroy(in_free[b]); }
+    if (out_bytes) *out_bytes = bytes;
+    if (out_records) *out_records = records;
+    return rc;
+}
+
+}  // extern "C"

@@ -304,6 +304,27 @@ int bsk_rmdup_dist_resolve(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void*
 int bsk_rmdup_dist_emit(bsk_ctx* ctx, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
                         bsk_out* out);
 
+/* ---- FileStore / StoreFASTXN  (bigseqkit-lib/helper.go:378-460 NewFileStore; bigseqkit/helper.go:186-195 StoreFASTX[N]) ----
+ * merge != 0: ONE file at `path`, the parts (partitions) in the order of their numbers whatever the order of the calls --
+ * the reference passes an MPI token from executor to executor (helper.go:418-436), here a part that comes before its
+ * turn waits in host memory.  merge == 0: directory `path` with one file part%05d per partition (SaveAsTextFile).
+ * Parts must be numbered 0, 1, 2, ... without gaps for the single file to grow while the parts arrive. */
+typedef struct bsk_store bsk_store;
+int bsk_store_open(const char* path, int merge, bsk_store** out);
+const char* bsk_store_error(const bsk_store* s);
+/* the output of an operator call (device memory of `ctx`), copied to the host in 64 MiB pieces through two pinned
+ * buffers -- the copy of a piece runs while the piece before it is written */
+int bsk_store_put(bsk_store* s, bsk_ctx* ctx, uint64_t part, const bsk_out* out);
+int bsk_store_put_host(bsk_store* s, uint64_t part, const void* data, size_t n);
+int bsk_store_close(bsk_store* s, uint64_t* total_bytes); /* also frees s */
+/* Call(partition) + FileStore for a partition in HOST memory (best: pinned, bsk_host_alloc): record-aligned chunks of
+ * 256 MiB (BSK_STAGE_BYTES) through two device buffers -- H2D of chunk i+1, the kernels of chunk i, and D2H + write of
+ * the output of chunk i-1 overlap (three streams and a writer thread).  seq, grep, locate, subseq, translate, fq2fa,
+ * duplicate are chunked; rmdup, rename, sort, grep -C / --delete-matched see the whole partition (their output is still
+ * drained in pieces).  out_bytes / out_records may be NULL. */
+int bsk_run_to_store(bsk_ctx* ctx, const void* host_shard, size_t n, int format, int64_t pid, bsk_store* s, uint64_t part,
+                     uint64_t* out_bytes, uint64_t* out_records);
+
 /* ---- synthetic inputs (bench + tests only) --------
  * Deterministic, counter-based: byte k of record i depends on (seed, i, k)
  * only, so any shard can be produced on the host or directly in HBM. */
