@@ -126,6 +126,7 @@ SIGNATURES = {
     "bsk_event_record": (_i, [_vp, _vp]),
     "bsk_event_elapsed_ms": (_i, [_vp, _vp, _p(C.c_float)]),
     "bsk_event_destroy": (_i, [_vp]),
+    "bsk_selftest_regex_find": (_i, [C.c_char_p, C.c_char_p, _sz, _sz, _p(C.c_uint32), _p(C.c_uint32)]),
     "bsk_store_open": (_i, [C.c_char_p, _i, _p(_vp)]),
     "bsk_store_error": (C.c_char_p, [_vp]),
     "bsk_store_put": (_i, [_vp, _vp, _u64, _vp]),

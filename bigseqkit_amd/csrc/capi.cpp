@@ -14,6 +14,7 @@
 #include "ops_host.hpp"
 #include "stats_host.hpp"
 #include "stream_stats.hpp"
+#include "regex_vm.hpp"
 #include "synth.hpp"
 
 namespace bsk {
@@ -218,6 +219,9 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_ftab) hipFree(c->d_ftab);
         if (c->d_redo) hipFree(c->d_redo);
         if (c->d_out_alt) hipFree(c->d_out_alt);
+        if (c->d_id_prog) hipFree(c->d_id_prog);
+        if (c->d_id_off) hipFree(c->d_id_off);
+        if (c->d_id_len) hipFree(c->d_id_len);
         if (c->d_cls) hipFree(c->d_cls);
         if (c->d_feat) hipFree(c->d_feat);
         if (c->d_regex) hipFree(c->d_regex);
@@ -1053,6 +1057,19 @@ int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64) {
     hipFree(d_in);
     hipFree(d_out);
     return BSK_OK;
+}
+
+// self-test of the position-reporting matcher (regex_vm.hpp) on the host: 1 match (caps filled), 0 no match, -1 the
+// expression was rejected (message in bsk_global_error)
+int bsk_selftest_regex_find(const char* expr, const uint8_t* text, size_t n, size_t from, uint32_t* caps4, uint32_t* ngroups) {
+    try {
+        const VmProgram P = compile_vm(expr ? expr : "");
+        if (ngroups) *ngroups = P.ngroups;
+        return vm_search(P, text, (uint32_t)n, (uint32_t)from, caps4) ? 1 : 0;
+    } catch (const std::exception& e) {
+        fail_global(BSK_ERR_OPTS, e.what());
+        return -1;
+    }
 }
 
 }  // extern "C"

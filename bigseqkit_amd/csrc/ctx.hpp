@@ -15,6 +15,7 @@
 #include "index.hpp"
 #include "opts.hpp"
 #include "regex_nfa.hpp"
+#include "regex_vm.hpp"
 
 struct bsk_ctx {
     bsk::Op op;
@@ -49,6 +50,14 @@ struct bsk_ctx {
 
     // ---- record table + per-record scratch (seq, grep, ...) ---------------------
     bsk::RecordTable table;          // ctx-owned arrays, grown on demand
+    // custom --id-regexp (neither the default nor the --id-ncbi one): program of the position-reporting matcher and
+    // the per-record ID spans of the last indexed shard (ops_idre.hip)
+    bool id_custom = false;
+    bsk::VmProgram id_prog;
+    bsk::VmProgram* d_id_prog = nullptr;
+    uint32_t* d_id_off = nullptr;
+    uint32_t* d_id_len = nullptr;
+    uint64_t id_cap = 0;
     uint64_t avg_record_bytes = 0;   // bytes per record in the head of the last indexed shard (0: unknown)
     bsk::RecordTable sparse;         // one-pass index: per-range slices, compacted into `table`
     uint64_t* d_range_count = nullptr;  // [cap_ranges]

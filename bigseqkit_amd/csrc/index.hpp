@@ -24,6 +24,9 @@ struct RecordTable {
     // FASTA only (written by the index pass): 0 = the sequence is one line (or empty), W = every line but the last has
     // W >= 16 bases and the last 1..W (base i sits at i + i / W), 0xFFFFFFFF = irregular wrapping (text.cuh)
     uint32_t* text_w = nullptr;
+    // custom --id-regexp only (else null): ID of record i = header bytes [1 + id_off[i], + id_len[i])
+    const uint32_t* id_off = nullptr;
+    const uint32_t* id_len = nullptr;
     uint64_t n = 0;
     uint64_t cap = 0;
 };
@@ -64,5 +67,10 @@ hipError_t launch_index_stitch(const RecordTable& dense, const RangePart* parts,
                                const uint64_t* range_base, uint32_t nranges, uint64_t* status, hipStream_t st);
 hipError_t launch_index_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
                                 const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, hipStream_t st);
+
+struct VmProgram;
+// custom --id-regexp: id_off / id_len of every record of the table (ops_idre.hip)
+hipError_t launch_id_spans(const uint8_t* buf, const RecordTable& t, const VmProgram* d_prog, uint32_t* id_off, uint32_t* id_len,
+                           hipStream_t st);
 
 }  // namespace bsk

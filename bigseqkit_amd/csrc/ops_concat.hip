@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_concat_size(const uint8_t* __restrict__
             if (P.full) { bytes = element_bytes(hl, t.l_seq[i], P); cnt = 1; }   // kept as it is (concat.go:112-127)
         } else {
             uint32_t off;
-            const uint32_t il = id_span_of(h, hl, P.id_mode, &off, P.buf_end);    // Name: recordA.ID (:133)
+            const uint32_t il = id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);    // Name: recordA.ID (:133)
             for (uint32_t k = 0; k < m2; ++k) {
                 const uint32_t b = mate_of(sorted, s, m1, m2raw, k);
                 bytes += element_bytes(il, (uint64_t)t.l_seq[i] + t.l_seq[b], P);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_concat_emit(const uint8_t* __restrict__
     const uint8_t* qa = P.fastq ? qual_of(buf, t, i) : nullptr;
     if (i < P.first2 && m2 > 0) {
         uint32_t off;
-        const uint32_t il = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
+        const uint32_t il = id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);
         for (uint32_t k = 0; k < m2; ++k) {
             const uint64_t b = mate_of(sorted, s, m1, m2raw, k);
             const Text TB = text_of(buf, t, tt, b);

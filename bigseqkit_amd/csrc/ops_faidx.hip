@@ -31,7 +31,7 @@ __device__ __forceinline__ Row row_of(const uint8_t* __restrict__ buf, const Rec
     const uint32_t lh = t.l_head[i];
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
     uint32_t off = 0;
-    r.name_len = P.full_head ? hl : id_span_of(h, hl, P.id_mode, &off, P.buf_end);  // parseHeadID, faidx.go:434-450
+    r.name_len = P.full_head ? hl : id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);  // parseHeadID, faidx.go:434-450
     r.name = h + off;
     r.length = t.l_seq[i];
     r.offset = P.base_offset + t.start[i] + lh + 1;

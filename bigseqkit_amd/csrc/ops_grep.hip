@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_grep_regex(const uint8_t* __restrict__ 
         }
     } else {
         uint32_t off = 0, tl = hl;
-        if (!P.by_name) tl = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
+        if (!P.by_name) tl = id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);
         for (int k = 0; k < P.npat && !hit; ++k) {
             const RegexProgram& p = P.regex[k];
             if (p.nullable) { hit = true; break; }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ b
     const uint8_t* h = buf + s + 1;
     uint32_t hl = lh > 0 ? lh - 1 : 0, off = 0;
     uint32_t tl = hl;
-    if (!P.by_name) tl = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
+    if (!P.by_name) tl = id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);
     bool hit = false;
     if (P.set_keys) {  // pattern set: probe by hash, verify by bytes (patterns[k] is a map key in the reference, grep.go:501-511)
         const uint64_t key = fnv1a64(h + off, tl, P.ignore_case);

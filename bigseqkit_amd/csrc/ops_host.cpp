@@ -248,6 +248,30 @@ int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     if (D.parts) HIP_TRYX(c, launch_index_stitch(c->table, c->d_parts, c->d_range_count, c->d_range_base, nranges, c->d_status, st));
     // start[n] = effective end of the shard (anchors[nranges])
     HIP_TRYX(c, hipMemcpyAsync(c->table.start + total, anchors + nranges, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    return id_spans(c, d_buf, st);
+}
+
+// custom --id-regexp: the ID span of every record of the new table, once per shard (ops_idre.hip)
+int id_spans(bsk_ctx* c, const uint8_t* d_buf, hipStream_t st) {
+    c->table.id_off = nullptr;
+    c->table.id_len = nullptr;
+    if (!c->id_custom || c->table.n == 0) return BSK_OK;
+    if (!c->d_id_prog) {
+        HIP_TRYX(c, hipMalloc((void**)&c->d_id_prog, sizeof(VmProgram)));
+        HIP_TRYX(c, hipMemcpy(c->d_id_prog, &c->id_prog, sizeof(VmProgram), hipMemcpyHostToDevice));
+    }
+    if (c->table.n > c->id_cap || !c->d_id_off) {
+        if (c->d_id_off) HIP_TRYX(c, hipFree(c->d_id_off));
+        if (c->d_id_len) HIP_TRYX(c, hipFree(c->d_id_len));
+        c->d_id_off = c->d_id_len = nullptr;
+        const uint64_t cap = c->table.n + c->table.n / 8 + 16;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_id_off, cap * 4));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_id_len, cap * 4));
+        c->id_cap = cap;
+    }
+    HIP_TRYX(c, launch_id_spans(d_buf, c->table, c->d_id_prog, c->d_id_off, c->d_id_len, st));
+    c->table.id_off = c->d_id_off;
+    c->table.id_len = c->d_id_len;
     return BSK_OK;
 }
 
@@ -283,9 +307,7 @@ void validate_seq_opts(bsk_ctx* c) {  // SeqTransform.Before, seq.go:28-79
         throw OptError("value of flag -Q (--min-qual) should be <= value of flag -R (--max-qual)");
     if (o.b("LowerCase") && o.b("UpperCase"))
         throw OptError("could not give both flags -l (--lower-case) and -u (--upper-case)");
-    const std::string& re = o.cs("IDRegexp");
-    if (!(re.empty() || re == "^(\\S+)\\s?" || re == "\\|([^\\|]+)\\| "))
-        throw OptError("libbsk: --id-regexp other than the default and the --id-ncbi one is not supported by the HIP path");
+    check_id_regexp(c);
 }
 
 // sequence bytes of the first record of a shard head (type guess, helper.go:286-291)
@@ -401,7 +423,7 @@ SeqParams format_params(bsk_ctx* c, bool fastq) {
     P.print_seq = 1;
     P.print_qual = fastq;
     P.line_width = fastq ? 0 : (int)c->opts.ci("LineWidth");
-    P.id_mode = c->opts.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     return P;
 }
 
@@ -434,10 +456,31 @@ static void parse_region_opt(const std::string& region, const char* cmd, int* st
     *end = (int)sb;
 }
 
-void check_id_regexp(const Options& o) {
-    const std::string& re = o.cs("IDRegexp");
-    if (!(re.empty() || re == "^(\\S+)\\s?" || re == "\\|([^\\|]+)\\| "))
-        throw OptError("libbsk: --id-regexp other than the default and the --id-ncbi one is not supported by the HIP path");
+// --id-regexp (bigseqkit-lib/helper.go:179-198): the default and the --id-ncbi expression have their own code; any other
+// expression is compiled for the position-reporting matcher (regex_vm.hpp) and its spans are computed per shard
+void check_id_regexp(bsk_ctx* c) {
+    const std::string& re = c->opts.cs("IDRegexp");
+    c->id_custom = false;
+    if (re.empty() || re == "^(\\S+)\\s?" || re == "\\|([^\\|]+)\\| ") return;
+    // reCheckIDregexpStr = `\(.+\)` (helper.go:156)
+    const size_t a = re.find('(');
+    const size_t b = re.rfind(')');
+    if (a == std::string::npos || b == std::string::npos || b < a + 2)
+        throw OptError("fastx: regular expression must contain \"(\" and \")\" to capture matched ID. default: ^(\\S+)\\s?");
+    try {
+        c->id_prog = compile_vm(re);
+    } catch (const OptError& e) {
+        if (std::string(e.what()).rfind("libbsk:", 0) == 0) throw;  // syntax this matcher does not take: say so
+        throw OptError("fastx: fail to compile regexp: " + re);
+    }
+    if (c->id_prog.ngroups == 0)
+        throw OptError("fastx: regular expression must contain \"(\" and \")\" to capture matched ID. default: ^(\\S+)\\s?");
+    c->id_custom = true;
+}
+
+int id_mode_of(const bsk_ctx* c) {  // 0 default regexp, 1 --id-ncbi, 2 custom (spans in the record table; no description)
+    if (c->id_custom) return 2;
+    return c->opts.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -571,7 +614,7 @@ static std::vector<std::pair<std::string, std::string>> read_pattern_fasta(const
 void validate_grep_opts(bsk_ctx* c) {
     Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     bool any = !o.s("PatternFile").empty();
     for (auto& p : o.sl("Pattern")) if (!p.empty()) any = true;
     // PARITY.md Q17: the default Pattern [""] must not defeat this guard (grep.go:53)
@@ -799,7 +842,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         // grep.go:404-409: protein / unlimit sequences are searched on the '+' strand only
         const bool only_pos = o.b("OnlyPositiveStrand") || ab == AB_UNLIMIT || ab == AB_PROTEIN;
         G.both_strands = G.by_seq && !only_pos;
-        G.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+        G.id_mode = id_mode_of(c);
         G.line_width = fastq ? 0 : (int)o.ci("LineWidth");
         G.npat = (int)c->patterns.size();
         rc = prepare_text(c, d_buf, format, st, &tt);  // uses d_out_len as scratch: before the match kernel
@@ -1016,7 +1059,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
 void validate_locate_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     bool any = !o.s("PatternFile").empty();
     for (auto& p : o.sl("Pattern")) if (!p.empty()) any = true;
     if (!any) throw OptError("one of flags -p (--pattern) and -f (--pattern-file) needed");  // PARITY.md Q17
@@ -1145,7 +1188,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             P.non_greedy = 0;  // "flag -G (--non-greedy) ignored when giving flag -m" (locate.go:67-69)
         }
         P.format = o.b("Gtf") ? 2 : (o.b("Bed") ? 3 : (o.b("HideMatched") ? 1 : 0));
-        P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+        P.id_mode = id_mode_of(c);
         P.npat = (int)c->patterns.size();
         std::vector<std::string> all = c->patterns;
         for (auto& p : c->patterns) all.push_back(revcom_pattern(p, ab));
@@ -1391,7 +1434,7 @@ static void load_features(bsk_ctx* c) {
 void validate_subseq_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     if (o.b("OnlyFlank")) {
         if (o.i("UpStream") > 0 && o.i("DownStream") > 0)
             throw OptError("when flag -f (--only-flank) given, only one of flags -u (--up-stream) and -d (--down-stream) is allowed");
@@ -1611,7 +1654,7 @@ static const GeneticCode* find_code(int id) {
 void validate_translate_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     if (!find_code((int)o.i("TranslTable"))) throw OptError("invalid translate table: " + std::to_string(o.i("TranslTable")));
     c->frames.clear();
     for (auto& f : o.sl("Frame")) {
@@ -1707,7 +1750,7 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     P.trim = o.b("Trim"); P.clean = o.b("Clean"); P.allow_unknown = o.b("AllowUnknownCodon");
     P.init_m = o.b("InitCodonAsM"); P.append_frame = o.b("AppendFrame");
     P.line_width = (int)o.ci("LineWidth");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 6 * 4096 + 256));
     {
         std::vector<uint8_t> tab(6 * 4096 + 256);
@@ -1820,7 +1863,7 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
 void validate_rmdup_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     if (o.b("BySeq") && o.b("ByName"))  // bigseqkit/rmdup.go:79-81
         throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
     if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :83-85
@@ -1875,7 +1918,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     P.by_seq = o.b("BySeq");
     P.by_name = o.b("ByName");
     P.ignore_case = o.b("IgnoreCase");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
@@ -2029,7 +2072,7 @@ static RmDupParams rmdup_params(bsk_ctx* c, bool fastq) {
     P.by_seq = o.b("BySeq");
     P.by_name = o.b("ByName");
     P.ignore_case = o.b("IgnoreCase");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = c->dist_buf ? c->dist_buf + c->dist_n : nullptr;
     return P;
@@ -2159,7 +2202,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     P.qual_only = o.b("Qual");
     P.only_id = o.b("OnlyId");
     P.buf_end = d_buf + n;
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.reverse = o.b("Reverse");
     P.remove_gaps = o.b("RemoveGaps");
     set_bits(P.gap_set, o.s("GapLetters"));

@@ -62,7 +62,9 @@ int empty_result(bsk_ctx* c, bsk_out* out);
 // SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
 SeqParams format_params(bsk_ctx* c, bool fastq);
 void set_bits(uint32_t* set, const std::string& letters);
-void check_id_regexp(const Options& o);
+void check_id_regexp(bsk_ctx* c);
+int id_mode_of(const bsk_ctx* c);
+int id_spans(bsk_ctx* c, const uint8_t* d_buf, hipStream_t st);
 // the context's feature set (ctx.features) uploaded and bound to P: name lookup, regions, suffixes, complement map
 int bind_features(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, SeqParams* P);
 // lines of a text file ("\r\n" trimmed, empty lines skipped): pattern files, region files

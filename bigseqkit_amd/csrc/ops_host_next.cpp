@@ -61,7 +61,7 @@ static int64_t go_parse_int(const std::string& s) {
 void validate_records_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (c->op == Op::Fq2Fa || c->op == Op::Rename || c->op == Op::Pair || c->op == Op::Concat) { check_id_regexp(o); return; }
+    if (c->op == Op::Fq2Fa || c->op == Op::Rename || c->op == Op::Pair || c->op == Op::Concat) { check_id_regexp(c); return; }
     if (c->op == Op::Duplicate) {
         // make([]string, times) panics for a negative count; zero copies is an empty result
         if (o.i("Times") < 0) throw OptError("value of -n (--times) should not be negative");
@@ -212,7 +212,7 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     memset(&P, 0, sizeof P);
     P.fastq = fastq;
     P.by_name = o.b("ByName");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
@@ -309,7 +309,7 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
 void validate_sort_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     int k = 0;  // sort.go:105-119 (ByBases implies ByLength)
     if (o.b("BySeq")) ++k;
     if (o.b("ByName")) ++k;
@@ -334,7 +334,7 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     P.fastq = fastq;
     P.mode = o.b("ByBases") ? 4 : o.b("ByLength") ? 3 : o.b("BySeq") ? 2 : o.b("ByName") ? 1 : 0;
     P.ignore_case = o.b("IgnoreCase");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.prefix_len = (uint32_t)std::min<int64_t>(o.i("SeqPrefixLength"), 0xFFFFFFFFll);
     set_bits(P.gap_set, o.s("GapLetters"));
     P.buf_end = d_buf + n;
@@ -464,7 +464,7 @@ static void parse_faidx_region(const std::string& region, std::string* id, long 
 void validate_faidx_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    if (!o.b("FullHead")) check_id_regexp(o);  // -f swaps the ID regexp for ^(.+)$ (faidx.go:69-73)
+    if (!o.b("FullHead")) check_id_regexp(c);  // -f swaps the ID regexp for ^(.+)$ (faidx.go:69-73)
     // region queries (FaidxQuery.Before, faidx.go:246-329): the region file first, then Regions
     c->features.clear();
     c->features_uploaded = false;
@@ -512,7 +512,7 @@ int faidx_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     memset(&P, 0, sizeof P);
     P.fastq = format == BSK_FORMAT_FASTQ;
     P.full_head = o.b("FullHead");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.base_offset = c->cur_base_offset;
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
@@ -590,7 +590,7 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     RmDupParams P;
     memset(&P, 0, sizeof P);
     P.fastq = fastq;
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     uint64_t cap = 0;
@@ -683,7 +683,7 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
 void validate_common_opts(bsk_ctx* c) {
     const Options& o = c->opts;
     c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
-    check_id_regexp(o);
+    check_id_regexp(c);
     if (o.b("BySeq") && o.b("ByName"))  // common.go:37-39
         throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
     if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :43-45
@@ -710,7 +710,7 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     P.by_seq = o.b("BySeq");
     P.by_name = o.b("ByName");
     P.ignore_case = o.b("IgnoreCase");
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     uint64_t cap = 0;
@@ -783,7 +783,7 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     RmDupParams P;
     memset(&P, 0, sizeof P);
     P.fastq = fastq;
-    P.id_mode = o.cs("IDRegexp") == "\\|([^\\|]+)\\| " ? 1 : 0;
+    P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     uint64_t cap = 0;

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
         const uint32_t lh = t.l_head[gi];
         const uint8_t* h = buf + t.start[gi] + 1;
         uint32_t off;
-        R.id_len = id_span_of(h, lh > 0 ? lh - 1 : 0, P.id_mode, &off, buf + buf_n);
+        R.id_len = id_span_rec(t, gi, h, lh > 0 ? lh - 1 : 0, P.id_mode, &off, buf + buf_n);
         R.id = h + off;
         have_id = true;
     };

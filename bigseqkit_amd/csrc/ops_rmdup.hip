@@ -49,7 +49,7 @@ __device__ __forceinline__ Subject subject_of(const uint8_t* buf, const RecordTa
         const uint32_t lh = t.l_head[i];
         const uint8_t* h = buf + t.start[i] + 1;
         uint32_t hl = lh > 0 ? lh - 1 : 0, off = 0;
-        if (!P.by_name) hl = id_span_of(h, hl, P.id_mode, &off, P.buf_end);
+        if (!P.by_name) hl = id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);
         s.h = h + off;
         s.len = hl;
         s.T.p = nullptr; s.T.L = 0; s.T.W = 0;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_rmdup_side_sizes(const uint8_t* __restr
     uint32_t r = 0;
     if (removed || has_dup[i]) {
         uint32_t off;
-        r = 20u + 1u + id_span_of(buf + t.start[i] + 1, hl, P.id_mode, &off) + 1u;
+        r = 20u + 1u + id_span_rec(t, i, buf + t.start[i] + 1, hl, P.id_mode, &off) + 1u;
     }
     row_len[i] = r;
 }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_rmdup_rows(const uint8_t* __restrict__ 
     const uint32_t lh = t.l_head[i];
     uint32_t off;
     const uint8_t* h = buf + t.start[i] + 1;
-    const uint32_t il = id_span_of(h, lh > 0 ? lh - 1 : 0, P.id_mode, &off);
+    const uint32_t il = id_span_rec(t, i, h, lh > 0 ? lh - 1 : 0, P.id_mode, &off);
     for (uint32_t q = 0; q < il; ++q) o[21 + q] = h[off + q];
     o[21 + il] = '\n';
 }

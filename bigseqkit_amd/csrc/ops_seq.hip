@@ -120,13 +120,13 @@ struct HeadSrc {
 };
 
 // rename: header of record g (ord > 0); returns false when the header stays as it is
-__device__ __forceinline__ bool rename_head(const SeqParams& P, uint64_t g, const uint8_t* head, uint32_t head_len,
+__device__ __forceinline__ bool rename_head(const RecordTable& t, const SeqParams& P, uint64_t g, const uint8_t* head, uint32_t head_len,
                                             HeadSrc* H) {
     if (!P.ren_ord) return false;
     const uint32_t ord = P.ren_ord[g];
     if (!ord) return false;
     uint32_t hoff, doff;
-    const uint32_t il = id_span_of(head, head_len, P.id_mode, &hoff, P.buf_end);
+    const uint32_t il = id_span_rec(t, g, head, head_len, P.id_mode, &hoff, P.buf_end);
     // Desc of parseHeadIDAndDesc (helper.go:329-369): only the default regexp yields one
     const uint32_t dl = hoff == 0 ? desc_of(head, head_len, P.id_mode, il, &doff) : 0u;
     uint32_t nd = 1;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
     }
     if (P.feat_on) {
         uint32_t off;
-        const uint32_t il = id_span_of(r.head, r.head_len, P.id_mode, &off, P.buf_end);
+        const uint32_t il = id_span_rec(t, i, r.head, r.head_len, P.id_mode, &off, P.buf_end);
         const int f = feature_of(P, r.head + off, il);
         if (f < 0) { out_len[i] = 0; return; }
         uint32_t b, e;
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
     if (keep) {
         if (P.print_name) {
             uint32_t hl = r.head_len, off;
-            if (P.only_id) hl = id_span_of(r.head, r.head_len, P.id_mode, &off, P.buf_end);
+            if (P.only_id) hl = id_span_rec(t, i, r.head, r.head_len, P.id_mode, &off, P.buf_end);
             HeadSrc H;
-            if (rename_head(P, i, r.head, r.head_len, &H)) hl = H.len;
+            if (rename_head(t, P, i, r.head, r.head_len, &H)) hl = H.len;
             n += (P.print_seq ? 1u : 0u) + hl + 1u;
         }
         if (P.print_seq) n += wrapped_len(kept, P.line_width) + 1u;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     uint8_t* o = out + out_off[g];
     const RecView r = view(buf, t, g, P.fastq);
     uint32_t hl = r.head_len, hoff = 0;
-    if (P.print_name && P.only_id) hl = id_span_of(r.head, r.head_len, P.id_mode, &hoff, P.buf_end);
+    if (P.print_name && P.only_id) hl = id_span_rec(t, g, r.head, r.head_len, P.id_mode, &hoff, P.buf_end);
     uint32_t sub_b = 0, sub_e = r.seq_len;
     if (P.region_on) sub_location(r.seq_len, P.region_start, P.region_end, &sub_b, &sub_e);
     bool reverse = P.reverse != 0, use_lut = P.use_lut != 0;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     const uint8_t* suffix = nullptr;  // feature mode: header = ID + suffix
     uint32_t id_len = hl;
     if (P.feat_on) {
-        id_len = id_span_of(r.head, r.head_len, P.id_mode, &hoff, P.buf_end);
+        id_len = id_span_rec(t, g, r.head, r.head_len, P.id_mode, &hoff, P.buf_end);
         const int f = feature_of(P, r.head + hoff, id_len);
         feature_region(P, f, r.seq_len, &sub_b, &sub_e);
         suffix = P.fsuffix + P.fsuffix_off[f];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     }
     HeadSrc HS;
     HS.head = r.head; HS.suffix = suffix; HS.hoff = hoff; HS.id_len = id_len; HS.ord = 0; HS.ndig = 0; HS.desc_off = 0;
-    if (rename_head(P, g, r.head, r.head_len, &HS)) hl = HS.len;
+    if (rename_head(t, P, g, r.head, r.head_len, &HS)) hl = HS.len;
     HS.len = hl;
     const uint32_t a = P.print_name ? (P.print_seq ? 1u : 0u) + hl + 1u : 0u;
     // random access to the bases: contiguous text, or a wrapped FASTA record through the text view

@@ -28,7 +28,7 @@ __device__ __forceinline__ uint32_t key_span(const uint8_t* __restrict__ buf, co
     const uint32_t lh = t.l_head[i];
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
     if (P.mode == 1) return hl;                                  // record.Name
-    return id_span_of(h, hl, P.id_mode, off, P.buf_end);         // record.ID
+    return id_span_rec(t, i, h, hl, P.id_mode, off, P.buf_end);         // record.ID
 }
 
 // Natural order (natsort.Compare, PARITY.md SORT): the key is cut into runs of digits and runs of other bytes; digit runs

@@ -78,10 +78,10 @@ __device__ __forceinline__ uint32_t dec_len(int v) {
 }
 
 // header of an element: ">Name" or ">ID_frame=N Desc" (translate.go:133-137), without the '\n'
-__device__ uint32_t header_len(const uint8_t* h, uint32_t hl, const TranslateParams& P, int frame) {
+__device__ uint32_t header_len(const RecordTable& t, uint64_t rec, const uint8_t* h, uint32_t hl, const TranslateParams& P, int frame) {
     if (!P.append_frame) return 1 + hl;
     uint32_t ioff, doff;
-    const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+    const uint32_t il = id_span_rec(t, rec, h, hl, P.id_mode, &ioff);
     const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
     return 1 + il + 7 + dec_len(frame) + 1 + dl;  // '>' id "_frame=" N ' ' desc
 }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_translate_size(const uint8_t* __restric
         }
     }
     const uint32_t lh = t.l_head[i];
-    uint32_t n = header_len(buf + t.start[i] + 1, lh > 0 ? lh - 1 : 0, P, frame) + 1;
+    uint32_t n = header_len(t, i, buf + t.start[i] + 1, lh > 0 ? lh - 1 : 0, P, frame) + 1;
     n += naa + ((P.line_width > 0 && naa > 0) ? (naa - 1) / (uint32_t)P.line_width : 0u);
     n += 1;  // FileStore's newline after the element
     out_len[e] = n;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_translate_emit(const uint8_t* __restric
             for (uint32_t k = 0; k < hl; ++k) o[hdr++] = h[k];
         } else {
             uint32_t ioff, doff;
-            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t il = id_span_rec(t, i, h, hl, P.id_mode, &ioff);
             const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
             for (uint32_t k = 0; k < il; ++k) o[hdr++] = h[ioff + k];
             const char* f = "_frame=";
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_translate_emit(const uint8_t* __restric
         o[hdr++] = '\n';
         o[n - 1] = '\n';
     }
-    const uint32_t H = header_len(h, hl, P, frame) + 1;
+    const uint32_t H = header_len(t, i, h, hl, P, frame) + 1;
     // body: wrapped amino acids; the trimmed length follows from the element size
     const uint32_t body = n - H - 1;
     const uint32_t w1 = P.line_width > 0 ? (uint32_t)P.line_width + 1u : 0u;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_translate_long(const uint8_t* __restric
     const uint8_t* h = buf + t.start[i] + 1;
     const uint32_t lh = t.l_head[i];
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
-    const uint32_t H = header_len(h, hl, P, frame) + 1;
+    const uint32_t H = header_len(t, i, h, hl, P, frame) + 1;
     const uint32_t body = n - H - 1;
     const uint32_t x_lo = blockIdx.x * LONG_BODY;
     if (x_lo >= body && blockIdx.x != 0) return;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_translate_long(const uint8_t* __restric
             for (uint32_t q = 0; q < hl; ++q) o[hdr++] = h[q];
         } else {
             uint32_t ioff, doff;
-            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t il = id_span_rec(t, i, h, hl, P.id_mode, &ioff);
             const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
             for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
             const char* f = "_frame=";
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
         const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
         const uint32_t n = out_len[e];
         uint8_t* o = out + out_off[e];
-        const uint32_t H = header_len(h, hl, P, frame) + 1;
+        const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
         const uint32_t body = n - H - 1;
         const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
         // header and the element's final newline
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_translate_frames(const uint8_t* __restr
         } else if (gl == 0) {
             uint32_t hdr = 0, ioff, doff;
             o[hdr++] = '>';
-            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t il = id_span_rec(t, g, h, hl, P.id_mode, &ioff);
             const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
             for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
             const char* fs = "_frame=";
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
         const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
         const uint32_t n = out_len[e];
         uint8_t* o = out + out_off[e];
-        const uint32_t H = header_len(h, hl, P, frame) + 1;
+        const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
         const uint32_t body = n - H - 1;
         const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
         if (!P.append_frame) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
         } else if (gl == 0) {
             uint32_t hdr = 0, ioff, doff;
             o[hdr++] = '>';
-            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t il = id_span_rec(t, g, h, hl, P.id_mode, &ioff);
             const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
             for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
             const char* fs = "_frame=";
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
             const uint32_t ix = ((uint32_t)s_iu[T.at(p0)] << 8) | ((uint32_t)s_iu[T.at(p0 + 1)] << 4) | (uint32_t)s_iu[T.at(p0 + 2)];
             const bool st = frame > 0 ? P.start[ix] != 0 : P.start_rc[ix] != 0;
             const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
-            const uint32_t H = header_len(h, hl, P, frame) + 1;
+            const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
             if (st && out_len[e] > H + 1u) out[out_off[e] + H] = 'M';
         }
     }
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256) void k_translate_wide(const uint8_t* __restric
         const int frame = P.frames[k];
         const uint32_t n = ne[k];
         uint8_t* o = out + oe[k];
-        const uint32_t H = header_len(h, hl, P, frame) + 1;
+        const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
         const uint32_t body = n - H - 1;
         const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
         if (!P.append_frame) {
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void k_translate_wide(const uint8_t* __restric
         } else if (gl == 0) {
             uint32_t hdr = 0, ioff, doff;
             o[hdr++] = '>';
-            const uint32_t il = id_span_of(h, hl, P.id_mode, &ioff);
+            const uint32_t il = id_span_rec(t, g, h, hl, P.id_mode, &ioff);
             const uint32_t dl = desc_of(h, hl, P.id_mode, il, &doff);
             for (uint32_t q = 0; q < il; ++q) o[hdr++] = h[ioff + q];
             const char* fs = "_frame=";
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_translate_wide(const uint8_t* __restric
             const uint32_t ix = ((uint32_t)s_iu[T.at(p0)] << 8) | ((uint32_t)s_iu[T.at(p0 + 1)] << 4) | (uint32_t)s_iu[T.at(p0 + 2)];
             const bool st = frame > 0 ? P.start[ix] != 0 : P.start_rc[ix] != 0;
             const uint64_t e = g * (uint64_t)P.nframes + (uint64_t)k;
-            const uint32_t H = header_len(h, hl, P, frame) + 1;
+            const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
             if (st && out_len[e] > H + 1u) out[out_off[e] + H] = 'M';
         }
     }

@@ -1,5 +1,6 @@
 // regex_nfa.cpp -- see regex_nfa.hpp.  Parser (recursive descent over RE2 syntax) + Glushkov construction.
 #include "regex_nfa.hpp"
+#include "regex_vm.hpp"
 
 #include <array>
 #include <cstring>
@@ -18,12 +19,14 @@ inline void bs_range(ByteSet& s, int lo, int hi) { for (int b = lo; b <= hi; ++b
 inline void bs_or(ByteSet& a, const ByteSet& b) { for (int i = 0; i < 8; ++i) a[i] |= b[i]; }
 inline ByteSet bs_not(const ByteSet& a) { ByteSet r; for (int i = 0; i < 8; ++i) r[i] = ~a[i]; return r; }
 
-enum class NT { Empty, Lit, Begin, End, Cat, Alt, Star, Plus, Quest, Repeat };
+enum class NT { Empty, Lit, Begin, End, Cat, Alt, Star, Plus, Quest, Repeat, Group };
 struct Node {
     NT t = NT::Empty;
     ByteSet set{};
     std::vector<std::unique_ptr<Node>> kids;
     int lo = 0, hi = 0;  // Repeat: hi < 0 == unbounded
+    int group = 0;       // Group: 1-based index of the capture group
+    bool lazy = false;   // Star / Plus / Quest / Repeat: prefer the shorter match (matters only where positions are asked for)
 };
 using NodeP = std::unique_ptr<Node>;
 
@@ -37,7 +40,8 @@ using NodeP = std::unique_ptr<Node>;
 struct Parser {
     const std::string& e;
     size_t i = 0;
-    bool icase = false, dotall = false;
+    bool icase = false, dotall = false, ungreedy = false;
+    int ngroups = 0;
     explicit Parser(const std::string& s) : e(s) {}
     bool more() const { return i < e.size(); }
     char peek() const { return e[i]; }
@@ -171,18 +175,25 @@ struct Parser {
         const char c = e[i++];
         switch (c) {
             case '(': {
+                bool capture = true;
                 if (more() && peek() == '?') {
-                    if (e.compare(i, 2, "?:") == 0) i += 2;
+                    if (e.compare(i, 2, "?:") == 0) { i += 2; capture = false; }
                     else if (e.compare(i, 3, "?P<") == 0) {
                         const size_t j = e.find('>', i);
                         if (j == std::string::npos) bad("invalid named capture", e);
                         i = j + 1;
                     } else unsupported("flags / look-around inside the expression", e);
                 }
+                const int idx = capture ? ++ngroups : 0;  // groups are numbered by their opening parenthesis
                 NodeP n = alt();
                 if (!more() || peek() != ')') bad("missing closing )", e);
                 ++i;
-                return n;
+                if (!capture) return n;
+                NodeP g(new Node);
+                g->t = NT::Group;
+                g->group = idx;
+                g->kids.push_back(std::move(n));
+                return g;
             }
             case '[': return char_class();
             case '.': {
@@ -238,7 +249,8 @@ struct Parser {
                 i = j + 1;
                 n->t = NT::Repeat; n->lo = lo; n->hi = hi;
             } else return a;
-            if (more() && peek() == '?') ++i;  // lazy form: same set of matching targets
+            n->lazy = ungreedy;
+            if (more() && peek() == '?') { ++i; n->lazy = !ungreedy; }  // lazy form: same set of matching targets, other positions
             n->kids.push_back(std::move(a));
             a = std::move(n);
         }
@@ -268,7 +280,7 @@ struct Parser {
             for (; j < e.size() && e[j] != ')'; ++j) {
                 if (e[j] == 'i') ic = true;
                 else if (e[j] == 's') ds = true;
-                else if (e[j] == 'U') {}  // swap greediness: irrelevant for a boolean match
+                else if (e[j] == 'U') ungreedy = true;  // swap greediness: irrelevant for a boolean match, kept for the VM
                 else { ok = false; break; }
             }
             if (!ok || j >= e.size()) break;
@@ -323,6 +335,7 @@ struct Builder {
             case NT::Star: { Frag f = build(*n.kids[0]); link(f.last, f.first); f.nullable = true; return f; }
             case NT::Plus: { Frag f = build(*n.kids[0]); link(f.last, f.first); return f; }
             case NT::Quest: { Frag f = build(*n.kids[0]); f.nullable = true; return f; }
+            case NT::Group: return build(*n.kids[0]);
             case NT::Repeat: {
                 Frag f{true, 0, 0};
                 for (int k = 0; k < n.lo; ++k) f = cat(f, build(*n.kids[0]));
@@ -376,6 +389,118 @@ bool regex_match(const RegexProgram& p, const uint8_t* text, size_t n) {
     for (size_t i = 0; i < n; ++i)
         if (step(text[i])) return true;
     return step(RE_SYM_END);
+}
+
+
+// ---------------------------------------------------------------------------
+// Thompson program for the Pike VM (regex_vm.hpp)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct VmBuilder {
+    const std::string& expr;
+    VmProgram P;
+    uint32_t nsets = 0;
+    explicit VmBuilder(const std::string& e) : expr(e) {}
+    uint32_t emit(uint8_t op, uint8_t arg = 0, uint8_t x = 0, uint8_t y = 0) {
+        if (P.n >= (uint32_t)VM_MAX_INST) unsupported("expression too large for the position-reporting matcher", expr);
+        P.inst[P.n] = VmInst{op, arg, x, y};
+        return P.n++;
+    }
+    uint8_t set_of(const ByteSet& s) {
+        for (uint32_t k = 0; k < nsets; ++k) {
+            bool same = true;
+            for (int i = 0; i < 8; ++i) same &= P.sets[k][i] == s[i];
+            if (same) return (uint8_t)k;
+        }
+        if (nsets >= (uint32_t)VM_MAX_SETS) unsupported("too many distinct character classes", expr);
+        for (int i = 0; i < 8; ++i) P.sets[nsets][i] = s[i];
+        return (uint8_t)nsets++;
+    }
+    void star(const Node& kid, bool lazy) {  // L1: split L2, L3; L2: e; jmp L1; L3:
+        const uint32_t l1 = emit(VM_SPLIT);
+        gen(kid);
+        emit(VM_JMP, 0, (uint8_t)l1);
+        const uint32_t l3 = P.n;
+        P.inst[l1].x = (uint8_t)(lazy ? l3 : l1 + 1);
+        P.inst[l1].y = (uint8_t)(lazy ? l1 + 1 : l3);
+    }
+    void quest(const Node& kid, bool lazy) {  // split L1, L2; L1: e; L2:
+        const uint32_t l0 = emit(VM_SPLIT);
+        gen(kid);
+        const uint32_t l2 = P.n;
+        P.inst[l0].x = (uint8_t)(lazy ? l2 : l0 + 1);
+        P.inst[l0].y = (uint8_t)(lazy ? l0 + 1 : l2);
+    }
+    void gen(const Node& n) {
+        switch (n.t) {
+            case NT::Empty: return;
+            case NT::Lit: emit(VM_CHAR, set_of(n.set)); return;
+            case NT::Begin: emit(VM_BEGIN); return;
+            case NT::End: emit(VM_END); return;
+            case NT::Cat: for (auto& k : n.kids) gen(*k); return;
+            case NT::Alt: {  // split L1, L2; L1: a; jmp END; L2: split ... (the first alternative is preferred)
+                std::vector<uint32_t> jumps;
+                for (size_t k = 0; k < n.kids.size(); ++k) {
+                    if (k + 1 < n.kids.size()) {
+                        const uint32_t sp = emit(VM_SPLIT);
+                        gen(*n.kids[k]);
+                        jumps.push_back(emit(VM_JMP));
+                        P.inst[sp].x = (uint8_t)(sp + 1);
+                        P.inst[sp].y = (uint8_t)P.n;
+                    } else {
+                        gen(*n.kids[k]);
+                    }
+                }
+                for (uint32_t j : jumps) P.inst[j].x = (uint8_t)P.n;
+                return;
+            }
+            case NT::Star: star(*n.kids[0], n.lazy); return;
+            case NT::Plus: {  // L1: e; split L1, L3
+                const uint32_t l1 = P.n;
+                gen(*n.kids[0]);
+                const uint32_t sp = emit(VM_SPLIT);
+                P.inst[sp].x = (uint8_t)(n.lazy ? sp + 1 : l1);
+                P.inst[sp].y = (uint8_t)(n.lazy ? l1 : sp + 1);
+                return;
+            }
+            case NT::Quest: quest(*n.kids[0], n.lazy); return;
+            case NT::Repeat: {
+                for (int k = 0; k < n.lo; ++k) gen(*n.kids[0]);
+                if (n.hi < 0) star(*n.kids[0], n.lazy);
+                else {
+                    // (e(e(e)?)?)? : every optional copy may end the repetition
+                    std::vector<uint32_t> splits;
+                    for (int k = n.lo; k < n.hi; ++k) { splits.push_back(emit(VM_SPLIT)); gen(*n.kids[0]); }
+                    for (uint32_t sp : splits) {
+                        P.inst[sp].x = (uint8_t)(n.lazy ? P.n : sp + 1);
+                        P.inst[sp].y = (uint8_t)(n.lazy ? sp + 1 : P.n);
+                    }
+                }
+                return;
+            }
+            case NT::Group:
+                if (n.group == 1) emit(VM_SAVE, 2);
+                gen(*n.kids[0]);
+                if (n.group == 1) emit(VM_SAVE, 3);
+                return;
+        }
+    }
+};
+
+}  // namespace
+
+VmProgram compile_vm(const std::string& expr) {
+    Parser ps(expr);
+    NodeP root = ps.parse();
+    VmBuilder b(expr);
+    memset(&b.P, 0, sizeof b.P);
+    b.emit(VM_SAVE, 0);
+    b.gen(*root);
+    b.emit(VM_SAVE, 1);
+    b.emit(VM_MATCH);
+    b.P.ngroups = (uint32_t)ps.ngroups;
+    return b.P;
 }
 
 }  // namespace bsk

@@ -89,6 +89,14 @@ __device__ inline uint32_t id_span_of(const uint8_t* h, uint32_t n, int id_mode,
     return n;
 }
 
+// the same for record `rec` of a table: with a custom --id-regexp the spans were computed once per shard by the
+// position-reporting matcher (k_id_spans, ops_idre.hip: FindSubmatch(head)[1], helper.go:362-368) and sit in the table
+__device__ inline uint32_t id_span_rec(const RecordTable& t, uint64_t rec, const uint8_t* h, uint32_t n, int id_mode,
+                                       uint32_t* id_off, const uint8_t* lim = nullptr) {
+    if (t.id_len) { *id_off = t.id_off[rec]; return t.id_len[rec]; }
+    return id_span_of(h, n, id_mode, id_off, lim);
+}
+
 // description after the ID (default regexp only; helper.go:331-345, incl. its skip-two loop)
 __device__ inline uint32_t desc_of(const uint8_t* h, uint32_t n, int id_mode, uint32_t id_len, uint32_t* desc_off) {
     *desc_off = n;

@@ -304,6 +304,11 @@ int bsk_rmdup_dist_resolve(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void*
 int bsk_rmdup_dist_emit(bsk_ctx* ctx, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
                         bsk_out* out);
 
+/* host-side self-test of the position-reporting regular-expression matcher (custom --id-regexp, locate -r):
+ * leftmost-first match at or after `from`; caps4 = {match start, match end, group-1 start, group-1 end} (0xFFFFFFFF:
+ * group 1 did not take part).  1 = match, 0 = none, -1 = expression rejected (bsk_global_error) */
+int bsk_selftest_regex_find(const char* expr, const uint8_t* text, size_t n, size_t from, uint32_t* caps4, uint32_t* ngroups);
+
 /* ---- FileStore / StoreFASTXN  (bigseqkit-lib/helper.go:378-460 NewFileStore; bigseqkit/helper.go:186-195 StoreFASTX[N]) ----
  * merge != 0: ONE file at `path`, the parts (partitions) in the order of their numbers whatever the order of the calls --
  * the reference passes an MPI token from executor to executor (helper.go:418-436), here a part that comes before its

@@ -252,7 +252,22 @@ void parse_head_id_desc(const std::string& head, bool default_re, const std::str
         id = head;  // not match -> whole head (helper.go:365-367)
         return;
     }
-    throw Error("oracle: custom --id-regexp other than the NCBI one is not restated");
+    // any other expression: found = idRegexp.FindSubmatch(head); nil -> head; else found[1] (helper.go:362-368).
+    // Go's regexp is not in this image: std::regex (ECMAScript, leftmost with the same alternation / greediness
+    // priorities) stands in for it on the syntax the two share -- a different engine from the product's Pike VM.
+    if (re.find('(') == std::string::npos || re.rfind(')') == std::string::npos || re.rfind(')') < re.find('(') + 2)
+        throw Error("fastx: regular expression must contain \"(\" and \")\" to capture matched ID. default: ^(\\S+)\\s?");
+    static std::string cached_text;
+    static std::regex cached;
+    if (cached_text != re) {
+        try { cached = std::regex(re, std::regex::ECMAScript); }
+        catch (const std::regex_error&) { throw Error("fastx: fail to compile regexp: " + re); }
+        cached_text = re;
+    }
+    std::smatch m;
+    if (!std::regex_search(head, m, cached)) { id = head; return; }
+    if (m.size() < 2) throw Error("fastx: regular expression must contain \"(\" and \")\" to capture matched ID. default: ^(\\S+)\\s?");
+    id = m[1].matched ? m[1].str() : std::string();
 }
 
 bool SeqParser::Read() {
