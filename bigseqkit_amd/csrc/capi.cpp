@@ -220,6 +220,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_redo) hipFree(c->d_redo);
         if (c->d_out_alt) hipFree(c->d_out_alt);
         if (c->d_id_prog) hipFree(c->d_id_prog);
+        if (c->d_vm_progs) hipFree(c->d_vm_progs);
         if (c->d_id_off) hipFree(c->d_id_off);
         if (c->d_id_len) hipFree(c->d_id_len);
         if (c->d_cls) hipFree(c->d_cls);

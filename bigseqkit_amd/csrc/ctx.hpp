@@ -128,6 +128,11 @@ struct bsk_ctx {
     std::vector<bsk::RegexProgram> regexes;
     bsk::RegexProgram* d_regex = nullptr;
     uint64_t regex_cap = 0;
+    // locate -r with matches of variable length: programs of the position-reporting matcher (regex_vm.hpp)
+    bool locate_vm = false;
+    std::vector<bsk::VmProgram> vm_progs;
+    bsk::VmProgram* d_vm_progs = nullptr;
+    uint64_t vm_progs_cap = 0;
     bool patterns_uploaded = false;  // exact patterns + set do not depend on the shard's alphabet when by name
     uint8_t* d_names = nullptr;
     uint32_t* d_names_off = nullptr;

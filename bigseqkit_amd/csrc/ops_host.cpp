@@ -1078,6 +1078,7 @@ void validate_locate_opts(bsk_ctx* c) {
     c->max_mm = (int)o.i("MaxMismatch");
     c->fmi_order = c->max_mm > 0 || o.b("UseFmi");
     c->general = o.b("Degenerate") || o.b("UseRegexp") || c->fmi_order;
+    c->locate_vm = false;
     std::vector<std::pair<std::string, std::string>> given;  // (name, sequence)
     const bool from_file = !o.s("PatternFile").empty();
     if (from_file) {
@@ -1091,26 +1092,58 @@ void validate_locate_opts(bsk_ctx* c) {
         // offset).  Provided for expressions that are a fixed-length chain of literals, '.', classes and escapes -- they
         // become class patterns, for which leftmost-first matching has nothing to choose; quantifiers, alternation,
         // groups with choices and anchors need Go's match priorities and are rejected (PARITY.md LOCRE).
+        // Expressions that are a fixed-length chain of literals, '.', classes and escapes become class patterns (leftmost-
+        // first matching has nothing to choose there, and 16 start positions are tested per step); as soon as one
+        // expression has quantifiers, alternation, groups with choices or anchors, ALL of them run on the position-
+        // reporting matcher instead (regex_vm.hpp: Go's leftmost-first priorities, matches of any length).
+        c->locate_vm = false;
+        c->vm_progs.clear();
+        std::vector<std::pair<std::string, std::string>> uniq;
         for (auto& g : given) {
-            if (std::find(c->pattern_names.begin(), c->pattern_names.end(), g.first) != c->pattern_names.end()) continue;
-            const RegexProgram pr = compile_regex(o.b("IgnoreCase") ? "(?i)" + g.second : g.second);  // :104-106
-            bool chain = pr.npos > 0 && !pr.nullable && pr.first == 1ull && pr.last == (1ull << (pr.npos - 1)) &&
-                         pr.accept[RE_SYM_BEGIN] == 0 && pr.accept[RE_SYM_END] == 0;
-            for (uint32_t q = 0; chain && q < pr.npos; ++q)
-                chain = pr.follow[q >> 3][1u << (q & 7)] == (q + 1 < pr.npos ? (1ull << (q + 1)) : 0ull);
-            if (!chain)
-                throw OptError("libbsk: locate -r is provided for fixed-length expressions (literals, '.', [classes], escapes); `" +
-                               g.second + "` needs regexp match priorities");
-            std::vector<ByteSet> sets(pr.npos);
-            for (uint32_t q = 0; q < pr.npos; ++q) {
-                sets[q].fill(0);
-                for (int b = 0; b < 256; ++b)
-                    if ((pr.accept[b] >> q) & 1ull) set_add(sets[q], (uint8_t)b);
+            bool seen = false;
+            for (auto& u : uniq) seen |= u.first == g.first;
+            if (!seen) uniq.push_back(g);
+        }
+        std::vector<std::vector<ByteSet>> chains;
+        for (auto& g : uniq) {
+            const std::string expr = o.b("IgnoreCase") ? "(?i)" + g.second : g.second;  // :104-106
+            bool chain = false;
+            RegexProgram pr;
+            try {
+                pr = compile_regex(expr);
+                chain = pr.npos > 0 && !pr.nullable && pr.first == 1ull && pr.last == (1ull << (pr.npos - 1)) &&
+                        pr.accept[RE_SYM_BEGIN] == 0 && pr.accept[RE_SYM_END] == 0;
+                for (uint32_t q = 0; chain && q < pr.npos; ++q)
+                    chain = pr.follow[q >> 3][1u << (q & 7)] == (q + 1 < pr.npos ? (1ull << (q + 1)) : 0ull);
+            } catch (const OptError& e) {
+                if (std::string(e.what()).rfind("libbsk:", 0) != 0) throw;  // a syntax error is one in any engine
             }
-            c->pattern_cls.push_back(sets);
+            if (chain) {
+                std::vector<ByteSet> sets(pr.npos);
+                for (uint32_t q = 0; q < pr.npos; ++q) {
+                    sets[q].fill(0);
+                    for (int b = 0; b < 256; ++b)
+                        if ((pr.accept[b] >> q) & 1ull) set_add(sets[q], (uint8_t)b);
+                }
+                chains.push_back(sets);
+            } else {
+                c->locate_vm = true;
+            }
+        }
+        if (c->locate_vm && o.b("Circular"))
+            throw OptError("libbsk: locate -r with matches of variable length is not provided together with --circular");
+        for (size_t k = 0; k < uniq.size(); ++k) {
+            auto& g = uniq[k];
             c->pattern_names.push_back(g.first);
             c->pattern_disp.push_back(g.second);
-            c->patterns.push_back(std::string(pr.npos, 'N'));  // carries the match length only
+            if (c->locate_vm) {
+                c->vm_progs.push_back(compile_vm(o.b("IgnoreCase") ? "(?i)" + g.second : g.second));
+                c->patterns.push_back("N");  // (the match length comes from the matcher)
+                c->pattern_cls.push_back(std::vector<ByteSet>(1, ByteSet{}));
+            } else {
+                c->pattern_cls.push_back(chains[k]);
+                c->patterns.push_back(std::string(chains[k].size(), 'N'));  // carries the match length only
+            }
         }
         return;
     }
@@ -1243,7 +1276,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         // (not with --non-greedy, whose search position depends on the previous match)
         uint64_t ncells_total = 0;
         const uint64_t per_cells = (uint64_t)P.npat * (P.both_strands ? 2 : 1);
-        if (!P.non_greedy && per_cells < 32768) {  // (cells of one record are counted in 32 bits: chunks <= 2^17)
+        if (!P.non_greedy && per_cells < 32768 && !c->locate_vm) {  // (the matcher of variable-length -r walks every record itself)  // (cells of one record are counted in 32 bits: chunks <= 2^17)
             const char* e = getenv("BSK_LONG_BYTES");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
             rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
@@ -1282,6 +1315,12 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             }
         }
         HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
+        if (c->locate_vm) {
+            rc = grow(c, &c->d_vm_progs, &c->vm_progs_cap, c->vm_progs.size());
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemcpyAsync(c->d_vm_progs, c->vm_progs.data(), c->vm_progs.size() * sizeof(VmProgram), hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, launch_locate_vm(false, d_buf, n, c->table, tt, P, c->d_vm_progs, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
+        } else
         HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st, c->avg_record_bytes));
         if (P.long_count) {
             // place every cell inside its record's rows, then the record sizes
@@ -1308,7 +1347,10 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     rc = ensure_out(c, total + header.size());
     if (rc != BSK_OK) return rc;
     if (!header.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_out, header.data(), header.size(), hipMemcpyHostToDevice, st));
-    if (total)
+    if (total && c->locate_vm)
+        HIP_TRYX(c, launch_locate_vm(true, d_buf, n, c->table, tt, P, c->d_vm_progs, c->d_out_len, c->d_out_off, c->d_out + header.size(),
+                                     c->d_counter + 1, st));
+    else if (total)
         HIP_TRYX(c, launch_locate(true, d_buf, n, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out + header.size(),
                                   c->d_counter + 1, st, c->avg_record_bytes));
     if (total) HIP_TRYX(c, hipMemcpyAsync(&nrows, c->d_counter + 1, sizeof nrows, hipMemcpyDeviceToHost, st));  // counted by the emit pass

@@ -13,6 +13,7 @@
 
 #include "ops_locate.hpp"
 #include "pattern_match.cuh"
+#include "regex_vm.hpp"
 #include "text.cuh"
 
 namespace bsk {
@@ -447,6 +448,84 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
     }
 }
 
+// ---------------------------------------------------------------------------
+// locate -r with matches of VARIABLE length (bigseqkit-lib/locate.go:583-667, 679-766): FindSubmatchIndex from a moving
+// offset, per pattern and strand; a match that lies inside an earlier one of the same pattern and strand is dropped
+// (:604-614).  One lane per record runs the Pike VM of regex_vm.hpp on the text view (the '-' strand is the
+// complement read backwards, never materialised).  Within one (pattern, strand) the match starts only grow, so
+// "inside an earlier match" is "does not end beyond the furthest end printed so far".  Count pass / emit pass as above.
+// ---------------------------------------------------------------------------
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_locate_vm(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+                                                  LocateParams P, const VmProgram* __restrict__ progs,
+                                                  uint32_t* __restrict__ out_len, const uint64_t* __restrict__ out_off,
+                                                  uint8_t* __restrict__ out, uint64_t* __restrict__ rows) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= t.n) return;
+    if (EMIT && out_len[g] == 0) return;
+    const Text T = text_of(buf, t, tt, g);
+    const uint32_t l = T.L;
+    RowCtx R;
+    {
+        const uint32_t lh = t.l_head[g];
+        const uint8_t* h = buf + t.start[g] + 1;
+        uint32_t off;
+        R.id_len = id_span_rec(t, g, h, lh > 0 ? lh - 1 : 0, P.id_mode, &off, buf + buf_n);
+        R.id = h + off;
+    }
+    R.format = P.format;
+    R.from_text = true;
+    R.lower = false;
+    R.T = T;
+    R.l = l;
+    R.comp = P.comp;
+    uint8_t* o = EMIT ? out + out_off[g] : nullptr;
+    uint64_t bytes = 0;
+    uint32_t nrows = 0;
+    const uint8_t* comp = P.comp;
+    for (int k = 0; k < P.npat; ++k) {
+        R.name = P.name + P.name_off[k];
+        R.name_len = P.name_off[k + 1] - P.name_off[k];
+        R.disp = P.disp + P.disp_off[k];
+        R.disp_len = P.disp_off[k + 1] - P.disp_off[k];
+        R.pat = nullptr;
+        const VmProgram& prog = progs[k];
+        for (int strand = 0; strand < (P.both_strands ? 2 : 1); ++strand) {
+            uint32_t offset = 0;
+            uint32_t far = 0;     // furthest end (in the strand's own coordinates) of a printed match
+            bool any = false;
+            for (;;) {
+                if (offset > l) break;
+                uint32_t caps[4];
+                bool found;
+                if (strand == 0) found = vm_search_fn(prog, [&](uint32_t i) { return T.at(offset + i); }, l - offset, 0u, caps);
+                else found = vm_search_fn(prog, [&](uint32_t i) { return comp[T.at(l - 1u - (offset + i))]; }, l - offset, 0u, caps);
+                if (!found) break;
+                const uint32_t s = offset + caps[0], e = offset + caps[1];  // the match in the strand's coordinates [s, e)
+                if (!(any && far >= e)) {
+                    const int64_t begin = strand == 0 ? (int64_t)s + 1 : (int64_t)l - (int64_t)e + 1;
+                    const int64_t end = strand == 0 ? (int64_t)e : (int64_t)l - (int64_t)s;
+                    R.pat_len = e - s;
+                    R.rc = strand != 0;
+                    R.f = strand == 0 ? s : l - e;
+                    if (EMIT) bytes += row_put(o + bytes, R, strand == 0 ? '+' : '-', begin, end);
+                    else bytes += row_len(R, begin, end);
+                    ++nrows;
+                    far = any ? (e > far ? e : far) : e;
+                    any = true;
+                }
+                offset = P.non_greedy ? e + 1u : s + 1u;
+                if (offset >= l) break;
+            }
+        }
+    }
+    if (EMIT) {
+        if (nrows) atomicAdd((unsigned long long*)rows, (unsigned long long)nrows);
+    } else {
+        out_len[g] = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes;
+    }
+}
+
 // records with rows -> hit_list (any order).  Each block owns a contiguous chunk: count, ONE atomicAdd to reserve the
 // slots, then write -- a few thousand atomics instead of one per hit.
 __global__ __launch_bounds__(256) void k_compact_hits(const uint32_t* __restrict__ out_len, uint64_t n, uint32_t* __restrict__ hit_list,
@@ -534,6 +613,17 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
         else { if (emit) BSK_LAUNCH_LONG(true, false); else BSK_LAUNCH_LONG(false, false); }
 #undef BSK_LAUNCH_LONG
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_locate_vm(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
+                            const LocateParams& P, const VmProgram* d_progs, uint32_t* out_len, const uint64_t* out_off,
+                            uint8_t* out, uint64_t* rows, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    const dim3 gr((unsigned)((t.n + 63) / 64)), bl(64);
+    if (emit) hipLaunchKernelGGL(k_locate_vm<true>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows);
+    else hipLaunchKernelGGL(k_locate_vm<false>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows);
     return hipGetLastError();
 }
 

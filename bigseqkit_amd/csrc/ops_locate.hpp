@@ -50,6 +50,12 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
                          uint64_t* rows, hipStream_t st, uint64_t avg_record_bytes = 0);
 
+struct VmProgram;
+// locate -r with matches of variable length: one lane per record runs the Pike VM (count pass: out_len; emit pass: rows)
+hipError_t launch_locate_vm(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
+                            const LocateParams& P, const VmProgram* d_progs, uint32_t* out_len, const uint64_t* out_off,
+                            uint8_t* out, uint64_t* rows, hipStream_t st);
+
 // hit_list := indices of the records with out_len != 0 (any order), *hit_count := how many (zeroed by the caller)
 // out_len of the long records := sum of their cells' bytes (after the scan of cell_bytes)
 hipError_t launch_locate_long_sizes(const LocateParams& P, uint32_t* out_len, hipStream_t st);

@@ -35,7 +35,9 @@ VmProgram compile_vm(const std::string& expr);
 
 // leftmost-first match of the program in text[0, n), searching from `from` (^ matches at 0 only, $ at n only).
 // caps[0..1] = bounds of the match, caps[2..3] = bounds of group 1 (0xFFFFFFFF when it did not take part).
-BSK_VM_HD inline bool vm_search(const VmProgram& P, const uint8_t* text, uint32_t n, uint32_t from, uint32_t* caps) {
+// (text(i): byte i of the target -- a plain pointer, a wrapped FASTA record, or the reverse complement read backwards)
+template <class TextFn>
+BSK_VM_HD inline bool vm_search_fn(const VmProgram& P, const TextFn& text, uint32_t n, uint32_t from, uint32_t* caps) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     struct Th { uint8_t pc; uint32_t c[4]; };
     Th la[VM_MAX_INST], lb[VM_MAX_INST];
@@ -89,7 +91,7 @@ BSK_VM_HD inline bool vm_search(const VmProgram& P, const uint8_t* text, uint32_
                 break;  // threads below this one are cut off
             }
             if (sp < n) {
-                const uint8_t ch = text[sp];
+                const uint8_t ch = text(sp);
                 if ((P.sets[I.arg][ch >> 5] >> (ch & 31)) & 1u) {
                     // marks of step sp + 1: distinct from step sp because `mark` holds the step number
                     add(nl, nnl, (uint8_t)(t.pc + 1), t.c, sp + 1);
@@ -101,6 +103,10 @@ BSK_VM_HD inline bool vm_search(const VmProgram& P, const uint8_t* text, uint32_
         if (sp >= n) break;
     }
     return matched;
+}
+
+BSK_VM_HD inline bool vm_search(const VmProgram& P, const uint8_t* text, uint32_t n, uint32_t from, uint32_t* caps) {
+    return vm_search_fn(P, [text](uint32_t i) { return text[i]; }, n, from, caps);
 }
 
 }  // namespace bsk

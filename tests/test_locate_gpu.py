@@ -239,7 +239,28 @@ def test_locate_regexp_hand_case_pattern_file_and_what_is_refused(tmp_path):
     pf.write_text(">motif one\nG[GC]A\n>second\nTT.T\n")
     check(fa, False, {"PatternFile": str(pf), "UseRegexp": True})
     check(fa, False, {"Pattern": ["A{4}", "(TT)G"], "UseRegexp": True})   # a fixed count and a plain group are still a chain
-    for bad in ("AC+G", "A|C", "(AC)?G", "^ACG", "AC{1,2}"):
-        with pytest.raises(bsk.BskError) as e:
-            bsk.Locate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(fa)]), _Opts({"Pattern": [bad], "UseRegexp": True}))
-        assert "fixed-length expressions" in str(e.value), bad
+    # expressions that need match priorities run on the position-reporting matcher (round 1 refused them)
+    for expr in ("AC+G", "A|C", "(AC)?G", "^ACG", "AC{1,2}"):
+        check(fa, False, {"Pattern": [expr], "UseRegexp": True})
+    # hand case (locate.go:583-667): A+ on AAAATTTTGGAAAA, greedy stepping: 1-4; 2-4, 3-4, 4-4 lie inside it and are dropped
+    # (:604-614); then 11-14 (12-14 .. dropped).  '-' strand: RevCom = TTTTCCAAAATTTT, A+ at 7-10 -> begin 14-10+1 = 5, end 8
+    got = check(fa[:21], False, {"Pattern": ["A+"], "UseRegexp": True})
+    assert got == (b"seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched\n"
+                   b"s1\tA+\tA+\t+\t1\t4\tAAAA\ns1\tA+\tA+\t+\t11\t14\tAAAA\ns1\tA+\tA+\t-\t5\t8\tAAAA\n")
+
+
+# ---------------------------------------------------------------- locate -r, matches of variable length (PARITY.md LOCRE)
+VM_EXPRS = ["AC+G", "A[CG]*T", "(AC|GT)+", "^A.*T$", "T{2,4}", "G.*?C", "(?:CG|C)(A|AT)T?", "A+", "^[ACGT]{3}", "N+|ACGT", "A(C|G){0,2}T$", "T*"]
+
+
+@pytest.mark.parametrize("expr", VM_EXPRS)
+def test_locate_regexp_variable_length(expr, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(len(expr) * 7 + ord(expr[0]))
+    fa = seqgen.random_fasta(rng, 150, 0, 300, alphabet="ACGTN")
+    fq = seqgen.random_fastq(rng, 200, 0, 80, alphabet="ACGT")
+    for o in ({}, {"OnlyPositiveStrand": True}, {"NonGreedy": True}, {"IgnoreCase": True, "HideMatched": True}, {"Bed": True}):
+        check(fa, False, dict({"Pattern": [expr], "UseRegexp": True}, **o))
+    check(fq, True, {"Pattern": [expr, "ACG", "C[AT]"], "UseRegexp": True})
+    with pytest.raises(bsk.BskError):
+        bsk.Locate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(fa)]), _Opts({"Pattern": [expr], "UseRegexp": True, "Circular": True}))
