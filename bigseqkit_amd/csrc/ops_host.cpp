@@ -1089,10 +1089,7 @@ void validate_locate_opts(bsk_ctx* c) {
     }
     if (o.b("UseRegexp")) {
         // locate.go:102-121, 153-172: the regexp branch shares the search loop of -d (FindSubmatchIndex from a moving
-        // offset).  Provided for expressions that are a fixed-length chain of literals, '.', classes and escapes -- they
-        // become class patterns, for which leftmost-first matching has nothing to choose; quantifiers, alternation,
-        // groups with choices and anchors need Go's match priorities and are rejected (PARITY.md LOCRE).
-        // Expressions that are a fixed-length chain of literals, '.', classes and escapes become class patterns (leftmost-
+        // offset).  Expressions that are a fixed-length chain of literals, '.', classes and escapes become class patterns (leftmost-
         // first matching has nothing to choose there, and 16 start positions are tested per step); as soon as one
         // expression has quantifiers, alternation, groups with choices or anchors, ALL of them run on the position-
         // reporting matcher instead (regex_vm.hpp: Go's leftmost-first priorities, matches of any length).
