@@ -219,6 +219,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_ftab) hipFree(c->d_ftab);
         if (c->d_redo) hipFree(c->d_redo);
         if (c->d_out_alt) hipFree(c->d_out_alt);
+        if (c->d_slices) hipFree(c->d_slices);
+        if (c->d_names_aux) hipFree(c->d_names_aux);
         if (c->d_id_prog) hipFree(c->d_id_prog);
         if (c->d_vm_progs) hipFree(c->d_vm_progs);
         if (c->d_id_off) hipFree(c->d_id_off);

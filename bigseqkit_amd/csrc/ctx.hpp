@@ -73,6 +73,10 @@ struct bsk_ctx {
     uint64_t out_cap = 0;
     uint8_t* d_out_alt = nullptr;       // second output buffer of bsk_run_to_store (drained while the next chunk computes)
     uint64_t out_alt_cap = 0;
+    uint8_t* d_slices = nullptr;        // per-range output slices of the names pass (stream_names.hip)
+    uint64_t slices_cap = 0;
+    uint64_t* d_names_aux = nullptr;    // [2 * (nranges + 2)]: bytes per range, scanned record counts
+    uint64_t names_aux_cap = 0;
     uint8_t* d_lut = nullptr;           // 256-byte byte map (seq)
     double* d_qual_err = nullptr;       // 256 doubles (seq -Q/-R)
     uint64_t* d_counter = nullptr;      // scratch counter

@@ -30,6 +30,7 @@
 #include "ops_seq.hpp"
 #include "ops_sort.hpp"
 #include "stream_filter.hpp"
+#include "stream_names.hpp"
 #include "stream_stats.hpp"
 
 namespace bsk {
@@ -97,21 +98,11 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
     return build_index_filtered(c, d_buf, n, format, st, nullptr);
 }
 
-// With a FilterDev (FASTQ only): the table holds ONLY the records whose sequence line contains one of the filter's
-// patterns (or only the others, with invert) -- stream_filter.hip.  BSK_ERR_FILTER_FALLBACK: the filter gave up
-// (pending-hit list full); the caller then takes the unfiltered path.
-int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F) {
-    const bool fastq = format == BSK_FORMAT_FASTQ;
-    c->table.n = 0;
-    c->avg_record_bytes = 0;
-    if (n == 0) return BSK_OK;
-    if (F && !fastq) { c->set_error("libbsk: the pattern filter runs on FASTQ only"); return BSK_ERR_INVALID_ARG; }
-    auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
-        if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
-        return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st);
-    };
-    const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp) : index_max_blocks_per_cu(fastq, c->use_dpp);
-    const int blocks = std::max(1, c->num_cus * per_cu);
+// ranges of a streaming pass over the shard: anchors[nranges + 1] (+ the queue word behind them) in ctx-owned memory.
+// FASTA ranges begin on line starts (a chromosome spans many ranges); the records that cross range boundaries are
+// completed by k_index_stitch from the per-range parts
+static int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, int blocks, hipStream_t st, uint32_t* nranges_out,
+                       uint64_t* chunk_out) {
     const uint64_t waves = (uint64_t)blocks * 4;
     const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
     const uint32_t nranges = (uint32_t)nr;
@@ -127,11 +118,34 @@ int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
         HIP_TRYX(c, hipMalloc((void**)&c->d_range_base, ((size_t)nranges + 2) * sizeof(uint64_t)));
         c->cap_ranges = nranges;
     }
+    uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
+    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, c->d_anchors, queue, st, /*line_mode=*/!fastq));
+    *nranges_out = nranges;
+    *chunk_out = chunk;
+    return BSK_OK;
+}
+
+// With a FilterDev (FASTQ only): the table holds ONLY the records whose sequence line contains one of the filter's
+// patterns (or only the others, with invert) -- stream_filter.hip.  BSK_ERR_FILTER_FALLBACK: the filter gave up
+// (pending-hit list full); the caller then takes the unfiltered path.
+int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F) {
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    c->table.n = 0;
+    c->avg_record_bytes = 0;
+    if (n == 0) return BSK_OK;
+    if (F && !fastq) { c->set_error("libbsk: the pattern filter runs on FASTQ only"); return BSK_ERR_INVALID_ARG; }
+    auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
+        if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
+        return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st);
+    };
+    const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp) : index_max_blocks_per_cu(fastq, c->use_dpp);
+    const int blocks = std::max(1, c->num_cus * per_cu);
+    uint32_t nranges = 0;
+    uint64_t chunk = 0;
+    int rcp = prep_ranges(c, d_buf, n, fastq, blocks, st, &nranges, &chunk);
+    if (rcp != BSK_OK) return rcp;
     uint64_t* anchors = c->d_anchors;
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
-    // FASTA ranges begin on line starts (a chromosome spans many ranges); the records that cross range boundaries are
-    // completed by k_index_stitch from the per-range parts
-    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st, /*line_mode=*/!fastq));
     IndexDev D;
     D.parts = nullptr;
     if (!fastq) {
@@ -2211,14 +2225,91 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     return BSK_OK;
 }
 
+// `seq -n` / `seq -n -i` on FASTQ: the names leave from the streaming pass itself (stream_names.hip) -- per-range slices
+// sized from the header density of the shard head, one scan over the ranges, one gather.  BSK_ERR_FILTER_FALLBACK: a
+// slice was too small (or the estimate does not fit); the caller takes the record-table path.
+static int seq_names_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const int blocks = std::max(1, c->num_cus * names_max_blocks_per_cu(c->use_dpp));
+    uint32_t nranges = 0;
+    uint64_t chunk = 0;
+    int rc = prep_ranges(c, d_buf, n, /*fastq=*/true, blocks, st, &nranges, &chunk);
+    if (rc != BSK_OK) return rc;
+    const size_t hb = std::min<size_t>(n, 256 * 1024);
+    std::vector<uint8_t> head(hb);
+    HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    uint64_t hdr = 0, line = 0, line_start = 0;
+    for (size_t i = 0; i < hb; ++i)
+        if (head[i] == '\n') { if ((line & 3) == 0) hdr += i - line_start; ++line; line_start = i + 1; }
+    if ((line & 3) == 0) hdr += hb - line_start;  // a header cut by the end of the sample
+    double ratio = (double)(hdr + 64) / (double)hb;
+    if (const char* sc = getenv("BSK_NAMES_SCALE")) ratio *= atof(sc);  // tests: force the overflow -> fallback route
+    uint64_t slice_cap = (uint64_t)((double)chunk * ratio * 1.25) + (getenv("BSK_NAMES_SCALE") ? 16 : 4096);
+    slice_cap = (slice_cap + 15) & ~(uint64_t)15;
+    if (slice_cap >= (1ull << 32) || slice_cap * nranges > (uint64_t)n + (64ull << 20)) return BSK_ERR_FILTER_FALLBACK;
+    rc = grow(c, &c->d_slices, &c->slices_cap, slice_cap * nranges, 256);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_names_aux, &c->names_aux_cap, 2 * ((uint64_t)nranges + 2), 16);
+    if (rc != BSK_OK) return rc;
+    NamesDev D;
+    D.slices = c->d_slices;
+    D.slice_cap = slice_cap;
+    D.range_bytes = c->d_names_aux;
+    D.range_count = c->d_range_count;
+    D.status = c->d_status;
+    D.only_id = o.b("OnlyId") ? 1 : 0;
+    D.id_mode = id_mode_of(c);
+    uint64_t* d_count_base = c->d_names_aux + nranges + 2;
+    {
+        Timed t(c, "k_names", st);
+        HIP_TRYX(c, launch_names(c->use_dpp, blocks, d_buf, n, c->d_anchors,
+                                 nranges, reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1), D, st));
+    }
+    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st));
+    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st));
+    uint64_t total = 0, records = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&records, d_count_base + nranges, sizeof records, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_CAPACITY) {
+        status &= ~(uint64_t)ERR_CAPACITY;
+        HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (status == 0) return BSK_ERR_FILTER_FALLBACK;
+    }
+    if (status) return kernel_error_to_status(c, status);
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    if (total) HIP_TRYX(c, launch_names_compact(D, c->d_range_base, nranges, c->d_out, st));
+    c->table.n = 0;  // no record table was built for this shard
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = records;
+    return BSK_OK;
+}
+
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     out->d_data = nullptr;
     out->len = 0;
     out->records = 0;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    {
+        // names only, nothing that needs the sequence (length / quality filters, gap removal, letter validation): the
+        // streaming pass writes them (BSK_NAMES=off keeps the record-table path)
+        const char* nm = getenv("BSK_NAMES");
+        const bool explicit_alphabet = !(c->alphabet == AB_NONE || c->alphabet == AB_UNLIMIT);
+        if (fastq && n > 0 && o.b("Name") && !o.b("Seq") && !o.b("RemoveGaps") && o.i("MinLen") <= 0 && o.i("MaxLen") <= 0 &&
+            !(o.f("MinQual") > 0) && !(o.f("MaxQual") > 0) && !o.b("ValidateSeq") && !explicit_alphabet &&
+            (!o.b("OnlyId") || id_mode_of(c) != 2) && !(nm && strcmp(nm, "off") == 0)) {
+            const int rcn = seq_names_run(c, d_buf, n, st, out);
+            if (rcn != BSK_ERR_FILTER_FALLBACK) return rcn;
+        }
+    }
     int rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
-    const bool fastq = format == BSK_FORMAT_FASTQ;
     // ---- per-partition decisions of SeqTransform.Call (seq.go:94-125)
     Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);  // parser.t after the first record
     if (rc != BSK_OK) return rc;

@@ -1,0 +1,210 @@
+// ============================================================================
+// stream_names.hip -- `seq -n` (and `seq -n -i`) on FASTQ inside the streaming pass.
+//
+// SeqTransform.Call with only Name set prints head (or ID) + "\n" per record
+// (/root/reference/bigseqkit-lib/seq.go:143-175): nothing of the sequence is needed
+// beyond what SeqParser.Read checks (helper.go:252-311: line roles, len(seq) ==
+// len(qual)).  The record-end event of the skeleton knows the header line, so the
+// names leave from the pass itself -- no 24 B/record table, no size / scan / emit.
+// Every range writes into its own slice of a scratch buffer (sized from the header
+// density of the shard head); k_names_compact gathers the slices in range order
+// (= file order).  A slice that overflows raises ERR_CAPACITY and the caller takes
+// the record-table path.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "stream_core.cuh"
+#include "stream_names.hpp"
+#include "text.cuh"
+
+namespace bsk {
+
+namespace {
+
+using namespace stream;
+
+template <bool DPP>
+struct NamesSink {
+    static constexpr bool TILE_HOOK = false;
+    NamesDev D;
+    uint8_t* slice = nullptr;  // this range's output slice
+    uint32_t cursor = 0;       // bytes written to it so far (wave-uniform)
+    uint32_t nrec = 0;         // records seen in this range (wave-uniform)
+    uint32_t err = 0;
+    const uint8_t* lim = nullptr;  // one past the last byte of the shard
+
+    __device__ __forceinline__ void begin_range(uint32_t r) {
+        slice = D.slices + (uint64_t)r * D.slice_cap;
+        cursor = 0;
+        nrec = 0;
+    }
+
+    template <bool FASTQ, bool ALL>
+    __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
+                                          uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
+        static_assert(FASTQ && !ALL, "the names sink runs on the sparse FASTQ path");
+        const int lane = threadIdx.x & 63;
+        for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
+            const uint32_t e = e0 + lane;
+            const bool on = e < E;
+            const uint32_t s = HISTORY + (on ? e : 0);
+            const uint32_t rank = wb + e;
+            const uint32_t p = L.pos[s];
+            const uint64_t abs_next = tile_idx + (uint64_t)(uint32_t)(p - tile_rel) + 1;
+            const uint32_t role = rank & 3u;
+            const uint8_t* src = nullptr;
+            uint32_t m = 0;       // bytes to copy (the '\n' comes on top)
+            uint32_t olen = 0;    // m + 1 for a record end, else 0
+            if (on) {
+                // the structural validation of the stats / index kernels (strict 4-line FASTQ)
+                if (role == 1u) {
+                    if (next_char(L, s, abs_next, re, buf) != '+') err |= ERR_BAD_PLUS;
+                } else if (role == 0u) {
+                    if (next_char(L, s, abs_next, re, buf) == '+') err |= ERR_BAD_PLUS;
+                } else if (role == 3u) {
+                    const uint32_t p1 = L.pos[s - 1], p2 = L.pos[s - 2], p3 = L.pos[s - 3], p4 = L.pos[s - 4];
+                    const uint32_t lq = p - p1 - 1u, ls = p2 - p3 - 1u, lh = p3 - p4 - 1u;
+                    if (lq != ls) err |= ERR_LEN_MISMATCH;
+                    if (abs_next < re && next_char(L, s, abs_next, re, buf) != '@') err |= ERR_BAD_HEADER;
+                    const uint8_t* h = buf + abs_of(p4, tile_idx, tile_rel) + 2;  // the header without its marker
+                    m = lh ? lh - 1u : 0u;
+                    src = h;
+                    if (D.only_id) {
+                        uint32_t off = 0;
+                        m = id_span_of(h, m, D.id_mode, &off, lim);
+                        src = h + off;
+                    }
+                    olen = m + 1u;
+                }
+            }
+            const uint32_t incl = wave_incl_scan<DPP>(olen);
+            const uint32_t tot = wave_last(incl);
+            if (olen) {
+                const uint32_t at = cursor + incl - olen;
+                if ((uint64_t)at + olen <= D.slice_cap) {
+                    uint8_t* dst = slice + at;
+                    uint32_t i = 0;
+                    for (; i + 16u <= m; i += 16u) {
+                        uint4 v;
+                        __builtin_memcpy(&v, src + i, 16);
+                        __builtin_memcpy(dst + i, &v, 16);
+                    }
+                    if (m & 8u) {
+                        uint2 v;
+                        __builtin_memcpy(&v, src + i, 8);
+                        __builtin_memcpy(dst + i, &v, 8);
+                        i += 8u;
+                    }
+                    if (m & 4u) {
+                        uint32_t v;
+                        __builtin_memcpy(&v, src + i, 4);
+                        __builtin_memcpy(dst + i, &v, 4);
+                        i += 4u;
+                    }
+                    if (m & 2u) {
+                        uint16_t v;
+                        __builtin_memcpy(&v, src + i, 2);
+                        __builtin_memcpy(dst + i, &v, 2);
+                        i += 2u;
+                    }
+                    if (m & 1u) { dst[i] = src[i]; }
+                    dst[m] = (uint8_t)'\n';
+                } else {
+                    err |= ERR_CAPACITY;
+                }
+            }
+            cursor += tot;
+            nrec += (uint32_t)__popcll(__ballot(olen != 0u));
+        }
+    }
+};
+
+template <bool DPP>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges,
+             uint32_t* __restrict__ queue, NamesDev D) {
+    __shared__ Lds<true, false> s_l[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    Lds<true, false>& L = s_l[wave];
+    NamesSink<DPP> sink;
+    sink.D = D;
+    sink.lim = buf + n;
+    PredConsts P;  // unused (sparse path)
+    P.k20 = P.k30 = 0;
+    P.ngap = 0;
+    const uint64_t n_eff = anchors[nranges];
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(queue, 1u);
+        r = wave_first(r);
+        if (r >= nranges) break;
+        uint64_t rs = anchors[r], re = anchors[r + 1];
+        rs = rs < n_eff ? rs : n_eff;
+        re = re < n_eff ? re : n_eff;
+        if (rs >= re) {
+            if (lane == 0) { D.range_bytes[r] = 0; D.range_count[r] = 0; }
+            continue;
+        }
+        sink.begin_range(r);
+        stream_range<true, false, DPP>(L, buf, n, rs, re, re == n_eff, P, sink);
+        if (lane == 0) { D.range_bytes[r] = sink.cursor; D.range_count[r] = sink.nrec; }
+    }
+    const uint32_t err = wave_or_u32(sink.err);
+    if (lane == 0 && err) atomicOr((unsigned long long*)&D.status[0], (unsigned long long)err);
+}
+
+// slices -> one text: block (r, k) copies the k-th 16 KiB of range r's slice to its place.  A slice begins 16-byte
+// aligned, its destination anywhere: aligned 16-byte loads, unaligned 16-byte stores.
+constexpr uint32_t COMPACT_CHUNK = 16384;
+
+__global__ __launch_bounds__(256) void k_names_compact(const uint8_t* __restrict__ slices, uint64_t slice_cap,
+                                                       const uint64_t* __restrict__ range_bytes,
+                                                       const uint64_t* __restrict__ range_base, uint32_t chunks_per_range,
+                                                       uint8_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x / chunks_per_range;
+    const uint32_t k = blockIdx.x % chunks_per_range;
+    const uint64_t nb = range_bytes[r];
+    const uint64_t c0 = (uint64_t)k * COMPACT_CHUNK;
+    if (c0 >= nb) return;
+    const uint64_t c1 = c0 + COMPACT_CHUNK < nb ? c0 + COMPACT_CHUNK : nb;
+    const uint8_t* src = slices + (uint64_t)r * slice_cap;
+    uint8_t* dst = out + range_base[r];
+    for (uint64_t i = c0 + 16ull * threadIdx.x; i < c1; i += 16ull * 256) {
+        if (i + 16 <= c1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+            __builtin_memcpy(dst + i, &v, 16);
+        } else {
+            for (uint64_t j = i; j < c1; ++j) dst[j] = src[j];
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_names(bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors, uint32_t nranges,
+                        uint32_t* queue, const NamesDev& D, hipStream_t st) {
+    const dim3 b(WAVES_PER_BLOCK * WAVE);
+    if (dpp) hipLaunchKernelGGL((k_names<true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+    else hipLaunchKernelGGL((k_names<false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+    return hipGetLastError();
+}
+
+int names_max_blocks_per_cu(bool dpp) {
+    int nb = 0;
+    const void* f = dpp ? (const void*)k_names<true> : (const void*)k_names<false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+hipError_t launch_names_compact(const NamesDev& D, const uint64_t* range_base, uint32_t nranges, uint8_t* out, hipStream_t st) {
+    const uint32_t cpr = (uint32_t)((D.slice_cap + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+    if (nranges == 0 || cpr == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_names_compact, dim3(nranges * cpr), dim3(256), 0, st, D.slices, D.slice_cap, D.range_bytes, range_base,
+                       cpr, out);
+    return hipGetLastError();
+}
+
+}  // namespace bsk
