@@ -220,6 +220,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_redo) hipFree(c->d_redo);
         if (c->d_out_alt) hipFree(c->d_out_alt);
         if (c->d_slices) hipFree(c->d_slices);
+        if (c->d_seg_src) hipFree(c->d_seg_src);
+        if (c->d_seg_first) hipFree(c->d_seg_first);
         if (c->d_names_aux) hipFree(c->d_names_aux);
         if (c->d_id_prog) hipFree(c->d_id_prog);
         if (c->d_vm_progs) hipFree(c->d_vm_progs);

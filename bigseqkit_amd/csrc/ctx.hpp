@@ -73,6 +73,10 @@ struct bsk_ctx {
     uint64_t out_cap = 0;
     uint8_t* d_out_alt = nullptr;       // second output buffer of bsk_run_to_store (drained while the next chunk computes)
     uint64_t out_alt_cap = 0;
+    uint64_t* d_seg_src = nullptr;      // segmented copy (ops_segcopy.hip): source address per record (+ one counter)
+    uint64_t seg_src_cap = 0;
+    uint32_t* d_seg_first = nullptr;    // ... and the segment of the first byte of every 4 KiB output tile
+    uint64_t seg_first_cap = 0;
     uint8_t* d_slices = nullptr;        // per-range output slices of the names pass (stream_names.hip)
     uint64_t slices_cap = 0;
     uint64_t* d_names_aux = nullptr;    // [2 * (nranges + 2)]: bytes per range, scanned record counts

@@ -27,6 +27,7 @@
 #include "ops_rmdup.hpp"
 #include "ops_text.hpp"
 #include "ops_translate.hpp"
+#include "ops_segcopy.hpp"
 #include "ops_seq.hpp"
 #include "ops_sort.hpp"
 #include "stream_filter.hpp"
@@ -412,6 +413,38 @@ int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
 }
 
 // tell the emit kernel which records it must leave to the block-per-chunk launch
+int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& Pin, uint64_t total, uint64_t kept, hipStream_t st) {
+    SeqParams P = Pin;
+    P.seg_src = nullptr;
+    const RecordTable& t = c->table;
+    const char* env = getenv("BSK_SEGCOPY");  // off: never; force: whenever the records qualify (tests)
+    const bool verbatim = P.fastq && !P.fasta_out && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id &&
+                          !P.reverse && !P.use_lut && !P.region_on && !P.feat_on && !P.remove_gaps && !P.ren_ord;
+    bool seg = verbatim && t.n > 0 && total > 0 && !(env && strcmp(env, "off") == 0);
+    if (seg && !(env && strcmp(env, "force") == 0)) seg = kept * 2 >= t.n && total >= (4u << 20);
+    if (seg) {
+        int rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+        if (rc != BSK_OK) return rc;
+        uint64_t* d_other = c->d_seg_src + t.n;
+        HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, c->d_out_len, c->d_seg_src, d_other, st));
+        HIP_TRYX(c, launch_seg_first(c->d_out_off, t.n, c->d_seg_first, st));
+        {
+            Timed tm(c, "k_seg_copy", st);
+            HIP_TRYX(c, launch_seg_copy(c->d_seg_src, c->d_out_off, t.n, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st));
+        }
+        uint64_t other = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (other == 0) return BSK_OK;
+        P.seg_src = c->d_seg_src;  // the few records the copy left out
+    }
+    HIP_TRYX(c, launch_seq_emit(d_buf, t, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    return BSK_OK;
+}
+
 void apply_long(const bsk_ctx* c, SeqParams* P) {
     P->long_list = c->long_count ? c->d_long_list : nullptr;
     P->long_count = c->long_count;
@@ -1060,7 +1093,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     SeqParams P = format_params(c, fastq);
     P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
     apply_long(c, &P);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -1613,7 +1646,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     apply_long(c, &P);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -2040,7 +2073,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     SeqParams F = format_params(c, fastq);
     F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
     apply_long(c, &F);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -2396,7 +2429,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     apply_long(c, &P);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;

@@ -58,6 +58,9 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
 // size array -> scan -> total / kept / kernel status (also lists the records with a very large output)
 int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept);
 void apply_long(const bsk_ctx* c, SeqParams* P);
+// the emit step of size -> scan -> emit into c->d_out (sizes in c->d_out_len / c->d_out_off): FASTQ records that leave
+// unchanged go through the segmented copy when most records have output, everything else through k_seq_emit
+int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, uint64_t total, uint64_t kept, hipStream_t st);
 int empty_result(bsk_ctx* c, bsk_out* out);
 // SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
 SeqParams format_params(bsk_ctx* c, bool fastq);

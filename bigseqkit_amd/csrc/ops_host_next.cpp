@@ -134,7 +134,7 @@ int fq2fa_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     apply_long(c, &P);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -295,7 +295,7 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return fail(rc);
     apply_long(c, &F);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }
     cleanup();
     out->d_data = c->d_out;
     out->len = total;
@@ -417,7 +417,7 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return fail(rc);
     apply_long(c, &F);
-    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess) return fail(BSK_ERR_HIP);
+    if (emit_records(c, d_buf, n, F, total, kept, st) != BSK_OK) return fail(BSK_ERR_HIP);
     cleanup();
     out->d_data = c->d_out;
     out->len = total;
@@ -758,7 +758,7 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     apply_long(c, &F);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
@@ -908,7 +908,7 @@ int faidx_query_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int forma
         rc = ensure_out(c, total);
         if (rc != BSK_OK) return rc;
         apply_long(c, &P);
-        HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+        { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
         out->d_data = c->d_out;
         out->len = total;
         out->records = kept;
@@ -931,7 +931,7 @@ int faidx_query_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int forma
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     apply_long(c, &P);
-    HIP_TRYX(c, launch_seq_emit(d_buf, c->table, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;

@@ -1,0 +1,29 @@
+// Segmented copy: the output text is a sequence of segments, segment k = `seg_off[k + 1] - seg_off[k]` bytes copied
+// verbatim from the absolute device address seg_src[k] (0: someone else writes these bytes).  Driven by the OUTPUT -- one
+// wave per 4 KiB of it, aligned 16-byte stores, unaligned 16-byte loads -- so the stores are full lines whatever the
+// record size (ops_segcopy.hip).  Used for the operators whose output records are byte-for-byte copies of input records
+// (FASTQ records that Format() reproduces exactly: seq, grep, rmdup, pair, common ...; bigseqkit-lib/seq.go:176-269).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "index.hpp"
+
+namespace bsk {
+
+constexpr uint32_t SEG_TILE = 4096;  // output bytes per wave
+
+inline uint64_t seg_tiles(uint64_t total) { return (total + SEG_TILE - 1) / SEG_TILE; }
+
+// seg_src of the records of a FASTQ table whose output (out_len[i] != 0 bytes at out_off[i]) is the record text itself:
+// bare '+' line, and the text incl. its final newline lies inside the shard.  Other records with output get 0 and are
+// counted in *n_other (they stay with the record-wise emit kernel).
+hipError_t launch_seg_build_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                  uint64_t* seg_src, uint64_t* n_other, hipStream_t st);
+// first4k[T] = the segment that holds output byte T * SEG_TILE (T < seg_tiles(total))
+hipError_t launch_seg_first(const uint64_t* seg_off, uint64_t nseg, uint32_t* first4k, hipStream_t st);
+hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
+                           uint8_t* out, uint64_t total, const uint8_t* lo, const uint8_t* hi, hipStream_t st);
+
+}  // namespace bsk

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
     if (g >= t.n) return;
     const uint32_t n = out_len[g];
     if (n == 0) return;
+    if (P.seg_src && P.seg_src[g]) return;                      // written by k_seg_copy
     if (!LONG && P.long_thresh && n >= P.long_thresh) return;  // written by the LONG launch
     const uint32_t clo = LONG ? blockIdx.x * LONG_CH : 0u;       // this block's slice [clo, chi) of the record's output
     if (clo >= n) return;

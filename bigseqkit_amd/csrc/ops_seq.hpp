@@ -57,6 +57,8 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     const uint32_t* long_list;              // their indices (launch_find_long), or null
     uint64_t long_count, long_max;          // how many, and the largest output size
     uint32_t long_thresh;                   // output bytes from which a record is 'long' (0: none are)
+    // records whose output is written by the segmented copy (ops_segcopy.hip): seg_src[i] != 0; null = none
+    const uint64_t* seg_src;
 };
 
 constexpr uint32_t SEQ_LONG_THRESH = 1u << 20;  // output bytes from which a record is 'long'

@@ -19,6 +19,13 @@
 #include "stream_names.hpp"
 #include "text.cuh"
 
+#ifndef BSK_NAMES_EXP
+#define BSK_NAMES_EXP 0
+#endif
+#ifndef BSK_NAMES_WAVES
+#define BSK_NAMES_WAVES 7
+#endif
+
 namespace bsk {
 
 namespace {
@@ -85,32 +92,80 @@ struct NamesSink {
                 const uint32_t at = cursor + incl - olen;
                 if ((uint64_t)at + olen <= D.slice_cap) {
                     uint8_t* dst = slice + at;
-                    uint32_t i = 0;
-                    for (; i + 16u <= m; i += 16u) {
-                        uint4 v;
-                        __builtin_memcpy(&v, src + i, 16);
-                        __builtin_memcpy(dst + i, &v, 16);
+#if BSK_NAMES_EXP == 1   // experiment: no loads
+                    { uint4 z = {at, at, at, at}; if (m >= 8) __builtin_memcpy(dst, &z, 8); dst[m] = '\n'; }
+#elif BSK_NAMES_EXP == 2  // experiment: no loads, no stores
+                    if (at == 0xFFFFFFF0u) dst[0] = 1;
+#elif BSK_NAMES_EXP == 3  // experiment: the same number of loads and stores, but bunched into every 8th tile
+                    if (((tile_idx >> 12) & 7u) == 0u) {
+                        for (int rep = 0; rep < 8; ++rep) {
+                            uint32_t w[4];
+                            __builtin_memcpy(w, src + rep, 16);
+                            __builtin_memcpy(dst + rep, w, 8);
+                            __builtin_memcpy(dst + rep + 8, &w[2], 4);
+                        }
                     }
-                    if (m & 8u) {
-                        uint2 v;
-                        __builtin_memcpy(&v, src + i, 8);
-                        __builtin_memcpy(dst + i, &v, 8);
-                        i += 8u;
+#else
+                    if (olen <= 16u && src + 16 <= lim) {
+                        // one 16-byte load; the '\n' is put at byte m in registers (it IS byte m of the text for a whole
+                        // head), then 8 / 4 / 2 / 1-byte stores of exactly olen bytes (neighbouring lanes own the rest)
+                        uint32_t w[4];
+                        __builtin_memcpy(w, src, 16);
+                        if (D.only_id) {
+                            const uint32_t sh = (m & 3u) * 8u;
+                            const uint32_t d = m >> 2;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (d == (uint32_t)q) w[q] = (w[q] & ~(0xFFu << sh)) | (0x0Au << sh);
+                        }
+                        uint32_t q = 0;  // dwords consumed
+                        if (olen & 16u) { __builtin_memcpy(dst, w, 16); }
+                        if (olen & 8u) { __builtin_memcpy(dst, w, 8); q = 2; }
+                        if (olen & 4u) {
+                            const uint32_t v = q ? w[2] : w[0];
+                            __builtin_memcpy(dst + 4u * q, &v, 4);
+                            q += 1;
+                        }
+                        if (olen & 3u) {
+                            const uint32_t v = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
+                            uint8_t* d2 = dst + 4u * q;
+                            if (olen & 2u) {
+                                const uint16_t h2 = (uint16_t)v;
+                                __builtin_memcpy(d2, &h2, 2);
+                                if (olen & 1u) d2[2] = (uint8_t)(v >> 16);
+                            } else {
+                                d2[0] = (uint8_t)v;
+                            }
+                        }
+                    } else {
+                        uint32_t i = 0;
+                        for (; i + 16u <= m; i += 16u) {
+                            uint4 v;
+                            __builtin_memcpy(&v, src + i, 16);
+                            __builtin_memcpy(dst + i, &v, 16);
+                        }
+                        if (m & 8u) {
+                            uint2 v;
+                            __builtin_memcpy(&v, src + i, 8);
+                            __builtin_memcpy(dst + i, &v, 8);
+                            i += 8u;
+                        }
+                        if (m & 4u) {
+                            uint32_t v;
+                            __builtin_memcpy(&v, src + i, 4);
+                            __builtin_memcpy(dst + i, &v, 4);
+                            i += 4u;
+                        }
+                        if (m & 2u) {
+                            uint16_t v;
+                            __builtin_memcpy(&v, src + i, 2);
+                            __builtin_memcpy(dst + i, &v, 2);
+                            i += 2u;
+                        }
+                        if (m & 1u) { dst[i] = src[i]; }
+                        dst[m] = (uint8_t)'\n';
                     }
-                    if (m & 4u) {
-                        uint32_t v;
-                        __builtin_memcpy(&v, src + i, 4);
-                        __builtin_memcpy(dst + i, &v, 4);
-                        i += 4u;
-                    }
-                    if (m & 2u) {
-                        uint16_t v;
-                        __builtin_memcpy(&v, src + i, 2);
-                        __builtin_memcpy(dst + i, &v, 2);
-                        i += 2u;
-                    }
-                    if (m & 1u) { dst[i] = src[i]; }
-                    dst[m] = (uint8_t)'\n';
+#endif
                 } else {
                     err |= ERR_CAPACITY;
                 }
@@ -122,7 +177,7 @@ struct NamesSink {
 };
 
 template <bool DPP>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(7, 8)))
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_NAMES_WAVES, 8)))
 void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges,
              uint32_t* __restrict__ queue, NamesDev D) {
     __shared__ Lds<true, false> s_l[WAVES_PER_BLOCK];
