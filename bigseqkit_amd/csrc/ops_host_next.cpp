@@ -417,7 +417,8 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return fail(rc);
     apply_long(c, &F);
-    if (emit_records(c, d_buf, n, F, total, kept, st) != BSK_OK) return fail(BSK_ERR_HIP);
+    // (offsets follow the SORTED order, not the record order: the record-wise emit, not the segmented copy)
+    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess) return fail(BSK_ERR_HIP);
     cleanup();
     out->d_data = c->d_out;
     out->len = total;
