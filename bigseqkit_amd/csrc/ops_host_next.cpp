@@ -21,6 +21,7 @@
 #include "ops_grep.hpp"
 #include "ops_group.hpp"
 #include "ops_records.hpp"
+#include "ops_segcopy.hpp"
 #include "ops_rmdup.hpp"
 #include "ops_seq.hpp"
 #include "ops_sort.hpp"
@@ -183,9 +184,28 @@ int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, h
     if (total == 0) return BSK_OK;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    rc = grow(c, &c->d_tile_first, &c->tile_first_cap, records_copy_tiles(total), 64);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_records_copy(d_buf, c->table, P, c->d_out_off, c->d_tile_first, c->d_out, total, st));
+    const char* sg = getenv("BSK_SEGCOPY");
+    if (P.times == 1 && !(sg && strcmp(sg, "off") == 0)) {
+        // range / head: the kept records are verbatim segments of the shard (ops_segcopy.hip)
+        const RecordTable& t = c->table;
+        rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+        if (rc != BSK_OK) return rc;
+        uint64_t* d_other = c->d_seg_src + t.n;
+        HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_seg_build_text(d_buf, n, t, c->d_out_len, c->d_seg_src, d_other, st));
+        HIP_TRYX(c, launch_seg_first(c->d_out_off, t.n, c->d_seg_first, st));
+        HIP_TRYX(c, launch_seg_copy(c->d_seg_src, c->d_out_off, t.n, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st));
+        uint64_t other = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (other) HIP_TRYX(c, launch_seg_fix_text(d_buf, t, c->d_out_len, c->d_out_off, c->d_seg_src, c->d_out, st));
+    } else {
+        rc = grow(c, &c->d_tile_first, &c->tile_first_cap, records_copy_tiles(total), 64);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_records_copy(d_buf, c->table, P, c->d_out_off, c->d_tile_first, c->d_out, total, st));
+    }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept * P.times;

@@ -23,6 +23,37 @@ __global__ __launch_bounds__(256) void k_seg_build_fastq(const uint8_t* __restri
     seg_src[i] = s;
 }
 
+// whole-record operators (range / head): the element is the record text, written back followed by '\n' -- a verbatim
+// segment when that newline is the byte after the text in the shard (always, except for a last record without one)
+__global__ __launch_bounds__(256) void k_seg_build_text(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+                                                        const uint32_t* __restrict__ out_len, uint64_t* __restrict__ seg_src,
+                                                        unsigned long long* __restrict__ n_other) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t n = out_len[i];
+    uint64_t s = 0;
+    if (n) {
+        const uint64_t st = t.start[i];
+        if (st + n <= buf_n && buf[st + n - 1] == '\n') s = (uint64_t)(uintptr_t)(buf + st);
+        else atomicAdd(n_other, 1ull);
+    }
+    seg_src[i] = s;
+}
+
+// the records k_seg_build_text left out: text + '\n', byte by byte (one thread per record; there is at most one)
+__global__ __launch_bounds__(256) void k_seg_fix_text(const uint8_t* __restrict__ buf, RecordTable t, const uint32_t* __restrict__ out_len,
+                                                      const uint64_t* __restrict__ out_off, const uint64_t* __restrict__ seg_src,
+                                                      uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t n = out_len[i];
+    if (n == 0 || seg_src[i] != 0) return;
+    const uint8_t* s = buf + t.start[i];
+    uint8_t* o = out + out_off[i];
+    for (uint32_t k = 0; k + 1 < n; ++k) o[k] = s[k];
+    o[n - 1] = (uint8_t)'\n';
+}
+
 __global__ __launch_bounds__(256) void k_seg_first(const uint64_t* __restrict__ seg_off, uint64_t nseg, uint32_t* __restrict__ first4k) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nseg) return;
@@ -180,6 +211,21 @@ hipError_t launch_seg_build_fastq(const uint8_t* buf, uint64_t buf_n, const Reco
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_seg_build_fastq, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, out_len, seg_src,
                        (unsigned long long*)n_other);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_build_text(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                 uint64_t* seg_src, uint64_t* n_other, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_build_text, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, out_len, seg_src,
+                       (unsigned long long*)n_other);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_fix_text(const uint8_t* buf, const RecordTable& t, const uint32_t* out_len, const uint64_t* out_off,
+                               const uint64_t* seg_src, uint8_t* out, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_fix_text, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, out_len, out_off, seg_src, out);
     return hipGetLastError();
 }
 

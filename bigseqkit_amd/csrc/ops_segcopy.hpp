@@ -21,6 +21,12 @@ inline uint64_t seg_tiles(uint64_t total) { return (total + SEG_TILE - 1) / SEG_
 // counted in *n_other (they stay with the record-wise emit kernel).
 hipError_t launch_seg_build_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
                                   uint64_t* seg_src, uint64_t* n_other, hipStream_t st);
+// range / head: out_len[i] = text + 1; verbatim when the byte after the text is the '\n' (else counted in *n_other and
+// written by launch_seg_fix_text)
+hipError_t launch_seg_build_text(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                 uint64_t* seg_src, uint64_t* n_other, hipStream_t st);
+hipError_t launch_seg_fix_text(const uint8_t* buf, const RecordTable& t, const uint32_t* out_len, const uint64_t* out_off,
+                               const uint64_t* seg_src, uint8_t* out, hipStream_t st);
 // first4k[T] = the segment that holds output byte T * SEG_TILE (T < seg_tiles(total))
 hipError_t launch_seg_first(const uint64_t* seg_off, uint64_t nseg, uint32_t* first4k, hipStream_t st);
 hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
