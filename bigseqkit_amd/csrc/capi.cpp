@@ -220,6 +220,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_redo) hipFree(c->d_redo);
         if (c->d_out_alt) hipFree(c->d_out_alt);
         if (c->d_slices) hipFree(c->d_slices);
+        if (c->d_norm) hipFree(c->d_norm);
         if (c->d_seg_src) hipFree(c->d_seg_src);
         if (c->d_seg_first) hipFree(c->d_seg_first);
         if (c->d_names_aux) hipFree(c->d_names_aux);
@@ -355,6 +356,8 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     return BSK_OK;
 }
 
+static int stage_shard(bsk_ctx* c, const void* shard, size_t n, int on_device, hipStream_t st, const uint8_t** d);
+
 int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* d_vec,
                   void* stream) {
     if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
@@ -376,6 +379,23 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
         else memcpy(c->first_bytes.data(), shard, want);
         c->first_pid = pid;
         c->first_format = format;
+        c->fastq_multiline = format == BSK_FORMAT_FASTQ && fastq_head_multiline(c->first_bytes.data(), c->first_bytes.size());
+    }
+    if (c->fastq_multiline && format == BSK_FORMAT_FASTQ) {
+        // records wrapped over several lines (helper.go:252-269): the whole shard is rewritten as 4-line FASTQ first
+        const uint8_t* d = nullptr;
+        int rc = stage_shard(c, shard, n, on_device, st, &d);
+        if (rc != BSK_OK) return rc;
+        const uint8_t* d2 = nullptr;
+        size_t n2 = 0;
+        rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
+        if (rc != BSK_OK) return rc;
+        if (pid == c->first_pid) {  // the type guess and Take(1) read the first record of the 4-line text
+            const size_t want = std::min(c->first_bytes.size(), n2);
+            c->first_bytes.resize(want);
+            HIP_TRY(c, hipMemcpy(c->first_bytes.data(), d2, want, hipMemcpyDeviceToHost));
+        }
+        return stats_run_device(c, d2, n2, format, (uint64_t*)d_vec, st);
     }
     if (on_device) return stats_run_device(c, (const uint8_t*)shard, n, format, (uint64_t*)d_vec, st);
 
@@ -677,6 +697,32 @@ int bsk_out_to_host(bsk_ctx* c, const bsk_out* out, void* dst, size_t cap) {
     return BSK_OK;
 }
 
+typedef int (*run_fn)(bsk_ctx*, const uint8_t*, size_t, int, hipStream_t, bsk_out*);
+
+// BSK_ERR_MULTILINE_FASTQ from an operator that cannot take the rewritten text
+static int multiline_unsupported(bsk_ctx* c) {
+    return fail(c, BSK_ERR_UNSUPPORTED,
+                "libbsk: multi-line FASTQ is not provided for this operator (range / head / duplicate print the record text as "
+                "it is; pair / common / concat and the multi-GPU rmdup take record-aligned pieces of several texts)");
+}
+
+// runs fn; when the head of a FASTQ shard shows records wrapped over several lines (helper.go:252-269), on the shard
+// rewritten as strict 4-line FASTQ
+static int run_maybe_multiline(bsk_ctx* c, run_fn fn, const uint8_t* d, size_t n, int format, hipStream_t st, bsk_out* out) {
+    int rc = fn(c, d, n, format, st, out);
+    if (rc != BSK_ERR_MULTILINE_FASTQ) return rc;
+    if (c->op == Op::Range || c->op == Op::Head || c->op == Op::Duplicate) return multiline_unsupported(c);
+    const uint8_t* d2 = nullptr;
+    size_t n2 = 0;
+    rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
+    if (rc != BSK_OK) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    c->norm_active = true;
+    rc = fn(c, d2, n2, format, st, out);
+    c->norm_active = false;
+    return rc;
+}
+
 int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, void* stream,
                     uint64_t* n_records) {
     int rc = check_run_args(c, shard, n, format);
@@ -688,6 +734,15 @@ int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int 
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
     rc = build_index(c, d, n, format, st);
+    if (rc == BSK_ERR_MULTILINE_FASTQ) {  // the table then describes the rewritten text (c->d_norm), not the caller's
+        const uint8_t* d2 = nullptr;
+        size_t n2 = 0;
+        rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
+        if (rc != BSK_OK) return rc;
+        c->norm_active = true;
+        rc = build_index(c, d2, n2, format, st);
+        c->norm_active = false;
+    }
     if (rc != BSK_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(st));
     uint64_t status = 0;
@@ -724,10 +779,9 @@ int bsk_seq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int form
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    return seq_run_device(c, d, n, format, st, out);
+    return run_maybe_multiline(c, seq_run_device, d, n, format, st, out);
 }
 
-typedef int (*run_fn)(bsk_ctx*, const uint8_t*, size_t, int, hipStream_t, bsk_out*);
 static int run_record_op(bsk_ctx* c, Op want, const char* what, run_fn fn, const void* shard, size_t n, int on_device,
                          int format, void* stream, bsk_out* out) {
     int rc = check_run_args(c, shard, n, format);
@@ -739,7 +793,7 @@ static int run_record_op(bsk_ctx* c, Op want, const char* what, run_fn fn, const
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    return fn(c, d, n, format, st, out);
+    return run_maybe_multiline(c, fn, d, n, format, st, out);
 }
 
 int bsk_grep_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
@@ -779,7 +833,10 @@ int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int 
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    return concat_run_device(c, d, n, n_first, format, st, out);
+    {
+        const int rcm = concat_run_device(c, d, n, n_first, format, st, out);
+        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
+    }
 }
 
 int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file_ends, uint32_t n_files, int on_device,
@@ -794,7 +851,10 @@ int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    return common_run_device(c, d, n, file_ends, n_files, format, st, out);
+    {
+        const int rcm = common_run_device(c, d, n, file_ends, n_files, format, st, out);
+        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
+    }
 }
 
 int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
@@ -808,7 +868,10 @@ int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    return pair_run_device(c, d, n, n_first, format, st, outs);
+    {
+        const int rcm = pair_run_device(c, d, n, n_first, format, st, outs);
+        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
+    }
 }
 
 int bsk_faidx_query_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
@@ -902,7 +965,10 @@ int bsk_rmdup_dist_keys(bsk_ctx* c, const void* d_shard, size_t n, int format, v
     if (rc != BSK_OK) return rc;
     if (!n_records) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_records");
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), (hipStream_t)stream));
-    return rmdup_dist_keys(c, (const uint8_t*)d_shard, n, format, (hipStream_t)stream, n_records);
+    {
+        const int rcm = rmdup_dist_keys(c, (const uint8_t*)d_shard, n, format, (hipStream_t)stream, n_records);
+        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
+    }
 }
 
 int bsk_rmdup_dist_pack(bsk_ctx* c, uint64_t base_index, int world, void* d_send, uint64_t* counts, void* stream) {

@@ -73,6 +73,10 @@ struct bsk_ctx {
     uint64_t out_cap = 0;
     uint8_t* d_out_alt = nullptr;       // second output buffer of bsk_run_to_store (drained while the next chunk computes)
     uint64_t out_alt_cap = 0;
+    uint8_t* d_norm = nullptr;          // a multi-line FASTQ shard rewritten as 4-line FASTQ (ops_mlfq.hip)
+    uint64_t norm_cap = 0;
+    bool norm_active = false;           // the operator is running on d_norm
+    bool fastq_multiline = false;       // stats: the head of the lowest shard showed wrapped records
     uint64_t* d_seg_src = nullptr;      // segmented copy (ops_segcopy.hip): source address per record (+ one counter)
     uint64_t seg_src_cap = 0;
     uint32_t* d_seg_first = nullptr;    // ... and the segment of the first byte of every 4 KiB output tile

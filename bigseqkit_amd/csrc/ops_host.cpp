@@ -23,6 +23,7 @@
 #include "ops_grep.hpp"
 #include "ops_group.hpp"
 #include "ops_locate.hpp"
+#include "ops_mlfq.hpp"
 #include "ops_records.hpp"
 #include "ops_rmdup.hpp"
 #include "ops_text.hpp"
@@ -187,6 +188,7 @@ int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
         std::vector<uint8_t> head(hb);
         HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
+        if (fastq && !c->norm_active && fastq_head_multiline(head.data(), hb)) return BSK_ERR_MULTILINE_FASTQ;
         uint64_t recs = 0;
         if (fastq) { for (size_t i = 0; i < hb; ++i) recs += head[i] == '\n'; recs /= 4; }
         else { for (size_t i = 0; i + 1 < hb; ++i) recs += (head[i] == '\n' && head[i + 1] == '>'); recs += 1; }
@@ -2258,6 +2260,147 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     return BSK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// multi-line FASTQ (SeqParser.Read accepts it, helper.go:252-269; the streaming kernels read strict 4-line records)
+// ---------------------------------------------------------------------------
+// true when a COMPLETE record in the sample has its sequence or its quality on more than one line (FASTQ grammar of
+// PARITY.md SPLIT-FQ); a sample of strict 4-line records, or one that cannot be judged, gives false
+bool fastq_head_multiline(const uint8_t* h, size_t hb) {
+    size_t p = 0;
+    auto line_end = [&](size_t s) { while (s < hb && h[s] != '\n') ++s; return s; };
+    while (p < hb && h[p] == '@') {
+        size_t e = line_end(p);
+        if (e >= hb) return false;
+        size_t cur = e + 1, seqlen = 0, quallen = 0, seqlines = 0, quallines = 0;
+        bool isq = false;
+        for (;;) {
+            if (cur >= hb) return false;  // the sample ends inside this record
+            const size_t le = line_end(cur);
+            if (le >= hb) return false;
+            const size_t k = le - cur;
+            if (!isq) {
+                if (k > 0 && h[cur] == '+') isq = true;
+                else { seqlen += k; ++seqlines; }
+            } else {
+                quallen += k;
+                ++quallines;
+            }
+            cur = le + 1;
+            if (isq && quallines && quallen >= seqlen) break;
+            if (isq && quallines && cur < hb && h[cur] == '@') break;
+        }
+        if (quallen != seqlen) return false;  // malformed either way: the strict path reports it
+        if (seqlines != 1 || quallines != 1) return true;
+        p = cur;
+    }
+    return false;
+}
+
+namespace {
+struct DevFree {
+    std::vector<void*> p;
+    ~DevFree() { for (void* q : p) if (q) hipFree(q); }
+    template <class T> hipError_t alloc(T** out, uint64_t count) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, std::max<uint64_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) p.push_back(q);
+        *out = (T*)q;
+        return e;
+    }
+};
+}  // namespace
+
+// the shard rewritten as strict 4-line FASTQ into c->d_norm (ops_mlfq.hip).  A rare path: scratch is allocated and
+// freed per call (about 0.6 bytes per input byte for text wrapped at 60 columns).
+int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out) {
+    *d_out = d_buf;
+    *n_out = n;
+    if (n == 0) return BSK_OK;
+    DevFree F;
+    const uint64_t nb = mlfq_blocks(n);
+    uint32_t* d_cnt = nullptr;
+    uint64_t *d_base = nullptr, *d_tmp = nullptr;
+    HIP_TRYX(c, F.alloc(&d_cnt, nb));
+    HIP_TRYX(c, F.alloc(&d_base, nb + 1));
+    HIP_TRYX(c, F.alloc(&d_tmp, 2 * ((nb + 2047) / 2048) + 4));
+    HIP_TRYX(c, launch_nl_count(d_buf, n, d_cnt, st));
+    HIP_TRYX(c, launch_scan_u32(d_cnt, d_base, nb, d_tmp, st));
+    uint64_t nnl = 0;
+    uint8_t last = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&nnl, d_base + nb, sizeof nnl, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&last, d_buf + n - 1, 1, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    const bool ends_nl = last == '\n';
+    const uint64_t L64 = nnl + (ends_nl ? 0 : 1);
+    if (L64 >= 0xFFFFFFF0ull) { c->set_error("libbsk: multi-line FASTQ with 2^32 or more lines in one shard"); return BSK_ERR_UNSUPPORTED; }
+    const uint32_t L = (uint32_t)L64;
+    uint64_t* d_ls = nullptr;
+    HIP_TRYX(c, F.alloc(&d_ls, L64 + 2));
+    HIP_TRYX(c, hipMemsetAsync(d_ls, 0, sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_nl_write(d_buf, n, d_base, d_ls, st));
+    if (!ends_nl) {
+        const uint64_t v = n + 1;
+        HIP_TRYX(c, hipMemcpyAsync(d_ls + L, &v, sizeof v, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+    }
+    MlfqScratch S;
+    const uint32_t nch = mlfq_chunks(L);
+    uint32_t* d_tb = nullptr;
+    HIP_TRYX(c, F.alloc(&S.next, L64));
+    HIP_TRYX(c, F.alloc(&S.plus, L64));
+    HIP_TRYX(c, F.alloc(&S.slen, L64));
+    HIP_TRYX(c, F.alloc(&S.exitp, L64));
+    HIP_TRYX(c, F.alloc(&S.is_start, L64));
+    HIP_TRYX(c, F.alloc(&S.entry, (uint64_t)nch));
+    HIP_TRYX(c, F.alloc(&S.status, 2));
+    HIP_TRYX(c, F.alloc(&d_tb, 1));
+    HIP_TRYX(c, hipMemsetAsync(S.is_start, 0, L64 * sizeof(uint32_t), st));
+    HIP_TRYX(c, hipMemsetAsync(S.entry, 0xFF, (uint64_t)nch * sizeof(uint32_t), st));
+    HIP_TRYX(c, hipMemsetAsync(S.status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_trailing_blank(d_ls, L, d_tb, st));
+    uint32_t tb = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&tb, d_tb, sizeof tb, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    HIP_TRYX(c, launch_mlfq_resolve(d_buf, d_ls, L, tb, S, st));
+    uint64_t *d_rank = nullptr, *d_tmp2 = nullptr;
+    HIP_TRYX(c, F.alloc(&d_rank, L64 + 1));
+    HIP_TRYX(c, F.alloc(&d_tmp2, 2 * ((L64 + 2047) / 2048) + 4));
+    HIP_TRYX(c, launch_scan_u32(S.is_start, d_rank, L64, d_tmp2, st));
+    uint64_t nrec = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&nrec, d_rank + L64, sizeof nrec, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, S.status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    auto format_error = [&](uint64_t f) {
+        if (f & 1) c->set_error("invalid FASTQ: record does not start with '@' (multi-line FASTQ reader)");
+        else if (f & 2) c->set_error("invalid FASTQ: a record has no '+' line or unmatched length of sequence and quality (multi-line FASTQ reader)");
+        else c->set_error("libbsk: a FASTQ record of 2^32 bytes or more");
+        return (f & 4) ? BSK_ERR_UNSUPPORTED : BSK_ERR_FORMAT;
+    };
+    if (status) return format_error(status);
+    uint32_t *d_rec = nullptr, *d_len = nullptr;
+    uint64_t *d_off = nullptr, *d_tmp3 = nullptr;
+    HIP_TRYX(c, F.alloc(&d_rec, nrec));
+    HIP_TRYX(c, F.alloc(&d_len, nrec));
+    HIP_TRYX(c, F.alloc(&d_off, nrec + 1));
+    HIP_TRYX(c, F.alloc(&d_tmp3, 2 * ((nrec + 2047) / 2048) + 4));
+    HIP_TRYX(c, launch_mlfq_list(d_ls, L, S, d_rank, d_rec, d_len, st));
+    uint64_t total = 0;
+    if (nrec) {
+        HIP_TRYX(c, launch_scan_u32(d_len, d_off, nrec, d_tmp3, st));
+        HIP_TRYX(c, hipMemcpyAsync(&total, d_off + nrec, sizeof total, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRYX(c, hipMemcpyAsync(&status, S.status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status) return format_error(status);
+    int rc = grow(c, &c->d_norm, &c->norm_cap, total + 16, total / 16 + 256);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_mlfq_emit(d_buf, d_ls, S, d_rec, d_off, nrec, c->d_norm, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // the scratch is freed on return
+    *d_out = c->d_norm;
+    *n_out = total;
+    return BSK_OK;
+}
+
 // `seq -n` / `seq -n -i` on FASTQ: the names leave from the streaming pass itself (stream_names.hip) -- per-range slices
 // sized from the header density of the shard head, one scan over the ranges, one gather.  BSK_ERR_FILTER_FALLBACK: a
 // slice was too small (or the estimate does not fit); the caller takes the record-table path.
@@ -2272,6 +2415,7 @@ static int seq_names_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t
     std::vector<uint8_t> head(hb);
     HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
+    if (!c->norm_active && fastq_head_multiline(head.data(), hb)) return BSK_ERR_MULTILINE_FASTQ;
     uint64_t hdr = 0, line = 0, line_start = 0;
     for (size_t i = 0; i < hb; ++i)
         if (head[i] == '\n') { if ((line & 3) == 0) hdr += i - line_start; ++line; line_start = i + 1; }

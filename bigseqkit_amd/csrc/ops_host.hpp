@@ -10,6 +10,11 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
 struct FilterDev;
 // not an API status: the fused pattern filter gave up (stream_filter.hpp) and the caller must build the full table
 constexpr int BSK_ERR_FILTER_FALLBACK = -1000;
+// internal: the head of a FASTQ shard shows records wrapped over several lines; the caller rewrites the shard
+// (normalize_multiline_fastq) and runs the operator on the 4-line text
+constexpr int BSK_ERR_MULTILINE_FASTQ = -1001;
+bool fastq_head_multiline(const uint8_t* h, size_t hb);
+int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out);
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
 void validate_seq_opts(bsk_ctx* c);
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);

@@ -251,6 +251,8 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
     }
     const char* env = getenv("BSK_STAGE_BYTES");
     const size_t want = env && strtoull(env, nullptr, 10) ? (size_t)strtoull(env, nullptr, 10) : ((size_t)256 << 20);
+    // records wrapped over several lines: the cut points below assume 4-line records, so the shard goes as one piece
+    if (format == BSK_FORMAT_FASTQ && fastq_head_multiline((const uint8_t*)host_shard, std::min<size_t>(n, 256 * 1024))) chunkable = false;
     const size_t chunk = chunkable ? want : n;
     const uint8_t* h = (const uint8_t*)host_shard;
     // cut points: record starts (a chunk holds whole records)
@@ -300,6 +302,21 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
         bsk_out o;
         memset(&o, 0, sizeof o);
         rc = fn(c, c->d_stage[b], cuts[i + 1] - cuts[i], format, st, &o);
+        if (rc == BSK_ERR_MULTILINE_FASTQ) {
+            if (c->op == Op::Range || c->op == Op::Head || c->op == Op::Duplicate) {
+                c->set_error("libbsk: multi-line FASTQ is not provided for range / head / duplicate (they print the record text as it is)");
+                rc = BSK_ERR_UNSUPPORTED;
+                break;
+            }
+            const uint8_t* d2 = nullptr;
+            size_t n2 = 0;
+            rc = normalize_multiline_fastq(c, c->d_stage[b], cuts[i + 1] - cuts[i], st, &d2, &n2);
+            if (rc != BSK_OK) break;
+            ST_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+            c->norm_active = true;
+            rc = fn(c, d2, n2, format, st, &o);
+            c->norm_active = false;
+        }
         if (rc != BSK_OK) break;
         ST_TRY(c, hipStreamSynchronize(st));  // the output is complete (the run functions end with launches in flight)
         ST_TRY(c, hipEventRecord(in_free[b], st));

@@ -182,7 +182,7 @@ def test_partitions_are_reduced():
 
 @pytest.mark.parametrize("data,code,msg", [
     (b"@a\nACGT\n+\nIII\n@b\nA\n+\nI\n", _lib.BSK_ERR_FORMAT, "unmatched length"),
-    (b"@a\nACGT\nAC\n+\nIIII\nII\n", _lib.BSK_ERR_UNSUPPORTED, None),          # multi-line FASTQ
+    (b"@a\nACGT\nAC\n+\nIIII\nIII\n", _lib.BSK_ERR_FORMAT, None),               # multi-line FASTQ, quality too long
     (b"\n@a\nACGT\n+\nIIII\n", _lib.BSK_ERR_UNSUPPORTED, "does not start"),
     (b"@a\nACGT\n+\nIIII\n@b\nAC\n", _lib.BSK_ERR_FORMAT, None),               # truncated
 ])
