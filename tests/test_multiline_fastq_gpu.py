@@ -34,10 +34,15 @@ def wrapped_fastq(rng, nrec, width, final_newline=True, trailing_blank=0, qwidth
         L = rng.choice([0, 1, width - 1, width, width + 1, 2 * width, rng.randint(0, 6 * width)])
         seq = "".join(rng.choice("ACGTN") for _ in range(L))
         qual = "".join(chr(rng.randint(33, 126)) for _ in range(L))
-        if L > width and rng.random() < 0.5:    # a quality CONTINUATION line that looks like a header / a '+' line
+        if L > width and rng.random() < 0.5:    # a quality CONTINUATION line that looks like a '+' line
             k = qwidth * rng.randint(1, (L - 1) // qwidth) if (L - 1) // qwidth >= 1 else 0
             if 0 < k < L:
-                qual = qual[:k] + rng.choice("@+") + qual[k + 1:]
+                qual = qual[:k] + "+" + qual[k + 1:]
+        # ('@' at the start of a continuation line ends the record under the grammar, PARITY.md SPLIT-FQ: see the
+        #  malformed cases below)
+        for k in range(qwidth, L, qwidth):
+            if qual[k] == "@":
+                qual = qual[:k] + "A" + qual[k + 1:]
         if L and rng.random() < 0.2:
             qual = rng.choice("@+") + qual[1:]
         name = "r%d" % i + (" d%d" % rng.randint(0, 99) if rng.random() < 0.5 else "")
@@ -116,7 +121,8 @@ def test_multiline_head_example_from_the_parser():
 def test_malformed_multiline_fastq_is_an_error():
     for bad in (b"@a\nACGT\nAC\n+\nIIII\nIII\n",            # quality longer than the sequence
                 b"@a\nACGT\nAC\n+\nIIII\n@b\nAC\n+\nII\n",    # quality shorter, then a header
-                b"@a\nACGT\nAC\nIIII\nII\n"):                 # no '+' line
+                b"@a\nACGT\nAC\nIIII\nII\n",                  # no '+' line
+                b"@a\nACGT\nAC\n+\nIIII\n@I\n"):               # a quality continuation line that begins with '@'
         with pytest.raises(oracle.OracleError):
             oracle.seq(bad, True, "{}")
         with pytest.raises(bsk.BskError) as e:
