@@ -437,8 +437,27 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return fail(rc);
     apply_long(c, &F);
-    // (offsets follow the SORTED order, not the record order: the record-wise emit, not the segmented copy)
-    if (launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess) return fail(BSK_ERR_HIP);
+    // the offsets follow the SORTED order: the segments of the copy are the records in that order (FASTQ records that leave
+    // unchanged; ops_segcopy.hip), the record-wise emit writes what is left
+    const char* sg = getenv("BSK_SEGCOPY");
+    bool seg_done = false;
+    if (fastq && !F.ren_ord && !(sg && strcmp(sg, "off") == 0) && ((sg && strcmp(sg, "force") == 0) || total >= (4u << 20))) {
+        if (grow(c, &c->d_seg_src, &c->seg_src_cap, 2 * N + 1, N / 4 + 16) != BSK_OK ||
+            grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64) != BSK_OK) return fail(BSK_ERR_HIP);
+        uint64_t* seg_sorted = c->d_seg_src;
+        uint64_t* seg_rec = c->d_seg_src + N;
+        uint64_t* d_other = c->d_seg_src + 2 * N;
+        uint64_t other = 0;
+        if (hipMemsetAsync(d_other, 0, sizeof(uint64_t), st) != hipSuccess ||
+            launch_seg_build_fastq_perm(d_buf, n, c->table, c->d_out_len, pin, seg_sorted, seg_rec, d_other, st) != hipSuccess ||
+            launch_seg_first(off_perm, N, c->d_seg_first, st) != hipSuccess ||
+            launch_seg_copy(seg_sorted, off_perm, N, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st) != hipSuccess ||
+            hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+        if (other == 0) seg_done = true;
+        else F.seg_src = seg_rec;
+    }
+    if (!seg_done && launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept) != hipSuccess) return fail(BSK_ERR_HIP);
     cleanup();
     out->d_data = c->d_out;
     out->len = total;

@@ -294,6 +294,25 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve(const uint8_t* __restrict
         const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
         bool same = a.len == b.len;
         uint32_t q = 0;
+        const bool plain = a.seq ? (a.T.W == 0 && b.T.W == 0 && !a.fold) : !a.fold;
+        if (same && plain) {
+            // contiguous subjects: 32 bytes of each per step, no early exit -- the loads of a step do not wait for the
+            // comparison of the one before (a `same &&` loop is a chain of ~19 dependent round trips per 150 bases)
+            const uint8_t* pa = a.seq ? a.T.p : a.h;
+            const uint8_t* pb = b.seq ? b.T.p : b.h;
+            uint32_t diff = 0;
+#pragma unroll 2
+            for (; q + 32 <= a.len; q += 32) {
+                uint4 a0, a1, b0, b1;
+                __builtin_memcpy(&a0, pa + q, 16);
+                __builtin_memcpy(&a1, pa + q + 16, 16);
+                __builtin_memcpy(&b0, pb + q, 16);
+                __builtin_memcpy(&b1, pb + q + 16, 16);
+                diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) |
+                        (a1.z ^ b1.z) | (a1.w ^ b1.w);
+            }
+            same = diff == 0;
+        }
         for (; same && q + 8 <= a.len; q += 8) same = word64(a, q) == word64(b, q);  // 8 subject bytes per step
         for (; same && q < a.len; ++q) same = a.at(q) == b.at(q);
         if (!same) {  // distinct subjects under one 64-bit key: refuse rather than guess
@@ -542,6 +561,25 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve_first(const uint8_t* __re
         const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
         bool same = a.len == b.len;
         uint32_t q = 0;
+        const bool plain = a.seq ? (a.T.W == 0 && b.T.W == 0 && !a.fold) : !a.fold;
+        if (same && plain) {
+            // contiguous subjects: 32 bytes of each per step, no early exit -- the loads of a step do not wait for the
+            // comparison of the one before (a `same &&` loop is a chain of ~19 dependent round trips per 150 bases)
+            const uint8_t* pa = a.seq ? a.T.p : a.h;
+            const uint8_t* pb = b.seq ? b.T.p : b.h;
+            uint32_t diff = 0;
+#pragma unroll 2
+            for (; q + 32 <= a.len; q += 32) {
+                uint4 a0, a1, b0, b1;
+                __builtin_memcpy(&a0, pa + q, 16);
+                __builtin_memcpy(&a1, pa + q + 16, 16);
+                __builtin_memcpy(&b0, pb + q, 16);
+                __builtin_memcpy(&b1, pb + q + 16, 16);
+                diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) |
+                        (a1.z ^ b1.z) | (a1.w ^ b1.w);
+            }
+            same = diff == 0;
+        }
         for (; same && q + 8 <= a.len; q += 8) same = word64(a, q) == word64(b, q);  // 8 subject bytes per step
         for (; same && q < a.len; ++q) same = a.at(q) == b.at(q);
         if (!same) {  // distinct subjects under one 64-bit key: refuse rather than guess

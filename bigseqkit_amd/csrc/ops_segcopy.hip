@@ -54,6 +54,25 @@ __global__ __launch_bounds__(256) void k_seg_fix_text(const uint8_t* __restrict_
     o[n - 1] = (uint8_t)'\n';
 }
 
+// sort: segment k is the record perm[k]; seg_rec (by record) tells the record-wise emit what is left to it
+__global__ __launch_bounds__(256) void k_seg_build_fastq_perm(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+                                                              const uint32_t* __restrict__ out_len, const uint32_t* __restrict__ perm,
+                                                              uint64_t* __restrict__ seg_sorted, uint64_t* __restrict__ seg_rec,
+                                                              unsigned long long* __restrict__ n_other) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= t.n) return;
+    const uint32_t i = perm[k];
+    const uint32_t n = out_len[i];
+    uint64_t s = 0;
+    if (n) {
+        const uint64_t st = t.start[i];
+        if (t.aux[i] == 1u && st + n <= buf_n) s = (uint64_t)(uintptr_t)(buf + st);
+        else atomicAdd(n_other, 1ull);
+    }
+    seg_sorted[k] = s;
+    seg_rec[i] = s;
+}
+
 __global__ __launch_bounds__(256) void k_seg_first(const uint64_t* __restrict__ seg_off, uint64_t nseg, uint32_t* __restrict__ first4k) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nseg) return;
@@ -226,6 +245,14 @@ hipError_t launch_seg_fix_text(const uint8_t* buf, const RecordTable& t, const u
                                const uint64_t* seg_src, uint8_t* out, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_seg_fix_text, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, out_len, out_off, seg_src, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_build_fastq_perm(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                       const uint32_t* perm, uint64_t* seg_sorted, uint64_t* seg_rec, uint64_t* n_other, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_build_fastq_perm, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, out_len, perm,
+                       seg_sorted, seg_rec, (unsigned long long*)n_other);
     return hipGetLastError();
 }
 

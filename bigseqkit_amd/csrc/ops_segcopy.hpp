@@ -21,6 +21,10 @@ inline uint64_t seg_tiles(uint64_t total) { return (total + SEG_TILE - 1) / SEG_
 // counted in *n_other (they stay with the record-wise emit kernel).
 hipError_t launch_seg_build_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
                                   uint64_t* seg_src, uint64_t* n_other, hipStream_t st);
+// sort: the same for the records in the order perm[0], perm[1], ... (seg_sorted[k] belongs to record perm[k]; seg_rec[i] to
+// record i, for the record-wise emit of what is left)
+hipError_t launch_seg_build_fastq_perm(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                       const uint32_t* perm, uint64_t* seg_sorted, uint64_t* seg_rec, uint64_t* n_other, hipStream_t st);
 // range / head: out_len[i] = text + 1; verbatim when the byte after the text is the '\n' (else counted in *n_other and
 // written by launch_seg_fix_text)
 hipError_t launch_seg_build_text(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
