@@ -415,14 +415,15 @@ int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
 }
 
 // tell the emit kernel which records it must leave to the block-per-chunk launch
-int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& Pin, uint64_t total, uint64_t kept, hipStream_t st) {
+int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& Pin, const uint32_t* d_len, const uint64_t* d_off,
+                    uint8_t* d_out, uint64_t total, uint64_t kept, hipStream_t st) {
     SeqParams P = Pin;
     P.seg_src = nullptr;
     const RecordTable& t = c->table;
     const char* env = getenv("BSK_SEGCOPY");  // off: never; force: whenever the records qualify (tests)
     const bool verbatim = P.fastq && !P.fasta_out && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id &&
                           !P.reverse && !P.use_lut && !P.region_on && !P.feat_on && !P.remove_gaps && !P.ren_ord;
-    bool seg = verbatim && t.n > 0 && total > 0 && !(env && strcmp(env, "off") == 0);
+    bool seg = verbatim && t.n > 0 && total > 0 && ((uintptr_t)d_out & 15u) == 0 && !(env && strcmp(env, "off") == 0);
     if (seg && !(env && strcmp(env, "force") == 0)) seg = kept * 2 >= t.n && total >= (4u << 20);
     if (seg) {
         int rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
@@ -431,11 +432,11 @@ int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& Pi
         if (rc != BSK_OK) return rc;
         uint64_t* d_other = c->d_seg_src + t.n;
         HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
-        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, c->d_out_len, c->d_seg_src, d_other, st));
-        HIP_TRYX(c, launch_seg_first(c->d_out_off, t.n, c->d_seg_first, st));
+        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, d_other, st));
+        HIP_TRYX(c, launch_seg_first(d_off, t.n, c->d_seg_first, st));
         {
             Timed tm(c, "k_seg_copy", st);
-            HIP_TRYX(c, launch_seg_copy(c->d_seg_src, c->d_out_off, t.n, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st));
+            HIP_TRYX(c, launch_seg_copy(c->d_seg_src, d_off, t.n, c->d_seg_first, d_out, total, d_buf, d_buf + n, st));
         }
         uint64_t other = 0;
         HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
@@ -443,8 +444,12 @@ int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& Pi
         if (other == 0) return BSK_OK;
         P.seg_src = c->d_seg_src;  // the few records the copy left out
     }
-    HIP_TRYX(c, launch_seq_emit(d_buf, t, P, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    HIP_TRYX(c, launch_seq_emit(d_buf, t, P, d_len, d_off, d_out, st, total, kept));
     return BSK_OK;
+}
+
+int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, uint64_t total, uint64_t kept, hipStream_t st) {
+    return emit_records_at(c, d_buf, n, P, c->d_out_len, c->d_out_off, c->d_out, total, kept, st);
 }
 
 void apply_long(const bsk_ctx* c, SeqParams* P) {

@@ -61,6 +61,9 @@ void apply_long(const bsk_ctx* c, SeqParams* P);
 // the emit step of size -> scan -> emit into c->d_out (sizes in c->d_out_len / c->d_out_off): FASTQ records that leave
 // unchanged go through the segmented copy when most records have output, everything else through k_seq_emit
 int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, uint64_t total, uint64_t kept, hipStream_t st);
+// the same with the caller's size / offset arrays (offsets in RECORD order) and output place
+int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, const uint32_t* d_len, const uint64_t* d_off,
+                    uint8_t* d_out, uint64_t total, uint64_t kept, hipStream_t st);
 int empty_result(bsk_ctx* c, bsk_out* out);
 // SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
 SeqParams format_params(bsk_ctx* c, bool fastq);

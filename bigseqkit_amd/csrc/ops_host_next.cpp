@@ -201,6 +201,25 @@ int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, h
         HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
         if (other) HIP_TRYX(c, launch_seg_fix_text(d_buf, t, c->d_out_len, c->d_out_off, c->d_seg_src, c->d_out, st));
+    } else if (P.times <= 4 && !(sg && strcmp(sg, "off") == 0)) {
+        // duplicate -n 2..4: `times` segments per record (more copies: the tile copy below, whose tables do not grow with n)
+        const RecordTable& t = c->table;
+        const uint64_t ns = t.n * P.times;
+        rc = grow(c, &c->d_seg_src, &c->seg_src_cap, 2 * ns + 2, ns / 4 + 16);
+        if (rc != BSK_OK) return rc;
+        rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+        if (rc != BSK_OK) return rc;
+        uint64_t* seg_src = c->d_seg_src;
+        uint64_t* seg_off2 = c->d_seg_src + ns;       // [ns + 1]
+        uint64_t* d_other = c->d_seg_src + 2 * ns + 1;
+        HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_seg_build_text_times(d_buf, n, t, c->d_out_len, c->d_out_off, P.times, seg_src, seg_off2, d_other, st));
+        HIP_TRYX(c, launch_seg_first(seg_off2, ns, c->d_seg_first, st));
+        HIP_TRYX(c, launch_seg_copy(seg_src, seg_off2, ns, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st));
+        uint64_t other = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (other) HIP_TRYX(c, launch_seg_fix_text_times(d_buf, t, c->d_out_len, c->d_out_off, P.times, seg_src, c->d_out, st));
     } else {
         rc = grow(c, &c->d_tile_first, &c->tile_first_cap, records_copy_tiles(total), 64);
         if (rc != BSK_OK) return rc;
@@ -707,7 +726,12 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
         } else {
             HIP_TRYX(c, launch_scan_u32(d_len, d_off, N, c->d_scan_tmp, st));
         }
-        HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, d_len, d_off, c->d_out + base[k], st, tot[k], tot[4 + k]));
+        if (k == 1) {  // offsets in the order of the first mates: the record-wise emit
+            HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, d_len, d_off, c->d_out + base[k], st, tot[k], tot[4 + k]));
+        } else {
+            rc = emit_records_at(c, d_buf, n, F, d_len, d_off, c->d_out + base[k], tot[k], tot[4 + k], st);
+            if (rc != BSK_OK) return rc;
+        }
         outs[k].d_data = c->d_out + base[k];
         outs[k].len = tot[k];
         outs[k].records = tot[4 + k];

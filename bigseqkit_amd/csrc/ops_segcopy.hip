@@ -73,6 +73,46 @@ __global__ __launch_bounds__(256) void k_seg_build_fastq_perm(const uint8_t* __r
     seg_rec[i] = s;
 }
 
+// duplicate: `times` segments per record with output, all from the record's text; seg_off2[i * times + j] = out_off[i] +
+// j * (out_len[i] / times); the entry after the last one (= total) is written by the thread of the last record
+__global__ __launch_bounds__(256) void k_seg_build_text_times(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+                                                              const uint32_t* __restrict__ out_len, const uint64_t* __restrict__ out_off,
+                                                              uint32_t times, uint64_t* __restrict__ seg_src, uint64_t* __restrict__ seg_off2,
+                                                              unsigned long long* __restrict__ n_other) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t n = out_len[i];
+    const uint64_t o = out_off[i];
+    const uint32_t unit = n / times;
+    uint64_t s = 0;
+    if (n) {
+        const uint64_t st = t.start[i];
+        if (st + unit <= buf_n && buf[st + unit - 1] == '\n') s = (uint64_t)(uintptr_t)(buf + st);
+        else atomicAdd(n_other, 1ull);
+    }
+    for (uint32_t j = 0; j < times; ++j) {
+        seg_src[i * times + j] = s;
+        seg_off2[i * times + j] = o + (uint64_t)j * unit;
+    }
+    if (i + 1 == t.n) seg_off2[t.n * times] = out_off[t.n];
+}
+
+__global__ __launch_bounds__(256) void k_seg_fix_text_times(const uint8_t* __restrict__ buf, RecordTable t, const uint32_t* __restrict__ out_len,
+                                                            const uint64_t* __restrict__ out_off, uint32_t times,
+                                                            const uint64_t* __restrict__ seg_src, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t n = out_len[i];
+    if (n == 0 || seg_src[i * times] != 0) return;
+    const uint32_t unit = n / times;
+    const uint8_t* s = buf + t.start[i];
+    for (uint32_t j = 0; j < times; ++j) {
+        uint8_t* o = out + out_off[i] + (uint64_t)j * unit;
+        for (uint32_t k = 0; k + 1 < unit; ++k) o[k] = s[k];
+        o[unit - 1] = (uint8_t)'\n';
+    }
+}
+
 __global__ __launch_bounds__(256) void k_seg_first(const uint64_t* __restrict__ seg_off, uint64_t nseg, uint32_t* __restrict__ first4k) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nseg) return;
@@ -253,6 +293,23 @@ hipError_t launch_seg_build_fastq_perm(const uint8_t* buf, uint64_t buf_n, const
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_seg_build_fastq_perm, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, out_len, perm,
                        seg_sorted, seg_rec, (unsigned long long*)n_other);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_build_text_times(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                       const uint64_t* out_off, uint32_t times, uint64_t* seg_src, uint64_t* seg_off2, uint64_t* n_other,
+                                       hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_build_text_times, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, out_len, out_off,
+                       times, seg_src, seg_off2, (unsigned long long*)n_other);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_fix_text_times(const uint8_t* buf, const RecordTable& t, const uint32_t* out_len, const uint64_t* out_off,
+                                     uint32_t times, const uint64_t* seg_src, uint8_t* out, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_fix_text_times, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, out_len, out_off, times,
+                       seg_src, out);
     return hipGetLastError();
 }
 

@@ -31,6 +31,12 @@ hipError_t launch_seg_build_text(const uint8_t* buf, uint64_t buf_n, const Recor
                                  uint64_t* seg_src, uint64_t* n_other, hipStream_t st);
 hipError_t launch_seg_fix_text(const uint8_t* buf, const RecordTable& t, const uint32_t* out_len, const uint64_t* out_off,
                                const uint64_t* seg_src, uint8_t* out, hipStream_t st);
+// duplicate: `times` segments per record (seg arrays of t.n * times (+ 1) entries)
+hipError_t launch_seg_build_text_times(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
+                                       const uint64_t* out_off, uint32_t times, uint64_t* seg_src, uint64_t* seg_off2, uint64_t* n_other,
+                                       hipStream_t st);
+hipError_t launch_seg_fix_text_times(const uint8_t* buf, const RecordTable& t, const uint32_t* out_len, const uint64_t* out_off,
+                                     uint32_t times, const uint64_t* seg_src, uint8_t* out, hipStream_t st);
 // first4k[T] = the segment that holds output byte T * SEG_TILE (T < seg_tiles(total))
 hipError_t launch_seg_first(const uint64_t* seg_off, uint64_t nseg, uint32_t* first4k, hipStream_t st);
 hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
