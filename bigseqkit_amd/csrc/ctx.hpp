@@ -88,7 +88,7 @@ struct bsk_ctx {
     uint8_t* d_lut = nullptr;           // 256-byte byte map (seq)
     double* d_qual_err = nullptr;       // 256 doubles (seq -Q/-R)
     uint64_t* d_counter = nullptr;      // scratch counter
-    // FASTA text view (text.cuh)
+    // FASTA text view (text_dev.hpp)
     uint32_t* d_text_w = nullptr;
     uint64_t* d_lin_off = nullptr;
     uint8_t* d_lin = nullptr;
@@ -125,7 +125,7 @@ struct bsk_ctx {
     uint64_t ftab_cap = 0;
     std::vector<std::string> pattern_names;  // locate: names as given (== the -p text, or the FASTA name with -f)
     std::vector<std::string> pattern_disp;   // locate -r: the expressions (pattern column); patterns[] then only carries the match length
-    // class patterns (-d, -m, -F): one 256-bit accept set per pattern position (pattern_match.cuh)
+    // class patterns (-d, -m, -F): one 256-bit accept set per pattern position (pattern_match_dev.hpp)
     std::vector<std::vector<std::array<uint32_t, 8>>> pattern_cls;
     bool general = false;     // match through pattern_cls instead of the exact byte compare
     int max_mm = 0;           // -m

@@ -22,7 +22,7 @@ struct RecordTable {
     uint32_t* l_seq = nullptr;
     uint32_t* aux = nullptr;
     // FASTA only (written by the index pass): 0 = the sequence is one line (or empty), W = every line but the last has
-    // W >= 16 bases and the last 1..W (base i sits at i + i / W), 0xFFFFFFFF = irregular wrapping (text.cuh)
+    // W >= 16 bases and the last 1..W (base i sits at i + i / W), 0xFFFFFFFF = irregular wrapping (text_dev.hpp)
     uint32_t* text_w = nullptr;
     // custom --id-regexp only (else null): ID of record i = header bytes [1 + id_off[i], + id_len[i])
     const uint32_t* id_off = nullptr;

@@ -3,7 +3,7 @@
 
 #include "ops_concat.hpp"
 #include "ops_records.hpp"  // ERR_RECORD_TOO_LARGE
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 namespace {

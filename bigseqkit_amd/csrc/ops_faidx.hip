@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ops_faidx.hpp"
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 namespace {

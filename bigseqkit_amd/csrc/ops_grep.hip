@@ -17,7 +17,7 @@
 #include "ops_grep.hpp"
 #include "ops_seq.hpp"
 #include "ops_translate.hpp"  // TextTableH
-#include "pattern_match.cuh"
+#include "pattern_match_dev.hpp"
 #include "regex_nfa.hpp"
 
 namespace bsk {

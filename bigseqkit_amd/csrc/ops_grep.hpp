@@ -19,7 +19,7 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     int npat;                // patterns; with both_strands the reverse-complemented copies follow
     const uint8_t* pat;      // concatenated pattern bytes (already lower-cased when ignore_case)
     const uint32_t* pat_off; // [npat_total + 1]
-    // class patterns (-d, -m): 8 dwords per pattern position, same offsets as `pat` (pattern_match.cuh)
+    // class patterns (-d, -m): 8 dwords per pattern position, same offsets as `pat` (pattern_match_dev.hpp)
     int general;
     int max_mm;
     const uint32_t* cls;

@@ -758,7 +758,7 @@ static int upload_classes(bsk_ctx* c, bool rc, Alphabet ab, hipStream_t st) {
     return BSK_OK;
 }
 
-// open-addressing set of the ID / name patterns keyed by fnv1a64 (pattern_match.cuh)
+// open-addressing set of the ID / name patterns keyed by fnv1a64 (pattern_match_dev.hpp)
 static int upload_pattern_set(bsk_ctx* c, hipStream_t st) {
     uint64_t slots = 16;
     while (slots < 2 * c->patterns.size()) slots <<= 1;

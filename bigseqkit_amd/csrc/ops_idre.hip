@@ -3,7 +3,7 @@
 // (/root/reference/bigseqkit-lib/helper.go:362-368): the leftmost-first match of the user's expression in the header and
 // the bounds of its first capture group; no match -> the whole header; a match whose group 1 took no part -> empty ID.
 // One lane per record runs the Pike VM of regex_vm.hpp (thread lists in private memory): a rare path, run once per
-// shard right after the record table is built; every later kernel reads the spans from the table (id_span_rec, text.cuh).
+// shard right after the record table is built; every later kernel reads the spans from the table (id_span_rec, text_dev.hpp).
 // ============================================================================
 #include <hip/hip_runtime.h>
 

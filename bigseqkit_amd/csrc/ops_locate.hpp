@@ -19,7 +19,7 @@ struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go
     const uint32_t* pat_off; // [2 * npat + 1]
     const uint8_t* name;     // pattern names as given (npat)
     const uint32_t* name_off;
-    // class patterns (-d, -m, -F; pattern_match.cuh): 8 dwords per position, offsets as `pat`
+    // class patterns (-d, -m, -F; pattern_match_dev.hpp): 8 dwords per position, offsets as `pat`
     int general, max_mm;
     const uint32_t* cls;
     int fmi_order;           // -m / -F: all patterns on '+', then all on '-'; no +l shift of '-' coordinates (locate.go:208-391)

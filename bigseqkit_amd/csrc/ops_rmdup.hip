@@ -16,7 +16,7 @@
 #include <cstdint>
 
 #include "ops_rmdup.hpp"
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 

@@ -14,7 +14,7 @@
 #include <cstdint>
 
 #include "ops_seq.hpp"
-#include "pattern_match.cuh"  // fnv1a64, TEXT_IRREGULAR (text.cuh)
+#include "pattern_match_dev.hpp"  // fnv1a64, TEXT_IRREGULAR (text_dev.hpp)
 
 namespace bsk {
 

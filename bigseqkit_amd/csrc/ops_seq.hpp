@@ -29,7 +29,7 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     int region_on, region_start, region_end; // Seq.SubSeq(start, end) applied to seq and qual (subseq -r)
     const uint8_t* lut;                     // device, 256 bytes
     const double* qual_err;                 // device, 256 doubles: 10^(-(q-base)/10) indexed by the raw byte
-    // FASTA text view (text.cuh): random access into wrapped sequences; null = contiguous records only on the
+    // FASTA text view (text_dev.hpp): random access into wrapped sequences; null = contiguous records only on the
     // parallel path (others take the sequential per-record walk)
     const uint32_t* text_w;
     const uint64_t* lin_off;

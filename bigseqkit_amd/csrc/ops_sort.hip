@@ -4,7 +4,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "ops_sort.hpp"
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 namespace {

@@ -1,11 +1,11 @@
 // ops_text.hip -- classify FASTA sequence regions (contiguous / uniformly wrapped /
-// irregular) and linearise the irregular ones.  See text.cuh.
+// irregular) and linearise the irregular ones.  See text_dev.hpp.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
 #include "ops_text.hpp"
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 

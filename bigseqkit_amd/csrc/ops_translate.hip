@@ -14,7 +14,7 @@
 #include <cstring>
 
 #include "ops_translate.hpp"
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 

@@ -8,7 +8,7 @@
 
 namespace bsk {
 
-struct TextTableH {  // host-visible mirror of TextTable (text.cuh)
+struct TextTableH {  // host-visible mirror of TextTable (text_dev.hpp)
     const uint32_t* text_w;
     const uint64_t* lin_off;
     const uint8_t* lin;

@@ -9,7 +9,7 @@
 
 #include <cstdint>
 
-#include "text.cuh"
+#include "text_dev.hpp"
 
 namespace bsk {
 

@@ -1,5 +1,5 @@
 // ============================================================================
-// stream_core.cuh -- the single-pass streaming skeleton shared by every kernel
+// stream_core_dev.hpp -- the single-pass streaming skeleton shared by every kernel
 // that has to find records in raw FASTA/FASTQ text on gfx950 (device code only).
 //
 // Replaces the reference's line-by-line SeqParser.Read

@@ -31,7 +31,7 @@
 #include <cstdint>
 
 #include "index.hpp"
-#include "stream_core.cuh"
+#include "stream_core_dev.hpp"
 #include "stream_filter.hpp"
 
 namespace bsk {

@@ -11,7 +11,7 @@
 #include <cstdint>
 
 #include "index.hpp"
-#include "stream_core.cuh"
+#include "stream_core_dev.hpp"
 
 namespace bsk {
 
@@ -29,7 +29,7 @@ struct IndexSink {
     // FASTA: the record that is open at the start of a batch
     uint64_t open_start = 0;  // absolute offset of its '>'
     uint32_t open_lhead = 0, open_key = 0;
-    // FASTA line layout of the open record (text.cuh): length of its first sequence line, any line seen so far that
+    // FASTA line layout of the open record (text_dev.hpp): length of its first sequence line, any line seen so far that
     // breaks "all lines but the last are equally long, the last is 1..W"
     uint32_t open_w = 0;
     bool open_irr = false;

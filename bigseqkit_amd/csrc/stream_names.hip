@@ -15,9 +15,9 @@
 
 #include <cstdint>
 
-#include "stream_core.cuh"
+#include "stream_core_dev.hpp"
 #include "stream_names.hpp"
-#include "text.cuh"
+#include "text_dev.hpp"
 
 #ifndef BSK_NAMES_EXP
 #define BSK_NAMES_EXP 0

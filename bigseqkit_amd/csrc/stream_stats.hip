@@ -1,10 +1,10 @@
 // ============================================================================
 // stream_stats.hip -- `stats` on gfx950: the StatsSink of the streaming skeleton
-// (stream_core.cuh) + k_prep (range anchors) + launchers.
+// (stream_core_dev.hpp) + k_prep (range anchors) + launchers.
 //
 // Replaces, for one shard resident in HBM, the reference's
 //   ReadFixer.Call   /root/reference/bigseqkit-lib/helper.go:41-66   (k_prep)
-//   SeqParser.Read   bigseqkit-lib/helper.go:219-325   (line structure, stream_core.cuh)
+//   SeqParser.Read   bigseqkit-lib/helper.go:219-325   (line structure, stream_core_dev.hpp)
 //   Stats.Call       bigseqkit-lib/stats.go:48-117     (StatsSink)
 // One pass, every byte read once; lengths go to an LDS histogram (bins < 2048)
 // flushed once per block; Q20/Q30/gap are differences of running counters taken
@@ -15,7 +15,7 @@
 #include <cstdint>
 
 #include "anchor.hpp"
-#include "stream_core.cuh"
+#include "stream_core_dev.hpp"
 #include "stream_stats.hpp"
 
 namespace bsk {

@@ -9,7 +9,7 @@ namespace bsk {
 constexpr int STATS_HDR = 8;  // == BSK_STATS_HDR in include/bsk.h
 constexpr int MAX_GAP_LETTERS = 8;
 
-// error flags raised by the kernels (status[0]); mirrored in stream_core.cuh
+// error flags raised by the kernels (status[0]); mirrored in stream_core_dev.hpp
 constexpr uint32_t ERR_BAD_HEADER = 1u;     // record does not start with '@' / '>'
 constexpr uint32_t ERR_BAD_PLUS = 2u;       // FASTQ: third line does not start with '+' (or sequence line does)
 constexpr uint32_t ERR_LEN_MISMATCH = 4u;   // FASTQ: len(seq) != len(qual)

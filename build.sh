@@ -10,7 +10,7 @@ FLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-un
 OBJS=()
 for f in $SRC/*.hip $SRC/*.cpp; do
   o="$OUT/$(basename "$f").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find $SRC include -newer "$o" \( -name '*.hpp' -o -name '*.h' -o -name '*.cuh' \) -print -quit)" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find $SRC include -newer "$o" \( -name '*.hpp' -o -name '*.h' \) -print -quit)" ]; then
     if [[ "$f" == *.hip ]]; then $HIPCC --offload-arch=gfx950 $FLAGS -c "$f" -o "$o"; else ${CXX:-g++} $FLAGS -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$f" -o "$o"; fi
   fi
   OBJS+=("$o")
