@@ -221,6 +221,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_out_alt) hipFree(c->d_out_alt);
         if (c->d_slices) hipFree(c->d_slices);
         if (c->d_norm) hipFree(c->d_norm);
+        if (c->d_group) hipFree(c->d_group);
         if (c->d_seg_src) hipFree(c->d_seg_src);
         if (c->d_seg_first) hipFree(c->d_seg_first);
         if (c->d_names_aux) hipFree(c->d_names_aux);

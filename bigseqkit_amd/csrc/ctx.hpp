@@ -73,6 +73,8 @@ struct bsk_ctx {
     uint64_t out_cap = 0;
     uint8_t* d_out_alt = nullptr;       // second output buffer of bsk_run_to_store (drained while the next chunk computes)
     uint64_t out_alt_cap = 0;
+    uint8_t* d_group = nullptr;         // scratch of group_resolve (sorted keys, permutations, bucket bounds)
+    uint64_t group_cap = 0;
     uint8_t* d_norm = nullptr;          // a multi-line FASTQ shard rewritten as 4-line FASTQ (ops_mlfq.hip)
     uint64_t norm_cap = 0;
     bool norm_active = false;           // the operator is running on d_norm

@@ -58,6 +58,58 @@ int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** tk, hipStrea
 
 static void complement_table(Alphabet ab, uint8_t m[256]);
 
+// Groups of equal subjects for rename / pair / common / concat.  In: c->d_keys[i] = XXH64 of the subject of record i.
+// Out: c->d_keys[i] = first record of i's group, d_has[first] = 1 for the groups of two or more, c->d_out_len[i] = formatted
+// size of record i if it is the first of its group (else 0); every later member is byte-compared with the first
+// (ERR_HASH_COLLISION in the status word).  Radix buckets + one LDS table per bucket (ops_rmdup.hip) out of a scratch of
+// its own -- the callers hold the arena --, the one big table in HBM when a bucket overflows, with BSK_RMDUP=table, or
+// from 2^32 records.
+int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint8_t* d_has, hipStream_t st) {
+    const uint64_t N = c->table.n;
+    bool by_buckets = N < (1ull << 32);
+    {
+        const char* e = getenv("BSK_RMDUP");
+        if (e && strcmp(e, "table") == 0) by_buckets = false;
+    }
+    if (by_buckets) {
+        size_t tmp_bytes = 0;
+        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, 16, &tmp_bytes));
+        Arena A;  // (used for its offset arithmetic only: the memory is c->d_group)
+        const uint64_t o_sk = A.take(N * 8), o_vi = A.take(N * 4), o_vo = A.take(N * 4), o_first = A.take(N * 4),
+                       o_bs = A.take((65536 + 2) * 4), o_tmp = A.take(tmp_bytes + 256);
+        int rc = grow(c, &c->d_group, &c->group_cap, A.used, A.used / 8 + 256);
+        if (rc != BSK_OK) return rc;
+        A.base = c->d_group;
+        uint64_t* d_sk = A.at<uint64_t>(o_sk);
+        uint32_t* d_vi = A.at<uint32_t>(o_vi);
+        uint32_t* d_vo = A.at<uint32_t>(o_vo);
+        uint32_t* d_first = A.at<uint32_t>(o_first);
+        HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
+        HIP_TRYX(c, launch_sort_iota(d_first, N, st));
+        HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
+        HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st));
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (!(status & ERR_BUCKET_OVERFLOW)) {
+            HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, c->d_keys, c->d_out_len, c->d_status, d_has, st));
+            return BSK_OK;
+        }
+        status &= ~(uint64_t)ERR_BUCKET_OVERFLOW;
+        HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+    }
+    uint64_t cap = 0;
+    uint64_t* tk = nullptr;
+    int rc = key_table(c, N, &cap, &tk, st);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
+    return BSK_OK;
+}
+
+
+
 int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
     if (!f) return BSK_OK;
     int code = BSK_ERR_FORMAT;

@@ -53,6 +53,9 @@ inline int arena_reserve(bsk_ctx* c, Arena* a) {
 // Open-addressing table of the key-grouping operators (rmdup, rename, pair, common, concat, grep --delete-matched):
 // d_keys for N records and `cap` zeroed slots (a power of two >= 2 N) of 16 bytes {key, ~first record index}.
 int key_table(bsk_ctx* c, uint64_t N, uint64_t* cap_out, uint64_t** table, hipStream_t st);
+struct RmDupParams;
+// c->d_keys: XXH64 keys -> first record of every record's group (+ d_has, c->d_out_len); see ops_host.cpp
+int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint8_t* d_has, hipStream_t st);
 // FASTA text view of the shard's records (text_dev.hpp); null pointers for FASTQ
 int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
 // size array -> scan -> total / kept / kernel status (also lists the records with a very large output)

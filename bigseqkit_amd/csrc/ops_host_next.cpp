@@ -255,15 +255,12 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
     const uint64_t N = c->table.n;
-    uint64_t cap = 0;
-    uint64_t* tk = nullptr;
-    rc = key_table(c, N, &cap, &tk, st);
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     // groups: the rmdup machinery (XXH64 of the ID / name, first occurrence wins, exact verification of every other one)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
     Arena A;
     const uint64_t o_has = A.take(N), o_ord = A.take(N * 4);
     rc = arena_reserve(c, &A);
@@ -277,7 +274,8 @@ int rename_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
     HIP_TRYX(c, hipMemsetAsync(d_ord, 0, N * 4, st));
     // collisions checked, and d_keys[i] := first record of i's group
-    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
+    rc = group_resolve(c, d_buf, tt, P, d_has, st);
+    if (rc != BSK_OK) return rc;
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     // how many records are not the first of their group
     uint64_t status = 0, m = 0;
@@ -652,9 +650,7 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
-    uint64_t cap = 0;
-    uint64_t* tk = nullptr;
-    rc = key_table(c, N, &cap, &tk, st);
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
@@ -677,9 +673,9 @@ int pair_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, 
     uint64_t* d_tot = A.at<uint64_t>(o_tot);
     // groups by ID (XXH64, first occurrence, exact verification of every other member)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
+    rc = group_resolve(c, d_buf, tt, P, d_has, st);
+    if (rc != BSK_OK) return rc;
     HIP_TRYX(c, hipMemsetAsync(d_tot, 0, 8 * 8, st));
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
@@ -777,9 +773,7 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
-    uint64_t cap = 0;
-    uint64_t* tk = nullptr;
-    rc = key_table(c, N, &cap, &tk, st);
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
@@ -792,9 +786,9 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
     uint64_t* d_ends = A.at<uint64_t>(o_ends);
     HIP_TRYX(c, hipMemcpyAsync(d_ends, file_ends, (size_t)nfiles * 8, hipMemcpyHostToDevice, st));
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
+    rc = group_resolve(c, d_buf, tt, P, d_has, st);
+    if (rc != BSK_OK) return rc;
     HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 8, st));
     HIP_TRYX(c, launch_common_masks(c->d_keys, c->table.start, N, d_ends, nfiles, d_masks, st));
     uint64_t status = 0;
@@ -850,9 +844,7 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
-    uint64_t cap = 0;
-    uint64_t* tk = nullptr;
-    rc = key_table(c, N, &cap, &tk, st);
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
@@ -869,9 +861,9 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     uint32_t* d_cnt = A.at<uint32_t>(o_cnt);
     uint64_t* d_cntoff = A.at<uint64_t>(o_cntoff);
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
     HIP_TRYX(c, hipMemsetAsync(d_has, 0, N, st));
-    HIP_TRYX(c, launch_rmdup_resolve_group(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, d_has, st));
+    rc = group_resolve(c, d_buf, tt, P, d_has, st);
+    if (rc != BSK_OK) return rc;
     HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_count_below(c->table.start, N, n_first, c->d_counter, st));
     uint64_t first2 = 0, status = 0;
