@@ -83,13 +83,23 @@ def main():
 
     if lib.bsk_device_count() <= 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py: no HIP device visible: the hot path has no CPU fallback (BSK_ERR_NO_DEVICE)")
+    # BSK_BENCH_SHARE_GPU=1: a FUNCTIONAL check of the N-rank path on a box with fewer GPUs than ranks -- the ranks share
+    # the devices (rank r on GPU r % count) and reduce over gloo (RCCL refuses two ranks on one device).  The line it prints
+    # says so ("shared_gpu_functional_check"); it is not a scaling measurement.
+    share = os.environ.get("BSK_BENCH_SHARE_GPU") == "1" and torch.cuda.device_count() < world
+    if share:
+        backend = "gloo"
+        local = local % torch.cuda.device_count()
     if torch.cuda.device_count() < (local + 1):
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         assert dist.get_world_size() == want_world
 
     # ---- the synthetic file, cut into record-aligned shards --------------------------
@@ -157,7 +167,7 @@ def main():
         dt = time.perf_counter() - t0
         lib.bsk_profile_enable(op.ctx, 0)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=bdist.coll_device(dev))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ms, n = C.c_double(), C.c_uint64()
@@ -190,7 +200,7 @@ def main():
         q30 += int((q >= 33 + 30).sum().item())
         del q
     if world > 1:
-        t = torch.tensor([q20, q30], dtype=torch.int64, device=dev)
+        t = torch.tensor([q20, q30], dtype=torch.int64, device=bdist.coll_device(dev))
         dist.all_reduce(t)
         q20, q30 = int(t[0].item()), int(t[1].item())
     verified_a = (ma.get(150) == total_rec and ma.get(-3) == 0 and ma.get(-1) == q20 and ma.get(-2) == q30
@@ -235,6 +245,8 @@ def main():
         "bit_exact_vs_expected_row": bool(verified),
         "shard_bytes_per_rank": nbytes,
         "allreduce_ms_per_step": round(reduce_ms, 4) if world > 1 else None,
+        "backend": (backend if world > 1 else None),
+        "shared_gpu_functional_check": bool(share),
         "roofline": {
             "bound": "hbm",
             "kernel": "k_stats<FASTQ,default>",

@@ -27,12 +27,28 @@ def shard_bounds(data, world, fmt):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def coll_device(device):
+    """The device a collective's tensors must live on: the rank's GPU under RCCL ("nccl"), the host under gloo (CPU
+    tests; two ranks sharing one GPU in bench.py's functional check)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
+
+
 def all_reduce_stats_vector(vec):
     """StatsReduce across ranks: ONE sum all-reduce of the stats vector (int64 tensor on the
     rank's device).  512 KB at hist_cap = 65536: latency-bound, not bandwidth-bound."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        cd = coll_device(vec.device)
+        if cd != vec.device:  # gloo: through the host
+            tmp = vec.to(cd)
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            vec.copy_(tmp)
+        else:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return vec
 
 
@@ -52,11 +68,12 @@ def exchange_stats_overflow(op, vec, group=None):
     check(lib.bsk_stats_overflow_get(op.ctx, None, 0, C.byref(n)), op.ctx)
     mine = (C.c_uint64 * max(1, n.value))()
     check(lib.bsk_stats_overflow_get(op.ctx, mine, n.value, C.byref(n)), op.ctx)
+    cdev = coll_device(vec.device)
     counts, _ = _all_gather_int(n.value, vec.device, group)
     width = max(counts)
-    pad = torch.zeros(max(1, width), dtype=torch.int64, device=vec.device)
+    pad = torch.zeros(max(1, width), dtype=torch.int64, device=cdev)
     if n.value:
-        pad[:n.value] = torch.tensor([int(x) for x in mine[:n.value]], dtype=torch.int64, device=vec.device)
+        pad[:n.value] = torch.tensor([int(x) for x in mine[:n.value]], dtype=torch.int64, device=cdev)
     parts = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     added = 0
@@ -168,6 +185,7 @@ def _all_gather_int(value, device, group=None):
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return [int(value)], 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    device = coll_device(device)
     parts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(parts, torch.tensor([int(value)], dtype=torch.int64, device=device), group=group)
     return [int(p.item()) for p in parts], rank
