@@ -91,7 +91,7 @@ def all_reduce_count(count, device="cpu"):
     """GrepReduceCount across ranks."""
     import torch
     import torch.distributed as dist
-    t = torch.tensor([int(count)], dtype=torch.int64, device=device)
+    t = torch.tensor([int(count)], dtype=torch.int64, device=coll_device(torch.device(device)))
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
@@ -158,9 +158,8 @@ def rmdup_distributed(shard, fmt, backend, group=None):
     n = backend.keys(shard, fmt)
     dev = shard.device
     if multi:
-        counts_all = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts_all, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
-        base = int(sum(int(c.item()) for c in counts_all[:rank]))
+        counts_all, _ = _all_gather_int(n, dev, group)
+        base = int(sum(counts_all[:rank]))
     else:
         base = 0
     send, in_splits = backend.pack(base, world)
@@ -168,14 +167,28 @@ def rmdup_distributed(shard, fmt, backend, group=None):
         return backend.emit(send, backend.resolve(send), base)
     t_in = torch.tensor(in_splits, dtype=torch.int64, device=dev)
     t_out = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(t_out, t_in, group=group)
+    _all_to_all_single(t_out, t_in, None, None, group)
     out_splits = [int(x) for x in t_out.tolist()]
     recv = torch.empty((sum(out_splits), 3), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+    _all_to_all_single(recv, send, out_splits, in_splits, group)
     keep = backend.resolve(recv)
     reply = torch.empty(n, dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(reply, keep, in_splits, out_splits, group=group)
+    _all_to_all_single(reply, keep, in_splits, out_splits, group)
     return backend.emit(send, reply, base)
+
+
+def _all_to_all_single(out, inp, out_splits, in_splits, group=None):
+    """dist.all_to_all_single on the rank's device under RCCL; staged through the host under gloo (CPU tests, ranks that
+    share a GPU)."""
+    import torch
+    import torch.distributed as dist
+    cd = coll_device(out.device)
+    if cd == out.device:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+        return
+    o = torch.empty(out.shape, dtype=out.dtype, device=cd)
+    dist.all_to_all_single(o, inp.to(cd), out_splits, in_splits, group=group)
+    out.copy_(o)
 
 
 def _all_gather_int(value, device, group=None):
