@@ -92,6 +92,70 @@ __global__ __launch_bounds__(256) void k_concat_size(const uint8_t* __restrict__
     count[i] = cnt;
 }
 
+
+// FASTQ elements as segments of the segmented copy (ops_segcopy.hip): an element "@ID\nSEQA SEQB\n+\nQUALA QUALB\n" is
+// five verbatim slices of the shard -- "@ID" of A | "\n" + sequence of A (the newline that ends A's head line) | sequence
+// of B + "\n+\n" (B's bare '+' line) | quality of A | quality of B + "\n" -- and a record kept as it is (Full) is one.
+// Five slots per element; a record whose elements do not fit that shape (a mate whose '+' line repeats the name, a last
+// record without final newline) keeps slot 0 of every element with source 0 and stays with k_concat_emit.
+__global__ __launch_bounds__(256) void k_concat_segs(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, ConcatParams P,
+                                                     const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ seg,
+                                                     const uint32_t* __restrict__ out_len, const uint64_t* __restrict__ out_off,
+                                                     const uint64_t* __restrict__ cnt_off, uint64_t* __restrict__ seg_src,
+                                                     uint64_t* __restrict__ seg_off, uint8_t* __restrict__ seg_done,
+                                                     unsigned long long* __restrict__ n_other) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    seg_done[i] = 0;
+    if (out_len[i] == 0) return;
+    const uint32_t s = seg[3 * i], m1 = seg[3 * i + 1], m2raw = seg[3 * i + 2], m2 = m2raw & ~SEG_DIRECT;
+    const uint64_t sa = t.start[i];
+    const uint32_t lh = t.l_head[i], hl = lh > 0 ? lh - 1 : 0, LA = t.l_seq[i];
+    const uint64_t e0 = cnt_off[i];
+    uint64_t o = out_off[i];
+    const uint64_t A = (uint64_t)(uintptr_t)buf;
+    auto put = [&](uint64_t slot, uint64_t src, uint64_t off) { seg_src[slot] = src; seg_off[slot] = off; };
+    const bool joined = i < P.first2 && m2 > 0;
+    if (!joined) {  // kept as it is: the whole record when Format() reproduces it
+        const uint64_t n = element_bytes(hl, LA, P);
+        const bool ok = t.aux[i] == 1u && sa + n <= buf_n;
+        put(5 * e0, ok ? A + sa : 0ull, o);
+        for (int k = 1; k < 5; ++k) put(5 * e0 + k, 0ull, o + n);
+        if (ok) seg_done[i] = 1; else atomicAdd(n_other, 1ull);
+        return;
+    }
+    uint32_t off;
+    const uint32_t il = id_span_rec(t, i, buf + sa + 1, hl, P.id_mode, &off, P.buf_end);
+    bool ok = off == 0;  // "@" + ID is one slice only when the ID begins the head (always, but for --id-ncbi / custom spans)
+    for (uint32_t k = 0; k < m2 && ok; ++k) {
+        const uint64_t b = mate_of(sorted, s, m1, m2raw, k);
+        const uint64_t qb = t.start[b] + t.l_head[b] + 1 + t.l_seq[b] + 1 + t.aux[b] + 1;
+        ok = t.aux[b] == 1u && qb + t.l_seq[b] + 1 <= buf_n;
+    }
+    if (!ok) atomicAdd(n_other, 1ull);
+    const uint64_t qa = sa + lh + 1 + LA + 1 + t.aux[i] + 1;
+    for (uint32_t k = 0; k < m2; ++k) {
+        const uint64_t b = mate_of(sorted, s, m1, m2raw, k);
+        const uint32_t LB = t.l_seq[b];
+        const uint64_t n = element_bytes(il, (uint64_t)LA + LB, P);
+        const uint64_t slot = 5 * (e0 + k);
+        if (!ok) {
+            put(slot, 0ull, o);
+            for (int q = 1; q < 5; ++q) put(slot + q, 0ull, o + n);
+        } else {
+            const uint64_t sb = t.start[b] + t.l_head[b] + 1;        // sequence of B
+            const uint64_t qb = sb + LB + 1 + 1 + 1;                 // its quality (bare '+' line)
+            put(slot, A + sa, o);                                    // "@ID"
+            put(slot + 1, A + sa + lh, o + 1 + il);                  // "\n" + SEQA
+            put(slot + 2, A + sb, o + 1 + il + 1 + LA);              // SEQB + "\n+\n"
+            put(slot + 3, A + qa, o + 1 + il + 1 + LA + LB + 3);     // QUALA
+            put(slot + 4, A + qb, o + 1 + il + 1 + LA + LB + 3 + LA);  // QUALB + "\n"
+        }
+        o += n;
+    }
+    if (ok) seg_done[i] = 1;
+}
+
 // FASTQ quality of record i (strict 4-line layout)
 __device__ __forceinline__ const uint8_t* qual_of(const uint8_t* __restrict__ buf, const RecordTable& t, uint64_t i) {
     return buf + t.start[i] + t.l_head[i] + 1 + t.l_seq[i] + 1 + t.aux[i] + 1;
@@ -168,10 +232,11 @@ template <int G>
 __global__ __launch_bounds__(256) void k_concat_emit(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt, ConcatParams P,
                                                      const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ seg,
                                                      const uint32_t* __restrict__ out_len, const uint64_t* __restrict__ out_off,
-                                                     uint8_t* __restrict__ out) {
+                                                     uint8_t* __restrict__ out, const uint8_t* __restrict__ seg_done) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
     if (i >= t.n || out_len[i] == 0) return;
+    if (seg_done && seg_done[i]) return;  // written by the segmented copy (k_concat_segs)
     const uint32_t s = seg[3 * i], m1 = seg[3 * i + 1], m2raw = seg[3 * i + 2], m2 = m2raw & ~SEG_DIRECT;
     const uint8_t* h = buf + t.start[i] + 1;
     const uint32_t lh = t.l_head[i];
@@ -211,16 +276,25 @@ hipError_t launch_concat_size(const uint8_t* buf, const RecordTable& t, const Co
 
 hipError_t launch_concat_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const ConcatParams& P,
                               const uint64_t* sorted, const uint32_t* seg, const uint32_t* out_len, const uint64_t* out_off,
-                              uint8_t* out, uint64_t avg_bytes, hipStream_t st) {
+                              uint8_t* out, uint64_t avg_bytes, hipStream_t st, const uint8_t* seg_done) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     // short reads: 4 lanes per record (a 150-byte span is 10 steps of 16 bytes), otherwise 16
     if (avg_bytes < 1024)
         hipLaunchKernelGGL((k_concat_emit<4>), dim3((unsigned)((t.n * 4 + 255) / 256)), dim3(256), 0, st, buf, t, d, P, sorted, seg,
-                           out_len, out_off, out);
+                           out_len, out_off, out, seg_done);
     else
         hipLaunchKernelGGL((k_concat_emit<16>), dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t, d, P, sorted, seg,
-                           out_len, out_off, out);
+                           out_len, out_off, out, seg_done);
+    return hipGetLastError();
+}
+
+hipError_t launch_concat_segs(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const ConcatParams& P, const uint64_t* sorted,
+                              const uint32_t* seg, const uint32_t* out_len, const uint64_t* out_off, const uint64_t* cnt_off,
+                              uint64_t* seg_src, uint64_t* seg_off, uint8_t* seg_done, uint64_t* n_other, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_concat_segs, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, P, sorted, seg, out_len, out_off,
+                       cnt_off, seg_src, seg_off, seg_done, (unsigned long long*)n_other);
     return hipGetLastError();
 }
 

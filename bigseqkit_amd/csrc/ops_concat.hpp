@@ -28,6 +28,11 @@ hipError_t launch_concat_size(const uint8_t* buf, const RecordTable& t, const Co
                               const uint32_t* seg, uint32_t* out_len, uint32_t* count, uint64_t* status, hipStream_t st);
 hipError_t launch_concat_emit(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const ConcatParams& P,
                               const uint64_t* sorted, const uint32_t* seg, const uint32_t* out_len, const uint64_t* out_off,
-                              uint8_t* out, uint64_t avg_bytes, hipStream_t st);
+                              uint8_t* out, uint64_t avg_bytes, hipStream_t st, const uint8_t* seg_done = nullptr);
+// FASTQ: five segments per element for the segmented copy (seg_src / seg_off: 5 * elements entries; the caller sets
+// seg_off[5 * elements] = total), seg_done[i] = 1 for the records it covers, *n_other counts the others
+hipError_t launch_concat_segs(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const ConcatParams& P, const uint64_t* sorted,
+                              const uint32_t* seg, const uint32_t* out_len, const uint64_t* out_off, const uint64_t* cnt_off,
+                              uint64_t* seg_src, uint64_t* seg_off, uint8_t* seg_done, uint64_t* n_other, hipStream_t st);
 
 }  // namespace bsk

@@ -904,8 +904,38 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     if (total == 0) return BSK_OK;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_concat_emit(d_buf, c->table, tt, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, c->d_out,
-                                   elements ? total / elements : 0, st));
+    const uint8_t* seg_done = nullptr;
+    bool emit_old = true;
+    {
+        // FASTQ: the elements are slices of the shard -- the segmented copy writes them (ops_segcopy.hip, k_concat_segs)
+        const char* sg = getenv("BSK_SEGCOPY");
+        const bool force = sg && strcmp(sg, "force") == 0;
+        if (fastq && elements > 0 && !(sg && strcmp(sg, "off") == 0) && (force || total >= (4u << 20))) {
+            const uint64_t ns = 5 * elements;
+            rc = grow(c, &c->d_seg_src, &c->seg_src_cap, 2 * ns + 2 + (N + 7) / 8 + 1, ns / 4 + 16);
+            if (rc != BSK_OK) return rc;
+            rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+            if (rc != BSK_OK) return rc;
+            uint64_t* seg_src = c->d_seg_src;
+            uint64_t* seg_off2 = c->d_seg_src + ns;  // [ns + 1]
+            uint64_t* d_other = c->d_seg_src + 2 * ns + 1;
+            uint8_t* d_done = reinterpret_cast<uint8_t*>(c->d_seg_src + 2 * ns + 2);
+            HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
+            HIP_TRYX(c, hipMemcpyAsync(seg_off2 + ns, &total, sizeof total, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, launch_concat_segs(d_buf, n, c->table, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, d_cntoff, seg_src,
+                                           seg_off2, d_done, d_other, st));
+            HIP_TRYX(c, launch_seg_first(seg_off2, ns, c->d_seg_first, st));
+            HIP_TRYX(c, launch_seg_copy(seg_src, seg_off2, ns, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st));
+            uint64_t other = 0;
+            HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            seg_done = d_done;
+            emit_old = other != 0;
+        }
+    }
+    if (emit_old)
+        HIP_TRYX(c, launch_concat_emit(d_buf, c->table, tt, Q, d_list + N, d_seg, c->d_out_len, c->d_out_off, c->d_out,
+                                       elements ? total / elements : 0, st, seg_done));
     out->d_data = c->d_out;
     out->len = total;
     out->records = elements;
