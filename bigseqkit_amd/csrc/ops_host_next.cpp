@@ -382,6 +382,11 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     Arena A;
     const uint64_t o_keys = A.take(2 * N * 8), o_perm = A.take(2 * N * 4), o_klen = A.take((N + 1) * 4),
                    o_tmp = A.take(tmp_bytes ? tmp_bytes : 16);
+    // string keys of more than three chunks: the tie pass (below)
+    const bool may_tie = P.mode < 3;
+    const uint64_t o_tied = A.take(may_tie ? N * 4 : 0), o_start = A.take(may_tie ? N * 4 : 0), o_rank = A.take(may_tie ? (N + 1) * 8 : 0),
+                   o_run = A.take(may_tie ? (N + 1) * 8 : 0), o_runof = A.take(may_tie ? N * 8 : 0), o_subpos = A.take(may_tie ? N * 4 : 0),
+                   o_subperm = A.take(may_tie ? 2 * N * 4 : 0);
     rc = arena_reserve(c, &A);
     if (rc != BSK_OK) return rc;
     uint64_t* d_keys2 = A.at<uint64_t>(o_keys);   // [2 N]
@@ -428,11 +433,57 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             launch_sort_keylen(d_buf, c->table, P, d_klen, d_klen + N, st) != hipSuccess ||
             hipMemcpyAsync(&maxlen, d_klen + N, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
-        // LSD over the 8-byte chunks of the keys, last chunk first; every pass is stable
-        for (uint32_t ch = (maxlen + 7) / 8; ch-- > 0;) {
-            if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, pin, ch, kin, st) != hipSuccess ||
-                launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 64, st) != hipSuccess) return fail(BSK_ERR_HIP);
-            std::swap(pin, pout);
+        const uint32_t nchunks = (maxlen + 7) / 8;
+        const char* se = getenv("BSK_SORT");  // lsd: every chunk for every record (the round-1 path)
+        if (nchunks <= 3 || (se && strcmp(se, "lsd") == 0)) {
+            // LSD over the 8-byte chunks of the keys, last chunk first; every pass is stable
+            for (uint32_t ch = nchunks; ch-- > 0;) {
+                if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, pin, ch, kin, st) != hipSuccess ||
+                    launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 64, st) != hipSuccess) return fail(BSK_ERR_HIP);
+                std::swap(pin, pout);
+            }
+        } else {
+            // long keys (sequences: 19 chunks for 150 bases): the order by the two LEADING chunks first -- 16 key bytes
+            // separate nearly all records -- then only the positions whose 16 bytes equal a neighbour's are ordered by the
+            // rest of the key (LSD over chunks n-1 .. 2 on that subset, then a stable pass by run number puts every run
+            // back in its place).  Same result as the full LSD sweep, ties in file order included.
+            rc = ensure_record_scratch(c);  // (the scan scratch)
+            if (rc != BSK_OK) return fail(rc);
+            for (uint32_t ch = 2; ch-- > 0;) {
+                if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, pin, ch, kin, st) != hipSuccess ||
+                    launch_sort_pairs(d_tmp, tmp_bytes, kin, kout, pin, pout, N, desc, 64, st) != hipSuccess) return fail(BSK_ERR_HIP);
+                std::swap(pin, pout);
+            }
+            // kout = chunk 0 in the new order; chunk 1 in that order once more
+            if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, pin, 1, kin, st) != hipSuccess) return fail(BSK_ERR_HIP);
+            uint32_t* d_tied = A.at<uint32_t>(o_tied);
+            uint32_t* d_start = A.at<uint32_t>(o_start);
+            uint64_t* d_rank = A.at<uint64_t>(o_rank);
+            uint64_t* d_run = A.at<uint64_t>(o_run);
+            uint64_t* d_run_of = A.at<uint64_t>(o_runof);
+            uint32_t* d_sub_pos = A.at<uint32_t>(o_subpos);
+            uint32_t* sp_in = A.at<uint32_t>(o_subperm);
+            uint32_t* sp_out = sp_in + N;
+            uint64_t m = 0;
+            if (launch_sort_tie_flags(kout, kin, N, d_tied, d_start, st) != hipSuccess ||
+                launch_scan_u32(d_tied, d_rank, N, c->d_scan_tmp, st) != hipSuccess ||
+                launch_scan_u32(d_start, d_run, N, c->d_scan_tmp, st) != hipSuccess ||
+                hipMemcpyAsync(&m, d_rank + N, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
+            if (m) {
+                if (launch_sort_tie_gather(d_tied, d_rank, d_run, d_start, pin, N, d_sub_pos, sp_in, d_run_of, st) != hipSuccess)
+                    return fail(BSK_ERR_HIP);
+                uint64_t* sk_in = kin;   // the key buffers are free again
+                uint64_t* sk_out = kout;
+                for (uint32_t ch = nchunks; ch-- > 2;) {
+                    if (launch_sort_chunk(d_buf, c->table, tt, P, d_klen, sp_in, ch, sk_in, st, m) != hipSuccess ||
+                        launch_sort_pairs(d_tmp, tmp_bytes, sk_in, sk_out, sp_in, sp_out, m, desc, 64, st) != hipSuccess) return fail(BSK_ERR_HIP);
+                    std::swap(sp_in, sp_out);
+                }
+                if (launch_sort_gather_keys(d_run_of, sp_in, m, sk_in, st) != hipSuccess ||
+                    launch_sort_pairs(d_tmp, tmp_bytes, sk_in, sk_out, sp_in, sp_out, m, false, 64, st) != hipSuccess ||
+                    launch_sort_tie_scatter(d_sub_pos, sp_out, m, pin, st) != hipSuccess) return fail(BSK_ERR_HIP);
+            }
         }
     }
     // sizes in file order, offsets in sorted order

@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256) void k_sort_keylen(const uint8_t* __restrict__
 __global__ __launch_bounds__(256) void k_sort_chunk(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
                                                     SortParams P, const uint32_t* __restrict__ key_len,
                                                     const uint32_t* __restrict__ perm, uint32_t chunk,
-                                                    uint64_t* __restrict__ keys) {
+                                                    uint64_t* __restrict__ keys, uint64_t count) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= t.n) return;
+    if (j >= count) return;
     const uint64_t i = perm[j];
     const uint32_t len = key_len[i];
     const uint32_t b0 = chunk * 8u;
@@ -196,10 +196,70 @@ hipError_t launch_sort_keylen(const uint8_t* buf, const RecordTable& t, const So
 }
 
 hipError_t launch_sort_chunk(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const SortParams& P,
-                             const uint32_t* key_len, const uint32_t* perm, uint32_t chunk, uint64_t* keys, hipStream_t st) {
-    if (t.n == 0) return hipSuccess;
+                             const uint32_t* key_len, const uint32_t* perm, uint32_t chunk, uint64_t* keys, hipStream_t st,
+                             uint64_t count) {
+    if (count == ~0ull) count = t.n;
+    if (count == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    hipLaunchKernelGGL(k_sort_chunk, grid_for(t.n), dim3(256), 0, st, buf, t, d, P, key_len, perm, chunk, keys);
+    hipLaunchKernelGGL(k_sort_chunk, grid_for(count), dim3(256), 0, st, buf, t, d, P, key_len, perm, chunk, keys, count);
+    return hipGetLastError();
+}
+
+// ---- ties after the two leading chunks (sort_run_device) ----------------------------------------------------------
+namespace {
+// position j of the order by (chunk 0, chunk 1): tied[j] = 1 when a neighbour has the same 16 key bytes, start[j] = 1 for
+// the first position of such a run
+__global__ __launch_bounds__(256) void k_sort_tie_flags(const uint64_t* __restrict__ k0, const uint64_t* __restrict__ k1, uint64_t n,
+                                                        uint32_t* __restrict__ tied, uint32_t* __restrict__ start) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const bool prev = j > 0 && k0[j - 1] == k0[j] && k1[j - 1] == k1[j];
+    const bool next = j + 1 < n && k0[j + 1] == k0[j] && k1[j + 1] == k1[j];
+    tied[j] = (prev || next) ? 1u : 0u;
+    start[j] = (!prev && next) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_sort_tie_gather(const uint32_t* __restrict__ tied, const uint64_t* __restrict__ rank,
+                                                         const uint64_t* __restrict__ run, const uint32_t* __restrict__ start,
+                                                         const uint32_t* __restrict__ perm, uint64_t n, uint32_t* __restrict__ sub_pos,
+                                                         uint32_t* __restrict__ sub_perm, uint64_t* __restrict__ run_of) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !tied[j]) return;
+    const uint64_t k = rank[j];
+    sub_pos[k] = (uint32_t)j;
+    sub_perm[k] = perm[j];
+    run_of[perm[j]] = run[j] + start[j] - 1u;  // runs before this position (its own counts from its first element on)
+}
+__global__ __launch_bounds__(256) void k_sort_gather_keys(const uint64_t* __restrict__ by_record, const uint32_t* __restrict__ perm,
+                                                          uint64_t m, uint64_t* __restrict__ keys) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) keys[k] = by_record[perm[k]];
+}
+__global__ __launch_bounds__(256) void k_sort_tie_scatter(const uint32_t* __restrict__ sub_pos, const uint32_t* __restrict__ sub_perm,
+                                                          uint64_t m, uint32_t* __restrict__ perm) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) perm[sub_pos[k]] = sub_perm[k];
+}
+}  // namespace
+
+hipError_t launch_sort_tie_flags(const uint64_t* k0, const uint64_t* k1, uint64_t n, uint32_t* tied, uint32_t* start, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_tie_flags, grid_for(n), dim3(256), 0, st, k0, k1, n, tied, start);
+    return hipGetLastError();
+}
+hipError_t launch_sort_tie_gather(const uint32_t* tied, const uint64_t* rank, const uint64_t* run, const uint32_t* start,
+                                  const uint32_t* perm, uint64_t n, uint32_t* sub_pos, uint32_t* sub_perm, uint64_t* run_of, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_tie_gather, grid_for(n), dim3(256), 0, st, tied, rank, run, start, perm, n, sub_pos, sub_perm, run_of);
+    return hipGetLastError();
+}
+hipError_t launch_sort_gather_keys(const uint64_t* by_record, const uint32_t* perm, uint64_t m, uint64_t* keys, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_gather_keys, grid_for(m), dim3(256), 0, st, by_record, perm, m, keys);
+    return hipGetLastError();
+}
+hipError_t launch_sort_tie_scatter(const uint32_t* sub_pos, const uint32_t* sub_perm, uint64_t m, uint32_t* perm, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_tie_scatter, grid_for(m), dim3(256), 0, st, sub_pos, sub_perm, m, perm);
     return hipGetLastError();
 }
 

@@ -37,7 +37,16 @@ hipError_t launch_sort_keylen(const uint8_t* buf, const RecordTable& t, const So
                               uint32_t* max_len, hipStream_t st);
 // keys[j] = bytes [8 chunk, 8 chunk + 8) of the key of record perm[j], big-endian, zero padded
 hipError_t launch_sort_chunk(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const SortParams& P,
-                             const uint32_t* key_len, const uint32_t* perm, uint32_t chunk, uint64_t* keys, hipStream_t st);
+                             const uint32_t* key_len, const uint32_t* perm, uint32_t chunk, uint64_t* keys, hipStream_t st,
+                             uint64_t count = ~0ull /* entries of perm; default: all records */);
+// long keys: after the order by the two leading chunks only the positions whose 16 key bytes equal a neighbour's need the
+// rest of the key.  tied / start flags of every position; the tied positions gathered (rank = exclusive scan of tied, run =
+// exclusive scan of start); the re-ordered subset put back
+hipError_t launch_sort_tie_flags(const uint64_t* k0, const uint64_t* k1, uint64_t n, uint32_t* tied, uint32_t* start, hipStream_t st);
+hipError_t launch_sort_tie_gather(const uint32_t* tied, const uint64_t* rank, const uint64_t* run, const uint32_t* start,
+                                  const uint32_t* perm, uint64_t n, uint32_t* sub_pos, uint32_t* sub_perm, uint64_t* run_of /* by record */, hipStream_t st);
+hipError_t launch_sort_gather_keys(const uint64_t* by_record, const uint32_t* perm, uint64_t m, uint64_t* keys, hipStream_t st);
+hipError_t launch_sort_tie_scatter(const uint32_t* sub_pos, const uint32_t* sub_perm, uint64_t m, uint32_t* perm, hipStream_t st);
 // modes 3, 4: keys[i] = length / non-gap bases of record i (as 64-bit keys)
 hipError_t launch_sort_intkeys(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const SortParams& P,
                                uint64_t* keys, hipStream_t st);

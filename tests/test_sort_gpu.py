@@ -113,3 +113,30 @@ def test_sort_natural_order_hand_case():
     # -N is ignored when sorting by sequence or length (sort.go:130-133)
     for o in ({"InNaturalOrder": True, "BySeq": True}, {"InNaturalOrder": True, "ByLength": True}):
         assert bsk.Sort(fr(), _Opts(o)) == oracle.sort(data, False, json.dumps(o)), o
+
+
+@pytest.mark.parametrize("opts", [{"BySeq": True}, {"BySeq": True, "Reverse": True}, {"BySeq": True, "IgnoreCase": True},
+                                  {"ByName": True}, {"ByName": True, "Reverse": True}])
+def test_long_keys_leading_chunks_then_ties_only(opts, monkeypatch):
+    """keys of more than three 8-byte chunks: the order by the two leading chunks, then only the tied positions by the rest
+    (ops_host_next.cpp sort_run_device).  Records that share 16, 24, 40 leading key bytes, exact duplicates (ties keep
+    file order), keys that end inside a chunk; the full LSD sweep (BSK_SORT=lsd) must give the same bytes."""
+    rng = random.Random(5151)
+    stems = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (16, 16, 24, 40, 41, 7)]
+    recs = []
+    for i in range(3000):
+        k = rng.random()
+        if k < 0.5:
+            s = rng.choice(stems) + "".join(rng.choice("ACGTacgt") for _ in range(rng.randint(0, 60)))
+        elif k < 0.6 and recs:
+            s = rng.choice(recs)[1]                     # an exact duplicate of an earlier sequence
+        else:
+            s = "".join(rng.choice("ACGTN") for _ in range(rng.randint(0, 150)))
+        name = "%s_%d tail %d" % (rng.choice(["a_long_common_name_prefix_of_more_than_16_bytes", "b" * 30, "c"]), rng.randrange(40), i % 7)
+        recs.append((name, s))
+    data = "".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in recs).encode()
+    want = oracle.sort(data, True, json.dumps(opts))
+    fr = lambda: bsk.SeqFrame(bsk.FORMAT_FASTQ, [dev(data)])
+    assert bsk.Sort(fr(), _Opts(opts)) == want
+    monkeypatch.setenv("BSK_SORT", "lsd")
+    assert bsk.Sort(fr(), _Opts(opts)) == want
