@@ -999,7 +999,13 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.pat_off = c->d_pat_off;
         rc = ensure_record_scratch(c);
         if (rc != BSK_OK) return rc;
-        if (G.by_seq && !G.general && !G.regex) {
+        if (filtered) {
+            // the table holds exactly the records the command prints (the streaming pass verified every occurrence,
+            // stream_filter.hip): no second search, only their formatted sizes
+            SeqParams FP = format_params(c, fastq);
+            FP.buf_end = d_buf + n;
+            HIP_TRYX(c, launch_seq_size(d_buf, c->table, FP, c->d_out_len, c->d_status, st));
+        } else if (G.by_seq && !G.general && !G.regex) {
             // chromosome-sized sequences are searched by whole blocks (k_grep_seq<.., LONG>): list them
             const char* e = getenv("BSK_LONG_BYTES");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
@@ -1021,7 +1027,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 G.long_thresh = thresh;
             }
         }
-        HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st, c->avg_record_bytes));
+        if (!filtered) HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st, c->avg_record_bytes));
         if (o.b("DeleteMatched") && !G.invert) {
             // grep.go:463-511 + bigseqkit/grep.go:144-156: a pattern is dropped at its first hit and the driver keeps
             // the lowest partition per pattern, so every pattern selects its FIRST record in file order (PARITY.md DEL)
