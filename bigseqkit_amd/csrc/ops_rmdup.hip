@@ -544,51 +544,55 @@ __global__ __launch_bounds__(256) void k_bucket_dedupe(const uint64_t* __restric
     }
 }
 
+// RV lanes per record (measured at C5: 1 -> 29.6, 2 -> 28.9, 4 -> 30.2, 8 -> 31.8 ms for the whole rmdup): a duplicate (one
+// record in five) is compared with its survivor by the lanes of its group, 16
+// bytes per lane and step -- with one lane per record the few lanes that had a duplicate walked 2 x 150 bytes alone
+#ifndef BSK_RMDUP_RV
+#define BSK_RMDUP_RV 2
+#endif
 template <bool GROUP>
 __global__ __launch_bounds__(256) void k_rmdup_resolve_first(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt,
                                                              RmDupParams P, const uint32_t* __restrict__ first_of,
                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ out_len,
                                                              uint64_t* __restrict__ status, uint8_t* __restrict__ has_dup) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t RV = BSK_RMDUP_RV;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / RV;
+    const uint32_t gl = threadIdx.x % RV;
     if (i >= t.n) return;
     const uint64_t first = first_of[i];
-    if (GROUP) {
+    if (GROUP && gl == 0) {
         keys[i] = first;
         if (first != i) has_dup[first] = 1;
     }
-    bool keep = first == i;
+    const bool keep = first == i;
     if (!keep) {
         const Subject a = subject_of(buf, t, tt, P, i), b = subject_of(buf, t, tt, P, first);
         bool same = a.len == b.len;
-        uint32_t q = 0;
         const bool plain = a.seq ? (a.T.W == 0 && b.T.W == 0 && !a.fold) : !a.fold;
         if (same && plain) {
-            // contiguous subjects: 32 bytes of each per step, no early exit -- the loads of a step do not wait for the
-            // comparison of the one before (a `same &&` loop is a chain of ~19 dependent round trips per 150 bases)
             const uint8_t* pa = a.seq ? a.T.p : a.h;
             const uint8_t* pb = b.seq ? b.T.p : b.h;
             uint32_t diff = 0;
-#pragma unroll 2
-            for (; q + 32 <= a.len; q += 32) {
-                uint4 a0, a1, b0, b1;
-                __builtin_memcpy(&a0, pa + q, 16);
-                __builtin_memcpy(&a1, pa + q + 16, 16);
-                __builtin_memcpy(&b0, pb + q, 16);
-                __builtin_memcpy(&b1, pb + q + 16, 16);
-                diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) |
-                        (a1.z ^ b1.z) | (a1.w ^ b1.w);
+            uint32_t q = 16u * gl;
+            for (; q + 16u <= a.len; q += 16u * RV) {  // (no early exit: the loads of a step do not wait for the step before)
+                uint4 x, y;
+                __builtin_memcpy(&x, pa + q, 16);
+                __builtin_memcpy(&y, pb + q, 16);
+                diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
             }
+            if (q < a.len)  // the lane whose next chunk is the last, partial one
+                for (uint32_t k = q; k < a.len; ++k) diff |= (uint32_t)(pa[k] ^ pb[k]);
             same = diff == 0;
+        } else if (same) {
+            for (uint32_t q = gl; same && q < a.len; q += RV) same = a.at(q) == b.at(q);
         }
-        for (; same && q + 8 <= a.len; q += 8) same = word64(a, q) == word64(b, q);  // 8 subject bytes per step
-        for (; same && q < a.len; ++q) same = a.at(q) == b.at(q);
-        if (!same) {  // distinct subjects under one 64-bit key: refuse rather than guess
-            atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
-            keep = true;
-        }
+        // distinct subjects under one 64-bit key: refuse rather than guess (the call fails: out_len does not matter then)
+        if (!same) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
     }
-    const uint32_t lh = t.l_head[i];
-    out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
+    if (gl == 0) {
+        const uint32_t lh = t.l_head[i];
+        out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
+    }
 }
 
 }  // namespace
@@ -705,7 +709,7 @@ hipError_t launch_rmdup_resolve_first(const uint8_t* buf, const RecordTable& t, 
                                       uint8_t* has_dup, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    const dim3 gr((unsigned)((t.n + 255) / 256));
+    const dim3 gr((unsigned)((t.n * BSK_RMDUP_RV + 255) / 256));
     if (keys_group) hipLaunchKernelGGL(k_rmdup_resolve_first<true>, gr, dim3(256), 0, st, buf, t, d, P, first, keys_group, out_len, status, has_dup);
     else hipLaunchKernelGGL(k_rmdup_resolve_first<false>, gr, dim3(256), 0, st, buf, t, d, P, first, (uint64_t*)nullptr, out_len, status, (uint8_t*)nullptr);
     return hipGetLastError();
