@@ -179,23 +179,38 @@ __device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_e
     const uint8_t* src = s.seq ? s.T.p : s.h;
     const uint64_t a = (uint64_t)(uintptr_t)src;
     const uint32_t q = lane >> 4, gl = lane & 15u;
-    for (uint32_t j = 0; j < 16u; ++j) {
-        const int r = (int)(4u * j + q);
-        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a, r, 64), hi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), r, 64);
-        const uint32_t len_r = (uint32_t)__shfl((int)(live ? s.len : 0u), r, 64);
-        const uint8_t* pr = (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-        const uint32_t off = gl * 16u;
-        if (off < len_r) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (pr + off + 16 <= buf_end) {
-                uint4 v;
-                __builtin_memcpy(&v, pr + off, 16);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                for (uint32_t b = 0; off + b < len_r; ++b) w[b >> 2] |= (uint32_t)pr[off + b] << (8 * (b & 3));
+    const uint32_t off = gl * 16u;
+    // eight records' loads are issued before the first of them is written to LDS (one load per loop turn left the wave
+    // waiting for memory sixteen times in a row, at 3 waves per SIMD -- the stage takes 42 KB of LDS per block)
+#pragma unroll
+    for (uint32_t half = 0; half < 2u; ++half) {
+        uint32_t w[8][4];
+        bool on[8];
+#pragma unroll
+        for (uint32_t jj = 0; jj < 8u; ++jj) {
+            const int r = (int)(4u * (8u * half + jj) + q);
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a, r, 64), hi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), r, 64);
+            const uint32_t len_r = (uint32_t)__shfl((int)(live ? s.len : 0u), r, 64);
+            const uint8_t* pr = (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+            on[jj] = off < len_r;
+            w[jj][0] = w[jj][1] = w[jj][2] = w[jj][3] = 0;
+            if (on[jj]) {
+                if (pr + off + 16 <= buf_end) {
+                    uint4 v;
+                    __builtin_memcpy(&v, pr + off, 16);
+                    w[jj][0] = v.x; w[jj][1] = v.y; w[jj][2] = v.z; w[jj][3] = v.w;
+                } else {
+                    for (uint32_t b = 0; off + b < len_r; ++b) w[jj][b >> 2] |= (uint32_t)pr[off + b] << (8 * (b & 3));
+                }
             }
-            uint32_t* d = reinterpret_cast<uint32_t*>(slot + (uint32_t)r * STAGE_STRIDE + off);
-            d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+        }
+#pragma unroll
+        for (uint32_t jj = 0; jj < 8u; ++jj) {
+            if (on[jj]) {
+                const uint32_t r = 4u * (8u * half + jj) + q;
+                uint32_t* d = reinterpret_cast<uint32_t*>(slot + r * STAGE_STRIDE + off);
+                d[0] = w[jj][0]; d[1] = w[jj][1]; d[2] = w[jj][2]; d[3] = w[jj][3];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -204,6 +219,8 @@ __device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_e
     return true;
 }
 
+// (Staging 32 subjects at a time -- 5.2 KB of LDS per wave instead of 10.5, i.e. 7 instead of 3 waves per SIMD -- was
+// measured slower: rmdup 31.6 vs 29.1 ms.  The kernel is not short of waves.)
 __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                     RmDupParams P, uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2) {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][64 * STAGE_STRIDE];
