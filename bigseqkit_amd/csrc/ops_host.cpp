@@ -474,7 +474,7 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
     const RecordTable& t = c->table;
     const char* env = getenv("BSK_SEGCOPY");  // off: never; force: whenever the records qualify (tests)
     const bool verbatim = P.fastq && !P.fasta_out && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id &&
-                          !P.reverse && !P.use_lut && !P.region_on && !P.feat_on && !P.remove_gaps && !P.ren_ord;
+                          !P.reverse && !P.use_lut && !P.region_on && !P.feat_on && !P.remove_gaps;  // (rename: per record, below)
     bool seg = verbatim && t.n > 0 && total > 0 && ((uintptr_t)d_out & 15u) == 0 && !(env && strcmp(env, "off") == 0);
     if (seg && !(env && strcmp(env, "force") == 0)) seg = kept * 2 >= t.n && total >= (4u << 20);
     if (seg) {
@@ -484,7 +484,7 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
         if (rc != BSK_OK) return rc;
         uint64_t* d_other = c->d_seg_src + t.n;
         HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
-        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, d_other, st));
+        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, d_other, st, P.ren_ord));
         HIP_TRYX(c, launch_seg_first(d_off, t.n, c->d_seg_first, st));
         {
             Timed tm(c, "k_seg_copy", st);

@@ -10,14 +10,15 @@ namespace {
 
 __global__ __launch_bounds__(256) void k_seg_build_fastq(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
                                                          const uint32_t* __restrict__ out_len, uint64_t* __restrict__ seg_src,
-                                                         unsigned long long* __restrict__ n_other) {
+                                                         unsigned long long* __restrict__ n_other, const uint32_t* __restrict__ ren_ord) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n) return;
     const uint32_t n = out_len[i];
     uint64_t s = 0;
     if (n) {
         const uint64_t st = t.start[i];
-        if (t.aux[i] == 1u && st + n <= buf_n) s = (uint64_t)(uintptr_t)(buf + st);
+        // (rename: a record with an ordinal gets a new head and stays with the record-wise emit)
+        if (t.aux[i] == 1u && st + n <= buf_n && !(ren_ord && ren_ord[i])) s = (uint64_t)(uintptr_t)(buf + st);
         else atomicAdd(n_other, 1ull);  // rare: a '+' line that repeats the name, or the last record of a shard without '\n'
     }
     seg_src[i] = s;
@@ -266,10 +267,10 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint64_t* __restrict__ s
 }  // namespace
 
 hipError_t launch_seg_build_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
-                                  uint64_t* seg_src, uint64_t* n_other, hipStream_t st) {
+                                  uint64_t* seg_src, uint64_t* n_other, hipStream_t st, const uint32_t* ren_ord) {
     if (t.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_seg_build_fastq, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, out_len, seg_src,
-                       (unsigned long long*)n_other);
+                       (unsigned long long*)n_other, ren_ord);
     return hipGetLastError();
 }
 

@@ -20,7 +20,8 @@ inline uint64_t seg_tiles(uint64_t total) { return (total + SEG_TILE - 1) / SEG_
 // bare '+' line, and the text incl. its final newline lies inside the shard.  Other records with output get 0 and are
 // counted in *n_other (they stay with the record-wise emit kernel).
 hipError_t launch_seg_build_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
-                                  uint64_t* seg_src, uint64_t* n_other, hipStream_t st);
+                                  uint64_t* seg_src, uint64_t* n_other, hipStream_t st,
+                                  const uint32_t* ren_ord = nullptr /* rename: records with ren_ord[i] != 0 get a new head */);
 // sort: the same for the records in the order perm[0], perm[1], ... (seg_sorted[k] belongs to record perm[k]; seg_rec[i] to
 // record i, for the record-wise emit of what is left)
 hipError_t launch_seg_build_fastq_perm(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* out_len,
