@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         const uint8_t* src = buf + t.start[g];
         const uint32_t body = n - 1;  // everything but the final newline, which the shard may lack
         const uint32_t hi = last_byte(0, body);
-        for (uint32_t x = first_step(0) + gl * 16u; x < hi; x += LANES * 16u) {
+        for (uint32_t x0 = first_step(0) + gl * 16u; x0 < hi; x0 += LANES * 16u) {
+            const uint32_t x = (!LONG && x0 + 16u > body && body >= 16u) ? body - 16u : x0;  // (see xform_copy)
             if (x + 16u <= body) {
                 uint4 v;
                 __builtin_memcpy(&v, src + x, 16);
@@ -310,6 +311,32 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         const bool verbatim = !reverse && !use_lut &&
                               ((TW == 0 && W == L) || (TW != 0 && (int)TW == P.line_width && sub_b == 0));
         if (verbatim) {
+            if (!LONG && a && !HS.suffix && !HS.ord) {
+                // the head (or the ID) is one slice of the record: marker and newline by lane 0, the bytes 16 at a time with
+                // the last step taken from the slice's end, or -- below 16 bytes -- 8 / 4 / 2 / 1 by one lane (a byte per
+                // lane and turn cost the group four turns for a 12-byte name)
+                const uint32_t m = P.print_seq ? 1u : 0u, nb = a - 1u - m;
+                const uint8_t* hs = HS.head + HS.hoff;
+                uint8_t* dst = o + m;
+                if (gl == 0) {
+                    if (m) o[0] = (P.fastq && !P.fasta_out) ? '@' : '>';
+                    o[a - 1] = '\n';
+                }
+                if (nb >= 16u) {
+                    for (uint32_t x0 = gl * 16u; x0 < nb; x0 += LANES * 16u) {
+                        const uint32_t x = x0 + 16u > nb ? nb - 16u : x0;
+                        uint4 v;
+                        __builtin_memcpy(&v, hs + x, 16);
+                        __builtin_memcpy(dst + x, &v, 16);
+                    }
+                } else if (gl == (LANES > 1u ? 1u : 0u)) {
+                    uint32_t k = 0;
+                    if (nb & 8u) { uint2 v; __builtin_memcpy(&v, hs, 8); __builtin_memcpy(dst, &v, 8); k = 8u; }
+                    if (nb & 4u) { uint32_t v; __builtin_memcpy(&v, hs + k, 4); __builtin_memcpy(dst + k, &v, 4); k += 4u; }
+                    if (nb & 2u) { uint16_t v; __builtin_memcpy(&v, hs + k, 2); __builtin_memcpy(dst + k, &v, 2); k += 2u; }
+                    if (nb & 1u) dst[k] = hs[k];
+                }
+            } else
             for (uint32_t x = clo + gl; x < (a < chi ? a : chi); x += LANES) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 uint8_t c;
@@ -321,7 +348,8 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
             auto group_copy = [&](uint32_t off, const uint8_t* src, uint32_t nb) {
                 uint8_t* dst = o + off;
                 const uint32_t hi = last_byte(off, nb);
-                for (uint32_t x = first_step(off) + gl * 16u; x < hi; x += LANES * 16u) {
+                for (uint32_t x0 = first_step(off) + gl * 16u; x0 < hi; x0 += LANES * 16u) {
+                    const uint32_t x = (!LONG && x0 + 16u > nb && nb >= 16u) ? nb - 16u : x0;  // (see xform_copy)
                     if (x + 16u <= nb) {
                         uint4 v;
                         __builtin_memcpy(&v, src + x, 16);
@@ -352,6 +380,32 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
         // (The LDS map holds P.lut, or the complement of a '-' strand feature; both are never active together.)
         const bool lut_in_lds = use_lut && (lut == P.lut ? P.use_lut != 0 : true);
         if (TW == 0 && W == L && (!use_lut || lut_in_lds)) {
+            if (!LONG && a && !HS.suffix && !HS.ord) {
+                // the head (or the ID) is one slice of the record: marker and newline by lane 0, the bytes 16 at a time with
+                // the last step taken from the slice's end, or -- below 16 bytes -- 8 / 4 / 2 / 1 by one lane (a byte per
+                // lane and turn cost the group four turns for a 12-byte name)
+                const uint32_t m = P.print_seq ? 1u : 0u, nb = a - 1u - m;
+                const uint8_t* hs = HS.head + HS.hoff;
+                uint8_t* dst = o + m;
+                if (gl == 0) {
+                    if (m) o[0] = (P.fastq && !P.fasta_out) ? '@' : '>';
+                    o[a - 1] = '\n';
+                }
+                if (nb >= 16u) {
+                    for (uint32_t x0 = gl * 16u; x0 < nb; x0 += LANES * 16u) {
+                        const uint32_t x = x0 + 16u > nb ? nb - 16u : x0;
+                        uint4 v;
+                        __builtin_memcpy(&v, hs + x, 16);
+                        __builtin_memcpy(dst + x, &v, 16);
+                    }
+                } else if (gl == (LANES > 1u ? 1u : 0u)) {
+                    uint32_t k = 0;
+                    if (nb & 8u) { uint2 v; __builtin_memcpy(&v, hs, 8); __builtin_memcpy(dst, &v, 8); k = 8u; }
+                    if (nb & 4u) { uint32_t v; __builtin_memcpy(&v, hs + k, 4); __builtin_memcpy(dst + k, &v, 4); k += 4u; }
+                    if (nb & 2u) { uint16_t v; __builtin_memcpy(&v, hs + k, 2); __builtin_memcpy(dst + k, &v, 2); k += 2u; }
+                    if (nb & 1u) dst[k] = hs[k];
+                }
+            } else
             for (uint32_t x = clo + gl; x < (a < chi ? a : chi); x += LANES) {
                 const uint32_t m = P.print_seq ? 1u : 0u;
                 uint8_t c;
@@ -363,7 +417,11 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
             auto xform_copy = [&](uint32_t off, const uint8_t* src, uint32_t nb, bool map) {
                 uint8_t* dst = o + off;
                 const uint32_t hi = last_byte(off, nb);
-                for (uint32_t x = first_step(off) + gl * 16u; x < hi; x += LANES * 16u) {
+                for (uint32_t x0 = first_step(off) + gl * 16u; x0 < hi; x0 += LANES * 16u) {
+                    // the last, partial step of a span of 16 bytes or more is taken 16 bytes wide from the span's end: it
+                    // overlaps the step before with the same bytes (a byte loop here kept one lane busy for up to 15 turns
+                    // per span while its group waited)
+                    const uint32_t x = (!LONG && x0 + 16u > nb && nb >= 16u) ? nb - 16u : x0;
                     if (x + 16u <= nb) {
                         uint4 v;
                         __builtin_memcpy(&v, src + (reverse ? nb - 16u - x : x), 16);
