@@ -91,12 +91,18 @@ BSK_HD bool fastq_record_at(const uint8_t* buf, uint64_t n, uint64_t p) {
     return true;
 }
 
-BSK_HD uint64_t find_fastq_start(const uint8_t* buf, uint64_t n, uint64_t from) {
+// `limit` (device side: ANCHOR_SEARCH_BYTES past `from`) bounds the search: text that is not FASTQ at all -- FASTA handed
+// over with the FASTQ flag -- holds no record start, and every range boundary of a 10 GB shard walking to the end of the
+// buffer kept the GPU busy for a quarter of an hour.  ANCHOR_NONE = nothing found before the limit.
+constexpr uint64_t ANCHOR_NONE = ~0ull;
+constexpr uint64_t ANCHOR_SEARCH_BYTES = 32ull << 20;  // (several of the longest reads there are)
+BSK_HD uint64_t find_fastq_start(const uint8_t* buf, uint64_t n, uint64_t from, uint64_t limit = ~0ull) {
     if (from >= n) return n;
     if (from == 0 && fastq_record_at(buf, n, 0)) return 0;
     uint64_t j = from == 0 ? find_byte(buf, n, 0, '\n') : find_byte(buf, n, from - 1, '\n');
     while (j < n) {
         if (fastq_record_at(buf, n, j + 1)) return j + 1;
+        if (j >= limit) return ANCHOR_NONE;
         j = find_byte(buf, n, j + 1, '\n');
     }
     return n;

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         r = wave_first(r);
         if (r >= nranges) break;
         uint64_t rs = anchors[r], re = anchors[r + 1];
+        if (rs == ANCHOR_NONE || re == ANCHOR_NONE) { sink.err |= ERR_ANCHOR; continue; }  // no record start within reach: not FASTQ
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) continue;
@@ -297,7 +298,8 @@ __global__ void k_prep(const uint8_t* __restrict__ buf, uint64_t n, uint64_t chu
         return;
     }
     const uint64_t from = (uint64_t)r * chunk;
-    anchors[r] = FASTQ ? find_fastq_start(buf, n, from) : (line_mode ? find_line_start(buf, n, from) : find_fasta_start(buf, n, from));
+    anchors[r] = FASTQ ? find_fastq_start(buf, n, from, from + ANCHOR_SEARCH_BYTES)
+                       : (line_mode ? find_line_start(buf, n, from) : find_fasta_start(buf, n, from));
 }
 
 // Records that cross range boundaries (FASTA, line-start ranges).  A record that is open at the end of range r (its

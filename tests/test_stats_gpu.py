@@ -283,3 +283,21 @@ def test_fasta_records_much_longer_than_a_range(all_, final_newline, monkeypatch
     if not final_newline:
         data = data[:-1]
     check_parity(data.encode(), False, {"All": all_})
+
+
+def test_text_that_is_not_fastq_fails_fast():
+    """FASTA handed over with the FASTQ flag holds no FASTQ record start: the anchor search of every range boundary is
+    bounded (anchor.hpp ANCHOR_SEARCH_BYTES) and the run ends with an error -- it used to walk to the end of the shard from
+    every boundary (a quarter of an hour for 10 GB)."""
+    import time
+    import ctypes as C
+    import torch
+    rb, nrec = 5107, 40000   # ~200 MB of FASTA-5k
+    t = torch.empty(rb * nrec, dtype=torch.uint8, device="cuda")
+    assert _lib.lib.bsk_synth_device(2, 42, 0, 0, C.c_void_p(t.data_ptr()), rb * nrec, 0, None) == 0
+    t0 = time.time()
+    with pytest.raises(bsk.BskError):
+        bsk.stats_map(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), bsk.SeqKitStatsOptions())
+    with pytest.raises(bsk.BskError):
+        bsk.Seq(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), bsk.SeqKitSeqOptions().Name(True))
+    assert time.time() - t0 < 60
