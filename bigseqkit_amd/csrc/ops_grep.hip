@@ -94,9 +94,12 @@ __global__ __launch_bounds__(256) void k_grep_seq(const uint8_t* __restrict__ bu
     // strand_only (1: '+', 2: '-'): one strand alone, for the per-(pattern, strand) hit bits of --delete-matched
     const int nstr = P.strand_only == 1 ? 1 : (P.both_strands ? 2 : 1);
     const int str0 = P.strand_only == 2 ? 1 : 0;
-    const bool fast = live && T.W == 0 && !P.circular && T.p >= buf && T.p < buf + buf_n;
+    // contiguous text: in the shard itself, or in the linear copies of wrapped FASTA records (text_dev.hpp)
+    const bool in_buf = T.p >= buf && T.p < buf + buf_n;
+    const bool in_lin = tt.lin_n != 0 && T.p >= tt.lin && T.p < tt.lin + tt.lin_n;
+    const bool fast = live && T.W == 0 && !P.circular && (in_buf || in_lin);
     if (fast) {
-        const uint8_t* const buf_end = buf + buf_n;
+        const uint8_t* const buf_end = in_buf ? buf + buf_n : tt.lin + tt.lin_n;  // (no wide load past it)
         for (int strand = str0; strand < nstr && !hit; ++strand) {
             uint32_t wb = 0, we = L;
             if (P.region_on) {
@@ -406,14 +409,14 @@ hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTab
     GrepParams P = Pin;
     P.buf_end = buf + buf_n;
     if (P.regex) {
-        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
         hipLaunchKernelGGL(k_grep_regex, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len);
     } else if (P.by_seq && P.general) {
-        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
         const uint64_t blocks = (t.n * GROUP + 255) / 256;
         hipLaunchKernelGGL(k_grep_seq_gen, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len);
     } else if (P.by_seq) {
-        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr};
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
         const uint64_t avg = avg_record_bytes ? avg_record_bytes : buf_n / t.n;  // bytes per record (a filtered table holds few of them)
         if (avg < 1024) {
             hipLaunchKernelGGL((k_grep_seq<BSK_GREP_LANES, false>), dim3((unsigned)((t.n * BSK_GREP_LANES + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);

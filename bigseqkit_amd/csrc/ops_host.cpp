@@ -951,7 +951,10 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         G.id_mode = id_mode_of(c);
         G.line_width = fastq ? 0 : (int)o.ci("LineWidth");
         G.npat = (int)c->patterns.size();
-        rc = prepare_text(c, d_buf, format, st, &tt);  // uses d_out_len as scratch: before the match kernel
+        // (uses d_out_len as scratch: before the match kernel.)  A search in the sequences reads them many times at
+        // arbitrary offsets: wrapped FASTA records get a linear copy first (the emit below goes back to the views)
+        const bool flat_text = !fastq && G.by_seq;
+        rc = prepare_text(c, d_buf, format, st, &tt, flat_text);
         if (rc != BSK_OK) return rc;
         if (!c->regexes.empty()) {
             if (!c->patterns_uploaded) {
@@ -1156,6 +1159,10 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     SeqParams P = format_params(c, fastq);
+    if (!fastq && tt.text_w == c->d_text_w) {  // the search ran on linear copies: the emit reads the wrapped text in place
+        rc = prepare_text(c, d_buf, format, st, &tt, false, /*keep_out_len=*/true);
+        if (rc != BSK_OK) return rc;
+    }
     P.text_w = tt.text_w; P.lin_off = tt.lin_off; P.lin = tt.lin;
     apply_long(c, &P);
     { const int rce = emit_records(c, d_buf, n, P, total, kept, st); if (rce != BSK_OK) return rce; }
@@ -1318,7 +1325,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
         if (rc != BSK_OK) return rc;
         if (ab == AB_NONE) ab = AB_UNLIMIT;
-        rc = prepare_text(c, d_buf, format, st, &tt);
+        rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/format != BSK_FORMAT_FASTQ);  // (see grep)
         if (rc != BSK_OK) return rc;
         P.fastq = format == BSK_FORMAT_FASTQ;
         P.ignore_case = o.b("IgnoreCase");
@@ -1721,10 +1728,11 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
 // ---------------------------------------------------------------------------
 // FASTA text view: classify every record, linearise the irregularly wrapped ones
 // ---------------------------------------------------------------------------
-int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt) {
+int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt, bool flatten, bool keep_out_len) {
     tt->text_w = nullptr;
     tt->lin_off = nullptr;
     tt->lin = nullptr;
+    tt->lin_n = 0;
     if (format == BSK_FORMAT_FASTQ || c->table.n == 0) return BSK_OK;
     const uint64_t n = c->table.n;
     if (n + 1 > c->text_cap || !c->d_lin_off) {
@@ -1742,7 +1750,30 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     // separate pass over the line ends (tests cross-check the two).
     const char* mode = getenv("BSK_TEXT");
     const uint32_t* text_w = c->table.text_w;
-    if (mode && strcmp(mode, "classify") == 0) {
+    if (keep_out_len) {
+        // the views once more AFTER the sizes of the output were computed (they sit in d_out_len): the lengths of the
+        // linear copies go through d_text_w, which the views do not use
+        HIP_TRYX(c, launch_lin_len(c->table, c->d_text_w, st));
+        HIP_TRYX(c, launch_scan_u32(c->d_text_w, c->d_lin_off, n, c->d_scan_tmp, st));
+        uint64_t total = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&total, c->d_lin_off + n, sizeof total, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (total) {
+            rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, launch_text_linearise(d_buf, c->table, text_w, c->d_lin_off, c->d_lin, st));
+        }
+        tt->lin_n = total;
+        tt->text_w = text_w;
+        tt->lin_off = c->d_lin_off;
+        tt->lin = c->d_lin;
+        return BSK_OK;
+    }
+    if (flatten && !(mode && strcmp(mode, "view") == 0)) {
+        // every wrapped record gets a linear copy; the kernels then read contiguous text (BSK_TEXT=view keeps the views)
+        HIP_TRYX(c, launch_lin_len_all(c->table, c->d_out_len, c->d_text_w, st));
+        text_w = c->d_text_w;
+    } else if (mode && strcmp(mode, "classify") == 0) {
         HIP_TRYX(c, launch_text_classify(d_buf, c->table, c->d_text_w, c->d_out_len, st));
         text_w = c->d_text_w;
     } else {
@@ -1755,8 +1786,10 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     if (total) {
         rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
         if (rc != BSK_OK) return rc;
-        HIP_TRYX(c, launch_text_linearise(d_buf, c->table, text_w, c->d_lin_off, c->d_lin, st));
+        if (text_w == c->d_text_w && flatten) HIP_TRYX(c, launch_text_flatten(d_buf, c->table, c->d_lin_off, c->d_lin, st));
+        else HIP_TRYX(c, launch_text_linearise(d_buf, c->table, text_w, c->d_lin_off, c->d_lin, st));
     }
+    tt->lin_n = total;
     tt->text_w = text_w;
     tt->lin_off = c->d_lin_off;
     tt->lin = c->d_lin;
@@ -2061,7 +2094,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
+    rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/!fastq && o.b("BySeq"));  // (see grep: hashed and compared as linear text)
     if (rc != BSK_OK) return rc;
     RmDupParams P;
     memset(&P, 0, sizeof P);
@@ -2136,6 +2169,10 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     SeqParams F = format_params(c, fastq);
+    if (!fastq && tt.text_w == c->d_text_w) {  // back to the views for the emit (and the side files)
+        rc = prepare_text(c, d_buf, format, st, &tt, false, /*keep_out_len=*/true);
+        if (rc != BSK_OK) return rc;
+    }
     F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
     apply_long(c, &F);
     { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }

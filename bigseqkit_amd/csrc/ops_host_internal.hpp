@@ -57,7 +57,8 @@ struct RmDupParams;
 // c->d_keys: XXH64 keys -> first record of every record's group (+ d_has, c->d_out_len); see ops_host.cpp
 int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint8_t* d_has, hipStream_t st);
 // FASTA text view of the shard's records (text_dev.hpp); null pointers for FASTQ
-int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt);
+int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt, bool flatten = false,
+                 bool keep_out_len = false);
 // size array -> scan -> total / kept / kernel status (also lists the records with a very large output)
 int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept);
 void apply_long(const bsk_ctx* c, SeqParams* P);

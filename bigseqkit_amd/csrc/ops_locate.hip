@@ -313,9 +313,11 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
             if (P.circular && npos > l) npos = l;
             const char sc = strand ? '-' : '+';
             // contiguous text inside the shard, plain greedy search: 16 positions per lane and step
-            const bool fastp = !GEN && !P.non_greedy && !P.circular && T.W == 0 && T.p >= buf && T.p < buf + buf_n;
+            const bool in_buf = T.p >= buf && T.p < buf + buf_n;
+            const bool in_lin = tt.lin_n != 0 && T.p >= tt.lin && T.p < tt.lin + tt.lin_n;  // linear copy of a wrapped record
+            const bool fastp = !GEN && !P.non_greedy && !P.circular && T.W == 0 && (in_buf || in_lin);
             if (fastp) {
-                const uint8_t* const buf_end = buf + buf_n;
+                const uint8_t* const buf_end = in_buf ? buf + buf_n : tt.lin + tt.lin_n;
                 const uint32_t npos32 = (uint32_t)npos, n32 = (uint32_t)n;  // not circular: n == l < 2^32
                 uint32_t p32 = 0;  // first min(m, 4) pattern bytes, loaded once per (record, pattern, strand)
                 for (uint32_t q = 0; q < m && q < 4; ++q) p32 |= (uint32_t)pp[q] << (8 * q);
@@ -592,7 +594,7 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
                          const LocateParams& P, uint32_t* out_len, const uint64_t* out_off, uint8_t* out,
                          uint64_t* rows, hipStream_t st, uint64_t avg_record_bytes) {
     if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     const uint64_t groups = emit ? P.nhit : t.n;
     const bool small = (avg_record_bytes ? avg_record_bytes : buf_n / t.n) < 1024;  // bytes per record (not of a filtered table)
     const int G = small ? 4 : 16;
@@ -624,7 +626,7 @@ hipError_t launch_locate_vm(bool emit, const uint8_t* buf, uint64_t buf_n, const
                             const LocateParams& P, const VmProgram* d_progs, uint32_t* out_len, const uint64_t* out_off,
                             uint8_t* out, uint64_t* rows, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     const dim3 gr((unsigned)((t.n + 63) / 64)), bl(64);
     if (emit) hipLaunchKernelGGL(k_locate_vm<true>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows);
     else hipLaunchKernelGGL(k_locate_vm<false>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows);

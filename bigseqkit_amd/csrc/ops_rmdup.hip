@@ -171,7 +171,8 @@ __device__ uint64_t xxh64_lds(const LdsSubject& s, uint64_t seed) {
 }
 
 // copy the subjects of the wave's 64 records into `slot` (64 x STAGE_STRIDE bytes of LDS); false = not applicable
-__device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_end, uint8_t* slot) {
+__device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_end, uint8_t* slot, const uint8_t* lin = nullptr,
+                               const uint8_t* lin_end = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const bool contiguous = s.seq ? s.T.W == 0 : true;
     const bool ok = !live || (contiguous && s.len <= STAGE_MAX);
@@ -195,7 +196,7 @@ __device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_e
             on[jj] = off < len_r;
             w[jj][0] = w[jj][1] = w[jj][2] = w[jj][3] = 0;
             if (on[jj]) {
-                if (pr + off + 16 <= buf_end) {
+                if ((pr >= lin && pr < lin_end) ? pr + off + 16 <= lin_end : pr + off + 16 <= buf_end) {  // (linear copy | shard)
                     uint4 v;
                     __builtin_memcpy(&v, pr + off, 16);
                     w[jj][0] = v.x; w[jj][1] = v.y; w[jj][2] = v.z; w[jj][3] = v.w;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ 
     const Subject s = subject_of(buf, t, tt, P, live ? i : 0);
     uint8_t* slot = s_stage[threadIdx.x >> 6];
     uint64_t k1, k2 = 0;
-    if (stage_subjects(s, live, buf + buf_n, slot)) {
+    if (stage_subjects(s, live, buf + buf_n, slot, tt.lin, tt.lin ? tt.lin + tt.lin_n : nullptr)) {
         LdsSubject ls{slot + (threadIdx.x & 63u) * STAGE_STRIDE, s.len, s.fold};
         k1 = xxh64_lds(ls, 0);
         if (keys2) k2 = xxh64_lds(ls, SEED2);
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve_first(const uint8_t* __re
 hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                              const RmDupParams& P, uint64_t* keys, uint64_t* keys2, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     hipLaunchKernelGGL(k_rmdup_hash, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, keys, keys2);
     return hipGetLastError();
 }
@@ -633,7 +634,7 @@ hipError_t launch_rmdup_resolve(const uint8_t* buf, const RecordTable& t, const 
                                 const uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
                                 uint64_t* status, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     hipLaunchKernelGGL(k_rmdup_resolve<false>, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P,
                        const_cast<uint64_t*>(keys), table, cap, out_len, status, (uint8_t*)nullptr);
     return hipGetLastError();
@@ -643,7 +644,7 @@ hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, 
                                       uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
                                       uint64_t* status, uint8_t* has_dup, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     hipLaunchKernelGGL(k_rmdup_resolve<true>, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, keys, table, cap,
                        out_len, status, has_dup);
     return hipGetLastError();
@@ -725,7 +726,7 @@ hipError_t launch_rmdup_resolve_first(const uint8_t* buf, const RecordTable& t, 
                                       const uint32_t* first, uint64_t* keys_group, uint32_t* out_len, uint64_t* status,
                                       uint8_t* has_dup, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    TextTable d{tt.text_w, tt.lin_off, tt.lin};
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     const dim3 gr((unsigned)((t.n * BSK_RMDUP_RV + 255) / 256));
     if (keys_group) hipLaunchKernelGGL(k_rmdup_resolve_first<true>, gr, dim3(256), 0, st, buf, t, d, P, first, keys_group, out_len, status, has_dup);
     else hipLaunchKernelGGL(k_rmdup_resolve_first<false>, gr, dim3(256), 0, st, buf, t, d, P, first, (uint64_t*)nullptr, out_len, status, (uint8_t*)nullptr);

@@ -62,6 +62,56 @@ __global__ __launch_bounds__(256) void k_text_linearise(const uint8_t* __restric
     }
 }
 
+// flatten: EVERY record that is not one line already gets a linear copy (grep -s / locate / rmdup -s read the bases of a
+// record many times at arbitrary offsets: one pass that removes the line ends costs less than a division per byte read)
+__global__ __launch_bounds__(256) void k_lin_len_all(RecordTable t, uint32_t* __restrict__ lin_len, uint32_t* __restrict__ text_w_flat) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t w = t.text_w[i];
+    lin_len[i] = w ? t.l_seq[i] : 0u;
+    text_w_flat[i] = w ? TEXT_IRREGULAR : 0u;  // "read the linear copy"
+}
+
+// 16 lanes per record: a uniformly wrapped record line by line, 16 bytes per step (the last step of a line from the line's
+// end); an irregular one byte by byte on lane 0
+__global__ __launch_bounds__(256) void k_text_flatten(const uint8_t* __restrict__ buf, RecordTable t, const uint64_t* __restrict__ lin_off,
+                                                      uint8_t* __restrict__ lin) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    const uint32_t gl = threadIdx.x % GROUP;
+    if (i >= t.n) return;
+    const uint32_t W = t.text_w[i];
+    if (W == 0) return;
+    const uint8_t* p = buf + t.start[i] + t.l_head[i] + 1;
+    const uint32_t L = t.l_seq[i];
+    uint8_t* o = lin + lin_off[i];
+    if (W == TEXT_IRREGULAR) {
+        if (gl) return;
+        const uint32_t region = t.aux[i];
+        uint32_t x = 0;
+        for (uint32_t k = 0; k < region; ++k) {
+            const uint8_t c = p[k];
+            if (c != '\n') o[x++] = c;
+        }
+        return;
+    }
+    const uint32_t lines = (L + W - 1) / W;
+    for (uint32_t l = gl; l < lines; l += GROUP) {
+        const uint32_t nb = (l + 1) * W <= L ? W : L - l * W;
+        const uint8_t* src = p + (uint64_t)l * (W + 1);
+        uint8_t* dst = o + (uint64_t)l * W;
+        if (nb >= 16u) {
+            for (uint32_t x0 = 0; x0 < nb; x0 += 16u) {
+                const uint32_t x = x0 + 16u > nb ? nb - 16u : x0;
+                uint4 v;
+                __builtin_memcpy(&v, src + x, 16);
+                __builtin_memcpy(dst + x, &v, 16);
+            }
+        } else {
+            for (uint32_t k = 0; k < nb; ++k) dst[k] = src[k];
+        }
+    }
+}
+
 // bytes each record needs in the linear side buffer, from the layout the index pass recorded (RecordTable::text_w)
 __global__ __launch_bounds__(256) void k_lin_len(RecordTable t, uint32_t* __restrict__ lin_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,6 +139,18 @@ hipError_t launch_text_linearise(const uint8_t* buf, const RecordTable& t, const
     if (t.n == 0) return hipSuccess;
     const uint64_t blocks = (t.n + 255) / 256;
     hipLaunchKernelGGL(k_text_linearise, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, text_w, lin_off, lin);
+    return hipGetLastError();
+}
+
+hipError_t launch_lin_len_all(const RecordTable& t, uint32_t* lin_len, uint32_t* text_w_flat, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lin_len_all, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, t, lin_len, text_w_flat);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_flatten(const uint8_t* buf, const RecordTable& t, const uint64_t* lin_off, uint8_t* lin, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_text_flatten, dim3((unsigned)((t.n * GROUP + 255) / 256)), dim3(256), 0, st, buf, t, lin_off, lin);
     return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@ struct TextTableH {  // host-visible mirror of TextTable (text_dev.hpp)
     const uint32_t* text_w;
     const uint64_t* lin_off;
     const uint8_t* lin;
+    uint64_t lin_n = 0;  // bytes in lin
 };
 
 struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/translate.go:33-64)

@@ -17,6 +17,7 @@ struct TextTable {            // device arrays; null for FASTQ
     const uint32_t* text_w;   // [n] 0 contiguous, W uniform width, TEXT_IRREGULAR -> linear copy
     const uint64_t* lin_off;  // [n + 1]
     const uint8_t* lin;
+    uint64_t lin_n = 0;       // bytes in lin (0: unknown -- kernels then treat linear copies as unbounded-unsafe for wide loads)
 };
 
 struct Text {

@@ -529,3 +529,22 @@ def test_grep_delete_matched_many_patterns_random(monkeypatch):
         if trial % 3 == 2: o["IgnoreCase"] = True
         check_grep(data, True, o)
         check_grep(data, True, {"Pattern": [p[:2] + "[AC]" + p[2:] for p in pats[:4]], "UseRegexp": True, "BySeq": True, "DeleteMatched": True})
+
+
+@pytest.mark.parametrize("width", [60, 17, 0])
+def test_wrapped_fasta_searches_on_linear_copies_equal_the_text_views(width, monkeypatch):
+    """grep -s / locate / rmdup -s on wrapped FASTA read linear copies of the records (ops_text.hip k_text_flatten);
+    BSK_TEXT=view keeps the in-place views of round 1: same bytes, and both equal the oracle."""
+    import seqgen
+    rng = random.Random(8800 + width)
+    data = seqgen.random_fasta(rng, 400, 0, 900, width=width)
+    data += data[:len(data) // 3]   # duplicates for rmdup
+    g = {"Pattern": ["ACGT", "TTGCA"], "BySeq": True}
+    l = {"Pattern": ["ACGT"]}
+    r = {"BySeq": True}
+    want = (oracle.grep(data, False, json.dumps(g)), oracle.locate(data, False, json.dumps(l)), oracle.rmdup(data, False, json.dumps(r)))
+    for mode in (None, "view"):
+        if mode:
+            monkeypatch.setenv("BSK_TEXT", mode)
+        got = (bsk.Grep(frame(data, False), _Opts(g)), bsk.Locate(frame(data, False), _Opts(l)), bsk.RmDup(frame(data, False), _Opts(r)))
+        assert got == want
