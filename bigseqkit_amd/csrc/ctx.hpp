@@ -140,6 +140,7 @@ struct bsk_ctx {
     uint64_t set_keys_cap = 0, set_idx_cap = 0, set_slots = 0;
     // -r: compiled position automata (regex_nfa.hpp)
     std::vector<bsk::RegexProgram> regexes;
+    std::vector<bsk::RegexProgram> locate_pre;  // locate -r (matcher): the same expressions as boolean automata -- which records match at all
     bsk::RegexProgram* d_regex = nullptr;
     uint64_t regex_cap = 0;
     // locate -r with matches of variable length: programs of the position-reporting matcher (regex_vm.hpp)

@@ -1248,6 +1248,17 @@ void validate_locate_opts(bsk_ctx* c) {
         }
         if (c->locate_vm && o.b("Circular"))
             throw OptError("libbsk: locate -r with matches of variable length is not provided together with --circular");
+        c->locate_pre.clear();
+        if (c->locate_vm) {
+            // the position-reporting matcher costs ~35 ns per base and lane; most records hold no match at all, and WHETHER
+            // one exists is what the boolean automaton of grep -r answers ten times faster: it goes first (expressions it
+            // does not take -- more than 64 positions -- leave the matcher alone with every record)
+            try {
+                for (auto& g : uniq) c->locate_pre.push_back(compile_regex(o.b("IgnoreCase") ? "(?i)" + g.second : g.second));
+            } catch (const OptError&) {
+                c->locate_pre.clear();
+            }
+        }
         for (size_t k = 0; k < uniq.size(); ++k) {
             auto& g = uniq[k];
             c->pattern_names.push_back(g.first);
@@ -1435,7 +1446,31 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             rc = grow(c, &c->d_vm_progs, &c->vm_progs_cap, c->vm_progs.size());
             if (rc != BSK_OK) return rc;
             HIP_TRYX(c, hipMemcpyAsync(c->d_vm_progs, c->vm_progs.data(), c->vm_progs.size() * sizeof(VmProgram), hipMemcpyHostToDevice, st));
-            HIP_TRYX(c, launch_locate_vm(false, d_buf, n, c->table, tt, P, c->d_vm_progs, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st));
+            bool pre = false;
+            if (!c->locate_pre.empty() && !getenv("BSK_LOCATE_NOPRE")) {
+                rc = grow(c, &c->d_regex, &c->regex_cap, c->locate_pre.size());
+                if (rc != BSK_OK) return rc;
+                HIP_TRYX(c, hipMemcpyAsync(c->d_regex, c->locate_pre.data(), c->locate_pre.size() * sizeof(RegexProgram), hipMemcpyHostToDevice, st));
+                GrepParams G;
+                memset(&G, 0, sizeof G);
+                G.fastq = P.fastq;
+                G.by_seq = 1;
+                G.both_strands = P.both_strands;
+                G.npat = (int)c->locate_pre.size();
+                G.regex = c->d_regex;
+                G.comp = P.comp;
+                HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st, c->avg_record_bytes));  // != 0: some match exists
+                pre = true;
+            }
+            uint64_t ncand = 0;
+            if (pre) {  // the candidates as a list: the matcher then runs with every lane busy
+                HIP_TRYX(c, launch_compact_hits(c->d_out_len, c->table.n, c->d_hit_list, c->d_counter, st));
+                HIP_TRYX(c, hipMemcpyAsync(&ncand, c->d_counter, sizeof ncand, hipMemcpyDeviceToHost, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
+            }
+            HIP_TRYX(c, launch_locate_vm(false, d_buf, n, c->table, tt, P, c->d_vm_progs, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st,
+                                         pre ? c->d_hit_list : nullptr, ncand));
         } else
         HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st, c->avg_record_bytes));
         if (P.long_count) {
@@ -1465,7 +1500,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
     if (!header.empty()) HIP_TRYX(c, hipMemcpyAsync(c->d_out, header.data(), header.size(), hipMemcpyHostToDevice, st));
     if (total && c->locate_vm)
         HIP_TRYX(c, launch_locate_vm(true, d_buf, n, c->table, tt, P, c->d_vm_progs, c->d_out_len, c->d_out_off, c->d_out + header.size(),
-                                     c->d_counter + 1, st));
+                                     c->d_counter + 1, st, P.hit_list, P.nhit));
     else if (total)
         HIP_TRYX(c, launch_locate(true, d_buf, n, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out + header.size(),
                                   c->d_counter + 1, st, c->avg_record_bytes));

@@ -465,9 +465,13 @@ template <bool EMIT>
 __global__ __launch_bounds__(64) void k_locate_vm(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                   LocateParams P, const VmProgram* __restrict__ progs,
                                                   uint32_t* __restrict__ out_len, const uint64_t* __restrict__ out_off,
-                                                  uint8_t* __restrict__ out, uint64_t* __restrict__ rows) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= t.n) return;
+                                                  uint8_t* __restrict__ out, uint64_t* __restrict__ rows,
+                                                  const uint32_t* __restrict__ list, uint64_t nlist) {
+    // with a list (records the boolean automaton of grep -r let through / records with rows): one lane per ENTRY, so
+    // that the lanes of a wave all have work -- one record in fifty matching left 63 lanes of 64 idle for the whole walk
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (list ? nlist : t.n)) return;
+    const uint64_t g = list ? (uint64_t)list[idx] : idx;
     if (EMIT && out_len[g] == 0) return;
     const Text T = text_of(buf, t, tt, g);
     const uint32_t l = T.L;
@@ -624,12 +628,13 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
 
 hipError_t launch_locate_vm(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                             const LocateParams& P, const VmProgram* d_progs, uint32_t* out_len, const uint64_t* out_off,
-                            uint8_t* out, uint64_t* rows, hipStream_t st) {
-    if (t.n == 0) return hipSuccess;
+                            uint8_t* out, uint64_t* rows, hipStream_t st, const uint32_t* list, uint64_t nlist) {
+    if (t.n == 0 || (list && nlist == 0)) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
-    const dim3 gr((unsigned)((t.n + 63) / 64)), bl(64);
-    if (emit) hipLaunchKernelGGL(k_locate_vm<true>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows);
-    else hipLaunchKernelGGL(k_locate_vm<false>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows);
+    const uint64_t items = list ? nlist : t.n;
+    const dim3 gr((unsigned)((items + 63) / 64)), bl(64);
+    if (emit) hipLaunchKernelGGL(k_locate_vm<true>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows, list, nlist);
+    else hipLaunchKernelGGL(k_locate_vm<false>, gr, bl, 0, st, buf, buf_n, t, d, P, d_progs, out_len, out_off, out, rows, list, nlist);
     return hipGetLastError();
 }
 

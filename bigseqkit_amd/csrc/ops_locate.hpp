@@ -54,7 +54,8 @@ struct VmProgram;
 // locate -r with matches of variable length: one lane per record runs the Pike VM (count pass: out_len; emit pass: rows)
 hipError_t launch_locate_vm(bool emit, const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                             const LocateParams& P, const VmProgram* d_progs, uint32_t* out_len, const uint64_t* out_off,
-                            uint8_t* out, uint64_t* rows, hipStream_t st);
+                            uint8_t* out, uint64_t* rows, hipStream_t st, const uint32_t* list = nullptr /* records to visit (else all) */,
+                            uint64_t nlist = 0);
 
 // hit_list := indices of the records with out_len != 0 (any order), *hit_count := how many (zeroed by the caller)
 // out_len of the long records := sum of their cells' bytes (after the scan of cell_bytes)
