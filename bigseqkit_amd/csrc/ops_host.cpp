@@ -2648,6 +2648,8 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     P.reverse = o.b("Reverse");
     P.remove_gaps = o.b("RemoveGaps");
     set_bits(P.gap_set, o.s("GapLetters"));
+    P.gap_lt64 = 1;
+    for (char ch : o.s("GapLetters")) if ((uint8_t)ch >= 64) P.gap_lt64 = 0;
     P.line_width = (fastq || o.b("Seq") || o.b("Qual")) ? 0 : (int)o.ci("LineWidth");
     P.min_len = (int)o.i("MinLen"); P.max_len = (int)o.i("MaxLen");
     P.min_qual = o.f("MinQual"); P.max_qual = o.f("MaxQual");
@@ -2693,7 +2695,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
         HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
         return kernel_error_to_status(c, status);
     }
-    if (!P.remove_gaps) {  // wrapped FASTA: random access through the text view (gap removal walks the record anyway)
+    {  // wrapped FASTA: random access through the text view (with gap removal: for the records without a gap letter)
         TextTableH tt{nullptr, nullptr, nullptr};
         rc = prepare_text(c, d_buf, format, st, &tt);
         if (rc != BSK_OK) return rc;

@@ -19,6 +19,7 @@ struct SeqParams {  // SeqTransform options after Before() (bigseqkit-lib/seq.go
     int use_lut;                            // complement / dna2rna / rna2dna / case folded into one 256-byte map
     int remove_gaps;
     uint32_t gap_set[8];                    // 256-bit set
+    int gap_lt64;                           // every gap letter is below 64 ('-', '.', ' ', '*'): 16 bytes at a time can be ruled out
     int line_width;                         // effective (0 for FASTQ, -s, -q)
     int min_len, max_len;                   // > 0 enables (seq.go:88-89)
     double min_qual, max_qual;              // > 0 enables (seq.go:90-91)
