@@ -144,13 +144,28 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
     uint32_t L = r.seq_len;
     uint32_t err = 0;
     if (P.validate) {
-        uint32_t seen = 0;
-        for (uint32_t k = 0; k < r.region && (P.validate_len <= 0 || seen < (uint32_t)P.validate_len); ++k) {
+        // (16 bytes per load, the letters tested in registers: a byte load per base on one lane was 45 ms per 5 GB of reads)
+        const uint32_t limit = P.validate_len <= 0 ? 0xFFFFFFFFu : (uint32_t)P.validate_len;
+        uint32_t seen = 0, k = 0;
+        bool bad = false;
+        for (; !bad && seen < limit && k + 16u <= r.region && r.seq + k + 16 <= P.buf_end; k += 16u) {
+            uint4 v;
+            __builtin_memcpy(&v, r.seq + k, 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const uint8_t c = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                const bool counts = !(c == '\n' && !P.fastq) && seen < limit;
+                if (counts) { ++seen; bad |= !in_set(P.valid_set, c); }
+            }
+        }
+        for (; !bad && k < r.region && seen < limit; ++k) {
             const uint8_t c = r.seq[k];
             if (c == '\n' && !P.fastq) continue;
             ++seen;
-            if (!in_set(P.valid_set, c)) { err |= ERR_INVALID_LETTER; break; }
+            bad = !in_set(P.valid_set, c);
         }
+        if (bad) err |= ERR_INVALID_LETTER;
     }
     uint32_t kept = L;
     if (P.remove_gaps) {
@@ -205,7 +220,21 @@ __global__ __launch_bounds__(256) void k_seq_size(const uint8_t* __restrict__ bu
         double aq = 0;
         if (P.fastq && kept > 0) {
             double sum = 0;
-            for (uint32_t k = 0; k < L; ++k) {
+            uint32_t k = 0;
+            // the sum stays sequential (float64, in record order: Seq.AvgQual); only the bytes come 16 at a time
+            for (; k + 16u <= L && r.qual + k + 16 <= P.buf_end && r.seq + k + 16 <= P.buf_end; k += 16u) {
+                uint4 q4, s4;
+                __builtin_memcpy(&q4, r.qual + k, 16);
+                const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+                uint32_t sw[4] = {0, 0, 0, 0};
+                if (P.remove_gaps) { __builtin_memcpy(&s4, r.seq + k, 16); sw[0] = s4.x; sw[1] = s4.y; sw[2] = s4.z; sw[3] = s4.w; }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (P.remove_gaps && in_set(P.gap_set, (uint8_t)(sw[b >> 2] >> (8 * (b & 3))))) continue;
+                    sum += P.qual_err[(uint8_t)(qw[b >> 2] >> (8 * (b & 3)))];
+                }
+            }
+            for (; k < L; ++k) {
                 if (P.remove_gaps && in_set(P.gap_set, r.seq[k])) continue;
                 sum += P.qual_err[r.qual[k]];
             }
