@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #include "ops_grep.hpp"
 #include "ops_seq.hpp"
@@ -294,6 +296,111 @@ __global__ __launch_bounds__(256) void k_grep_seq_gen(const uint8_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// class patterns of at most 64 positions, at most SA_MAX_MM mismatches, not circular: Shift-And with mismatch rows
+// (Wu-Manber without insertions and deletions), one lane per record.  B[c] = bit q set where byte c is in the class of
+// pattern position q, one 2 KB table per (strand, pattern) in LDS; per text byte
+//     R_j = ((R_j << 1 | 1) & B[c]) | (R_{j-1} << 1 | 1),      hit when bit m-1 of R_maxmm is set.
+// The same start positions and the same mismatch count as k_grep_seq_gen tests one by one (a window holds a match iff
+// some m consecutive bytes of it differ from the classes in at most max_mm places).  The text comes 16 bytes per load.
+// ---------------------------------------------------------------------------
+constexpr int SA_MAX_TABLES = 8;
+constexpr int SA_MAX_MM = 3;
+
+template <int KMM>
+__device__ __forceinline__ bool sa_search(const uint64_t* __restrict__ B, uint32_t m, const Text& T, uint32_t wb, uint32_t wl,
+                                          bool contig, const uint8_t* hi) {
+    uint64_t R[KMM + 1];
+#pragma unroll
+    for (int j = 0; j <= KMM; ++j) R[j] = 0;
+    const uint64_t last = 1ull << (m - 1u);
+    uint64_t seen = 0;
+    for (uint32_t x0 = 0; x0 < wl; x0 += 16u) {
+        const uint32_t nb = wl - x0 < 16u ? wl - x0 : 16u;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (contig && T.p + wb + x0 + 16 <= hi) {
+            uint4 v;
+            __builtin_memcpy(&v, T.p + wb + x0, 16);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (uint32_t b = 0; b < nb; ++b) w[b >> 2] |= (uint32_t)T.at(wb + x0 + b) << (8u * (b & 3u));
+        }
+        if (nb == 16u) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const uint64_t bc = B[(w[b >> 2] >> (8 * (b & 3))) & 255u];
+#pragma unroll
+                for (int j = KMM; j >= 1; --j) R[j] = (((R[j] << 1) | 1ull) & bc) | ((R[j - 1] << 1) | 1ull);
+                R[0] = ((R[0] << 1) | 1ull) & bc;
+                seen |= R[KMM];
+            }
+        } else {
+            for (uint32_t b = 0; b < nb; ++b) {
+                const uint64_t bc = B[(w[b >> 2] >> (8u * (b & 3u))) & 255u];
+#pragma unroll
+                for (int j = KMM; j >= 1; --j) R[j] = (((R[j] << 1) | 1ull) & bc) | ((R[j - 1] << 1) | 1ull);
+                R[0] = ((R[0] << 1) | 1ull) & bc;
+                seen |= R[KMM];
+            }
+        }
+        if (seen & last) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_grep_shiftand(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+                                                       GrepParams P, uint32_t* __restrict__ out_len) {
+    __shared__ uint64_t s_B[SA_MAX_TABLES * 256];
+    const int nstr_all = P.both_strands ? 2 : 1;
+    const int ntab = nstr_all * P.npat;
+    for (int tb = 0; tb < ntab; ++tb) {
+        const uint32_t m = P.pat_off[tb + 1] - P.pat_off[tb];
+        const uint32_t* cls = P.cls + (uint64_t)P.pat_off[tb] * 8u;
+        const uint32_t c = threadIdx.x;  // blockDim.x == 256: one byte value per thread
+        uint64_t bits = 0;
+        for (uint32_t q = 0; q < m; ++q) bits |= (uint64_t)((cls[q * 8u + (c >> 5)] >> (c & 31u)) & 1u) << q;
+        s_B[tb * 256 + c] = bits;
+    }
+    __syncthreads();
+    const int nstr = P.strand_only == 1 ? 1 : nstr_all;
+    const int str0 = P.strand_only == 2 ? 1 : 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Text T = text_of(buf, t, tt, i);
+        const uint32_t L = T.L;
+        const bool in_buf = T.p >= buf && T.p < buf + buf_n;
+        const bool in_lin = tt.lin_n != 0 && T.p >= tt.lin && T.p < tt.lin + tt.lin_n;
+        const bool contig = T.W == 0 && (in_buf || in_lin);
+        const uint8_t* hi = in_buf ? buf + buf_n : tt.lin + tt.lin_n;
+        bool hit = false;
+        for (int strand = str0; strand < nstr && !hit; ++strand) {
+            uint32_t wb = 0, we = L;
+            if (P.region_on) {
+                uint32_t b, e;
+                sub_location(L, P.region_start, P.region_end, &b, &e);
+                if (strand == 0) { wb = b; we = e; }
+                else { wb = L - e; we = L - b; }
+            }
+            const uint32_t wl = we - wb;
+            for (int k = 0; k < P.npat && !hit; ++k) {
+                const int pk = strand * P.npat + k;
+                const uint32_t m = P.pat_off[pk + 1] - P.pat_off[pk];
+                if (m == 0) { hit = true; break; }
+                if (m > wl) continue;
+                const uint64_t* B = s_B + pk * 256;
+                switch (P.max_mm) {
+                    case 0: hit = sa_search<0>(B, m, T, wb, wl, contig, hi); break;
+                    case 1: hit = sa_search<1>(B, m, T, wb, wl, contig, hi); break;
+                    case 2: hit = sa_search<2>(B, m, T, wb, wl, contig, hi); break;
+                    default: hit = sa_search<3>(B, m, T, wb, wl, contig, hi); break;
+                }
+            }
+        }
+        const uint32_t lh = t.l_head[i];
+        const bool sel = P.invert ? !hit : hit;
+        out_len[i] = sel ? format_len(lh > 0 ? lh - 1 : 0, L, P.fastq, P.line_width) : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // -r: re.Match(target) (grep.go:459-468) as a bit-parallel position automaton, one lane per record.
 // State = 64-bit set of active positions; per byte: S = (follow(S) | first) & accept[byte]; follow(S) is the OR of
 // one table entry per 8 state bits.  The search is unanchored (first is injected before every byte); ^ and $ are
@@ -478,6 +585,14 @@ hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTab
         hipLaunchKernelGGL(k_grep_regex, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len, buf_n);
     } else if (P.by_seq && P.general) {
         TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
+        const char* sa_env = getenv("BSK_GREP_SHIFTAND");
+        const bool sa_off = sa_env && !strcmp(sa_env, "off");
+        if (!sa_off && Pin.sa_ok) {
+            uint64_t blocks = (t.n + 255) / 256;
+            if (blocks > 256ull * 8ull) blocks = 256ull * 8ull;
+            hipLaunchKernelGGL(k_grep_shiftand, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);
+            return hipGetLastError();
+        }
         const uint64_t blocks = (t.n * GROUP + 255) / 256;
         hipLaunchKernelGGL(k_grep_seq_gen, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, d, P, out_len);
     } else if (P.by_seq) {

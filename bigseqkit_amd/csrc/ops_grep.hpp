@@ -23,6 +23,7 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     int general;
     int max_mm;
     const uint32_t* cls;
+    int sa_ok;               // every pattern <= 64 positions, <= 8 (strand, pattern) tables, max_mm <= 3, not circular: k_grep_shiftand
     // ID / name pattern set (many patterns, e.g. -f ids.txt): open addressing on fnv1a64, verified by bytes
     // -r: Glushkov programs (regex_nfa.hpp), `npat` of them, in device memory; comp: complement map for the '-' strand
     const struct RegexProgram* regex;

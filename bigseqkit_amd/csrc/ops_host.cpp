@@ -996,6 +996,9 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 G.general = 1;
                 G.max_mm = c->max_mm;
                 G.cls = c->d_cls;
+                size_t longest = 0;
+                for (auto& p : all) longest = std::max(longest, p.size());
+                G.sa_ok = longest <= 64 && all.size() <= 8 && c->max_mm <= 3 && !G.circular;
             }
         }
         G.pat = c->d_pat;
@@ -1008,6 +1011,18 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             SeqParams FP = format_params(c, fastq);
             FP.buf_end = d_buf + n;
             HIP_TRYX(c, launch_seq_size(d_buf, c->table, FP, c->d_out_len, c->d_status, st));
+        } else if (G.by_seq && G.general && G.sa_ok) {
+            // one lane per record (k_grep_shiftand): not for chromosomes
+            const char* e = getenv("BSK_LONG_BYTES");
+            const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+            rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+            HIP_TRYX(c, launch_find_long(c->table.l_seq, c->table.n, thresh, c->d_long_list, c->d_counter + 2, st));
+            uint64_t lc[2] = {0, 0};
+            HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (lc[0]) G.sa_ok = 0;
         } else if (G.by_seq && !G.general && !G.regex) {
             // chromosome-sized sequences are searched by whole blocks (k_grep_seq<.., LONG>): list them
             const char* e = getenv("BSK_LONG_BYTES");
@@ -1403,6 +1418,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         // (not with --non-greedy, whose search position depends on the previous match)
         uint64_t ncells_total = 0;
         const uint64_t per_cells = (uint64_t)P.npat * (P.both_strands ? 2 : 1);
+        bool long_checked = false;
         if (!P.non_greedy && per_cells < 32768 && !c->locate_vm) {  // (the matcher of variable-length -r walks every record itself)  // (cells of one record are counted in 32 bits: chunks <= 2^17)
             const char* e = getenv("BSK_LONG_BYTES");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
@@ -1413,6 +1429,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             uint64_t lc[2] = {0, 0};
             HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
             HIP_TRYX(c, hipStreamSynchronize(st));
+            long_checked = true;
             if (lc[0]) {
                 const uint64_t nl = lc[0];
                 auto al = [](uint64_t b) { return (b + 15) & ~15ull; };
@@ -1471,8 +1488,37 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             }
             HIP_TRYX(c, launch_locate_vm(false, d_buf, n, c->table, tt, P, c->d_vm_progs, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st,
                                          pre ? c->d_hit_list : nullptr, ncand));
-        } else
-        HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st, c->avg_record_bytes));
+        } else {
+            // -d / -m: whether a record holds an occurrence at all is what grep's Shift-And answers at one table lookup per
+            // base; the position-reporting search (one class test per start position and pattern byte) then runs on the
+            // few records that do.  Long records have their own cell launches and are not prefiltered.
+            size_t longest = 0;
+            for (auto& p : all) longest = std::max(longest, p.size());
+            if (c->general && long_checked && !P.long_count && !P.circular && longest <= 64 && all.size() <= 8 && c->max_mm <= 3 &&
+                !getenv("BSK_LOCATE_NOPRE")) {
+                GrepParams G;
+                memset(&G, 0, sizeof G);
+                G.fastq = P.fastq;
+                G.by_seq = 1;
+                G.both_strands = P.both_strands;
+                G.npat = P.npat;
+                G.pat = P.pat;
+                G.pat_off = P.pat_off;
+                G.general = 1;
+                G.max_mm = P.max_mm;
+                G.cls = P.cls;
+                G.sa_ok = 1;
+                HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st, c->avg_record_bytes));
+                HIP_TRYX(c, launch_compact_hits(c->d_out_len, c->table.n, c->d_hit_list, c->d_counter, st));
+                HIP_TRYX(c, hipMemcpyAsync(&P.ncand, c->d_counter, sizeof P.ncand, hipMemcpyDeviceToHost, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(uint64_t), st));
+                P.cand = c->d_hit_list;
+            }
+            if (!P.cand || P.ncand)
+                HIP_TRYX(c, launch_locate(false, d_buf, n, c->table, tt, P, c->d_out_len, nullptr, nullptr, c->d_counter + 1, st, c->avg_record_bytes));
+            P.cand = nullptr;
+        }
         if (P.long_count) {
             // place every cell inside its record's rows, then the record sizes
             HIP_TRYX(c, launch_scan_u32(P.cell_bytes, const_cast<uint64_t*>(P.cell_off), ncells_total, c->d_scan_tmp, st));

@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void k_locate(const uint8_t* __restrict__ buf,
         a_lo = (uint64_t)c * LOCATE_LONG_CH;
         a_hi = a_lo + LOCATE_LONG_CH;
     } else {
-        live = EMIT ? slot < P.nhit : slot < t.n;
-        g = EMIT ? (live ? (uint64_t)P.hit_list[slot] : 0) : slot;
+        live = EMIT ? slot < P.nhit : (P.cand ? slot < P.ncand : slot < t.n);
+        g = EMIT ? (live ? (uint64_t)P.hit_list[slot] : 0) : (P.cand ? (live ? (uint64_t)P.cand[slot] : 0) : slot);
         if (live && P.long_thresh && t.l_seq[g] >= P.long_thresh) live = false;  // a cell launch handles this record
     }
     const uint64_t gi = live ? g : 0;
@@ -599,7 +599,7 @@ hipError_t launch_locate(bool emit, const uint8_t* buf, uint64_t buf_n, const Re
                          uint64_t* rows, hipStream_t st, uint64_t avg_record_bytes) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
-    const uint64_t groups = emit ? P.nhit : t.n;
+    const uint64_t groups = emit ? P.nhit : (P.cand ? P.ncand : t.n);
     const bool small = (avg_record_bytes ? avg_record_bytes : buf_n / t.n) < 1024;  // bytes per record (not of a filtered table)
     const int G = small ? 4 : 16;
     const uint64_t blocks = (groups * G + 255) / 256;

@@ -22,6 +22,8 @@ struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go
     // class patterns (-d, -m, -F; pattern_match_dev.hpp): 8 dwords per position, offsets as `pat`
     int general, max_mm;
     const uint32_t* cls;
+    const uint32_t* cand;    // count pass: null, or the records that hold an occurrence at all (k_grep_shiftand went first); the
+    uint64_t ncand;          // others keep the 0 the prefilter left in out_len
     int fmi_order;           // -m / -F: all patterns on '+', then all on '-'; no +l shift of '-' coordinates (locate.go:208-391)
     int matched_lower;       // the matched column shows the lower-cased text (-i without -d)
     const uint8_t* comp;     // 256-byte complement map of the shard's alphabet ('-' strand matched column)

@@ -548,3 +548,45 @@ def test_wrapped_fasta_searches_on_linear_copies_equal_the_text_views(width, mon
             monkeypatch.setenv("BSK_TEXT", mode)
         got = (bsk.Grep(frame(data, False), _Opts(g)), bsk.Locate(frame(data, False), _Opts(l)), bsk.RmDup(frame(data, False), _Opts(r)))
         assert got == want
+
+
+# ---------------------------------------------------------------- -d / -m: Shift-And (k_grep_shiftand) against the position-wise kernel
+@pytest.mark.parametrize("i", range(len(GREP_GEN_OPTS)))
+def test_grep_class_patterns_both_engines(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1500 + i)
+    data = planted_fastq(rng, 500)
+    n1 = check_grep(data, True, GREP_GEN_OPTS[i])
+    monkeypatch.setenv("BSK_GREP_SHIFTAND", "off")
+    assert check_grep(data, True, GREP_GEN_OPTS[i]) == n1
+
+
+def test_grep_class_patterns_engine_limits(monkeypatch):
+    """64 positions is the last pattern length with one state word; 9 (strand, pattern) tables and 4 mismatches leave the fast kernel"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(1600)
+    recs, pats = [], []
+    base = "".join(rng.choice("ACGT") for _ in range(70))
+    for k in range(300):
+        L = rng.randint(0, 200)
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if k % 3 == 0 and L >= 70:
+            p = rng.randrange(L - 69)
+            s[p:p + 70] = base
+            if k % 2:
+                s[p + 10] = "A" if s[p + 10] != "A" else "C"
+                s[p + 69] = "A" if s[p + 69] != "A" else "C"
+        recs.append("@r%d\n%s\n+\n%s\n" % (k, "".join(s), "I" * L))
+    data = "".join(recs).encode()
+    for m in (63, 64, 65, 70):
+        for mm in (0, 1, 2, 3, 4):
+            o = {"Pattern": [base[:m]], "MaxMismatch": mm} if mm else {"Pattern": [base[:m - 1] + "N"], "Degenerate": True}
+            assert check_grep(data, True, o) > 0
+    five = [base[j:j + 12] for j in range(0, 50, 10)]
+    assert check_grep(data, True, {"Pattern": five, "MaxMismatch": 1}) > 0              # 10 tables
+    assert check_grep(data, True, {"Pattern": five[:4], "MaxMismatch": 1}) > 0          # 8 tables
+    assert check_grep(data, True, {"Pattern": five, "MaxMismatch": 1, "OnlyPositiveStrand": True}) > 0
+    # windows shorter than the pattern, empty sequences, a region of one base
+    assert check_grep(data, True, {"Pattern": [base[:20]], "MaxMismatch": 2, "Region": "1:19"}) == 0
+    check_grep(data, True, {"Pattern": [base[:20]], "MaxMismatch": 2, "Region": "-20:-1"})
+    check_grep(b"@e\n\n+\n\n@f\nA\n+\nI\n", True, {"Pattern": ["A"], "MaxMismatch": 1})

@@ -264,3 +264,19 @@ def test_locate_regexp_variable_length(expr, monkeypatch):
     check(fq, True, {"Pattern": [expr, "ACG", "C[AT]"], "UseRegexp": True})
     with pytest.raises(bsk.BskError):
         bsk.Locate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(fa)]), _Opts({"Pattern": [expr], "UseRegexp": True, "Circular": True}))
+
+
+@pytest.mark.parametrize("i", range(len(LOC_GEN_OPTS)))
+def test_locate_general_with_and_without_the_prefilter(i, monkeypatch):
+    """-d / -m: grep's Shift-And marks the records that hold an occurrence before the position-wise search runs (ops_host.cpp)"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(2100 + i)
+    data = seqgen.random_fastq(rng, 400, 0, 100, alphabet="ACGT" * 5 + "acgtN")
+    got = check(data, True, LOC_GEN_OPTS[i])
+    monkeypatch.setenv("BSK_LOCATE_NOPRE", "1")
+    assert check(data, True, LOC_GEN_OPTS[i]) == got
+    monkeypatch.delenv("BSK_LOCATE_NOPRE")
+    # a rare pattern: most records are skipped by the prefilter
+    o = dict(LOC_GEN_OPTS[i], Pattern=["ACGTTGCAAGCTAA"[:14]])
+    if "MaxMismatch" in o or "Degenerate" in o:
+        check(data, True, o)
