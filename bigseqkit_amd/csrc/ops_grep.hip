@@ -306,14 +306,19 @@ __global__ __launch_bounds__(256) void k_grep_seq_gen(const uint8_t* __restrict_
 constexpr int SA_MAX_TABLES = 8;
 constexpr int SA_MAX_MM = 3;
 
-template <int KMM>
-__device__ __forceinline__ bool sa_search(const uint64_t* __restrict__ B, uint32_t m, const Text& T, uint32_t wb, uint32_t wl,
-                                          bool contig, const uint8_t* hi) {
-    uint64_t R[KMM + 1];
+// NT tables over the same window in one pass of the text (both strands of one pattern when no region is set)
+template <int KMM, int NT>
+__device__ __forceinline__ bool sa_search(const uint64_t* __restrict__ B, const uint32_t (&mt)[NT], const Text& T, uint32_t wb,
+                                          uint32_t wl, bool contig, const uint8_t* hi) {
+    uint64_t R[NT][KMM + 1];
+    uint64_t last[NT], seen[NT];
 #pragma unroll
-    for (int j = 0; j <= KMM; ++j) R[j] = 0;
-    const uint64_t last = 1ull << (m - 1u);
-    uint64_t seen = 0;
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j <= KMM; ++j) R[t][j] = 0;
+        last[t] = 1ull << (mt[t] - 1u);
+        seen[t] = 0;
+    }
     for (uint32_t x0 = 0; x0 < wl; x0 += 16u) {
         const uint32_t nb = wl - x0 < 16u ? wl - x0 : 16u;
         uint32_t w[4] = {0, 0, 0, 0};
@@ -327,22 +332,33 @@ __device__ __forceinline__ bool sa_search(const uint64_t* __restrict__ B, uint32
         if (nb == 16u) {
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
-                const uint64_t bc = B[(w[b >> 2] >> (8 * (b & 3))) & 255u];
+                const uint32_t ch = (w[b >> 2] >> (8 * (b & 3))) & 255u;
 #pragma unroll
-                for (int j = KMM; j >= 1; --j) R[j] = (((R[j] << 1) | 1ull) & bc) | ((R[j - 1] << 1) | 1ull);
-                R[0] = ((R[0] << 1) | 1ull) & bc;
-                seen |= R[KMM];
+                for (int t = 0; t < NT; ++t) {
+                    const uint64_t bc = B[t * 256 + ch];
+#pragma unroll
+                    for (int j = KMM; j >= 1; --j) R[t][j] = (((R[t][j] << 1) | 1ull) & bc) | ((R[t][j - 1] << 1) | 1ull);
+                    R[t][0] = ((R[t][0] << 1) | 1ull) & bc;
+                    seen[t] |= R[t][KMM];
+                }
             }
         } else {
             for (uint32_t b = 0; b < nb; ++b) {
-                const uint64_t bc = B[(w[b >> 2] >> (8u * (b & 3u))) & 255u];
+                const uint32_t ch = (w[b >> 2] >> (8u * (b & 3u))) & 255u;
 #pragma unroll
-                for (int j = KMM; j >= 1; --j) R[j] = (((R[j] << 1) | 1ull) & bc) | ((R[j - 1] << 1) | 1ull);
-                R[0] = ((R[0] << 1) | 1ull) & bc;
-                seen |= R[KMM];
+                for (int t = 0; t < NT; ++t) {
+                    const uint64_t bc = B[t * 256 + ch];
+#pragma unroll
+                    for (int j = KMM; j >= 1; --j) R[t][j] = (((R[t][j] << 1) | 1ull) & bc) | ((R[t][j - 1] << 1) | 1ull);
+                    R[t][0] = ((R[t][0] << 1) | 1ull) & bc;
+                    seen[t] |= R[t][KMM];
+                }
             }
         }
-        if (seen & last) return true;
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) any |= (seen[t] & last[t]) != 0;
+        if (any) return true;
     }
     return false;
 }
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(256) void k_grep_shiftand(const uint8_t* __restrict
     __syncthreads();
     const int nstr = P.strand_only == 1 ? 1 : nstr_all;
     const int str0 = P.strand_only == 2 ? 1 : 0;
+    const bool pair = P.npat == 1 && nstr == 2 && str0 == 0 && !P.region_on;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (uint64_t)gridDim.x * blockDim.x) {
         const Text T = text_of(buf, t, tt, i);
         const uint32_t L = T.L;
@@ -371,6 +388,19 @@ __global__ __launch_bounds__(256) void k_grep_shiftand(const uint8_t* __restrict
         const bool contig = T.W == 0 && (in_buf || in_lin);
         const uint8_t* hi = in_buf ? buf + buf_n : tt.lin + tt.lin_n;
         bool hit = false;
+        if (pair) {  // tables 0 ('+') and 1 ('-') of the one pattern, whole sequence
+            const uint32_t m = P.pat_off[1] - P.pat_off[0];
+            if (m == 0) hit = true;
+            else if (m <= L) {
+                const uint32_t mt[2] = {m, m};
+                switch (P.max_mm) {
+                    case 0: hit = sa_search<0, 2>(s_B, mt, T, 0, L, contig, hi); break;
+                    case 1: hit = sa_search<1, 2>(s_B, mt, T, 0, L, contig, hi); break;
+                    case 2: hit = sa_search<2, 2>(s_B, mt, T, 0, L, contig, hi); break;
+                    default: hit = sa_search<3, 2>(s_B, mt, T, 0, L, contig, hi); break;
+                }
+            }
+        } else
         for (int strand = str0; strand < nstr && !hit; ++strand) {
             uint32_t wb = 0, we = L;
             if (P.region_on) {
@@ -386,11 +416,12 @@ __global__ __launch_bounds__(256) void k_grep_shiftand(const uint8_t* __restrict
                 if (m == 0) { hit = true; break; }
                 if (m > wl) continue;
                 const uint64_t* B = s_B + pk * 256;
+                const uint32_t mt[1] = {m};
                 switch (P.max_mm) {
-                    case 0: hit = sa_search<0>(B, m, T, wb, wl, contig, hi); break;
-                    case 1: hit = sa_search<1>(B, m, T, wb, wl, contig, hi); break;
-                    case 2: hit = sa_search<2>(B, m, T, wb, wl, contig, hi); break;
-                    default: hit = sa_search<3>(B, m, T, wb, wl, contig, hi); break;
+                    case 0: hit = sa_search<0, 1>(B, mt, T, wb, wl, contig, hi); break;
+                    case 1: hit = sa_search<1, 1>(B, mt, T, wb, wl, contig, hi); break;
+                    case 2: hit = sa_search<2, 1>(B, mt, T, wb, wl, contig, hi); break;
+                    default: hit = sa_search<3, 1>(B, mt, T, wb, wl, contig, hi); break;
                 }
             }
         }
