@@ -1478,6 +1478,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
                 G.comp = P.comp;
                 HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G, c->d_out_len, st, c->avg_record_bytes));  // != 0: some match exists
                 pre = true;
+                P.pre_regex = c->d_regex;
             }
             uint64_t ncand = 0;
             if (pre) {  // the candidates as a list: the matcher then runs with every lane busy

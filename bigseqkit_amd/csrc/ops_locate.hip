@@ -13,6 +13,7 @@
 
 #include "ops_locate.hpp"
 #include "pattern_match_dev.hpp"
+#include "regex_nfa.hpp"
 #include "regex_vm.hpp"
 #include "text_dev.hpp"
 
@@ -504,12 +505,35 @@ __global__ __launch_bounds__(64) void k_locate_vm(const uint8_t* __restrict__ bu
             uint32_t offset = 0;
             uint32_t far = 0;     // furthest end (in the strand's own coordinates) of a printed match
             bool any = false;
+            // An expression that consumes a byte per step (no ^ / $, not nullable) has all its matches end where the boolean
+            // automaton of grep -r is in a final state: a strand on which it never is holds no match, and no match ends
+            // beyond the last such position -- the matcher (the costly one) walks [offset, lim) instead of [offset, l), the
+            // matches it reports are the same (those of a start are the ones that end by lim, in the same priority order).
+            uint32_t lim = l;
+            if (P.pre_regex) {
+                const RegexProgram& pr = P.pre_regex[k];
+                if (!pr.nullable && pr.accept[RE_SYM_BEGIN] == 0 && pr.accept[RE_SYM_END] == 0) {
+                    const uint32_t nchunk = (pr.npos + 7u) >> 3;
+                    uint64_t S = 0;
+                    uint32_t last_e = 0;
+                    bool acc = false;
+                    for (uint32_t x = 0; x < l; ++x) {
+                        const uint32_t ch = strand == 0 ? T.at(x) : comp[T.at(l - 1u - x)];
+                        uint64_t f = pr.first;
+                        for (uint32_t q = 0; q < nchunk; ++q) f |= pr.follow[q][(S >> (8u * q)) & 255u];
+                        S = f & pr.accept[ch];
+                        if (S & pr.last) { acc = true; last_e = x + 1u; }
+                    }
+                    if (!acc) continue;
+                    lim = last_e;
+                }
+            }
             for (;;) {
-                if (offset > l) break;
+                if (offset > lim) break;
                 uint32_t caps[4];
                 bool found;
-                if (strand == 0) found = vm_search_fn(prog, [&](uint32_t i) { return T.at(offset + i); }, l - offset, 0u, caps);
-                else found = vm_search_fn(prog, [&](uint32_t i) { return comp[T.at(l - 1u - (offset + i))]; }, l - offset, 0u, caps);
+                if (strand == 0) found = vm_search_fn(prog, [&](uint32_t i) { return T.at(offset + i); }, lim - offset, 0u, caps);
+                else found = vm_search_fn(prog, [&](uint32_t i) { return comp[T.at(l - 1u - (offset + i))]; }, lim - offset, 0u, caps);
                 if (!found) break;
                 const uint32_t s = offset + caps[0], e = offset + caps[1];  // the match in the strand's coordinates [s, e)
                 if (!(any && far >= e)) {
@@ -525,7 +549,7 @@ __global__ __launch_bounds__(64) void k_locate_vm(const uint8_t* __restrict__ bu
                     any = true;
                 }
                 offset = P.non_greedy ? e + 1u : s + 1u;
-                if (offset >= l) break;
+                if (offset >= lim) break;
             }
         }
     }

@@ -22,6 +22,7 @@ struct LocateParams {  // Locate options after Before() (bigseqkit-lib/locate.go
     // class patterns (-d, -m, -F; pattern_match_dev.hpp): 8 dwords per position, offsets as `pat`
     int general, max_mm;
     const uint32_t* cls;
+    const struct RegexProgram* pre_regex;  // -r: boolean automata of the expressions (null: none); bound the matcher's walks
     const uint32_t* cand;    // count pass: null, or the records that hold an occurrence at all (k_grep_shiftand went first); the
     uint64_t ncand;          // others keep the 0 the prefilter left in out_len
     int fmi_order;           // -m / -F: all patterns on '+', then all on '-'; no +l shift of '-' coordinates (locate.go:208-391)

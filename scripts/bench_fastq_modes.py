@@ -36,7 +36,9 @@ CASES = [(G, {"Pattern": [P12], "BySeq": True}), (G, {"Pattern": [P12], "BySeq":
          (S, {"Seq": True}), (S, {"Qual": True}), (S, {"MinQual": 20}), (S, {"ValidateSeq": True}),
          (R, {"ByName": True}), (R, {"BySeq": True, "IgnoreCase": True}),
          (SS, {"Region": "10:100"}), (T, {"Frame": ["6"]}), (T, {"Frame": ["1"], "Trim": True})]
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""   # substring of "<operator> <options>": run those cases only
 for (name, fn), opts in CASES:
+    if ONLY not in name + " " + json.dumps(opts): continue
     try:
         ms, ol = run(name, fn, opts)
         print("%-16s %-66s %9.2f ms  out %6.2f GB  %6.0f GB/s" % (name, json.dumps(opts), ms, ol / 1e9, (t.numel() + ol) / ms / 1e6), flush=True)
