@@ -23,6 +23,7 @@ def run(name, fn, opts, t, reps=3):
         return (time.perf_counter() - t0) / reps * 1e3, out.len
 
 GB = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""   # substring of "<layout> <operator> <options>": those cases only
 CASES = [("Grep", lib.bsk_grep_run, {"Pattern": ["ACGTTGCAAGCT"], "BySeq": True}),
          ("Grep", lib.bsk_grep_run, {"Pattern": ["S0000000123"]}),
          ("Locate", lib.bsk_locate_run, {"Pattern": ["ACGTTGCAAGCT"]}),
@@ -38,6 +39,7 @@ CASES = [("Grep", lib.bsk_grep_run, {"Pattern": ["ACGTTGCAAGCT"], "BySeq": True}
 for kind, name in ((1, "FASTA-1k"), (2, "FASTA-5k")):
     t, n = synth(kind, GB * 1e9)
     for op, fn, opts in CASES:
+        if ONLY not in name + " " + op + " " + json.dumps(opts): continue
         try:
             ms, ol = run(op, fn, opts, t)
             print("%-9s %-16s %-52s %9.2f ms  out %6.2f GB  %6.0f GB/s" % (name, op, json.dumps(opts), ms, ol / 1e9, (t.numel() + ol) / ms / 1e6), flush=True)

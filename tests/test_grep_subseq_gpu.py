@@ -543,11 +543,21 @@ def test_wrapped_fasta_searches_on_linear_copies_equal_the_text_views(width, mon
     l = {"Pattern": ["ACGT"]}
     r = {"BySeq": True}
     want = (oracle.grep(data, False, json.dumps(g)), oracle.locate(data, False, json.dumps(l)), oracle.rmdup(data, False, json.dumps(r)))
+    # class patterns (Shift-And on views reads byte by byte through the line map) and the position-reporting matcher
+    gm = {"Pattern": ["ACGTTGCA"], "BySeq": True, "MaxMismatch": 2}
+    gd = {"Pattern": ["ACNNTGCR"], "BySeq": True, "Degenerate": True, "Region": "5:-5"}
+    lm = {"Pattern": ["ACGTTG"], "MaxMismatch": 1}
+    lr = {"Pattern": ["AC+G[AT]"], "UseRegexp": True}
+    want2 = (oracle.grep(data, False, json.dumps(gm)), oracle.grep(data, False, json.dumps(gd)),
+             oracle.locate(data, False, json.dumps(lm)), oracle.locate(data, False, json.dumps(lr)))
     for mode in (None, "view"):
         if mode:
             monkeypatch.setenv("BSK_TEXT", mode)
         got = (bsk.Grep(frame(data, False), _Opts(g)), bsk.Locate(frame(data, False), _Opts(l)), bsk.RmDup(frame(data, False), _Opts(r)))
         assert got == want
+        got2 = (bsk.Grep(frame(data, False), _Opts(gm)), bsk.Grep(frame(data, False), _Opts(gd)),
+                bsk.Locate(frame(data, False), _Opts(lm)), bsk.Locate(frame(data, False), _Opts(lr)))
+        assert got2 == want2
 
 
 # ---------------------------------------------------------------- -d / -m: Shift-And (k_grep_shiftand) against the position-wise kernel
