@@ -488,6 +488,94 @@ __global__ __launch_bounds__(256) void k_seq_emit(const uint8_t* __restrict__ bu
             }
             return;
         }
+        // FASTA whose line layout changes (unwrapped, re-wrapped at another width, cut to a region) or whose bases are mapped
+        // (case, dna <-> rna, complement, reversed), source lines and output lines of at least 16 bases: OUTPUT-driven, a
+        // lane writes 16 consecutive output bytes per step.  Those hold at most one output newline and come from at most 17
+        // consecutive source bytes with at most one source newline in them, both at positions known from two divisions:
+        // 32 source bytes in registers, the source newline squeezed out, (reverse: the 16 bytes mirrored,) the map through
+        // LDS, the output newline opened up -- all dword-wise with v_alignbyte and masks.  Stores of a group are contiguous.
+        // (The source-driven version below cut a source line at the output line ends and copied the pieces: pieces under
+        // 16 bytes went byte by byte, 24 ms for 10 GB re-wrapped from 60 to 70.)
+        {
+            const uint32_t lw = (uint32_t)(P.line_width > 0 ? P.line_width : 0);
+            if (!P.fastq && P.print_seq && !P.print_qual && (TW == 0 || TW >= 16u) && (lw == 0 || lw >= 16u) && (!use_lut || lut_in_lds) &&
+                W >= 16u) {
+                put_head();
+                uint8_t* d0 = o + a;
+                const uint32_t text_len = r.seq_len + (TW && r.seq_len ? (r.seq_len - 1u) / TW : 0u);  // source bytes of the record's text
+                const bool wide_ok = sp >= buf && sp + text_len <= P.buf_end;
+                const uint32_t hi = last_byte(a, W);
+                for (uint32_t x0 = first_step(a) + gl * 16u; x0 < hi; x0 += LANES * 16u) {
+                    const uint32_t x = x0 + 16u > W ? W - 16u : x0;  // the last step is taken from the region's end
+                    uint32_t q0 = x, k_out = 16u;
+                    if (lw) {
+                        const uint32_t ol = x / w1, col = x - ol * w1;  // col <= lw; == lw: the step starts on the newline
+                        q0 = ol * lw + (col < lw ? col : lw);
+                        k_out = lw - col;
+                    }
+                    const uint32_t nbases = k_out < 16u ? 15u : 16u;
+                    const uint32_t lo_b = reverse ? sub_e - q0 - nbases : sub_b + q0;  // first (lowest) source base of the step
+                    uint32_t s0 = lo_b, k_in = 64u;
+                    if (TW) { const uint32_t sl = lo_b / TW; s0 = lo_b + sl; k_in = TW - (lo_b - sl * TW); }
+                    uint32_t w[6];
+                    if (wide_ok && sp + s0 + 32 <= P.buf_end) {
+                        uint4 v0, v1;
+                        __builtin_memcpy(&v0, sp + s0, 16);
+                        __builtin_memcpy(&v1, sp + s0 + 16, 16);
+                        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y;
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 6; ++d) {
+                            uint32_t z = 0;
+                            for (int e = 0; e < 4; ++e)
+                                if (s0 + (uint32_t)(4 * d + e) < text_len) z |= (uint32_t)sp[s0 + (uint32_t)(4 * d + e)] << (8 * e);
+                            w[d] = z;
+                        }
+                    }
+                    uint32_t c[5];  // the bases lo_b .. lo_b + 19, the source newline (window byte k_in) removed
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) {
+                        const int tt = (int)k_in - 4 * d;
+                        const uint32_t keep = tt >= 4 ? 0xFFFFFFFFu : (tt <= 0 ? 0u : (1u << (8 * tt)) - 1u);
+                        c[d] = (w[d] & keep) | (__builtin_amdgcn_alignbyte(w[d + 1], w[d], 1) & ~keep);
+                    }
+                    uint32_t B[4];
+                    if (reverse) {
+                        const uint32_t rv[5] = {__builtin_bswap32(c[3]), __builtin_bswap32(c[2]), __builtin_bswap32(c[1]), __builtin_bswap32(c[0]), 0u};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) B[d] = nbases == 16u ? rv[d] : __builtin_amdgcn_alignbyte(rv[d + 1], rv[d], 1);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) B[d] = c[d];
+                    }
+                    if (use_lut) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            B[d] = (uint32_t)s_lut[B[d] & 0xFFu] | ((uint32_t)s_lut[(B[d] >> 8) & 0xFFu] << 8) |
+                                   ((uint32_t)s_lut[(B[d] >> 16) & 0xFFu] << 16) | ((uint32_t)s_lut[B[d] >> 24] << 24);
+                    }
+                    uint32_t O[4];
+                    if (k_out < 16u) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const int tt = (int)k_out - 4 * d;
+                            const uint32_t keep = tt >= 4 ? 0xFFFFFFFFu : (tt <= 0 ? 0u : (1u << (8 * tt)) - 1u);
+                            const uint32_t up = __builtin_amdgcn_alignbyte(B[d], d ? B[d - 1] : 0u, 3);
+                            uint32_t v = (B[d] & keep) | (up & ~keep);
+                            if ((int)(k_out >> 2) == d) { const uint32_t sh = 8u * (k_out & 3u); v = (v & ~(0xFFu << sh)) | (0x0Au << sh); }
+                            O[d] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) O[d] = B[d];
+                    }
+                    const uint4 ov = make_uint4(O[0], O[1], O[2], O[3]);
+                    __builtin_memcpy(d0 + x, &ov, 16);
+                }
+                if (gl == 0 && mine(a + W)) d0[W] = (uint8_t)'\n';
+                return;
+            }
+        }
         // A wrapped FASTA source that is unwrapped, re-wrapped at another width, cut to a region or mapped (case, dna <-> rna,
         // complement, reversed): the output is made of pieces that are contiguous in the source AND in the output --
         // between two line ends of either.  A lane takes a source line, cuts it at the output line ends and copies every
@@ -655,7 +743,8 @@ hipError_t launch_seq_emit(const uint8_t* buf, const RecordTable& t, const SeqPa
     SeqParams P = Pin;
     if (!(P.long_list && P.long_count)) P.long_thresh = 0u;
     // tiny records (names only) are written by the per-byte path: one pass of 16 lanes beats three of 4
-    const bool small = records > 0 && total_bytes / records < 1024 && total_bytes / records >= 48;
+    // (4 lanes up to 640 bytes per record: 1 kb records measured 12.1 ms with 4 lanes against 8.7 ms with 16 at 10 GB)
+    const bool small = records > 0 && total_bytes / records < 640 && total_bytes / records >= 48;
     if (small) {
         const uint64_t blocks = (t.n * 4 + 255) / 256;
         hipLaunchKernelGGL((k_seq_emit<4, false>), dim3((unsigned)blocks), dim3(256), 0, st, buf, t, P, out_len, out_off, out);

@@ -281,3 +281,53 @@ def test_records_much_longer_than_a_range_through_every_operator(monkeypatch):
     assert bsk.Translate(fr(), _Opts(o)) == oracle.translate(data, False, json.dumps(o))
     o = {"BySeq": True}
     assert bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data + data)]), _Opts(o)) == oracle.rmdup(data + data, False, json.dumps(o))
+
+
+# ---------------------------------------------------------------- FASTA re-wrapped / mapped 16 output bytes per lane (k_seq_emit)
+REWRAP_XFORMS = [{}, {"Reverse": True}, {"Complement": True}, {"Reverse": True, "Complement": True}, {"UpperCase": True, "Dna2rna": True},
+                 {"Seq": True}, {"Seq": True, "Reverse": True, "Complement": True}]
+
+
+@pytest.mark.parametrize("src_w", [60, 16, 17, 31, 70, 0, 9])
+def test_seq_fasta_rewrap_matrix(src_w, monkeypatch):
+    """source width x output width x transform: the output-driven path (source and output lines of >= 16 bases), the
+    source-driven one (narrow lines) and the byte path (records under 16 bytes of text) against the oracle; lengths around
+    the multiples of both widths, records at the very end of the shard (no 32-byte load past it)"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "2048")
+    rng = random.Random(4300 + src_w)
+    recs = []
+    lens = list(range(0, 40)) + [59, 60, 61, 69, 70, 71, 119, 120, 121, 139, 140, 141, 419, 420, 421] + [rng.randint(1, 1500) for _ in range(120)]
+    rng.shuffle(lens)
+    for k, L in enumerate(lens):
+        s = "".join(rng.choice("ACGTNacgtu") for _ in range(L))
+        body = s + "\n" if src_w == 0 else "".join(s[j:j + src_w] + "\n" for j in range(0, L, src_w))
+        if L == 0:
+            body = "\n" if k % 2 else ""
+        recs.append(">r%d some words\n%s" % (k, body))
+    data = "".join(recs).encode()
+    for out_w in (0, 16, 17, 60, 61, 70, 100, 7):
+        for x in REWRAP_XFORMS:
+            o = dict(x, Config={"LineWidth": out_w})
+            check_seq(data, False, o)
+    for region in ("3:-3", "17:200", "-100:-1", "61:61"):
+        for out_w in (0, 60, 33):
+            o = {"Region": region, "Config": {"LineWidth": out_w}}
+            assert bsk.Subseq(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)]), _Opts(o)) == oracle.subseq(data, False, json.dumps(o))
+
+
+def test_seq_fasta_rewrap_long_records(monkeypatch):
+    """records above BSK_LONG_BYTES are written by whole blocks, 64 KiB of output each: the 16-byte steps at the slice borders"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_LONG_BYTES", "20000")
+    rng = random.Random(4400)
+    recs = []
+    for k, (L, w) in enumerate([(200_001, 60), (131_072, 64), (65_535, 0), (70_000, 17), (19_000, 60), (66_000, 100)]):
+        s = "".join(rng.choice("ACGTacgtn") for _ in range(L))
+        body = s + "\n" if w == 0 else "".join(s[j:j + w] + "\n" for j in range(0, L, w))
+        recs.append(">long%d\n%s" % (k, body))
+    data = "".join(recs).encode()
+    for out_w in (0, 60, 70, 64, 16):
+        for x in ({}, {"Reverse": True, "Complement": True}, {"LowerCase": True}):
+            check_seq(data, False, dict(x, Config={"LineWidth": out_w}))
+    o = {"Region": "1001:-1001", "Config": {"LineWidth": 80}}
+    assert bsk.Subseq(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)]), _Opts(o)) == oracle.subseq(data, False, json.dumps(o))
