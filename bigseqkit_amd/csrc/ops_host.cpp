@@ -954,7 +954,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         // (uses d_out_len as scratch: before the match kernel.)  A search in the sequences reads them many times at
         // arbitrary offsets: wrapped FASTA records get a linear copy first (the emit below goes back to the views)
         const bool flat_text = !fastq && G.by_seq;
-        rc = prepare_text(c, d_buf, format, st, &tt, flat_text);
+        rc = prepare_text(c, d_buf, format, st, &tt, flat_text, false, n);
         if (rc != BSK_OK) return rc;
         if (!c->regexes.empty()) {
             if (!c->patterns_uploaded) {
@@ -1351,7 +1351,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
         if (rc != BSK_OK) return rc;
         if (ab == AB_NONE) ab = AB_UNLIMIT;
-        rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/format != BSK_FORMAT_FASTQ);  // (see grep)
+        rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/format != BSK_FORMAT_FASTQ, false, n);  // (see grep)
         if (rc != BSK_OK) return rc;
         P.fastq = format == BSK_FORMAT_FASTQ;
         P.ignore_case = o.b("IgnoreCase");
@@ -1810,7 +1810,7 @@ int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
 // ---------------------------------------------------------------------------
 // FASTA text view: classify every record, linearise the irregularly wrapped ones
 // ---------------------------------------------------------------------------
-int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt, bool flatten, bool keep_out_len) {
+int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt, bool flatten, bool keep_out_len, uint64_t buf_n) {
     tt->text_w = nullptr;
     tt->lin_off = nullptr;
     tt->lin = nullptr;
@@ -1868,7 +1868,7 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     if (total) {
         rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
         if (rc != BSK_OK) return rc;
-        if (text_w == c->d_text_w && flatten) HIP_TRYX(c, launch_text_flatten(d_buf, c->table, c->d_lin_off, c->d_lin, st));
+        if (text_w == c->d_text_w && flatten) HIP_TRYX(c, launch_text_flatten(d_buf, buf_n, c->table, c->d_lin_off, c->d_lin, st));
         else HIP_TRYX(c, launch_text_linearise(d_buf, c->table, text_w, c->d_lin_off, c->d_lin, st));
     }
     tt->lin_n = total;
@@ -2176,7 +2176,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/!fastq && o.b("BySeq"));  // (see grep: hashed and compared as linear text)
+    rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/!fastq && o.b("BySeq"), false, n);  // (see grep: hashed and compared as linear text)
     if (rc != BSK_OK) return rc;
     RmDupParams P;
     memset(&P, 0, sizeof P);

@@ -58,7 +58,7 @@ struct RmDupParams;
 int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint8_t* d_has, hipStream_t st);
 // FASTA text view of the shard's records (text_dev.hpp); null pointers for FASTQ
 int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt, bool flatten = false,
-                 bool keep_out_len = false);
+                 bool keep_out_len = false, uint64_t buf_n = 0);  // buf_n: bytes in the shard (flatten: bounds its wide loads)
 // size array -> scan -> total / kept / kernel status (also lists the records with a very large output)
 int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept);
 void apply_long(const bsk_ctx* c, SeqParams* P);

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_lin_len_all(RecordTable t, uint32_t* __
 // 16 lanes per record: a uniformly wrapped record line by line, 16 bytes per step (the last step of a line from the line's
 // end); an irregular one byte by byte on lane 0
 __global__ __launch_bounds__(256) void k_text_flatten(const uint8_t* __restrict__ buf, RecordTable t, const uint64_t* __restrict__ lin_off,
-                                                      uint8_t* __restrict__ lin) {
+                                                      uint8_t* __restrict__ lin, const uint8_t* __restrict__ buf_end) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
     const uint32_t gl = threadIdx.x % GROUP;
     if (i >= t.n) return;
@@ -91,6 +91,41 @@ __global__ __launch_bounds__(256) void k_text_flatten(const uint8_t* __restrict_
         for (uint32_t k = 0; k < region; ++k) {
             const uint8_t c = p[k];
             if (c != '\n') o[x++] = c;
+        }
+        return;
+    }
+    if (W >= 16u && L >= 16u) {
+        // output-driven: a lane writes 16 consecutive bases per step (the group's stores are contiguous); they come from 17
+        // consecutive source bytes with at most one newline, squeezed out in registers (ops_seq.hip, same scheme)
+        const uint32_t text_len = L + (L - 1u) / W;
+        for (uint32_t x0 = gl * 16u; x0 < L; x0 += GROUP * 16u) {
+            const uint32_t x = x0 + 16u > L ? L - 16u : x0;
+            const uint32_t sl = x / W, s0 = x + sl, k_in = W - (x - sl * W);
+            uint32_t w[5];
+            if (buf_end ? p + s0 + 20 <= buf_end : s0 + 20u <= text_len) {
+                uint4 v0;
+                uint32_t v1;
+                __builtin_memcpy(&v0, p + s0, 16);
+                __builtin_memcpy(&v1, p + s0 + 16, 4);
+                w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1;
+            } else {
+#pragma unroll
+                for (int d = 0; d < 5; ++d) {
+                    uint32_t z = 0;
+                    for (int e = 0; e < 4; ++e)
+                        if (s0 + (uint32_t)(4 * d + e) < text_len) z |= (uint32_t)p[s0 + (uint32_t)(4 * d + e)] << (8 * e);
+                    w[d] = z;
+                }
+            }
+            uint32_t c[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int tt = (int)k_in - 4 * d;
+                const uint32_t keep = tt >= 4 ? 0xFFFFFFFFu : (tt <= 0 ? 0u : (1u << (8 * tt)) - 1u);
+                c[d] = (w[d] & keep) | (__builtin_amdgcn_alignbyte(w[d + 1], w[d], 1) & ~keep);
+            }
+            const uint4 ov = make_uint4(c[0], c[1], c[2], c[3]);
+            __builtin_memcpy(o + x, &ov, 16);
         }
         return;
     }
@@ -148,9 +183,10 @@ hipError_t launch_lin_len_all(const RecordTable& t, uint32_t* lin_len, uint32_t*
     return hipGetLastError();
 }
 
-hipError_t launch_text_flatten(const uint8_t* buf, const RecordTable& t, const uint64_t* lin_off, uint8_t* lin, hipStream_t st) {
+hipError_t launch_text_flatten(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint64_t* lin_off, uint8_t* lin, hipStream_t st) {
     if (t.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_text_flatten, dim3((unsigned)((t.n * GROUP + 255) / 256)), dim3(256), 0, st, buf, t, lin_off, lin);
+    hipLaunchKernelGGL(k_text_flatten, dim3((unsigned)((t.n * GROUP + 255) / 256)), dim3(256), 0, st, buf, t, lin_off, lin,
+                       buf_n ? buf + buf_n : nullptr);
     return hipGetLastError();
 }
 
