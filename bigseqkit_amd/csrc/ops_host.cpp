@@ -2101,7 +2101,8 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             if (!c->d_counter) HIP_TRYX(c, hipMalloc((void**)&c->d_counter, 4 * sizeof(uint64_t)));
             HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, sizeof(uint64_t), st));
             // wide kernel: a wave per record from ~3 k bases (a step of 64 lanes covers 3072), 16 lanes per record below
-            const int wide_lanes = forced == 16 || forced == 64 ? forced : (avg >= 3000 ? 64 : 16);
+            // (reads: a step of 4 lanes covers 192 bases; 16 lanes per 150-base read left 12 of them idle)
+            const int wide_lanes = forced == 4 || forced == 16 || forced == 64 ? forced : (avg >= 3000 ? 64 : (avg < 500 ? 4 : 16));
             HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
                                                 c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter));
             HIP_TRYX(c, launch_translate_long(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status,

@@ -1211,6 +1211,9 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
             if (wide_lanes == 64)
                 hipLaunchKernelGGL(k_translate_wide<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);
+            else if (wide_lanes == 4)
+                hipLaunchKernelGGL(k_translate_wide<4>, dim3((unsigned)((t.n * 4 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
+                                   P, out_len, out_off, out, redo, redo_count, status);
             else
                 hipLaunchKernelGGL(k_translate_wide<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);
