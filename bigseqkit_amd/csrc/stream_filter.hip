@@ -317,7 +317,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_FILTER_ATTR void k_filt
         r = wave_first(r);
         if (r >= nranges) break;
         uint64_t rs = anchors[r], re = anchors[r + 1];
-        if (rs == ANCHOR_NONE || re == ANCHOR_NONE) { sink.err |= ERR_ANCHOR; continue; }  // no record start within reach: not FASTQ
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) {

@@ -198,7 +198,6 @@ void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __rest
         r = wave_first(r);
         if (r >= nranges) break;
         uint64_t rs = anchors[r], re = anchors[r + 1];
-        if (rs == ANCHOR_NONE || re == ANCHOR_NONE) { sink.err |= ERR_ANCHOR; continue; }  // no record start within reach: not FASTQ
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) {

@@ -15,6 +15,7 @@
 #include <cstdint>
 
 #include "anchor.hpp"
+#include "anchor_wave_dev.hpp"
 #include "stream_core_dev.hpp"
 #include "stream_stats.hpp"
 
@@ -248,7 +249,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         r = wave_first(r);
         if (r >= nranges) break;
         uint64_t rs = anchors[r], re = anchors[r + 1];
-        if (rs == ANCHOR_NONE || re == ANCHOR_NONE) { sink.err |= ERR_ANCHOR; continue; }  // no record start within reach: not FASTQ
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) continue;
@@ -284,22 +284,27 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
 // anchors[0] = 0, anchors[r] = first record start >= r * chunk, anchors[nranges] = n_eff
 // ---------------------------------------------------------------------------
 template <bool FASTQ>
-__global__ void k_prep(const uint8_t* __restrict__ buf, uint64_t n, uint64_t chunk, uint32_t nranges,
-                       uint64_t* __restrict__ anchors, uint32_t* __restrict__ queue, int line_mode) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_prep(const uint8_t* __restrict__ buf, uint64_t n, uint64_t chunk, uint32_t nranges,
+                                              uint64_t* __restrict__ anchors, uint32_t* __restrict__ queue, int line_mode) {
+    // one WAVE per range boundary (anchor_wave_dev.hpp): the line ends are searched 1 KiB per step
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool lane0 = (threadIdx.x & 63u) == 0u;
     if (r > nranges) return;
     if (r == 0) {
-        anchors[0] = 0;
-        *queue = 0;
+        if (lane0) { anchors[0] = 0; *queue = 0; }
         return;
     }
     if (r == nranges) {
-        anchors[nranges] = effective_end(buf, n);
+        if (lane0) anchors[nranges] = effective_end(buf, n);
         return;
     }
     const uint64_t from = (uint64_t)r * chunk;
-    anchors[r] = FASTQ ? find_fastq_start(buf, n, from, from + ANCHOR_SEARCH_BYTES)
-                       : (line_mode ? find_line_start(buf, n, from) : find_fasta_start(buf, n, from));
+    const uint64_t a = FASTQ ? wave_anchor::find_fastq_start(buf, n, from, from + ANCHOR_SEARCH_BYTES)
+                             : (line_mode ? wave_anchor::find_line_start(buf, n, from) : wave_anchor::find_fasta_start(buf, n, from));
+    // No record start within reach (text that is not FASTQ): the range begins at the raw boundary.  The streaming pass
+    // validates every line it reads, so it reports the malformed text itself -- a check of the anchors inside its range loop
+    // cost k_stats two spilled registers and 1 ms at 100 GB.
+    if (lane0) anchors[r] = a == ANCHOR_NONE ? from : a;
 }
 
 // Records that cross range boundaries (FASTA, line-start ranges).  A record that is open at the end of range r (its
@@ -382,8 +387,8 @@ __global__ void k_scan_selftest(const uint32_t* in, uint32_t* out) {
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
                        uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode) {
-    const int threads = 64;
-    const int blocks = (int)((nranges + 1 + threads - 1) / threads);
+    const int threads = 256;  // four boundaries per block, a wave each
+    const int blocks = (int)(((uint64_t)nranges + 1 + 3) / 4);
     if (fastq) hipLaunchKernelGGL(k_prep<true>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, 0);
     else hipLaunchKernelGGL(k_prep<false>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, line_mode ? 1 : 0);
     return hipGetLastError();

@@ -331,3 +331,41 @@ def test_seq_fasta_rewrap_long_records(monkeypatch):
             check_seq(data, False, dict(x, Config={"LineWidth": out_w}))
     o = {"Region": "1001:-1001", "Config": {"LineWidth": 80}}
     assert bsk.Subseq(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(data)]), _Opts(o)) == oracle.subseq(data, False, json.dumps(o))
+
+
+def test_long_read_fastq_with_small_ranges(monkeypatch):
+    """reads of 3-40 kb on one line, ranges of a few KiB: every range boundary falls inside a line that is longer than the
+    range, the anchor search (k_prep, one wave per boundary) walks several such lines; all commands against the oracle"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(9100)
+    recs = []
+    for i in range(120):
+        L = rng.choice([0, 1, 50, 3000, 8191, 8192, 8193, 20000, 40000])
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        q = "".join(chr(rng.randint(33, 100)) for _ in range(L))
+        if L and i % 5 == 0:
+            q = "@" + q[1:]          # a quality line that looks like a header
+        if L > 1 and i % 7 == 0:
+            q = q[0] + "+" + q[2:]
+        recs.append("@long%d ch=%d\n%s\n+\n%s\n" % (i, i, s, q))
+    for final_newline in (True, False):
+        data = "".join(recs).encode()
+        if not final_newline:
+            data = data[:-1]
+        t = dev(data)
+        fr = lambda: bsk.SeqFrame(bsk.FORMAT_FASTQ, [t])
+        so = bsk.SeqKitStatsOptions()
+        so.All(True)
+        so.Tabular(True)
+        assert bsk.StatsString("input0", "N/A", fr(), so) == oracle.stats_string(data, True, '{"All": true, "Tabular": true}')
+        check_seq(data, True, {})
+        check_seq(data, True, {"Name": True})
+        check_seq(data, True, {"Reverse": True, "Complement": True, "MinLen": 100})
+        o = {"Pattern": ["ACGTTGCA"], "BySeq": True}
+        g = bsk.SeqKitGrepOptions()
+        g.Pattern(["ACGTTGCA"])
+        g.BySeq(True)
+        assert bsk.Grep(fr(), g) == oracle.grep(data, True, json.dumps(dict(o, Count=False)))
+        o = {"Region": "11:-11"}
+        assert bsk.Subseq(fr(), _Opts(o)) == oracle.subseq(data, True, json.dumps(o))
+        assert bsk.RmDup(fr(), _Opts({"BySeq": True})) == oracle.rmdup(data, True, '{"BySeq": true}')
