@@ -1863,12 +1863,24 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     }
     HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_lin_off, n, c->d_scan_tmp, st));
     uint64_t total = 0;
+    uint64_t lc[2] = {0, 0};
+    const bool flat = text_w == c->d_text_w && flatten;
+    const char* lenv = getenv("BSK_LONG_BYTES");
+    const uint32_t long_thresh = lenv && atoll(lenv) > 0 ? (uint32_t)atoll(lenv) : SEQ_LONG_THRESH;
+    if (flat) {  // chromosome-sized records are copied by whole blocks: list them (read back with the total, one wait)
+        rc = grow(c, &c->d_long_list, &c->long_list_cap, n, n / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        if (!c->d_counter) HIP_TRYX(c, hipMalloc((void**)&c->d_counter, 4 * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_find_long(c->table.l_seq, n, long_thresh, c->d_long_list, c->d_counter + 2, st));
+        HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRYX(c, hipMemcpyAsync(&total, c->d_lin_off + n, sizeof total, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
     if (total) {
         rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
         if (rc != BSK_OK) return rc;
-        if (text_w == c->d_text_w && flatten) HIP_TRYX(c, launch_text_flatten(d_buf, buf_n, c->table, c->d_lin_off, c->d_lin, st));
+        if (flat) HIP_TRYX(c, launch_text_flatten(d_buf, buf_n, c->table, c->d_lin_off, c->d_lin, st, c->d_long_list, lc[0], lc[1], long_thresh));
         else HIP_TRYX(c, launch_text_linearise(d_buf, c->table, text_w, c->d_lin_off, c->d_lin, st));
     }
     tt->lin_n = total;

@@ -72,10 +72,44 @@ __global__ __launch_bounds__(256) void k_lin_len_all(RecordTable t, uint32_t* __
     text_w_flat[i] = w ? TEXT_IRREGULAR : 0u;  // "read the linear copy"
 }
 
+// 16 bases of the linear copy from position x0 (the last step of a record is taken from its end): 17 consecutive source
+// bytes with at most one line end among them (W >= 16), squeezed out in registers
+__device__ __forceinline__ void flatten_step(const uint8_t* __restrict__ p, uint8_t* __restrict__ o, uint32_t L, uint32_t W, uint32_t x0,
+                                             const uint8_t* __restrict__ buf_end) {
+    const uint32_t text_len = L + (L - 1u) / W;
+    const uint32_t x = x0 + 16u > L ? L - 16u : x0;
+    const uint32_t sl = x / W, s0 = x + sl, k_in = W - (x - sl * W);
+    uint32_t w[5];
+    if (buf_end ? p + s0 + 20 <= buf_end : s0 + 20u <= text_len) {
+        uint4 v0;
+        uint32_t v1;
+        __builtin_memcpy(&v0, p + s0, 16);
+        __builtin_memcpy(&v1, p + s0 + 16, 4);
+        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            uint32_t z = 0;
+            for (int e = 0; e < 4; ++e)
+                if (s0 + (uint32_t)(4 * d + e) < text_len) z |= (uint32_t)p[s0 + (uint32_t)(4 * d + e)] << (8 * e);
+            w[d] = z;
+        }
+    }
+    uint32_t c[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int tt = (int)k_in - 4 * d;
+        const uint32_t keep = tt >= 4 ? 0xFFFFFFFFu : (tt <= 0 ? 0u : (1u << (8 * tt)) - 1u);
+        c[d] = (w[d] & keep) | (__builtin_amdgcn_alignbyte(w[d + 1], w[d], 1) & ~keep);
+    }
+    const uint4 ov = make_uint4(c[0], c[1], c[2], c[3]);
+    __builtin_memcpy(o + x, &ov, 16);
+}
+
 // 16 lanes per record: a uniformly wrapped record line by line, 16 bytes per step (the last step of a line from the line's
 // end); an irregular one byte by byte on lane 0
 __global__ __launch_bounds__(256) void k_text_flatten(const uint8_t* __restrict__ buf, RecordTable t, const uint64_t* __restrict__ lin_off,
-                                                      uint8_t* __restrict__ lin, const uint8_t* __restrict__ buf_end) {
+                                                      uint8_t* __restrict__ lin, const uint8_t* __restrict__ buf_end, uint32_t long_thresh) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
     const uint32_t gl = threadIdx.x % GROUP;
     if (i >= t.n) return;
@@ -95,38 +129,10 @@ __global__ __launch_bounds__(256) void k_text_flatten(const uint8_t* __restrict_
         return;
     }
     if (W >= 16u && L >= 16u) {
+        if (long_thresh && L >= long_thresh) return;  // k_text_flatten_long: whole blocks per 64 KiB of the copy
         // output-driven: a lane writes 16 consecutive bases per step (the group's stores are contiguous); they come from 17
         // consecutive source bytes with at most one newline, squeezed out in registers (ops_seq.hip, same scheme)
-        const uint32_t text_len = L + (L - 1u) / W;
-        for (uint32_t x0 = gl * 16u; x0 < L; x0 += GROUP * 16u) {
-            const uint32_t x = x0 + 16u > L ? L - 16u : x0;
-            const uint32_t sl = x / W, s0 = x + sl, k_in = W - (x - sl * W);
-            uint32_t w[5];
-            if (buf_end ? p + s0 + 20 <= buf_end : s0 + 20u <= text_len) {
-                uint4 v0;
-                uint32_t v1;
-                __builtin_memcpy(&v0, p + s0, 16);
-                __builtin_memcpy(&v1, p + s0 + 16, 4);
-                w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1;
-            } else {
-#pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    uint32_t z = 0;
-                    for (int e = 0; e < 4; ++e)
-                        if (s0 + (uint32_t)(4 * d + e) < text_len) z |= (uint32_t)p[s0 + (uint32_t)(4 * d + e)] << (8 * e);
-                    w[d] = z;
-                }
-            }
-            uint32_t c[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int tt = (int)k_in - 4 * d;
-                const uint32_t keep = tt >= 4 ? 0xFFFFFFFFu : (tt <= 0 ? 0u : (1u << (8 * tt)) - 1u);
-                c[d] = (w[d] & keep) | (__builtin_amdgcn_alignbyte(w[d + 1], w[d], 1) & ~keep);
-            }
-            const uint4 ov = make_uint4(c[0], c[1], c[2], c[3]);
-            __builtin_memcpy(o + x, &ov, 16);
-        }
+        for (uint32_t x0 = gl * 16u; x0 < L; x0 += GROUP * 16u) flatten_step(p, o, L, W, x0, buf_end);
         return;
     }
     const uint32_t lines = (L + W - 1) / W;
@@ -145,6 +151,23 @@ __global__ __launch_bounds__(256) void k_text_flatten(const uint8_t* __restrict_
             for (uint32_t k = 0; k < nb; ++k) dst[k] = src[k];
         }
     }
+}
+
+// chromosome-sized records (uniformly wrapped, lines of >= 16 bases): one block per FLAT_CH bytes of the copy, grid = chunks x
+// long records.  (16 lanes walking a 250 MB record alone: 590 ms for grep -s / locate on 2 GB of chromosomes.)
+constexpr uint32_t FLAT_CH = 64u * 1024u;
+__global__ __launch_bounds__(256) void k_text_flatten_long(const uint8_t* __restrict__ buf, RecordTable t, const uint64_t* __restrict__ lin_off,
+                                                           uint8_t* __restrict__ lin, const uint8_t* __restrict__ buf_end,
+                                                           const uint32_t* __restrict__ long_list) {
+    const uint64_t i = long_list[blockIdx.y];
+    const uint32_t W = t.text_w[i];
+    const uint32_t L = t.l_seq[i];
+    const uint64_t lo = (uint64_t)blockIdx.x * FLAT_CH;
+    if (W == 0 || W == TEXT_IRREGULAR || W < 16u || lo >= L) return;
+    const uint8_t* p = buf + t.start[i] + t.l_head[i] + 1;
+    uint8_t* o = lin + lin_off[i];
+    const uint64_t hi = lo + FLAT_CH < L ? lo + FLAT_CH : L;
+    for (uint64_t x0 = lo + threadIdx.x * 16u; x0 < hi; x0 += 256u * 16u) flatten_step(p, o, L, W, (uint32_t)x0, buf_end);
 }
 
 // bytes each record needs in the linear side buffer, from the layout the index pass recorded (RecordTable::text_w)
@@ -183,10 +206,15 @@ hipError_t launch_lin_len_all(const RecordTable& t, uint32_t* lin_len, uint32_t*
     return hipGetLastError();
 }
 
-hipError_t launch_text_flatten(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint64_t* lin_off, uint8_t* lin, hipStream_t st) {
+hipError_t launch_text_flatten(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint64_t* lin_off, uint8_t* lin, hipStream_t st,
+                               const uint32_t* long_list, uint64_t long_count, uint64_t long_max, uint32_t long_thresh) {
     if (t.n == 0) return hipSuccess;
+    const uint8_t* buf_end = buf_n ? buf + buf_n : nullptr;
     hipLaunchKernelGGL(k_text_flatten, dim3((unsigned)((t.n * GROUP + 255) / 256)), dim3(256), 0, st, buf, t, lin_off, lin,
-                       buf_n ? buf + buf_n : nullptr);
+                       buf_end, long_count ? long_thresh : 0u);
+    if (long_count)
+        hipLaunchKernelGGL(k_text_flatten_long, dim3((unsigned)((long_max + FLAT_CH - 1) / FLAT_CH), (unsigned)long_count), dim3(256), 0, st,
+                           buf, t, lin_off, lin, buf_end, long_list);
     return hipGetLastError();
 }
 
