@@ -1815,6 +1815,8 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     tt->lin_off = nullptr;
     tt->lin = nullptr;
     tt->lin_n = 0;
+    c->flat_long_count = 0;
+    c->flat_long_thresh = 0;
     if (format == BSK_FORMAT_FASTQ || c->table.n == 0) return BSK_OK;
     const uint64_t n = c->table.n;
     if (n + 1 > c->text_cap || !c->d_lin_off) {
@@ -1877,6 +1879,8 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     }
     HIP_TRYX(c, hipMemcpyAsync(&total, c->d_lin_off + n, sizeof total, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
+    c->flat_long_count = flat ? lc[0] : 0;
+    c->flat_long_thresh = flat ? long_thresh : 0u;
     if (total) {
         rc = grow(c, &c->d_lin, &c->lin_cap, total, total / 8 + 64);
         if (rc != BSK_OK) return rc;
@@ -2207,7 +2211,9 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     if (rc != BSK_OK) return rc;
     rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
+    if (!fastq && P.by_seq && c->flat_long_count) P.hash_long_min = c->flat_long_thresh;  // (listed by prepare_text just above)
     HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+    HIP_TRYX(c, launch_rmdup_hash_long(d_buf, n, c->table, tt, P, c->d_keys, nullptr, c->d_long_list, c->flat_long_count, st));
     // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
     // overflows, or with 2^32 records) keeps the one big table in HBM
     uint32_t* d_first = nullptr;

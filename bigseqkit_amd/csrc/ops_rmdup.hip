@@ -76,6 +76,37 @@ __device__ __forceinline__ uint64_t word64(const Subject& s, uint32_t i) {
     return v;
 }
 
+// XXH64 from stripe position p (a multiple of 32, p + 32 <= len or p == 0) with the accumulators as they stand there
+__device__ uint64_t xxh64_from(const Subject& s, uint64_t seed, uint64_t v1, uint64_t v2, uint64_t v3, uint64_t v4, uint32_t p) {
+    const uint32_t len = s.len;
+    uint64_t h;
+    if (len >= 32) {
+        while (p + 32 <= len) {
+            v1 = xround(v1, word64(s, p));
+            v2 = xround(v2, word64(s, p + 8));
+            v3 = xround(v3, word64(s, p + 16));
+            v4 = xround(v4, word64(s, p + 24));
+            p += 32;
+        }
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= len) { h ^= xround(0, word64(s, p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= len) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; ++k) w |= (uint32_t)s.at(p + k) << (8 * k);
+        h ^= (uint64_t)w * P1;
+        h = rotl64(h, 23) * P2 + P3;
+        p += 4;
+    }
+    while (p < len) { h ^= (uint64_t)s.at(p) * P5; h = rotl64(h, 11) * P1; ++p; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
 __device__ uint64_t xxh64_subject(const Subject& s, uint64_t seed = 0) {
     const uint32_t len = s.len;
     uint32_t p = 0;
@@ -220,6 +251,11 @@ __device__ bool stage_subjects(const Subject& s, bool live, const uint8_t* buf_e
     return true;
 }
 
+// sequences that a whole wave hashes (k_rmdup_hash_long): long, and contiguous in memory (a FASTQ line, a linear copy)
+__device__ __forceinline__ bool hash_by_wave(const Subject& s, const RmDupParams& P) {
+    return P.hash_long_min != 0u && s.seq && s.T.W == 0u && s.len >= P.hash_long_min;
+}
+
 // (Staging 32 subjects at a time -- 5.2 KB of LDS per wave instead of 10.5, i.e. 7 instead of 3 waves per SIMD -- was
 // measured slower: rmdup 31.6 vs 29.1 ms.  The kernel is not short of waves.)
 __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
@@ -228,6 +264,7 @@ __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < t.n;
     const Subject s = subject_of(buf, t, tt, P, live ? i : 0);
+    if (hash_by_wave(s, P)) return;  // k_rmdup_hash_long writes the keys of this record (the rest of the wave is then not staged)
     uint8_t* slot = s_stage[threadIdx.x >> 6];
     uint64_t k1, k2 = 0;
     if (stage_subjects(s, live, buf + buf_n, slot, tt.lin, tt.lin ? tt.lin + tt.lin_n : nullptr)) {
@@ -241,6 +278,66 @@ __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ 
     if (live) {
         keys[i] = k1;
         if (keys2) keys2[i] = k2;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Chromosome-sized sequences.  XXH64 is four serial accumulator chains over 32-byte stripes; one lane walking 250 MB with
+// a memory round trip per stripe hashed 55 MB/s (4.6 s for eight chromosomes).  Here a wave owns the record: all lanes
+// copy 4 KiB chunks into LDS with coalesced 16-byte loads (the next chunk is in flight while the current one is hashed),
+// lanes 0..3 run the four chains of seed 0 and lanes 4..7 those of the second seed from LDS, lane 0 finishes (merge,
+// last stripes, tail) with the scalar code.
+// ---------------------------------------------------------------------------
+constexpr uint32_t HCH = 4096;
+__device__ __forceinline__ uint32_t fold4(uint32_t x) {  // lower8 on four bytes
+    const uint32_t ge_a = (x & 0x7F7F7F7Fu) + 0x3F3F3F3Fu, ge_z1 = (x & 0x7F7F7F7Fu) + 0x25252525u;
+    return x | ((ge_a & ~ge_z1 & ~x & 0x80808080u) >> 2);
+}
+__global__ __launch_bounds__(64) void k_rmdup_hash_long(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+                                                        RmDupParams P, uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
+                                                        const uint32_t* __restrict__ long_list) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][HCH];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t i = long_list[blockIdx.x];
+    const Subject s = subject_of(buf, t, tt, P, i);
+    if (!hash_by_wave(s, P)) return;  // (k_rmdup_hash took it)
+    const uint8_t* p = s.T.p;
+    const uint32_t k = lane & 3u;
+    const uint64_t seed = lane < 4u ? 0ull : SEED2;
+    uint64_t v = k == 0 ? seed + P1 + P2 : (k == 1 ? seed + P2 : (k == 2 ? seed : seed - P1));
+    const uint32_t nfull = s.len / HCH;
+    uint4 r[4];
+    auto load = [&](uint32_t c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_memcpy(&r[q], p + (uint64_t)c * HCH + (uint32_t)q * 1024u + lane * 16u, 16);
+            if (s.fold) r[q] = make_uint4(fold4(r[q].x), fold4(r[q].y), fold4(r[q].z), fold4(r[q].w));
+        }
+    };
+    auto store = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(s_buf[b] + (uint32_t)q * 1024u + lane * 16u) = r[q];
+    };
+    if (nfull) {
+        load(0);
+        store(0);
+    }
+    for (uint32_t c = 0; c < nfull; ++c) {
+        if (c + 1 < nfull) load(c + 1);
+        __syncthreads();
+        if (lane < 8u) {
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(s_buf[c & 1u]) + k;
+#pragma unroll 8
+            for (uint32_t st = 0; st < HCH / 32u; ++st) v = xround(v, w[st * 4u]);
+        }
+        __syncthreads();
+        if (c + 1 < nfull) store((c + 1) & 1u);
+    }
+    const uint64_t a1 = __shfl(v, 0), a2 = __shfl(v, 1), a3 = __shfl(v, 2), a4 = __shfl(v, 3);
+    const uint64_t b1 = __shfl(v, 4), b2 = __shfl(v, 5), b3 = __shfl(v, 6), b4 = __shfl(v, 7);
+    if (lane == 0) {
+        keys[i] = xxh64_from(s, 0, a1, a2, a3, a4, nfull * HCH);
+        if (keys2) keys2[i] = xxh64_from(s, SEED2, b1, b2, b3, b4, nfull * HCH);
     }
 }
 
@@ -620,6 +717,15 @@ hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTab
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
     hipLaunchKernelGGL(k_rmdup_hash, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P, keys, keys2);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_hash_long(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
+                                  const RmDupParams& P, uint64_t* keys, uint64_t* keys2, const uint32_t* long_list,
+                                  uint64_t long_count, hipStream_t st) {
+    if (long_count == 0 || P.hash_long_min == 0) return hipSuccess;
+    TextTable d{tt.text_w, tt.lin_off, tt.lin, tt.lin_n};
+    hipLaunchKernelGGL(k_rmdup_hash_long, dim3((unsigned)long_count), dim3(64), 0, st, buf, buf_n, t, d, P, keys, keys2, long_list);
     return hipGetLastError();
 }
 

@@ -16,6 +16,9 @@ struct RmDupParams {  // RmDupPrepare / RmDupCheck options (bigseqkit-lib/rmdup.
     int id_mode;
     int line_width;
     const uint8_t* buf_end;  // one past the shard, or null
+    // sequences of at least this many bases on contiguous text are left out by k_rmdup_hash and hashed by a wave each
+    // (k_rmdup_hash_long); 0: none
+    uint32_t hash_long_min;
 };
 
 constexpr uint32_t ERR_HASH_COLLISION = 512u;
@@ -24,6 +27,10 @@ constexpr uint32_t ERR_BUCKET_OVERFLOW = 1u << 21;  // a radix bucket with too m
 // keys[i] = XXH64(subject i, seed 0); keys2 (may be null) = the same with another seed (multi-GPU verification key)
 hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                              const RmDupParams& P, uint64_t* keys, uint64_t* keys2, hipStream_t st);
+// the records of `long_list` (launch_find_long on l_seq with P.hash_long_min), one wave each; after launch_rmdup_hash
+hipError_t launch_rmdup_hash_long(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
+                                  const RmDupParams& P, uint64_t* keys, uint64_t* keys2, const uint32_t* long_list,
+                                  uint64_t long_count, hipStream_t st);
 // table: `cap` slots (power of two) of 16 bytes {key, ~first record}, zeroed by the caller (key_table)
 hipError_t launch_rmdup_insert(const uint64_t* keys, uint64_t n, uint64_t base_index, uint64_t* table, uint64_t cap,
                                hipStream_t st);

@@ -350,3 +350,36 @@ def test_rmdup_bucket_path_heavy_duplicates_and_table_cross_check(monkeypatch):
     assert got == want
     monkeypatch.setenv("BSK_RMDUP", "table")
     assert bsk.RmDup(frame(data, True), _Opts({"BySeq": True})) == want
+
+
+def test_rmdup_by_seq_on_long_fasta_records_hashed_by_a_wave(monkeypatch):
+    """sequences above BSK_LONG_BYTES on wrapped FASTA: XXH64 by k_rmdup_hash_long (4 KiB chunks through LDS, four lanes per
+    seed run the accumulator chains) must give the keys of the one-lane code -- same groups, same survivors; lengths around
+    the chunk and stripe sizes, duplicates that differ only in case (-i) or in their wrapping"""
+    import json
+    import random
+    import oracle
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_LONG_BYTES", "20000")
+    rng = random.Random(777)
+    seqs = []
+    for L in (20000, 20001, 20479, 20480, 20481, 24575, 24576, 24607, 24608, 32768, 65536 + 31, 100003, 19999):
+        seqs.append("".join(rng.choice("ACGTacgtN") for _ in range(L)))
+    recs = []
+    def put(name, s, w):
+        recs.append(">%s\n%s" % (name, "".join(s[j:j + w] + "\n" for j in range(0, len(s), w))))
+    for k, s in enumerate(seqs):
+        put("a%d" % k, s, 60)
+    for k, s in enumerate(seqs[::2]):
+        put("dup%d same text other width" % k, s, 70)          # duplicates of a0, a2, ...
+    for k, s in enumerate(seqs[1::3]):
+        put("case%d" % k, s.swapcase(), 60)                      # duplicates only with -i
+    put("last", seqs[3][:-1] + ("A" if seqs[3][-1] != "A" else "C"), 60)   # differs in the last base only
+    data = "".join(recs).encode()
+    t = dev(data)
+    for o in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}):
+        got = bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts(o))
+        assert got == oracle.rmdup(data, False, json.dumps(o))
+    monkeypatch.setenv("BSK_LONG_BYTES", "100000000")           # nothing is long: the one-lane code on the same input
+    for o in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}):
+        assert bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts(o)) == oracle.rmdup(data, False, json.dumps(o))
