@@ -327,6 +327,9 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
         for (char ch : c->opts.s("GapLetters"))
             if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
         for (char ch : uniq) D.pred.gap_rep[D.pred.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;
+        uint32_t top = 0;
+        for (char ch : uniq) top = std::max(top, (uint32_t)(uint8_t)ch);
+        D.pred.kgap = top >= 127u ? 0xFFFFFFFFu : (0x80u - (top + 1u)) * 0x01010101u;
     }
     uint64_t* anchors = c->d_anchors;
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);

@@ -177,6 +177,9 @@ struct Lds {
     // sparse path (ALL == false): the 16-byte pieces that contain a newline, compacted in byte order
     __attribute__((aligned(16))) uint4 sdata[(ALL) ? 1 : WAVE];
     uint16_t stag[(ALL) ? 2 : WAVE];  // piece * 64 + lane of the owner
+    // sparse FASTQ path with role counts: role[k] = (lines before the byte after the k-th flagged piece of the tile) & 3,
+    // role[0] = the same at the tile start -- what a piece WITHOUT a newline needs to know about itself
+    uint8_t role[(FASTQ && !ALL) ? WAVE * NPIECE + 4 : 4];
 };
 
 
@@ -224,6 +227,20 @@ __device__ __forceinline__ uint64_t abs_of(uint32_t rel, uint64_t tile_idx, uint
     return tile_idx + (uint64_t)(int64_t)(int32_t)(rel - tile_rel);
 }
 
+// A sink with `static constexpr bool ROLE_COUNTS = true` (FASTQ, sparse path) receives Q20 / Q30 / gap counts in its
+// rq20 / rq30 / rgap members (uint32_t per lane, the caller folds them after every range): they are sums over the
+// file, so they are counted per 16-byte piece by the ROLE of its bytes
+// (line index & 3: 0 header, 1 bases, 2 plus, 3 qualities) instead of as differences of running counters at the events.
+template <class S, class = void>
+struct sink_role_counts { static constexpr bool value = false; };
+template <class S>
+struct sink_role_counts<S, decltype((void)S::ROLE_COUNTS)> { static constexpr bool value = S::ROLE_COUNTS; };
+
+// set 0x80 flags of four dwords counted (v_bcnt accumulates)
+__device__ __forceinline__ uint32_t popc4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return (uint32_t)__popc(a) + (uint32_t)__popc(b) + (uint32_t)__popc(c) + (uint32_t)__popc(d);
+}
+
 // ---------------------------------------------------------------------------
 // stream one range [rs, re) of the shard through `sink`.
 //   sink.err            uint32_t error flags (per lane)
@@ -240,6 +257,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                                                  uint64_t rs, uint64_t re, bool is_last, const PredConsts& P,
                                                  Sink& sink) {
     const int lane = threadIdx.x & 63;
+    constexpr bool ROLES = FASTQ && !ALL && sink_role_counts<Sink>::value;
     // virtual events before the range: a newline at relative position -1
     if (lane < HISTORY) {
         L.pos[lane] = 0xFFFFFFFFu;
@@ -300,11 +318,16 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                 // zero byte below it in the same dword, so "any newline in these 16 bytes" is exact
                 const uint32_t h = (((y0 - 0x01010101u) & ~y0) | ((y1 - 0x01010101u) & ~y1) |
                                     ((y2 - 0x01010101u) & ~y2) | ((y3 - 0x01010101u) & ~y3)) & 0x80808080u;
-                const bool f = h != 0u;
+                // role counts: on an edge tile every piece takes the masked path of the flagged ones
+                const bool f = h != 0u || (ROLES && edge);
                 const uint64_t bal = __ballot(f);
                 flagged[p] = f;
+                // for a piece that is not flagged: the number of flagged pieces before it
                 slot_p[p] = tot_slots + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                 tot_slots += (uint32_t)__popcll(bal);
+            }
+            if constexpr (ROLES) {
+                if (lane == 0) L.role[0] = (uint8_t)(tile_rank_base & 3u);
             }
             for (uint32_t sbase = 0; sbase < tot_slots; sbase += WAVE) {
                 // owners publish their flagged pieces of this round
@@ -323,18 +346,47 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                 if (have) { v = L.sdata[lane]; tag = L.stag[lane]; }
                 const uint32_t off0 = (tag >> 6) * (uint32_t)PIECE_BYTES + (tag & 63u) * 16u;
                 uint32_t nl = have ? eq_mask16(v, 0x0A0A0A0Au) : 0u;
+                uint32_t vmask = have ? 0xFFFFu : 0u;  // bytes of the piece that belong to the range
                 if (edge) {
                     const uint64_t I = tile_idx + off0;
                     int64_t lo = (int64_t)rs - (int64_t)I, hi = (int64_t)re - (int64_t)I;
                     lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
                     hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-                    nl &= hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    vmask &= hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    nl &= vmask;
                 }
                 const uint32_t cnt = (uint32_t)__popc(nl);
                 const uint32_t incl = wave_incl_scan<DPP>(cnt);
                 const uint32_t round_base = line_base;
                 const uint32_t rank0 = round_base + incl - cnt;
                 line_base += wave_last(incl);
+                if constexpr (ROLES) {
+                    if (have) L.role[1u + sbase + (uint32_t)lane] = (uint8_t)((rank0 + cnt) & 3u);
+                    // pieces with a newline (and every piece of an edge tile): the bytes between its newlines take the
+                    // roles rank0, rank0 + 1, ...; cq / cs = the bytes of quality / sequence lines
+                    uint32_t m = nl, lo = 0, r = rank0 & 3u, cq = 0, cs = 0;
+                    while (m) {
+                        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+                        m &= m - 1u;
+                        const uint32_t seg = ((1u << b) - 1u) & ~((1u << lo) - 1u);
+                        cq |= r == 3u ? seg : 0u;
+                        cs |= r == 1u ? seg : 0u;
+                        lo = b + 1u;
+                        r = (r + 1u) & 3u;
+                    }
+                    const uint32_t seg = 0xFFFFu & ~((1u << lo) - 1u);
+                    cq |= r == 3u ? seg : 0u;
+                    cs |= r == 1u ? seg : 0u;
+                    cq &= vmask;
+                    cs &= vmask;
+                    sink.rq20 += (uint32_t)__popc(ge_mask16(v, P.k20) & cq);
+                    sink.rq30 += (uint32_t)__popc(ge_mask16(v, P.k30) & cq);
+                    const uint32_t low = P.kgap != 0xFFFFFFFFu ? (~ge_mask16(v, P.kgap) & cs) : cs;
+                    if (__ballot(low != 0u)) {
+#pragma nounroll
+                        for (int k = 0; k < P.ngap; ++k) sink.rgap += (uint32_t)__popc(eq_mask16(v, P.gap_rep[k]) & cs);
+                    }
+                }
                 for (uint32_t wb = round_base; wb < line_base; wb += CAP) {
                     uint32_t m = nl, k = 0;
                     while (m) {
@@ -369,6 +421,42 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                     keep_history<FASTQ, ALL>(L, E);
                 }
                 wave_lds_fence();  // the next round overwrites sdata / stag
+            }
+            if constexpr (ROLES) {
+                if (!edge) {
+                    // pieces without a newline: all 16 bytes have ONE role, the one published by the flagged piece before
+                    wave_lds_fence();
+#pragma unroll
+                    for (int p = 0; p < NPIECE; ++p) {
+                        const uint4 v = cur[p];
+                        const uint32_t r = L.role[slot_p[p]];
+                        const bool isq = !flagged[p] && r == 3u, iss = !flagged[p] && r == 1u;
+                        const uint32_t a0 = v.x & 0x7F7F7F7Fu, a1 = v.y & 0x7F7F7F7Fu, a2 = v.z & 0x7F7F7F7Fu,
+                                       a3 = v.w & 0x7F7F7F7Fu;
+                        constexpr uint32_t HI = 0x80808080u;
+                        // one family of "byte >= t" counts with a lane-selected threshold: quality bytes >= Q20 on a
+                        // quality line; on a sequence line bytes above the largest gap letter (bases are letters, so
+                        // 16 of 16 settle the gap count without looking at the letters)
+                        const uint32_t ka = r == 1u ? P.kgap : P.k20;
+                        const uint32_t ca = popc4(((a0 + ka) | v.x) & HI, ((a1 + ka) | v.y) & HI, ((a2 + ka) | v.z) & HI,
+                                                  ((a3 + ka) | v.w) & HI);
+                        const uint32_t c30 = popc4(((a0 + P.k30) | v.x) & HI, ((a1 + P.k30) | v.y) & HI,
+                                                   ((a2 + P.k30) | v.z) & HI, ((a3 + P.k30) | v.w) & HI);
+                        sink.rq20 += isq ? ca : 0u;
+                        sink.rq30 += isq ? c30 : 0u;
+                        if (__ballot(iss && (ca != 16u || P.kgap == 0xFFFFFFFFu))) {
+                            // gap letters are distinct: a byte equals at most one of them, the counts add up
+                            uint32_t cg = 0;
+#pragma nounroll
+                            for (int k = 0; k < P.ngap; ++k) {
+                                const uint32_t rep = P.gap_rep[k];
+                                cg += popc4(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep), zero_bytes(v.z ^ rep),
+                                            zero_bytes(v.w ^ rep));
+                            }
+                            sink.rgap += iss ? cg : 0u;
+                        }
+                    }
+                }
             }
             if (line_base == tile_rank_base) {
                 // lines longer than 2^31 bytes cannot be measured with 32-bit relative positions

@@ -78,12 +78,19 @@ __device__ __forceinline__ void add_length(bool has, uint32_t len, uint32_t* s_h
 // ---------------------------------------------------------------------------
 // StatsSink: Stats.Call (bigseqkit-lib/stats.go:48-117) on newline events
 // ---------------------------------------------------------------------------
-struct StatsSink {
+// ROLES (`stats -a` on FASTQ): Q20 / Q30 / gap are counted by the skeleton per line role (sink_role_counts), the events
+// carry no running counters and the sink works as for the default row.
+template <bool ROLES>
+struct StatsSinkT {
     static constexpr bool TILE_HOOK = false;
+    static constexpr bool ROLE_COUNTS = ROLES;
     uint32_t* s_hist;
     StatsDev D;
     // per-lane accumulators, reduced once per wave at kernel end
     uint64_t q20 = 0, q30 = 0, gap = 0, nrec = 0, sumlen = 0;
+    // ROLES: the skeleton counts into these per lane and range (a lane sees 1/64 of a range: no overflow below 256 GB);
+    // k_stats folds them into wave totals after every range
+    uint32_t rq20 = 0, rq30 = 0, rgap = 0;
     uint32_t err = 0;
     // FASTA: header-end of the record that is open at the start of a batch
     uint32_t open_key = 0, open_sg = 0;
@@ -211,10 +218,14 @@ struct StatsSink {
 };
 
 // 7 waves per SIMD (<= 72 VGPRs): measured 18.27 -> 17.72 ms (stats) against the compiler's own choice (74 VGPRs,
-// 6 waves).  The FASTQ -a kernel needs ~90 VGPRs: at 7 waves it spills 17 of them (24 GB of scratch writes per 100 GB
-// pass, PMC) -- 5 waves without spills: 40.7 -> 37.4 ms.
+// 6 waves).  The FASTQ -a kernel on the dense path (BSK_STATS_A_ROLES 0) needs ~90 VGPRs: at 7 waves it spills 17 of
+// them (24 GB of scratch writes per 100 GB pass, PMC) -- 5 waves without spills: 40.7 -> 37.4 ms.
 #ifndef BSK_STATS_WAVES
 #define BSK_STATS_WAVES 7
+#endif
+// FASTQ -a by line roles on the sparse path (1) or by running counters on the dense path (0)
+#ifndef BSK_STATS_A_ROLES
+#define BSK_STATS_A_ROLES 1
 #endif
 #ifndef BSK_STATS_WAVES_ALL
 #define BSK_STATS_WAVES_ALL 5
@@ -231,18 +242,21 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
                                                                    StatsDev D) {
     __shared__ uint32_t s_hist[LDS_HIST + 2 * BIG_SLOTS];  // dense bins, then the (length, count) cache of add_big
-    __shared__ Lds<FASTQ, ALL> s_l[WAVES_PER_BLOCK];
+    constexpr bool ROLES = FASTQ && ALL && BSK_STATS_A_ROLES;
+    constexpr bool SALL = ALL && !ROLES;  // what the skeleton and the events see
+    __shared__ Lds<FASTQ, SALL> s_l[WAVES_PER_BLOCK];
     for (int i = threadIdx.x; i < LDS_HIST + 2 * BIG_SLOTS; i += blockDim.x)
         s_hist[i] = (i >= LDS_HIST && i < LDS_HIST + BIG_SLOTS) ? BIG_EMPTY : 0u;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<FASTQ, ALL>& L = s_l[wave];
-    StatsSink sink;
+    Lds<FASTQ, SALL>& L = s_l[wave];
+    StatsSinkT<ROLES> sink;
     sink.s_hist = s_hist;
     sink.D = D;
     const uint64_t n_eff = anchors[nranges];
+    uint64_t w20 = 0, w30 = 0, wgap = 0;  // ROLES: wave totals
     for (;;) {
         uint32_t r = 0;
         if (lane == 0) r = atomicAdd(queue, 1u);
@@ -253,11 +267,19 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         re = re < n_eff ? re : n_eff;
         if (rs >= re) continue;
         sink.begin_range(r);
-        stream_range<FASTQ, ALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink);
+        stream_range<FASTQ, SALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink);
         if constexpr (!FASTQ) sink.template end_range<ALL>();
+        if constexpr (ROLES) {
+            // wave totals of the range (uniform: they live in scalar registers between ranges)
+            w20 += wave_first((uint32_t)wave_sum_u64(sink.rq20));
+            w30 += wave_first((uint32_t)wave_sum_u64(sink.rq30));
+            wgap += wave_first((uint32_t)wave_sum_u64(sink.rgap));
+            sink.rq20 = sink.rq30 = sink.rgap = 0;
+        }
     }
     // flush ---------------------------------------------------------------
-    const uint64_t q20 = wave_sum_u64(sink.q20), q30 = wave_sum_u64(sink.q30), gap = wave_sum_u64(sink.gap);
+    const uint64_t q20 = ROLES ? w20 : wave_sum_u64(sink.q20), q30 = ROLES ? w30 : wave_sum_u64(sink.q30),
+                   gap = ROLES ? wgap : wave_sum_u64(sink.gap);
     const uint64_t nrec = wave_sum_u64(sink.nrec), sumlen = wave_sum_u64(sink.sumlen);
     const uint32_t err = wave_or_u32(sink.err);
     if (lane == 0) {

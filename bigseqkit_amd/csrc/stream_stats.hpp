@@ -23,6 +23,9 @@ struct PredConsts {
     uint32_t k20, k30;  // (0x80 - threshold) replicated in the 4 bytes
     uint32_t gap_rep[MAX_GAP_LETTERS];
     int ngap;
+    // prefilter of the gap count (`stats -a` on FASTQ, line-role path): (0x80 - (largest gap letter + 1)) replicated --
+    // 16 bytes that are all above the largest gap letter hold no gap; 0xFFFFFFFF = no prefilter (a gap letter >= 127)
+    uint32_t kgap;
 };
 
 struct StatsDev {
