@@ -180,6 +180,8 @@ struct Lds {
     // sparse FASTQ path with role counts: role[k] = (lines before the byte after the k-th flagged piece of the tile) & 3,
     // role[0] = the same at the tile start -- what a piece WITHOUT a newline needs to know about itself
     uint8_t role[(FASTQ && !ALL) ? WAVE * NPIECE + 4 : 4];
+    // the same path: below[j] = packed_below(j), j = 0..16 (the bytes before byte j of a piece in the layout of pack_flags)
+    uint32_t below[(FASTQ && !ALL) ? 18 : 1];
 };
 
 
@@ -267,6 +269,9 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
         // FASTA ranges may begin inside a record (on any line start): the virtual event before the range closed a
         // record only if the range begins with a header
         if constexpr (!FASTQ) L.flag[lane] = buf[rs] == '>' ? 1 : 0;
+    }
+    if constexpr (ROLES) {
+        if (lane <= 16) L.below[lane] = lane == 16 ? 0x0F0F0F0Fu : packed_below((uint32_t)lane);
     }
     wave_lds_fence();
     if (lane == 0) {
@@ -363,28 +368,47 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                 if constexpr (ROLES) {
                     if (have) L.role[1u + sbase + (uint32_t)lane] = (uint8_t)((rank0 + cnt) & 3u);
                     // pieces with a newline (and every piece of an edge tile): the bytes between its newlines take the
-                    // roles rank0, rank0 + 1, ...; cq / cs = the bytes of quality / sequence lines
-                    uint32_t m = nl, lo = 0, r = rank0 & 3u, cq = 0, cs = 0;
+                    // roles rank0, rank0 + 1, ...; cq / cs = the bytes of quality / sequence lines.  Flags and masks stay
+                    // in the layout of pack_flags (a byte-order mask costs 31 instructions per predicate, a packed one
+                    // 13); the packed "bytes before byte b" come from LDS, both ends of a segment in one read.
+                    uint32_t m = nl, r = rank0 & 3u, cq = 0, cs = 0, pl = 0;
                     while (m) {
                         const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
                         m &= m - 1u;
-                        const uint32_t seg = ((1u << b) - 1u) & ~((1u << lo) - 1u);
+                        const uint32_t seg = L.below[b] & ~pl;
+                        pl = L.below[b + 1u];
                         cq |= r == 3u ? seg : 0u;
                         cs |= r == 1u ? seg : 0u;
-                        lo = b + 1u;
                         r = (r + 1u) & 3u;
                     }
-                    const uint32_t seg = 0xFFFFu & ~((1u << lo) - 1u);
+                    const uint32_t seg = 0x0F0F0F0Fu & ~pl;
                     cq |= r == 3u ? seg : 0u;
                     cs |= r == 1u ? seg : 0u;
-                    cq &= vmask;
-                    cs &= vmask;
-                    sink.rq20 += (uint32_t)__popc(ge_mask16(v, P.k20) & cq);
-                    sink.rq30 += (uint32_t)__popc(ge_mask16(v, P.k30) & cq);
-                    const uint32_t low = P.kgap != 0xFFFFFFFFu ? (~ge_mask16(v, P.kgap) & cs) : cs;
+                    if (edge) {
+                        const uint32_t vp = packed_from_mask16(vmask);
+                        cq &= vp;
+                        cs &= vp;
+                    } else if (!have) {
+                        cq = cs = 0;
+                    }
+                    constexpr uint32_t HI = 0x80808080u;
+                    const uint32_t a0 = v.x & 0x7F7F7F7Fu, a1 = v.y & 0x7F7F7F7Fu, a2 = v.z & 0x7F7F7F7Fu,
+                                   a3 = v.w & 0x7F7F7F7Fu;
+                    sink.rq20 += (uint32_t)__popc(pack_flags(((a0 + P.k20) | v.x) & HI, ((a1 + P.k20) | v.y) & HI,
+                                                             ((a2 + P.k20) | v.z) & HI, ((a3 + P.k20) | v.w) & HI) & cq);
+                    sink.rq30 += (uint32_t)__popc(pack_flags(((a0 + P.k30) | v.x) & HI, ((a1 + P.k30) | v.y) & HI,
+                                                             ((a2 + P.k30) | v.z) & HI, ((a3 + P.k30) | v.w) & HI) & cq);
+                    uint32_t low = cs;  // sequence bytes that may be gap letters
+                    if (P.kgap != 0xFFFFFFFFu)
+                        low &= ~pack_flags(((a0 + P.kgap) | v.x) & HI, ((a1 + P.kgap) | v.y) & HI, ((a2 + P.kgap) | v.z) & HI,
+                                           ((a3 + P.kgap) | v.w) & HI);
                     if (__ballot(low != 0u)) {
 #pragma nounroll
-                        for (int k = 0; k < P.ngap; ++k) sink.rgap += (uint32_t)__popc(eq_mask16(v, P.gap_rep[k]) & cs);
+                        for (int k = 0; k < P.ngap; ++k) {
+                            const uint32_t rep = P.gap_rep[k];
+                            sink.rgap += (uint32_t)__popc(pack_flags(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep),
+                                                                     zero_bytes(v.z ^ rep), zero_bytes(v.w ^ rep)) & cs);
+                        }
                     }
                 }
                 for (uint32_t wb = round_base; wb < line_base; wb += CAP) {

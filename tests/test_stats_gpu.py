@@ -301,3 +301,24 @@ def test_text_that_is_not_fastq_fails_fast():
     with pytest.raises(bsk.BskError):
         bsk.Seq(bsk.SeqFrame(bsk.FORMAT_FASTQ, [t]), bsk.SeqKitSeqOptions().Name(True))
     assert time.time() - t0 < 60
+
+
+@pytest.mark.parametrize("gaps", ["- .", "N-", "-\x7f", "ACGT"])
+@pytest.mark.parametrize("min_range", [256, 4096, 1 << 20])
+def test_stats_a_line_role_counts_on_hostile_reads(gaps, min_range, monkeypatch):
+    """`stats -a` counts Q20 / Q30 / gap by line role (stream_core_dev.hpp, sink_role_counts): reads with gap letters,
+    empty reads (three and more newlines inside 16 bytes), bytes >= 128 in names and qualities, `@` / `+` leading
+    qualities, a gap letter above the bases (no prefilter possible) and one at 127 (prefilter switched off)."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", str(min_range))
+    rng = random.Random(sum(map(ord, gaps)) * 31 + min_range)
+    recs = []
+    for i in range(4000):
+        L = rng.choice([0, 0, 1, 2, 7, 15, 16, 17, 31, 33, 64, 150, 151, 400])
+        s = bytes(rng.choice(b"ACGTNacgtn-. \x7f") for _ in range(L))
+        q = bytes(rng.choice(b"!+5?@IJ~\x80\xff") for _ in range(L))
+        name = b"r%d" % i + (b" caf\xc3\xa9 \xff" if i % 7 == 0 else b"")
+        recs.append(b"@" + name + b"\n" + s + b"\n+" + (name if i % 11 == 0 else b"") + b"\n" + q + b"\n")
+    data = b"".join(recs)
+    assert oracle.is_strict_4line_fastq(data)
+    check_parity(data, True, {"All": True, "GapLetters": gaps})
+    check_parity(data[:-1], True, {"All": True, "GapLetters": gaps})  # no final newline
