@@ -238,9 +238,16 @@ struct sink_role_counts { static constexpr bool value = false; };
 template <class S>
 struct sink_role_counts<S, decltype((void)S::ROLE_COUNTS)> { static constexpr bool value = S::ROLE_COUNTS; };
 
-// set 0x80 flags of four dwords counted (v_bcnt accumulates)
-__device__ __forceinline__ uint32_t popc4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    return (uint32_t)__popc(a) + (uint32_t)__popc(b) + (uint32_t)__popc(c) + (uint32_t)__popc(d);
+// set 0x80 flags of four dwords counted on top of acc: a chain of four v_bcnt_u32_b32 (count + accumulator)
+// (written as instructions: the compiler turns the sum of four popcounts into three v_bcnt with a zero accumulator, one
+// chained and a v_add3)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t popc4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t acc = 0u) {
+    return bcnt_acc(d, bcnt_acc(c, bcnt_acc(b, bcnt_acc(a, acc))));
 }
 
 // ---------------------------------------------------------------------------
@@ -464,10 +471,12 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                         const uint32_t ka = r == 1u ? P.kgap : P.k20;
                         const uint32_t ca = popc4(((a0 + ka) | v.x) & HI, ((a1 + ka) | v.y) & HI, ((a2 + ka) | v.z) & HI,
                                                   ((a3 + ka) | v.w) & HI);
-                        const uint32_t c30 = popc4(((a0 + P.k30) | v.x) & HI, ((a1 + P.k30) | v.y) & HI,
-                                                   ((a2 + P.k30) | v.z) & HI, ((a3 + P.k30) | v.w) & HI);
+                        // Q30: the flags of lanes that are not on a quality line are masked away, the counts chain into
+                        // the accumulator
+                        const uint32_t mq = isq ? HI : 0u;
+                        sink.rq30 = popc4(((a0 + P.k30) | v.x) & mq, ((a1 + P.k30) | v.y) & mq, ((a2 + P.k30) | v.z) & mq,
+                                          ((a3 + P.k30) | v.w) & mq, sink.rq30);
                         sink.rq20 += isq ? ca : 0u;
-                        sink.rq30 += isq ? c30 : 0u;
                         if (__ballot(iss && (ca != 16u || P.kgap == 0xFFFFFFFFu))) {
                             // gap letters are distinct: a byte equals at most one of them, the counts add up
                             uint32_t cg = 0;

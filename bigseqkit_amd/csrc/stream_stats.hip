@@ -271,9 +271,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         if constexpr (!FASTQ) sink.template end_range<ALL>();
         if constexpr (ROLES) {
             // wave totals of the range (uniform: they live in scalar registers between ranges)
-            w20 += wave_first((uint32_t)wave_sum_u64(sink.rq20));
-            w30 += wave_first((uint32_t)wave_sum_u64(sink.rq30));
-            wgap += wave_first((uint32_t)wave_sum_u64(sink.rgap));
+            const uint64_t s20 = wave_sum_u64(sink.rq20), s30 = wave_sum_u64(sink.rq30), sgap = wave_sum_u64(sink.rgap);
+            w20 += ((uint64_t)wave_first((uint32_t)(s20 >> 32)) << 32) | wave_first((uint32_t)s20);
+            w30 += ((uint64_t)wave_first((uint32_t)(s30 >> 32)) << 32) | wave_first((uint32_t)s30);
+            wgap += ((uint64_t)wave_first((uint32_t)(sgap >> 32)) << 32) | wave_first((uint32_t)sgap);
             sink.rq20 = sink.rq30 = sink.rgap = 0;
         }
     }
