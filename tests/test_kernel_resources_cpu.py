@@ -1,4 +1,4 @@
-"""The headline kernel must not spill: `k_stats<FASTQ, default, DPP>` runs at 7 waves per SIMD with every value in registers.
+"""The headline kernels must not spill: `k_stats<FASTQ, default, DPP>` runs at 7 waves per SIMD with every value in registers.
 A harmless-looking extra branch in its range loop once cost two spilled VGPRs and 1 ms of 17 at 100 GB without any test
 noticing; this compiles the file for gfx950 (no GPU needed) and reads the compiler's resource report."""
 import os
@@ -19,15 +19,19 @@ def test_k_stats_keeps_its_registers(tmp_path):
                         "-c", src, "-o", str(tmp_path / "s.o")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     blocks = re.split(r"remark: Function Name: ", r.stderr)
-    seen = 0
+    seen = set()
+    # k_stats<FASTQ = true, ALL = false, DPP = true>: the variant that runs, 7 waves per SIMD;
+    # k_stats<true, true, true>: `stats -a` by line roles, VALU-bound at 5 waves (6 waves spilled 178 registers: 44 ms for 25)
+    want = {"7k_statsILb1ELb0ELb1E": 7, "7k_statsILb1ELb1ELb1E": 5}
     for b in blocks:
         name = b.split(" ", 1)[0]
-        if "7k_statsILb1ELb0ELb1E" not in name:     # k_stats<FASTQ = true, ALL = false, DPP = true>: the variant that runs
+        key = next((k for k in want if k in name), None)
+        if key is None:
             continue
-        seen += 1
+        seen.add(key)
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
         assert (scratch, spill) == (0, 0), (name, scratch, spill)
-        assert occ >= 7, (name, occ)
-    assert seen >= 1
+        assert occ >= want[key], (name, occ)
+    assert seen == set(want)
