@@ -84,6 +84,8 @@ int init_device(bsk_ctx* c) {
     c->num_cus = p.multiProcessorCount;
     const char* sc = getenv("BSK_SCAN");
     c->use_dpp = !(sc && strcmp(sc, "shfl") == 0);
+    const char* sa = getenv("BSK_STATS_A");
+    c->stats_a_dense = sa && strcmp(sa, "dense") == 0;
     const char* mr = getenv("BSK_MIN_RANGE_BYTES");
     c->min_range_bytes = mr && atoll(mr) > 0 ? (uint64_t)atoll(mr) : MIN_RANGE_BYTES;
     HIP_TRY(c, hipMalloc((void**)&c->d_status, 4 * sizeof(uint64_t)));  // [2]: scratch of bsk_stats_collect
@@ -287,7 +289,7 @@ int bsk_stats_reset(bsk_ctx* c, void* stream) {
 static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, uint64_t* d_vec, hipStream_t st) {
     const bool fastq = format == BSK_FORMAT_FASTQ;
     const bool all = c->opts.b("All");
-    const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp);
+    const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp, c->stats_a_dense);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
     const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
@@ -354,7 +356,7 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     }
     {
         Timed t(c, "k_stats", st);
-        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st));
+        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, c->stats_a_dense));
     }
     if (!fastq) HIP_TRY(c, launch_stats_stitch(nranges, D, st));
     return BSK_OK;

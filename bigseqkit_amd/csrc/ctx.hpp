@@ -29,6 +29,7 @@ struct bsk_ctx {
     int num_cus = 0;
     uint64_t min_range_bytes = 64 * 1024;
     bool use_dpp = true;          // BSK_SCAN=shfl selects the ds_bpermute scan
+    bool stats_a_dense = false;   // BSK_STATS_A=dense: FASTQ `stats -a` by running counters (dense path) instead of line roles
     uint64_t* d_anchors = nullptr;  // [cap_ranges + 1] + queue word
     uint32_t cap_ranges = 0;
     hipStream_t own_stream = nullptr;

@@ -218,15 +218,13 @@ struct StatsSinkT {
 };
 
 // 7 waves per SIMD (<= 72 VGPRs): measured 18.27 -> 17.72 ms (stats) against the compiler's own choice (74 VGPRs,
-// 6 waves).  The FASTQ -a kernel on the dense path (BSK_STATS_A_ROLES 0) needs ~90 VGPRs: at 7 waves it spills 17 of
+// 6 waves).  The FASTQ -a kernel on the dense path (BSK_STATS_A=dense) needs ~90 VGPRs: at 7 waves it spills 17 of
 // them (24 GB of scratch writes per 100 GB pass, PMC) -- 5 waves without spills: 40.7 -> 37.4 ms.
 #ifndef BSK_STATS_WAVES
 #define BSK_STATS_WAVES 7
 #endif
-// FASTQ -a by line roles on the sparse path (1) or by running counters on the dense path (0)
-#ifndef BSK_STATS_A_ROLES
-#define BSK_STATS_A_ROLES 1
-#endif
+// FASTQ -a: by line roles on the sparse path (ROLES_T, the default) or by running counters on the dense path
+// (BSK_STATS_A=dense at run time: the two count the same bytes in unrelated ways, tests hold them against each other)
 #ifndef BSK_STATS_WAVES_ALL
 #define BSK_STATS_WAVES_ALL 5
 #endif
@@ -236,13 +234,13 @@ struct StatsSinkT {
 #define BSK_STATS_ATTR
 #endif
 
-template <bool FASTQ, bool ALL, bool DPP>
+template <bool FASTQ, bool ALL, bool DPP, bool ROLES_T = true>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats(const uint8_t* __restrict__ buf, uint64_t n,
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
                                                                    StatsDev D) {
     __shared__ uint32_t s_hist[LDS_HIST + 2 * BIG_SLOTS];  // dense bins, then the (length, count) cache of add_big
-    constexpr bool ROLES = FASTQ && ALL && BSK_STATS_A_ROLES;
+    constexpr bool ROLES = FASTQ && ALL && ROLES_T;
     constexpr bool SALL = ALL && !ROLES;  // what the skeleton and the events see
     __shared__ Lds<FASTQ, SALL> s_l[WAVES_PER_BLOCK];
     for (int i = threadIdx.x; i < LDS_HIST + 2 * BIG_SLOTS; i += blockDim.x)
@@ -440,33 +438,35 @@ hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t 
     return hipGetLastError();
 }
 
-template <bool FASTQ, bool ALL>
+template <bool FASTQ, bool ALL, bool ROLES_T = true>
 static hipError_t launch_stats_t(bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
                                  uint32_t nranges, uint32_t* queue, const StatsDev& D, hipStream_t st) {
     const dim3 b(WAVES_PER_BLOCK * WAVE);
-    if (dpp) hipLaunchKernelGGL((k_stats<FASTQ, ALL, true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
-    else hipLaunchKernelGGL((k_stats<FASTQ, ALL, false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+    if (dpp) hipLaunchKernelGGL((k_stats<FASTQ, ALL, true, ROLES_T>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+    else hipLaunchKernelGGL((k_stats<FASTQ, ALL, false, ROLES_T>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
     return hipGetLastError();
 }
 
 hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_t* buf, uint64_t n,
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
-                        hipStream_t st) {
+                        hipStream_t st, bool a_dense) {
+    if (fastq && all && a_dense) return launch_stats_t<true, true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st);
     if (fastq) return all ? launch_stats_t<true, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st)
                           : launch_stats_t<true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st);
     return all ? launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st)
                : launch_stats_t<false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st);
 }
 
-int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp) {
+int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense) {
     int nb = 0;
     const void* f = nullptr;
-#define BSK_PICK(FQ, AL)                                                             \
-    f = dpp ? (const void*)k_stats<FQ, AL, true> : (const void*)k_stats<FQ, AL, false>;
-    if (fastq && all) { BSK_PICK(true, true) }
-    else if (fastq) { BSK_PICK(true, false) }
-    else if (all) { BSK_PICK(false, true) }
-    else { BSK_PICK(false, false) }
+#define BSK_PICK(FQ, AL, RO)                                                             \
+    f = dpp ? (const void*)k_stats<FQ, AL, true, RO> : (const void*)k_stats<FQ, AL, false, RO>;
+    if (fastq && all && a_dense) { BSK_PICK(true, true, false) }
+    else if (fastq && all) { BSK_PICK(true, true, true) }
+    else if (fastq) { BSK_PICK(true, false, true) }
+    else if (all) { BSK_PICK(false, true, true) }
+    else { BSK_PICK(false, false, true) }
 #undef BSK_PICK
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;

@@ -53,8 +53,8 @@ hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t 
 hipError_t launch_hist_extent(const uint64_t* hist, uint32_t cap, uint64_t* out, hipStream_t st);
 hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_t* buf, uint64_t n,
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
-                        hipStream_t st);
-int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp);
+                        hipStream_t st, bool a_dense = false);  // a_dense: FASTQ -a on the dense path (BSK_STATS_A=dense)
+int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense = false);
 hipError_t launch_stream_read(int blocks, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
                               uint32_t* queue, uint32_t* sink, hipStream_t st);
 hipError_t launch_scan_selftest(bool dpp, const uint32_t* in, uint32_t* out, hipStream_t st);

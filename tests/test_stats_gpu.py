@@ -322,3 +322,17 @@ def test_stats_a_line_role_counts_on_hostile_reads(gaps, min_range, monkeypatch)
     assert oracle.is_strict_4line_fastq(data)
     check_parity(data, True, {"All": True, "GapLetters": gaps})
     check_parity(data[:-1], True, {"All": True, "GapLetters": gaps})  # no final newline
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stats_a_line_roles_equal_the_dense_path(seed, monkeypatch):
+    """Two unrelated device implementations of FASTQ `stats -a` -- line roles on the sparse path (default) and running
+    counters on the dense path (BSK_STATS_A=dense) -- must give the same map, and the oracle's."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", str([256, 4096, 65536, 1 << 20][seed]))
+    rng = random.Random(40 + seed)
+    data = seqgen.random_fastq(rng, 4000, 0, [40, 300, 3000, 150][seed], final_newline=seed % 2 == 0, trailing_blank=seed % 3)
+    opts = {"All": True, "GapLetters": ["- .", "N-", "-", "ACGT"][seed]}
+    roles = gpu_map(data, True, opts)
+    monkeypatch.setenv("BSK_STATS_A", "dense")
+    dense = gpu_map(data, True, opts)
+    assert roles == dense == oracle.stats_map(data, True, json.dumps(opts))
