@@ -24,6 +24,223 @@ FILE_BYTES = 100_000_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# "ops": the other BASELINE configs, measured by the same process the driver runs (N = 1).
+#   seq -n @ C2 (the 100 GB file of the stats legs), grep -s -p ACGTTGCAAGCT @ one GPU's C3 shard (12.5 GB, planted motif),
+#   translate -f 6 @ C4 (50 GB FASTA-5k CDS), rmdup -s @ one GPU's C5 shard (25 GB, 20 % duplicates).
+# Every entry: `ms` = mean wall time of `calls` whole operator calls through the C ABI after a warm-up, each one
+# HIP-synchronised (record table / selection, sizes, scan, emit -- everything the call does), `algorithmic_bytes` per
+# BASELINE.md section 4, `frac` = algorithmic bytes / ms / 8 TB/s, `kernels` = HIP-event time per call of the stages libbsk
+# brackets (bsk_profile_dump), and `exact` = the COMPLETE output compared byte for byte with an expectation computed here
+# with torch from the fixed layout of the synthetic file (no parser, no oracle).
+# ---------------------------------------------------------------------------------------------------------------------
+def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
+    ops = {}
+    calls = max(1, args.ops_calls)
+
+    def dev_bytes(ptr, n):
+        """torch uint8 view of n device bytes at ptr (libbsk's output buffer), no copy"""
+        class _Arr:  # __cuda_array_interface__ works for HIP pointers in torch-rocm
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(a, device=dev)
+
+    def timed_calls(name, fn, opts, buf, nbytes, fmt):
+        out = _lib.Out()
+        op = bsk.Operator(name, json.dumps(opts), local)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(fn(op.ctx, C.c_void_p(buf.data_ptr()), nbytes, 1, fmt, 0, st, C.byref(out)), op.ctx)  # warm-up (allocations)
+        torch.cuda.synchronize()
+        lib.bsk_profile_reset(op.ctx)
+        lib.bsk_profile_enable(op.ctx, 1)
+        times = []
+        for _ in range(calls):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            check(fn(op.ctx, C.c_void_p(buf.data_ptr()), nbytes, 1, fmt, 0, st, C.byref(out)), op.ctx)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        lib.bsk_profile_enable(op.ctx, 0)
+        pb = C.create_string_buffer(1 << 16)
+        check(lib.bsk_profile_dump(op.ctx, pb, len(pb)), op.ctx)
+        kern = {}
+        for item in pb.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.rsplit("=", 1)
+                ms, n = v.split("/")
+                kern[k] = round(float(ms) / calls, 4)
+        return op, out, sum(times) / calls, min(times), kern
+
+    def entry(cmd, workload, nrec, in_bytes, alg_bytes, out, mean_s, min_s, kern, exact, how, extra=None):
+        e = {"command": cmd, "workload": workload, "records": int(nrec), "in_bytes": int(in_bytes),
+             "out_bytes": int(out.len), "out_records": int(out.records), "calls": calls,
+             "ms": round(mean_s * 1e3, 4), "ms_min": round(min_s * 1e3, 4),
+             "M_records_per_s": round(nrec / mean_s / 1e6, 2),
+             "algorithmic_bytes": int(alg_bytes), "achieved_GBps": round(alg_bytes / mean_s / 1e9, 1),
+             "frac": round(alg_bytes / mean_s / 1e9 / HBM_PEAK_GBS, 4),
+             "kernels_ms_per_call": kern, "exact": bool(exact), "exact_how": how}
+        if extra:
+            e.update(extra)
+        return e
+
+    def rows_equal(out_t, view, mask_fn, width, rows_per_chunk=4_000_000):
+        """out_t == concat(view[i] for i with mask_fn(i0, i1)[i - i0]) ; mask None = every row; width = bytes per row"""
+        pos, ok, n = 0, True, view.shape[0]
+        for i0 in range(0, n, rows_per_chunk):
+            i1 = min(n, i0 + rows_per_chunk)
+            blk = view[i0:i1]
+            if mask_fn is not None:
+                blk = blk[mask_fn(i0, i1)]
+            k = blk.shape[0] * width
+            if pos + k > out_t.numel():
+                return False, pos
+            ok = ok and bool(torch.equal(out_t[pos:pos + k].view(-1, width), blk))
+            pos += k
+            del blk
+        return ok and pos == out_t.numel(), pos
+
+    def synth(kind, flags, want_bytes):
+        rb = lib.bsk_synth_record_bytes(kind)
+        n = int(want_bytes) // rb * rb
+        t = torch.empty(n, dtype=torch.uint8, device=dev)
+        check(lib.bsk_synth_device(kind, 42, flags, 0, C.c_void_p(t.data_ptr()), n, local, None))
+        torch.cuda.synchronize()
+        return t, n // rb
+
+    # ---- seq -n @ C2: the names of the 100 GB file -----------------------------------------------------------------
+    nbytes = total_rec * REC
+    op, out, mean_s, min_s, kern = timed_calls("SeqTransform", lib.bsk_seq_run, {"Name": True}, shard, nbytes, bsk.FORMAT_FASTQ)
+    names = dev_bytes(out.d_data, out.len)
+    view = shard.view(total_rec, REC)
+    ok = out.len == 12 * total_rec and out.records == total_rec
+    if ok:
+        ok, _ = rows_equal(names, view[:, 1:13], None, 12, 16_000_000)
+        ok = ok and bytes(names[:12].cpu().tolist()) == b"S0000000000\n" \
+            and bytes(names[-12:].cpu().tolist()) == b"S%010d\n" % (total_rec - 1)
+    ops["seq -n @ C2"] = entry("seq -n", "%.1f GB FASTQ-150 (the file of the stats legs)" % (nbytes / 1e9), total_rec, nbytes,
+                               nbytes + 12 * total_rec, out, mean_s, min_s, kern, ok,
+                               "output == columns [1, 13) of every 317-byte record (torch.equal over all %d names), "
+                               "12 x N bytes, first / last name" % total_rec)
+    del names, view
+    op.close()
+    shard.data = torch.empty(0, dtype=torch.uint8, device=dev)  # the 100 GB file is not needed any more
+    torch.cuda.empty_cache()  # libbsk allocates with hipMalloc, outside torch's pool
+
+    # ---- grep -s -p ACGTTGCAAGCT @ C3: one GPU's 12.5 GB shard of the 100 GB file, motif planted in 2 % of the reads --
+    t, nrec = synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * args.ops_scale)
+    op, out, mean_s, min_s, kern = timed_calls("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t,
+                                               t.numel(), bsk.FORMAT_FASTQ)
+    view = t.view(nrec, REC)
+    pats = [torch.tensor(list(p), dtype=torch.uint8, device=dev) for p in (b"ACGTTGCAAGCT", b"AGCTTGCAACGT")]  # + and - strand
+    planted = [0]
+
+    def hit_mask(i0, i1):
+        seqs = view[i0:i1, 13:163]
+        m = torch.zeros(i1 - i0, dtype=torch.bool, device=dev)
+        for p in pats:
+            w = seqs[:, 0:139] == p[0]
+            for j in range(1, 12):
+                w &= seqs[:, j:j + 139] == p[j]
+            m |= w.any(dim=1)
+        idx = torch.arange(i0, i1, device=dev) % 100
+        planted[0] += int(((idx == 0) | (idx == 50)).sum().item())
+        return m
+
+    got = dev_bytes(out.d_data, out.len)
+    ok, pos = rows_equal(got, view, hit_mask, REC, 2_000_000)
+    hits = pos // REC
+    ok = ok and out.records == hits and hits >= planted[0]
+    ops["grep -s -p @ C3 shard"] = entry(
+        "grep -s -p ACGTTGCAAGCT", "%.2f GB FASTQ-150, one GPU's shard of C3, motif planted on + / - strand in 2 %% of the reads"
+        % (t.numel() / 1e9), nrec, t.numel(), t.numel() + out.len, out, mean_s, min_s, kern, ok,
+        "output == the records whose bases hold the 12-mer or its reverse complement (sliding compare in torch over all "
+        "records), in file order", {"hits": int(hits), "planted": int(planted[0]), "background": int(hits - planted[0])})
+    del got, view, t
+    op.close()
+    torch.cuda.empty_cache()
+
+    # ---- translate -f 6 @ C4: 50 GB FASTA, 5 kb CDS records wrapped at 60 -------------------------------------------
+    t, nrec = synth(_lib.SYNTH_FASTA5K_CDS, 0, 50e9 * args.ops_scale)
+    RB = 5107
+    op, out, mean_s, min_s, kern = timed_calls("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, t.numel(), bsk.FORMAT_FASTA)
+    # expectation: per input record six elements (frames 1, 2, 3, -1, -2, -3), each ">" + name + "\n" + protein wrapped at 60
+    # + "\n"; table 1 (the standard code) in TCAG order
+    aa_tab = torch.tensor(list(b"FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"), dtype=torch.uint8, device=dev)
+    code = torch.zeros(256, dtype=torch.int64, device=dev)
+    comp = torch.zeros(256, dtype=torch.int64, device=dev)
+    for ch, v, cc in ((b"T", 0, b"A"), (b"C", 1, b"G"), (b"A", 2, b"T"), (b"G", 3, b"C")):
+        code[ch[0]] = v
+        comp[ch[0]] = cc[0]
+    bidx = torch.arange(5001, device=dev)
+    seq_cols = 22 + (bidx // 60) * 61 + (bidx % 60)
+    naa = [(5001 - k) // 3 for k in (0, 1, 2, 0, 1, 2)]
+    el_len = [22 + a + (a + 59) // 60 for a in naa]
+    OUT_RB = sum(el_len)
+    view = t.view(nrec, RB)
+    got = dev_bytes(out.d_data, out.len)
+    ok = out.len == OUT_RB * nrec and out.records == 6 * nrec
+    first_protein = None
+    if ok:
+        gv = got.view(nrec, OUT_RB)
+        chunk = 100_000
+        for i0 in range(0, nrec, chunk):
+            i1 = min(nrec, i0 + chunk)
+            blk = view[i0:i1]
+            seqs = blk[:, seq_cols].long()                      # (m, 5001) bases
+            rc = comp[seqs.flip(1)]                               # reverse complement
+            exp = torch.full((i1 - i0, OUT_RB), 10, dtype=torch.uint8, device=dev)   # '\n' everywhere, then fill
+            base = 0
+            for e, (src, k) in enumerate(((seqs, 0), (seqs, 1), (seqs, 2), (rc, 0), (rc, 1), (rc, 2))):
+                a = naa[e]
+                c = code[src[:, k:k + 3 * a]].view(i1 - i0, a, 3)
+                prot = aa_tab[c[:, :, 0] * 16 + c[:, :, 1] * 4 + c[:, :, 2]]
+                exp[:, base] = ord(">")
+                exp[:, base + 1:base + 22] = blk[:, 1:22]         # name + '\n'
+                j = torch.arange(a, device=dev)
+                exp[:, base + 22 + (j // 60) * 61 + (j % 60)] = prot
+                if e == 0 and first_protein is None:
+                    first_protein = bytes(prot[0].cpu().tolist())
+                base += el_len[e]
+            ok = ok and bool(torch.equal(gv[i0:i1], exp))
+            del blk, seqs, rc, exp
+        ok = ok and first_protein is not None and first_protein[:1] == b"M" and first_protein[-1:] == b"*" \
+            and len(first_protein) == 1667 and b"*" not in first_protein[:-1]
+    ops["translate -f 6 @ C4"] = entry(
+        "translate --frame 6", "%.1f GB FASTA, %d CDS records of 5 001 bases wrapped at 60 (ATG + 1 665 sense codons + TAA)"
+        % (t.numel() / 1e9, nrec), nrec, t.numel(), t.numel() + out.len, out, mean_s, min_s, kern, ok,
+        "output == six frames per record translated here with torch (standard code as a 64-entry gather, reverse strand = "
+        "flipped complement), headers and 60-column wrapping included, all records; frame 1 of record 0 is M...* of 1 667 aa")
+    del got, view, t
+    op.close()
+    torch.cuda.empty_cache()
+
+    # ---- rmdup -s @ C5: one GPU's 25 GB shard, every fifth record repeats the bases of an earlier one -------------------
+    t, nrec = synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_DUPS, 25e9 * args.ops_scale)
+    op, out, mean_s, min_s, kern = timed_calls("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, t.numel(), bsk.FORMAT_FASTQ)
+    view = t.view(nrec, REC)
+    got = dev_bytes(out.d_data, out.len)
+    keep = nrec - nrec // 5
+    ok = out.records == keep and out.len == keep * REC
+    if ok:
+        ok, _ = rows_equal(got, view, lambda i0, i1: (torch.arange(i0, i1, device=dev) % 5) != 4, REC)
+    # a second pass over the output removes nothing
+    out2 = _lib.Out()
+    with bsk.Operator("RmDup", json.dumps({"BySeq": True}), local) as op2:
+        check(lib.bsk_rmdup_run(op2.ctx, C.c_void_p(out.d_data), out.len, 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out2)), op2.ctx)
+        torch.cuda.synchronize()
+        ok = ok and out2.records == keep and out2.len == out.len
+    ops["rmdup -s @ C5 shard"] = entry(
+        "rmdup -s", "%.1f GB FASTQ-150, one GPU's shard of C5, record i with i %% 5 == 4 repeats the bases of an earlier record"
+        % (t.numel() / 1e9), nrec, t.numel(), t.numel() + 16 * nrec + out.len, out, mean_s, min_s, kern, ok,
+        "output == the records with i % 5 != 4, byte for byte in file order (N - N // 5 survivors); rmdup of the output keeps "
+        "every record", {"survivors": int(out.records)})
+    del got, view, t
+    op.close()
+    torch.cuda.empty_cache()
+    return ops
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,6 +249,10 @@ def main():
     ap.add_argument("--gb", type=float, default=FILE_BYTES / 1e9, help="size of the synthetic file (GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-ops", action="store_true", help="skip the 'ops' object (seq -n / grep / translate / rmdup at the "
+                                                           "BASELINE config sizes, N = 1 only)")
+    ap.add_argument("--ops-scale", type=float, default=1.0, help="scale the sizes of the 'ops' workloads (tests)")
+    ap.add_argument("--ops-calls", type=int, default=5, help="timed calls per operator of the 'ops' object")
     ap.add_argument("--launch-check", action="store_true",
                     help="only prove that --gpus N ranks start and reduce together (backend from BSK_BENCH_BACKEND, "
                          "default nccl; the CPU test suite runs it with gloo), print one JSON line and exit")
@@ -321,6 +542,15 @@ def main():
                 }
         except Exception as e:  # never let the extra baseline break the bench line
             out["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
+    # ---- the other BASELINE configs (N = 1): seq -n @ C2, grep @ C3 shard, translate @ C4, rmdup @ C5 shard
+    if world == 1 and not args.no_ops:
+        if total_bytes > 99e9 or args.ops_scale != 1.0:
+            try:
+                out["ops"] = run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec)
+            except Exception as e:  # the headline line must survive a failure here; the failure is reported, not hidden
+                out["ops"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        else:
+            out["ops"] = {"skipped": "the 'ops' workloads are defined at the full BASELINE sizes (--gb 100) or with --ops-scale"}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

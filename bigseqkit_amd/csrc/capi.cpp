@@ -1079,6 +1079,25 @@ int bsk_profile_read(bsk_ctx* c, const char* kernel, double* total_ms, uint64_t*
     return BSK_OK;
 }
 
+// every timed stage of the context as "name=total_ms/launches;..." (bench.py: per-kernel times of an operator call)
+int bsk_profile_dump(bsk_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || cap == 0) return BSK_ERR_INVALID_ARG;
+    double d;
+    uint64_t l;
+    int rc = bsk_profile_read(c, "", &d, &l);
+    if (rc != BSK_OK) return rc;
+    std::string out;
+    for (auto& kv : c->prof) {
+        char num[96];
+        snprintf(num, sizeof num, "=%.6f/%llu;", kv.second.ms, (unsigned long long)kv.second.launches);
+        out += kv.first;
+        out += num;
+    }
+    if (out.size() + 1 > cap) { c->set_error("libbsk: bsk_profile_dump: buffer too small"); return BSK_ERR_CAPACITY; }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return BSK_OK;
+}
+
 int bsk_profile_reset(bsk_ctx* c) {
     if (!c) return BSK_ERR_INVALID_ARG;
     double d;

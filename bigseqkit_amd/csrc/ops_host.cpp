@@ -2072,8 +2072,11 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     rc = ensure_record_scratch(c);
     c->table.n = saved_n;
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_translate_size(d_buf, c->table, tt, P, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, ne, c->d_scan_tmp, st));
+    {
+        Timed t(c, "k_translate_size+scan", st);
+        HIP_TRYX(c, launch_translate_size(d_buf, c->table, tt, P, c->d_out_len, c->d_status, st));
+        HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, ne, c->d_scan_tmp, st));
+    }
     uint64_t total = 0;
     HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + ne, sizeof total, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
@@ -2119,8 +2122,11 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             // wide kernel: a wave per record from ~3 k bases (a step of 64 lanes covers 3072), 16 lanes per record below
             // (reads: a step of 4 lanes covers 192 bases; 16 lanes per 150-base read left 12 of them idle)
             const int wide_lanes = forced == 4 || forced == 16 || forced == 64 ? forced : (avg >= 3000 ? 64 : (avg < 500 ? 4 : 16));
-            HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
-                                                c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter));
+            {
+                Timed t(c, "k_translate", st);
+                HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
+                                                    c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter));
+            }
             HIP_TRYX(c, launch_translate_long(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status,
                                               long_max, st));
         }
@@ -2212,8 +2218,11 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     if (!fastq && P.by_seq && c->flat_long_count) P.hash_long_min = c->flat_long_thresh;  // (listed by prepare_text just above)
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
-    HIP_TRYX(c, launch_rmdup_hash_long(d_buf, n, c->table, tt, P, c->d_keys, nullptr, c->d_long_list, c->flat_long_count, st));
+    {
+        Timed t(c, "k_rmdup_hash", st);
+        HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+        HIP_TRYX(c, launch_rmdup_hash_long(d_buf, n, c->table, tt, P, c->d_keys, nullptr, c->d_long_list, c->flat_long_count, st));
+    }
     // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
     // overflows, or with 2^32 records) keeps the one big table in HBM
     uint32_t* d_first = nullptr;
@@ -2234,10 +2243,13 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         uint32_t* d_vi = A.at<uint32_t>(o_vi);
         uint32_t* d_vo = A.at<uint32_t>(o_vo);
         d_first = A.at<uint32_t>(o_first);
-        HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
-        HIP_TRYX(c, launch_sort_iota(d_first, N, st));
-        HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
-        HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st));
+        {
+            Timed t(c, "rmdup_group(sort+dedupe)", st);
+            HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
+            HIP_TRYX(c, launch_sort_iota(d_first, N, st));
+            HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
+            HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st));
+        }
         uint64_t status = 0;
         HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
@@ -2247,6 +2259,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             HIP_TRYX(c, hipStreamSynchronize(st));
             by_buckets = false;
         } else {
+            Timed t(c, "k_rmdup_resolve", st);
             HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
         }
     }
@@ -2660,7 +2673,10 @@ static int seq_names_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t
     if (status) return kernel_error_to_status(c, status);
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    if (total) HIP_TRYX(c, launch_names_compact(D, c->d_range_base, nranges, c->d_out, st));
+    if (total) {
+        Timed t(c, "k_names_compact", st);
+        HIP_TRYX(c, launch_names_compact(D, c->d_range_base, nranges, c->d_out, st));
+    }
     c->table.n = 0;  // no record table was built for this shard
     out->d_data = c->d_out;
     out->len = total;

@@ -355,6 +355,8 @@ int bsk_event_destroy(void* ev);
 int bsk_profile_enable(bsk_ctx* ctx, int on);
 int bsk_profile_read(bsk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 int bsk_profile_reset(bsk_ctx* ctx);
+/* all timed stages of the context: "name=total_ms/launches;..." (NUL-terminated) */
+int bsk_profile_dump(bsk_ctx* ctx, char* buf, size_t cap);
 
 /* ---- device self tests used by tests/ (-m gpu) ---------------------------- */
 int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64);

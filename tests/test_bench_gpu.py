@@ -43,3 +43,22 @@ def test_bench_n_ranks_sharing_one_gpu(n):
     # (on a box with >= n GPUs the ranks get a GPU each and the collective is RCCL)
     assert d["backend"] in ("gloo", "nccl")
     assert abs(d["shard_bytes_per_rank"] * n - d["config"]["bytes"]) <= 317 * n
+
+
+def test_bench_ops_object_small():
+    """the 'ops' object of the driver-run line (seq -n @ C2, grep @ C3 shard, translate @ C4, rmdup @ C5 shard) at 1 / 50
+    of the BASELINE sizes: every entry must carry its timing, its algorithmic bytes and an exact full-output check"""
+    d = run_bench(["--gb", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ops-scale", "0.02", "--ops-calls", "2"])
+    ops = d["ops"]
+    assert "error" not in ops, ops
+    assert set(ops) == {"seq -n @ C2", "grep -s -p @ C3 shard", "translate -f 6 @ C4", "rmdup -s @ C5 shard"}
+    for name, e in ops.items():
+        assert e["exact"] is True, (name, e)
+        assert e["ms"] > 0 and e["algorithmic_bytes"] >= e["in_bytes"] and 0 < e["frac"] < 1, (name, e)
+        assert e["kernels_ms_per_call"], (name, e)
+    g = ops["grep -s -p @ C3 shard"]
+    assert g["hits"] >= g["planted"] > 0 and g["out_bytes"] == 317 * g["hits"]
+    r = ops["rmdup -s @ C5 shard"]
+    assert r["survivors"] == r["records"] - r["records"] // 5
+    t = ops["translate -f 6 @ C4"]
+    assert t["out_records"] == 6 * t["records"] and t["out_bytes"] == 10298 * t["records"]
