@@ -138,6 +138,7 @@ SIGNATURES = {
     "bsk_profile_reset": (_i, [_vp]),
     "bsk_profile_dump": (_i, [_vp, C.c_char_p, _sz]),
     "bsk_selftest_scan": (_i, [_i, _p(C.c_uint32), _p(C.c_uint32)]),
+    "bsk_selftest_rmdup_keys": (_i, [_vp, _p(_u64), _p(_u64), _sz, _p(_sz)]),
     "bsk_selftest_stream_read": (_i, [_vp, _sz, _i, _i, _p(C.c_float)]),
 }
 

@@ -241,6 +241,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_arena) hipFree(c->d_arena);
         if (c->d_long_list) hipFree(c->d_long_list);
         if (c->d_keys2) hipFree(c->d_keys2);
+        if (c->d_keys_sparse) hipFree(c->d_keys_sparse);
+        if (c->d_ovf) hipFree(c->d_ovf);
         if (c->d_own) hipFree(c->d_own);
         if (c->d_set_keys) hipFree(c->d_set_keys);
         if (c->d_set_idx) hipFree(c->d_set_idx);
@@ -975,6 +977,22 @@ int bsk_rmdup_dist_keys(bsk_ctx* c, const void* d_shard, size_t n, int format, v
         const int rcm = rmdup_dist_keys(c, (const uint8_t*)d_shard, n, format, (hipStream_t)stream, n_records);
         return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
     }
+}
+
+// tests: the two keys of every record of the shard of the last bsk_rmdup_dist_keys, in record order
+int bsk_selftest_rmdup_keys(bsk_ctx* c, uint64_t* k1, uint64_t* k2, size_t cap, size_t* n_out) {
+    int rc = dist_enter(c, "bsk_selftest_rmdup_keys");
+    if (rc != BSK_OK) return rc;
+    const size_t N = (size_t)c->table.n;
+    if (n_out) *n_out = N;
+    if (N > cap || !k1 || !k2) return fail(c, BSK_ERR_CAPACITY, "libbsk: key buffers too small");
+    if (N && (!c->d_keys || !c->d_keys2)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: no keys (call bsk_rmdup_dist_keys first)");
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (N) {
+        HIP_TRY(c, hipMemcpy(k1, c->d_keys, N * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(k2, c->d_keys2, N * 8, hipMemcpyDeviceToHost));
+    }
+    return BSK_OK;
 }
 
 int bsk_rmdup_dist_pack(bsk_ctx* c, uint64_t base_index, int world, void* d_send, uint64_t* counts, void* stream) {

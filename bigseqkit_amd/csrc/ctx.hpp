@@ -110,6 +110,10 @@ struct bsk_ctx {
     // multi-GPU rmdup: second keys, owner-side table, the shard the keys phase indexed
     uint64_t* d_keys2 = nullptr;
     uint64_t keys2_cap = 0;
+    uint64_t* d_keys_sparse = nullptr;  // k1 ++ k2 in the per-range slices of the hashing index pass (stream_rmdup.hip)
+    uint64_t keys_sparse_cap = 0;
+    uint32_t* d_ovf = nullptr;          // rmdup: records whose first-of-key disagrees in the second key (+ a counter word)
+    uint64_t ovf_cap = 0;
     uint64_t* d_own = nullptr;   // table_keys[cap] ++ table_first[cap] ++ table_k2[cap]
     uint64_t own_cap = 0;
     const uint8_t* dist_buf = nullptr;

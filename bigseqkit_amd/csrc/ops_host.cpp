@@ -33,6 +33,7 @@
 #include "ops_sort.hpp"
 #include "stream_filter.hpp"
 #include "stream_names.hpp"
+#include "stream_rmdup.hpp"
 #include "stream_stats.hpp"
 
 namespace bsk {
@@ -183,16 +184,26 @@ static int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, i
 // patterns (or only the others, with invert) -- stream_filter.hip.  BSK_ERR_FILTER_FALLBACK: the filter gave up
 // (pending-hit list full); the caller then takes the unfiltered path.
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F) {
+    return build_index_ex(c, d_buf, n, format, st, F, nullptr);
+}
+
+// hash != null (FASTQ): the same pass also leaves the two keys of every record's sequence (hash_dev.hpp) in c->d_keys /
+// c->d_keys2 (stream_rmdup.hip); hash->fold: keys of the lower-cased sequence (-i)
+int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F, const HashReq* hash) {
     const bool fastq = format == BSK_FORMAT_FASTQ;
     c->table.n = 0;
     c->avg_record_bytes = 0;
     if (n == 0) return BSK_OK;
     if (F && !fastq) { c->set_error("libbsk: the pattern filter runs on FASTQ only"); return BSK_ERR_INVALID_ARG; }
+    if (hash && (!fastq || F)) { c->set_error("libbsk: the hashing pass runs on unfiltered FASTQ only"); return BSK_ERR_INVALID_ARG; }
+    HashDev HD{nullptr, nullptr};
     auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
         if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
+        if (hash) return launch_rmdup_stream(c->use_dpp, hash->fold, blocks, d_buf, n, anchors, nranges, queue, D, HD, st);
         return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st);
     };
-    const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp) : index_max_blocks_per_cu(fastq, c->use_dpp);
+    const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp)
+                         : (hash ? rmdup_stream_max_blocks_per_cu(c->use_dpp, hash->fold) : index_max_blocks_per_cu(fastq, c->use_dpp));
     const int blocks = std::max(1, c->num_cus * per_cu);
     uint32_t nranges = 0;
     uint64_t chunk = 0;
@@ -254,8 +265,14 @@ int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             D.t = c->sparse;
             D.write = 2;
             D.sparse_cap = sparse_cap;
+            if (hash) {  // keys in the same slices: k1 ++ k2
+                rc2 = grow(c, &c->d_keys_sparse, &c->keys_sparse_cap, 2 * c->sparse.cap, 16);
+                if (rc2 != BSK_OK) return rc2;
+                HD.k1 = c->d_keys_sparse;
+                HD.k2 = c->d_keys_sparse + c->sparse.cap;
+            }
             {
-                Timed t(c, F ? "k_filter" : "k_index", st);
+                Timed t(c, F ? "k_filter" : (hash ? "k_rmdup_stream" : "k_index"), st);
                 HIP_TRYX(c, launch_pass(blocks, anchors, nranges, queue, D));
             }
             HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
@@ -279,7 +296,14 @@ int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
                 int rc3 = alloc_table(c->table, total + total / 8 + 16);
                 if (rc3 != BSK_OK) return rc3;
                 c->table.n = total;
-                if (total)
+                if (total && hash) {
+                    rc3 = grow(c, &c->d_keys, &c->keys_cap, total, total / 8 + 16);
+                    if (rc3 == BSK_OK) rc3 = grow(c, &c->d_keys2, &c->keys2_cap, total, total / 8 + 16);
+                    if (rc3 != BSK_OK) return rc3;
+                    Timed t(c, "k_rmdup_compact", st);
+                    HIP_TRYX(c, launch_rmdup_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges, c->table, HD,
+                                                     HashDev{c->d_keys, c->d_keys2}, st));
+                } else if (total)
                     HIP_TRYX(c, launch_index_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges,
                                                      c->table, st));
                 done = true;
@@ -308,6 +332,13 @@ int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
         if (rc4 != BSK_OK) return rc4;
         c->table.n = total;
         if (total == 0) return BSK_OK;
+        if (hash) {
+            rc4 = grow(c, &c->d_keys, &c->keys_cap, total, total / 8 + 16);
+            if (rc4 == BSK_OK) rc4 = grow(c, &c->d_keys2, &c->keys2_cap, total, total / 8 + 16);
+            if (rc4 != BSK_OK) return rc4;
+            HD.k1 = c->d_keys;
+            HD.k2 = c->d_keys2;
+        }
         D.t = c->table;
         D.write = 1;
         HIP_TRYX(c, launch_reset_queue(queue, st));
@@ -2192,10 +2223,78 @@ int rmdup_finish(bsk_ctx* c) {
     return write(o.s("DupNumFile"), c->dup_nums);
 }
 
+// The records dedupe left in the overflow list (ops_rmdup.hip: same XXH64 key as an earlier record, another second key):
+// groups of equal (k1, k2) among them keep their lowest record, exactly as the map of RmDupCheck.Call would
+// (rmdup.go:150-199) -- a few records per 10^4 shards, settled on the host.  BSK_ERR_FILTER_FALLBACK: the list did not fit.
+static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st) {
+    uint32_t m = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&m, c->d_ovf, sizeof m, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (m == 0) return BSK_OK;
+    if ((uint64_t)m + 1 > c->ovf_cap) return BSK_ERR_FILTER_FALLBACK;
+    uint64_t* d_kk = nullptr;
+    uint32_t* d_patch = nullptr;
+    HIP_TRYX(c, hipMalloc((void**)&d_kk, (size_t)m * 16));
+    std::vector<uint32_t> idx(m);
+    std::vector<uint64_t> kk(2 * (size_t)m);
+    int rc = BSK_OK;
+    do {
+        if (launch_gather_keys(c->d_ovf + 1, m, c->d_keys, c->d_keys2, d_kk, st) != hipSuccess ||
+            hipMemcpyAsync(idx.data(), c->d_ovf + 1, (size_t)m * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(kk.data(), d_kk, (size_t)m * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+        std::vector<uint32_t> order(m);
+        for (uint32_t j = 0; j < m; ++j) order[j] = j;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            if (kk[2 * a] != kk[2 * b]) return kk[2 * a] < kk[2 * b];
+            if (kk[2 * a + 1] != kk[2 * b + 1]) return kk[2 * a + 1] < kk[2 * b + 1];
+            return idx[a] < idx[b];
+        });
+        std::vector<uint32_t> pi, pv;  // first[pi] := pv
+        for (uint32_t j = 0; j < m;) {
+            uint32_t e = j + 1;
+            while (e < m && kk[2 * order[e]] == kk[2 * order[j]] && kk[2 * order[e] + 1] == kk[2 * order[j] + 1]) ++e;
+            for (uint32_t q = j + 1; q < e; ++q) { pi.push_back(idx[order[q]]); pv.push_back(idx[order[j]]); }
+            j = e;
+        }
+        if (pi.empty()) break;
+        const size_t pm = pi.size();
+        if (hipMalloc((void**)&d_patch, pm * 8) != hipSuccess ||
+            hipMemcpyAsync(d_patch, pi.data(), pm * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_patch + pm, pv.data(), pm * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            launch_scatter_u32(d_patch, d_patch + pm, (uint32_t)pm, d_first, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+    } while (false);
+    if (d_kk) hipFree(d_kk);
+    if (d_patch) hipFree(d_patch);
+    if (rc != BSK_OK) c->set_error("libbsk: rmdup: settling the overflow list failed on the device");
+    return rc;
+}
+
 int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
-    int rc = build_index(c, d_buf, n, format, st);
+    // `-s` on FASTQ: the index pass also hashes (stream_rmdup.hip) and the two keys decide (hash_dev.hpp); everything else
+    // (names, IDs, FASTA), BSK_RMDUP=table and BSK_RMDUP_KEYS=off take the separate hash kernel and compare the bytes
+    bool by_keys = fastq && o.b("BySeq");
+    bool verify_bytes = false;
+    uint32_t k1_bits = 64;
+    {
+        const char* e = getenv("BSK_RMDUP");
+        if (e && strcmp(e, "table") == 0) by_keys = false;
+        e = getenv("BSK_RMDUP_KEYS");
+        if (e && strcmp(e, "off") == 0) by_keys = false;
+        if (e && strcmp(e, "verify") == 0) verify_bytes = true;  // keys decide, the bytes of every duplicate are compared on top
+        e = getenv("BSK_RMDUP_K1_BITS");                         // tests: keep only the low bits of k1 (forces the overflow list)
+        if (e && atoi(e) >= 16 && atoi(e) < 64) k1_bits = (uint32_t)atoi(e);
+    }
+    int rc;
+    if (by_keys) {
+        const HashReq hq{o.b("IgnoreCase")};
+        rc = build_index_ex(c, d_buf, n, format, st, nullptr, &hq);
+    } else {
+        rc = build_index(c, d_buf, n, format, st);
+    }
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     TextTableH tt;
@@ -2215,13 +2314,15 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     uint64_t* tk = nullptr;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
-    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
-    if (rc != BSK_OK) return rc;
-    if (!fastq && P.by_seq && c->flat_long_count) P.hash_long_min = c->flat_long_thresh;  // (listed by prepare_text just above)
-    {
+    if (!by_keys) {
+        rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        if (!fastq && P.by_seq && c->flat_long_count) P.hash_long_min = c->flat_long_thresh;  // (listed by prepare_text just above)
         Timed t(c, "k_rmdup_hash", st);
         HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
         HIP_TRYX(c, launch_rmdup_hash_long(d_buf, n, c->table, tt, P, c->d_keys, nullptr, c->d_long_list, c->flat_long_count, st));
+    } else if (k1_bits < 64) {
+        HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << k1_bits) - 1ull, st));
     }
     // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
     // overflows, or with 2^32 records) keeps the one big table in HBM
@@ -2243,12 +2344,21 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         uint32_t* d_vi = A.at<uint32_t>(o_vi);
         uint32_t* d_vo = A.at<uint32_t>(o_vo);
         d_first = A.at<uint32_t>(o_first);
+        uint32_t ovf_cap = 0;
+        if (by_keys) {
+            const uint64_t want = std::max<uint64_t>(4096, N / 16) + 1;
+            rc = grow(c, &c->d_ovf, &c->ovf_cap, want, 16);
+            if (rc != BSK_OK) return rc;
+            ovf_cap = (uint32_t)std::min<uint64_t>(c->ovf_cap - 1, 0xFFFFFFFFull);
+            HIP_TRYX(c, hipMemsetAsync(c->d_ovf, 0, sizeof(uint32_t), st));
+        }
         {
             Timed t(c, "rmdup_group(sort+dedupe)", st);
             HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
             HIP_TRYX(c, launch_sort_iota(d_first, N, st));
             HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
-            HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st));
+            HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
+                                             by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap));
         }
         uint64_t status = 0;
         HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
@@ -2258,12 +2368,27 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
             HIP_TRYX(c, hipStreamSynchronize(st));
             by_buckets = false;
+        } else if (by_keys) {
+            rc = rmdup_settle_overflow(c, d_first, st);
+            if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;  // (the list did not fit: the table path compares bytes)
+            else if (rc != BSK_OK) return rc;
+            else if (verify_bytes) {
+                Timed t(c, "k_rmdup_resolve", st);
+                HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
+            } else {
+                Timed t(c, "k_rmdup_sizes", st);
+                HIP_TRYX(c, launch_rmdup_sizes(c->table, P, d_first, c->d_out_len, st));
+            }
         } else {
             Timed t(c, "k_rmdup_resolve", st);
             HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
         }
     }
     if (!by_buckets) {
+        if (by_keys && k1_bits < 64) {
+            c->set_error("libbsk: BSK_RMDUP_K1_BITS is a test switch of the key path; the table path needs whole keys");
+            return BSK_ERR_INVALID_ARG;
+        }
         rc = key_table(c, N, &cap, &tk, st);
         if (rc != BSK_OK) return rc;
         HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
@@ -2385,7 +2510,11 @@ int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         c->set_error("libbsk: -d / -D side files are not available on the multi-GPU rmdup path");
         return BSK_ERR_UNSUPPORTED;
     }
-    int rc = build_index(c, d_buf, n, format, st);
+    // `-s` on FASTQ: both keys come out of the index pass (stream_rmdup.hip); every rank computes the same two functions
+    // whichever kernel it takes (hash_dev.hpp)
+    const bool fused = format == BSK_FORMAT_FASTQ && c->opts.b("BySeq") && !(getenv("BSK_RMDUP_KEYS") && strcmp(getenv("BSK_RMDUP_KEYS"), "off") == 0);
+    const HashReq hq{c->opts.b("IgnoreCase")};
+    int rc = fused ? build_index_ex(c, d_buf, n, format, st, nullptr, &hq) : build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
     c->dist_buf = d_buf;
     c->dist_n = n;
@@ -2404,7 +2533,7 @@ int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     if (rc != BSK_OK) return rc;
     rc = grow(c, &c->d_keys2, &c->keys2_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
+    if (!fused) HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
     return kernel_error_to_status(c, status);

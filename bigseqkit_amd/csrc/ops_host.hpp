@@ -16,6 +16,9 @@ constexpr int BSK_ERR_MULTILINE_FASTQ = -1001;
 bool fastq_head_multiline(const uint8_t* h, size_t hb);
 int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out);
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
+// the record table and, with hash != null (unfiltered FASTQ), the two keys of every record's sequence in c->d_keys / c->d_keys2
+struct HashReq { bool fold; };
+int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F, const HashReq* hash);
 void validate_seq_opts(bsk_ctx* c);
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_grep_opts(bsk_ctx* c);

@@ -15,6 +15,7 @@
 
 #include <cstdint>
 
+#include "hash_dev.hpp"
 #include "ops_rmdup.hpp"
 #include "text_dev.hpp"
 
@@ -57,11 +58,7 @@ __device__ __forceinline__ Subject subject_of(const uint8_t* buf, const RecordTa
     return s;
 }
 
-constexpr uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull,
-                   P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
-__device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) { return rotl64(acc + in * P2, 31) * P1; }
-__device__ __forceinline__ uint64_t xmerge(uint64_t acc, uint64_t v) { return (acc ^ xround(0, v)) * P1 + P4; }
+using namespace hashdev;  // XXH64 primitives and the second key k2 (hash_dev.hpp)
 
 __device__ __forceinline__ uint64_t word64(const Subject& s, uint32_t i) {
     if (s.seq ? (s.T.W == 0 && !s.fold) : !s.fold) {
@@ -139,13 +136,34 @@ __device__ uint64_t xxh64_subject(const Subject& s, uint64_t seed = 0) {
     return h;
 }
 
+// the second key (hash_dev.hpp), one lane per subject
+template <class S, class W64>
+__device__ __forceinline__ uint64_t k2_serial(const S& s, uint32_t len, W64 word64_of) {
+    uint64_t b0 = k2_init(0), b1 = k2_init(1), b2 = k2_init(2), b3 = k2_init(3);
+    uint32_t p = 0;
+    for (; p + 32 <= len; p += 32) {
+        b0 = k2_step(b0, word64_of(p), Q0);
+        b1 = k2_step(b1, word64_of(p + 8), Q1);
+        b2 = k2_step(b2, word64_of(p + 16), Q2);
+        b3 = k2_step(b3, word64_of(p + 24), Q3);
+    }
+    if (p + 8 <= len) { b0 = k2_step(b0, word64_of(p), Q0); p += 8; }
+    if (p + 8 <= len) { b1 = k2_step(b1, word64_of(p), Q1); p += 8; }
+    if (p + 8 <= len) { b2 = k2_step(b2, word64_of(p), Q2); p += 8; }
+    uint64_t rest = 0;
+    for (uint32_t k = 0; p + k < len; ++k) rest |= (uint64_t)s.at(p + k) << (8 * k);
+    return k2_finish(b0, b1, b2, b3, rest, len);
+}
+__device__ uint64_t k2_subject(const Subject& s) {
+    return k2_serial(s, s.len, [&](uint32_t i) { return word64(s, i); });
+}
+
 // ---------------------------------------------------------------------------
 // Short subjects (reads, IDs): one lane per record reading its own subject 8 bytes at a time touches 64 different
 // cache lines per load instruction.  Instead the wave first copies the 64 subjects into LDS with 16-byte loads that
 // are contiguous inside a record (16 lanes per record, 4 records per step), then every lane hashes its subject from
 // LDS.  Slots are 164 bytes apart (41 dwords, odd: the 64 lanes hit 64 different banks).
 // ---------------------------------------------------------------------------
-constexpr uint64_t SEED2 = 0x9E3779B97F4A7C15ull;  // seed of the second key (multi-GPU verification)
 constexpr uint32_t STAGE_MAX = 160;   // longest subject staged
 constexpr uint32_t STAGE_STRIDE = 164;
 
@@ -199,6 +217,10 @@ __device__ uint64_t xxh64_lds(const LdsSubject& s, uint64_t seed) {
     while (p < len) { h ^= (uint64_t)s.at(p) * P5; h = rotl64(h, 11) * P1; ++p; }
     h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
     return h;
+}
+
+__device__ uint64_t k2_lds(const LdsSubject& s) {
+    return k2_serial(s, s.len, [&](uint32_t i) { return s.word64(i); });
 }
 
 // copy the subjects of the wave's 64 records into `slot` (64 x STAGE_STRIDE bytes of LDS); false = not applicable
@@ -270,10 +292,10 @@ __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ 
     if (stage_subjects(s, live, buf + buf_n, slot, tt.lin, tt.lin ? tt.lin + tt.lin_n : nullptr)) {
         LdsSubject ls{slot + (threadIdx.x & 63u) * STAGE_STRIDE, s.len, s.fold};
         k1 = xxh64_lds(ls, 0);
-        if (keys2) k2 = xxh64_lds(ls, SEED2);
+        if (keys2) k2 = k2_lds(ls);
     } else {
         k1 = xxh64_subject(s, 0);
-        if (keys2) k2 = xxh64_subject(s, SEED2);
+        if (keys2) k2 = k2_subject(s);
     }
     if (live) {
         keys[i] = k1;
@@ -289,10 +311,6 @@ __global__ __launch_bounds__(256) void k_rmdup_hash(const uint8_t* __restrict__ 
 // last stripes, tail) with the scalar code.
 // ---------------------------------------------------------------------------
 constexpr uint32_t HCH = 4096;
-__device__ __forceinline__ uint32_t fold4(uint32_t x) {  // lower8 on four bytes
-    const uint32_t ge_a = (x & 0x7F7F7F7Fu) + 0x3F3F3F3Fu, ge_z1 = (x & 0x7F7F7F7Fu) + 0x25252525u;
-    return x | ((ge_a & ~ge_z1 & ~x & 0x80808080u) >> 2);
-}
 __global__ __launch_bounds__(64) void k_rmdup_hash_long(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                         RmDupParams P, uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
                                                         const uint32_t* __restrict__ long_list) {
@@ -303,8 +321,10 @@ __global__ __launch_bounds__(64) void k_rmdup_hash_long(const uint8_t* __restric
     if (!hash_by_wave(s, P)) return;  // (k_rmdup_hash took it)
     const uint8_t* p = s.T.p;
     const uint32_t k = lane & 3u;
-    const uint64_t seed = lane < 4u ? 0ull : SEED2;
-    uint64_t v = k == 0 ? seed + P1 + P2 : (k == 1 ? seed + P2 : (k == 2 ? seed : seed - P1));
+    const uint64_t seed = 0ull;
+    // lanes 0..3: the XXH64 accumulators; lanes 4..7: the four chains of the second key (hash_dev.hpp)
+    uint64_t v = lane >= 4u ? k2_init(k) : (k == 0 ? seed + P1 + P2 : (k == 1 ? seed + P2 : (k == 2 ? seed : seed - P1)));
+    const uint64_t qk = k2_q(k);
     const uint32_t nfull = s.len / HCH;
     uint4 r[4];
     auto load = [&](uint32_t c) {
@@ -328,16 +348,30 @@ __global__ __launch_bounds__(64) void k_rmdup_hash_long(const uint8_t* __restric
         if (lane < 8u) {
             const uint64_t* w = reinterpret_cast<const uint64_t*>(s_buf[c & 1u]) + k;
 #pragma unroll 8
-            for (uint32_t st = 0; st < HCH / 32u; ++st) v = xround(v, w[st * 4u]);
+            for (uint32_t st = 0; st < HCH / 32u; ++st) v = lane < 4u ? xround(v, w[st * 4u]) : k2_step(v, w[st * 4u], qk);
         }
         __syncthreads();
         if (c + 1 < nfull) store((c + 1) & 1u);
     }
     const uint64_t a1 = __shfl(v, 0), a2 = __shfl(v, 1), a3 = __shfl(v, 2), a4 = __shfl(v, 3);
-    const uint64_t b1 = __shfl(v, 4), b2 = __shfl(v, 5), b3 = __shfl(v, 6), b4 = __shfl(v, 7);
+    uint64_t b1 = __shfl(v, 4), b2 = __shfl(v, 5), b3 = __shfl(v, 6), b4 = __shfl(v, 7);
     if (lane == 0) {
         keys[i] = xxh64_from(s, 0, a1, a2, a3, a4, nfull * HCH);
-        if (keys2) keys2[i] = xxh64_from(s, SEED2, b1, b2, b3, b4, nfull * HCH);
+        if (keys2) {
+            uint32_t q = nfull * HCH;
+            for (; q + 32 <= s.len; q += 32) {
+                b1 = k2_step(b1, word64(s, q), Q0);
+                b2 = k2_step(b2, word64(s, q + 8), Q1);
+                b3 = k2_step(b3, word64(s, q + 16), Q2);
+                b4 = k2_step(b4, word64(s, q + 24), Q3);
+            }
+            if (q + 8 <= s.len) { b1 = k2_step(b1, word64(s, q), Q0); q += 8; }
+            if (q + 8 <= s.len) { b2 = k2_step(b2, word64(s, q), Q1); q += 8; }
+            if (q + 8 <= s.len) { b3 = k2_step(b3, word64(s, q), Q2); q += 8; }
+            uint64_t rest = 0;
+            for (uint32_t k8 = 0; q + k8 < s.len; ++k8) rest |= (uint64_t)s.at(q + k8) << (8 * k8);
+            keys2[i] = k2_finish(b1, b2, b3, b4, rest, s.len);
+        }
     }
 }
 
@@ -619,9 +653,14 @@ __global__ __launch_bounds__(256) void k_bucket_starts(const uint64_t* __restric
     bstart[b] = (uint32_t)lo;
 }
 
+// k2 != null: a record whose key is in the table is a duplicate of the table's record only if their SECOND keys agree too
+// (hash_dev.hpp); the few that do not (two subjects under one XXH64 value: ~ N^2 / 2^65 per shard) are listed in ovf and
+// settled by the host (rmdup_settle_overflow).  k2 == null: first[] names the lowest record of the key, the caller compares
+// the bytes (k_rmdup_resolve_first).
 __global__ __launch_bounds__(256) void k_bucket_dedupe(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ sidx,
                                                        const uint32_t* __restrict__ bstart, uint32_t* __restrict__ first,
-                                                       uint64_t* __restrict__ status) {
+                                                       uint64_t* __restrict__ status, const uint64_t* __restrict__ k2,
+                                                       uint32_t* __restrict__ ovf, uint32_t ovf_cap) {
     __shared__ unsigned long long s_key[BUCKET_SLOTS];
     __shared__ uint32_t s_first[BUCKET_SLOTS];
     __shared__ uint32_t s_used;
@@ -655,8 +694,37 @@ __global__ __launch_bounds__(256) void k_bucket_dedupe(const uint64_t* __restric
         uint32_t s = (uint32_t)(((k >> BUCKET_BITS) * 0x9E3779B97F4A7C15ull) >> 40) & MASK;
         while (s_key[s] != k) s = (s + 1) & MASK;
         const uint32_t f = s_first[s];
-        if (f != idx) first[idx] = f;
+        if (f != idx) {
+            if (!k2 || k2[idx] == k2[f]) first[idx] = f;
+            else {
+                const uint32_t at = atomicAdd(&ovf[0], 1u);  // (rare: no aggregation)
+                if (at < ovf_cap) ovf[1u + at] = idx;
+            }
+        }
     }
+}
+
+// out_len from first[] without looking at the text (the keys decided): a record survives iff it is the first of its group
+__global__ __launch_bounds__(256) void k_rmdup_sizes(RecordTable t, RmDupParams P, const uint32_t* __restrict__ first_of,
+                                                     uint32_t* __restrict__ out_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t lh = t.l_head[i];
+    out_len[i] = first_of[i] == (uint32_t)i ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_gather_keys(const uint32_t* __restrict__ list, uint32_t m, const uint64_t* __restrict__ k1,
+                                                     const uint64_t* __restrict__ k2, uint64_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t i = list[j];
+    out[2 * j] = k1[i];
+    out[2 * j + 1] = k2[i];
+}
+__global__ __launch_bounds__(256) void k_scatter_u32(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, uint32_t m,
+                                                     uint32_t* __restrict__ dst) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) dst[idx[j]] = val[j];
 }
 
 // RV lanes per record (measured at C5: 1 -> 29.6, 2 -> 28.9, 4 -> 30.2, 8 -> 31.8 ms for the whole rmdup): a duplicate (one
@@ -820,11 +888,39 @@ hipError_t launch_rmdup_apply(const RecordTable& t, const RmDupParams& P, const 
 namespace bsk {
 
 hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
-                                uint64_t* status, hipStream_t st) {
+                                uint64_t* status, hipStream_t st, const uint64_t* k2, uint32_t* ovf, uint32_t ovf_cap) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = (1u << BUCKET_BITS);
     hipLaunchKernelGGL(k_bucket_starts, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, skeys, n, bstart);
-    hipLaunchKernelGGL(k_bucket_dedupe, dim3(nb), dim3(256), 0, st, skeys, sidx, bstart, first, status);
+    hipLaunchKernelGGL(k_bucket_dedupe, dim3(nb), dim3(256), 0, st, skeys, sidx, bstart, first, status, k2, ovf, ovf_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmdup_sizes(const RecordTable& t, const RmDupParams& P, const uint32_t* first, uint32_t* out_len, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rmdup_sizes, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, t, P, first, out_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_keys(const uint32_t* list, uint32_t m, const uint64_t* k1, const uint64_t* k2, uint64_t* out, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_keys, dim3((m + 255) / 256), dim3(256), 0, st, list, m, k1, k2, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_mask_keys(uint64_t* __restrict__ k, uint64_t n, uint64_t mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) k[i] &= mask;
+}
+hipError_t launch_mask_keys(uint64_t* keys, uint64_t n, uint64_t mask, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mask_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_u32(const uint32_t* idx, const uint32_t* val, uint32_t m, uint32_t* dst, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_u32, dim3((m + 255) / 256), dim3(256), 0, st, idx, val, m, dst);
     return hipGetLastError();
 }
 

@@ -45,8 +45,18 @@ hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, 
 
 // grouping by radix buckets: skeys / sidx = the (key, record) pairs sorted by the low 16 key bits (launch_sort_pairs_bits),
 // bstart: scratch [65 537]; first[] must hold iota and receives, for every duplicate, the lowest record with its key
+// k2 != null (second keys by record): a duplicate must agree with the first record of its key in k2 as well; the records
+// that do not are listed in ovf[1..] (ovf[0] = their number, zeroed by the caller; entries beyond ovf_cap are dropped)
 hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
-                                uint64_t* status, hipStream_t st);
+                                uint64_t* status, hipStream_t st, const uint64_t* k2 = nullptr, uint32_t* ovf = nullptr,
+                                uint32_t ovf_cap = 0);
+// out_len[i] = formatted size of record i if first[i] == i, else 0 (the keys decided; no text is read)
+hipError_t launch_rmdup_sizes(const RecordTable& t, const RmDupParams& P, const uint32_t* first, uint32_t* out_len, hipStream_t st);
+// out[2 j], out[2 j + 1] = k1, k2 of record list[j];  dst[idx[j]] = val[j]
+hipError_t launch_gather_keys(const uint32_t* list, uint32_t m, const uint64_t* k1, const uint64_t* k2, uint64_t* out, hipStream_t st);
+// tests: keys[i] &= mask (forces distinct subjects under one key)
+hipError_t launch_mask_keys(uint64_t* keys, uint64_t n, uint64_t mask, hipStream_t st);
+hipError_t launch_scatter_u32(const uint32_t* idx, const uint32_t* val, uint32_t m, uint32_t* dst, hipStream_t st);
 // out_len from first[] (a duplicate is byte-compared with its survivor); keys_group != null: also keys_group[i] := first[i]
 // and has_dup[first] := 1 (the -d / -D side outputs)
 hipError_t launch_rmdup_resolve_first(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const RmDupParams& P,

@@ -360,6 +360,9 @@ int bsk_profile_dump(bsk_ctx* ctx, char* buf, size_t cap);
 
 /* ---- device self tests used by tests/ (-m gpu) ---------------------------- */
 int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64);
+/* the two 64-bit keys (XXH64 seed 0, and the second key of csrc/hash_dev.hpp) of every record of the shard of the last
+ * bsk_rmdup_dist_keys call, in record order */
+int bsk_selftest_rmdup_keys(bsk_ctx* ctx, uint64_t* k1, uint64_t* k2, size_t cap, size_t* n_out);
 /* streaming read of d_buf[0..n) with k_stats' tile/queue pattern and no per-byte work:
  * the read ceiling of that pattern and the FETCH_SIZE calibration run */
 int bsk_selftest_stream_read(const void* d_buf, size_t n, int reps, int blocks_per_cu, float* avg_ms);

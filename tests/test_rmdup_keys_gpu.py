@@ -1,0 +1,160 @@
+"""The two 64-bit keys behind `rmdup` (csrc/hash_dev.hpp): k1 must be XXH64(seed 0) of the subject -- the reference's
+grouping key, int64(xxhash.Sum64(subject)) (/root/reference/bigseqkit-lib/rmdup.go:67-84), held here to python-xxhash -- and
+k2 the second hash, restated below.  Both come from the fused index + hash pass (stream_rmdup.hip: `-s` on FASTQ) and from
+the per-record kernels (ops_rmdup.hip: names, IDs, FASTA, BSK_RMDUP_KEYS=off); the two must agree with each other and with
+the Python side, whatever the tile / range / quad a sequence falls into.  Then the paths that only a key collision
+reaches: BSK_RMDUP_K1_BITS keeps a few bits of k1, so that distinct sequences share a key and the overflow list decides."""
+import ctypes as C
+import json
+import random
+
+import pytest
+
+import bigseqkit_amd as bsk
+from bigseqkit_amd import _lib
+from bigseqkit_amd._lib import lib, check
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+Q = [0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0xD6E8FEB86659FD93]
+QF1, QF2, QF3 = 0x9FB21C651E98DF25, 0xFF51AFD7ED558CCD, 0xC4CEB9FE1A85EC53
+
+
+def rotl(x, r):
+    return ((x << r) | (x >> (64 - r))) & M64
+
+
+def k2_py(s):
+    b = [Q[(k + 1) & 3] for k in range(4)]
+    nw = len(s) // 8
+    for j in range(nw):
+        w = int.from_bytes(s[8 * j:8 * j + 8], "little")
+        k = j & 3
+        b[k] = rotl(((b[k] ^ w) * Q[k]) & M64, 31)
+    rest = int.from_bytes(s[8 * nw:], "little")
+    t = b[0] ^ rotl(b[1], 16) ^ rotl(b[2], 32) ^ rotl(b[3], 48)
+    t = ((t ^ rest) * QF1) & M64
+    t ^= t >> 32
+    t = ((t + len(s)) * QF2) & M64
+    t ^= t >> 29
+    t = (t * QF3) & M64
+    t ^= t >> 32
+    return t
+
+
+def device_keys(data, fastq, opts, monkeypatch=None, env=None):
+    import torch
+    if env and monkeypatch:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    with bsk.Operator("RmDup", json.dumps(opts), 0) as op:
+        n = C.c_uint64()
+        check(lib.bsk_rmdup_dist_keys(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA,
+                                      None, C.byref(n)), op.ctx)
+        k1 = (C.c_uint64 * max(1, n.value))()
+        k2 = (C.c_uint64 * max(1, n.value))()
+        got = C.c_size_t()
+        check(lib.bsk_selftest_rmdup_keys(op.ctx, k1, k2, n.value, C.byref(got)), op.ctx)
+        assert got.value == n.value
+        return list(k1)[:n.value], list(k2)[:n.value]
+
+
+def fastq_of(seqs, rng):
+    out = []
+    for i, s in enumerate(seqs):
+        q = bytes(rng.choice(b"#$%&'()*+,-./0123456789:;<=>?@ABCDEFGHI") for _ in s)
+        out.append(b"@r%d some text\n%s\n+\n%s\n" % (i, s, q))
+    return b"".join(out)
+
+
+def rand_seq(rng, n, alphabet=b"ACGTacgtN"):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+@pytest.mark.parametrize("seed,lens", [(1, list(range(0, 200))), (2, [150] * 600), (3, [31, 32, 33, 63, 64, 65, 95, 96, 127, 128, 129] * 20),
+                                       (4, [500, 511, 512, 513, 600, 1000, 4000, 4096, 5000, 9000, 20000])])
+@pytest.mark.parametrize("fold", [False, True])
+def test_fused_keys_are_xxh64_and_k2(seed, lens, fold, monkeypatch):
+    xxhash = pytest.importorskip("xxhash")
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(seed)
+    seqs = [rand_seq(rng, n) for n in lens]
+    rng.shuffle(seqs)
+    data = fastq_of(seqs, rng)
+    opts = {"BySeq": True, "IgnoreCase": fold}
+    k1, k2 = device_keys(data, True, opts)
+    assert len(k1) == len(seqs)
+    for i, s in enumerate(seqs):
+        subj = s.lower() if fold else s
+        assert k1[i] == xxhash.xxh64(subj).intdigest(), (i, len(s))
+        assert k1[i] == oracle.xxh64(subj)
+        assert k2[i] == k2_py(subj), (i, len(s))
+    # the per-record kernels compute the same two functions
+    monkeypatch.setenv("BSK_RMDUP_KEYS", "off")
+    j1, j2 = device_keys(data, True, opts)
+    assert j1 == k1 and j2 == k2
+
+
+@pytest.mark.parametrize("opts", [{"ByName": True}, {}, {"ByName": True, "IgnoreCase": True}])
+def test_name_and_id_keys(opts):
+    xxhash = pytest.importorskip("xxhash")
+    rng = random.Random(7)
+    seqs = [rand_seq(rng, rng.randint(1, 80)) for _ in range(300)]
+    data = fastq_of(seqs, rng)
+    k1, k2 = device_keys(data, True, opts)
+    for i in range(len(seqs)):
+        subj = (b"r%d some text" % i) if opts.get("ByName") else (b"r%d" % i)
+        if opts.get("IgnoreCase"):
+            subj = subj.lower()
+        assert k1[i] == xxhash.xxh64(subj).intdigest() and k2[i] == k2_py(subj)
+
+
+def test_fasta_sequence_keys_wrapped_and_long(monkeypatch):
+    xxhash = pytest.importorskip("xxhash")
+    monkeypatch.setenv("BSK_LONG_BYTES", "3000")
+    rng = random.Random(11)
+    seqs = [rand_seq(rng, n) for n in (0, 1, 59, 60, 61, 150, 1000, 2999, 3000, 5000, 20000, 70000)]
+    data = b"".join(b">s%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, len(s), 60)) for i, s in enumerate(seqs))
+    k1, k2 = device_keys(data, False, {"BySeq": True})
+    for i, s in enumerate(seqs):
+        assert k1[i] == xxhash.xxh64(s).intdigest() and k2[i] == k2_py(s), (i, len(s))
+
+
+def run_rmdup(data, opts):
+    return bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTQ, [data]), type("O", (), {"to_json": lambda self: json.dumps(opts)})())
+
+
+@pytest.mark.parametrize("bits", [16, 18, 24])
+@pytest.mark.parametrize("fold", [False, True])
+def test_distinct_sequences_under_one_key_are_kept_apart(bits, fold, monkeypatch):
+    """With 16..24 bits of k1 nearly every record shares its key with an unrelated earlier one: the second key must keep
+    them apart, the overflow list must still find the real duplicates among them -- the output is the oracle's."""
+    rng = random.Random(100 + bits)
+    uniq = [rand_seq(rng, rng.choice((36, 150, 151, 250))) for _ in range(1500)]
+    seqs = uniq + [rng.choice(uniq) for _ in range(700)] + [rng.choice(uniq).lower() for _ in range(100)]
+    rng.shuffle(seqs)
+    data = fastq_of(seqs, rng)
+    opts = {"BySeq": True, "IgnoreCase": fold}
+    want = oracle.rmdup(data, True, json.dumps(opts))
+    assert run_rmdup(data, opts) == want
+    monkeypatch.setenv("BSK_RMDUP_K1_BITS", str(bits))
+    assert run_rmdup(data, opts) == want
+    monkeypatch.setenv("BSK_RMDUP_KEYS", "verify")  # ... and the byte comparison of every duplicate agrees
+    assert run_rmdup(data, opts) == want
+
+
+def test_key_path_equals_byte_path_on_c5_layout(monkeypatch):
+    import torch
+    rb, nrec = 317, 400_000
+    t = torch.empty(rb * nrec, dtype=torch.uint8, device="cuda")
+    assert lib.bsk_synth_device(0, 42, _lib.SYNTH_FLAG_DUPS, 0, C.c_void_p(t.data_ptr()), rb * nrec, 0, None) == 0
+    data = bytes(t.cpu().numpy().tobytes())
+    a = run_rmdup(data, {"BySeq": True})
+    assert len(a) == rb * (nrec - nrec // 5)
+    monkeypatch.setenv("BSK_RMDUP_KEYS", "off")
+    assert run_rmdup(data, {"BySeq": True}) == a
+    monkeypatch.setenv("BSK_RMDUP_KEYS", "verify")
+    assert run_rmdup(data, {"BySeq": True}) == a
