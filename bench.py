@@ -347,7 +347,7 @@ def main():
         vec = torch.zeros(vlen, dtype=torch.int64, device=dev)
         return op, vec
 
-    reduce_s = [0.0]
+    reduce_ev = [] if world > 1 else None  # (start, stop) HIP events around the all-reduce of every timed step
 
     def one_step(op, vec):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -356,15 +356,22 @@ def main():
         check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nbytes, 1, bsk.FORMAT_FASTQ, rank,
                                 C.c_void_p(vec.data_ptr()), st), op.ctx)
         if world > 1:
-            # StatsReduce (bigseqkit/stats.go:91): ONE sum all-reduce of the dense map over RCCL -- the only collective.
-            # Timed on its own (host clock around a synchronised collective; includes the wait for the slowest rank).
-            torch.cuda.synchronize()
-            t_r = time.perf_counter()
-            bdist.all_reduce_stats_vector(vec)
-            bdist.exchange_stats_overflow(op, vec)  # lengths >= 65536 of the other ranks (none for 150 bp reads)
-            torch.cuda.synchronize()
-            reduce_s[0] += time.perf_counter() - t_r
-        m = bsk.api._collect_map(op, C.c_void_p(vec.data_ptr()))
+            # StatsReduce (bigseqkit/stats.go:91): ONE sum all-reduce of the dense map over RCCL -- the only collective --
+            # and the collect behind it (the step's one synchronising copy; the overflow lists of chromosome-sized
+            # records are exchanged only when the reduced vector counts any: never for reads).  HIP events on the stream
+            # bracket the all-reduce (device time of the collective incl. the wait for the slowest rank), read after the
+            # timed region.
+            if reduce_ev is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                bdist.all_reduce_stats_vector(vec)
+                ev[1].record()
+                reduce_ev.append(ev)
+                m = bdist.collect_reduced(op, vec, reduce=False)
+            else:
+                m = bdist.collect_reduced(op, vec)
+        else:
+            m = bsk.api._collect_map(op, C.c_void_p(vec.data_ptr()))
         info = bsk.api._finalize(op, m)
         buf = C.create_string_buffer(4096)
         check(lib.bsk_stats_string(op.ctx, b"input0", b"N/A", C.byref(info), buf, len(buf)), op.ctx)
@@ -376,38 +383,45 @@ def main():
         lib.bsk_profile_reset(op.ctx)
         lib.bsk_profile_enable(op.ctx, 1)
         if world > 1:
-            dist.barrier()
+            bdist.barrier()
         torch.cuda.synchronize()
-        reduce_s[0] = 0.0
+        if reduce_ev is not None:
+            del reduce_ev[:]
         t0 = time.perf_counter()
         for _ in range(steps):
             m, text = one_step(op, vec)
         torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0          # this rank's K steps (before it waits for the others)
         if world > 1:
-            dist.barrier()
+            bdist.barrier()
         dt = time.perf_counter() - t0
         lib.bsk_profile_enable(op.ctx, 0)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=bdist.coll_device(dev))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
         ms, n = C.c_double(), C.c_uint64()
         lib.bsk_profile_read(op.ctx, b"k_stats", C.byref(ms), C.byref(n))
         k_ms = ms.value / max(1, n.value)
         lib.bsk_profile_read(op.ctx, b"k_prep", C.byref(ms), C.byref(n))
         p_ms = ms.value / max(1, n.value)
-        return dt, m, text, k_ms, p_ms
+        r_ms = sum(a.elapsed_time(b) for a, b in reduce_ev) / max(1, len(reduce_ev)) if reduce_ev else 0.0
+        ranks = None
+        if world > 1:
+            dt = bdist.all_reduce_max_float(dt, dev)
+            # what every rank saw: explains a step time that is not 1 / N of the single-GPU one
+            rows = bdist.all_gather_floats([k_ms, p_ms, r_ms, t_own / steps * 1e3], dev)
+            ranks = {"k_stats_ms": [round(r[0], 4) for r in rows], "k_prep_ms": [round(r[1], 4) for r in rows],
+                     "allreduce_ms": [round(r[2], 4) for r in rows], "own_ms_per_step": [round(r[3], 4) for r in rows]}
+            own = ranks["own_ms_per_step"]
+            ranks["barrier_skew_ms_per_step"] = round(max(own) - min(own), 4)
+        return dt, m, text, k_ms, p_ms, r_ms, ranks
 
     op, vec = make_op(False)
-    dt, m, text, k_ms, p_ms = timed(op, vec, args.steps, args.warmup)
-    reduce_ms = reduce_s[0] / args.steps * 1e3
+    dt, m, text, k_ms, p_ms, reduce_ms, per_rank = timed(op, vec, args.steps, args.warmup)
     want_row = "input0\tN/A\tDNA\t%d\t%d\t150\t150.0\t150" % (total_rec, total_rec * 150)
     verified = (m.get(150) == total_rec) and text.splitlines()[1] == want_row
     op.close()
 
     # secondary line: stats -a (Q20/Q30/gap counters on top), same timing recipe
     op, vec = make_op(True)
-    dta, ma, texta, ka_ms, _ = timed(op, vec, max(3, args.steps // 2), 1)
+    dta, ma, texta, ka_ms, _, _, _ = timed(op, vec, max(3, args.steps // 2), 1)
     stepsa = max(3, args.steps // 2)
     op.close()
     # exact expectation for -a, computed WITHOUT the parser: FASTQ-150 records are 317 bytes with the quality string at
@@ -421,9 +435,7 @@ def main():
         q30 += int((q >= 33 + 30).sum().item())
         del q
     if world > 1:
-        t = torch.tensor([q20, q30], dtype=torch.int64, device=bdist.coll_device(dev))
-        dist.all_reduce(t)
-        q20, q30 = int(t[0].item()), int(t[1].item())
+        q20, q30 = bdist.all_reduce_count(q20, dev), bdist.all_reduce_count(q30, dev)
     verified_a = (ma.get(150) == total_rec and ma.get(-3) == 0 and ma.get(-1) == q20 and ma.get(-2) == q30
                   and sum(v for k, v in ma.items() if k >= 0) == total_rec)
 
@@ -466,7 +478,8 @@ def main():
         "bit_exact_vs_expected_row": bool(verified),
         "shard_bytes_per_rank": nbytes,
         "allreduce_ms_per_step": round(reduce_ms, 4) if world > 1 else None,
-        "backend": (backend if world > 1 else None),
+        "backend": (dist.get_backend() if world > 1 else None),
+        "per_rank": per_rank,
         "shared_gpu_functional_check": bool(share),
         "roofline": {
             "bound": "hbm",

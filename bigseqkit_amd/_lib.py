@@ -42,7 +42,7 @@ _preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 BSK_OK, BSK_ERR_INVALID_ARG, BSK_ERR_OPTS, BSK_ERR_FORMAT, BSK_ERR_UNSUPPORTED, BSK_ERR_HIP, \
-    BSK_ERR_NO_DEVICE, BSK_ERR_CAPACITY = range(8)
+    BSK_ERR_NO_DEVICE, BSK_ERR_CAPACITY, BSK_ERR_OVERFLOW_EXCHANGE = range(9)
 FORMAT_FASTA, FORMAT_FASTQ = 0, 1
 STATS_HDR = 8
 SYNTH_FASTQ150, SYNTH_FASTA1K, SYNTH_FASTA5K_CDS = 0, 1, 2
@@ -79,6 +79,7 @@ SIGNATURES = {
     "bsk_stats_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _vp]),
     "bsk_stats_reset": (_i, [_vp, _vp]),
     "bsk_stats_collect": (_i, [_vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
+    "bsk_stats_overflow_total": (_i, [_vp, _p(_u64)]),
     "bsk_stats_overflow_get": (_i, [_vp, _p(_u64), _sz, _p(_sz)]),
     "bsk_stats_overflow_add": (_i, [_vp, _p(_u64), _sz]),
     "bsk_stats_collect_host": (_i, [_vp, _p(_u64), _sz, _vp, _sz, _i, _p(_i64), _p(_i64), _sz, _p(_sz)]),

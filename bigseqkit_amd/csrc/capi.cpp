@@ -572,13 +572,20 @@ int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* val
     }
     // v[5] counts the lengths >= hist_cap that went into this vector (it is summed by the all-reduce); the list itself
     // is per context.  A vector reduced over ranks whose lists were not exchanged would silently lose those records.
+    c->last_overflow_total = v[5];
     if (v[5] != ov.size())
-        return fail(c, BSK_ERR_INVALID_ARG,
+        return fail(c, BSK_ERR_OVERFLOW_EXCHANGE,
                     "libbsk: the stats vector counts " + std::to_string(v[5]) + " sequence lengths >= " +
                         std::to_string(c->hist_cap) + " but this context holds " + std::to_string(ov.size()) +
                         ": exchange the overflow lists of the other shards (bsk_stats_overflow_get / _add) before "
                         "collecting, and reset the context together with a caller-owned vector (bsk_stats_reset)");
     return stats_vector_to_map(c, v, ov, keys, vals, cap, n_out);
+}
+
+int bsk_stats_overflow_total(const bsk_ctx* c, uint64_t* total) {
+    if (!c || c->op != Op::Stats || !total) return fail(const_cast<bsk_ctx*>(c), BSK_ERR_INVALID_ARG, "libbsk: bad argument");
+    *total = c->last_overflow_total;
+    return BSK_OK;
 }
 
 int bsk_stats_overflow_get(bsk_ctx* c, uint64_t* lens, size_t cap, size_t* n_out) {

@@ -47,6 +47,7 @@ struct bsk_ctx {
     std::vector<uint8_t> first_bytes;  // head of the lowest-pid shard (type guess, Take(1))
     int64_t first_pid = INT64_MAX;
     int first_format = -1;
+    uint64_t last_overflow_total = 0;  // slot [5] of the vector the last bsk_stats_collect read (bsk_stats_overflow_total)
     std::string type_if_F;  // alphabet name the driver would guess from Take(1) (bigseqkit/stats.go:117-129)
 
     // ---- record table + per-record scratch (seq, grep, ...) ---------------------

@@ -252,7 +252,7 @@ struct RmdupSink {
 };
 
 #ifndef BSK_RMSTREAM_WAVES
-#define BSK_RMSTREAM_WAVES 5
+#define BSK_RMSTREAM_WAVES 4  // 4: 96 -> 128 VGPRs, no spills: 9.0 ms per 25 GB against 9.7 at 5 (scripts/r03_var.sh); the pass is bound by its instructions
 #endif
 #if BSK_RMSTREAM_WAVES
 #define BSK_RMSTREAM_ATTR __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES, 8)))

@@ -27,55 +27,98 @@ def shard_bounds(data, world, fmt):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def coll_device(device):
+def coll_device(device, group=None):
     """The device a collective's tensors must live on: the rank's GPU under RCCL ("nccl"), the host under gloo (CPU
     tests; two ranks sharing one GPU in bench.py's functional check)."""
     import torch
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_backend() == "gloo":
+    if dist.is_initialized() and dist.get_backend(group) == "gloo":
         return torch.device("cpu")
-    return device
+    return torch.device(device)
 
 
-def all_reduce_stats_vector(vec):
+# ---- the only places where this module hands tensors to torch.distributed -------------------------------------------
+# RCCL moves device memory and nothing else: a host tensor that reaches an "nccl" collective is an error that shows up
+# as a hang or a crash on the first multi-GPU node.  Every collective below goes through _checked(), which refuses
+# (ValueError) any tensor that does not live where the backend needs it -- the GPU under nccl, the host under gloo --
+# BEFORE the call, so that the mistake is a test failure on one box, not a dead rank on eight.
+def _checked(tensors, group=None):
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    for t in tensors:
+        on_host = t.device.type == "cpu"
+        if backend == "nccl" and on_host:
+            raise ValueError("bigseqkit_amd.dist: a host tensor was handed to an RCCL collective (backend nccl); "
+                             "build it on coll_device(<rank's GPU>)")
+        if backend == "gloo" and not on_host:
+            raise ValueError("bigseqkit_amd.dist: a %s tensor was handed to a gloo collective; stage it through "
+                             "coll_device()" % t.device.type)
+    return tensors
+
+
+def _all_reduce(t, op=None, group=None):
+    import torch.distributed as dist
+    _checked([t], group)
+    dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def _all_gather(parts, t, group=None):
+    import torch.distributed as dist
+    _checked(list(parts) + [t], group)
+    dist.all_gather(parts, t, group=group)
+    return parts
+
+
+def barrier(group=None):
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+
+
+def all_reduce_stats_vector(vec, group=None):
     """StatsReduce across ranks: ONE sum all-reduce of the stats vector (int64 tensor on the
     rank's device).  512 KB at hist_cap = 65536: latency-bound, not bandwidth-bound."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        cd = coll_device(vec.device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        cd = coll_device(vec.device, group)
         if cd != vec.device:  # gloo: through the host
             tmp = vec.to(cd)
-            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            _all_reduce(tmp, group=group)
             vec.copy_(tmp)
         else:
-            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            _all_reduce(vec, group=group)
     return vec
 
 
-def exchange_stats_overflow(op, vec, group=None):
+def exchange_stats_overflow(op, vec, group=None, total=None):
     """After the all-reduce, slot [5] of the stats vector is the number of sequence lengths >= hist_cap over ALL ranks,
     but the lengths themselves sit in per-context lists (include/bsk.h).  Every rank hands its list to every other
     (one all_gather of the counts, one of the padded lists) so that bsk_stats_collect on any rank sees all of them --
-    without this a chromosome that another rank parsed would vanish from num_seqs / sum_len / N50."""
+    without this a chromosome that another rank parsed would vanish from num_seqs / sum_len / N50.
+    `total` = slot [5] as every rank already knows it (bsk_stats_overflow_total after a collect: no device round trip);
+    None reads it from the device (one synchronising copy)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return 0
-    if int(vec[5].item()) == 0:      # nothing over the dense histogram anywhere (short reads): no exchange
+    if total is None:
+        total = int(vec[5].item())
+    if int(total) == 0:              # nothing over the dense histogram anywhere (short reads): no exchange
         return 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = C.c_size_t()
     check(lib.bsk_stats_overflow_get(op.ctx, None, 0, C.byref(n)), op.ctx)
     mine = (C.c_uint64 * max(1, n.value))()
     check(lib.bsk_stats_overflow_get(op.ctx, mine, n.value, C.byref(n)), op.ctx)
-    cdev = coll_device(vec.device)
+    cdev = coll_device(vec.device, group)
     counts, _ = _all_gather_int(n.value, vec.device, group)
     width = max(counts)
     pad = torch.zeros(max(1, width), dtype=torch.int64, device=cdev)
     if n.value:
         pad[:n.value] = torch.tensor([int(x) for x in mine[:n.value]], dtype=torch.int64, device=cdev)
     parts = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    _all_gather(parts, pad, group)
     added = 0
     for r in range(world):
         if r == rank or counts[r] == 0:
@@ -87,14 +130,65 @@ def exchange_stats_overflow(op, vec, group=None):
     return added
 
 
-def all_reduce_count(count, device="cpu"):
+def collect_reduced(op, vec, group=None, reduce=True):
+    """StatsReduce + the driver's collect for one step, WITHOUT a device round trip of its own: the sum all-reduce of the
+    stats vector, then bsk_stats_collect (the one synchronising copy of the step).  The collect records slot [5] -- the
+    number of lengths >= hist_cap over all ranks, the same on every rank -- and only when it is non-zero do the ranks
+    exchange their overflow lists and collect again (chromosome-sized records; never for reads).  Returns the map."""
+    import torch.distributed as dist
+    from . import _lib
+    from .api import _collect_map
+    if reduce:  # (False: the caller has issued all_reduce_stats_vector itself, e.g. between timing events)
+        all_reduce_stats_vector(vec, group)
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    dvec = C.c_void_p(vec.data_ptr())
+    try:
+        m = _collect_map(op, dvec)
+        if not multi:
+            return m
+    except _lib.BskError as e:
+        if not (multi and e.code == _lib.BSK_ERR_OVERFLOW_EXCHANGE):
+            raise
+        m = None
+    total = C.c_uint64()
+    check(lib.bsk_stats_overflow_total(op.ctx, C.byref(total)), op.ctx)
+    if total.value == 0:
+        return m
+    exchange_stats_overflow(op, vec, group, total=total.value)   # (every rank: slot [5] is the reduced value)
+    return _collect_map(op, dvec)
+
+
+def all_reduce_count(count, device="cpu", group=None):
     """GrepReduceCount across ranks."""
     import torch
     import torch.distributed as dist
-    t = torch.tensor([int(count)], dtype=torch.int64, device=coll_device(torch.device(device)))
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = torch.tensor([int(count)], dtype=torch.int64, device=coll_device(device, group))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        _all_reduce(t, group=group)
     return int(t.item())
+
+
+def all_reduce_max_float(value, device, group=None):
+    """max over ranks of one float (bench.py: the step time is the slowest rank's)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=coll_device(device, group))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        _all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def all_gather_floats(values, device, group=None):
+    """[[values of rank 0], ..., [values of rank world-1]] (bench.py: per-rank kernel times, barrier skew)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return [[float(v) for v in values]]
+    cd = coll_device(device, group)
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=cd)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    _all_gather(parts, mine, group)
+    return [[float(x) for x in p.tolist()] for p in parts]
 
 
 # ---------------------------------------------------------------------------
@@ -182,12 +276,15 @@ def _all_to_all_single(out, inp, out_splits, in_splits, group=None):
     share a GPU)."""
     import torch
     import torch.distributed as dist
-    cd = coll_device(out.device)
+    cd = coll_device(out.device, group)
     if cd == out.device:
+        _checked([out, inp], group)
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
         return
     o = torch.empty(out.shape, dtype=out.dtype, device=cd)
-    dist.all_to_all_single(o, inp.to(cd), out_splits, in_splits, group=group)
+    i = inp.to(cd)
+    _checked([o, i], group)
+    dist.all_to_all_single(o, i, out_splits, in_splits, group=group)
     out.copy_(o)
 
 
@@ -198,10 +295,11 @@ def _all_gather_int(value, device, group=None):
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return [int(value)], 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    device = coll_device(device)
+    device = coll_device(device, group)
     parts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(parts, torch.tensor([int(value)], dtype=torch.int64, device=device), group=group)
-    return [int(p.item()) for p in parts], rank
+    _all_gather(parts, torch.tensor([int(value)], dtype=torch.int64, device=device), group)
+    # ONE device -> host copy for all counts (a .item() per part would be `world` synchronising copies under RCCL)
+    return [int(x) for x in torch.cat(parts).tolist()], rank
 
 
 class HipRangeBackend:
@@ -272,7 +370,7 @@ def store_fastx(path, payload, group=None, device=None):
     if rank == 0:
         with open(path, "wb") as f:
             f.truncate(total)
-    dist.barrier(group=group)
+    barrier(group)
     fd = os.open(path, os.O_WRONLY)
     try:
         done, view = 0, memoryview(payload)
@@ -280,5 +378,5 @@ def store_fastx(path, payload, group=None, device=None):
             done += os.pwrite(fd, view[done:], off + done)
     finally:
         os.close(fd)
-    dist.barrier(group=group)
+    barrier(group)
     return total

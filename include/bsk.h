@@ -39,6 +39,8 @@ extern "C" {
 #define BSK_ERR_HIP 5         /* HIP runtime error                                     */
 #define BSK_ERR_NO_DEVICE 6   /* no gfx950 device visible                              */
 #define BSK_ERR_CAPACITY 7    /* caller-provided output buffer too small               */
+#define BSK_ERR_OVERFLOW_EXCHANGE 8 /* bsk_stats_collect on a vector reduced over ranks: slot [5] counts more lengths >=
+                                     * hist_cap than this context's list holds -- exchange the lists, collect again */
 
 #define BSK_FORMAT_FASTA 0
 #define BSK_FORMAT_FASTQ 1
@@ -129,6 +131,13 @@ int bsk_stats_overflow_add(bsk_ctx* ctx, const uint64_t* lens, size_t n);
  * into the reference's map form, sorted by key.  Key -4 is computed from the
  * first record seen by this ctx (bigseqkit-lib/stats.go:106-114). */
 int bsk_stats_collect(bsk_ctx* ctx, const void* d_vec, int64_t* keys, int64_t* vals, size_t cap, size_t* n_out);
+/* Slot [5] of the vector the LAST bsk_stats_collect of this context read (0 before any): after an all-reduce it is the
+ * same number on every rank, so "is an exchange of the overflow lists needed" is decided by all ranks alike and WITHOUT a
+ * device round trip of its own (the collect already brought the vector to the host).  Protocol of a reduced step:
+ *   all-reduce -> collect; if the total is non-zero on a world of more than one rank: every rank exchanges its list
+ *   (bsk_stats_overflow_get / _add), then collects again.  A collect that finds fewer list entries than slot [5] counts
+ *   returns BSK_ERR_OVERFLOW_EXCHANGE (and still records the total). */
+int bsk_stats_overflow_total(const bsk_ctx* ctx, uint64_t* total);
 /* Same conversion for a stats vector that already lives in HOST memory (e.g. after a
  * reduction done elsewhere); needs no device.  first_record (may be NULL) is the text of
  * the first record of partition 0, used for the type column exactly like Take(1). */

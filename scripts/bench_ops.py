@@ -33,16 +33,31 @@ def synth(kind, flags, nbytes):
     return t, n // rb
 
 
+last_stages = {}
+
+
 def run(op_name, fn, opts, t, fmt):
     out = _lib.Out()
     with bsk.Operator(op_name, json.dumps(opts), 0) as op:
         check(fn(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, fmt, 0, None, C.byref(out)), op.ctx)  # warm-up
         torch.cuda.synchronize()
+        prof = os.environ.get("BSK_BENCH_PROFILE") == "1"   # HIP-event time of the stages libbsk brackets, per call
+        if prof:
+            lib.bsk_profile_reset(op.ctx)
+            lib.bsk_profile_enable(op.ctx, 1)
         t0 = time.perf_counter()
         for _ in range(reps):
             check(fn(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, fmt, 0, None, C.byref(out)), op.ctx)
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        last_stages.clear()
+        if prof:
+            pb = C.create_string_buffer(1 << 16)
+            check(lib.bsk_profile_dump(op.ctx, pb, len(pb)), op.ctx)
+            for item in pb.value.decode().split(";"):
+                if "=" in item:
+                    k, v = item.rsplit("=", 1)
+                    last_stages[k] = round(float(v.split("/")[0]) / reps, 3)
         return dt, out.len, out.records
 
 
@@ -53,7 +68,8 @@ def report(name, nrec, in_bytes, dt, out_len, note=""):
     alg = in_bytes + out_len
     res[name] = {"records": nrec, "in_GB": round(in_bytes / 1e9, 2), "out_GB": round(out_len / 1e9, 3),
                  "ms": round(dt * 1e3, 2), "M_records_per_s": round(nrec / dt / 1e6, 1),
-                 "algorithmic_GBps": round(alg / dt / 1e9, 1), "frac_of_8TBps": round(alg / dt / 8e12, 4), "note": note}
+                 "algorithmic_GBps": round(alg / dt / 1e9, 1), "frac_of_8TBps": round(alg / dt / 8e12, 4),
+                 "note": note + (" " + json.dumps(last_stages) if last_stages else "")}
 
 
 # C2: seq -n on 100 GB FASTQ-150

@@ -46,9 +46,7 @@ def main():
         if shard.numel():
             check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), shard.numel(), 1, fmt, rank, C.c_void_p(vec.data_ptr()), None), op.ctx)
         torch.cuda.synchronize()
-        bdist.all_reduce_stats_vector(vec)
-        bdist.exchange_stats_overflow(op, vec)
-        m = bsk.api._collect_map(op, C.c_void_p(vec.data_ptr()))
+        m = bdist.collect_reduced(op, vec)   # all-reduce + collect (+ the overflow exchange when the reduced vector asks)
         put("stats", json.dumps(sorted(m.items())).encode())
     # grep -C: one all-reduce of a count
     g = {"Pattern": ["ACG"], "BySeq": True, "Count": True}

@@ -310,3 +310,142 @@ def test_global_operators_see_several_shards_as_one():
     # and the joined text is what the oracle dedups globally: r1 appears twice, once per shard
     want = oracle.rmdup(bytes(one.shards[0]), True, json.dumps({"BySeq": True}))
     assert want.count(b"@r1") == 1
+
+
+# ---------------------------------------------------------------- the RCCL ("nccl") branches, as far as a box without GPUs can hold them
+class _FakeDist:
+    """torch.distributed with a chosen backend name and collectives that only RECORD what they were handed: what the
+    nccl branches of dist.py would give RCCL on a multi-GPU node (VERDICT r02 weak #4: that code had never run)."""
+
+    def __init__(self, backend, world=2, rank=0):
+        import torch.distributed as real
+        self.ReduceOp = real.ReduceOp
+        self.backend, self.world, self.rank = backend, world, rank
+        self.calls = []
+
+    def is_initialized(self):
+        return True
+
+    def get_backend(self, group=None):
+        return self.backend
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def all_reduce(self, t, op=None, group=None):
+        self.calls.append(("all_reduce", [t.device.type]))
+
+    def all_gather(self, parts, t, group=None):
+        self.calls.append(("all_gather", [p.device.type for p in parts] + [t.device.type]))
+        for p in parts:
+            p.copy_(t)
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None, group=None):
+        self.calls.append(("all_to_all_single", [out.device.type, inp.device.type]))
+
+    def barrier(self, group=None):
+        self.calls.append(("barrier", []))
+
+
+def test_no_host_tensor_reaches_an_rccl_collective(monkeypatch):
+    """Under backend "nccl" every tensor dist.py hands to a collective must live on the rank's GPU.  Without a GPU here:
+    (1) with host tensors every helper must REFUSE before the collective is called (ValueError, nothing recorded);
+    (2) with tensors on a non-host device (torch's "meta" device stands in for the GPU) the helpers that need no values
+    back reach the collective, and everything they hand over is on that device."""
+    import torch
+    import torch.distributed as real
+    fake = _FakeDist("nccl")
+    for name in ("is_initialized", "get_backend", "get_world_size", "get_rank", "all_reduce", "all_gather",
+                 "all_to_all_single", "barrier"):
+        monkeypatch.setattr(real, name, getattr(fake, name))
+    host = torch.zeros(16, dtype=torch.int64)
+    with pytest.raises(ValueError, match="host tensor"):
+        bdist.all_reduce_stats_vector(host)
+    with pytest.raises(ValueError, match="host tensor"):
+        bdist.all_reduce_count(3, "cpu")
+    with pytest.raises(ValueError, match="host tensor"):
+        bdist.all_reduce_max_float(1.0, "cpu")
+    with pytest.raises(ValueError, match="host tensor"):
+        bdist.all_gather_floats([1.0, 2.0], "cpu")
+    with pytest.raises(ValueError, match="host tensor"):
+        bdist._all_gather_int(5, torch.device("cpu"))
+    with pytest.raises(ValueError, match="host tensor"):
+        bdist._all_to_all_single(torch.zeros(4, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), None, None)
+    assert fake.calls == []   # nothing got through
+    # (2) device-resident tensors pass, and stay on the device all the way into the collective
+    meta = torch.device("meta")
+    bdist.all_reduce_stats_vector(torch.zeros(16, dtype=torch.int64, device=meta))
+    bdist._all_to_all_single(torch.zeros(4, dtype=torch.int64, device=meta), torch.zeros(4, dtype=torch.int64, device=meta), None, None)
+    bdist.barrier()
+    assert [c[0] for c in fake.calls] == ["all_reduce", "all_to_all_single", "barrier"]
+    assert all(d == "meta" for _, devs in fake.calls for d in devs)
+    assert bdist.coll_device("cuda:3") == torch.device("cuda", 3)
+
+
+def test_gloo_collectives_refuse_device_tensors_and_stage_through_the_host(monkeypatch):
+    import torch
+    import torch.distributed as real
+    fake = _FakeDist("gloo")
+    for name in ("is_initialized", "get_backend", "get_world_size", "get_rank", "all_reduce", "all_gather",
+                 "all_to_all_single", "barrier"):
+        monkeypatch.setattr(real, name, getattr(fake, name))
+    assert bdist.coll_device("cuda:0") == torch.device("cpu")
+    with pytest.raises(ValueError, match="gloo"):
+        bdist._checked([torch.zeros(1, device="meta")])
+    assert bdist.all_reduce_count(7, "cuda:0") == 7          # built on the host although the rank's device is a GPU
+    counts, rank = bdist._all_gather_int(5, torch.device("cuda", 0))
+    assert counts == [5, 5] and rank == 0
+    assert all(d == "cpu" for _, devs in fake.calls for d in devs)
+
+
+def test_overflow_exchange_is_decided_without_a_device_round_trip(monkeypatch):
+    """collect_reduced: the all-reduce, ONE collect, and an exchange of the overflow lists only when the collect saw a
+    non-zero slot [5] -- decided from bsk_stats_overflow_total (host state of the context), never from vec[5].item()."""
+    import torch
+    import torch.distributed as real
+    fake = _FakeDist("gloo")
+    for name in ("is_initialized", "get_backend", "get_world_size", "get_rank", "all_reduce", "all_gather",
+                 "all_to_all_single", "barrier"):
+        monkeypatch.setattr(real, name, getattr(fake, name))
+    from bigseqkit_amd import api
+    events = []
+
+    class Vec:  # a stats vector whose VALUES must not be looked at by the protocol
+        device = torch.device("cpu")
+
+        def data_ptr(self):
+            return 0
+
+        def to(self, d):
+            return torch.zeros(8, dtype=torch.int64)
+
+        def copy_(self, t):
+            return self
+
+        def __getitem__(self, i):
+            raise AssertionError("collect_reduced read the vector on its own (a synchronising device copy per step)")
+
+    class Op:
+        ctx = None
+
+    state = {"total": 0, "collects": 0}
+
+    def fake_collect(op, d_vec=None):
+        state["collects"] += 1
+        events.append("collect")
+        if state["total"] and state["collects"] == 1:
+            raise _lib.BskError(_lib.BSK_ERR_OVERFLOW_EXCHANGE, "exchange the overflow lists")
+        return {150: 7}
+
+    monkeypatch.setattr(api, "_collect_map", fake_collect)
+    monkeypatch.setattr(lib, "bsk_stats_overflow_total", lambda ctx, p: (setattr(p._obj, "value", state["total"]), 0)[1])
+    monkeypatch.setattr(bdist, "exchange_stats_overflow", lambda op, vec, group=None, total=None: events.append(("exchange", total)))
+    assert bdist.collect_reduced(Op(), Vec()) == {150: 7}
+    assert events == ["collect"]                       # reads: one collect, no exchange
+    events.clear()
+    state.update(total=3, collects=0)
+    assert bdist.collect_reduced(Op(), Vec()) == {150: 7}
+    assert events == ["collect", ("exchange", 3), "collect"]

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_ranks_on_the_gpu_box(world, tmp_path):
+def test_ranks_on_the_gpu_box(world, tmp_path, record_property):
     rng = random.Random(4200 + world)
     data = seqgen.random_fastq(rng, 3000, 0, 200)
     # plant duplicates across the future shard cuts: the same records again at the end
@@ -51,3 +51,18 @@ def test_ranks_on_the_gpu_box(world, tmp_path):
     assert cat("rmdup") == oracle.rmdup(data, True, '{"BySeq": true}')
     assert cat("range") == oracle.range_(data, True, '{"Range": "3:-3"}')
     assert (tmp_path / "merged.fq").read_bytes() == oracle.seq(data, True, '{"Reverse": true}')
+    # which collectives carried this run: RCCL when the box gave every rank a GPU, gloo through the host otherwise --
+    # written next to the test log (gpurun_out/) and into the junit properties, so that a GPUTEST record says which
+    backends = {(tmp_path / ("backend.%d" % r)).read_text() for r in range(world)}
+    assert len(backends) == 1
+    backend = backends.pop()
+    import torch
+    assert backend == ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    record_property("collective_backend", backend)
+    print("multirank world=%d backend=%s gpus=%d" % (world, backend, torch.cuda.device_count()))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "multirank_backend_world%d.json" % world), "w") as f:
+            json.dump({"world": world, "backend": backend, "gpus_visible": torch.cuda.device_count()}, f)
+    except OSError:
+        pass
