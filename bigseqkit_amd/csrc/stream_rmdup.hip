@@ -25,6 +25,7 @@
 #include "index.hpp"
 #include "stream_core_dev.hpp"
 #include "stream_rmdup.hpp"
+#include "tile_lds_dev.hpp"
 
 namespace bsk {
 
@@ -33,23 +34,7 @@ namespace {
 using namespace stream;
 using namespace hashdev;
 
-constexpr uint32_t CARRY = 512;               // bytes of the previous tile kept in front of the current one
-constexpr uint32_t TBUF = CARRY + TILE + 16;  // + 16: an 8-byte word that ends on the last tile byte is read as three dwords
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
-__device__ __forceinline__ uint4 lds_r128(uint32_t a) {
-    const u32x4 v = *(lds_u32x4*)(uintptr_t)a;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void lds_w128(uint32_t a, const uint4& v) {
-    u32x4 w;
-    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-    *(lds_u32x4*)(uintptr_t)a = w;
-}
-__device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(lds_u32*)(uintptr_t)a; }
+using namespace tilelds;
 
 // value of lane K of this lane's quad (quad_perm DPP)
 template <int K>
@@ -75,34 +60,20 @@ struct RmdupSink {
     static constexpr bool TILE_HOOK = true;
     IndexDev D;
     HashDev H;
-    uint32_t tb = 0;            // LDS byte address of this wave's text buffer (CARRY ++ tile ++ pad)
+    TileLds T;                  // this wave's tile in LDS (tile_lds_dev.hpp)
     uint64_t base = 0, limit = 0;
-    uint64_t staged = ~0ull;    // tile_idx of the tile in LDS
-    bool carry_ok = false;      // the CARRY bytes in front of it are the end of the tile before
     uint32_t err = 0;
 
     __device__ __forceinline__ void begin_range(uint64_t b, uint64_t lim) {
         base = b;
         limit = lim;
-        staged = ~0ull;
-        carry_ok = false;
+        T.reset();
     }
 
     template <class CUR>
     __device__ __forceinline__ void tile(const CUR& cur, uint64_t tile_idx, uint64_t rs, uint64_t re, const uint8_t* __restrict__ buf) {
         if (!D.write) return;  // count pass of the exact fallback: no keys
-        const uint32_t lane = threadIdx.x & 63u;
-        const bool cont = staged != ~0ull && tile_idx == staged + TILE;  // (wave-uniform)
-        if (cont) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (lane < CARRY / 16u) v = lds_r128(tb + TILE + lane * 16u);  // the last CARRY bytes of the old tile
-            if (lane < CARRY / 16u) lds_w128(tb + lane * 16u, v);
-        }
-        carry_ok = cont;
-#pragma unroll
-        for (int p = 0; p < NPIECE; ++p) lds_w128(tb + CARRY + (uint32_t)p * PIECE_BYTES + lane * 16u, cur[p]);
-        staged = tile_idx;
-        wave_lds_fence();
+        T.stage(cur, tile_idx);
     }
 
     // keys of up to 16 sequence lines, one per quad: `so` = offset of the line's first byte relative to the tile,
@@ -110,17 +81,13 @@ struct RmdupSink {
     __device__ __forceinline__ void hash_quads(int32_t so, uint32_t ln, bool vq, uint64_t tile_idx,
                                                const uint8_t* __restrict__ buf, uint64_t g) {
         const uint32_t k = threadIdx.x & 3u;
-        const bool in_lds = vq && tile_idx == staged && so >= (carry_ok ? -(int32_t)CARRY : 0);
+        const bool in_lds = vq && T.holds(tile_idx, so);
         const uint8_t* gp = buf + (int64_t)tile_idx + (int64_t)so;  // the line in global memory
-        const uint32_t la = tb + CARRY + (uint32_t)so;              // ... and in LDS
+        const uint32_t la = T.addr(so);                             // ... and in LDS
         auto ld64 = [&](uint32_t o) -> uint64_t {
             uint32_t lo, hi;
             if (in_lds) {
-                const uint32_t a = la + o;
-                const uint32_t a4 = a & ~3u;
-                const uint32_t d0 = lds_r32(a4), d1 = lds_r32(a4 + 4u), d2 = lds_r32(a4 + 8u);
-                lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
-                hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+                lds_ld64(la + o, lo, hi);
             } else {
                 uint64_t v;
                 __builtin_memcpy(&v, gp + o, 8);
@@ -273,7 +240,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_RMSTREAM_ATTR void k_rm
     RmdupSink<DPP, FOLD> sink;
     sink.D = D;
     sink.H = H;
-    sink.tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_tb[wave];
+    sink.T.tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_tb[wave];
     PredConsts P;  // unused (sparse path)
     P.k20 = P.k30 = 0;
     P.ngap = 0;

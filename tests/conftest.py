@@ -38,3 +38,12 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+# BSK_TEST_FAULTHANDLER=<seconds> (default 240 on a GPU box): dump the Python stacks of a test session that sits still
+# -- twice in round 3 the first in-process GPU test of a full run waited 9 - 13 minutes on a fresh box, with no CPU time
+# spent; the stacks on stderr say where (they do not fail anything).
+_fh = os.environ.get("BSK_TEST_FAULTHANDLER", "240" if has_gpu() else "")
+if _fh:
+    import faulthandler
+    faulthandler.dump_traceback_later(float(_fh), repeat=True, file=sys.stderr)
