@@ -267,6 +267,8 @@ void bsk_destroy(bsk_ctx* c) {
 
 const char* bsk_opts_json(const bsk_ctx* c) { return c ? c->opts_json.c_str() : ""; }
 
+const char* bsk_log_text(const bsk_ctx* c) { return c ? c->log_text.c_str() : ""; }
+
 int bsk_find_record_start(const uint8_t* buf, size_t n, size_t from, int format, size_t* out) {
     if (!buf || !out) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null argument");
     *out = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_start(buf, n, from) : (size_t)find_fasta_start(buf, n, from);

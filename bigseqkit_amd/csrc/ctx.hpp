@@ -7,6 +7,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstdint>
+#include <cstdio>
 #include <map>
 #include <mutex>
 #include <string>
@@ -212,6 +213,22 @@ struct bsk_ctx {
         std::lock_guard<std::mutex> g(mu);
         last_error = m;
     }
+
+    // ---- the reference's log.Warn / log.Info lines (bigseqkit-lib/seq.go:53-68, grep.go:66-206, locate.go:58-144,
+    // subseq.go:99-158): written to stderr as "[WARN] ..." / "[INFO] ..." and kept for bsk_log_text().  Which messages
+    // --quiet suppresses is the reference's choice, message by message (the callers pass `unless_quiet`).
+    mutable std::string log_text;
+    void log(const char* level, const std::string& m, bool unless_quiet = false) const {
+        if (unless_quiet && opts.cb("Quiet")) return;
+        const std::string line = std::string("[") + level + "] " + m + "\n";
+        {
+            std::lock_guard<std::mutex> g(mu);
+            log_text += line;
+        }
+        fputs(line.c_str(), stderr);
+    }
+    void warn(const std::string& m, bool unless_quiet = false) const { log("WARN", m, unless_quiet); }
+    void info(const std::string& m, bool unless_quiet = false) const { log("INFO", m, unless_quiet); }
 };
 
 // optional HIP-event bracket around one launch (bsk_profile_enable): read back by bsk_profile_read under `name`

@@ -408,7 +408,25 @@ void validate_seq_opts(bsk_ctx* c) {  // SeqTransform.Before, seq.go:28-79
     if (o.b("LowerCase") && o.b("UpperCase"))
         throw OptError("could not give both flags -l (--lower-case) and -u (--upper-case)");
     check_id_regexp(c);
+    // the messages of seq.go:52-69 (log.Warn always, the log.Info unless --quiet)
+    if ((o.i("MinLen") >= 0 || o.i("MaxLen") >= 0) && !o.b("RemoveGaps")) c->warn("you may switch on flag -g/--remove-gaps to remove spaces");
+    if (o.b("Complement") && (c->alphabet == AB_NONE || c->alphabet == AB_PROTEIN))
+        c->warn("flag -t (--seq-type) (DNA/RNA) is recommended for computing complement sequences");
+    if (!o.b("ValidateSeq") && !(c->alphabet == AB_NONE || c->alphabet == AB_UNLIMIT))
+        c->info("when flag -t (--seq-type) given, flag -v (--validate-seq) is automatically switched on", /*unless_quiet=*/true);
 }
+
+// `\{[^\}]*$|^[^\{]*\}` (grep.go:38): an opening brace without its closing one, or the reverse -- what is left of "A{2,}"
+// when the command line cut it at the comma
+static bool has_unquoted_comma(const std::string& p) {
+    const size_t open = p.rfind('{');
+    if (open != std::string::npos && p.find('}', open) == std::string::npos) return true;
+    const size_t close = p.find('}');
+    return close != std::string::npos && p.find('{') > close;
+}
+static const char* const HELP_UNQUOTED_COMMA =
+    "possible unquoted comma detected, please use double quotation marks for patterns containing comma, e.g., -p '\"A{2,}\"' "
+    "or -p \"\\\"A{2,}\\\"\"";
 
 // sequence bytes of the first record of a shard head (type guess, helper.go:286-291)
 static std::vector<uint8_t> head_first_seq(const std::vector<uint8_t>& b, int format, size_t limit) {
@@ -756,17 +774,24 @@ void validate_grep_opts(bsk_ctx* c) {
     for (auto& p : o.sl("Pattern")) if (!p.empty()) any = true;
     // PARITY.md Q17: the default Pattern [""] must not defeat this guard (grep.go:53)
     if (!any) throw OptError("one of flags -p (--pattern) and -f (--pattern-file) needed");
+    // the log lines of Grep.Before (grep.go:57-98), in its order
+    for (auto& p : o.sl("Pattern"))
+        if (has_unquoted_comma(p)) { c->warn(HELP_UNQUOTED_COMMA); break; }
+    if (o.b("Degenerate") && !o.b("BySeq")) c->info("when flag -d (--degenerate) given, flag -s (--by-seq) is automatically on");
     if (o.b("Degenerate")) o.mut("BySeq").b = true;
     if (o.i("MaxMismatch") > 0) {
         if (o.b("UseRegexp") || o.b("Degenerate"))
             throw OptError("flag -r (--use-regexp) or -d (--degenerate) not allowed when giving flag -m (--max-mismatch)");
+        if (!o.b("BySeq")) c->info("when value of flag -m (--max-mismatch) > 0, flag -s (--by-seq) is automatically on");
         o.mut("BySeq").b = true;
+        if (o.i("MaxMismatch") > 4) c->warn("large value flag -m/--max-mismatch will slow down the search");
     }
     if (o.b("UseRegexp") && o.b("Degenerate"))
         throw OptError("could not give both flags -d (--degenerate) and -r (--use-regexp)");
     c->region_on = false;
     if (!o.s("Region").empty()) {
         c->region_on = true;
+        if (!o.b("BySeq")) c->info("when flag -R (--region) given, flag -s (--by-seq) is automatically on");
         o.mut("BySeq").b = true;
         parse_region_opt(o.s("Region"), "grep", &c->region_start, &c->region_end);
     }
@@ -779,8 +804,14 @@ void validate_grep_opts(bsk_ctx* c) {
     // grep.go:122-252: the pattern file replaces -p when given
     const std::vector<std::string> given = !o.s("PatternFile").empty() ? read_pattern_lines(o.s("PatternFile")) : o.sl("Pattern");
     std::unordered_set<std::string> seen;
+    const bool default_id_re = o.cs("IDRegexp") == "^(\\S+)\\s?" && !o.cb("IDNCBI");
     for (std::string p : given) {
         if (p.empty()) continue;
+        // grep.go:140-147, 199-207 (unless --quiet)
+        if (p[0] == '>') c->warn("symbol \">\" detected, it should not be a part of the sequence ID/name: " + p, true);
+        else if (p[0] == '@') c->warn("symbol \"@\" detected, it should not be a part of the sequence ID/name. " + p, true);
+        else if (!o.b("ByName") && default_id_re && p.find_first_of("\t ") != std::string::npos)
+            c->warn("space found in pattern, you may need use -n/--by-name: " + p, true);
         if (o.b("UseRegexp")) {  // grep.go:148-153, 211-225: "(?i)" + p with -i, then regexp.Compile
             if (o.b("IgnoreCase")) p = "(?i)" + p;
             if (!seen.insert(p).second) continue;
@@ -807,6 +838,11 @@ void validate_grep_opts(bsk_ctx* c) {
         if (!seen.insert(p).second) continue;
         if (c->general) c->pattern_cls.push_back(class_sets(p, false, false, o.b("IgnoreCase")));
         c->patterns.push_back(p);
+    }
+    if (!o.s("PatternFile").empty()) {  // grep.go:191-197 (unless --quiet; a warning when the file held none)
+        const size_t np = o.b("UseRegexp") ? c->regexes.size() : c->patterns.size();
+        const std::string m = std::to_string(np) + " patterns loaded from file";
+        if (np == 0) c->warn(m, true); else c->info(m, true);
     }
     if (o.b("DeleteMatched") && !o.b("InvertMatch")) {  // PARITY.md DEL
         // with -m the reference takes grepBySeqMismatches (grep.go:255-365), which never deletes a pattern, and the driver
@@ -1228,9 +1264,12 @@ void validate_locate_opts(bsk_ctx* c) {
     bool any = !o.s("PatternFile").empty();
     for (auto& p : o.sl("Pattern")) if (!p.empty()) any = true;
     if (!any) throw OptError("one of flags -p (--pattern) and -f (--pattern-file) needed");  // PARITY.md Q17
+    for (auto& p : o.sl("Pattern"))  // locate.go:50-59
+        if (has_unquoted_comma(p)) { c->warn(HELP_UNQUOTED_COMMA); break; }
     if (o.i("MaxMismatch") > 0) {
         if (o.b("Degenerate")) throw OptError("flag -d (--degenerate) not allowed when giving flag -m (--max-mismatch)");
         if (o.b("UseRegexp")) throw OptError("flag -r (--use-regexp) not allowed when giving flag -m (--use-regexp)");
+        if (o.b("NonGreedy")) c->info("flag -G (--non-greedy) ignored when giving flag -m (--max-mismatch)", true);  // :68-70
     }
     if (o.b("UseFmi")) {
         if (o.b("Degenerate")) throw OptError("flag -d (--degenerate) ignored when giving flag -F (--use-fmi)");
@@ -1251,6 +1290,11 @@ void validate_locate_opts(bsk_ctx* c) {
         if (given.empty()) throw OptError("no FASTA sequences found in pattern file: " + o.s("PatternFile"));
     } else {
         for (const std::string& p : o.sl("Pattern")) if (!p.empty()) given.emplace_back(p, p);
+    }
+    // locate.go:96-98 (a pattern file: bytes.Contains(seq, "\t ") -- the two bytes in a row, as written), :143-145 (-p: any)
+    for (auto& g : given) {
+        if (from_file) { if (g.second.find("\t ") != std::string::npos) c->warn("space found in sequence: " + g.first, true); }
+        else if (g.second.find_first_of(" \t") != std::string::npos) c->warn("space found in sequence: '" + g.first + "'", true);
     }
     if (o.b("UseRegexp")) {
         // locate.go:102-121, 153-172: the regexp branch shares the search loop of -d (FindSubmatchIndex from a moving
@@ -1640,6 +1684,8 @@ static void load_features(bsk_ctx* c) {
     c->features.clear();
     c->features_uploaded = false;
     std::unordered_set<std::string> seen;
+    c->info(gtf ? "read GTF file ..." : "read BED file ...", /*unless_quiet=*/true);  // subseq.go:98-100, 131-133
+    size_t nloaded = 0;  // len(features) of the reference: every accepted line, before the per-name map keeps the first
     for (const std::string& line : read_pattern_lines(gtf ? o.s("Gtf") : o.s("Bed"))) {
         if (line.empty() || line[0] == '#') continue;
         if (!gtf && ((line.size() > 7 && line.compare(0, 7, "browser") == 0) || (line.size() > 5 && line.compare(0, 5, "track") == 0)))
@@ -1682,6 +1728,7 @@ static void load_features(bsk_ctx* c) {
                 strand = items[5];
             }
         }
+        ++nloaded;
         const std::string key = lower_str(items[0]);
         if (!seen.insert(key).second) continue;  // a later feature of the same name is never reached
         bsk_ctx::Feature f;
@@ -1697,6 +1744,7 @@ static void load_features(bsk_ctx* c) {
         f.suffix = "_" + std::to_string(st) + "-" + std::to_string(en) + ":" + strand + flank + " " + label;
         c->features.push_back(f);
     }
+    c->info(std::to_string(nloaded) + (gtf ? " GTF" : " BED") + " features loaded", true);  // subseq.go:127-129, 157-159
 }
 
 // ---------------------------------------------------------------------------

@@ -72,6 +72,11 @@ void bsk_destroy(bsk_ctx* ctx); /* == After() */
 /* canonical JSON of the options after defaults (the text the reference's
  * executor would see); returned pointer lives as long as ctx */
 const char* bsk_opts_json(const bsk_ctx* ctx);
+/* The reference's log.Warn / log.Info lines of this context so far ("[WARN] ...\n[INFO] ...\n"; they are also written
+ * to stderr as they occur): option advice of Before() -- bigseqkit-lib/seq.go:52-69, grep.go:57-98, 140-207,
+ * locate.go:50-70, 96-98, 143-145, subseq.go:98-100, 127-133, 157-159.  Config.Quiet suppresses exactly the messages the
+ * reference guards with it. */
+const char* bsk_log_text(const bsk_ctx* ctx);
 
 /* ---- record boundaries: PlainFile(path, delim) + ReadFixer ---------------
  * bigseqkit/helper.go:148-178, bigseqkit-lib/helper.go:41-66.
