@@ -206,6 +206,7 @@ void bsk_destroy(bsk_ctx* c) {
         hipSetDevice(c->device);
         hipDeviceSynchronize();
         for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+        bsk::store_drainer_free(c);
         if (c->d_anchors) hipFree(c->d_anchors);
         if (c->d_rng) hipFree(c->d_rng);
         if (c->d_parts) hipFree(c->d_parts);

@@ -194,6 +194,7 @@ struct bsk_ctx {
     uint64_t last_count = 0;               // grep -C result of the last run
 
     // ---- staging for host-resident shards ------------------------------------
+    void* drainer = nullptr;   // pinned staging + events of the output drain (store.cpp: Drainer)
     uint8_t* pinned[2] = {nullptr, nullptr};
     uint8_t* d_stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;

@@ -51,6 +51,7 @@ int common_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, const uint64_t
                       hipStream_t st, bsk_out* out);
 int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first, int format, hipStream_t st, bsk_out* out);
 int faidx_query_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
+void store_drainer_free(bsk_ctx* c);  // store.cpp
 int ensure_out(bsk_ctx* c, uint64_t bytes);
 int ensure_record_scratch(bsk_ctx* c);
 Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc);

@@ -70,4 +70,43 @@ for path, where in targets:
     res["rows"]["translate -f 6 -> %s" % where] = {"in_GB": round(n / 1e9, 2), "out_GB": round(ob / 1e9, 3), "s": round(dt, 3),
                                                    "in_GB_per_s": round(n / dt / 1e9, 2), "in_plus_out_GB_per_s": round((n + ob) / dt / 1e9, 2)}
 lib.bsk_host_free(C.c_void_p(h))
+
+# ---- a directory of part files (StoreFASTXN, the reference's default layout) written by several contexts at once: ONE file
+# takes 6 - 10 GB/s whatever is done (scripts/experiments/write_rates.cpp), a file per writer scales
+if "--parts" in sys.argv:
+    from concurrent.futures import ThreadPoolExecutor
+    from bigseqkit_amd import dist as bdist
+    import shutil
+    h, n, nrec = pinned_copy_of(_lib.SYNTH_FASTQ150, 0, gb * 1e9)
+    rb = 317
+    for P in (1, 4, 8, 16):
+        per = nrec // P
+        bounds = [(k * per * rb, ((k + 1) * per if k + 1 < P else nrec) * rb) for k in range(P)]
+        for where, base in ([("page cache (/dev/shm)", "/dev/shm/bsk_f2f_parts")] + ([("disk (/tmp)", "/tmp/bsk_f2f_parts")] if disk else [])):
+            best = None
+            for rep in range(2):
+                shutil.rmtree(base, ignore_errors=True)
+                s = C.c_void_p()
+                assert lib.bsk_store_open(base.encode(), 0, C.byref(s)) == 0
+                ops = [bsk.Operator("SeqTransform", json.dumps({"Reverse": True, "Complement": True, "Config": {"SeqType": "dna", "Quiet": True}}), 0) for _ in range(P)]
+
+                def work(k):
+                    lo, hi = bounds[k]
+                    nb, nr = C.c_uint64(), C.c_uint64()
+                    check(lib.bsk_run_to_store(ops[k].ctx, C.c_void_p(h + lo), hi - lo, 1, k, s, k, C.byref(nb), C.byref(nr)), ops[k].ctx)
+                    return nb.value
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(P) as ex:
+                    outb = sum(ex.map(work, range(P)))
+                dt = time.perf_counter() - t0
+                tot = C.c_uint64()
+                assert lib.bsk_store_close(s, C.byref(tot)) == 0 and tot.value == outb
+                for o in ops:
+                    o.close()
+                best = dt if best is None else min(best, dt)
+            shutil.rmtree(base, ignore_errors=True)
+            res["rows"]["seq -r -p, %d partitions -> %d part files at once -> %s" % (P, P, where)] = {
+                "in_GB": round(n / 1e9, 2), "out_GB": round(outb / 1e9, 2), "s": round(best, 3),
+                "in_GB_per_s": round(n / best / 1e9, 2), "in_plus_out_GB_per_s": round((n + outb) / best / 1e9, 2)}
+    lib.bsk_host_free(C.c_void_p(h))
 print(json.dumps(res, indent=1))
