@@ -78,6 +78,18 @@ __device__ __forceinline__ uint64_t find_byte(const uint8_t* __restrict__ buf, u
     return n;
 }
 
+// first line start in [from, limit), else ANCHOR_NONE: the search of ONE nominal chunk (k_prep, FASTA) -- a chromosome on
+// one line spans hundreds of chunks, and every boundary inside it searching to the line's end made k_prep the slowest
+// kernel of every FASTA command (390 ms per 250 MB line: one wave walks the whole line)
+__device__ __forceinline__ uint64_t find_line_start_within(const uint8_t* buf, uint64_t n, uint64_t from, uint64_t limit) {
+    if (from == 0) return 0;
+    if (from >= n) return n;
+    const uint64_t stop = limit < n ? limit : n;   // a line start below `stop` follows a newline below stop - 1
+    if (stop <= from) return ANCHOR_NONE;
+    const uint64_t j = find_byte(buf, stop - 1, from - 1, '\n');
+    return j < stop - 1 ? j + 1 : ANCHOR_NONE;
+}
+
 __device__ __forceinline__ uint64_t find_line_start(const uint8_t* buf, uint64_t n, uint64_t from) {
     if (from == 0) return 0;
     if (from >= n) return n;

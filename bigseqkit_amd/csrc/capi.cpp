@@ -67,8 +67,8 @@ int ensure_ranges(bsk_ctx* c, uint32_t nranges) {
     if (nranges <= c->cap_ranges && c->d_anchors) return BSK_OK;
     if (c->d_anchors) HIP_TRY(c, hipFree(c->d_anchors));
     c->d_anchors = nullptr;
-    // anchors[nranges + 1] followed by the queue word
-    HIP_TRY(c, hipMalloc((void**)&c->d_anchors, ((size_t)nranges + 2) * sizeof(uint64_t)));
+    // anchors[nranges + 1] followed by the queue word, then k_prep's raw anchors [nranges + 1] (FASTA)
+    HIP_TRY(c, hipMalloc((void**)&c->d_anchors, 2 * ((size_t)nranges + 2) * sizeof(uint64_t)));
     c->cap_ranges = nranges;
     return BSK_OK;
 }
@@ -357,11 +357,15 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     }
     {
         Timed t(c, "k_prep", st);
-        HIP_TRY(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st, /*line_mode=*/!fastq));
+        HIP_TRY(c, launch_prep(fastq, d_buf, n, chunk, nranges, anchors, queue, st, /*line_mode=*/!fastq,
+                               /*raw=*/fastq ? nullptr : c->d_anchors + (size_t)nranges + 2));
     }
     {
         Timed t(c, "k_stats", st);
-        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, c->stats_a_dense));
+        // FASTA: a line longer than a chunk is not read between its own chunk and its last tile; with `-a` the gap letters
+        // of the chunks it covers are counted by those chunks' (otherwise empty) ranges
+        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, c->stats_a_dense,
+                                !fastq ? chunk : 0));
     }
     if (!fastq) HIP_TRY(c, launch_stats_stitch(nranges, D, st));
     return BSK_OK;

@@ -53,8 +53,10 @@ struct IndexDev {
     uint64_t sparse_cap;         // mode 2: slots reserved per range (range r writes at r * sparse_cap)
 };
 
+// skip_chunk (FASTA, anchors from launch_prep with `raw`): the nominal chunk size -- the newline-free middle of a line
+// longer than a chunk is not read; 0: every byte
 hipError_t launch_index(bool fastq, bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
-                        uint32_t nranges, uint32_t* queue, const IndexDev& D, hipStream_t st);
+                        uint32_t nranges, uint32_t* queue, const IndexDev& D, hipStream_t st, uint64_t skip_chunk = 0);
 int index_max_blocks_per_cu(bool fastq, bool dpp);
 // exclusive scan of u64 counts (n <= a few 10^4; one block): out[0..n], out[n] = total
 hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st);

@@ -168,13 +168,14 @@ static int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, i
         if (c->d_range_count) HIP_TRYX(c, hipFree(c->d_range_count));
         if (c->d_range_base) HIP_TRYX(c, hipFree(c->d_range_base));
         c->d_anchors = nullptr; c->d_range_count = nullptr; c->d_range_base = nullptr;
-        HIP_TRYX(c, hipMalloc((void**)&c->d_anchors, ((size_t)nranges + 2) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_anchors, 2 * ((size_t)nranges + 2) * sizeof(uint64_t)));  // (+ k_prep's raw anchors)
         HIP_TRYX(c, hipMalloc((void**)&c->d_range_count, ((size_t)nranges + 1) * sizeof(uint64_t)));
         HIP_TRYX(c, hipMalloc((void**)&c->d_range_base, ((size_t)nranges + 2) * sizeof(uint64_t)));
         c->cap_ranges = nranges;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
-    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, c->d_anchors, queue, st, /*line_mode=*/!fastq));
+    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, c->d_anchors, queue, st, /*line_mode=*/!fastq,
+                            /*raw=*/fastq ? nullptr : c->d_anchors + (size_t)nranges + 2));
     *nranges_out = nranges;
     *chunk_out = chunk;
     return BSK_OK;
@@ -197,16 +198,16 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     if (F && !fastq) { c->set_error("libbsk: the pattern filter runs on FASTQ only"); return BSK_ERR_INVALID_ARG; }
     if (hash && (!fastq || F)) { c->set_error("libbsk: the hashing pass runs on unfiltered FASTQ only"); return BSK_ERR_INVALID_ARG; }
     HashDev HD{nullptr, nullptr};
+    uint64_t chunk = 0;  // nominal bytes per range (prep_ranges)
     auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
         if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
         if (hash) return launch_rmdup_stream(c->use_dpp, hash->fold, blocks, d_buf, n, anchors, nranges, queue, D, HD, st);
-        return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st);
+        return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, fastq ? 0 : chunk);
     };
     const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp)
                          : (hash ? rmdup_stream_max_blocks_per_cu(c->use_dpp, hash->fold) : index_max_blocks_per_cu(fastq, c->use_dpp));
     const int blocks = std::max(1, c->num_cus * per_cu);
     uint32_t nranges = 0;
-    uint64_t chunk = 0;
     int rcp = prep_ranges(c, d_buf, n, fastq, blocks, st, &nranges, &chunk);
     if (rcp != BSK_OK) return rcp;
     uint64_t* anchors = c->d_anchors;

@@ -904,8 +904,16 @@ __device__ __forceinline__ void load_window(const uint8_t* a, const uint8_t* buf
     }
 }
 
+#ifndef BSK_TRW_WAVES
+#define BSK_TRW_WAVES 0
+#endif
+#if BSK_TRW_WAVES
+#define BSK_TRW_ATTR __attribute__((amdgpu_waves_per_eu(BSK_TRW_WAVES, 8)))
+#else
+#define BSK_TRW_ATTR
+#endif
 template <int G>
-__global__ __launch_bounds__(256) void k_translate_wide(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+__global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                         TranslateParams P, const uint32_t* __restrict__ out_len,
                                                         const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                         uint8_t* __restrict__ redo, uint64_t* __restrict__ redo_count,

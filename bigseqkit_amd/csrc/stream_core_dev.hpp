@@ -267,10 +267,17 @@ __device__ __forceinline__ uint32_t popc4(uint32_t a, uint32_t b, uint32_t c, ui
 //       previous HISTORY events.
 // returns the number of lines (newline events) in the range
 // ---------------------------------------------------------------------------
+//   skip_from (FASTA, sparse path): the caller knows that [skip_from - 1, re - 1) holds no newline -- the nominal chunks
+//       behind the range's own one in which k_prep found no line start (a chromosome on one line).  Tiles that begin at
+//       or after skip_from are not read, except the last one (it holds the line's newline at re - 1): what the events
+//       need of a line is where it ends, not what is in it.  ~0: read everything.
+//   count_resume (FASTA -a, dense path): the gap letters of the 16-byte pieces in [skip_from, count_resume) are NOT counted
+//       here -- those bytes belong to nominal chunks without a line start, whose own (otherwise empty) ranges count them
+//       (k_stats) and k_stats_stitch adds them when the long line is a sequence line.
 template <bool FASTQ, bool ALL, bool DPP, class Sink>
 __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8_t* __restrict__ buf, uint64_t n,
                                                  uint64_t rs, uint64_t re, bool is_last, const PredConsts& P,
-                                                 Sink& sink) {
+                                                 Sink& sink, uint64_t skip_from = ~0ull, uint64_t count_resume = 0) {
     const int lane = threadIdx.x & 63;
     constexpr bool ROLES = FASTQ && !ALL && sink_role_counts<Sink>::value;
     // virtual events before the range: a newline at relative position -1
@@ -296,6 +303,10 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
     uint32_t k_ctl;
     asm volatile("s_mov_b32 %0, 0x20202020" : "=s"(k_ctl));
 #endif
+    if constexpr (!FASTQ) {
+        // positions are 32-bit and relative to the range: a range of 2^31 bytes (one line longer than that) cannot be measured
+        if (re - rs > 0x7FFFFFFFull) sink.err |= ERR_LINE_TOO_LONG;
+    }
     uint32_t line_base = 0;                    // newlines seen so far in this range
     uint32_t run_a = 0, run_b = 0, run_c = 0;  // running counters (mod 2^32)
     uint32_t quiet_tiles = 0;                  // consecutive tiles without a newline
@@ -548,7 +559,9 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                         mb = pack_flags(ge_bytes(v.x, P.k30), ge_bytes(v.y, P.k30), ge_bytes(v.z, P.k30), ge_bytes(v.w, P.k30));
                         mc = g;
                     } else {
-                        ma = g;
+                        // (pieces of the chunks that a long line covers are counted by those chunks' ranges)
+                        const uint64_t I = tile_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16;
+                        ma = (I >= skip_from && I < count_resume) ? 0u : g;
                     }
                 }
                 if (edge) {
@@ -662,6 +675,22 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
             }
         }
         if (t + 1 < ntiles) {
+            if constexpr (!FASTQ && !BSK_PREFETCH) {
+                // the newline-free stretch of a line that is longer than the range's nominal chunk: on to its last tile
+                // (-a: the bytes from count_resume on are this range's to count -- the tile that holds them is the target)
+                uint64_t tgt = ntiles - 1;
+                if constexpr (ALL) {
+                    if (count_resume > idx0 && (count_resume - idx0) / TILE < tgt) tgt = (count_resume - idx0) / TILE;
+                }
+                if (tile_idx + TILE >= skip_from && t + 1 < tgt) {
+                    t = tgt - 1;
+                    quiet_tiles = 0;
+                    const uint64_t tgt_idx = idx0 + tgt * TILE;
+#pragma unroll
+                    for (int p = 0; p < NPIECE; ++p) cur[p] = load16(buf, n, tgt_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
+                    continue;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < NPIECE; ++p)
                 cur[p] = BSK_PREFETCH ? nxt[p]

@@ -274,7 +274,7 @@ template <bool FASTQ, bool DPP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index(const uint8_t* __restrict__ buf, uint64_t n,
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
-                                                                   IndexDev D) {
+                                                                   IndexDev D, uint64_t chunk) {
     __shared__ Lds<FASTQ, false> s_l[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -301,7 +301,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index
         if (D.write == 1) b = D.range_base[r];
         else if (D.write == 2) { b = (uint64_t)r * D.sparse_cap; lim = b + D.sparse_cap; if (lim > D.t.cap) lim = D.t.cap; }
         sink.begin_range(b, lim, rs, re, r, !FASTQ && buf[rs] != '>');
-        const uint32_t lines = stream_range<FASTQ, false, DPP>(L, buf, n, rs, re, re == n_eff, P, sink);
+        // FASTA: the newline-free middle of a line longer than the nominal chunk is not read (stream_core_dev.hpp)
+        const uint64_t skip_from = (!FASTQ && chunk) ? (uint64_t)(r + 1u) * chunk : ~0ull;
+        const uint32_t lines = stream_range<FASTQ, false, DPP>(L, buf, n, rs, re, re == n_eff, P, sink, skip_from);
         if constexpr (!FASTQ) sink.end_range();
         if (D.write != 1 && lane == 0) D.range_count[r] = FASTQ ? (uint64_t)(lines >> 2) : (uint64_t)sink.nrec;
     }
@@ -476,14 +478,14 @@ __global__ __launch_bounds__(256) void k_index_compact(RecordTable sp, uint64_t 
 }  // namespace
 
 hipError_t launch_index(bool fastq, bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
-                        uint32_t nranges, uint32_t* queue, const IndexDev& D, hipStream_t st) {
+                        uint32_t nranges, uint32_t* queue, const IndexDev& D, hipStream_t st, uint64_t skip_chunk) {
     const dim3 b(WAVES_PER_BLOCK * WAVE);
     if (fastq) {
-        if (dpp) hipLaunchKernelGGL((k_index<true, true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
-        else hipLaunchKernelGGL((k_index<true, false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+        if (dpp) hipLaunchKernelGGL((k_index<true, true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D, 0ull);
+        else hipLaunchKernelGGL((k_index<true, false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D, 0ull);
     } else {
-        if (dpp) hipLaunchKernelGGL((k_index<false, true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
-        else hipLaunchKernelGGL((k_index<false, false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+        if (dpp) hipLaunchKernelGGL((k_index<false, true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D, skip_chunk);
+        else hipLaunchKernelGGL((k_index<false, false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D, skip_chunk);
     }
     return hipGetLastError();
 }

@@ -98,13 +98,14 @@ struct StatsSinkT {
     uint32_t range_id = 0;
     bool open_is_header = false;  // open_key belongs to a header of THIS range (else: to the range start)
     bool any_event = false, last_closing = true;
+    bool last_line_hdr = false;   // FASTA: the line the last event ended is a header line
     uint32_t last_key = 0, last_a = 0;
 
     __device__ __forceinline__ void begin_range(uint32_t r) {
         open_key = 0; open_sg = 0;
         range_id = r;
         open_is_header = false;
-        any_event = false; last_closing = true;
+        any_event = false; last_closing = true; last_line_hdr = false;
         last_key = 0; last_a = 0;
     }
 
@@ -118,6 +119,9 @@ struct StatsSinkT {
             if (open_is_header) { D.r_tail[range_id] = bases; f |= RF_TAIL_OPEN; }
             else D.r_head[range_id] = bases;  // no header and no closing line: the whole range is inside one record
             if constexpr (ALL) gap += (uint32_t)(last_a - (open_is_header ? open_sg : 0u));
+        }
+        if constexpr (ALL) {
+            if (any_event && !last_line_hdr) f |= RF_SKIP_SEQ;  // (the RF_MID ranges that follow, if any, are sequence bytes)
         }
         atomicOr(&D.r_flags[range_id], f);
     }
@@ -210,6 +214,7 @@ struct StatsSinkT {
                 const uint32_t sl = HISTORY + (E - 1u);
                 last_key = L.pos[sl] - (wb + (E - 1u));
                 last_closing = L.flag[sl] != 0;
+                last_line_hdr = L.flag[sl - 1u] != 0;
                 if constexpr (ALL) last_a = L.a[sl];
                 any_event = true;
             }
@@ -238,7 +243,7 @@ template <bool FASTQ, bool ALL, bool DPP, bool ROLES_T = true>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats(const uint8_t* __restrict__ buf, uint64_t n,
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
-                                                                   StatsDev D) {
+                                                                   StatsDev D, uint64_t chunk) {
     __shared__ uint32_t s_hist[LDS_HIST + 2 * BIG_SLOTS];  // dense bins, then the (length, count) cache of add_big
     constexpr bool ROLES = FASTQ && ALL && ROLES_T;
     constexpr bool SALL = ALL && !ROLES;  // what the skeleton and the events see
@@ -263,9 +268,36 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         uint64_t rs = anchors[r], re = anchors[r + 1];
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
-        if (rs >= re) continue;
+        if (rs >= re) {
+            if constexpr (!FASTQ && ALL) {
+                // an empty range inside a long line (k_prep found no line start in its nominal chunk): `-a` counts the gap
+                // letters of the chunk here; k_stats_stitch adds them if the line is a sequence line
+                if (chunk && r > 0u) {
+                    const uint64_t lo = (uint64_t)r * chunk, hi = lo + chunk < n_eff ? lo + chunk : n_eff;
+                    if (lo < hi) {
+                        uint64_t cnt = 0;
+                        for (uint64_t i = lo + (uint64_t)lane * 16u; i < hi; i += 64u * 16u) {
+                            const uint4 v = load16(buf, hi, i);  // (bytes past hi read as 0)
+                            for (int k = 0; k < D.pred.ngap; ++k) {
+                                const uint32_t rep = D.pred.gap_rep[k];
+                                if (rep == 0u && i + 16u > hi) continue;  // (a NUL gap letter against the zero padding: never in text)
+                                cnt += popc4(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep), zero_bytes(v.z ^ rep), zero_bytes(v.w ^ rep));
+                            }
+                        }
+                        cnt = wave_sum_u64(cnt);
+                        if (lane == 0) { D.r_head[r] = cnt; atomicOr(&D.r_flags[r], RF_MID); }
+                    }
+                }
+            }
+            continue;
+        }
         sink.begin_range(r);
-        stream_range<FASTQ, SALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink);
+        // FASTA: a range that reaches beyond its nominal chunk ends with ONE long line (k_prep found no line start in the
+        // chunks it covers): the default row needs that line's end, not its bytes; `-a` leaves the gap letters of those
+        // chunks to their own ranges (above)
+        const uint64_t skip_from = (!FASTQ && chunk) ? (uint64_t)(r + 1u) * chunk : ~0ull;
+        const uint64_t count_resume = (!FASTQ && chunk) ? (re == n_eff ? re : (re / chunk) * chunk) : 0ull;
+        stream_range<FASTQ, SALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink, skip_from, count_resume);
         if constexpr (!FASTQ) sink.template end_range<ALL>();
         if constexpr (ROLES) {
             // wave totals of the range (uniform: they live in scalar registers between ranges)
@@ -320,12 +352,29 @@ __global__ __launch_bounds__(256) void k_prep(const uint8_t* __restrict__ buf, u
         return;
     }
     const uint64_t from = (uint64_t)r * chunk;
+    if (!FASTQ && line_mode == 2) {
+        // a line start inside this boundary's OWN chunk, or none: k_prep_fill gives a boundary without one the next
+        // boundary's anchor (an empty range), and the range that holds the long line skips the chunks in between
+        const uint64_t a = wave_anchor::find_line_start_within(buf, n, from, from + chunk);
+        if (lane0) anchors[r] = a;  // (ANCHOR_NONE stays until k_prep_fill)
+        return;
+    }
     const uint64_t a = FASTQ ? wave_anchor::find_fastq_start(buf, n, from, from + ANCHOR_SEARCH_BYTES)
                              : (line_mode ? wave_anchor::find_line_start(buf, n, from) : wave_anchor::find_fasta_start(buf, n, from));
     // No record start within reach (text that is not FASTQ): the range begins at the raw boundary.  The streaming pass
     // validates every line it reads, so it reports the malformed text itself -- a check of the anchors inside its range loop
     // cost k_stats two spilled registers and 1 ms at 100 GB.
     if (lane0) anchors[r] = a == ANCHOR_NONE ? from : a;
+}
+
+// FASTA: raw[r] = the line start k_prep found in chunk r, or ANCHOR_NONE -> anchors[r] = the first anchor at or after r
+// (raw[nranges] = the effective end is always one).  Runs of chunks without a line start are one long line.
+__global__ __launch_bounds__(256) void k_prep_fill(const uint64_t* __restrict__ raw, uint32_t nranges, uint64_t* __restrict__ anchors) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nranges) return;
+    uint32_t j = r;
+    while (j < nranges && raw[j] == ANCHOR_NONE) ++j;
+    anchors[r] = raw[j];
 }
 
 // Records that cross range boundaries (FASTA, line-start ranges).  A record that is open at the end of range r (its
@@ -357,6 +406,12 @@ __global__ __launch_bounds__(256) void k_stats_stitch(uint32_t nranges, StatsDev
             const uint64_t i = atomicAdd((unsigned long long*)&D.status[1], 1ull);
             if (i < D.overflow_cap) D.overflow[i] = len;
         }
+    }
+    // `-a`: the gap letters of the chunks that a long SEQUENCE line covers (counted by their own, otherwise empty, ranges)
+    if (r0 < nranges && (D.r_flags[r0] & (RF_VISITED | RF_SKIP_SEQ)) == (RF_VISITED | RF_SKIP_SEQ)) {
+        unsigned long long g = 0;
+        for (uint32_t r = r0 + 1; r < nranges && (D.r_flags[r] & RF_MID); ++r) g += D.r_head[r];
+        if (g) atomicAdd((unsigned long long*)&D.vec[2], g);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x)
@@ -407,11 +462,15 @@ __global__ void k_scan_selftest(const uint32_t* in, uint32_t* out) {
 // host launchers
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
-                       uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode) {
+                       uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode, uint64_t* raw) {
     const int threads = 256;  // four boundaries per block, a wave each
     const int blocks = (int)(((uint64_t)nranges + 1 + 3) / 4);
     if (fastq) hipLaunchKernelGGL(k_prep<true>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, 0);
-    else hipLaunchKernelGGL(k_prep<false>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, line_mode ? 1 : 0);
+    else if (line_mode && raw) {
+        // every boundary searches its own chunk only (raw), then the boundaries without a line start take the next anchor
+        hipLaunchKernelGGL(k_prep<false>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, raw, queue, 2);
+        hipLaunchKernelGGL(k_prep_fill, dim3((nranges + 1 + 255) / 256), dim3(256), 0, st, (const uint64_t*)raw, nranges, anchors);
+    } else hipLaunchKernelGGL(k_prep<false>, dim3(blocks), dim3(threads), 0, st, buf, n, chunk, nranges, anchors, queue, line_mode ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -440,21 +499,21 @@ hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t 
 
 template <bool FASTQ, bool ALL, bool ROLES_T = true>
 static hipError_t launch_stats_t(bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
-                                 uint32_t nranges, uint32_t* queue, const StatsDev& D, hipStream_t st) {
+                                 uint32_t nranges, uint32_t* queue, const StatsDev& D, hipStream_t st, uint64_t chunk) {
     const dim3 b(WAVES_PER_BLOCK * WAVE);
-    if (dpp) hipLaunchKernelGGL((k_stats<FASTQ, ALL, true, ROLES_T>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
-    else hipLaunchKernelGGL((k_stats<FASTQ, ALL, false, ROLES_T>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+    if (dpp) hipLaunchKernelGGL((k_stats<FASTQ, ALL, true, ROLES_T>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D, chunk);
+    else hipLaunchKernelGGL((k_stats<FASTQ, ALL, false, ROLES_T>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D, chunk);
     return hipGetLastError();
 }
 
 hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_t* buf, uint64_t n,
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
-                        hipStream_t st, bool a_dense) {
-    if (fastq && all && a_dense) return launch_stats_t<true, true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st);
-    if (fastq) return all ? launch_stats_t<true, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st)
-                          : launch_stats_t<true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st);
-    return all ? launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st)
-               : launch_stats_t<false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st);
+                        hipStream_t st, bool a_dense, uint64_t skip_chunk) {
+    if (fastq && all && a_dense) return launch_stats_t<true, true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0);
+    if (fastq) return all ? launch_stats_t<true, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0)
+                          : launch_stats_t<true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0);
+    return all ? launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk)
+               : launch_stats_t<false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
 }
 
 int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense) {

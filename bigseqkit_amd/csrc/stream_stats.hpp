@@ -44,16 +44,23 @@ struct StatsDev {
 };
 
 constexpr uint32_t RF_VISITED = 1u, RF_HAS_HEADER = 2u, RF_HEAD_CLOSED = 4u, RF_TAIL_OPEN = 8u;
+// `-a` and lines longer than a chunk: RF_MID = an empty range whose nominal chunk lies inside a long line; r_head holds the
+// gap letters among its bytes.  RF_SKIP_SEQ = the range's last line is a sequence line: the RF_MID ranges behind it are its
+constexpr uint32_t RF_MID = 16u, RF_SKIP_SEQ = 32u;
 
 // line_mode (FASTA only): anchors are line starts, not record starts
+// raw (FASTA line mode; [nranges + 1] scratch): every boundary searches only its own chunk for a line start and the
+// boundaries without one take the next anchor (k_prep_fill) -- a line longer than a chunk (a chromosome on one line) then
+// lies in ONE range followed by empty ones, and the streaming kernels skip its newline-free middle (skip_chunk below)
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
-                       uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode = false);
+                       uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode = false, uint64_t* raw = nullptr);
 hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st);
 // *out := one past the highest non-zero entry of hist[0, cap)
 hipError_t launch_hist_extent(const uint64_t* hist, uint32_t cap, uint64_t* out, hipStream_t st);
+// skip_chunk (FASTA default row, anchors from launch_prep with `raw`): the nominal chunk size; 0: read every byte
 hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_t* buf, uint64_t n,
                         const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const StatsDev& D,
-                        hipStream_t st, bool a_dense = false);  // a_dense: FASTQ -a on the dense path (BSK_STATS_A=dense)
+                        hipStream_t st, bool a_dense = false, uint64_t skip_chunk = 0);  // a_dense: FASTQ -a on the dense path (BSK_STATS_A=dense)
 int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense = false);
 hipError_t launch_stream_read(int blocks, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
                               uint32_t* queue, uint32_t* sink, hipStream_t st);
