@@ -75,6 +75,7 @@ SIGNATURES = {
     "bsk_destroy": (None, [_vp]),
     "bsk_opts_json": (C.c_char_p, [_vp]),
     "bsk_log_text": (C.c_char_p, [_vp]),
+    "bsk_ctx_set": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "bsk_find_record_start": (_i, [_vp, _sz, _sz, _i, _p(_sz)]),
     "bsk_stats_vector_len": (_sz, [_vp]),
     "bsk_stats_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _vp]),

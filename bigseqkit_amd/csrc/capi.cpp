@@ -73,6 +73,13 @@ int ensure_ranges(bsk_ctx* c, uint32_t nranges) {
     return BSK_OK;
 }
 
+// the switches a context caches in fields (read again after bsk_ctx_set)
+static void apply_tuning(bsk_ctx* c) {
+    c->use_dpp = !c->tune.is("scan", "shfl");
+    c->stats_a_dense = c->tune.is("stats_a", "dense");
+    c->min_range_bytes = (uint64_t)c->tune.num("min_range_bytes", (long long)MIN_RANGE_BYTES);
+}
+
 int init_device(bsk_ctx* c) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -82,12 +89,7 @@ int init_device(bsk_ctx* c) {
     hipDeviceProp_t p;
     HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
     c->num_cus = p.multiProcessorCount;
-    const char* sc = getenv("BSK_SCAN");
-    c->use_dpp = !(sc && strcmp(sc, "shfl") == 0);
-    const char* sa = getenv("BSK_STATS_A");
-    c->stats_a_dense = sa && strcmp(sa, "dense") == 0;
-    const char* mr = getenv("BSK_MIN_RANGE_BYTES");
-    c->min_range_bytes = mr && atoll(mr) > 0 ? (uint64_t)atoll(mr) : MIN_RANGE_BYTES;
+    apply_tuning(c);
     HIP_TRY(c, hipMalloc((void**)&c->d_status, 4 * sizeof(uint64_t)));  // [2]: scratch of bsk_stats_collect
     HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(uint64_t)));
     if (c->op == Op::Stats) {
@@ -150,6 +152,7 @@ int bsk_create(const char* op_name_, const char* opts_json, int device, bsk_ctx*
     if (!c) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: out of memory");
     c->op = op;
     c->device = device;
+    c->tune.load_env();  // the environment's switches become this context's defaults, once
     try {
         c->opts = Options::from_json(op, opts_json && *opts_json ? opts_json : "{}");
         c->opts_json = c->opts.to_json();
@@ -270,6 +273,17 @@ const char* bsk_opts_json(const bsk_ctx* c) { return c ? c->opts_json.c_str() : 
 
 const char* bsk_log_text(const bsk_ctx* c) { return c ? c->log_text.c_str() : ""; }
 
+int bsk_ctx_set(bsk_ctx* c, const char* key, const char* value) {
+    if (!c || !key) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bsk_ctx_set: null argument");
+    std::string k(key);
+    if (k.rfind("BSK_", 0) == 0) k = k.substr(4);
+    for (auto& ch : k) ch = (char)tolower((unsigned char)ch);
+    if (!bsk_tuning::known(k)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bsk_ctx_set: unknown switch '" + std::string(key) + "'");
+    if (value) c->tune.v[k] = value; else c->tune.v.erase(k);
+    apply_tuning(c);
+    return BSK_OK;
+}
+
 int bsk_find_record_start(const uint8_t* buf, size_t n, size_t from, int format, size_t* out) {
     if (!buf || !out) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null argument");
     *out = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_start(buf, n, from) : (size_t)find_fasta_start(buf, n, from);
@@ -297,7 +311,7 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp, c->stats_a_dense);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
-    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
+    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes, (int)c->tune.num("ranges_per_wave"));
     const uint32_t nranges = (uint32_t)nr;
     // 16-byte aligned nominal chunk so that most range starts keep tile alignment cheap
     uint64_t chunk = (n + nranges - 1) / nranges;
@@ -417,8 +431,7 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     // host-resident shard: record-aligned chunks through two device buffers; the copy of chunk i+1 (copy stream)
     // overlaps the kernels of chunk i (caller's stream).  Pinned host memory (bsk_host_alloc / hipHostMalloc /
     // hipHostRegister) makes the copies true DMA at PCIe rate; pageable memory works but is staged by the runtime.
-    const char* chunk_env = getenv("BSK_STAGE_BYTES");
-    const size_t chunk = chunk_env && strtoull(chunk_env, nullptr, 10) ? (size_t)strtoull(chunk_env, nullptr, 10) : ((size_t)256 << 20);
+    const size_t chunk = (size_t)c->tune.num("stage_bytes", (long long)256 << 20);
     const uint8_t* h = (const uint8_t*)shard;
     if (!c->copy_stream[0]) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {

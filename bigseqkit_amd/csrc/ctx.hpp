@@ -6,8 +6,10 @@
 #include <algorithm>
 #include <array>
 #include <cstdlib>
+#include <cctype>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -18,7 +20,40 @@
 #include "regex_nfa.hpp"
 #include "regex_vm.hpp"
 
+// Run-time switches of a context (which kernel variant runs, thresholds used by the tests).  Round 2 read them with
+// getenv() on the call path; now a context takes the environment's values ONCE, when it is created (BSK_<NAME>), and
+// bsk_ctx_set(ctx, "<name>", "<value>") changes them for that context only -- a cgo caller sets them per operator instead
+// of per process.  Names (lower case, without the BSK_ prefix) and meanings: INTEGRATION.md "Switches".
+struct bsk_tuning {
+    static const char* const* names() {
+        static const char* const N[] = {"filter", "grep_shiftand", "index", "locate_nopre", "long_bytes", "min_range_bytes", "names",
+                                        "names_scale", "ranges_per_wave", "rmdup", "rmdup_k1_bits", "rmdup_keys", "scan", "segcopy",
+                                        "sort", "stage_bytes", "stats_a", "text", "translate", "tr_lanes", nullptr};
+        return N;
+    }
+    std::map<std::string, std::string> v;
+    static bool known(const std::string& k) {
+        for (const char* const* n = names(); *n; ++n) if (k == *n) return true;
+        return false;
+    }
+    void load_env() {
+        for (const char* const* n = names(); *n; ++n) {
+            std::string e = "BSK_";
+            for (const char* q = *n; *q; ++q) e.push_back((char)toupper((unsigned char)*q));
+            if (const char* val = getenv(e.c_str())) v[*n] = val;
+        }
+    }
+    // the value, or null when unset (the shape of the getenv() calls it replaces)
+    const char* get(const char* k) const {
+        auto it = v.find(k);
+        return it == v.end() ? nullptr : it->second.c_str();
+    }
+    bool is(const char* k, const char* val) const { const char* e = get(k); return e && strcmp(e, val) == 0; }
+    long long num(const char* k, long long dflt = 0) const { const char* e = get(k); return e && atoll(e) > 0 ? atoll(e) : dflt; }
+};
+
 struct bsk_ctx {
+    bsk_tuning tune;
     bsk::Op op;
     bsk::Options opts;
     std::string opts_json;
@@ -256,9 +291,8 @@ struct Timed {
 // Ranges of the persistent streaming kernels (k_stats, k_index): about 512 KiB each -- measured on 3-100 GB shards,
 // ranges below ~200 KiB pay their start-up (anchor, LDS window, validation) and fewer than ~4 ranges per wave leave a
 // tail: 100 GB 17.7 -> 17.1 ms with 16 ranges per wave instead of 4, small shards unchanged (scripts/sweep_ranges.sh).
-// min_range_bytes (BSK_MIN_RANGE_BYTES, tests) bounds the range size from below; BSK_RANGES_PER_WAVE pins the count.
-inline uint64_t pick_nranges(uint64_t n, uint64_t waves, uint64_t min_range_bytes) {
-    static const int pinned = [] { const char* e = getenv("BSK_RANGES_PER_WAVE"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+// min_range_bytes (tuning min_range_bytes, tests) bounds the range size from below; `pinned` (tuning ranges_per_wave) pins the count.
+inline uint64_t pick_nranges(uint64_t n, uint64_t waves, uint64_t min_range_bytes, int pinned = 0) {
     uint64_t nr;
     if (pinned) nr = waves * (uint64_t)pinned;
     else {

@@ -616,9 +616,7 @@ hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTab
         hipLaunchKernelGGL(k_grep_regex, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len, buf_n);
     } else if (P.by_seq && P.general) {
         TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
-        const char* sa_env = getenv("BSK_GREP_SHIFTAND");
-        const bool sa_off = sa_env && !strcmp(sa_env, "off");
-        if (!sa_off && Pin.sa_ok) {
+        if (Pin.sa_ok) {  // (the caller clears sa_ok for the context's switch grep_shiftand = off)
             uint64_t blocks = (t.n + 255) / 256;
             if (blocks > 256ull * 8ull) blocks = 256ull * 8ull;
             hipLaunchKernelGGL(k_grep_shiftand, dim3((unsigned)blocks), dim3(256), 0, st, buf, buf_n, t, d, P, out_len);

@@ -69,7 +69,7 @@ int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const 
     const uint64_t N = c->table.n;
     bool by_buckets = N < (1ull << 32);
     {
-        const char* e = getenv("BSK_RMDUP");
+        const char* e = c->tune.get("rmdup");
         if (e && strcmp(e, "table") == 0) by_buckets = false;
     }
     if (by_buckets) {
@@ -159,7 +159,7 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
 static int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, int blocks, hipStream_t st, uint32_t* nranges_out,
                        uint64_t* chunk_out) {
     const uint64_t waves = (uint64_t)blocks * 4;
-    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes);
+    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes, (int)c->tune.num("ranges_per_wave"));
     const uint32_t nranges = (uint32_t)nr;
     uint64_t chunk = (n + nranges - 1) / nranges;
     chunk = (chunk + 15) & ~(uint64_t)15;
@@ -246,7 +246,7 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     // ---- one-pass path: every range writes into its own slice of a sparse table sized from the
     // record density of the shard head; slices are then gathered (6 % of the data volume).
     // Falls back to the exact count + write passes when a slice overflows.
-    const char* ix = getenv("BSK_INDEX");
+    const char* ix = c->tune.get("index");
     if (!(ix && strcmp(ix, "twopass") == 0)) {
         const size_t hb = std::min<size_t>(n, 256 * 1024);
         std::vector<uint8_t> head(hb);
@@ -501,7 +501,7 @@ int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
     int rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
     if (rc != BSK_OK) return rc;
     {
-        const char* e = getenv("BSK_LONG_BYTES");
+        const char* e = c->tune.get("long_bytes");
         c->long_thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
     }
     HIP_TRYX(c, launch_find_long(c->d_out_len, c->table.n, c->long_thresh, c->d_long_list, c->d_counter + 2, st));
@@ -522,7 +522,7 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
     SeqParams P = Pin;
     P.seg_src = nullptr;
     const RecordTable& t = c->table;
-    const char* env = getenv("BSK_SEGCOPY");  // off: never; force: whenever the records qualify (tests)
+    const char* env = c->tune.get("segcopy");  // off: never; force: whenever the records qualify (tests)
     const bool verbatim = P.fastq && !P.fasta_out && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id &&
                           !P.reverse && !P.use_lut && !P.region_on && !P.feat_on && !P.remove_gaps;  // (rename: per record, below)
     bool seg = verbatim && t.n > 0 && total > 0 && ((uintptr_t)d_out & 15u) == 0 && !(env && strcmp(env, "off") == 0);
@@ -931,7 +931,7 @@ static int upload_patterns(bsk_ctx* c, const std::vector<std::string>& all, hipS
 static bool make_filter(bsk_ctx* c, const std::vector<std::string>& all, size_t nuse, bool invert, bool icase, hipStream_t st,
                         FilterDev* F, int* rc) {
     *rc = BSK_OK;
-    const char* env = getenv("BSK_FILTER");
+    const char* env = c->tune.get("filter");
     if (env && strcmp(env, "off") == 0) return false;
     if (nuse == 0 || nuse * 4 > FILTER_MAX_ENTRIES) return false;
     for (size_t k = 0; k < nuse; ++k)
@@ -1066,7 +1066,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 G.cls = c->d_cls;
                 size_t longest = 0;
                 for (auto& p : all) longest = std::max(longest, p.size());
-                G.sa_ok = longest <= 64 && all.size() <= 8 && c->max_mm <= 3 && !G.circular;
+                G.sa_ok = longest <= 64 && all.size() <= 8 && c->max_mm <= 3 && !G.circular && !c->tune.is("grep_shiftand", "off");
             }
         }
         G.pat = c->d_pat;
@@ -1081,7 +1081,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             HIP_TRYX(c, launch_seq_size(d_buf, c->table, FP, c->d_out_len, c->d_status, st));
         } else if (G.by_seq && G.general && G.sa_ok) {
             // one lane per record (k_grep_shiftand): not for chromosomes
-            const char* e = getenv("BSK_LONG_BYTES");
+            const char* e = c->tune.get("long_bytes");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
             rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
             if (rc != BSK_OK) return rc;
@@ -1093,7 +1093,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             if (lc[0]) G.sa_ok = 0;
         } else if (G.by_seq && !G.general && !G.regex) {
             // chromosome-sized sequences are searched by whole blocks (k_grep_seq<.., LONG>): list them
-            const char* e = getenv("BSK_LONG_BYTES");
+            const char* e = c->tune.get("long_bytes");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
             rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
             if (rc != BSK_OK) return rc;
@@ -1496,7 +1496,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
         const uint64_t per_cells = (uint64_t)P.npat * (P.both_strands ? 2 : 1);
         bool long_checked = false;
         if (!P.non_greedy && per_cells < 32768 && !c->locate_vm) {  // (the matcher of variable-length -r walks every record itself)  // (cells of one record are counted in 32 bits: chunks <= 2^17)
-            const char* e = getenv("BSK_LONG_BYTES");
+            const char* e = c->tune.get("long_bytes");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
             rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
             if (rc != BSK_OK) return rc;
@@ -1540,7 +1540,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             if (rc != BSK_OK) return rc;
             HIP_TRYX(c, hipMemcpyAsync(c->d_vm_progs, c->vm_progs.data(), c->vm_progs.size() * sizeof(VmProgram), hipMemcpyHostToDevice, st));
             bool pre = false;
-            if (!c->locate_pre.empty() && !getenv("BSK_LOCATE_NOPRE")) {
+            if (!c->locate_pre.empty() && !c->tune.get("locate_nopre")) {
                 rc = grow(c, &c->d_regex, &c->regex_cap, c->locate_pre.size());
                 if (rc != BSK_OK) return rc;
                 HIP_TRYX(c, hipMemcpyAsync(c->d_regex, c->locate_pre.data(), c->locate_pre.size() * sizeof(RegexProgram), hipMemcpyHostToDevice, st));
@@ -1572,7 +1572,7 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             size_t longest = 0;
             for (auto& p : all) longest = std::max(longest, p.size());
             if (c->general && long_checked && !P.long_count && !P.circular && longest <= 64 && all.size() <= 8 && c->max_mm <= 3 &&
-                !getenv("BSK_LOCATE_NOPRE")) {
+                !c->tune.get("locate_nopre")) {
                 GrepParams G;
                 memset(&G, 0, sizeof G);
                 G.fastq = P.fastq;
@@ -1912,7 +1912,7 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     if (rc != BSK_OK) return rc;
     // The line layout of every record comes out of the index pass (RecordTable::text_w); BSK_TEXT=classify keeps the
     // separate pass over the line ends (tests cross-check the two).
-    const char* mode = getenv("BSK_TEXT");
+    const char* mode = c->tune.get("text");
     const uint32_t* text_w = c->table.text_w;
     if (keep_out_len) {
         // the views once more AFTER the sizes of the output were computed (they sit in d_out_len): the lengths of the
@@ -1947,7 +1947,7 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
     uint64_t total = 0;
     uint64_t lc[2] = {0, 0};
     const bool flat = text_w == c->d_text_w && flatten;
-    const char* lenv = getenv("BSK_LONG_BYTES");
+    const char* lenv = c->tune.get("long_bytes");
     const uint32_t long_thresh = lenv && atoll(lenv) > 0 ? (uint32_t)atoll(lenv) : SEQ_LONG_THRESH;
     if (flat) {  // chromosome-sized records are copied by whole blocks: list them (read back with the total, one wait)
         rc = grow(c, &c->d_long_list, &c->long_list_cap, n, n / 8 + 16);
@@ -2165,9 +2165,9 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     // chromosome-sized records leave the per-record kernels (one wave would translate 10^8 bases alone)
     uint64_t long_max = 0;
     {
-        const char* e = getenv("BSK_LONG_BYTES");
+        const char* e = c->tune.get("long_bytes");
         const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
-        const char* mode = getenv("BSK_TRANSLATE");
+        const char* mode = c->tune.get("translate");
         if (!(mode && strcmp(mode, "legacy") == 0)) {
             rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
             if (rc != BSK_OK) return rc;
@@ -2187,12 +2187,12 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     {
         // wave per record for long sequences, 16 lanes per record for reads; BSK_TRANSLATE=legacy keeps
         // the per-(record, frame) kernel (used by tests to cross-check the two implementations)
-        const char* mode = getenv("BSK_TRANSLATE");
+        const char* mode = c->tune.get("translate");
         if (mode && strcmp(mode, "legacy") == 0) {
             HIP_TRYX(c, launch_translate_emit(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status, st));
         } else {
             const uint64_t avg = n / std::max<uint64_t>(1, c->table.n);
-            static const int forced = [] { const char* e = getenv("BSK_TR_LANES"); return e ? atoi(e) : 0; }();  // measurement knob
+            const int forced = (int)c->tune.num("tr_lanes");  // measurement knob
             // one flag byte per record for the records k_translate_wide leaves to k_translate_frames4
             rc = grow(c, &c->d_redo, &c->redo_cap, c->table.n, c->table.n / 8 + 64);
             if (rc != BSK_OK) return rc;
@@ -2205,7 +2205,8 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             {
                 Timed t(c, "k_translate", st);
                 HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
-                                                    c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter));
+                                                    c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter,
+                                                    c->tune.is("translate", "v3") ? 1 : (c->tune.is("translate", "frames4") ? 2 : 0)));
             }
             HIP_TRYX(c, launch_translate_long(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status,
                                               long_max, st));
@@ -2329,12 +2330,12 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     bool verify_bytes = false;
     uint32_t k1_bits = 64;
     {
-        const char* e = getenv("BSK_RMDUP");
+        const char* e = c->tune.get("rmdup");
         if (e && strcmp(e, "table") == 0) by_keys = false;
-        e = getenv("BSK_RMDUP_KEYS");
+        e = c->tune.get("rmdup_keys");
         if (e && strcmp(e, "off") == 0) by_keys = false;
         if (e && strcmp(e, "verify") == 0) verify_bytes = true;  // keys decide, the bytes of every duplicate are compared on top
-        e = getenv("BSK_RMDUP_K1_BITS");                         // tests: keep only the low bits of k1 (forces the overflow list)
+        e = c->tune.get("rmdup_k1_bits");                         // tests: keep only the low bits of k1 (forces the overflow list)
         if (e && atoi(e) >= 16 && atoi(e) < 64) k1_bits = (uint32_t)atoi(e);
     }
     int rc;
@@ -2378,7 +2379,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     uint32_t* d_first = nullptr;
     bool by_buckets = N < (1ull << 32);
     {
-        const char* e = getenv("BSK_RMDUP");
+        const char* e = c->tune.get("rmdup");
         if (e && strcmp(e, "table") == 0) by_buckets = false;
     }
     if (by_buckets) {
@@ -2561,7 +2562,7 @@ int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     }
     // `-s` on FASTQ: both keys come out of the index pass (stream_rmdup.hip); every rank computes the same two functions
     // whichever kernel it takes (hash_dev.hpp)
-    const bool fused = format == BSK_FORMAT_FASTQ && c->opts.b("BySeq") && !(getenv("BSK_RMDUP_KEYS") && strcmp(getenv("BSK_RMDUP_KEYS"), "off") == 0);
+    const bool fused = format == BSK_FORMAT_FASTQ && c->opts.b("BySeq") && !(c->tune.get("rmdup_keys") && strcmp(c->tune.get("rmdup_keys"), "off") == 0);
     const HashReq hq{c->opts.b("IgnoreCase")};
     int rc = fused ? build_index_ex(c, d_buf, n, format, st, nullptr, &hq) : build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
@@ -2813,8 +2814,8 @@ static int seq_names_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t
         if (head[i] == '\n') { if ((line & 3) == 0) hdr += i - line_start; ++line; line_start = i + 1; }
     if ((line & 3) == 0) hdr += hb - line_start;  // a header cut by the end of the sample
     double ratio = (double)(hdr + 64) / (double)hb;
-    if (const char* sc = getenv("BSK_NAMES_SCALE")) ratio *= atof(sc);  // tests: force the overflow -> fallback route
-    uint64_t slice_cap = (uint64_t)((double)chunk * ratio * 1.25) + (getenv("BSK_NAMES_SCALE") ? 16 : 4096);
+    if (const char* sc = c->tune.get("names_scale")) ratio *= atof(sc);  // tests: force the overflow -> fallback route
+    uint64_t slice_cap = (uint64_t)((double)chunk * ratio * 1.25) + (c->tune.get("names_scale") ? 16 : 4096);
     slice_cap = (slice_cap + 15) & ~(uint64_t)15;
     if (slice_cap >= (1ull << 32) || slice_cap * nranges > (uint64_t)n + (64ull << 20)) return BSK_ERR_FILTER_FALLBACK;
     rc = grow(c, &c->d_slices, &c->slices_cap, slice_cap * nranges, 256);
@@ -2871,7 +2872,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     {
         // names only, nothing that needs the sequence (length / quality filters, gap removal, letter validation): the
         // streaming pass writes them (BSK_NAMES=off keeps the record-table path)
-        const char* nm = getenv("BSK_NAMES");
+        const char* nm = c->tune.get("names");
         const bool explicit_alphabet = !(c->alphabet == AB_NONE || c->alphabet == AB_UNLIMIT);
         if (fastq && n > 0 && o.b("Name") && !o.b("Seq") && !o.b("RemoveGaps") && o.i("MinLen") <= 0 && o.i("MaxLen") <= 0 &&
             !(o.f("MinQual") > 0) && !(o.f("MaxQual") > 0) && !o.b("ValidateSeq") && !explicit_alphabet &&

@@ -184,7 +184,7 @@ int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, h
     if (total == 0) return BSK_OK;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    const char* sg = getenv("BSK_SEGCOPY");
+    const char* sg = c->tune.get("segcopy");
     if (P.times == 1 && !(sg && strcmp(sg, "off") == 0)) {
         // range / head: the kept records are verbatim segments of the shard (ops_segcopy.hip)
         const RecordTable& t = c->table;
@@ -441,7 +441,7 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             hipMemcpyAsync(&maxlen, d_klen + N, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) return fail(BSK_ERR_HIP);
         const uint32_t nchunks = (maxlen + 7) / 8;
-        const char* se = getenv("BSK_SORT");  // lsd: every chunk for every record (the round-1 path)
+        const char* se = c->tune.get("sort");  // lsd: every chunk for every record (the round-1 path)
         if (nchunks <= 3 || (se && strcmp(se, "lsd") == 0)) {
             // LSD over the 8-byte chunks of the keys, last chunk first; every pass is stable
             for (uint32_t ch = nchunks; ch-- > 0;) {
@@ -514,7 +514,7 @@ int sort_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     apply_long(c, &F);
     // the offsets follow the SORTED order: the segments of the copy are the records in that order (FASTQ records that leave
     // unchanged; ops_segcopy.hip), the record-wise emit writes what is left
-    const char* sg = getenv("BSK_SEGCOPY");
+    const char* sg = c->tune.get("segcopy");
     bool seg_done = false;
     if (fastq && !F.ren_ord && !(sg && strcmp(sg, "off") == 0) && ((sg && strcmp(sg, "force") == 0) || total >= (4u << 20))) {
         if (grow(c, &c->d_seg_src, &c->seg_src_cap, 2 * N + 1, N / 4 + 16) != BSK_OK ||
@@ -966,7 +966,7 @@ int concat_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, size_t n_first
     bool emit_old = true;
     {
         // FASTQ: the elements are slices of the shard -- the segmented copy writes them (ops_segcopy.hip, k_concat_segs)
-        const char* sg = getenv("BSK_SEGCOPY");
+        const char* sg = c->tune.get("segcopy");
         const bool force = sg && strcmp(sg, "force") == 0;
         if (fastq && elements > 0 && !(sg && strcmp(sg, "off") == 0) && (force || total >= (4u << 20))) {
             const uint64_t ns = 5 * elements;

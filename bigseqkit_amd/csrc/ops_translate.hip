@@ -1207,11 +1207,10 @@ hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const
 hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                    uint8_t* out, uint64_t* status, hipStream_t st, uint64_t buf_n, uint8_t* redo, int wide_lanes,
-                                   uint64_t* redo_count) {
+                                   uint64_t* redo_count, int variant) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
-    static const bool v3 = [] { const char* e = getenv("BSK_TRANSLATE"); return e && !strcmp(e, "v3"); }();
-    static const bool nowide = [] { const char* e = getenv("BSK_TRANSLATE"); return e && !strcmp(e, "frames4"); }();
+    const bool v3 = variant == 1, nowide = variant == 2;  // (the context's switch "translate": v3 / frames4)
     if (!v3) {
         // the wide kernel first (plain A/C/G/T text in ordinary layouts), then frames4 for the records it flagged
         const uint8_t* only = nullptr;

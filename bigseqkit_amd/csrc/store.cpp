@@ -397,7 +397,7 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
         ST_TRY(c, hipEventCreateWithFlags(&S.in_done[b], hipEventDisableTiming));
         ST_TRY(c, hipEventCreateWithFlags(&S.in_free[b], hipEventDisableTiming));
     }
-    const char* env = getenv("BSK_STAGE_BYTES");
+    const char* env = c->tune.get("stage_bytes");
     const size_t want = env && strtoull(env, nullptr, 10) ? (size_t)strtoull(env, nullptr, 10) : ((size_t)256 << 20);
     // records wrapped over several lines: the cut points below assume 4-line records, so the shard goes as one piece
     if (format == BSK_FORMAT_FASTQ && fastq_head_multiline((const uint8_t*)host_shard, std::min<size_t>(n, 256 * 1024))) chunkable = false;

@@ -77,6 +77,11 @@ const char* bsk_opts_json(const bsk_ctx* ctx);
  * locate.go:50-70, 96-98, 143-145, subseq.go:98-100, 127-133, 157-159.  Config.Quiet suppresses exactly the messages the
  * reference guards with it. */
 const char* bsk_log_text(const bsk_ctx* ctx);
+/* Run-time switches of ONE context (which kernel variant runs, thresholds): key = a name of INTEGRATION.md "Switches"
+ * ("segcopy", "rmdup_keys", "min_range_bytes", ...; the old environment spelling "BSK_SEGCOPY" is accepted), value = its
+ * text, NULL = unset.  A context takes the process environment's BSK_<NAME> values once, in bsk_create; nothing reads the
+ * environment on the call path.  Unknown keys: BSK_ERR_INVALID_ARG. */
+int bsk_ctx_set(bsk_ctx* ctx, const char* key, const char* value);
 
 /* ---- record boundaries: PlainFile(path, delim) + ReadFixer ---------------
  * bigseqkit/helper.go:148-178, bigseqkit-lib/helper.go:41-66.

@@ -207,3 +207,20 @@ def test_stats_merge_sums_like_oracle_reduce():
     assert lib.bsk_stats_merge(ka, va, len(a), kb, vb, len(b), ko, vo, 16, C.byref(n)) == 0
     got = dict(zip(ko[:n.value], vo[:n.value]))
     assert got == {150: 7, 10: 1, 7: 2, -1: 6, -2: 9, -3: 2, -4: ord("D")}
+
+
+def test_ctx_set_knows_its_switches_and_refuses_others():
+    """bsk_ctx_set: run-time switches per context (INTEGRATION.md "Switches"); the environment only supplies defaults at
+    bsk_create.  Options-only context: no device needed."""
+    import ctypes as C
+    from bigseqkit_amd._lib import lib
+    ctx = C.c_void_p()
+    assert lib.bsk_create(b"RmDup", b'{"BySeq": true}', -1, C.byref(ctx)) == 0
+    try:
+        for key in (b"segcopy", b"BSK_SEGCOPY", b"rmdup_keys", b"min_range_bytes", b"long_bytes", b"stage_bytes", b"translate"):
+            assert lib.bsk_ctx_set(ctx, key, b"1") == 0, key
+            assert lib.bsk_ctx_set(ctx, key, None) == 0, key
+        assert lib.bsk_ctx_set(ctx, b"no_such_switch", b"1") != 0
+        assert b"unknown switch" in lib.bsk_last_error(ctx)
+    finally:
+        lib.bsk_destroy(ctx)

@@ -158,3 +158,32 @@ def test_key_path_equals_byte_path_on_c5_layout(monkeypatch):
     assert run_rmdup(data, {"BySeq": True}) == a
     monkeypatch.setenv("BSK_RMDUP_KEYS", "verify")
     assert run_rmdup(data, {"BySeq": True}) == a
+
+
+def test_switches_belong_to_a_context_not_to_the_process():
+    """bsk_ctx_set: two contexts of one process take different paths at the same time (the byte-comparing path and the
+    key path), no environment variable involved, same survivors"""
+    import torch
+    rng = random.Random(3)
+    uniq = [rand_seq(rng, 150, b"ACGT") for _ in range(3000)]
+    seqs = uniq + [rng.choice(uniq) for _ in range(1500)]
+    rng.shuffle(seqs)
+    data = fastq_of(seqs, rng)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    outs = []
+    with bsk.Operator("RmDup", json.dumps({"BySeq": True}), 0) as a, bsk.Operator("RmDup", json.dumps({"BySeq": True}), 0) as b:
+        check(lib.bsk_ctx_set(b.ctx, b"rmdup_keys", b"off"), b.ctx)
+        check(lib.bsk_ctx_set(b.ctx, b"segcopy", b"off"), b.ctx)
+        for op in (a, b, a):
+            out = _lib.Out()
+            lib.bsk_profile_reset(op.ctx)
+            lib.bsk_profile_enable(op.ctx, 1)
+            check(lib.bsk_rmdup_run(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out)), op.ctx)
+            buf = C.create_string_buffer(max(1, out.len))
+            check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+            pb = C.create_string_buffer(4096)
+            check(lib.bsk_profile_dump(op.ctx, pb, len(pb)), op.ctx)
+            outs.append((buf.raw[:out.len], pb.value.decode()))
+    assert outs[0][0] == outs[1][0] == outs[2][0] == oracle.rmdup(data, True, json.dumps({"BySeq": True}))
+    assert "k_rmdup_stream" in outs[0][1] and "k_rmdup_stream" in outs[2][1]      # context a: the fused pass
+    assert "k_rmdup_stream" not in outs[1][1] and "k_rmdup_hash" in outs[1][1]     # context b: its own switches
