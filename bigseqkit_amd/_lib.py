@@ -38,6 +38,22 @@ def _preload_hip_runtime():
                 pass
 
 
+def _import_torch_first():
+    """PyTorch, when it is installed, is imported BEFORE libbsk.so touches the HIP runtime.  Measured on the GPU box
+    (scripts/dbg_torch_init.py): `import torch` after a HIP call of libbsk (hipGetDeviceCount is enough) takes 2.7 - 10.5 s
+    instead of 0.8 s -- with the runtime already initialised, libtorch_hip.so registers ALL its code objects eagerly while it
+    is loaded, which reads the whole library; on a box whose image is not in the page cache that was a wait of 9 - 13
+    minutes in front of the first GPU test of a session (round 3: two of five full test runs).  Imported first, torch
+    registers lazily.  BSK_NO_TORCH_IMPORT=1 skips this (callers that never use torch)."""
+    if os.environ.get("BSK_NO_TORCH_IMPORT") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+_import_torch_first()
 _preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 

@@ -22,6 +22,13 @@ def _ensure_built():
 
 _ensure_built()
 
+# torch before anything of libbsk touches the HIP runtime (bigseqkit_amd/_lib.py _import_torch_first: the other order makes
+# `import torch` register all its device code eagerly -- seconds on a warm box, minutes on a cold one)
+try:
+    import torch  # noqa: F401,E402
+except Exception:
+    pass
+
 
 def has_gpu():
     try:
