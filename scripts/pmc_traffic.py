@@ -15,7 +15,7 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
                  "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; bytes = FETCH_SIZE x 1024 x 2 "
                  "(gfx950 half-count of 16 B/lane coalesced reads, profiles/r01_calibration_stream_read.json) + WRITE_SIZE x 1024",
        "raw": {}, "per_launch": {}}
-names = {"k_stats<true, false, true>": "stats", "k_stats<true, true, true>": "stats -a"}
+names = {"k_stats<true, false, true": "stats", "k_stats<true, true, true": "stats -a"}  # (<FASTQ, ALL, DPP[, ROLES]>)
 for counter, d in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):
     for f in glob.glob(f"gpurun_out/{d}{tag}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
