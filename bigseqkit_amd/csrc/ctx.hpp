@@ -28,7 +28,7 @@ struct bsk_tuning {
     static const char* const* names() {
         static const char* const N[] = {"filter", "grep_shiftand", "index", "locate_nopre", "long_bytes", "min_range_bytes", "names",
                                         "names_scale", "ranges_per_wave", "rmdup", "rmdup_k1_bits", "rmdup_keys", "scan", "segcopy",
-                                        "sort", "stage_bytes", "stats_a", "text", "translate", "tr_lanes", nullptr};
+                                        "sort", "stage_bytes", "stats_a", "text", "translate", "translate_index", "tr_lanes", nullptr};
         return N;
     }
     std::map<std::string, std::string> v;
@@ -137,6 +137,7 @@ struct bsk_ctx {
     // translate
     uint8_t* d_codon = nullptr;   // 4096 + 4096 bytes (aa table, start table)
     std::vector<int> frames;
+    bool translate_light_ok = true;  // FASTA: try the record table from the '>' bytes alone first (stream_fasta_light.hip)
     uint8_t* d_redo = nullptr;    // one byte per record: left by k_translate_wide to k_translate_frames4
     uint64_t redo_cap = 0;
     // rmdup

@@ -31,6 +31,7 @@
 #include "ops_segcopy.hpp"
 #include "ops_seq.hpp"
 #include "ops_sort.hpp"
+#include "stream_fasta_light.hpp"
 #include "stream_filter.hpp"
 #include "stream_names.hpp"
 #include "stream_rmdup.hpp"
@@ -350,6 +351,113 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     // start[n] = effective end of the shard (anchors[nranges])
     HIP_TRYX(c, hipMemcpyAsync(c->table.start + total, anchors + nranges, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     return id_spans(c, d_buf, st);
+}
+
+// The record table of a FASTA shard from its '>' bytes alone (stream_fasta_light.hip): starts, header lengths and regions
+// are exact; l_seq and text_w hold what they WOULD be if every line of a record but the last were as long as its first.
+// Only for a caller that has every byte of the text validated against that layout afterwards (translate: k_translate_wide)
+// and falls back to build_index otherwise.  BSK_ERR_FILTER_FALLBACK: not this path's input (a slice overflowed, a first
+// line shorter than 16 bases, a custom --id-regexp, text that does not begin with '>').
+int build_index_light(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st) {
+    c->table.n = 0;
+    c->avg_record_bytes = 0;
+    if (n == 0 || c->id_custom) return BSK_ERR_FILTER_FALLBACK;
+    const size_t hb = std::min<size_t>(n, 256 * 1024);
+    std::vector<uint8_t> head(hb);
+    HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (head[0] != '>') return BSK_ERR_FILTER_FALLBACK;
+    uint64_t recs = 1;
+    for (size_t i = 0; i + 1 < hb; ++i) recs += (head[i] == '\n' && head[i + 1] == '>');
+    // the sample must look like this path's text: letters A C G T (any case) on the sequence lines
+    {
+        bool in_head = true;
+        for (size_t i = 0; i < hb; ++i) {
+            const uint8_t ch = head[i];
+            if (ch == '\n') { in_head = i + 1 < hb && head[i + 1] == '>'; continue; }
+            if (in_head) continue;
+            const uint8_t u = ch & 0xDFu;
+            if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) return BSK_ERR_FILTER_FALLBACK;
+        }
+    }
+    const double avg = (double)hb / (double)recs;
+    c->avg_record_bytes = (uint64_t)avg;
+    const int blocks = std::max(1, c->num_cus * fasta_starts_max_blocks_per_cu());
+    const uint64_t waves = (uint64_t)blocks * 4;
+    const uint32_t nranges = (uint32_t)pick_nranges(n, waves, c->min_range_bytes, (int)c->tune.num("ranges_per_wave"));
+    uint64_t chunk = (n + nranges - 1) / nranges;
+    chunk = (chunk + 15) & ~(uint64_t)15;
+    if (nranges > c->cap_ranges || !c->d_anchors || !c->d_range_count) {
+        if (c->d_anchors) HIP_TRYX(c, hipFree(c->d_anchors));
+        if (c->d_range_count) HIP_TRYX(c, hipFree(c->d_range_count));
+        if (c->d_range_base) HIP_TRYX(c, hipFree(c->d_range_base));
+        c->d_anchors = nullptr; c->d_range_count = nullptr; c->d_range_base = nullptr;
+        HIP_TRYX(c, hipMalloc((void**)&c->d_anchors, 2 * ((size_t)nranges + 2) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_range_count, ((size_t)nranges + 1) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&c->d_range_base, ((size_t)nranges + 2) * sizeof(uint64_t)));
+        c->cap_ranges = nranges;
+    }
+    uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
+    const uint64_t sparse_cap = (uint64_t)((double)chunk / std::max(avg * 0.5, 6.0)) + 64;
+    const uint64_t need = sparse_cap * nranges;
+    if (need * 8 > (uint64_t)n / 4 + (64ull << 20)) return BSK_ERR_FILTER_FALLBACK;  // (tiny records: the full pass is the better one)
+    int rc = grow(c, &c->d_keys_sparse, &c->keys_sparse_cap, need, 16);  // (the slices: plain u64 scratch of the context)
+    if (rc != BSK_OK) return rc;
+    uint64_t n_eff = n;
+    {   // effective end of the shard (trailing blank lines dropped), as k_prep computes it -- from the last bytes on the host
+        const size_t tb = std::min<size_t>(n, 4096);
+        std::vector<uint8_t> tail(tb);
+        HIP_TRYX(c, hipMemcpyAsync(tail.data(), d_buf + n - tb, tb, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        size_t e = tb;
+        while (e >= 2 && tail[e - 1] == '\n' && tail[e - 2] == '\n') --e;
+        if (e < 2 && tb < n) return BSK_ERR_FILTER_FALLBACK;  // (kilobytes of blank lines: leave it to k_prep)
+        n_eff = n - (tb - e);
+    }
+    HIP_TRYX(c, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
+    {
+        Timed t(c, "k_fasta_starts", st);
+        HIP_TRYX(c, launch_fasta_starts(blocks, d_buf, n_eff, chunk, nranges, queue, c->d_keys_sparse, sparse_cap, c->d_range_count,
+                                        c->d_status, st));
+    }
+    HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
+    uint64_t total = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    auto give_up = [&](uint64_t bits) -> int {
+        status &= ~bits;
+        HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        return BSK_ERR_FILTER_FALLBACK;
+    };
+    if (status & ERR_CAPACITY) return give_up(ERR_CAPACITY);
+    if (total == 0 || total >= (1ull << 32)) return BSK_ERR_FILTER_FALLBACK;
+    RecordTable& t = c->table;
+    const uint64_t cap = total + total / 8 + 16;
+    if (cap > t.cap || !t.start) {
+        for (void* p : {(void*)t.start, (void*)t.l_head, (void*)t.l_seq, (void*)t.aux, (void*)t.text_w})
+            if (p) HIP_TRYX(c, hipFree(p));
+        t = RecordTable();
+        HIP_TRYX(c, hipMalloc((void**)&t.start, (cap + 1) * sizeof(uint64_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.l_head, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.l_seq, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.aux, cap * sizeof(uint32_t)));
+        HIP_TRYX(c, hipMalloc((void**)&t.text_w, cap * sizeof(uint32_t)));
+        t.cap = cap;
+    }
+    t.n = total;
+    t.id_off = nullptr;
+    t.id_len = nullptr;
+    {
+        Timed tm(c, "k_fasta_heads", st);
+        HIP_TRYX(c, launch_fasta_starts_compact(c->d_keys_sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges, n_eff, total, t, st));
+        HIP_TRYX(c, launch_fasta_heads(d_buf, n_eff, t, c->d_status, st));
+    }
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & (ERR_LIGHT_UNFIT | ERR_LINE_TOO_LONG)) { t.n = 0; return give_up(ERR_LIGHT_UNFIT | ERR_LINE_TOO_LONG); }
+    return BSK_OK;
 }
 
 // custom --id-regexp: the ID span of every record of the new table, once per shard (ops_idre.hip)
@@ -2092,7 +2200,20 @@ static int translate_list_tables(bsk_ctx* c, bsk_out* out) {
 int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     if (o.i("ListTranslTable") == 0 || o.i("ListTranslTableWithAmbCodons") == 0) return translate_list_tables(c, out);
-    int rc = build_index(c, d_buf, n, format, st);
+    // FASTA: first with the record table from the '>' bytes alone (stream_fasta_light.hip) -- k_translate_wide validates the
+    // whole text against the layout that table assumes; whatever does not fit (a record flagged by the wide kernel, a
+    // chromosome-sized one, ...) sends the call through the full index pass below, and the context remembers it
+    bool light = format == BSK_FORMAT_FASTA && c->translate_light_ok && !c->tune.is("translate_index", "full") &&
+                 !c->tune.get("translate") && !o.b("InitCodonAsM");
+    int rc = BSK_ERR_FILTER_FALLBACK;
+    if (light) {
+        rc = build_index_light(c, d_buf, n, st);
+        if (rc != BSK_OK && rc != BSK_ERR_FILTER_FALLBACK) return rc;
+    }
+    if (rc == BSK_ERR_FILTER_FALLBACK) {
+        light = false;
+        rc = build_index(c, d_buf, n, format, st);
+    }
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
     Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
@@ -2176,6 +2297,10 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             uint64_t lc[2] = {0, 0};
             HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
             HIP_TRYX(c, hipStreamSynchronize(st));
+            if (light && lc[0]) {  // chromosome-sized records are translated from positions, nothing validates their layout
+                c->translate_light_ok = false;
+                return translate_run_device(c, d_buf, n, format, st, out);
+            }
             if (lc[0] && lc[0] * (uint64_t)P.nframes <= 65535) {  // (grid.y; more long records than that stay per record)
                 P.long_list = c->d_long_list;
                 P.long_count = lc[0];
@@ -2202,11 +2327,19 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             // wide kernel: a wave per record from ~3 k bases (a step of 64 lanes covers 3072), 16 lanes per record below
             // (reads: a step of 4 lanes covers 192 bases; 16 lanes per 150-base read left 12 of them idle)
             const int wide_lanes = forced == 4 || forced == 16 || forced == 64 ? forced : (avg >= 3000 ? 64 : (avg < 500 ? 4 : 16));
+            uint64_t redo_left = 0;
             {
                 Timed t(c, "k_translate", st);
                 HIP_TRYX(c, launch_translate_frames(avg >= 1024 ? 64 : 16, d_buf, c->table, tt, P, c->d_out_len, c->d_out_off,
                                                     c->d_out, c->d_status, st, n, c->d_redo, wide_lanes, c->d_counter,
-                                                    c->tune.is("translate", "v3") ? 1 : (c->tune.is("translate", "frames4") ? 2 : 0)));
+                                                    c->tune.is("translate", "v3") ? 1 : (c->tune.is("translate", "frames4") ? 2 : 0),
+                                                    light ? &redo_left : nullptr));
+            }
+            if (light && redo_left) {
+                // a record did not fit the layout the light table assumed (or holds letters beyond ACGT): its l_seq cannot
+                // be trusted -- the whole call again with the full index pass; this context stays with it
+                c->translate_light_ok = false;
+                return translate_run_device(c, d_buf, n, format, st, out);
             }
             HIP_TRYX(c, launch_translate_long(d_buf, c->table, tt, P, c->d_out_len, c->d_out_off, c->d_out, c->d_status,
                                               long_max, st));

@@ -18,6 +18,7 @@ int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStr
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
 // the record table and, with hash != null (unfiltered FASTQ), the two keys of every record's sequence in c->d_keys / c->d_keys2
 struct HashReq { bool fold; };
+int build_index_light(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st);  // FASTA, from the '>' bytes alone (translate)
 int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F, const HashReq* hash);
 void validate_seq_opts(bsk_ctx* c);
 int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);

@@ -1207,7 +1207,7 @@ hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const
 hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                    uint8_t* out, uint64_t* status, hipStream_t st, uint64_t buf_n, uint8_t* redo, int wide_lanes,
-                                   uint64_t* redo_count, int variant) {
+                                   uint64_t* redo_count, int variant, uint64_t* redo_left_stop) {
     if (t.n == 0) return hipSuccess;
     TextTable d{tt.text_w, tt.lin_off, tt.lin};
     const bool v3 = variant == 1, nowide = variant == 2;  // (the context's switch "translate": v3 / frames4)
@@ -1231,6 +1231,7 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
             hipError_t e = hipMemcpyAsync(&left, redo_count, sizeof left, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
+            if (redo_left_stop) { *redo_left_stop = left; if (left) return hipGetLastError(); }  // (the caller starts over)
             if (left == 0) return hipGetLastError();
         }
         if (lanes_per_record == 64)

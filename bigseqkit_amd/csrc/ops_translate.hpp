@@ -47,7 +47,9 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                    uint8_t* out, uint64_t* status, hipStream_t st, uint64_t buf_n = 0, uint8_t* redo = nullptr,
                                    int wide_lanes = 16, uint64_t* redo_count = nullptr /* zeroed device word */,
-                                   int variant = 0 /* 1: the round-1 frames kernel only, 2: frames4 without the wide kernel */);
+                                   int variant = 0 /* 1: the round-1 frames kernel only, 2: frames4 without the wide kernel */,
+                                   uint64_t* redo_left_stop = nullptr /* receives the number of records the wide kernel left; when
+                                   it is non-zero nothing more is launched */);
 // elements of the records in P.long_list; max_len = longest of those sequences
 hipError_t launch_translate_long(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const TranslateParams& P,
                                  const uint32_t* out_len, const uint64_t* out_off, uint8_t* out, uint64_t* status,
