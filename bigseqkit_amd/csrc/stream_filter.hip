@@ -267,8 +267,12 @@ struct FilterSink {
     }
 };
 
+// 4 waves per SIMD (128 VGPRs, 32 bytes of scratch) since round 3: at 5 (95 VGPRs) 34 registers were spilled around the
+// out-of-line verification that nearly every tile calls -- the 3.3 GB of writes and the 1.44 x fetch that PMC showed for a
+// 12.5 GB pass were scratch traffic.  k_filter 4.07 -> 3.72 ms, grep 4.76 -> 4.40 ms (scripts/r03_var.sh);
+// 3 waves (no scratch at all): 4.42 ms.
 #ifndef BSK_FILTER_WAVES
-#define BSK_FILTER_WAVES 5
+#define BSK_FILTER_WAVES 4
 #endif
 #if BSK_FILTER_WAVES
 #define BSK_FILTER_ATTR __attribute__((amdgpu_waves_per_eu(BSK_FILTER_WAVES, 8)))
