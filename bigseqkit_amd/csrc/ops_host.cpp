@@ -958,8 +958,8 @@ void validate_grep_opts(bsk_ctx* c) {
         // returns its records as they are (bigseqkit/grep.go:141-143): --delete-matched is a no-op there
         if (o.b("BySeq") && c->max_mm > 0) o.mut("DeleteMatched").b = false;
         const size_t np = o.b("UseRegexp") ? c->regexes.size() : c->patterns.size();
-        if ((o.b("BySeq") || o.b("UseRegexp")) && np > 15)
-            throw OptError("libbsk: --delete-matched with more than 15 sequence / regexp patterns is not provided");
+        if ((o.b("BySeq") || o.b("UseRegexp")) && np > 255)  // (15 per hit-bit array, 17 arrays; round 2 stopped at 15)
+            throw OptError("libbsk: --delete-matched with more than 255 sequence / regexp patterns is not provided");
     }
 }
 
@@ -1262,17 +1262,20 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                 // record per pattern is selected, so the walk is: hit bits of every pattern (one match launch each),
                 // then <= npat rounds of "first record after the last selected one that still matches something".
                 const int np = G.npat;
+                // hit bits in arrays of 15 patterns each (bit k = pattern on '+', bit 16 + k = on '-', bit 31 of array 0 =
+                // selected); round 2 had one array and refused more than 15 patterns
+                const int nblk = (np + 14) / 15;
                 Arena A;
-                const uint64_t o_masks = A.take(N * 4), o_hit = A.take(N * 4);
+                const uint64_t o_masks = A.take((uint64_t)nblk * N * 4), o_hit = A.take(N * 4);
                 rc = arena_reserve(c, &A);
                 if (rc != BSK_OK) return rc;
                 uint32_t* d_masks = A.at<uint32_t>(o_masks);
                 uint32_t* d_hit = A.at<uint32_t>(o_hit);
-                HIP_TRYX(c, hipMemsetAsync(d_masks, 0, N * 4, st));
+                HIP_TRYX(c, hipMemsetAsync(d_masks, 0, (uint64_t)nblk * N * 4, st));
                 const std::vector<std::string> all_patterns = c->patterns;
                 const auto all_cls = c->pattern_cls;
                 // the reference asks the '+' strand about every remaining pattern before it turns to the '-' strand
-                // (grep.go:420-433): bit k = pattern k on '+', bit 16 + k = pattern k on '-'
+                // (grep.go:420-433)
                 const int nstrands = G.both_strands ? 2 : 1;
                 for (int k = 0; k < np; ++k) {
                     GrepParams G1 = G;
@@ -1294,25 +1297,46 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                         G1.strand_only = sd + 1;
                         if (G1.long_hit) HIP_TRYX(c, hipMemsetAsync(c->d_hit_list, 0, G.long_count * sizeof(uint32_t), st));
                         HIP_TRYX(c, launch_grep_match(d_buf, n, c->table, &tt, G1, d_hit, st, c->avg_record_bytes));
-                        HIP_TRYX(c, launch_or_bit(d_masks, d_hit, N, 1u << (16 * sd + k), st));
+                        HIP_TRYX(c, launch_or_bit(d_masks + (uint64_t)(k / 15) * N, d_hit, N, 1u << (16 * sd + k % 15), st));
                     }
                 }
-                uint32_t remaining = (1u << np) - 1u;  // (np <= 15)
+                std::vector<uint32_t> remaining(nblk);
+                for (int b = 0; b < nblk; ++b) remaining[b] = (1u << std::min(15, np - 15 * b)) - 1u;
                 uint64_t from = 0;
-                while (remaining && from < N) {
+                auto any_left = [&] { for (uint32_t r : remaining) if (r) return true; return false; };
+                while (any_left() && from < N) {
+                    // the first record at or after `from` that one of the remaining patterns matches: per array, then the lowest
                     uint64_t idx = ~0ull;
+                    std::vector<uint64_t> first(nblk, ~0ull);
                     HIP_TRYX(c, hipMemsetAsync(c->d_counter + 3, 0xFF, 8, st));
-                    HIP_TRYX(c, launch_first_masked(d_masks, N, remaining | (remaining << 16), from, c->d_counter + 3, st));
-                    HIP_TRYX(c, hipMemcpyAsync(&idx, c->d_counter + 3, 8, hipMemcpyDeviceToHost, st));
-                    HIP_TRYX(c, hipStreamSynchronize(st));
+                    if (nblk == 1) {
+                        HIP_TRYX(c, launch_first_masked(d_masks, N, remaining[0] | (remaining[0] << 16), from, c->d_counter + 3, st));
+                        HIP_TRYX(c, hipMemcpyAsync(&idx, c->d_counter + 3, 8, hipMemcpyDeviceToHost, st));
+                        HIP_TRYX(c, hipStreamSynchronize(st));
+                    } else {
+                        for (int b = 0; b < nblk; ++b) {
+                            if (!remaining[b]) continue;
+                            HIP_TRYX(c, hipMemsetAsync(c->d_counter + 3, 0xFF, 8, st));
+                            HIP_TRYX(c, launch_first_masked(d_masks + (uint64_t)b * N, N, remaining[b] | (remaining[b] << 16), from, c->d_counter + 3, st));
+                            HIP_TRYX(c, hipMemcpyAsync(&first[b], c->d_counter + 3, 8, hipMemcpyDeviceToHost, st));
+                            HIP_TRYX(c, hipStreamSynchronize(st));
+                            idx = std::min(idx, first[b]);
+                        }
+                    }
                     if (idx == ~0ull) break;
-                    uint32_t m = 0;
-                    HIP_TRYX(c, hipMemcpy(&m, d_masks + idx, 4, hipMemcpyDeviceToHost));
-                    const uint32_t plus = m & remaining, minus = (m >> 16) & remaining;
-                    const uint32_t hitp = plus ? plus : minus;
-                    remaining &= ~(hitp & (0u - hitp));  // the first remaining pattern (in the order given) that matched
-                    m |= 0x80000000u;                    // bit 31: selected
-                    HIP_TRYX(c, hipMemcpy(d_masks + idx, &m, 4, hipMemcpyHostToDevice));
+                    // the first remaining pattern (in the order given) that matched, '+' strand before '-'
+                    std::vector<uint32_t> m(nblk);
+                    for (int b = 0; b < nblk; ++b) HIP_TRYX(c, hipMemcpy(&m[b], d_masks + (uint64_t)b * N + idx, 4, hipMemcpyDeviceToHost));
+                    int drop = -1;
+                    for (int pass = 0; pass < 2 && drop < 0; ++pass)
+                        for (int b = 0; b < nblk && drop < 0; ++b) {
+                            const uint32_t hit = (pass ? (m[b] >> 16) : m[b]) & remaining[b];
+                            if (hit) drop = 15 * b + (__builtin_ffs((int)hit) - 1);
+                        }
+                    if (drop < 0) break;  // (cannot happen: idx matched something)
+                    remaining[drop / 15] &= ~(1u << (drop % 15));
+                    m[0] |= 0x80000000u;  // bit 31 of array 0: selected
+                    HIP_TRYX(c, hipMemcpy(d_masks + idx, &m[0], 4, hipMemcpyHostToDevice));
                     from = idx + 1;
                 }
                 HIP_TRYX(c, launch_keep_selected(c->d_out_len, d_masks, N, st));

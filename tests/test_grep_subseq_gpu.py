@@ -510,8 +510,29 @@ def test_grep_delete_matched_keeps_the_first_record_of_every_pattern(tmp_path, m
     # with -m the reference never drops a pattern (grepBySeqMismatches, grep.go:255-365): a plain grep -m
     assert both(fa, False, {"Pattern": ["ACGT"], "MaxMismatch": 1, "DeleteMatched": True}) == b">a 1\nACGT\n>c\nACGA\n"
     with pytest.raises(bsk.BskError) as e:
-        bsk.Grep(frame(fa, False), _Opts({"Pattern": ["A" * k for k in range(1, 18)], "BySeq": True, "DeleteMatched": True}))
-    assert "more than 15" in str(e.value)
+        bsk.Grep(frame(fa, False), _Opts({"Pattern": ["A" * k for k in range(1, 258)], "BySeq": True, "DeleteMatched": True}))
+    assert "more than 255" in str(e.value)
+
+
+@pytest.mark.parametrize("npat", [16, 17, 31, 40, 120])
+def test_grep_delete_matched_more_than_fifteen_patterns(npat, monkeypatch):
+    """round 2 refused --delete-matched with more than 15 sequence / regexp patterns (one 32-bit hit word per record); the
+    hit bits now sit in arrays of 15 patterns each and the greedy walk of grep.go:463-511 goes over all of them"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(npat)
+    recs = []
+    for i in range(500):
+        L = rng.randint(20, 70)
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(L)), "I" * L))
+    data = "".join(recs).encode()
+    pats = []
+    while len(pats) < npat:
+        p = "".join(rng.choice("ACGT") for _ in range(rng.randint(3, 6)))
+        if p not in pats:
+            pats.append(p)
+    check_grep(data, True, {"Pattern": pats, "BySeq": True, "DeleteMatched": True})
+    check_grep(data, True, {"Pattern": pats, "BySeq": True, "DeleteMatched": True, "OnlyPositiveStrand": True})
+    check_grep(data, True, {"Pattern": [p[:2] + "[AG]" + p[2:] for p in pats[:20]], "UseRegexp": True, "BySeq": True, "DeleteMatched": True})
 
 
 def test_grep_delete_matched_many_patterns_random(monkeypatch):
