@@ -1469,8 +1469,6 @@ void validate_locate_opts(bsk_ctx* c) {
                 c->locate_vm = true;
             }
         }
-        if (c->locate_vm && o.b("Circular"))
-            throw OptError("libbsk: locate -r with matches of variable length is not provided together with --circular");
         c->locate_pre.clear();
         if (c->locate_vm) {
             // the position-reporting matcher costs ~35 ns per base and lane; most records hold no match at all, and WHETHER
@@ -1672,7 +1670,8 @@ int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hi
             if (rc != BSK_OK) return rc;
             HIP_TRYX(c, hipMemcpyAsync(c->d_vm_progs, c->vm_progs.data(), c->vm_progs.size() * sizeof(VmProgram), hipMemcpyHostToDevice, st));
             bool pre = false;
-            if (!c->locate_pre.empty() && !c->tune.get("locate_nopre")) {
+            // (--circular: an occurrence across the origin is invisible to the boolean pass over the plain text)
+            if (!c->locate_pre.empty() && !c->tune.get("locate_nopre") && !P.circular) {
                 rc = grow(c, &c->d_regex, &c->regex_cap, c->locate_pre.size());
                 if (rc != BSK_OK) return rc;
                 HIP_TRYX(c, hipMemcpyAsync(c->d_regex, c->locate_pre.data(), c->locate_pre.size() * sizeof(RegexProgram), hipMemcpyHostToDevice, st));

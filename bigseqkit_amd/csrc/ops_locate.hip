@@ -84,7 +84,7 @@ __device__ uint32_t put_matched(uint8_t* o, const RowCtx& r) {
     const uint32_t m = r.pat_len;
     for (uint32_t q = 0; q < m; ++q) {
         uint64_t j = r.f + (r.rc ? m - 1 - q : q);
-        if (j >= r.l) j -= r.l;
+        while (r.l && j >= r.l) j -= r.l;  // (--circular: a match may wrap, and one longer than the sequence more than once)
         uint8_t c = r.T.at((uint32_t)j);
         if (r.rc) c = r.comp[c];
         if (r.lower) c = lower8(c);
@@ -501,16 +501,21 @@ __global__ __launch_bounds__(64) void k_locate_vm(const uint8_t* __restrict__ bu
         R.disp_len = P.disp_off[k + 1] - P.disp_off[k];
         R.pat = nullptr;
         const VmProgram& prog = progs[k];
+        // --circular (locate.go:231-234, 595-597, 694-703): the text is the sequence twice, a match must begin in the first
+        // copy, and on the '-' strand a match that reaches into the second copy is reported l further on
+        const uint32_t tl = P.circular ? 2u * l : l;   // length of the text that is searched
+        auto fw = [&](uint32_t i) -> uint8_t { return T.at(i >= l ? i - l : i); };
         for (int strand = 0; strand < (P.both_strands ? 2 : 1); ++strand) {
             uint32_t offset = 0;
             uint32_t far = 0;     // furthest end (in the strand's own coordinates) of a printed match
-            bool any = false;
+            uint32_t far_x = 0;   // ... among the '-' matches that reach into the second copy (their rows are shifted by l)
+            bool any = false, any_x = false;
             // An expression that consumes a byte per step (no ^ / $, not nullable) has all its matches end where the boolean
             // automaton of grep -r is in a final state: a strand on which it never is holds no match, and no match ends
             // beyond the last such position -- the matcher (the costly one) walks [offset, lim) instead of [offset, l), the
             // matches it reports are the same (those of a start are the ones that end by lim, in the same priority order).
-            uint32_t lim = l;
-            if (P.pre_regex) {
+            uint32_t lim = tl;
+            if (P.pre_regex && !P.circular) {
                 const RegexProgram& pr = P.pre_regex[k];
                 if (!pr.nullable && pr.accept[RE_SYM_BEGIN] == 0 && pr.accept[RE_SYM_END] == 0) {
                     const uint32_t nchunk = (pr.npos + 7u) >> 3;
@@ -532,21 +537,37 @@ __global__ __launch_bounds__(64) void k_locate_vm(const uint8_t* __restrict__ bu
                 if (offset > lim) break;
                 uint32_t caps[4];
                 bool found;
-                if (strand == 0) found = vm_search_fn(prog, [&](uint32_t i) { return T.at(offset + i); }, lim - offset, 0u, caps);
-                else found = vm_search_fn(prog, [&](uint32_t i) { return comp[T.at(l - 1u - (offset + i))]; }, lim - offset, 0u, caps);
+                if (!P.circular) {
+                    if (strand == 0) found = vm_search_fn(prog, [&](uint32_t i) { return T.at(offset + i); }, lim - offset, 0u, caps);
+                    else found = vm_search_fn(prog, [&](uint32_t i) { return comp[T.at(l - 1u - (offset + i))]; }, lim - offset, 0u, caps);
+                } else {
+                    if (strand == 0) found = vm_search_fn(prog, [&](uint32_t i) { return fw(offset + i); }, lim - offset, 0u, caps);
+                    else found = vm_search_fn(prog, [&](uint32_t i) { return comp[fw(tl - 1u - (offset + i))]; }, lim - offset, 0u, caps);
+                }
                 if (!found) break;
                 const uint32_t s = offset + caps[0], e = offset + caps[1];  // the match in the strand's coordinates [s, e)
-                if (!(any && far >= e)) {
-                    const int64_t begin = strand == 0 ? (int64_t)s + 1 : (int64_t)l - (int64_t)e + 1;
-                    const int64_t end = strand == 0 ? (int64_t)e : (int64_t)l - (int64_t)s;
+                if (P.circular && s >= l) break;                            // "2nd clone of original part"
+                // inside an earlier match of this pattern and strand?  Starts only grow, so it is a question of ends -- in
+                // the coordinates of the ROWS: a '-' match that crosses the origin is shifted by l, an earlier one that does
+                // not cross holds a later crossing one never, an earlier crossing one holds a later plain one iff it ends
+                // l further on
+                const bool cross = P.circular && strand != 0 && e > l;
+                bool inside;
+                if (cross) inside = any_x && far_x >= e;
+                else inside = (any && far >= e) || (any_x && (uint64_t)far_x >= (uint64_t)l + e);
+                if (!inside) {
+                    int64_t begin = strand == 0 ? (int64_t)s + 1 : (int64_t)l - (int64_t)e + 1;
+                    int64_t end = strand == 0 ? (int64_t)e : (int64_t)l - (int64_t)s;
+                    if (cross) { begin += l; end += l; }
                     R.pat_len = e - s;
                     R.rc = strand != 0;
-                    R.f = strand == 0 ? s : l - e;
+                    if (strand == 0) R.f = s;
+                    else { uint64_t f = (uint64_t)tl - e; while (l && f >= l) f -= l; R.f = f; }
                     if (EMIT) bytes += row_put(o + bytes, R, strand == 0 ? '+' : '-', begin, end);
                     else bytes += row_len(R, begin, end);
                     ++nrows;
-                    far = any ? (e > far ? e : far) : e;
-                    any = true;
+                    if (cross) { far_x = any_x ? (e > far_x ? e : far_x) : e; any_x = true; }
+                    else { far = any ? (e > far ? e : far) : e; any = true; }
                 }
                 offset = P.non_greedy ? e + 1u : s + 1u;
                 if (offset >= lim) break;

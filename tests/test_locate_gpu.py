@@ -262,8 +262,21 @@ def test_locate_regexp_variable_length(expr, monkeypatch):
     for o in ({}, {"OnlyPositiveStrand": True}, {"NonGreedy": True}, {"IgnoreCase": True, "HideMatched": True}, {"Bed": True}):
         check(fa, False, dict({"Pattern": [expr], "UseRegexp": True}, **o))
     check(fq, True, {"Pattern": [expr, "ACG", "C[AT]"], "UseRegexp": True})
-    with pytest.raises(bsk.BskError):
-        bsk.Locate(bsk.SeqFrame(bsk.FORMAT_FASTA, [dev(fa)]), _Opts({"Pattern": [expr], "UseRegexp": True, "Circular": True}))
+    # --circular with the position-reporting matcher (round 2 refused it): the text is the sequence twice, a match begins in
+    # the first copy, '-' matches across the origin are reported l further on (locate.go:231-234, 595-597, 694-703)
+    small = seqgen.random_fasta(rng, 120, 1, 40, alphabet="ACGT")
+    for o in ({}, {"OnlyPositiveStrand": True}, {"NonGreedy": True}, {"Bed": True}):
+        check(small, False, dict({"Pattern": [expr], "UseRegexp": True, "Circular": True}, **o))
+    check(fq, True, {"Pattern": [expr, "C[AT]+G"], "UseRegexp": True, "Circular": True})
+
+
+def test_locate_regexp_variable_length_circular_hand_case():
+    # GTAAAAAC, C+G+T?: '+' strand: the doubled text GTAAAAACGTAAAAAC holds "CGT" at 8..10 (begins in the first copy, ends
+    # beyond l = 8); '-' strand: RevCom doubled GTTTTTACGTTTTTAC holds "CGT" at 0-based 7: begin = 8-0-10+1 = -1, end = 1,
+    # crossing -> 7, 9 (locate.go:697-702)
+    got = check(b">c\nGTAAAAAC\n", False, {"Pattern": ["C+G+T?"], "UseRegexp": True, "Circular": True})
+    assert got == (b"seqID\tpatternName\tpattern\tstrand\tstart\tend\tmatched\n"
+                   b"c\tC+G+T?\tC+G+T?\t+\t8\t10\tCGT\nc\tC+G+T?\tC+G+T?\t-\t7\t9\tCGT\n")
 
 
 @pytest.mark.parametrize("i", range(len(LOC_GEN_OPTS)))
