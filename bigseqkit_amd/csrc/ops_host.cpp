@@ -34,6 +34,7 @@
 #include "stream_fasta_light.hpp"
 #include "stream_filter.hpp"
 #include "stream_names.hpp"
+#include "stream_subseq.hpp"
 #include "stream_rmdup.hpp"
 #include "stream_stats.hpp"
 
@@ -1980,8 +1981,102 @@ int bind_features(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStr
     return BSK_OK;
 }
 
+// `subseq -r a:b` on FASTQ: the records leave from the streaming pass itself (stream_subseq.hip) -- per-range slices sized
+// from the shard head, one scan over the ranges, one gather.  BSK_ERR_FILTER_FALLBACK: not this path's input (long lines,
+// a slice too small); the caller takes the record-table path.
+static int subseq_stream_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, bsk_out* out) {
+    const int blocks = std::max(1, c->num_cus * subseq_stream_max_blocks_per_cu(c->use_dpp));
+    uint32_t nranges = 0;
+    uint64_t chunk = 0;
+    int rc = prep_ranges(c, d_buf, n, /*fastq=*/true, blocks, st, &nranges, &chunk);
+    if (rc != BSK_OK) return rc;
+    const size_t hb = std::min<size_t>(n, 256 * 1024);
+    std::vector<uint8_t> head(hb);
+    HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (!c->norm_active && fastq_head_multiline(head.data(), hb)) return BSK_ERR_MULTILINE_FASTQ;
+    // output bytes per input byte over the complete records of the sample
+    uint64_t in_b = 0, out_b = 0, line = 0, line_start = 0, rec_out = 0, max_line = 0;
+    for (size_t i = 0; i < hb; ++i) {
+        if (head[i] != '\n') continue;
+        const uint64_t ll = i - line_start;
+        max_line = std::max(max_line, ll);
+        const uint32_t role = (uint32_t)(line & 3);
+        if (role == 0) rec_out = ll + 1;
+        else if (role == 2) rec_out += 2;
+        else {
+            uint32_t b, e;
+            sub_location((uint32_t)ll, c->region_start, c->region_end, &b, &e);
+            rec_out += (uint64_t)(e - b) + 1;
+        }
+        if (role == 3) { out_b += rec_out; in_b = i + 1; }
+        ++line;
+        line_start = i + 1;
+    }
+    max_line = std::max<uint64_t>(max_line, hb - line_start);
+    // a lane copies its piece alone: lines of kilobytes (long reads) stay with the record-table kernels
+    if (max_line > 2048 || in_b == 0) return BSK_ERR_FILTER_FALLBACK;
+    double ratio = (double)(out_b + 64) / (double)in_b;
+    if (const char* sc = c->tune.get("subseq_scale")) ratio *= atof(sc);  // tests: force the overflow -> fallback route
+    uint64_t slice_cap = (uint64_t)((double)chunk * ratio * 1.25) + (c->tune.get("subseq_scale") ? 16 : 4096);
+    slice_cap = (slice_cap + 15) & ~(uint64_t)15;
+    if (slice_cap >= (1ull << 32) || slice_cap * nranges > 2 * (uint64_t)n + (64ull << 20)) return BSK_ERR_FILTER_FALLBACK;
+    rc = grow(c, &c->d_slices, &c->slices_cap, slice_cap * nranges, 256);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_names_aux, &c->names_aux_cap, 2 * ((uint64_t)nranges + 2), 16);
+    if (rc != BSK_OK) return rc;
+    SubseqDev D;
+    D.slices = c->d_slices;
+    D.slice_cap = slice_cap;
+    D.range_bytes = c->d_names_aux;
+    D.range_count = c->d_range_count;
+    D.status = c->d_status;
+    D.region_start = c->region_start;
+    D.region_end = c->region_end;
+    uint64_t* d_count_base = c->d_names_aux + nranges + 2;
+    {
+        Timed t(c, "k_subseq_stream", st);
+        HIP_TRYX(c, launch_subseq_stream(c->use_dpp, blocks, d_buf, n, c->d_anchors, nranges,
+                                         reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1), D, st));
+    }
+    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st));
+    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st));
+    uint64_t total = 0, records = 0, status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&records, d_count_base + nranges, sizeof records, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_CAPACITY) {
+        status &= ~(uint64_t)ERR_CAPACITY;
+        HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (status == 0) return BSK_ERR_FILTER_FALLBACK;
+    }
+    if (status) return kernel_error_to_status(c, status);
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    if (total) {
+        Timed t(c, "k_subseq_compact", st);
+        NamesDev G;
+        memset(&G, 0, sizeof G);
+        G.slices = D.slices;
+        G.slice_cap = D.slice_cap;
+        G.range_bytes = D.range_bytes;
+        HIP_TRYX(c, launch_names_compact(G, c->d_range_base, nranges, c->d_out, st));
+    }
+    c->table.n = 0;  // no record table was built for this shard
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = records;
+    return BSK_OK;
+}
+
 int subseq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const bool fastq = format == BSK_FORMAT_FASTQ;
+    if (fastq && n > 0 && c->region_on && !c->tune.is("subseq", "table")) {
+        const int rcs = subseq_stream_run(c, d_buf, n, st, out);
+        if (rcs != BSK_ERR_FILTER_FALLBACK) return rcs;
+    }
     int rc = build_index(c, d_buf, n, format, st);
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
