@@ -816,6 +816,7 @@ __global__ __launch_bounds__(256) BSK_TR_ATTR void k_translate_frames4(const uin
 //     output per frame, so almost every line is written whole.
 // ---------------------------------------------------------------------------
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+typedef uint32_t trw_u32x4 __attribute__((ext_vector_type(4)));
 
 // codes of base slot `bit / 2` .. from the 128-bit code string (bit is a compile-time constant)
 template <int BIT>
@@ -843,7 +844,8 @@ struct Slots {  // residues of class C, slots K..15, forward ascending / reverse
 // nbytes = how many of the 16 (17 with a break inside) bytes exist, counted from `at` (whole: 16 / 17)
 // after16: a line break follows the block's 16th residue directly (first == 16) and exists in the body (another residue
 // comes after it) -- the block writes it, so that no separate pass has to touch the lines of the output beforehand
-__device__ __forceinline__ void put16(uint8_t* at, const uint32_t (&p)[4], uint32_t first, const uint2* s_ins, uint32_t skip,
+// returns: the lane took the whole-block path (one 16-byte store)
+__device__ __forceinline__ bool put16(uint8_t* at, const uint32_t (&p)[4], uint32_t first, const uint2* s_ins, uint32_t skip,
                                       uint32_t nres, bool after16) {
     uint32_t d[4];
     if (first >= 16u) {
@@ -880,6 +882,49 @@ __device__ __forceinline__ void put16(uint8_t* at, const uint32_t (&p)[4], uint3
         }
         if (b1 > 16u) at[16] = (uint8_t)(p[3] >> 24);
         else if (after16 && skip + nres == 16u) at[16] = (uint8_t)'\n';
+        return false;
+    }
+    return true;
+}
+
+// ---- blocks written through a buffer resource (a wave per record) ----------------------------------------------------
+// The body of an element is described by a raw buffer resource (base = its first byte, num_records = its bytes): gfx950
+// checks every dword of a buffer_store_dwordx4 against the end of the resource on its own and drops the dwords that do
+// not fit entirely (measured: scripts/experiments/probe_buffer_clip.hip -- a dword at offset s is written iff
+// s + 4 <= num_records, a byte iff s < num_records, a NEGATIVE offset drops the whole store).  So the blocks at the end of
+// an element (fewer residues than sixteen: the end of the sequence, --trim) leave as the same 16-byte store as every
+// other block, and the at most three bytes of the dword across the end as byte stores that the hardware clips as well.
+// The straight-line predicated byte stores this replaces (put16, skip / nres) were more than half of the kernel's 2 400
+// vector instructions per record: every wave ran them in its last step for all six frames.
+__device__ __forceinline__ void put16_buf(__amdgpu_buffer_rsrc_t rs, uint32_t nr, uint32_t o, const uint32_t (&p)[4], uint32_t first,
+                                          const uint2* s_ins) {
+    uint32_t d[4];
+    if (first >= 16u) {
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int fm = (int)first - 4 * i;  // position of the break inside dword i
+            fm = fm < -1 ? -1 : (fm > 4 ? 4 : fm);
+            const uint2 e = s_ins[fm + 1];
+            d[i] = __builtin_amdgcn_perm(p[i], i ? p[i - 1] : 0u, e.x) | e.y;
+        }
+    }
+    trw_u32x4 v;
+    v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)o, 0, 0);
+    // the 17th byte: the block's last residue behind a break inside it, or the break that follows the block directly
+    // (dropped by the hardware when the body ends with the block)
+    if (first <= 16u) __builtin_amdgcn_raw_buffer_store_b8(first < 16u ? (uint8_t)(p[3] >> 24) : (uint8_t)'\n', rs, (int)(o + 16u), 0, 0);
+    // the dword across the end of the body
+    const uint32_t rem = nr - o;  // bytes of the body from the block's first one (wraps when the block lies behind the body)
+    if (rem < 16u && (rem & 3u)) {
+        const uint32_t k = rem >> 2;
+        const uint32_t w = k == 0u ? d[0] : (k == 1u ? d[1] : (k == 2u ? d[2] : d[3]));
+        const uint32_t at = o + 4u * k;
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)w, rs, (int)at, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w >> 8), rs, (int)(at + 1u), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w >> 16), rs, (int)(at + 2u), 0, 0);
     }
 }
 
@@ -904,6 +949,45 @@ __device__ __forceinline__ void load_window(const uint8_t* a, const uint8_t* buf
     }
 }
 
+// ---- the window as loads of our own -----------------------------------------------------------------------------
+// gfx950 keeps ONE in-order counter (vmcnt) for vector loads and stores.  The window of step s + 1 is requested in the
+// middle of step s, in front of that step's stores; the compiler, which has to assume that any of those stores (they sit
+// in divergent branches) may not have been issued, can only wait for vmcnt(0) at the top of step s + 1 -- i.e. for the
+// acknowledgement of every store of step s from HBM, with nothing else to do (266 s_waitcnt vmcnt(0) in the round-2
+// kernel).  Issued as inline asm the loads are invisible to that bookkeeping; the kernel counts the 16-byte stores it
+// has certainly issued since (one per put16 whose fast path any lane took) and waits for vmcnt(that number): the window
+// has arrived, the stores behind it are still on their way.
+struct WinRegs { trw_u32x4 a, b, c; uint32_t d; };
+
+__device__ __forceinline__ void window_issue(const uint8_t* a, WinRegs& w) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                 "global_load_dword %3, %4, off offset:48"
+                 : "=&v"(w.a), "=&v"(w.b), "=&v"(w.c), "=&v"(w.d) : "v"(a) : "memory");
+}
+// lb = 16-byte stores certainly issued behind the loads (wave-uniform).  ONE asm statement with the window registers
+// tied in and out: with one statement per count the compiler merged their outputs through copies that READ the
+// registers in front of the wait.
+__device__ __forceinline__ void window_arrive(WinRegs& w, uint32_t lb) {
+    asm volatile("s_cmp_ge_u32 %4, 6\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_cmp_ge_u32 %4, 3\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_branch 3f\n"
+                 "1:\n\t"
+                 "s_waitcnt vmcnt(6)\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "s_waitcnt vmcnt(3)\n"
+                 "3:"
+                 : "+v"(w.a), "+v"(w.b), "+v"(w.c), "+v"(w.d) : "s"(__builtin_amdgcn_readfirstlane((int)lb)) : "memory", "scc");
+}
+
+#ifndef BSK_TRW_ASM
+#define BSK_TRW_ASM 0  // measured: 53.3 ms against 47.5 with the compiler's loads at C4 -- the kernel was bound by its instructions
+#endif
 #ifndef BSK_TRW_WAVES
 #define BSK_TRW_WAVES 0
 #endif
@@ -919,6 +1003,9 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
                                                         uint8_t* __restrict__ redo, uint64_t* __restrict__ redo_count,
                                                         uint64_t* __restrict__ status) {
     constexpr uint32_t LB = 48;            // bases per lane and step (16 codon slots)
+    // the window as loads of our own (window_issue): for a wave per record; with 4 / 16 lanes per record the kernel would
+    // go from 127 to 136 VGPRs (3 waves per SIMD instead of 4)
+    constexpr bool ASMW = BSK_TRW_ASM && G == 64;
     constexpr uint32_t STEPB = G * LB;     // bases per group and step
     __shared__ __attribute__((aligned(128))) uint8_t s_tab64[128];  // forward ++ reverse-complement residues by 2-bit codon index
     __shared__ uint8_t s_iu[256];
@@ -964,13 +1051,26 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
     const uint8_t* const buf_end = buf + buf_n;
     // the window of the first step is requested before anything else is done with the record, the window of step s + 1
     // while step s is translated: the text's round trip to HBM hides behind the headers / the previous step
+    // (see window_issue) every lane asks for 52 bytes: lanes without a window, and the few whose window crosses the end of
+    // the buffer (they read it byte by byte when its turn comes), ask for the first bytes of the buffer
+    WinRegs wr;
+    bool wtail = false;
+    uint32_t lb = 0;  // 16-byte stores certainly issued behind the pending window (wave-uniform)
     uint32_t rn[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (LB * gl < L) load_window(T.p + LB * gl + rnl, buf_end, rn);
+    if constexpr (ASMW) {
+        const uint8_t* a = T.p + LB * gl + rnl;
+        const bool lv = LB * gl < L;
+        wtail = lv && a + 52 > buf_end;
+        window_issue(lv && !wtail ? a : buf, wr);
+    } else {
+        if (LB * gl < L) load_window(T.p + LB * gl + rnl, buf_end, rn);
+    }
 
     constexpr uint64_t NONE = ~0ull;
     uint64_t fb[3] = {NONE, NONE, NONE};   // body offsets from `out`
     uint64_t rbq[3] = {NONE, NONE, NONE};
     uint32_t fk[3] = {0, 0, 0}, rkq[3] = {0, 0, 0};
+    uint32_t fnr[3] = {0, 0, 0}, rnq[3] = {0, 0, 0};  // bytes of the bodies (G == 64: the ends of the buffer resources)
     // everything the six elements need from memory is requested at once (a loop that fetched out_len / out_off / the
     // header bytes frame by frame put six dependent round trips in front of every record: the waves of this kernel live
     // for ~30 us, and most of that was waiting)
@@ -982,16 +1082,9 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         ne[k] = k < P.nframes ? out_len[e0 + k] : 0u;
         oe[k] = k < P.nframes ? out_off[e0 + k] : 0ull;
     }
+    // header line and final line break of element k (n bytes at o, header of H bytes)
     const uint8_t hbyte = (gl >= 1u && gl - 1u < hl) ? h[gl - 1u] : (uint8_t)0;  // header byte of position gl (frames share it)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        if (k >= P.nframes) break;
-        const int frame = P.frames[k];
-        const uint32_t n = ne[k];
-        uint8_t* o = out + oe[k];
-        const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
-        const uint32_t body = n - H - 1;
-        const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
+    auto put_header = [&](int frame, uint8_t* o, uint32_t n, uint32_t H) {
         if (!P.append_frame) {
             if (gl < H) o[gl] = gl == 0 ? (uint8_t)'>' : (gl == H - 1 ? (uint8_t)'\n' : hbyte);
             for (uint32_t x = gl + G; x < H; x += G) o[x] = x == H - 1 ? (uint8_t)'\n' : h[x - 1];
@@ -1009,27 +1102,40 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
             o[hdr++] = '\n';
         }
         if (gl == 0) o[n - 1] = '\n';  // (the line breaks of the body are written with the residues around them)
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k >= P.nframes) break;
+        const int frame = P.frames[k];
+        const uint32_t n = ne[k];
+        const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
+        const uint32_t body = n - H - 1;
+        const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
+        if constexpr (!ASMW) put_header(frame, out + oe[k], n, H);
         uint64_t bodyp = oe[k] + H;
         if constexpr (G == 64)  // one record per wave: the body addresses are wave-uniform -> scalar base + 32-bit offset
             bodyp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bodyp >> 32)) << 32) |
                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bodyp);
+        uint32_t bodyn = body;
+        if constexpr (G == 64) bodyn = (uint32_t)__builtin_amdgcn_readfirstlane((int)body);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (frame == c + 1) { fb[c] = bodyp; fk[c] = kept; }
-            if (frame == -(c + 1)) { rbq[c] = bodyp; rkq[c] = kept; }
+            if (frame == c + 1) { fb[c] = bodyp; fk[c] = kept; fnr[c] = bodyn; }
+            if (frame == -(c + 1)) { rbq[c] = bodyp; rkq[c] = kept; rnq[c] = bodyn; }
         }
     }
     // codons of class c (starting at base c + 3 s) belong to reverse frame -(sl + 1), sl = (L % 3 + 3 - c) % 3, as its
     // residue (L - 3 - c) / 3 - s
     const uint32_t Lm = L % 3u;
     uint64_t rb[3];
-    uint32_t rk[3];
+    uint32_t rk[3], rnr[3];
     int32_t r0[3];  // residue index of slot 0
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const uint32_t sl = (Lm + 3u - (uint32_t)c) % 3u;
         rb[c] = sl == 0 ? rbq[0] : (sl == 1 ? rbq[1] : rbq[2]);
         rk[c] = sl == 0 ? rkq[0] : (sl == 1 ? rkq[1] : rkq[2]);
+        rnr[c] = sl == 0 ? rnq[0] : (sl == 1 ? rnq[1] : rnq[2]);
         r0[c] = L >= 3u + (uint32_t)c ? (int32_t)((L - 3u - (uint32_t)c) / 3u) : -1;
     }
     const uint32_t g16 = 16u * G;  // residues per group and step
@@ -1059,13 +1165,22 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         uint32_t rnl2 = rnl, rcol2 = rcol;
         if (W) { rnl2 += sdq; rcol2 += smq; if (rcol2 >= W) { rcol2 -= W; ++rnl2; } }
         const uint32_t kbrk = W ? W - rcol : 0xFFFFu;            // raw bytes before this window's line break
+        if constexpr (ASMW) window_arrive(wr, lb);
         if (live) {
             const uint32_t nb = L - q < 50u ? L - q : 50u;     // bases of the lane's window that exist
             const bool brk = kbrk < nb;                          // (a break after the last base needed is not read)
             const uint32_t nraw = nb + (brk ? 1u : 0u);
             uint32_t r[13];
+            if constexpr (ASMW) {
+                r[0] = wr.a.x; r[1] = wr.a.y; r[2] = wr.a.z; r[3] = wr.a.w;
+                r[4] = wr.b.x; r[5] = wr.b.y; r[6] = wr.b.z; r[7] = wr.b.w;
+                r[8] = wr.c.x; r[9] = wr.c.y; r[10] = wr.c.z; r[11] = wr.c.w;
+                r[12] = wr.d;
+                if (wtail) load_window(T.p + q + rnl, buf_end, r);  // (the last bytes of the shard)
+            } else {
 #pragma unroll
-            for (int i = 0; i < 13; ++i) r[i] = rn[i];
+                for (int i = 0; i < 13; ++i) r[i] = rn[i];
+            }
             // bytes past the window (the next letters, or whatever follows the record) must not take part in the check
             if (nraw >= 48u) {
                 const uint32_t keep = nraw - 48u;  // 0..3 bytes of dword 12
@@ -1092,7 +1207,9 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
             X[1] = d8[4] | (d8[5] << 8) | (d8[6] << 16) | (d8[7] << 24);
             X[2] = d8[8] | (d8[9] << 8) | (d8[10] << 16) | (d8[11] << 24);
             X[3] = d8[12];
-            if (q + STEPB < L) load_window(T.p + q + STEPB + rnl2, buf_end, rn);  // (r is consumed: its registers are free)
+            if constexpr (!ASMW) {
+                if (q + STEPB < L) load_window(T.p + q + STEPB + rnl2, buf_end, rn);  // (r is consumed: its registers are free)
+            }
             if (brk) {  // cut the two bits of the break (raw byte kbrk) out of the string
                 const uint32_t Y[5] = {X[0], X[1], X[2], X[3], 0u};
 #pragma unroll
@@ -1104,6 +1221,13 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
                 }
             }
         }
+        if constexpr (ASMW) {  // the window of the next step, requested by every lane of the wave (r is consumed: its registers are free)
+            const uint8_t* a = T.p + q + STEPB + rnl2;
+            const bool lv = q + STEPB < L;
+            wtail = lv && a + 52 > buf_end;
+            window_issue(lv && !wtail ? a : buf, wr);
+        }
+        uint32_t fastm = 0;  // bit per put16 of this step whose whole-block store this lane issued
         // a group that met a letter this kernel does not know leaves the record to k_translate_frames4
         {
             const uint64_t bb = __ballot(bad);
@@ -1123,13 +1247,42 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
                 // complete codons among the lane's sixteen slots of this class
                 uint32_t nv = 0;
                 if (q + (uint32_t)c + 2u < L) { nv = (L - q - (uint32_t)c - 3u) / 3u + 1u; if (nv > 16u) nv = 16u; }
+                if constexpr (G == 64) {
+                    // a wave per record: the blocks leave through buffer resources that end with the bodies (put16_buf)
+                    // (the resource words as scalars by decree: they come through selects on L % 3, a vector register as far as
+                    // the compiler knows, and a resource in vector registers costs a waterfall loop around every store)
+                    auto body_rsrc = [&](uint64_t off, uint32_t nr) {
+                        const uint64_t a = (uint64_t)(uintptr_t)out + off;
+                        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+                        return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)u, 0, __builtin_amdgcn_readfirstlane((int)nr), 0x00020000);
+                    };
+                    if (wf) put16_buf(body_rsrc(fb[c], fnr[c]), fnr[c], fj + fo, pf, lw ? lw - fc : 17u, s_ins);
+                    if (wr && rj[c] >= 0) {
+                        put16_buf(body_rsrc(rb[c], rnr[c]), rnr[c], (uint32_t)rj[c] + ro[c], pr, lw ? lw - rcc[c] : 17u, s_ins);
+                    } else if (wr && rj[c] > -16) {
+                        // the block across residue 0 (one lane per frame and record; a negative offset would drop the whole
+                        // store): its residues 0 .. hi - 1 (< 16 <= lw) are on the first line
+                        int32_t hi = rj[c] + 16;
+                        if (hi > (int32_t)rk[c]) hi = (int32_t)rk[c];
+                        int32_t lo = rj[c] + 16 - (int32_t)nv;
+                        if (lo < 0) lo = 0;
+                        uint8_t* base = out + rb[c];
+                        for (int32_t j = lo; j < hi; ++j) {
+                            const uint32_t kk = (uint32_t)(j - rj[c]);
+                            base[j] = (uint8_t)(pr[kk >> 2] >> (8 * (kk & 3u)));
+                        }
+                    }
+                    continue;
+                }
                 if (wf) {
                     // residues fj .. fj + nv - 1, cut by `kept` (--trim)
                     uint32_t nres = nv;
                     if (fj >= fk[c]) nres = 0; else if (fj + nres > fk[c]) nres = fk[c] - fj;
                     if (nres) {
                         const uint32_t first = lw ? lw - fc : 17u;
-                        put16(out + fb[c] + (uint32_t)(fj + fo), pf, first, s_ins, 0u, nres, first == 16u && fj + 16u < fk[c]);
+                        const bool fst = put16(out + fb[c] + (uint32_t)(fj + fo), pf, first, s_ins, 0u, nres, first == 16u && fj + 16u < fk[c]);
+                        fastm |= fst ? 1u << (2 * c) : 0u;
                     }
                 }
                 if (wr) {
@@ -1143,8 +1296,9 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
                         // block position: residue rj may be negative (then skip > 0): positions are relative to residue rj
                         if (rj[c] >= 0) {
                             const uint32_t first = lw ? lw - rcc[c] : 17u;
-                            put16(out + rb[c] + (uint32_t)((uint32_t)rj[c] + ro[c]), pr, first, s_ins, skip, (uint32_t)(hi - lo),
-                                  first == 16u && (uint32_t)rj[c] + 16u < rk[c]);
+                            const bool fst = put16(out + rb[c] + (uint32_t)((uint32_t)rj[c] + ro[c]), pr, first, s_ins, skip, (uint32_t)(hi - lo),
+                                                   first == 16u && (uint32_t)rj[c] + 16u < rk[c]);
+                            fastm |= fst ? 2u << (2 * c) : 0u;
                         } else {
                             // the block starts before residue 0: its residues 0 .. hi-1 (< 16 <= lw) are on the first line
                             uint8_t* base = out + rb[c];
@@ -1157,6 +1311,11 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
                     }
                 }
             }
+        }
+        if constexpr (ASMW) {
+            lb = 0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) lb += __ballot((fastm >> b) & 1u) != 0ull ? 1u : 0u;
         }
         // ---- advance the cursors by one step
         fj += g16;
@@ -1174,6 +1333,26 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
     if (give_up) {
         if (gl == 0) { redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
         return;
+    }
+    if constexpr (ASMW) {
+        // ---- headers and final line breaks, behind the bodies: a store in front of the first window would have to be
+        // acknowledged before that window counts as arrived.  Place and size of an element come back from its body offset
+        // and its residue count (registers): a load here would wait for every store of the body
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k >= P.nframes) break;
+            const int frame = P.frames[k];
+            uint64_t bodyp = 0;
+            uint32_t kept = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (frame == c + 1) { bodyp = fb[c]; kept = fk[c]; }
+                if (frame == -(c + 1)) { bodyp = rbq[c]; kept = rkq[c]; }
+            }
+            const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
+            const uint32_t body = kept + ((lw && kept) ? (kept - 1u) / lw : 0u);
+            put_header(frame, out + (bodyp - H), H + body + 1u, H);
+        }
     }
     // ---- -M: residue 0 of a frame becomes 'M' when its codon is a start codon (after every other store)
     if (P.init_m && gl == 0) {
@@ -1214,7 +1393,7 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
     if (!v3) {
         // the wide kernel first (plain A/C/G/T text in ordinary layouts), then frames4 for the records it flagged
         const uint8_t* only = nullptr;
-        if (redo && !nowide) {
+        if (redo && !nowide && buf_n >= 64) {  // (k_translate_wide asks for 52 bytes at `buf` on behalf of idle lanes)
             if (wide_lanes == 64)
                 hipLaunchKernelGGL(k_translate_wide<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);
