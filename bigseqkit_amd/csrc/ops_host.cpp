@@ -2352,9 +2352,9 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     P.init_m = o.b("InitCodonAsM"); P.append_frame = o.b("AppendFrame");
     P.line_width = (int)o.ci("LineWidth");
     P.id_mode = id_mode_of(c);
-    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 6 * 4096 + 256));
+    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 6 * 4096 + 256 + 16384));
     {
-        std::vector<uint8_t> tab(6 * 4096 + 256);
+        std::vector<uint8_t> tab(6 * 4096 + 256 + 16384);
         uint8_t *fw = tab.data(), *stt = fw + 4096, *rcw = fw + 8192, *rcs = fw + 12288, *iu = fw + 16384;
         build_codon_tables(*find_code((int)o.i("TranslTable")), fw, stt);
         auto comp = [](int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); };
@@ -2375,9 +2375,23 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             if (P.clean && a == '*') a = 'X';
             tab[16384 + 256 + i] = a;
         }
+        {   // pairs of plain-letter codons for k_translate_wide (TranslateParams::pair)
+            const uint8_t* baked = tab.data() + 16384 + 256;
+            const int iu4[4] = {1, 2, 8, 4};  // IUPAC code of the 2-bit codes A C T G
+            auto full = [&](int j) { return (iu4[j & 3] << 8) | (iu4[(j >> 2) & 3] << 4) | iu4[(j >> 4) & 3]; };
+            uint8_t* pair = tab.data() + 6 * 4096 + 256;
+            for (int i = 0; i < 4096; ++i) {
+                const int lo = i & 63, hi = i >> 6;
+                pair[2 * i] = baked[full(lo)];
+                pair[2 * i + 1] = baked[full(hi)];
+                pair[8192 + 2 * i] = baked[4096 + full(hi)];
+                pair[8192 + 2 * i + 1] = baked[4096 + full(lo)];
+            }
+        }
         HIP_TRYX(c, hipMemcpyAsync(c->d_codon, tab.data(), tab.size(), hipMemcpyHostToDevice, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
     }
+    P.pair = c->d_codon + 6 * 4096 + 256;
     P.baked = c->d_codon + 16384 + 256;
     P.codon = c->d_codon;
     P.start = c->d_codon + 4096;

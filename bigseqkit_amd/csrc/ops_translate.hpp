@@ -28,6 +28,10 @@ struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/tra
     const uint8_t* start_rc; // device, 4096 bytes
     const uint8_t* iupac;    // device, 256 bytes: byte -> 4-bit IUPAC code (0 = not a base)
     const uint8_t* baked;    // device, 8192 bytes, 16-byte aligned: codon ++ codon_rc with -x (0 -> 'X') and --clean ('*' -> 'X') applied
+    // device, 16384 bytes, 16-byte aligned: for two codons of plain letters in 2-bit codes ((b >> 1) & 3: A 0, C 1, T 2, G 3; first
+    // base in the low bits; index = first codon | second << 6) the two residues of `baked` as uint16: [0, 8192) forward, first
+    // codon's residue in the low byte; [8192, 16384) reverse complement, SECOND codon's residue in the low byte
+    const uint8_t* pair;
     // chromosome-sized records (l_seq >= long_thresh): skipped by the per-record kernels, translated by whole blocks
     // (launch_translate_long: one block per 16 KiB of an element's body)
     const uint32_t* long_list;
