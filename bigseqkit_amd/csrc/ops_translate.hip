@@ -930,16 +930,10 @@ __device__ __forceinline__ void put16_buf(__amdgpu_buffer_rsrc_t rs, uint32_t nr
     }
     trw_u32x4 v;
     v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
-#if BSK_TRW_EXP == 6
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(o & ~15u), 0, 0);
-#else
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)o, 0, 0);
-#endif
     // the 17th byte: the block's last residue behind a break inside it, or the break that follows the block directly
     // (dropped by the hardware when the body ends with the block)
-#if BSK_TRW_EXP != 4 && BSK_TRW_EXP != 5
     if (first <= 16u) __builtin_amdgcn_raw_buffer_store_b8(first < 16u ? (uint8_t)(p[3] >> 24) : (uint8_t)'\n', rs, (int)(o + 16u), 0, 0);
-#endif
     if (at_end) {
         // the dword across the end of the body
         const uint32_t rem = nr - o;  // bytes of the body from the block's first one (wraps when the block lies behind the body)
@@ -975,9 +969,6 @@ __device__ __forceinline__ void load_window(const uint8_t* a, const uint8_t* buf
     }
 }
 
-#ifndef BSK_TRW_EXP
-#define BSK_TRW_EXP 0  // timing experiments (wrong output): 4 no 17th-byte stores, 5 nor headers, 6 aligned block offsets
-#endif
 #ifndef BSK_TRW_WAVES
 #define BSK_TRW_WAVES 0
 #endif
@@ -1084,9 +1075,7 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
         const uint32_t body = n - H - 1;
         const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
-#if BSK_TRW_EXP != 5
         put_header(frame, out + oe[k], n, H);
-#endif
         uint64_t bodyp = oe[k] + H;
         if constexpr (G == 64)  // one record per wave: the body addresses are wave-uniform -> scalar base + 32-bit offset
             bodyp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bodyp >> 32)) << 32) |
