@@ -227,6 +227,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_out_alt) hipFree(c->d_out_alt);
         if (c->d_slices) hipFree(c->d_slices);
         if (c->d_norm) hipFree(c->d_norm);
+        if (c->d_norm2) hipFree(c->d_norm2);
         if (c->d_group) hipFree(c->d_group);
         if (c->d_seg_src) hipFree(c->d_seg_src);
         if (c->d_seg_first) hipFree(c->d_seg_first);
@@ -737,25 +738,84 @@ typedef int (*run_fn)(bsk_ctx*, const uint8_t*, size_t, int, hipStream_t, bsk_ou
 // BSK_ERR_MULTILINE_FASTQ from an operator that cannot take the rewritten text
 static int multiline_unsupported(bsk_ctx* c) {
     return fail(c, BSK_ERR_UNSUPPORTED,
-                "libbsk: multi-line FASTQ is not provided for this operator (range / head / duplicate print the record text as "
-                "it is; pair / common / concat and the multi-GPU rmdup take record-aligned pieces of several texts)");
+                "libbsk: multi-line FASTQ is not provided for the phases of the multi-GPU rmdup (they take record-aligned "
+                "pieces of a file that was cut with the 4-line record finder)");
 }
 
 // runs fn; when the head of a FASTQ shard shows records wrapped over several lines (helper.go:252-269), on the shard
 // rewritten as strict 4-line FASTQ
 static int run_maybe_multiline(bsk_ctx* c, run_fn fn, const uint8_t* d, size_t n, int format, hipStream_t st, bsk_out* out) {
+    c->last_kernel_flags = 0;
     int rc = fn(c, d, n, format, st, out);
-    if (rc != BSK_ERR_MULTILINE_FASTQ) return rc;
-    if (c->op == Op::Range || c->op == Op::Head || c->op == Op::Duplicate) return multiline_unsupported(c);
+    // (range / head / duplicate print the record text as it stands and deal with wrapped records themselves: records_run_device)
+    const bool wrapped_head = rc == BSK_ERR_MULTILINE_FASTQ;
+    // the head of the shard was 4-line FASTQ and the strict reader gave up further down: wrapped records there?
+    const bool wrapped_later = rc != BSK_OK && !wrapped_head && format == BSK_FORMAT_FASTQ && !c->norm_active &&
+                               (c->last_kernel_flags & STRICT_FASTQ_FLAGS) != 0;
+    if (!wrapped_head && !wrapped_later) return rc;
+    const std::string msg = c->last_error;
+    const int rc0 = rc;
     const uint8_t* d2 = nullptr;
     size_t n2 = 0;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
     rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
-    if (rc != BSK_OK) return rc;
+    if (rc != BSK_OK) {
+        if (wrapped_later) { c->set_error(msg); return rc0; }  // (not FASTQ under either reader: the first complaint stands)
+        return rc;
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
     c->norm_active = true;
     rc = fn(c, d2, n2, format, st, out);
     c->norm_active = false;
     return rc;
+}
+
+// pair / common / concat: several FASTQ texts in one buffer (ends[k] = one past text k).  When the strict reader gives up
+// on one of them, every text is rewritten as 4-line FASTQ by itself and the rewritten texts, back to back, take the
+// place of the buffer: *d2 / ends2.  The combined text lives in c->d_norm2.
+static int normalize_pieces(bsk_ctx* c, const uint8_t* d, const std::vector<uint64_t>& ends, hipStream_t st, const uint8_t** d2,
+                            std::vector<uint64_t>* ends2) {
+    ends2->clear();
+    uint64_t total = 0, from = 0;
+    for (size_t k = 0; k < ends.size(); ++k) {
+        const uint8_t* dk = nullptr;
+        size_t nk = 0;
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+        int rc = normalize_multiline_fastq(c, d + from, ends[k] - from, st, &dk, &nk);
+        if (rc != BSK_OK) return rc;
+        // (a text that does not end with a newline must not run into the next one)
+        uint8_t last = '\n';
+        if (nk) HIP_TRY(c, hipMemcpy(&last, dk + nk - 1, 1, hipMemcpyDeviceToHost));
+        const uint64_t need = total + nk + 1;
+        if (need > c->norm2_cap) {
+            uint8_t* g = nullptr;
+            const uint64_t cap = need + need / 4 + (ends.back() - from) + 256;
+            HIP_TRY(c, hipMalloc((void**)&g, cap));
+            if (total) HIP_TRY(c, hipMemcpy(g, c->d_norm2, total, hipMemcpyDeviceToDevice));
+            if (c->d_norm2) HIP_TRY(c, hipFree(c->d_norm2));
+            c->d_norm2 = g;
+            c->norm2_cap = cap;
+        }
+        if (nk) HIP_TRY(c, hipMemcpyAsync(c->d_norm2 + total, dk, nk, hipMemcpyDeviceToDevice, st));
+        total += nk;
+        if (nk && last != '\n' && k + 1 < ends.size()) {
+            const uint8_t nl = '\n';
+            HIP_TRY(c, hipMemcpyAsync(c->d_norm2 + total, &nl, 1, hipMemcpyHostToDevice, st));
+            total += 1;
+        }
+        HIP_TRY(c, hipStreamSynchronize(st));  // (c->d_norm is written again by the next text)
+        ends2->push_back(total);
+        from = ends[k];
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    *d2 = c->d_norm2;
+    return BSK_OK;
+}
+
+// does rc of a multi-text operator call for the multi-line reader?  (the head of a text is wrapped, or the strict reader gave up)
+static bool wants_multiline(bsk_ctx* c, int rc, int format) {
+    if (rc == BSK_ERR_MULTILINE_FASTQ) return true;
+    return rc != BSK_OK && format == BSK_FORMAT_FASTQ && !c->norm_active && (c->last_kernel_flags & STRICT_FASTQ_FLAGS) != 0;
 }
 
 int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, void* stream,
@@ -768,21 +828,36 @@ int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int 
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
+    c->last_kernel_flags = 0;
     rc = build_index(c, d, n, format, st);
-    if (rc == BSK_ERR_MULTILINE_FASTQ) {  // the table then describes the rewritten text (c->d_norm), not the caller's
+    uint64_t status = 0;
+    if (rc == BSK_OK) {
+        HIP_TRY(c, hipStreamSynchronize(st));
+        HIP_TRY(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        rc = kernel_error_to_status(c, status);
+    }
+    // records wrapped over several lines at the head of the shard, or -- the strict reader complained -- further down:
+    // the table then describes the rewritten text (c->d_norm), not the caller's
+    if (rc == BSK_ERR_MULTILINE_FASTQ || (rc != BSK_OK && format == BSK_FORMAT_FASTQ && (c->last_kernel_flags & STRICT_FASTQ_FLAGS))) {
+        const std::string msg = c->last_error;
+        const int rc0 = rc;
         const uint8_t* d2 = nullptr;
         size_t n2 = 0;
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
         rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
-        if (rc != BSK_OK) return rc;
+        if (rc != BSK_OK) {
+            if (rc0 != BSK_ERR_MULTILINE_FASTQ) { c->set_error(msg); return rc0; }
+            return rc;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
         c->norm_active = true;
         rc = build_index(c, d2, n2, format, st);
         c->norm_active = false;
+        if (rc != BSK_OK) return rc;
+        HIP_TRY(c, hipStreamSynchronize(st));
+        HIP_TRY(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        rc = kernel_error_to_status(c, status);
     }
-    if (rc != BSK_OK) return rc;
-    HIP_TRY(c, hipStreamSynchronize(st));
-    uint64_t status = 0;
-    HIP_TRY(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
-    rc = kernel_error_to_status(c, status);
     if (rc != BSK_OK) return rc;
     if (n_records) *n_records = c->table.n;
     return BSK_OK;
@@ -868,10 +943,18 @@ int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int 
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    {
-        const int rcm = concat_run_device(c, d, n, n_first, format, st, out);
-        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
-    }
+    c->last_kernel_flags = 0;
+    const int rcm = concat_run_device(c, d, n, n_first, format, st, out);
+    if (!wants_multiline(c, rcm, format)) return rcm;
+    const std::string msg = c->last_error;
+    const uint8_t* d2 = nullptr;
+    std::vector<uint64_t> e2;
+    rc = normalize_pieces(c, d, {(uint64_t)n_first, (uint64_t)n}, st, &d2, &e2);
+    if (rc != BSK_OK) { if (rcm != BSK_ERR_MULTILINE_FASTQ) { c->set_error(msg); return rcm; } return rc; }
+    c->norm_active = true;
+    rc = concat_run_device(c, d2, e2[1], e2[0], format, st, out);
+    c->norm_active = false;
+    return rc;
 }
 
 int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file_ends, uint32_t n_files, int on_device,
@@ -886,10 +969,18 @@ int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    {
-        const int rcm = common_run_device(c, d, n, file_ends, n_files, format, st, out);
-        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
-    }
+    c->last_kernel_flags = 0;
+    const int rcm = common_run_device(c, d, n, file_ends, n_files, format, st, out);
+    if (!wants_multiline(c, rcm, format)) return rcm;
+    const std::string msg = c->last_error;
+    const uint8_t* d2 = nullptr;
+    std::vector<uint64_t> e2;
+    rc = normalize_pieces(c, d, std::vector<uint64_t>(file_ends, file_ends + n_files), st, &d2, &e2);
+    if (rc != BSK_OK) { if (rcm != BSK_ERR_MULTILINE_FASTQ) { c->set_error(msg); return rcm; } return rc; }
+    c->norm_active = true;
+    rc = common_run_device(c, d2, e2.back(), e2.data(), n_files, format, st, out);
+    c->norm_active = false;
+    return rc;
 }
 
 int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
@@ -903,10 +994,18 @@ int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
-    {
-        const int rcm = pair_run_device(c, d, n, n_first, format, st, outs);
-        return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
-    }
+    c->last_kernel_flags = 0;
+    const int rcm = pair_run_device(c, d, n, n_first, format, st, outs);
+    if (!wants_multiline(c, rcm, format)) return rcm;
+    const std::string msg = c->last_error;
+    const uint8_t* d2 = nullptr;
+    std::vector<uint64_t> e2;
+    rc = normalize_pieces(c, d, {(uint64_t)n_first, (uint64_t)n}, st, &d2, &e2);
+    if (rc != BSK_OK) { if (rcm != BSK_ERR_MULTILINE_FASTQ) { c->set_error(msg); return rcm; } return rc; }
+    c->norm_active = true;
+    rc = pair_run_device(c, d2, e2[1], e2[0], format, st, outs);
+    c->norm_active = false;
+    return rc;
 }
 
 int bsk_faidx_query_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

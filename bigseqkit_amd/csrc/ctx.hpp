@@ -121,6 +121,9 @@ struct bsk_ctx {
     uint64_t seg_src_cap = 0;
     uint32_t* d_seg_first = nullptr;    // ... and the segment of the first byte of every 4 KiB output tile
     uint64_t seg_first_cap = 0;
+    uint8_t* d_norm2 = nullptr;         // several rewritten FASTQ texts back to back (pair / common / concat on multi-line FASTQ)
+    uint64_t norm2_cap = 0;
+    uint64_t last_kernel_flags = 0;     // what kernel_error_to_status saw last (the strict FASTQ reader's complaints send a shard to the multi-line reader)
     uint8_t* d_slices = nullptr;        // per-range output slices of the names pass (stream_names.hip)
     uint64_t slices_cap = 0;
     uint64_t* d_names_aux = nullptr;    // [2 * (nranges + 2)]: bytes per range, scanned record counts

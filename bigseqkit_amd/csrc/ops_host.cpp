@@ -114,6 +114,7 @@ int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const 
 
 
 int kernel_error_to_status(bsk_ctx* c, uint64_t f) {
+    c->last_kernel_flags = f;
     if (!f) return BSK_OK;
     int code = BSK_ERR_FORMAT;
     std::string m;
@@ -2970,9 +2971,13 @@ struct DevFree {
 
 // the shard rewritten as strict 4-line FASTQ into c->d_norm (ops_mlfq.hip).  A rare path: scratch is allocated and
 // freed per call (about 0.6 bytes per input byte for text wrapped at 60 columns).
+// d_out == null: no text is written -- c->table gets the records of the text AS THEY STAND (start[] only: what the
+// operators that print a record's text need, range / head / duplicate) and *n_out the byte behind the last record.
 int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out) {
-    *d_out = d_buf;
+    const bool starts_only = d_out == nullptr;
+    if (d_out) *d_out = d_buf;
     *n_out = n;
+    if (starts_only) c->table.n = 0;
     if (n == 0) return BSK_OK;
     DevFree F;
     const uint64_t nb = mlfq_blocks(n);
@@ -3042,6 +3047,33 @@ int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStr
     HIP_TRYX(c, F.alloc(&d_off, nrec + 1));
     HIP_TRYX(c, F.alloc(&d_tmp3, 2 * ((nrec + 2047) / 2048) + 4));
     HIP_TRYX(c, launch_mlfq_list(d_ls, L, S, d_rank, d_rec, d_len, st));
+    if (starts_only) {
+        HIP_TRYX(c, hipMemcpyAsync(&status, S.status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (status) return format_error(status);
+        RecordTable& t = c->table;
+        if (nrec + 1 > t.cap || !t.start) {
+            for (void* q : {(void*)t.start, (void*)t.l_head, (void*)t.l_seq, (void*)t.aux, (void*)t.text_w})
+                if (q) HIP_TRYX(c, hipFree(q));
+            t = RecordTable();
+            const uint64_t cap = nrec + nrec / 8 + 16;
+            HIP_TRYX(c, hipMalloc((void**)&t.start, (cap + 1) * sizeof(uint64_t)));
+            HIP_TRYX(c, hipMalloc((void**)&t.l_head, cap * sizeof(uint32_t)));
+            HIP_TRYX(c, hipMalloc((void**)&t.l_seq, cap * sizeof(uint32_t)));
+            HIP_TRYX(c, hipMalloc((void**)&t.aux, cap * sizeof(uint32_t)));
+            HIP_TRYX(c, hipMalloc((void**)&t.text_w, cap * sizeof(uint32_t)));
+            t.cap = cap;
+        }
+        t.n = nrec;
+        uint64_t end = n;
+        if (nrec) {
+            HIP_TRYX(c, launch_mlfq_starts(d_ls, S, d_rec, nrec, n, t.start, st));
+            HIP_TRYX(c, hipMemcpyAsync(&end, t.start + nrec, sizeof end, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRYX(c, hipStreamSynchronize(st));  // the scratch is freed on return
+        *n_out = end;
+        return BSK_OK;
+    }
     uint64_t total = 0;
     if (nrec) {
         HIP_TRYX(c, launch_scan_u32(d_len, d_off, nrec, d_tmp3, st));

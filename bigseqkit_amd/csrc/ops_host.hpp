@@ -14,6 +14,11 @@ constexpr int BSK_ERR_FILTER_FALLBACK = -1000;
 // (normalize_multiline_fastq) and runs the operator on the 4-line text
 constexpr int BSK_ERR_MULTILINE_FASTQ = -1001;
 bool fastq_head_multiline(const uint8_t* h, size_t hb);
+// kernel flags (stream_stats.hpp) with which the strict 4-line reader gives a FASTQ shard up: bad header 1, bad '+' line 2,
+// unmatched lengths 4, truncated 8, a range that ends inside a record 16 -- a shard wrapped further down than its head
+// raises one of them and is then read by the multi-line reader (c->last_kernel_flags)
+constexpr uint64_t STRICT_FASTQ_FLAGS = 1u | 2u | 4u | 8u | 16u;
+// d_out == null: c->table := where the records of the text begin (start[] only), *n_out := the byte behind the last one
 int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out);
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
 // the record table and, with hash != null (unfiltered FASTQ), the two keys of every record's sequence in c->d_keys / c->d_keys2

@@ -163,21 +163,44 @@ int records_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, h
         P.times = 1;
     }
     int rc = build_index(c, d_buf, n, format, st);
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    rc = ensure_record_scratch(c);
-    if (rc != BSK_OK) return rc;
-    HIP_TRYX(c, launch_records_size(d_buf, n, c->table, P, c->d_out_len, c->d_status, st));
-    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
     uint64_t total = 0, kept = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&kept, c->d_counter, sizeof kept, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    rc = kernel_error_to_status(c, status);
-    if (rc != BSK_OK) return rc;
+    for (int attempt = 0;; ++attempt) {
+        if (P.fastq && !c->norm_active &&
+            (rc == BSK_ERR_MULTILINE_FASTQ || (rc != BSK_OK && (c->last_kernel_flags & STRICT_FASTQ_FLAGS)))) {
+            // FASTQ records on more than four lines (helper.go:252-269; at the head of the shard, or -- the strict reader
+            // complained -- further down): these operators print the record TEXT, wrapped as it stands, so the multi-line
+            // reader only says where the records begin and the text leaves like FASTA text does: from one record start to
+            // the next, minus the final newline
+            const std::string msg = c->last_error;
+            const int rc0 = rc;
+            size_t n_eff = n;
+            HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+            rc = normalize_multiline_fastq(c, d_buf, n, st, nullptr, &n_eff);
+            if (rc != BSK_OK) {
+                if (rc0 != BSK_ERR_MULTILINE_FASTQ) { c->set_error(msg); return rc0; }  // (not FASTQ either way: the first complaint stands)
+                return rc;
+            }
+            P.fastq = 0;
+            n = n_eff;
+        }
+        if (rc != BSK_OK) return rc;
+        if (c->table.n == 0) return empty_result(c, out);
+        rc = ensure_record_scratch(c);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_records_size(d_buf, n, c->table, P, c->d_out_len, c->d_status, st));
+        HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
+        HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
+        HIP_TRYX(c, hipMemcpyAsync(&total, c->d_out_off + c->table.n, sizeof total, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipMemcpyAsync(&kept, c->d_counter, sizeof kept, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        rc = kernel_error_to_status(c, status);
+        // (the index pass leaves its complaints in the status word: a shard that is wrapped behind its head is seen here)
+        if (rc != BSK_OK && attempt == 0 && P.fastq && !c->norm_active && (status & STRICT_FASTQ_FLAGS)) continue;
+        if (rc != BSK_OK) return rc;
+        break;
+    }
     out->d_data = nullptr;
     out->len = 0;
     out->records = 0;

@@ -230,4 +230,27 @@ hipError_t launch_mlfq_emit(const uint8_t* buf, const uint64_t* ls, const MlfqSc
     return hipGetLastError();
 }
 
+namespace {
+// start[r] = first byte of record r; start[nrec] = first byte behind the last record's text (its final newline included)
+__global__ __launch_bounds__(256) void k_mlfq_starts(const uint64_t* __restrict__ ls, const uint32_t* __restrict__ rec_line,
+                                                     const uint32_t* __restrict__ next, uint64_t nrec, uint64_t n,
+                                                     uint64_t* __restrict__ start) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint32_t l0 = rec_line[r];
+    start[r] = ls[l0];
+    if (r + 1 == nrec) {
+        const uint64_t e = ls[next[l0]];  // (n + 1 for a last line without a newline)
+        start[nrec] = e < n ? e : n;
+    }
+}
+}  // namespace
+
+hipError_t launch_mlfq_starts(const uint64_t* ls, const MlfqScratch& S, const uint32_t* rec_line, uint64_t nrec, uint64_t n,
+                              uint64_t* start, hipStream_t st) {
+    if (nrec == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mlfq_starts, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, ls, rec_line, S.next, nrec, n, start);
+    return hipGetLastError();
+}
+
 }  // namespace bsk

@@ -29,4 +29,8 @@ hipError_t launch_mlfq_list(const uint64_t* ls, uint32_t L, const MlfqScratch& S
 hipError_t launch_mlfq_emit(const uint8_t* buf, const uint64_t* ls, const MlfqScratch& S, const uint32_t* rec_line,
                             const uint64_t* out_off, uint64_t nrec, uint8_t* out, hipStream_t st);
 
+// the records of the text as they stand: start[r] = first byte of record r, start[nrec] = the byte behind the last record
+hipError_t launch_mlfq_starts(const uint64_t* ls, const MlfqScratch& S, const uint32_t* rec_line, uint64_t nrec, uint64_t n,
+                              uint64_t* start, hipStream_t st);
+
 }  // namespace bsk

@@ -51,7 +51,7 @@ def test_bench_ops_object_small():
     d = run_bench(["--gb", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ops-scale", "0.02", "--ops-calls", "2"])
     ops = d["ops"]
     assert "error" not in ops, ops
-    assert set(ops) == {"seq -n @ C2", "grep -s -p @ C3 shard", "translate -f 6 @ C4", "rmdup -s @ C5 shard"}
+    assert set(ops) == {"seq -n @ C2", "subseq -r 1:50 (25 GB)", "grep -s -p @ C3 shard", "translate -f 6 @ C4", "rmdup -s @ C5 shard"}
     for name, e in ops.items():
         assert e["exact"] is True, (name, e)
         assert e["ms"] > 0 and e["algorithmic_bytes"] >= e["in_bytes"] and 0 < e["frac"] < 1, (name, e)

@@ -130,13 +130,54 @@ def test_malformed_multiline_fastq_is_an_error():
         assert e.value.code in (_lib.BSK_ERR_FORMAT, _lib.BSK_ERR_UNSUPPORTED)
 
 
-def test_range_on_multiline_fastq_is_refused():
-    # range / head / duplicate print the record TEXT (wrapped as it is): not served by the 4-line rewrite
-    rng = random.Random(3300)
-    data = wrapped_fastq(rng, 50, 9)
+@pytest.mark.parametrize("seed,width", [(0, 7), (1, 60), (2, 1)])
+def test_record_text_operators_on_multiline_fastq(seed, width, monkeypatch):
+    # range / head / duplicate print the record TEXT, wrapped as it stands (bigseqkit-lib/range.go, duplicate.go:22-29): the
+    # multi-line reader says where the records begin, the text leaves verbatim
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "2048")
+    rng = random.Random(3300 + seed)
+    data = wrapped_fastq(rng, 300, width, final_newline=seed != 1, trailing_blank=2 if seed == 2 else 0)
+    assert not oracle.is_strict_4line_fastq(data)
+    assert bsk.Head(frame(data), _Opts({"N": 7})) == oracle.head(data, True, '{"N": 7}')
+    for r in ("1:12", "5:9", "-20:-1", "250:400"):
+        assert bsk.Range(frame(data), _Opts({"Range": r})) == oracle.range_(data, True, json.dumps({"Range": r})), r
+    for times in (1, 2, 3, 7):
+        assert bsk.Duplicate(frame(data), _Opts({"Times": times})) == oracle.duplicate(data, True, json.dumps({"Times": times})), times
+
+
+def test_records_wrapped_only_further_down(monkeypatch):
+    # the head of the shard (what the reader is chosen from) is 4-line FASTQ, the records behind it are wrapped: the strict
+    # reader gives up, the multi-line reader takes the shard
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(3400)
+    plain = "".join("@p%d\n%s\n+\n%s\n" % (i, "ACGT" * 20, "IIII" * 20) for i in range(5000)).encode()   # > 256 KiB
+    assert len(plain) > 300 * 1024
+    data = plain + wrapped_fastq(rng, 200, 11)
+    assert run("seq", frame(data), {}) == oracle.seq(data, True, "{}")
+    assert run("grep", frame(data), {"Pattern": ["ACG"], "BySeq": True}) == oracle.grep(data, True, '{"Pattern": ["ACG"], "BySeq": true}')
+    assert bsk.Head(frame(data), _Opts({"N": 5100})) == oracle.head(data, True, '{"N": 5100}')
+    assert bsk.Range(frame(data), _Opts({"Range": "-50:-1"})) == oracle.range_(data, True, '{"Range": "-50:-1"}')
+    # a shard that is FASTQ under neither reader keeps the strict reader's complaint
+    bad = plain + b"@x\nACGT\n+\nIII\n"
     with pytest.raises(bsk.BskError) as e:
-        bsk.Head(frame(data), _Opts({"N": 3}))
-    assert e.value.code == _lib.BSK_ERR_UNSUPPORTED
+        run("seq", frame(bad), {})
+    assert "unmatched length" in str(e.value)
+
+
+def test_two_input_operators_on_multiline_fastq(monkeypatch):
+    # pair / common / concat read several texts: every text is rewritten by itself
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "2048")
+    rng = random.Random(3500)
+    a = wrapped_fastq(rng, 120, 9)
+    # a second file with (mostly) the same IDs on four lines each
+    b4 = "".join("@r%d%s\n%s\n+\n%s\n" % (i, " mate" if i % 3 else "", "ACGTN"[i % 5] * (i % 40), "I" * (i % 40))
+                 for i in range(0, 150, 1) if i % 7).encode()
+    assert oracle.is_strict_4line_fastq(b4) and not oracle.is_strict_4line_fastq(a)
+    fa, fb = frame(a), frame(b4)
+    for x, y, xd, yd in ((fa, fb, a, b4), (fb, fa, b4, a), (fa, fa, a, a)):
+        assert bsk.Common(x, y, _Opts({})) == oracle.common([xd, yd], True, "{}")
+        assert bsk.Concat(x, y, _Opts({})) == oracle.concat(xd, yd, True, "{}")
+        assert tuple(bsk.Pair(x, y, _Opts({"SaveUnpaired": True}))) == tuple(oracle.pair(xd, yd, True, '{"SaveUnpaired": true}'))
 
 
 def test_file_to_file_pipeline_on_multiline_fastq(tmp_path):
