@@ -49,7 +49,12 @@ hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, 
 // that do not are listed in ovf[1..] (ovf[0] = their number, zeroed by the caller; entries beyond ovf_cap are dropped)
 hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
                                 uint64_t* status, hipStream_t st, const uint64_t* k2 = nullptr, uint32_t* ovf = nullptr,
-                                uint32_t ovf_cap = 0);
+                                uint32_t ovf_cap = 0, bool have_bstart = false /* bstart comes from launch_bucket_pass */);
+// the pairs (key, record) of keys[0, n) by bucket (key & 0xFFFF), in no particular order inside a bucket: a 16-bit histogram
+// (hist: 65 536 words of scratch, zero again afterwards), its prefix sums (bstart: 65 537 words) and one scatter;
+// first[i] := i on the way.  n < 2^32.
+hipError_t launch_bucket_pass(const uint64_t* keys, uint64_t n, uint32_t* hist, uint32_t* bstart, uint32_t* first, uint64_t* skeys,
+                              uint32_t* sidx, hipStream_t st);
 // out_len[i] = formatted size of record i if first[i] == i, else 0 (the keys decided; no text is read)
 hipError_t launch_rmdup_sizes(const RecordTable& t, const RmDupParams& P, const uint32_t* first, uint32_t* out_len, hipStream_t st);
 // out[2 j], out[2 j + 1] = k1, k2 of record list[j];  dst[idx[j]] = val[j]

@@ -146,6 +146,25 @@ def test_distinct_sequences_under_one_key_are_kept_apart(bits, fold, monkeypatch
     assert run_rmdup(data, opts) == want
 
 
+@pytest.mark.parametrize("keys", ["", "off"])
+def test_bucket_pass_by_hand_equals_the_library_sort(keys, monkeypatch):
+    """BSK_RMDUP_BUCKETS=hand: one 16-bit histogram + an unstable scatter instead of rocPRIM's two digit passes (slower, kept
+    as a measurement: ops_rmdup.hip) -- the LDS tables take a bucket's pairs in any order, so the answer is the same"""
+    rng = random.Random(4242)
+    uniq = [rand_seq(rng, rng.choice((36, 150, 151))) for _ in range(3000)]
+    seqs = uniq + [rng.choice(uniq) for _ in range(1500)]
+    rng.shuffle(seqs)
+    data = fastq_of(seqs, rng)
+    if keys:
+        monkeypatch.setenv("BSK_RMDUP_KEYS", keys)
+    want = oracle.rmdup(data, True, '{"BySeq": true}')
+    assert run_rmdup(data, {"BySeq": True}) == want
+    monkeypatch.setenv("BSK_RMDUP_BUCKETS", "hand")
+    assert run_rmdup(data, {"BySeq": True}) == want
+    assert bsk.RmDup(bsk.SeqFrame(bsk.FORMAT_FASTQ, [data]), type("O", (), {"to_json": lambda self: '{"ByName": true}'})()) == \
+        oracle.rmdup(data, True, '{"ByName": true}')
+
+
 def test_key_path_equals_byte_path_on_c5_layout(monkeypatch):
     import torch
     rb, nrec = 317, 400_000
