@@ -458,12 +458,7 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
         bsk_out o;
         memset(&o, 0, sizeof o);
         rc = fn(c, c->d_stage[b], cuts[i + 1] - cuts[i], format, st, &o);
-        if (rc == BSK_ERR_MULTILINE_FASTQ) {
-            if (c->op == Op::Range || c->op == Op::Head || c->op == Op::Duplicate) {
-                c->set_error("libbsk: multi-line FASTQ is not provided for range / head / duplicate (they print the record text as it is)");
-                rc = BSK_ERR_UNSUPPORTED;
-                break;
-            }
+        if (rc == BSK_ERR_MULTILINE_FASTQ) {  // (range / head / duplicate deal with wrapped records themselves: records_run_device)
             const uint8_t* d2 = nullptr;
             size_t n2 = 0;
             rc = normalize_multiline_fastq(c, c->d_stage[b], cuts[i + 1] - cuts[i], st, &d2, &n2);

@@ -195,3 +195,21 @@ def test_file_to_file_pipeline_on_multiline_fastq(tmp_path):
     tot = C.c_uint64()
     _lib.check(_lib.lib.bsk_store_close(st, C.byref(tot)))
     assert out.read_bytes() == want
+
+
+def test_file_to_file_duplicate_on_multiline_fastq(tmp_path):
+    # the record-text operators through the chunked pipeline: the wrapped shard goes as one piece, the text verbatim
+    import ctypes as C
+    rng = random.Random(3600)
+    data = wrapped_fastq(rng, 500, 13)
+    want = oracle.duplicate(data, True, '{"Times": 2}')
+    out = tmp_path / "d.fq"
+    st = C.c_void_p()
+    _lib.check(_lib.lib.bsk_store_open(str(out).encode(), 1, C.byref(st)))
+    with bsk.Operator("Duplicate", '{"Times": 2}', 0) as op:
+        b = C.create_string_buffer(data, len(data))
+        nb, nr = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib.bsk_run_to_store(op.ctx, b, len(data), bsk.FORMAT_FASTQ, 0, st, 0, C.byref(nb), C.byref(nr)), op.ctx)
+    tot = C.c_uint64()
+    _lib.check(_lib.lib.bsk_store_close(st, C.byref(tot)))
+    assert out.read_bytes() == want
