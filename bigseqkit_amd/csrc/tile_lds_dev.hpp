@@ -66,8 +66,23 @@ struct TileLds {
     __device__ __forceinline__ uint32_t addr(int32_t so) const { return tb + CARRY + (uint32_t)so; }
 };
 
+// gfx950 takes LDS accesses of any alignment in ONE instruction (measured for ds_write_b128 in
+// scripts/experiments/probe_lds_realign.hip; the parity tests of the sinks below hold the reads): BSK_LDS_UNALIGNED=0 keeps
+// the round-2 composition from aligned dwords and v_alignbyte (9 instructions per 16 bytes instead of one)
+#ifndef BSK_LDS_UNALIGNED
+#define BSK_LDS_UNALIGNED 1
+#endif
+typedef __attribute__((address_space(3))) u32x4 __attribute__((aligned(1))) lds_u32x4_any;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 __attribute__((aligned(1))) lds_u32x2_any;
+
 // 8 / 4 bytes at LDS byte address a (any alignment; reads whole dwords up to a + 11)
 __device__ __forceinline__ void lds_ld64(uint32_t a, uint32_t& lo, uint32_t& hi) {
+#if BSK_LDS_UNALIGNED
+    const u32x2 v = *(lds_u32x2_any*)(uintptr_t)a;
+    lo = v.x; hi = v.y;
+    return;
+#endif
     const uint32_t a4 = a & ~3u;
     const uint32_t d0 = lds_r32(a4), d1 = lds_r32(a4 + 4u), d2 = lds_r32(a4 + 8u);
     lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
@@ -75,6 +90,11 @@ __device__ __forceinline__ void lds_ld64(uint32_t a, uint32_t& lo, uint32_t& hi)
 }
 // 16 bytes at LDS byte address a (any alignment; reads whole dwords up to a + 19)
 __device__ __forceinline__ void lds_ld128(uint32_t a, uint32_t (&w)[4]) {
+#if BSK_LDS_UNALIGNED
+    const u32x4 v = *(lds_u32x4_any*)(uintptr_t)a;
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    return;
+#endif
     const uint32_t a4 = a & ~3u, sh = a & 3u;
     const uint32_t d0 = lds_r32(a4), d1 = lds_r32(a4 + 4u), d2 = lds_r32(a4 + 8u), d3 = lds_r32(a4 + 12u), d4 = lds_r32(a4 + 16u);
     w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
