@@ -411,7 +411,17 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
         c->first_format = format;
         c->fastq_multiline = format == BSK_FORMAT_FASTQ && fastq_head_multiline(c->first_bytes.data(), c->first_bytes.size());
     }
-    if (c->fastq_multiline && format == BSK_FORMAT_FASTQ) {
+    // every shard is judged by its OWN head (round 2 took the verdict of the lowest-pid shard for all of them: a wrapped
+    // shard behind a 4-line one was an error at collect time); the first shard's head is at hand already
+    bool wrapped = c->fastq_multiline && pid == c->first_pid;
+    if (format == BSK_FORMAT_FASTQ && pid != c->first_pid) {
+        const size_t hb = std::min<size_t>(n, 256 * 1024);
+        std::vector<uint8_t> head(hb);
+        if (on_device) HIP_TRY(c, hipMemcpy(head.data(), shard, hb, hipMemcpyDeviceToHost));
+        else memcpy(head.data(), shard, hb);
+        wrapped = fastq_head_multiline(head.data(), hb);
+    }
+    if (wrapped && format == BSK_FORMAT_FASTQ) {
         // records wrapped over several lines (helper.go:252-269): the whole shard is rewritten as 4-line FASTQ first
         const uint8_t* d = nullptr;
         int rc = stage_shard(c, shard, n, on_device, st, &d);

@@ -112,6 +112,21 @@ def test_stats_on_multiline_fastq(seed, width):
             assert got == oracle.stats_string(data, True, json.dumps(opts))
 
 
+def test_stats_judges_every_shard_by_its_own_head():
+    # a 4-line shard followed by a wrapped one (and the other way round): each is read by the reader its own head calls for
+    rng = random.Random(3250)
+    plain = "".join("@p%d\n%s\n+\n%s\n" % (i, "ACGTN" * (i % 9), "IIIII" * (i % 9)) for i in range(300)).encode()
+    wrapped = wrapped_fastq(rng, 300, 9)
+    for a, b in ((plain, wrapped), (wrapped, plain)):
+        for opts in ({"All": True}, {}):
+            o = bsk.SeqKitStatsOptions()
+            for kk, v in opts.items():
+                getattr(o, kk)(v)
+            for on_device in (True, False):
+                fr = bsk.SeqFrame(bsk.FORMAT_FASTQ, [dev(a), dev(b)] if on_device else [a, b])
+                assert bsk.StatsString("input0", "N/A", fr, o) == oracle.stats_string(a + b, True, json.dumps(opts))
+
+
 def test_multiline_head_example_from_the_parser():
     data = b"@a\nACGT\nAC\n+\nIIII\nII\n@b desc\nA\nC\nG\n+b\n@\n+\nI\n"
     assert run("seq", frame(data), {}) == oracle.seq(data, True, "{}") == b"@a\nACGTAC\n+\nIIIIII\n@b desc\nACG\n+\n@+I\n"
