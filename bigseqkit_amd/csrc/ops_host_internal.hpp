@@ -77,6 +77,15 @@ int id_mode_of(const bsk_ctx* c);
 int id_spans(bsk_ctx* c, const uint8_t* d_buf, hipStream_t st);
 // the context's feature set (ctx.features) uploaded and bound to P: name lookup, regions, suffixes, complement map
 int bind_features(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, SeqParams* P);
+// helpers shared by the per-operator files (ops_host_search / subseq / translate / rmdup / seq .cpp)
+bool has_unquoted_comma(const std::string& p);
+extern const char* const HELP_UNQUOTED_COMMA;
+void parse_region_opt(const std::string& region, const char* cmd, int* start, int* end);  // reRegion + the range checks of Before()
+// ranges of the streaming kernels for a shard: anchors in c->d_anchors (k_prep), the work queue behind them
+int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, int blocks, hipStream_t st, uint32_t* nranges_out,
+                uint64_t* chunk_out);
+const char* alphabet_letters(Alphabet a);
+void complement_table(Alphabet ab, uint8_t m[256]);
 // lines of a text file ("\r\n" trimmed, empty lines skipped): pattern files, region files
 std::vector<std::string> read_pattern_lines(const std::string& path);
 

@@ -1,0 +1,476 @@
+// Host side of `rmdup` (RmDupPrepare / RmDupCheck, /root/reference/bigseqkit-lib/rmdup.go) and of its multi-GPU phases.
+// (split off ops_host.cpp in round 3; shared helpers: ops_host_internal.hpp)  C-ABI in include/bsk.h.
+#include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
+#include <cerrno>
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/bsk.h"
+#include "ctx.hpp"
+#include "ops_host.hpp"
+#include "ops_host_internal.hpp"
+#include "ops_concat.hpp"
+#include "ops_faidx.hpp"
+#include "ops_grep.hpp"
+#include "ops_group.hpp"
+#include "ops_locate.hpp"
+#include "ops_mlfq.hpp"
+#include "ops_records.hpp"
+#include "ops_rmdup.hpp"
+#include "ops_text.hpp"
+#include "ops_translate.hpp"
+#include "ops_segcopy.hpp"
+#include "ops_seq.hpp"
+#include "ops_sort.hpp"
+#include "stream_fasta_light.hpp"
+#include "stream_filter.hpp"
+#include "stream_names.hpp"
+#include "stream_subseq.hpp"
+#include "stream_rmdup.hpp"
+#include "stream_stats.hpp"
+
+namespace bsk {
+
+// ---------------------------------------------------------------------------
+// rmdup  (bigseqkit/rmdup.go:70-108 + bigseqkit-lib/rmdup.go)
+// ---------------------------------------------------------------------------
+void validate_rmdup_opts(bsk_ctx* c) {
+    const Options& o = c->opts;
+    c->alphabet = alphabet_from_seqtype(o.cs("SeqType"));
+    check_id_regexp(c);
+    if (o.b("BySeq") && o.b("ByName"))  // bigseqkit/rmdup.go:79-81
+        throw OptError("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
+    if (o.b("OnlyPositiveStrand") && !o.b("BySeq"))  // :83-85
+        throw OptError("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
+}
+
+// RmDupCheck.After (rmdup.go:244-279) with the swapped directory names of Q9 put right: the removed records go to
+// <DupSeqsFile>/<executor id>, the duplicate-number lines to <DupNumFile>/<executor id>; nothing is written when no
+// record was removed.  The executor id is the device index of the context.
+int rmdup_finish(bsk_ctx* c) {
+    if (c->side_written) return BSK_OK;
+    c->side_written = true;
+    if (c->removed == 0) return BSK_OK;
+    const Options& o = c->opts;
+    auto write = [&](const std::string& dir, const std::string& text) -> int {
+        if (dir.empty()) return BSK_OK;
+        std::string acc;
+        for (size_t i = 0; i <= dir.size(); ++i) {  // os.MkdirAll
+            if (i == dir.size() || dir[i] == '/') {
+                if (!acc.empty() && mkdir(acc.c_str(), 0777) != 0 && errno != EEXIST) {
+                    c->set_error("mkdir " + acc + ": " + strerror(errno));
+                    return BSK_ERR_INVALID_ARG;
+                }
+            }
+            if (i < dir.size()) acc.push_back(dir[i]);
+        }
+        const std::string path = dir + "/" + std::to_string(c->device < 0 ? 0 : c->device);
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) { c->set_error("open " + path + ": " + strerror(errno)); return BSK_ERR_INVALID_ARG; }
+        const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+        fclose(f);
+        if (!ok) { c->set_error("write " + path + " failed"); return BSK_ERR_INVALID_ARG; }
+        return BSK_OK;
+    };
+    int rc = write(o.s("DupSeqsFile"), c->dup_seqs);
+    if (rc != BSK_OK) return rc;
+    return write(o.s("DupNumFile"), c->dup_nums);
+}
+
+// The records dedupe left in the overflow list (ops_rmdup.hip: same XXH64 key as an earlier record, another second key):
+// groups of equal (k1, k2) among them keep their lowest record, exactly as the map of RmDupCheck.Call would
+// (rmdup.go:150-199) -- a few records per 10^4 shards, settled on the host.  BSK_ERR_FILTER_FALLBACK: the list did not fit.
+static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st) {
+    uint32_t m = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&m, c->d_ovf, sizeof m, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (m == 0) return BSK_OK;
+    if ((uint64_t)m + 1 > c->ovf_cap) return BSK_ERR_FILTER_FALLBACK;
+    uint64_t* d_kk = nullptr;
+    uint32_t* d_patch = nullptr;
+    HIP_TRYX(c, hipMalloc((void**)&d_kk, (size_t)m * 16));
+    std::vector<uint32_t> idx(m);
+    std::vector<uint64_t> kk(2 * (size_t)m);
+    int rc = BSK_OK;
+    do {
+        if (launch_gather_keys(c->d_ovf + 1, m, c->d_keys, c->d_keys2, d_kk, st) != hipSuccess ||
+            hipMemcpyAsync(idx.data(), c->d_ovf + 1, (size_t)m * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(kk.data(), d_kk, (size_t)m * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+        std::vector<uint32_t> order(m);
+        for (uint32_t j = 0; j < m; ++j) order[j] = j;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            if (kk[2 * a] != kk[2 * b]) return kk[2 * a] < kk[2 * b];
+            if (kk[2 * a + 1] != kk[2 * b + 1]) return kk[2 * a + 1] < kk[2 * b + 1];
+            return idx[a] < idx[b];
+        });
+        std::vector<uint32_t> pi, pv;  // first[pi] := pv
+        for (uint32_t j = 0; j < m;) {
+            uint32_t e = j + 1;
+            while (e < m && kk[2 * order[e]] == kk[2 * order[j]] && kk[2 * order[e] + 1] == kk[2 * order[j] + 1]) ++e;
+            for (uint32_t q = j + 1; q < e; ++q) { pi.push_back(idx[order[q]]); pv.push_back(idx[order[j]]); }
+            j = e;
+        }
+        if (pi.empty()) break;
+        const size_t pm = pi.size();
+        if (hipMalloc((void**)&d_patch, pm * 8) != hipSuccess ||
+            hipMemcpyAsync(d_patch, pi.data(), pm * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_patch + pm, pv.data(), pm * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            launch_scatter_u32(d_patch, d_patch + pm, (uint32_t)pm, d_first, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+    } while (false);
+    if (d_kk) hipFree(d_kk);
+    if (d_patch) hipFree(d_patch);
+    if (rc != BSK_OK) c->set_error("libbsk: rmdup: settling the overflow list failed on the device");
+    return rc;
+}
+
+int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
+    const Options& o = c->opts;
+    const bool fastq = format == BSK_FORMAT_FASTQ;
+    // `-s` on FASTQ: the index pass also hashes (stream_rmdup.hip) and the two keys decide (hash_dev.hpp); everything else
+    // (names, IDs, FASTA), BSK_RMDUP=table and BSK_RMDUP_KEYS=off take the separate hash kernel and compare the bytes
+    bool by_keys = fastq && o.b("BySeq");
+    bool verify_bytes = false;
+    uint32_t k1_bits = 64;
+    {
+        const char* e = c->tune.get("rmdup");
+        if (e && strcmp(e, "table") == 0) by_keys = false;
+        e = c->tune.get("rmdup_keys");
+        if (e && strcmp(e, "off") == 0) by_keys = false;
+        if (e && strcmp(e, "verify") == 0) verify_bytes = true;  // keys decide, the bytes of every duplicate are compared on top
+        e = c->tune.get("rmdup_k1_bits");                         // tests: keep only the low bits of k1 (forces the overflow list)
+        if (e && atoi(e) >= 16 && atoi(e) < 64) k1_bits = (uint32_t)atoi(e);
+    }
+    int rc;
+    if (by_keys) {
+        const HashReq hq{o.b("IgnoreCase")};
+        rc = build_index_ex(c, d_buf, n, format, st, nullptr, &hq);
+    } else {
+        rc = build_index(c, d_buf, n, format, st);
+    }
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/!fastq && o.b("BySeq"), false, n);  // (see grep: hashed and compared as linear text)
+    if (rc != BSK_OK) return rc;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.by_seq = o.b("BySeq");
+    P.by_name = o.b("ByName");
+    P.ignore_case = o.b("IgnoreCase");
+    P.id_mode = id_mode_of(c);
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = d_buf + n;
+    const uint64_t N = c->table.n;
+    uint64_t cap = 0;
+    uint64_t* tk = nullptr;
+    rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    if (!by_keys) {
+        rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        if (!fastq && P.by_seq && c->flat_long_count) P.hash_long_min = c->flat_long_thresh;  // (listed by prepare_text just above)
+        Timed t(c, "k_rmdup_hash", st);
+        HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
+        HIP_TRYX(c, launch_rmdup_hash_long(d_buf, n, c->table, tt, P, c->d_keys, nullptr, c->d_long_list, c->flat_long_count, st));
+    } else if (k1_bits < 64) {
+        HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << k1_bits) - 1ull, st));
+    }
+    // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
+    // overflows, or with 2^32 records) keeps the one big table in HBM
+    uint32_t* d_first = nullptr;
+    bool by_buckets = N < (1ull << 32);
+    {
+        const char* e = c->tune.get("rmdup");
+        if (e && strcmp(e, "table") == 0) by_buckets = false;
+    }
+    if (by_buckets) {
+        size_t tmp_bytes = 0;
+        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, 16, &tmp_bytes));
+        Arena A;
+        const uint64_t o_sk = A.take(N * 8), o_vi = A.take(N * 4), o_vo = A.take(N * 4), o_first = A.take(N * 4),
+                       o_bs = A.take((65536 + 2) * 4), o_hist = A.take(65536 * 4), o_tmp = A.take(tmp_bytes + 256);
+        rc = arena_reserve(c, &A);
+        if (rc != BSK_OK) return rc;
+        uint64_t* d_sk = A.at<uint64_t>(o_sk);
+        uint32_t* d_vi = A.at<uint32_t>(o_vi);
+        uint32_t* d_vo = A.at<uint32_t>(o_vo);
+        d_first = A.at<uint32_t>(o_first);
+        uint32_t ovf_cap = 0;
+        if (by_keys) {
+            const uint64_t want = std::max<uint64_t>(4096, N / 16) + 1;
+            rc = grow(c, &c->d_ovf, &c->ovf_cap, want, 16);
+            if (rc != BSK_OK) return rc;
+            ovf_cap = (uint32_t)std::min<uint64_t>(c->ovf_cap - 1, 0xFFFFFFFFull);
+            HIP_TRYX(c, hipMemsetAsync(c->d_ovf, 0, sizeof(uint32_t), st));
+        }
+        {
+            Timed t(c, "rmdup_group(sort+dedupe)", st);
+            if (!c->tune.is("rmdup_buckets", "hand")) {  // the device radix sort of the pairs (two 8-bit digit passes: 1.5 ms per 79 M pairs)
+                HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
+                HIP_TRYX(c, launch_sort_iota(d_first, N, st));
+                HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
+                HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
+                                                 by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap));
+            } else {  // one 16-bit histogram + scatter by hand (ops_rmdup.hip): 6.8 ms -- kept for the comparison
+                HIP_TRYX(c, launch_bucket_pass(c->d_keys, N, A.at<uint32_t>(o_hist), A.at<uint32_t>(o_bs), d_first, d_sk, d_vo, st));
+                HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
+                                                 by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap, true));
+            }
+        }
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        if (status & ERR_BUCKET_OVERFLOW) {
+            status &= ~(uint64_t)ERR_BUCKET_OVERFLOW;
+            HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            by_buckets = false;
+        } else if (by_keys) {
+            rc = rmdup_settle_overflow(c, d_first, st);
+            if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;  // (the list did not fit: the table path compares bytes)
+            else if (rc != BSK_OK) return rc;
+            else if (verify_bytes) {
+                Timed t(c, "k_rmdup_resolve", st);
+                HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
+            } else {
+                Timed t(c, "k_rmdup_sizes", st);
+                HIP_TRYX(c, launch_rmdup_sizes(c->table, P, d_first, c->d_out_len, st));
+            }
+        } else {
+            Timed t(c, "k_rmdup_resolve", st);
+            HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
+        }
+    }
+    if (!by_buckets) {
+        if (by_keys && k1_bits < 64) {
+            c->set_error("libbsk: BSK_RMDUP_K1_BITS is a test switch of the key path; the table path needs whole keys");
+            return BSK_ERR_INVALID_ARG;
+        }
+        rc = key_table(c, N, &cap, &tk, st);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
+        HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
+    }
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc == BSK_OK) {
+        uint64_t status = 0;
+        HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        if (status & ERR_HASH_COLLISION) {
+            c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
+            return BSK_ERR_UNSUPPORTED;
+        }
+    }
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    SeqParams F = format_params(c, fastq);
+    if (!fastq && tt.text_w == c->d_text_w) {  // back to the views for the emit (and the side files)
+        rc = prepare_text(c, d_buf, format, st, &tt, false, /*keep_out_len=*/true);
+        if (rc != BSK_OK) return rc;
+    }
+    F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
+    apply_long(c, &F);
+    { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    if (!o.s("DupSeqsFile").empty() || !o.s("DupNumFile").empty()) {
+        // side outputs, after the main emit on the same stream (d_out_len / d_out_off are free again)
+        c->removed += N - kept;
+        c->side_written = false;
+        uint8_t* d_has = nullptr;
+        uint32_t* d_row_len = nullptr;
+        uint64_t* d_row_off = nullptr;
+        uint8_t* d_side = nullptr;
+        auto cleanup = [&]() {
+            for (void* p : {(void*)d_has, (void*)d_row_len, (void*)d_row_off, (void*)d_side}) if (p) hipFree(p);
+        };
+        int src = BSK_OK;
+        do {
+            if (hipMalloc((void**)&d_has, N) != hipSuccess || hipMalloc((void**)&d_row_len, N * 4) != hipSuccess ||
+                hipMalloc((void**)&d_row_off, (N + 1) * 8) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (hipMemsetAsync(d_has, 0, N, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (by_buckets) {  // keys[i] := survivor of record i, has_dup[survivor] := 1, from first[] (d_out_len is scratch here)
+                if (launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, c->d_keys, c->d_out_len, c->d_status, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            } else if (launch_rmdup_group(N, c->d_keys, tk, cap, d_has, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_rmdup_side_sizes(d_buf, c->table, P, c->d_keys, d_has, c->d_out_len, d_row_len, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_scan_u32(c->d_out_len, c->d_out_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (launch_scan_u32(d_row_len, d_row_off, N, c->d_scan_tmp, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            uint64_t dup_total = 0, row_total = 0;
+            hipMemcpyAsync(&dup_total, c->d_out_off + N, 8, hipMemcpyDeviceToHost, st);
+            hipMemcpyAsync(&row_total, d_row_off + N, 8, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (hipMalloc((void**)&d_side, std::max<uint64_t>(1, std::max(dup_total, row_total))) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            if (!o.s("DupSeqsFile").empty() && dup_total) {
+                SeqParams F2 = F;  // other sizes than the main output: every record goes through the per-record kernel
+                F2.long_list = nullptr; F2.long_count = 0;
+                if (launch_seq_emit(d_buf, c->table, F2, c->d_out_len, c->d_out_off, d_side, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                const size_t at = c->dup_seqs.size();
+                c->dup_seqs.resize(at + dup_total);
+                if (hipMemcpyAsync(&c->dup_seqs[at], d_side, dup_total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+            }
+            if (!o.s("DupNumFile").empty() && row_total) {
+                if (launch_rmdup_rows(d_buf, c->table, P, c->d_keys, d_row_len, d_row_off, d_side, st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                std::string rows(row_total, '\0');
+                if (hipMemcpyAsync(&rows[0], d_side, row_total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { src = BSK_ERR_HIP; break; }
+                // rows are in file order: group them by survivor, groups in the order of their survivor
+                std::vector<std::pair<uint64_t, std::string>> groups;  // survivor -> "id, id, ..."
+                std::unordered_map<uint64_t, size_t> where;
+                std::vector<uint32_t> count;
+                for (size_t i = 0; i < rows.size();) {
+                    const size_t e = rows.find('\n', i);
+                    const uint64_t g = strtoull(rows.substr(i, 20).c_str(), nullptr, 10);
+                    const std::string id = rows.substr(i + 21, e - i - 21);
+                    auto it = where.find(g);
+                    if (it == where.end()) { where[g] = groups.size(); groups.emplace_back(g, id); count.push_back(1); }
+                    else { groups[it->second].second += ", " + id; ++count[it->second]; }
+                    i = e + 1;
+                }
+                std::vector<size_t> order(groups.size());
+                for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return groups[a].first < groups[b].first; });
+                for (size_t k : order) c->dup_nums += std::to_string(count[k]) + "\t" + groups[k].second + "\n";
+            }
+        } while (false);
+        cleanup();
+        if (src != BSK_OK) { c->set_error("libbsk: rmdup side outputs (-d / -D) failed on the device"); return src; }
+    }
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rmdup across ranks.  One call sequence per rank, the caller runs the collectives in between:
+//   keys  -> [all-gather of record counts]      -> pack -> [all-to-all of tuples]
+//   resolve (owner side)                        -> [all-to-all of keep bytes, reversed]
+//   emit
+// The context keeps the record table of the shard between keys and emit.
+// ---------------------------------------------------------------------------
+static RmDupParams rmdup_params(bsk_ctx* c, bool fastq) {
+    const Options& o = c->opts;
+    RmDupParams P;
+    memset(&P, 0, sizeof P);
+    P.fastq = fastq;
+    P.by_seq = o.b("BySeq");
+    P.by_name = o.b("ByName");
+    P.ignore_case = o.b("IgnoreCase");
+    P.id_mode = id_mode_of(c);
+    P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
+    P.buf_end = c->dist_buf ? c->dist_buf + c->dist_n : nullptr;
+    return P;
+}
+
+int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, uint64_t* n_records) {
+    if (!c->opts.s("DupSeqsFile").empty() || !c->opts.s("DupNumFile").empty()) {
+        c->set_error("libbsk: -d / -D side files are not available on the multi-GPU rmdup path");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    // `-s` on FASTQ: both keys come out of the index pass (stream_rmdup.hip); every rank computes the same two functions
+    // whichever kernel it takes (hash_dev.hpp)
+    const bool fused = format == BSK_FORMAT_FASTQ && c->opts.b("BySeq") && !(c->tune.get("rmdup_keys") && strcmp(c->tune.get("rmdup_keys"), "off") == 0);
+    const HashReq hq{c->opts.b("IgnoreCase")};
+    int rc = fused ? build_index_ex(c, d_buf, n, format, st, nullptr, &hq) : build_index(c, d_buf, n, format, st);
+    if (rc != BSK_OK) return rc;
+    c->dist_buf = d_buf;
+    c->dist_n = n;
+    c->dist_format = format;
+    const uint64_t N = c->table.n;
+    *n_records = N;
+    uint64_t status = 0;
+    if (N == 0) {
+        HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
+        return kernel_error_to_status(c, status);
+    }
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_keys, &c->keys_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_keys2, &c->keys2_cap, N, N / 8 + 16);
+    if (rc != BSK_OK) return rc;
+    if (!fused) HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    return kernel_error_to_status(c, status);
+}
+
+int rmdup_dist_pack(bsk_ctx* c, uint64_t base, int world, uint64_t* d_send, uint64_t* counts, hipStream_t st) {
+    const uint64_t N = c->table.n;
+    for (int r = 0; r < world; ++r) counts[r] = 0;
+    if (N == 0) return BSK_OK;
+    int rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, 64 + 16, 16);  // [0..63] counts, then cursors
+    if (rc != BSK_OK) return rc;
+    uint64_t* d_counts = c->d_scan_tmp;
+    HIP_TRYX(c, hipMemsetAsync(d_counts, 0, 64 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_rmdup_count_owner(c->d_keys, N, (uint32_t)world, d_counts, st));
+    HIP_TRYX(c, hipMemcpyAsync(counts, d_counts, world * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    uint64_t cursor[64], acc = 0;
+    for (int r = 0; r < world; ++r) { cursor[r] = acc; acc += counts[r]; }
+    HIP_TRYX(c, hipMemcpyAsync(d_counts, cursor, world * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, launch_rmdup_pack(c->d_keys, c->d_keys2, N, base, (uint32_t)world, d_counts, d_send, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // cursor lives on the host stack
+    return BSK_OK;
+}
+
+int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t* d_keep, hipStream_t st) {
+    if (m == 0) return BSK_OK;
+    uint64_t cap = 1024;
+    while (cap < 2 * m) cap <<= 1;
+    int rc = grow(c, &c->d_own, &c->own_cap, 3 * cap);
+    if (rc != BSK_OK) return rc;
+    uint64_t *tk = c->d_own, *tf = c->d_own + cap, *t2 = c->d_own + 2 * cap;
+    HIP_TRYX(c, hipMemsetAsync(tk, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(t2, 0, cap * sizeof(uint64_t), st));
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_rmdup_own(d_tuples, m, tk, tf, t2, cap, d_keep, c->d_status, st));
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_HASH_COLLISION) {
+        c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    return BSK_OK;
+}
+
+int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, uint64_t base, hipStream_t st, bsk_out* out) {
+    const uint64_t N = c->table.n;
+    if (N == 0) return empty_result(c, out);
+    const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
+    int rc = ensure_record_scratch(c);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_rmdup_apply(c->table, rmdup_params(c, fastq), d_send, d_reply, base, c->d_out_len, st));
+    uint64_t total = 0, kept = 0;
+    rc = finish_sizes(c, st, &total, &kept);
+    if (rc != BSK_OK) return rc;
+    rc = ensure_out(c, total);
+    if (rc != BSK_OK) return rc;
+    SeqParams F = format_params(c, fastq);
+    if (!fastq) { F.text_w = c->table.text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
+    apply_long(c, &F);
+    HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    out->d_data = c->d_out;
+    out->len = total;
+    out->records = kept;
+    return BSK_OK;
+}
+
+
+}  // namespace bsk

@@ -281,7 +281,7 @@ def test_locate_regexp_variable_length_circular_hand_case():
 
 @pytest.mark.parametrize("i", range(len(LOC_GEN_OPTS)))
 def test_locate_general_with_and_without_the_prefilter(i, monkeypatch):
-    """-d / -m: grep's Shift-And marks the records that hold an occurrence before the position-wise search runs (ops_host.cpp)"""
+    """-d / -m: grep's Shift-And marks the records that hold an occurrence before the position-wise search runs (ops_host_search.cpp)"""
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
     rng = random.Random(2100 + i)
     data = seqgen.random_fastq(rng, 400, 0, 100, alphabet="ACGT" * 5 + "acgtN")
