@@ -478,8 +478,16 @@ def main():
     pmc = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if pmc and world == 1 and total_bytes > 99e9:
         try:
-            traffic = json.load(open(pmc[-1]))["per_launch"]["stats"]["traffic_bytes"]
+            pj = json.load(open(pmc[-1]))
+            traffic = pj["per_launch"]["stats"]["traffic_bytes"]
             traffic_src = "profiles/" + os.path.basename(pmc[-1]) + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, gfx950-corrected)"
+            # the counters belong to the kernel sources they were collected on: say so when those have changed since
+            import hashlib
+            h = hashlib.sha256()
+            for f in ("stream_stats.hip", "stream_core_dev.hpp", "anchor_wave_dev.hpp"):
+                h.update(open(os.path.join(ROOT, "bigseqkit_amd", "csrc", f), "rb").read())
+            if pj.get("kernel_sources_sha256") and pj["kernel_sources_sha256"] != h.hexdigest():
+                traffic_src += " -- STALE: the kernel sources have changed since that pass"
         except (KeyError, ValueError):
             pass
     out = {

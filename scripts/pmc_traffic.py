@@ -28,5 +28,13 @@ for label, r in out["raw"].items():
     fetch = mean.get("FETCH_SIZE", 0) * 1024 * 2
     write = mean.get("WRITE_SIZE", 0) * 1024
     out["per_launch"][label] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write}
+# the sources of the measured kernel: bench.py marks the figure as stale when they have changed since
+import hashlib
+import os
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in ("stream_stats.hip", "stream_core_dev.hpp", "anchor_wave_dev.hpp"):
+    h.update(open(os.path.join(root, "bigseqkit_amd", "csrc", f), "rb").read())
+out["kernel_sources_sha256"] = h.hexdigest()
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["per_launch"], indent=1))
