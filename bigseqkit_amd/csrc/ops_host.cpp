@@ -75,10 +75,10 @@ int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const 
     }
     if (by_buckets) {
         size_t tmp_bytes = 0;
-        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, 16, &tmp_bytes));
+        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, (int)RMDUP_BUCKET_BITS, &tmp_bytes));
         Arena A;  // (used for its offset arithmetic only: the memory is c->d_group)
         const uint64_t o_sk = A.take(N * 8), o_vi = A.take(N * 4), o_vo = A.take(N * 4), o_first = A.take(N * 4),
-                       o_bs = A.take((65536 + 2) * 4), o_hist = A.take(65536 * 4), o_tmp = A.take(tmp_bytes + 256);
+                       o_bs = A.take(((1u << RMDUP_BUCKET_BITS) + 2) * 4), o_hist = A.take((1u << RMDUP_BUCKET_BITS) * 4), o_tmp = A.take(tmp_bytes + 256);
         int rc = grow(c, &c->d_group, &c->group_cap, A.used, A.used / 8 + 256);
         if (rc != BSK_OK) return rc;
         A.base = c->d_group;
@@ -89,7 +89,7 @@ int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const 
         if (!c->tune.is("rmdup_buckets", "hand")) {  // the device radix sort of the pairs (two 8-bit digit passes: 1.5 ms per 79 M pairs)
             HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
             HIP_TRYX(c, launch_sort_iota(d_first, N, st));
-            HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
+            HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, (int)RMDUP_BUCKET_BITS, st));
             HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st));
         } else {  // one 16-bit histogram + scatter by hand (ops_rmdup.hip): 6.8 ms -- kept for the comparison
             HIP_TRYX(c, launch_bucket_pass(c->d_keys, N, A.at<uint32_t>(o_hist), A.at<uint32_t>(o_bs), d_first, d_sk, d_vo, st));

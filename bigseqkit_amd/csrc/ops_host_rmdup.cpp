@@ -197,10 +197,10 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     }
     if (by_buckets) {
         size_t tmp_bytes = 0;
-        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, 16, &tmp_bytes));
+        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, (int)RMDUP_BUCKET_BITS, &tmp_bytes));
         Arena A;
         const uint64_t o_sk = A.take(N * 8), o_vi = A.take(N * 4), o_vo = A.take(N * 4), o_first = A.take(N * 4),
-                       o_bs = A.take((65536 + 2) * 4), o_hist = A.take(65536 * 4), o_tmp = A.take(tmp_bytes + 256);
+                       o_bs = A.take(((1u << RMDUP_BUCKET_BITS) + 2) * 4), o_hist = A.take((1u << RMDUP_BUCKET_BITS) * 4), o_tmp = A.take(tmp_bytes + 256);
         rc = arena_reserve(c, &A);
         if (rc != BSK_OK) return rc;
         uint64_t* d_sk = A.at<uint64_t>(o_sk);
@@ -220,7 +220,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             if (!c->tune.is("rmdup_buckets", "hand")) {  // the device radix sort of the pairs (two 8-bit digit passes: 1.5 ms per 79 M pairs)
                 HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
                 HIP_TRYX(c, launch_sort_iota(d_first, N, st));
-                HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, 16, st));
+                HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, (int)RMDUP_BUCKET_BITS, st));
                 HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
                                                  by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap));
             } else {  // one 16-bit histogram + scatter by hand (ops_rmdup.hip): 6.8 ms -- kept for the comparison

@@ -625,8 +625,9 @@ __global__ __launch_bounds__(256) void k_rmdup_apply(RecordTable t, RmDupParams 
 // ---------------------------------------------------------------------------
 // Grouping by radix buckets (the "radix-bucket pass" of the design): instead of one open-addressing table in HBM that
 // every record probes twice at random (insert 9.8 ms + resolve 8.1 ms per 79 M records: two 64-byte lines per record and
-// pass), the (key, record) pairs are first brought into 65 536 buckets by the top 16 bits of the key (two passes of the
-// device radix sort over bits 48..63; the pairs are 12 bytes per record, read and written in streams) and every bucket
+// pass), the (key, record) pairs are first brought into 65 536 buckets by the LOW RMDUP_BUCKET_BITS = 16 bits of the key
+// (the device radix sort over bits [0, 16): two 8-bit digit passes; the pairs are 12 bytes per record, read and written in
+// streams; the hosts' launch_sort_pairs_bits(..., 0, RMDUP_BUCKET_BITS) and the kernels here share the constant) and every bucket
 // -- ~1 200 pairs, a few tens of KB -- is then deduplicated by ONE block in LDS:
 //   k_bucket_starts : first position of every bucket in the sorted pairs (binary search; 65 537 threads)
 //   k_bucket_dedupe : LDS table of the bucket's DISTINCT keys (atomicCAS on the 64-bit key, atomicMin on the record
@@ -638,7 +639,8 @@ __global__ __launch_bounds__(256) void k_rmdup_apply(RecordTable t, RmDupParams 
 //   k_rmdup_resolve_first : a record survives iff first[i] == i; a duplicate is byte-compared with its survivor
 //                     (RmDupCheck's exact test, rmdup.go:193-199) as before.
 // ---------------------------------------------------------------------------
-constexpr uint32_t BUCKET_BITS = 16;
+constexpr uint32_t BUCKET_BITS = RMDUP_BUCKET_BITS;  // (ops_rmdup.hpp: the sort's bit range on the host side is the same constant)
+static_assert(BUCKET_BITS == 16, "k_bucket_scan divides 2^BUCKET_BITS by 1024 threads and the LDS slot hash takes the bits above");
 constexpr uint32_t BUCKET_SLOTS = 4096;  // LDS slots per bucket table (48 KB: u64 key + u32 first)
 
 __global__ __launch_bounds__(256) void k_bucket_starts(const uint64_t* __restrict__ skeys, uint64_t n, uint32_t* __restrict__ bstart) {

@@ -43,6 +43,9 @@ hipError_t launch_rmdup_resolve_group(const uint8_t* buf, const RecordTable& t, 
                                       uint64_t* keys, const uint64_t* table, uint64_t cap, uint32_t* out_len,
                                       uint64_t* status, uint8_t* has_dup, hipStream_t st);
 
+// the (key, record) pairs are bucketed by the low RMDUP_BUCKET_BITS bits of the key: the bit range of the host's sort call
+// and the bucket arithmetic of the kernels (ops_rmdup.hip) are this one constant
+constexpr uint32_t RMDUP_BUCKET_BITS = 16;
 // grouping by radix buckets: skeys / sidx = the (key, record) pairs sorted by the low 16 key bits (launch_sort_pairs_bits),
 // bstart: scratch [65 537]; first[] must hold iota and receives, for every duplicate, the lowest record with its key
 // k2 != null (second keys by record): a duplicate must agree with the first record of its key in k2 as well; the records
