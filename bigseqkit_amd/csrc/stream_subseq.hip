@@ -45,6 +45,22 @@ using namespace tilelds;
 
 constexpr uint32_t SUB_TBUF = TBUF + 16;  // a short piece is fetched as 16 bytes from its start: up to 19 past the tile
 
+// sub_location (ops_seq.hpp: Seq.SubSeq's 1-based inclusive region, negative = from the end) in 32-bit arithmetic: the
+// lines of this pass are shorter than 2^31 bytes (the skeleton raises ERR_LINE_TOO_LONG beyond), so every intermediate of
+// the 64-bit original fits once the negative positions are taken as distances from the end (-x <= L or the bound clamps)
+__device__ __forceinline__ void sub_location32(uint32_t L, int start, int end, uint32_t* b, uint32_t* e) {
+    *b = *e = 0;
+    if (L == 0) return;
+    uint32_t s, t;  // 1-based, inclusive
+    if (start < 0) { const uint32_t d = 0u - (uint32_t)start; s = d > L ? 1u : L - d + 1u; }   // L + start + 1, at least 1
+    else s = start == 0 ? 1u : (uint32_t)start;
+    if (end < 0) { const uint32_t d = 0u - (uint32_t)end; if (d > L) return; t = L - d + 1u; }  // (L + end + 1 < 1: empty)
+    else t = (uint32_t)end > L ? L : (uint32_t)end;
+    if (s > L || t < 1u || s > t) return;
+    *b = s - 1u;
+    *e = t;
+}
+
 template <bool DPP>
 struct SubseqSink {
     static constexpr bool TILE_HOOK = true;
@@ -99,7 +115,7 @@ struct SubseqSink {
                         if (abs_next < re && next_char(L, s, abs_next, re, buf) != '@') err |= ERR_BAD_HEADER;
                     }
                     uint32_t b, en;
-                    sub_location(ll, D.region_start, D.region_end, &b, &en);
+                    sub_location32(ll, D.region_start, D.region_end, &b, &en);
                     from = b;
                     cnt = en - b + 1u;
                 }
