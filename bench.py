@@ -34,21 +34,43 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # brackets (bsk_profile_dump), and `exact` = the COMPLETE output compared byte for byte with an expectation computed here
 # with torch from the fixed layout of the synthetic file (no parser, no oracle).
 # ---------------------------------------------------------------------------------------------------------------------
-def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
-    ops = {}
-    calls = max(1, args.ops_calls)
+class _Helpers:
+    """what the 'ops' legs share: device views of libbsk's output, timed operator calls, the exact row-wise comparison and
+    the synthetic inputs"""
 
-    def dev_bytes(ptr, n):
+    def __init__(self, args, torch, bsk, _lib, lib, check, dev, local):
+        self.args, self.torch, self.bsk, self._lib, self.lib, self.check, self.dev, self.local = \
+            args, torch, bsk, _lib, lib, check, dev, local
+        self.calls = max(1, args.ops_calls)
+
+    def dev_bytes(self, ptr, n):
         """torch uint8 view of n device bytes at ptr (libbsk's output buffer), no copy"""
+        if int(n) == 0:
+            return self.torch.empty(0, dtype=self.torch.uint8, device=self.dev)
+
         class _Arr:  # __cuda_array_interface__ works for HIP pointers in torch-rocm
             pass
         a = _Arr()
         a.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(a, device=dev)
+        return self.torch.as_tensor(a, device=self.dev)
 
-    def timed_calls(name, fn, opts, buf, nbytes, fmt):
-        out = _lib.Out()
-        op = bsk.Operator(name, json.dumps(opts), local)
+    def kernels(self, op, calls):
+        pb = C.create_string_buffer(1 << 16)
+        self.check(self.lib.bsk_profile_dump(op.ctx, pb, len(pb)), op.ctx)
+        kern = {}
+        for item in pb.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.rsplit("=", 1)
+                ms, n = v.split("/")
+                kern[k] = round(float(ms) / calls, 4)
+        return kern
+
+    def timed_calls(self, name, fn, opts, buf, nbytes, fmt, sets=()):
+        torch, lib, check, calls = self.torch, self.lib, self.check, self.calls
+        out = self._lib.Out()
+        op = self.bsk.Operator(name, json.dumps(opts), self.local)
+        for k, v in sets:
+            check(lib.bsk_ctx_set(op.ctx, k, v), op.ctx)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(fn(op.ctx, C.c_void_p(buf.data_ptr()), nbytes, 1, fmt, 0, st, C.byref(out)), op.ctx)  # warm-up (allocations)
         torch.cuda.synchronize()
@@ -62,30 +84,25 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         lib.bsk_profile_enable(op.ctx, 0)
-        pb = C.create_string_buffer(1 << 16)
-        check(lib.bsk_profile_dump(op.ctx, pb, len(pb)), op.ctx)
-        kern = {}
-        for item in pb.value.decode().split(";"):
-            if "=" in item:
-                k, v = item.rsplit("=", 1)
-                ms, n = v.split("/")
-                kern[k] = round(float(ms) / calls, 4)
-        return op, out, sum(times) / calls, min(times), kern
+        return op, out, sum(times) / calls, min(times), self.kernels(op, calls)
 
-    def entry(cmd, workload, nrec, in_bytes, alg_bytes, out, mean_s, min_s, kern, exact, how, extra=None):
+    def entry(self, cmd, workload, nrec, in_bytes, alg_bytes, out, mean_s, min_s, kern, exact, how, extra=None):
         e = {"command": cmd, "workload": workload, "records": int(nrec), "in_bytes": int(in_bytes),
-             "out_bytes": int(out.len), "out_records": int(out.records), "calls": calls,
+             "out_bytes": int(out.len), "out_records": int(out.records), "calls": self.calls,
              "ms": round(mean_s * 1e3, 4), "ms_min": round(min_s * 1e3, 4),
              "M_records_per_s": round(nrec / mean_s / 1e6, 2),
              "algorithmic_bytes": int(alg_bytes), "achieved_GBps": round(alg_bytes / mean_s / 1e9, 1),
              "frac": round(alg_bytes / mean_s / 1e9 / HBM_PEAK_GBS, 4),
-             "kernels_ms_per_call": kern, "exact": bool(exact), "exact_how": how}
+             "kernels_ms_per_call": kern,
+             "host_ms_per_call": round(mean_s * 1e3 - sum(kern.values()), 4) if kern else None,
+             "exact": bool(exact), "exact_how": how}
         if extra:
             e.update(extra)
         return e
 
-    def rows_equal(out_t, view, mask_fn, width, rows_per_chunk=4_000_000):
+    def rows_equal(self, out_t, view, mask_fn, width, rows_per_chunk=4_000_000):
         """out_t == concat(view[i] for i with mask_fn(i0, i1)[i - i0]) ; mask None = every row; width = bytes per row"""
+        torch = self.torch
         pos, ok, n = 0, True, view.shape[0]
         for i0 in range(0, n, rows_per_chunk):
             i1 = min(n, i0 + rows_per_chunk)
@@ -100,13 +117,38 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
             del blk
         return ok and pos == out_t.numel(), pos
 
-    def synth(kind, flags, want_bytes):
-        rb = lib.bsk_synth_record_bytes(kind)
+    def synth(self, kind, flags, want_bytes, first_record=0):
+        torch = self.torch
+        rb = self.lib.bsk_synth_record_bytes(kind)
         n = int(want_bytes) // rb * rb
-        t = torch.empty(n, dtype=torch.uint8, device=dev)
-        check(lib.bsk_synth_device(kind, 42, flags, 0, C.c_void_p(t.data_ptr()), n, local, None))
+        t = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        self.check(self.lib.bsk_synth_device(kind, 42, flags, first_record, C.c_void_p(t.data_ptr()), n, self.local, None))
         torch.cuda.synchronize()
         return t, n // rb
+
+    def motif_hit_mask(self, view, planted, first_record=0):
+        """rows of `view` (records of 317 bytes) whose bases hold ACGTTGCAAGCT or its reverse complement: a sliding compare"""
+        torch, dev = self.torch, self.dev
+        pats = [torch.tensor(list(p), dtype=torch.uint8, device=dev) for p in (b"ACGTTGCAAGCT", b"AGCTTGCAACGT")]  # + / -
+
+        def hit_mask(i0, i1):
+            seqs = view[i0:i1, 13:163]
+            m = torch.zeros(i1 - i0, dtype=torch.bool, device=dev)
+            for p in pats:
+                w = seqs[:, 0:139] == p[0]
+                for j in range(1, 12):
+                    w &= seqs[:, j:j + 139] == p[j]
+                m |= w.any(dim=1)
+            idx = torch.arange(first_record + i0, first_record + i1, device=dev) % 100
+            planted[0] += int(((idx == 0) | (idx == 50)).sum().item())
+            return m
+        return hit_mask
+
+
+def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
+    ops = {}
+    H = _Helpers(args, torch, bsk, _lib, lib, check, dev, local)
+    calls, dev_bytes, timed_calls, entry, rows_equal, synth = H.calls, H.dev_bytes, H.timed_calls, H.entry, H.rows_equal, H.synth
 
     # ---- seq -n @ C2: the names of the 100 GB file -----------------------------------------------------------------
     nbytes = total_rec * REC
@@ -157,20 +199,8 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     op, out, mean_s, min_s, kern = timed_calls("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t,
                                                t.numel(), bsk.FORMAT_FASTQ)
     view = t.view(nrec, REC)
-    pats = [torch.tensor(list(p), dtype=torch.uint8, device=dev) for p in (b"ACGTTGCAAGCT", b"AGCTTGCAACGT")]  # + and - strand
     planted = [0]
-
-    def hit_mask(i0, i1):
-        seqs = view[i0:i1, 13:163]
-        m = torch.zeros(i1 - i0, dtype=torch.bool, device=dev)
-        for p in pats:
-            w = seqs[:, 0:139] == p[0]
-            for j in range(1, 12):
-                w &= seqs[:, j:j + 139] == p[j]
-            m |= w.any(dim=1)
-        idx = torch.arange(i0, i1, device=dev) % 100
-        planted[0] += int(((idx == 0) | (idx == 50)).sum().item())
-        return m
+    hit_mask = H.motif_hit_mask(view, planted)
 
     got = dev_bytes(out.d_data, out.len)
     ok, pos = rows_equal(got, view, hit_mask, REC, 2_000_000)
@@ -266,6 +296,123 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     return ops
 
 
+def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, bdist, backend_name):
+    """The two BASELINE configs that are DEFINED on several GPUs, at N > 1 (every rank calls this):
+      grep -s -p ACGTTGCAAGCT @ C3 -- the 100 GB file (motif planted) in N record-aligned shards, bsk_grep_run per rank,
+            the global number of selected records from ONE sum all-reduce (GrepReduceCount, bigseqkit/grep.go:175);
+            the selected records stay in every rank's HBM (rank order == file order).  Strong scaling.
+      rmdup -s @ C5 -- 25 GB of the duplicate-planted file per rank (C5 is 8 x 25 GB; weak scaling below 8 GPUs) through
+            dist.rmdup_distributed: keys -> all_gather(counts) -> pack -> all_to_all(24-byte tuples to owner = key % N)
+            -> resolve -> all_to_all(keep bytes) -> emit (GroupByKey + RmDupCheck, bigseqkit/rmdup.go:97); a duplicate's
+            first occurrence may live on the rank before (the copy source is up to 1 001 records back); survivors stay in HBM.
+    Timing: barrier + synchronize on both sides of `calls` whole calls, max over ranks.  `exact` = every rank's COMPLETE
+    output compared with the expectation computed with torch from the fixed layout (no parser, no oracle), AND-ed over the
+    ranks; the global counts are sums over the ranks of what torch counted."""
+    H = _Helpers(args, torch, bsk, _lib, lib, check, dev, local)
+    calls = H.calls
+    ops = {}
+
+    def job_time(fn):
+        fn()  # warm-up (allocations, RCCL channel set-up)
+        bdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            r = fn()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
+        bdist.barrier()
+        dt = bdist.all_reduce_max_float(time.perf_counter() - t0, dev)
+        return r, dt / calls, own / calls
+
+    def all_ok(ok):
+        return bdist.all_reduce_count(0 if ok else 1, dev) == 0
+
+    # ---- grep -s -p @ C3 over N GPUs -----------------------------------------------------------------------------------
+    total = int(100e9 * args.ops_scale) // REC
+    lo, hi = total * rank // world, total * (rank + 1) // world
+    t, nrec = H.synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_MOTIF, (hi - lo) * REC, lo)
+    out = _lib.Out()
+    op = bsk.Operator("Grep", json.dumps({"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}), local)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def grep_call():
+        check(lib.bsk_grep_run(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, bsk.FORMAT_FASTQ, rank, st, C.byref(out)), op.ctx)
+        return bdist.all_reduce_count(out.records, dev)
+
+    lib.bsk_profile_reset(op.ctx)
+    global_hits, per_call, own = job_time(grep_call)
+    view = t.view(nrec, REC)
+    planted = [0]
+    got = H.dev_bytes(out.d_data, out.len)
+    ok, pos = H.rows_equal(got, view, H.motif_hit_mask(view, planted, lo), REC, 2_000_000)
+    ok = ok and out.records == pos // REC
+    want_hits = bdist.all_reduce_count(pos // REC, dev)
+    planted_all = bdist.all_reduce_count(planted[0], dev)
+    out_bytes_all = bdist.all_reduce_count(out.len, dev)
+    rows = bdist.all_gather_floats([own * 1e3, nrec], dev)
+    ok = all_ok(ok) and global_hits == want_hits and want_hits >= planted_all
+    alg = total * REC + out_bytes_all
+    ops["grep -s -p @ C3"] = {
+        "command": "grep -s -p ACGTTGCAAGCT", "n_gpus": world, "backend": backend_name, "scaling": "strong",
+        "workload": "%.1f GB FASTQ-150 (C3), motif planted on + / - strand in 2 %% of the reads, %d record-aligned shards of %.2f GB"
+                    % (total * REC / 1e9, world, (hi - lo) * REC / 1e9),
+        "records": total, "in_bytes": total * REC, "out_bytes": out_bytes_all, "hits": int(global_hits),
+        "planted": int(planted_all), "background": int(global_hits - planted_all), "calls": calls,
+        "collective": "one sum all-reduce of the per-rank record counts (GrepReduceCount)",
+        "ms": round(per_call * 1e3, 4), "M_records_per_s": round(total / per_call / 1e6, 2),
+        "algorithmic_bytes": int(alg), "achieved_GBps": round(alg / per_call / 1e9, 1),
+        "frac": round(alg / per_call / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "per_rank_own_ms": [round(r[0], 4) for r in rows], "per_rank_records": [int(r[1]) for r in rows],
+        "exact": bool(ok),
+        "exact_how": "every rank: output == the rows of its shard whose bases hold the 12-mer or its reverse complement "
+                     "(torch sliding compare, all records); the all-reduced count == the sum of those row counts"}
+    del got, view, t
+    op.close()
+    torch.cuda.empty_cache()
+
+    # ---- rmdup -s @ C5 over N GPUs: 25 GB per rank ----------------------------------------------------------------------
+    per = int(25e9 * args.ops_scale) // REC
+    lo = rank * per
+    t, nrec = H.synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_DUPS, per * REC, lo)
+    be = bdist.HipRmDupBackend(json.dumps({"BySeq": True}), local)
+    text, per_call, own = job_time(lambda: bdist.rmdup_distributed(t, bsk.FORMAT_FASTQ, be, to_host=False))
+    phases = {}
+    text = bdist.rmdup_distributed(t, bsk.FORMAT_FASTQ, be, to_host=False, phases=phases)   # one more call, synchronised per phase
+    view = t.view(nrec, REC)
+    got = text.tensor()
+    ok, _ = H.rows_equal(got, view, lambda i0, i1: (torch.arange(lo + i0, lo + i1, device=dev) % 5) != 4, REC)
+    N = per * world
+    surv_all = bdist.all_reduce_count(text.records, dev)
+    out_bytes_all = bdist.all_reduce_count(text.len, dev)
+    ok = all_ok(ok and text.len == REC * text.records) and surv_all == N - N // 5
+    names = ["keys", "pack", "all_to_all", "resolve", "reply", "emit"]
+    rows = bdist.all_gather_floats([own * 1e3] + [phases.get(k, 0.0) for k in names]
+                                   + [phases.get("tuple_bytes_sent", 0), phases.get("tuple_bytes_sent_off_rank", 0)], dev)
+    alg = N * REC + 16 * N + out_bytes_all
+    ops["rmdup -s @ C5"] = {
+        "command": "rmdup -s", "n_gpus": world, "backend": backend_name, "scaling": "weak",
+        "workload": "%.1f GB FASTQ-150 per rank x %d ranks (C5 is 8 x 25 GB), record i with i %% 5 == 4 repeats the bases of a "
+                    "record up to 1 001 places earlier (possibly on the rank before)" % (per * REC / 1e9, world),
+        "records": N, "in_bytes": N * REC, "out_bytes": out_bytes_all, "survivors": int(surv_all), "calls": calls,
+        "collective": "all_gather(record counts) + all_to_all_single(24-byte tuples to owner = key %% N) + "
+                      "all_to_all_single(keep bytes)",
+        "ms": round(per_call * 1e3, 4), "M_records_per_s": round(N / per_call / 1e6, 2),
+        "algorithmic_bytes": int(alg), "achieved_GBps": round(alg / per_call / 1e9, 1),
+        "frac": round(alg / per_call / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "per_rank_own_ms": [round(r[0], 4) for r in rows],
+        "phases_ms_per_rank": {k: [round(r[1 + i], 4) for r in rows] for i, k in enumerate(names)},
+        "tuple_bytes_sent_per_rank": [int(r[7]) for r in rows], "tuple_bytes_sent_off_rank_per_rank": [int(r[8]) for r in rows],
+        "survivors_resident": "HBM (DeviceText: the context's output buffer; no host copy)",
+        "exact": bool(ok),
+        "exact_how": "every rank: output == the records of its shard with GLOBAL index %% 5 != 4, byte for byte in file order; "
+                     "survivors over all ranks == N - N // 5"}
+    del got, view, t, text
+    be.close()
+    torch.cuda.empty_cache()
+    return ops
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,10 +489,12 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        pg_timeout = datetime.timedelta(minutes=5)   # a rank that died must not hold the others for the default 10 - 30 min
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=pg_timeout)
         assert dist.get_world_size() == want_world
 
     # ---- the synthetic file, cut into record-aligned shards --------------------------
@@ -463,6 +612,19 @@ def main():
         q20, q30 = bdist.all_reduce_count(q20, dev), bdist.all_reduce_count(q30, dev)
     verified_a = (ma.get(150) == total_rec and ma.get(-3) == 0 and ma.get(-1) == q20 and ma.get(-2) == q30
                   and sum(v for k, v in ma.items() if k >= 0) == total_rec)
+
+    # ---- the BASELINE configs that are defined on several GPUs (C3, C5) -- every rank takes part
+    ops_multi = None
+    if world > 1 and not args.no_ops:
+        del view
+        shard = None
+        torch.cuda.empty_cache()
+        try:
+            ops_multi = run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, bdist, dist.get_backend())
+        except Exception as e:  # reported, not hidden; the collectives of the other ranks may then time out -- say which rank
+            ops_multi = {"error": "rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:400])}
+            if rank != 0:
+                print("bench.py rank %d: ops leg failed: %s" % (rank, ops_multi["error"]), file=sys.stderr, flush=True)
 
     if rank != 0:
         if world > 1:
@@ -597,6 +759,8 @@ def main():
                 out["ops"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         else:
             out["ops"] = {"skipped": "the 'ops' workloads are defined at the full BASELINE sizes (--gb 100) or with --ops-scale"}
+    if ops_multi is not None:
+        out["ops"] = ops_multi
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

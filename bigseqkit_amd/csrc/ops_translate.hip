@@ -969,6 +969,16 @@ __device__ __forceinline__ void load_window(const uint8_t* a, const uint8_t* buf
     }
 }
 
+// the raw byte at which a lane's window expects its line break (offset kb; none expected: any byte of the window).  The
+// window check (v_sad_u8 == 57) says that the window holds ONE byte that is no letter; it does not say where.  Lines of
+// 60 / 50 / 60 / 60 bases have the line count and the length of 60 / 60 / 60 / 50 and a break in every window that expects
+// one -- ten bytes early.  So the byte at the expected offset is fetched beside the window (the same cache
+// line, one byte load per lane and step) and must be '\n'.
+__device__ __forceinline__ uint32_t load_break(const uint8_t* a, uint32_t kb, const uint8_t* buf_end) {
+    const uint8_t* p = a + (kb < 51u ? kb : 51u);
+    return p < buf_end ? (uint32_t)*p : 0u;
+}
+
 #ifndef BSK_TRW_WAVES
 #define BSK_TRW_WAVES 0
 #endif
@@ -1028,7 +1038,11 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
     // the window of the first step is requested before anything else is done with the record, the window of step s + 1
     // while step s is translated: the text's round trip to HBM hides behind the headers / the previous step
     uint32_t rn[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (LB * gl < L) load_window(T.p + LB * gl + rnl, buf_end, rn);
+    uint32_t rbk = 0;  // the byte at the window's expected line break (load_break)
+    if (LB * gl < L) {
+        load_window(T.p + LB * gl + rnl, buf_end, rn);
+        rbk = load_break(T.p + LB * gl + rnl, W ? W - rcol : 0u, buf_end);
+    }
 
     constexpr uint64_t NONE = ~0ull;
     uint64_t fb[3] = {NONE, NONE, NONE};   // body offsets from `out`
@@ -1157,12 +1171,16 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
                 sad = __builtin_amdgcn_sad_u8(r[i] | 0x20202020u, __builtin_amdgcn_perm(LET, LET, cd), sad);
                 d8[i] = __builtin_amdgcn_udot4(cd, 0x40100401u, 0u, false);
             }
-            bad = sad != (brk ? 57u : 0u);  // |('\n' | 0x20) - 'c'| = 57: the break, and nothing else, may differ
+            // |('\n' | 0x20) - 'c'| = 57: one byte, and nothing else, may differ -- and it must be a '\n' where the layout puts it
+            bad = sad != (brk ? 57u : 0u) || (brk && rbk != 0x0Au);
             X[0] = d8[0] | (d8[1] << 8) | (d8[2] << 16) | (d8[3] << 24);
             X[1] = d8[4] | (d8[5] << 8) | (d8[6] << 16) | (d8[7] << 24);
             X[2] = d8[8] | (d8[9] << 8) | (d8[10] << 16) | (d8[11] << 24);
             X[3] = d8[12];
-            if (q + STEPB < L) load_window(T.p + q + STEPB + rnl2, buf_end, rn);  // (r is consumed: its registers are free)
+            if (q + STEPB < L) {  // (r is consumed: its registers are free)
+                load_window(T.p + q + STEPB + rnl2, buf_end, rn);
+                rbk = load_break(T.p + q + STEPB + rnl2, W ? W - rcol2 : 0u, buf_end);
+            }
             if (brk) {  // cut the two bits of the break (raw byte kbrk) out of the string
                 const uint32_t Y[5] = {X[0], X[1], X[2], X[3], 0u};
 #pragma unroll

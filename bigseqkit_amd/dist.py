@@ -17,11 +17,24 @@ def shard_bounds(data, world, fmt):
     """Cut host-resident file text into `world` record-aligned byte ranges
     (PlainFileN + ReadFixer: every shard begins on a record).  Returns [(lo, hi)] * world."""
     n = len(data)
-    arr = (C.c_char * max(1, n)).from_buffer_copy(data if n else b"\0")
+    # the text is read in place (a file of 100 GB is not copied to be cut): bytes through c_char_p, writable buffers
+    # (bytearray, mmap, numpy) through from_buffer; only a read-only view that is not `bytes` costs a copy
+    if n == 0:
+        keep = C.create_string_buffer(1)
+        ptr = C.cast(keep, C.c_void_p)
+    elif isinstance(data, bytes):
+        keep = C.c_char_p(data)
+        ptr = C.cast(keep, C.c_void_p)
+    else:
+        try:
+            keep = (C.c_char * n).from_buffer(data)
+        except (TypeError, ValueError):
+            keep = (C.c_char * n).from_buffer_copy(data)
+        ptr = C.cast(keep, C.c_void_p)
     cuts = [0]
     for k in range(1, world):
         out = C.c_size_t()
-        check(lib.bsk_find_record_start(C.cast(arr, C.c_void_p), n, n * k // world, fmt, C.byref(out)))
+        check(lib.bsk_find_record_start(ptr, n, n * k // world, fmt, C.byref(out)))
         cuts.append(max(cuts[-1], out.value))
     cuts.append(n)
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
@@ -191,6 +204,37 @@ def all_gather_floats(values, device, group=None):
     return [[float(x) for x in p.tolist()] for p in parts]
 
 
+class DeviceText:
+    """What an operator left in its context's output buffer (`bsk_out`): `len` bytes of record text in HBM, owned by the
+    context until its next run.  At BASELINE sizes a rank's survivors are 20 GB: they stay where they are (a writer drains
+    them with bsk_store_put, another operator reads them in place); `bytes()` is the host copy the tests compare."""
+
+    def __init__(self, op, out, device):
+        self.op, self.ptr, self.len, self.records, self.device = op, int(out.d_data or 0), int(out.len), int(out.records), device
+
+    def __len__(self):
+        return self.len
+
+    def tensor(self):
+        """torch uint8 view of the bytes (no copy; valid until the context's next run)"""
+        import torch
+        if self.len == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+
+        class _Arr:  # __cuda_array_interface__ works for HIP pointers in torch-rocm
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {"shape": (self.len,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+        return torch.as_tensor(a, device=self.device)
+
+    def __bytes__(self):
+        from . import _lib
+        out = _lib.Out(self.ptr, self.len, self.records)
+        buf = C.create_string_buffer(max(1, self.len))
+        check(lib.bsk_out_to_host(self.op.ctx, C.byref(out), buf, self.len), self.op.ctx)
+        return buf.raw[:self.len]
+
+
 # ---------------------------------------------------------------------------
 # rmdup across ranks: duplicates are global, so this is the one command with a real exchange step.
 # The reference shuffles whole records (GroupByKey, bigseqkit/rmdup.go:97); here 24-byte tuples travel to
@@ -230,45 +274,85 @@ class HipRmDupBackend:
                                          C.c_void_p(keep.data_ptr()), None), self.op.ctx)
         return keep
 
-    def emit(self, send, reply, base):
+    def emit(self, send, reply, base, to_host=True):
+        """survivors of this rank's shard: host bytes (tests), or with to_host=False a DeviceText -- the text stays in the
+        context's output buffer in HBM (20 GB per rank at C5 do not belong on the host)"""
         from . import _lib
         out = _lib.Out()
         check(lib.bsk_rmdup_dist_emit(self.op.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(reply.data_ptr()), base, None,
                                       C.byref(out)), self.op.ctx)
-        buf = C.create_string_buffer(max(1, out.len))
-        check(lib.bsk_out_to_host(self.op.ctx, C.byref(out), buf, out.len), self.op.ctx)
-        return buf.raw[:out.len]
+        text = DeviceText(self.op, out, self._keep.device)
+        return bytes(text) if to_host else text
 
 
-def rmdup_distributed(shard, fmt, backend, group=None):
-    """RmDup over the shards of all ranks of `group`; returns the survivors of THIS rank's shard (bytes, file
-    order), so that the concatenation over ranks equals the single-GPU output.  Collectives: one all_gather of
-    the record counts, one all_to_all of split sizes, one all_to_all of tuples, one all_to_all of keep bytes."""
+class _Phases:
+    """wall clock per phase of rmdup_distributed, each one closed by a device synchronisation (only when the caller asks
+    for them: bench.py's breakdown call; the synchronisations are not part of the product path)"""
+
+    def __init__(self, sink, device):
+        self.sink, self.device, self.t = sink, device, None
+
+    def mark(self, name=None):
+        if self.sink is None:
+            return
+        import time
+        import torch
+        if getattr(self.device, "type", "cpu") == "cuda":
+            torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        if name is not None:
+            self.sink[name] = self.sink.get(name, 0.0) + (now - self.t) * 1e3
+        self.t = now
+
+
+def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None):
+    """RmDup over the shards of all ranks of `group`; returns the survivors of THIS rank's shard (file order), so that the
+    concatenation over ranks equals the single-GPU output: host bytes, or with to_host=False whatever the backend's emit
+    leaves on the device (HipRmDupBackend: a DeviceText).  Collectives: one all_gather of the record counts, one
+    all_to_all of split sizes, one all_to_all of tuples, one all_to_all of keep bytes.
+    `phases` (a dict) receives milliseconds per phase -- keys / pack / all_to_all / resolve / reply / emit -- and
+    `tuple_bytes_sent` / `tuple_bytes_sent_off_rank`."""
     import torch
     import torch.distributed as dist
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
-    n = backend.keys(shard, fmt)
     dev = shard.device
+    ph = _Phases(phases, dev)
+    ph.mark()
+    n = backend.keys(shard, fmt)
+    ph.mark("keys")
     if multi:
         counts_all, _ = _all_gather_int(n, dev, group)
         base = int(sum(counts_all[:rank]))
     else:
         base = 0
     send, in_splits = backend.pack(base, world)
+    ph.mark("pack")
+    if phases is not None:
+        phases["tuple_bytes_sent"] = 24 * int(sum(in_splits))
+        phases["tuple_bytes_sent_off_rank"] = 24 * int(sum(c for r, c in enumerate(in_splits) if r != rank))
     if not multi:
-        return backend.emit(send, backend.resolve(send), base)
+        keep = backend.resolve(send)
+        ph.mark("resolve")
+        out = backend.emit(send, keep, base) if to_host else backend.emit(send, keep, base, to_host=False)
+        ph.mark("emit")
+        return out
     t_in = torch.tensor(in_splits, dtype=torch.int64, device=dev)
     t_out = torch.empty(world, dtype=torch.int64, device=dev)
     _all_to_all_single(t_out, t_in, None, None, group)
     out_splits = [int(x) for x in t_out.tolist()]
     recv = torch.empty((sum(out_splits), 3), dtype=torch.int64, device=dev)
     _all_to_all_single(recv, send, out_splits, in_splits, group)
+    ph.mark("all_to_all")
     keep = backend.resolve(recv)
+    ph.mark("resolve")
     reply = torch.empty(n, dtype=torch.uint8, device=dev)
     _all_to_all_single(reply, keep, in_splits, out_splits, group)
-    return backend.emit(send, reply, base)
+    ph.mark("reply")
+    out = backend.emit(send, reply, base) if to_host else backend.emit(send, reply, base, to_host=False)
+    ph.mark("emit")
+    return out
 
 
 def _all_to_all_single(out, inp, out_splits, in_splits, group=None):
@@ -318,7 +402,7 @@ class HipRangeBackend:
         check(lib.bsk_index_build(self.op.ctx, C.c_void_p(shard.data_ptr()), shard.numel(), 1, fmt, None, C.byref(n)), self.op.ctx)
         return n.value
 
-    def run(self, first_record, total):
+    def run(self, first_record, total, to_host=True):
         from . import _lib
         needs = C.c_int()
         check(lib.bsk_range_needs_count(self.op.ctx, C.byref(needs)), self.op.ctx)
@@ -328,17 +412,19 @@ class HipRangeBackend:
         s = self._shard
         check(lib.bsk_range_run(self.op.ctx, C.c_void_p(s.data_ptr()), s.numel(), 1, self._fmt, 0, first_record, None,
                                 C.byref(out)), self.op.ctx)
-        buf = C.create_string_buffer(max(1, out.len))
-        check(lib.bsk_out_to_host(self.op.ctx, C.byref(out), buf, out.len), self.op.ctx)
-        return buf.raw[:out.len]
+        text = DeviceText(self.op, out, s.device)
+        return bytes(text) if to_host else text
 
 
-def range_distributed(shard, fmt, backend, group=None):
+def range_distributed(shard, fmt, backend, group=None, to_host=True):
     """Range / Head over the shards of all ranks: the record index of MapWithIndex is global, so every rank learns the
     number of records before its shard (and the total, for negative positions) from ONE all_gather of the counts.
-    Returns this rank's selected records; the concatenation over ranks equals the single-GPU output."""
+    Returns this rank's selected records (host bytes, or with to_host=False what the backend leaves on the device); the
+    concatenation over ranks equals the single-GPU output."""
     counts, rank = _all_gather_int(backend.count(shard, fmt), shard.device, group)
-    return backend.run(sum(counts[:rank]), sum(counts))
+    if to_host:
+        return backend.run(sum(counts[:rank]), sum(counts))
+    return backend.run(sum(counts[:rank]), sum(counts), to_host=False)
 
 
 def faidx_distributed(shard, fmt, run, group=None):

@@ -53,8 +53,21 @@ class OracleRmDupBackend:
             assert first[k][1] == k2 or cur is None or cur[1] == k2
         return torch.tensor([1 if first[k][0] == g else 0 for k, k2, g in rows], dtype=torch.uint8)
 
-    def emit(self, send, reply, base):
+    def emit(self, send, reply, base, to_host=True):
         keep = {}
         for (k, k2, g), r in zip(send.tolist(), reply.tolist()):
             keep[g - base] = r
-        return b"".join(rec for i, rec in enumerate(self.records) if keep[i])
+        text = b"".join(rec for i, rec in enumerate(self.records) if keep[i])
+        if to_host:
+            return text
+        return ResidentText(text, sum(1 for i in range(len(self.records)) if keep[i]))
+
+
+class ResidentText:
+    """what HipRmDupBackend.emit(to_host=False) returns (dist.DeviceText), on the host: the text stays with the backend"""
+
+    def __init__(self, text, records):
+        self.text, self.len, self.records = text, len(text), records
+
+    def __bytes__(self):
+        return self.text

@@ -35,14 +35,24 @@ def test_bench_single_gpu_line_small():
 
 @pytest.mark.parametrize("n", [2, 3])
 def test_bench_n_ranks_sharing_one_gpu(n):
-    d = run_bench(["--gpus", str(n), "--gb", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                  {"BSK_BENCH_SHARE_GPU": "1"})
+    d = run_bench(["--gpus", str(n), "--gb", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ops-scale", "0.02",
+                   "--ops-calls", "2"], {"BSK_BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == n
     assert d["bit_exact_vs_expected_row"] is True and d["stats_all"]["verified"] is True
     assert d["allreduce_ms_per_step"] is not None
     # (on a box with >= n GPUs the ranks get a GPU each and the collective is RCCL)
     assert d["backend"] in ("gloo", "nccl")
     assert abs(d["shard_bytes_per_rank"] * n - d["config"]["bytes"]) <= 317 * n
+    # the configs that are defined on several GPUs: grep @ C3 (sum all-reduce of the counts) and rmdup @ C5 (tuple
+    # all-to-all, a duplicate's first occurrence may sit on the rank before), survivors resident in HBM
+    ops = d["ops"]
+    assert "error" not in ops, ops
+    g, r = ops["grep -s -p @ C3"], ops["rmdup -s @ C5"]
+    assert g["exact"] is True and g["n_gpus"] == n and g["hits"] >= g["planted"] > 0 and g["out_bytes"] == 317 * g["hits"], g
+    assert r["exact"] is True and r["n_gpus"] == n and r["survivors"] == r["records"] - r["records"] // 5, r
+    assert set(r["phases_ms_per_rank"]) == {"keys", "pack", "all_to_all", "resolve", "reply", "emit"}
+    assert len(r["per_rank_own_ms"]) == n and all(b > 0 for b in r["tuple_bytes_sent_per_rank"])
+    assert sum(r["tuple_bytes_sent_per_rank"]) == 24 * r["records"]
 
 
 def test_bench_ops_object_small():

@@ -125,6 +125,13 @@ def _rmdup_worker(rank, world, port, data, opts, q, store=None):
         lo, hi = bdist.shard_bounds(data, world, bsk.FORMAT_FASTQ)[rank]
         shard = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.empty(0, dtype=torch.uint8)
         out = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts))
+        # the resident form (bench.py's N > 1 leg: survivors stay with the backend) and the per-phase clock
+        phases = {}
+        res = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts), to_host=False, phases=phases)
+        assert bytes(res) == out and res.len == len(out) and res.records == out.count(b"\n") // 4
+        assert set(phases) >= {"keys", "pack", "all_to_all", "resolve", "reply", "emit", "tuple_bytes_sent"}
+        assert phases["tuple_bytes_sent"] == 24 * (shard.numpy().tobytes().count(b"\n") // 4)
+        assert 0 <= phases["tuple_bytes_sent_off_rank"] <= phases["tuple_bytes_sent"]
         if store:
             bdist.store_fastx(store, out)   # scan of sizes + one pwrite per rank (FileStore's ordered single-file merge)
         q.put((rank, out))

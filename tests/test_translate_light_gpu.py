@@ -103,3 +103,29 @@ def test_text_that_does_not_fit_goes_through_the_full_index(why, monkeypatch):
     if why != "narrow":   # (the head sample of the narrow file already says no: the light pass is not even tried)
         assert ("k_fasta_starts" in outs[0][1]) == (why != "switch")
     assert "k_fasta_starts" not in outs[1][1]        # the context remembered
+
+
+@pytest.mark.parametrize("lines_of", [(60, 50, 60, 60), (60, 55, 60, 5), (60, 60, 48, 60, 12), (70, 69, 70, 1)])
+def test_a_break_in_the_right_window_but_the_wrong_place_is_not_trusted(lines_of, monkeypatch):
+    """lines of 60 / 50 / 60 / 60 bases have the line COUNT and the LENGTH that the light table derives
+    from "every line but the last is as long as the first" (60 / 60 / 60 / 50), and every window of k_translate_wide that
+    expects a line break holds one -- a few bytes off.  The window check must look at the PLACE of the break: such a
+    record goes through the full index pass and comes out as SeqParser joins it (helper.go:252-283)."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(sum(lines_of))
+    data = fasta(rng, 900, lines_of[0], lens=(300, 900))   # a regular file around the records in question
+    recs = []
+    for i in range(40):
+        s = "".join(rng.choice("ACGT") for _ in range(sum(lines_of)))
+        body, at = "", 0
+        for w in lines_of:
+            body += s[at:at + w] + "\n"
+            at += w
+        recs.append(">odd%d\n%s" % (i, body))
+    data = data + "".join(recs).encode() + fasta(rng, 50, lines_of[0])
+    opts = {"Frame": ["6"]}
+    want = oracle.translate(data, False, json.dumps(opts))
+    outs = translate(data, opts)
+    assert outs[0][0] == want and outs[1][0] == want
+    assert "k_fasta_starts" in outs[0][1] and "k_index=" in outs[0][1]   # tried light, fell back
+    assert "k_fasta_starts" not in outs[1][1]
