@@ -44,6 +44,13 @@ int fail(const bsk_ctx* c, int code, const std::string& m) {
             return fail(ctx, BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// entry of a call that uses the context's device state: refuses a second concurrent caller, selects the device
+#define BSK_ENTER(ctx)                                                            \
+    bsk_call_scope scope__(ctx);                                                  \
+    if (!scope__.owns) return fail(ctx, BSK_ERR_INVALID_ARG, BSK_BUSY_TEXT);      \
+    HIP_TRY(ctx, hipSetDevice((ctx)->device))
+
+
 constexpr uint64_t MIN_RANGE_BYTES = 64 * 1024;  // BSK_MIN_RANGE_BYTES overrides (tests stress tiny ranges)
 constexpr int RANGES_PER_WAVE = 4;
 
@@ -90,8 +97,14 @@ int init_device(bsk_ctx* c) {
     HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
     c->num_cus = p.multiProcessorCount;
     apply_tuning(c);
-    HIP_TRY(c, hipMalloc((void**)&c->d_status, 4 * sizeof(uint64_t)));  // [2]: scratch of bsk_stats_collect
-    HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_ctl, bsk_ctx::CTL_WORDS * sizeof(uint64_t)));
+    HIP_TRY(c, hipMemset(c->d_ctl, 0, bsk_ctx::CTL_WORDS * sizeof(uint64_t)));
+    c->d_status = c->d_ctl;        // [2]: scratch of bsk_stats_collect
+    c->d_counter = c->d_ctl + 8;
+    c->d_fin = c->d_ctl + 16;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, bsk_ctx::CTL_WORDS * sizeof(uint64_t), hipHostMallocDefault));
+    memset(c->h_ctl, 0, bsk_ctx::CTL_WORDS * sizeof(uint64_t));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_head, bsk_ctx::HEAD_BYTES + bsk_ctx::TAIL_BYTES, hipHostMallocDefault));
     if (c->op == Op::Stats) {
         const size_t len = (size_t)STATS_HDR + c->hist_cap;
         HIP_TRY(c, hipMalloc((void**)&c->d_vec, len * sizeof(uint64_t)));
@@ -214,7 +227,9 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_rng) hipFree(c->d_rng);
         if (c->d_parts) hipFree(c->d_parts);
         if (c->d_vec) hipFree(c->d_vec);
-        if (c->d_status) hipFree(c->d_status);
+        if (c->d_ctl) hipFree(c->d_ctl);
+        if (c->h_ctl) hipHostFree(c->h_ctl);
+        if (c->h_head) hipHostFree(c->h_head);
         if (c->d_overflow) hipFree(c->d_overflow);
         for (void* p : {(void*)c->d_text_w, (void*)c->d_lin_off, (void*)c->d_lin, (void*)c->d_codon, (void*)c->d_keys,
                         (void*)c->d_table})
@@ -256,8 +271,7 @@ void bsk_destroy(bsk_ctx* c) {
             if (p) hipFree(p);
         for (void* p : {(void*)c->table.start, (void*)c->table.l_head, (void*)c->table.l_seq, (void*)c->table.aux, (void*)c->table.text_w,
                         (void*)c->d_range_count, (void*)c->d_range_base, (void*)c->d_out_len, (void*)c->d_out_off,
-                        (void*)c->d_scan_tmp, (void*)c->d_out, (void*)c->d_lut, (void*)c->d_qual_err,
-                        (void*)c->d_counter})
+                        (void*)c->d_scan_tmp, (void*)c->d_out, (void*)c->d_lut, (void*)c->d_qual_err})
             if (p) hipFree(p);
         for (int i = 0; i < 2; ++i) {
             if (c->d_stage[i]) hipFree(c->d_stage[i]);
@@ -299,10 +313,10 @@ size_t bsk_stats_vector_len(const bsk_ctx* c) { return c ? (size_t)STATS_HDR + c
 int bsk_stats_reset(bsk_ctx* c, void* stream) {
     if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
     if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(c, hipMemsetAsync(c->d_vec, 0, ((size_t)STATS_HDR + c->hist_cap) * sizeof(uint64_t), st));
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     return BSK_OK;
 }
 
@@ -396,7 +410,7 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
         return fail(c, BSK_ERR_INVALID_ARG, "libbsk: format must be BSK_FORMAT_FASTA or BSK_FORMAT_FASTQ");
     if (n == 0) return BSK_OK;
     if (!shard) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null shard");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
 
     // head of the lowest-pid shard: type guess (stats.go:106-114) and Take(1) (bigseqkit/stats.go:117)
@@ -580,7 +594,7 @@ int bsk_stats_collect(bsk_ctx* c, const void* d_vec, int64_t* keys, int64_t* val
     if (!c || c->op != Op::Stats) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Stats context");
     if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
     if (!n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_out");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     HIP_TRY(c, hipDeviceSynchronize());
     // only the used part of the 512 KiB histogram crosses PCIe (short reads: a few hundred bins)
     const uint64_t* dv = d_vec ? (const uint64_t*)d_vec : c->d_vec;
@@ -622,7 +636,7 @@ int bsk_stats_overflow_total(const bsk_ctx* c, uint64_t* total) {
 int bsk_stats_overflow_get(bsk_ctx* c, uint64_t* lens, size_t cap, size_t* n_out) {
     if (!c || c->op != Op::Stats || !n_out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
     if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     HIP_TRY(c, hipDeviceSynchronize());
     uint64_t status[2];
     HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
@@ -638,7 +652,7 @@ int bsk_stats_overflow_add(bsk_ctx* c, const uint64_t* lens, size_t n) {
     if (!c || c->op != Op::Stats || (n && !lens)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad argument");
     if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
     if (n == 0) return BSK_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     HIP_TRY(c, hipDeviceSynchronize());
     uint64_t status[2];
     HIP_TRY(c, hipMemcpy(status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
@@ -737,7 +751,7 @@ static int check_run_args(bsk_ctx* c, const void* shard, size_t n, int format) {
 int bsk_out_to_host(bsk_ctx* c, const bsk_out* out, void* dst, size_t cap) {
     if (!c || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null argument");
     if (out->len > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     HIP_TRY(c, hipDeviceSynchronize());
     if (out->len) HIP_TRY(c, hipMemcpy(dst, out->d_data, out->len, hipMemcpyDeviceToHost));
     return BSK_OK;
@@ -767,13 +781,13 @@ static int run_maybe_multiline(bsk_ctx* c, run_fn fn, const uint8_t* d, size_t n
     const int rc0 = rc;
     const uint8_t* d2 = nullptr;
     size_t n2 = 0;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
     if (rc != BSK_OK) {
         if (wrapped_later) { c->set_error(msg); return rc0; }  // (not FASTQ under either reader: the first complaint stands)
         return rc;
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     c->norm_active = true;
     rc = fn(c, d2, n2, format, st, out);
     c->norm_active = false;
@@ -790,7 +804,7 @@ static int normalize_pieces(bsk_ctx* c, const uint8_t* d, const std::vector<uint
     for (size_t k = 0; k < ends.size(); ++k) {
         const uint8_t* dk = nullptr;
         size_t nk = 0;
-        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
         int rc = normalize_multiline_fastq(c, d + from, ends[k] - from, st, &dk, &nk);
         if (rc != BSK_OK) return rc;
         // (a text that does not end with a newline must not run into the next one)
@@ -817,7 +831,7 @@ static int normalize_pieces(bsk_ctx* c, const uint8_t* d, const std::vector<uint
         ends2->push_back(total);
         from = ends[k];
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     *d2 = c->d_norm2;
     return BSK_OK;
 }
@@ -832,9 +846,9 @@ int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int 
                     uint64_t* n_records) {
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
@@ -853,13 +867,13 @@ int bsk_index_build(bsk_ctx* c, const void* shard, size_t n, int on_device, int 
         const int rc0 = rc;
         const uint8_t* d2 = nullptr;
         size_t n2 = 0;
-        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
         rc = normalize_multiline_fastq(c, d, n, st, &d2, &n2);
         if (rc != BSK_OK) {
             if (rc0 != BSK_ERR_MULTILINE_FASTQ) { c->set_error(msg); return rc0; }
             return rc;
         }
-        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
         c->norm_active = true;
         rc = build_index(c, d2, n2, format, st);
         c->norm_active = false;
@@ -877,7 +891,7 @@ int bsk_index_copy(bsk_ctx* c, uint64_t* starts, uint32_t* head_len, uint32_t* s
     if (!c || c->device < 0) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad context");
     const uint64_t n = c->table.n;
     if (n > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     HIP_TRY(c, hipDeviceSynchronize());
     if (n == 0) return BSK_OK;
     if (starts) HIP_TRY(c, hipMemcpy(starts, c->table.start, n * 8, hipMemcpyDeviceToHost));
@@ -893,9 +907,9 @@ int bsk_seq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int form
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Seq || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a SeqTransform context");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
@@ -907,9 +921,9 @@ static int run_record_op(bsk_ctx* c, Op want, const char* what, run_fn fn, const
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != want || !out) return fail(c, BSK_ERR_INVALID_ARG, std::string("libbsk: not a ") + what + " context");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
@@ -947,9 +961,9 @@ int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int 
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Concat || !out || n_first > n) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Concat context / bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
@@ -973,9 +987,9 @@ int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Common || !out || !file_ends || n_files < 2 || n_files > 64 || file_ends[n_files - 1] != n)
         return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Common context / bad argument (2..64 files, file_ends[last] == n)");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
@@ -998,9 +1012,9 @@ int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Pair || !outs || n_first > n) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Pair context / bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
+    BSK_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
     rc = stage_shard(c, shard, n, on_device, st, &d);
     if (rc != BSK_OK) return rc;
@@ -1098,17 +1112,17 @@ static int dist_enter(bsk_ctx* c, const char* what) {
     if (!c) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null context");
     if (c->op != Op::RmDup) return fail(c, BSK_ERR_INVALID_ARG, std::string("libbsk: ") + what + " needs a RmDup context");
     if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context has no device (options only)");
-    HIP_TRY(c, hipSetDevice(c->device));
     return BSK_OK;
 }
 
 int bsk_rmdup_dist_keys(bsk_ctx* c, const void* d_shard, size_t n, int format, void* stream, uint64_t* n_records) {
     int rc = dist_enter(c, "bsk_rmdup_dist_keys");
     if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
     rc = check_run_args(c, d_shard, n, format);
     if (rc != BSK_OK) return rc;
     if (!n_records) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null n_records");
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), (hipStream_t)stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), (hipStream_t)stream));
     {
         const int rcm = rmdup_dist_keys(c, (const uint8_t*)d_shard, n, format, (hipStream_t)stream, n_records);
         return rcm == BSK_ERR_MULTILINE_FASTQ ? multiline_unsupported(c) : rcm;
@@ -1119,6 +1133,7 @@ int bsk_rmdup_dist_keys(bsk_ctx* c, const void* d_shard, size_t n, int format, v
 int bsk_selftest_rmdup_keys(bsk_ctx* c, uint64_t* k1, uint64_t* k2, size_t cap, size_t* n_out) {
     int rc = dist_enter(c, "bsk_selftest_rmdup_keys");
     if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
     const size_t N = (size_t)c->table.n;
     if (n_out) *n_out = N;
     if (N > cap || !k1 || !k2) return fail(c, BSK_ERR_CAPACITY, "libbsk: key buffers too small");
@@ -1134,6 +1149,7 @@ int bsk_selftest_rmdup_keys(bsk_ctx* c, uint64_t* k1, uint64_t* k2, size_t cap, 
 int bsk_rmdup_dist_pack(bsk_ctx* c, uint64_t base_index, int world, void* d_send, uint64_t* counts, void* stream) {
     int rc = dist_enter(c, "bsk_rmdup_dist_pack");
     if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
     if (world < 1 || world > 64 || !counts || (!d_send && c->table.n)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad pack arguments");
     return rmdup_dist_pack(c, base_index, world, (uint64_t*)d_send, counts, (hipStream_t)stream);
 }
@@ -1141,6 +1157,7 @@ int bsk_rmdup_dist_pack(bsk_ctx* c, uint64_t base_index, int world, void* d_send
 int bsk_rmdup_dist_resolve(bsk_ctx* c, const void* d_tuples, uint64_t m, void* d_keep, void* stream) {
     int rc = dist_enter(c, "bsk_rmdup_dist_resolve");
     if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
     if (m && (!d_tuples || !d_keep)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null tuples / keep");
     return rmdup_dist_resolve(c, (const uint64_t*)d_tuples, m, (uint8_t*)d_keep, (hipStream_t)stream);
 }
@@ -1149,6 +1166,7 @@ int bsk_rmdup_dist_emit(bsk_ctx* c, const void* d_send, const void* d_reply, uin
                         bsk_out* out) {
     int rc = dist_enter(c, "bsk_rmdup_dist_emit");
     if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
     if (!out || (c->table.n && (!d_send || !d_reply))) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null send / reply / out");
     return rmdup_dist_emit(c, (const uint64_t*)d_send, (const uint8_t*)d_reply, base_index, (hipStream_t)stream, out);
 }
@@ -1214,7 +1232,7 @@ int bsk_profile_enable(bsk_ctx* c, int on) {
 int bsk_profile_read(bsk_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
     if (!c || !kernel) return BSK_ERR_INVALID_ARG;
     if (c->device >= 0) {
-        HIP_TRY(c, hipSetDevice(c->device));
+        BSK_ENTER(c);
         for (auto& p : c->pending) {
             HIP_TRY(c, hipEventSynchronize(p.b));
             float ms = 0;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdlib>
 #include <cctype>
 #include <cstdint>
@@ -60,6 +61,11 @@ struct bsk_ctx {
     int device = -1;  // < 0: options only
     mutable std::mutex mu;
     mutable std::string last_error;
+    // One caller at a time (include/bsk.h "Threads"): a context owns its output buffer, record table and control block, so
+    // the reference's "Call() from Threads() goroutines on one struct" (bigseqkit-lib/helper.go:413-416) maps to one
+    // context per caller thread.  A second call that arrives while one is running is refused (BSK_ERR_INVALID_ARG,
+    // "context busy"), not raced.
+    std::atomic<bool> busy{false};
 
     // ---- device state shared by the ops -----------------------------------
     int num_cus = 0;
@@ -76,7 +82,29 @@ struct bsk_ctx {
     bsk::Alphabet alphabet = bsk::AB_NONE;  // forced by -t, else AB_NONE
     uint32_t hist_cap = 1u << 16;
     uint64_t* d_vec = nullptr;       // ctx-owned stats vector
-    uint64_t* d_status = nullptr;    // [0] err flags [1] overflow count
+    uint64_t* d_status = nullptr;    // [0] err flags [1] overflow count            (= d_ctl)
+    // ---- the control block: every scalar a call reads back lives in ONE allocation and comes to the host with ONE copy
+    // into pinned memory (ctl_readback).  Round 3 fetched total / kept / long count / status with a copy each: ~17 us of
+    // stream time per copy, twenty of them in a `grep` call -- 0.6 ms of a 4.4 ms call.
+    //   d_ctl[0..7]  = d_status ([0] flags [1] stats overflow count [2] collect scratch [3] rmdup overflow-list count;
+    //                  zeroed at the entry of every run)    d_ctl[8..15] = d_counter    d_ctl[16..31] = d_fin (FIN_* below)
+    uint64_t* d_ctl = nullptr;
+    uint64_t* h_ctl = nullptr;       // pinned mirror [CTL_WORDS]
+    uint64_t* d_fin = nullptr;
+    static constexpr int CTL_WORDS = 32;
+    enum { FIN_TOTAL = 0, FIN_KEPT = 1, FIN_LONG_COUNT = 2, FIN_LONG_MAX = 3, FIN_OTHER = 4, FIN_TABLE_N = 5, FIN_AUX0 = 6, FIN_AUX1 = 7 };
+    uint64_t fin(int k) const { return h_ctl[16 + k]; }
+    uint64_t status_word() const { return h_ctl[0]; }
+    // ---- head (and tail) of the shard of the running call, in pinned memory: ONE copy per call serves the alphabet
+    // guess, the record density, the multi-line check and the light FASTA table (each took its own copy before)
+    uint8_t* h_head = nullptr;       // [HEAD_BYTES + TAIL_BYTES]
+    static constexpr size_t HEAD_BYTES = 256 * 1024, TAIL_BYTES = 4096;
+    const uint8_t* head_of = nullptr;  // the shard the sample belongs to (null: none)
+    size_t head_n = 0, head_len = 0, tail_len = 0;
+    uint64_t call_gen = 0, head_gen = ~0ull;  // a sample lives for one call
+    uint64_t alpha_gen = ~0ull;               // ... and so does the alphabet guessed from it (partition_alphabet)
+    const uint8_t* alpha_of = nullptr;
+    int alpha_format = -1, alpha_value = 0;
     uint64_t* d_overflow = nullptr;
     uint64_t overflow_cap = 0;
     int qual_offset = 33;
@@ -169,6 +197,7 @@ struct bsk_ctx {
     uint8_t* d_pat = nullptr;
     uint32_t* d_pat_off = nullptr;
     uint64_t pat_cap = 0, pat_off_cap = 0;
+    std::string pat_sig, ftab_sig;  // what d_pat / d_ftab hold (the uploads are skipped when a call needs the same again)
     uint8_t* d_ftab = nullptr;  // pair-hash table of the fused pattern filter (stream_filter.hpp): u32 tab[slots] ++ u16 ent[slots]
     uint64_t ftab_cap = 0;
     std::vector<std::string> pattern_names;  // locate: names as given (== the -p text, or the FASTA name with -f)
@@ -270,6 +299,21 @@ struct bsk_ctx {
     void warn(const std::string& m, bool unless_quiet = false) const { log("WARN", m, unless_quiet); }
     void info(const std::string& m, bool unless_quiet = false) const { log("INFO", m, unless_quiet); }
 };
+
+// the scope of one C-ABI call that runs on the context's device state (BSK_ENTER in capi.cpp / store.cpp)
+struct bsk_call_scope {
+    bsk_ctx* c;
+    bool owns;
+    explicit bsk_call_scope(bsk_ctx* c_) : c(c_), owns(false) {
+        bool expected = false;
+        owns = c->busy.compare_exchange_strong(expected, true, std::memory_order_acquire);
+        if (owns) ++c->call_gen;
+    }
+    ~bsk_call_scope() { if (owns) c->busy.store(false, std::memory_order_release); }
+    bsk_call_scope(const bsk_call_scope&) = delete;
+    bsk_call_scope& operator=(const bsk_call_scope&) = delete;
+};
+#define BSK_BUSY_TEXT "libbsk: context busy: another call is running on this context (one context per caller thread, include/bsk.h)"
 
 // optional HIP-event bracket around one launch (bsk_profile_enable): read back by bsk_profile_read under `name`
 struct Timed {

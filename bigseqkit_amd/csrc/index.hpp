@@ -59,9 +59,11 @@ hipError_t launch_index(bool fastq, bool dpp, int blocks, const uint8_t* buf, ui
                         uint32_t nranges, uint32_t* queue, const IndexDev& D, hipStream_t st, uint64_t skip_chunk = 0);
 int index_max_blocks_per_cu(bool fastq, bool dpp);
 // exclusive scan of u64 counts (n <= a few 10^4; one block): out[0..n], out[n] = total
-hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st);
+hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st, uint64_t* total_at = nullptr);
 // exclusive scan u32 -> u64 over N items (N up to 2^32): out[0..N], out[N] = total; tmp: u64[(N + 2047) / 2048 + 1]
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st);
+hipError_t launch_scan_u32_fin(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, uint32_t thresh, uint32_t* long_list,
+                               uint64_t* fin, hipStream_t st);
 hipError_t launch_reset_queue(uint32_t* queue, hipStream_t st);
 // gather the per-range slices of a sparse table (mode 2) into a dense one
 // FASTA, line-start ranges: complete l_seq / aux / text_w of the records that span ranges (dense table, exact bases)

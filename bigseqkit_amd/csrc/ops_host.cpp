@@ -255,11 +255,13 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     // Falls back to the exact count + write passes when a slice overflows.
     const char* ix = c->tune.get("index");
     if (!(ix && strcmp(ix, "twopass") == 0)) {
-        const size_t hb = std::min<size_t>(n, 256 * 1024);
-        std::vector<uint8_t> head(hb);
-        HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
-        HIP_TRYX(c, hipStreamSynchronize(st));
-        if (fastq && !c->norm_active && fastq_head_multiline(head.data(), hb)) return BSK_ERR_MULTILINE_FASTQ;
+        {   // (the call's one head sample: pinned memory, shared with the alphabet guess)
+            const int rch = sample_head(c, d_buf, n, st);
+            if (rch != BSK_OK) return rch;
+        }
+        const size_t hb = c->head_len;
+        const uint8_t* head = c->h_head;
+        if (fastq && !c->norm_active && fastq_head_multiline(head, hb)) return BSK_ERR_MULTILINE_FASTQ;
         uint64_t recs = 0;
         if (fastq) { for (size_t i = 0; i < hb; ++i) recs += head[i] == '\n'; recs /= 4; }
         else { for (size_t i = 0; i + 1 < hb; ++i) recs += (head[i] == '\n' && head[i + 1] == '>'); recs += 1; }
@@ -283,11 +285,13 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
                 Timed t(c, F ? "k_filter" : (hash ? "k_rmdup_stream" : "k_index"), st);
                 HIP_TRYX(c, launch_pass(blocks, anchors, nranges, queue, D));
             }
-            HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st));
-            uint64_t status = 0;
-            HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
-            HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-            HIP_TRYX(c, hipStreamSynchronize(st));
+            HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st, c->d_fin + bsk_ctx::FIN_TABLE_N));
+            {   // number of records + status word: one read-back
+                const int rcr = ctl_readback(c, st);
+                if (rcr != BSK_OK) return rcr;
+            }
+            total = c->fin(bsk_ctx::FIN_TABLE_N);
+            uint64_t status = c->status_word();
             if (status & ERR_FILTER_OVERFLOW) {
                 status &= ~(uint64_t)(ERR_FILTER_OVERFLOW | ERR_CAPACITY);
                 HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
@@ -562,14 +566,44 @@ static std::vector<uint8_t> head_first_seq(const std::vector<uint8_t>& b, int fo
     return s;
 }
 
+// ---- the control block and the head sample (ctx.hpp): what a call learns from the device, in as few round trips as the
+// data dependencies allow.  A stream synchronisation costs 15 - 30 us of idle device, a copy of eight bytes as much as a
+// copy of 256: round 3's calls made twenty of them (0.6 ms of a 4.4 ms grep), this round's four.
+int ctl_readback(bsk_ctx* c, hipStream_t st) {
+    HIP_TRYX(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, bsk_ctx::CTL_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    return BSK_OK;
+}
+
+// head (<= 256 KiB) and tail (<= 4 KiB) of the shard of the running call in c->h_head; a second request of the same call
+// for the same shard costs nothing
+int sample_head(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st) {
+    if (c->head_gen == c->call_gen && c->head_of == d_buf && c->head_n == n) return BSK_OK;
+    c->head_len = std::min<size_t>(n, bsk_ctx::HEAD_BYTES);
+    c->tail_len = std::min<size_t>(n, bsk_ctx::TAIL_BYTES);
+    if (c->head_len) HIP_TRYX(c, hipMemcpyAsync(c->h_head, d_buf, c->head_len, hipMemcpyDeviceToHost, st));
+    if (c->tail_len) HIP_TRYX(c, hipMemcpyAsync(c->h_head + bsk_ctx::HEAD_BYTES, d_buf + n - c->tail_len, c->tail_len, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    c->head_of = d_buf;
+    c->head_n = n;
+    c->head_gen = c->call_gen;
+    return BSK_OK;
+}
+
 Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, int* rc) {
     *rc = BSK_OK;
     if (c->alphabet != AB_NONE) return c->alphabet;
+    if (c->alpha_gen == c->call_gen && c->alpha_of == d_buf && c->alpha_format == format) return (Alphabet)c->alpha_value;
     const int64_t thr = c->opts.ci("AlphabetGuessSeqLength");
     size_t want = (size_t)std::max<int64_t>(thr, 10000) * 2 + 65536;
     want = std::min(want, n);
-    std::vector<uint8_t> h(want);
-    if (want) {
+    std::vector<uint8_t> h;
+    if (want <= bsk_ctx::HEAD_BYTES) {  // the call's head sample holds it
+        *rc = sample_head(c, d_buf, n, st);
+        if (*rc != BSK_OK) return AB_UNLIMIT;
+        h.assign(c->h_head, c->h_head + want);
+    } else {
+        h.resize(want);
         hipError_t e = hipMemcpyAsync(h.data(), d_buf, want, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
@@ -580,7 +614,9 @@ Alphabet partition_alphabet(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     }
     std::vector<uint8_t> s = head_first_seq(h, format, (size_t)std::max<int64_t>(thr, 1) );
     if (thr == 0) s = head_first_seq(h, format, h.size());
-    return guess_alphabet_less_conservatively(s.data(), s.size(), thr);
+    const Alphabet ab = guess_alphabet_less_conservatively(s.data(), s.size(), thr);
+    c->alpha_gen = c->call_gen; c->alpha_of = d_buf; c->alpha_format = format; c->alpha_value = (int)ab;
+    return ab;
 }
 
 // (slack so that a slightly larger next result does not reallocate; capped: 1/8 of a 100 GB output is 12 GB of HBM)
@@ -598,36 +634,30 @@ int ensure_record_scratch(bsk_ctx* c) {
         HIP_TRYX(c, hipMalloc((void**)&c->d_out_off, (cap + 1) * sizeof(uint64_t)));
         c->out_len_cap = cap;
     }
-    const uint64_t need = 2 * ((n + 2047) / 2048) + 4;
+    const uint64_t need = 3 * ((n + 2047) / 2048) + 6;  // block sums, their scan, non-zero counts (launch_scan_u32_fin)
     rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, need, 16);
     if (rc != BSK_OK) return rc;
-    if (!c->d_counter) HIP_TRYX(c, hipMalloc((void**)&c->d_counter, 4 * sizeof(uint64_t)));
-    return BSK_OK;
+    return BSK_OK;  // (c->d_counter: part of the control block, init_device)
 }
 
-// size array -> scan -> total / kept / kernel status; then the caller emits
+// size array -> scan -> total / kept / kernel status; then the caller emits.  Three launches and ONE read-back (round 3:
+// seven launches, four copies): the scan kernels count the records with output and list the records with a very large
+// output (written by whole blocks, k_seq_emit<.., LONG>) on the way, and leave every scalar in the control block.
 int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
-    HIP_TRYX(c, launch_scan_u32(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, st));
-    HIP_TRYX(c, hipMemsetAsync(c->d_counter, 0, 4 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_count_nonzero(c->d_out_len, c->table.n, c->d_counter, st));
-    // records with a very large output are written by whole blocks (k_seq_emit<.., LONG>): list them now, the
-    // synchronisation below is needed anyway
     int rc = grow(c, &c->d_long_list, &c->long_list_cap, c->table.n, c->table.n / 8 + 16);
     if (rc != BSK_OK) return rc;
     {
         const char* e = c->tune.get("long_bytes");
         c->long_thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
     }
-    HIP_TRYX(c, launch_find_long(c->d_out_len, c->table.n, c->long_thresh, c->d_long_list, c->d_counter + 2, st));
-    uint64_t status = 0, lc[2] = {0, 0};
-    HIP_TRYX(c, hipMemcpyAsync(total, c->d_out_off + c->table.n, sizeof *total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(kept, c->d_counter, sizeof *kept, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    c->long_count = lc[0];
-    c->long_max = lc[1];
-    return kernel_error_to_status(c, status);
+    HIP_TRYX(c, launch_scan_u32_fin(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, c->long_thresh, c->d_long_list, c->d_fin, st));
+    rc = ctl_readback(c, st);
+    if (rc != BSK_OK) return rc;
+    *total = c->fin(bsk_ctx::FIN_TOTAL);
+    *kept = c->fin(bsk_ctx::FIN_KEPT);
+    c->long_count = c->fin(bsk_ctx::FIN_LONG_COUNT);
+    c->long_max = c->fin(bsk_ctx::FIN_LONG_MAX);
+    return kernel_error_to_status(c, c->status_word());
 }
 
 // tell the emit kernel which records it must leave to the block-per-chunk launch
@@ -646,7 +676,7 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
         if (rc != BSK_OK) return rc;
         rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
         if (rc != BSK_OK) return rc;
-        uint64_t* d_other = c->d_seg_src + t.n;
+        uint64_t* d_other = c->d_fin + bsk_ctx::FIN_OTHER;  // (in the control block: comes back with the final read-back)
         HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
         HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, d_other, st, P.ren_ord));
         HIP_TRYX(c, launch_seg_first(d_off, t.n, c->d_seg_first, st));
@@ -654,10 +684,9 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
             Timed tm(c, "k_seg_copy", st);
             HIP_TRYX(c, launch_seg_copy(c->d_seg_src, d_off, t.n, c->d_seg_first, d_out, total, d_buf, d_buf + n, st));
         }
-        uint64_t other = 0;
-        HIP_TRYX(c, hipMemcpyAsync(&other, d_other, sizeof other, hipMemcpyDeviceToHost, st));
-        HIP_TRYX(c, hipStreamSynchronize(st));
-        if (other == 0) return BSK_OK;
+        rc = ctl_readback(c, st);
+        if (rc != BSK_OK) return rc;
+        if (c->fin(bsk_ctx::FIN_OTHER) == 0) return BSK_OK;
         P.seg_src = c->d_seg_src;  // the few records the copy left out
     }
     HIP_TRYX(c, launch_seq_emit(d_buf, t, P, d_len, d_off, d_out, st, total, kept));
@@ -847,7 +876,12 @@ int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, T
 // PARITY.md SPLIT-FQ); a sample of strict 4-line records, or one that cannot be judged, gives false
 bool fastq_head_multiline(const uint8_t* h, size_t hb) {
     size_t p = 0;
-    auto line_end = [&](size_t s) { while (s < hb && h[s] != '\n') ++s; return s; };
+    // (memchr: this walks the whole 256 KiB sample of every call -- byte by byte it cost 0.18 ms of host time per call)
+    auto line_end = [&](size_t s) {
+        if (s >= hb) return s;
+        const void* q = memchr(h + s, '\n', hb - s);
+        return q ? (size_t)((const uint8_t*)q - h) : hb;
+    };
     while (p < hb && h[p] == '@') {
         size_t e = line_end(p);
         if (e >= hb) return false;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,22 @@ int group_resolve(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const 
 // FASTA text view of the shard's records (text_dev.hpp); null pointers for FASTQ
 int prepare_text(bsk_ctx* c, const uint8_t* d_buf, int format, hipStream_t st, TextTableH* tt, bool flatten = false,
                  bool keep_out_len = false, uint64_t buf_n = 0);  // buf_n: bytes in the shard (flatten: bounds its wide loads)
+// the control block (status, counters, summary words) in c->h_ctl: one copy + one synchronisation
+int ctl_readback(bsk_ctx* c, hipStream_t st);
+// head / tail of the call's shard in c->h_head (one copy per call and shard)
+int sample_head(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st);
+// f(start, end, terminated) for every line of h[0, hb) -- end = position of its '\n', or hb for a last line without one.
+// memchr per line: the samples are walked once per call, and a byte loop over 256 KiB costs a quarter of a millisecond
+template <class F>
+inline void for_lines(const uint8_t* h, size_t hb, F f) {
+    size_t p = 0;
+    while (p < hb) {
+        const void* q = memchr(h + p, '\n', hb - p);
+        const size_t e = q ? (size_t)((const uint8_t*)q - h) : hb;
+        f(p, e, q != nullptr);
+        p = e + 1;
+    }
+}
 // size array -> scan -> total / kept / kernel status (also lists the records with a very large output)
 int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept);
 void apply_long(const bsk_ctx* c, SeqParams* P);

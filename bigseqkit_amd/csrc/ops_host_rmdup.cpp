@@ -89,10 +89,8 @@ int rmdup_finish(bsk_ctx* c) {
 // The records dedupe left in the overflow list (ops_rmdup.hip: same XXH64 key as an earlier record, another second key):
 // groups of equal (k1, k2) among them keep their lowest record, exactly as the map of RmDupCheck.Call would
 // (rmdup.go:150-199) -- a few records per 10^4 shards, settled on the host.  BSK_ERR_FILTER_FALLBACK: the list did not fit.
-static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st) {
-    uint32_t m = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&m, c->d_ovf, sizeof m, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
+static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st, uint64_t m64) {
+    const uint32_t m = (uint32_t)std::min<uint64_t>(m64, 0xFFFFFFFFull);  // (the list's length: status word [3] of the read-back)
     if (m == 0) return BSK_OK;
     if ((uint64_t)m + 1 > c->ovf_cap) return BSK_ERR_FILTER_FALLBACK;
     uint64_t* d_kk = nullptr;
@@ -229,16 +227,16 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
                                                  by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap, true));
             }
         }
-        uint64_t status = 0;
-        HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-        HIP_TRYX(c, hipStreamSynchronize(st));
+        rc = ctl_readback(c, st);  // status word + the length of the overflow list: one copy
+        if (rc != BSK_OK) return rc;
+        uint64_t status = c->status_word();
         if (status & ERR_BUCKET_OVERFLOW) {
             status &= ~(uint64_t)ERR_BUCKET_OVERFLOW;
             HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));
             HIP_TRYX(c, hipStreamSynchronize(st));
             by_buckets = false;
         } else if (by_keys) {
-            rc = rmdup_settle_overflow(c, d_first, st);
+            rc = rmdup_settle_overflow(c, d_first, st, c->h_ctl[3]);
             if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;  // (the list did not fit: the table path compares bytes)
             else if (rc != BSK_OK) return rc;
             else if (verify_bytes) {
@@ -264,15 +262,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     }
     uint64_t total = 0, kept = 0;
-    rc = finish_sizes(c, st, &total, &kept);
-    if (rc == BSK_OK) {
-        uint64_t status = 0;
-        HIP_TRYX(c, hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost));
-        if (status & ERR_HASH_COLLISION) {
-            c->set_error("libbsk: two distinct subjects share one 64-bit XXH64 key; refusing to guess (rerun on the CPU path)");
-            return BSK_ERR_UNSUPPORTED;
-        }
-    }
+    rc = finish_sizes(c, st, &total, &kept);  // (ERR_HASH_COLLISION comes back as BSK_ERR_UNSUPPORTED: kernel_error_to_status)
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;

@@ -51,15 +51,16 @@ static int seq_names_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t
     uint64_t chunk = 0;
     int rc = prep_ranges(c, d_buf, n, /*fastq=*/true, blocks, st, &nranges, &chunk);
     if (rc != BSK_OK) return rc;
-    const size_t hb = std::min<size_t>(n, 256 * 1024);
-    std::vector<uint8_t> head(hb);
-    HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    if (!c->norm_active && fastq_head_multiline(head.data(), hb)) return BSK_ERR_MULTILINE_FASTQ;
-    uint64_t hdr = 0, line = 0, line_start = 0;
-    for (size_t i = 0; i < hb; ++i)
-        if (head[i] == '\n') { if ((line & 3) == 0) hdr += i - line_start; ++line; line_start = i + 1; }
-    if ((line & 3) == 0) hdr += hb - line_start;  // a header cut by the end of the sample
+    rc = sample_head(c, d_buf, n, st);  // (the call's one head sample, pinned)
+    if (rc != BSK_OK) return rc;
+    const size_t hb = c->head_len;
+    const uint8_t* head = c->h_head;
+    if (!c->norm_active && fastq_head_multiline(head, hb)) return BSK_ERR_MULTILINE_FASTQ;
+    uint64_t hdr = 0, line = 0;
+    for_lines(head, hb, [&](size_t s0, size_t e0, bool) {  // (a header cut by the end of the sample counts as far as it goes)
+        if ((line & 3) == 0) hdr += e0 - s0;
+        ++line;
+    });
     double ratio = (double)(hdr + 64) / (double)hb;
     if (const char* sc = c->tune.get("names_scale")) ratio *= atof(sc);  // tests: force the overflow -> fallback route
     uint64_t slice_cap = (uint64_t)((double)chunk * ratio * 1.25) + (c->tune.get("names_scale") ? 16 : 4096);
@@ -83,13 +84,12 @@ static int seq_names_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t
         HIP_TRYX(c, launch_names(c->use_dpp, blocks, d_buf, n, c->d_anchors,
                                  nranges, reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1), D, st));
     }
-    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st));
-    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st));
-    uint64_t total = 0, records = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&records, d_count_base + nranges, sizeof records, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
+    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st, c->d_fin + bsk_ctx::FIN_AUX0));
+    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st, c->d_fin + bsk_ctx::FIN_AUX1));
+    rc = ctl_readback(c, st);  // bytes, records, status: one copy
+    if (rc != BSK_OK) return rc;
+    const uint64_t total = c->fin(bsk_ctx::FIN_AUX0), records = c->fin(bsk_ctx::FIN_AUX1);
+    uint64_t status = c->status_word();
     if (status & ERR_CAPACITY) {
         status &= ~(uint64_t)ERR_CAPACITY;
         HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));

@@ -264,17 +264,17 @@ static int subseq_stream_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStre
     uint64_t chunk = 0;
     int rc = prep_ranges(c, d_buf, n, /*fastq=*/true, blocks, st, &nranges, &chunk);
     if (rc != BSK_OK) return rc;
-    const size_t hb = std::min<size_t>(n, 256 * 1024);
-    std::vector<uint8_t> head(hb);
-    HIP_TRYX(c, hipMemcpyAsync(head.data(), d_buf, hb, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
-    if (!c->norm_active && fastq_head_multiline(head.data(), hb)) return BSK_ERR_MULTILINE_FASTQ;
+    rc = sample_head(c, d_buf, n, st);  // (the call's one head sample, pinned)
+    if (rc != BSK_OK) return rc;
+    const size_t hb = c->head_len;
+    const uint8_t* head = c->h_head;
+    if (!c->norm_active && fastq_head_multiline(head, hb)) return BSK_ERR_MULTILINE_FASTQ;
     // output bytes per input byte over the complete records of the sample
-    uint64_t in_b = 0, out_b = 0, line = 0, line_start = 0, rec_out = 0, max_line = 0;
-    for (size_t i = 0; i < hb; ++i) {
-        if (head[i] != '\n') continue;
-        const uint64_t ll = i - line_start;
+    uint64_t in_b = 0, out_b = 0, line = 0, rec_out = 0, max_line = 0;
+    for_lines(head, hb, [&](size_t s0, size_t e0, bool terminated) {
+        const uint64_t ll = e0 - s0;
         max_line = std::max(max_line, ll);
+        if (!terminated) return;
         const uint32_t role = (uint32_t)(line & 3);
         if (role == 0) rec_out = ll + 1;
         else if (role == 2) rec_out += 2;
@@ -283,11 +283,9 @@ static int subseq_stream_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStre
             sub_location((uint32_t)ll, c->region_start, c->region_end, &b, &e);
             rec_out += (uint64_t)(e - b) + 1;
         }
-        if (role == 3) { out_b += rec_out; in_b = i + 1; }
+        if (role == 3) { out_b += rec_out; in_b = e0 + 1; }
         ++line;
-        line_start = i + 1;
-    }
-    max_line = std::max<uint64_t>(max_line, hb - line_start);
+    });
     // a lane copies its piece alone: lines of kilobytes (long reads) stay with the record-table kernels
     if (max_line > 2048 || in_b == 0) return BSK_ERR_FILTER_FALLBACK;
     double ratio = (double)(out_b + 64) / (double)in_b;
@@ -313,13 +311,12 @@ static int subseq_stream_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStre
         HIP_TRYX(c, launch_subseq_stream(c->use_dpp, blocks, d_buf, n, c->d_anchors, nranges,
                                          reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1), D, st));
     }
-    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st));
-    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st));
-    uint64_t total = 0, records = 0, status = 0;
-    HIP_TRYX(c, hipMemcpyAsync(&total, c->d_range_base + nranges, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&records, d_count_base + nranges, sizeof records, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRYX(c, hipStreamSynchronize(st));
+    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st, c->d_fin + bsk_ctx::FIN_AUX0));
+    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st, c->d_fin + bsk_ctx::FIN_AUX1));
+    rc = ctl_readback(c, st);  // bytes, records, status: one copy
+    if (rc != BSK_OK) return rc;
+    const uint64_t total = c->fin(bsk_ctx::FIN_AUX0), records = c->fin(bsk_ctx::FIN_AUX1);
+    uint64_t status = c->status_word();
     if (status & ERR_CAPACITY) {
         status &= ~(uint64_t)ERR_CAPACITY;
         HIP_TRYX(c, hipMemcpyAsync(c->d_status, &status, sizeof status, hipMemcpyHostToDevice, st));

@@ -701,6 +701,7 @@ __global__ __launch_bounds__(256) void k_bucket_dedupe(const uint64_t* __restric
             else {
                 const uint32_t at = atomicAdd(&ovf[0], 1u);  // (rare: no aggregation)
                 if (at < ovf_cap) ovf[1u + at] = idx;
+                atomicAdd((unsigned long long*)&status[3], 1ull);  // the count again, where the host's one read-back finds it
             }
         }
     }

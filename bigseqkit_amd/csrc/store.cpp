@@ -320,6 +320,8 @@ int bsk_store_put_host(bsk_store* s, uint64_t part, const void* data, size_t n) 
 int bsk_store_put(bsk_store* s, bsk_ctx* c, uint64_t part, const bsk_out* o) {
     if (!s || !c || !o) return BSK_ERR_INVALID_ARG;
     if (c->device < 0) { c->set_error("libbsk: context was created without a device"); return BSK_ERR_NO_DEVICE; }
+    bsk_call_scope scope(c);
+    if (!scope.owns) { c->set_error(BSK_BUSY_TEXT); return BSK_ERR_INVALID_ARG; }
     ST_TRY(c, hipSetDevice(c->device));
     ST_TRY(c, hipDeviceSynchronize());
     if (!c->copy_stream[1]) ST_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking));
@@ -364,6 +366,10 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
     bool chunkable = false;
     dev_fn fn = fn_of(c, &chunkable);
     if (!fn) { c->set_error("libbsk: bsk_run_to_store: operator without a single-shard record output"); return BSK_ERR_INVALID_ARG; }
+    if (out_bytes) *out_bytes = 0;      // (also on the early ways out: ADVICE r03)
+    if (out_records) *out_records = 0;
+    bsk_call_scope scope(c);
+    if (!scope.owns) { c->set_error(BSK_BUSY_TEXT); return BSK_ERR_INVALID_ARG; }
     ST_TRY(c, hipSetDevice(c->device));
     for (int b = 0; b < 2; ++b)
         if (!c->copy_stream[b]) ST_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[b], hipStreamNonBlocking));
@@ -439,7 +445,7 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
         const int b = (int)(i & 1);
         if (i + 1 < nchunks) { rc = stage_in(i + 1); if (rc != BSK_OK) break; }
         ST_TRY(c, hipStreamWaitEvent(st, S.in_done[b], 0));
-        ST_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+        ST_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
         c->cur_pid = (pid == 0 && i == 0) ? 0 : (pid == 0 ? 1 : pid);  // locate: the header row belongs to the first chunk of partition 0
         // SeqType auto: the reference guesses the alphabet ONCE per partition, from its first record (helper.go:286-291);
         // a chunk that guessed from its own first record could search other strands or validate other letters than a
@@ -457,13 +463,14 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
         S.swapped = !S.swapped;
         bsk_out o;
         memset(&o, 0, sizeof o);
+        ++c->call_gen;  // (the staging buffers come round again with other text: nothing sampled from chunk i - 2 may survive)
         rc = fn(c, c->d_stage[b], cuts[i + 1] - cuts[i], format, st, &o);
         if (rc == BSK_ERR_MULTILINE_FASTQ) {  // (range / head / duplicate deal with wrapped records themselves: records_run_device)
             const uint8_t* d2 = nullptr;
             size_t n2 = 0;
             rc = normalize_multiline_fastq(c, c->d_stage[b], cuts[i + 1] - cuts[i], st, &d2, &n2);
             if (rc != BSK_OK) break;
-            ST_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
+            ST_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
             c->norm_active = true;
             rc = fn(c, d2, n2, format, st, &o);
             c->norm_active = false;

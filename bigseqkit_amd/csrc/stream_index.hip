@@ -313,7 +313,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index
 
 // exclusive scan of up to a few 10^6 u64 values with one block: 8 consecutive values per thread and round (the block
 // sums of a 3 x 10^8 record scan are 154 000 values: 75 rounds instead of 600)
-__global__ __launch_bounds__(256) void k_scan_small(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n) {
+__global__ __launch_bounds__(256) void k_scan_small(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n,
+                                                    uint64_t* __restrict__ total_at) {
     constexpr uint32_t PER = 8;
     __shared__ uint64_t s_w[4];
     __shared__ uint64_t s_carry;
@@ -351,7 +352,10 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint64_t* __restrict__
         if (threadIdx.x == 255) s_carry = off + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[n] = s_carry;
+    if (threadIdx.x == 0) {
+        out[n] = s_carry;
+        if (total_at) *total_at = s_carry;  // (a second place for the total: the end of a two-level scan, the control block)
+    }
 }
 
 // ---- large exclusive scan u32 -> u64: reduce / scan of block sums / downsweep ----------
@@ -409,6 +413,127 @@ __global__ void k_set_total(const uint64_t* __restrict__ block_off, uint64_t nbl
 }
 
 __global__ void k_reset_queue(uint32_t* q) { *q = 0; }
+
+// ---- the same scan with the summary of finish_sizes folded in (round 4): three launches instead of seven (reduce, block
+// scan, down sweep, total, memset, count_nonzero, find_long), and every scalar the host wants lands in `fin` (the control
+// block of the context: ONE copy brings total, kept, the long records' count / largest size and the status word)
+__global__ __launch_bounds__(256) void k_scan_reduce_fin(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ sums,
+                                                         uint64_t* __restrict__ cnts) {
+    const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BLOCK;
+    uint64_t acc = 0, nz = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint64_t i = b0 + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) { const uint32_t v = in[i]; acc += v; nz += v != 0u; }
+    }
+    acc = wave_sum_u64(acc);
+    nz = wave_sum_u64(nz);
+    __shared__ uint64_t s_w[4], s_z[4];
+    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = acc; s_z[threadIdx.x >> 6] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        cnts[blockIdx.x] = s_z[0] + s_z[1] + s_z[2] + s_z[3];
+    }
+}
+
+// one block: exclusive scan of the block sums (k_scan_small's loop), the sum of the non-zero counts, out[n] and the
+// summary words; zeroes the long-record words that the down sweep behind it fills
+__global__ __launch_bounds__(256) void k_scan_small_fin(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t nb,
+                                                        const uint64_t* __restrict__ cnts, uint64_t* __restrict__ total_at,
+                                                        uint64_t* __restrict__ fin) {
+    constexpr uint32_t PER = 8;
+    __shared__ uint64_t s_w[4];
+    __shared__ uint64_t s_carry;
+    __shared__ uint64_t s_z[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    uint64_t nz = 0;
+    for (uint32_t i0 = 0; i0 < nb; i0 += 256 * PER) {
+        const uint32_t i = i0 + threadIdx.x * PER;
+        uint64_t v[PER];
+        uint64_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            v[k] = i + k < nb ? in[i + k] : 0;
+            mine += v[k];
+            if (i + k < nb) nz += cnts[i + k];
+        }
+        uint64_t x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+            if (lane >= d) x += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint64_t off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        uint64_t run = off + x - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            if (i + k < nb) out[i + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = off + x;
+        __syncthreads();
+    }
+    nz = wave_sum_u64(nz);
+    if (lane == 0) s_z[wave] = nz;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[nb] = s_carry;
+        *total_at = s_carry;
+        fin[0] = s_carry;                             // FIN_TOTAL
+        fin[1] = s_z[0] + s_z[1] + s_z[2] + s_z[3];   // FIN_KEPT
+        fin[2] = 0;                                   // FIN_LONG_COUNT   (k_scan_down_fin)
+        fin[3] = 0;                                   // FIN_LONG_MAX
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_down_fin(const uint32_t* __restrict__ in, uint64_t n,
+                                                       const uint64_t* __restrict__ block_off, uint64_t* __restrict__ out,
+                                                       uint32_t thresh, uint32_t* __restrict__ long_list,
+                                                       unsigned long long* __restrict__ fin) {
+    __shared__ uint64_t s_w[4];
+    const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint64_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = b0 + k < n ? in[b0 + k] : 0u;
+        tot += v[k];
+        if (v[k] >= thresh && long_list) {  // rare by construction (a record of a MiB or more)
+            long_list[atomicAdd(&fin[2], 1ull)] = (uint32_t)(b0 + k);
+            atomicMax(&fin[3], (unsigned long long)v[k]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64);
+        const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+        if (lane >= d) x += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint64_t off = block_off[blockIdx.x] + x - tot;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (b0 + k < n) out[b0 + k] = off;
+        off += v[k];
+    }
+}
+
+__global__ void k_fin_zero(uint64_t* __restrict__ out0, uint64_t* __restrict__ fin) {
+    out0[0] = 0;
+    fin[0] = 0; fin[1] = 0; fin[2] = 0; fin[3] = 0;
+}
 
 // FASTA, line-start ranges: records that span ranges.  The thread of range r finishes the record that is open at the
 // end of r: bases, region and line layout are completed from the head parts of the following ranges, up to the range
@@ -498,14 +623,14 @@ int index_max_blocks_per_cu(bool fastq, bool dpp) {
     return nb;
 }
 
-hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, in, out, n);
+hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st, uint64_t* total_at) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, in, out, n, total_at);
     return hipGetLastError();
 }
 
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st) {
     if (n == 0) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint64_t*)nullptr, out, 0u);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint64_t*)nullptr, out, 0u, (uint64_t*)nullptr);
         return hipGetLastError();
     }
     const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -513,9 +638,29 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64
     uint64_t* sums = tmp;
     uint64_t* offs = tmp + nb;  // [nb + 1]
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint64_t*)sums, offs, (uint32_t)nb);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint64_t*)sums, offs, (uint32_t)nb, out + n);  // (+ the total)
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(256), 0, st, in, n, (const uint64_t*)offs, out);
-    hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, st, (const uint64_t*)offs, nb, out, n);
+    return hipGetLastError();
+}
+
+// exclusive scan of the output sizes + the summary of the size pass: fin[0] = total bytes, fin[1] = records with output,
+// fin[2] / fin[3] = number / largest size of the records with >= thresh bytes (listed in long_list, any order).
+// tmp: 3 * ceil(n / 2048) + 2 words.
+hipError_t launch_scan_u32_fin(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, uint32_t thresh, uint32_t* long_list,
+                               uint64_t* fin, hipStream_t st) {
+    if (n == 0) {
+        hipLaunchKernelGGL(k_fin_zero, dim3(1), dim3(1), 0, st, out, fin);
+        return hipGetLastError();
+    }
+    const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    uint64_t* sums = tmp;
+    uint64_t* offs = tmp + nb;          // [nb + 1]
+    uint64_t* cnts = tmp + 2 * nb + 1;  // [nb]
+    hipLaunchKernelGGL(k_scan_reduce_fin, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums, cnts);
+    hipLaunchKernelGGL(k_scan_small_fin, dim3(1), dim3(256), 0, st, (const uint64_t*)sums, offs, (uint32_t)nb, (const uint64_t*)cnts,
+                       out + n, fin);
+    hipLaunchKernelGGL(k_scan_down_fin, dim3((unsigned)nb), dim3(256), 0, st, in, n, (const uint64_t*)offs, out, thresh, long_list,
+                       (unsigned long long*)fin);
     return hipGetLastError();
 }
 

@@ -46,10 +46,13 @@ def run(op_name, fn, opts, t, fmt):
             lib.bsk_profile_reset(op.ctx)
             lib.bsk_profile_enable(op.ctx, 1)
         t0 = time.perf_counter()
+        pause = 0.02 if os.environ.get("BSK_TIMELINE") == "1" else 0.0   # scripts/timeline_ops.sh: calls apart in the trace
         for _ in range(reps):
+            if pause:
+                time.sleep(pause)
             check(fn(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, fmt, 0, None, C.byref(out)), op.ctx)
             torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = (time.perf_counter() - t0) / reps - pause
         last_stages.clear()
         if prof:
             pb = C.create_string_buffer(1 << 16)
