@@ -168,6 +168,8 @@ struct bsk_ctx {
     // translate
     uint8_t* d_codon = nullptr;   // 4096 + 4096 bytes (aa table, start table)
     std::vector<int> frames;
+    bool codon_ready = false;        // d_codon holds the tables of this context's options
+    bool translate_uniform_ok = true;  // FASTA: try the table-free pass on records that all look alike first (UniformLayout)
     bool translate_light_ok = true;  // FASTA: try the record table from the '>' bytes alone first (stream_fasta_light.hip)
     uint8_t* d_redo = nullptr;    // one byte per record: left by k_translate_wide to k_translate_frames4
     uint64_t redo_cap = 0;

@@ -156,34 +156,77 @@ static int translate_list_tables(bsk_ctx* c, bsk_out* out) {
     return BSK_OK;
 }
 
+// The layout of a FASTA shard whose records all look alike, proposed from the head sample: header length, line width,
+// bases and stride of record 0, confirmed on every complete record of the sample (the kernel verifies ALL records byte by
+// byte; this probe only decides whether the attempt is worth a launch).  false: not such a shard.
+static bool translate_uniform_probe(bsk_ctx* c, size_t n, const TranslateParams& P, UniformLayout* U) {
+    const uint8_t* h = c->h_head;
+    const size_t hb = c->head_len;
+    if (hb < 64 || h[0] != '>') return false;
+    // record 0: header line, sequence lines up to the next '>' at a line start
+    std::vector<size_t> nl;  // positions of its line breaks
+    size_t S = 0;
+    {
+        size_t p = 0;
+        while (p < hb) {
+            const void* q = memchr(h + p, '\n', hb - p);
+            if (!q) return false;  // (record 0 does not end inside the sample)
+            const size_t e = (size_t)((const uint8_t*)q - h);
+            nl.push_back(e);
+            p = e + 1;
+            if (p < hb && h[p] == '>') { S = p; break; }
+            if (p >= hb) return false;
+        }
+    }
+    if (S == 0 || nl.size() < 2) return false;
+    const size_t H = nl[0];                       // header line length, marker included
+    const size_t nlines = nl.size() - 1;          // sequence lines
+    const size_t W0 = nl[1] - nl[0] - 1;          // first line
+    size_t L = 0;
+    for (size_t k = 1; k < nl.size(); ++k) {
+        const size_t w = nl[k] - nl[k - 1] - 1;
+        if (k + 1 < nl.size() ? w != W0 : (w == 0 || w > W0)) return false;
+        L += w;
+    }
+    if (L == 0 || H < 1 || H > 65535) return false;
+    const uint32_t W = nlines > 1 ? (uint32_t)W0 : 0u;
+    if (W && W < 50u) return false;               // (k_translate_wide's windows hold at most one line break)
+    const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
+    if (lw && lw < 16u) return false;
+    if (L >= (1u << 20)) return false;            // chromosome-sized records have their own launches
+    // the file is a whole number of such records (the last one may lack its '\n')
+    if (!(n % S == 0 || (n + 1) % S == 0)) return false;
+    const uint64_t R = (n + 1) / S;
+    if (R < 2) return false;
+    // every complete record of the sample: '>' at k * S and the same line breaks
+    for (size_t k = 1; (k + 1) * S <= hb; ++k) {
+        const uint8_t* r = h + k * S;
+        if (r[0] != '>') return false;
+        for (size_t e : nl) if (r[e] != '\n') return false;
+        size_t cnt = 0;
+        for (const uint8_t* q = r; (q = (const uint8_t*)memchr(q, '\n', (size_t)(r + S - q))) != nullptr; ++q) ++cnt;
+        if (cnt != nl.size()) return false;
+    }
+    memset(U, 0, sizeof *U);
+    U->on = 1; U->H = (uint32_t)H; U->L = (uint32_t)L; U->W = W; U->S = S; U->n = R;
+    uint64_t off = 0;
+    for (int k = 0; k < P.nframes; ++k) {
+        const uint32_t f = (uint32_t)(P.frames[k] < 0 ? -P.frames[k] : P.frames[k]);
+        const uint32_t naa = L >= f - 1u ? (uint32_t)((L - (f - 1u)) / 3u) : 0u;  // num_aa(L, frame)
+        uint32_t len = 1u + ((uint32_t)H - 1u) + 1u;                              // '>' name '\n'
+        len += naa + ((lw && naa) ? (naa - 1u) / lw : 0u) + 1u;                    // residues, their line breaks, the final '\n'
+        U->len[k] = len;
+        U->off[k] = (uint32_t)off;
+        off += len;
+    }
+    U->out_S = off;
+    return off < (1ull << 32);
+}
+
 int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     if (o.i("ListTranslTable") == 0 || o.i("ListTranslTableWithAmbCodons") == 0) return translate_list_tables(c, out);
-    // FASTA: first with the record table from the '>' bytes alone (stream_fasta_light.hip) -- k_translate_wide validates the
-    // whole text against the layout that table assumes; whatever does not fit (a record flagged by the wide kernel, a
-    // chromosome-sized one, ...) sends the call through the full index pass below, and the context remembers it
-    bool light = format == BSK_FORMAT_FASTA && c->translate_light_ok && !c->tune.is("translate_index", "full") &&
-                 !c->tune.get("translate") && !o.b("InitCodonAsM");
-    int rc = BSK_ERR_FILTER_FALLBACK;
-    if (light) {
-        rc = build_index_light(c, d_buf, n, st);
-        if (rc != BSK_OK && rc != BSK_ERR_FILTER_FALLBACK) return rc;
-    }
-    if (rc == BSK_ERR_FILTER_FALLBACK) {
-        light = false;
-        rc = build_index(c, d_buf, n, format, st);
-    }
-    if (rc != BSK_OK) return rc;
-    if (c->table.n == 0) return empty_result(c, out);
-    Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
-    if (rc != BSK_OK) return rc;
-    if (!(ab == AB_DNA || ab == AB_DNAredundant || ab == AB_RNA || ab == AB_RNAredundant)) {  // translate.go:116-122
-        c->set_error("command 'seqkit translate' only apply to DNA/RNA sequences");
-        return BSK_ERR_FORMAT;
-    }
-    TextTableH tt;
-    rc = prepare_text(c, d_buf, format, st, &tt);
-    if (rc != BSK_OK) return rc;
+    int rc = BSK_OK;
     TranslateParams P;
     memset(&P, 0, sizeof P);
     P.fastq = format == BSK_FORMAT_FASTQ;
@@ -193,8 +236,8 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     P.init_m = o.b("InitCodonAsM"); P.append_frame = o.b("AppendFrame");
     P.line_width = (int)o.ci("LineWidth");
     P.id_mode = id_mode_of(c);
-    if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 6 * 4096 + 256 + 16384));
-    {
+    if (!c->codon_ready) {  // the tables follow from the options: built and uploaded once per context (0.3 ms of host time per call before)
+        if (!c->d_codon) HIP_TRYX(c, hipMalloc((void**)&c->d_codon, 6 * 4096 + 256 + 16384));
         std::vector<uint8_t> tab(6 * 4096 + 256 + 16384);
         uint8_t *fw = tab.data(), *stt = fw + 4096, *rcw = fw + 8192, *rcs = fw + 12288, *iu = fw + 16384;
         build_codon_tables(*find_code((int)o.i("TranslTable")), fw, stt);
@@ -231,6 +274,7 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
         }
         HIP_TRYX(c, hipMemcpyAsync(c->d_codon, tab.data(), tab.size(), hipMemcpyHostToDevice, st));
         HIP_TRYX(c, hipStreamSynchronize(st));
+        c->codon_ready = true;
     }
     P.pair = c->d_codon + 6 * 4096 + 256;
     P.baked = c->d_codon + 16384 + 256;
@@ -239,6 +283,76 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     P.codon_rc = c->d_codon + 8192;
     P.start_rc = c->d_codon + 12288;
     P.iupac = c->d_codon + 16384;
+
+    // ---- FASTA whose records all look alike: no table at all (UniformLayout, ops_translate.hpp).  The host proposes the
+    // layout from the head sample, k_translate_wide<G, true> verifies every record against it; one record that differs and
+    // the call starts over below, and the context does not try again.  translate_index = full / light skip the attempt.
+    if (format == BSK_FORMAT_FASTA && n > 0 && c->translate_uniform_ok && !c->tune.get("translate_index") && !c->tune.get("translate") &&
+        !P.init_m && !P.trim && !P.append_frame && !c->id_custom) {
+        rc = sample_head(c, d_buf, n, st);
+        if (rc != BSK_OK) return rc;
+        UniformLayout U;
+        if (translate_uniform_probe(c, n, P, &U)) {
+            Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+            if (rc != BSK_OK) return rc;
+            if (!(ab == AB_DNA || ab == AB_DNAredundant || ab == AB_RNA || ab == AB_RNAredundant)) {  // translate.go:116-122
+                c->set_error("command 'seqkit translate' only apply to DNA/RNA sequences");
+                return BSK_ERR_FORMAT;
+            }
+            const uint64_t total = U.n * U.out_S;
+            rc = ensure_out(c, total);
+            if (rc != BSK_OK) return rc;
+            P.uni = U;
+            const int forced = (int)c->tune.num("tr_lanes");
+            const uint64_t avg = U.S;
+            const int wide_lanes = forced == 4 || forced == 16 || forced == 64 ? forced : (avg >= 3000 ? 64 : (avg < 500 ? 4 : 16));
+            uint64_t* d_redo_count = c->d_fin + bsk_ctx::FIN_AUX0;
+            HIP_TRYX(c, hipMemsetAsync(d_redo_count, 0, sizeof(uint64_t), st));
+            {
+                Timed t(c, "k_translate_uniform", st);
+                HIP_TRYX(c, launch_translate_uniform(wide_lanes, d_buf, n, P, c->d_out, d_redo_count, c->d_status, st));
+            }
+            rc = ctl_readback(c, st);  // records that did not verify + the status word: the call's one read-back
+            if (rc != BSK_OK) return rc;
+            if (c->fin(bsk_ctx::FIN_AUX0) == 0) {
+                rc = kernel_error_to_status(c, c->status_word());
+                if (rc != BSK_OK) return rc;
+                c->table.n = 0;  // no record table was built for this shard
+                out->d_data = c->d_out;
+                out->len = total;
+                out->records = U.n * (uint64_t)P.nframes;
+                return BSK_OK;
+            }
+            c->translate_uniform_ok = false;  // a record that is not like record 0: the table paths, from now on
+            P.uni.on = 0;
+        }
+    }
+
+    // FASTA: first with the record table from the '>' bytes alone (stream_fasta_light.hip) -- k_translate_wide validates the
+    // whole text against the layout that table assumes; whatever does not fit (a record flagged by the wide kernel, a
+    // chromosome-sized one, ...) sends the call through the full index pass below, and the context remembers it
+    bool light = format == BSK_FORMAT_FASTA && c->translate_light_ok && !c->tune.is("translate_index", "full") &&
+                 !c->tune.get("translate") && !o.b("InitCodonAsM");
+    rc = BSK_ERR_FILTER_FALLBACK;
+    if (light) {
+        rc = build_index_light(c, d_buf, n, st);
+        if (rc != BSK_OK && rc != BSK_ERR_FILTER_FALLBACK) return rc;
+    }
+    if (rc == BSK_ERR_FILTER_FALLBACK) {
+        light = false;
+        rc = build_index(c, d_buf, n, format, st);
+    }
+    if (rc != BSK_OK) return rc;
+    if (c->table.n == 0) return empty_result(c, out);
+    Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+    if (rc != BSK_OK) return rc;
+    if (!(ab == AB_DNA || ab == AB_DNAredundant || ab == AB_RNA || ab == AB_RNAredundant)) {  // translate.go:116-122
+        c->set_error("command 'seqkit translate' only apply to DNA/RNA sequences");
+        return BSK_ERR_FORMAT;
+    }
+    TextTableH tt;
+    rc = prepare_text(c, d_buf, format, st, &tt);
+    if (rc != BSK_OK) return rc;
     // per-element scratch: nframes elements per record
     const uint64_t ne = c->table.n * (uint64_t)P.nframes;
     const uint64_t saved_n = c->table.n;

@@ -987,7 +987,7 @@ __device__ __forceinline__ uint32_t load_break(const uint8_t* a, uint32_t kb, co
 #else
 #define BSK_TRW_ATTR
 #endif
-template <int G>
+template <int G, bool UNI>
 __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
                                                         TranslateParams P, const uint32_t* __restrict__ out_len,
                                                         const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
@@ -1016,19 +1016,52 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
     __syncthreads();
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const uint32_t gl = threadIdx.x % G;
-    if (g >= t.n) return;  // no block-level barrier below
-    if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
-    const Text T = text_of(buf, t, tt, g);
+    if (g >= (UNI ? P.uni.n : t.n)) return;  // no block-level barrier below
+    Text T;
+    uint64_t rstart;  // the record's '>'
+    uint32_t lh;      // header line length, marker included
+    if constexpr (UNI) {  // everything follows from the record number (UniformLayout) -- and is verified below
+        rstart = g * P.uni.S;
+        lh = P.uni.H;
+        T.p = buf + rstart + lh + 1;
+        T.L = P.uni.L;
+        T.W = P.uni.W;
+    } else {
+        if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
+        T = text_of(buf, t, tt, g);
+        rstart = t.start[g];
+        lh = t.l_head[g];
+    }
     const uint32_t L = T.L;
     const uint32_t W = T.W;
     const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
     if ((W && W < 50u) || (lw && lw < 16u)) {  // (wave-uniform per group) not this kernel's layout
-        if (gl == 0) { redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
+        if (gl == 0) { if constexpr (!UNI) redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
         return;
     }
-    const uint8_t* h = buf + t.start[g] + 1;
-    const uint32_t lh = t.l_head[g];
+    const uint8_t* h = buf + rstart + 1;
     const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    bool give_up = false;
+    if constexpr (UNI) {
+        // the frame of the record: '>' at its place behind a line break, a header line of exactly lh bytes, the last line
+        // break at S - 1 (or the shard ends there: a file need not end with '\n').  The sequence lines are verified window
+        // by window below (letters, and every break at its place).
+        const uint8_t* rec = buf + rstart;
+        const uint64_t endp = rstart + P.uni.S - 1u;  // the record's final line break
+        bool bad0 = false;
+        if (gl == 0) {
+            bad0 = rec[0] != (uint8_t)'>' || (rstart > 0 && rec[-1] != (uint8_t)'\n') || rec[lh] != (uint8_t)'\n' ||
+                   (endp < buf_n ? buf[endp] != (uint8_t)'\n' : endp != buf_n);
+        }
+        for (uint32_t x = 1u + gl; x < lh; x += G) bad0 = bad0 || rec[x] == (uint8_t)'\n';
+        const uint64_t bb = __ballot(bad0);
+        const uint32_t shift = ((threadIdx.x & 63u) / G) * G;
+        const uint64_t gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << shift);
+        if (bb & gmask) {
+            if (gl == 0) atomicAdd((unsigned long long*)redo_count, 1ull);
+            return;
+        }
+    }
 
     // raw cursor of the lane's first base (wrapped source): line breaks before it and its column
     uint32_t rnl = 0, rcol = LB * gl;
@@ -1057,8 +1090,13 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
     const uint64_t e0 = g * (uint64_t)P.nframes;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        ne[k] = k < P.nframes ? out_len[e0 + k] : 0u;
-        oe[k] = k < P.nframes ? out_off[e0 + k] : 0ull;
+        if constexpr (UNI) {
+            ne[k] = k < P.nframes ? P.uni.len[k] : 0u;
+            oe[k] = k < P.nframes ? g * P.uni.out_S + P.uni.off[k] : 0ull;
+        } else {
+            ne[k] = k < P.nframes ? out_len[e0 + k] : 0u;
+            oe[k] = k < P.nframes ? out_off[e0 + k] : 0ull;
+        }
     }
     // header line and final line break of element k (n bytes at o, header of H bytes)
     const uint8_t hbyte = (gl >= 1u && gl - 1u < hl) ? h[gl - 1u] : (uint8_t)0;  // header byte of position gl (frames share it)
@@ -1086,7 +1124,7 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         if (k >= P.nframes) break;
         const int frame = P.frames[k];
         const uint32_t n = ne[k];
-        const uint32_t H = header_len(t, g, h, hl, P, frame) + 1;
+        const uint32_t H = (UNI ? 1u + hl : header_len(t, g, h, hl, P, frame)) + 1;
         const uint32_t body = n - H - 1;
         const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
         put_header(frame, out + oe[k], n, H);
@@ -1131,7 +1169,6 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         if (lw && rj[c] >= 0) { ro[c] = (uint32_t)rj[c] / lw; rcc[c] = (uint32_t)rj[c] - ro[c] * lw; }
     }
     constexpr uint32_t LET = 0x67746361u;  // 'a' 'c' 't' 'g' at byte 0..3 == letter of code 0..3
-    bool give_up = false;
 
 #pragma unroll 1
     for (uint32_t sb = 0; sb < L; sb += STEPB) {
@@ -1300,11 +1337,11 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         rnl = rnl2; rcol = rcol2;
     }
     if (give_up) {
-        if (gl == 0) { redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
+        if (gl == 0) { if constexpr (!UNI) redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
         return;
     }
     // ---- -M: residue 0 of a frame becomes 'M' when its codon is a start codon (after every other store)
-    if (P.init_m && gl == 0) {
+    if constexpr (!UNI) if (P.init_m && gl == 0) {
         __threadfence();
         for (int k = 0; k < P.nframes; ++k) {
             const int frame = P.frames[k];
@@ -1345,13 +1382,13 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
         const uint8_t* only = nullptr;
         if (redo && !nowide && buf_n >= 64) {  // (k_translate_wide asks for 52 bytes at `buf` on behalf of idle lanes)
             if (wide_lanes == 64)
-                hipLaunchKernelGGL(k_translate_wide<64>, dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
+                hipLaunchKernelGGL((k_translate_wide<64, false>), dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);
             else if (wide_lanes == 4)
-                hipLaunchKernelGGL(k_translate_wide<4>, dim3((unsigned)((t.n * 4 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
+                hipLaunchKernelGGL((k_translate_wide<4, false>), dim3((unsigned)((t.n * 4 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);
             else
-                hipLaunchKernelGGL(k_translate_wide<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
+                hipLaunchKernelGGL((k_translate_wide<16, false>), dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);
             only = redo;
             // how many records are left for k_translate_frames4: usually none, and 2.4 M blocks that look at their flags and
@@ -1378,6 +1415,24 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
         hipLaunchKernelGGL(k_translate_frames<16>, dim3((unsigned)((t.n * 16 + 255) / 256)), dim3(256), 0, st, buf, t, d,
                            P, out_len, out_off, out, status);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_translate_uniform(int wide_lanes, const uint8_t* buf, uint64_t buf_n, const TranslateParams& P, uint8_t* out,
+                                    uint64_t* redo_count, uint64_t* status, hipStream_t st) {
+    if (!P.uni.on || P.uni.n == 0) return hipSuccess;
+    const RecordTable t{};
+    const TextTable d{nullptr, nullptr, nullptr};
+    const uint64_t n = P.uni.n;
+    if (wide_lanes == 64)
+        hipLaunchKernelGGL((k_translate_wide<64, true>), dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P,
+                           (const uint32_t*)nullptr, (const uint64_t*)nullptr, out, (uint8_t*)nullptr, redo_count, status);
+    else if (wide_lanes == 4)
+        hipLaunchKernelGGL((k_translate_wide<4, true>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P,
+                           (const uint32_t*)nullptr, (const uint64_t*)nullptr, out, (uint8_t*)nullptr, redo_count, status);
+    else
+        hipLaunchKernelGGL((k_translate_wide<16, true>), dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d, P,
+                           (const uint32_t*)nullptr, (const uint64_t*)nullptr, out, (uint8_t*)nullptr, redo_count, status);
     return hipGetLastError();
 }
 

@@ -15,6 +15,26 @@ struct TextTableH {  // host-visible mirror of TextTable (text_dev.hpp)
     uint64_t lin_n = 0;  // bytes in lin
 };
 
+// A FASTA shard in which EVERY record has the same header length, line width, sequence length and therefore the same
+// byte stride (synthetic benchmarks, fixed-length amplicon / CDS sets): records, text layout and output places follow from
+// the record number, so no pass over the 50 GB has to find the '>' bytes first (k_fasta_starts: 8.8 ms of a 58 ms call at
+// C4) and no table has to be built, scanned or read.  The host proposes the layout from the head of the shard
+// (translate_uniform_probe); k_translate_wide<G, true> VERIFIES every byte of every record against it -- the '>' at i * S
+// behind a '\n', no line break inside the header and one at its end, every sequence line break at its place and nothing but
+// A C G T between them, the final '\n' at i * S + S - 1 (or the end of the shard) -- and one record that differs sends the
+// whole call back to the table paths (redo count), with nothing of this pass's output kept.
+struct UniformLayout {
+    uint32_t on;       // 0: the record table decides
+    uint32_t H;        // header line length, marker included (== RecordTable::l_head)
+    uint32_t L;        // bases per record
+    uint32_t W;        // bases per full line (0: the sequence is on one line)
+    uint64_t S;        // bytes from one '>' to the next
+    uint64_t n;        // records
+    uint64_t out_S;    // output bytes per record (all its frames)
+    uint32_t len[6];   // output bytes of element k of a record ...
+    uint32_t off[6];   // ... and where it begins inside the record's output
+};
+
 struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/translate.go:33-64)
     int fastq;
     int nframes;
@@ -37,6 +57,7 @@ struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/tra
     const uint32_t* long_list;
     uint64_t long_count;
     uint32_t long_thresh;
+    UniformLayout uni;
 };
 
 constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
@@ -54,6 +75,10 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
                                    int variant = 0 /* 1: the round-1 frames kernel only, 2: frames4 without the wide kernel */,
                                    uint64_t* redo_left_stop = nullptr /* receives the number of records the wide kernel left; when
                                    it is non-zero nothing more is launched */);
+// the uniform-layout pass (P.uni.on): k_translate_wide<wide_lanes, true> alone, no tables; *redo_left receives the number
+// of records that did not verify (the caller then starts over on the table paths)
+hipError_t launch_translate_uniform(int wide_lanes, const uint8_t* buf, uint64_t buf_n, const TranslateParams& P, uint8_t* out,
+                                    uint64_t* redo_count /* zeroed device word */, uint64_t* status, hipStream_t st);
 // elements of the records in P.long_list; max_len = longest of those sequences
 hipError_t launch_translate_long(const uint8_t* buf, const RecordTable& t, const TextTableH& tt, const TranslateParams& P,
                                  const uint32_t* out_len, const uint64_t* out_off, uint8_t* out, uint64_t* status,
