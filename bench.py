@@ -145,6 +145,138 @@ class _Helpers:
         return hit_mask
 
 
+def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, seconds=None):
+    """The oracle (oracle/: C++ restatement of the reference's operator, `port`) on a bounded prefix of the SAME input, 1 thread
+    and -- where the records are independent -- all host cores (one record-aligned slice per thread; ctypes releases the
+    GIL).  A reported baseline, not a target; returns the `cpu_baseline` object of an `ops` entry."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    if seconds is None:
+        seconds = max(0.3, H.args.cpu_seconds / 6.0)   # (five operators x two legs beside the stats baseline: ~30 s in all)
+    fn = getattr(oracle, fn_name)
+    oj = json.dumps(opts)
+    nrec_all = tensor.numel() // rec_bytes
+    pilot_rec = max(1, min(nrec_all, (4 << 20) // rec_bytes))
+    pilot = bytes(tensor[:pilot_rec * rec_bytes].cpu().numpy().tobytes())
+    t0 = time.perf_counter()
+    fn(pilot, fastq, oj)
+    rate = pilot_rec / max(1e-6, time.perf_counter() - t0)           # records / s, one thread
+    srec = int(max(pilot_rec, min(nrec_all, rate * seconds, (512 << 20) // rec_bytes)))
+    sample = bytes(tensor[:srec * rec_bytes].cpu().numpy().tobytes())
+    t0 = time.perf_counter()
+    fn(sample, fastq, oj)
+    ct = time.perf_counter() - t0
+    out = {"value": round(srec / ct / 1e6, 4), "unit": "M records/s", "gb_per_s": round(srec * rec_bytes / ct / 1e9, 4), "cores": 1,
+           "kind": "port", "sample": "oracle.%s (C++ restatement of the reference operator, NOT IgnisHPC/Go) on the first %d records "
+                                     "(%.3f GB) of the same input, %.2f s, 1 thread of %d host cores" % (fn_name, srec, srec * rec_bytes / 1e9, ct, os.cpu_count())}
+    if all_cores:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(os.cpu_count() or 1, 256))
+            per = max(1, int(min(nrec_all // nthr, rate * seconds, (64 << 20) // rec_bytes)))
+            big = bytes(tensor[:per * nthr * rec_bytes].cpu().numpy().tobytes())
+            parts = [big[k * per * rec_bytes:(k + 1) * per * rec_bytes] for k in range(nthr)]
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(lambda b: fn(b[:rec_bytes * 64], fastq, oj), parts))   # threads started
+                t0 = time.perf_counter()
+                list(ex.map(lambda b: fn(b, fastq, oj), parts))
+                ct = time.perf_counter() - t0
+            out["all_cores"] = {"value": round(per * nthr / ct / 1e6, 2), "unit": "M records/s", "gb_per_s": round(per * nthr * rec_bytes / ct / 1e9, 2),
+                                "cores": nthr, "kind": "port", "sample": "%d threads x %d records (%.2f GB), one pass, %.2f s" % (nthr, per, per * nthr * rec_bytes / 1e9, ct)}
+        except Exception as e:
+            out["all_cores"] = {"error": str(e)[:200]}
+    return out
+
+
+def run_end_to_end(H, gb=8.0):
+    """File-to-result rates with the input in HOST memory (pinned): what a caller that hands libbsk a file's bytes gets --
+    PCIe Gen5 x16 (~55 GB/s) in, and for the record operators the output back out and into files.  `stats` -> the map;
+    `seq -n` -> one merged file (StoreFASTX); `grep -s -p` -> a directory of four part files written by four contexts at once
+    (StoreFASTXN).  Wall clock of the calls, second run.  PCIe- / page-cache-bound by two orders of magnitude against the HBM-
+    resident rates: reported beside them, never `value`."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    torch, lib, check, bsk, _lib = H.torch, H.lib, H.check, H.bsk, H._lib
+    t, nrec = H.synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_MOTIF, gb * 1e9)
+    n = t.numel()
+    # what the device path answers on the same bytes (exact-checked in the ops leg): the numbers the files must hold
+    out = _lib.Out()
+    with bsk.Operator("Grep", json.dumps({"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}), H.local) as op:
+        check(lib.bsk_grep_run(op.ctx, C.c_void_p(t.data_ptr()), n, 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out)), op.ctx)
+        torch.cuda.synchronize()
+        want_hits = int(out.records)
+    h = lib.bsk_host_alloc(n)
+    if not h:
+        return {"error": "pinned allocation of %.1f GB failed" % (n / 1e9)}
+    check(lib.bsk_device_copy(C.c_void_p(h), C.c_void_p(t.data_ptr()), n, 2))
+    del t
+    torch.cuda.empty_cache()
+    res = {"input": "%.2f GB FASTQ-150 (%d records, C3 motif planted) in pinned host memory" % (n / 1e9, nrec),
+           "note": "wall clock, host bytes -> result; PCIe- and page-cache-bound; never `value`"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    try:
+        with bsk.Operator("Stats", "{}", H.local) as op:
+            keys, vals, cnt = (C.c_int64 * 4096)(), (C.c_int64 * 4096)(), C.c_size_t()
+            best = None
+            for _ in range(2):
+                check(lib.bsk_stats_reset(op.ctx, None), op.ctx)
+                t0 = time.perf_counter()
+                check(lib.bsk_stats_run(op.ctx, C.c_void_p(h), n, 0, bsk.FORMAT_FASTQ, 0, None, None), op.ctx)
+                check(lib.bsk_stats_collect(op.ctx, None, keys, vals, 4096, C.byref(cnt)), op.ctx)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            m = dict(zip(keys[:cnt.value], vals[:cnt.value]))
+            res["stats (host bytes -> map)"] = {"s": round(best, 4), "GB_per_s": round(n / best / 1e9, 2),
+                                                "M_records_per_s": round(nrec / best / 1e6, 1), "exact": m.get(150) == nrec}
+
+        def to_store(op_name, opts, parts, merge):
+            path = os.path.join(base, "bsk_bench_e2e_%d" % os.getpid())
+            best, ob, orec = None, 0, 0
+            for _ in range(2):
+                shutil.rmtree(path, ignore_errors=True)
+                if os.path.exists(path):
+                    os.unlink(path)
+                st = C.c_void_p()
+                assert lib.bsk_store_open(path.encode(), 1 if merge else 0, C.byref(st)) == 0
+                per = nrec // parts
+                bounds = [(k * per * REC, ((k + 1) * per if k + 1 < parts else nrec) * REC) for k in range(parts)]
+                ops = [bsk.Operator(op_name, json.dumps(opts), H.local) for _ in range(parts)]
+
+                def work(k):
+                    lo, hi = bounds[k]
+                    nb, nr = C.c_uint64(), C.c_uint64()
+                    check(lib.bsk_run_to_store(ops[k].ctx, C.c_void_p(h + lo), hi - lo, bsk.FORMAT_FASTQ, k, st, k, C.byref(nb), C.byref(nr)), ops[k].ctx)
+                    return nb.value, nr.value
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(parts) as ex:
+                    got = list(ex.map(work, range(parts)))
+                tot = C.c_uint64()
+                assert lib.bsk_store_close(st, C.byref(tot)) == 0
+                dt = time.perf_counter() - t0
+                for o in ops:
+                    o.close()
+                ob, orec = sum(g[0] for g in got), sum(g[1] for g in got)
+                assert tot.value == ob
+                best = dt if best is None else min(best, dt)
+            on_disk = sum(os.path.getsize(os.path.join(path, f)) for f in os.listdir(path)) if os.path.isdir(path) else os.path.getsize(path)
+            shutil.rmtree(path, ignore_errors=True)
+            if os.path.exists(path):
+                os.unlink(path)
+            return best, ob, orec, on_disk
+
+        dt, ob, orec, disk = to_store("SeqTransform", {"Name": True}, 1, True)
+        res["seq -n (host bytes -> one merged file in %s)" % base] = {
+            "s": round(dt, 4), "in_GB_per_s": round(n / dt / 1e9, 2), "out_bytes": ob, "M_records_per_s": round(nrec / dt / 1e6, 1),
+            "exact": ob == 12 * nrec and orec == nrec and disk == ob}
+        dt, ob, orec, disk = to_store("Grep", {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, 4, False)
+        res["grep -s -p (host bytes -> 4 part files in %s, 4 contexts at once)" % base] = {
+            "s": round(dt, 4), "in_GB_per_s": round(n / dt / 1e9, 2), "out_bytes": ob, "M_records_per_s": round(nrec / dt / 1e6, 1),
+            "exact": orec == want_hits and ob == REC * want_hits and disk == ob}
+    finally:
+        lib.bsk_host_free(C.c_void_p(h))
+    return res
+
+
 def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     ops = {}
     H = _Helpers(args, torch, bsk, _lib, lib, check, dev, local)
@@ -163,7 +295,8 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     ops["seq -n @ C2"] = entry("seq -n", "%.1f GB FASTQ-150 (the file of the stats legs)" % (nbytes / 1e9), total_rec, nbytes,
                                nbytes + 12 * total_rec, out, mean_s, min_s, kern, ok,
                                "output == columns [1, 13) of every 317-byte record (torch.equal over all %d names), "
-                               "12 x N bytes, first / last name" % total_rec)
+                               "12 x N bytes, first / last name" % total_rec,
+                               None if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "seq", {"Name": True}, shard, REC, True)})
     del names
     op.close()
 
@@ -188,7 +321,8 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         "subseq -r 1:50", "%.1f GB FASTQ-150 (the first quarter of the file of the stats legs)" % (nsub * REC / 1e9), nsub,
         nsub * REC, nsub * REC + 117 * nsub, out, mean_s, min_s, kern, ok,
         "output == columns [0, 63) ++ '\\n+\\n' ++ columns [166, 216) ++ '\\n' of every 317-byte record (torch.equal over all "
-        "%d records)" % nsub)
+        "%d records)" % nsub,
+        None if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "subseq", {"Region": "1:50"}, shard, REC, True)})
     del got, view
     op.close()
     shard.data = torch.empty(0, dtype=torch.uint8, device=dev)  # the 100 GB file is not needed any more
@@ -210,7 +344,9 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         "grep -s -p ACGTTGCAAGCT", "%.2f GB FASTQ-150, one GPU's shard of C3, motif planted on + / - strand in 2 %% of the reads"
         % (t.numel() / 1e9), nrec, t.numel(), t.numel() + out.len, out, mean_s, min_s, kern, ok,
         "output == the records whose bases hold the 12-mer or its reverse complement (sliding compare in torch over all "
-        "records), in file order", {"hits": int(hits), "planted": int(planted[0]), "background": int(hits - planted[0])})
+        "records), in file order", dict({"hits": int(hits), "planted": int(planted[0]), "background": int(hits - planted[0])},
+                                        **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(
+                                            H, "grep", {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t, REC, True)})))
     del got, view, t
     op.close()
     torch.cuda.empty_cache()
@@ -265,7 +401,8 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         "translate --frame 6", "%.1f GB FASTA, %d CDS records of 5 001 bases wrapped at 60 (ATG + 1 665 sense codons + TAA)"
         % (t.numel() / 1e9, nrec), nrec, t.numel(), t.numel() + out.len, out, mean_s, min_s, kern, ok,
         "output == six frames per record translated here with torch (standard code as a 64-entry gather, reverse strand = "
-        "flipped complement), headers and 60-column wrapping included, all records; frame 1 of record 0 is M...* of 1 667 aa")
+        "flipped complement), headers and 60-column wrapping included, all records; frame 1 of record 0 is M...* of 1 667 aa",
+        None if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "translate", {"Frame": ["6"]}, t, RB, False)})
     del got, view, t
     op.close()
     torch.cuda.empty_cache()
@@ -285,11 +422,26 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         check(lib.bsk_rmdup_run(op2.ctx, C.c_void_p(out.d_data), out.len, 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out2)), op2.ctx)
         torch.cuda.synchronize()
         ok = ok and out2.records == keep and out2.len == out.len
+    # the same call with rmdup_keys = two-key: equal (k1, k2) decide without the byte comparison of the default (PARITY.md KEYS)
+    op_k, out_k, mean_k, min_k, kern_k = timed_calls("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, t.numel(), bsk.FORMAT_FASTQ,
+                                                     sets=((b"rmdup_keys", b"two-key"),))
+    ok_k = out_k.records == keep and out_k.len == keep * REC
+    if ok_k:
+        ok_k, _ = rows_equal(dev_bytes(out_k.d_data, out_k.len), view, lambda i0, i1: (torch.arange(i0, i1, device=dev) % 5) != 4, REC)
+    op_k.close()
+    extra = {"survivors": int(out.records),
+             "rmdup_keys": "verify (default): XXH64 + second key group the records, the sequence bytes of every duplicate are compared "
+                           "with its survivor's (RmDupCheck, rmdup.go:193-199)",
+             "rmdup_keys_two_key": {"ms": round(mean_k * 1e3, 4), "ms_min": round(min_k * 1e3, 4), "kernels_ms_per_call": kern_k,
+                                    "exact": bool(ok_k), "note": "bsk_ctx_set(ctx, 'rmdup_keys', 'two-key'): no byte comparison"}}
+    if not args.no_cpu_baseline:
+        extra["cpu_baseline"] = cpu_baseline_op(H, "rmdup", {"BySeq": True}, t, REC, True, all_cores=False)
+        extra["cpu_baseline"]["sample"] += " (duplicates are global: one thread, one group table)"
     ops["rmdup -s @ C5 shard"] = entry(
         "rmdup -s", "%.1f GB FASTQ-150, one GPU's shard of C5, record i with i %% 5 == 4 repeats the bases of an earlier record"
         % (t.numel() / 1e9), nrec, t.numel(), t.numel() + 16 * nrec + out.len, out, mean_s, min_s, kern, ok,
         "output == the records with i % 5 != 4, byte for byte in file order (N - N // 5 survivors); rmdup of the output keeps "
-        "every record", {"survivors": int(out.records)})
+        "every record", extra)
     del got, view, t
     op.close()
     torch.cuda.empty_cache()
@@ -757,6 +909,12 @@ def main():
                 out["ops"] = run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec)
             except Exception as e:  # the headline line must survive a failure here; the failure is reported, not hidden
                 out["ops"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+            try:
+                shard = None
+                torch.cuda.empty_cache()
+                out["end_to_end"] = run_end_to_end(_Helpers(args, torch, bsk, _lib, lib, check, dev, local), 8.0 * min(1.0, args.ops_scale * 4))
+            except Exception as e:
+                out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         else:
             out["ops"] = {"skipped": "the 'ops' workloads are defined at the full BASELINE sizes (--gb 100) or with --ops-scale"}
     if ops_multi is not None:

@@ -672,21 +672,23 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
     bool seg = verbatim && t.n > 0 && total > 0 && ((uintptr_t)d_out & 15u) == 0 && !(env && strcmp(env, "off") == 0);
     if (seg && !(env && strcmp(env, "force") == 0)) seg = kept * 2 >= t.n && total >= (4u << 20);
     if (seg) {
-        int rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
-        if (rc != BSK_OK) return rc;
-        rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+        int rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
         if (rc != BSK_OK) return rc;
         uint64_t* d_other = c->d_fin + bsk_ctx::FIN_OTHER;  // (in the control block: comes back with the final read-back)
         HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
-        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, d_other, st, P.ren_ord));
         HIP_TRYX(c, launch_seg_first(d_off, t.n, c->d_seg_first, st));
         {
-            Timed tm(c, "k_seg_copy", st);
-            HIP_TRYX(c, launch_seg_copy(c->d_seg_src, d_off, t.n, c->d_seg_first, d_out, total, d_buf, d_buf + n, st));
+            Timed tm(c, "k_seg_copy", st);  // (the sources follow from the table inside the copy: no k_seg_build pass)
+            HIP_TRYX(c, launch_seg_copy_fastq(d_buf, n, t, P.ren_ord, d_other, d_off, c->d_seg_first, d_out, total, st));
         }
         rc = ctl_readback(c, st);
         if (rc != BSK_OK) return rc;
         if (c->fin(bsk_ctx::FIN_OTHER) == 0) return BSK_OK;
+        // rare: records the copy left out (a '+' line that repeats the name, a last record without '\n', renamed heads):
+        // their list for the record-wise emit
+        rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, c->d_seg_src + t.n, st, P.ren_ord));
         P.seg_src = c->d_seg_src;  // the few records the copy left out
     }
     HIP_TRYX(c, launch_seq_emit(d_buf, t, P, d_len, d_off, d_out, st, total, kept));

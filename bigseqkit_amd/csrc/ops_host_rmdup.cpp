@@ -137,15 +137,19 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     const bool fastq = format == BSK_FORMAT_FASTQ;
     // `-s` on FASTQ: the index pass also hashes (stream_rmdup.hip) and the two keys decide (hash_dev.hpp); everything else
     // (names, IDs, FASTA), BSK_RMDUP=table and BSK_RMDUP_KEYS=off take the separate hash kernel and compare the bytes
+    // rmdup_keys: (default) "verify" -- the keys group, and the bytes of every duplicate are compared with its survivor's
+    // (RmDupCheck's test, rmdup.go:193-199; a difference fails the call: ERR_HASH_COLLISION); "two-key" -- equal (k1, k2)
+    // decide alone, 128 bits and no second look at the text (PARITY.md KEYS: round 3's default, ~1.5 ms faster at C5);
+    // "off" -- the separate hash kernel and the byte-comparing table path
     bool by_keys = fastq && o.b("BySeq");
-    bool verify_bytes = false;
+    bool verify_bytes = true;
     uint32_t k1_bits = 64;
     {
         const char* e = c->tune.get("rmdup");
         if (e && strcmp(e, "table") == 0) by_keys = false;
         e = c->tune.get("rmdup_keys");
         if (e && strcmp(e, "off") == 0) by_keys = false;
-        if (e && strcmp(e, "verify") == 0) verify_bytes = true;  // keys decide, the bytes of every duplicate are compared on top
+        if (e && (strcmp(e, "two-key") == 0 || strcmp(e, "keys") == 0)) verify_bytes = false;
         e = c->tune.get("rmdup_k1_bits");                         // tests: keep only the low bits of k1 (forces the overflow list)
         if (e && atoi(e) >= 16 && atoi(e) < 64) k1_bits = (uint32_t)atoi(e);
     }
@@ -195,14 +199,13 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     }
     if (by_buckets) {
         size_t tmp_bytes = 0;
-        HIP_TRYX(c, sort_pairs_bits_temp_bytes(N, 0, (int)RMDUP_BUCKET_BITS, &tmp_bytes));
+        HIP_TRYX(c, sort_pairs_bits_iota_temp_bytes(N, 0, (int)RMDUP_BUCKET_BITS, &tmp_bytes));
         Arena A;
-        const uint64_t o_sk = A.take(N * 8), o_vi = A.take(N * 4), o_vo = A.take(N * 4), o_first = A.take(N * 4),
+        const uint64_t o_sk = A.take(N * 8), o_vo = A.take(N * 4), o_first = A.take(N * 4),
                        o_bs = A.take(((1u << RMDUP_BUCKET_BITS) + 2) * 4), o_hist = A.take((1u << RMDUP_BUCKET_BITS) * 4), o_tmp = A.take(tmp_bytes + 256);
         rc = arena_reserve(c, &A);
         if (rc != BSK_OK) return rc;
         uint64_t* d_sk = A.at<uint64_t>(o_sk);
-        uint32_t* d_vi = A.at<uint32_t>(o_vi);
         uint32_t* d_vo = A.at<uint32_t>(o_vo);
         d_first = A.at<uint32_t>(o_first);
         uint32_t ovf_cap = 0;
@@ -216,9 +219,9 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         {
             Timed t(c, "rmdup_group(sort+dedupe)", st);
             if (!c->tune.is("rmdup_buckets", "hand")) {  // the device radix sort of the pairs (two 8-bit digit passes: 1.5 ms per 79 M pairs)
-                HIP_TRYX(c, launch_sort_iota(d_vi, N, st));
                 HIP_TRYX(c, launch_sort_iota(d_first, N, st));
-                HIP_TRYX(c, launch_sort_pairs_bits(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vi, d_vo, N, 0, (int)RMDUP_BUCKET_BITS, st));
+                // (the record numbers travel as a counting iterator: no second iota pass, no array to read)
+                HIP_TRYX(c, launch_sort_pairs_bits_iota(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vo, N, 0, (int)RMDUP_BUCKET_BITS, st));
                 HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
                                                  by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap));
             } else {  // one 16-bit histogram + scatter by hand (ops_rmdup.hip): 6.8 ms -- kept for the comparison
@@ -240,8 +243,8 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;  // (the list did not fit: the table path compares bytes)
             else if (rc != BSK_OK) return rc;
             else if (verify_bytes) {
-                Timed t(c, "k_rmdup_resolve", st);
-                HIP_TRYX(c, launch_rmdup_resolve_first(d_buf, c->table, tt, P, d_first, nullptr, c->d_out_len, c->d_status, nullptr, st));
+                Timed t(c, "k_rmdup_verify", st);
+                HIP_TRYX(c, launch_rmdup_verify_fastq(d_buf, c->table, P, d_first, c->d_out_len, c->d_status, st));
             } else {
                 Timed t(c, "k_rmdup_sizes", st);
                 HIP_TRYX(c, launch_rmdup_sizes(c->table, P, d_first, c->d_out_len, st));

@@ -781,7 +781,78 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve_first(const uint8_t* __re
     }
 }
 
+// ---- `rmdup -s` on FASTQ, the byte comparison of every duplicate with its survivor (RmDupCheck's exact test,
+// rmdup.go:193-199) -- round 4.  One record in five is a duplicate; k_rmdup_resolve_first gave two lanes to EVERY record and
+// left four fifths of them idle while the rest walked 2 x 150 bytes.  Here a block takes 2 048 records, writes their output
+// sizes (a record survives iff first[i] == i), collects its duplicates in an LDS list, and then gives FOUR lanes to every
+// listed duplicate: 16 bytes per lane and step from either text, the last 16 bytes of the sequence once more instead of
+// a byte tail.  Distinct texts under equal keys raise ERR_HASH_COLLISION (the call fails: nothing is dropped on a guess).
+constexpr uint32_t VER_RECORDS = 2048;
+template <bool FOLD>
+__global__ __launch_bounds__(256) void k_rmdup_verify_fastq(const uint8_t* __restrict__ buf, RecordTable t, RmDupParams P,
+                                                            const uint32_t* __restrict__ first_of, uint32_t* __restrict__ out_len,
+                                                            uint64_t* __restrict__ status) {
+    __shared__ uint32_t s_list[VER_RECORDS];
+    __shared__ uint32_t s_n;
+    const uint64_t base = (uint64_t)blockIdx.x * VER_RECORDS;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < VER_RECORDS / 256u; ++k) {
+        const uint64_t i = base + k * 256u + threadIdx.x;
+        if (i < t.n) {
+            const bool keep = first_of[i] == (uint32_t)i;
+            const uint32_t lh = t.l_head[i];
+            out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], 1, 0) : 0u;
+            if (!keep) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)(i - base);
+        }
+    }
+    __syncthreads();
+    const uint32_t nd = s_n, gl = threadIdx.x & 3u;
+    uint32_t bad = 0;
+    for (uint32_t d = threadIdx.x >> 2; d < nd; d += 64u) {
+        const uint64_t i = base + s_list[d];
+        const uint64_t f = first_of[i];
+        const uint32_t la = t.l_seq[i], lb = t.l_seq[f];
+        const uint8_t* pa = buf + t.start[i] + t.l_head[i] + 1;
+        const uint8_t* pb = buf + t.start[f] + t.l_head[f] + 1;
+        uint32_t diff = la ^ lb;
+        if (diff == 0) {
+            auto cmp16 = [&](uint32_t q) {
+                uint4 x, y;
+                __builtin_memcpy(&x, pa + q, 16);
+                __builtin_memcpy(&y, pb + q, 16);
+                if (FOLD) {
+                    x.x = fold4(x.x); x.y = fold4(x.y); x.z = fold4(x.z); x.w = fold4(x.w);
+                    y.x = fold4(y.x); y.y = fold4(y.y); y.z = fold4(y.z); y.w = fold4(y.w);
+                }
+                diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+            };
+            for (uint32_t q = 16u * gl; q + 16u <= la; q += 64u) cmp16(q);  // (no early exit: the loads do not wait for each other)
+            if (gl == 3u) {
+                if (la >= 16u) { if (la & 15u) cmp16(la - 16u); }   // the tail: the sequence's last 16 bytes once more
+                else for (uint32_t q = 0; q < la; ++q) {
+                    uint8_t ca = pa[q], cb = pb[q];
+                    if (FOLD) { ca = lower8(ca); cb = lower8(cb); }
+                    diff |= (uint32_t)(ca ^ cb);
+                }
+            }
+        }
+        bad |= diff;
+    }
+    if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
+}
+
 }  // namespace
+
+hipError_t launch_rmdup_verify_fastq(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint32_t* first,
+                                     uint32_t* out_len, uint64_t* status, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    const dim3 g((unsigned)((t.n + VER_RECORDS - 1) / VER_RECORDS));
+    if (P.ignore_case) hipLaunchKernelGGL((k_rmdup_verify_fastq<true>), g, dim3(256), 0, st, buf, t, P, first, out_len, status);
+    else hipLaunchKernelGGL((k_rmdup_verify_fastq<false>), g, dim3(256), 0, st, buf, t, P, first, out_len, status);
+    return hipGetLastError();
+}
 
 hipError_t launch_rmdup_hash(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const TextTableH& tt,
                              const RmDupParams& P, uint64_t* keys, uint64_t* keys2, hipStream_t st) {

@@ -50,6 +50,10 @@ constexpr uint32_t RMDUP_BUCKET_BITS = 16;
 // bstart: scratch [65 537]; first[] must hold iota and receives, for every duplicate, the lowest record with its key
 // k2 != null (second keys by record): a duplicate must agree with the first record of its key in k2 as well; the records
 // that do not are listed in ovf[1..] (ovf[0] = their number, zeroed by the caller; entries beyond ovf_cap are dropped)
+// `rmdup -s` on FASTQ: output sizes from first[] (a record survives iff first[i] == i) and the byte comparison of every
+// duplicate's sequence with its survivor's (-i: case-folded); a difference raises ERR_HASH_COLLISION
+hipError_t launch_rmdup_verify_fastq(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint32_t* first,
+                                     uint32_t* out_len, uint64_t* status, hipStream_t st);
 hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
                                 uint64_t* status, hipStream_t st, const uint64_t* k2 = nullptr, uint32_t* ovf = nullptr,
                                 uint32_t ovf_cap = 0, bool have_bstart = false /* bstart comes from launch_bucket_pass */);

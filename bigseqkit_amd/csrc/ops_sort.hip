@@ -2,6 +2,7 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "ops_sort.hpp"
 #include "text_dev.hpp"
@@ -294,6 +295,20 @@ hipError_t launch_sort_pairs_bits(void* tmp, size_t tmp_bytes, const uint64_t* k
                                   uint32_t* vout, uint64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n == 0) return hipSuccess;
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, begin_bit, end_bit, st);
+}
+
+// the same with the values 0, 1, 2, ... as input (a counting iterator: no iota pass, no array to read)
+hipError_t sort_pairs_bits_iota_temp_bytes(uint64_t n, int begin_bit, int end_bit, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+                                     (uint32_t*)nullptr, (size_t)n, begin_bit, end_bit, (hipStream_t)0);
+}
+
+hipError_t launch_sort_pairs_bits_iota(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, uint32_t* vout, uint64_t n,
+                                       int begin_bit, int end_bit, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, rocprim::counting_iterator<uint32_t>(0), vout, (size_t)n, begin_bit,
+                                     end_bit, st);
 }
 
 hipError_t launch_sort_gather(const uint32_t* out_len, const uint32_t* perm, uint64_t n, uint32_t* len_perm, hipStream_t st) {

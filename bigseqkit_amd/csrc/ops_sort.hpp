@@ -58,6 +58,10 @@ hipError_t launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* kin, u
 hipError_t sort_pairs_bits_temp_bytes(uint64_t n, int begin_bit, int end_bit, size_t* bytes);
 hipError_t launch_sort_pairs_bits(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                                   uint32_t* vout, uint64_t n, int begin_bit, int end_bit, hipStream_t st);
+// ... with the values 0 .. n - 1 as input (no iota array)
+hipError_t sort_pairs_bits_iota_temp_bytes(uint64_t n, int begin_bit, int end_bit, size_t* bytes);
+hipError_t launch_sort_pairs_bits_iota(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, uint32_t* vout, uint64_t n,
+                                       int begin_bit, int end_bit, hipStream_t st);
 // len_perm[j] = out_len[perm[j]];  out_off[perm[j]] = off_perm[j]
 hipError_t launch_sort_gather(const uint32_t* out_len, const uint32_t* perm, uint64_t n, uint32_t* len_perm, hipStream_t st);
 hipError_t launch_sort_scatter(const uint64_t* off_perm, const uint32_t* perm, uint64_t n, uint64_t* out_off, hipStream_t st);

@@ -58,7 +58,7 @@ def test_bench_n_ranks_sharing_one_gpu(n):
 def test_bench_ops_object_small():
     """the 'ops' object of the driver-run line (seq -n @ C2, grep @ C3 shard, translate @ C4, rmdup @ C5 shard) at 1 / 50
     of the BASELINE sizes: every entry must carry its timing, its algorithmic bytes and an exact full-output check"""
-    d = run_bench(["--gb", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ops-scale", "0.02", "--ops-calls", "2"])
+    d = run_bench(["--gb", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--ops-scale", "0.02", "--ops-calls", "2"])
     ops = d["ops"]
     assert "error" not in ops, ops
     assert set(ops) == {"seq -n @ C2", "subseq -r 1:50 (25 GB)", "grep -s -p @ C3 shard", "translate -f 6 @ C4", "rmdup -s @ C5 shard"}
@@ -72,3 +72,18 @@ def test_bench_ops_object_small():
     assert r["survivors"] == r["records"] - r["records"] // 5
     t = ops["translate -f 6 @ C4"]
     assert t["out_records"] == 6 * t["records"] and t["out_bytes"] == 10298 * t["records"]
+    assert "k_translate_uniform" in t["kernels_ms_per_call"]       # the C4 layout needs no table
+    # the byte-comparing default and the two-key mode beside it
+    assert r["rmdup_keys"].startswith("verify") and "k_rmdup_verify" in r["kernels_ms_per_call"]
+    assert r["rmdup_keys_two_key"]["exact"] is True and "k_rmdup_sizes" in r["rmdup_keys_two_key"]["kernels_ms_per_call"]
+    # a CPU baseline (the oracle: a port, 1 thread and all cores) beside every operator, and the host-bytes-to-result leg
+    for name, e in ops.items():
+        cb = e["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0, (name, cb)
+        if name != "rmdup -s @ C5 shard":
+            assert cb["all_cores"]["value"] > 0 and cb["all_cores"]["cores"] >= 1, (name, cb)
+        assert e["host_ms_per_call"] is not None
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    legs = [v for k, v in e2e.items() if isinstance(v, dict)]
+    assert len(legs) == 3 and all(v["exact"] is True for v in legs), e2e
