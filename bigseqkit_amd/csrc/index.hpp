@@ -61,6 +61,9 @@ int index_max_blocks_per_cu(bool fastq, bool dpp);
 // exclusive scan of u64 counts (n <= a few 10^4; one block): out[0..n], out[n] = total
 hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st, uint64_t* total_at = nullptr);
 // exclusive scan u32 -> u64 over N items (N up to 2^32): out[0..N], out[N] = total; tmp: u64[(N + 2047) / 2048 + 1]
+// two scans of n values each in one launch; total0 / total1 (may be null) also receive the sums
+hipError_t launch_scan_small2(const uint64_t* in0, uint64_t* out0, uint64_t* total0, const uint64_t* in1, uint64_t* out1, uint64_t* total1,
+                              uint32_t n, hipStream_t st);
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st);
 hipError_t launch_scan_u32_fin(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, uint32_t thresh, uint32_t* long_list,
                                uint64_t* fin, hipStream_t st);

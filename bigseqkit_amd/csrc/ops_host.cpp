@@ -181,8 +181,11 @@ int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, int bloc
         c->cap_ranges = nranges;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
-    HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, c->d_anchors, queue, st, /*line_mode=*/!fastq,
-                            /*raw=*/fastq ? nullptr : c->d_anchors + (size_t)nranges + 2));
+    {
+        Timed t(c, "k_prep", st);
+        HIP_TRYX(c, launch_prep(fastq, d_buf, n, chunk, nranges, c->d_anchors, queue, st, /*line_mode=*/!fastq,
+                                /*raw=*/fastq ? nullptr : c->d_anchors + (size_t)nranges + 2));
+    }
     *nranges_out = nranges;
     *chunk_out = chunk;
     return BSK_OK;
@@ -285,7 +288,10 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
                 Timed t(c, F ? "k_filter" : (hash ? "k_rmdup_stream" : "k_index"), st);
                 HIP_TRYX(c, launch_pass(blocks, anchors, nranges, queue, D));
             }
-            HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st, c->d_fin + bsk_ctx::FIN_TABLE_N));
+            {
+                Timed t(c, "k_range_scan", st);
+                HIP_TRYX(c, launch_scan_small(c->d_range_count, c->d_range_base, nranges, st, c->d_fin + bsk_ctx::FIN_TABLE_N));
+            }
             {   // number of records + status word: one read-back
                 const int rcr = ctl_readback(c, st);
                 if (rcr != BSK_OK) return rcr;
@@ -315,9 +321,11 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
                     Timed t(c, "k_rmdup_compact", st);
                     HIP_TRYX(c, launch_rmdup_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges, c->table, HD,
                                                      HashDev{c->d_keys, c->d_keys2}, st));
-                } else if (total)
+                } else if (total) {
+                    Timed t(c, "k_index_compact", st);
                     HIP_TRYX(c, launch_index_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges,
                                                      c->table, st));
+                }
                 done = true;
             }
         }
@@ -650,7 +658,10 @@ int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
         const char* e = c->tune.get("long_bytes");
         c->long_thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
     }
-    HIP_TRYX(c, launch_scan_u32_fin(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, c->long_thresh, c->d_long_list, c->d_fin, st));
+    {
+        Timed t(c, "k_sizes_scan", st);
+        HIP_TRYX(c, launch_scan_u32_fin(c->d_out_len, c->d_out_off, c->table.n, c->d_scan_tmp, c->long_thresh, c->d_long_list, c->d_fin, st));
+    }
     rc = ctl_readback(c, st);
     if (rc != BSK_OK) return rc;
     *total = c->fin(bsk_ctx::FIN_TOTAL);
@@ -672,23 +683,27 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
     bool seg = verbatim && t.n > 0 && total > 0 && ((uintptr_t)d_out & 15u) == 0 && !(env && strcmp(env, "off") == 0);
     if (seg && !(env && strcmp(env, "force") == 0)) seg = kept * 2 >= t.n && total >= (4u << 20);
     if (seg) {
-        int rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+        int rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
+        if (rc != BSK_OK) return rc;
+        rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
         if (rc != BSK_OK) return rc;
         uint64_t* d_other = c->d_fin + bsk_ctx::FIN_OTHER;  // (in the control block: comes back with the final read-back)
         HIP_TRYX(c, hipMemsetAsync(d_other, 0, sizeof(uint64_t), st));
-        HIP_TRYX(c, launch_seg_first(d_off, t.n, c->d_seg_first, st));
         {
-            Timed tm(c, "k_seg_copy", st);  // (the sources follow from the table inside the copy: no k_seg_build pass)
-            HIP_TRYX(c, launch_seg_copy_fastq(d_buf, n, t, P.ren_ord, d_other, d_off, c->d_seg_first, d_out, total, st));
+            // (round 4 tried to derive the sources inside k_seg_copy from the table instead of building seg_src: the build
+            // pass went away, 0.37 ms per 79 M records, and the copy grew by 0.7 ms -- two dependent loads more at the head
+            // of every tile; profiles/r04d_*.  The source array stays.)
+            Timed tm(c, "k_seg_prep", st);
+            HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, d_other, st, P.ren_ord));
+            HIP_TRYX(c, launch_seg_first(d_off, t.n, c->d_seg_first, st));
+        }
+        {
+            Timed tm(c, "k_seg_copy", st);
+            HIP_TRYX(c, launch_seg_copy(c->d_seg_src, d_off, t.n, c->d_seg_first, d_out, total, d_buf, d_buf + n, st));
         }
         rc = ctl_readback(c, st);
         if (rc != BSK_OK) return rc;
         if (c->fin(bsk_ctx::FIN_OTHER) == 0) return BSK_OK;
-        // rare: records the copy left out (a '+' line that repeats the name, a last record without '\n', renamed heads):
-        // their list for the record-wise emit
-        rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
-        if (rc != BSK_OK) return rc;
-        HIP_TRYX(c, launch_seg_build_fastq(d_buf, n, t, d_len, c->d_seg_src, c->d_seg_src + t.n, st, P.ren_ord));
         P.seg_src = c->d_seg_src;  // the few records the copy left out
     }
     HIP_TRYX(c, launch_seq_emit(d_buf, t, P, d_len, d_off, d_out, st, total, kept));

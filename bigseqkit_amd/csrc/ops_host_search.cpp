@@ -499,6 +499,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             // stream_filter.hip): no second search, only their formatted sizes
             SeqParams FP = format_params(c, fastq);
             FP.buf_end = d_buf + n;
+            Timed t(c, "k_seq_size", st);
             HIP_TRYX(c, launch_seq_size(d_buf, c->table, FP, c->d_out_len, c->d_status, st));
         } else if (G.by_seq && G.general && G.sa_ok) {
             // one lane per record (k_grep_shiftand): not for chromosomes

@@ -311,8 +311,11 @@ static int subseq_stream_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStre
         HIP_TRYX(c, launch_subseq_stream(c->use_dpp, blocks, d_buf, n, c->d_anchors, nranges,
                                          reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1), D, st));
     }
-    HIP_TRYX(c, launch_scan_small(D.range_bytes, c->d_range_base, nranges, st, c->d_fin + bsk_ctx::FIN_AUX0));
-    HIP_TRYX(c, launch_scan_small(D.range_count, d_count_base, nranges, st, c->d_fin + bsk_ctx::FIN_AUX1));
+    {
+        Timed t(c, "k_range_scan", st);
+        HIP_TRYX(c, launch_scan_small2(D.range_bytes, c->d_range_base, c->d_fin + bsk_ctx::FIN_AUX0, D.range_count, d_count_base,
+                                       c->d_fin + bsk_ctx::FIN_AUX1, nranges, st));
+    }
     rc = ctl_readback(c, st);  // bytes, records, status: one copy
     if (rc != BSK_OK) return rc;
     const uint64_t total = c->fin(bsk_ctx::FIN_AUX0), records = c->fin(bsk_ctx::FIN_AUX1);

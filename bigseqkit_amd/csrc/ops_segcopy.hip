@@ -133,33 +133,9 @@ __device__ __forceinline__ uint32_t incl_scan64(uint32_t v) {  // inclusive sum 
 
 constexpr int32_t REL_MIN = -(1 << 30), REL_MAX = (1 << 30);
 
-// FT (round 4): the segments are the FASTQ records of a table and their sources follow from it -- what k_seg_build_fastq
-// wrote into seg_src (8 bytes per record written and read back, 0.37 ms per 79 M records) is derived where it is used:
-// a record with output leaves verbatim when its '+' line is bare (aux == 1), it lies inside the buffer and it keeps its head
-// (rename); any other record with output is counted in n_other (only "none" / "some" matters: the caller then builds the
-// source array after all and the record-wise emit writes those records).
-struct SegTable {
-    const uint64_t* start;
-    const uint32_t* aux;
-    const uint32_t* ren_ord;
-    const uint8_t* buf;
-    uint64_t buf_n;
-    unsigned long long* n_other;
-};
-template <bool FT>
-__device__ __forceinline__ uint64_t seg_source(const uint64_t* __restrict__ seg_src, const SegTable& S, uint64_t k, uint64_t len) {
-    if constexpr (!FT) return seg_src[k];
-    if (len == 0) return 0;
-    const uint64_t st = S.start[k];
-    if (S.aux[k] == 1u && st + len <= S.buf_n && !(S.ren_ord && S.ren_ord[k])) return (uint64_t)(uintptr_t)(S.buf + st);
-    atomicAdd(S.n_other, 1ull);  // rare: a '+' line that repeats the name, or the last record of a shard without '\n'
-    return 0;
-}
-
-template <bool FT>
 __global__ __launch_bounds__(256) void k_seg_copy(const uint64_t* __restrict__ seg_src, const uint64_t* __restrict__ seg_off,
                                                   uint64_t nseg, const uint32_t* __restrict__ first4k, uint8_t* __restrict__ out,
-                                                  uint64_t total, const uint8_t* lo, const uint8_t* hi, SegTable S) {
+                                                  uint64_t total, const uint8_t* lo, const uint8_t* hi) {
     __shared__ int32_t s_rel[4][66];     // begin of the wave's segments relative to its tile (clamped); [m] = end of the last
     __shared__ uint64_t s_delta[4][64];  // source address of output byte x = delta + x
     __shared__ uint32_t s_hist[4][64];
@@ -176,7 +152,7 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint64_t* __restrict__ s
         {
             const uint64_t k = k0 + lane;
             uint64_t off = 0, offn = 0;
-            if (lane < (int)m) { off = seg_off[k]; offn = seg_off[k + 1]; sa = seg_source<FT>(seg_src, S, k, offn - off); }
+            if (lane < (int)m) { off = seg_off[k]; sa = seg_src[k]; offn = seg_off[k + 1]; }
             const int64_t rel = (int64_t)off - (int64_t)T0;
             s_rel[wv][lane] = lane < (int)m ? (int32_t)(rel < REL_MIN ? REL_MIN : rel) : REL_MAX;
             if (lane == (int)m - 1) {
@@ -278,12 +254,11 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint64_t* __restrict__ s
         }
         uint64_t k = a;
         uint64_t nextk = seg_off[k + 1];
-        uint64_t base = seg_off[k];
-        uint64_t src = seg_source<FT>(seg_src, S, k, nextk - base);
+        uint64_t src = seg_src[k], base = seg_off[k];
         const uint32_t nb = pos + 16 <= total ? 16u : (uint32_t)(total - pos);
         for (uint32_t j = 0; j < nb; ++j) {
             const uint64_t x = pos + j;
-            while (x >= nextk && k < k1) { ++k; base = nextk; nextk = seg_off[k + 1]; src = seg_source<FT>(seg_src, S, k, nextk - base); }
+            while (x >= nextk && k < k1) { ++k; base = nextk; nextk = seg_off[k + 1]; src = seg_src[k]; }
             if (src) out[x] = *(const uint8_t*)(uintptr_t)(src + (x - base));
         }
     }
@@ -349,18 +324,8 @@ hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uin
                            uint8_t* out, uint64_t total, const uint8_t* lo, const uint8_t* hi, hipStream_t st) {
     if (nseg == 0 || total == 0) return hipSuccess;
     const uint64_t tiles = seg_tiles(total);
-    hipLaunchKernelGGL((k_seg_copy<false>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, seg_src, seg_off, nseg, first4k, out, total,
-                       lo, hi, SegTable{});
-    return hipGetLastError();
-}
-
-hipError_t launch_seg_copy_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* ren_ord, uint64_t* n_other,
-                                 const uint64_t* seg_off, const uint32_t* first4k, uint8_t* out, uint64_t total, hipStream_t st) {
-    if (t.n == 0 || total == 0) return hipSuccess;
-    const uint64_t tiles = seg_tiles(total);
-    const SegTable S{t.start, t.aux, ren_ord, buf, buf_n, (unsigned long long*)n_other};
-    hipLaunchKernelGGL((k_seg_copy<true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, (const uint64_t*)nullptr, seg_off, t.n,
-                       first4k, out, total, buf, buf + buf_n, S);
+    hipLaunchKernelGGL(k_seg_copy, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, seg_src, seg_off, nseg, first4k, out, total,
+                       lo, hi);
     return hipGetLastError();
 }
 

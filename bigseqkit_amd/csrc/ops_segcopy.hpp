@@ -42,9 +42,5 @@ hipError_t launch_seg_fix_text_times(const uint8_t* buf, const RecordTable& t, c
 hipError_t launch_seg_first(const uint64_t* seg_off, uint64_t nseg, uint32_t* first4k, hipStream_t st);
 hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
                            uint8_t* out, uint64_t total, const uint8_t* lo, const uint8_t* hi, hipStream_t st);
-// the same for the FASTQ records of a table that leave verbatim (what launch_seg_build_fastq + launch_seg_copy do, without the
-// source array): *n_other (zeroed device word) counts the records with output that the copy left to the record-wise emit
-hipError_t launch_seg_copy_fastq(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const uint32_t* ren_ord, uint64_t* n_other,
-                                 const uint64_t* seg_off, const uint32_t* first4k, uint8_t* out, uint64_t total, hipStream_t st);
 
 }  // namespace bsk

@@ -358,6 +358,56 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint64_t* __restrict__
     }
 }
 
+// TWO such scans in one launch (the bytes and the record counts of the ranges of a streaming pass: k_names, k_subseq_stream),
+// a block of 1 024 threads each: 2 x 0.12 ms -> 0.03 ms for the 2 x 10^5 ranges of a 100 GB shard
+__global__ __launch_bounds__(1024) void k_scan_small2(const uint64_t* __restrict__ in0, uint64_t* __restrict__ out0, uint64_t* __restrict__ total0,
+                                                      const uint64_t* __restrict__ in1, uint64_t* __restrict__ out1, uint64_t* __restrict__ total1,
+                                                      uint32_t n) {
+    constexpr uint32_t PER = 8, NT = 1024, NW = NT / 64;
+    const uint64_t* in = blockIdx.x ? in1 : in0;
+    uint64_t* out = blockIdx.x ? out1 : out0;
+    uint64_t* total_at = blockIdx.x ? total1 : total0;
+    __shared__ uint64_t s_w[NW];
+    __shared__ uint64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += NT * PER) {
+        const uint32_t i = i0 + threadIdx.x * PER;
+        uint64_t v[PER];
+        uint64_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            v[k] = i + k < n ? in[i + k] : 0;
+            mine += v[k];
+        }
+        uint64_t x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+            if (lane >= d) x += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint64_t off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        uint64_t run = off + x - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            if (i + k < n) out[i + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == NT - 1) s_carry = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[n] = s_carry;
+        if (total_at) *total_at = s_carry;
+    }
+}
+
 // ---- large exclusive scan u32 -> u64: reduce / scan of block sums / downsweep ----------
 constexpr int SCAN_ITEMS = 8;                  // per thread
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;   // 2048 per block
@@ -625,6 +675,12 @@ int index_max_blocks_per_cu(bool fastq, bool dpp) {
 
 hipError_t launch_scan_small(const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t st, uint64_t* total_at) {
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, in, out, n, total_at);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_small2(const uint64_t* in0, uint64_t* out0, uint64_t* total0, const uint64_t* in1, uint64_t* out1, uint64_t* total1,
+                              uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_small2, dim3(2), dim3(1024), 0, st, in0, out0, total0, in1, out1, total1, n);
     return hipGetLastError();
 }
 

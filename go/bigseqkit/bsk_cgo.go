@@ -1,0 +1,430 @@
+// bsk_cgo.go -- the cgo binding a BigSeqKit maintainer adds to the driver package `bigseqkit` so that the seven hot-path
+// commands run on libbsk.so (MI355X) instead of IgnisHPC executors.
+//
+// UNVERIFIED: no Go toolchain exists in the environment this file was written in (`go version`: not found), so it has never
+// been compiled.  The same call sequences are exercised through ctypes by bigseqkit_amd/api.py and the `-m gpu` tests; the
+// C declarations are include/bsk.h.  Citations are file:line in the reference tree (citiususc/BigSeqKit).
+//
+// What it replaces, function by function (the option structs, their builders and setDefaults() stay as they are):
+//
+//   Stats / StatsString   bigseqkit/stats.go:75-288     MapPartitions(Stats) + Reduce(StatsReduce) + driver arithmetic
+//   Seq                   bigseqkit/seq.go:157-170      MapPartitions(SeqTransform)
+//   Grep / GrepCount      bigseqkit/grep.go:121-180     MapPartitionsWithIndex(Grep) [+ Reduce(GrepReduceCount)]
+//   Locate                bigseqkit/locate.go:122-134   MapPartitionsWithIndex(Locate)
+//   Subseq                bigseqkit/subseq.go:86-100    MapPartitions(SubseqTransform)
+//   Translate             bigseqkit/translate.go:87-100 MapPartitions(Translate)
+//   RmDup                 bigseqkit/rmdup.go:70-108     MapPartitions(RmDupPrepare) + GroupByKey + Flatmap(RmDupCheck)
+//   ReadFASTA/Q[N]        bigseqkit/helper.go:148-178   PlainFile(path, delim) + ReadFixer
+//   StoreFASTX[N]         bigseqkit/helper.go:180-195   SaveAsTextFile / FileStore
+//
+// Threads (include/bsk.h "THREADS"): the reference calls Call() of one operator struct from Threads() goroutines
+// (bigseqkit-lib/helper.go:413-416).  A bsk_ctx is single-caller, so mapPartitions below creates one context PER WORKER
+// GOROUTINE from the same options JSON; the FileStore (bsk_store) is the one object the workers share.
+package bigseqkit
+
+/*
+#cgo CFLAGS:  -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../bigseqkit_amd/lib -lbsk -Wl,-rpath,${SRCDIR}/../../bigseqkit_amd/lib
+#include <stdlib.h>
+#include <stdint.h>
+#include "bsk.h"
+
+// cgo cannot take the address of a Go function-typed field; thin wrappers keep one signature for the record operators
+typedef int (*bsk_run_fn)(bsk_ctx*, const void*, size_t, int, int, int64_t, void*, bsk_out*);
+static int bsk_call_run(bsk_run_fn f, bsk_ctx* c, const void* p, size_t n, int on_dev, int fmt, int64_t pid, bsk_out* o) {
+	return f(c, p, n, on_dev, fmt, pid, NULL, o);
+}
+static bsk_run_fn bsk_fn_seq(void)       { return bsk_seq_run; }
+static bsk_run_fn bsk_fn_grep(void)      { return bsk_grep_run; }
+static bsk_run_fn bsk_fn_locate(void)    { return bsk_locate_run; }
+static bsk_run_fn bsk_fn_subseq(void)    { return bsk_subseq_run; }
+static bsk_run_fn bsk_fn_translate(void) { return bsk_translate_run; }
+static bsk_run_fn bsk_fn_rmdup(void)     { return bsk_rmdup_run; }
+*/
+import "C"
+
+import (
+	"errors"
+	"os"
+	"runtime"
+	"sync"
+	"unsafe"
+)
+
+const (
+	FormatFASTA = C.BSK_FORMAT_FASTA
+	FormatFASTQ = C.BSK_FORMAT_FASTQ
+)
+
+// Shard is one partition: file bytes that begin on a record (PlainFile + ReadFixer, bigseqkit/helper.go:140-178;
+// bigseqkit-lib/helper.go:41-66).  Data may be a slice of an mmap of the input file: nothing is copied to cut it.
+type Shard struct {
+	Data []byte
+}
+
+// SeqFrame stands where the reference has *api.IDataFrame[string]: the partitions of one input and its format.
+type SeqFrame struct {
+	Format int
+	Shards []Shard
+	Device int // GPU of this process (one process per GPU; see DESIGN.md section 5)
+}
+
+// ---- ReadFASTA / ReadFASTQ [N] --------------------------------------------------------------------------------------
+// bigseqkit/helper.go:148-178.  minPartitions record-aligned shards; the cut points come from bsk_find_record_start (the
+// rule of IgnisHPC's delimiter "\n@!\n+" for FASTQ, '>' at a line start for FASTA).
+func readFASTX(data []byte, format, minPartitions, device int) (*SeqFrame, error) {
+	if minPartitions < 1 {
+		minPartitions = 1
+	}
+	n := len(data)
+	cuts := []int{0}
+	for k := 1; k < minPartitions && n > 0; k++ {
+		var out C.size_t
+		if rc := C.bsk_find_record_start((*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(n), C.size_t(n*k/minPartitions),
+			C.int(format), &out); rc != C.BSK_OK {
+			return nil, errors.New(C.GoString(C.bsk_global_error()))
+		}
+		if int(out) > cuts[len(cuts)-1] {
+			cuts = append(cuts, int(out))
+		}
+	}
+	cuts = append(cuts, n)
+	f := &SeqFrame{Format: format, Device: device}
+	for k := 0; k+1 < len(cuts); k++ {
+		if cuts[k+1] > cuts[k] {
+			f.Shards = append(f.Shards, Shard{data[cuts[k]:cuts[k+1]]})
+		}
+	}
+	return f, nil
+}
+func ReadFASTA(data []byte, device int) (*SeqFrame, error) { return readFASTX(data, FormatFASTA, 1, device) }
+func ReadFASTQ(data []byte, device int) (*SeqFrame, error) { return readFASTX(data, FormatFASTQ, 1, device) }
+func ReadFASTAN(data []byte, minPartitions, device int) (*SeqFrame, error) {
+	return readFASTX(data, FormatFASTA, minPartitions, device)
+}
+func ReadFASTQN(data []byte, minPartitions, device int) (*SeqFrame, error) {
+	return readFASTX(data, FormatFASTQ, minPartitions, device)
+}
+
+// ---- operator lifecycle: plugin.Lookup("New"+name) + Before(ctx) ... After(ctx) ---------------------------------------
+type bskOp struct{ ctx *C.bsk_ctx }
+
+func newBskOp(name, optsJSON string, device int) (*bskOp, error) {
+	cn, cj := C.CString(name), C.CString(optsJSON)
+	defer C.free(unsafe.Pointer(cn))
+	defer C.free(unsafe.Pointer(cj))
+	var ctx *C.bsk_ctx
+	if rc := C.bsk_create(cn, cj, C.int(device), &ctx); rc != C.BSK_OK {
+		return nil, errors.New(C.GoString(C.bsk_global_error())) // the reference's Before() message
+	}
+	return &bskOp{ctx}, nil
+}
+func (o *bskOp) Close()     { C.bsk_destroy(o.ctx) }
+func (o *bskOp) err() error { return errors.New(C.GoString(C.bsk_last_error(o.ctx))) }
+
+// Result of a record command: the text of every partition in partition order (an element per record + '\n', what
+// FileStore / SaveAsTextFile would write), or -- when a store is given -- already in the output file(s).
+type Result struct {
+	Parts   [][]byte
+	Records uint64
+	Bytes   uint64
+}
+
+// FileStore: bigseqkit-lib/helper.go:378-460 (merge) / SaveAsTextFile (directory of parts).
+type FileStore struct{ s *C.bsk_store }
+
+func OpenStore(path string, merge bool) (*FileStore, error) {
+	cp := C.CString(path)
+	defer C.free(unsafe.Pointer(cp))
+	var s *C.bsk_store
+	m := 0
+	if merge {
+		m = 1
+	}
+	if rc := C.bsk_store_open(cp, C.int(m), &s); rc != C.BSK_OK {
+		return nil, errors.New(C.GoString(C.bsk_global_error()))
+	}
+	return &FileStore{s}, nil
+}
+func (f *FileStore) Close() (uint64, error) {
+	var total C.uint64_t
+	if rc := C.bsk_store_close(f.s, &total); rc != C.BSK_OK {
+		return uint64(total), errors.New("bsk_store_close failed")
+	}
+	return uint64(total), nil
+}
+
+// mapPartitions == api.MapPartitions[WithIndex](input, libSource(name)+opts): Call() per partition, `workers` goroutines,
+// ONE CONTEXT EACH.  Host shards go through bsk_run_to_store when a store is given (chunked H2D || kernels || D2H + write),
+// else through bsk_<op>_run(on_device = 0) + bsk_out_to_host.  No Go pointer is retained by C past a call.
+func mapPartitions(name string, fn C.bsk_run_fn, optsJSON string, in *SeqFrame, store *FileStore, workers int) (*Result, error) {
+	if workers < 1 {
+		workers = 1
+	}
+	if workers > len(in.Shards) {
+		workers = len(in.Shards)
+	}
+	res := &Result{Parts: make([][]byte, len(in.Shards))}
+	var mu sync.Mutex
+	var firstErr error
+	next := 0
+	var wg sync.WaitGroup
+	for w := 0; w < workers; w++ {
+		wg.Add(1)
+		go func() {
+			defer wg.Done()
+			runtime.LockOSThread() // the HIP runtime's current device is per OS thread
+			defer runtime.UnlockOSThread()
+			op, err := newBskOp(name, optsJSON, in.Device)
+			if err != nil {
+				mu.Lock()
+				if firstErr == nil {
+					firstErr = err
+				}
+				mu.Unlock()
+				return
+			}
+			defer op.Close()
+			for {
+				mu.Lock()
+				pid := next
+				next++
+				failed := firstErr != nil
+				mu.Unlock()
+				if failed || pid >= len(in.Shards) {
+					return
+				}
+				d := in.Shards[pid].Data
+				var ptr unsafe.Pointer
+				if len(d) > 0 {
+					ptr = unsafe.Pointer(&d[0])
+				}
+				var e error
+				if store != nil {
+					var nb, nr C.uint64_t
+					if rc := C.bsk_run_to_store(op.ctx, ptr, C.size_t(len(d)), C.int(in.Format), C.int64_t(pid), store.s,
+						C.uint64_t(pid), &nb, &nr); rc != C.BSK_OK {
+						e = op.err()
+					}
+					mu.Lock()
+					res.Bytes += uint64(nb)
+					res.Records += uint64(nr)
+					mu.Unlock()
+				} else {
+					var out C.bsk_out
+					if rc := C.bsk_call_run(fn, op.ctx, ptr, C.size_t(len(d)), 0, C.int(in.Format), C.int64_t(pid), &out); rc != C.BSK_OK {
+						e = op.err()
+					} else {
+						buf := make([]byte, int(out.len))
+						if out.len > 0 {
+							if rc := C.bsk_out_to_host(op.ctx, &out, unsafe.Pointer(&buf[0]), out.len); rc != C.BSK_OK {
+								e = op.err()
+							}
+						}
+						mu.Lock()
+						res.Parts[pid] = buf
+						res.Bytes += uint64(out.len)
+						res.Records += uint64(out.records)
+						mu.Unlock()
+					}
+				}
+				if e != nil {
+					mu.Lock()
+					if firstErr == nil {
+						firstErr = e
+					}
+					mu.Unlock()
+					return
+				}
+			}
+		}()
+	}
+	wg.Wait()
+	if firstErr != nil {
+		return nil, firstErr
+	}
+	return res, nil
+}
+
+// ---- Stats (bigseqkit/stats.go:75-166) ---------------------------------------------------------------------------------
+// Stats.Call per partition accumulates into the context's device vector; StatsReduce is implied (one context sums its
+// partitions; several contexts merge with bsk_stats_merge); Stats()'s driver arithmetic is bsk_stats_finalize.
+func Stats(name, format string, input *SeqFrame, o *SeqKitStatsOptions) (*StatInfo, error) {
+	o.setDefaults()
+	op, err := newBskOp("Stats", OptionsToString(o), input.Device)
+	if err != nil {
+		return nil, err
+	}
+	defer op.Close()
+	for pid, s := range input.Shards {
+		if len(s.Data) == 0 {
+			continue
+		}
+		if rc := C.bsk_stats_run(op.ctx, unsafe.Pointer(&s.Data[0]), C.size_t(len(s.Data)), 0, C.int(input.Format),
+			C.int64_t(pid), nil, nil); rc != C.BSK_OK {
+			return nil, op.err()
+		}
+	}
+	capN := 1 << 17
+	for {
+		keys := make([]C.int64_t, capN)
+		vals := make([]C.int64_t, capN)
+		var n C.size_t
+		rc := C.bsk_stats_collect(op.ctx, nil, &keys[0], &vals[0], C.size_t(capN), &n)
+		if rc == C.BSK_ERR_CAPACITY && int(n) > capN {
+			capN = int(n)
+			continue
+		}
+		if rc != C.BSK_OK {
+			return nil, op.err() // e.g. "unmatched length of sequence and quality"
+		}
+		var info C.bsk_statinfo
+		if rc := C.bsk_stats_finalize(op.ctx, &keys[0], &vals[0], n, &info); rc != C.BSK_OK {
+			return nil, op.err()
+		}
+		return &StatInfo{name, format, C.GoString(&info._type[0]),
+			uint64(info.num), uint64(info.len_sum), uint64(info.gap_sum), uint64(info.len_min),
+			float64(info.len_avg), uint64(info.len_max), uint64(info.n50), int(info.l50),
+			float64(info.q1), float64(info.q2), float64(info.q3), float64(info.q20), float64(info.q30)}, nil
+	}
+}
+
+// StatsString (bigseqkit/stats.go:168-288) keeps its body: it only formats a *StatInfo.
+
+// ---- the record commands ---------------------------------------------------------------------------------------------
+func workersFor(in *SeqFrame) int {
+	w := runtime.NumCPU() / 8 // a handful of contexts keeps one GPU busy; more only queue behind each other
+	if w < 1 {
+		w = 1
+	}
+	if w > 8 {
+		w = 8
+	}
+	return w
+}
+
+// Seq: bigseqkit/seq.go:157-170
+func Seq(input *SeqFrame, o *SeqKitSeqOptions) (*Result, error) {
+	o.setDefaults()
+	return mapPartitions("SeqTransform", C.bsk_fn_seq(), OptionsToString(o), input, nil, workersFor(input))
+}
+
+// Grep: bigseqkit/grep.go:121-159.  (Q3 of SURVEY section 9: the reference names "GrepPairMatched" here; the operator is Grep.)
+// --delete-matched needs every pattern's FIRST record over the whole input (grep.go:144-156): one partition, one context.
+func Grep(input *SeqFrame, o *SeqKitGrepOptions) (*Result, error) {
+	o.setDefaults()
+	f := false
+	o.Count = &f
+	in := input
+	if o.DeleteMatched != nil && *o.DeleteMatched {
+		in = joined(input)
+	}
+	return mapPartitions("Grep", C.bsk_fn_grep(), OptionsToString(o), in, nil, workersFor(in))
+}
+
+// GrepCount: bigseqkit/grep.go:161-180 -- Reduce(GrepReduceCount) is the sum of the partitions' record counts
+func GrepCount(input *SeqFrame, o *SeqKitGrepOptions) (int64, error) {
+	o.setDefaults()
+	t := true
+	o.Count = &t
+	r, err := mapPartitions("Grep", C.bsk_fn_grep(), OptionsToString(o), input, nil, workersFor(input))
+	if err != nil {
+		return 0, err
+	}
+	var total int64
+	for _, p := range r.Parts { // every partition answers one decimal line
+		var v int64
+		for _, ch := range p {
+			if ch >= '0' && ch <= '9' {
+				v = v*10 + int64(ch-'0')
+			}
+		}
+		total += v
+	}
+	return total, nil
+}
+
+// Locate: bigseqkit/locate.go:122-134 (partition 0 carries the header row, bigseqkit-lib/locate.go:198-204)
+func Locate(input *SeqFrame, o *SeqKitLocateOptions) (*Result, error) {
+	o.setDefaults()
+	return mapPartitions("Locate", C.bsk_fn_locate(), OptionsToString(o), input, nil, workersFor(input))
+}
+
+// Subseq: bigseqkit/subseq.go:86-100
+func Subseq(input *SeqFrame, o *SeqKitSubseqOptions) (*Result, error) {
+	o.setDefaults()
+	return mapPartitions("SubseqTransform", C.bsk_fn_subseq(), OptionsToString(o), input, nil, workersFor(input))
+}
+
+// Translate: bigseqkit/translate.go:87-100
+func Translate(input *SeqFrame, o *SeqKitTranslateOptions) (*Result, error) {
+	o.setDefaults()
+	return mapPartitions("Translate", C.bsk_fn_translate(), OptionsToString(o), input, nil, workersFor(input))
+}
+
+// RmDup: bigseqkit/rmdup.go:70-108.  Duplicates are global (GroupByKey): the partitions of this process are joined and
+// seen by ONE context; across processes (one per GPU) the bsk_rmdup_dist_* phases exchange 24-byte tuples instead of
+// records (INTEGRATION.md "Multi-GPU").  RmDupCheck.After (-d / -D files) runs inside bsk_destroy / bsk_rmdup_finish.
+func RmDup(input *SeqFrame, o *SeqKitRmDupOptions) (*Result, error) {
+	o.setDefaults()
+	if o.BySeq != nil && *o.BySeq && o.ByName != nil && *o.ByName { // rmdup.go:79-81 (also checked by bsk_create)
+		return nil, errors.New("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed")
+	}
+	return mapPartitions("RmDup", C.bsk_fn_rmdup(), OptionsToString(o), joined(input), nil, 1)
+}
+
+// joined: all partitions as one shard (Union + Repartition(1)); a missing final newline between partitions is added
+func joined(in *SeqFrame) *SeqFrame {
+	if len(in.Shards) <= 1 {
+		return in
+	}
+	var all []byte
+	for _, s := range in.Shards {
+		all = append(all, s.Data...)
+		if n := len(all); n > 0 && all[n-1] != '\n' {
+			all = append(all, '\n')
+		}
+	}
+	return &SeqFrame{Format: in.Format, Shards: []Shard{{all}}, Device: in.Device}
+}
+
+// ---- StoreFASTX / StoreFASTXN (bigseqkit/helper.go:180-195) -----------------------------------------------------------
+// For results already in memory.  To stream a command straight into files pass a FileStore to mapPartitions instead
+// (bsk_run_to_store: the partition never exists in Go memory).
+func StoreFASTX(r *Result, path string) error {
+	st, err := OpenStore(path, true)
+	if err != nil {
+		return err
+	}
+	for pid, p := range r.Parts {
+		var ptr unsafe.Pointer
+		if len(p) > 0 {
+			ptr = unsafe.Pointer(&p[0])
+		}
+		if rc := C.bsk_store_put_host(st.s, C.uint64_t(pid), ptr, C.size_t(len(p))); rc != C.BSK_OK {
+			return errors.New(C.GoString(C.bsk_store_error(st.s)))
+		}
+	}
+	_, err = st.Close()
+	return err
+}
+func StoreFASTXN(r *Result, path string) error {
+	if err := os.MkdirAll(path, 0o777); err != nil {
+		return err
+	}
+	st, err := OpenStore(path, false)
+	if err != nil {
+		return err
+	}
+	for pid, p := range r.Parts {
+		var ptr unsafe.Pointer
+		if len(p) > 0 {
+			ptr = unsafe.Pointer(&p[0])
+		}
+		if rc := C.bsk_store_put_host(st.s, C.uint64_t(pid), ptr, C.size_t(len(p))); rc != C.BSK_OK {
+			return errors.New(C.GoString(C.bsk_store_error(st.s)))
+		}
+	}
+	_, err = st.Close()
+	return err
+}

@@ -20,6 +20,29 @@
  * bsk_last_error(ctx) or, for failures that have no ctx, bsk_global_error().
  * There is NO CPU fallback: without a usable HIP device every compute entry
  * point fails with BSK_ERR_NO_DEVICE.
+ *
+ * THREADS.  The reference calls Call() of ONE operator struct from Threads()
+ * goroutines at once (bigseqkit-lib/helper.go:413-416 per-thread channels,
+ * rmdup.go:100,224 a mutex around the shared maps).  A bsk_ctx is NOT that
+ * struct: it owns the device state of a call -- output buffer, record table,
+ * control block, staging buffers -- so the rule is
+ *     ONE CONTEXT PER CALLER THREAD (create them from the same options JSON),
+ *     any number of contexts per device, any thread may use any context,
+ *     but only one call at a time runs on a context.
+ * A second call that arrives while one is running on the same context is
+ * refused with BSK_ERR_INVALID_ARG ("context busy"), never raced; this covers
+ * every entry point that touches the context's device state (the *_run
+ * family, bsk_stats_*, bsk_index_*, bsk_out_to_host, bsk_store_put,
+ * bsk_run_to_store, the bsk_rmdup_dist_* phases, bsk_profile_read).
+ * The bsk_out a run returns points into the context's output buffer and is
+ * valid until the next run on that context.  Objects meant to be SHARED by
+ * the threads of an executor: a bsk_store (FileStore: parts may arrive from
+ * any thread in any order; internally locked) and the input shard (read-only).
+ * bsk_global_error() is thread-local; bsk_last_error(ctx) belongs to the ctx.
+ * Results that the reference merges across threads merge the same way here:
+ * stats vectors add (bsk_stats_merge, or one device vector passed to several
+ * contexts' runs on ONE stream), grep counts add, rmdup needs ONE context for
+ * the whole partition (duplicates are global), the store orders the parts.
  * ==========================================================================*/
 #ifndef BSK_H
 #define BSK_H
