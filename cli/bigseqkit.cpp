@@ -55,6 +55,8 @@ const Flag kPersistent[] = {
     {"order", 0, BOOL, "", "false"},
     {"device", 0, INT, "", "0"},
     {"dry-run", 0, BOOL, "", "false"},
+    {"plan", 0, BOOL, "", "false"},      // one JSON object: operator, options, files, output place (python -m bigseqkit_amd.run)
+    {"devices", 0, STR, "", ""},         // "0,1,2,3" / "0-7": one worker per GPU (bigseqkit_amd/run.py takes over)
 };
 
 struct Command {
@@ -690,6 +692,41 @@ static int run_main(int argc, char** argv) {
         std::cout << inv.cmd->op << "\n" << inv.js << "\n";
         for (auto& f : inv.files) std::cout << f << "\n";
         return 0;
+    }
+    if (inv.pget("plan") == "true") {
+        // what the multi-GPU launcher needs to know, decided by THIS program's flag tables (no second parser in Python)
+        std::string files;
+        for (size_t k = 0; k < inv.files.size(); ++k) files += (k ? "," : "") + jquote(inv.files[k]);
+        std::cout << "{\"use\":" << jquote(inv.cmd->use) << ",\"op\":" << jquote(inv.cmd->op) << ",\"opts\":" << inv.js
+                  << ",\"files\":[" << files << "],\"out_file\":" << jquote(inv.pget("out-file"))
+                  << ",\"merge\":" << (inv.pget("merge") == "true" ? "true" : "false")
+                  << ",\"partitions\":" << strtol(inv.pget("partitions").c_str(), nullptr, 10) << "}\n";
+        return 0;
+    }
+    if (!inv.pget("devices").empty()) {
+        // several GPUs: one worker process per device, the file cut on record starts, collectives where the command has
+        // a reduction or an exchange (bigseqkit_amd/run.py; bigseqkit/helper.go:148-195 + bigseqkit-cli/helper.go:87-141)
+        char exe[4096];
+        const ssize_t el = readlink("/proc/self/exe", exe, sizeof exe - 1);
+        std::string root = ".";
+        if (el > 0) {
+            exe[el] = 0;
+            root = exe;
+            for (int up = 0; up < 3; ++up) { const size_t sl = root.rfind('/'); if (sl == std::string::npos) break; root.resize(sl); }
+        }
+        const char* pp = getenv("PYTHONPATH");
+        setenv("PYTHONPATH", (root + (pp ? std::string(":") + pp : std::string())).c_str(), 1);
+        std::vector<std::string> av{"python3", "-m", "bigseqkit_amd.run", "--devices", inv.pget("devices"), "--"};
+        for (size_t i = 0; i < args.size(); ++i) {
+            if (args[i] == "--devices") { ++i; continue; }
+            if (args[i].rfind("--devices=", 0) == 0) continue;
+            av.push_back(args[i]);
+        }
+        std::vector<char*> cav;
+        for (auto& a : av) cav.push_back(const_cast<char*>(a.c_str()));
+        cav.push_back(nullptr);
+        execvp("python3", cav.data());
+        die("cannot start python3 -m bigseqkit_amd.run");
     }
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
     g_faidx_query = faidx_query;

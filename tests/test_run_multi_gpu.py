@@ -1,0 +1,107 @@
+"""`python -m bigseqkit_amd.run --devices ...` / `bigseqkit <cmd> ... --devices ...`: the user-facing entry point for several
+GPUs (one worker per device, the file cut on record starts in 1 MiB windows, collectives where the command reduces or
+exchanges -- /root/reference/bigseqkit/helper.go:148-195, bigseqkit-cli/helper.go:87-141).  Two workers share the one GPU of
+the test box (gloo): their files must equal what the single-device command line writes."""
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bigseqkit_amd", "bin", "bigseqkit")
+
+
+def fastq(nrec, seed):
+    rng = random.Random(seed)
+    seqs, out = [], []
+    for i in range(nrec):
+        if i > 20 and rng.random() < 0.25:
+            s = seqs[rng.randrange(len(seqs))]
+        else:
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(40, 180)))
+            if rng.random() < 0.05:
+                k = rng.randrange(len(s) - 12)
+                s = s[:k] + "ACGTTGCAAGCT" + s[k + 12:]
+        seqs.append(s)
+        q = "".join(chr(rng.randint(35, 73)) for _ in s)
+        if i % 97 == 5:
+            q = "@" + q[1:]                       # a quality line that begins like a header
+        out.append("@read%d some description\n%s\n+\n%s\n" % (i, s, q))
+    return "".join(out).encode()
+
+
+def fasta(nrec, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(nrec):
+        s = "".join(rng.choice("ACGT") for _ in range(rng.randint(200, 2000)))
+        out.append(">cds%d len=%d\n" % (i, len(s)) + "".join(s[j:j + 60] + "\n" for j in range(0, len(s), 60)))
+    return "".join(out).encode()
+
+
+def read_out(path):
+    if os.path.isdir(path):
+        return b"".join(open(os.path.join(path, f), "rb").read() for f in sorted(os.listdir(path)))
+    return open(path, "rb").read()
+
+
+def run(cmd, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run(cmd, capture_output=True, cwd=ROOT, env=env, timeout=600)
+    assert p.returncode == 0, (cmd, p.stderr.decode()[-3000:])
+    return p.stdout
+
+
+CASES = [("seq", ["seq", "-r", "-p", "-t", "dna", "--quiet"], "fq"),
+         ("grep", ["grep", "-s", "-p", "ACGTTGCAAGCT"], "fq"),
+         ("subseq", ["subseq", "-r", "5:-5"], "fq"),
+         ("rmdup", ["rmdup", "-s"], "fq"),
+         ("locate", ["locate", "-p", "ACGTTGCA"], "fq"),
+         ("translate", ["translate", "-f", "6", "-x"], "fa"),
+         ("seqfa", ["seq", "-w", "70"], "fa")]
+
+
+@pytest.mark.parametrize("merge", [False, True])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_two_workers_write_what_one_device_writes(case, merge, tmp_path):
+    name, args, kind = case
+    data = fastq(30000, 11) if kind == "fq" else fasta(3000, 12)
+    src = str(tmp_path / ("in." + kind))
+    open(src, "wb").write(data)
+    one, two = str(tmp_path / "one.out"), str(tmp_path / "two.out")
+    extra = ["--merge"] if merge else []
+    run([CLI] + args + [src, "-o", one] + extra)
+    run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0,0", "--share-gpu", "--"] + args + [src, "-o", two] + extra)
+    want, got = read_out(one), read_out(two)
+    assert len(want) > 0 and got == want
+    if not merge:
+        assert sorted(os.listdir(two)) == ["part00000", "part00001"]
+    else:
+        assert os.path.isfile(two) and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+
+
+def test_stats_and_grep_count_reduce_over_the_workers(tmp_path):
+    data = fastq(30000, 13)
+    src = str(tmp_path / "in.fq")
+    open(src, "wb").write(data)
+    for args in (["stats", "-a", "-T"], ["stats"], ["grep", "-s", "-p", "ACGTTGCAAGCT", "-C"]):
+        want = run([CLI] + args + [src])
+        got = run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0,0,0", "--share-gpu", "--"] + args + [src])
+        assert got == want and len(want) > 0, (args, got, want)
+
+
+def test_the_command_line_hands_over_with_devices(tmp_path):
+    """`bigseqkit <cmd> ... --devices 0,0`: the C++ command line starts the workers itself"""
+    data = fastq(12000, 14)
+    src = str(tmp_path / "in.fq")
+    open(src, "wb").write(data)
+    one, two = str(tmp_path / "one.out"), str(tmp_path / "two.out")
+    run([CLI, "rmdup", "-s", src, "-o", one, "--merge"])
+    run([CLI, "rmdup", "-s", src, "-o", two, "--merge", "--devices", "0,0"], {"BSK_RUN_SHARE_GPU": "1"})
+    assert read_out(two) == read_out(one)
