@@ -156,10 +156,20 @@ def worker(devices, share, cli_args):
     if world > 1:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        # (the collective libraries greet on stdout -- "[Gloo] Rank 0 is connected to ..." -- and stdout is where `stats`,
+        # `grep -C` and `-o -` put their RESULT: while the group forms, file descriptor 1 is the workers' stderr)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+            bdist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     try:
         return _work(plan, use, opts, path, world, rank, device, dev, torch, bsk, _lib, bdist, lib, check)
     finally:
