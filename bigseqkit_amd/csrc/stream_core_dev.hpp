@@ -170,16 +170,19 @@ struct Piece {  // what a lane keeps of one 16-byte piece (dense path; packed fl
     uint32_t ex_hi;   // exclusive prefix: b  | c << 16
 };
 
-template <bool FASTQ, bool ALL>
+// CAPV: newline events the window holds (CAP; 256 for the sinks that take whole FASTQ records, see RECORDS4 below)
+template <bool FASTQ, bool ALL, int CAPV = CAP>
 struct Lds {
-    uint32_t pos[SLOTS];
-    uint32_t a[(ALL) ? SLOTS : 1];
-    uint32_t b[(ALL && FASTQ) ? SLOTS : 1];
-    uint32_t c[(ALL && FASTQ) ? SLOTS : 1];
-    uint8_t flag[(!FASTQ) ? SLOTS : 4];
+    static constexpr int CAPW = CAPV;
+    static constexpr int NSLOTS = HISTORY + CAPV;
+    __attribute__((aligned(16))) uint32_t pos[NSLOTS];
+    uint32_t a[(ALL) ? NSLOTS : 1];
+    uint32_t b[(ALL && FASTQ) ? NSLOTS : 1];
+    uint32_t c[(ALL && FASTQ) ? NSLOTS : 1];
+    uint8_t flag[(!FASTQ) ? NSLOTS : 4];
     // FASTQ: the byte that follows the newline when the emitting lane had it in registers
     // (0x100 | byte), 0 = unknown -> the sink probes memory (1 event in 16 on the sparse path)
-    uint16_t nc[(FASTQ) ? SLOTS : 4];
+    __attribute__((aligned(8))) uint16_t nc[(FASTQ) ? NSLOTS : 4];
     // sparse path (ALL == false): the 16-byte pieces that contain a newline, compacted in byte order
     __attribute__((aligned(16))) uint4 sdata[(ALL) ? 1 : WAVE];
     uint16_t stag[(ALL) ? 2 : WAVE];  // piece * 64 + lane of the owner
@@ -192,8 +195,8 @@ struct Lds {
 
 
 // keep the last HISTORY events of (history ++ batch) for the next batch
-template <bool FASTQ, bool ALL>
-__device__ __forceinline__ void keep_history(Lds<FASTQ, ALL>& L, uint32_t E) {
+template <bool FASTQ, bool ALL, int CV>
+__device__ __forceinline__ void keep_history(Lds<FASTQ, ALL, CV>& L, uint32_t E) {
     const int lane = threadIdx.x & 63;
     wave_lds_fence();
     uint32_t hp = 0, ha = 0, hb = 0, hc = 0;
@@ -218,8 +221,8 @@ __device__ __forceinline__ void keep_history(Lds<FASTQ, ALL>& L, uint32_t E) {
 }
 
 // the byte after newline event `s` (its absolute index is abs_next); 0 when past the range
-template <bool FASTQ, bool ALL>
-__device__ __forceinline__ uint8_t next_char(const Lds<FASTQ, ALL>& L, uint32_t s, uint64_t abs_next, uint64_t re,
+template <bool FASTQ, bool ALL, int CV>
+__device__ __forceinline__ uint8_t next_char(const Lds<FASTQ, ALL, CV>& L, uint32_t s, uint64_t abs_next, uint64_t re,
                                              const uint8_t* __restrict__ buf) {
     if (abs_next >= re) return 0;
     if constexpr (FASTQ) {
@@ -243,6 +246,37 @@ template <class S, class = void>
 struct sink_role_counts { static constexpr bool value = false; };
 template <class S>
 struct sink_role_counts<S, decltype((void)S::ROLE_COUNTS)> { static constexpr bool value = S::ROLE_COUNTS; };
+
+// A sink with `static constexpr bool RECORDS4 = true` (FASTQ, sparse path) takes WHOLE RECORDS, one lane per record:
+//     sink.records<LDS>(L, R, wb, tile_idx, tile_rel, rs, re, buf)
+// R records = events [wb, wb + 4 R) (wb % 4 == 0) in slots [HISTORY, HISTORY + 4 R): lane j reads the five line ends of record
+// j with one ds_read_b128 + one ds_read_b32 (and the three "next byte" words with one ds_read_b64) and does the work of the
+// four event lanes of batch().  The skeleton DEFERS: the events of the tiles pile up in a window of 256 and the sink runs
+// when 64 records are complete -- one sink iteration per ~5 tiles of 150-base reads with all 64 lanes busy, where batch()
+// ran once per tile with 52 event lanes of which a quarter (the record ends) did the sink's real work.  Round 4: the
+// streaming sinks were at their instruction issue time, and this is the part of it that scales with
+// events instead of bytes.  Events that do not fill a record at the end of a range (a truncated file) go through
+// batch(), whose per-event rules and error flags are the reference for both.
+template <class S, class = void>
+struct sink_records4 { static constexpr bool value = false; };
+template <class S>
+struct sink_records4<S, decltype((void)S::RECORDS4)> { static constexpr bool value = S::RECORDS4; };
+
+// the window after `done` events were consumed: slots [done, done + HISTORY + keep) move to the front (keep = events that
+// stay pending; HISTORY + keep <= 64)
+template <bool FASTQ, bool ALL, int CV>
+__device__ __forceinline__ void shift_window(Lds<FASTQ, ALL, CV>& L, uint32_t done, uint32_t keep) {
+    static_assert(FASTQ && !ALL, "deferred windows exist on the sparse FASTQ path only");
+    const uint32_t lane = threadIdx.x & 63;
+    wave_lds_fence();
+    uint32_t hp = 0;
+    uint16_t hn = 0;
+    const bool mine = lane < (uint32_t)HISTORY + keep;
+    if (mine) { hp = L.pos[done + lane]; hn = L.nc[done + lane]; }
+    wave_lds_fence();
+    if (mine) { L.pos[lane] = hp; L.nc[lane] = hn; }
+    wave_lds_fence();
+}
 
 // set 0x80 flags of four dwords counted on top of acc: a chain of four v_bcnt_u32_b32 (count + accumulator)
 // (written as instructions: the compiler turns the sum of four popcounts into three v_bcnt with a zero accumulator, one
@@ -274,12 +308,16 @@ __device__ __forceinline__ uint32_t popc4(uint32_t a, uint32_t b, uint32_t c, ui
 //   count_resume (FASTA -a, dense path): the gap letters of the 16-byte pieces in [skip_from, count_resume) are NOT counted
 //       here -- those bytes belong to nominal chunks without a line start, whose own (otherwise empty) ranges count them
 //       (k_stats) and k_stats_stitch adds them when the long line is a sequence line.
-template <bool FASTQ, bool ALL, bool DPP, class Sink>
-__device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8_t* __restrict__ buf, uint64_t n,
+template <bool FASTQ, bool ALL, bool DPP, class Sink, int CV>
+__device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const uint8_t* __restrict__ buf, uint64_t n,
                                                  uint64_t rs, uint64_t re, bool is_last, const PredConsts& P,
                                                  Sink& sink, uint64_t skip_from = ~0ull, uint64_t count_resume = 0) {
     const int lane = threadIdx.x & 63;
     constexpr bool ROLES = FASTQ && !ALL && sink_role_counts<Sink>::value;
+    constexpr bool REC4 = FASTQ && !ALL && sink_records4<Sink>::value;  // whole records, deferred (see sink_records4)
+    constexpr uint32_t CAPW = (uint32_t)CV;
+    static_assert(!REC4 || (CV % 4 == 0 && CV >= 128), "a window of whole records");
+    uint32_t pend_base = 0;  // REC4: rank of the event in slot HISTORY (a multiple of 4)
     // virtual events before the range: a newline at relative position -1
     if (lane < HISTORY) {
         L.pos[lane] = 0xFFFFFFFFu;
@@ -453,14 +491,15 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                         }
                     }
                 }
-                for (uint32_t wb = round_base; wb < line_base; wb += CAP) {
+                // this lane's newlines -> events in the window whose first slot is the event of rank `wb`
+                auto emit_events = [&](uint32_t wb) {
                     uint32_t m = nl, k = 0;
                     while (m) {
                         const uint32_t bpos = (uint32_t)__ffs((int)m) - 1u;
                         m &= m - 1u;
                         const uint32_t w = rank0 + k - wb;
                         ++k;
-                        if (w < (uint32_t)CAP) {
+                        if (w < CAPW) {
                             const uint32_t s = HISTORY + w;
                             const uint32_t off = off0 + bpos;
                             L.pos[s] = tile_rel + off;
@@ -481,10 +520,25 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                             }
                         }
                     }
-                    wave_lds_fence();
-                    const uint32_t E = (line_base - wb) < (uint32_t)CAP ? (line_base - wb) : (uint32_t)CAP;
-                    sink.template batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf);
-                    keep_history<FASTQ, ALL>(L, E);
+                };
+                if constexpr (REC4) {
+                    // deferred: the events join the window; the sink runs when it is full (64 whole records)
+                    for (;;) {
+                        emit_events(pend_base);
+                        if (line_base - pend_base <= CAPW) break;  // (wave-uniform) everything of this round is in
+                        wave_lds_fence();
+                        sink.template records<Lds<FASTQ, ALL, CV>>(L, CAPW / 4u, pend_base, tile_idx, tile_rel, rs, re, buf);
+                        shift_window(L, CAPW, 0u);
+                        pend_base += CAPW;
+                    }
+                } else {
+                    for (uint32_t wb = round_base; wb < line_base; wb += CAPW) {
+                        emit_events(wb);
+                        wave_lds_fence();
+                        const uint32_t E = (line_base - wb) < CAPW ? (line_base - wb) : CAPW;
+                        sink.template batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf);
+                        keep_history<FASTQ, ALL>(L, E);
+                    }
                 }
                 wave_lds_fence();  // the next round overwrites sdata / stag
             }
@@ -624,7 +678,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                 c_w[1] = ((pc[2].m_b_c >> 4) & LOW) | (pc[3].m_b_c & ~LOW);
             }
             const uint64_t m64 = (uint64_t)nl_w[0] | ((uint64_t)nl_w[1] << 32);
-            for (uint32_t wb = tile_rank_base; wb < line_base; wb += CAP) {
+            for (uint32_t wb = tile_rank_base; wb < line_base; wb += CAPW) {
                 uint64_t m = m64;
                 while (m) {
                     // (the newlines of a lane are visited in bit order, not byte order: every event computes its own rank)
@@ -652,7 +706,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                     }
                     const uint32_t rank = r0 + (uint32_t)__popc((h ? nl_w[1] : nl_w[0]) & below);
                     const uint32_t w = rank - wb;
-                    if (w < (uint32_t)CAP) {
+                    if (w < CAPW) {
                         const uint32_t s = HISTORY + w;
                         const uint32_t off = p * (uint32_t)PIECE_BYTES + (uint32_t)lane * 16u + bpos;
                         L.pos[s] = tile_rel + off;
@@ -669,7 +723,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
                     }
                 }
                 wave_lds_fence();
-                const uint32_t E = (line_base - wb) < (uint32_t)CAP ? (line_base - wb) : (uint32_t)CAP;
+                const uint32_t E = (line_base - wb) < CAPW ? (line_base - wb) : CAPW;
                 sink.template batch<FASTQ, ALL>(L, E, wb, tile_idx, tile_rel, re, buf);
                 keep_history<FASTQ, ALL>(L, E);
             }
@@ -708,7 +762,29 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL>& L, const uint8
     } else {
         virt = is_last && buf[re - 1] != '\n';
     }
-    if (virt) {
+    if constexpr (REC4) {
+        // what is still in the window: whole records to the sink; the events of an incomplete last record (a truncated
+        // file, a range that does not end on a record) take batch()'s per-event rules.  The virtual newline at the end of
+        // a file that stops inside its last quality line completes that record first.
+        const uint32_t vt_rel = (uint32_t)(end_tile - rs);
+        uint32_t pending = line_base - pend_base;
+        if (virt) {
+            if (pending >= CAPW) {  // (cannot be: the window is flushed when it is full, and 3 mod 4 < CAPW)
+                sink.err |= ERR_CAPACITY;
+            } else {
+                if (lane == 0) { L.pos[HISTORY + pending] = end_rel; L.nc[HISTORY + pending] = 0; }
+                pending += 1;
+                line_base += 1;
+            }
+        }
+        wave_lds_fence();
+        const uint32_t R = pending >> 2, left = pending & 3u;
+        if (R) sink.template records<Lds<FASTQ, ALL, CV>>(L, R, pend_base, end_tile, vt_rel, rs, re, buf);
+        if (left) {
+            shift_window(L, 4u * R, left);
+            sink.template batch<FASTQ, ALL>(L, left, pend_base + 4u * R, end_tile, vt_rel, re, buf);
+        }
+    } else if (virt) {
         if (lane == 0) {
             L.pos[HISTORY] = end_rel;
             if constexpr (FASTQ) L.nc[HISTORY] = 0;

@@ -36,6 +36,7 @@ using namespace stream;
 template <bool DPP>
 struct NamesSink {
     static constexpr bool TILE_HOOK = false;
+    static constexpr bool RECORDS4 = true;  // whole records, 64 at a time (records() below)
     NamesDev D;
     uint8_t* slice = nullptr;  // this range's output slice
     uint32_t cursor = 0;       // bytes written to it so far (wave-uniform)
@@ -49,8 +50,121 @@ struct NamesSink {
         nrec = 0;
     }
 
-    template <bool FASTQ, bool ALL>
-    __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
+    // olen = m + 1 bytes of a name (m from src, then '\n') to dst
+    __device__ __forceinline__ void copy_name(uint8_t* dst, const uint8_t* src, uint32_t m, uint32_t olen) {
+                    if (olen <= 16u && src + 16 <= lim) {
+            // one 16-byte load; the '\n' is put at byte m in registers (it IS byte m of the text for a whole
+            // head), then 8 / 4 / 2 / 1-byte stores of exactly olen bytes (neighbouring lanes own the rest)
+            uint32_t w[4];
+            __builtin_memcpy(w, src, 16);
+            if (D.only_id) {
+                const uint32_t sh = (m & 3u) * 8u;
+                const uint32_t d = m >> 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (d == (uint32_t)q) w[q] = (w[q] & ~(0xFFu << sh)) | (0x0Au << sh);
+            }
+            uint32_t q = 0;  // dwords consumed
+            if (olen & 16u) { __builtin_memcpy(dst, w, 16); }
+            if (olen & 8u) { __builtin_memcpy(dst, w, 8); q = 2; }
+            if (olen & 4u) {
+                const uint32_t v = q ? w[2] : w[0];
+                __builtin_memcpy(dst + 4u * q, &v, 4);
+                q += 1;
+            }
+            if (olen & 3u) {
+                const uint32_t v = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
+                uint8_t* d2 = dst + 4u * q;
+                if (olen & 2u) {
+                    const uint16_t h2 = (uint16_t)v;
+                    __builtin_memcpy(d2, &h2, 2);
+                    if (olen & 1u) d2[2] = (uint8_t)(v >> 16);
+                } else {
+                    d2[0] = (uint8_t)v;
+                }
+            }
+        } else {
+            uint32_t i = 0;
+            for (; i + 16u <= m; i += 16u) {
+                uint4 v;
+                __builtin_memcpy(&v, src + i, 16);
+                __builtin_memcpy(dst + i, &v, 16);
+            }
+            if (m & 8u) {
+                uint2 v;
+                __builtin_memcpy(&v, src + i, 8);
+                __builtin_memcpy(dst + i, &v, 8);
+                i += 8u;
+            }
+            if (m & 4u) {
+                uint32_t v;
+                __builtin_memcpy(&v, src + i, 4);
+                __builtin_memcpy(dst + i, &v, 4);
+                i += 4u;
+            }
+            if (m & 2u) {
+                uint16_t v;
+                __builtin_memcpy(&v, src + i, 2);
+                __builtin_memcpy(dst + i, &v, 2);
+                i += 2u;
+            }
+            if (m & 1u) { dst[i] = src[i]; }
+            dst[m] = (uint8_t)'\n';
+        }
+    }
+
+    // whole records, lane j = record j of the window (stream_core_dev.hpp sink_records4): the rules of batch() for the four
+    // events of the record, then ONE scan over 64 name lengths and 64 names written back to back -- where batch() ran
+    // the scan and the copy once per tile for the 13 record ends among its 52 event lanes
+    template <class LDS>
+    __device__ __forceinline__ void records(LDS& L, uint32_t R, uint32_t wb, uint64_t tile_idx, uint32_t tile_rel, uint64_t rs,
+                                            uint64_t re, const uint8_t* __restrict__ buf) {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t end_rel = (uint32_t)(re - rs);
+        auto next_of = [&](uint32_t v16, uint32_t p) -> uint32_t {
+            if (p + 1u >= end_rel) return 0u;
+            if (v16 & 0x100u) return v16 & 0xFFu;
+            return buf[rs + p + 1u];
+        };
+        for (uint32_t r0 = 0; r0 < R; r0 += WAVE) {
+            const uint32_t j = r0 + lane;
+            const bool on = j < R;
+            const uint32_t s = HISTORY + 4u * (on ? j : 0u);
+            const uint8_t* src = nullptr;
+            uint32_t m = 0, olen = 0;
+            if (on) {
+                const uint32_t p0 = L.pos[s - 1u], ph = L.pos[s], pb = L.pos[s + 1u];
+                if (next_of(L.nc[s], ph) == '+') err |= ERR_BAD_PLUS;
+                if (next_of(L.nc[s + 1u], pb) != '+') err |= ERR_BAD_PLUS;
+                const uint32_t pp = L.pos[s + 2u], pq = L.pos[s + 3u];
+                if (pq - pp != pb - ph) err |= ERR_LEN_MISMATCH;
+                if (pq + 1u < end_rel && next_of(L.nc[s + 3u], pq) != '@') err |= ERR_BAD_HEADER;
+                const uint32_t lh = ph - p0 - 1u;
+                const uint8_t* h = buf + rs + (uint64_t)(p0 + 1u) + 1u;  // the header without its marker (p0 + 1 wraps to 0 at the range start)
+                m = lh ? lh - 1u : 0u;
+                src = h;
+                if (D.only_id) {
+                    uint32_t off = 0;
+                    m = id_span_of(h, m, D.id_mode, &off, lim);
+                    src = h + off;
+                }
+                olen = m + 1u;
+            }
+            const uint32_t incl = wave_incl_scan<DPP>(olen);
+            const uint32_t tot = wave_last(incl);
+            if (olen) {
+                const uint32_t at = cursor + incl - olen;
+                if ((uint64_t)at + olen <= D.slice_cap) copy_name(slice + at, src, m, olen);
+                else err |= ERR_CAPACITY;
+            }
+            cursor += tot;
+            nrec += (uint32_t)__popcll(__ballot(olen != 0u));
+        }
+        (void)wb; (void)tile_idx; (void)tile_rel;
+    }
+
+    template <bool FASTQ, bool ALL, class LDS>
+    __device__ __forceinline__ void batch(LDS& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
         static_assert(FASTQ && !ALL, "the names sink runs on the sparse FASTQ path");
         const int lane = threadIdx.x & 63;
@@ -93,80 +207,7 @@ struct NamesSink {
                 const uint32_t at = cursor + incl - olen;
                 if ((uint64_t)at + olen <= D.slice_cap) {
                     uint8_t* dst = slice + at;
-#if BSK_NAMES_EXP == 1   // experiment: no loads
-                    { uint4 z = {at, at, at, at}; if (m >= 8) __builtin_memcpy(dst, &z, 8); dst[m] = '\n'; }
-#elif BSK_NAMES_EXP == 2  // experiment: no loads, no stores
-                    if (at == 0xFFFFFFF0u) dst[0] = 1;
-#elif BSK_NAMES_EXP == 3  // experiment: the same number of loads and stores, but bunched into every 8th tile
-                    if (((tile_idx >> 12) & 7u) == 0u) {
-                        for (int rep = 0; rep < 8; ++rep) {
-                            uint32_t w[4];
-                            __builtin_memcpy(w, src + rep, 16);
-                            __builtin_memcpy(dst + rep, w, 8);
-                            __builtin_memcpy(dst + rep + 8, &w[2], 4);
-                        }
-                    }
-#else
-                    if (olen <= 16u && src + 16 <= lim) {
-                        // one 16-byte load; the '\n' is put at byte m in registers (it IS byte m of the text for a whole
-                        // head), then 8 / 4 / 2 / 1-byte stores of exactly olen bytes (neighbouring lanes own the rest)
-                        uint32_t w[4];
-                        __builtin_memcpy(w, src, 16);
-                        if (D.only_id) {
-                            const uint32_t sh = (m & 3u) * 8u;
-                            const uint32_t d = m >> 2;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (d == (uint32_t)q) w[q] = (w[q] & ~(0xFFu << sh)) | (0x0Au << sh);
-                        }
-                        uint32_t q = 0;  // dwords consumed
-                        if (olen & 16u) { __builtin_memcpy(dst, w, 16); }
-                        if (olen & 8u) { __builtin_memcpy(dst, w, 8); q = 2; }
-                        if (olen & 4u) {
-                            const uint32_t v = q ? w[2] : w[0];
-                            __builtin_memcpy(dst + 4u * q, &v, 4);
-                            q += 1;
-                        }
-                        if (olen & 3u) {
-                            const uint32_t v = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
-                            uint8_t* d2 = dst + 4u * q;
-                            if (olen & 2u) {
-                                const uint16_t h2 = (uint16_t)v;
-                                __builtin_memcpy(d2, &h2, 2);
-                                if (olen & 1u) d2[2] = (uint8_t)(v >> 16);
-                            } else {
-                                d2[0] = (uint8_t)v;
-                            }
-                        }
-                    } else {
-                        uint32_t i = 0;
-                        for (; i + 16u <= m; i += 16u) {
-                            uint4 v;
-                            __builtin_memcpy(&v, src + i, 16);
-                            __builtin_memcpy(dst + i, &v, 16);
-                        }
-                        if (m & 8u) {
-                            uint2 v;
-                            __builtin_memcpy(&v, src + i, 8);
-                            __builtin_memcpy(dst + i, &v, 8);
-                            i += 8u;
-                        }
-                        if (m & 4u) {
-                            uint32_t v;
-                            __builtin_memcpy(&v, src + i, 4);
-                            __builtin_memcpy(dst + i, &v, 4);
-                            i += 4u;
-                        }
-                        if (m & 2u) {
-                            uint16_t v;
-                            __builtin_memcpy(&v, src + i, 2);
-                            __builtin_memcpy(dst + i, &v, 2);
-                            i += 2u;
-                        }
-                        if (m & 1u) { dst[i] = src[i]; }
-                        dst[m] = (uint8_t)'\n';
-                    }
-#endif
+                    copy_name(dst, src, m, olen);
                 } else {
                     err |= ERR_CAPACITY;
                 }
@@ -181,10 +222,10 @@ template <bool DPP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_NAMES_WAVES, 8)))
 void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges,
              uint32_t* __restrict__ queue, NamesDev D) {
-    __shared__ Lds<true, false> s_l[WAVES_PER_BLOCK];
+    __shared__ Lds<true, false, 256> s_l[WAVES_PER_BLOCK];  // 64 whole records per sink call (NamesSink::records)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<true, false>& L = s_l[wave];
+    Lds<true, false, 256>& L = s_l[wave];
     NamesSink<DPP> sink;
     sink.D = D;
     sink.lim = buf + n;

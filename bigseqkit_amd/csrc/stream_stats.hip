@@ -84,6 +84,7 @@ template <bool ROLES>
 struct StatsSinkT {
     static constexpr bool TILE_HOOK = false;
     static constexpr bool ROLE_COUNTS = ROLES;
+    static constexpr bool RECORDS4 = true;  // FASTQ on the sparse path: whole records, 64 at a time (records() below)
     uint32_t* s_hist;
     StatsDev D;
     // per-lane accumulators, reduced once per wave at kernel end
@@ -126,8 +127,46 @@ struct StatsSinkT {
         atomicOr(&D.r_flags[range_id], f);
     }
 
-    template <bool FASTQ, bool ALL>
-    __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
+    // Stats.Call on WHOLE FASTQ records, lane j = record j of the window (stream_core_dev.hpp sink_records4): the four line
+    // ends of the record in one 16-byte LDS read, the rules of batch() below for its four events at once -- line 2 begins
+    // with '+', the bases do not, as many qualities as bases, a '@' behind the record -- and one histogram update per 64
+    // records (fixed-length reads: one LDS atomic)
+    template <class LDS>
+    __device__ __forceinline__ void records(LDS& L, uint32_t R, uint32_t wb, uint64_t tile_idx, uint32_t tile_rel, uint64_t rs,
+                                            uint64_t re, const uint8_t* __restrict__ buf) {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t end_rel = (uint32_t)(re - rs);
+        // the byte behind the newline at relative position p: 0 past the range, the byte the emitting lane kept, else memory
+        auto next_of = [&](uint32_t v16, uint32_t p) -> uint32_t {
+            if (p + 1u >= end_rel) return 0u;
+            if (v16 & 0x100u) return v16 & 0xFFu;
+            return buf[rs + p + 1u];
+        };
+        for (uint32_t r0 = 0; r0 < R; r0 += WAVE) {
+            const uint32_t j = r0 + lane;
+            const bool on = j < R;
+            const uint32_t s = HISTORY + 4u * (on ? j : 0u);
+            // ends of the header and bases lines first, of the plus and quality lines when their turn comes (the values are
+            // read where they are used: this runs in the middle of a tile with its 16 data registers live, and two more
+            // registers held across the histogram update were two spilled ones at 7 waves per SIMD)
+            const uint32_t ph = L.pos[s], pb = L.pos[s + 1u];
+            const uint32_t ls = pb - ph - 1u;
+            add_length(on, ls, s_hist, D);
+            if (on) {
+                sumlen += ls;
+                nrec += 1;
+                if (next_of(L.nc[s], ph) == '+') err |= ERR_BAD_PLUS;        // a non-empty sequence line must not start with '+'
+                if (next_of(L.nc[s + 1u], pb) != '+') err |= ERR_BAD_PLUS;
+                const uint32_t pp = L.pos[s + 2u], pq = L.pos[s + 3u];
+                if (pq - pp - 1u != ls) err |= ERR_LEN_MISMATCH;
+                if (pq + 1u < end_rel && next_of(L.nc[s + 3u], pq) != '@') err |= ERR_BAD_HEADER;
+            }
+        }
+        (void)wb; (void)tile_idx; (void)tile_rel;
+    }
+
+    template <bool FASTQ, bool ALL, class LDS>
+    __device__ __forceinline__ void batch(LDS& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
         const int lane = threadIdx.x & 63;
         for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
@@ -247,14 +286,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
     __shared__ uint32_t s_hist[LDS_HIST + 2 * BIG_SLOTS];  // dense bins, then the (length, count) cache of add_big
     constexpr bool ROLES = FASTQ && ALL && ROLES_T;
     constexpr bool SALL = ALL && !ROLES;  // what the skeleton and the events see
-    __shared__ Lds<FASTQ, SALL> s_l[WAVES_PER_BLOCK];
+    constexpr int WINDOW = (FASTQ && !SALL) ? 256 : CAP;  // FASTQ on the sparse path: 64 whole records per sink call
+    __shared__ Lds<FASTQ, SALL, WINDOW> s_l[WAVES_PER_BLOCK];
     for (int i = threadIdx.x; i < LDS_HIST + 2 * BIG_SLOTS; i += blockDim.x)
         s_hist[i] = (i >= LDS_HIST && i < LDS_HIST + BIG_SLOTS) ? BIG_EMPTY : 0u;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<FASTQ, SALL>& L = s_l[wave];
+    Lds<FASTQ, SALL, WINDOW>& L = s_l[wave];
     StatsSinkT<ROLES> sink;
     sink.s_hist = s_hist;
     sink.D = D;
