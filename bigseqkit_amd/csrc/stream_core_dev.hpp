@@ -41,6 +41,8 @@ constexpr int NPIECE = BSK_NPIECE;        // 16-byte pieces per lane per tile
 constexpr int PIECE_BYTES = WAVE * 16;    // 1 KiB per wave-piece
 constexpr int TILE = PIECE_BYTES * NPIECE;  // 4 KiB per wave-tile
 constexpr int CAP = 128;                  // newline events per LDS batch
+constexpr int REC_WINDOW = 512;           // ... of the sinks that take whole FASTQ records (sink_records4): the window holds the
+                                          // events of several tiles; the sink runs at the END of a tile once 256 are pending
 constexpr int HISTORY = 4;                // events kept from the previous batch
 constexpr int SLOTS = HISTORY + CAP;
 constexpr int LDS_HIST = 2048;
@@ -262,6 +264,16 @@ struct sink_records4 { static constexpr bool value = false; };
 template <class S>
 struct sink_records4<S, decltype((void)S::RECORDS4)> { static constexpr bool value = S::RECORDS4; };
 
+// WHEN the deferred sink runs.  REC_TILE_END = true (default): at the end of a tile once the window is half full -- the 16
+// data registers of the tile are dead there, which is what lets k_index / k_names keep 72 registers without a spill.
+// false: inside the rounds, when the window is full (64 records of a 256 window) -- what k_stats' default row needs: it
+// has LDS for 7 blocks per CU only with the small window, and the compiler fits THAT shape into its 72 registers
+// (the tile-end shape: 82, nine of them spilled).  The register allocator decides; tests/test_kernel_resources_cpu.py holds it.
+template <class S, class = void>
+struct sink_rec_tile_end { static constexpr bool value = true; };
+template <class S>
+struct sink_rec_tile_end<S, decltype((void)S::REC_TILE_END)> { static constexpr bool value = S::REC_TILE_END; };
+
 // the window after `done` events were consumed: slots [done, done + HISTORY + keep) move to the front (keep = events that
 // stay pending; HISTORY + keep <= 64)
 template <bool FASTQ, bool ALL, int CV>
@@ -315,8 +327,9 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
     const int lane = threadIdx.x & 63;
     constexpr bool ROLES = FASTQ && !ALL && sink_role_counts<Sink>::value;
     constexpr bool REC4 = FASTQ && !ALL && sink_records4<Sink>::value;  // whole records, deferred (see sink_records4)
+    constexpr bool REC_TE = REC4 && sink_rec_tile_end<Sink>::value;     // ... at the end of a tile / when the window is full
     constexpr uint32_t CAPW = (uint32_t)CV;
-    static_assert(!REC4 || (CV % 4 == 0 && CV >= 128), "a window of whole records");
+    static_assert(!REC4 || (CV % 4 == 0 && CV >= 256), "a window of whole records with room for a tile behind the ones that wait");
     uint32_t pend_base = 0;  // REC4: rank of the event in slot HISTORY (a multiple of 4)
     // virtual events before the range: a newline at relative position -1
     if (lane < HISTORY) {
@@ -522,12 +535,15 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                     }
                 };
                 if constexpr (REC4) {
-                    // deferred: the events join the window; the sink runs when it is full (64 whole records)
+                    // deferred: the events join the window and wait for the end of a tile (below), which leaves room for
+                    // CAPW - 256 more.  A tile with more newlines than that (lines of a few bytes) sends the full window
+                    // through the per-event rules right here -- a whole number of records, so the window keeps beginning on one.
                     for (;;) {
                         emit_events(pend_base);
                         if (line_base - pend_base <= CAPW) break;  // (wave-uniform) everything of this round is in
                         wave_lds_fence();
-                        sink.template records<Lds<FASTQ, ALL, CV>>(L, CAPW / 4u, pend_base, tile_idx, tile_rel, rs, re, buf);
+                        if constexpr (REC_TE) sink.template batch<FASTQ, ALL>(L, CAPW, pend_base, tile_idx, tile_rel, re, buf);
+                        else sink.template records<Lds<FASTQ, ALL, CV>>(L, CAPW / 4u, pend_base, tile_idx, tile_rel, rs, re, buf);
                         shift_window(L, CAPW, 0u);
                         pend_base += CAPW;
                     }
@@ -585,6 +601,29 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                 if (++quiet_tiles >= (1u << 31) / TILE) sink.err |= ERR_LINE_TOO_LONG;
             } else {
                 quiet_tiles = 0;
+            }
+            if constexpr (REC_TE) {
+                // the whole records of the window, at the END of a tile: its 16 data registers are dead here (inside the
+                // rounds the same call cost k_stats two spilled registers at 7 waves per SIMD).  Run once 256 events are
+                // pending -- 64 .. 128 records per call, every fifth tile of 150-base reads -- and at the end of the range,
+                // where the virtual newline of a file that stops inside its last quality line completes that record first.
+                const bool last_tile = t + 1 == ntiles;
+                uint32_t pending = line_base - pend_base;
+                if (last_tile && is_last && (line_base & 3u) == 3u && pending < CAPW) {
+                    if (lane == 0) { L.pos[HISTORY + pending] = (uint32_t)(re - rs); L.nc[HISTORY + pending] = 0; }
+                    pending += 1;
+                    line_base += 1;
+                }
+                // (a window of 512: 256 wait, 256 are room for the next tile; a smaller window -- k_stats at 7 waves per SIMD has
+                // LDS for 320 -- keeps room for 128)
+                constexpr uint32_t FLUSH_AT = CV >= 512 ? 256u : (uint32_t)CV - 128u;
+                if (pending >= FLUSH_AT || last_tile) {  // (wave-uniform)
+                    const uint32_t R = pending >> 2;
+                    wave_lds_fence();
+                    if (R) sink.template records<Lds<FASTQ, ALL, CV>>(L, R, pend_base, tile_idx, tile_rel, rs, re, buf);
+                    shift_window(L, 4u * R, pending & 3u);
+                    pend_base += 4u * R;
+                }
             }
         } else {
             Piece pc[NPIECE];
@@ -763,27 +802,30 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
         virt = is_last && buf[re - 1] != '\n';
     }
     if constexpr (REC4) {
-        // what is still in the window: whole records to the sink; the events of an incomplete last record (a truncated
-        // file, a range that does not end on a record) take batch()'s per-event rules.  The virtual newline at the end of
-        // a file that stops inside its last quality line completes that record first.
-        const uint32_t vt_rel = (uint32_t)(end_tile - rs);
-        uint32_t pending = line_base - pend_base;
-        if (virt) {
-            if (pending >= CAPW) {  // (cannot be: the window is flushed when it is full, and 3 mod 4 < CAPW)
-                sink.err |= ERR_CAPACITY;
-            } else {
+        if constexpr (!REC_TE) {
+            // (sinks that run when their window is full) what is still in the window: the virtual newline of a file that
+            // stops inside its last quality line completes that record, then the whole records go to the sink
+            uint32_t pending = line_base - pend_base;
+            if (virt && pending < CAPW) {
                 if (lane == 0) { L.pos[HISTORY + pending] = end_rel; L.nc[HISTORY + pending] = 0; }
                 pending += 1;
                 line_base += 1;
             }
+            wave_lds_fence();
+            const uint32_t R = pending >> 2;
+            if (R) sink.template records<Lds<FASTQ, ALL, CV>>(L, R, pend_base, end_tile, (uint32_t)(end_tile - rs), rs, re, buf);
+            shift_window(L, 4u * R, pending & 3u);
+            pend_base += 4u * R;
         }
-        wave_lds_fence();
-        const uint32_t R = pending >> 2, left = pending & 3u;
-        if (R) sink.template records<Lds<FASTQ, ALL, CV>>(L, R, pend_base, end_tile, vt_rel, rs, re, buf);
+        // the whole records have gone to the sink (tile-end sinks: at the end of the last tile, virtual newline included);
+        // what is left are the events of an incomplete last record -- a truncated file, a range that does not end on a
+        // record: batch()'s per-event rules and error flags
+        const uint32_t left = line_base - pend_base;
         if (left) {
-            shift_window(L, 4u * R, left);
-            sink.template batch<FASTQ, ALL>(L, left, pend_base + 4u * R, end_tile, vt_rel, re, buf);
+            wave_lds_fence();
+            sink.template batch<FASTQ, ALL>(L, left, pend_base, end_tile, (uint32_t)(end_tile - rs), re, buf);
         }
+        (void)virt; (void)end_rel;
     } else if (virt) {
         if (lane == 0) {
             L.pos[HISTORY] = end_rel;

@@ -22,6 +22,7 @@ using namespace stream;
 
 struct IndexSink {
     static constexpr bool TILE_HOOK = false;
+    static constexpr bool RECORDS4 = true;  // FASTQ: whole records, 64 at a time (records() below)
     IndexDev D;
     uint64_t base = 0;   // global index of the first record of the range (wave-uniform)
     uint64_t limit = 0;  // first index this range must not write (table capacity or end of its sparse slice)
@@ -96,8 +97,52 @@ struct IndexSink {
         atomicOr(&Q.flags, f);
     }
 
-    template <bool FASTQ, bool ALL>
-    __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
+    // FASTQ, whole records: lane j = record j of the window (stream_core_dev.hpp sink_records4) -- the rules of batch() for
+    // its four events, then the table row; 64 consecutive rows per store instruction (batch() wrote the 13 of a tile)
+    template <class LDS>
+    __device__ __forceinline__ void records(LDS& L, uint32_t R, uint32_t wb, uint64_t tile_idx, uint32_t tile_rel, uint64_t rs,
+                                            uint64_t re, const uint8_t* __restrict__ buf) {
+        if (!D.write) return;  // count pass of the exact fallback: the number of lines is all it wants
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t end_rel = (uint32_t)(re - rs);
+        auto next_of = [&](uint32_t v16, uint32_t p) -> uint32_t {
+            if (p + 1u >= end_rel) return 0u;
+            if (v16 & 0x100u) return v16 & 0xFFu;
+            return buf[rs + p + 1u];
+        };
+        // the rows of this call begin at a wave-uniform place: scalar bases + a small lane index (no 64-bit row number per lane)
+        const uint64_t g0 = base + (wb >> 2);
+        const uint64_t room64 = limit > g0 ? limit - g0 : 0ull;
+        const uint32_t room = room64 > 0xFFFFull ? 0xFFFFu : (uint32_t)room64;
+        uint64_t* const t_start = D.t.start + g0;
+        uint32_t* const t_lhead = D.t.l_head + g0;
+        uint32_t* const t_lseq = D.t.l_seq + g0;
+        uint32_t* const t_aux = D.t.aux + g0;
+        for (uint32_t r0 = 0; r0 < R; r0 += WAVE) {
+            const uint32_t j = (r0 + lane) & 0xFFFFu;  // (R <= window / 4)
+            if (j >= R) continue;
+            const uint32_t s = HISTORY + 4u * j;
+            const uint32_t p0 = L.pos[s - 1u], ph = L.pos[s], pb = L.pos[s + 1u];
+            if (next_of(L.nc[s], ph) == '+') err |= ERR_BAD_PLUS;
+            if (next_of(L.nc[s + 1u], pb) != '+') err |= ERR_BAD_PLUS;
+            const uint32_t pp = L.pos[s + 2u], pq = L.pos[s + 3u];
+            const uint32_t ls = pb - ph - 1u;
+            if (pq - pp - 1u != ls) err |= ERR_LEN_MISMATCH;
+            if (pq + 1u < end_rel && next_of(L.nc[s + 3u], pq) != '@') err |= ERR_BAD_HEADER;
+            if (j < room) {
+                t_start[j] = rs + (uint64_t)(p0 + 1u);   // (p0 + 1 wraps to 0 at the range start)
+                t_lhead[j] = ph - p0 - 1u;
+                t_lseq[j] = ls;
+                t_aux[j] = pp - pb - 1u;
+            } else {
+                err |= ERR_CAPACITY;
+            }
+        }
+        (void)tile_idx; (void)tile_rel;
+    }
+
+    template <bool FASTQ, bool ALL, class LDS>
+    __device__ __forceinline__ void batch(LDS& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
         const int lane = threadIdx.x & 63;
         for (uint32_t e0 = 0; e0 < E; e0 += WAVE) {
@@ -275,10 +320,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
                                                                    IndexDev D, uint64_t chunk) {
-    __shared__ Lds<FASTQ, false> s_l[WAVES_PER_BLOCK];
+    constexpr int WINDOW = FASTQ ? REC_WINDOW : CAP;  // FASTQ: 64 whole records per sink call (IndexSink::records)
+    __shared__ Lds<FASTQ, false, WINDOW> s_l[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<FASTQ, false>& L = s_l[wave];
+    Lds<FASTQ, false, WINDOW>& L = s_l[wave];
     IndexSink sink;
     sink.D = D;
     PredConsts P;  // unused (ALL == false)

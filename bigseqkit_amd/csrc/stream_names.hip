@@ -222,10 +222,10 @@ template <bool DPP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_NAMES_WAVES, 8)))
 void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges,
              uint32_t* __restrict__ queue, NamesDev D) {
-    __shared__ Lds<true, false, 256> s_l[WAVES_PER_BLOCK];  // 64 whole records per sink call (NamesSink::records)
+    __shared__ Lds<true, false, REC_WINDOW> s_l[WAVES_PER_BLOCK];  // 64 whole records per sink call (NamesSink::records)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<true, false, 256>& L = s_l[wave];
+    Lds<true, false, REC_WINDOW>& L = s_l[wave];
     NamesSink<DPP> sink;
     sink.D = D;
     sink.lim = buf + n;
