@@ -542,7 +542,9 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                         emit_events(pend_base);
                         if (line_base - pend_base <= CAPW) break;  // (wave-uniform) everything of this round is in
                         wave_lds_fence();
-                        if constexpr (REC_TE) sink.template batch<FASTQ, ALL>(L, CAPW, pend_base, tile_idx, tile_rel, re, buf);
+                        // (batch() takes positions relative to the tile it is handed and expects none before it: the window
+                        // holds events of earlier tiles, so it is handed the range itself -- tile (rs, 0))
+                        if constexpr (REC_TE) sink.template batch<FASTQ, ALL>(L, CAPW, pend_base, rs, 0u, re, buf);
                         else sink.template records<Lds<FASTQ, ALL, CV>>(L, CAPW / 4u, pend_base, tile_idx, tile_rel, rs, re, buf);
                         shift_window(L, CAPW, 0u);
                         pend_base += CAPW;
@@ -823,9 +825,9 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
         const uint32_t left = line_base - pend_base;
         if (left) {
             wave_lds_fence();
-            sink.template batch<FASTQ, ALL>(L, left, pend_base, end_tile, (uint32_t)(end_tile - rs), re, buf);
+            sink.template batch<FASTQ, ALL>(L, left, pend_base, rs, 0u, re, buf);  // (events of earlier tiles: tile (rs, 0))
         }
-        (void)virt; (void)end_rel;
+        (void)virt; (void)end_rel; (void)end_tile;
     } else if (virt) {
         if (lane == 0) {
             L.pos[HISTORY] = end_rel;

@@ -85,7 +85,9 @@ struct StatsSinkT {
     static constexpr bool TILE_HOOK = false;
     static constexpr bool ROLE_COUNTS = ROLES;
     static constexpr bool RECORDS4 = true;  // FASTQ on the sparse path: whole records, 64 at a time (records() below)
-    static constexpr bool REC_TILE_END = ROLES;  // the default row: when its window of 256 is full (stream_core_dev.hpp)
+    // both rows run their sink when the window of 256 is full (stream_core_dev.hpp): the default row has LDS and registers
+    // for nothing else at 7 waves per SIMD, and `-a` measured 21.0 ms that way against 22.6 at the end of tiles with 512
+    static constexpr bool REC_TILE_END = false;
     uint32_t* s_hist;
     StatsDev D;
     // per-lane accumulators, reduced once per wave at kernel end
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
     // FASTQ on the sparse path: whole records, deferred.  The default row runs at 7 waves per SIMD = 7 blocks per CU: 22.8 KB
     // of LDS each, of which the length histogram takes 8.7 -- a window of 256 events fits, 512 would cost two waves per SIMD
     // (measured before: 7 waves against 6 is 3 % of the kernel); `-a` by line roles runs at 5 waves and takes the full window
-    constexpr int WINDOW = (FASTQ && !SALL) ? (ROLES ? REC_WINDOW : 256) : CAP;
+    constexpr int WINDOW = (FASTQ && !SALL) ? 256 : CAP;
     __shared__ Lds<FASTQ, SALL, WINDOW> s_l[WAVES_PER_BLOCK];
     for (int i = threadIdx.x; i < LDS_HIST + 2 * BIG_SLOTS; i += blockDim.x)
         s_hist[i] = (i >= LDS_HIST && i < LDS_HIST + BIG_SLOTS) ? BIG_EMPTY : 0u;
