@@ -44,8 +44,12 @@ def _import_torch_first():
     instead of 0.8 s -- with the runtime already initialised, libtorch_hip.so registers ALL its code objects eagerly while it
     is loaded, which reads the whole library; on a box whose image is not in the page cache that was a wait of 9 - 13
     minutes in front of the first GPU test of a session (round 3: two of five full test runs).  Imported first, torch
-    registers lazily.  BSK_NO_TORCH_IMPORT=1 skips this (callers that never use torch)."""
-    if os.environ.get("BSK_NO_TORCH_IMPORT") == "1":
+    registers lazily.
+    Round 4: importing bigseqkit_amd no longer imports torch by itself -- 0.8 s and torch's memory are a heavy
+    hidden side effect for a caller that never uses it.  The rule is the caller's: `import torch` BEFORE `import bigseqkit_amd`
+    (tests/conftest.py, bench.py, bigseqkit_amd/run.py do), or set BSK_TORCH_FIRST=1 to have it done here."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("BSK_TORCH_FIRST") != "1":
         return
     try:
         import torch  # noqa: F401

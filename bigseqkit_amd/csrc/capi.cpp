@@ -419,8 +419,12 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
         size_t want = (size_t)std::max<int64_t>(thr, 10000) * 2 + 65536;
         want = std::min(want, n);
         c->first_bytes.resize(want);
-        if (on_device) HIP_TRY(c, hipMemcpy(c->first_bytes.data(), shard, want, hipMemcpyDeviceToHost));
-        else memcpy(c->first_bytes.data(), shard, want);
+        // (on the caller's stream: a shard filled asynchronously on a non-blocking stream is not read before it is written
+        // -- ADVICE r03; a copy on the null stream does not wait for such a stream)
+        if (on_device) {
+            HIP_TRY(c, hipMemcpyAsync(c->first_bytes.data(), shard, want, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        } else memcpy(c->first_bytes.data(), shard, want);
         c->first_pid = pid;
         c->first_format = format;
         c->fastq_multiline = format == BSK_FORMAT_FASTQ && fastq_head_multiline(c->first_bytes.data(), c->first_bytes.size());
@@ -429,11 +433,15 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     // shard behind a 4-line one was an error at collect time); the first shard's head is at hand already
     bool wrapped = c->fastq_multiline && pid == c->first_pid;
     if (format == BSK_FORMAT_FASTQ && pid != c->first_pid) {
-        const size_t hb = std::min<size_t>(n, 256 * 1024);
-        std::vector<uint8_t> head(hb);
-        if (on_device) HIP_TRY(c, hipMemcpy(head.data(), shard, hb, hipMemcpyDeviceToHost));
-        else memcpy(head.data(), shard, hb);
-        wrapped = fastq_head_multiline(head.data(), hb);
+        // the head of THIS shard: the context's pinned sample, on the caller's stream (one copy of 256 KiB + one
+        // synchronisation per shard that is not the first; round 3 copied on the null stream into pageable memory)
+        if (on_device) {
+            const int rch = sample_head(c, (const uint8_t*)shard, n, st);
+            if (rch != BSK_OK) return rch;
+            wrapped = fastq_head_multiline(c->h_head, c->head_len);
+        } else {
+            wrapped = fastq_head_multiline((const uint8_t*)shard, std::min<size_t>(n, 256 * 1024));
+        }
     }
     if (wrapped && format == BSK_FORMAT_FASTQ) {
         // records wrapped over several lines (helper.go:252-269): the whole shard is rewritten as 4-line FASTQ first

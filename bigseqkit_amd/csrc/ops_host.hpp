@@ -14,6 +14,8 @@ constexpr int BSK_ERR_FILTER_FALLBACK = -1000;
 // (normalize_multiline_fastq) and runs the operator on the 4-line text
 constexpr int BSK_ERR_MULTILINE_FASTQ = -1001;
 bool fastq_head_multiline(const uint8_t* h, size_t hb);
+// head / tail of the call's device shard in the context's pinned sample (c->h_head, c->head_len): one copy per call and shard
+int sample_head(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st);
 // kernel flags (stream_stats.hpp) with which the strict 4-line reader gives a FASTQ shard up: bad header 1, bad '+' line 2,
 // unmatched lengths 4, truncated 8, a range that ends inside a record 16 -- a shard wrapped further down than its head
 // raises one of them and is then read by the multi-line reader (c->last_kernel_flags)

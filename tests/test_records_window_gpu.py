@@ -77,16 +77,13 @@ def test_the_last_record_of_a_file(cut, monkeypatch):
         elif cut == "after_bases": data = body + last[:last.index(b"+")]
         elif cut == "after_header": data = body + last[:last.index(b"\n") + 1]
         else: data = body + last[:-4]
-        try:
-            want = oracle.stats_string(data, True, json.dumps({"Tabular": True, "All": True}), name="x")
-        except oracle.OracleError:
-            want = None
-        if want is None:
+        if not oracle.is_strict_4line_fastq(data):   # (a record cut short: an error, never a different answer)
             for fn in (lambda: stats_row(data, True), lambda: stats_row(data, False), lambda: run_seq(data, {"Name": True}),
                        lambda: run_seq(data, {"Reverse": True})):
-                with pytest.raises(_lib.BskError):
+                with pytest.raises(_lib.BskError) as e:
                     fn()
+                assert e.value.code in (_lib.BSK_ERR_FORMAT, _lib.BSK_ERR_UNSUPPORTED)
         else:
-            assert stats_row(data, True) == want
+            assert stats_row(data, True) == oracle.stats_string(data, True, json.dumps({"Tabular": True, "All": True}), name="x")
             for opts in ({"Name": True}, {"Reverse": True}):
                 assert run_seq(data, opts)[0] == oracle.seq(data, True, json.dumps(opts))
