@@ -432,9 +432,15 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
 #pragma unroll
                 for (int p = 0; p < NPIECE; ++p) {
                     const uint32_t sl = slot_p[p] - sbase;
+                    // the byte BEHIND the piece -- the first byte of the next lane's piece (DPP wave_shl:1, every lane takes
+                    // part) -- travels in the high byte of the tag: a newline in the last byte of a piece then knows what
+                    // follows it without a load.  Round 4: with the sinks deferred those loads (1 event in 16) came 5 tiles
+                    // late and missed the caches -- 6 GB of fetches per 100 GB, the whole distance of k_stats to a plain read.
+                    // (lane 63 has no neighbour: 1 event in 1 000 still asks memory)
+                    const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[p].x, 0x130, 0xf, 0xf, true) & 0xFFu;
                     if (flagged[p] && sl < (uint32_t)WAVE) {
                         L.sdata[sl] = cur[p];
-                        L.stag[sl] = (uint16_t)(p * WAVE + lane);
+                        L.stag[sl] = (uint16_t)((uint32_t)(p * WAVE + lane) | (nx << 8));
                     }
                 }
                 wave_lds_fence();
@@ -442,6 +448,8 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                 uint4 v = make_uint4(0, 0, 0, 0);
                 uint32_t tag = 0;
                 if (have) { v = L.sdata[lane]; tag = L.stag[lane]; }
+                const uint32_t nxb = tag >> 8;  // the byte behind the piece (valid unless lane 63 owns it)
+                tag &= 0xFFu;
                 const uint32_t off0 = (tag >> 6) * (uint32_t)PIECE_BYTES + (tag & 63u) * 16u;
                 uint32_t nl = have ? eq_mask16(v, 0x0A0A0A0Au) : 0u;
                 uint32_t vmask = have ? 0xFFFFu : 0u;  // bytes of the piece that belong to the range
@@ -522,6 +530,8 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                                 const uint32_t d = (bpos + 1u) >> 2, sh8 = ((bpos + 1u) & 3u) * 8u;
                                 const uint32_t wd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
                                 nc16 = 0x100u | ((wd >> sh8) & 0xFFu);
+                            } else if ((tag & 63u) != 63u) {
+                                nc16 = 0x100u | nxb;  // ... or is the first byte of the neighbour's piece
                             }
                             if constexpr (FASTQ) {
                                 L.nc[s] = (uint16_t)nc16;
