@@ -20,9 +20,19 @@ namespace {
 
 using namespace stream;
 
+// FASTQ: the deferred window of the whole-record sink (stream_core_dev.hpp): its size, and whether the sink runs at the end of
+// a tile (1) or when the window is full (0)
+#ifndef BSK_INDEX_WINDOW
+#define BSK_INDEX_WINDOW REC_WINDOW
+#endif
+#ifndef BSK_INDEX_TE
+#define BSK_INDEX_TE 1
+#endif
+
 struct IndexSink {
     static constexpr bool TILE_HOOK = false;
     static constexpr bool RECORDS4 = true;  // FASTQ: whole records, 64 at a time (records() below)
+    static constexpr bool REC_TILE_END = BSK_INDEX_TE != 0;
     IndexDev D;
     uint64_t base = 0;   // global index of the first record of the range (wave-uniform)
     uint64_t limit = 0;  // first index this range must not write (table capacity or end of its sparse slice)
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_INDEX_ATTR void k_index
                                                                    const uint64_t* __restrict__ anchors,
                                                                    uint32_t nranges, uint32_t* __restrict__ queue,
                                                                    IndexDev D, uint64_t chunk) {
-    constexpr int WINDOW = FASTQ ? REC_WINDOW : CAP;  // FASTQ: 64 whole records per sink call (IndexSink::records)
+    constexpr int WINDOW = FASTQ ? BSK_INDEX_WINDOW : CAP;  // FASTQ: 64 whole records per sink call (IndexSink::records)
     __shared__ Lds<FASTQ, false, WINDOW> s_l[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

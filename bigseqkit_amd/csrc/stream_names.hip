@@ -23,6 +23,13 @@
 #ifndef BSK_NAMES_EXP
 #define BSK_NAMES_EXP 0
 #endif
+#ifndef BSK_NAMES_WINDOW
+#define BSK_NAMES_WINDOW 384  // events the deferred window holds: 384 / tile end 20.25 ms, 256 / window full 20.38, 512 / tile end 22.07 at C2
+                              // (scripts/history/r04_names.sh: the later the sink runs, the colder the header lines it loads)
+#endif
+#ifndef BSK_NAMES_TE
+#define BSK_NAMES_TE 1               // the sink runs at the end of a tile (1) / when the window is full (0)
+#endif
 #ifndef BSK_NAMES_WAVES
 #define BSK_NAMES_WAVES 7
 #endif
@@ -37,6 +44,7 @@ template <bool DPP>
 struct NamesSink {
     static constexpr bool TILE_HOOK = false;
     static constexpr bool RECORDS4 = true;  // whole records, 64 at a time (records() below)
+    static constexpr bool REC_TILE_END = BSK_NAMES_TE != 0;
     NamesDev D;
     uint8_t* slice = nullptr;  // this range's output slice
     uint32_t cursor = 0;       // bytes written to it so far (wave-uniform)
@@ -222,10 +230,10 @@ template <bool DPP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_NAMES_WAVES, 8)))
 void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges,
              uint32_t* __restrict__ queue, NamesDev D) {
-    __shared__ Lds<true, false, REC_WINDOW> s_l[WAVES_PER_BLOCK];  // 64 whole records per sink call (NamesSink::records)
+    __shared__ Lds<true, false, BSK_NAMES_WINDOW> s_l[WAVES_PER_BLOCK];  // 64 whole records per sink call (NamesSink::records)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<true, false, REC_WINDOW>& L = s_l[wave];
+    Lds<true, false, BSK_NAMES_WINDOW>& L = s_l[wave];
     NamesSink<DPP> sink;
     sink.D = D;
     sink.lim = buf + n;
