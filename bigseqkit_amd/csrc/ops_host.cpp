@@ -211,11 +211,11 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     uint64_t chunk = 0;  // nominal bytes per range (prep_ranges)
     auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
         if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
-        if (hash) return launch_rmdup_stream(c->use_dpp, hash->fold, blocks, d_buf, n, anchors, nranges, queue, D, HD, st);
+        if (hash) return launch_rmdup_stream(c->use_dpp, hash->fold, hash->k2, blocks, d_buf, n, anchors, nranges, queue, D, HD, st);
         return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, fastq ? 0 : chunk);
     };
     const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp)
-                         : (hash ? rmdup_stream_max_blocks_per_cu(c->use_dpp, hash->fold) : index_max_blocks_per_cu(fastq, c->use_dpp));
+                         : (hash ? rmdup_stream_max_blocks_per_cu(c->use_dpp, hash->fold, hash->k2) : index_max_blocks_per_cu(fastq, c->use_dpp));
     const int blocks = std::max(1, c->num_cus * per_cu);
     uint32_t nranges = 0;
     int rcp = prep_ranges(c, d_buf, n, fastq, blocks, st, &nranges, &chunk);
@@ -282,7 +282,7 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
                 rc2 = grow(c, &c->d_keys_sparse, &c->keys_sparse_cap, 2 * c->sparse.cap, 16);
                 if (rc2 != BSK_OK) return rc2;
                 HD.k1 = c->d_keys_sparse;
-                HD.k2 = c->d_keys_sparse + c->sparse.cap;
+                HD.k2 = hash->k2 ? c->d_keys_sparse + c->sparse.cap : nullptr;
             }
             {
                 Timed t(c, F ? "k_filter" : (hash ? "k_rmdup_stream" : "k_index"), st);
@@ -316,11 +316,11 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
                 c->table.n = total;
                 if (total && hash) {
                     rc3 = grow(c, &c->d_keys, &c->keys_cap, total, total / 8 + 16);
-                    if (rc3 == BSK_OK) rc3 = grow(c, &c->d_keys2, &c->keys2_cap, total, total / 8 + 16);
+                    if (rc3 == BSK_OK && hash->k2) rc3 = grow(c, &c->d_keys2, &c->keys2_cap, total, total / 8 + 16);
                     if (rc3 != BSK_OK) return rc3;
                     Timed t(c, "k_rmdup_compact", st);
                     HIP_TRYX(c, launch_rmdup_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges, c->table, HD,
-                                                     HashDev{c->d_keys, c->d_keys2}, st));
+                                                     HashDev{c->d_keys, hash->k2 ? c->d_keys2 : nullptr}, st));
                 } else if (total) {
                     Timed t(c, "k_index_compact", st);
                     HIP_TRYX(c, launch_index_compact(c->sparse, sparse_cap, c->d_range_count, c->d_range_base, nranges,
@@ -354,10 +354,10 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
         if (total == 0) return BSK_OK;
         if (hash) {
             rc4 = grow(c, &c->d_keys, &c->keys_cap, total, total / 8 + 16);
-            if (rc4 == BSK_OK) rc4 = grow(c, &c->d_keys2, &c->keys2_cap, total, total / 8 + 16);
+            if (rc4 == BSK_OK && hash->k2) rc4 = grow(c, &c->d_keys2, &c->keys2_cap, total, total / 8 + 16);
             if (rc4 != BSK_OK) return rc4;
             HD.k1 = c->d_keys;
-            HD.k2 = c->d_keys2;
+            HD.k2 = hash->k2 ? c->d_keys2 : nullptr;
         }
         D.t = c->table;
         D.write = 1;

@@ -24,7 +24,7 @@ constexpr uint64_t STRICT_FASTQ_FLAGS = 1u | 2u | 4u | 8u | 16u;
 int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out);
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
 // the record table and, with hash != null (unfiltered FASTQ), the two keys of every record's sequence in c->d_keys / c->d_keys2
-struct HashReq { bool fold; };
+struct HashReq { bool fold; bool k2 = true; };  // k2 = false: k1 alone (the caller compares the bytes; c->d_keys2 is not written)
 int build_index_light(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st);  // FASTA, from the '>' bytes alone (translate)
 int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F, const HashReq* hash);
 void validate_seq_opts(bsk_ctx* c);

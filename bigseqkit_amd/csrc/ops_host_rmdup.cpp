@@ -154,18 +154,27 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         if (e && atoi(e) >= 16 && atoi(e) < 64) k1_bits = (uint32_t)atoi(e);
     }
     int rc;
+    TextTableH tt;
+    RmDupParams P;
+    uint64_t N = 0, cap = 0, total = 0, kept = 0;
+    uint64_t* tk = nullptr;
+    uint32_t* d_first = nullptr;
+    bool by_buckets = false;
+    // verify (default): k1 alone groups and the bytes decide -- the pass computes one key, nothing gathers second keys; only a
+    // shard on which the comparison finds two different sequences under one k1 goes round again with both keys
+    bool with_k2 = !verify_bytes;
+    SeqParams F;
+    for (;;) {
     if (by_keys) {
-        const HashReq hq{o.b("IgnoreCase")};
+        const HashReq hq{o.b("IgnoreCase"), with_k2};
         rc = build_index_ex(c, d_buf, n, format, st, nullptr, &hq);
     } else {
         rc = build_index(c, d_buf, n, format, st);
     }
     if (rc != BSK_OK) return rc;
     if (c->table.n == 0) return empty_result(c, out);
-    TextTableH tt;
     rc = prepare_text(c, d_buf, format, st, &tt, /*flatten=*/!fastq && o.b("BySeq"), false, n);  // (see grep: hashed and compared as linear text)
     if (rc != BSK_OK) return rc;
-    RmDupParams P;
     memset(&P, 0, sizeof P);
     P.fastq = fastq;
     P.by_seq = o.b("BySeq");
@@ -174,9 +183,9 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     P.id_mode = id_mode_of(c);
     P.line_width = fastq ? 0 : (int)o.ci("LineWidth");
     P.buf_end = d_buf + n;
-    const uint64_t N = c->table.n;
-    uint64_t cap = 0;
-    uint64_t* tk = nullptr;
+    N = c->table.n;
+    cap = 0;
+    tk = nullptr;
     rc = ensure_record_scratch(c);
     if (rc != BSK_OK) return rc;
     if (!by_keys) {
@@ -191,8 +200,8 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     }
     // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
     // overflows, or with 2^32 records) keeps the one big table in HBM
-    uint32_t* d_first = nullptr;
-    bool by_buckets = N < (1ull << 32);
+    d_first = nullptr;
+    by_buckets = N < (1ull << 32);
     {
         const char* e = c->tune.get("rmdup");
         if (e && strcmp(e, "table") == 0) by_buckets = false;
@@ -209,7 +218,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         uint32_t* d_vo = A.at<uint32_t>(o_vo);
         d_first = A.at<uint32_t>(o_first);
         uint32_t ovf_cap = 0;
-        if (by_keys) {
+        if (by_keys && with_k2) {
             const uint64_t want = std::max<uint64_t>(4096, N / 16) + 1;
             rc = grow(c, &c->d_ovf, &c->ovf_cap, want, 16);
             if (rc != BSK_OK) return rc;
@@ -223,11 +232,11 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
                 // (the record numbers travel as a counting iterator: no second iota pass, no array to read)
                 HIP_TRYX(c, launch_sort_pairs_bits_iota(A.at<uint8_t>(o_tmp), tmp_bytes, c->d_keys, d_sk, d_vo, N, 0, (int)RMDUP_BUCKET_BITS, st));
                 HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
-                                                 by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap));
+                                                 by_keys && with_k2 ? c->d_keys2 : nullptr, by_keys && with_k2 ? c->d_ovf : nullptr, ovf_cap));
             } else {  // one 16-bit histogram + scatter by hand (ops_rmdup.hip): 6.8 ms -- kept for the comparison
                 HIP_TRYX(c, launch_bucket_pass(c->d_keys, N, A.at<uint32_t>(o_hist), A.at<uint32_t>(o_bs), d_first, d_sk, d_vo, st));
                 HIP_TRYX(c, launch_bucket_dedupe(d_sk, d_vo, N, A.at<uint32_t>(o_bs), d_first, c->d_status, st,
-                                                 by_keys ? c->d_keys2 : nullptr, by_keys ? c->d_ovf : nullptr, ovf_cap, true));
+                                                 by_keys && with_k2 ? c->d_keys2 : nullptr, by_keys && with_k2 ? c->d_ovf : nullptr, ovf_cap, true));
             }
         }
         rc = ctl_readback(c, st);  // status word + the length of the overflow list: one copy
@@ -239,7 +248,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             HIP_TRYX(c, hipStreamSynchronize(st));
             by_buckets = false;
         } else if (by_keys) {
-            rc = rmdup_settle_overflow(c, d_first, st, c->h_ctl[3]);
+            rc = with_k2 ? rmdup_settle_overflow(c, d_first, st, c->h_ctl[3]) : BSK_OK;  // (k1 alone: no list, the bytes tell)
             if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;  // (the list did not fit: the table path compares bytes)
             else if (rc != BSK_OK) return rc;
             else if (verify_bytes) {
@@ -264,12 +273,23 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         HIP_TRYX(c, launch_rmdup_insert(c->d_keys, N, 0, tk, cap, st));
         HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     }
-    uint64_t total = 0, kept = 0;
+    total = kept = 0;
     rc = finish_sizes(c, st, &total, &kept);  // (ERR_HASH_COLLISION comes back as BSK_ERR_UNSUPPORTED: kernel_error_to_status)
+    if (rc == BSK_ERR_UNSUPPORTED && by_keys && by_buckets && !with_k2 && (c->last_kernel_flags & ERR_HASH_COLLISION) &&
+        !(c->last_kernel_flags & ~(uint64_t)ERR_HASH_COLLISION)) {
+        // two different sequences under one XXH64 value (about N^2 / 2^65 per shard): once more with the second key, whose
+        // overflow list settles exactly such records; the byte comparison then runs again on what the two keys grouped
+        uint64_t zero = 0;
+        HIP_TRYX(c, hipMemcpyAsync(c->d_status, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        c->set_error("");
+        with_k2 = true;
+        continue;
+    }
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    SeqParams F = format_params(c, fastq);
+    F = format_params(c, fastq);
     if (!fastq && tt.text_w == c->d_text_w) {  // back to the views for the emit (and the side files)
         rc = prepare_text(c, d_buf, format, st, &tt, false, /*keep_out_len=*/true);
         if (rc != BSK_OK) return rc;
@@ -277,6 +297,8 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
     apply_long(c, &F);
     { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }
+    break;
+    }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void k_rmdup_verify_fastq(const uint8_t* __res
         if (i < t.n) {
             const bool keep = first_of[i] == (uint32_t)i;
             const uint32_t lh = t.l_head[i];
-            out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], 1, 0) : 0u;
+            if (out_len) out_len[i] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], 1, 0) : 0u;  // (null: k_rmdup_sizes writes them, this kernel runs beside it)
             if (!keep) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)(i - base);
         }
     }

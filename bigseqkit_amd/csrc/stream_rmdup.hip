@@ -55,7 +55,9 @@ __device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
     return v + o;
 }
 
-template <bool DPP, bool FOLD>
+// K2 = false: k1 alone (rmdup's default: the bytes of every duplicate are compared afterwards, ops_host_rmdup.cpp) -- a
+// quarter of the hashing instructions and 8 bytes per record less (8.7 -> 7.5 ms per 25 GB, scripts/history/r04_rmstream.sh)
+template <bool DPP, bool FOLD, bool K2>
 struct RmdupSink {
     static constexpr bool TILE_HOOK = true;
     IndexDev D;
@@ -105,7 +107,7 @@ struct RmdupSink {
             if (st < nst) {
                 const uint64_t w = ld64(32u * st + 8u * k);
                 v = xround(v, w);
-                b = k2_step(b, w, qk);
+                if (K2) b = k2_step(b, w, qk);
             }
         }
         // merge: h = sum of the rotated accumulators, then the four xmerge steps (their xround halves in parallel)
@@ -128,7 +130,7 @@ struct RmdupSink {
         if (vq && k < nw) {
             const uint64_t w = ld64(t0 + 8u * k);
             tr = xround(0, w);
-            b = k2_step(b, w, qk);
+            if (K2) b = k2_step(b, w, qk);
         }
         const uint64_t tr0 = quad_bcast64<0>(tr), tr1 = quad_bcast64<1>(tr), tr2 = quad_bcast64<2>(tr);
         if (nw > 0u) { h ^= tr0; h = rotl64(h, 27) * P1 + P4; }
@@ -156,10 +158,10 @@ struct RmdupSink {
         if (nb > 1u) { h ^= ((tailb >> 8) & 0xFFull) * P5; h = rotl64(h, 11) * P1; }
         if (nb > 2u) { h ^= ((tailb >> 16) & 0xFFull) * P5; h = rotl64(h, 11) * P1; }
         h = xavalanche(h);
-        const uint64_t key2 = k2_finish(quad_bcast64<0>(b), quad_bcast64<1>(b), quad_bcast64<2>(b), quad_bcast64<3>(b), rest, ln);
+        const uint64_t key2 = !K2 ? 0ull : k2_finish(quad_bcast64<0>(b), quad_bcast64<1>(b), quad_bcast64<2>(b), quad_bcast64<3>(b), rest, ln);
         if (vq && k == 0u && g < limit) {
             H.k1[g] = h;
-            H.k2[g] = key2;
+            if (K2) H.k2[g] = key2;
         }
     }
 
@@ -219,25 +221,21 @@ struct RmdupSink {
 };
 
 #ifndef BSK_RMSTREAM_WAVES
-#define BSK_RMSTREAM_WAVES 4  // 4: 96 -> 128 VGPRs, no spills: 9.0 ms per 25 GB against 9.7 at 5 (scripts/r03_var.sh); the pass is bound by its instructions
+#define BSK_RMSTREAM_WAVES 4  // both keys: 96 -> 128 VGPRs, no spills: 9.0 ms per 25 GB against 9.7 at 5 (scripts/r03_var.sh); the pass is bound by its instructions
 #endif
-#if BSK_RMSTREAM_WAVES
-#define BSK_RMSTREAM_ATTR __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES, 8)))
-#else
-#define BSK_RMSTREAM_ATTR
+#ifndef BSK_RMSTREAM_WAVES_K1
+#define BSK_RMSTREAM_WAVES_K1 5  // k1 alone: 98 VGPRs wanted, 5 waves per SIMD fit without spills: 7.5 ms against 8.0 at 4
 #endif
 
-template <bool DPP, bool FOLD>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_RMSTREAM_ATTR void k_rmdup_stream(const uint8_t* __restrict__ buf, uint64_t n,
-                                                                             const uint64_t* __restrict__ anchors,
-                                                                             uint32_t nranges, uint32_t* __restrict__ queue,
-                                                                             IndexDev D, HashDev H) {
+template <bool DPP, bool FOLD, bool K2>
+__device__ __forceinline__ void rmdup_stream_body(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors,
+                                                  uint32_t nranges, uint32_t* __restrict__ queue, const IndexDev& D, const HashDev& H) {
     __shared__ Lds<true, false> s_l[WAVES_PER_BLOCK];
     __shared__ __attribute__((aligned(16))) uint8_t s_tb[WAVES_PER_BLOCK][TBUF];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     Lds<true, false>& L = s_l[wave];
-    RmdupSink<DPP, FOLD> sink;
+    RmdupSink<DPP, FOLD, K2> sink;
     sink.D = D;
     sink.H = H;
     sink.T.tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_tb[wave];
@@ -268,6 +266,19 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_RMSTREAM_ATTR void k_rm
     if (lane == 0 && err) atomicOr((unsigned long long*)&D.status[0], (unsigned long long)err);
 }
 
+template <bool DPP, bool FOLD>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES, 8))) void k_rmdup_stream(
+    const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges, uint32_t* __restrict__ queue,
+    IndexDev D, HashDev H) {
+    rmdup_stream_body<DPP, FOLD, true>(buf, n, anchors, nranges, queue, D, H);
+}
+template <bool DPP, bool FOLD>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES_K1, 8))) void k_rmdup_stream_k1(
+    const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges, uint32_t* __restrict__ queue,
+    IndexDev D, HashDev H) {
+    rmdup_stream_body<DPP, FOLD, false>(buf, n, anchors, nranges, queue, D, H);
+}
+
 // one block per range: its slice of the sparse table and of the sparse keys to their dense positions
 __global__ __launch_bounds__(256) void k_rmdup_compact(RecordTable sp, uint64_t sparse_cap, const uint64_t* __restrict__ range_count,
                                                        const uint64_t* __restrict__ range_base, RecordTable dn, HashDev hs, HashDev hd) {
@@ -279,33 +290,29 @@ __global__ __launch_bounds__(256) void k_rmdup_compact(RecordTable sp, uint64_t 
         dn.l_seq[dst + i] = sp.l_seq[src + i];
         dn.aux[dst + i] = sp.aux[src + i];
         hd.k1[dst + i] = hs.k1[src + i];
-        hd.k2[dst + i] = hs.k2[src + i];
+        if (hs.k2) hd.k2[dst + i] = hs.k2[src + i];
     }
 }
 
 template <bool DPP, bool FOLD>
-const void* kernel_ptr() { return (const void*)k_rmdup_stream<DPP, FOLD>; }
+const void* kernel_ptr(bool k2) { return k2 ? (const void*)k_rmdup_stream<DPP, FOLD> : (const void*)k_rmdup_stream_k1<DPP, FOLD>; }
+const void* kernel_of(bool dpp, bool fold, bool k2) {
+    return dpp ? (fold ? kernel_ptr<true, true>(k2) : kernel_ptr<true, false>(k2)) : (fold ? kernel_ptr<false, true>(k2) : kernel_ptr<false, false>(k2));
+}
 
 }  // namespace
 
-hipError_t launch_rmdup_stream(bool dpp, bool fold, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
+hipError_t launch_rmdup_stream(bool dpp, bool fold, bool k2, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
                                uint32_t nranges, uint32_t* queue, const IndexDev& D, const HashDev& H, hipStream_t st) {
-    const dim3 b(WAVES_PER_BLOCK * WAVE), g(blocks);
-    if (dpp) {
-        if (fold) hipLaunchKernelGGL((k_rmdup_stream<true, true>), g, b, 0, st, buf, n, anchors, nranges, queue, D, H);
-        else hipLaunchKernelGGL((k_rmdup_stream<true, false>), g, b, 0, st, buf, n, anchors, nranges, queue, D, H);
-    } else {
-        if (fold) hipLaunchKernelGGL((k_rmdup_stream<false, true>), g, b, 0, st, buf, n, anchors, nranges, queue, D, H);
-        else hipLaunchKernelGGL((k_rmdup_stream<false, false>), g, b, 0, st, buf, n, anchors, nranges, queue, D, H);
-    }
-    return hipGetLastError();
+    IndexDev d = D;
+    HashDev h = H;
+    void* args[] = {(void*)&buf, (void*)&n, (void*)&anchors, (void*)&nranges, (void*)&queue, (void*)&d, (void*)&h};
+    return hipLaunchKernel(kernel_of(dpp, fold, k2), dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), args, 0, st);
 }
 
-int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold) {
+int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold, bool k2) {
     int nb = 0;
-    const void* f = dpp ? (fold ? kernel_ptr<true, true>() : kernel_ptr<true, false>())
-                        : (fold ? kernel_ptr<false, true>() : kernel_ptr<false, false>());
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel_of(dpp, fold, k2), WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 

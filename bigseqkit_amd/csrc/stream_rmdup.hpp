@@ -14,9 +14,9 @@ struct HashDev {
     uint64_t* k2;  // the second key
 };
 
-hipError_t launch_rmdup_stream(bool dpp, bool fold, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
+hipError_t launch_rmdup_stream(bool dpp, bool fold, bool k2, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
                                uint32_t nranges, uint32_t* queue, const IndexDev& D, const HashDev& H, hipStream_t st);
-int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold);
+int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold, bool k2);
 // gather the per-range slices of the sparse table and of the sparse keys into the dense arrays (k_index_compact + keys)
 hipError_t launch_rmdup_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
                                 const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, const HashDev& hs,

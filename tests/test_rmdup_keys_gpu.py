@@ -144,6 +144,37 @@ def test_distinct_sequences_under_one_key_are_kept_apart(bits, fold, monkeypatch
     assert run_rmdup(data, opts) == want
     monkeypatch.setenv("BSK_RMDUP_KEYS", "verify")  # ... and the byte comparison of every duplicate agrees
     assert run_rmdup(data, opts) == want
+    monkeypatch.setenv("BSK_RMDUP_KEYS", "two-key")  # ... round 3's default: the two keys alone
+    assert run_rmdup(data, opts) == want
+
+
+def test_verify_mode_takes_one_key_and_goes_round_again_on_a_collision():
+    """The default groups by k1 ALONE and compares the bytes; a shard on which the comparison meets two different sequences
+    under one k1 (forced here with 16 bits of k1) runs once more with both keys and the overflow list -- seen in the
+    context's profile as a second streaming pass -- and still gives the oracle's output."""
+    import torch
+    rng = random.Random(77)
+    uniq = [rand_seq(rng, 150, b"ACGT") for _ in range(2500)]
+    seqs = uniq + [rng.choice(uniq) for _ in range(900)]
+    rng.shuffle(seqs)
+    data = fastq_of(seqs, rng)
+    want = oracle.rmdup(data, True, json.dumps({"BySeq": True}))
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    for bits, passes in ((None, 1), (b"16", 2)):
+        with bsk.Operator("RmDup", json.dumps({"BySeq": True}), 0) as op:
+            if bits:
+                check(lib.bsk_ctx_set(op.ctx, b"rmdup_k1_bits", bits), op.ctx)
+            out = _lib.Out()
+            lib.bsk_profile_reset(op.ctx)
+            lib.bsk_profile_enable(op.ctx, 1)
+            check(lib.bsk_rmdup_run(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out)), op.ctx)
+            buf = C.create_string_buffer(max(1, out.len))
+            check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+            pb = C.create_string_buffer(4096)
+            check(lib.bsk_profile_dump(op.ctx, pb, len(pb)), op.ctx)
+            assert buf.raw[:out.len] == want
+            prof = dict(kv.split("=") for kv in pb.value.decode().split(";") if kv)  # name=ms/launches;
+            assert int(prof["k_rmdup_stream"].split("/")[1]) == passes, prof
 
 
 @pytest.mark.parametrize("keys", ["", "off"])
