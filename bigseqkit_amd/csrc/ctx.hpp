@@ -222,6 +222,7 @@ struct bsk_ctx {
     uint64_t regex_cap = 0;
     // locate -r with matches of variable length: programs of the position-reporting matcher (regex_vm.hpp)
     bool locate_vm = false;
+    bool grep_vm = false;    // grep -r: an expression the bit-parallel automaton does not take (\b, > 64 positions): all go to the thread-list matcher (vm_progs)
     std::vector<bsk::VmProgram> vm_progs;
     bsk::VmProgram* d_vm_progs = nullptr;
     uint64_t vm_progs_cap = 0;

@@ -21,6 +21,7 @@
 #include "ops_translate.hpp"  // TextTableH
 #include "pattern_match_dev.hpp"
 #include "regex_nfa.hpp"
+#include "regex_vm.hpp"
 
 namespace bsk {
 
@@ -559,6 +560,44 @@ __global__ __launch_bounds__(256) void k_grep_regex(const uint8_t* __restrict__ 
     out_len[i] = sel ? format_len(hl, t.l_seq[i], P.fastq, P.line_width) : 0u;
 }
 
+// -r through the thread-list matcher (regex_vm.hpp): the expressions the bit-parallel automaton does not take -- word
+// boundaries, more than 64 positions.  One lane per record, thread lists in private memory: a rare path, not a fast one;
+// the same targets, strands, region and circular doubling as k_grep_regex.
+__global__ __launch_bounds__(64) void k_grep_vm(const uint8_t* __restrict__ buf, RecordTable t, TextTable tt, GrepParams P,
+                                                uint32_t* __restrict__ out_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const uint32_t lh = t.l_head[i];
+    const uint8_t* h = buf + t.start[i] + 1;
+    const uint32_t hl = lh > 0 ? lh - 1 : 0;
+    bool hit = false;
+    uint32_t caps[4];
+    if (P.by_seq) {
+        const Text T = text_of(buf, t, tt, i);
+        const uint32_t L = T.L;
+        const int nstr = P.strand_only == 1 ? 1 : (P.both_strands ? 2 : 1);
+        const int str0 = P.strand_only == 2 ? 1 : 0;
+        for (int strand = str0; strand < nstr && !hit; ++strand) {
+            uint32_t wb = 0, we = L;
+            if (P.region_on) sub_location(L, P.region_start, P.region_end, &wb, &we);
+            const uint32_t wl = we - wb;
+            const uint64_t tl64 = P.circular ? 2ull * wl : wl;
+            const uint32_t tl = tl64 > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)tl64;
+            auto at = [&](uint32_t x) -> uint8_t {
+                const uint32_t j = (x >= wl ? x - wl : x) + wb;
+                return strand == 0 ? T.at(j) : P.comp[T.at(L - 1u - j)];
+            };
+            for (int k = 0; k < P.npat && !hit; ++k) hit = vm_search_fn(P.vm[k], at, tl, 0u, caps);
+        }
+    } else {
+        uint32_t off = 0, tl = hl;
+        if (!P.by_name) tl = id_span_rec(t, i, h, hl, P.id_mode, &off, P.buf_end);
+        for (int k = 0; k < P.npat && !hit; ++k) hit = vm_search(P.vm[k], h + off, tl, 0u, caps);
+    }
+    const bool sel = P.invert ? !hit : hit;
+    out_len[i] = sel ? format_len(hl, t.l_seq[i], P.fastq, P.line_width) : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_grep_name(const uint8_t* __restrict__ buf, RecordTable t, GrepParams P,
                                                    uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -611,7 +650,10 @@ hipError_t launch_grep_match(const uint8_t* buf, uint64_t buf_n, const RecordTab
     if (t.n == 0) return hipSuccess;
     GrepParams P = Pin;
     P.buf_end = buf + buf_n;
-    if (P.regex) {
+    if (P.vm) {
+        TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
+        hipLaunchKernelGGL(k_grep_vm, dim3((unsigned)((t.n + 63) / 64)), dim3(64), 0, st, buf, t, d, P, out_len);
+    } else if (P.regex) {
         TextTable d{tt ? tt->text_w : nullptr, tt ? tt->lin_off : nullptr, tt ? tt->lin : nullptr, tt ? tt->lin_n : 0};
         hipLaunchKernelGGL(k_grep_regex, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, st, buf, t, d, P, out_len, buf_n);
     } else if (P.by_seq && P.general) {

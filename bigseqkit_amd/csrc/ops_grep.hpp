@@ -27,6 +27,8 @@ struct GrepParams {  // Grep options after Before() (bigseqkit-lib/grep.go:41-25
     // ID / name pattern set (many patterns, e.g. -f ids.txt): open addressing on fnv1a64, verified by bytes
     // -r: Glushkov programs (regex_nfa.hpp), `npat` of them, in device memory; comp: complement map for the '-' strand
     const struct RegexProgram* regex;
+    // -r with an expression the automaton does not take (\b, > 64 positions): thread-list programs (regex_vm.hpp) instead
+    const struct VmProgram* vm;
     const uint8_t* comp;
     // sequences of at least long_thresh bases are searched by whole blocks (k_grep_seq<.., LONG>)
     const uint32_t* long_list;  // their record indices

@@ -200,6 +200,7 @@ void validate_grep_opts(bsk_ctx* c) {
     }
     c->patterns.clear();
     c->regexes.clear();
+    c->grep_vm = false;
     c->pattern_cls.clear();
     c->max_mm = (int)o.i("MaxMismatch");
     c->general = o.b("Degenerate") || c->max_mm > 0;
@@ -218,7 +219,12 @@ void validate_grep_opts(bsk_ctx* c) {
         if (o.b("UseRegexp")) {  // grep.go:148-153, 211-225: "(?i)" + p with -i, then regexp.Compile
             if (o.b("IgnoreCase")) p = "(?i)" + p;
             if (!seen.insert(p).second) continue;
-            c->regexes.push_back(compile_regex(p));
+            try {
+                c->regexes.push_back(compile_regex(p));
+            } catch (const OptError& e) {
+                if (std::string(e.what()).rfind("libbsk:", 0) != 0) throw;  // a syntax error is one in any engine
+                c->grep_vm = true;  // \b, more than 64 positions: the thread-list matcher takes what the automaton does not
+            }
             c->patterns.push_back(p);
             continue;
         }
@@ -242,8 +248,13 @@ void validate_grep_opts(bsk_ctx* c) {
         if (c->general) c->pattern_cls.push_back(class_sets(p, false, false, o.b("IgnoreCase")));
         c->patterns.push_back(p);
     }
+    if (c->grep_vm) {  // one engine for all expressions of the call (compile_vm throws what it cannot take either)
+        c->regexes.clear();
+        c->vm_progs.clear();
+        for (auto& p : c->patterns) c->vm_progs.push_back(compile_vm(p));
+    }
     if (!o.s("PatternFile").empty()) {  // grep.go:191-197 (unless --quiet; a warning when the file held none)
-        const size_t np = o.b("UseRegexp") ? c->regexes.size() : c->patterns.size();
+        const size_t np = c->patterns.size();
         const std::string m = std::to_string(np) + " patterns loaded from file";
         if (np == 0) c->warn(m, true); else c->info(m, true);
     }
@@ -251,7 +262,7 @@ void validate_grep_opts(bsk_ctx* c) {
         // with -m the reference takes grepBySeqMismatches (grep.go:255-365), which never deletes a pattern, and the driver
         // returns its records as they are (bigseqkit/grep.go:141-143): --delete-matched is a no-op there
         if (o.b("BySeq") && c->max_mm > 0) o.mut("DeleteMatched").b = false;
-        const size_t np = o.b("UseRegexp") ? c->regexes.size() : c->patterns.size();
+        const size_t np = c->patterns.size();
         if ((o.b("BySeq") || o.b("UseRegexp")) && np > 255)  // (15 per hit-bit array, 17 arrays; round 2 stopped at 15)
             throw OptError("libbsk: --delete-matched with more than 255 sequence / regexp patterns is not provided");
     }
@@ -397,7 +408,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     // per-record kernels below run on the selected ones only.  Everything else (and any shard on which the filter gives
     // up) goes through the table of all records.
     bool filtered = false;
-    if (fastq && n > 0 && o.b("BySeq") && !c->general && c->regexes.empty() && !c->region_on && !o.b("Circular") &&
+    if (fastq && n > 0 && o.b("BySeq") && !c->general && c->regexes.empty() && !c->grep_vm && !c->region_on && !o.b("Circular") &&
         !o.b("DeleteMatched") && !c->patterns.empty()) {
         Alphabet fab = partition_alphabet(c, d_buf, n, format, st, &rc);
         if (rc != BSK_OK) return rc;
@@ -445,8 +456,14 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
         const bool flat_text = !fastq && G.by_seq;
         rc = prepare_text(c, d_buf, format, st, &tt, flat_text, false, n);
         if (rc != BSK_OK) return rc;
-        if (!c->regexes.empty()) {
-            if (!c->patterns_uploaded) {
+        if (!c->regexes.empty() || c->grep_vm) {
+            if (!c->patterns_uploaded && c->grep_vm) {
+                rc = grow(c, &c->d_vm_progs, &c->vm_progs_cap, c->vm_progs.size());
+                if (rc != BSK_OK) return rc;
+                HIP_TRYX(c, hipMemcpyAsync(c->d_vm_progs, c->vm_progs.data(), c->vm_progs.size() * sizeof(VmProgram), hipMemcpyHostToDevice, st));
+                HIP_TRYX(c, hipStreamSynchronize(st));
+                c->patterns_uploaded = true;
+            } else if (!c->patterns_uploaded) {
                 rc = grow(c, &c->d_regex, &c->regex_cap, c->regexes.size());
                 if (rc != BSK_OK) return rc;
                 HIP_TRYX(c, hipMemcpyAsync(c->d_regex, c->regexes.data(), c->regexes.size() * sizeof(RegexProgram),
@@ -459,7 +476,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             if (!c->d_lut) HIP_TRYX(c, hipMalloc((void**)&c->d_lut, 256));
             HIP_TRYX(c, hipMemcpyAsync(c->d_lut, comp, 256, hipMemcpyHostToDevice, st));
             HIP_TRYX(c, hipStreamSynchronize(st));  // comp lives on the host stack
-            G.regex = c->d_regex;
+            if (c->grep_vm) G.vm = c->d_vm_progs; else G.regex = c->d_regex;
             G.comp = c->d_lut;
         } else if (!G.by_seq) {
             // ID / name: the patterns do not depend on the shard, upload once per context
@@ -513,7 +530,7 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
             HIP_TRYX(c, hipMemcpyAsync(lc, c->d_counter + 2, sizeof lc, hipMemcpyDeviceToHost, st));
             HIP_TRYX(c, hipStreamSynchronize(st));
             if (lc[0]) G.sa_ok = 0;
-        } else if (G.by_seq && !G.general && !G.regex) {
+        } else if (G.by_seq && !G.general && !G.regex && !G.vm) {
             // chromosome-sized sequences are searched by whole blocks (k_grep_seq<.., LONG>): list them
             const char* e = c->tune.get("long_bytes");
             const uint32_t thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
@@ -596,6 +613,8 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
                     G1.npat = 1;
                     if (G.regex) {
                         G1.regex = c->d_regex + k;
+                    } else if (G.vm) {
+                        G1.vm = c->d_vm_progs + k;
                     } else {
                         c->patterns.assign(1, all_patterns[k]);
                         if (c->general) c->pattern_cls.assign(1, all_cls[k]);

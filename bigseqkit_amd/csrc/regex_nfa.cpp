@@ -19,7 +19,7 @@ inline void bs_range(ByteSet& s, int lo, int hi) { for (int b = lo; b <= hi; ++b
 inline void bs_or(ByteSet& a, const ByteSet& b) { for (int i = 0; i < 8; ++i) a[i] |= b[i]; }
 inline ByteSet bs_not(const ByteSet& a) { ByteSet r; for (int i = 0; i < 8; ++i) r[i] = ~a[i]; return r; }
 
-enum class NT { Empty, Lit, Begin, End, Cat, Alt, Star, Plus, Quest, Repeat, Group };
+enum class NT { Empty, Lit, Begin, End, WordB, NotWordB, Cat, Alt, Star, Plus, Quest, Repeat, Group };
 struct Node {
     NT t = NT::Empty;
     ByteSet set{};
@@ -95,7 +95,7 @@ struct Parser {
                 }
                 bad("invalid escape sequence", e);
             }
-            case 'b': case 'B': unsupported("word boundary \\b", e);
+            case 'b': case 'B': bad("invalid escape sequence", e);  // (\\b inside a class; outside, atom() takes it)
             case 'p': case 'P': unsupported("Unicode class \\p", e);
             case 'A': case 'z': case 'Q': case 'E': case 'C': unsupported(std::string("\\") + c, e);
             default:
@@ -208,6 +208,11 @@ struct Parser {
             case '^': { NodeP n(new Node); n->t = NT::Begin; return n; }
             case '$': { NodeP n(new Node); n->t = NT::End; return n; }
             case '\\': {
+                if (more() && (peek() == 'b' || peek() == 'B')) {  // ASCII word boundary / not a boundary (RE2: \b \B)
+                    NodeP n(new Node);
+                    n->t = e[i++] == 'b' ? NT::WordB : NT::NotWordB;
+                    return n;
+                }
                 ByteSet cls{};
                 int b = 0;
                 if (escape(&cls, &b)) { NodeP n(new Node); n->t = NT::Lit; n->set = cls; return n; }
@@ -322,6 +327,9 @@ struct Builder {
             case NT::Lit: { uint64_t b = newpos(n.set, false, false); return {false, b, b}; }
             case NT::Begin: { uint64_t b = newpos(ByteSet{}, true, false); return {false, b, b}; }
             case NT::End: { uint64_t b = newpos(ByteSet{}, false, true); return {false, b, b}; }
+            // (an assertion over TWO neighbouring bytes is no position of a Glushkov automaton: the callers that only need
+            // "matches or not" take the thread-list matcher of regex_vm.hpp for such an expression)
+            case NT::WordB: case NT::NotWordB: unsupported("word boundary \\b in the bit-parallel automaton", expr);
             case NT::Cat: {
                 Frag f{true, 0, 0};
                 for (auto& k : n.kids) f = cat(f, build(*k));
@@ -438,6 +446,8 @@ struct VmBuilder {
             case NT::Lit: emit(VM_CHAR, set_of(n.set)); return;
             case NT::Begin: emit(VM_BEGIN); return;
             case NT::End: emit(VM_END); return;
+            case NT::WordB: emit(VM_WORDB); return;
+            case NT::NotWordB: emit(VM_NWORDB); return;
             case NT::Cat: for (auto& k : n.kids) gen(*k); return;
             case NT::Alt: {  // split L1, L2; L1: a; jmp END; L2: split ... (the first alternative is preferred)
                 std::vector<uint32_t> jumps;

@@ -20,7 +20,7 @@ namespace bsk {
 
 constexpr int VM_MAX_INST = 64;
 constexpr int VM_MAX_SETS = 24;
-enum : uint8_t { VM_CHAR = 0, VM_SPLIT = 1, VM_JMP = 2, VM_SAVE = 3, VM_BEGIN = 4, VM_END = 5, VM_MATCH = 6 };
+enum : uint8_t { VM_CHAR = 0, VM_SPLIT = 1, VM_JMP = 2, VM_SAVE = 3, VM_BEGIN = 4, VM_END = 5, VM_MATCH = 6, VM_WORDB = 7, VM_NWORDB = 8 };
 
 struct VmInst { uint8_t op, arg; uint8_t x, y; };  // CHAR: arg = set; SPLIT: x first (preferred), y second; JMP: x; SAVE: arg = slot (0..3)
 struct VmProgram {
@@ -69,6 +69,13 @@ BSK_VM_HD inline bool vm_search_fn(const VmProgram& P, const TextFn& text, uint3
                 if (I.op == VM_SAVE) { t.c[I.arg] = sp; ++t.pc; continue; }
                 if (I.op == VM_BEGIN) { if (sp != 0) break; ++t.pc; continue; }
                 if (I.op == VM_END) { if (sp != n) break; ++t.pc; continue; }
+                if (I.op == VM_WORDB || I.op == VM_NWORDB) {  // \b / \B: ASCII word characters [0-9A-Za-z_] (RE2)
+                    auto word = [](uint8_t ch) { return (ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || ch == '_'; };
+                    const bool before = sp > 0 && word(text(sp - 1)), after = sp < n && word(text(sp));
+                    if ((before != after) != (I.op == VM_WORDB)) break;
+                    ++t.pc;
+                    continue;
+                }
                 list[cnt++] = t;  // CHAR or MATCH
                 break;
             }

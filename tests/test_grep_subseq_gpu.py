@@ -428,6 +428,35 @@ GREP_RE_OPTS = [
 ]
 
 
+# expressions the bit-parallel automaton does not take go to the thread-list matcher (k_grep_vm, round 4): word boundaries
+GREP_VM_OPTS = [
+    {"Pattern": [r"\br1\d\b"], "UseRegexp": True},
+    {"Pattern": [r"\bd[03]\b"], "UseRegexp": True, "ByName": True},
+    {"Pattern": [r"R1\B", r"^r2\d\d$"], "UseRegexp": True, "IgnoreCase": True},
+    {"Pattern": [r"\b7$"], "UseRegexp": True, "ByName": True, "InvertMatch": True},
+    {"Pattern": [r"\bACG", r"GCT\b"], "UseRegexp": True, "BySeq": True},
+    {"Pattern": [r"acgttg(ca|gg)agct\B"], "UseRegexp": True, "BySeq": True, "IgnoreCase": True, "OnlyPositiveStrand": True},
+    {"Pattern": [r"GCAAGCT.*\BACGTTG|TTTTTTTT\b"], "UseRegexp": True, "BySeq": True, "Circular": True},
+    {"Pattern": [r"^ACG\B"], "UseRegexp": True, "Region": "5:60"},
+    {"Pattern": [r"\bAC", r"\br1", r"T\b"], "UseRegexp": True, "BySeq": True, "DeleteMatched": True},
+]
+
+
+@pytest.mark.parametrize("i", range(len(GREP_VM_OPTS)))
+def test_grep_regexp_word_boundaries(i, monkeypatch):
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(3350 + i)
+    n = check_grep(planted_fastq(rng, 700), True, GREP_VM_OPTS[i])
+    assert 0 <= n <= 700
+    recs = []
+    for k in range(150):
+        L = rng.choice((0, 1, 7, 60, 61, 200))
+        recs.append((b"r%d d%d" % (k, k % 7), bytes(rng.choice(b"ACGTacgtN") for _ in range(L))))
+    for width in (60, 0):
+        fa = b"".join(b">" + h + b"\n" + (b"\n".join(s[j:j + width] for j in range(0, len(s), width)) if width else s) + b"\n" for h, s in recs)
+        check_grep(fa, False, GREP_VM_OPTS[i])
+
+
 @pytest.mark.parametrize("i", range(len(GREP_RE_OPTS)))
 def test_grep_regexp_fastq(i, monkeypatch):
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")

@@ -38,7 +38,7 @@ def headers(rng, n):
     return out
 
 
-REGEXPS = [r"^([^\s/]+)", r"gi\|(\d+)\|", r"id=(\w+)", r"^(\S+?)_", r"(\d+)$", r"^(?:read|plain)(_?\d+)", r"sample=([A-Z])|^(x)"]
+REGEXPS = [r"^([^\s/]+)", r"gi\|(\d+)\|", r"id=(\w+)", r"^(\S+?)_", r"(\d+)$", r"^(?:read|plain)(_?\d+)", r"sample=([A-Z])|^(x)", r"\b(\w+)\b$", r"^(\w+)\b"]
 
 
 @pytest.mark.parametrize("re_", REGEXPS)
@@ -72,7 +72,7 @@ def test_operators_that_use_ids(re_, monkeypatch):
 
 
 def test_rejections():
-    for re_, msg in ((r"^\S+", "must contain"), (r"^(\S+))", "fail to compile regexp"), (r"^(\w+)\b", "not supported by the HIP path")):
+    for re_, msg in ((r"^\S+", "must contain"), (r"^(\S+))", "fail to compile regexp"), (r"^(\pL+)", "not supported by the HIP path")):
         with pytest.raises(bsk.BskError) as e:
             bsk.Operator("SeqTransform", json.dumps({"Config": {"IDRegexp": re_}}), 0)
         assert msg in str(e.value), (re_, str(e.value))

@@ -250,7 +250,8 @@ def test_locate_regexp_hand_case_pattern_file_and_what_is_refused(tmp_path):
 
 
 # ---------------------------------------------------------------- locate -r, matches of variable length (PARITY.md LOCRE)
-VM_EXPRS = ["AC+G", "A[CG]*T", "(AC|GT)+", "^A.*T$", "T{2,4}", "G.*?C", "(?:CG|C)(A|AT)T?", "A+", "^[ACGT]{3}", "N+|ACGT", "A(C|G){0,2}T$", "T*"]
+VM_EXPRS = ["AC+G", "A[CG]*T", "(AC|GT)+", "^A.*T$", "T{2,4}", "G.*?C", "(?:CG|C)(A|AT)T?", "A+", "^[ACGT]{3}", "N+|ACGT", "A(C|G){0,2}T$", "T*",
+            r"\bAC+G", r"T+\b", r"A\B[CG]+"]  # ASCII word boundaries (round 4): inside a sequence only the ends of the searched text are boundaries
 
 
 @pytest.mark.parametrize("expr", VM_EXPRS)

@@ -41,7 +41,9 @@ def py_find(expr, text, start):
 EXPRS = [r"^(\S+)\s?", r"\|([^\|]+)\| ", r"^([^ ]+) ", r"(\d+)$", r"id=(\w+)", r"^gi\|(\d+)\|", r"(a|ab)(c|bcd)", r"(a+)(a*)", r"(a+?)(a*)",
          r"x*", r"(x*)y", r"(?i)ac(g+)t", r"[^ ]+ (.+)$", r"^(.*?)_", r"^(.*)_", r"(AC|ACG|ACGT)T?", r"(A{2,4})C", r"(A{2,4}?)C", r"A(C|G){0,2}T",
          r"(?:AB)+(C)", r"(?P<name>[A-Z]+)\d", r"\.(\w+)$", r"([ACGT]+)N+([ACGT]+)", r"(GA|G)(AT|A)T", r"(T[AG]A)", r"AC+G", r"^A.*T$",
-         r"(AC|GT){2}", r"()", r"(a|b)*c", r"(\w+)\s(\w+)", r"[[:digit:]]+([[:alpha:]]*)"]
+         r"(AC|GT){2}", r"()", r"(a|b)*c", r"(\w+)\s(\w+)", r"[[:digit:]]+([[:alpha:]]*)",
+         # ASCII word boundaries (RE2 \b \B; round 4)
+         r"\bid=(\w+)\b", r"(\w+)\b", r"\B(a+)", r"\b(AC|GT)+\b", r"x\b", r"\b", r"a\Bb", r"\b(\d+)\b", r"(?i)\bacg(t*)\b", r"\B", r"(\S+)\b "]
 
 
 @pytest.mark.parametrize("expr", EXPRS)
@@ -56,12 +58,14 @@ def test_same_spans_as_python_re(expr):
         for start in {0, min(1, len(t)), len(t) // 2, len(t)}:
             got, ng = find(expr, t, start)
             want = py_find(expr, t, start)
+            if expr == r"\B" and t == b"":  # Python < 3.14 never matches \B in an empty text; RE2 / Go do (no boundary there)
+                want = (0, 0, NONE, NONE)
             assert got == want, (expr, t, start, got, want)
 
 
 def test_group_count_and_rejections():
     assert find(r"(a)(b)(?:c)(?P<x>d)", b"abcd")[1] == 3
     assert find(r"abc", b"abc")[1] == 0
-    for bad in [r"a\b", r"(?m)^a", r"\pL", "[ab]{40}[cd]{40}"]:
+    for bad in [r"[\b]", r"(?m)^a", r"\pL", "[ab]{40}[cd]{40}"]:
         caps = (C.c_uint32 * 4)()
         assert lib.bsk_selftest_regex_find(bad.encode(), b"x", 1, 0, caps, None) == -1
