@@ -286,6 +286,7 @@ struct Parser {
                 if (e[j] == 'i') ic = true;
                 else if (e[j] == 's') ds = true;
                 else if (e[j] == 'U') ungreedy = true;  // swap greediness: irrelevant for a boolean match, kept for the VM
+                else if (e[j] == 'm') {}  // ^ $ also at line breaks: the targets (ID, name, bases of ONE record) hold none -- the same matches
                 else { ok = false; break; }
             }
             if (!ok || j >= e.size()) break;

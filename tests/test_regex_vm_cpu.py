@@ -22,12 +22,13 @@ def find(expr, text, start=0):
 
 def py_find(expr, text, start):
     flags = 0
-    m = re.match(r"^\(\?([isU]+)\)", expr)
+    m = re.match(r"^\(\?([ismU]+)\)", expr)
     body = expr
     if m:
         body = expr[m.end():]
         if "i" in m.group(1): flags |= re.I
         if "s" in m.group(1): flags |= re.S
+        if "m" in m.group(1): flags |= re.M  # (the texts of this test hold no line break: the targets of the library never do)
     body = body.replace("[[:digit:]]", "[0-9]").replace("[[:alpha:]]", "[A-Za-z]")  # POSIX names are RE2 syntax, not Python's
     # ^ / $ : Go without (?m) anchors at the ends of the text only; search from `start` keeps position 0 as the beginning
     rx = re.compile(body.encode(), flags)
@@ -43,7 +44,7 @@ EXPRS = [r"^(\S+)\s?", r"\|([^\|]+)\| ", r"^([^ ]+) ", r"(\d+)$", r"id=(\w+)", r
          r"(?:AB)+(C)", r"(?P<name>[A-Z]+)\d", r"\.(\w+)$", r"([ACGT]+)N+([ACGT]+)", r"(GA|G)(AT|A)T", r"(T[AG]A)", r"AC+G", r"^A.*T$",
          r"(AC|GT){2}", r"()", r"(a|b)*c", r"(\w+)\s(\w+)", r"[[:digit:]]+([[:alpha:]]*)",
          # ASCII word boundaries (RE2 \b \B; round 4)
-         r"\bid=(\w+)\b", r"(\w+)\b", r"\B(a+)", r"\b(AC|GT)+\b", r"x\b", r"\b", r"a\Bb", r"\b(\d+)\b", r"(?i)\bacg(t*)\b", r"\B", r"(\S+)\b "]
+         r"\bid=(\w+)\b", r"(\w+)\b", r"\B(a+)", r"\b(AC|GT)+\b", r"x\b", r"\b", r"a\Bb", r"\b(\d+)\b", r"(?i)\bacg(t*)\b", r"\B", r"(\S+)\b ", r"(?m)^(\w+)$", r"(?im)a(c+)$"]
 
 
 @pytest.mark.parametrize("expr", EXPRS)
@@ -66,6 +67,6 @@ def test_same_spans_as_python_re(expr):
 def test_group_count_and_rejections():
     assert find(r"(a)(b)(?:c)(?P<x>d)", b"abcd")[1] == 3
     assert find(r"abc", b"abc")[1] == 0
-    for bad in [r"[\b]", r"(?m)^a", r"\pL", "[ab]{40}[cd]{40}"]:
+    for bad in [r"[\b]", r"a(?m)b", r"\pL", "[ab]{40}[cd]{40}"]:
         caps = (C.c_uint32 * 4)()
         assert lib.bsk_selftest_regex_find(bad.encode(), b"x", 1, 0, caps, None) == -1
