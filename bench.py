@@ -609,6 +609,15 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node == --gpus "
                          "(or without torchrun: bench.py starts the ranks itself)" % (want_world, world))
     backend = os.environ.get("BSK_BENCH_BACKEND", "nccl")
+    # BSK_BENCH_DIST_SINGLE=1 (with --gpus 1): the N-rank code path -- process group, the all-reduce of every step, the
+    # multi-GPU legs with their all-to-all -- with ONE rank.  On a one-GPU box this is the only way the RCCL calls of that
+    # path run at all; the line says "single_rank_dist_check" and is no scaling measurement.
+    dist_on = world > 1 or os.environ.get("BSK_BENCH_DIST_SINGLE") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("BSK_DIST_SINGLE_RANK_COLLECTIVES", "1")
     if args.launch_check:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -644,7 +653,7 @@ def main():
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         pg_timeout = datetime.timedelta(minutes=5)   # a rank that died must not hold the others for the default 10 - 30 min
@@ -678,7 +687,7 @@ def main():
         vec = torch.zeros(vlen, dtype=torch.int64, device=dev)
         return op, vec
 
-    reduce_ev = [] if world > 1 else None  # (start, stop) HIP events around the all-reduce of every timed step
+    reduce_ev = [] if dist_on else None  # (start, stop) HIP events around the all-reduce of every timed step
 
     def one_step(op, vec):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -686,7 +695,7 @@ def main():
         check(lib.bsk_stats_reset(op.ctx, st), op.ctx)  # error flags + overflow list of the context (the vector is ours)
         check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nbytes, 1, bsk.FORMAT_FASTQ, rank,
                                 C.c_void_p(vec.data_ptr()), st), op.ctx)
-        if world > 1:
+        if dist_on:
             # StatsReduce (bigseqkit/stats.go:91): ONE sum all-reduce of the dense map over RCCL -- the only collective --
             # and the collect behind it (the step's one synchronising copy; the overflow lists of chromosome-sized
             # records are exchanged only when the reduced vector counts any: never for reads).  HIP events on the stream
@@ -713,7 +722,7 @@ def main():
             one_step(op, vec)
         lib.bsk_profile_reset(op.ctx)
         lib.bsk_profile_enable(op.ctx, 1)
-        if world > 1:
+        if dist_on:
             bdist.barrier()
         torch.cuda.synchronize()
         if reduce_ev is not None:
@@ -723,7 +732,7 @@ def main():
             m, text = one_step(op, vec)
         torch.cuda.synchronize()
         t_own = time.perf_counter() - t0          # this rank's K steps (before it waits for the others)
-        if world > 1:
+        if dist_on:
             bdist.barrier()
         dt = time.perf_counter() - t0
         lib.bsk_profile_enable(op.ctx, 0)
@@ -734,7 +743,7 @@ def main():
         p_ms = ms.value / max(1, n.value)
         r_ms = sum(a.elapsed_time(b) for a, b in reduce_ev) / max(1, len(reduce_ev)) if reduce_ev else 0.0
         ranks = None
-        if world > 1:
+        if dist_on:
             dt = bdist.all_reduce_max_float(dt, dev)
             # what every rank saw: explains a step time that is not 1 / N of the single-GPU one
             rows = bdist.all_gather_floats([k_ms, p_ms, r_ms, t_own / steps * 1e3], dev)
@@ -765,14 +774,14 @@ def main():
         q20 += int((q >= 33 + 20).sum().item())
         q30 += int((q >= 33 + 30).sum().item())
         del q
-    if world > 1:
+    if dist_on:
         q20, q30 = bdist.all_reduce_count(q20, dev), bdist.all_reduce_count(q30, dev)
     verified_a = (ma.get(150) == total_rec and ma.get(-3) == 0 and ma.get(-1) == q20 and ma.get(-2) == q30
                   and sum(v for k, v in ma.items() if k >= 0) == total_rec)
 
     # ---- the BASELINE configs that are defined on several GPUs (C3, C5) -- every rank takes part
     ops_multi = None
-    if world > 1 and not args.no_ops:
+    if dist_on and not args.no_ops:
         del view
         shard = None
         torch.cuda.empty_cache()
@@ -784,7 +793,7 @@ def main():
                 print("bench.py rank %d: ops leg failed: %s" % (rank, ops_multi["error"]), file=sys.stderr, flush=True)
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -795,7 +804,7 @@ def main():
     # full single-GPU workload it was collected on.
     traffic, traffic_src = None, None
     pmc = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if pmc and world == 1 and total_bytes > 99e9:
+    if pmc and not dist_on and total_bytes > 99e9:
         try:
             pj = json.load(open(pmc[-1]))
             traffic = pj["per_launch"]["stats"]["traffic_bytes"]
@@ -815,7 +824,7 @@ def main():
         "unit": "M records/s",
         "gb_per_s": round(total_bytes * args.steps / dt / 1e9, 2),
         "frac_of_hbm_peak": round(total_bytes * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
-        "n_gpus": dist.get_world_size() if world > 1 else 1,
+        "n_gpus": dist.get_world_size() if dist_on else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -829,10 +838,11 @@ def main():
                    "command": "stats", "records": total_rec, "bytes": total_bytes, "seed": 42},
         "bit_exact_vs_expected_row": bool(verified),
         "shard_bytes_per_rank": nbytes,
-        "allreduce_ms_per_step": round(reduce_ms, 4) if world > 1 else None,
-        "backend": (dist.get_backend() if world > 1 else None),
+        "allreduce_ms_per_step": round(reduce_ms, 4) if dist_on else None,
+        "backend": (dist.get_backend() if dist_on else None),
         "per_rank": per_rank,
         "shared_gpu_functional_check": bool(share),
+        "single_rank_dist_check": bool(dist_on and world == 1),
         "roofline": {
             "bound": "hbm",
             "kernel": "k_stats<FASTQ,default>",
@@ -857,7 +867,7 @@ def main():
     }
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
-    if world == 1 and not args.no_cpu_baseline:
+    if not dist_on and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle
         pilot = shard[:REC * 200_000].cpu()
@@ -908,7 +918,7 @@ def main():
         except Exception as e:  # never let the extra baseline break the bench line
             out["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
     # ---- the other BASELINE configs (N = 1): seq -n @ C2, grep @ C3 shard, translate @ C4, rmdup @ C5 shard
-    if world == 1 and not args.no_ops:
+    if not dist_on and not args.no_ops:
         if total_bytes > 99e9 or args.ops_scale != 1.0:
             try:
                 out["ops"] = run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec)
@@ -925,7 +935,7 @@ def main():
     if ops_multi is not None:
         out["ops"] = ops_multi
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

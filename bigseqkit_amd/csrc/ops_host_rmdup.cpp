@@ -89,7 +89,9 @@ int rmdup_finish(bsk_ctx* c) {
 // The records dedupe left in the overflow list (ops_rmdup.hip: same XXH64 key as an earlier record, another second key):
 // groups of equal (k1, k2) among them keep their lowest record, exactly as the map of RmDupCheck.Call would
 // (rmdup.go:150-199) -- a few records per 10^4 shards, settled on the host.  BSK_ERR_FILTER_FALLBACK: the list did not fit.
-static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st, uint64_t m64) {
+static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st, uint64_t m64, const uint64_t* d_k1 = nullptr,
+                                 const uint64_t* d_k2 = nullptr) {
+    if (!d_k1) { d_k1 = c->d_keys; d_k2 = c->d_keys2; }
     const uint32_t m = (uint32_t)std::min<uint64_t>(m64, 0xFFFFFFFFull);  // (the list's length: status word [3] of the read-back)
     if (m == 0) return BSK_OK;
     if ((uint64_t)m + 1 > c->ovf_cap) return BSK_ERR_FILTER_FALLBACK;
@@ -100,7 +102,7 @@ static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st, 
     std::vector<uint64_t> kk(2 * (size_t)m);
     int rc = BSK_OK;
     do {
-        if (launch_gather_keys(c->d_ovf + 1, m, c->d_keys, c->d_keys2, d_kk, st) != hipSuccess ||
+        if (launch_gather_keys(c->d_ovf + 1, m, d_k1, d_k2, d_kk, st) != hipSuccess ||
             hipMemcpyAsync(idx.data(), c->d_ovf + 1, (size_t)m * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(kk.data(), d_kk, (size_t)m * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
@@ -444,6 +446,54 @@ int rmdup_dist_pack(bsk_ctx* c, uint64_t base, int world, uint64_t* d_send, uint
 
 int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t* d_keep, hipStream_t st) {
     if (m == 0) return BSK_OK;
+    // Round 4: the received tuples are grouped the way a shard groups its own records -- radix sort by the low key bits, one
+    // LDS table per bucket, k2 compared inside, the few k1 collisions settled exactly through the overflow list -- instead
+    // of one big table in HBM (3 x 2^28 words zeroed and hit at random: 18.4 ms for the 79 M tuples of a C5 rank; now
+    // profiles/r04j_*).  `rmdup=table`, 2^32 tuples or a bucket that overflows keep the table.
+    bool by_buckets = m < (1ull << 32) && !c->tune.is("rmdup", "table");
+    if (by_buckets) {
+        int rc = grow(c, &c->d_own, &c->own_cap, 2 * m);
+        if (rc != BSK_OK) return rc;
+        uint64_t *k1 = c->d_own, *k2 = c->d_own + m;
+        size_t tmp_bytes = 0;
+        HIP_TRYX(c, sort_pairs_bits_iota_temp_bytes(m, 0, (int)RMDUP_BUCKET_BITS, &tmp_bytes));
+        Arena A;
+        const uint64_t o_sk = A.take(m * 8), o_vo = A.take(m * 4), o_first = A.take(m * 4),
+                       o_bs = A.take(((1u << RMDUP_BUCKET_BITS) + 2) * 4), o_tmp = A.take(tmp_bytes + 256);
+        rc = arena_reserve(c, &A);
+        if (rc != BSK_OK) return rc;
+        uint32_t* d_first = A.at<uint32_t>(o_first);
+        const uint64_t want = std::max<uint64_t>(4096, m / 16) + 1;
+        rc = grow(c, &c->d_ovf, &c->ovf_cap, want, 16);
+        if (rc != BSK_OK) return rc;
+        const uint32_t ovf_cap = (uint32_t)std::min<uint64_t>(c->ovf_cap - 1, 0xFFFFFFFFull);
+        HIP_TRYX(c, hipMemsetAsync(c->d_ovf, 0, sizeof(uint32_t), st));
+        HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_split_tuples(d_tuples, m, k1, k2, st));
+        HIP_TRYX(c, launch_sort_iota(d_first, m, st));
+        HIP_TRYX(c, launch_sort_pairs_bits_iota(A.at<uint8_t>(o_tmp), tmp_bytes, k1, A.at<uint64_t>(o_sk), A.at<uint32_t>(o_vo), m, 0,
+                                                (int)RMDUP_BUCKET_BITS, st));
+        HIP_TRYX(c, launch_bucket_dedupe(A.at<uint64_t>(o_sk), A.at<uint32_t>(o_vo), m, A.at<uint32_t>(o_bs), d_first, c->d_status, st, k2,
+                                         c->d_ovf, ovf_cap));
+        rc = ctl_readback(c, st);
+        if (rc != BSK_OK) return rc;
+        uint64_t status = c->status_word();
+        if (status & ERR_BUCKET_OVERFLOW) {
+            by_buckets = false;
+        } else {
+            rc = rmdup_settle_overflow(c, d_first, st, c->h_ctl[3], k1, k2);
+            if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;
+            else if (rc != BSK_OK) return rc;
+        }
+        if (by_buckets) {
+            // (the sorted keys are done with: their array is the scratch of the per-group minimum)
+            HIP_TRYX(c, launch_keep_lowest(d_tuples, d_first, m, A.at<uint64_t>(o_sk), d_keep, st));
+            HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(uint64_t), st));  // (word 3 counted the list)
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            return BSK_OK;
+        }
+        HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(uint64_t), st));
+    }
     uint64_t cap = 1024;
     while (cap < 2 * m) cap <<= 1;
     int rc = grow(c, &c->d_own, &c->own_cap, 3 * cap);
@@ -480,7 +530,8 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     SeqParams F = format_params(c, fastq);
     if (!fastq) { F.text_w = c->table.text_w; F.lin_off = c->d_lin_off; F.lin = c->d_lin; }  // prepared by the keys phase
     apply_long(c, &F);
-    HIP_TRYX(c, launch_seq_emit(c->dist_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+    // (emit_records: the verbatim survivors of a FASTQ shard leave through the segment copy, like the single-GPU call's)
+    { const int rce = emit_records(c, c->dist_buf, c->dist_n, F, total, kept, st); if (rce != BSK_OK) return rce; }
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;

@@ -940,6 +940,45 @@ hipError_t launch_rmdup_pack(const uint64_t* keys, const uint64_t* keys2, uint64
     return hipGetLastError();
 }
 
+namespace {
+// owner side of the tuple exchange, grouped like a shard's own records (round 4): the two keys of the received tuples as
+// plain arrays (the sort and the bucket tables take arrays, the tuples are 24-byte rows) ...
+__global__ __launch_bounds__(256) void k_split_tuples(const uint64_t* __restrict__ tuples, uint64_t m, uint64_t* __restrict__ k1,
+                                                      uint64_t* __restrict__ k2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    k1[i] = tuples[3 * i];
+    k2[i] = tuples[3 * i + 1];
+}
+// ... and the answer: a tuple is kept iff it carries the lowest GLOBAL record number of its group.  first[] names one member
+// of every group (the pack scatters with atomic cursors, so positions in the receive buffer are in no file order): the
+// lowest number is found per group with one 64-bit atomicMin per tuple on the slot of its group's member.
+__global__ __launch_bounds__(256) void k_group_min(const uint64_t* __restrict__ tuples, const uint32_t* __restrict__ first, uint64_t m,
+                                                   unsigned long long* __restrict__ gmin) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) atomicMin(&gmin[first[i]], (unsigned long long)tuples[3 * i + 2]);
+}
+__global__ __launch_bounds__(256) void k_keep_min(const uint64_t* __restrict__ tuples, const uint32_t* __restrict__ first, uint64_t m,
+                                                  const unsigned long long* __restrict__ gmin, uint8_t* __restrict__ keep) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) keep[i] = (unsigned long long)tuples[3 * i + 2] == gmin[first[i]] ? 1 : 0;
+}
+}  // namespace
+
+hipError_t launch_split_tuples(const uint64_t* tuples, uint64_t m, uint64_t* k1, uint64_t* k2, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_split_tuples, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, tuples, m, k1, k2);
+    return hipGetLastError();
+}
+hipError_t launch_keep_lowest(const uint64_t* tuples, const uint32_t* first, uint64_t m, uint64_t* gmin, uint8_t* keep, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    if (hipMemsetAsync(gmin, 0xFF, m * sizeof(uint64_t), st) != hipSuccess) return hipGetLastError();
+    const dim3 g((unsigned)((m + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_group_min, g, b, 0, st, tuples, first, m, (unsigned long long*)gmin);
+    hipLaunchKernelGGL(k_keep_min, g, b, 0, st, tuples, first, m, (const unsigned long long*)gmin, keep);
+    return hipGetLastError();
+}
+
 hipError_t launch_rmdup_own(const uint64_t* tuples, uint64_t m, uint64_t* table_keys, uint64_t* table_first,
                             uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st) {
     if (m == 0) return hipSuccess;

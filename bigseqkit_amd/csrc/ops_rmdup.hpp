@@ -66,6 +66,10 @@ hipError_t launch_bucket_pass(const uint64_t* keys, uint64_t n, uint32_t* hist, 
 hipError_t launch_rmdup_sizes(const RecordTable& t, const RmDupParams& P, const uint32_t* first, uint32_t* out_len, hipStream_t st);
 // out[2 j], out[2 j + 1] = k1, k2 of record list[j];  dst[idx[j]] = val[j]
 hipError_t launch_gather_keys(const uint32_t* list, uint32_t m, const uint64_t* k1, const uint64_t* k2, uint64_t* out, hipStream_t st);
+// owner side of the multi-GPU exchange: k1[i], k2[i] of tuple i (24-byte rows: k1, k2, global record number);
+// keep[i] = tuple i carries the lowest record number of its group (first[i] = one member of the group; gmin: m words scratch)
+hipError_t launch_split_tuples(const uint64_t* tuples, uint64_t m, uint64_t* k1, uint64_t* k2, hipStream_t st);
+hipError_t launch_keep_lowest(const uint64_t* tuples, const uint32_t* first, uint64_t m, uint64_t* gmin, uint8_t* keep, hipStream_t st);
 // tests: keys[i] &= mask (forces distinct subjects under one key)
 hipError_t launch_mask_keys(uint64_t* keys, uint64_t n, uint64_t mask, hipStream_t st);
 hipError_t launch_scatter_u32(const uint32_t* idx, const uint32_t* val, uint32_t m, uint32_t* dst, hipStream_t st);

@@ -8,6 +8,7 @@ plus the exchange of rmdup (GroupByKey) and the two prefix sums that MapWithInde
     Range / Head     (bigseqkit/range.go:69-103) -> all_gather of the record counts
     Faidx            (bigseqkit/faidx.go:69-80)  -> all_gather of the shard sizes
 """
+import os
 import ctypes as C
 
 from ._lib import lib, check
@@ -314,7 +315,10 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
     `tuple_bytes_sent` / `tuple_bytes_sent_off_rank`."""
     import torch
     import torch.distributed as dist
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    # (BSK_DIST_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank still takes the exchange -- every collective of the
+    # N-rank path then runs over the backend, which is how a one-GPU box executes the RCCL calls at all: bench.py
+    # BSK_BENCH_DIST_SINGLE)
+    multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("BSK_DIST_SINGLE_RANK_COLLECTIVES") == "1")
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
     dev = shard.device
@@ -355,21 +359,55 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
     return out
 
 
+# No single message of an all-to-all may exceed this many bytes.  Measured on this image (RCCL 2.26.6, torch 2.10, one rank
+# sending to itself: scripts/history/r04_a2a_probe2.py): all_to_all_single delivers a message of up to 1 GiB whole and of a
+# larger one only the FIRST HALF -- silently.  A C5 rank sends 1.9 GB of tuples; with 8 ranks a message is 236 MB, with 2
+# ranks 946 MB, with one 1.9 GB.  Larger exchanges go in rounds of at most this size per message.
+A2A_MAX_BYTES = 512 << 20
+
+
 def _all_to_all_single(out, inp, out_splits, in_splits, group=None):
     """dist.all_to_all_single on the rank's device under RCCL; staged through the host under gloo (CPU tests, ranks that
-    share a GPU)."""
+    share a GPU).  With split lists (rows of dim 0 per peer) the exchange runs in as many rounds as the largest message
+    anywhere needs to stay under A2A_MAX_BYTES (BSK_A2A_MAX_BYTES overrides: the tests force the rounds)."""
     import torch
     import torch.distributed as dist
     cd = coll_device(out.device, group)
-    if cd == out.device:
-        _checked([out, inp], group)
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+    if cd != out.device:
+        o = torch.empty(out.shape, dtype=out.dtype, device=cd)
+        i = inp.to(cd)
+        _all_to_all_single(o, i, out_splits, in_splits, group)
+        out.copy_(o)
         return
-    o = torch.empty(out.shape, dtype=out.dtype, device=cd)
-    i = inp.to(cd)
-    _checked([o, i], group)
-    dist.all_to_all_single(o, i, out_splits, in_splits, group=group)
-    out.copy_(o)
+    _checked([out, inp], group)
+    if out_splits is None:  # equal split (the few words of the split sizes themselves)
+        dist.all_to_all_single(out, inp, None, None, group=group)
+        return
+    row_bytes = max(1, inp.element_size() * (inp[0].numel() if inp.dim() > 1 else 1))
+    limit = max(1, int(os.environ.get("BSK_A2A_MAX_BYTES", A2A_MAX_BYTES)) // row_bytes)  # rows per message
+    biggest = torch.tensor([max(list(out_splits) + list(in_splits) + [0])], dtype=torch.int64, device=cd)
+    _all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)  # (every rank must take the same number of rounds)
+    rounds = max(1, -(-int(biggest.item()) // limit))
+    if rounds == 1:
+        dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
+        return
+    def offsets(splits):
+        acc, r = 0, []
+        for c in splits:
+            r.append(acc)
+            acc += c
+        return r
+    o_off, i_off = offsets(out_splits), offsets(in_splits)
+    for r in range(rounds):
+        piece = lambda c: max(0, min(limit, c - r * limit))
+        o_cnt, i_cnt = [piece(c) for c in out_splits], [piece(c) for c in in_splits]
+        send = torch.cat([inp[i_off[p] + r * limit: i_off[p] + r * limit + i_cnt[p]] for p in range(len(in_splits))])
+        recv = torch.empty((sum(o_cnt),) + tuple(out.shape[1:]), dtype=out.dtype, device=cd)
+        dist.all_to_all_single(recv, send, o_cnt, i_cnt, group=group)
+        at = 0
+        for p in range(len(out_splits)):
+            out[o_off[p] + r * limit: o_off[p] + r * limit + o_cnt[p]].copy_(recv[at: at + o_cnt[p]])
+            at += o_cnt[p]
 
 
 def _all_gather_int(value, device, group=None):

@@ -55,6 +55,22 @@ def test_bench_n_ranks_sharing_one_gpu(n):
     assert sum(r["tuple_bytes_sent_per_rank"]) == 24 * r["records"]
 
 
+def test_bench_one_rank_over_rccl():
+    """BSK_BENCH_DIST_SINGLE=1: the N-rank path with ONE rank -- process group "nccl", the all-reduce of every step, the
+    grep count all-reduce, the rmdup tuple exchange (all_gather + three all_to_all_single) -- so that the RCCL calls of
+    that path run on a one-GPU box at all.  A small message limit forces the exchange into rounds."""
+    d = run_bench(["--gpus", "1", "--gb", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ops-scale", "0.02",
+                   "--ops-calls", "2"], {"BSK_BENCH_DIST_SINGLE": "1", "BSK_A2A_MAX_BYTES": str(8 << 20)})
+    assert d["single_rank_dist_check"] is True and d["backend"] == "nccl" and d["n_gpus"] == 1
+    assert d["bit_exact_vs_expected_row"] is True and d["allreduce_ms_per_step"] is not None
+    ops = d["ops"]
+    assert "error" not in ops, ops
+    g, r = ops["grep -s -p @ C3"], ops["rmdup -s @ C5"]
+    assert g["exact"] is True and g["backend"] == "nccl", g
+    assert r["exact"] is True and r["survivors"] == r["records"] - r["records"] // 5, r
+    assert r["phases_ms_per_rank"]["all_to_all"][0] > 0   # the exchange ran (24 bytes per record to "the owner")
+
+
 def test_bench_ops_object_small():
     """the 'ops' object of the driver-run line (seq -n @ C2, grep @ C3 shard, translate @ C4, rmdup @ C5 shard) at 1 / 50
     of the BASELINE sizes: every entry must carry its timing, its algorithmic bytes and an exact full-output check"""

@@ -139,11 +139,16 @@ def _rmdup_worker(rank, world, port, data, opts, q, store=None):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("a2a_max_bytes", [None, 240])
 @pytest.mark.parametrize("opts", [{"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}])
-def test_two_ranks_gloo_rmdup_exchange(opts, tmp_path):
+def test_two_ranks_gloo_rmdup_exchange(opts, a2a_max_bytes, tmp_path, monkeypatch):
     """all_gather(counts) + all_to_all(tuples) + all_to_all(keep bytes): the concatenated per-rank survivors equal the
-    single-shard result, i.e. the first occurrence in FILE order survives even when it lives on the other rank."""
+    single-shard result, i.e. the first occurrence in FILE order survives even when it lives on the other rank.
+    a2a_max_bytes = 240: ten tuples per message, the exchange runs in rounds (dist._all_to_all_single: RCCL on this image
+    delivers only the first half of a message beyond 1 GiB, so large exchanges are cut)."""
     import torch.multiprocessing as mp
+    if a2a_max_bytes:
+        monkeypatch.setenv("BSK_A2A_MAX_BYTES", str(a2a_max_bytes))  # (the spawned ranks inherit the environment)
     rng = random.Random(77)
     seqs, recs = [], []
     for i in range(600):
