@@ -420,6 +420,8 @@ int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     rc = grow(c, &c->d_keys2, &c->keys2_cap, N, N / 8 + 16);
     if (rc != BSK_OK) return rc;
     if (!fused) HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
+    if (const char* e = c->tune.get("rmdup_k1_bits"))  // tests: only the low bits of k1 (different subjects under one k1 at the owner)
+        if (atoi(e) >= 16 && atoi(e) < 64) HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << atoi(e)) - 1ull, st));
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
     return kernel_error_to_status(c, status);

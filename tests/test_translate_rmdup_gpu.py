@@ -285,6 +285,19 @@ def test_rmdup_across_virtual_ranks_fastq(i, world, monkeypatch):
     assert _virtual_ranks(data, True, RMDUP_OPTS[i], world) == want
 
 
+@pytest.mark.parametrize("world", [1, 2, 5])
+@pytest.mark.parametrize("bits", [16, 20])
+def test_rmdup_across_virtual_ranks_with_colliding_first_keys(world, bits, monkeypatch):
+    """With 16 / 20 bits of k1 many different sequences share their first key at the owner: its grouping (sort + bucket
+    tables, round 4) keeps them apart by the second key through the overflow list -- the HBM table it replaced refused."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    monkeypatch.setenv("BSK_RMDUP_K1_BITS", str(bits))
+    rng = random.Random(5100 + bits)
+    data = dup_fastq(rng, 3000)
+    for o in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}):
+        assert _virtual_ranks(data, True, o, world) == oracle.rmdup(data, True, json.dumps(o))
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_rmdup_across_virtual_ranks_fasta(world):
     rng = random.Random(41)
