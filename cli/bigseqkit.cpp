@@ -624,6 +624,8 @@ void store(const Invocation& inv, const Output& out, const std::vector<std::stri
         std::ofstream f(outp, std::ios::binary);
         if (!f) die("cannot create " + outp);
         f.write(out_text.data(), (std::streamsize)out_text.size());
+        f.close();  // (die() ends the process without destructors: nothing may still sit in a stream buffer by then)
+        if (!f) die("write " + outp + " failed");
         return;
     }
     // StoreFASTXN == SaveAsTextFile: a directory of part files; a record is never split between two parts
@@ -647,6 +649,8 @@ void store(const Invocation& inv, const Output& out, const std::vector<std::stri
         snprintf(nm, sizeof nm, "/part%05ld", p);
         std::ofstream f(outp + nm, std::ios::binary);
         f.write(out_text.data() + pos, (std::streamsize)(end - pos));
+        f.close();
+        if (!f) die("write " + outp + nm + " failed");
         pos = end;
     }
 }
@@ -800,6 +804,8 @@ static int run_main(int argc, char** argv) {
             std::ofstream f(outdir + "/" + names[k], std::ios::binary);
             if (!f) die("cannot create " + outdir + "/" + names[k]);
             f.write(text.data(), (std::streamsize)text.size());
+            f.close();
+            if (!f) die("write " + outdir + "/" + names[k] + " failed");
         }
         bsk_destroy(c);
         return 0;
