@@ -108,6 +108,89 @@ BSK_HD uint64_t find_fastq_start(const uint8_t* buf, uint64_t n, uint64_t from, 
     return n;
 }
 
+// ---- FASTQ whose sequence / quality text is wrapped over several lines (SeqParser reads it: /root/reference/
+// bigseqkit-lib/helper.go:252-269) -- HOST side only: where a file may be cut (bsk_find_record_start, the staging
+// pipelines).  The shards themselves are rewritten to four lines per record on the device (capi.cpp).
+// A record starts at line p iff p begins with '@', the lines below it up to the first line that begins with '+' hold S > 0
+// bytes of bases, and the lines below the '+' line reach EXACTLY S bytes of qualities at a line end -- after which the
+// text ends or a line that begins with '@' follows.  A quality line that begins with '@' passes this for one record only
+// by accident; the test is therefore repeated on the records that follow (fastq_multiline_record_at).
+// Returns the byte after the record's last quality line (n when the text ends without a final line break), 0 = no record.
+inline uint64_t fastq_multiline_record_end(const uint8_t* buf, uint64_t n, uint64_t p) {
+    if (p >= n || buf[p] != '@') return 0;
+    uint64_t e = find_byte(buf, n, p, '\n');
+    if (e >= n) return 0;
+    uint64_t s = e + 1, S = 0;
+    for (;;) {  // sequence lines (none of a real record begins with '@': a candidate that needs one to be read as bases is a
+                // quality line followed by the next record's header -- as a place to cut it is passed over)
+        if (s >= n) return 0;
+        if (buf[s] == '+') break;
+        if (buf[s] == '@') return 0;
+        e = find_byte(buf, n, s, '\n');
+        if (e >= n) return 0;
+        S += e - s;
+        s = e + 1;
+    }
+    e = find_byte(buf, n, s, '\n');  // the '+' line
+    if (e >= n) return 0;
+    s = e + 1;
+    uint64_t Q = 0;
+    if (S == 0) {  // an empty record: one EMPTY quality line (the grammar asks for a quality line), or the end of the text
+        if (s >= n) return n;
+        if (buf[s] != '\n') return 0;
+        s += 1;
+        if (s < n && buf[s] != '@' && buf[s] != '\n') return 0;
+        return s;
+    }
+    while (Q < S) {  // quality lines
+        if (s >= n) return 0;
+        e = find_byte(buf, n, s, '\n');
+        Q += (e < n ? e : n) - s;
+        if (e >= n) return Q == S ? n : 0;
+        s = e + 1;
+    }
+    if (Q != S) return 0;
+    if (s < n && buf[s] != '@' && buf[s] != '\n') return 0;
+    return s;
+}
+inline bool fastq_multiline_record_at(const uint8_t* buf, uint64_t n, uint64_t p) {
+    // three records in a row (or fewer and the end of the text): a quality line that begins with '@' reads as a record of its
+    // own only by accident, and the accident has to repeat.  (Text wrapped at one or two bytes per line defeats any such
+    // test -- the lines carry no structure; files are wrapped at 50 - 80.)
+    uint64_t q = p;
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t e = fastq_multiline_record_end(buf, n, q);
+        if (e == 0) return false;
+        q = e;
+        while (q < n && buf[q] == '\n') ++q;  // (blank lines at the end of the text)
+        if (q >= n) return true;
+    }
+    return true;
+}
+// first record start at or after `from`, looking at most `limit` bytes ahead (n = none found)
+inline uint64_t find_fastq_start_multiline(const uint8_t* buf, uint64_t n, uint64_t from, uint64_t limit = 64ull << 20) {
+    if (from >= n) return n;
+    if (from == 0 && fastq_multiline_record_at(buf, n, 0)) return 0;
+    uint64_t j = from == 0 ? find_byte(buf, n, 0, '\n') : find_byte(buf, n, from - 1, '\n');
+    while (j < n) {
+        if (j + 1 < n && buf[j + 1] == '@' && fastq_multiline_record_at(buf, n, j + 1)) return j + 1;
+        if (j + 1 > from + limit) return n;
+        j = find_byte(buf, n, j + 1, '\n');
+    }
+    return n;
+}
+// where a host-resident FASTQ text may be cut.  The wrapped reading goes first: on a four-line file it names the same
+// record starts as the strict rule (a four-line record is a wrapped one), while the strict rule on a WRAPPED file can take
+// four full-width quality lines for a record ('@...', line, '+...', line of the same width, then a header).  The strict
+// rule still answers where the wrapped reading finds nothing it can confirm with a second record (a damaged tail).
+inline uint64_t find_fastq_cut(const uint8_t* buf, uint64_t n, uint64_t from) {
+    if (from >= n) return n;
+    const uint64_t wrapped = find_fastq_start_multiline(buf, n, from);
+    if (wrapped < n) return wrapped;
+    const uint64_t strict = find_fastq_start(buf, n, from);
+    return strict == ANCHOR_NONE ? n : strict;
+}
+
 // end of the shard once trailing blank lines are dropped: at most one '\n'
 // is kept after the last non-newline byte; a buffer of only newlines is empty.
 BSK_HD uint64_t effective_end(const uint8_t* buf, uint64_t n) {

@@ -414,7 +414,7 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
     while (cuts.back() < n) {
         size_t lo = cuts.back(), hi = n;
         if (n - lo > chunk) {
-            hi = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_start(h, n, lo + chunk) : (size_t)find_fasta_start(h, n, lo + chunk);
+            hi = format == BSK_FORMAT_FASTQ ? (size_t)find_fastq_cut(h, n, lo + chunk) : (size_t)find_fasta_start(h, n, lo + chunk);
             if (hi <= lo || hi > n) hi = n;
         }
         cuts.push_back(hi);

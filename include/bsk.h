@@ -110,7 +110,9 @@ int bsk_ctx_set(bsk_ctx* ctx, const char* key, const char* value);
  * bigseqkit/helper.go:148-178, bigseqkit-lib/helper.go:41-66.
  * Finds, on the HOST, the first record start at or after `from` in a window of
  * file bytes (used to cut a file into per-GPU shards that begin on a record).
- * Returns n if there is none. */
+ * FASTQ: four lines per record or wrapped over several lines (SeqParser reads both,
+ * bigseqkit-lib/helper.go:252-269); the window should hold the three records behind
+ * the answer (1 MiB does for reads).  Returns n if there is none. */
 int bsk_find_record_start(const uint8_t* buf, size_t n, size_t from, int format, size_t* out);
 
 /* ---- Stats  (bigseqkit-lib/stats.go:27-117, StatsReduce :128-137) ---------

@@ -228,3 +228,50 @@ def test_file_to_file_duplicate_on_multiline_fastq(tmp_path):
     tot = C.c_uint64()
     _lib.check(_lib.lib.bsk_store_close(st, C.byref(tot)))
     assert out.read_bytes() == want
+
+
+@pytest.mark.parametrize("width", [60, 13])
+def test_host_shard_in_small_staging_chunks(width, tmp_path, monkeypatch):
+    """the staging pipelines (bsk_stats_run on a host buffer, bsk_run_to_store) cut a wrapped host shard on record starts of
+    the wrapped grammar (round 4; before, a wrapped shard went as one piece)"""
+    import ctypes as C
+    monkeypatch.setenv("BSK_STAGE_BYTES", "20000")
+    rng = random.Random(3700 + width)
+    data = wrapped_fastq(rng, 3000, width)
+    assert len(data) > 5 * 20000
+    for opts in ({"All": True}, {}):
+        o = bsk.SeqKitStatsOptions()
+        for kk, v in opts.items():
+            getattr(o, kk)(v)
+        assert bsk.StatsString("input0", "N/A", frame(data, False), o) == oracle.stats_string(data, True, json.dumps(opts))
+    want = oracle.seq(data, True, '{"Reverse": true}')
+    out = tmp_path / "o.fq"
+    st = C.c_void_p()
+    _lib.check(_lib.lib.bsk_store_open(str(out).encode(), 1, C.byref(st)))
+    with bsk.Operator("SeqTransform", '{"Reverse": true}', 0) as op:
+        b = C.create_string_buffer(data, len(data))
+        nb, nr = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib.bsk_run_to_store(op.ctx, b, len(data), bsk.FORMAT_FASTQ, 0, st, 0, C.byref(nb), C.byref(nr)), op.ctx)
+    tot = C.c_uint64()
+    _lib.check(_lib.lib.bsk_store_close(st, C.byref(tot)))
+    assert out.read_bytes() == want
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rmdup_exchange_on_wrapped_shards(world, monkeypatch):
+    from test_translate_rmdup_gpu import _virtual_ranks
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(3800 + world)
+    seqs, recs = [], []
+    for i in range(1500):
+        s = seqs[rng.randrange(len(seqs))] if (i > 5 and rng.random() < 0.3) else "".join(rng.choice("ACGTacgt") for _ in range(rng.randint(1, 200)))
+        seqs.append(s)
+        q = [chr(rng.randint(35, 73)) for _ in s]
+        for k in range(50, len(s), 50):
+            if q[k] == "@":
+                q[k] = "A"     # ('@' at the start of a continuation line begins a record under the grammar)
+        q = "".join(q)
+        recs.append("@r%d c\n%s\n+\n%s\n" % (i, "\n".join(s[j:j + 50] for j in range(0, len(s), 50)), "\n".join(q[j:j + 50] for j in range(0, len(q), 50))))
+    data = "".join(recs).encode()
+    for o in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}):
+        assert _virtual_ranks(data, True, o, world) == oracle.rmdup(data, True, json.dumps(o))

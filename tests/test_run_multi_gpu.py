@@ -86,6 +86,51 @@ def test_two_workers_write_what_one_device_writes(case, merge, tmp_path):
         assert os.path.isfile(two) and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
 
 
+def wrapped_fastq(nrec, seed, width=60):
+    """the same kind of reads with bases and qualities wrapped at `width` (SeqParser reads them, helper.go:252-269); first
+    quality characters '@' / '+' and continuation lines that begin with '+' included"""
+    rng = random.Random(seed)
+    seqs, out = [], []
+    for i in range(nrec):
+        if i > 20 and rng.random() < 0.25:
+            s = seqs[rng.randrange(len(seqs))]
+        else:
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(40, 400)))
+            if rng.random() < 0.05:
+                k = rng.randrange(len(s) - 12)
+                s = s[:k] + "ACGTTGCAAGCT" + s[k + 12:]
+        seqs.append(s)
+        q = [chr(rng.randint(35, 73)) for _ in s]
+        for k in range(width, len(s), width):
+            q[k] = "+" if rng.random() < 0.2 else ("A" if q[k] == "@" else q[k])
+        if i % 37 == 5:
+            q[0] = "@"
+        q = "".join(q)
+        out.append("@read%d some description\n%s\n+\n%s\n" % (i, "\n".join(s[j:j + width] for j in range(0, len(s), width)),
+                                                              "\n".join(q[j:j + width] for j in range(0, len(q), width))))
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[2] == "fq"], ids=[c[0] for c in CASES if c[2] == "fq"])
+def test_two_workers_on_a_wrapped_fastq_file(case, tmp_path):
+    """Round 4: a FASTQ file whose records are wrapped over several lines is cut on record starts too (bsk_find_record_start
+    reads the wrapped grammar), every worker rewrites its shard to four lines per record on the device as a single shard
+    always did, and the rmdup exchange takes such shards (bsk_rmdup_dist_keys used to refuse them)."""
+    name, args, kind = case
+    data = wrapped_fastq(12000, 21)
+    src = str(tmp_path / "in.fq")
+    open(src, "wb").write(data)
+    one, two = str(tmp_path / "one.out"), str(tmp_path / "two.out")
+    run([CLI] + args + [src, "-o", one, "--merge"])
+    run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0,0,0", "--share-gpu", "--"] + args + [src, "-o", two, "--merge"])
+    want, got = read_out(one), read_out(two)
+    assert len(want) > 0 and got == want
+    if name == "stats":
+        return
+    for sargs in (["stats", "-a", "-T"],):
+        assert run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0,0", "--share-gpu", "--"] + sargs + [src]) == run([CLI] + sargs + [src])
+
+
 def test_stats_and_grep_count_reduce_over_the_workers(tmp_path):
     data = fastq(30000, 13)
     src = str(tmp_path / "in.fq")
