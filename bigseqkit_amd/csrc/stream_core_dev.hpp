@@ -164,6 +164,24 @@ __device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ buf, uint64_
         if (idx + b < n) w[b >> 2] |= (uint32_t)buf[idx + b] << ((b & 3) * 8);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
+// the same as a non-temporal load -- for the passes that read every byte of the shard once and come back to none
+// (sink_tile_nt below)
+__device__ __forceinline__ uint4 load16_nt(const uint8_t* __restrict__ buf, uint64_t n, uint64_t idx) {
+    if (idx + 16 <= n) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(buf + idx));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 16; ++b)
+        if (idx + b < n) w[b >> 2] |= (uint32_t)buf[idx + b] << ((b & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <bool NT>
+__device__ __forceinline__ uint4 load16_tile(const uint8_t* __restrict__ buf, uint64_t n, uint64_t idx) {
+    if constexpr (NT) return load16_nt(buf, n, idx);
+    else return load16(buf, n, idx);
+}
 
 struct Piece {  // what a lane keeps of one 16-byte piece (dense path; packed flags, see pack_flags)
     uint32_t m_nl_a;  // newlines in the low nibbles, a in the high nibbles   (a = q>=20 for FASTQ, gap for FASTA)
@@ -263,6 +281,16 @@ template <class S, class = void>
 struct sink_records4 { static constexpr bool value = false; };
 template <class S>
 struct sink_records4<S, decltype((void)S::RECORDS4)> { static constexpr bool value = S::RECORDS4; };
+
+// Non-temporal tile loads: a sink says TILE_NT = true when its pass never comes back to a byte of the shard.  Measured at
+// C2 / C5 (scripts/history/r04_nt_loads.sh, r04_nt_more.sh): k_stats 16.42 -> 15.39 ms (0.761 -> 0.812 of the HBM peak),
+// k_rmdup_stream 7.45 -> 7.15.  NOT for the sinks that fetch header bytes again (k_names 20.0 -> 24.5 ms with it), k_filter
+// (3.17 -> 3.29), k_index / k_subseq_stream (no change), `stats -a` (20.5 -> 20.3 but one spilled register), any FASTA pass
+// (`stats -a` at 20 GB 6.75 -> 7.80).
+template <class S, class = void>
+struct sink_tile_nt { static constexpr bool value = false; };
+template <class S>
+struct sink_tile_nt<S, decltype((void)S::TILE_NT)> { static constexpr bool value = S::TILE_NT; };
 
 // WHEN the deferred sink runs.  REC_TILE_END = true (default): at the end of a tile once the window is half full -- the 16
 // data registers of the tile are dead there, which is what lets k_index / k_names keep 72 registers without a spill.
@@ -365,9 +393,10 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
     const uint64_t idx0 = rs & ~(uint64_t)15;
     const uint64_t ntiles = (re - idx0 + TILE - 1) / TILE;
 
+    constexpr bool TILE_NT = sink_tile_nt<Sink>::value && FASTQ && !ALL;
     uint4 cur[NPIECE], nxt[NPIECE];
 #pragma unroll
-    for (int p = 0; p < NPIECE; ++p) cur[p] = load16(buf, n, idx0 + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
+    for (int p = 0; p < NPIECE; ++p) cur[p] = load16_tile<TILE_NT>(buf, n, idx0 + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
 
     for (uint64_t t = 0; t < ntiles; ++t) {
         const uint64_t tile_idx = idx0 + t * TILE;
@@ -376,7 +405,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
         if (BSK_PREFETCH && t + 1 < ntiles) {
 #pragma unroll
             for (int p = 0; p < NPIECE; ++p)
-                nxt[p] = load16(buf, n, tile_idx + TILE + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
+                nxt[p] = load16_tile<TILE_NT>(buf, n, tile_idx + TILE + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
         }
         const bool edge = (tile_idx < rs) || (tile_idx + TILE > re);  // wave-uniform
 
@@ -792,14 +821,14 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                     quiet_tiles = 0;
                     const uint64_t tgt_idx = idx0 + tgt * TILE;
 #pragma unroll
-                    for (int p = 0; p < NPIECE; ++p) cur[p] = load16(buf, n, tgt_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
+                    for (int p = 0; p < NPIECE; ++p) cur[p] = load16_tile<TILE_NT>(buf, n, tgt_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
                     continue;
                 }
             }
 #pragma unroll
             for (int p = 0; p < NPIECE; ++p)
                 cur[p] = BSK_PREFETCH ? nxt[p]
-                                      : load16(buf, n, tile_idx + TILE + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
+                                      : load16_tile<TILE_NT>(buf, n, tile_idx + TILE + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16);
         }
     }
 

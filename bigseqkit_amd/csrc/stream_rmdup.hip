@@ -60,6 +60,7 @@ __device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
 template <bool DPP, bool FOLD, bool K2>
 struct RmdupSink {
     static constexpr bool TILE_HOOK = true;
+    static constexpr bool TILE_NT = true;  // every byte once: non-temporal tile loads (stream_core_dev.hpp)
     IndexDev D;
     HashDev H;
     TileLds T;                  // this wave's tile in LDS (tile_lds_dev.hpp)

@@ -88,6 +88,7 @@ struct StatsSinkT {
     // both rows run their sink when the window of 256 is full (stream_core_dev.hpp): the default row has LDS and registers
     // for nothing else at 7 waves per SIMD, and `-a` measured 21.0 ms that way against 22.6 at the end of tiles with 512
     static constexpr bool REC_TILE_END = false;
+    static constexpr bool TILE_NT = !ROLES;  // the default row reads every byte once (non-temporal tile loads: stream_core_dev.hpp)
     uint32_t* s_hist;
     StatsDev D;
     // per-lane accumulators, reduced once per wave at kernel end
@@ -275,8 +276,13 @@ struct StatsSinkT {
 #ifndef BSK_STATS_WAVES_ALL
 #define BSK_STATS_WAVES_ALL 5
 #endif
+// FASTQ default row: with non-temporal tile loads the pass is bound by HBM alone -- 15.42 ms at 6, 7 and 8 waves per SIMD
+// (scripts/history/r04_nt_waves.sh); at 6 nothing spills (at 7: two registers)
+#ifndef BSK_STATS_WAVES_FQ
+#define BSK_STATS_WAVES_FQ 6
+#endif
 #if BSK_STATS_WAVES
-#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu((ALL && FASTQ) ? BSK_STATS_WAVES_ALL : BSK_STATS_WAVES, 8)))
+#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu((ALL && FASTQ) ? BSK_STATS_WAVES_ALL : (FASTQ ? BSK_STATS_WAVES_FQ : BSK_STATS_WAVES), 8)))
 #else
 #define BSK_STATS_ATTR
 #endif

@@ -1,4 +1,4 @@
-"""The headline kernels must not spill: `k_stats<FASTQ, default, DPP>` runs at 7 waves per SIMD with every value in registers.
+"""The headline kernels must not spill: `k_stats<FASTQ, default, DPP>` runs at 6 waves per SIMD (7 until round 4) with every value in registers.
 A harmless-looking extra branch in its range loop once cost two spilled VGPRs and 1 ms of 17 at 100 GB without any test
 noticing; this compiles the file for gfx950 (no GPU needed) and reads the compiler's resource report."""
 import os
@@ -20,9 +20,10 @@ def test_k_stats_keeps_its_registers(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     blocks = re.split(r"remark: Function Name: ", r.stderr)
     seen = set()
-    # k_stats<FASTQ = true, ALL = false, DPP = true>: the variant that runs, 7 waves per SIMD;
+    # k_stats<FASTQ = true, ALL = false, DPP = true>: the variant that runs; 6 waves per SIMD since its tile loads are
+    # non-temporal (round 4: bound by HBM alone, the same 15.4 ms at 6 / 7 / 8 waves; at 7 two registers spill);
     # k_stats<true, true, true>: `stats -a` by line roles, VALU-bound at 5 waves (6 waves spilled 178 registers: 44 ms for 25)
-    want = {"7k_statsILb1ELb0ELb1E": 7, "7k_statsILb1ELb1ELb1E": 5}
+    want = {"7k_statsILb1ELb0ELb1E": 6, "7k_statsILb1ELb1ELb1E": 5}
     for b in blocks:
         name = b.split(" ", 1)[0]
         key = next((k for k in want if k in name), None)
