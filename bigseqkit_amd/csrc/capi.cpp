@@ -66,8 +66,7 @@ void validate_stats(bsk_ctx* c) {  // bigseqkit-lib/stats.go:27-46
     std::string uniq;
     for (char ch : g)
         if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
-    if ((int)uniq.size() > MAX_GAP_LETTERS)
-        throw OptError("libbsk: at most 8 distinct gap letters are supported by the HIP path");
+    // (more than MAX_GAP_LETTERS distinct letters: counted by a pass of their own over the record table, stats_run_device)
 }
 
 int ensure_ranges(bsk_ctx* c, uint32_t nranges) {
@@ -358,10 +357,13 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     D.pred.k30 = (0x80u - t30) * 0x01010101u;
     D.pred.ngap = 0;
     for (int k = 0; k < MAX_GAP_LETTERS; ++k) D.pred.gap_rep[k] = 0;
+    std::string gap_letters;
     {
         std::string uniq;
         for (char ch : c->opts.s("GapLetters"))
             if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
+        gap_letters = uniq;
+        if ((int)uniq.size() > MAX_GAP_LETTERS) uniq.clear();  // the streaming pass counts none of them: launch_gap_set_count below
         for (char ch : uniq) D.pred.gap_rep[D.pred.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;
         uint32_t top = 0;
         for (char ch : uniq) top = std::max(top, (uint32_t)(uint8_t)ch);
@@ -397,6 +399,15 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
                                 !fastq ? chunk : 0));
     }
     if (!fastq) HIP_TRY(c, launch_stats_stitch(nranges, D, st));
+    if (all && (int)gap_letters.size() > MAX_GAP_LETTERS) {
+        // the reference counts any number of gap letters (stats.go:36-43, 102: byteutil.CountBytes); beyond the eight the
+        // streaming pass holds in registers they are counted over the record table (it is built for this alone)
+        const int rci = build_index(c, d_buf, n, format, st);
+        if (rci != BSK_OK) return rci;
+        uint32_t set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (char ch : gap_letters) set[(uint8_t)ch >> 5] |= 1u << ((uint8_t)ch & 31u);
+        HIP_TRY(c, launch_gap_set_count(d_buf, c->table, set, fastq, D.vec + 2, st));
+    }
     return BSK_OK;
 }
 

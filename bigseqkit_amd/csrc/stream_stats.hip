@@ -12,10 +12,12 @@
 // ============================================================================
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "anchor.hpp"
 #include "anchor_wave_dev.hpp"
+#include "index.hpp"
 #include "stream_core_dev.hpp"
 #include "stream_stats.hpp"
 
@@ -541,6 +543,37 @@ __global__ __launch_bounds__(1024) void k_hist_extent(const uint64_t* __restrict
 
 hipError_t launch_hist_extent(const uint64_t* hist, uint32_t cap, uint64_t* out, hipStream_t st) {
     hipLaunchKernelGGL(k_hist_extent, dim3(1), dim3(1024), 0, st, hist, cap, out);
+    return hipGetLastError();
+}
+
+namespace {
+struct GapSet { uint32_t w[8]; };
+__global__ __launch_bounds__(256) void k_gap_set_count(const uint8_t* __restrict__ buf, RecordTable t, GapSet S, int fastq,
+                                                       unsigned long long* __restrict__ gap_slot) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    uint64_t acc = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < t.n; r += nwaves) {
+        const uint64_t from = t.start[r] + t.l_head[r] + 1;
+        // FASTQ: the one sequence line; FASTA: the text up to the next record (its line breaks are no sequence bytes)
+        const uint64_t to = fastq ? from + t.l_seq[r] : t.start[r + 1];
+        for (uint64_t i = from + lane; i < to; i += 64) {
+            const uint8_t c = buf[i];
+            if (c != '\n' && ((S.w[c >> 5] >> (c & 31u)) & 1u)) ++acc;
+        }
+    }
+    acc = wave_sum_u64(acc);
+    if (lane == 0 && acc) atomicAdd(gap_slot, (unsigned long long)acc);
+}
+}  // namespace
+
+hipError_t launch_gap_set_count(const uint8_t* buf, const RecordTable& t, const uint32_t (&set)[8], bool fastq, uint64_t* gap_slot,
+                                hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    GapSet S;
+    for (int i = 0; i < 8; ++i) S.w[i] = set[i];
+    const uint64_t blocks = std::min<uint64_t>((t.n + 3) / 4, 256ull * 32ull);
+    hipLaunchKernelGGL(k_gap_set_count, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, S, fastq ? 1 : 0, (unsigned long long*)gap_slot);
     return hipGetLastError();
 }
 

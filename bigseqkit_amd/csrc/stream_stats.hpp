@@ -55,6 +55,12 @@ constexpr uint32_t RF_MID = 16u, RF_SKIP_SEQ = 32u;
 hipError_t launch_prep(bool fastq, const uint8_t* buf, uint64_t n, uint64_t chunk, uint32_t nranges,
                        uint64_t* anchors, uint32_t* queue, hipStream_t st, bool line_mode = false, uint64_t* raw = nullptr);
 hipError_t launch_stats_stitch(uint32_t nranges, const StatsDev& D, hipStream_t st);
+// more than MAX_GAP_LETTERS gap letters (`stats -a -G ...`; the reference takes any number, bigseqkit-lib/stats.go:36-43,
+// 102): the streaming pass counts none and this pass adds, over the record table of the shard, the sequence bytes that are
+// in the 256-bit set -- a rare path, one wave per record
+struct RecordTable;
+hipError_t launch_gap_set_count(const uint8_t* buf, const RecordTable& t, const uint32_t (&set)[8], bool fastq, uint64_t* gap_slot,
+                                hipStream_t st);
 // *out := one past the highest non-zero entry of hist[0, cap)
 hipError_t launch_hist_extent(const uint64_t* hist, uint32_t cap, uint64_t* out, hipStream_t st);
 // skip_chunk (FASTA default row, anchors from launch_prep with `raw`): the nominal chunk size; 0: read every byte

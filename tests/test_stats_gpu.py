@@ -164,6 +164,22 @@ def test_gap_letters_and_encoding_options():
     check_parity(data, True, {"All": True, "Config": {"SeqType": "dna"}})
 
 
+@pytest.mark.parametrize("gaps", ["-.*NnXx ~", "ACGTNacgtn-.", "".join(chr(c) for c in range(33, 127))])
+def test_more_than_eight_gap_letters(gaps, monkeypatch):
+    """the reference counts any number of gap letters (stats.go:36-43, 102); beyond the eight the streaming pass keeps in
+    registers they are counted by a pass over the record table (round 4; before: refused)"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(len(gaps))
+    fq = seqgen.random_fastq(rng, 900, 0, 150, alphabet="ACGTNacgtn-.*Xx")
+    fa = seqgen.random_fasta(rng, 200, 0, 900, width=60, alphabet="ACGTNacgtn-.*Xx")
+    for on_device in (True, False):
+        check_parity(fq, True, {"All": True, "GapLetters": gaps}, on_device=on_device)
+        check_parity(fa, False, {"All": True, "GapLetters": gaps}, on_device=on_device)
+    check_parity(fq, True, {"GapLetters": gaps})          # without -a nothing is counted
+    one_line = b">chr1 one line\n" + b"ACGT-N.x" * 60000 + b"\n>chr2\n" + (b"AC-TN" * 12 + b"\n") * 3000
+    check_parity(one_line, False, {"All": True, "GapLetters": gaps})
+
+
 def test_host_resident_shard():
     rng = random.Random(13)
     data = seqgen.random_fastq(rng, 800, 0, 150)
