@@ -616,8 +616,20 @@ def main():
     if dist_on and world == 1:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("BSK_DIST_SINGLE_RANK_COLLECTIVES", "1")
+    if dist_on or args.launch_check:
+        # RCCL (and gloo) write their greetings to file descriptor 1 -- RCCL's version banner appears when the communicator is
+        # first used or torn down, i.e. AFTER the result line (seen with one rank over RCCL) -- and the contract is ONE JSON
+        # line on stdout.  Descriptor 1 becomes the ranks' stderr; sys.stdout is re-opened on the real one.
+        sys.stdout.flush()
+        _real_out = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(_real_out, "w")
     if args.launch_check:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -41,6 +41,14 @@ def shard_bounds(data, world, fmt):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def _active(group=None):
+    """a process group whose collectives are to be run: more than one rank -- or ONE rank when
+    BSK_DIST_SINGLE_RANK_COLLECTIVES=1 asks for it (bench.py BSK_BENCH_DIST_SINGLE: how a one-GPU box executes the RCCL calls
+    of the N-rank path at all)"""
+    import torch.distributed as dist
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("BSK_DIST_SINGLE_RANK_COLLECTIVES") == "1")
+
+
 def coll_device(device, group=None):
     """The device a collective's tensors must live on: the rank's GPU under RCCL ("nccl"), the host under gloo (CPU
     tests; two ranks sharing one GPU in bench.py's functional check)."""
@@ -86,7 +94,7 @@ def _all_gather(parts, t, group=None):
 
 def barrier(group=None):
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.barrier(group=group)
 
 
@@ -94,7 +102,7 @@ def all_reduce_stats_vector(vec, group=None):
     """StatsReduce across ranks: ONE sum all-reduce of the stats vector (int64 tensor on the
     rank's device).  512 KB at hist_cap = 65536: latency-bound, not bandwidth-bound."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         cd = coll_device(vec.device, group)
         if cd != vec.device:  # gloo: through the host
             tmp = vec.to(cd)
@@ -114,7 +122,7 @@ def exchange_stats_overflow(op, vec, group=None, total=None):
     None reads it from the device (one synchronising copy)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not _active(group):
         return 0
     if total is None:
         total = int(vec[5].item())
@@ -154,7 +162,7 @@ def collect_reduced(op, vec, group=None, reduce=True):
     from .api import _collect_map
     if reduce:  # (False: the caller has issued all_reduce_stats_vector itself, e.g. between timing events)
         all_reduce_stats_vector(vec, group)
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _active(group)
     dvec = C.c_void_p(vec.data_ptr())
     try:
         m = _collect_map(op, dvec)
@@ -177,7 +185,7 @@ def all_reduce_count(count, device="cpu", group=None):
     import torch
     import torch.distributed as dist
     t = torch.tensor([int(count)], dtype=torch.int64, device=coll_device(device, group))
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         _all_reduce(t, group=group)
     return int(t.item())
 
@@ -187,7 +195,7 @@ def all_reduce_max_float(value, device, group=None):
     import torch
     import torch.distributed as dist
     t = torch.tensor([float(value)], dtype=torch.float64, device=coll_device(device, group))
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         _all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -196,7 +204,7 @@ def all_gather_floats(values, device, group=None):
     """[[values of rank 0], ..., [values of rank world-1]] (bench.py: per-rank kernel times, barrier skew)"""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not _active(group):
         return [[float(v) for v in values]]
     cd = coll_device(device, group)
     mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=cd)
@@ -318,7 +326,7 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
     # (BSK_DIST_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank still takes the exchange -- every collective of the
     # N-rank path then runs over the backend, which is how a one-GPU box executes the RCCL calls at all: bench.py
     # BSK_BENCH_DIST_SINGLE)
-    multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("BSK_DIST_SINGLE_RANK_COLLECTIVES") == "1")
+    multi = _active(group)
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
     dev = shard.device
@@ -414,7 +422,7 @@ def _all_gather_int(value, device, group=None):
     """[value of rank 0, ..., value of rank world-1] (a list of one element without a process group)"""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not _active(group):
         return [int(value)], 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = coll_device(device, group)
@@ -481,7 +489,7 @@ def store_fastx(path, payload, group=None, device=None):
     import os
     import torch
     import torch.distributed as dist
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _active(group)
     if not multi:
         with open(path, "wb") as f:
             f.write(payload)

@@ -153,27 +153,38 @@ def worker(devices, share, cli_args):
             os.sched_setaffinity(0, cpus)  # the reader / writer threads of this worker stay next to its GPU
         except OSError:
             pass
-    if world > 1:
+    # BSK_DIST_SINGLE_RANK_COLLECTIVES=1: ONE worker still forms a process group and runs every collective of the N-worker
+    # path (dist._active) -- how a one-GPU box executes the RCCL calls of this entry point at all (tests/test_run_multi_gpu.py)
+    grouped = world > 1 or os.environ.get("BSK_DIST_SINGLE_RANK_COLLECTIVES") == "1"
+    if grouped:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # (the collective libraries greet on stdout -- "[Gloo] Rank 0 is connected to ..." -- and stdout is where `stats`,
-        # `grep -C` and `-o -` put their RESULT: while the group forms, file descriptor 1 is the workers' stderr)
+        if "MASTER_PORT" not in os.environ:  # (one worker started by hand: any free port)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        # The collective libraries greet on file descriptor 1 -- "[Gloo] Rank 0 is connected to ..." while the group forms,
+        # RCCL's version banner when its communicator is first used (after a `stats` table had been printed: found by
+        # running one worker over RCCL, tests/test_run_multi_gpu.py) -- and stdout is where `stats`, `grep -C` and `-o -`
+        # put their RESULT.  For the life of a grouped worker descriptor 1 IS its stderr; results go to the real stdout
+        # through sys.stdout, which is re-opened on a duplicate of it.
         sys.stdout.flush()
-        saved = os.dup(1)
+        real_out = os.dup(1)
         os.dup2(2, 1)
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
-            else:
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
-            bdist.barrier()
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
+        sys.stdout = os.fdopen(real_out, "w")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        bdist.barrier()
     try:
         return _work(plan, use, opts, path, world, rank, device, dev, torch, bsk, _lib, bdist, lib, check)
     finally:
-        if world > 1:
+        if grouped:
+            sys.stdout.flush()
             dist.destroy_process_group()
 
 
@@ -285,7 +296,7 @@ def _records(use, op_name, h, n, fmt, ojs, out_file, merge, rank, world, device,
             open(os.path.join(out_file, "part%05d" % rank), "ab").close()
         return 0
     # ---- one file: offsets from an all_gather of the sizes, every worker places its own part (FileStore's order)
-    sizes, _ = bdist._all_gather_int(nb.value, dev) if world > 1 else ([nb.value], 0)
+    sizes, _ = bdist._all_gather_int(nb.value, dev)   # (one element without a group)
     off, total = sum(sizes[:rank]), sum(sizes)
     if to_stdout:
         for r in range(world):               # in turn

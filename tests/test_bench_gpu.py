@@ -21,8 +21,9 @@ def run_bench(args, env_extra=None):
     env.pop("LOCAL_RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines   # ONE JSON line on stdout (the collective libraries' greetings go to stderr)
+    return json.loads(lines[0])
 
 
 def test_bench_single_gpu_line_small():

@@ -131,6 +131,27 @@ def test_two_workers_on_a_wrapped_fastq_file(case, tmp_path):
         assert run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0,0", "--share-gpu", "--"] + sargs + [src]) == run([CLI] + sargs + [src])
 
 
+@pytest.mark.parametrize("args", [["rmdup", "-s"], ["stats", "-a", "-T"], ["grep", "-s", "-p", "ACGTTGCAAGCT", "-C"], ["seq", "-n", "-i"]],
+                         ids=["rmdup", "stats", "grep-count", "seq"])
+def test_one_worker_over_rccl(args, tmp_path):
+    """BSK_DIST_SINGLE_RANK_COLLECTIVES=1: one worker, backend "nccl" -- the process group, the barrier, the all-reduces of
+    stats / grep -C, the all_gather + all_to_all exchange of rmdup and the size scan of --merge run over RCCL on the one GPU
+    of the box (round 4; with more ranks than GPUs they run over gloo)."""
+    data = fastq(20000, 31)
+    src = str(tmp_path / "in.fq")
+    open(src, "wb").write(data)
+    env = {"BSK_DIST_SINGLE_RANK_COLLECTIVES": "1", "BSK_A2A_MAX_BYTES": "100000"}
+    if args[0] in ("stats",) or args[-1] == "-C":
+        want = run([CLI] + args + [src])
+        got = run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0", "--"] + args + [src], env)
+        assert got == want and len(want) > 0
+        return
+    one, two = str(tmp_path / "one.out"), str(tmp_path / "two.out")
+    run([CLI] + args + [src, "-o", one, "--merge"])
+    run([sys.executable, "-m", "bigseqkit_amd.run", "--devices", "0", "--"] + args + [src, "-o", two, "--merge"], env)
+    assert len(read_out(one)) > 0 and read_out(two) == read_out(one)
+
+
 def test_stats_and_grep_count_reduce_over_the_workers(tmp_path):
     data = fastq(30000, 13)
     src = str(tmp_path / "in.fq")
