@@ -49,6 +49,44 @@ __device__ __forceinline__ uint64_t k2_finish(uint64_t b0, uint64_t b1, uint64_t
     return t;
 }
 
+// ---- the GROUPING key of the byte-verifying `rmdup -s` (round 5) ------------------------------------------------------
+// When the bytes of every duplicate are compared with its survivor's (ops_host_rmdup.cpp, the default), the key only
+// GROUPS: its value never reaches the output, so it need not be the reference's XXH64 -- whose four serial accumulator
+// chains, merge, tail and avalanche were 40 % of the vector instructions of k_rmdup_stream.  This one has no
+// chain at all: the subject is cut into 16-byte chunks (the last one zero padded), chunk c is four dwords w0..w3, and with
+// two independent key streams K, K' (eight dwords per chunk position, splitmix64 of the position)
+//      a  += (w0 + K0) * (w1 + K1) + (w2 + K2) * (w3 + K3)         (32 x 32 -> 64 bit products: one v_mad_u64_u32 each)
+//      a' += (w0 + K0') * (w1 + K1') + (w2 + K2') * (w3 + K3')
+// -- the NH family of UMAC (Black, Halevi, Krawczyk, Krovetz, Rogaway 1999): two subjects of equal length collide in one
+// 64-bit sum with probability <= 2^-32 over the keys, in both with 2^-64 -- summed over the chunks in ANY order, so the
+// four lanes of a quad take chunks c = k, k + 4, ... and add up with two DPP steps.  Positions repeat every 64 chunks
+// (1 KiB); a lane that passes its 16th, 32nd, ... chunk stirs its sums (rotate, multiply) so that chunks 1 KiB apart do
+// not commute.  The two sums, the length and a multiply-xorshift finish give the key (its LOW bits choose the radix
+// bucket).  A collision costs a second round with XXH64 + k2 (the path that exists and is tested), never a wrong answer.
+// tests/test_rmdup_keys_gpu.py restates it in Python.
+constexpr uint32_t GKEY_POS = 64;                 // chunk positions with keys of their own
+constexpr uint32_t GKEY_BYTES = GKEY_POS * 32;    // 2 KiB of LDS per block
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// dword j (0..7) of chunk position p: K0..K3 then K0'..K3'
+__host__ __device__ __forceinline__ uint32_t gkey_word(uint32_t p, uint32_t j) {
+    const uint64_t v = splitmix64(0x6b73625f67726f75ull + (uint64_t)(p * 4u + (j >> 1)));
+    return (j & 1u) ? (uint32_t)(v >> 32) : (uint32_t)v;
+}
+__device__ __forceinline__ uint64_t gkey_stir1(uint64_t a) { return rotl64(a, 29) * P1; }
+__device__ __forceinline__ uint64_t gkey_stir2(uint64_t a) { return rotl64(a, 31) * P2; }
+__device__ __forceinline__ uint64_t gkey_finish(uint64_t a1, uint64_t a2, uint64_t len) {
+    uint64_t h = (a1 + len) * P1 + rotl64(a2, 32) * P2;
+    h ^= h >> 32;
+    h *= P3;
+    h ^= h >> 29;
+    return h;
+}
+
 // lower8 on four bytes at once
 __device__ __forceinline__ uint32_t fold4(uint32_t x) {
     const uint32_t ge_a = (x & 0x7F7F7F7Fu) + 0x3F3F3F3Fu, ge_z1 = (x & 0x7F7F7F7Fu) + 0x25252525u;

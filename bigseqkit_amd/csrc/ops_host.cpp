@@ -211,11 +211,11 @@ int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     uint64_t chunk = 0;  // nominal bytes per range (prep_ranges)
     auto launch_pass = [&](int blocks, const uint64_t* anchors, uint32_t nranges, uint32_t* queue, const IndexDev& D) -> hipError_t {
         if (F) return launch_filter(c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, *F, st);
-        if (hash) return launch_rmdup_stream(c->use_dpp, hash->fold, hash->k2, blocks, d_buf, n, anchors, nranges, queue, D, HD, st);
+        if (hash) return launch_rmdup_stream(c->use_dpp, hash->fold, hash->mode(), blocks, d_buf, n, anchors, nranges, queue, D, HD, st);
         return launch_index(fastq, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, fastq ? 0 : chunk);
     };
     const int per_cu = F ? filter_max_blocks_per_cu(c->use_dpp)
-                         : (hash ? rmdup_stream_max_blocks_per_cu(c->use_dpp, hash->fold, hash->k2) : index_max_blocks_per_cu(fastq, c->use_dpp));
+                         : (hash ? rmdup_stream_max_blocks_per_cu(c->use_dpp, hash->fold, hash->mode()) : index_max_blocks_per_cu(fastq, c->use_dpp));
     const int blocks = std::max(1, c->num_cus * per_cu);
     uint32_t nranges = 0;
     int rcp = prep_ranges(c, d_buf, n, fastq, blocks, st, &nranges, &chunk);

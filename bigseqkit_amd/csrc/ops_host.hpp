@@ -24,7 +24,9 @@ constexpr uint64_t STRICT_FASTQ_FLAGS = 1u | 2u | 4u | 8u | 16u;
 int normalize_multiline_fastq(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st, const uint8_t** d_out, size_t* n_out);
 int build_index_filtered(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F);
 // the record table and, with hash != null (unfiltered FASTQ), the two keys of every record's sequence in c->d_keys / c->d_keys2
-struct HashReq { bool fold; bool k2 = true; };  // k2 = false: k1 alone (the caller compares the bytes; c->d_keys2 is not written)
+// k2 = false: k1 alone (the caller compares the bytes; c->d_keys2 is not written); group: k1 is the chain-free grouping key of
+// hash_dev.hpp instead of XXH64 (only with k2 = false: a key whose value nothing but the grouping sees)
+struct HashReq { bool fold; bool k2 = true; bool group = false; int mode() const { return k2 ? 1 : (group ? 2 : 0); } };
 int build_index_light(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStream_t st);  // FASTA, from the '>' bytes alone (translate)
 int build_index_ex(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, const FilterDev* F, const HashReq* hash);
 void validate_seq_opts(bsk_ctx* c);

@@ -40,6 +40,8 @@
 
 namespace bsk {
 
+static_assert(SEG_TILE == 4096, "k_rmdup_place (ops_rmdup.hip, SEG_TILE_BYTES) writes first4k[] for tiles of this size");
+
 // ---------------------------------------------------------------------------
 // rmdup  (bigseqkit/rmdup.go:70-108 + bigseqkit-lib/rmdup.go)
 // ---------------------------------------------------------------------------
@@ -162,13 +164,17 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     uint64_t* tk = nullptr;
     uint32_t* d_first = nullptr;
     bool by_buckets = false;
+    bool placed = false;  // sizes, comparison, offsets and segment list came from the one pass of k_rmdup_place
     // verify (default): k1 alone groups and the bytes decide -- the pass computes one key, nothing gathers second keys; only a
     // shard on which the comparison finds two different sequences under one k1 goes round again with both keys
     bool with_k2 = !verify_bytes;
     SeqParams F;
     for (;;) {
     if (by_keys) {
-        const HashReq hq{o.b("IgnoreCase"), with_k2};
+        // (k1 alone groups and the bytes decide: the key's VALUE is seen by nothing but the grouping, so it is the chain-free
+        // grouping key of hash_dev.hpp, not XXH64 -- `rmdup_hash=xxh64` keeps the reference's function there too)
+        HashReq hq{o.b("IgnoreCase"), with_k2};
+        hq.group = !with_k2 && !c->tune.is("rmdup_hash", "xxh64");
         rc = build_index_ex(c, d_buf, n, format, st, nullptr, &hq);
     } else {
         rc = build_index(c, d_buf, n, format, st);
@@ -253,7 +259,26 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
             rc = with_k2 ? rmdup_settle_overflow(c, d_first, st, c->h_ctl[3]) : BSK_OK;  // (k1 alone: no list, the bytes tell)
             if (rc == BSK_ERR_FILTER_FALLBACK) by_buckets = false;  // (the list did not fit: the table path compares bytes)
             else if (rc != BSK_OK) return rc;
-            else if (verify_bytes) {
+            else if (verify_bytes && !c->tune.is("segcopy", "off") && !c->tune.is("rmdup_place", "off")) {
+                // round 5: the comparison, the output offsets and the segment list of the copy in ONE pass over the table
+                // (k_rmdup_place: decoupled look-back) instead of verify + three scan launches + segment build + first-of-tile
+                rc = grow(c, &c->d_seg_src, &c->seg_src_cap, N + 1, N / 8 + 16);
+                if (rc != BSK_OK) return rc;
+                rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles((uint64_t)n + 1) + 1, 64);  // (survivors are copies: no more output than input)
+                if (rc != BSK_OK) return rc;
+                {
+                    const char* e = c->tune.get("long_bytes");
+                    c->long_thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+                }
+                const uint64_t nb = rmdup_place_blocks(N);
+                uint64_t* chain = c->d_scan_tmp;  // [nb] chain words + the ticket (ensure_record_scratch: 3 nb + 6 words)
+                HIP_TRYX(c, hipMemsetAsync(chain, 0, (nb + 1) * sizeof(uint64_t), st));
+                HIP_TRYX(c, hipMemsetAsync(c->d_fin, 0, 5 * sizeof(uint64_t), st));  // FIN_TOTAL .. FIN_OTHER
+                Timed t(c, "k_rmdup_place", st);
+                HIP_TRYX(c, launch_rmdup_place(d_buf, n, c->table, P, d_first, chain, reinterpret_cast<uint32_t*>(chain + nb), c->d_out_off,
+                                               c->d_seg_src, c->d_seg_first, c->d_fin, c->long_thresh, c->d_status, st));
+                placed = true;
+            } else if (verify_bytes) {
                 Timed t(c, "k_rmdup_verify", st);
                 HIP_TRYX(c, launch_rmdup_verify_fastq(d_buf, c->table, P, d_first, c->d_out_len, c->d_status, st));
             } else {
@@ -276,7 +301,25 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         HIP_TRYX(c, launch_rmdup_resolve(d_buf, c->table, tt, P, c->d_keys, tk, cap, c->d_out_len, c->d_status, st));
     }
     total = kept = 0;
-    rc = finish_sizes(c, st, &total, &kept);  // (ERR_HASH_COLLISION comes back as BSK_ERR_UNSUPPORTED: kernel_error_to_status)
+    if (placed && by_buckets) {
+        rc = ctl_readback(c, st);
+        if (rc != BSK_OK) return rc;
+        total = c->fin(bsk_ctx::FIN_TOTAL);
+        kept = c->fin(bsk_ctx::FIN_KEPT);
+        c->long_count = 0;
+        c->long_max = 0;
+        rc = kernel_error_to_status(c, c->status_word());
+        if (rc == BSK_OK && c->fin(bsk_ctx::FIN_LONG_COUNT) > 0) {
+            // a record of a MiB or more: its copy is a block-per-chunk launch that wants the list of such records -- the
+            // size pass of the general path writes it (the comparison is done: sizes from first[] alone)
+            placed = false;
+            HIP_TRYX(c, launch_rmdup_sizes(c->table, P, d_first, c->d_out_len, st));
+            rc = finish_sizes(c, st, &total, &kept);
+        }
+    } else {
+        placed = false;
+        rc = finish_sizes(c, st, &total, &kept);  // (ERR_HASH_COLLISION comes back as BSK_ERR_UNSUPPORTED: kernel_error_to_status)
+    }
     if (rc == BSK_ERR_UNSUPPORTED && by_keys && by_buckets && !with_k2 && (c->last_kernel_flags & ERR_HASH_COLLISION) &&
         !(c->last_kernel_flags & ~(uint64_t)ERR_HASH_COLLISION)) {
         // two different sequences under one XXH64 value (about N^2 / 2^65 per shard): once more with the second key, whose
@@ -286,6 +329,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         HIP_TRYX(c, hipStreamSynchronize(st));
         c->set_error("");
         with_k2 = true;
+        placed = false;
         continue;
     }
     if (rc != BSK_OK) return rc;
@@ -298,7 +342,23 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     }
     F.text_w = tt.text_w; F.lin_off = tt.lin_off; F.lin = tt.lin;
     apply_long(c, &F);
-    { const int rce = emit_records(c, d_buf, n, F, total, kept, st); if (rce != BSK_OK) return rce; }
+    if (placed) {
+        if (total) {
+            Timed tm(c, "k_seg_copy", st);
+            HIP_TRYX(c, launch_seg_copy(c->d_seg_src, c->d_out_off, N, c->d_seg_first, c->d_out, total, d_buf, d_buf + n, st));
+        }
+        if (c->fin(bsk_ctx::FIN_OTHER) != 0) {
+            // the few records the copy left out ('+' lines that repeat the name, a last record without '\n'): the record-wise
+            // emit writes them, from sizes recomputed for it
+            HIP_TRYX(c, launch_rmdup_sizes(c->table, P, d_first, c->d_out_len, st));
+            F.seg_src = c->d_seg_src;
+            HIP_TRYX(c, launch_seq_emit(d_buf, c->table, F, c->d_out_len, c->d_out_off, c->d_out, st, total, kept));
+            F.seg_src = nullptr;
+        }
+    } else {
+        const int rce = emit_records(c, d_buf, n, F, total, kept, st);
+        if (rce != BSK_OK) return rce;
+    }
     break;
     }
     out->d_data = c->d_out;

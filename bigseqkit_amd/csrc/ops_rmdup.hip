@@ -788,6 +788,7 @@ __global__ __launch_bounds__(256) void k_rmdup_resolve_first(const uint8_t* __re
 // listed duplicate: 16 bytes per lane and step from either text, the last 16 bytes of the sequence once more instead of
 // a byte tail.  Distinct texts under equal keys raise ERR_HASH_COLLISION (the call fails: nothing is dropped on a guess).
 constexpr uint32_t VER_RECORDS = 2048;
+constexpr uint64_t SEG_TILE_BYTES = 4096;  // == SEG_TILE of ops_segcopy.hpp (static_assert in the host file)
 template <bool FOLD>
 __global__ __launch_bounds__(256) void k_rmdup_verify_fastq(const uint8_t* __restrict__ buf, RecordTable t, RmDupParams P,
                                                             const uint32_t* __restrict__ first_of, uint32_t* __restrict__ out_len,
@@ -843,7 +844,234 @@ __global__ __launch_bounds__(256) void k_rmdup_verify_fastq(const uint8_t* __res
     if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
 }
 
+
+// ---- round 5: sizes, byte comparison, output offsets and segment list of `rmdup -s` on FASTQ in ONE pass ------------------
+// Round 4 ran five passes over the 79 M table rows of a C5 shard between the grouping and the copy: k_rmdup_verify_fastq
+// (sizes + comparison), k_scan_reduce_fin / k_scan_small_fin / k_scan_down_fin (offsets), k_seg_build_fastq (source
+// addresses) and k_seg_first (the segment of every 4 KiB output tile) -- 1.2 ms of them re-reading what the pass before
+// wrote.  Here a block takes 2 048 consecutive records (a thread eight neighbours: 32-byte loads), computes their output
+// sizes, learns where its output begins from the blocks before it through a chain of (flag, value) words -- a block
+// publishes its total at once and its inclusive prefix as soon as it knows it; a wave looks back over 64 predecessors at
+// a time (Merrill & Garland's decoupled look-back; blocks number themselves with a ticket, so every predecessor is
+// running or done) -- and writes out_off[], seg_src[] and first4k[] from registers; then it compares its duplicates as
+// k_rmdup_verify_fastq does.  fin[0] = total bytes (the last block), fin[1] += survivors, fin[2] += records of >= thresh
+// bytes, fin[4] += records the segmented copy must leave to the record-wise emit.
+constexpr uint64_t PL_FLAG_AGG = 1ull << 62, PL_FLAG_PREFIX = 2ull << 62, PL_VALUE = (1ull << 62) - 1ull;
+__device__ __forceinline__ uint64_t pl_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pl_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t pl_wave_sum(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(256) void k_rmdup_place(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+                                                     const uint32_t* __restrict__ first_of, uint64_t* __restrict__ chain,
+                                                     uint32_t* __restrict__ ticket, uint64_t* __restrict__ out_off,
+                                                     uint64_t* __restrict__ seg_src, uint32_t* __restrict__ first4k,
+                                                     unsigned long long* __restrict__ fin, uint32_t long_thresh,
+                                                     uint64_t* __restrict__ status) {
+    __shared__ uint32_t s_list[VER_RECORDS];
+    __shared__ uint32_t s_n, s_bid;
+    __shared__ uint64_t s_w[4], s_excl;
+    if (threadIdx.x == 0) { s_bid = atomicAdd(ticket, 1u); s_n = 0; }
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const uint64_t base = (uint64_t)bid * VER_RECORDS;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t PER = VER_RECORDS / 256u;  // 8 consecutive records per thread
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * PER;
+    uint32_t len[PER], aux[PER];
+    uint64_t start[PER];
+    uint32_t dupmask = 0, kept = 0, nlong = 0;
+    if (base + VER_RECORDS <= t.n) {  // (all but the last block: 32-byte loads)
+        uint32_t f[PER], lh[PER], ls[PER];
+        *reinterpret_cast<uint4*>(&f[0]) = *reinterpret_cast<const uint4*>(first_of + i0);
+        *reinterpret_cast<uint4*>(&f[4]) = *reinterpret_cast<const uint4*>(first_of + i0 + 4);
+        *reinterpret_cast<uint4*>(&lh[0]) = *reinterpret_cast<const uint4*>(t.l_head + i0);
+        *reinterpret_cast<uint4*>(&lh[4]) = *reinterpret_cast<const uint4*>(t.l_head + i0 + 4);
+        *reinterpret_cast<uint4*>(&ls[0]) = *reinterpret_cast<const uint4*>(t.l_seq + i0);
+        *reinterpret_cast<uint4*>(&ls[4]) = *reinterpret_cast<const uint4*>(t.l_seq + i0 + 4);
+        *reinterpret_cast<uint4*>(&aux[0]) = *reinterpret_cast<const uint4*>(t.aux + i0);
+        *reinterpret_cast<uint4*>(&aux[4]) = *reinterpret_cast<const uint4*>(t.aux + i0 + 4);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k += 2) {
+            const uint4 v = *reinterpret_cast<const uint4*>(t.start + i0 + k);
+            start[k] = ((uint64_t)v.y << 32) | v.x;
+            start[k + 1] = ((uint64_t)v.w << 32) | v.z;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const bool keep = f[k] == (uint32_t)(i0 + k);
+            len[k] = keep ? format_len(lh[k] > 0 ? lh[k] - 1 : 0, ls[k], 1, 0) : 0u;
+            dupmask |= keep ? 0u : (1u << k);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint64_t i = i0 + k;
+            len[k] = 0; aux[k] = 0; start[k] = 0;
+            if (i < t.n) {
+                const bool keep = first_of[i] == (uint32_t)i;
+                const uint32_t lh = t.l_head[i];
+                len[k] = keep ? format_len(lh > 0 ? lh - 1 : 0, t.l_seq[i], 1, 0) : 0u;
+                aux[k] = t.aux[i];
+                start[k] = t.start[i];
+                dupmask |= keep ? 0u : (1u << k);
+            }
+        }
+    }
+    uint64_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        mine += len[k];
+        kept += len[k] != 0u;
+        nlong += len[k] >= long_thresh;
+    }
+    // the duplicates of the block (their comparison comes last: the blocks behind wait for this block's total, not for it)
+    if (dupmask) {
+        const uint32_t at = atomicAdd(&s_n, (uint32_t)__popc(dupmask));
+        uint32_t m = dupmask, q = at;
+        while (m) { const uint32_t k = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u; s_list[q++] = threadIdx.x * PER + k; }
+    }
+    // block scan of the sizes
+    uint64_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+        if ((int)lane >= d) x += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 63) s_w[wave] = x;
+    {
+        const uint64_t kl = pl_wave_sum(((uint64_t)nlong << 32) | kept);
+        if (lane == 0 && kl) {
+            if ((uint32_t)kl) atomicAdd(&fin[1], (unsigned long long)(uint32_t)kl);
+            if (kl >> 32) atomicAdd(&fin[2], (unsigned long long)(kl >> 32));
+        }
+    }
+    __syncthreads();
+    // the block's total is known: the blocks behind can pass over this one from now on.  The comparison of the duplicates
+    // comes BEFORE this block's own look-back -- its gathers are long, and the predecessors finish meanwhile
+    if (threadIdx.x == 0) pl_store(chain + bid, (bid == 0 ? PL_FLAG_PREFIX : PL_FLAG_AGG) | (s_w[0] + s_w[1] + s_w[2] + s_w[3]));
+    // the byte comparison of the block's duplicates: four lanes each, 16 bytes per lane and step
+    const uint32_t nd = s_n, gl = threadIdx.x & 3u;
+    uint32_t bad = 0;
+    for (uint32_t d = threadIdx.x >> 2; d < nd; d += 64u) {
+        const uint64_t i = base + s_list[d];
+        const uint64_t f = first_of[i];
+        const uint32_t la = t.l_seq[i], lb = t.l_seq[f];
+        const uint8_t* pa = buf + t.start[i] + t.l_head[i] + 1;
+        const uint8_t* pb = buf + t.start[f] + t.l_head[f] + 1;
+        uint32_t diff = la ^ lb;
+        if (diff == 0) {
+            auto cmp16 = [&](uint32_t q) {
+                uint4 xa, ya;
+                __builtin_memcpy(&xa, pa + q, 16);
+                __builtin_memcpy(&ya, pb + q, 16);
+                if (FOLD) {
+                    xa.x = fold4(xa.x); xa.y = fold4(xa.y); xa.z = fold4(xa.z); xa.w = fold4(xa.w);
+                    ya.x = fold4(ya.x); ya.y = fold4(ya.y); ya.z = fold4(ya.z); ya.w = fold4(ya.w);
+                }
+                diff |= (xa.x ^ ya.x) | (xa.y ^ ya.y) | (xa.z ^ ya.z) | (xa.w ^ ya.w);
+            };
+            for (uint32_t q = 16u * gl; q + 16u <= la; q += 64u) cmp16(q);
+            if (gl == 3u) {
+                if (la >= 16u) { if (la & 15u) cmp16(la - 16u); }
+                else for (uint32_t q = 0; q < la; ++q) {
+                    uint8_t ca = pa[q], cb = pb[q];
+                    if (FOLD) { ca = lower8(ca); cb = lower8(cb); }
+                    diff |= (uint32_t)(ca ^ cb);
+                }
+            }
+        }
+        bad |= diff;
+    }
+    if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
+    if (wave == 0) {
+        const uint64_t total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        uint64_t excl = 0;
+        if (bid > 0) {
+            int64_t j = (int64_t)bid - 1 - (int64_t)lane;  // lane 0 looks at the nearest predecessor
+            for (;;) {
+                uint64_t v = j >= 0 ? pl_load(chain + j) : PL_FLAG_PREFIX;
+                while (__ballot((v >> 62) == 0ull) != 0ull) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((v >> 62) == 0ull) v = pl_load(chain + j);
+                }
+                const uint64_t pm = __ballot((v >> 62) == 2ull);  // lanes that saw an inclusive prefix
+                if (pm) {
+                    const uint32_t fl = (uint32_t)__ffsll((long long)pm) - 1u;  // the nearest of them ends the walk
+                    excl += pl_wave_sum(lane <= fl ? (v & PL_VALUE) : 0ull);
+                    break;
+                }
+                excl += pl_wave_sum(v & PL_VALUE);
+                j -= 64;
+            }
+            if (lane == 0) pl_store(chain + bid, PL_FLAG_PREFIX | (excl + total));
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (base + VER_RECORDS >= t.n) { out_off[t.n] = excl + total; fin[0] = excl + total; }  // the last block
+        }
+    }
+    __syncthreads();
+    uint64_t off = s_excl + x - mine;
+    for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+    uint32_t other = 0;
+    if (base + VER_RECORDS <= t.n) {
+        uint64_t o[PER], sp[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            o[k] = off;
+            const uint64_t b = off + len[k];
+            for (uint64_t T = (off + SEG_TILE_BYTES - 1) / SEG_TILE_BYTES; T * SEG_TILE_BYTES < b; ++T) first4k[T] = (uint32_t)(i0 + k);
+            const bool verb = aux[k] == 1u && start[k] + len[k] <= buf_n;
+            sp[k] = (len[k] && verb) ? (uint64_t)(uintptr_t)(buf + start[k]) : 0ull;
+            other += len[k] && !verb;
+            off = b;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k += 2) {
+            *reinterpret_cast<uint4*>(out_off + i0 + k) = make_uint4((uint32_t)o[k], (uint32_t)(o[k] >> 32), (uint32_t)o[k + 1], (uint32_t)(o[k + 1] >> 32));
+            *reinterpret_cast<uint4*>(seg_src + i0 + k) = make_uint4((uint32_t)sp[k], (uint32_t)(sp[k] >> 32), (uint32_t)sp[k + 1], (uint32_t)(sp[k + 1] >> 32));
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint64_t i = i0 + k;
+            if (i < t.n) {
+                out_off[i] = off;
+                const uint64_t b = off + len[k];
+                for (uint64_t T = (off + SEG_TILE_BYTES - 1) / SEG_TILE_BYTES; T * SEG_TILE_BYTES < b; ++T) first4k[T] = (uint32_t)i;
+                const bool verb = aux[k] == 1u && start[k] + len[k] <= buf_n;
+                seg_src[i] = (len[k] && verb) ? (uint64_t)(uintptr_t)(buf + start[k]) : 0ull;
+                other += len[k] && !verb;
+                off = b;
+            }
+        }
+    }
+    if (other) atomicAdd(&fin[4], (unsigned long long)other);  // rare: a '+' line that repeats the name, a last record without '\n'
+}
+
 }  // namespace
+
+uint64_t rmdup_place_blocks(uint64_t n) { return (n + VER_RECORDS - 1) / VER_RECORDS; }
+
+hipError_t launch_rmdup_place(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const RmDupParams& P, const uint32_t* first,
+                              uint64_t* chain, uint32_t* ticket, uint64_t* out_off, uint64_t* seg_src, uint32_t* first4k, uint64_t* fin,
+                              uint32_t long_thresh, uint64_t* status, hipStream_t st) {
+    if (t.n == 0) return hipSuccess;
+    const dim3 g((unsigned)rmdup_place_blocks(t.n));
+    if (P.ignore_case) hipLaunchKernelGGL((k_rmdup_place<true>), g, dim3(256), 0, st, buf, buf_n, t, first, chain, ticket, out_off, seg_src,
+                                          first4k, (unsigned long long*)fin, long_thresh, status);
+    else hipLaunchKernelGGL((k_rmdup_place<false>), g, dim3(256), 0, st, buf, buf_n, t, first, chain, ticket, out_off, seg_src, first4k,
+                            (unsigned long long*)fin, long_thresh, status);
+    return hipGetLastError();
+}
 
 hipError_t launch_rmdup_verify_fastq(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint32_t* first,
                                      uint32_t* out_len, uint64_t* status, hipStream_t st) {

@@ -54,6 +54,14 @@ constexpr uint32_t RMDUP_BUCKET_BITS = 16;
 // duplicate's sequence with its survivor's (-i: case-folded); a difference raises ERR_HASH_COLLISION
 hipError_t launch_rmdup_verify_fastq(const uint8_t* buf, const RecordTable& t, const RmDupParams& P, const uint32_t* first,
                                      uint32_t* out_len, uint64_t* status, hipStream_t st);
+// round 5: the same comparison AND the output offsets, segment sources and per-tile first segments of the survivors in one
+// pass (decoupled look-back over blocks of 2 048 records).  chain: rmdup_place_blocks(n) words, ticket: one word, both
+// zeroed by the caller; fin = the control block's FIN words ([0] total, [1] survivors, [2] records >= long_thresh bytes,
+// [4] records left to the record-wise emit; [1], [2], [4] zeroed by the caller); first4k as launch_seg_first writes it
+uint64_t rmdup_place_blocks(uint64_t n);
+hipError_t launch_rmdup_place(const uint8_t* buf, uint64_t buf_n, const RecordTable& t, const RmDupParams& P, const uint32_t* first,
+                              uint64_t* chain, uint32_t* ticket, uint64_t* out_off, uint64_t* seg_src, uint32_t* first4k, uint64_t* fin,
+                              uint32_t long_thresh, uint64_t* status, hipStream_t st);
 hipError_t launch_bucket_dedupe(const uint64_t* skeys, const uint32_t* sidx, uint64_t n, uint32_t* bstart, uint32_t* first,
                                 uint64_t* status, hipStream_t st, const uint64_t* k2 = nullptr, uint32_t* ovf = nullptr,
                                 uint32_t ovf_cap = 0, bool have_bstart = false /* bstart comes from launch_bucket_pass */);

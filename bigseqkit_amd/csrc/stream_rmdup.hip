@@ -55,15 +55,21 @@ __device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
     return v + o;
 }
 
-// K2 = false: k1 alone (rmdup's default: the bytes of every duplicate are compared afterwards, ops_host_rmdup.cpp) -- a
-// quarter of the hashing instructions and 8 bytes per record less (8.7 -> 7.5 ms per 25 GB, scripts/history/r04_rmstream.sh)
-template <bool DPP, bool FOLD, bool K2>
+// MODE 1: XXH64 + k2 (two-key decisions, the multi-GPU exchange); MODE 0: XXH64 alone -- a quarter of the hashing
+// instructions and 8 bytes per record less (8.7 -> 7.5 ms per 25 GB, scripts/history/r04_rmstream.sh);
+// MODE 2 (round 5, rmdup's default: the bytes of every duplicate are compared afterwards, ops_host_rmdup.cpp): the
+// chain-free grouping key of hash_dev.hpp instead of XXH64
+constexpr int MODE_K1 = 0, MODE_K1K2 = 1, MODE_GROUP = 2;
+template <bool DPP, bool FOLD, int MODE>
 struct RmdupSink {
+    static constexpr bool K2 = MODE == MODE_K1K2;
     static constexpr bool TILE_HOOK = true;
     static constexpr bool TILE_NT = true;  // every byte once: non-temporal tile loads (stream_core_dev.hpp)
     IndexDev D;
     HashDev H;
     TileLds T;                  // this wave's tile in LDS (tile_lds_dev.hpp)
+    uint32_t gk = 0;            // MODE_GROUP: LDS byte address of the block's key table (hash_dev.hpp, GKEY_BYTES)
+    const uint8_t* buf_end = nullptr;  // (the group key loads 16 bytes at a time: where the shard's memory ends)
     uint64_t base = 0, limit = 0;
     uint32_t err = 0;
 
@@ -166,6 +172,61 @@ struct RmdupSink {
         }
     }
 
+    // the grouping key of up to 16 sequence lines, one per quad (hash_dev.hpp "GROUPING key"): lane k of the quad takes the
+    // 16-byte chunks k, k + 4, ... of its line -- one unaligned ds_read_b128 of text, two aligned ones of keys, eight adds and
+    // four v_mad_u64_u32 per chunk, nothing carried from chunk to chunk; two DPP adds fold the quad
+    __device__ __forceinline__ void group_quads(int32_t so, uint32_t ln, bool vq, uint64_t tile_idx,
+                                                const uint8_t* __restrict__ buf, uint64_t g) {
+        const uint32_t k = threadIdx.x & 3u;
+        const bool in_lds = vq && T.holds(tile_idx, so);
+        const uint8_t* gp = buf + (int64_t)tile_idx + (int64_t)so;  // the line in global memory
+        const uint32_t la = T.addr(so);                             // ... and in LDS
+        const uint32_t nch = vq ? (ln + 15u) >> 4 : 0u;
+        uint64_t a1 = 0, a2 = 0;
+        for (uint32_t c = k; __ballot(c < nch) != 0ull; c += 4u) {
+            if (c < nch) {
+                // (named dwords, no indexed array: one dynamic index sends the four of them through scratch memory)
+                uint32_t w0, w1, w2, w3;
+                const uint32_t rem = ln - 16u * c;  // bytes of the line from this chunk on (>= 1)
+                if (in_lds) {
+                    const u32x4 v = *(lds_u32x4_any*)(uintptr_t)(la + 16u * c);  // (reads past the line inside the padded buffer; masked below)
+                    w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+                } else {  // a line longer than the carry, or cut by the tile before: from global memory, never past the shard
+                    uint64_t lo = 0, hi = 0;
+                    const uint8_t* q = gp + 16u * c;
+                    if (q + 16 <= buf_end) {
+                        __builtin_memcpy(&lo, q, 8);
+                        __builtin_memcpy(&hi, q + 8, 8);
+                    } else {
+                        for (uint32_t i = 0; i < 8u && i < rem; ++i) lo |= (uint64_t)q[i] << (8u * i);
+                        for (uint32_t i = 8; i < 16u && i < rem; ++i) hi |= (uint64_t)q[i] << (8u * (i - 8u));
+                    }
+                    w0 = (uint32_t)lo; w1 = (uint32_t)(lo >> 32); w2 = (uint32_t)hi; w3 = (uint32_t)(hi >> 32);
+                }
+                if (rem < 16u) {  // zero padding of the last chunk: byte j of the chunk stays iff j < rem
+                    const uint32_t sh = (rem & 3u) * 8u, part = (1u << sh) - 1u;  // (rem & 3 == 0: part = 0)
+                    const uint32_t q = rem >> 2;                                     // whole dwords kept
+                    w0 &= q > 0u ? 0xFFFFFFFFu : part;
+                    w1 &= q > 1u ? 0xFFFFFFFFu : (q == 1u ? part : 0u);
+                    w2 &= q > 2u ? 0xFFFFFFFFu : (q == 2u ? part : 0u);
+                    w3 &= q == 3u ? part : 0u;
+                }
+                if (FOLD) { w0 = fold4(w0); w1 = fold4(w1); w2 = fold4(w2); w3 = fold4(w3); }
+                const uint32_t ka = gk + (c & (GKEY_POS - 1u)) * 32u;
+                const uint4 K = lds_r128(ka), Q = lds_r128(ka + 16u);
+                a1 += (uint64_t)(w0 + K.x) * (uint64_t)(w1 + K.y);
+                a1 += (uint64_t)(w2 + K.z) * (uint64_t)(w3 + K.w);
+                a2 += (uint64_t)(w0 + Q.x) * (uint64_t)(w1 + Q.y);
+                a2 += (uint64_t)(w2 + Q.z) * (uint64_t)(w3 + Q.w);
+                if ((c & (GKEY_POS - 1u)) >= GKEY_POS - 4u) { a1 = gkey_stir1(a1); a2 = gkey_stir2(a2); }
+            }
+        }
+        a1 = quad_sum64(a1);
+        a2 = quad_sum64(a2);
+        const uint64_t h = gkey_finish(a1, a2, (uint64_t)ln);
+        if (vq && k == 0u && g < limit) H.k1[g] = h;
+    }
+
     template <bool FASTQ, bool ALL>
     __device__ __forceinline__ void batch(Lds<FASTQ, ALL>& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
@@ -215,7 +276,11 @@ struct RmdupSink {
                 const int32_t so = __shfl(line_off, src, 64);
                 const uint32_t ln = (uint32_t)__shfl((int)line_len, src, 64);
                 const bool vq = __shfl((int)is_seq, src, 64) != 0;
-                if (__ballot(vq) != 0ull) hash_quads(so, ln, vq, tile_idx, buf, base + ((wb + e0 + (uint32_t)src) >> 2));
+                if (__ballot(vq) != 0ull) {
+                    const uint64_t g = base + ((wb + e0 + (uint32_t)src) >> 2);
+                    if constexpr (MODE == MODE_GROUP) group_quads(so, ln, vq, tile_idx, buf, g);
+                    else hash_quads(so, ln, vq, tile_idx, buf, g);
+                }
             }
         }
     }
@@ -228,7 +293,11 @@ struct RmdupSink {
 #define BSK_RMSTREAM_WAVES_K1 5  // k1 alone: 98 VGPRs wanted, 5 waves per SIMD fit without spills: 7.5 ms against 8.0 at 4
 #endif
 
-template <bool DPP, bool FOLD, bool K2>
+#ifndef BSK_RMSTREAM_WAVES_G
+#define BSK_RMSTREAM_WAVES_G 5
+#endif
+
+template <bool DPP, bool FOLD, int MODE>
 __device__ __forceinline__ void rmdup_stream_body(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors,
                                                   uint32_t nranges, uint32_t* __restrict__ queue, const IndexDev& D, const HashDev& H) {
     __shared__ Lds<true, false> s_l[WAVES_PER_BLOCK];
@@ -236,10 +305,17 @@ __device__ __forceinline__ void rmdup_stream_body(const uint8_t* __restrict__ bu
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     Lds<true, false>& L = s_l[wave];
-    RmdupSink<DPP, FOLD, K2> sink;
+    RmdupSink<DPP, FOLD, MODE> sink;
     sink.D = D;
     sink.H = H;
     sink.T.tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_tb[wave];
+    sink.buf_end = buf + n;
+    if constexpr (MODE == MODE_GROUP) {
+        __shared__ __attribute__((aligned(16))) uint32_t s_gk[GKEY_BYTES / 4];
+        for (uint32_t i = threadIdx.x; i < GKEY_BYTES / 4u; i += blockDim.x) s_gk[i] = gkey_word(i >> 3, i & 7u);
+        __syncthreads();
+        sink.gk = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_gk;
+    }
     PredConsts P;  // unused (sparse path)
     P.k20 = P.k30 = 0;
     P.ngap = 0;
@@ -271,13 +347,19 @@ template <bool DPP, bool FOLD>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES, 8))) void k_rmdup_stream(
     const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges, uint32_t* __restrict__ queue,
     IndexDev D, HashDev H) {
-    rmdup_stream_body<DPP, FOLD, true>(buf, n, anchors, nranges, queue, D, H);
+    rmdup_stream_body<DPP, FOLD, MODE_K1K2>(buf, n, anchors, nranges, queue, D, H);
 }
 template <bool DPP, bool FOLD>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES_K1, 8))) void k_rmdup_stream_k1(
     const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges, uint32_t* __restrict__ queue,
     IndexDev D, HashDev H) {
-    rmdup_stream_body<DPP, FOLD, false>(buf, n, anchors, nranges, queue, D, H);
+    rmdup_stream_body<DPP, FOLD, MODE_K1>(buf, n, anchors, nranges, queue, D, H);
+}
+template <bool DPP, bool FOLD>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_RMSTREAM_WAVES_G, 8))) void k_rmdup_stream_g(
+    const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges, uint32_t* __restrict__ queue,
+    IndexDev D, HashDev H) {
+    rmdup_stream_body<DPP, FOLD, MODE_GROUP>(buf, n, anchors, nranges, queue, D, H);
 }
 
 // one block per range: its slice of the sparse table and of the sparse keys to their dense positions
@@ -296,24 +378,28 @@ __global__ __launch_bounds__(256) void k_rmdup_compact(RecordTable sp, uint64_t 
 }
 
 template <bool DPP, bool FOLD>
-const void* kernel_ptr(bool k2) { return k2 ? (const void*)k_rmdup_stream<DPP, FOLD> : (const void*)k_rmdup_stream_k1<DPP, FOLD>; }
-const void* kernel_of(bool dpp, bool fold, bool k2) {
-    return dpp ? (fold ? kernel_ptr<true, true>(k2) : kernel_ptr<true, false>(k2)) : (fold ? kernel_ptr<false, true>(k2) : kernel_ptr<false, false>(k2));
+const void* kernel_ptr(int mode) {
+    return mode == MODE_K1K2 ? (const void*)k_rmdup_stream<DPP, FOLD>
+                             : (mode == MODE_GROUP ? (const void*)k_rmdup_stream_g<DPP, FOLD> : (const void*)k_rmdup_stream_k1<DPP, FOLD>);
+}
+const void* kernel_of(bool dpp, bool fold, int mode) {
+    return dpp ? (fold ? kernel_ptr<true, true>(mode) : kernel_ptr<true, false>(mode))
+               : (fold ? kernel_ptr<false, true>(mode) : kernel_ptr<false, false>(mode));
 }
 
 }  // namespace
 
-hipError_t launch_rmdup_stream(bool dpp, bool fold, bool k2, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
+hipError_t launch_rmdup_stream(bool dpp, bool fold, int mode, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
                                uint32_t nranges, uint32_t* queue, const IndexDev& D, const HashDev& H, hipStream_t st) {
     IndexDev d = D;
     HashDev h = H;
     void* args[] = {(void*)&buf, (void*)&n, (void*)&anchors, (void*)&nranges, (void*)&queue, (void*)&d, (void*)&h};
-    return hipLaunchKernel(kernel_of(dpp, fold, k2), dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), args, 0, st);
+    return hipLaunchKernel(kernel_of(dpp, fold, mode), dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), args, 0, st);
 }
 
-int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold, bool k2) {
+int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold, int mode) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel_of(dpp, fold, k2), WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel_of(dpp, fold, mode), WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 

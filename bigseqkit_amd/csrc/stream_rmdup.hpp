@@ -14,9 +14,10 @@ struct HashDev {
     uint64_t* k2;  // the second key
 };
 
-hipError_t launch_rmdup_stream(bool dpp, bool fold, bool k2, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
+// mode: 0 = XXH64 alone, 1 = XXH64 + k2, 2 = the grouping key of hash_dev.hpp (k1 only; the caller compares the bytes)
+hipError_t launch_rmdup_stream(bool dpp, bool fold, int mode, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors,
                                uint32_t nranges, uint32_t* queue, const IndexDev& D, const HashDev& H, hipStream_t st);
-int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold, bool k2);
+int rmdup_stream_max_blocks_per_cu(bool dpp, bool fold, int mode);
 // gather the per-range slices of the sparse table and of the sparse keys into the dense arrays (k_index_compact + keys)
 hipError_t launch_rmdup_compact(const RecordTable& sparse, uint64_t sparse_cap, const uint64_t* range_count,
                                 const uint64_t* range_base, uint32_t nranges, const RecordTable& dense, const HashDev& hs,

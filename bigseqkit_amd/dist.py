@@ -29,9 +29,12 @@ def shard_bounds(data, world, fmt):
     else:
         try:
             keep = (C.c_char * n).from_buffer(data)
+            ptr = C.cast(keep, C.c_void_p)
         except (TypeError, ValueError):
-            keep = (C.c_char * n).from_buffer_copy(data)
-        ptr = C.cast(keep, C.c_void_p)
+            # a read-only buffer (an mmap opened ACCESS_READ): its address through numpy, as run.cut_points does -- no copy
+            import numpy as np
+            keep = np.frombuffer(data, dtype=np.uint8)
+            ptr = C.c_void_p(keep.ctypes.data)
     cuts = [0]
     for k in range(1, world):
         out = C.c_size_t()
@@ -391,7 +394,12 @@ def _all_to_all_single(out, inp, out_splits, in_splits, group=None):
     if out_splits is None:  # equal split (the few words of the split sizes themselves)
         dist.all_to_all_single(out, inp, None, None, group=group)
         return
-    row_bytes = max(1, inp.element_size() * (inp[0].numel() if inp.dim() > 1 else 1))
+    # (the row size comes from the SHAPE: a rank whose shard holds no record sends a (0, 3) tensor, and inp[0] of that
+    # raises before the all-reduce below -- the other ranks would wait in it for ever)
+    row_elems = 1
+    for d in tuple(inp.shape[1:]):
+        row_elems *= int(d)
+    row_bytes = max(1, inp.element_size() * row_elems)
     limit = max(1, int(os.environ.get("BSK_A2A_MAX_BYTES", A2A_MAX_BYTES)) // row_bytes)  # rows per message
     biggest = torch.tensor([max(list(out_splits) + list(in_splits) + [0])], dtype=torch.int64, device=cd)
     _all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)  # (every rank must take the same number of rounds)

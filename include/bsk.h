@@ -405,7 +405,8 @@ int bsk_profile_dump(bsk_ctx* ctx, char* buf, size_t cap);
 /* ---- device self tests used by tests/ (-m gpu) ---------------------------- */
 int bsk_selftest_scan(int use_dpp, const uint32_t* in64, uint32_t* out64);
 /* the two 64-bit keys (XXH64 seed 0, and the second key of csrc/hash_dev.hpp) of every record of the shard of the last
- * bsk_rmdup_dist_keys call, in record order */
+ * bsk_rmdup_dist_keys call, in record order.  k2 == NULL: k1 alone -- after a bsk_rmdup_run (-s on FASTQ, keys verified by
+ * bytes) that is the chain-free GROUPING key of csrc/hash_dev.hpp, which the tests restate in Python */
 int bsk_selftest_rmdup_keys(bsk_ctx* ctx, uint64_t* k1, uint64_t* k2, size_t cap, size_t* n_out);
 /* streaming read of d_buf[0..n) with k_stats' tile/queue pattern and no per-byte work:
  * the read ceiling of that pattern and the FETCH_SIZE calibration run */

@@ -175,6 +175,45 @@ def test_two_ranks_gloo_rmdup_exchange(opts, a2a_max_bytes, tmp_path, monkeypatc
     assert open(merged, "rb").read() == want
 
 
+@pytest.mark.parametrize("a2a_max_bytes", [None, 240])
+def test_two_ranks_gloo_rmdup_with_an_empty_rank(a2a_max_bytes, monkeypatch):
+    """A file with fewer records than ranks: one rank's shard is EMPTY, it sends a (0, 3) tuple tensor.  ADVICE r04: the
+    chunked all-to-all took its row size from inp[0] and raised IndexError on that rank before the all-reduce of the round
+    count -- the other rank then waited in the collective until the launcher killed it."""
+    import torch.multiprocessing as mp
+    if a2a_max_bytes:
+        monkeypatch.setenv("BSK_A2A_MAX_BYTES", str(a2a_max_bytes))
+    data = b"@only one\nACGTACGT\n+\nIIIIIIII\n"
+    assert [hi - lo for lo, hi in bdist.shard_bounds(data, 2, bsk.FORMAT_FASTQ)].count(0) == 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rmdup_worker, args=(r, 2, port, data, {"BySeq": True}, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0] + outs[1] == data
+
+
+def test_shard_bounds_reads_a_read_only_mapping_in_place(tmp_path):
+    """a read-only mmap fell back to from_buffer_copy -- the file it says is 'not copied to be cut' was copied
+    in full.  The address now comes through numpy, as run.cut_points takes it."""
+    import mmap
+    rng = random.Random(5)
+    data = "".join(f"@r{i}\n{''.join(rng.choice('ACGT') for _ in range(40))}\n+\n{'I' * 40}\n" for i in range(300)).encode()
+    f = tmp_path / "x.fq"
+    f.write_bytes(data)
+    with open(f, "rb") as fh:
+        m = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        try:
+            assert bdist.shard_bounds(m, 3, bsk.FORMAT_FASTQ) == bdist.shard_bounds(data, 3, bsk.FORMAT_FASTQ)
+        finally:
+            m.close()
+
+
 # ---------------------------------------------------------------- range / head / faidx: one all_gather each
 class _CpuRangeBackend:
     """TEST stand-in for HipRangeBackend: libbsk's host-side range arithmetic (bsk_create on device -1,

@@ -98,6 +98,89 @@ def test_fused_keys_are_xxh64_and_k2(seed, lens, fold, monkeypatch):
     assert j1 == k1 and j2 == k2
 
 
+# ---- the grouping key of the byte-verifying mode (csrc/hash_dev.hpp "GROUPING key"), restated
+P1, P2, P3 = 11400714785074694791, 14029467366897019727, 1609587929392839161
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M64
+    return x ^ (x >> 31)
+
+
+def gkey_word(p, j):
+    v = splitmix64((0x6b73625f67726f75 + p * 4 + (j >> 1)) & M64)
+    return (v >> 32) if (j & 1) else (v & 0xFFFFFFFF)
+
+
+GK = [[gkey_word(p, j) for j in range(8)] for p in range(64)]
+
+
+def gkey_py(s):
+    a1, a2 = [0, 0, 0, 0], [0, 0, 0, 0]       # the sums of the four lanes of a quad (lane k: chunks k, k + 4, ...)
+    for c in range((len(s) + 15) // 16):
+        ch = s[16 * c:16 * c + 16].ljust(16, b"\0")
+        w = [int.from_bytes(ch[4 * d:4 * d + 4], "little") for d in range(4)]
+        K, k = GK[c & 63], c & 3
+        m32 = 0xFFFFFFFF
+        a1[k] = (a1[k] + ((w[0] + K[0]) & m32) * ((w[1] + K[1]) & m32) + ((w[2] + K[2]) & m32) * ((w[3] + K[3]) & m32)) & M64
+        a2[k] = (a2[k] + ((w[0] + K[4]) & m32) * ((w[1] + K[5]) & m32) + ((w[2] + K[6]) & m32) * ((w[3] + K[7]) & m32)) & M64
+        if (c & 63) >= 60:
+            a1[k] = (rotl(a1[k], 29) * P1) & M64
+            a2[k] = (rotl(a2[k], 31) * P2) & M64
+    s1, s2 = sum(a1) & M64, sum(a2) & M64
+    h = (((s1 + len(s)) & M64) * P1 + rotl(s2, 32) * P2) & M64
+    h ^= h >> 32
+    h = (h * P3) & M64
+    h ^= h >> 29
+    return h
+
+
+def group_keys(data, opts, env=None):
+    """k1 of every record after a bsk_rmdup_run in the byte-verifying mode"""
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    with bsk.Operator("RmDup", json.dumps(opts), 0) as op:
+        for k, v in (env or {}).items():
+            check(lib.bsk_ctx_set(op.ctx, k.encode(), v.encode()), op.ctx)
+        out = _lib.Out()
+        check(lib.bsk_rmdup_run(op.ctx, C.c_void_p(t.data_ptr()), t.numel(), 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out)), op.ctx)
+        buf = C.create_string_buffer(max(1, out.len))
+        check(lib.bsk_out_to_host(op.ctx, C.byref(out), buf, out.len), op.ctx)
+        n = data.count(b"\n") // 4
+        k1 = (C.c_uint64 * max(1, n))()
+        got = C.c_size_t()
+        check(lib.bsk_selftest_rmdup_keys(op.ctx, k1, None, n, C.byref(got)), op.ctx)
+        assert got.value == n
+        return list(k1)[:n], buf.raw[:out.len]
+
+
+@pytest.mark.parametrize("seed,lens", [(1, list(range(0, 200))), (2, [150] * 600), (3, [15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129] * 20),
+                                       (4, [500, 511, 512, 513, 600, 1000, 1023, 1024, 1025, 4000, 4096, 5000, 9000, 20000])])
+@pytest.mark.parametrize("fold", [False, True])
+def test_grouping_key_of_the_verify_mode(seed, lens, fold, monkeypatch):
+    """`rmdup -s` (bytes verified) groups by the chain-free key of hash_dev.hpp, whatever tile / range / quad a sequence falls
+    into, from LDS or (long and cut lines) from global memory; `rmdup_hash=xxh64` keeps XXH64 there; same survivors."""
+    xxhash = pytest.importorskip("xxhash")
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    rng = random.Random(seed)
+    seqs = [rand_seq(rng, n) for n in lens]
+    seqs += [rng.choice(seqs) for _ in range(len(seqs) // 3)]
+    rng.shuffle(seqs)
+    data = fastq_of(seqs, rng)
+    opts = {"BySeq": True, "IgnoreCase": fold}
+    want = oracle.rmdup(data, True, json.dumps(opts))
+    k1, out = group_keys(data, opts)
+    assert out == want
+    for i, s in enumerate(seqs):
+        assert k1[i] == gkey_py(s.lower() if fold else s), (i, len(s))
+    x1, out = group_keys(data, opts, {"rmdup_hash": "xxh64"})
+    assert out == want
+    for i, s in enumerate(seqs):
+        assert x1[i] == xxhash.xxh64(s.lower() if fold else s).intdigest(), (i, len(s))
+
+
 @pytest.mark.parametrize("opts", [{"ByName": True}, {}, {"ByName": True, "IgnoreCase": True}])
 def test_name_and_id_keys(opts):
     xxhash = pytest.importorskip("xxhash")
@@ -175,6 +258,32 @@ def test_verify_mode_takes_one_key_and_goes_round_again_on_a_collision():
             assert buf.raw[:out.len] == want
             prof = dict(kv.split("=") for kv in pb.value.decode().split(";") if kv)  # name=ms/launches;
             assert int(prof["k_rmdup_stream"].split("/")[1]) == passes, prof
+
+
+@pytest.mark.parametrize("nrec", [1, 7, 2047, 2048, 2049, 4096, 30011])
+def test_one_pass_placement_equals_the_separate_passes(nrec, monkeypatch):
+    """k_rmdup_place (sizes + byte comparison + output offsets by decoupled look-back + segment list in one pass) against
+    round 4's verify / scan / segment-build passes (`rmdup_place=off`) and the oracle: block boundaries at 2 048 records,
+    '+' lines that repeat the name and a last record without a newline (left to the record-wise emit), a record above the
+    'long' threshold (the general size pass takes over)."""
+    rng = random.Random(nrec)
+    uniq = [rand_seq(rng, rng.choice((20, 36, 150, 151)), b"ACGT") for _ in range(max(1, nrec * 2 // 3))]
+    seqs = [rng.choice(uniq) for _ in range(nrec)]
+    recs = []
+    for i, s in enumerate(seqs):
+        q = bytes(rng.choice(b"#$%&'()*+,-./0123456789:;<=>?@ABCDEFGHI") for _ in s)
+        plus = (b"+r%d x" % i) if (i % 97 == 5) else b"+"
+        recs.append(b"@r%d x\n%s\n%s\n%s\n" % (i, s, plus, q))
+    data = b"".join(recs)
+    for variant in (data, data[:-1]):
+        want = oracle.rmdup(variant, True, '{"BySeq": true}')
+        assert run_rmdup(variant, {"BySeq": True}) == want
+        monkeypatch.setenv("BSK_RMDUP_PLACE", "off")
+        assert run_rmdup(variant, {"BySeq": True}) == want
+        monkeypatch.delenv("BSK_RMDUP_PLACE")
+    if nrec >= 2048:
+        monkeypatch.setenv("BSK_LONG_BYTES", "300")   # records of 150 bases are "long": the list-writing size pass runs
+        assert run_rmdup(data, {"BySeq": True}) == oracle.rmdup(data, True, '{"BySeq": true}')
 
 
 @pytest.mark.parametrize("keys", ["", "off"])
