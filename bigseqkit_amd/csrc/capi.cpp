@@ -322,7 +322,10 @@ int bsk_stats_reset(bsk_ctx* c, void* stream) {
 static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, uint64_t* d_vec, hipStream_t st) {
     const bool fastq = format == BSK_FORMAT_FASTQ;
     const bool all = c->opts.b("All");
-    const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp, c->stats_a_dense);
+    // FASTQ -a: the dense path (stats_a=dense); FASTA default row: the pass that publishes every newline (stats_fasta=events)
+    // instead of the round-5 one that publishes the two kinds the sink acts on -- the older variants the tests compare with
+    const bool variant = fastq ? c->stats_a_dense : (!all && c->tune.is("stats_fasta", "events"));
+    const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp, variant);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
     const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes, (int)c->tune.num("ranges_per_wave"));
@@ -395,7 +398,7 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
         Timed t(c, "k_stats", st);
         // FASTA: a line longer than a chunk is not read between its own chunk and its last tile; with `-a` the gap letters
         // of the chunks it covers are counted by those chunks' (otherwise empty) ranges
-        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, c->stats_a_dense,
+        HIP_TRY(c, launch_stats(fastq, all, c->use_dpp, blocks, d_buf, n, anchors, nranges, queue, D, st, variant,
                                 !fastq ? chunk : 0));
     }
     if (!fastq) HIP_TRY(c, launch_stats_stitch(nranges, D, st));

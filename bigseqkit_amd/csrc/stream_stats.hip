@@ -19,6 +19,7 @@
 #include "anchor_wave_dev.hpp"
 #include "index.hpp"
 #include "stream_core_dev.hpp"
+#include "stream_fasta2_dev.hpp"
 #include "stream_stats.hpp"
 
 namespace bsk {
@@ -171,6 +172,38 @@ struct StatsSinkT {
         (void)wb; (void)tile_idx; (void)tile_rel;
     }
 
+    // FASTA, round 5 (stream_fasta2_dev.hpp): E <= 64 PUBLISHED newlines -- the ones in front of a '>' (closing) and the ones
+    // that end a header line -- with key = position - newline index; the rules of batch()'s FASTA branch on them
+    __device__ __forceinline__ void events2(LdsF2& L, uint32_t first, uint32_t E) {
+        const uint32_t lane = threadIdx.x & 63;
+        const bool on = lane < E;
+        const uint32_t ei = (first + lane) & (F2_EVENTS - 1u);
+        uint32_t key = 0, fl = 0;
+        if (on) { key = L.ekey[ei]; fl = L.eflag[ei]; }
+        const bool closing = (fl & F2_CLOSING) != 0u, hdr_end = (fl & F2_HDR_END) != 0u;
+        const uint64_t hb = __ballot(hdr_end);
+        const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        const uint64_t hh = hb & upto;
+        const int src = hh ? 63 - __clzll((long long)hh) : (int)lane;
+        const uint32_t key_h = (uint32_t)__shfl((int)key, src, 64);
+        uint32_t seqlen = 0;
+        bool whole = true;  // header and closing line of the record are both in this range
+        if (closing) {
+            uint32_t key_i;
+            if (hh) key_i = key_h;
+            else { key_i = open_key; whole = open_is_header; }  // (else the record began in an earlier range: only its tail is here)
+            seqlen = key - key_i;
+            if (whole) { sumlen += seqlen; nrec += 1; }
+            else { D.r_head[range_id] = seqlen; atomicOr(&D.r_flags[range_id], RF_HEAD_CLOSED); }
+        }
+        add_length(closing && whole, seqlen, s_hist, D);
+        if (hb) {  // carry the last header end of this group (wave-uniform)
+            const int last = 63 - __clzll((long long)hb);
+            open_key = (uint32_t)__builtin_amdgcn_readlane((int)key, last);
+            open_is_header = true;
+        }
+    }
+
     template <bool FASTQ, bool ALL, class LDS>
     __device__ __forceinline__ void batch(LDS& L, uint32_t E, uint32_t wb, uint64_t tile_idx,
                                           uint32_t tile_rel, uint64_t re, const uint8_t* __restrict__ buf) {
@@ -301,14 +334,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
     // of LDS each, of which the length histogram takes 8.7 -- a window of 256 events fits, 512 would cost two waves per SIMD
     // (measured before: 7 waves against 6 is 3 % of the kernel); `-a` by line roles runs at 5 waves and takes the full window
     constexpr int WINDOW = (FASTQ && !SALL) ? 256 : CAP;
-    __shared__ Lds<FASTQ, SALL, WINDOW> s_l[WAVES_PER_BLOCK];
+    // FASTA default row, round 5: only the newlines the sink acts on become events (stream_fasta2_dev.hpp); ROLES_T = false keeps
+    // the pass that publishes every newline (stats_fasta=events: the tests hold the two against each other)
+    constexpr bool F2 = !FASTQ && !ALL && ROLES_T;
+    __shared__ Lds<FASTQ, SALL, F2 ? 4 : WINDOW> s_l[F2 ? 1 : WAVES_PER_BLOCK];
+    __shared__ LdsF2 s_f2[F2 ? WAVES_PER_BLOCK : 1];
     for (int i = threadIdx.x; i < LDS_HIST + 2 * BIG_SLOTS; i += blockDim.x)
         s_hist[i] = (i >= LDS_HIST && i < LDS_HIST + BIG_SLOTS) ? BIG_EMPTY : 0u;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Lds<FASTQ, SALL, WINDOW>& L = s_l[wave];
+    Lds<FASTQ, SALL, F2 ? 4 : WINDOW>& L = s_l[F2 ? 0 : wave];
     StatsSinkT<ROLES> sink;
     sink.s_hist = s_hist;
     sink.D = D;
@@ -351,7 +388,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         // chunks to their own ranges (above)
         const uint64_t skip_from = (!FASTQ && chunk) ? (uint64_t)(r + 1u) * chunk : ~0ull;
         const uint64_t count_resume = (!FASTQ && chunk) ? (re == n_eff ? re : (re / chunk) * chunk) : 0ull;
-        stream_range<FASTQ, SALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink, skip_from, count_resume);
+        if constexpr (F2) {
+            const F2Tail T = stream_range_fasta2<DPP>(s_f2[wave], buf, n, rs, re, re == n_eff, sink, skip_from);
+            sink.any_event = T.lines != 0u;
+            sink.last_closing = T.last_closing;
+            sink.last_key = T.last_key;
+            (void)count_resume; (void)L;
+        } else {
+            stream_range<FASTQ, SALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink, skip_from, count_resume);
+        }
         if constexpr (!FASTQ) sink.template end_range<ALL>();
         if constexpr (ROLES) {
             // wave totals of the range (uniform: they live in scalar registers between ranges)
@@ -597,8 +642,10 @@ hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_
     if (fastq && all && a_dense) return launch_stats_t<true, true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0);
     if (fastq) return all ? launch_stats_t<true, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0)
                           : launch_stats_t<true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0);
-    return all ? launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk)
-               : launch_stats_t<false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
+    if (all) return launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
+    // (FASTA default row: a_dense = the pass that publishes every newline, stats_fasta=events)
+    return a_dense ? launch_stats_t<false, false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk)
+                   : launch_stats_t<false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
 }
 
 int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense) {
@@ -610,6 +657,7 @@ int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense) {
     else if (fastq && all) { BSK_PICK(true, true, true) }
     else if (fastq) { BSK_PICK(true, false, true) }
     else if (all) { BSK_PICK(false, true, true) }
+    else if (a_dense) { BSK_PICK(false, false, false) }
     else { BSK_PICK(false, false, true) }
 #undef BSK_PICK
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, WAVES_PER_BLOCK * WAVE, 0) != hipSuccess || nb < 1) nb = 1;
