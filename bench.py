@@ -282,6 +282,45 @@ def run_end_to_end(H, gb=8.0):
     return res
 
 
+def stats_leg(H, cmd, t, nrec, fmt, opts, want, workload, how, pre_ok=True):
+    """One `stats` leg of the 'ops' object: `calls` whole steps (reset -> bsk_stats_run -> bsk_stats_collect, each one
+    synchronised by the collect), the map compared with `want` (every key of `want` must be there with that value, and the
+    length bins must hold nothing else), HIP-event time of the stages in a second set of calls."""
+    torch, lib, check, bsk = H.torch, H.lib, H.check, H.bsk
+    keys, vals, cnt = (C.c_int64 * 65536)(), (C.c_int64 * 65536)(), C.c_size_t()
+    n = t.numel()
+    with bsk.Operator("Stats", json.dumps(opts), H.local) as op:
+        def step():
+            check(lib.bsk_stats_reset(op.ctx, None), op.ctx)
+            check(lib.bsk_stats_run(op.ctx, C.c_void_p(t.data_ptr()), n, 1, fmt, 0, None, None), op.ctx)
+            check(lib.bsk_stats_collect(op.ctx, None, keys, vals, 65536, C.byref(cnt)), op.ctx)
+        step()
+        times = []
+        for _ in range(H.calls):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        m = dict(zip(keys[:cnt.value], vals[:cnt.value]))
+        lib.bsk_profile_reset(op.ctx)
+        lib.bsk_profile_enable(op.ctx, 1)
+        for _ in range(H.calls):
+            step()
+        lib.bsk_profile_enable(op.ctx, 0)
+        kern = H.kernels(op, H.calls)
+    lens = {k: v for k, v in m.items() if k >= 0}
+    ok = bool(pre_ok) and lens == {k: v for k, v in want.items() if k >= 0} and all(m.get(k, 0) == v for k, v in want.items() if k < 0)
+    mean_s = sum(times) / len(times)
+    e = {"command": cmd, "workload": workload, "records": int(nrec), "in_bytes": int(n), "calls": H.calls,
+         "ms": round(mean_s * 1e3, 4), "ms_min": round(min(times) * 1e3, 4), "M_records_per_s": round(nrec / mean_s / 1e6, 2),
+         "algorithmic_bytes": int(n), "achieved_GBps": round(n / mean_s / 1e9, 1), "frac": round(n / mean_s / 1e9 / HBM_PEAK_GBS, 4),
+         "kernels_ms_per_call": kern, "host_ms_per_call": round(mean_s * 1e3 - sum(kern.values()), 4) if kern else None,
+         "exact": ok, "exact_how": how}
+    if "k_stats" in kern and kern["k_stats"] > 0:
+        e["kernel_frac"] = round(n / (kern["k_stats"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return e
+
+
 def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     ops = {}
     H = _Helpers(args, torch, bsk, _lib, lib, check, dev, local)
@@ -333,6 +372,30 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     shard.data = torch.empty(0, dtype=torch.uint8, device=dev)  # the 100 GB file is not needed any more
     torch.cuda.empty_cache()  # libbsk allocates with hipMalloc, outside torch's pool
 
+    # ---- stats @ FASTA-1k: BASELINE C1's layout (1 kb records in 60-column lines) at 20 GB -- the FASTA pass ------
+    t, nrec = synth(_lib.SYNTH_FASTA1K, 0, 20e9 * args.ops_scale)
+    wl = "%.1f GB FASTA, %d records of 1 000 bases in 60-column lines (the layout of BASELINE C1)" % (t.numel() / 1e9, nrec)
+    v1k = t.view(nrec, 1027)
+    cols = torch.tensor([10 + (b // 60) * 61 + (b % 60) for b in range(1000)], device=dev)
+    layout_ok, gaps = True, 0
+    for i0 in range(0, nrec, 2_000_000):     # the expectation from the bytes: '>' + 8 name bytes + '\n', 1 000 letters, 17 line breaks
+        blk = v1k[i0:i0 + 2_000_000]
+        layout_ok = layout_ok and bool((blk[:, 0] == ord(">")).all()) and bool((blk[:, 9] == 10).all()) \
+            and int((blk == 10).sum().item()) == 18 * blk.shape[0]
+        sq = blk[:, cols]
+        gaps += int(((sq == ord("-")) | (sq == ord(" ")) | (sq == ord("."))).sum().item())
+        layout_ok = layout_ok and bool((sq >= ord("A")).all())
+        del blk, sq
+    ops["stats @ FASTA-1k (C1 layout, 20 GB)"] = stats_leg(
+        H, "stats", t, nrec, bsk.FORMAT_FASTA, {}, {1000: nrec}, wl,
+        "map == {1000: N}: every record is '>' + 8 name bytes + a line break, then 1 000 letters with 17 line breaks "
+        "(checked on the bytes with torch: markers, line-break count per record, letters at the sequence columns)", layout_ok)
+    ops["stats -a @ FASTA-1k (C1 layout, 20 GB)"] = stats_leg(
+        H, "stats -a", t, nrec, bsk.FORMAT_FASTA, {"All": True}, {1000: nrec, -3: gaps}, wl,
+        "map == {1000: N, gap: the count of '-', ' ', '.' at the sequence columns (torch)}", layout_ok)
+    del t, v1k, cols
+    torch.cuda.empty_cache()
+
     # ---- grep -s -p ACGTTGCAAGCT @ C3: one GPU's 12.5 GB shard of the 100 GB file, motif planted in 2 % of the reads --
     t, nrec = synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_MOTIF, 12.5e9 * args.ops_scale)
     op, out, mean_s, min_s, kern = timed_calls("Grep", lib.bsk_grep_run, {"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}, t,
@@ -357,22 +420,47 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     torch.cuda.empty_cache()
 
     # ---- translate -f 6 @ C4: 50 GB FASTA, 5 kb CDS records wrapped at 60 -------------------------------------------
-    t, nrec = synth(_lib.SYNTH_FASTA5K_CDS, 0, 50e9 * args.ops_scale)
-    RB = 5107
-    op, out, mean_s, min_s, kern = timed_calls("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, t.numel(), bsk.FORMAT_FASTA)
     # expectation: per input record six elements (frames 1, 2, 3, -1, -2, -3), each ">" + name + "\n" + protein wrapped at 60
-    # + "\n"; table 1 (the standard code) in TCAG order
+    # + "\n"; table 1 (the standard code) in TCAG order -- computed here with torch from records of a KNOWN shape (hdr =
+    # bytes of the header line with its newline, L bases in 60-column lines)
     aa_tab = torch.tensor(list(b"FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"), dtype=torch.uint8, device=dev)
     code = torch.zeros(256, dtype=torch.int64, device=dev)
     comp = torch.zeros(256, dtype=torch.int64, device=dev)
     for ch, v, cc in ((b"T", 0, b"A"), (b"C", 1, b"G"), (b"A", 2, b"T"), (b"G", 3, b"C")):
         code[ch[0]] = v
         comp[ch[0]] = cc[0]
-    bidx = torch.arange(5001, device=dev)
-    seq_cols = 22 + (bidx // 60) * 61 + (bidx % 60)
-    naa = [(5001 - k) // 3 for k in (0, 1, 2, 0, 1, 2)]
-    el_len = [22 + a + (a + 59) // 60 for a in naa]
-    OUT_RB = sum(el_len)
+
+    def shape_of(hdr, L):
+        naa = [(L - k) // 3 for k in (0, 1, 2, 0, 1, 2)]
+        el_len = [hdr + a + (a + 59) // 60 for a in naa]
+        return naa, el_len, sum(el_len)
+
+    def expected_translation(blk, hdr, L):
+        """blk: (m, hdr + L + ceil(L / 60)) input records of one shape -> (m, OUT_RB) expected output, frame 1 of row 0"""
+        m = blk.shape[0]
+        naa, el_len, out_rb = shape_of(hdr, L)
+        bidx = torch.arange(L, device=dev)
+        seqs = blk[:, hdr + (bidx // 60) * 61 + (bidx % 60)].long()   # (m, L) bases
+        rc = comp[seqs.flip(1)]                                        # reverse complement
+        exp = torch.full((m, out_rb), 10, dtype=torch.uint8, device=dev)   # '\n' everywhere, then fill
+        base, first = 0, None
+        for e, (src, k) in enumerate(((seqs, 0), (seqs, 1), (seqs, 2), (rc, 0), (rc, 1), (rc, 2))):
+            a = naa[e]
+            c = code[src[:, k:k + 3 * a]].view(m, a, 3)
+            prot = aa_tab[c[:, :, 0] * 16 + c[:, :, 1] * 4 + c[:, :, 2]]
+            exp[:, base] = ord(">")
+            exp[:, base + 1:base + hdr] = blk[:, 1:hdr]               # name + '\n'
+            j = torch.arange(a, device=dev)
+            exp[:, base + hdr + (j // 60) * 61 + (j % 60)] = prot
+            if e == 0:
+                first = prot[0]
+            base += el_len[e]
+        return exp, first
+
+    t, nrec = synth(_lib.SYNTH_FASTA5K_CDS, 0, 50e9 * args.ops_scale)
+    RB = 5107
+    op, out, mean_s, min_s, kern = timed_calls("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, t.numel(), bsk.FORMAT_FASTA)
+    _, _, OUT_RB = shape_of(22, 5001)
     view = t.view(nrec, RB)
     got = dev_bytes(out.d_data, out.len)
     ok = out.len == OUT_RB * nrec and out.records == 6 * nrec
@@ -382,24 +470,11 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         chunk = 100_000
         for i0 in range(0, nrec, chunk):
             i1 = min(nrec, i0 + chunk)
-            blk = view[i0:i1]
-            seqs = blk[:, seq_cols].long()                      # (m, 5001) bases
-            rc = comp[seqs.flip(1)]                               # reverse complement
-            exp = torch.full((i1 - i0, OUT_RB), 10, dtype=torch.uint8, device=dev)   # '\n' everywhere, then fill
-            base = 0
-            for e, (src, k) in enumerate(((seqs, 0), (seqs, 1), (seqs, 2), (rc, 0), (rc, 1), (rc, 2))):
-                a = naa[e]
-                c = code[src[:, k:k + 3 * a]].view(i1 - i0, a, 3)
-                prot = aa_tab[c[:, :, 0] * 16 + c[:, :, 1] * 4 + c[:, :, 2]]
-                exp[:, base] = ord(">")
-                exp[:, base + 1:base + 22] = blk[:, 1:22]         # name + '\n'
-                j = torch.arange(a, device=dev)
-                exp[:, base + 22 + (j // 60) * 61 + (j % 60)] = prot
-                if e == 0 and first_protein is None:
-                    first_protein = bytes(prot[0].cpu().tolist())
-                base += el_len[e]
+            exp, first = expected_translation(view[i0:i1], 22, 5001)
+            if first_protein is None:
+                first_protein = bytes(first.cpu().tolist())
             ok = ok and bool(torch.equal(gv[i0:i1], exp))
-            del blk, seqs, rc, exp
+            del exp
         ok = ok and first_protein is not None and first_protein[:1] == b"M" and first_protein[-1:] == b"*" \
             and len(first_protein) == 1667 and b"*" not in first_protein[:-1]
     ops["translate -f 6 @ C4"] = entry(
@@ -407,8 +482,88 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         % (t.numel() / 1e9, nrec), nrec, t.numel(), t.numel() + out.len, out, mean_s, min_s, kern, ok,
         "output == six frames per record translated here with torch (standard code as a 64-entry gather, reverse strand = "
         "flipped complement), headers and 60-column wrapping included, all records; frame 1 of record 0 is M...* of 1 667 aa",
-        None if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "translate", {"Frame": ["6"]}, t, RB, False)})
-    del got, view, t
+        dict({"layout_path": "uniform: every record has the shape of the first (UniformLayout, verified in-kernel: stage "
+                             "'k_translate_uniform'%s); the leg below is the same command on records that differ"
+                             % ("" if "k_translate_uniform" in kern else " -- NOT taken"),},
+             **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "translate", {"Frame": ["6"]}, t, RB, False)})))
+    del got, view
+    op.close()
+    # the same file as the input of `stats` (FASTA, 5 kb records): the default row, exact from the fixed layout
+    ops["stats @ C4 input (50 GB FASTA-5k)"] = stats_leg(H, "stats", t, nrec, bsk.FORMAT_FASTA, {}, {5001: nrec},
+                                                        "%.1f GB FASTA, %d records of 5 001 bases in 60-column lines" % (t.numel() / 1e9, nrec),
+                                                        "map == {5001: N} (every record of the synthetic layout has 5 001 bases: 22 header "
+                                                        "bytes, 84 line breaks, 5 107 bytes per record)")
+    del t
+    torch.cuda.empty_cache()
+
+    # ---- the same command on records that do NOT all look alike: unpadded record numbers in the header
+    # (15 .. 22 header bytes), one record in a hundred 4 998 or 5 004 bases long -- UniformLayout is refused, the call takes
+    # the table path (k_fasta_starts / k_fasta_heads + k_translate_wide<.., table>)
+    VAR = _lib.SYNTH_FASTA5K_VAR
+    nrec = 1
+    while lib.bsk_synth_offset(VAR, nrec * 2) <= 50e9 * args.ops_scale:
+        nrec *= 2
+    lo_n, hi_n = nrec, nrec * 2
+    while lo_n + 1 < hi_n:          # the largest record count whose file fits the size of C4
+        mid = (lo_n + hi_n) // 2
+        if lib.bsk_synth_offset(VAR, mid) <= 50e9 * args.ops_scale:
+            lo_n = mid
+        else:
+            hi_n = mid
+    nrec = lo_n
+    nbytes_v = int(lib.bsk_synth_offset(VAR, nrec))
+    t = torch.empty(nbytes_v, dtype=torch.uint8, device=dev)
+    check(lib.bsk_synth_device(VAR, 42, 0, 0, C.c_void_p(t.data_ptr()), nbytes_v, local, None))
+    torch.cuda.synchronize()
+    op, out, mean_s, min_s, kern = timed_calls("Translate", lib.bsk_translate_run, {"Frame": ["6"]}, t, nbytes_v, bsk.FORMAT_FASTA)
+    got = dev_bytes(out.d_data, out.len)
+    # shapes by record number: digits d(i), bases L(i) (synth.hpp KIND_FASTA5K_VAR); offsets are prefix sums of the sizes
+    idx = torch.arange(nrec, device=dev, dtype=torch.int64)
+    dig = torch.ones(nrec, device=dev, dtype=torch.int64)
+    p10 = 10
+    while p10 <= nrec:
+        dig += (idx >= p10).long()
+        p10 *= 10
+    Ls = torch.full((nrec,), 5001, device=dev, dtype=torch.int64)
+    Ls[idx % 100 == 37] = 4998
+    Ls[idx % 100 == 73] = 5004
+    in_sz = 14 + dig + Ls + 84
+    in_off = torch.cumsum(in_sz, 0) - in_sz
+    out_sz = torch.zeros(nrec, device=dev, dtype=torch.int64)
+    for k in (0, 1, 2, 0, 1, 2):
+        a = (Ls - k) // 3
+        out_sz += 14 + dig + a + (a + 59) // 60
+    out_off = torch.cumsum(out_sz, 0) - out_sz
+    ok = int(in_sz.sum().item()) == nbytes_v and out.len == int(out_sz.sum().item()) and out.records == 6 * nrec
+    nclass = 0
+    if ok:
+        chunk = 50_000
+        for i0 in range(0, nrec, chunk):
+            i1 = min(nrec, i0 + chunk)
+            dd, ll = dig[i0:i1], Ls[i0:i1]
+            for d in torch.unique(dd).tolist():
+                for L in (5001, 4998, 5004):
+                    sel = torch.nonzero((dd == d) & (ll == L)).flatten() + i0
+                    if sel.numel() == 0:
+                        continue
+                    nclass += 1
+                    hdr = 14 + int(d)
+                    rbc = hdr + L + 84
+                    _, _, orb = shape_of(hdr, L)
+                    blk = t[in_off[sel][:, None] + torch.arange(rbc, device=dev)[None, :]]
+                    exp, _ = expected_translation(blk, hdr, L)
+                    g = got[out_off[sel][:, None] + torch.arange(orb, device=dev)[None, :]]
+                    ok = ok and bool(torch.equal(g, exp))
+                    del blk, exp, g
+    ops["translate -f 6 @ C4, records that differ"] = entry(
+        "translate --frame 6", "%.1f GB FASTA, %d CDS records: '>cds%%d len=%%d' with unpadded numbers (15 .. 22 header bytes), "
+        "99 %% of 5 001 bases, 1 %% of 4 998 / 5 004, wrapped at 60" % (nbytes_v / 1e9, nrec), nrec, nbytes_v, nbytes_v + out.len, out,
+        mean_s, min_s, kern, ok,
+        "output == the same torch translation, records gathered by shape class (header digits x length) from offsets that are "
+        "prefix sums of the record sizes, every record compared",
+        {"layout_path": "table: the head sample's records differ, UniformLayout is refused ('k_translate_uniform' is %s the stages of "
+                        "this call)" % ("NOT among" if "k_translate_uniform" not in kern else "AMONG"), "shape_classes_checked": nclass})
+    del got, t, idx, dig, Ls, in_sz, in_off, out_sz, out_off
     op.close()
     torch.cuda.empty_cache()
 
@@ -435,8 +590,10 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         ok_k, _ = rows_equal(dev_bytes(out_k.d_data, out_k.len), view, lambda i0, i1: (torch.arange(i0, i1, device=dev) % 5) != 4, REC)
     op_k.close()
     extra = {"survivors": int(out.records),
-             "rmdup_keys": "verify (default): XXH64 + second key group the records, the sequence bytes of every duplicate are compared "
-                           "with its survivor's (RmDupCheck, rmdup.go:193-199)",
+             "rmdup_keys": "verify (default): ONE 64-bit key groups the records -- the chain-free grouping key of csrc/hash_dev.hpp, whose "
+                           "value nothing but the grouping sees -- and the sequence bytes of every duplicate are compared with its "
+                           "survivor's (RmDupCheck, rmdup.go:193-199); a shard whose comparison meets two sequences under one key "
+                           "runs again with XXH64 + the second key",
              "rmdup_keys_two_key": {"ms": round(mean_k * 1e3, 4), "ms_min": round(min_k * 1e3, 4), "kernels_ms_per_call": kern_k,
                                     "exact": bool(ok_k), "note": "bsk_ctx_set(ctx, 'rmdup_keys', 'two-key'): no byte comparison"}}
     if not args.no_cpu_baseline:

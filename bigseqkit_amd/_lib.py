@@ -65,7 +65,7 @@ BSK_OK, BSK_ERR_INVALID_ARG, BSK_ERR_OPTS, BSK_ERR_FORMAT, BSK_ERR_UNSUPPORTED, 
     BSK_ERR_NO_DEVICE, BSK_ERR_CAPACITY, BSK_ERR_OVERFLOW_EXCHANGE = range(9)
 FORMAT_FASTA, FORMAT_FASTQ = 0, 1
 STATS_HDR = 8
-SYNTH_FASTQ150, SYNTH_FASTA1K, SYNTH_FASTA5K_CDS = 0, 1, 2
+SYNTH_FASTQ150, SYNTH_FASTA1K, SYNTH_FASTA5K_CDS, SYNTH_FASTA5K_VAR = 0, 1, 2, 3
 SYNTH_FLAG_MOTIF, SYNTH_FLAG_DUPS = 1, 2
 
 
@@ -143,6 +143,7 @@ SIGNATURES = {
     "bsk_rmdup_dist_resolve": (_i, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "bsk_rmdup_dist_emit": (_i, [_vp, _vp, _vp, C.c_uint64, _vp, _p(Out)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
+    "bsk_synth_offset": (_u64, [_i, _u64]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),
     "bsk_synth_device": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz, _i, _vp]),
     "bsk_event_create": (_i, [_p(_vp)]),

@@ -1207,15 +1207,19 @@ int bsk_rmdup_dist_emit(bsk_ctx* c, const void* d_send, const void* d_reply, uin
 // synthetic inputs
 // ---------------------------------------------------------------------------
 size_t bsk_synth_record_bytes(int kind) { return synth::record_bytes(kind); }
+uint64_t bsk_synth_offset(int kind, uint64_t record) {
+    return kind == synth::KIND_FASTA5K_VAR ? synth::var_offset(record) : record * (uint64_t)synth::record_bytes(kind);
+}
 
 int bsk_synth_host(int kind, uint64_t seed, unsigned flags, uint64_t first_record, uint8_t* dst, size_t n) {
     if (!dst && n) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null dst");
-    const uint32_t rb = synth::record_bytes(kind);
+    const bool var = kind == synth::KIND_FASTA5K_VAR;
+    uint32_t rb = var ? synth::var_record_bytes(first_record) : synth::record_bytes(kind);
     uint64_t i = first_record;
     uint32_t k = 0;
     for (size_t p = 0; p < n; ++p) {
         dst[p] = synth::byte_at(kind, seed, flags, i, k);
-        if (++k == rb) { k = 0; ++i; }
+        if (++k == rb) { k = 0; ++i; if (var) rb = synth::var_record_bytes(i); }
     }
     return BSK_OK;
 }

@@ -49,7 +49,7 @@ struct F2Tail {
 };
 
 #ifndef BSK_F2_NT
-#define BSK_F2_NT 0  // non-temporal tile loads of this pass (measured in scripts/history/r05_fasta2.sh)
+#define BSK_F2_NT 1  // non-temporal tile loads: FASTA-5k 50 GB 9.72 -> 9.22 ms, FASTA-1k 20 GB 3.65 -> 3.63 (scripts/history/r05_d.sh)
 #endif
 
 template <bool DPP, class Sink>

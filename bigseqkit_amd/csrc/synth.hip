@@ -14,13 +14,23 @@ __global__ __launch_bounds__(256) void k_synth(int kind, uint64_t seed, unsigned
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks;
          c += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t off = c * 16;
-        uint64_t i = first_record + off / rb;
-        uint32_t k = (uint32_t)(off % rb);
+        uint64_t i;
+        uint32_t k, cur;
+        if (kind == synth::KIND_FASTA5K_VAR) {  // records of several sizes: the record of a file byte by search over the closed-form offsets
+            const uint64_t x = synth::var_offset(first_record) + off;
+            i = synth::var_record_at(x);
+            k = (uint32_t)(x - synth::var_offset(i));
+            cur = synth::var_record_bytes(i);
+        } else {
+            i = first_record + off / rb;
+            k = (uint32_t)(off % rb);
+            cur = rb;
+        }
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             w[b >> 2] |= (uint32_t)synth::byte_at(kind, seed, flags, i, k) << ((b & 3) * 8);
-            if (++k == rb) { k = 0; ++i; }
+            if (++k == cur) { k = 0; ++i; if (kind == synth::KIND_FASTA5K_VAR) cur = synth::var_record_bytes(i); }
         }
         if (off + 16 <= n && (((uintptr_t)dst) & 15) == 0) {
             *reinterpret_cast<uint4*>(dst + off) = make_uint4(w[0], w[1], w[2], w[3]);

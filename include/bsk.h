@@ -380,9 +380,13 @@ int bsk_run_to_store(bsk_ctx* ctx, const void* host_shard, size_t n, int format,
 #define BSK_SYNTH_FASTQ150 0 /* 317 B/record                          */
 #define BSK_SYNTH_FASTA1K 1  /* 1027 B/record, 60-column lines        */
 #define BSK_SYNTH_FASTA5K_CDS 2
+#define BSK_SYNTH_FASTA5K_VAR 3 /* the same CDS records with unpadded numbers in the header and 1 % of them 3 bases shorter /
+                                 * longer: records of several sizes (bsk_synth_record_bytes = 0, bsk_synth_offset) */
 #define BSK_SYNTH_FLAG_MOTIF 1u /* C3: plant ACGTTGCAAGCT / its revcomp */
 #define BSK_SYNTH_FLAG_DUPS 2u  /* C5: 20 % sequence duplicates         */
 size_t bsk_synth_record_bytes(int kind);
+/* file offset of record `record` (== bytes of the records below it); n bytes from there: bsk_synth_host / _device */
+uint64_t bsk_synth_offset(int kind, uint64_t record);
 /* fill dst[0..n) with the bytes [first_record*record_bytes, ...+n) of the
  * synthetic file; n need not be a whole number of records */
 int bsk_synth_host(int kind, uint64_t seed, unsigned flags, uint64_t first_record, uint8_t* dst, size_t n);

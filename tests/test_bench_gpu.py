@@ -78,7 +78,9 @@ def test_bench_ops_object_small():
     d = run_bench(["--gb", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--ops-scale", "0.02", "--ops-calls", "2"])
     ops = d["ops"]
     assert "error" not in ops, ops
-    assert set(ops) == {"seq -n @ C2", "subseq -r 1:50 (25 GB)", "grep -s -p @ C3 shard", "translate -f 6 @ C4", "rmdup -s @ C5 shard"}
+    stats_legs = {"stats @ FASTA-1k (C1 layout, 20 GB)", "stats -a @ FASTA-1k (C1 layout, 20 GB)", "stats @ C4 input (50 GB FASTA-5k)"}
+    assert set(ops) == {"seq -n @ C2", "subseq -r 1:50 (25 GB)", "grep -s -p @ C3 shard", "translate -f 6 @ C4",
+                        "translate -f 6 @ C4, records that differ", "rmdup -s @ C5 shard"} | stats_legs
     for name, e in ops.items():
         assert e["exact"] is True, (name, e)
         assert e["ms"] > 0 and e["algorithmic_bytes"] >= e["in_bytes"] and 0 < e["frac"] < 1, (name, e)
@@ -90,11 +92,17 @@ def test_bench_ops_object_small():
     t = ops["translate -f 6 @ C4"]
     assert t["out_records"] == 6 * t["records"] and t["out_bytes"] == 10298 * t["records"]
     assert "k_translate_uniform" in t["kernels_ms_per_call"]       # the C4 layout needs no table
-    # the byte-comparing default and the two-key mode beside it
-    assert r["rmdup_keys"].startswith("verify") and "k_rmdup_verify" in r["kernels_ms_per_call"]
+    tv = ops["translate -f 6 @ C4, records that differ"]           # ... records that differ do
+    assert "k_translate_uniform" not in tv["kernels_ms_per_call"] and tv["out_records"] == 6 * tv["records"] and tv["shape_classes_checked"] >= 3
+    for name in stats_legs:                                        # FASTA `stats` (the pass of stream_fasta2_dev.hpp), exact maps
+        assert "k_stats" in ops[name]["kernels_ms_per_call"] and 0 < ops[name]["kernel_frac"] < 1, ops[name]
+    # the byte-comparing default (one pass: comparison + placement) and the two-key mode beside it
+    assert r["rmdup_keys"].startswith("verify") and "k_rmdup_place" in r["kernels_ms_per_call"]
     assert r["rmdup_keys_two_key"]["exact"] is True and "k_rmdup_sizes" in r["rmdup_keys_two_key"]["kernels_ms_per_call"]
     # a CPU baseline (the oracle: a port, 1 thread and all cores) beside every operator, and the host-bytes-to-result leg
     for name, e in ops.items():
+        if name in stats_legs or name == "translate -f 6 @ C4, records that differ":
+            continue
         cb = e["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0, (name, cb)
         if name != "rmdup -s @ C5 shard":
