@@ -514,6 +514,11 @@ int bsk_stats_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
     return BSK_OK;
 }
 
+int bsk_device_select(int device) {
+    if (hipSetDevice(device) != hipSuccess) return fail_global(BSK_ERR_NO_DEVICE, "libbsk: no such HIP device");
+    return BSK_OK;
+}
+
 void* bsk_device_alloc(size_t n) {
     void* p = nullptr;
     if (hipMalloc(&p, n ? n : 1) != hipSuccess) { fail_global(BSK_ERR_HIP, "libbsk: device allocation failed"); return nullptr; }

@@ -35,13 +35,13 @@ done
 LIBKEY=$(printf '%s' "$KEYS" | sha256sum | cut -d' ' -f1)
 if [ ! -f "$OUT/libbsk.so" ] || [ ! -f "$OUT/libbsk.so.key" ] || [ "$(cat "$OUT/libbsk.so.key")" != "$LIBKEY" ]; then
   rm -f "$OUT/libbsk.so.key"
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbsk.so" "${OBJS[@]}"
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbsk.so" "${OBJS[@]}" -ldl -lpthread
   printf '%s' "$LIBKEY" > "$OUT/libbsk.so.key"
 fi
 CLIKEY="$(hash_of cli/bigseqkit.cpp $SRC/json.hpp include/bsk.h) $LIBKEY"
 if [ ! -f bigseqkit_amd/bin/bigseqkit ] || [ ! -f bigseqkit_amd/bin/bigseqkit.key ] || [ "$(cat bigseqkit_amd/bin/bigseqkit.key)" != "$CLIKEY" ]; then
   rm -f bigseqkit_amd/bin/bigseqkit.key
-  $CXX $FLAGS -o bigseqkit_amd/bin/bigseqkit cli/bigseqkit.cpp -L"$OUT" -lbsk -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
+  $CXX $FLAGS -pthread -o bigseqkit_amd/bin/bigseqkit cli/bigseqkit.cpp -L"$OUT" -lbsk -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
   printf '%s' "$CLIKEY" > bigseqkit_amd/bin/bigseqkit.key
 fi
 make -s -C oracle

@@ -13,8 +13,11 @@
 // Extras of this CLI: --device N, --dry-run (print the operator name and option JSON, no GPU needed),
 // and "-o -" for standard output.
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <sys/sendfile.h>
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -23,8 +26,10 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <atomic>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/bsk.h"
@@ -56,7 +61,8 @@ const Flag kPersistent[] = {
     {"device", 0, INT, "", "0"},
     {"dry-run", 0, BOOL, "", "false"},
     {"plan", 0, BOOL, "", "false"},      // one JSON object: operator, options, files, output place (python -m bigseqkit_amd.run)
-    {"devices", 0, STR, "", ""},         // "0,1,2,3" / "0-7": one worker per GPU (bigseqkit_amd/run.py takes over)
+    {"devices", 0, STR, "", ""},         // "0,1,2,3" / "0-7": one worker THREAD per GPU in this process, collectives over librccl
+                                         // (run_devices below); a device named twice shares its GPU (tests)
 };
 
 struct Command {
@@ -655,6 +661,291 @@ void store(const Invocation& inv, const Output& out, const std::vector<std::stri
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// several GPUs, in THIS process (round 5): one worker thread + one context per device, the collectives of the command
+// behind the C ABI (bsk_comm_*: librccl, ncclCommInitAll) -- what ignisDriver does with executors
+// (bigseqkit-cli/helper.go:87-141; ReadFASTA/Q[N] + StoreFASTX[N], bigseqkit/helper.go:148-195).  No Python in the process
+// tree (until round 4 this flag exec'd `python -m bigseqkit_amd.run`, which stays as the test harness of the Python side).
+//   * the FILE is cut, not copied: it is mapped, every cut is the first record start at or behind size * k / world, found in
+//     a 1 MiB window of the mapping (bsk_find_record_start: the ReadFixer rule; the window grows while it ends on a record
+//     that may be cut off), and every worker reads only its own byte range into pinned host memory;
+//   * seq / grep / locate / subseq / translate / fq2fa: bsk_run_to_store (H2D || kernels || D2H + write) into
+//     <out>/part%05d, one per worker (StoreFASTXN) or, with --merge, into ONE file at offsets from an all-gather of the
+//     sizes (the reference passes an MPI token, bigseqkit-lib/helper.go:399-429);
+//   * stats: bsk_stats_collect_reduced (StatsReduce: one ncclAllReduce of the stats vector), worker 0 prints the table;
+//   * grep -C: bsk_count_allreduce;   rmdup: bsk_rmdup_dist_run (the 24-byte tuple exchange of GroupByKey).
+// ---------------------------------------------------------------------------
+std::vector<int> parse_devices(const std::string& text) {
+    std::vector<int> out;
+    size_t i = 0;
+    while (i <= text.size()) {
+        const size_t e = std::min(text.find(',', i), text.size());
+        const std::string piece = text.substr(i, e - i);
+        if (!piece.empty()) {
+            const size_t dash = piece.find('-', 1);
+            char* end = nullptr;
+            if (dash == std::string::npos) {
+                const long v = strtol(piece.c_str(), &end, 10);
+                if (*end || v < 0) die("--devices: bad device '" + piece + "'");
+                out.push_back((int)v);
+            } else {
+                const long a = strtol(piece.substr(0, dash).c_str(), &end, 10), b = strtol(piece.substr(dash + 1).c_str(), nullptr, 10);
+                if (a < 0 || b < a || b - a > 63) die("--devices: bad range '" + piece + "'");
+                for (long v = a; v <= b; ++v) out.push_back((int)v);
+            }
+        }
+        i = e + 1;
+    }
+    if (out.empty()) die("--devices names no device");
+    if (out.size() > 64) die("--devices: at most 64 workers");
+    return out;
+}
+
+std::vector<size_t> cut_points(const uint8_t* map, size_t size, int world, int fmt) {
+    std::vector<size_t> cuts{0};
+    for (int k = 1; k < world; ++k) {
+        const size_t nominal = (size_t)((unsigned __int128)size * (unsigned)k / (unsigned)world);
+        const size_t lo = std::max(nominal, cuts.back());
+        if (lo >= size) { cuts.push_back(size); continue; }
+        size_t win = 1u << 20;
+        for (;;) {
+            const size_t a = lo > 0 ? lo - 1 : 0;  // (the byte before `lo` tells whether `lo` begins a line)
+            const size_t b = std::min(size, lo + win);
+            size_t found = 0;
+            if (bsk_find_record_start(map + a, b - a, lo - a, fmt, &found) != BSK_OK) die(bsk_global_error());
+            found += a;
+            // a start close to the window's end was judged on a record that may be cut off: once more with more text behind it
+            if (b < size && found + (64u << 10) > b) { win *= 4; continue; }
+            cuts.push_back(std::min(found, size));
+            break;
+        }
+    }
+    cuts.push_back(size);
+    return cuts;
+}
+
+struct Worker {
+    std::string error;            // why this worker gave up ("" = fine)
+    uint64_t out_bytes = 0, out_records = 0;
+    std::string spool;            // --merge / -o -: this worker's part before it is put in place
+    std::string text;             // worker 0: what goes to stdout (stats table, grep -C count)
+};
+
+int run_devices(const Invocation& inv) {
+    const std::string use = inv.cmd->use;
+    static const char* const kStreamed[] = {"seq", "grep", "locate", "subseq", "translate", "fq2fa"};
+    bool streamed = false;
+    for (const char* u : kStreamed) streamed = streamed || use == u;
+    if (!streamed && use != "stats" && use != "rmdup")
+        die("'" + use + "' runs on one device (bigseqkit " + use + " ... --device N); several GPUs: fq2fa, grep, locate, rmdup, seq, stats, subseq, translate");
+    if (inv.files.size() != 1) die("--devices: exactly one input file (it is cut into one shard per GPU)");
+    const std::vector<int> devices = parse_devices(inv.pget("devices"));
+    const int world = (int)devices.size();
+    if (bsk_device_count() <= 0) die("no HIP device visible (the hot path has no CPU fallback)");
+    const std::string& path = inv.files[0];
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("open " + path + ": no such file or directory");
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) die("stat " + path + " failed");
+    const size_t size = (size_t)sb.st_size;
+    const uint8_t* map = nullptr;
+    if (size) {
+        map = (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
+        if (map == MAP_FAILED) die("mmap " + path + " failed");
+    }
+    const int fmt = sniff_format(path, size ? std::string((const char*)map, 1) : std::string());
+    const std::vector<size_t> cuts = size ? cut_points(map, size, world, fmt) : std::vector<size_t>((size_t)world + 1, 0);
+    if (map) munmap((void*)map, size);
+    // RCCL greets on file descriptor 1 (its version banner, when a communicator is first used) -- and stdout is where
+    // `stats`, `grep -C` and `-o -` put their RESULT.  For the rest of this call descriptor 1 IS stderr; results go to the
+    // real stdout through a duplicate of it.
+    fflush(stdout);
+    const int real_out = dup(1);
+    if (real_out < 0 || dup2(2, 1) < 0) die("cannot duplicate the standard output");
+    std::vector<bsk_comm*> comms((size_t)world, nullptr);
+    if (bsk_comm_init_all(world, devices.data(), comms.data()) != BSK_OK) die(bsk_comm_error(nullptr));
+
+    std::string out_file = inv.pget("out-file");
+    if (out_file.empty()) out_file = path + "-out";
+    const bool merge = inv.pget("merge") == "true", to_stdout = out_file == "-";
+    const bool grep_count = use == "grep" && inv.pget("count") == "true";
+    const bool records = !(use == "stats" || grep_count);
+    bsk_store* dir_store = nullptr;
+    char token[64];
+    snprintf(token, sizeof token, "%d-%08x", (int)getpid(), (unsigned)((uintptr_t)&token ^ (uintptr_t)time(nullptr) * 2654435761u));
+    if (records && !merge && !to_stdout) {
+        if (!is_dir(out_file) && mkdir(out_file.c_str(), 0755) != 0) die("cannot create directory " + out_file);
+        // (part files of an earlier run with MORE workers would be read as part of this result: ADVICE r04)
+        for (int k = world; k < world + 4096; ++k) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "/part%05d", k);
+            if (unlink((out_file + nm).c_str()) != 0) break;
+        }
+        if (bsk_store_open(out_file.c_str(), 0, &dir_store) != BSK_OK) die("cannot open the directory " + out_file);
+    }
+    std::vector<Worker> W((size_t)world);
+    std::atomic<int> failed{0};
+
+    auto work = [&](int rank) {
+        Worker& me = W[(size_t)rank];
+        bsk_comm* comm = comms[(size_t)rank];
+        const int device = devices[(size_t)rank];
+        const size_t lo = cuts[(size_t)rank], n = cuts[(size_t)rank + 1] - lo;
+        bsk_ctx* ctx = nullptr;
+        void* h = nullptr;
+        void* d_shard = nullptr;
+        bsk_store* own = nullptr;
+        auto give_up = [&](const std::string& m) { if (me.error.empty()) me.error = m.empty() ? "failed" : m; failed.fetch_add(1); };
+        do {
+            if (bsk_create(inv.cmd->op, inv.js.c_str(), device, &ctx) != BSK_OK) { give_up(bsk_global_error()); break; }
+            // this worker's bytes, and only they, into pinned host memory
+            h = bsk_host_alloc(std::max<size_t>(1, n));
+            if (!h) { give_up("pinned allocation of " + std::to_string(n) + " bytes failed"); break; }
+            size_t done = 0;
+            while (done < n) {
+                const ssize_t got = pread(fd, (char*)h + done, std::min<size_t>(n - done, 256u << 20), (off_t)(lo + done));
+                if (got <= 0) break;
+                done += (size_t)got;
+            }
+            if (done < n) { give_up("short read of " + path); break; }
+        } while (false);
+        // every worker enters every collective, also the one that has given up (its contribution is empty): the others must
+        // not wait for it for ever
+        const bool ok0 = me.error.empty();
+        if (use == "stats") {
+            std::vector<int64_t> keys(1 << 20), vals(1 << 20);
+            size_t cnt = 0;
+            int rc = ok0 ? bsk_stats_reset(ctx, nullptr) : BSK_ERR_INVALID_ARG;
+            if (rc == BSK_OK && n) rc = bsk_stats_run(ctx, h, n, 0, fmt, rank, nullptr, nullptr);
+            if (ok0 && rc != BSK_OK) give_up(bsk_last_error(ctx));
+            uint64_t bad = (uint64_t)failed.load();
+            if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); return; }
+            if (bad) return;  // (somebody failed before the reduction: nobody enters it)
+            rc = bsk_stats_collect_reduced(ctx, comm, nullptr, nullptr, keys.data(), vals.data(), keys.size(), &cnt);
+            if (rc != BSK_OK) { give_up(bsk_last_error(ctx)); }
+            else if (rank == 0) {
+                bsk_statinfo info;
+                bsk_stats_finalize(ctx, keys.data(), vals.data(), cnt, &info);
+                std::vector<char> buf(1 << 16);
+                if (bsk_stats_string(ctx, "input0", "N/A", &info, buf.data(), buf.size()) != BSK_OK) give_up(bsk_last_error(ctx));
+                else {
+                    const std::string table = buf.data();
+                    const size_t nl = table.find('\n');
+                    me.text = table.substr(0, nl + 1) + table.substr(nl + 1) + "\n";  // (head + Join(lines[1:]) + "\n", as the single-device CLI)
+                }
+            }
+        } else if (grep_count) {
+            uint64_t cnt = 0;
+            if (ok0) {
+                bsk_out o;
+                if (bsk_grep_run(ctx, h, n, 0, fmt, rank, nullptr, &o) != BSK_OK || bsk_grep_last_count(ctx, &cnt) != BSK_OK) give_up(bsk_last_error(ctx));
+            }
+            uint64_t bad = (uint64_t)failed.load();
+            if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); return; }
+            if (!bad) {
+                if (bsk_count_allreduce(comm, &cnt, nullptr) != BSK_OK) give_up(bsk_comm_error(comm));
+                else if (rank == 0) me.text = std::to_string(cnt);  // fmt.Print: no newline (bigseqkit-cli/grep.go:14)
+            }
+        } else {
+            bsk_store* st = dir_store;
+            uint64_t part = (uint64_t)rank;
+            if (ok0 && !dir_store) {  // --merge / -o -: this worker's part goes to a spool file of its own first
+                char nm[96];
+                snprintf(nm, sizeof nm, ".bsk-%s-part%05d.tmp", token, rank);
+                me.spool = (to_stdout ? std::string(getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp") + "/bsk-stdout" : out_file) + nm;
+                const int tfd = open(me.spool.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);  // (never through a planted link)
+                if (tfd < 0) give_up("cannot create " + me.spool);
+                else {
+                    close(tfd);
+                    if (bsk_store_open(me.spool.c_str(), 1, &own) != BSK_OK) give_up("cannot create " + me.spool);
+                    st = own;
+                    part = 0;
+                }
+            }
+            if (use == "rmdup") {
+                bsk_out o{nullptr, 0, 0};
+                if (me.error.empty()) {
+                    bsk_device_select(device);
+                    d_shard = bsk_device_alloc(std::max<size_t>(1, n));
+                    if (!d_shard || (n && bsk_device_copy(d_shard, h, n, BSK_COPY_H2D) != BSK_OK)) give_up(bsk_global_error());
+                }
+                uint64_t bad = (uint64_t)failed.load();
+                if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); bad = 1; }
+                if (!bad) {
+                    if (bsk_rmdup_dist_run(ctx, comm, d_shard, n, fmt, nullptr, &o) != BSK_OK) give_up(bsk_last_error(ctx));
+                    else if (bsk_store_put(st, ctx, part, &o) != BSK_OK) give_up(bsk_store_error(st));
+                    me.out_bytes = o.len; me.out_records = o.records;
+                }
+            } else if (me.error.empty()) {
+                if (bsk_run_to_store(ctx, h, n, fmt, rank, st, part, &me.out_bytes, &me.out_records) != BSK_OK) give_up(bsk_last_error(ctx));
+            }
+            if (own) {
+                uint64_t tot = 0;
+                if (bsk_store_close(own, &tot) != BSK_OK) give_up("closing " + me.spool + " failed");
+            }
+        }
+        if (d_shard) bsk_device_free(d_shard);
+        if (h) bsk_host_free(h);
+        if (ctx) bsk_destroy(ctx);
+    };
+    std::vector<std::thread> threads;
+    for (int r = 0; r < world; ++r) threads.emplace_back(work, r);
+    for (auto& t : threads) t.join();
+    for (auto* c : comms) bsk_comm_destroy(c);
+    close(fd);
+    uint64_t tot = 0;
+    if (dir_store && bsk_store_close(dir_store, &tot) != BSK_OK) { W[0].error = "closing the output failed"; failed.fetch_add(1); }
+    auto drop_spools = [&] { for (auto& w : W) if (!w.spool.empty()) unlink(w.spool.c_str()); };
+    if (failed.load()) {
+        drop_spools();
+        for (int r = 0; r < world; ++r)
+            if (!W[(size_t)r].error.empty()) die("worker " + std::to_string(r) + " (device " + std::to_string(devices[(size_t)r]) + "): " + W[(size_t)r].error);
+        die("a worker failed");
+    }
+    if (!records) {
+        size_t w = 0;
+        while (w < W[0].text.size()) {
+            const ssize_t k = write(real_out, W[0].text.data() + w, W[0].text.size() - w);
+            if (k <= 0) die("write to the standard output failed");
+            w += (size_t)k;
+        }
+        return 0;
+    }
+    if (dir_store) {
+        for (int r = 0; r < world; ++r)  // (an empty part file still marks the partition, as SaveAsTextFile does)
+            if (W[(size_t)r].out_bytes == 0) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "/part%05d", r);
+                const int e = open((out_file + nm).c_str(), O_CREAT | O_WRONLY, 0644);
+                if (e >= 0) close(e);
+            }
+        return 0;
+    }
+    // ---- one file (or stdout): the parts in rank order == file order (FileStore's order)
+    const int dst = to_stdout ? real_out : open(out_file.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (dst < 0) { drop_spools(); die("cannot create " + out_file); }
+    bool okw = true;
+    std::vector<char> buf(8u << 20);
+    for (int r = 0; r < world && okw; ++r) {
+        const int src = open(W[(size_t)r].spool.c_str(), O_RDONLY);
+        if (src < 0) { okw = false; break; }
+        for (;;) {
+            const ssize_t k = read(src, buf.data(), buf.size());
+            if (k < 0) { okw = false; break; }
+            if (k == 0) break;
+            ssize_t w = 0;
+            while (w < k) { const ssize_t x = write(dst, buf.data() + w, (size_t)(k - w)); if (x <= 0) { okw = false; break; } w += x; }
+            if (!okw) break;
+        }
+        close(src);
+    }
+    if (!to_stdout && close(dst) != 0) okw = false;
+    drop_spools();
+    if (!okw) die("write " + out_file + " failed");
+    return 0;
+}
+
 }  // namespace
 
 static int run_main(int argc, char** argv) {
@@ -707,31 +998,7 @@ static int run_main(int argc, char** argv) {
                   << ",\"partitions\":" << strtol(inv.pget("partitions").c_str(), nullptr, 10) << "}\n";
         return 0;
     }
-    if (!inv.pget("devices").empty()) {
-        // several GPUs: one worker process per device, the file cut on record starts, collectives where the command has
-        // a reduction or an exchange (bigseqkit_amd/run.py; bigseqkit/helper.go:148-195 + bigseqkit-cli/helper.go:87-141)
-        char exe[4096];
-        const ssize_t el = readlink("/proc/self/exe", exe, sizeof exe - 1);
-        std::string root = ".";
-        if (el > 0) {
-            exe[el] = 0;
-            root = exe;
-            for (int up = 0; up < 3; ++up) { const size_t sl = root.rfind('/'); if (sl == std::string::npos) break; root.resize(sl); }
-        }
-        const char* pp = getenv("PYTHONPATH");
-        setenv("PYTHONPATH", (root + (pp ? std::string(":") + pp : std::string())).c_str(), 1);
-        std::vector<std::string> av{"python3", "-m", "bigseqkit_amd.run", "--devices", inv.pget("devices"), "--"};
-        for (size_t i = 0; i < args.size(); ++i) {
-            if (args[i] == "--devices") { ++i; continue; }
-            if (args[i].rfind("--devices=", 0) == 0) continue;
-            av.push_back(args[i]);
-        }
-        std::vector<char*> cav;
-        for (auto& a : av) cav.push_back(const_cast<char*>(a.c_str()));
-        cav.push_back(nullptr);
-        execvp("python3", cav.data());
-        die("cannot start python3 -m bigseqkit_amd.run");
-    }
+    if (!inv.pget("devices").empty()) return run_devices(inv);  // several GPUs: worker threads + librccl, in this process
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
     g_faidx_query = faidx_query;
     std::vector<Part> inputs = read_parts(inv.files);

@@ -146,6 +146,7 @@ int bsk_stats_run(bsk_ctx* ctx, const void* shard, size_t n, int on_device, int 
 #define BSK_COPY_H2D 1
 #define BSK_COPY_D2H 2
 #define BSK_COPY_D2D 3
+int bsk_device_select(int device); /* the current device of the calling thread (hipSetDevice): where bsk_device_alloc allocates */
 void* bsk_device_alloc(size_t n);
 void bsk_device_free(void* p);
 int bsk_device_copy(void* dst, const void* src, size_t n, int kind); /* synchronous */
@@ -347,6 +348,45 @@ int bsk_rmdup_dist_pack(bsk_ctx* ctx, uint64_t base_index, int world, void* d_se
 int bsk_rmdup_dist_resolve(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void* d_keep, void* stream);
 int bsk_rmdup_dist_emit(bsk_ctx* ctx, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
                         bsk_out* out);
+
+/* ---- collectives behind the C ABI (round 5): RCCL over xGMI, no Python, no torch -----------------------------------------
+ * In the reference the driver gets Reduce and GroupByKey from IgnisHPC, in the same binary (bigseqkit/stats.go:91,
+ * grep.go:175, rmdup.go:97; the executors from ignisDriver, bigseqkit-cli/helper.go:87-132).  A bsk_comm is one rank's
+ * handle on a group of `world` ranks, each with its own GPU and its own bsk_ctx:
+ *   one rank per PROCESS : rank 0 calls bsk_comm_unique_id, the host hands the 128 bytes to the other ranks (a file, a
+ *                          socket, the launcher's environment), every rank calls bsk_comm_init_rank   (ncclCommInitRank)
+ *   all ranks in ONE process, a thread each : bsk_comm_init_all(ndev, devices, comms)                 (ncclCommInitAll);
+ *                          devices that repeat (ranks sharing a GPU: RCCL refuses that) get the "local" backend -- the
+ *                          same calls through host memory between the threads (tests on a one-GPU box)
+ * librccl is loaded at the first of these calls, not with libbsk.so.  Every collective must be entered by ALL ranks.
+ * Errors: the code, and bsk_comm_error(comm) (bsk_comm_error(NULL): the calling thread's last failure without a comm). */
+typedef struct bsk_comm bsk_comm;
+#define BSK_COMM_ID_BYTES 128
+int bsk_comm_unique_id(void* id128);
+int bsk_comm_init_rank(int world, int rank, const void* id128, int device, bsk_comm** out);
+int bsk_comm_init_all(int ndev, const int* devices, bsk_comm** out /* [ndev] */);
+int bsk_comm_destroy(bsk_comm* comm);
+int bsk_comm_info(const bsk_comm* comm, int* world, int* rank, int* device, int* over_rccl);
+const char* bsk_comm_error(const bsk_comm* comm);
+int bsk_comm_barrier(bsk_comm* comm, void* stream);
+/* in place on `count` device words; op: 0 sum, 1 max, 2 min */
+int bsk_comm_allreduce_u64(bsk_comm* comm, void* d_buf, size_t count, int op, void* stream);
+/* one word of every rank -> out[world] on the host (record counts, shard and part sizes: Range / Head, bigseqkit/range.go:69-103;
+ * FaidxOffset, faidx.go:69-80; the offsets of FileStore's ordered single file, bigseqkit-lib/helper.go:399-429); synchronises */
+int bsk_comm_allgather_u64(bsk_comm* comm, uint64_t value, uint64_t* out, void* stream);
+/* GrepReduceCount (bigseqkit-lib/grep.go:598-611 through Reduce, bigseqkit/grep.go:175): *inout becomes the sum over ranks */
+int bsk_count_allreduce(bsk_comm* comm, uint64_t* inout, void* stream);
+/* StatsReduce (bigseqkit-lib/stats.go:128-137 through Reduce, bigseqkit/stats.go:91) + the driver's collect: ONE sum
+ * all-reduce of the stats vector (d_vec, or the context's own when NULL) and bsk_stats_collect; only when the reduced vector
+ * counts sequence lengths beyond the dense histogram do the ranks exchange their overflow lists and collect again.  Every
+ * rank receives the whole map. */
+int bsk_stats_collect_reduced(bsk_ctx* ctx, bsk_comm* comm, void* d_vec, void* stream, int64_t* keys, int64_t* vals, size_t cap,
+                              size_t* n_out);
+/* RmDup over the shards of all ranks in ONE call (GroupByKey, bigseqkit/rmdup.go:97): the four phases above with their
+ * collectives in between -- all-gather of the record counts, tuples to their owners by grouped ncclSend / ncclRecv (in
+ * rounds of at most 512 MiB per message), one keep byte per tuple back the same way.  `out`: the survivors of THIS rank's
+ * shard in file order; the concatenation over the ranks equals the single-GPU output. */
+int bsk_rmdup_dist_run(bsk_ctx* ctx, bsk_comm* comm, const void* d_shard, size_t n, int format, void* stream, bsk_out* out);
 
 /* host-side self-test of the position-reporting regular-expression matcher (custom --id-regexp, locate -r):
  * leftmost-first match at or after `from`; caps4 = {match start, match end, group-1 start, group-1 end} (0xFFFFFFFF:
