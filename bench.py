@@ -150,26 +150,40 @@ class _Helpers:
         return hit_mask
 
 
-def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, seconds=None):
+def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, seconds=None, min_bytes=0):
     """The oracle (oracle/: C++ restatement of the reference's operator, `port`) on a bounded prefix of the SAME input, 1 thread
     and -- where the records are independent -- all host cores (one record-aligned slice per thread; ctypes releases the
-    GIL).  A reported baseline, not a target; returns the `cpu_baseline` object of an `ops` entry."""
+    GIL).  A reported baseline, not a target; returns the `cpu_baseline` object of an `ops` entry.
+    Round 5: through oracle.run_ptr -- the slice is read in place and the output goes into an uninitialised buffer sized
+    for the operator.  Round 4 went through the test entries, which copy the input, zero-fill 4 x its size and copy the
+    result: with 256 threads the page faults of those buffers were what got timed (`seq -n` 1.30 M records/s on one thread,
+    1.69 on 256)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     if seconds is None:
         seconds = max(0.3, H.args.cpu_seconds / 6.0)   # (five operators x two legs beside the stats baseline: ~30 s in all)
-    fn = getattr(oracle, fn_name)
     oj = json.dumps(opts)
+    out_factor = {"seq": 1.0 / 16 if opts.get("Name") else 1.05, "grep": 1.0 / 8, "subseq": 0.5, "translate": 2.2, "rmdup": 1.01}[fn_name]
     nrec_all = tensor.numel() // rec_bytes
+    nthr = max(1, min(os.cpu_count() or 1, 256)) if all_cores else 1
     pilot_rec = max(1, min(nrec_all, (4 << 20) // rec_bytes))
-    pilot = bytes(tensor[:pilot_rec * rec_bytes].cpu().numpy().tobytes())
+    host = tensor[:min(nrec_all, max(pilot_rec, (1 << 30) // rec_bytes)) * rec_bytes].cpu().numpy()   # (<= 1 GB; grown below if the legs want more)
+    base = host.ctypes.data
+
+    def call(first_rec, nrec):
+        nb = nrec * rec_bytes
+        return oracle.run_ptr(fn_name, base + first_rec * rec_bytes, nb, fastq, oj, int(nb * out_factor) + 4096)
     t0 = time.perf_counter()
-    fn(pilot, fastq, oj)
+    call(0, pilot_rec)
     rate = pilot_rec / max(1e-6, time.perf_counter() - t0)           # records / s, one thread
-    srec = int(max(pilot_rec, min(nrec_all, rate * seconds, (512 << 20) // rec_bytes)))
-    sample = bytes(tensor[:srec * rec_bytes].cpu().numpy().tobytes())
+    srec = int(max(pilot_rec, min(nrec_all, max(rate * seconds, min_bytes // rec_bytes), (512 << 20) // rec_bytes)))
+    per = max(1, int(min(nrec_all // nthr, rate * seconds, (64 << 20) // rec_bytes))) if all_cores else 0
+    need = max(srec, per * nthr)
+    if need * rec_bytes > host.nbytes:
+        host = tensor[:need * rec_bytes].cpu().numpy()
+        base = host.ctypes.data
     t0 = time.perf_counter()
-    fn(sample, fastq, oj)
+    call(0, srec)
     ct = time.perf_counter() - t0
     out = {"value": round(srec / ct / 1e6, 4), "unit": "M records/s", "gb_per_s": round(srec * rec_bytes / ct / 1e9, 4), "cores": 1,
            "kind": "port", "sample": "oracle.%s (C++ restatement of the reference operator, NOT IgnisHPC/Go) on the first %d records "
@@ -177,14 +191,10 @@ def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, 
     if all_cores:
         try:
             from concurrent.futures import ThreadPoolExecutor
-            nthr = max(1, min(os.cpu_count() or 1, 256))
-            per = max(1, int(min(nrec_all // nthr, rate * seconds, (64 << 20) // rec_bytes)))
-            big = bytes(tensor[:per * nthr * rec_bytes].cpu().numpy().tobytes())
-            parts = [big[k * per * rec_bytes:(k + 1) * per * rec_bytes] for k in range(nthr)]
             with ThreadPoolExecutor(nthr) as ex:
-                list(ex.map(lambda b: fn(b[:rec_bytes * 64], fastq, oj), parts))   # threads started
+                list(ex.map(lambda k: call(k * per, min(per, 64)), range(nthr)))   # threads started
                 t0 = time.perf_counter()
-                list(ex.map(lambda b: fn(b, fastq, oj), parts))
+                list(ex.map(lambda k: call(k * per, per), range(nthr)))
                 ct = time.perf_counter() - t0
             out["all_cores"] = {"value": round(per * nthr / ct / 1e6, 2), "unit": "M records/s", "gb_per_s": round(per * nthr * rec_bytes / ct / 1e9, 2),
                                 "cores": nthr, "kind": "port", "sample": "%d threads x %d records (%.2f GB), one pass, %.2f s" % (nthr, per, per * nthr * rec_bytes / 1e9, ct)}
@@ -485,7 +495,7 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         dict({"layout_path": "uniform: every record has the shape of the first (UniformLayout, verified in-kernel: stage "
                              "'k_translate_uniform'%s); the leg below is the same command on records that differ"
                              % ("" if "k_translate_uniform" in kern else " -- NOT taken"),},
-             **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "translate", {"Frame": ["6"]}, t, RB, False)})))
+             **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "translate", {"Frame": ["6"]}, t, RB, False, min_bytes=int(0.5e9 * min(1.0, args.ops_scale * 50)))})))
     del got, view
     op.close()
     # the same file as the input of `stats` (FASTA, 5 kb records): the default row, exact from the fixed layout
@@ -610,6 +620,26 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     return ops
 
 
+def cut_by_anchor(lib, flags, total_rec, k, world):
+    """Record number at which shard k of `world` begins: the first record start at or behind the NOMINAL BYTE offset
+    total_bytes * k / world, found by bsk_find_record_start (the ReadFixer rule every caller of the library cuts a file with)
+    in a window of the synthetic file produced on the host around that offset -- not by record arithmetic."""
+    if k <= 0:
+        return 0
+    if k >= world:
+        return total_rec
+    nominal = total_rec * REC * k // world
+    first = max(0, nominal // REC - 2)
+    nwin = min(total_rec - first, 4096) * REC
+    buf = C.create_string_buffer(nwin)
+    assert lib.bsk_synth_host(0, 42, flags, first, buf, nwin) == 0
+    out = C.c_size_t()
+    assert lib.bsk_find_record_start(C.cast(buf, C.c_void_p), nwin, nominal - first * REC, 1, C.byref(out)) == 0
+    pos = first * REC + out.value
+    assert pos % REC == 0 and nominal <= pos < nominal + REC, (pos, nominal)
+    return pos // REC
+
+
 def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, bdist, backend_name):
     """The two BASELINE configs that are DEFINED on several GPUs, at N > 1 (every rank calls this):
       grep -s -p ACGTTGCAAGCT @ C3 -- the 100 GB file (motif planted) in N record-aligned shards, bsk_grep_run per rank,
@@ -644,7 +674,7 @@ def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, b
 
     # ---- grep -s -p @ C3 over N GPUs -----------------------------------------------------------------------------------
     total = int(100e9 * args.ops_scale) // REC
-    lo, hi = total * rank // world, total * (rank + 1) // world
+    lo, hi = cut_by_anchor(lib, _lib.SYNTH_FLAG_MOTIF, total, rank, world), cut_by_anchor(lib, _lib.SYNTH_FLAG_MOTIF, total, rank + 1, world)
     t, nrec = H.synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_MOTIF, (hi - lo) * REC, lo)
     out = _lib.Out()
     op = bsk.Operator("Grep", json.dumps({"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}), local)
@@ -687,7 +717,8 @@ def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, b
 
     # ---- rmdup -s @ C5 over N GPUs: 25 GB per rank ----------------------------------------------------------------------
     per = int(25e9 * args.ops_scale) // REC
-    lo = rank * per
+    lo = cut_by_anchor(lib, _lib.SYNTH_FLAG_DUPS, per * world, rank, world)   # (== rank * per: the cut of a file of `world` such shards)
+    assert lo == rank * per
     t, nrec = H.synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_DUPS, per * REC, lo)
     be = bdist.HipRmDupBackend(json.dumps({"BySeq": True}), local)
     text, per_call, own = job_time(lambda: bdist.rmdup_distributed(t, bsk.FORMAT_FASTQ, be, to_host=False))
@@ -718,6 +749,10 @@ def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, b
         "phases_ms_per_rank": {k: [round(r[1 + i], 4) for r in rows] for i, k in enumerate(names)},
         "tuple_bytes_sent_per_rank": [int(r[7]) for r in rows], "tuple_bytes_sent_off_rank_per_rank": [int(r[8]) for r in rows],
         "survivors_resident": "HBM (DeviceText: the context's output buffer; no host copy)",
+        "rmdup_keys": "two-key: across ranks a record travels as (XXH64, second 64-bit key, global index) to owner = key % N, and "
+                      "equal (k1, k2) decide -- the owner does not hold the text; equal k1 with different k2 are kept apart through "
+                      "the overflow list (PARITY.md KEYS).  The single-GPU call compares the bytes of every duplicate (ops entry "
+                      "'rmdup -s @ C5 shard', N = 1 line)",
         "exact": bool(ok),
         "exact_how": "every rank: output == the records of its shard with GLOBAL index %% 5 != 4, byte for byte in file order; "
                      "survivors over all ranks == N - N // 5"}
@@ -835,7 +870,7 @@ def main():
     # ---- the synthetic file, cut into record-aligned shards --------------------------
     total_rec = int(args.gb * 1e9) // REC
     while True:
-        lo, hi = total_rec * rank // world, total_rec * (rank + 1) // world
+        lo, hi = cut_by_anchor(lib, 0, total_rec, rank, world), cut_by_anchor(lib, 0, total_rec, rank + 1, world)
         nrec = hi - lo
         # last whole record; the very last shard drops the final '\n' (a file need not end with one)
         nbytes = nrec * REC
@@ -858,11 +893,12 @@ def main():
 
     reduce_ev = [] if dist_on else None  # (start, stop) HIP events around the all-reduce of every timed step
 
-    def one_step(op, vec):
+    def one_step(op, vec, nb=None):
+        nb = nbytes if nb is None else nb
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         vec.zero_()
         check(lib.bsk_stats_reset(op.ctx, st), op.ctx)  # error flags + overflow list of the context (the vector is ours)
-        check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nbytes, 1, bsk.FORMAT_FASTQ, rank,
+        check(lib.bsk_stats_run(op.ctx, C.c_void_p(shard.data_ptr()), nb, 1, bsk.FORMAT_FASTQ, rank,
                                 C.c_void_p(vec.data_ptr()), st), op.ctx)
         if dist_on:
             # StatsReduce (bigseqkit/stats.go:91): ONE sum all-reduce of the dense map over RCCL -- the only collective --
@@ -886,9 +922,9 @@ def main():
         check(lib.bsk_stats_string(op.ctx, b"input0", b"N/A", C.byref(info), buf, len(buf)), op.ctx)
         return m, buf.value.decode()
 
-    def timed(op, vec, steps, warmup):
+    def timed(op, vec, steps, warmup, nb=None):
         for _ in range(warmup):
-            one_step(op, vec)
+            one_step(op, vec, nb)
         lib.bsk_profile_reset(op.ctx)
         lib.bsk_profile_enable(op.ctx, 1)
         if dist_on:
@@ -898,7 +934,7 @@ def main():
             del reduce_ev[:]
         t0 = time.perf_counter()
         for _ in range(steps):
-            m, text = one_step(op, vec)
+            m, text = one_step(op, vec, nb)
         torch.cuda.synchronize()
         t_own = time.perf_counter() - t0          # this rank's K steps (before it waits for the others)
         if dist_on:
@@ -947,6 +983,29 @@ def main():
         q20, q30 = bdist.all_reduce_count(q20, dev), bdist.all_reduce_count(q30, dev)
     verified_a = (ma.get(150) == total_rec and ma.get(-3) == 0 and ma.get(-1) == q20 and ma.get(-2) == q30
                   and sum(v for k, v in ma.items() if k >= 0) == total_rec)
+
+    # ---- what one GPU does with the shard of an N-GPU job (N = 1 line only): the same step on the first 1/2, 1/4, 1/8 of the
+    # file -- the term of the 1 / 2 / 4 / 8 curve that this box CAN measure.  An ESTIMATE of the curve, not the curve: the
+    # 512 KB all-reduce per step and the other GPUs are not in it.
+    scaling_model = None
+    if not dist_on:
+        op, vec = make_op(False)
+        rows = {}
+        for g in (1, 2, 4, 8):
+            nb_g = (nrec // g) * REC
+            if nb_g <= 0:
+                continue
+            dtg, mg, _, kg, pg, _, _ = timed(op, vec, max(5, args.steps // 2), 2, nb_g)
+            step = dtg / max(5, args.steps // 2) * 1e3
+            rows[str(g)] = {"shard_GB": round(nb_g / 1e9, 3), "ms_per_step": round(step, 4), "k_stats_ms": round(kg, 4), "k_prep_ms": round(pg, 4),
+                            "outside_k_stats_ms": round(step - kg, 4), "k_stats_frac": round(nb_g / (kg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kg > 0 else None,
+                            "exact": mg.get(150) == nrec // g}
+        op.close()
+        if "1" in rows:
+            scaling_model = {"what": "ESTIMATE: one GPU running the stats step on the shard an N-GPU job would give it (the first 1/N of the same "
+                                     "file); no collective, no second GPU -- not a measured scaling curve",
+                             "per_n_gpus": rows,
+                             "speedup_if_ranks_do_not_disturb_each_other": {g: round(rows["1"]["ms_per_step"] / r["ms_per_step"], 3) for g, r in rows.items()}}
 
     # ---- the BASELINE configs that are defined on several GPUs (C3, C5) -- every rank takes part
     ops_multi = None
@@ -1101,6 +1160,8 @@ def main():
                 out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         else:
             out["ops"] = {"skipped": "the 'ops' workloads are defined at the full BASELINE sizes (--gb 100) or with --ops-scale"}
+    if scaling_model is not None:
+        out["scaling_model"] = scaling_model
     if ops_multi is not None:
         out["ops"] = ops_multi
     print(json.dumps(out), flush=True)

@@ -131,6 +131,7 @@ SIGNATURES = {
     "bsk_range_needs_count": (_i, [_vp, _p(C.c_int)]),
     "bsk_range_set_count": (_i, [_vp, C.c_uint64]),
     "bsk_range_bounds": (_i, [_vp, _p(_i64), _p(_i64)]),
+    "bsk_device_select": (_i, [_i]),
     "bsk_device_alloc": (_vp, [_sz]),
     "bsk_device_free": (None, [_vp]),
     "bsk_device_copy": (_i, [_vp, _vp, _sz, _i]),
@@ -142,6 +143,18 @@ SIGNATURES = {
     "bsk_rmdup_dist_pack": (_i, [_vp, C.c_uint64, _i, _vp, _p(C.c_uint64), _vp]),
     "bsk_rmdup_dist_resolve": (_i, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "bsk_rmdup_dist_emit": (_i, [_vp, _vp, _vp, C.c_uint64, _vp, _p(Out)]),
+    "bsk_comm_unique_id": (_i, [_vp]),
+    "bsk_comm_init_rank": (_i, [_i, _i, _vp, _i, _p(_vp)]),
+    "bsk_comm_init_all": (_i, [_i, _p(_i), _p(_vp)]),
+    "bsk_comm_destroy": (_i, [_vp]),
+    "bsk_comm_info": (_i, [_vp, _p(_i), _p(_i), _p(_i), _p(_i)]),
+    "bsk_comm_error": (C.c_char_p, [_vp]),
+    "bsk_comm_barrier": (_i, [_vp, _vp]),
+    "bsk_comm_allreduce_u64": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "bsk_comm_allgather_u64": (_i, [_vp, _u64, _p(_u64), _vp]),
+    "bsk_count_allreduce": (_i, [_vp, _p(_u64), _vp]),
+    "bsk_stats_collect_reduced": (_i, [_vp, _vp, _vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
+    "bsk_rmdup_dist_run": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _p(Out)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_offset": (_u64, [_i, _u64]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),

@@ -228,6 +228,30 @@ def sub_location(length, start, end):
     return b.value, e.value
 
 
+def run_ptr(name, ptr, n, fastq, opts_json, out_cap):
+    """Timing entry of bench.py's cpu_baseline legs: operator `name` ("seq", "grep", "subseq", "translate", "rmdup") on the n
+    bytes at address `ptr` -- no copy of the input, the output written into an UNINITIALISED buffer of out_cap bytes (grown
+    once if the operator needs more) and discarded.  Returns (output bytes, output records).  The test entries above copy
+    the input, zero-fill four times its size for the output and copy the result: fine for parity tests, but with 256
+    callers at once the page faults of those buffers, not the restatement, were what got timed."""
+    import numpy as np
+    fn, mk = {"seq": (_lib.orc_seq, seq_opts), "grep": (_lib.orc_grep, grep_opts), "subseq": (_lib.orc_subseq, subseq_opts),
+              "translate": (_lib.orc_translate, translate_opts), "rmdup": (_lib.orc_rmdup, rmdup_opts)}[name]
+    o = mk(opts_json)
+    cap = int(out_cap)
+    while True:
+        out = np.empty(max(16, cap), dtype=np.uint8)
+        nout, nrec, err = C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
+        rc = fn(C.c_void_p(ptr), C.c_size_t(n), int(fastq), C.byref(o), 1, C.c_void_p(out.ctypes.data), C.c_size_t(out.size), C.byref(nout),
+                C.byref(nrec), err, _ERR)
+        if rc == 2:
+            cap = nout.value + 16
+            continue
+        if rc:
+            raise OracleError(err.value.decode())
+        return nout.value, nrec.value
+
+
 def _buf(data):
     return (C.c_char * len(data)).from_buffer_copy(data) if len(data) else (C.c_char * 1)()
 

@@ -120,16 +120,6 @@ def test_the_collectives_through_the_c_abi():
     import torch
     import bigseqkit_amd as bsk
     from bigseqkit_amd._lib import lib, check
-    lib.bsk_comm_unique_id.argtypes = [C.c_void_p]
-    lib.bsk_comm_init_rank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-    lib.bsk_comm_allreduce_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    lib.bsk_comm_allgather_u64.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
-    lib.bsk_count_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
-    lib.bsk_comm_destroy.argtypes = [C.c_void_p]
-    lib.bsk_comm_error.restype = C.c_char_p
-    lib.bsk_comm_error.argtypes = [C.c_void_p]
-    lib.bsk_stats_collect_reduced.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                              C.c_size_t, C.POINTER(C.c_size_t)]
     ident = C.create_string_buffer(128)
     assert lib.bsk_comm_unique_id(ident) == 0, lib.bsk_comm_error(None)
     comm = C.c_void_p()
