@@ -324,7 +324,7 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
     const bool all = c->opts.b("All");
     // FASTQ -a: the dense path (stats_a=dense); FASTA default row: the pass that publishes every newline (stats_fasta=events)
     // instead of the round-5 one that publishes the two kinds the sink acts on -- the older variants the tests compare with
-    const bool variant = fastq ? c->stats_a_dense : (!all && c->tune.is("stats_fasta", "events"));
+    const bool variant = fastq ? c->stats_a_dense : c->tune.is("stats_fasta", "events");
     const int per_cu = stats_max_blocks_per_cu(fastq, all, c->use_dpp, variant);
     const int blocks = std::max(1, c->num_cus * per_cu);
     const uint64_t waves = (uint64_t)blocks * 4;
@@ -367,7 +367,8 @@ static int stats_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int form
             if (uniq.find(ch) == std::string::npos) uniq.push_back(ch);
         gap_letters = uniq;
         if ((int)uniq.size() > MAX_GAP_LETTERS) uniq.clear();  // the streaming pass counts none of them: launch_gap_set_count below
-        for (char ch : uniq) D.pred.gap_rep[D.pred.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;
+        for (char ch : uniq)
+            if (ch != '\n') D.pred.gap_rep[D.pred.ngap++] = (uint32_t)(uint8_t)ch * 0x01010101u;  // (a line break is in no sequence: SeqParser joins the lines)
         uint32_t top = 0;
         for (char ch : uniq) top = std::max(top, (uint32_t)(uint8_t)ch);
         D.pred.kgap = top >= 127u ? 0xFFFFFFFFu : (0x80u - (top + 1u)) * 0x01010101u;

@@ -33,28 +33,40 @@ constexpr uint32_t F2_QUEUE = 128;   // flagged pieces that wait for a full roun
 constexpr uint32_t F2_EVENTS = 128;  // published events that wait for the sink (ring)
 constexpr uint32_t F2_CLOSING = 1u, F2_HDR_END = 2u;
 
-struct LdsF2 {
+// GAPS (`stats -a`): the events also carry their position -- the sink looks at the bytes of every header line
+template <bool GAPS>
+struct LdsF2T {
     __attribute__((aligned(16))) uint4 qdata[F2_QUEUE];
     int32_t qpos[F2_QUEUE];    // position of the piece's first byte relative to the range start (negative: the piece begins before it)
     uint16_t qnx[F2_QUEUE];    // 0x100 | the byte behind the piece, 0 = unknown (memory is asked)
     uint32_t ekey[F2_EVENTS];  // position - rank of a published newline = bytes of the range before it that are no newlines
+    uint32_t epos[GAPS ? F2_EVENTS : 1];  // its position
     uint8_t eflag[F2_EVENTS];  // F2_CLOSING | F2_HDR_END
 };
+using LdsF2 = LdsF2T<false>;
 
 // what a range leaves behind for the sink's end_range() / the stitch kernel
 struct F2Tail {
     uint32_t lines;      // newlines of the range (the virtual one of a file without a final newline included)
     uint32_t last_key;   // position - rank of the last newline
     bool last_closing;   // ... which closed a record (a '>' or the end of the shard follows it)
+    bool last_hdr;       // ... which ended a header line
 };
 
 #ifndef BSK_F2_NT
 #define BSK_F2_NT 1  // non-temporal tile loads: FASTA-5k 50 GB 9.72 -> 9.22 ms, FASTA-1k 20 GB 3.65 -> 3.63 (scripts/history/r05_d.sh)
 #endif
 
-template <bool DPP, class Sink>
-__device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* __restrict__ buf, uint64_t n, uint64_t rs, uint64_t re,
-                                                      bool is_last, Sink& sink, uint64_t skip_from = ~0ull) {
+// GAPS (`stats -a`): the gap letters of P among ALL bytes of the range are counted into sink.rgap (a uint32_t per lane; the
+// caller folds it after every range) -- pieces without a byte below 0x20 by the "all sixteen above the largest gap letter"
+// test of the FASTQ line-role path, queued pieces (and every piece of an edge tile) exactly, clipped to the range, in their
+// round.  The gap count of the SEQUENCES is that sum minus the gap letters of the header lines, which the sink counts at the
+// header-end events (their positions travel with the events).  The pieces in [skip_from, count_resume) -- the middle of a
+// line longer than a chunk, whose chunks' own ranges count them (k_stats, RF_MID) -- are left out, as on the dense path.
+template <bool DPP, bool GAPS = false, class Sink>
+__device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2T<GAPS>& L, const uint8_t* __restrict__ buf, uint64_t n, uint64_t rs, uint64_t re,
+                                                      bool is_last, Sink& sink, const PredConsts& PC, uint64_t skip_from = ~0ull,
+                                                      uint64_t count_resume = 0) {
     const uint32_t lane = threadIdx.x & 63u;
     const int32_t end_rel = (int32_t)(uint32_t)(re - rs);
     if (re - rs > 0x7FFFFFFFull) sink.err |= ERR_LINE_TOO_LONG;  // (positions are 32-bit and relative to the range)
@@ -63,6 +75,7 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
     uint32_t line_base = 0;                             // newlines seen so far (all of them, published or not)
     uint32_t carry_cl = buf[rs] == '>' ? 1u : 0u;       // "the newline before the next one closed a record": a range that begins with a header
     uint32_t last_pos = 0;                              // position of the last newline seen
+    uint32_t carry_hd = 0;                              // ... which ended a header line
 #if BSK_NL_SGPR
     uint32_t k_ctl;
     asm volatile("s_mov_b32 %0, 0x20202020" : "=s"(k_ctl));
@@ -93,6 +106,24 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
             lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
             hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
             nl &= hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+        }
+        if constexpr (GAPS) {
+            // the gap letters of the queued pieces, exactly (flags in the layout of pack_flags: 13 instructions per letter
+            // instead of 31 for a byte-order mask), clipped to the range on the rounds that hold a piece across its ends
+            uint32_t vp = have ? 0x0F0F0F0Fu : 0u;
+            if (__ballot(have && (prel < 0 || prel + 16 > end_rel)) != 0ull) {
+                int32_t lo = -prel, hi = end_rel - prel;
+                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                vp = have ? packed_from_mask16(hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u) : 0u;
+            }
+            const uint64_t I = rs + (uint64_t)(int64_t)prel;
+            if (I >= skip_from && I < count_resume) vp = 0u;
+#pragma nounroll
+            for (int k = 0; k < PC.ngap; ++k) {
+                const uint32_t rep = PC.gap_rep[k];
+                sink.rgap += (uint32_t)__popc(pack_flags(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep), zero_bytes(v.z ^ rep), zero_bytes(v.w ^ rep)) & vp);
+            }
         }
         const uint32_t cnt = (uint32_t)__popc(nl);
         const uint32_t incl = wave_incl_scan<DPP>(cnt);
@@ -131,6 +162,7 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
             const uint32_t pub = clmask | hdmask;
             const int top = 63 - __clzll((long long)bc);  // the lane of the last newline of this round
             carry_cl = (uint32_t)((bl >> top) & 1ull);
+            carry_hd = ((uint32_t)__builtin_amdgcn_readlane((int)(hdmask >> ((cnt - 1u) & 31u)), top)) & 1u;
             {
                 const uint32_t hb = 31u - (uint32_t)__clz((int)(nl | 1u));
                 last_pos = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)prel + hb), top);
@@ -152,6 +184,7 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
                             if (g >= done && g < done + take) {
                                 const uint32_t ei = (ehead + ecnt + (g - done)) & (F2_EVENTS - 1u);
                                 L.ekey[ei] = ((uint32_t)prel + b) - (rank0 + k);
+                                if constexpr (GAPS) L.epos[ei] = (uint32_t)prel + b;
                                 L.eflag[ei] = (uint8_t)((((clmask >> k) & 1u) ? F2_CLOSING : 0u) | (((hdmask >> k) & 1u) ? F2_HDR_END : 0u));
                             }
                             ++j;
@@ -184,7 +217,25 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
             const uint32_t h = (((v.x - k_ctl) & ~v.x) | ((v.y - k_ctl) & ~v.y) | ((v.z - k_ctl) & ~v.z) | ((v.w - k_ctl) & ~v.w)) & 0x80808080u;
             const int32_t prel = tile_rel + p * PIECE_BYTES + (int32_t)lane * 16;
             bool f = h != 0u;
-            if (edge) f = f && prel + 16 > 0 && prel < end_rel;
+            if (edge) f = (f || GAPS) && prel + 16 > 0 && prel < end_rel;  // (GAPS: every piece of an edge tile is counted in a round, clipped)
+            if constexpr (GAPS) {
+                // a piece without a newline (nothing below 0x20): sixteen bytes above the largest gap letter hold no gap
+                // letter -- sequence text, always; only a wave with a candidate looks at the letters
+                const uint32_t kg = PC.kgap;
+                const uint32_t ca = popc4((((v.x & 0x7F7F7F7Fu) + kg) | v.x) & 0x80808080u, (((v.y & 0x7F7F7F7Fu) + kg) | v.y) & 0x80808080u,
+                                          (((v.z & 0x7F7F7F7Fu) + kg) | v.z) & 0x80808080u, (((v.w & 0x7F7F7F7Fu) + kg) | v.w) & 0x80808080u);
+                const uint64_t I = tile_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16;
+                const bool mine = !f && !edge && !(I >= skip_from && I < count_resume);
+                if (__ballot(mine && (ca != 16u || kg == 0xFFFFFFFFu)) != 0ull) {
+                    uint32_t cg = 0;
+#pragma nounroll
+                    for (int k = 0; k < PC.ngap; ++k) {
+                        const uint32_t rep = PC.gap_rep[k];
+                        cg += popc4(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep), zero_bytes(v.z ^ rep), zero_bytes(v.w ^ rep));
+                    }
+                    sink.rgap += mine ? cg : 0u;
+                }
+            }
             // the byte behind the piece: the first byte of the next lane's piece, for lane 63 of the next piece's lane 0
             const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130, 0xf, 0xf, true) & 0xFFu;
             // (lane 63: lane 0 of the next piece -- a scalar read, outside any divergent branch; unknown behind the tile's last piece)
@@ -204,7 +255,10 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
         }
         if (t + 1 < ntiles) {
             // the newline-free stretch of a line that is longer than the range's nominal chunk: on to its last tile
-            const uint64_t tgt = ntiles - 1;
+            uint64_t tgt = ntiles - 1;
+            if constexpr (GAPS) {  // (the bytes from count_resume on are this range's to count: the tile that holds them is the target)
+                if (count_resume > idx0 && (count_resume - idx0) / TILE < tgt) tgt = (count_resume - idx0) / TILE;
+            }
             if (tile_idx + TILE >= skip_from && t + 1 < tgt) {
                 t = tgt - 1;
                 const uint64_t tgt_idx = idx0 + tgt * TILE;
@@ -223,11 +277,13 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
         if (lane == 0) {
             const uint32_t ei = (ehead + ecnt) & (F2_EVENTS - 1u);
             L.ekey[ei] = (uint32_t)end_rel - line_base;
+            if constexpr (GAPS) L.epos[ei] = (uint32_t)end_rel;
             L.eflag[ei] = (uint8_t)(F2_CLOSING | (carry_cl ? F2_HDR_END : 0u));
         }
         ecnt += 1;
         last_pos = (uint32_t)end_rel;
         line_base += 1;
+        carry_hd = carry_cl;
         carry_cl = 1u;
     }
     while (ecnt) run_sink(ecnt < 64u ? ecnt : 64u);
@@ -235,6 +291,7 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2& L, const uint8_t* _
     T.lines = line_base;
     T.last_key = last_pos - (line_base - 1u);
     T.last_closing = carry_cl != 0u;
+    T.last_hdr = carry_hd != 0u;
     return T;
 }
 

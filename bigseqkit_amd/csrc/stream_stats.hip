@@ -115,6 +115,7 @@ struct StatsSinkT {
         open_is_header = false;
         any_event = false; last_closing = true; last_line_hdr = false;
         last_key = 0; last_a = 0;
+        last_pub_pos = 0xFFFFFFFFu;
     }
 
     // FASTA: what this range leaves open (lane 0 records it for k_stats_stitch)
@@ -126,7 +127,7 @@ struct StatsSinkT {
             const uint64_t bases = (uint64_t)(uint32_t)(last_key - (open_is_header ? open_key : 0u));
             if (open_is_header) { D.r_tail[range_id] = bases; f |= RF_TAIL_OPEN; }
             else D.r_head[range_id] = bases;  // no header and no closing line: the whole range is inside one record
-            if constexpr (ALL) gap += (uint32_t)(last_a - (open_is_header ? open_sg : 0u));
+            if constexpr (ALL) { if (!f2) gap += (uint32_t)(last_a - (open_is_header ? open_sg : 0u)); }  // (f2: the gap count is a sum over bytes, not over records)
         }
         if constexpr (ALL) {
             if (any_event && !last_line_hdr) f |= RF_SKIP_SEQ;  // (the RF_MID ranges that follow, if any, are sequence bytes)
@@ -173,14 +174,42 @@ struct StatsSinkT {
     }
 
     // FASTA, round 5 (stream_fasta2_dev.hpp): E <= 64 PUBLISHED newlines -- the ones in front of a '>' (closing) and the ones
-    // that end a header line -- with key = position - newline index; the rules of batch()'s FASTA branch on them
-    __device__ __forceinline__ void events2(LdsF2& L, uint32_t first, uint32_t E) {
+    // that end a header line -- with key = position - newline index; the rules of batch()'s FASTA branch on them.
+    // GAPS (`stats -a`): the skeleton counts the gap letters among ALL bytes of the range (rgap); the letters of the HEADER
+    // lines are no sequence bytes -- every header-end event counts those of its line (from the newline before it, which
+    // closed a record and is therefore the event before this one, to its own) into rsub.  Headers are a few bytes per
+    // record: one lane each, byte loads.
+    bool f2 = false;                 // this range ran on the pass of stream_fasta2_dev.hpp (end_range: no per-record gap sums)
+    uint32_t rsub = 0;               // GAPS: gap letters inside header lines (per lane and range)
+    uint32_t last_pub_pos = 0xFFFFFFFFu;  // position of the last published newline of the range (~0: none, the range start is a line start)
+    const uint8_t* f2_buf = nullptr;
+    uint64_t f2_rs = 0, f2_skip_lo = ~0ull, f2_skip_hi = 0;   // bytes at [skip_lo, skip_hi) are counted by other ranges (RF_MID)
+    template <bool GAPS>
+    __device__ __forceinline__ void events2(LdsF2T<GAPS>& L, uint32_t first, uint32_t E) {
         const uint32_t lane = threadIdx.x & 63;
         const bool on = lane < E;
         const uint32_t ei = (first + lane) & (F2_EVENTS - 1u);
         uint32_t key = 0, fl = 0;
         if (on) { key = L.ekey[ei]; fl = L.eflag[ei]; }
         const bool closing = (fl & F2_CLOSING) != 0u, hdr_end = (fl & F2_HDR_END) != 0u;
+        if constexpr (GAPS) {
+            uint32_t pos = 0;
+            if (on) pos = L.epos[ei];
+            uint32_t prev = (uint32_t)__shfl_up((int)pos, 1, 64);
+            if (lane == 0) prev = last_pub_pos;
+            if (hdr_end) {
+                const PredConsts& P = D.pred;
+                for (uint32_t x = prev + 1u; x < pos; ++x) {   // (prev + 1 wraps to 0 at the range start)
+                    const uint64_t a = f2_rs + x;
+                    if (a >= f2_skip_lo && a < f2_skip_hi) continue;
+                    const uint32_t c = f2_buf[a];
+                    // (static indices: a run-time index into the sink's copy of the constants would put the whole sink into scratch memory)
+#pragma unroll
+                    for (int k = 0; k < MAX_GAP_LETTERS; ++k) rsub += (k < P.ngap && (P.gap_rep[k] & 0xFFu) == c) ? 1u : 0u;
+                }
+            }
+            if (E) last_pub_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(E - 1u));
+        }
         const uint64_t hb = __ballot(hdr_end);
         const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
         const uint64_t hh = hb & upto;
@@ -317,7 +346,10 @@ struct StatsSinkT {
 #define BSK_STATS_WAVES_FQ 6
 #endif
 #if BSK_STATS_WAVES
-#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu((ALL && FASTQ) ? BSK_STATS_WAVES_ALL : (FASTQ ? BSK_STATS_WAVES_FQ : BSK_STATS_WAVES), 8)))
+#ifndef BSK_STATS_WAVES_FA_ALL
+#define BSK_STATS_WAVES_FA_ALL 5   // FASTA -a on the pass of stream_fasta2_dev.hpp (ROLES_T): ~100 VGPRs wanted
+#endif
+#define BSK_STATS_ATTR __attribute__((amdgpu_waves_per_eu((ALL && FASTQ) ? BSK_STATS_WAVES_ALL : (FASTQ ? BSK_STATS_WAVES_FQ : ((ALL && ROLES_T) ? BSK_STATS_WAVES_FA_ALL : BSK_STATS_WAVES)), 8)))
 #else
 #define BSK_STATS_ATTR
 #endif
@@ -336,9 +368,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
     constexpr int WINDOW = (FASTQ && !SALL) ? 256 : CAP;
     // FASTA default row, round 5: only the newlines the sink acts on become events (stream_fasta2_dev.hpp); ROLES_T = false keeps
     // the pass that publishes every newline (stats_fasta=events: the tests hold the two against each other)
-    constexpr bool F2 = !FASTQ && !ALL && ROLES_T;
+    constexpr bool F2 = !FASTQ && ROLES_T;   // (`-a` too: the gap letters are counted over all bytes, the header lines taken off)
     __shared__ Lds<FASTQ, SALL, F2 ? 4 : WINDOW> s_l[F2 ? 1 : WAVES_PER_BLOCK];
-    __shared__ LdsF2 s_f2[F2 ? WAVES_PER_BLOCK : 1];
+    __shared__ LdsF2T<F2 && ALL> s_f2[F2 ? WAVES_PER_BLOCK : 1];
     for (int i = threadIdx.x; i < LDS_HIST + 2 * BIG_SLOTS; i += blockDim.x)
         s_hist[i] = (i >= LDS_HIST && i < LDS_HIST + BIG_SLOTS) ? BIG_EMPTY : 0u;
     __syncthreads();
@@ -389,11 +421,19 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         const uint64_t skip_from = (!FASTQ && chunk) ? (uint64_t)(r + 1u) * chunk : ~0ull;
         const uint64_t count_resume = (!FASTQ && chunk) ? (re == n_eff ? re : (re / chunk) * chunk) : 0ull;
         if constexpr (F2) {
-            const F2Tail T = stream_range_fasta2<DPP>(s_f2[wave], buf, n, rs, re, re == n_eff, sink, skip_from);
+            sink.f2 = true;
+            if constexpr (ALL) { sink.f2_buf = buf; sink.f2_rs = rs; sink.f2_skip_lo = skip_from; sink.f2_skip_hi = count_resume; }
+            const F2Tail T = stream_range_fasta2<DPP, ALL>(s_f2[wave], buf, n, rs, re, re == n_eff, sink, D.pred, skip_from, count_resume);
             sink.any_event = T.lines != 0u;
             sink.last_closing = T.last_closing;
             sink.last_key = T.last_key;
-            (void)count_resume; (void)L;
+            sink.last_line_hdr = T.last_hdr;
+            if constexpr (ALL) {
+                // (per-lane differences may be negative: the sum over the wave, modulo 2^64, is what counts)
+                sink.gap += (uint64_t)sink.rgap - (uint64_t)sink.rsub;
+                sink.rgap = 0; sink.rsub = 0;
+            }
+            (void)L;
         } else {
             stream_range<FASTQ, SALL, DPP>(L, buf, n, rs, re, re == n_eff, D.pred, sink, skip_from, count_resume);
         }
@@ -650,8 +690,9 @@ hipError_t launch_stats(bool fastq, bool all, bool dpp, int blocks, const uint8_
     if (fastq && all && a_dense) return launch_stats_t<true, true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0);
     if (fastq) return all ? launch_stats_t<true, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0)
                           : launch_stats_t<true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, 0);
-    if (all) return launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
-    // (FASTA default row: a_dense = the pass that publishes every newline, stats_fasta=events)
+    // (FASTA: a_dense = the pass that publishes every newline -- with `-a` the dense path with running counters --, stats_fasta=events)
+    if (all) return a_dense ? launch_stats_t<false, true, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk)
+                            : launch_stats_t<false, true>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
     return a_dense ? launch_stats_t<false, false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk)
                    : launch_stats_t<false, false>(dpp, blocks, buf, n, anchors, nranges, queue, D, st, skip_chunk);
 }
@@ -664,6 +705,7 @@ int stats_max_blocks_per_cu(bool fastq, bool all, bool dpp, bool a_dense) {
     if (fastq && all && a_dense) { BSK_PICK(true, true, false) }
     else if (fastq && all) { BSK_PICK(true, true, true) }
     else if (fastq) { BSK_PICK(true, false, true) }
+    else if (all && a_dense) { BSK_PICK(false, true, false) }
     else if (all) { BSK_PICK(false, true, true) }
     else if (a_dense) { BSK_PICK(false, false, false) }
     else { BSK_PICK(false, false, true) }

@@ -25,20 +25,27 @@ class _Opts:
         return json.dumps(self.d)
 
 
-def gpu_map(data):
+def gpu_map(data, opts):
     import torch
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
-    m, op = bsk.stats_map(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts({}))
+    m, op = bsk.stats_map(bsk.SeqFrame(bsk.FORMAT_FASTA, [t]), _Opts(opts))
     op.close()
     return m
 
 
-def both(data, monkeypatch):
-    want = oracle.stats_map(data, False, "{}")
-    assert gpu_map(data) == want
-    monkeypatch.setenv("BSK_STATS_FASTA", "events")
-    assert gpu_map(data) == want
-    monkeypatch.delenv("BSK_STATS_FASTA")
+# the default row, and `-a`: the gap letters counted over ALL bytes with the header lines taken off -- with the default
+# letters (a blank: in every header of the generators below), with bases, '>' and a tab as gap letters (letters that fill
+# sequences, begin headers, sit below 0x20), and with a letter above 126 (no "all sixteen above" shortcut)
+OPTS = [{}, {"All": True}, {"All": True, "GapLetters": "ACg \t>"}, {"All": True, "GapLetters": "-\x7f"}]
+
+
+def both(data, monkeypatch, opts_list=OPTS):
+    for opts in opts_list:
+        want = oracle.stats_map(data, False, json.dumps(opts))
+        assert gpu_map(data, opts) == want, opts
+        monkeypatch.setenv("BSK_STATS_FASTA", "events")
+        assert gpu_map(data, opts) == want, opts
+        monkeypatch.delenv("BSK_STATS_FASTA")
 
 
 def fasta(rng, nrec, lens, width, head=lambda i, rng: b"r%d some text" % i, final_newline=True):
@@ -100,6 +107,10 @@ def test_lines_longer_than_a_range(monkeypatch):
         parts.append(b">chr%d\n" % i + bytes(rng.choice(b"ACGT") for _ in range(L)) + b"\n")
     both(b"".join(parts), monkeypatch)
     both(b"".join(parts)[:-1], monkeypatch)
+    # ... and a HEADER line longer than a range (its middle is counted by no one: the chunks' own ranges count it, the stitch
+    # kernel adds those counts for sequence lines only, and the header-end event leaves the same bytes out)
+    long_head = b">h " + bytes(rng.choice(b"ab -.c") for _ in range(50000)) + b"\nAC-GT\n>next one\nA.C\n"
+    both(b"".join(parts[:2]) + long_head + parts[3], monkeypatch)
 
 
 def test_synthetic_layouts_of_the_bench(monkeypatch):
@@ -113,4 +124,4 @@ def test_synthetic_layouts_of_the_bench(monkeypatch):
         t = torch.empty(n, dtype=torch.uint8, device="cuda")
         assert lib.bsk_synth_device(kind, 42, 0, 0, C.c_void_p(t.data_ptr()), n, 0, None) == 0
         torch.cuda.synchronize()
-        both(bytes(t.cpu().numpy().tobytes()), monkeypatch)
+        both(bytes(t.cpu().numpy().tobytes()), monkeypatch, OPTS[:2])
