@@ -617,6 +617,7 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     del got, view, t
     op.close()
     torch.cuda.empty_cache()
+    attach_traffic(ops)
     return ops
 
 
@@ -638,6 +639,45 @@ def cut_by_anchor(lib, flags, total_rec, k, world):
     pos = first * REC + out.value
     assert pos % REC == 0 and nominal <= pos < nominal + REC, (pos, nominal)
     return pos // REC
+
+
+def attach_traffic(ops):
+    """`traffic` (HBM bytes per call from the PMC passes, a FETCH_SIZE factor per access shape) and `traffic_over_algorithmic`
+    for the ops entries, from the committed evidence of the same commands at the same sizes (scripts/r05_evidence.sh ->
+    profiles/*_ops_traffic.json; rocprofv3 cannot wrap the process that is being timed).  The counters belong to the kernel
+    sources they were collected on: a changed source marks the figure STALE instead of passing it on silently."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_ops_traffic.json")))
+    if not files:
+        return
+    try:
+        tj = json.load(open(files[-1]))
+    except ValueError:
+        return
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "bigseqkit_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    src = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/bench_ops.py; " \
+          "FETCH_SIZE x 2 for coalesced streams, x 1.1 - 1.8 for the gather shapes: profiles/r05_fetch_calibration.json)"
+    if tj.get("kernel_sources_sha256") != h.hexdigest():
+        src += " -- STALE: the kernel sources have changed since that pass"
+    prefix = {"seq -n @ C2": "seq -n", "subseq -r 1:50 (25 GB)": "subseq", "grep -s -p @ C3 shard": "grep -s",
+              "translate -f 6 @ C4": "translate", "rmdup -s @ C5 shard": "rmdup"}
+    for name, pre in prefix.items():
+        e = ops.get(name)
+        t = next((v for k, v in tj.get("ops", {}).items() if k.startswith(pre)), None)
+        if not isinstance(e, dict) or t is None:
+            continue
+        # (only at the sizes the counters were collected on)
+        if abs(e["algorithmic_bytes"] / 1e9 - t["algorithmic_GB"]) > 0.02 * t["algorithmic_GB"]:
+            continue
+        e["traffic"] = int(t["traffic_GB"] * 1e9)
+        e["traffic_over_algorithmic"] = t["traffic_over_algorithmic"]
+        e["traffic_upper_bound_over_algorithmic"] = t["upper_bound_over_algorithmic"]
+        e["traffic_source"] = src
 
 
 def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, bdist, backend_name):
