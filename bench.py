@@ -672,7 +672,7 @@ def attach_traffic(ops):
         if not isinstance(e, dict) or t is None:
             continue
         # (only at the sizes the counters were collected on)
-        if abs(e["algorithmic_bytes"] / 1e9 - t["algorithmic_GB"]) > 0.02 * t["algorithmic_GB"]:
+        if abs(e["algorithmic_bytes"] / 1e9 - t["algorithmic_GB"]) > 0.05 * t["algorithmic_GB"]:   # (rmdup: bench.py adds the 16 B/record key exchange of SURVEY 8d to the algorithmic bytes)
             continue
         e["traffic"] = int(t["traffic_GB"] * 1e9)
         e["traffic_over_algorithmic"] = t["traffic_over_algorithmic"]
