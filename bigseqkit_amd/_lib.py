@@ -193,5 +193,8 @@ class BskError(RuntimeError):
 
 def check(rc, ctx=None):
     if rc != BSK_OK:
-        msg = lib.bsk_last_error(ctx) if ctx else lib.bsk_global_error()
+        # (every failure also leaves its text in the calling thread's bsk_global_error(); a call refused as "context busy"
+        # leaves it ONLY there -- the context's text belongs to the call that is running)
+        g = lib.bsk_global_error() or b""
+        msg = g if (not ctx or b"context busy" in g) else (lib.bsk_last_error(ctx) or g)
         raise BskError(rc, (msg or b"").decode("utf-8", "replace"))

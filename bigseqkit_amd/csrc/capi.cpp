@@ -37,6 +37,12 @@ int fail(const bsk_ctx* c, int code, const std::string& m) {
     g_error = m;
     return code;
 }
+// a call refused because another one is running on the context: the message goes to the CALLER's thread-local error only --
+// writing it into the context would race with the running call, which reads and writes ctx->last_error
+static int fail_busy() {
+    g_error = BSK_BUSY_TEXT;
+    return BSK_ERR_INVALID_ARG;
+}
 #define HIP_TRY(ctx, expr)                                                                       \
     do {                                                                                         \
         hipError_t e__ = (expr);                                                                 \
@@ -47,7 +53,7 @@ int fail(const bsk_ctx* c, int code, const std::string& m) {
 // entry of a call that uses the context's device state: refuses a second concurrent caller, selects the device
 #define BSK_ENTER(ctx)                                                            \
     bsk_call_scope scope__(ctx);                                                  \
-    if (!scope__.owns) return fail(ctx, BSK_ERR_INVALID_ARG, BSK_BUSY_TEXT);      \
+    if (!scope__.owns) return fail_busy();                                        \
     HIP_TRY(ctx, hipSetDevice((ctx)->device))
 
 
@@ -937,12 +943,22 @@ int bsk_seq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int form
     return run_maybe_multiline(c, seq_run_device, d, n, format, st, out);
 }
 
+// per-call values of the context (partition id, index of the first record, file offset of the shard): written AFTER the
+// call owns the context -- a call that is refused as busy must not change the state of the one that is running
+struct CallValues {
+    const int64_t* pid = nullptr;
+    const int64_t* first_record = nullptr;
+    const uint64_t* base_offset = nullptr;
+};
 static int run_record_op(bsk_ctx* c, Op want, const char* what, run_fn fn, const void* shard, size_t n, int on_device,
-                         int format, void* stream, bsk_out* out) {
+                         int format, void* stream, bsk_out* out, const CallValues& cv = CallValues()) {
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != want || !out) return fail(c, BSK_ERR_INVALID_ARG, std::string("libbsk: not a ") + what + " context");
     BSK_ENTER(c);
+    if (cv.pid) c->cur_pid = *cv.pid;
+    if (cv.first_record) c->cur_first_record = *cv.first_record;
+    if (cv.base_offset) c->cur_base_offset = *cv.base_offset;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
     const uint8_t* d = nullptr;
@@ -973,8 +989,9 @@ int bsk_faidx_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
                   void* stream, bsk_out* out) {
     (void)pid;
     if (!c) return BSK_ERR_INVALID_ARG;
-    c->cur_base_offset = base_offset;
-    return run_record_op(c, Op::Faidx, "Faidx", faidx_run_device, shard, n, on_device, format, stream, out);
+    CallValues cv;
+    cv.base_offset = &base_offset;
+    return run_record_op(c, Op::Faidx, "Faidx", faidx_run_device, shard, n, on_device, format, stream, out, cv);
 }
 
 int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
@@ -1099,9 +1116,11 @@ int bsk_range_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
                   void* stream, bsk_out* out) {
     (void)pid;
     if (!c) return BSK_ERR_INVALID_ARG;
-    c->cur_first_record = (int64_t)first_record;
+    const int64_t fr = (int64_t)first_record;
+    CallValues cv;
+    cv.first_record = &fr;
     return run_record_op(c, c->op == Op::Head ? Op::Head : Op::Range, "Range", records_run_device, shard, n, on_device,
-                         format, stream, out);
+                         format, stream, out, cv);
 }
 
 int bsk_duplicate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
@@ -1112,8 +1131,9 @@ int bsk_duplicate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, in
 
 int bsk_locate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                    bsk_out* out) {
-    if (c) c->cur_pid = pid;
-    return run_record_op(c, Op::Locate, "Locate", locate_run_device, shard, n, on_device, format, stream, out);
+    CallValues cv;
+    cv.pid = &pid;
+    return run_record_op(c, Op::Locate, "Locate", locate_run_device, shard, n, on_device, format, stream, out, cv);
 }
 
 int bsk_translate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,

@@ -257,7 +257,17 @@ def _records(use, op_name, h, n, fmt, ojs, out_file, merge, rank, world, device,
     """the record commands: every worker's output is part `rank`; --merge: one file, the parts at the offsets of a scan"""
     to_stdout = out_file == "-"
     if to_stdout or merge:
-        target = "%s.bsk-part%05d.tmp" % (out_file if not to_stdout else "/tmp/bsk-stdout-%d" % os.getppid(), rank)
+        # this worker's part goes to a spool file of its own first.  Its name holds a token that only this JOB knows (the
+        # rendezvous port) and it is created with O_EXCL: two jobs started from one shell no longer share a spool, and a
+        # planted link is not followed (ADVICE r04: the name used to be /tmp/bsk-stdout-<ppid>...)
+        import tempfile
+        token = "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        base = os.path.join(tempfile.gettempdir(), "bsk-stdout") if to_stdout else out_file
+        target = "%s.bsk-%s-part%05d.tmp" % (base, token, rank)
+        try:
+            os.close(os.open(target, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600))
+        except OSError:
+            raise SystemExit("bigseqkit_amd.run: cannot create " + target)
         st = C.c_void_p()
         if lib.bsk_store_open(target.encode(), 1, C.byref(st)) != 0:
             raise SystemExit("bigseqkit_amd.run: cannot create " + target)
@@ -265,6 +275,11 @@ def _records(use, op_name, h, n, fmt, ojs, out_file, merge, rank, world, device,
     else:
         if rank == 0:
             os.makedirs(out_file, exist_ok=True)
+            # (part files of an earlier run with MORE workers would be read as part of this result)
+            k = world
+            while os.path.exists(os.path.join(out_file, "part%05d" % k)):
+                os.unlink(os.path.join(out_file, "part%05d" % k))
+                k += 1
         bdist.barrier()
         st = C.c_void_p()
         if lib.bsk_store_open(out_file.encode(), 0, C.byref(st)) != 0:

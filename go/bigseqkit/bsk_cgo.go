@@ -89,6 +89,8 @@ func readFASTX(data []byte, format, minPartitions, device int) (*SeqFrame, error
 		}
 	}
 	cuts = append(cuts, n)
+	// (a cut that finds no record start behind it collapses onto the one before: the frame then has FEWER shards than
+	// minPartitions, numbered 0, 1, ... without gaps -- the partition ids the operators see are the indices of this slice)
 	f := &SeqFrame{Format: format, Device: device}
 	for k := 0; k+1 < len(cuts); k++ {
 		if cuts[k+1] > cuts[k] {
@@ -402,7 +404,9 @@ func StoreFASTX(r *Result, path string) error {
 			ptr = unsafe.Pointer(&p[0])
 		}
 		if rc := C.bsk_store_put_host(st.s, C.uint64_t(pid), ptr, C.size_t(len(p))); rc != C.BSK_OK {
-			return errors.New(C.GoString(C.bsk_store_error(st.s)))
+			msg := C.GoString(C.bsk_store_error(st.s))
+			st.Close() // (also frees the store: an error path must not leak it)
+			return errors.New(msg)
 		}
 	}
 	_, err = st.Close()
@@ -422,9 +426,192 @@ func StoreFASTXN(r *Result, path string) error {
 			ptr = unsafe.Pointer(&p[0])
 		}
 		if rc := C.bsk_store_put_host(st.s, C.uint64_t(pid), ptr, C.size_t(len(p))); rc != C.BSK_OK {
-			return errors.New(C.GoString(C.bsk_store_error(st.s)))
+			msg := C.GoString(C.bsk_store_error(st.s))
+			st.Close() // (also frees the store: an error path must not leak it)
+			return errors.New(msg)
 		}
 	}
 	_, err = st.Close()
 	return err
+}
+
+// ---- several GPUs from Go: the collectives behind the C ABI (include/bsk.h "collectives", csrc/comm.cpp) ----------------
+// In the reference Reduce and GroupByKey come from IgnisHPC in the same binary (bigseqkit/stats.go:91, grep.go:175,
+// rmdup.go:97).  Here one goroutine per GPU (locked to its OS thread: the HIP device is per thread) owns a context and a
+// communicator of one group made by bsk_comm_init_all -- librccl over xGMI when every rank has a GPU of its own.  No
+// Python, no torch.  (UNVERIFIED like the rest of this file: no Go toolchain here; the same call sequence is what
+// `bigseqkit <cmd> ... --devices` runs in C++ and tests/test_devices_native_gpu.py exercises.)
+
+// Comms is a group of communicators, one per device of the list.
+type Comms struct{ c []*C.bsk_comm }
+
+func NewComms(devices []int) (*Comms, error) {
+	devs := make([]C.int, len(devices))
+	for i, d := range devices {
+		devs[i] = C.int(d)
+	}
+	out := make([]*C.bsk_comm, len(devices))
+	if rc := C.bsk_comm_init_all(C.int(len(devices)), &devs[0], &out[0]); rc != C.BSK_OK {
+		return nil, errors.New(C.GoString(C.bsk_comm_error(nil)))
+	}
+	return &Comms{out}, nil
+}
+
+func (g *Comms) Close() {
+	for _, c := range g.c {
+		C.bsk_comm_destroy(c)
+	}
+}
+
+// onEveryDevice runs f(rank) on one locked goroutine per device and returns the first error.  EVERY rank must enter every
+// collective f reaches, also after a failure of its own (the C entry points are written that way).
+func onEveryDevice(n int, f func(rank int) error) error {
+	errs := make([]error, n)
+	var wg sync.WaitGroup
+	for r := 0; r < n; r++ {
+		wg.Add(1)
+		go func(r int) {
+			defer wg.Done()
+			runtime.LockOSThread()
+			defer runtime.UnlockOSThread()
+			errs[r] = f(r)
+		}(r)
+	}
+	wg.Wait()
+	for _, e := range errs {
+		if e != nil {
+			return e
+		}
+	}
+	return nil
+}
+
+// StatsN: Stats over the shards of `input` on the devices of `g`, shard k on device k (len(input.Shards) == len(devices)):
+// bsk_stats_run per rank, then StatsReduce + collect in ONE call (bsk_stats_collect_reduced: a single ncclAllReduce of the
+// dense vector; the overflow lists of chromosome-sized records are exchanged only when the reduced vector counts any).
+func StatsN(name, format string, input *SeqFrame, o *SeqKitStatsOptions, g *Comms, devices []int) (*StatInfo, error) {
+	o.setDefaults()
+	js := OptionsToString(o)
+	var result *StatInfo
+	err := onEveryDevice(len(devices), func(rank int) error {
+		op, err := newBskOp("Stats", js, devices[rank])
+		if err != nil {
+			return err
+		}
+		defer op.Close()
+		d := input.Shards[rank].Data
+		if len(d) > 0 {
+			if rc := C.bsk_stats_run(op.ctx, unsafe.Pointer(&d[0]), C.size_t(len(d)), 0, C.int(input.Format), C.int64_t(rank), nil, nil); rc != C.BSK_OK {
+				return op.err()
+			}
+		}
+		capN := 1 << 20
+		keys := make([]C.int64_t, capN)
+		vals := make([]C.int64_t, capN)
+		var n C.size_t
+		if rc := C.bsk_stats_collect_reduced(op.ctx, g.c[rank], nil, nil, &keys[0], &vals[0], C.size_t(capN), &n); rc != C.BSK_OK {
+			return op.err()
+		}
+		if rank != 0 {
+			return nil
+		}
+		var info C.bsk_statinfo
+		if rc := C.bsk_stats_finalize(op.ctx, &keys[0], &vals[0], n, &info); rc != C.BSK_OK {
+			return op.err()
+		}
+		result = &StatInfo{name, format, C.GoString(&info._type[0]),
+			uint64(info.num), uint64(info.len_sum), uint64(info.gap_sum), uint64(info.len_min),
+			float64(info.len_avg), uint64(info.len_max), uint64(info.n50), int(info.l50),
+			float64(info.q1), float64(info.q2), float64(info.q3), float64(info.q20), float64(info.q30)}
+		return nil
+	})
+	return result, err
+}
+
+// GrepCountN: per-rank counts summed by bsk_count_allreduce (GrepReduceCount, bigseqkit/grep.go:161-180).
+func GrepCountN(input *SeqFrame, o *SeqKitGrepOptions, g *Comms, devices []int) (uint64, error) {
+	o.setDefaults()
+	o.Count = true
+	js := OptionsToString(o)
+	var total uint64
+	err := onEveryDevice(len(devices), func(rank int) error {
+		op, err := newBskOp("Grep", js, devices[rank])
+		if err != nil {
+			return err
+		}
+		defer op.Close()
+		d := input.Shards[rank].Data
+		var ptr unsafe.Pointer
+		if len(d) > 0 {
+			ptr = unsafe.Pointer(&d[0])
+		}
+		var out C.bsk_out
+		var cnt C.uint64_t
+		rc := C.bsk_grep_run(op.ctx, ptr, C.size_t(len(d)), 0, C.int(input.Format), C.int64_t(rank), nil, &out)
+		if rc == C.BSK_OK {
+			rc = C.bsk_grep_last_count(op.ctx, &cnt)
+		}
+		var e error
+		if rc != C.BSK_OK {
+			e = op.err()
+			cnt = 0
+		}
+		if rc2 := C.bsk_count_allreduce(g.c[rank], &cnt, nil); rc2 != C.BSK_OK && e == nil {
+			e = errors.New(C.GoString(C.bsk_comm_error(g.c[rank])))
+		}
+		if rank == 0 {
+			total = uint64(cnt)
+		}
+		return e
+	})
+	return total, err
+}
+
+// RmDupN: the survivors of every rank's shard (file order; their concatenation equals the single-GPU output), duplicates
+// found across ranks by bsk_rmdup_dist_run (24-byte tuples to owner = key % N by grouped ncclSend / ncclRecv, keep bytes
+// back; GroupByKey + RmDupCheck, bigseqkit/rmdup.go:97).
+func RmDupN(input *SeqFrame, o *SeqKitRmDupOptions, g *Comms, devices []int) (*Result, error) {
+	o.setDefaults()
+	js := OptionsToString(o)
+	res := &Result{Parts: make([][]byte, len(devices))}
+	var mu sync.Mutex
+	err := onEveryDevice(len(devices), func(rank int) error {
+		op, err := newBskOp("RmDup", js, devices[rank])
+		if err != nil {
+			return err
+		}
+		defer op.Close()
+		d := input.Shards[rank].Data
+		C.bsk_device_select(C.int(devices[rank]))
+		dev := C.bsk_device_alloc(C.size_t(len(d) + 1))
+		if dev == nil {
+			return errors.New(C.GoString(C.bsk_global_error()))
+		}
+		defer C.bsk_device_free(dev)
+		if len(d) > 0 {
+			if rc := C.bsk_device_copy(dev, unsafe.Pointer(&d[0]), C.size_t(len(d)), C.BSK_COPY_H2D); rc != C.BSK_OK {
+				return errors.New(C.GoString(C.bsk_global_error()))
+			}
+		}
+		var out C.bsk_out
+		if rc := C.bsk_rmdup_dist_run(op.ctx, g.c[rank], dev, C.size_t(len(d)), C.int(input.Format), nil, &out); rc != C.BSK_OK {
+			return op.err()
+		}
+		buf := make([]byte, int(out.len))
+		if out.len > 0 {
+			if rc := C.bsk_out_to_host(op.ctx, &out, unsafe.Pointer(&buf[0]), out.len); rc != C.BSK_OK {
+				return op.err()
+			}
+		}
+		mu.Lock()
+		res.Parts[rank] = buf
+		res.Bytes += uint64(out.len)
+		res.Records += uint64(out.records)
+		mu.Unlock()
+		return nil
+	})
+	if err != nil {
+		return nil, err
+	}
+	return res, nil
 }

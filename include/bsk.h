@@ -30,7 +30,9 @@
  *     any number of contexts per device, any thread may use any context,
  *     but only one call at a time runs on a context.
  * A second call that arrives while one is running on the same context is
- * refused with BSK_ERR_INVALID_ARG ("context busy"), never raced; this covers
+ * refused with BSK_ERR_INVALID_ARG, never raced -- the text "context busy" is in
+ * the REFUSED caller's bsk_global_error() (thread-local; the context's own error
+ * text and per-call state belong to the call that is running) --; this covers
  * every entry point that touches the context's device state (the *_run
  * family, bsk_stats_*, bsk_index_*, bsk_out_to_host, bsk_store_put,
  * bsk_run_to_store, the bsk_rmdup_dist_* phases, bsk_profile_read).
