@@ -531,7 +531,8 @@ func StatsN(name, format string, input *SeqFrame, o *SeqKitStatsOptions, g *Comm
 // GrepCountN: per-rank counts summed by bsk_count_allreduce (GrepReduceCount, bigseqkit/grep.go:161-180).
 func GrepCountN(input *SeqFrame, o *SeqKitGrepOptions, g *Comms, devices []int) (uint64, error) {
 	o.setDefaults()
-	o.Count = true
+	t := true
+	o.Count = &t
 	js := OptionsToString(o)
 	var total uint64
 	err := onEveryDevice(len(devices), func(rank int) error {
