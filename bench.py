@@ -775,6 +775,7 @@ def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, b
     rows = bdist.all_gather_floats([own * 1e3] + [phases.get(k, 0.0) for k in names]
                                    + [phases.get("tuple_bytes_sent", 0), phases.get("tuple_bytes_sent_off_rank", 0)], dev)
     alg = N * REC + 16 * N + out_bytes_all
+    lp_rows = bdist.all_gather_floats([float(getattr(be, "local_pairs", 0))], dev)
     ops["rmdup -s @ C5"] = {
         "command": "rmdup -s", "n_gpus": world, "backend": backend_name, "scaling": "weak",
         "workload": "%.1f GB FASTQ-150 per rank x %d ranks (C5 is 8 x 25 GB), record i with i %% 5 == 4 repeats the bases of a "
@@ -789,10 +790,12 @@ def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, b
         "phases_ms_per_rank": {k: [round(r[1 + i], 4) for r in rows] for i, k in enumerate(names)},
         "tuple_bytes_sent_per_rank": [int(r[7]) for r in rows], "tuple_bytes_sent_off_rank_per_rank": [int(r[8]) for r in rows],
         "survivors_resident": "HBM (DeviceText: the context's output buffer; no host copy)",
-        "rmdup_keys": "two-key: across ranks a record travels as (XXH64, second 64-bit key, global index) to owner = key % N, and "
-                      "equal (k1, k2) decide -- the owner does not hold the text; equal k1 with different k2 are kept apart through "
-                      "the overflow list (PARITY.md KEYS).  The single-GPU call compares the bytes of every duplicate (ops entry "
-                      "'rmdup -s @ C5 shard', N = 1 line)",
+        "rmdup_keys": "across ranks a record travels as (XXH64, second 64-bit key, global index) to owner = key % N and equal (k1, k2) "
+                      "decide there -- the owner does not hold the text; equal k1 with different k2 are kept apart through the overflow "
+                      "list.  The owner's reply names the survivor: a duplicate whose survivor lives in the SAME shard is byte-compared "
+                      "with it on its rank (RmDupCheck's test, as the single-GPU call does for every duplicate); pairs that cross "
+                      "ranks stay with the two keys (PARITY.md KEYS)",
+        "pairs_byte_compared_per_rank": [int(r[0]) for r in lp_rows],
         "exact": bool(ok),
         "exact_how": "every rank: output == the records of its shard with GLOBAL index %% 5 != 4, byte for byte in file order; "
                      "survivors over all ranks == N - N // 5"}

@@ -143,6 +143,8 @@ SIGNATURES = {
     "bsk_rmdup_dist_pack": (_i, [_vp, C.c_uint64, _i, _vp, _p(C.c_uint64), _vp]),
     "bsk_rmdup_dist_resolve": (_i, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "bsk_rmdup_dist_emit": (_i, [_vp, _vp, _vp, C.c_uint64, _vp, _p(Out)]),
+    "bsk_rmdup_dist_resolve_ex": (_i, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "bsk_rmdup_dist_emit_ex": (_i, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _p(Out), _p(C.c_uint64)]),
     "bsk_comm_unique_id": (_i, [_vp]),
     "bsk_comm_init_rank": (_i, [_i, _i, _vp, _i, _p(_vp)]),
     "bsk_comm_init_all": (_i, [_i, _p(_i), _p(_vp)]),

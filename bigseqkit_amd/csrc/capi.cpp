@@ -1220,6 +1220,25 @@ int bsk_rmdup_dist_resolve(bsk_ctx* c, const void* d_tuples, uint64_t m, void* d
     return rmdup_dist_resolve(c, (const uint64_t*)d_tuples, m, (uint8_t*)d_keep, (hipStream_t)stream);
 }
 
+int bsk_rmdup_dist_resolve_ex(bsk_ctx* c, const void* d_tuples, uint64_t m, void* d_keep, void* d_survivor, void* stream) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_resolve_ex");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (m && (!d_tuples || !d_keep)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null tuples / keep");
+    return rmdup_dist_resolve(c, (const uint64_t*)d_tuples, m, (uint8_t*)d_keep, (hipStream_t)stream, (uint64_t*)d_survivor);
+}
+
+int bsk_rmdup_dist_emit_ex(bsk_ctx* c, const void* d_send, const void* d_reply, const void* d_survivor_reply, uint64_t base_index,
+                           void* stream, bsk_out* out, uint64_t* local_pairs_verified) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_emit_ex");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (!out || (c->table.n && (!d_send || !d_reply))) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null send / reply / out");
+    rc = rmdup_dist_emit(c, (const uint64_t*)d_send, (const uint8_t*)d_reply, base_index, (hipStream_t)stream, out, (const uint64_t*)d_survivor_reply);
+    if (local_pairs_verified) *local_pairs_verified = rc == BSK_OK ? c->dist_local_pairs : 0;
+    return rc;
+}
+
 int bsk_rmdup_dist_emit(bsk_ctx* c, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
                         bsk_out* out) {
     int rc = dist_enter(c, "bsk_rmdup_dist_emit");

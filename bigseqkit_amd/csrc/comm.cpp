@@ -464,7 +464,8 @@ int bsk_rmdup_dist_run(bsk_ctx* ctx, bsk_comm* c, const void* d_shard, size_t n,
     if (hipSetDevice(c->device) != hipSuccess) { ctx->set_error("libbsk: hipSetDevice failed"); return BSK_ERR_HIP; }
     uint64_t *d_send = nullptr, *d_recv = nullptr;
     uint8_t *d_keep = nullptr, *d_reply = nullptr;
-    auto cleanup = [&] { for (void* p : {(void*)d_send, (void*)d_recv, (void*)d_keep, (void*)d_reply}) if (p) hipFree(p); };
+    uint64_t *d_surv = nullptr, *d_surv_reply = nullptr;  // the survivor's global index per tuple, and routed back per record
+    auto cleanup = [&] { for (void* p : {(void*)d_send, (void*)d_recv, (void*)d_keep, (void*)d_reply, (void*)d_surv, (void*)d_surv_reply}) if (p) hipFree(p); };
     std::vector<uint64_t> send_cnt((size_t)W, 0), matrix((size_t)W * (size_t)W + 1, 0), recv_cnt((size_t)W);
     int rc_pack = BSK_OK;
     if (hipMalloc((void**)&d_send, std::max<uint64_t>(24, nrec * 24)) != hipSuccess) { ctx->set_error("libbsk: no device memory for the tuples"); rc_pack = BSK_ERR_HIP; }
@@ -491,7 +492,8 @@ int bsk_rmdup_dist_run(bsk_ctx* ctx, bsk_comm* c, const void* d_shard, size_t n,
     for (int p = 0; p < W; ++p) { recv_cnt[(size_t)p] = matrix[(size_t)p * (size_t)W + (size_t)c->rank]; m += recv_cnt[(size_t)p]; }
     int rc_own = BSK_OK;
     if (hipMalloc((void**)&d_recv, std::max<uint64_t>(24, m * 24)) != hipSuccess || hipMalloc((void**)&d_keep, std::max<uint64_t>(1, m)) != hipSuccess ||
-        hipMalloc((void**)&d_reply, std::max<uint64_t>(1, nrec)) != hipSuccess) { ctx->set_error("libbsk: no device memory for the exchange"); rc_own = BSK_ERR_HIP; }
+        hipMalloc((void**)&d_reply, std::max<uint64_t>(1, nrec)) != hipSuccess || hipMalloc((void**)&d_surv, std::max<uint64_t>(8, m * 8)) != hipSuccess ||
+        hipMalloc((void**)&d_surv_reply, std::max<uint64_t>(8, nrec * 8)) != hipSuccess) { ctx->set_error("libbsk: no device memory for the exchange"); rc_own = BSK_ERR_HIP; }
     {
         std::vector<uint64_t> okv((size_t)W);
         rc = allgather_value(c, rc_own == BSK_OK ? 0 : 1, okv.data(), st);
@@ -501,7 +503,7 @@ int bsk_rmdup_dist_run(bsk_ctx* ctx, bsk_comm* c, const void* d_shard, size_t n,
     }
     rc = alltoallv(c, (const uint8_t*)d_send, send_cnt.data(), (uint8_t*)d_recv, recv_cnt.data(), 24, biggest, st);
     if (rc != BSK_OK) { cleanup(); ctx->set_error(c->err); return rc; }
-    rc_own = bsk_rmdup_dist_resolve(ctx, d_recv, m, d_keep, stream);
+    rc_own = bsk_rmdup_dist_resolve_ex(ctx, d_recv, m, d_keep, d_surv, stream);
     {
         std::vector<uint64_t> okv((size_t)W);
         rc = allgather_value(c, rc_own == BSK_OK ? 0 : 1, okv.data(), st);
@@ -511,7 +513,10 @@ int bsk_rmdup_dist_run(bsk_ctx* ctx, bsk_comm* c, const void* d_shard, size_t n,
     }
     rc = alltoallv(c, d_keep, recv_cnt.data(), d_reply, send_cnt.data(), 1, biggest, st);  // the same routes backwards
     if (rc != BSK_OK) { cleanup(); ctx->set_error(c->err); return rc; }
-    rc = bsk_rmdup_dist_emit(ctx, d_send, d_reply, base, stream, out);
+    // ... and who survives: a duplicate whose survivor is in this rank's own shard gets the byte comparison of the single-GPU call
+    rc = alltoallv(c, (const uint8_t*)d_surv, recv_cnt.data(), (uint8_t*)d_surv_reply, send_cnt.data(), 8, biggest, st);
+    if (rc != BSK_OK) { cleanup(); ctx->set_error(c->err); return rc; }
+    rc = bsk_rmdup_dist_emit_ex(ctx, d_send, d_reply, d_surv_reply, base, stream, out, nullptr);
     if (rc == BSK_OK && hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; ctx->set_error("libbsk: the emit of the survivors failed"); }
     cleanup();
     return rc;

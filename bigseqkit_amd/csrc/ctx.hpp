@@ -241,6 +241,7 @@ struct bsk_ctx {
     uint32_t long_thresh = 1u << 20;        // BSK_LONG_BYTES overrides (tests)
     uint64_t flat_long_count = 0;           // prepare_text(flatten): records of >= flat_long_thresh bases, listed in d_long_list
     uint32_t flat_long_thresh = 0;
+    uint64_t dist_local_pairs = 0;  // multi-GPU rmdup: duplicates of the last emit whose survivor was in the same shard (byte-compared)
     uint64_t long_count = 0, long_max = 0;  // records with >= SEQ_LONG_THRESH output bytes in the last finish_sizes()
     uint32_t* d_long_list = nullptr;
     uint64_t long_list_cap = 0;

@@ -506,7 +506,7 @@ int rmdup_dist_pack(bsk_ctx* c, uint64_t base, int world, uint64_t* d_send, uint
     return BSK_OK;
 }
 
-int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t* d_keep, hipStream_t st) {
+int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t* d_keep, hipStream_t st, uint64_t* d_surv) {
     if (m == 0) return BSK_OK;
     // Round 4: the received tuples are grouped the way a shard groups its own records -- radix sort by the low key bits, one
     // LDS table per bucket, k2 compared inside, the few k1 collisions settled exactly through the overflow list -- instead
@@ -549,7 +549,7 @@ int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t
         }
         if (by_buckets) {
             // (the sorted keys are done with: their array is the scratch of the per-group minimum)
-            HIP_TRYX(c, launch_keep_lowest(d_tuples, d_first, m, A.at<uint64_t>(o_sk), d_keep, st));
+            HIP_TRYX(c, launch_keep_lowest(d_tuples, d_first, m, A.at<uint64_t>(o_sk), d_keep, st, d_surv));
             HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(uint64_t), st));  // (word 3 counted the list)
             HIP_TRYX(c, hipStreamSynchronize(st));
             return BSK_OK;
@@ -565,7 +565,7 @@ int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t
     HIP_TRYX(c, hipMemsetAsync(tf, 0xFF, cap * sizeof(uint64_t), st));
     HIP_TRYX(c, hipMemsetAsync(t2, 0, cap * sizeof(uint64_t), st));
     HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
-    HIP_TRYX(c, launch_rmdup_own(d_tuples, m, tk, tf, t2, cap, d_keep, c->d_status, st));
+    HIP_TRYX(c, launch_rmdup_own(d_tuples, m, tk, tf, t2, cap, d_keep, c->d_status, st, d_surv));
     uint64_t status = 0;
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
@@ -576,7 +576,8 @@ int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t
     return BSK_OK;
 }
 
-int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, uint64_t base, hipStream_t st, bsk_out* out) {
+int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, uint64_t base, hipStream_t st, bsk_out* out,
+                    const uint64_t* d_surv_reply) {
     const uint64_t N = c->table.n;
     if (N == 0) return empty_result(c, out);
     const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
@@ -584,6 +585,22 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_rmdup_apply(c->table, rmdup_params(c, fastq), d_send, d_reply, base, c->d_out_len, st));
+    if (d_surv_reply && fastq && c->opts.b("BySeq") && N < (1ull << 32)) {
+        // Round 5: across ranks equal (k1, k2) decide -- the owner holds no text -- but a
+        // duplicate whose survivor lives in THIS shard can be held to RmDupCheck's own test (rmdup.go:193-199) for the
+        // price of the comparison: the owner's reply names the survivor's global index, the pairs inside the shard go
+        // through the byte comparison of the single-GPU call; a difference fails the call (ERR_HASH_COLLISION), as there.
+        // Pairs that cross ranks stay with the two keys (PARITY.md KEYS).
+        Arena A;
+        const uint64_t o_first = A.take(N * 4);
+        rc = arena_reserve(c, &A);
+        if (rc != BSK_OK) return rc;
+        uint64_t* d_nloc = c->d_fin + bsk_ctx::FIN_AUX0;
+        HIP_TRYX(c, hipMemsetAsync(d_nloc, 0, sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_dist_first(d_send, d_reply, d_surv_reply, N, base, A.at<uint32_t>(o_first), d_nloc, st));
+        Timed t(c, "k_rmdup_verify", st);
+        HIP_TRYX(c, launch_rmdup_verify_fastq(c->dist_buf, c->table, rmdup_params(c, fastq), A.at<uint32_t>(o_first), nullptr, c->d_status, st));
+    }
     uint64_t total = 0, kept = 0;
     rc = finish_sizes(c, st, &total, &kept);
     if (rc != BSK_OK) return rc;
@@ -597,6 +614,7 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
+    c->dist_local_pairs = d_surv_reply ? c->fin(bsk_ctx::FIN_AUX0) : 0;   // (came back with the size pass's read-back)
     return BSK_OK;
 }
 

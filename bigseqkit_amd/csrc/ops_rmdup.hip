@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_rmdup_own_insert(const uint64_t* __rest
 __global__ __launch_bounds__(256) void k_rmdup_own_keep(const uint64_t* __restrict__ tuples, uint64_t m,
                                                         const uint64_t* __restrict__ table_keys,
                                                         const uint64_t* __restrict__ table_first, uint64_t cap,
-                                                        uint8_t* __restrict__ keep) {
+                                                        uint8_t* __restrict__ keep, uint64_t* __restrict__ surv) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= m) return;
     const uint64_t k = slot_key(tuples[3 * p]);
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(256) void k_rmdup_own_keep(const uint64_t* __restri
     uint64_t s = slot_of(k, mask);
     while (table_keys[s] != k) s = (s + 1) & mask;
     keep[p] = table_first[s] == tuples[3 * p + 2] ? 1 : 0;
+    if (surv) surv[p] = table_first[s];
 }
 
 __global__ __launch_bounds__(256) void k_rmdup_apply(RecordTable t, RmDupParams P, const uint64_t* __restrict__ send,
@@ -1186,10 +1187,29 @@ __global__ __launch_bounds__(256) void k_group_min(const uint64_t* __restrict__ 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) atomicMin(&gmin[first[i]], (unsigned long long)tuples[3 * i + 2]);
 }
+// surv (may be null): the global index of the record that survives for tuple i's subject -- what lets the sender compare
+// the bytes of a duplicate with a survivor that lives in its own shard (round 5)
 __global__ __launch_bounds__(256) void k_keep_min(const uint64_t* __restrict__ tuples, const uint32_t* __restrict__ first, uint64_t m,
-                                                  const unsigned long long* __restrict__ gmin, uint8_t* __restrict__ keep) {
+                                                  const unsigned long long* __restrict__ gmin, uint8_t* __restrict__ keep,
+                                                  uint64_t* __restrict__ surv) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) keep[i] = (unsigned long long)tuples[3 * i + 2] == gmin[first[i]] ? 1 : 0;
+    if (i < m) {
+        const unsigned long long g = gmin[first[i]];
+        keep[i] = (unsigned long long)tuples[3 * i + 2] == g ? 1 : 0;
+        if (surv) surv[i] = g;
+    }
+}
+// first_of[i] for the byte comparison of the multi-GPU path: i itself for a survivor and for a duplicate whose survivor
+// lives on another rank (no text to compare with here), else the survivor's index in THIS shard
+__global__ __launch_bounds__(256) void k_dist_first(const uint64_t* __restrict__ send, const uint8_t* __restrict__ reply,
+                                                    const uint64_t* __restrict__ surv, uint64_t n, uint64_t base,
+                                                    uint32_t* __restrict__ first_of, unsigned long long* __restrict__ n_local) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t i = send[3 * p + 2] - base, s = surv[p];
+    const bool local = !reply[p] && s >= base && s < base + n && s - base != i;
+    first_of[i] = (uint32_t)(local ? s - base : i);
+    if (local) atomicAdd(n_local, 1ull);
 }
 }  // namespace
 
@@ -1198,21 +1218,29 @@ hipError_t launch_split_tuples(const uint64_t* tuples, uint64_t m, uint64_t* k1,
     hipLaunchKernelGGL(k_split_tuples, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, tuples, m, k1, k2);
     return hipGetLastError();
 }
-hipError_t launch_keep_lowest(const uint64_t* tuples, const uint32_t* first, uint64_t m, uint64_t* gmin, uint8_t* keep, hipStream_t st) {
+hipError_t launch_keep_lowest(const uint64_t* tuples, const uint32_t* first, uint64_t m, uint64_t* gmin, uint8_t* keep, hipStream_t st,
+                              uint64_t* surv) {
     if (m == 0) return hipSuccess;
     if (hipMemsetAsync(gmin, 0xFF, m * sizeof(uint64_t), st) != hipSuccess) return hipGetLastError();
     const dim3 g((unsigned)((m + 255) / 256)), b(256);
     hipLaunchKernelGGL(k_group_min, g, b, 0, st, tuples, first, m, (unsigned long long*)gmin);
-    hipLaunchKernelGGL(k_keep_min, g, b, 0, st, tuples, first, m, (const unsigned long long*)gmin, keep);
+    hipLaunchKernelGGL(k_keep_min, g, b, 0, st, tuples, first, m, (const unsigned long long*)gmin, keep, surv);
+    return hipGetLastError();
+}
+hipError_t launch_dist_first(const uint64_t* send, const uint8_t* reply, const uint64_t* surv, uint64_t n, uint64_t base, uint32_t* first_of,
+                             uint64_t* n_local, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dist_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, send, reply, surv, n, base, first_of,
+                       (unsigned long long*)n_local);
     return hipGetLastError();
 }
 
 hipError_t launch_rmdup_own(const uint64_t* tuples, uint64_t m, uint64_t* table_keys, uint64_t* table_first,
-                            uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st) {
+                            uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st, uint64_t* surv) {
     if (m == 0) return hipSuccess;
     const dim3 g((unsigned)((m + 255) / 256)), b(256);
     hipLaunchKernelGGL(k_rmdup_own_insert, g, b, 0, st, tuples, m, table_keys, table_first, table_k2, cap, status);
-    hipLaunchKernelGGL(k_rmdup_own_keep, g, b, 0, st, tuples, m, table_keys, table_first, cap, keep);
+    hipLaunchKernelGGL(k_rmdup_own_keep, g, b, 0, st, tuples, m, table_keys, table_first, cap, keep, surv);
     return hipGetLastError();
 }
 

@@ -77,7 +77,11 @@ hipError_t launch_gather_keys(const uint32_t* list, uint32_t m, const uint64_t* 
 // owner side of the multi-GPU exchange: k1[i], k2[i] of tuple i (24-byte rows: k1, k2, global record number);
 // keep[i] = tuple i carries the lowest record number of its group (first[i] = one member of the group; gmin: m words scratch)
 hipError_t launch_split_tuples(const uint64_t* tuples, uint64_t m, uint64_t* k1, uint64_t* k2, hipStream_t st);
-hipError_t launch_keep_lowest(const uint64_t* tuples, const uint32_t* first, uint64_t m, uint64_t* gmin, uint8_t* keep, hipStream_t st);
+hipError_t launch_keep_lowest(const uint64_t* tuples, const uint32_t* first, uint64_t m, uint64_t* gmin, uint8_t* keep, hipStream_t st,
+                              uint64_t* surv = nullptr /* [m]: global index of every tuple's survivor */);
+// multi-GPU emit: first_of[] for the byte comparison of the duplicates whose survivor lives in the same shard (*n_local += their number)
+hipError_t launch_dist_first(const uint64_t* send, const uint8_t* reply, const uint64_t* surv, uint64_t n, uint64_t base, uint32_t* first_of,
+                             uint64_t* n_local, hipStream_t st);
 // tests: keys[i] &= mask (forces distinct subjects under one key)
 hipError_t launch_mask_keys(uint64_t* keys, uint64_t n, uint64_t mask, hipStream_t st);
 hipError_t launch_scatter_u32(const uint32_t* idx, const uint32_t* val, uint32_t m, uint32_t* dst, hipStream_t st);
@@ -102,7 +106,7 @@ hipError_t launch_rmdup_pack(const uint64_t* keys, const uint64_t* keys2, uint64
                              uint64_t* cursor, uint64_t* send, hipStream_t st);
 // table_keys / table_k2 zeroed, table_first 0xFF-filled by the caller; keep[p] = tuple p is the first of its key
 hipError_t launch_rmdup_own(const uint64_t* tuples, uint64_t m, uint64_t* table_keys, uint64_t* table_first,
-                            uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st);
+                            uint64_t* table_k2, uint64_t cap, uint8_t* keep, uint64_t* status, hipStream_t st, uint64_t* surv = nullptr);
 hipError_t launch_rmdup_apply(const RecordTable& t, const RmDupParams& P, const uint64_t* send, const uint8_t* reply,
                               uint64_t base, uint32_t* out_len, hipStream_t st);
 

@@ -286,13 +286,30 @@ class HipRmDupBackend:
                                          C.c_void_p(keep.data_ptr()), None), self.op.ctx)
         return keep
 
-    def emit(self, send, reply, base, to_host=True):
+    def resolve_ex(self, tuples):
+        """resolve + the global index of every tuple's survivor (bsk_rmdup_dist_resolve_ex)"""
+        import torch
+        keep = torch.empty(tuples.shape[0], dtype=torch.uint8, device=tuples.device)
+        surv = torch.empty(tuples.shape[0], dtype=torch.int64, device=tuples.device)
+        check(lib.bsk_rmdup_dist_resolve_ex(self.op.ctx, C.c_void_p(tuples.data_ptr()), tuples.shape[0], C.c_void_p(keep.data_ptr()),
+                                            C.c_void_p(surv.data_ptr()), None), self.op.ctx)
+        return keep, surv
+
+    def emit(self, send, reply, base, to_host=True, surv_reply=None):
         """survivors of this rank's shard: host bytes (tests), or with to_host=False a DeviceText -- the text stays in the
-        context's output buffer in HBM (20 GB per rank at C5 do not belong on the host)"""
+        context's output buffer in HBM (20 GB per rank at C5 do not belong on the host).  surv_reply (the survivors' global
+        indices, routed back like the keep bytes): the duplicates whose survivor lives in this shard are byte-compared with
+        it (bsk_rmdup_dist_emit_ex); self.local_pairs = how many"""
         from . import _lib
         out = _lib.Out()
-        check(lib.bsk_rmdup_dist_emit(self.op.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(reply.data_ptr()), base, None,
-                                      C.byref(out)), self.op.ctx)
+        if surv_reply is None:
+            check(lib.bsk_rmdup_dist_emit(self.op.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(reply.data_ptr()), base, None,
+                                          C.byref(out)), self.op.ctx)
+        else:
+            n = C.c_uint64()
+            check(lib.bsk_rmdup_dist_emit_ex(self.op.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(reply.data_ptr()),
+                                             C.c_void_p(surv_reply.data_ptr()), base, None, C.byref(out), C.byref(n)), self.op.ctx)
+            self.local_pairs = n.value
         text = DeviceText(self.op, out, self._keep.device)
         return bytes(text) if to_host else text
 
@@ -347,10 +364,12 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
     if phases is not None:
         phases["tuple_bytes_sent"] = 24 * int(sum(in_splits))
         phases["tuple_bytes_sent_off_rank"] = 24 * int(sum(c for r, c in enumerate(in_splits) if r != rank))
+    ex = hasattr(backend, "resolve_ex")   # (round 5: the owner also names the survivor, local pairs are byte-compared)
     if not multi:
-        keep = backend.resolve(send)
+        keep, surv = backend.resolve_ex(send) if ex else (backend.resolve(send), None)
         ph.mark("resolve")
-        out = backend.emit(send, keep, base) if to_host else backend.emit(send, keep, base, to_host=False)
+        kw = {"surv_reply": surv} if ex else {}
+        out = backend.emit(send, keep, base, **kw) if to_host else backend.emit(send, keep, base, to_host=False, **kw)
         ph.mark("emit")
         return out
     t_in = torch.tensor(in_splits, dtype=torch.int64, device=dev)
@@ -360,12 +379,17 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
     recv = torch.empty((sum(out_splits), 3), dtype=torch.int64, device=dev)
     _all_to_all_single(recv, send, out_splits, in_splits, group)
     ph.mark("all_to_all")
-    keep = backend.resolve(recv)
+    keep, surv = backend.resolve_ex(recv) if ex else (backend.resolve(recv), None)
     ph.mark("resolve")
     reply = torch.empty(n, dtype=torch.uint8, device=dev)
     _all_to_all_single(reply, keep, in_splits, out_splits, group)
+    kw = {}
+    if ex:
+        surv_reply = torch.empty(n, dtype=torch.int64, device=dev)
+        _all_to_all_single(surv_reply, surv, in_splits, out_splits, group)
+        kw = {"surv_reply": surv_reply}
     ph.mark("reply")
-    out = backend.emit(send, reply, base) if to_host else backend.emit(send, reply, base, to_host=False)
+    out = backend.emit(send, reply, base, **kw) if to_host else backend.emit(send, reply, base, to_host=False, **kw)
     ph.mark("emit")
     return out
 

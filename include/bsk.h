@@ -350,6 +350,15 @@ int bsk_rmdup_dist_pack(bsk_ctx* ctx, uint64_t base_index, int world, void* d_se
 int bsk_rmdup_dist_resolve(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void* d_keep, void* stream);
 int bsk_rmdup_dist_emit(bsk_ctx* ctx, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
                         bsk_out* out);
+/* The same two phases with the survivor's identity (round 5): _resolve_ex also writes d_survivor (u64[m]: the global index of
+ * the record that survives for every tuple's subject); routed back like the keep bytes (d_survivor_reply, u64[n_records] in
+ * the order of d_send) it lets _emit_ex compare the BYTES of every duplicate whose survivor lives in the same shard with that
+ * survivor's (RmDupCheck's own test, bigseqkit-lib/rmdup.go:193-199; `-s` on FASTQ) -- a difference fails the call, as in
+ * the single-GPU run.  Pairs that cross ranks are decided by the two keys alone (PARITY.md KEYS).  Either pointer NULL:
+ * the plain phases.  *local_pairs_verified (may be NULL): how many pairs were compared. */
+int bsk_rmdup_dist_resolve_ex(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void* d_keep, void* d_survivor, void* stream);
+int bsk_rmdup_dist_emit_ex(bsk_ctx* ctx, const void* d_send, const void* d_reply, const void* d_survivor_reply, uint64_t base_index,
+                           void* stream, bsk_out* out, uint64_t* local_pairs_verified);
 
 /* ---- collectives behind the C ABI (round 5): RCCL over xGMI, no Python, no torch -----------------------------------------
  * In the reference the driver gets Reduce and GroupByKey from IgnisHPC, in the same binary (bigseqkit/stats.go:91,

@@ -25,12 +25,13 @@ class OracleRmDupBackend:
         if lines and lines[-1] == b"":
             lines.pop()
         assert len(lines) % 4 == 0
-        self.records, self.k1, self.k2 = [], [], []
+        self.records, self.k1, self.k2, self.subjects = [], [], [], []
         for r in range(0, len(lines), 4):
             self.records.append(b"\n".join(lines[r:r + 4]) + b"\n")
             subject = lines[r + 1] if self.by_seq else lines[r][1:].split(b" ")[0]
             if self.fold:
                 subject = subject.lower()
+            self.subjects.append(subject)
             self.k1.append(oracle.xxh64(subject))
             self.k2.append(xxhash.xxh64(subject, seed=SEED2).intdigest())
         return len(self.records)
@@ -53,10 +54,26 @@ class OracleRmDupBackend:
             assert first[k][1] == k2 or cur is None or cur[1] == k2
         return torch.tensor([1 if first[k][0] == g else 0 for k, k2, g in rows], dtype=torch.uint8)
 
-    def emit(self, send, reply, base, to_host=True):
+    def resolve_ex(self, tuples):
+        """resolve + the global index of every tuple's survivor (what bsk_rmdup_dist_resolve_ex answers)"""
+        keep = self.resolve(tuples)
+        first = {}
+        rows = tuples.tolist()
+        for k, k2, g in rows:
+            first[k] = min(first.get(k, g), g)
+        return keep, torch.tensor([first[k] for k, k2, g in rows], dtype=torch.int64)
+
+    def emit(self, send, reply, base, to_host=True, surv_reply=None):
         keep = {}
-        for (k, k2, g), r in zip(send.tolist(), reply.tolist()):
+        self.local_pairs = 0
+        for p, ((k, k2, g), r) in enumerate(zip(send.tolist(), reply.tolist())):
             keep[g - base] = r
+            if surv_reply is not None:
+                s = int(surv_reply[p])
+                assert (s == g) == bool(r)
+                if not r and base <= s < base + len(self.records):   # the survivor lives in this shard: the bytes must agree
+                    assert self.subjects[s - base] == self.subjects[g - base]
+                    self.local_pairs += 1
         text = b"".join(rec for i, rec in enumerate(self.records) if keep[i])
         if to_host:
             return text

@@ -320,9 +320,66 @@ def test_rmdup_distributed_single_rank_equals_rmdup():
     b = bdist.HipRmDupBackend(json.dumps({"BySeq": True}), 0)
     try:
         got = bdist.rmdup_distributed(dev(data), bsk.FORMAT_FASTQ, b)
+        local_pairs = b.local_pairs
     finally:
         b.close()
-    assert got == bsk.RmDup(frame(data, True), _Opts({"BySeq": True})) == oracle.rmdup(data, True, '{"BySeq": true}')
+    want = oracle.rmdup(data, True, '{"BySeq": true}')
+    assert got == bsk.RmDup(frame(data, True), _Opts({"BySeq": True})) == want
+    # round 5: the owner's reply names the survivor; with one rank EVERY duplicate's survivor is in the same shard, so every
+    # removed record went through the byte comparison of the single-GPU call (bsk_rmdup_dist_emit_ex)
+    assert local_pairs == data.count(b"\n") // 4 - want.count(b"\n") // 4 > 0
+
+
+def test_rmdup_distributed_compares_the_pairs_inside_a_shard():
+    """three virtual ranks: the duplicates whose survivor lives in the same shard are byte-compared there (the rest is decided
+    by the two keys); the sum over the ranks is what a walk over the oracle's survivors predicts"""
+    import torch
+    from bigseqkit_amd import dist as bdist
+    rng = random.Random(19)
+    data = dup_fastq(rng, 4000)
+    world = 3
+    bounds = bdist.shard_bounds(data, world, bsk.FORMAT_FASTQ)
+    shards = [dev(data[lo:hi]) for lo, hi in bounds]
+    backs = [bdist.HipRmDupBackend(json.dumps({"BySeq": True}), 0) for _ in range(world)]
+    try:
+        ns = [b.keys(s, bsk.FORMAT_FASTQ) for b, s in zip(backs, shards)]
+        bases = [sum(ns[:r]) for r in range(world)]
+        packed = [b.pack(bases[r], world) for r, b in enumerate(backs)]
+
+        def bucket(t, counts, o):
+            a = sum(counts[:o])
+            return t[a:a + counts[o]]
+        keeps, survs = [], []
+        for o in range(world):
+            recv = torch.cat([bucket(packed[r][0], packed[r][1], o) for r in range(world)])
+            k, sv = backs[o].resolve_ex(recv)
+            keeps.append(k)
+            survs.append(sv)
+        outs, pairs = [], 0
+        for r in range(world):
+            # what comes back to rank r: from every owner o, the slice of its answers that belongs to r's tuples, owner after owner
+            rep, srep = [], []
+            for o in range(world):
+                a = sum(packed[q][1][o] for q in range(r))
+                rep.append(keeps[o][a:a + packed[r][1][o]])
+                srep.append(survs[o][a:a + packed[r][1][o]])
+            outs.append(backs[r].emit(packed[r][0], torch.cat(rep), bases[r], surv_reply=torch.cat(srep)))
+            pairs += backs[r].local_pairs
+    finally:
+        for b in backs:
+            b.close()
+    assert b"".join(outs) == oracle.rmdup(data, True, '{"BySeq": true}')
+    # prediction: a removed record whose first occurrence (file order) lies in the same shard
+    seqs = data.split(b"\n")[1::4]
+    first, same = {}, 0
+    starts = [sum(ns[:r]) for r in range(world)] + [sum(ns)]
+    rank_of = lambda i: max(r for r in range(world) if starts[r] <= i)
+    for i, s in enumerate(seqs):
+        if s in first:
+            same += rank_of(first[s]) == rank_of(i)
+        else:
+            first[s] = i
+    assert pairs == same > 0
 
 
 @pytest.mark.parametrize("i", range(len(TR_OPTS)))
