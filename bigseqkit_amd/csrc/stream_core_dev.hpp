@@ -274,7 +274,7 @@ struct sink_role_counts<S, decltype((void)S::ROLE_COUNTS)> { static constexpr bo
 // four event lanes of batch().  The skeleton DEFERS: the events of the tiles pile up in a window of 256 and the sink runs
 // when 64 records are complete -- one sink iteration per ~5 tiles of 150-base reads with all 64 lanes busy, where batch()
 // ran once per tile with 52 event lanes of which a quarter (the record ends) did the sink's real work.  Round 4: the
-// streaming sinks were at their instruction issue time, and this is the part of it that scales with
+// streaming sinks were at their instruction issue time (HISTORY.md §7), and this is the part of it that scales with
 // events instead of bytes.  Events that do not fill a record at the end of a range (a truncated file) go through
 // batch(), whose per-event rules and error flags are the reference for both.
 template <class S, class = void>
