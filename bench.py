@@ -150,6 +150,26 @@ class _Helpers:
         return hit_mask
 
 
+_MALLOC_SET = False
+
+
+def _malloc_for_many_threads():
+    """glibc's allocator for the all-cores legs: the restatement allocates per record like the Go code it restates; with 256
+    threads the default thresholds give freed memory back to the kernel and map it again all the time (33 minutes of system
+    time in a 5-minute run, one address space's mmap lock).  Keep what was freed: no trimming, no mmap for large blocks."""
+    global _MALLOC_SET
+    if _MALLOC_SET:
+        return
+    _MALLOC_SET = True
+    try:
+        libc = C.CDLL("libc.so.6")
+        libc.mallopt(-1, 1 << 30)    # M_TRIM_THRESHOLD
+        libc.mallopt(-3, 1 << 30)    # M_MMAP_THRESHOLD
+        libc.mallopt(-2, 64 << 20)   # M_TOP_PAD
+    except OSError:
+        pass
+
+
 def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, seconds=None, min_bytes=0):
     """The oracle (oracle/: C++ restatement of the reference's operator, `port`) on a bounded prefix of the SAME input, 1 thread
     and -- where the records are independent -- all host cores (one record-aligned slice per thread; ctypes releases the
@@ -160,6 +180,7 @@ def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, 
     1.69 on 256)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
+    _malloc_for_many_threads()
     if seconds is None:
         seconds = max(0.3, H.args.cpu_seconds / 6.0)   # (five operators x two legs beside the stats baseline: ~30 s in all)
     oj = json.dumps(opts)

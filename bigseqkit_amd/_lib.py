@@ -197,6 +197,7 @@ def check(rc, ctx=None):
     if rc != BSK_OK:
         # (every failure also leaves its text in the calling thread's bsk_global_error(); a call refused as "context busy"
         # leaves it ONLY there -- the context's text belongs to the call that is running)
+        # (the thread's text is sticky: only a refusal -- always BSK_ERR_INVALID_ARG -- is looked up there first)
         g = lib.bsk_global_error() or b""
-        msg = g if (not ctx or b"context busy" in g) else (lib.bsk_last_error(ctx) or g)
+        msg = g if (not ctx or (rc == BSK_ERR_INVALID_ARG and b"context busy" in g)) else (lib.bsk_last_error(ctx) or g)
         raise BskError(rc, (msg or b"").decode("utf-8", "replace"))

@@ -987,56 +987,37 @@ __device__ __forceinline__ uint32_t load_break(const uint8_t* a, uint32_t kb, co
 #else
 #define BSK_TRW_ATTR
 #endif
-template <int G, bool UNI>
-__global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
-                                                        TranslateParams P, const uint32_t* __restrict__ out_len,
-                                                        const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                                                        uint8_t* __restrict__ redo, uint64_t* __restrict__ redo_count,
-                                                        uint64_t* __restrict__ status) {
+// what the wide kernel needs to know of ONE record: where it is, how its text is laid out, and where its elements go
+struct WideRec {
+    uint64_t g;        // record number (table modes: row of the record table)
+    Text T;            // sequence text: first base, bases, line width
+    uint64_t rstart;   // the record's '>'
+    uint32_t lh;       // header line length, marker included
+    uint32_t ne[6];    // bytes of element k (frame k of the call)
+    uint64_t oe[6];    // ... and its offset in the output
+};
+
+// The body of k_translate_wide for one record and one group of G lanes.  UNI: the record follows from its number
+// (UniformLayout) and its frame is verified here; STREAM (round 5, k_translate_stream): the record comes from the pass that
+// found it -- no record table exists (no redo list, no -M / -F: the host does not choose that pass for them).
+template <int G, bool UNI, bool STREAM>
+__device__ __forceinline__ void translate_wide_record(const uint8_t* __restrict__ buf, uint64_t buf_n, const RecordTable& t,
+                                                      const TranslateParams& P, const uint32_t* __restrict__ out_len,
+                                                      const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                      uint8_t* __restrict__ redo, uint64_t* __restrict__ redo_count,
+                                                      const uint8_t* s_pair, const uint8_t* s_iu, const uint2* s_ins, const WideRec& R) {
     constexpr uint32_t LB = 48;            // bases per lane and step (16 codon slots)
     constexpr uint32_t STEPB = G * LB;     // bases per group and step
-    __shared__ __attribute__((aligned(16))) uint8_t s_pair[16384];  // residues of two 2-bit codons at once (Slots), from P.pair
-    __shared__ uint8_t s_iu[256];
-    __shared__ uint2 s_ins[6];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // 16 KiB by 256 threads
-        const uint4 v = *reinterpret_cast<const uint4*>(P.pair + 16 * (threadIdx.x + 256 * i));
-        *reinterpret_cast<uint4*>(s_pair + 16 * (threadIdx.x + 256 * i)) = v;
-    }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
-    if (threadIdx.x == 0) {
-        // break inside dword i at byte fm (index fm + 1): bytes below fm from p[i], the break, bytes above from one lower
-        s_ins[0] = make_uint2(0x06050403u, 0u);            // fm <= -1: the break came earlier, everything one byte up
-        s_ins[1] = make_uint2(0x0605040Cu, 0x0000000Au);   // fm == 0
-        s_ins[2] = make_uint2(0x06050C04u, 0x00000A00u);
-        s_ins[3] = make_uint2(0x060C0504u, 0x000A0000u);
-        s_ins[4] = make_uint2(0x0C060504u, 0x0A000000u);
-        s_ins[5] = make_uint2(0x07060504u, 0u);            // fm >= 4: the break comes later
-    }
-    __syncthreads();
-    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint64_t g = R.g;
     const uint32_t gl = threadIdx.x % G;
-    if (g >= (UNI ? P.uni.n : t.n)) return;  // no block-level barrier below
-    Text T;
-    uint64_t rstart;  // the record's '>'
-    uint32_t lh;      // header line length, marker included
-    if constexpr (UNI) {  // everything follows from the record number (UniformLayout) -- and is verified below
-        rstart = g * P.uni.S;
-        lh = P.uni.H;
-        T.p = buf + rstart + lh + 1;
-        T.L = P.uni.L;
-        T.W = P.uni.W;
-    } else {
-        if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
-        T = text_of(buf, t, tt, g);
-        rstart = t.start[g];
-        lh = t.l_head[g];
-    }
+    const Text T = R.T;
+    const uint64_t rstart = R.rstart;
+    const uint32_t lh = R.lh;
     const uint32_t L = T.L;
     const uint32_t W = T.W;
     const uint32_t lw = P.line_width > 0 ? (uint32_t)P.line_width : 0u;
     if ((W && W < 50u) || (lw && lw < 16u)) {  // (wave-uniform per group) not this kernel's layout
-        if (gl == 0) { if constexpr (!UNI) redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
+        if (gl == 0) { if constexpr (!UNI && !STREAM) redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
         return;
     }
     const uint8_t* h = buf + rstart + 1;
@@ -1087,17 +1068,8 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
     // for ~30 us, and most of that was waiting)
     uint32_t ne[6];
     uint64_t oe[6];
-    const uint64_t e0 = g * (uint64_t)P.nframes;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        if constexpr (UNI) {
-            ne[k] = k < P.nframes ? P.uni.len[k] : 0u;
-            oe[k] = k < P.nframes ? g * P.uni.out_S + P.uni.off[k] : 0ull;
-        } else {
-            ne[k] = k < P.nframes ? out_len[e0 + k] : 0u;
-            oe[k] = k < P.nframes ? out_off[e0 + k] : 0ull;
-        }
-    }
+    for (int k = 0; k < 6; ++k) { ne[k] = R.ne[k]; oe[k] = R.oe[k]; }
     // header line and final line break of element k (n bytes at o, header of H bytes)
     const uint8_t hbyte = (gl >= 1u && gl - 1u < hl) ? h[gl - 1u] : (uint8_t)0;  // header byte of position gl (frames share it)
     auto put_header = [&](int frame, uint8_t* o, uint32_t n, uint32_t H) {
@@ -1124,7 +1096,7 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         if (k >= P.nframes) break;
         const int frame = P.frames[k];
         const uint32_t n = ne[k];
-        const uint32_t H = (UNI ? 1u + hl : header_len(t, g, h, hl, P, frame)) + 1;
+        const uint32_t H = ((UNI || STREAM) ? 1u + hl : header_len(t, g, h, hl, P, frame)) + 1;
         const uint32_t body = n - H - 1;
         const uint32_t kept = body - (lw ? body / (lw + 1) : 0u);
         put_header(frame, out + oe[k], n, H);
@@ -1337,11 +1309,11 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
         rnl = rnl2; rcol = rcol2;
     }
     if (give_up) {
-        if (gl == 0) { if constexpr (!UNI) redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
+        if (gl == 0) { if constexpr (!UNI && !STREAM) redo[g] = 1; atomicAdd((unsigned long long*)redo_count, 1ull); }
         return;
     }
     // ---- -M: residue 0 of a frame becomes 'M' when its codon is a start codon (after every other store)
-    if constexpr (!UNI) if (P.init_m && gl == 0) {
+    if constexpr (!UNI && !STREAM) if (P.init_m && gl == 0) {
         __threadfence();
         for (int k = 0; k < P.nframes; ++k) {
             const int frame = P.frames[k];
@@ -1355,11 +1327,325 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
             if (st && out_len[e] > H + 1u) out[out_off[e] + H] = 'M';
         }
     }
+    (void)out_len; (void)out_off;
+}
+
+template <int G, bool UNI>
+__global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t, TextTable tt,
+                                                        TranslateParams P, const uint32_t* __restrict__ out_len,
+                                                        const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                        uint8_t* __restrict__ redo, uint64_t* __restrict__ redo_count,
+                                                        uint64_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_pair[16384];  // residues of two 2-bit codons at once (Slots), from P.pair
+    __shared__ uint8_t s_iu[256];
+    __shared__ uint2 s_ins[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // 16 KiB by 256 threads
+        const uint4 v = *reinterpret_cast<const uint4*>(P.pair + 16 * (threadIdx.x + 256 * i));
+        *reinterpret_cast<uint4*>(s_pair + 16 * (threadIdx.x + 256 * i)) = v;
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
+    if (threadIdx.x == 0) {
+        // break inside dword i at byte fm (index fm + 1): bytes below fm from p[i], the break, bytes above from one lower
+        s_ins[0] = make_uint2(0x06050403u, 0u);            // fm <= -1: the break came earlier, everything one byte up
+        s_ins[1] = make_uint2(0x0605040Cu, 0x0000000Au);   // fm == 0
+        s_ins[2] = make_uint2(0x06050C04u, 0x00000A00u);
+        s_ins[3] = make_uint2(0x060C0504u, 0x000A0000u);
+        s_ins[4] = make_uint2(0x0C060504u, 0x0A000000u);
+        s_ins[5] = make_uint2(0x07060504u, 0u);            // fm >= 4: the break comes later
+    }
+    __syncthreads();
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (g >= (UNI ? P.uni.n : t.n)) return;  // no block-level barrier below
+    WideRec R;
+    R.g = g;
+    if constexpr (UNI) {  // everything follows from the record number (UniformLayout) -- and is verified in the body
+        R.rstart = g * P.uni.S;
+        R.lh = P.uni.H;
+        R.T.p = buf + R.rstart + R.lh + 1;
+        R.T.L = P.uni.L;
+        R.T.W = P.uni.W;
+    } else {
+        if (P.long_thresh && t.l_seq[g] >= P.long_thresh) return;  // launch_translate_long handles this record
+        R.T = text_of(buf, t, tt, g);
+        R.rstart = t.start[g];
+        R.lh = t.l_head[g];
+    }
+    // everything the six elements need from memory is requested at once (a loop that fetched out_len / out_off / the
+    // header bytes frame by frame put six dependent round trips in front of every record: the waves of this kernel live
+    // for ~30 us, and most of that was waiting)
+    const uint64_t e0 = g * (uint64_t)P.nframes;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if constexpr (UNI) {
+            R.ne[k] = k < P.nframes ? P.uni.len[k] : 0u;
+            R.oe[k] = k < P.nframes ? g * P.uni.out_S + P.uni.off[k] : 0ull;
+        } else {
+            R.ne[k] = k < P.nframes ? out_len[e0 + k] : 0u;
+            R.oe[k] = k < P.nframes ? out_off[e0 + k] : 0ull;
+        }
+    }
+    translate_wide_record<G, UNI, false>(buf, buf_n, t, P, out_len, out_off, out, redo, redo_count, s_pair, s_iu, s_ins, R);
     (void)status;
 }
 
 
+// ---- round 5: `translate` on FASTA records that do NOT all look alike, in ONE pass over the input --------------------------
+// The table path reads the shard twice: k_fasta_starts looks for the '>' bytes (8.5 ms per 50 GB), then the wide kernel reads
+// the text again -- with k_fasta_heads and the size / scan launches in between, 57 ms at C4 against 43 ms for records that
+// all look alike.  Here persistent blocks take small line-start ranges of the input (64 KiB: what a block reads in phase A
+// is still in the caches when phase D reads it again) from a queue:
+//   A  the '>' at line starts of the range                                   (16 bytes per thread and step, SWAR compare)
+//   B  per record: header end and first line from its first bytes, the next record's start (the range's last record:
+//      a forward scan of the block), bases as "every line but the last is as long as the first" -- the rule of the
+//      light table, verified window by window in phase D -- and the bytes of its elements
+//   C  where the block's output begins: the blocks before it publish their totals in a chain of (flag, value) words as
+//      soon as phase B is done; a wave looks back 64 predecessors at a time (as k_rmdup_place)
+//   D  a wave per record: translate_wide_record<64, false, STREAM>
+// Anything that does not fit -- more records in a range than the list holds, a first line under 16 bases that is not the
+// only one, a record of a MiB, a window that fails its check, an output beyond the reserved capacity -- counts into
+// redo_count, and the host runs the call again on the table paths (and the context stays with them).
+constexpr uint32_t TS_MAXR = 256;
+// 16-bit mask of the bytes of v that equal the replicated byte `rep` (bit b = byte b)
+__device__ __forceinline__ uint32_t ts_eq_mask16(const uint4& v, uint32_t rep) {
+    auto z = [](uint32_t x) { const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu; };
+    return z(v.x ^ rep) | (z(v.y ^ rep) << 4) | (z(v.z ^ rep) << 8) | (z(v.w ^ rep) << 12);
+}
+constexpr uint64_t TS_FLAG_AGG = 1ull << 62, TS_FLAG_PREFIX = 2ull << 62, TS_VALUE = (1ull << 62) - 1ull;
+__device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ts_wave_sum(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+// bytes of the elements of a record with header line lh (marker included) and L bases
+__device__ __forceinline__ uint32_t ts_element_bytes(const TranslateParams& P, uint32_t lh, uint32_t L, int k) {
+    const uint32_t naa = num_aa(L, P.frames[k]);
+    return lh + 1u + naa + ((P.line_width > 0 && naa > 0) ? (naa - 1u) / (uint32_t)P.line_width : 0u) + 1u;
+}
+
+__global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uint8_t* __restrict__ buf, uint64_t buf_n,
+                                                          const uint64_t* __restrict__ anchors, uint32_t nranges,
+                                                          uint32_t* __restrict__ queue, TranslateParams P, uint8_t* __restrict__ out,
+                                                          uint64_t out_cap, uint64_t* __restrict__ chain, uint64_t* __restrict__ fin,
+                                                          uint64_t* __restrict__ redo_count, uint64_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_pair[16384];
+    __shared__ uint8_t s_iu[256];
+    __shared__ uint2 s_ins[6];
+    __shared__ uint64_t s_pos[TS_MAXR], s_start[TS_MAXR + 1], s_off[TS_MAXR];
+    __shared__ uint32_t s_lh[TS_MAXR], s_L[TS_MAXR], s_W[TS_MAXR];
+    __shared__ uint32_t s_n, s_r;
+    __shared__ unsigned long long s_next;
+    __shared__ uint64_t s_w[4], s_excl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(P.pair + 16 * (threadIdx.x + 256 * i));
+        *reinterpret_cast<uint4*>(s_pair + 16 * (threadIdx.x + 256 * i)) = v;
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_iu[i] = P.iupac[i];
+    if (threadIdx.x == 0) {
+        s_ins[0] = make_uint2(0x06050403u, 0u);
+        s_ins[1] = make_uint2(0x0605040Cu, 0x0000000Au);
+        s_ins[2] = make_uint2(0x06050C04u, 0x00000A00u);
+        s_ins[3] = make_uint2(0x060C0504u, 0x000A0000u);
+        s_ins[4] = make_uint2(0x0C060504u, 0x0A000000u);
+        s_ins[5] = make_uint2(0x07060504u, 0u);
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t n_eff = anchors[nranges];
+    const uint8_t* lim = buf + n_eff;
+    RecordTable t_none;  // (no table on this pass; the record body does not touch it: no -F, no -M)
+    memset(&t_none, 0, sizeof t_none);
+    for (;;) {
+        __syncthreads();  // (the lists of the range before are done with)
+        if (threadIdx.x == 0) { s_r = atomicAdd(queue, 1u); s_n = 0; s_next = ~0ull; }
+        __syncthreads();
+        const uint32_t r = s_r;
+        if (r >= nranges) break;
+        uint64_t rs = anchors[r], re = anchors[r + 1];
+        rs = rs < n_eff ? rs : n_eff;
+        re = re < n_eff ? re : n_eff;
+        if (r == 0 && threadIdx.x == 0 && n_eff && buf[0] != (uint8_t)'>') atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_BAD_HEADER);
+        // ---- A: record starts of the range
+        for (uint64_t at = rs + 16ull * threadIdx.x; at < re; at += 16ull * 256ull) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (at + 16 <= buf_n) __builtin_memcpy(&v, buf + at, 16);
+            else {
+                uint32_t wv[4] = {0, 0, 0, 0};
+                for (uint32_t b = 0; at + b < buf_n; ++b) wv[b >> 2] |= (uint32_t)buf[at + b] << ((b & 3u) * 8u);
+                v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+            uint32_t m = ts_eq_mask16(v, 0x3E3E3E3Eu);
+            if (re - at < 16) m &= (1u << (re - at)) - 1u;
+            while (m) {
+                const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                const uint64_t p = at + b;
+                if (p == 0 || buf[p - 1] == (uint8_t)'\n') {
+                    const uint32_t k = atomicAdd(&s_n, 1u);
+                    if (k < TS_MAXR) s_pos[k] = p;
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t nrec = s_n;
+        bool unfit = nrec > TS_MAXR;
+        if (unfit) nrec = 0;
+        // in file order (a rank sort: the list is a few dozen entries)
+        for (uint32_t i = threadIdx.x; i < nrec; i += 256u) {
+            const uint64_t p = s_pos[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nrec; ++j) rank += s_pos[j] < p;
+            s_start[rank] = p;
+        }
+        __syncthreads();
+        // ---- B: the start of the record behind the range's last one (it lies in a later range): the first '>' at a line
+        // start at or behind re
+        if (nrec) {
+            for (uint64_t base = re; base < n_eff; base += 16ull * 256ull) {
+                const uint64_t at = base + 16ull * threadIdx.x;
+                if (at < n_eff) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (at + 16 <= buf_n) __builtin_memcpy(&v, buf + at, 16);
+                    else {
+                        uint32_t wv[4] = {0, 0, 0, 0};
+                        for (uint32_t b = 0; at + b < buf_n; ++b) wv[b >> 2] |= (uint32_t)buf[at + b] << ((b & 3u) * 8u);
+                        v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                    }
+                    uint32_t m = ts_eq_mask16(v, 0x3E3E3E3Eu);
+                    if (n_eff - at < 16) m &= (1u << (n_eff - at)) - 1u;
+                    while (m) {
+                        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+                        m &= m - 1u;
+                        const uint64_t p = at + b;
+                        if (buf[p - 1] == (uint8_t)'\n') { atomicMin(&s_next, (unsigned long long)p); break; }
+                    }
+                }
+                __syncthreads();
+                const bool found = s_next != ~0ull;
+                __syncthreads();
+                if (found) break;
+            }
+            if (threadIdx.x == 0) s_start[nrec] = s_next != ~0ull ? (uint64_t)s_next : n_eff;
+        }
+        __syncthreads();
+        // header end, first line, bases (the rule of k_fasta_heads) and the bytes of the elements of every record
+        uint64_t mine = 0;
+        if (threadIdx.x < nrec) {
+            const uint64_t s0 = s_start[threadIdx.x], e0 = s_start[threadIdx.x + 1];
+            const uint64_t span = e0 - s0;
+            uint32_t lh = span > 0xFFFFFFFFull ? 0xFFFFFFFFu : find_byte_in(buf + s0, (uint32_t)span, '\n', lim);  // header line without its newline (== span: none)
+            const uint64_t region = span > (uint64_t)lh + 1 ? span - lh - 1 : 0;
+            uint32_t w = 0, lseq = 0, tw = 0;
+            bool bad = span > 0xFFFFFFFFull;
+            if (region && !bad) {
+                w = find_byte_in(buf + s0 + lh + 1, (uint32_t)region, '\n', lim);
+                const uint64_t R = (e0 == n_eff && buf[n_eff - 1] != (uint8_t)'\n') ? region + 1 : region;
+                if (R <= (uint64_t)w + 1) { lseq = w; tw = 0; }
+                else if (w < 16u) bad = true;
+                else {
+                    const uint64_t qn = R / ((uint64_t)w + 1), rem = R % ((uint64_t)w + 1);
+                    lseq = (uint32_t)(qn * w + (rem ? rem - 1 : 0));
+                    tw = w;
+                }
+            }
+            if (P.long_thresh && lseq >= P.long_thresh) bad = true;  // a chromosome: whole blocks translate it (table path)
+            s_lh[threadIdx.x] = lh;
+            s_L[threadIdx.x] = lseq;
+            s_W[threadIdx.x] = tw;
+            if (bad) atomicAdd((unsigned long long*)redo_count, 1ull);
+            else
+                for (int k = 0; k < P.nframes; ++k) mine += ts_element_bytes(P, lh, lseq, k);
+        }
+        if (unfit && threadIdx.x == 0) atomicAdd((unsigned long long*)redo_count, 1ull);
+        // ---- C: output offsets -- block scan, then the chain over the ranges
+        uint64_t x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+            if ((int)lane >= d) x += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        if (wave == 0) {
+            const uint64_t total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (lane == 0) ts_store(chain + r, (r == 0 ? TS_FLAG_PREFIX : TS_FLAG_AGG) | total);
+            uint64_t excl = 0;
+            if (r > 0) {
+                int64_t j = (int64_t)r - 1 - (int64_t)lane;
+                for (;;) {
+                    uint64_t v = j >= 0 ? ts_load(chain + j) : TS_FLAG_PREFIX;
+                    while (__ballot((v >> 62) == 0ull) != 0ull) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((v >> 62) == 0ull) v = ts_load(chain + j);
+                    }
+                    const uint64_t pm = __ballot((v >> 62) == 2ull);
+                    if (pm) {
+                        const uint32_t fl = (uint32_t)__ffsll((long long)pm) - 1u;
+                        excl += ts_wave_sum(lane <= fl ? (v & TS_VALUE) : 0ull);
+                        break;
+                    }
+                    excl += ts_wave_sum(v & TS_VALUE);
+                    j -= 64;
+                }
+                if (lane == 0) ts_store(chain + r, TS_FLAG_PREFIX | (excl + total));
+            }
+            if (lane == 0) {
+                s_excl = excl;
+                if (nrec) atomicAdd((unsigned long long*)&fin[1], (unsigned long long)nrec);
+                if (r + 1 == nranges) fin[0] = excl + total;  // the whole output
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nrec) {
+            uint64_t off = s_excl + x - mine;
+            for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_w[w2];
+            s_off[threadIdx.x] = off;
+            if (off + mine > out_cap) { s_L[threadIdx.x] = 0xFFFFFFFFu; atomicAdd((unsigned long long*)redo_count, 1ull); }  // (never written)
+        }
+        __syncthreads();
+        // ---- D: a wave per record
+        for (uint32_t i = wave; i < nrec; i += 4u) {
+            const uint32_t L = s_L[i];
+            if (L == 0xFFFFFFFFu) continue;
+            WideRec R;
+            R.g = 0;
+            R.rstart = s_start[i];
+            R.lh = s_lh[i];
+            R.T.p = buf + R.rstart + R.lh + 1;
+            R.T.L = L;
+            R.T.W = s_W[i];
+            uint64_t o = s_off[i];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t nk = k < P.nframes ? ts_element_bytes(P, R.lh, L, k) : 0u;
+                R.ne[k] = nk;
+                R.oe[k] = o;
+                o += nk;
+            }
+            translate_wide_record<64, false, true>(buf, buf_n, t_none, P, nullptr, nullptr, out, nullptr, redo_count, s_pair, s_iu, s_ins, R);
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_translate_stream(int blocks, const uint8_t* buf, uint64_t buf_n, const uint64_t* anchors, uint32_t nranges, uint32_t* queue,
+                                   const TranslateParams& P, uint8_t* out, uint64_t out_cap, uint64_t* chain, uint64_t* fin,
+                                   uint64_t* redo_count, uint64_t* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_translate_stream, dim3(blocks), dim3(256), 0, st, buf, buf_n, anchors, nranges, queue, P, out, out_cap, chain, fin,
+                       redo_count, status);
+    return hipGetLastError();
+}
+int translate_stream_max_blocks_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_translate_stream, 256, 0) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
 
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                  const TranslateParams& P, uint32_t* out_len, uint64_t* status, hipStream_t st) {

@@ -62,6 +62,14 @@ struct TranslateParams {  // Translate options after Before() (bigseqkit-lib/tra
 
 constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
 
+// round 5: FASTA records that do not all look alike, in ONE pass -- record starts, sizes, output offsets (a chain over the
+// ranges) and the translation itself by persistent blocks over small line-start ranges (anchors / queue from launch_prep in
+// line mode).  chain: nranges words, fin[0..1] and *redo_count zeroed by the caller; fin[0] = bytes written, fin[1] = records,
+// *redo_count != 0: something did not fit, the output is to be discarded and the table paths take the call
+hipError_t launch_translate_stream(int blocks, const uint8_t* buf, uint64_t buf_n, const uint64_t* anchors, uint32_t nranges, uint32_t* queue,
+                                   const TranslateParams& P, uint8_t* out, uint64_t out_cap, uint64_t* chain, uint64_t* fin,
+                                   uint64_t* redo_count, uint64_t* status, hipStream_t st);
+int translate_stream_max_blocks_per_cu();
 // elements are numbered record * nframes + f
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                  const TranslateParams& P, uint32_t* out_len, uint64_t* status, hipStream_t st);
