@@ -592,8 +592,12 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         mean_s, min_s, kern, ok,
         "output == the same torch translation, records gathered by shape class (header digits x length) from offsets that are "
         "prefix sums of the record sizes, every record compared",
-        {"layout_path": "table: the head sample's records differ, UniformLayout is refused ('k_translate_uniform' is %s the stages of "
-                        "this call)" % ("NOT among" if "k_translate_uniform" not in kern else "AMONG"), "shape_classes_checked": nclass})
+        {"layout_path": "%s: the head sample's records differ, UniformLayout is refused ('k_translate_uniform' is %s the stages of "
+                        "this call)" % ("one pass over the file that finds the records, places them through a look-back and writes "
+                                        "their frames ('k_translate_stream'), no record table"
+                                        if "k_translate_stream" in kern else "record table, then the translate kernel",
+                                        "NOT among" if "k_translate_uniform" not in kern else "AMONG"),
+         "shape_classes_checked": nclass})
     del got, t, idx, dig, Ls, in_sz, in_off, out_sz, out_off
     op.close()
     torch.cuda.empty_cache()

@@ -29,7 +29,7 @@ struct bsk_tuning {
     static const char* const* names() {
         static const char* const N[] = {"filter", "grep_shiftand", "index", "locate_nopre", "long_bytes", "min_range_bytes", "names",
                                         "names_scale", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_keys", "rmdup_place", "scan", "segcopy",
-                                        "sort", "stage_bytes", "stats_a", "stats_fasta", "subseq", "subseq_scale", "text", "translate", "translate_index", "tr_lanes", nullptr};
+                                        "sort", "stage_bytes", "stats_a", "stats_fasta", "subseq", "subseq_scale", "text", "translate", "translate_index", "translate_stream", "tr_lanes", nullptr};
         return N;
     }
     std::map<std::string, std::string> v;
@@ -170,6 +170,7 @@ struct bsk_ctx {
     std::vector<int> frames;
     bool codon_ready = false;        // d_codon holds the tables of this context's options
     bool translate_uniform_ok = true;  // FASTA: try the table-free pass on records that all look alike first (UniformLayout)
+    bool translate_stream_ok = true;  // FASTA of long records: try the one-pass translation (k_translate_stream) before any table
     bool translate_light_ok = true;  // FASTA: try the record table from the '>' bytes alone first (stream_fasta_light.hip)
     uint8_t* d_redo = nullptr;    // one byte per record: left by k_translate_wide to k_translate_frames4
     uint64_t redo_cap = 0;

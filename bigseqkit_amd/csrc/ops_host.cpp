@@ -164,9 +164,10 @@ int build_index(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStrea
 // FASTA ranges begin on line starts (a chromosome spans many ranges); the records that cross range boundaries are
 // completed by k_index_stitch from the per-range parts
 int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, int blocks, hipStream_t st, uint32_t* nranges_out,
-                       uint64_t* chunk_out) {
+                       uint64_t* chunk_out, uint64_t force_chunk) {
     const uint64_t waves = (uint64_t)blocks * 4;
-    const uint64_t nr = pick_nranges(n, waves, c->min_range_bytes, (int)c->tune.num("ranges_per_wave"));
+    uint64_t nr = pick_nranges(n, waves, c->min_range_bytes, (int)c->tune.num("ranges_per_wave"));
+    if (force_chunk) nr = std::min<uint64_t>(std::max<uint64_t>(1, (n + force_chunk - 1) / force_chunk), 0x7FFFFFF0ull);
     const uint32_t nranges = (uint32_t)nr;
     uint64_t chunk = (n + nranges - 1) / nranges;
     chunk = (chunk + 15) & ~(uint64_t)15;

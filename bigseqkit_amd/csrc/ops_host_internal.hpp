@@ -99,8 +99,9 @@ bool has_unquoted_comma(const std::string& p);
 extern const char* const HELP_UNQUOTED_COMMA;
 void parse_region_opt(const std::string& region, const char* cmd, int* start, int* end);  // reRegion + the range checks of Before()
 // ranges of the streaming kernels for a shard: anchors in c->d_anchors (k_prep), the work queue behind them
+// force_chunk != 0: ranges of that nominal size (a multiple of 16) instead of the number pick_nranges chooses
 int prep_ranges(bsk_ctx* c, const uint8_t* d_buf, size_t n, bool fastq, int blocks, hipStream_t st, uint32_t* nranges_out,
-                uint64_t* chunk_out);
+                uint64_t* chunk_out, uint64_t force_chunk = 0);
 const char* alphabet_letters(Alphabet a);
 void complement_table(Alphabet ab, uint8_t m[256]);
 // lines of a text file ("\r\n" trimmed, empty lines skipped): pattern files, region files

@@ -328,6 +328,71 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
         }
     }
 
+    // ---- FASTA of long records that do NOT all look alike (round 5): one pass -- record starts, sizes, output offsets and the
+    // translation itself (k_translate_stream), every window verified; anything that does not fit and the call goes on below
+    // with the tables, and the context stays with them.  translate_stream = off skips it, = force takes it for short records too.
+    if (format == BSK_FORMAT_FASTA && n > 0 && c->translate_stream_ok && !c->tune.get("translate_index") && !c->tune.get("translate") &&
+        !c->tune.is("translate_stream", "off") && !P.init_m && !P.trim && !P.append_frame && !c->id_custom && (P.line_width == 0 || P.line_width >= 16)) {
+        rc = sample_head(c, d_buf, n, st);
+        if (rc != BSK_OK) return rc;
+        uint64_t heads = 1;
+        for (size_t i = 0; i + 1 < c->head_len; ++i) heads += (c->h_head[i] == '\n' && c->h_head[i + 1] == '>');
+        const uint64_t avg = c->head_len / heads;
+        if (avg >= 1500 || c->tune.is("translate_stream", "force")) {   // (a wave per record: from ~3 k bases; shorter records take 4 / 16 lanes)
+            Alphabet ab = partition_alphabet(c, d_buf, n, format, st, &rc);
+            if (rc != BSK_OK) return rc;
+            if (!(ab == AB_DNA || ab == AB_DNAredundant || ab == AB_RNA || ab == AB_RNAredundant)) {  // translate.go:116-122
+                c->set_error("command 'seqkit translate' only apply to DNA/RNA sequences");
+                return BSK_ERR_FORMAT;
+            }
+            const int blocks = std::max(1, c->num_cus * translate_stream_max_blocks_per_cu());
+            uint32_t nranges = 0;
+            uint64_t chunk = 0;
+            // ranges of ~200 records (the lists of a block hold 512), between 256 KiB and 2 MiB: the per-range phases of the pass
+            // cost what they cost per RANGE (64 KiB: 76 ms at C4, 512 KiB: 55, 1 MiB: 51 -- scripts/history/r05_trstream.sh);
+            // min_range_bytes pins the size (tests: ranges of 4 KiB)
+            uint64_t want_chunk = std::min<uint64_t>(2ull << 20, std::max<uint64_t>(256ull << 10, avg * 200));
+            if (c->tune.num("min_range_bytes", 0) > 0) want_chunk = (uint64_t)c->tune.num("min_range_bytes", 0);
+            want_chunk = std::max<uint64_t>(16, want_chunk & ~15ull);
+            rc = prep_ranges(c, d_buf, n, false, blocks, st, &nranges, &chunk, want_chunk);
+            if (rc != BSK_OK) return rc;
+            uint32_t* queue = reinterpret_cast<uint32_t*>(c->d_anchors + (size_t)nranges + 1);
+            // six frames of L bases are 2 L residues + their line breaks + six headers: the reserved room is checked per record
+            const uint64_t out_cap = (uint64_t)n * (uint64_t)std::max(1, P.nframes) * 3 / 8 + (64ull << 20);
+            rc = ensure_out(c, out_cap);
+            if (rc != BSK_OK) return rc;
+            rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, (uint64_t)nranges + 8, 64);
+            if (rc != BSK_OK) return rc;
+            HIP_TRYX(c, hipMemsetAsync(c->d_scan_tmp, 0, ((size_t)nranges + 1) * sizeof(uint64_t), st));
+            HIP_TRYX(c, hipMemsetAsync(c->d_fin, 0, 2 * sizeof(uint64_t), st));
+            uint64_t* d_redo_count = c->d_fin + bsk_ctx::FIN_AUX0;
+            HIP_TRYX(c, hipMemsetAsync(d_redo_count, 0, sizeof(uint64_t), st));
+            {
+                const char* e = c->tune.get("long_bytes");
+                P.long_thresh = e && atoll(e) > 0 ? (uint32_t)atoll(e) : SEQ_LONG_THRESH;
+            }
+            {
+                Timed t(c, "k_translate_stream", st);
+                HIP_TRYX(c, launch_translate_stream(blocks, d_buf, n, c->d_anchors, nranges, queue, P, c->d_out, out_cap, c->d_scan_tmp, c->d_fin,
+                                                    d_redo_count, c->d_status, st));
+            }
+            P.long_thresh = 0;
+            rc = ctl_readback(c, st);
+            if (rc != BSK_OK) return rc;
+            if (c->fin(bsk_ctx::FIN_AUX0) == 0) {
+                rc = kernel_error_to_status(c, c->status_word());
+                if (rc != BSK_OK) return rc;
+                c->table.n = 0;  // no record table was built for this shard
+                out->d_data = c->d_out;
+                out->len = c->fin(bsk_ctx::FIN_TOTAL);
+                out->records = c->fin(bsk_ctx::FIN_KEPT) * (uint64_t)P.nframes;
+                return BSK_OK;
+            }
+            c->translate_stream_ok = false;  // something did not fit: the table paths, from now on
+            HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
+        }
+    }
+
     // FASTA: first with the record table from the '>' bytes alone (stream_fasta_light.hip) -- k_translate_wide validates the
     // whole text against the layout that table assumes; whatever does not fit (a record flagged by the wide kernel, a
     // chromosome-sized one, ...) sends the call through the full index pass below, and the context remembers it

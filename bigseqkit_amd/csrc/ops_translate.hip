@@ -1405,12 +1405,13 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_wide(const uint8
 // Anything that does not fit -- more records in a range than the list holds, a first line under 16 bases that is not the
 // only one, a record of a MiB, a window that fails its check, an output beyond the reserved capacity -- counts into
 // redo_count, and the host runs the call again on the table paths (and the context stays with them).
-constexpr uint32_t TS_MAXR = 256;
+constexpr uint32_t TS_MAXR = 512;   // records per range the lists hold (512 KiB ranges of records from 1.5 kB: the host's gate)
 // 16-bit mask of the bytes of v that equal the replicated byte `rep` (bit b = byte b)
 __device__ __forceinline__ uint32_t ts_eq_mask16(const uint4& v, uint32_t rep) {
     auto z = [](uint32_t x) { const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu; };
     return z(v.x ^ rep) | (z(v.y ^ rep) << 4) | (z(v.z ^ rep) << 8) | (z(v.w ^ rep) << 12);
 }
+constexpr uint32_t TS_PER = TS_MAXR / 256u;
 constexpr uint64_t TS_FLAG_AGG = 1ull << 62, TS_FLAG_PREFIX = 2ull << 62, TS_VALUE = (1ull << 62) - 1ull;
 __device__ __forceinline__ uint64_t ts_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ts_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1428,7 +1429,10 @@ __device__ __forceinline__ uint32_t ts_element_bytes(const TranslateParams& P, u
     return lh + 1u + naa + ((P.line_width > 0 && naa > 0) ? (naa - 1u) / (uint32_t)P.line_width : 0u) + 1u;
 }
 
-__global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uint8_t* __restrict__ buf, uint64_t buf_n,
+#ifndef BSK_TRS_WAVES
+#define BSK_TRS_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSK_TRS_WAVES, 8))) void k_translate_stream(const uint8_t* __restrict__ buf, uint64_t buf_n,
                                                           const uint64_t* __restrict__ anchors, uint32_t nranges,
                                                           uint32_t* __restrict__ queue, TranslateParams P, uint8_t* __restrict__ out,
                                                           uint64_t out_cap, uint64_t* __restrict__ chain, uint64_t* __restrict__ fin,
@@ -1437,7 +1441,7 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uin
     __shared__ uint8_t s_iu[256];
     __shared__ uint2 s_ins[6];
     __shared__ uint64_t s_pos[TS_MAXR], s_start[TS_MAXR + 1], s_off[TS_MAXR];
-    __shared__ uint32_t s_lh[TS_MAXR], s_L[TS_MAXR], s_W[TS_MAXR];
+    __shared__ uint32_t s_lh[TS_MAXR], s_L[TS_MAXR], s_W[TS_MAXR], s_sz[TS_MAXR];
     __shared__ uint32_t s_n, s_r;
     __shared__ unsigned long long s_next;
     __shared__ uint64_t s_w[4], s_excl;
@@ -1470,26 +1474,45 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uin
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (r == 0 && threadIdx.x == 0 && n_eff && buf[0] != (uint8_t)'>') atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_BAD_HEADER);
-        // ---- A: record starts of the range
-        for (uint64_t at = rs + 16ull * threadIdx.x; at < re; at += 16ull * 256ull) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (at + 16 <= buf_n) __builtin_memcpy(&v, buf + at, 16);
-            else {
-                uint32_t wv[4] = {0, 0, 0, 0};
-                for (uint32_t b = 0; at + b < buf_n; ++b) wv[b >> 2] |= (uint32_t)buf[at + b] << ((b & 3u) * 8u);
-                v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-            }
-            uint32_t m = ts_eq_mask16(v, 0x3E3E3E3Eu);
-            if (re - at < 16) m &= (1u << (re - at)) - 1u;
-            while (m) {
-                const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
-                m &= m - 1u;
-                const uint64_t p = at + b;
-                if (p == 0 || buf[p - 1] == (uint8_t)'\n') {
-                    const uint32_t k = atomicAdd(&s_n, 1u);
-                    if (k < TS_MAXR) s_pos[k] = p;
+        // ---- A: record starts of the range (four loads in flight per thread: one at a time, the 128 steps of a 512 KiB range
+        // cost a memory round trip each -- 15 % of the pass; eight in flight now)
+        {
+            auto take = [&](uint64_t at, const uint4& v) {
+                // (sequence text is letters: a piece without a byte below 0x3F holds no '>' -- 3 in 4 pieces stop here)
+                const uint32_t h = (((v.x - 0x3F3F3F3Fu) & ~v.x) | ((v.y - 0x3F3F3F3Fu) & ~v.y) | ((v.z - 0x3F3F3F3Fu) & ~v.z) | ((v.w - 0x3F3F3F3Fu) & ~v.w)) & 0x80808080u;
+                if (h == 0u) return;
+                uint32_t m = ts_eq_mask16(v, 0x3E3E3E3Eu);
+                if (re - at < 16) m &= (1u << (re - at)) - 1u;
+                while (m) {
+                    const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+                    m &= m - 1u;
+                    const uint64_t p = at + b;
+                    if (p == 0 || buf[p - 1] == (uint8_t)'\n') {
+                        const uint32_t k = atomicAdd(&s_n, 1u);
+                        if (k < TS_MAXR) s_pos[k] = p;
+                    }
                 }
+            };
+            auto load = [&](uint64_t at) -> uint4 {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (at + 16 <= buf_n) __builtin_memcpy(&v, buf + at, 16);
+                else {
+                    uint32_t wv[4] = {0, 0, 0, 0};
+                    for (uint32_t b = 0; at + b < buf_n; ++b) wv[b >> 2] |= (uint32_t)buf[at + b] << ((b & 3u) * 8u);
+                    v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                }
+                return v;
+            };
+            constexpr uint64_t STRIDE = 16ull * 256ull;
+            uint64_t at = rs + 16ull * threadIdx.x;
+            for (; at + 7 * STRIDE < re; at += 8 * STRIDE) {
+                uint4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = load(at + (uint64_t)k * STRIDE);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) take(at + (uint64_t)k * STRIDE, v[k]);
             }
+            for (; at < re; at += STRIDE) take(at, load(at));
         }
         __syncthreads();
         uint32_t nrec = s_n;
@@ -1535,8 +1558,9 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uin
         __syncthreads();
         // header end, first line, bases (the rule of k_fasta_heads) and the bytes of the elements of every record
         uint64_t mine = 0;
-        if (threadIdx.x < nrec) {
-            const uint64_t s0 = s_start[threadIdx.x], e0 = s_start[threadIdx.x + 1];
+        // (a thread takes TS_PER NEIGHBOURING records: the block scan below then is a scan over the records in file order)
+        for (uint32_t i = threadIdx.x * TS_PER; i < nrec && i < (threadIdx.x + 1u) * TS_PER; ++i) {
+            const uint64_t s0 = s_start[i], e0 = s_start[i + 1];
             const uint64_t span = e0 - s0;
             uint32_t lh = span > 0xFFFFFFFFull ? 0xFFFFFFFFu : find_byte_in(buf + s0, (uint32_t)span, '\n', lim);  // header line without its newline (== span: none)
             const uint64_t region = span > (uint64_t)lh + 1 ? span - lh - 1 : 0;
@@ -1554,12 +1578,15 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uin
                 }
             }
             if (P.long_thresh && lseq >= P.long_thresh) bad = true;  // a chromosome: whole blocks translate it (table path)
-            s_lh[threadIdx.x] = lh;
-            s_L[threadIdx.x] = lseq;
-            s_W[threadIdx.x] = tw;
+            s_lh[i] = lh;
+            s_L[i] = lseq;
+            s_W[i] = tw;
+            uint32_t bytes = 0;
             if (bad) atomicAdd((unsigned long long*)redo_count, 1ull);
             else
-                for (int k = 0; k < P.nframes; ++k) mine += ts_element_bytes(P, lh, lseq, k);
+                for (int k = 0; k < P.nframes; ++k) bytes += ts_element_bytes(P, lh, lseq, k);
+            s_sz[i] = bytes;
+            mine += bytes;
         }
         if (unfit && threadIdx.x == 0) atomicAdd((unsigned long long*)redo_count, 1ull);
         // ---- C: output offsets -- block scan, then the chain over the ranges
@@ -1601,11 +1628,14 @@ __global__ __launch_bounds__(256) BSK_TRW_ATTR void k_translate_stream(const uin
             }
         }
         __syncthreads();
-        if (threadIdx.x < nrec) {
+        {
             uint64_t off = s_excl + x - mine;
             for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_w[w2];
-            s_off[threadIdx.x] = off;
-            if (off + mine > out_cap) { s_L[threadIdx.x] = 0xFFFFFFFFu; atomicAdd((unsigned long long*)redo_count, 1ull); }  // (never written)
+            for (uint32_t i = threadIdx.x * TS_PER; i < nrec && i < (threadIdx.x + 1u) * TS_PER; ++i) {
+                s_off[i] = off;
+                off += s_sz[i];
+                if (off > out_cap) { s_L[i] = 0xFFFFFFFFu; atomicAdd((unsigned long long*)redo_count, 1ull); }  // (never written)
+            }
         }
         __syncthreads();
         // ---- D: a wave per record

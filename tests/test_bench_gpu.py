@@ -94,6 +94,7 @@ def test_bench_ops_object_small():
     assert "k_translate_uniform" in t["kernels_ms_per_call"]       # the C4 layout needs no table
     tv = ops["translate -f 6 @ C4, records that differ"]           # ... records that differ do
     assert "k_translate_uniform" not in tv["kernels_ms_per_call"] and tv["out_records"] == 6 * tv["records"] and tv["shape_classes_checked"] >= 3
+    assert "k_translate_stream" in tv["kernels_ms_per_call"]       # found, placed and written in one pass over the file
     for name in stats_legs:                                        # FASTA `stats` (the pass of stream_fasta2_dev.hpp), exact maps
         assert "k_stats" in ops[name]["kernels_ms_per_call"] and 0 < ops[name]["kernel_frac"] < 1, ops[name]
     # the byte-comparing default (one pass: comparison + placement) and the two-key mode beside it
