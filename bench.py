@@ -308,8 +308,59 @@ def run_end_to_end(H, gb=8.0):
         res["grep -s -p (host bytes -> 4 part files in %s, 4 contexts at once)" % base] = {
             "s": round(dt, 4), "in_GB_per_s": round(n / dt / 1e9, 2), "out_bytes": ob, "M_records_per_s": round(nrec / dt / 1e6, 1),
             "exact": orec == want_hits and ob == REC * want_hits and disk == ob}
+        res.update(file_to_result(base, h, n, nrec, want_hits))
     finally:
         lib.bsk_host_free(C.c_void_p(h))
+    return res
+
+
+def file_to_result(base, h, n, nrec, want_hits):
+    """FILE -> result through the native driver `bigseqkit_amd/bin/bigseqkit <cmd> <file> --devices 0`: a fresh
+    process per call (exec, HIP + RCCL start-up, the file's bytes from the page cache into pinned memory, copy to the GPU,
+    kernels, the answer on stdout / in a file).  The input is the same sample, written to `base` first (not timed)."""
+    import subprocess
+    cli = os.path.join(ROOT, "bigseqkit_amd", "bin", "bigseqkit")
+    if not os.path.exists(cli):
+        return {"file -> result": {"error": "bigseqkit_amd/bin/bigseqkit is not built"}}
+    src = os.path.join(base, "bsk_bench_in_%d.fastq" % os.getpid())
+    dst = os.path.join(base, "bsk_bench_out_%d" % os.getpid())
+    res = {}
+    try:
+        view = memoryview((C.c_char * n).from_address(h)).cast("B")
+        with open(src, "wb", buffering=0) as f:
+            at = 0
+            while at < n:
+                at += f.write(view[at:at + (256 << 20)])
+
+        def run(args):
+            best, outp = None, b""
+            for _ in range(2):
+                t0 = time.perf_counter()
+                p = subprocess.run([cli] + args, capture_output=True, timeout=600, env=dict(os.environ, TMPDIR=base))
+                dt = time.perf_counter() - t0
+                if p.returncode != 0:
+                    raise RuntimeError("%s: rc %d: %s" % (" ".join(args), p.returncode, p.stderr.decode(errors="replace")[-300:]))
+                best, outp = (dt if best is None else min(best, dt)), p.stdout
+            return best, outp
+        dt, outp = run(["stats", "-T", src, "--devices", "0"])
+        row = outp.decode().strip().split("\n")[-1].split("\t")
+        res["stats (file in %s -> row on stdout; fresh process)" % base] = {
+            "s": round(dt, 4), "GB_per_s": round(n / dt / 1e9, 2), "M_records_per_s": round(nrec / dt / 1e6, 1),
+            "exact": len(row) > 4 and row[3].replace(",", "") == str(nrec) and row[4].replace(",", "") == str(150 * nrec)}
+        dt, outp = run(["grep", "-s", "-p", "ACGTTGCAAGCT", src, "-o", dst, "--merge", "--devices", "0"])
+        ob = os.path.getsize(dst) if os.path.isfile(dst) else -1
+        res["grep -s -p (file in %s -> one file; fresh process)" % base] = {
+            "s": round(dt, 4), "in_GB_per_s": round(n / dt / 1e9, 2), "out_bytes": ob, "M_records_per_s": round(nrec / dt / 1e6, 1),
+            "exact": ob == REC * want_hits}
+    except Exception as e:
+        res["file -> result"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    finally:
+        import shutil
+        for q in (src, dst):
+            if os.path.isdir(q):
+                shutil.rmtree(q, ignore_errors=True)
+            elif os.path.exists(q):
+                os.unlink(q)
     return res
 
 

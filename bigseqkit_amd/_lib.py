@@ -157,6 +157,7 @@ SIGNATURES = {
     "bsk_count_allreduce": (_i, [_vp, _p(_u64), _vp]),
     "bsk_stats_collect_reduced": (_i, [_vp, _vp, _vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_rmdup_dist_run": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _p(Out)]),
+    "bsk_shard_load": (_i, [_i, _u64, _sz, _i, _i, C.POINTER(_vp)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_offset": (_u64, [_i, _u64]),
     "bsk_synth_host": (_i, [_i, _u64, C.c_uint, _u64, _vp, _sz]),

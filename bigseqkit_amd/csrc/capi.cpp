@@ -139,6 +139,10 @@ std::vector<uint8_t> first_record_seq(const std::vector<uint8_t>& b, int format,
 
 }  // namespace
 
+namespace bsk {
+int global_error_set(int code, const std::string& m) { return fail_global(code, m); }
+}
+
 extern "C" {
 
 int bsk_version(void) { return 100; }

@@ -298,6 +298,11 @@ int bsk_comm_init_all(int ndev, const int* devices, bsk_comm** out) {
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return global_fail(BSK_ERR_NO_DEVICE, "libbsk: no HIP device visible");
     for (int a = 0; a < ndev; ++a)
         if (devices[a] < 0 || devices[a] >= have) return global_fail(BSK_ERR_NO_DEVICE, "libbsk: device " + std::to_string(devices[a]) + " is not visible");
+    // ONE worker has nobody to talk to: its collectives are copies, and loading librccl + ncclCommInitAll costs 1.7 s of a
+    // command that runs for 0.7 s (scripts/history/r05_cli_timing.sh).  BSK_COMM=rccl keeps the one-rank RCCL communicator
+    // (the tests: every collective of the N-rank path through librccl on the one GPU of the test box).
+    const char* want = getenv("BSK_COMM");
+    if (ndev == 1 && !(want && !strcmp(want, "rccl"))) distinct = false;
     if (distinct) {  // RCCL over xGMI: one communicator per device, all in this process
         if (!rccl()->handle) return global_fail(BSK_ERR_UNSUPPORTED, rccl()->error);
         std::vector<ncclComm_t> comms((size_t)ndev, nullptr);

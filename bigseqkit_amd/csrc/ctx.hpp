@@ -358,3 +358,7 @@ inline uint64_t pick_nranges(uint64_t n, uint64_t waves, uint64_t min_range_byte
     return std::max<uint64_t>(1, nr);
 }
 
+// the caller thread's error text (bsk_global_error) for entry points that have no context (capi.cpp)
+namespace bsk {
+int global_error_set(int code, const std::string& m);
+}

@@ -32,6 +32,8 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+
 #include "../include/bsk.h"
 #include "../bigseqkit_amd/csrc/json.hpp"
 
@@ -669,13 +671,25 @@ void store(const Invocation& inv, const Output& out, const std::vector<std::stri
 // tree (until round 4 this flag exec'd `python -m bigseqkit_amd.run`, which stays as the test harness of the Python side).
 //   * the FILE is cut, not copied: it is mapped, every cut is the first record start at or behind size * k / world, found in
 //     a 1 MiB window of the mapping (bsk_find_record_start: the ReadFixer rule; the window grows while it ends on a record
-//     that may be cut off), and every worker reads only its own byte range into pinned host memory;
-//   * seq / grep / locate / subseq / translate / fq2fa: bsk_run_to_store (H2D || kernels || D2H + write) into
+//     that may be cut off), and every worker brings only its own byte range to its GPU (bsk_shard_load: several readers,
+//     pread || H2D in 16 MiB pieces);
+//   * seq / grep / locate / subseq / translate / fq2fa: one call over the device-resident shard + bsk_store_put (D2H ||
+//     write), or for shards over 48 GB bsk_run_to_store (pinned shard; H2D || kernels || D2H + write in chunks), into
 //     <out>/part%05d, one per worker (StoreFASTXN) or, with --merge, into ONE file at offsets from an all-gather of the
 //     sizes (the reference passes an MPI token, bigseqkit-lib/helper.go:399-429);
 //   * stats: bsk_stats_collect_reduced (StatsReduce: one ncclAllReduce of the stats vector), worker 0 prints the table;
 //   * grep -C: bsk_count_allreduce;   rmdup: bsk_rmdup_dist_run (the 24-byte tuple exchange of GroupByKey).
 // ---------------------------------------------------------------------------
+// BSK_CLI_TIMING=1: where the wall clock of a --devices call goes (stderr)
+void mark(const char* what, int rank = -1) {
+    static const bool on = getenv("BSK_CLI_TIMING") != nullptr;
+    static const auto t0 = std::chrono::steady_clock::now();
+    if (!on) return;
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rank < 0) fprintf(stderr, "[timing] %8.3f s  %s\n", s, what);
+    else fprintf(stderr, "[timing] %8.3f s  worker %d: %s\n", s, rank, what);
+}
+
 std::vector<int> parse_devices(const std::string& text) {
     std::vector<int> out;
     size_t i = 0;
@@ -742,6 +756,7 @@ int run_devices(const Invocation& inv) {
     if (inv.files.size() != 1) die("--devices: exactly one input file (it is cut into one shard per GPU)");
     const std::vector<int> devices = parse_devices(inv.pget("devices"));
     const int world = (int)devices.size();
+    mark("start");
     if (bsk_device_count() <= 0) die("no HIP device visible (the hot path has no CPU fallback)");
     const std::string& path = inv.files[0];
     const int fd = open(path.c_str(), O_RDONLY);
@@ -757,6 +772,7 @@ int run_devices(const Invocation& inv) {
     const int fmt = sniff_format(path, size ? std::string((const char*)map, 1) : std::string());
     const std::vector<size_t> cuts = size ? cut_points(map, size, world, fmt) : std::vector<size_t>((size_t)world + 1, 0);
     if (map) munmap((void*)map, size);
+    mark("device count + cut points");
     // RCCL greets on file descriptor 1 (its version banner, when a communicator is first used) -- and stdout is where
     // `stats`, `grep -C` and `-o -` put their RESULT.  For the rest of this call descriptor 1 IS stderr; results go to the
     // real stdout through a duplicate of it.
@@ -765,6 +781,7 @@ int run_devices(const Invocation& inv) {
     if (real_out < 0 || dup2(2, 1) < 0) die("cannot duplicate the standard output");
     std::vector<bsk_comm*> comms((size_t)world, nullptr);
     if (bsk_comm_init_all(world, devices.data(), comms.data()) != BSK_OK) die(bsk_comm_error(nullptr));
+    mark("communicators");
 
     std::string out_file = inv.pget("out-file");
     if (out_file.empty()) out_file = path + "-out";
@@ -786,6 +803,10 @@ int run_devices(const Invocation& inv) {
     }
     std::vector<Worker> W((size_t)world);
     std::atomic<int> failed{0};
+    // shard + output + tables of a record operator next to each other in 288 GB: shards up to 48 GB (translate -f 6 writes
+    // twice its input); BSK_HOST_PIPELINE_FROM moves the line (tests: 0 = always the chunked host pipeline)
+    size_t host_pipeline_from = (size_t)48 << 30;
+    if (const char* e = getenv("BSK_HOST_PIPELINE_FROM")) host_pipeline_from = (size_t)strtoull(e, nullptr, 10);
 
     auto work = [&](int rank) {
         Worker& me = W[(size_t)rank];
@@ -793,13 +814,22 @@ int run_devices(const Invocation& inv) {
         const int device = devices[(size_t)rank];
         const size_t lo = cuts[(size_t)rank], n = cuts[(size_t)rank + 1] - lo;
         bsk_ctx* ctx = nullptr;
-        void* h = nullptr;
         void* d_shard = nullptr;
+        void* h = nullptr;
+        const bool via_host = streamed && n > host_pipeline_from;
         bsk_store* own = nullptr;
         auto give_up = [&](const std::string& m) { if (me.error.empty()) me.error = m.empty() ? "failed" : m; failed.fetch_add(1); };
         do {
             if (bsk_create(inv.cmd->op, inv.js.c_str(), device, &ctx) != BSK_OK) { give_up(bsk_global_error()); break; }
-            // this worker's bytes, and only they, into pinned host memory
+            mark("context", rank);
+            // this worker's bytes, and only they: from the file to the device in pieces, several readers (bsk_shard_load).
+            // A record operator whose shard AND output may not fit the GPU side by side keeps the chunked host pipeline
+            // (bsk_run_to_store: pinned shard, 256 MiB chunks through two device buffers).
+            if (!via_host) {
+                if (bsk_shard_load(fd, (uint64_t)lo, n, device, 0, &d_shard) != BSK_OK) { give_up(bsk_global_error()); break; }
+                mark("shard on the device", rank);
+                break;
+            }
             h = bsk_host_alloc(std::max<size_t>(1, n));
             if (!h) { give_up("pinned allocation of " + std::to_string(n) + " bytes failed"); break; }
             size_t done = 0;
@@ -809,6 +839,7 @@ int run_devices(const Invocation& inv) {
                 done += (size_t)got;
             }
             if (done < n) { give_up("short read of " + path); break; }
+            mark("shard in pinned memory", rank);
         } while (false);
         // every worker enters every collective, also the one that has given up (its contribution is empty): the others must
         // not wait for it for ever
@@ -817,7 +848,7 @@ int run_devices(const Invocation& inv) {
             std::vector<int64_t> keys(1 << 20), vals(1 << 20);
             size_t cnt = 0;
             int rc = ok0 ? bsk_stats_reset(ctx, nullptr) : BSK_ERR_INVALID_ARG;
-            if (rc == BSK_OK && n) rc = bsk_stats_run(ctx, h, n, 0, fmt, rank, nullptr, nullptr);
+            if (rc == BSK_OK && n) rc = bsk_stats_run(ctx, d_shard, n, 1, fmt, rank, nullptr, nullptr);
             if (ok0 && rc != BSK_OK) give_up(bsk_last_error(ctx));
             uint64_t bad = (uint64_t)failed.load();
             if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); return; }
@@ -839,7 +870,7 @@ int run_devices(const Invocation& inv) {
             uint64_t cnt = 0;
             if (ok0) {
                 bsk_out o;
-                if (bsk_grep_run(ctx, h, n, 0, fmt, rank, nullptr, &o) != BSK_OK || bsk_grep_last_count(ctx, &cnt) != BSK_OK) give_up(bsk_last_error(ctx));
+                if (bsk_grep_run(ctx, d_shard, n, 1, fmt, rank, nullptr, &o) != BSK_OK || bsk_grep_last_count(ctx, &cnt) != BSK_OK) give_up(bsk_last_error(ctx));
             }
             uint64_t bad = (uint64_t)failed.load();
             if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); return; }
@@ -865,11 +896,6 @@ int run_devices(const Invocation& inv) {
             }
             if (use == "rmdup") {
                 bsk_out o{nullptr, 0, 0};
-                if (me.error.empty()) {
-                    bsk_device_select(device);
-                    d_shard = bsk_device_alloc(std::max<size_t>(1, n));
-                    if (!d_shard || (n && bsk_device_copy(d_shard, h, n, BSK_COPY_H2D) != BSK_OK)) give_up(bsk_global_error());
-                }
                 uint64_t bad = (uint64_t)failed.load();
                 if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); bad = 1; }
                 if (!bad) {
@@ -877,22 +903,34 @@ int run_devices(const Invocation& inv) {
                     else if (bsk_store_put(st, ctx, part, &o) != BSK_OK) give_up(bsk_store_error(st));
                     me.out_bytes = o.len; me.out_records = o.records;
                 }
-            } else if (me.error.empty()) {
+            } else if (me.error.empty() && via_host) {
                 if (bsk_run_to_store(ctx, h, n, fmt, rank, st, part, &me.out_bytes, &me.out_records) != BSK_OK) give_up(bsk_last_error(ctx));
+            } else if (me.error.empty()) {
+                // the shard is on the device: one call over all of it, its output drained in pieces (bsk_store_put: the
+                // copy of a piece runs while the piece before it is written)
+                Part in;
+                in.fmt = fmt; in.dptr = d_shard; in.n = n;
+                bsk_out o{nullptr, 0, 0};
+                if (n && run_op(use, ctx, in, rank, 0, &o) != BSK_OK) give_up(bsk_last_error(ctx));
+                else if (bsk_store_put(st, ctx, part, &o) != BSK_OK) give_up(bsk_store_error(st));
+                me.out_bytes = o.len; me.out_records = o.records;
             }
             if (own) {
                 uint64_t tot = 0;
                 if (bsk_store_close(own, &tot) != BSK_OK) give_up("closing " + me.spool + " failed");
             }
         }
+        mark("command done", rank);
         if (d_shard) bsk_device_free(d_shard);
         if (h) bsk_host_free(h);
         if (ctx) bsk_destroy(ctx);
+        mark("released", rank);
     };
     std::vector<std::thread> threads;
     for (int r = 0; r < world; ++r) threads.emplace_back(work, r);
     for (auto& t : threads) t.join();
     for (auto* c : comms) bsk_comm_destroy(c);
+    mark("communicators destroyed");
     close(fd);
     uint64_t tot = 0;
     if (dir_store && bsk_store_close(dir_store, &tot) != BSK_OK) { W[0].error = "closing the output failed"; failed.fetch_add(1); }

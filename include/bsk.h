@@ -158,6 +158,13 @@ int bsk_device_copy(void* dst, const void* src, size_t n, int kind); /* synchron
  * chunks, two device buffers; BSK_STAGE_BYTES overrides the chunk size).  NULL when the allocation fails. */
 void* bsk_host_alloc(size_t n);
 void bsk_host_free(void* p);
+
+/* ReadFASTA[N] / ReadFASTQ[N] (bigseqkit/helper.go:148-178: worker.PlainFile[N] gives every executor its byte ranges of the
+ * file): the bytes [offset, offset + n) of the open file `fd` into a NEW buffer on `device` (*d_shard, bsk_device_free).
+ * `threads` readers (<= 0: 8) pread() pieces of 16 MiB (BSK_SHARD_PIECE_BYTES) into two pinned buffers each and copy them
+ * on streams of their own: reading the file and crossing PCIe overlap, 32 MiB per reader is pinned.  The caller cuts the
+ * file at record starts (bsk_find_record_start on a window around size * k / world).  Errors: bsk_global_error(). */
+int bsk_shard_load(int fd, uint64_t offset, size_t n, int device, int threads, void** d_shard);
 int bsk_stats_reset(bsk_ctx* ctx, void* stream); /* zero the ctx-owned vector, error flags and overflow list */
 /* The context's list of sequence lengths >= hist_cap (the part of the reference's map[int64]int64,
  * bigseqkit-lib/stats.go:86, that does not fit the dense vector).  _get copies it to the host (cap 0 + NULL: size

@@ -2,8 +2,9 @@
 bsk_comm_*, bsk_stats_collect_reduced, bsk_count_allreduce, bsk_rmdup_dist_run over librccl) -- VERDICT r04 missing 2: until
 round 5 only Python + torch.distributed could drive more than one GPU (/root/reference/bigseqkit/stats.go:91, grep.go:175,
 rmdup.go:97 get Reduce / GroupByKey from the framework in the same binary; bigseqkit-cli/helper.go:87-132).
-  * `--devices 0`     : ONE rank over RCCL (ncclCommInitAll of one device: what the one GPU of the test box allows) -- every
-                        collective of the N-rank path runs through librccl, messages cut into rounds;
+  * `--devices 0`     : with BSK_COMM=rccl ONE rank over RCCL (ncclCommInitAll of one device: what the one GPU of the test box
+                        allows) -- every collective of the N-rank path runs through librccl, messages cut into rounds; by
+                        default a lone worker's collectives are copies (librccl is not even loaded);
   * `--devices 0,0[,0]`: ranks that share the GPU take the "local" backend (the same calls through host memory between the
                         threads), so the N > 1 logic -- cuts, counts, owners, replies, part order -- runs here at all.
 The command line is started with an empty PATH: no python3 can be exec'd, the process tree is the one binary."""
@@ -22,6 +23,7 @@ pytestmark = pytest.mark.gpu
 def run_native(cmd, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["PATH"] = "/nonexistent"          # (an exec of python3 -- round 4's --devices -- would fail here)
+    env["BSK_COMM"] = "rccl"              # (`--devices 0`: the one-rank RCCL communicator; the default is tested below)
     env.update(env_extra or {})
     p = subprocess.run(cmd, capture_output=True, cwd=ROOT, env=env, timeout=600)
     assert p.returncode == 0, (cmd, p.stderr.decode()[-3000:])
@@ -145,3 +147,57 @@ def test_the_collectives_through_the_c_abi():
             assert n1.value == n2.value > 0 and list(k1[:n1.value]) == list(k2[:n2.value]) and list(v1[:n1.value]) == list(v2[:n2.value])
     finally:
         lib.bsk_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_a_lone_worker_without_rccl_and_the_chunked_host_pipeline(case, tmp_path):
+    """`--devices 0` as it runs by default (no communicator library); and the same command with every shard sent through
+    bsk_run_to_store (BSK_HOST_PIPELINE_FROM=0: what shards over 48 GB take) in chunks of 64 KiB"""
+    name, args, kind = case
+    data = fastq(30000, 31) if kind == "fq" else fasta(3000, 32)
+    src = str(tmp_path / ("in." + kind))
+    open(src, "wb").write(data)
+    one = str(tmp_path / "one.out")
+    run_native([CLI] + args + [src, "-o", one, "--merge"])
+    want = read_out(one)
+    for k, env in enumerate(({"BSK_COMM": ""}, {"BSK_HOST_PIPELINE_FROM": "0", "BSK_STAGE_BYTES": "65536"},
+                             {"BSK_SHARD_PIECE_BYTES": "4096"})):
+        for devices in ("0", "0,0,0"):
+            many = str(tmp_path / ("many%d%d.out" % (k, len(devices))))
+            run_native([CLI] + args + [src, "-o", many, "--merge", "--devices", devices], env)
+            assert read_out(many) == want and len(want) > 0, (env, devices)
+
+
+def test_shard_load_reads_the_range_it_is_asked_for(tmp_path):
+    """bsk_shard_load: offsets, lengths that are no multiple of the piece, more readers than pieces, an empty range, a range
+    behind the end of the file (an error, nothing allocated)"""
+    import numpy as np
+    import torch
+    from bigseqkit_amd._lib import lib
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, 256, size=3_000_001, dtype=np.uint8)
+    path = str(tmp_path / "blob")
+    data.tofile(path)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        for piece in ("4096", "1000003", ""):
+            if piece:
+                os.environ["BSK_SHARD_PIECE_BYTES"] = piece
+            else:
+                os.environ.pop("BSK_SHARD_PIECE_BYTES", None)
+            for off, n, threads in ((0, len(data), 0), (17, 2_999_000, 3), (2_999_999, 2, 64), (5, 0, 1), (123_457, 1_000_000, 1)):
+                d = C.c_void_p()
+                assert lib.bsk_shard_load(fd, off, n, 0, threads, C.byref(d)) == 0, lib.bsk_global_error()
+                assert d.value
+                if n:
+                    back = np.empty(n, dtype=np.uint8)
+                    assert lib.bsk_device_copy(back.ctypes.data_as(C.c_void_p), d, n, 2) == 0
+                    assert np.array_equal(back, data[off:off + n]), (piece, off, n, threads)
+                lib.bsk_device_free(d)
+        d = C.c_void_p()
+        assert lib.bsk_shard_load(fd, len(data) - 10, 100, 0, 2, C.byref(d)) != 0 and not d.value
+        assert b"short read" in lib.bsk_global_error()
+        assert lib.bsk_shard_load(fd, 0, 10, 99, 2, C.byref(d)) != 0 and not d.value
+    finally:
+        os.environ.pop("BSK_SHARD_PIECE_BYTES", None)
+        os.close(fd)
