@@ -167,13 +167,45 @@ inline bool fastq_multiline_record_at(const uint8_t* buf, uint64_t n, uint64_t p
     }
     return true;
 }
+// ... and the text BEFORE the candidate must agree: only the first of the three records can be the accidental
+// one -- a quality line that begins with '@', then lines read as bases, a quality line that begins with '+', and quality
+// lines that happen to add up, followed by a real header; the two records behind it are genuine and confirm nothing.  A
+// genuine start is where the record before it ENDS.  Walking back over the lines that begin with '@' (at most `back`
+// bytes): one whose record ends exactly at p confirms the candidate; one that reads as records in a row and whose first
+// record reaches beyond p refutes it (p lies inside that record).  Text that begins too late to tell (a window into the
+// file) leaves the candidate standing, as before.
+inline bool fastq_multiline_prev_agrees(const uint8_t* buf, uint64_t n, uint64_t p, uint64_t back = 8ull << 20) {
+    if (p == 0 || buf[p - 1] != '\n') return true;
+    const uint64_t stop = p > back ? p - back : 0;
+    uint64_t q = p - 1;  // the line feed that ends the line before
+    while (q > stop && buf[q - 1] == '\n') --q;  // (blank lines before the candidate: the end of the text before it)
+    while (q > stop) {
+        uint64_t s = q;  // start of the line that ends at q
+        while (s > stop && buf[s - 1] != '\n') --s;
+        if (s == stop && stop > 0) return true;  // out of look-behind: cannot tell
+        if (s == 0 && buf[0] != '@') return true;  // the text begins inside a record (a window): cannot tell
+        if (buf[s] == '@') {
+            const uint64_t e = fastq_multiline_record_end(buf, n, s);
+            if (e != 0 && e <= p) {
+                uint64_t g = e;
+                while (g < p && buf[g] == '\n') ++g;
+                if (g == p) return true;  // the record before ends here
+            } else if (e > p && fastq_multiline_record_at(buf, n, s)) {
+                return false;  // p lies inside a record that is confirmed by the ones behind it
+            }
+        }
+        if (s == 0) return true;  // (reached the beginning without a verdict)
+        q = s - 1;
+    }
+    return true;
+}
 // first record start at or after `from`, looking at most `limit` bytes ahead (n = none found)
 inline uint64_t find_fastq_start_multiline(const uint8_t* buf, uint64_t n, uint64_t from, uint64_t limit = 64ull << 20) {
     if (from >= n) return n;
     if (from == 0 && fastq_multiline_record_at(buf, n, 0)) return 0;
     uint64_t j = from == 0 ? find_byte(buf, n, 0, '\n') : find_byte(buf, n, from - 1, '\n');
     while (j < n) {
-        if (j + 1 < n && buf[j + 1] == '@' && fastq_multiline_record_at(buf, n, j + 1)) return j + 1;
+        if (j + 1 < n && buf[j + 1] == '@' && fastq_multiline_record_at(buf, n, j + 1) && fastq_multiline_prev_agrees(buf, n, j + 1)) return j + 1;
         if (j + 1 > from + limit) return n;
         j = find_byte(buf, n, j + 1, '\n');
     }

@@ -71,7 +71,7 @@ def sniff_format(path, first_byte):
 
 def cut_points(mm, size, world, fmt, lib, check):
     """world + 1 offsets; cut k = the first record start at or behind size * k / world, searched in a window of the mapped
-    file (1 MiB, grown while the window holds no whole record start): nothing but those windows is touched"""
+    file (1 MiB either side, grown until the next larger window names the same start): nothing but those windows is touched"""
     import numpy as np
     view = np.frombuffer(mm, dtype=np.uint8)
     base = view.ctypes.data
@@ -83,14 +83,19 @@ def cut_points(mm, size, world, fmt, lib, check):
             cuts.append(size)
             continue
         win = 1 << 20
-        while True:
-            a = lo - 1 if lo > 0 else 0            # (the byte before `lo` tells whether `lo` begins a line)
-            b = min(size, lo + win)
+
+        def look(w):
+            # up to `w` bytes before `lo` (a FASTQ start is also judged by the record that ends there) and `w` behind it
+            a = lo - w if lo > w else 0
+            b = min(size, lo + w)
             out = C.c_size_t()
             check(lib.bsk_find_record_start(C.c_void_p(base + a), b - a, lo - a, fmt, C.byref(out)))
-            found = a + out.value
-            # a start close to the window's end was judged on a cut-off record: look again with more text behind it
-            if b < size and found + (64 << 10) > b:
+            return a + out.value, b
+        while True:
+            found, b = look(win)
+            # a start close to the window's end was judged on a cut-off record, and a candidate passed over because the
+            # window cut its record off shows up as a different answer of the next larger window: look again with more text
+            if b < size and (found + (64 << 10) > b or look(win * 4)[0] != found):
                 win *= 4
                 continue
             cuts.append(min(found, size))

@@ -722,15 +722,23 @@ std::vector<size_t> cut_points(const uint8_t* map, size_t size, int world, int f
         const size_t nominal = (size_t)((unsigned __int128)size * (unsigned)k / (unsigned)world);
         const size_t lo = std::max(nominal, cuts.back());
         if (lo >= size) { cuts.push_back(size); continue; }
+        // the window: up to `win` bytes before `lo` (a FASTQ start is also judged by the record that ends there: anchor.hpp)
+        // and `win` bytes behind it.  A start is taken when the next larger window names the same one -- a candidate that
+        // was passed over because the window cut its record off shows up as a different answer -- and does not
+        // sit within 64 KiB of the window's end.
         size_t win = 1u << 20;
-        for (;;) {
-            const size_t a = lo > 0 ? lo - 1 : 0;  // (the byte before `lo` tells whether `lo` begins a line)
-            const size_t b = std::min(size, lo + win);
+        auto look = [&](size_t w, size_t* b_out) {
+            const size_t a = lo > w ? lo - w : 0;
+            const size_t b = std::min(size, lo + w);
             size_t found = 0;
             if (bsk_find_record_start(map + a, b - a, lo - a, fmt, &found) != BSK_OK) die(bsk_global_error());
-            found += a;
-            // a start close to the window's end was judged on a record that may be cut off: once more with more text behind it
-            if (b < size && found + (64u << 10) > b) { win *= 4; continue; }
+            *b_out = b;
+            return found + a;
+        };
+        for (;;) {
+            size_t b = 0, b4 = 0;
+            const size_t found = look(win, &b);
+            if (b < size && (found + (64u << 10) > b || look(win * 4, &b4) != found)) { win *= 4; continue; }
             cuts.push_back(std::min(found, size));
             break;
         }

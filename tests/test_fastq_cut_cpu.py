@@ -80,3 +80,37 @@ def test_shards_of_a_wrapped_file_cover_it_record_by_record():
             assert hi == lo2
         assert all(lo in set(starts) or lo == len(data) for lo, _ in b)
         assert len({lo for lo, _ in b}) == world   # (real cuts: the wrapped reading found record starts, not the end)
+
+
+def _accident():
+    """a wrapped record whose quality lines read, from the second of them on, as a record of their own: '@'-led quality line,
+    two lines taken for bases, a '+'-led quality line, two lines of 'qualities' -- then genuine records"""
+    w = 10
+    seq = "ACGTACGTAC" * 7
+    qual_lines = ["IIIIIIIIII", "@IIIIIIIII", "IIIIIIIIII", "IIIIIIIIII", "+IIIIIIIII", "IIIIIIIIII", "IIIIIIIIII"]
+    victim = "@victim\n" + "\n".join(seq[j:j + w] for j in range(0, len(seq), w)) + "\n+\n" + "\n".join(qual_lines) + "\n"
+    plain = "".join("@r%d\nACGTACGTAC\nACGTA\n+\nIIIIIIIIII\nIIIII\n" % i for i in range(6))
+    before = "".join("@p%d\nACGTACGTAC\nACG\n+\nIIIIIIIIII\nIII\n" % i for i in range(4))
+    return before, victim, plain
+
+
+def test_a_quality_line_that_reads_as_a_record_is_no_place_to_cut():
+    before, victim, plain = _accident()
+    data = (before + victim + plain).encode()
+    v0 = len(before)
+    false_start = v0 + victim.index("\n@IIIIIIIII") + 1
+    true_next = v0 + len(victim)
+    # the accident is real: read from the '@'-led quality line on, the text IS three records in a row
+    assert cut(data[false_start:], 0) == 0
+    # with the text before it in view the record that spans the line refutes it, wherever the search begins inside the victim
+    for pos in (v0 + 1, v0 + 20, false_start - 3, false_start):
+        assert cut(data, pos) == true_next, pos
+    assert cut(data, v0) == v0 and cut(data, true_next) == true_next
+    # every genuine start still stands, also the first one of the text and the ones a window begins inside of
+    starts = [m for m in range(len(data)) if data[m:m + 1] == b"@" and (m == 0 or data[m - 1:m] == b"\n")
+              and not (v0 < m < true_next)]
+    for s in starts:
+        assert cut(data, s) == s
+        for a in (s - 1, s - 7, max(0, s - 40)):
+            if a >= 0:
+                assert cut(data[a:], s - a) == s - a, (s, a)
