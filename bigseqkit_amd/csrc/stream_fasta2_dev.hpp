@@ -83,6 +83,8 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2T<GAPS>& L, const uin
     const uint32_t k_ctl = 0x20202020u;
 #endif
     const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64u - lane));
+    // GAPS: the successor of the largest gap letter in every byte (kgap = 0x80 - (top + 1) per byte: capi.cpp)
+    const uint32_t k_low = GAPS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x80808080u - PC.kgap)) : 0u;
 
     auto run_sink = [&](uint32_t E) {
         wave_lds_fence();
@@ -101,6 +103,7 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2T<GAPS>& L, const uin
         uint32_t nxw = 0;
         if (have) { v = L.qdata[qi]; prel = L.qpos[qi]; nxw = L.qnx[qi]; }
         uint32_t nl = have ? eq_mask16(v, 0x0A0A0A0Au) : 0u;
+        const uint32_t nl_all = nl;  // (before the clip below)
         if (__ballot(have && (prel < 0 || prel + 16 > end_rel)) != 0ull) {  // pieces across the ends of the range
             int32_t lo = -prel, hi = end_rel - prel;
             lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
@@ -119,10 +122,19 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2T<GAPS>& L, const uin
             }
             const uint64_t I = rs + (uint64_t)(int64_t)prel;
             if (I >= skip_from && I < count_resume) vp = 0u;
+            // the queued pieces hold line feeds, so "sixteen bytes above the largest gap letter" never holds for them -- but
+            // a piece whose bytes at or below that letter are ALL line feeds holds no gap letter either: sequence lines,
+            // always, and header lines without blanks (a genome's few headers: no round pays for the letters)
+            const uint32_t kg = PC.kgap;
+            const uint32_t ca = popc4((((v.x & 0x7F7F7F7Fu) + kg) | v.x) & 0x80808080u, (((v.y & 0x7F7F7F7Fu) + kg) | v.y) & 0x80808080u,
+                                      (((v.z & 0x7F7F7F7Fu) + kg) | v.z) & 0x80808080u, (((v.w & 0x7F7F7F7Fu) + kg) | v.w) & 0x80808080u);
+            const bool cand = have && vp != 0u && (kg == 0xFFFFFFFFu || 16u - ca != (uint32_t)__popc(nl_all));
+            if (__ballot(cand) != 0ull) {
 #pragma nounroll
-            for (int k = 0; k < PC.ngap; ++k) {
-                const uint32_t rep = PC.gap_rep[k];
-                sink.rgap += (uint32_t)__popc(pack_flags(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep), zero_bytes(v.z ^ rep), zero_bytes(v.w ^ rep)) & vp);
+                for (int k = 0; k < PC.ngap; ++k) {
+                    const uint32_t rep = PC.gap_rep[k];
+                    sink.rgap += (uint32_t)__popc(pack_flags(zero_bytes(v.x ^ rep), zero_bytes(v.y ^ rep), zero_bytes(v.z ^ rep), zero_bytes(v.w ^ rep)) & vp);
+                }
             }
         }
         const uint32_t cnt = (uint32_t)__popc(nl);
@@ -221,12 +233,12 @@ __device__ __forceinline__ F2Tail stream_range_fasta2(LdsF2T<GAPS>& L, const uin
             if constexpr (GAPS) {
                 // a piece without a newline (nothing below 0x20): sixteen bytes above the largest gap letter hold no gap
                 // letter -- sequence text, always; only a wave with a candidate looks at the letters
-                const uint32_t kg = PC.kgap;
-                const uint32_t ca = popc4((((v.x & 0x7F7F7F7Fu) + kg) | v.x) & 0x80808080u, (((v.y & 0x7F7F7F7Fu) + kg) | v.y) & 0x80808080u,
-                                          (((v.z & 0x7F7F7F7Fu) + kg) | v.z) & 0x80808080u, (((v.w & 0x7F7F7F7Fu) + kg) | v.w) & 0x80808080u);
+                // ("some byte at or below it": the borrow trick of the newline filter with the letter's successor -- exact as
+                // a yes / no, two instructions per dword where the count of the bytes above takes five)
+                const uint32_t lowb = (((v.x - k_low) & ~v.x) | ((v.y - k_low) & ~v.y) | ((v.z - k_low) & ~v.z) | ((v.w - k_low) & ~v.w)) & 0x80808080u;
                 const uint64_t I = tile_idx + (uint64_t)p * PIECE_BYTES + (uint64_t)lane * 16;
                 const bool mine = !f && !edge && !(I >= skip_from && I < count_resume);
-                if (__ballot(mine && (ca != 16u || kg == 0xFFFFFFFFu)) != 0ull) {
+                if (__ballot(mine && (lowb != 0u || PC.kgap == 0xFFFFFFFFu)) != 0ull) {
                     uint32_t cg = 0;
 #pragma nounroll
                     for (int k = 0; k < PC.ngap; ++k) {
