@@ -183,7 +183,7 @@ struct StatsSinkT {
     uint32_t rsub = 0;               // GAPS: gap letters inside header lines (per lane and range)
     uint32_t last_pub_pos = 0xFFFFFFFFu;  // position of the last published newline of the range (~0: none, the range start is a line start)
     const uint8_t* f2_buf = nullptr;
-    uint64_t f2_rs = 0, f2_skip_lo = ~0ull, f2_skip_hi = 0;   // bytes at [skip_lo, skip_hi) are counted by other ranges (RF_MID)
+    uint64_t f2_rs = 0, f2_n = 0, f2_skip_lo = ~0ull, f2_skip_hi = 0;   // bytes at [skip_lo, skip_hi) are counted by other ranges (RF_MID)
     template <bool GAPS>
     __device__ __forceinline__ void events2(LdsF2T<GAPS>& L, uint32_t first, uint32_t E) {
         const uint32_t lane = threadIdx.x & 63;
@@ -198,14 +198,45 @@ struct StatsSinkT {
             uint32_t prev = (uint32_t)__shfl_up((int)pos, 1, 64);
             if (lane == 0) prev = last_pub_pos;
             if (hdr_end) {
+                // the gap letters of the header line [prev + 1, pos): sixteen bytes per load (until round 5 one byte per
+                // load, ten dependent loads for `>r0000001` on the few lanes that hold a header); a chunk without a byte
+                // at or below the largest gap letter -- a name without blanks -- is done after the test
                 const PredConsts& P = D.pred;
-                for (uint32_t x = prev + 1u; x < pos; ++x) {   // (prev + 1 wraps to 0 at the range start)
+                uint32_t x = prev + 1u;   // (prev + 1 wraps to 0 at the range start)
+                while (x < pos) {
                     const uint64_t a = f2_rs + x;
-                    if (a >= f2_skip_lo && a < f2_skip_hi) continue;
-                    const uint32_t c = f2_buf[a];
-                    // (static indices: a run-time index into the sink's copy of the constants would put the whole sink into scratch memory)
+                    const uint32_t len = pos - x < 16u ? pos - x : 16u;
+                    if (a + 16 <= f2_n && (a + 16 <= f2_skip_lo || a >= f2_skip_hi)) {
+                        uint32_t w[4];
+                        __builtin_memcpy(w, f2_buf + a, 16);
+                        uint32_t low = 0, m[4];
 #pragma unroll
-                    for (int k = 0; k < MAX_GAP_LETTERS; ++k) rsub += (k < P.ngap && (P.gap_rep[k] & 0xFFu) == c) ? 1u : 0u;
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t nv = len > 4u * d ? (len - 4u * d >= 4u ? 4u : len - 4u * d) : 0u;
+                            m[d] = nv >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * nv)) - 1u));
+                            low |= ~ge_bytes(w[d], P.kgap) & m[d];
+                        }
+                        if (low != 0u || P.kgap == 0xFFFFFFFFu) {
+                            // (static indices: a run-time index into the sink's copy of the constants would put the whole sink into scratch memory)
+#pragma unroll
+                            for (int k = 0; k < MAX_GAP_LETTERS; ++k) {
+                                if (k < P.ngap) {
+                                    const uint32_t rep = P.gap_rep[k];
+                                    rsub += (uint32_t)__popc((zero_bytes(w[0] ^ rep) & m[0]) >> 7) + (uint32_t)__popc((zero_bytes(w[1] ^ rep) & m[1]) >> 7) +
+                                            (uint32_t)__popc((zero_bytes(w[2] ^ rep) & m[2]) >> 7) + (uint32_t)__popc((zero_bytes(w[3] ^ rep) & m[3]) >> 7);
+                                }
+                            }
+                        }
+                    } else {  // at the end of the shard, or across bytes that other ranges count: byte by byte
+                        for (uint32_t y = x; y < x + len; ++y) {
+                            const uint64_t b = f2_rs + y;
+                            if (b >= f2_skip_lo && b < f2_skip_hi) continue;
+                            const uint32_t c = f2_buf[b];
+#pragma unroll
+                            for (int k = 0; k < MAX_GAP_LETTERS; ++k) rsub += (k < P.ngap && (P.gap_rep[k] & 0xFFu) == c) ? 1u : 0u;
+                        }
+                    }
+                    x += len;
                 }
             }
             if (E) last_pub_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(E - 1u));
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) BSK_STATS_ATTR void k_stats
         const uint64_t count_resume = (!FASTQ && chunk) ? (re == n_eff ? re : (re / chunk) * chunk) : 0ull;
         if constexpr (F2) {
             sink.f2 = true;
-            if constexpr (ALL) { sink.f2_buf = buf; sink.f2_rs = rs; sink.f2_skip_lo = skip_from; sink.f2_skip_hi = count_resume; }
+            if constexpr (ALL) { sink.f2_buf = buf; sink.f2_rs = rs; sink.f2_n = n; sink.f2_skip_lo = skip_from; sink.f2_skip_hi = count_resume; }
             const F2Tail T = stream_range_fasta2<DPP, ALL>(s_f2[wave], buf, n, rs, re, re == n_eff, sink, D.pred, skip_from, count_resume);
             sink.any_event = T.lines != 0u;
             sink.last_closing = T.last_closing;
