@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
 ( time (timeout 2400 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | grep -v "^  File" | tail -15) ) > $O/r05_full_tests.log 2>&1
 cat $O/r05_full_tests.log
-( time (timeout 1500 python bench.py 2>$O/r05_full_bench.err | tail -1) > $O/r05_full_bench.json ) 2>&1 | tail -3
+T0=$(date +%s); timeout 1500 python bench.py 2>$O/r05_full_bench.err | tail -1 > $O/r05_full_bench.json; echo "bench.py wall: $(( $(date +%s) - T0 )) s" | tee $O/r05_full_bench.wall
 python - <<PY
 import json
 d=json.load(open("$O/r05_full_bench.json"))

@@ -112,4 +112,5 @@ def test_bench_ops_object_small():
     e2e = d["end_to_end"]
     assert "error" not in e2e, e2e
     legs = [v for k, v in e2e.items() if isinstance(v, dict)]
-    assert len(legs) == 3 and all(v["exact"] is True for v in legs), e2e
+    assert len(legs) == 5 and all(v["exact"] is True for v in legs), e2e
+    assert sum("fresh process" in k for k in e2e) == 2, e2e     # FILE -> result through the native driver
