@@ -10,14 +10,18 @@
 // GB/s), 0.15 s copying, 0.78 s unpinning.  Now `threads` readers take pieces of 16 MiB from a shared counter; each has
 // two pinned buffers and a stream of its own, so the pread() of a piece runs while the piece before it crosses PCIe and
 // while the other readers do the same -- the read of the file and the copy overlap, and only 2 x 16 MiB per reader is
-// ever pinned.
+// ever pinned.  The readers run on the CPUs of the GPU's NUMA node when the platform names it (BSK_NUMA=off: wherever
+// the scheduler puts them), their pinned buffers are first touched there.
 // ============================================================================
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -37,6 +41,8 @@ struct LoadJob {
     size_t n, piece;
     int device;
     char* d;
+    bool pin = false;
+    cpu_set_t cpus;
     std::atomic<uint64_t> next{0};
     std::atomic<int> bad{0};
     std::mutex m;
@@ -48,7 +54,47 @@ struct LoadJob {
     }
 };
 
+// the CPUs of the NUMA node the GPU hangs on ("pin reader threads per GPU" -- eight workers reading through
+// one socket's memory controllers is what bends the scaling curve of the file -> result path); empty when the platform does
+// not say (a container without /sys/bus/pci, numa_node == -1) or BSK_NUMA=off
+bool numa_cpus_of_device(int device, cpu_set_t* set) {
+    const char* off = getenv("BSK_NUMA");
+    if (off && !strcmp(off, "off")) return false;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess || !bdf[0]) return false;
+    for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const size_t k = fread(list, 1, sizeof list - 1, f);
+    fclose(f);
+    if (k == 0) return false;
+    CPU_ZERO(set);
+    int any = 0;
+    for (char* p = list; *p;) {  // "0-31,64-95"
+        char* e = nullptr;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { if (c >= 0) { CPU_SET((int)c, set); any = 1; } }
+        p = e;
+        while (*p == ',' || *p == '\n' || *p == ' ') ++p;
+    }
+    return any != 0;
+}
+
 void reader(LoadJob* J) {
+    if (J->pin) sched_setaffinity(0, sizeof J->cpus, &J->cpus);  // (this thread only; refused outside the cgroup's set: then it stays where it is)
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool used[2] = {false, false};
@@ -104,9 +150,10 @@ extern "C" int bsk_shard_load(int fd, uint64_t offset, size_t n, int device, int
         const uint64_t pieces = (n + J.piece - 1) / J.piece;
         int T = threads > 0 ? threads : 8;
         T = (int)std::min<uint64_t>((uint64_t)std::min(T, 64), pieces);
+        J.pin = numa_cpus_of_device(device, &J.cpus);
+        // (every reader is a thread of its own: the caller's affinity is not touched)
         std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back(reader, &J);
-        reader(&J);
+        for (int t = 0; t < T; ++t) pool.emplace_back(reader, &J);
         for (auto& t : pool) t.join();
         if (J.bad.load()) {
             hipFree(d);
