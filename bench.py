@@ -891,6 +891,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-ops", action="store_true", help="skip the 'ops' object (seq -n / grep / translate / rmdup at the "
                                                            "BASELINE config sizes, N = 1 only)")
+    ap.add_argument("--no-scaling-model", action="store_true", help="skip the single-GPU shard steps of 'scaling_model' (the "
+                    "profiling passes: every k_stats dispatch of the run is then a whole-file one)")
     ap.add_argument("--ops-scale", type=float, default=1.0, help="scale the sizes of the 'ops' workloads (tests)")
     ap.add_argument("--ops-calls", type=int, default=5, help="timed calls per operator of the 'ops' object")
     ap.add_argument("--launch-check", action="store_true",
@@ -1107,7 +1109,7 @@ def main():
     # file -- the term of the 1 / 2 / 4 / 8 curve that this box CAN measure.  An ESTIMATE of the curve, not the curve: the
     # 512 KB all-reduce per step and the other GPUs are not in it.
     scaling_model = None
-    if not dist_on:
+    if not dist_on and not args.no_scaling_model:
         op, vec = make_op(False)
         rows = {}
         for g in (1, 2, 4, 8):
