@@ -869,8 +869,19 @@ __device__ __forceinline__ uint64_t pl_wave_sum(uint64_t v) {
     return v;
 }
 
+#ifndef BSK_PLACE_W
+#define BSK_PLACE_W 0
+#endif
+#if BSK_PLACE_W
+#define BSK_PLACE_ATTR __attribute__((amdgpu_waves_per_eu(BSK_PLACE_W, 8)))
+#else
+#define BSK_PLACE_ATTR
+#endif
+#ifndef BSK_PLACE_CH
+#define BSK_PLACE_CH 4  // chunks of a pair loaded before the first is looked at (scripts/history/r05_place_ab.sh: 4 at 4 waves per SIMD 2.52 ms, 2 at 4 waves 2.58, 2 or 4 at 5 waves with spills 2.65 - 2.73; round 4's loop 2.80)
+#endif
 template <bool FOLD>
-__global__ __launch_bounds__(256) void k_rmdup_place(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
+__global__ __launch_bounds__(256) BSK_PLACE_ATTR void k_rmdup_place(const uint8_t* __restrict__ buf, uint64_t buf_n, RecordTable t,
                                                      const uint32_t* __restrict__ first_of, uint64_t* __restrict__ chain,
                                                      uint32_t* __restrict__ ticket, uint64_t* __restrict__ out_off,
                                                      uint64_t* __restrict__ seg_src, uint32_t* __restrict__ first4k,
@@ -879,6 +890,8 @@ __global__ __launch_bounds__(256) void k_rmdup_place(const uint8_t* __restrict__
     __shared__ uint32_t s_list[VER_RECORDS];
     __shared__ uint32_t s_n, s_bid;
     __shared__ uint64_t s_w[4], s_excl;
+    __shared__ uint64_t s_pa[256], s_pb[256];  // where the bases of a duplicate and of its survivor begin
+    __shared__ uint32_t s_la[256];             // their length (0: the lengths differ, nothing to compare)
     if (threadIdx.x == 0) { s_bid = atomicAdd(ticket, 1u); s_n = 0; }
     __syncthreads();
     const uint32_t bid = s_bid;
@@ -958,28 +971,75 @@ __global__ __launch_bounds__(256) void k_rmdup_place(const uint8_t* __restrict__
     // the block's total is known: the blocks behind can pass over this one from now on.  The comparison of the duplicates
     // comes BEFORE this block's own look-back -- its gathers are long, and the predecessors finish meanwhile
     if (threadIdx.x == 0) pl_store(chain + bid, (bid == 0 ? PL_FLAG_PREFIX : PL_FLAG_AGG) | (s_w[0] + s_w[1] + s_w[2] + s_w[3]));
-    // the byte comparison of the block's duplicates: four lanes each, 16 bytes per lane and step
+    // the byte comparison of the block's duplicates, 256 at a time.  Every thread first fetches the rows of ONE duplicate and
+    // of its survivor (a random record: three gathers) into LDS -- 256 chains of dependent loads at once where the quads of
+    // the loop below used to walk them 64 at a time, each through first_of -> rows -> text --, then four lanes compare each
+    // pair, two 16-byte chunks per lane and side loaded before the first is looked at.
     const uint32_t nd = s_n, gl = threadIdx.x & 3u;
     uint32_t bad = 0;
-    for (uint32_t d = threadIdx.x >> 2; d < nd; d += 64u) {
-        const uint64_t i = base + s_list[d];
-        const uint64_t f = first_of[i];
-        const uint32_t la = t.l_seq[i], lb = t.l_seq[f];
-        const uint8_t* pa = buf + t.start[i] + t.l_head[i] + 1;
-        const uint8_t* pb = buf + t.start[f] + t.l_head[f] + 1;
-        uint32_t diff = la ^ lb;
-        if (diff == 0) {
+    for (uint32_t b0 = 0; b0 < nd; b0 += 256u) {
+        const uint32_t d = b0 + threadIdx.x;
+        if (d < nd) {
+            const uint64_t i = base + s_list[d];
+            const uint64_t f = first_of[i];
+            // (measured and dropped, scripts/history/r05_place_ab.sh: one packed word per record -- offset of the bases | their
+            // number -- written by the gather of the hashing pass, so that a survivor costs one sector here instead of three:
+            // this kernel 2.56 -> 2.52 ms, the gather 0.91 -> 1.14)
+            const uint64_t pa = t.start[i] + t.l_head[i] + 1, pb = t.start[f] + t.l_head[f] + 1;
+            const uint32_t la = t.l_seq[i], lb = t.l_seq[f];
+            s_pa[threadIdx.x] = pa;
+            s_pb[threadIdx.x] = pb;
+            s_la[threadIdx.x] = la == lb ? la : 0u;
+            bad |= la ^ lb;
+        }
+        __syncthreads();
+        const uint32_t cnt = nd - b0 < 256u ? nd - b0 : 256u;
+        for (uint32_t e = threadIdx.x >> 2; e < cnt; e += 64u) {
+            const uint8_t* pa = buf + s_pa[e];
+            const uint8_t* pb = buf + s_pb[e];
+            const uint32_t la = s_la[e];
+            uint32_t diff = 0;
+            auto fold = [&](uint4& v) { if (FOLD) { v.x = fold4(v.x); v.y = fold4(v.y); v.z = fold4(v.z); v.w = fold4(v.w); } };
             auto cmp16 = [&](uint32_t q) {
                 uint4 xa, ya;
                 __builtin_memcpy(&xa, pa + q, 16);
                 __builtin_memcpy(&ya, pb + q, 16);
-                if (FOLD) {
-                    xa.x = fold4(xa.x); xa.y = fold4(xa.y); xa.z = fold4(xa.z); xa.w = fold4(xa.w);
-                    ya.x = fold4(ya.x); ya.y = fold4(ya.y); ya.z = fold4(ya.z); ya.w = fold4(ya.w);
-                }
+                fold(xa); fold(ya);
                 diff |= (xa.x ^ ya.x) | (xa.y ^ ya.y) | (xa.z ^ ya.z) | (xa.w ^ ya.w);
             };
-            for (uint32_t q = 16u * gl; q + 16u <= la; q += 64u) cmp16(q);
+#if BSK_PLACE_CH == 4
+            uint4 xa[4], ya[4];
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) {  // chunks gl, gl + 4, gl + 8, gl + 12: reads of 256 bases and fewer end here
+                const uint32_t q = 16u * (gl + 4u * c);
+                xa[c] = make_uint4(0, 0, 0, 0);
+                ya[c] = make_uint4(0, 0, 0, 0);
+                if (q + 16u <= la) {
+                    __builtin_memcpy(&xa[c], pa + q, 16);
+                    __builtin_memcpy(&ya[c], pb + q, 16);
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) {
+                fold(xa[c]); fold(ya[c]);
+                diff |= (xa[c].x ^ ya[c].x) | (xa[c].y ^ ya[c].y) | (xa[c].z ^ ya[c].z) | (xa[c].w ^ ya[c].w);
+            }
+#else
+            // (two chunks per lane in flight: four cost 23 more registers and a wave per SIMD)
+            for (uint32_t q0 = 16u * gl; q0 + 16u <= la && q0 < 256u; q0 += 128u) {  // chunks gl, gl + 4 | gl + 8, gl + 12
+                uint4 xa0, ya0, xa1 = make_uint4(0, 0, 0, 0), ya1 = make_uint4(0, 0, 0, 0);
+                __builtin_memcpy(&xa0, pa + q0, 16);
+                __builtin_memcpy(&ya0, pb + q0, 16);
+                if (q0 + 80u <= la) {
+                    __builtin_memcpy(&xa1, pa + q0 + 64u, 16);
+                    __builtin_memcpy(&ya1, pb + q0 + 64u, 16);
+                }
+                fold(xa0); fold(ya0); fold(xa1); fold(ya1);
+                diff |= (xa0.x ^ ya0.x) | (xa0.y ^ ya0.y) | (xa0.z ^ ya0.z) | (xa0.w ^ ya0.w) |
+                        (xa1.x ^ ya1.x) | (xa1.y ^ ya1.y) | (xa1.z ^ ya1.z) | (xa1.w ^ ya1.w);
+            }
+#endif
+            for (uint32_t q = 16u * (gl + 16u); q + 16u <= la; q += 64u) cmp16(q);
             if (gl == 3u) {
                 if (la >= 16u) { if (la & 15u) cmp16(la - 16u); }
                 else for (uint32_t q = 0; q < la; ++q) {
@@ -988,8 +1048,9 @@ __global__ __launch_bounds__(256) void k_rmdup_place(const uint8_t* __restrict__
                     diff |= (uint32_t)(ca ^ cb);
                 }
             }
+            bad |= diff;
         }
-        bad |= diff;
+        __syncthreads();
     }
     if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_HASH_COLLISION);
     if (wave == 0) {
