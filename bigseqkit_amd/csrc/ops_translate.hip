@@ -1429,6 +1429,9 @@ __device__ __forceinline__ uint32_t ts_element_bytes(const TranslateParams& P, u
     return lh + 1u + naa + ((P.line_width > 0 && naa > 0) ? (naa - 1u) / (uint32_t)P.line_width : 0u) + 1u;
 }
 
+#ifndef BSK_TRS_INFLIGHT
+#define BSK_TRS_INFLIGHT 4  // 16-byte loads per thread in flight while a range is searched for its '>' (scripts/history/r05_trs_inflight.sh, one visit: 4 -> 49.8-50.1 ms, 8 -> 50.3-50.4, 16 -> 50.7: the search shares the memory system with the blocks that translate)
+#endif
 #ifndef BSK_TRS_WAVES
 #define BSK_TRS_WAVES 4
 #endif
@@ -1475,7 +1478,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSK_TRS_WAV
         re = re < n_eff ? re : n_eff;
         if (r == 0 && threadIdx.x == 0 && n_eff && buf[0] != (uint8_t)'>') atomicOr((unsigned long long*)&status[0], (unsigned long long)ERR_BAD_HEADER);
         // ---- A: record starts of the range (four loads in flight per thread: one at a time, the 128 steps of a 512 KiB range
-        // cost a memory round trip each -- 15 % of the pass; eight in flight now)
+        // cost a memory round trip each -- 15 % of the pass; four in flight: see BSK_TRS_INFLIGHT)
         {
             auto take = [&](uint64_t at, const uint4& v) {
                 // (sequence text is letters: a piece without a byte below 0x3F holds no '>' -- 3 in 4 pieces stop here)
@@ -1505,12 +1508,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSK_TRS_WAV
             };
             constexpr uint64_t STRIDE = 16ull * 256ull;
             uint64_t at = rs + 16ull * threadIdx.x;
-            for (; at + 7 * STRIDE < re; at += 8 * STRIDE) {
-                uint4 v[8];
+            for (; at + (BSK_TRS_INFLIGHT - 1) * STRIDE < re; at += BSK_TRS_INFLIGHT * STRIDE) {
+                uint4 v[BSK_TRS_INFLIGHT];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = load(at + (uint64_t)k * STRIDE);
+                for (int k = 0; k < BSK_TRS_INFLIGHT; ++k) v[k] = load(at + (uint64_t)k * STRIDE);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) take(at + (uint64_t)k * STRIDE, v[k]);
+                for (int k = 0; k < BSK_TRS_INFLIGHT; ++k) take(at + (uint64_t)k * STRIDE, v[k]);
             }
             for (; at < re; at += STRIDE) take(at, load(at));
         }
