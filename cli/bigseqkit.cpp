@@ -20,6 +20,7 @@
 #include <sys/sendfile.h>
 #include <sys/stat.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -219,11 +220,32 @@ bool has_suffix(std::string s, const std::vector<const char*>& es) {
 }
 
 std::string read_file(const std::string& path) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) die("open " + path + ": no such file or directory");
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
+    // (one read() loop into the string: the stream-buffer copy this replaced moved a file of 8 GB twice)
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("open " + path + ": no such file or directory");
+    struct stat sb;
+    std::string text;
+    if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+        text.resize((size_t)sb.st_size);
+        size_t done = 0;
+        while (done < text.size()) {
+            const ssize_t got = read(fd, &text[done], std::min<size_t>(text.size() - done, (size_t)256 << 20));
+            if (got < 0 && errno == EINTR) continue;
+            if (got <= 0) break;
+            done += (size_t)got;
+        }
+        text.resize(done);
+    } else {  // a pipe, a character device: until it ends
+        char buf[1 << 16];
+        for (;;) {
+            const ssize_t got = read(fd, buf, sizeof buf);
+            if (got < 0 && errno == EINTR) continue;
+            if (got <= 0) break;
+            text.append(buf, (size_t)got);
+        }
+    }
+    close(fd);
+    return text;
 }
 
 // bigseqkit-cli/helper.go:63-78
@@ -585,12 +607,34 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
     return res;
 }
 
-std::vector<Part> read_parts(const std::vector<std::string>& files) {
+// device >= 0: the files go straight to that GPU (bsk_shard_load: several readers, pread || H2D) -- what every command but
+// the ones that join their inputs on the host (concat, common, pair) takes; device < 0: host strings
+std::vector<Part> read_parts(const std::vector<std::string>& files, int device = -1) {
     std::vector<Part> parts;
     for (auto& f : files) {
         Part p;
-        p.host = read_file(f);
-        p.fmt = sniff_format(f, p.host);
+        if (device < 0) {
+            p.host = read_file(f);
+            p.fmt = sniff_format(f, p.host);
+        } else {
+            const int fd = open(f.c_str(), O_RDONLY);
+            if (fd < 0) die("open " + f + ": no such file or directory");
+            struct stat sb;
+            if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {  // (a pipe: read to its end first)
+                close(fd);
+                p.host = read_file(f);
+                p.fmt = sniff_format(f, p.host);
+                parts.push_back(std::move(p));
+                continue;
+            }
+            char first = 0;
+            const ssize_t got = pread(fd, &first, 1, 0);
+            p.fmt = sniff_format(f, got == 1 ? std::string(1, first) : std::string());
+            p.n = (size_t)sb.st_size;
+            if (bsk_shard_load(fd, 0, p.n, device, 0, &p.dptr) != BSK_OK) die(bsk_global_error());
+            p.owned_alloc = true;
+            close(fd);
+        }
         parts.push_back(std::move(p));
     }
     return parts;
@@ -613,7 +657,7 @@ Output run_job(const bsk::json::Value& j, bool root) {
     std::vector<std::string> args;
     for (auto& a : cmd->arr) args.push_back(a->str);
     Invocation inv = parse_invocation(args);
-    for (auto& p : read_parts(inv.files)) inputs.push_back(std::move(p));
+    for (auto& p : read_parts(inv.files, (int)strtol(inv.pget("device").c_str(), nullptr, 10))) inputs.push_back(std::move(p));
     if (inputs.empty()) die("no input for job command " + args[0]);
     Output o = execute(inv, inputs, !root);
     release(inputs);
@@ -1047,7 +1091,10 @@ static int run_main(int argc, char** argv) {
     if (!inv.pget("devices").empty()) return run_devices(inv);  // several GPUs: worker threads + librccl, in this process
     if (inv.files.empty()) die("no input files (stdin is not supported by the IgnisHPC CLI either)");
     g_faidx_query = faidx_query;
-    std::vector<Part> inputs = read_parts(inv.files);
+    const std::string use_cmd = inv.cmd->use;
+    const bool joins_on_host = use_cmd == "concat" || use_cmd == "common" || use_cmd == "pair";
+    if (!joins_on_host && bsk_device_count() <= 0) die("no HIP device visible (the hot path has no CPU fallback)");
+    std::vector<Part> inputs = read_parts(inv.files, joins_on_host ? -1 : (int)strtol(inv.pget("device").c_str(), nullptr, 10));
     if (std::string(inv.cmd->use) == "concat") {
         if (inputs.size() != 2) die("2 files needed");
         if (inputs[0].fmt != inputs[1].fmt) die("concat: inputs of different formats");
