@@ -210,15 +210,30 @@ def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, 
            "kind": "port", "sample": "oracle.%s (C++ restatement of the reference operator, NOT IgnisHPC/Go) on the first %d records "
                                      "(%.3f GB) of the same input, %.2f s, 1 thread of %d host cores" % (fn_name, srec, srec * rec_bytes / 1e9, ct, os.cpu_count())}
     if all_cores:
+        # the restatement allocates per record like the Go code it restates: with every hardware thread at once the heaps of
+        # 256 arenas grow through one address space's mmap lock and `subseq` ran at 5.6 M records/s on 256 threads against
+        # 3.2 on one.  So the leg climbs -- 1/16, 1/4, all of the hardware threads -- and reports the best of them with the
+        # thread count it used; it stops climbing when more threads gave less.
         try:
             from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(nthr) as ex:
-                list(ex.map(lambda k: call(k * per, min(per, 64)), range(nthr)))   # threads started
-                t0 = time.perf_counter()
-                list(ex.map(lambda k: call(k * per, per), range(nthr)))
-                ct = time.perf_counter() - t0
-            out["all_cores"] = {"value": round(per * nthr / ct / 1e6, 2), "unit": "M records/s", "gb_per_s": round(per * nthr * rec_bytes / ct / 1e9, 2),
-                                "cores": nthr, "kind": "port", "sample": "%d threads x %d records (%.2f GB), one pass, %.2f s" % (nthr, per, per * nthr * rec_bytes / 1e9, ct)}
+            best = None
+            tried = []
+            for T in sorted({max(1, nthr // 16), max(1, nthr // 4), nthr}):
+                with ThreadPoolExecutor(T) as ex:
+                    list(ex.map(lambda k: call(k * per, min(per, 64)), range(T)))   # threads started
+                    t0 = time.perf_counter()
+                    list(ex.map(lambda k: call(k * per, per), range(T)))
+                    ct = time.perf_counter() - t0
+                val = per * T / ct / 1e6
+                tried.append("%d threads: %.2f" % (T, val))
+                if best is None or val > best[0]:
+                    best = (val, T, ct)
+                elif val < 0.8 * best[0]:
+                    break
+            val, T, ct = best
+            out["all_cores"] = {"value": round(val, 2), "unit": "M records/s", "gb_per_s": round(val * 1e6 * rec_bytes / 1e9, 2),
+                                "cores": T, "kind": "port", "sample": "%d threads x %d records (%.2f GB), one pass, %.2f s; M records/s by thread count: %s"
+                                                                      % (T, per, per * T * rec_bytes / 1e9, ct, ", ".join(tried))}
         except Exception as e:
             out["all_cores"] = {"error": str(e)[:200]}
     return out
