@@ -47,14 +47,18 @@ struct TileLds {
     __device__ __forceinline__ void stage(const CUR& cur, uint64_t tile_idx) {
         const uint32_t lane = threadIdx.x & 63u;
         const bool cont = staged != ~0ull && tile_idx == staged + stream::TILE;  // (wave-uniform)
-        if (cont) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (lane < CARRY / 16u) v = lds_r128(tb + stream::TILE + lane * 16u);  // the last CARRY bytes of the old tile
-            if (lane < CARRY / 16u) lds_w128(tb + lane * 16u, v);
-        }
+        // The carry is READ first and WRITTEN last: a wave's LDS instructions execute in order, so the tile's own writes
+        // (the last of which covers the bytes the carry is read from) may be issued behind the read without waiting for
+        // its data -- the read's latency passes while they issue, where read -> wait -> write used to stand in front of them.
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cont && lane < CARRY / 16u) v = lds_r128(tb + stream::TILE + lane * 16u);  // the last CARRY bytes of the old tile
+        // (the bytes this lane reads are overwritten by OTHER lanes' stores below: per thread the compiler sees no alias and
+        // may sink the load under them -- it did.  A compiler-only barrier: the order of issue is what has to hold)
+        asm volatile("" ::: "memory");
         carry_ok = cont;
 #pragma unroll
         for (int p = 0; p < stream::NPIECE; ++p) lds_w128(tb + CARRY + (uint32_t)p * stream::PIECE_BYTES + lane * 16u, cur[p]);
+        if (cont && lane < CARRY / 16u) lds_w128(tb + lane * 16u, v);
         staged = tile_idx;
         stream::wave_lds_fence();
     }
