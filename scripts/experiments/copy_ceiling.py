@@ -20,3 +20,9 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): b64.copy_(a64)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print("torch copy_ i64 %.2f ms = %.2f TB/s" % (dt * 1e3, 2 * n / dt / 1e12))
+# ... and a plain READ of the same bytes: torch's sum over int64 / int32 views (a vendor reduction kernel)
+for name, v in (("torch sum i64", a64), ("torch sum i32", a.view(torch.int32))):
+    v.sum(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): s = v.sum()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print("%-14s %.2f ms for %.0f GB = %.2f TB/s" % (name, dt * 1e3, n / 1e9, n / dt / 1e12))
