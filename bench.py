@@ -239,6 +239,31 @@ def cpu_baseline_op(H, fn_name, opts, tensor, rec_bytes, fastq, all_cores=True, 
     return out
 
 
+def vendor_yardsticks(torch, dev, gb=20.0):
+    """What VENDOR kernels move on this box, beside the 8 TB/s of the data sheet that `frac` is quoted against: a plain
+    device-to-device copy (torch `copy_` = the runtime's copy kernel; read + write bytes) and a plain read (`torch.sum`
+    over an int64 view).  Five calls each after one warm-up, HBM-resident."""
+    n = int(gb * 1e9) // 8 * 8
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.random_(0, 255)
+
+    def rate(fn, nbytes):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        return round(nbytes / ((time.perf_counter() - t0) / 5) / 1e9, 1)
+    a64 = a.view(torch.int64)
+    out = {"bytes": n, "d2d_copy_GBps_read_plus_write": rate(lambda: b.copy_(a), 2 * n), "read_sum_int64_GBps": rate(lambda: a64.sum(), n),
+           "note": "torch / runtime kernels on the same GPU in the same run: what a copy and a reduction reach of the 8 000 GB/s peak"}
+    del a, b, a64
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_end_to_end(H, gb=8.0):
     """File-to-result rates with the input in HOST memory (pinned): what a caller that hands libbsk a file's bytes gets --
     PCIe Gen5 x16 (~55 GB/s) in, and for the record operators the output back out and into files.  `stats` -> the map;
@@ -1294,6 +1319,10 @@ def main():
                 out["end_to_end"] = run_end_to_end(_Helpers(args, torch, bsk, _lib, lib, check, dev, local), 8.0 * min(1.0, args.ops_scale * 4))
             except Exception as e:
                 out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+            try:
+                out["vendor_yardsticks"] = vendor_yardsticks(torch, dev, 20.0 * min(1.0, args.ops_scale * 4))
+            except Exception as e:
+                out["vendor_yardsticks"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         else:
             out["ops"] = {"skipped": "the 'ops' workloads are defined at the full BASELINE sizes (--gb 100) or with --ops-scale"}
     if scaling_model is not None:
