@@ -157,6 +157,12 @@ SIGNATURES = {
     "bsk_count_allreduce": (_i, [_vp, _p(_u64), _vp]),
     "bsk_stats_collect_reduced": (_i, [_vp, _vp, _vp, _vp, _p(_i64), _p(_i64), _sz, _p(_sz)]),
     "bsk_rmdup_dist_run": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _p(Out)]),
+    "bsk_rmdup_dist_xpack": (_i, [_vp, _vp, _vp, _vp, C.c_uint64, _p(C.c_uint64), _i, _p(C.c_uint64), _p(C.c_uint64), _p(_vp), _p(_vp), _vp]),
+    "bsk_rmdup_dist_xcompare": (_i, [_vp, _vp, _p(C.c_uint64), _vp, _p(C.c_uint64), _i, _vp, _vp]),
+    "bsk_rmdup_dist_xapply": (_i, [_vp, _vp, _p(C.c_uint64), _p(C.c_uint64), _vp]),
+    "bsk_rmdup_dist_flagged_get": (_i, [_vp, _vp, _sz, _p(_sz)]),
+    "bsk_rmdup_dist_flagged_settle": (_i, [_vp, _vp, _sz]),
+    "bsk_rmdup_dist_stats": (_i, [_vp, _p(C.c_uint64), _p(C.c_uint64), _p(C.c_uint64)]),
     "bsk_shard_load": (_i, [_i, _u64, _sz, _i, _i, C.POINTER(_vp)]),
     "bsk_synth_record_bytes": (_sz, [_i]),
     "bsk_synth_offset": (_u64, [_i, _u64]),

@@ -273,6 +273,8 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_keys_sparse) hipFree(c->d_keys_sparse);
         if (c->d_ovf) hipFree(c->d_ovf);
         if (c->d_own) hipFree(c->d_own);
+        for (void* p : {(void*)c->d_xreq, (void*)c->d_xtext, (void*)c->d_xflag, (void*)c->d_xres})
+            if (p) hipFree(p);
         if (c->d_set_keys) hipFree(c->d_set_keys);
         if (c->d_set_idx) hipFree(c->d_set_idx);
         if (c->d_pat_off) hipFree(c->d_pat_off);
@@ -326,6 +328,7 @@ int bsk_stats_reset(bsk_ctx* c, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(c, hipMemsetAsync(c->d_vec, 0, ((size_t)STATS_HDR + c->hist_cap) * sizeof(uint64_t), st));
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
+    c->vec_reduced = false;
     return BSK_OK;
 }
 
@@ -1241,6 +1244,64 @@ int bsk_rmdup_dist_emit_ex(bsk_ctx* c, const void* d_send, const void* d_reply, 
     rc = rmdup_dist_emit(c, (const uint64_t*)d_send, (const uint8_t*)d_reply, base_index, (hipStream_t)stream, out, (const uint64_t*)d_survivor_reply);
     if (local_pairs_verified) *local_pairs_verified = rc == BSK_OK ? c->dist_local_pairs : 0;
     return rc;
+}
+
+int bsk_rmdup_dist_xpack(bsk_ctx* c, const void* d_send, const void* d_reply, const void* d_survivor_reply, uint64_t base_index,
+                         const uint64_t* rank_base, int world, uint64_t* req_counts, uint64_t* byte_counts, void** d_requests, void** d_text,
+                         void* stream) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_xpack");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (world < 1 || world > 64 || !rank_base || !req_counts || !byte_counts || !d_requests || !d_text ||
+        (c->table.n && (!d_send || !d_reply || !d_survivor_reply)))
+        return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad xpack arguments");
+    return rmdup_dist_xpack(c, (const uint64_t*)d_send, (const uint8_t*)d_reply, (const uint64_t*)d_survivor_reply, base_index, rank_base, world,
+                            req_counts, byte_counts, d_requests, d_text, (hipStream_t)stream);
+}
+
+int bsk_rmdup_dist_xcompare(bsk_ctx* c, const void* d_requests_in, const uint64_t* req_from, const void* d_text_in, const uint64_t* bytes_from,
+                            int world, void* d_verdict, void* stream) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_xcompare");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (world < 1 || world > 64 || !req_from || !bytes_from) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: bad xcompare arguments");
+    uint64_t m = 0;
+    for (int r = 0; r < world; ++r) m += req_from[r];
+    if (m && (!d_requests_in || !d_verdict)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null requests / verdict");
+    return rmdup_dist_xcompare(c, (const uint64_t*)d_requests_in, req_from, (const uint8_t*)d_text_in, bytes_from, world, (uint8_t*)d_verdict,
+                               (hipStream_t)stream);
+}
+
+int bsk_rmdup_dist_xapply(bsk_ctx* c, const void* d_verdict_back, uint64_t* n_flagged, uint64_t* pairs_compared, void* stream) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_xapply");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (!n_flagged || (c->x_m_req && !d_verdict_back)) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null verdicts / n_flagged");
+    return rmdup_dist_xapply(c, (const uint8_t*)d_verdict_back, n_flagged, pairs_compared, (hipStream_t)stream);
+}
+
+int bsk_rmdup_dist_flagged_get(bsk_ctx* c, void* buf, size_t cap, size_t* need) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_flagged_get");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (!need) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null need");
+    return rmdup_dist_flagged_get(c, buf, cap, need, nullptr);
+}
+
+int bsk_rmdup_dist_flagged_settle(bsk_ctx* c, const void* all, size_t n) {
+    int rc = dist_enter(c, "bsk_rmdup_dist_flagged_settle");
+    if (rc != BSK_OK) return rc;
+    BSK_ENTER(c);
+    if (n && !all) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null lists");
+    return rmdup_dist_flagged_settle(c, all, n, nullptr);
+}
+
+int bsk_rmdup_dist_stats(const bsk_ctx* c, uint64_t* local_pairs, uint64_t* cross_pairs, uint64_t* flagged) {
+    if (!c) return fail_global(BSK_ERR_INVALID_ARG, "libbsk: null context");
+    if (local_pairs) *local_pairs = c->dist_local_pairs;
+    if (cross_pairs) *cross_pairs = c->dist_cross_pairs;
+    if (flagged) *flagged = c->x_flag_host.size();
+    return BSK_OK;
 }
 
 int bsk_rmdup_dist_emit(bsk_ctx* c, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,

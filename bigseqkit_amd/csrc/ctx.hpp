@@ -28,7 +28,7 @@
 struct bsk_tuning {
     static const char* const* names() {
         static const char* const N[] = {"filter", "grep_shiftand", "index", "locate_nopre", "long_bytes", "min_range_bytes", "names",
-                                        "names_scale", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_keys", "rmdup_place", "scan", "segcopy",
+                                        "names_scale", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_k2_bits", "rmdup_keys", "rmdup_place", "rmdup_xcheck", "rmdup_xlocal", "scan", "segcopy",
                                         "sort", "stage_bytes", "stats_a", "stats_fasta", "subseq", "subseq_scale", "text", "translate", "translate_index", "translate_stream", "tr_lanes", nullptr};
         return N;
     }
@@ -66,6 +66,8 @@ struct bsk_ctx {
     // context per caller thread.  A second call that arrives while one is running is refused (BSK_ERR_INVALID_ARG,
     // "context busy"), not raced.
     std::atomic<bool> busy{false};
+    std::atomic<bool> reducing{false};  // a bsk_stats_collect_reduced is running on this context (its phases take `busy` one after the other)
+    bool vec_reduced = false;           // the context's own stats vector went through an all-reduce since the last bsk_stats_reset
 
     // ---- device state shared by the ops -----------------------------------
     int num_cus = 0;
@@ -191,6 +193,26 @@ struct bsk_ctx {
     const uint8_t* dist_buf = nullptr;
     size_t dist_n = 0;
     int dist_format = -1;
+    // round 6, the text comparison of duplicates whose survivor lives on another rank (ops_rmdup_xcheck.hip): this rank's
+    // requests and the subjects that go with them, the records whose text differs from their survivor's ("flagged"), and
+    // those of them that survive after the exact settlement (first of their TEXT over all ranks)
+    uint64_t* d_xreq = nullptr;
+    uint64_t xreq_cap = 0;          // words
+    uint8_t* d_xtext = nullptr;
+    uint64_t xtext_cap = 0;
+    uint32_t* d_xflag = nullptr;    // [0] count, entries from [1]
+    uint64_t xflag_cap = 0;
+    uint32_t* d_xres = nullptr;
+    uint64_t xres_cap = 0;
+    uint32_t xres_n = 0;
+    uint64_t x_m_req = 0, x_base = 0;
+    const uint64_t* x_send = nullptr;
+    const uint8_t* x_reply = nullptr;
+    const uint64_t* x_surv = nullptr;
+    bool dist_xchecked = false;     // bsk_rmdup_dist_xapply ran: the emit does not compare the local pairs again
+    uint64_t dist_cross_pairs = 0;  // duplicates of the last exchange whose survivor lives on another rank (their text went there)
+    std::vector<uint32_t> x_flag_host;  // the flagged records of this shard, ascending
+    std::string x_flag_blob;            // ... serialised for the exchange (bsk_rmdup_dist_flagged_get)
     // -d / -D: what RmDupCheck accumulates until After() (rmdup.go:100-104, 224-238)
     std::string dup_seqs, dup_nums;
     uint64_t removed = 0;

@@ -44,6 +44,14 @@ int rmdup_dist_pack(bsk_ctx* c, uint64_t base, int world, uint64_t* d_send, uint
 int rmdup_dist_resolve(bsk_ctx* c, const uint64_t* d_tuples, uint64_t m, uint8_t* d_keep, hipStream_t st, uint64_t* d_surv = nullptr);
 int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, uint64_t base, hipStream_t st, bsk_out* out,
                     const uint64_t* d_surv_reply = nullptr);
+// round 6: the text comparison of duplicates whose survivor lives on another rank (ops_host_rmdup.cpp, include/bsk.h)
+int rmdup_dist_xpack(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, const uint64_t* d_surv, uint64_t base,
+                     const uint64_t* rank_base, int world, uint64_t* req_cnt, uint64_t* byte_cnt, void** d_req, void** d_text, hipStream_t st);
+int rmdup_dist_xcompare(bsk_ctx* c, const uint64_t* d_req_in, const uint64_t* req_from, const uint8_t* d_text_in, const uint64_t* bytes_from,
+                        int world, uint8_t* d_verdict, hipStream_t st);
+int rmdup_dist_xapply(bsk_ctx* c, const uint8_t* d_verdict_back, uint64_t* n_flagged, uint64_t* pairs_compared, hipStream_t st);
+int rmdup_dist_flagged_get(bsk_ctx* c, void* buf, size_t cap, size_t* need, hipStream_t st);
+int rmdup_dist_flagged_settle(bsk_ctx* c, const void* all, size_t n, hipStream_t st);
 int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);
 void validate_locate_opts(bsk_ctx* c);
 int locate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out);

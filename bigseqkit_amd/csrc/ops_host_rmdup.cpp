@@ -26,6 +26,7 @@
 #include "ops_mlfq.hpp"
 #include "ops_records.hpp"
 #include "ops_rmdup.hpp"
+#include "ops_rmdup_xcheck.hpp"
 #include "ops_text.hpp"
 #include "ops_translate.hpp"
 #include "ops_segcopy.hpp"
@@ -136,6 +137,8 @@ static int rmdup_settle_overflow(bsk_ctx* c, uint32_t* d_first, hipStream_t st, 
     return rc;
 }
 
+static int rmdup_settle_first(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint32_t* d_first, hipStream_t st);
+
 int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipStream_t st, bsk_out* out) {
     const Options& o = c->opts;
     const bool fastq = format == BSK_FORMAT_FASTQ;
@@ -147,7 +150,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
     // "off" -- the separate hash kernel and the byte-comparing table path
     bool by_keys = fastq && o.b("BySeq");
     bool verify_bytes = true;
-    uint32_t k1_bits = 64;
+    uint32_t k1_bits = 64, k2_bits = 64;
     {
         const char* e = c->tune.get("rmdup");
         if (e && strcmp(e, "table") == 0) by_keys = false;
@@ -156,6 +159,8 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         if (e && (strcmp(e, "two-key") == 0 || strcmp(e, "keys") == 0)) verify_bytes = false;
         e = c->tune.get("rmdup_k1_bits");                         // tests: keep only the low bits of k1 (forces the overflow list)
         if (e && atoi(e) >= 16 && atoi(e) < 64) k1_bits = (uint32_t)atoi(e);
+        e = c->tune.get("rmdup_k2_bits");                         // tests: ... and of k2 (different sequences under one PAIR of keys: the exact settlement)
+        if (e && atoi(e) >= 1 && atoi(e) < 64) k2_bits = (uint32_t)atoi(e);
     }
     int rc;
     TextTableH tt;
@@ -203,8 +208,10 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         Timed t(c, "k_rmdup_hash", st);
         HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, P, c->d_keys, nullptr, st));
         HIP_TRYX(c, launch_rmdup_hash_long(d_buf, n, c->table, tt, P, c->d_keys, nullptr, c->d_long_list, c->flat_long_count, st));
-    } else if (k1_bits < 64) {
-        HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << k1_bits) - 1ull, st));
+        if (k1_bits < 64) HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << k1_bits) - 1ull, st));
+    } else {
+        if (k1_bits < 64) HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << k1_bits) - 1ull, st));
+        if (with_k2 && k2_bits < 64) HIP_TRYX(c, launch_mask_keys(c->d_keys2, N, (1ull << k2_bits) - 1ull, st));
     }
     // grouping: radix buckets + one LDS table per bucket (ops_rmdup.hip); BSK_RMDUP=table (and any shard on which a bucket
     // overflows, or with 2^32 records) keeps the one big table in HBM
@@ -291,7 +298,7 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         }
     }
     if (!by_buckets) {
-        if (by_keys && k1_bits < 64) {
+        if (k1_bits < 64) {
             c->set_error("libbsk: BSK_RMDUP_K1_BITS is a test switch of the key path; the table path needs whole keys");
             return BSK_ERR_INVALID_ARG;
         }
@@ -331,6 +338,22 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         with_k2 = true;
         placed = false;
         continue;
+    }
+    if (rc == BSK_ERR_UNSUPPORTED && by_buckets && (with_k2 || !by_keys) && (c->last_kernel_flags & ERR_HASH_COLLISION) &&
+        !(c->last_kernel_flags & ~(uint64_t)ERR_HASH_COLLISION)) {
+        // Round 6: two different subjects under one key group even so (both keys equal: about N^2 / 2^129 per shard; the
+        // tests mask the keys).  RmDupCheck keys its map by the subject TEXT (rmdup.go:193-211): both survive.  The
+        // records that differ from the record their group names are regrouped by text on the host, first[] is put right,
+        // and the sizes follow from it without another look at the text.
+        uint64_t zero = 0;
+        HIP_TRYX(c, hipMemcpyAsync(c->d_status, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+        HIP_TRYX(c, hipStreamSynchronize(st));
+        c->set_error("");
+        rc = rmdup_settle_first(c, d_buf, tt, P, d_first, st);
+        if (rc != BSK_OK) return rc;
+        placed = false;
+        HIP_TRYX(c, launch_rmdup_sizes(c->table, P, d_first, c->d_out_len, st));
+        rc = finish_sizes(c, st, &total, &kept);
     }
     if (rc != BSK_OK) return rc;
     rc = ensure_out(c, total);
@@ -482,6 +505,8 @@ int rmdup_dist_keys(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     if (!fused) HIP_TRYX(c, launch_rmdup_hash(d_buf, n, c->table, tt, rmdup_params(c, format == BSK_FORMAT_FASTQ), c->d_keys, c->d_keys2, st));
     if (const char* e = c->tune.get("rmdup_k1_bits"))  // tests: only the low bits of k1 (different subjects under one k1 at the owner)
         if (atoi(e) >= 16 && atoi(e) < 64) HIP_TRYX(c, launch_mask_keys(c->d_keys, N, (1ull << atoi(e)) - 1ull, st));
+    if (const char* e = c->tune.get("rmdup_k2_bits"))  // tests: ... and of k2 (different subjects under one PAIR of keys: the text comparison across ranks)
+        if (atoi(e) >= 1 && atoi(e) < 64) HIP_TRYX(c, launch_mask_keys(c->d_keys2, N, (1ull << atoi(e)) - 1ull, st));
     HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIP_TRYX(c, hipStreamSynchronize(st));
     return kernel_error_to_status(c, status);
@@ -585,12 +610,18 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     if (rc != BSK_OK) return rc;
     HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint64_t), st));
     HIP_TRYX(c, launch_rmdup_apply(c->table, rmdup_params(c, fastq), d_send, d_reply, base, c->d_out_len, st));
-    if (d_surv_reply && fastq && c->opts.b("BySeq") && N < (1ull << 32)) {
-        // Round 5: across ranks equal (k1, k2) decide -- the owner holds no text -- but a
-        // duplicate whose survivor lives in THIS shard can be held to RmDupCheck's own test (rmdup.go:193-199) for the
-        // price of the comparison: the owner's reply names the survivor's global index, the pairs inside the shard go
-        // through the byte comparison of the single-GPU call; a difference fails the call (ERR_HASH_COLLISION), as there.
-        // Pairs that cross ranks stay with the two keys (PARITY.md KEYS).
+    const bool xchecked = c->dist_xchecked;  // (bsk_rmdup_dist_xapply compared every pair, local and across ranks)
+    c->dist_xchecked = false;
+    if (xchecked) {
+        // the flagged records that are the first of their TEXT over all ranks survive after all (rmdup_dist_flagged_settle)
+        if (c->xres_n) HIP_TRYX(c, launch_x_resurrect(c->table, rmdup_params(c, fastq), c->d_xres, c->xres_n, c->d_out_len, st));
+        c->xres_n = 0;
+    } else if (d_surv_reply && fastq && c->opts.b("BySeq") && N < (1ull << 32)) {
+        // Round 5: a caller that does NOT run the cross-rank check (bsk_rmdup_dist_x*) still
+        // has the duplicates whose survivor lives in THIS shard held to RmDupCheck's own test (rmdup.go:193-199): the
+        // owner's reply names the survivor's global index, the pairs inside the shard go through the byte comparison of
+        // the single-GPU call; a difference fails the call (ERR_HASH_COLLISION).  Pairs that cross ranks then rest on the
+        // two keys (PARITY.md KEYS).
         Arena A;
         const uint64_t o_first = A.take(N * 4);
         rc = arena_reserve(c, &A);
@@ -614,7 +645,345 @@ int rmdup_dist_emit(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, 
     out->d_data = c->d_out;
     out->len = total;
     out->records = kept;
-    c->dist_local_pairs = d_surv_reply ? c->fin(bsk_ctx::FIN_AUX0) : 0;   // (came back with the size pass's read-back)
+    if (!xchecked) c->dist_local_pairs = d_surv_reply ? c->fin(bsk_ctx::FIN_AUX0) : 0;   // (came back with the size pass's read-back)
+    return BSK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Round 6: RmDupCheck's text comparison (bigseqkit-lib/rmdup.go:193-211) for EVERY duplicate of the multi-GPU path, also the
+// ones whose survivor lives on another rank (7 of 8 at C5 on eight GPUs; until round 5 they rested on the two keys).
+//   xpack    : per destination rank the requests of this shard's cross-rank duplicates and their subject text
+//              [requests all-to-all, text all-to-all]
+//   xcompare : survivor side, one verdict byte per request                [verdicts back the same routes]
+//   xapply   : the requests that came back "differs" and the local pairs that differ -> the flagged list
+//              [sum of the flagged counts; only when it is not zero: the flagged texts to every rank]
+//   flagged_get / flagged_settle : the exact settlement of flagged records on the host -- grouped by TEXT over all ranks,
+//              the lowest global index of every text survives: what RmDupCheck's map keyed by the subject decides
+// ---------------------------------------------------------------------------
+static TextTableH dist_text(bsk_ctx* c, bool fastq) {
+    TextTableH tt;
+    tt.text_w = fastq ? nullptr : c->table.text_w;
+    tt.lin_off = fastq ? nullptr : c->d_lin_off;
+    tt.lin = fastq ? nullptr : c->d_lin;
+    tt.lin_n = 0;
+    return tt;
+}
+
+constexpr uint64_t XFLAG_MAX = 1u << 20;  // more flagged records than this: the call fails (keys that collide a million times are no keys)
+
+int rmdup_dist_xpack(bsk_ctx* c, const uint64_t* d_send, const uint8_t* d_reply, const uint64_t* d_surv, uint64_t base,
+                     const uint64_t* rank_base, int world, uint64_t* req_cnt, uint64_t* byte_cnt, void** d_req, void** d_text,
+                     hipStream_t st) {
+    const uint64_t N = c->table.n;
+    for (int r = 0; r < world; ++r) req_cnt[r] = byte_cnt[r] = 0;
+    c->x_send = d_send; c->x_reply = d_reply; c->x_surv = d_surv; c->x_base = base;
+    c->x_m_req = 0;
+    c->dist_cross_pairs = 0;
+    c->xres_n = 0;
+    c->x_flag_host.clear();
+    c->x_flag_blob.clear();
+    *d_req = nullptr;
+    *d_text = nullptr;
+    if (N == 0) return BSK_OK;
+    XRanks R;
+    memset(&R, 0, sizeof R);
+    R.world = (uint32_t)world;
+    int rank = -1;
+    for (int r = 0; r <= world; ++r) R.base[r] = rank_base[r];
+    for (int r = 0; r < world; ++r)
+        if (rank_base[r] == base && rank_base[r + 1] == base + N) { rank = r; break; }
+    if (rank < 0) { c->set_error("libbsk: rmdup: this shard's records are not a range of rank_base[]"); return BSK_ERR_INVALID_ARG; }
+    R.rank = (uint32_t)rank;
+    const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
+    const TextTableH tt = dist_text(c, fastq);
+    const RmDupParams P = rmdup_params(c, fastq);
+    int rc = grow(c, &c->d_scan_tmp, &c->scan_tmp_cap, 4 * XCHECK_MAX_WORLD + 16, 16);
+    if (rc != BSK_OK) return rc;
+    uint64_t* d_cnt = c->d_scan_tmp;              // [64] requests per destination, [64] bytes, then the two cursor arrays
+    uint64_t* d_bytes = d_cnt + XCHECK_MAX_WORLD;
+    HIP_TRYX(c, hipMemsetAsync(d_cnt, 0, 4 * XCHECK_MAX_WORLD * sizeof(uint64_t), st));
+    HIP_TRYX(c, launch_x_count(c->dist_buf, c->table, tt, P, d_send, d_reply, d_surv, N, R, d_cnt, d_bytes, st));
+    uint64_t h[2 * XCHECK_MAX_WORLD];
+    HIP_TRYX(c, hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    uint64_t m = 0, nb = 0;
+    XFrom seg;
+    memset(&seg, 0, sizeof seg);
+    seg.world = (uint32_t)world;
+    uint64_t cur[2 * XCHECK_MAX_WORLD];
+    memset(cur, 0, sizeof cur);
+    for (int r = 0; r < world; ++r) {
+        req_cnt[r] = h[r];
+        byte_cnt[r] = h[XCHECK_MAX_WORLD + r];
+        cur[r] = m;                 // requests of destination r begin here ...
+        seg.req_start[r] = m;
+        seg.byte_start[r] = nb;     // ... and their text here
+        m += h[r];
+        nb += h[XCHECK_MAX_WORLD + r];
+    }
+    seg.req_start[world] = m;
+    seg.byte_start[world] = nb;
+    c->x_m_req = m;
+    c->dist_cross_pairs = m;
+    if (m == 0) return BSK_OK;
+    rc = grow(c, &c->d_xreq, &c->xreq_cap, XREQ_WORDS * m, m / 4 + 64);
+    if (rc != BSK_OK) return rc;
+    rc = grow(c, &c->d_xtext, &c->xtext_cap, nb + 16, nb / 8 + 64);
+    if (rc != BSK_OK) return rc;
+    uint64_t* d_cur = d_cnt + 2 * XCHECK_MAX_WORLD;
+    HIP_TRYX(c, hipMemcpyAsync(d_cur, cur, sizeof cur, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, launch_x_place(c->dist_buf, c->table, tt, P, d_send, d_reply, d_surv, N, R, d_cur, d_cur + XCHECK_MAX_WORLD, c->d_xreq, st));
+    HIP_TRYX(c, launch_x_copy(c->dist_buf, c->table, tt, P, c->d_xreq, m, R, seg, c->d_xtext, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));  // (cur lives on this stack; the caller hands the buffers to a collective next)
+    *d_req = c->d_xreq;
+    *d_text = c->d_xtext;
+    return BSK_OK;
+}
+
+int rmdup_dist_xcompare(bsk_ctx* c, const uint64_t* d_req_in, const uint64_t* req_from, const uint8_t* d_text_in, const uint64_t* bytes_from,
+                        int world, uint8_t* d_verdict, hipStream_t st) {
+    XFrom from;
+    memset(&from, 0, sizeof from);
+    from.world = (uint32_t)world;
+    uint64_t m = 0, nb = 0;
+    for (int r = 0; r < world; ++r) {
+        from.req_start[r] = m;
+        from.byte_start[r] = nb;
+        m += req_from[r];
+        nb += bytes_from[r];
+    }
+    from.req_start[world] = m;
+    from.byte_start[world] = nb;
+    if (m == 0) return BSK_OK;
+    const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
+    HIP_TRYX(c, launch_x_compare(c->dist_buf, c->table, dist_text(c, fastq), rmdup_params(c, fastq), d_req_in, m, from, d_text_in, c->x_base,
+                                 d_verdict, c->d_status, st));
+    uint64_t status = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    if (status & ERR_HASH_COLLISION) {  // (k_x_compare: a request that names no record of this shard, or text outside its segment)
+        HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, sizeof(uint64_t), st));
+        c->set_error("libbsk: rmdup: a request of the cross-rank comparison names no record of this shard");
+        return BSK_ERR_INVALID_ARG;
+    }
+    return kernel_error_to_status(c, status);
+}
+
+// the flagged list (count word + entries) of the running exchange, emptied
+static int xflag_reset(bsk_ctx* c, hipStream_t st) {
+    int rc = grow(c, &c->d_xflag, &c->xflag_cap, XFLAG_MAX + 1);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, hipMemsetAsync(c->d_xflag, 0, sizeof(uint32_t), st));
+    return BSK_OK;
+}
+// ... brought to the host, ascending (c->x_flag_host)
+static int xflag_fetch(bsk_ctx* c, hipStream_t st) {
+    uint32_t cnt = 0;
+    HIP_TRYX(c, hipMemcpyAsync(&cnt, c->d_xflag, sizeof cnt, hipMemcpyDeviceToHost, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    c->x_flag_host.clear();
+    if (cnt == 0) return BSK_OK;
+    if (cnt > XFLAG_MAX) {
+        c->set_error("libbsk: rmdup: more than 2^20 records differ from the survivor of their key group; refusing (keys that collide that often are no keys)");
+        return BSK_ERR_UNSUPPORTED;
+    }
+    c->x_flag_host.resize(cnt);
+    HIP_TRYX(c, hipMemcpy(c->x_flag_host.data(), c->d_xflag + 1, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    std::sort(c->x_flag_host.begin(), c->x_flag_host.end());
+    return BSK_OK;
+}
+
+int rmdup_dist_xapply(bsk_ctx* c, const uint8_t* d_verdict_back, uint64_t* n_flagged, uint64_t* pairs_compared, hipStream_t st) {
+    const uint64_t N = c->table.n;
+    *n_flagged = 0;
+    if (pairs_compared) *pairs_compared = 0;
+    c->dist_xchecked = true;
+    c->dist_local_pairs = 0;
+    c->xres_n = 0;
+    if (N == 0) return BSK_OK;
+    const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
+    const TextTableH tt = dist_text(c, fastq);
+    const RmDupParams P = rmdup_params(c, fastq);
+    int rc = xflag_reset(c, st);
+    if (rc != BSK_OK) return rc;
+    if (c->x_m_req) HIP_TRYX(c, launch_x_apply(c->d_xreq, d_verdict_back, c->x_m_req, c->d_xflag, (uint32_t)XFLAG_MAX, st));
+    // the pairs inside the shard.  `-s` on FASTQ: the comparison kernel of the single-GPU call (4 lanes per duplicate, raises
+    // a flag); only when it has found a difference does the listing kernel walk the pairs again.  Every other subject
+    // (names, IDs, wrapped FASTA) goes to the listing kernel at once.
+    uint64_t* d_nloc = c->d_fin + bsk_ctx::FIN_AUX0;
+    HIP_TRYX(c, hipMemsetAsync(d_nloc, 0, sizeof(uint64_t), st));
+    bool listed = false;
+    if (fastq && c->opts.b("BySeq") && N < (1ull << 32) && !c->tune.is("rmdup_xlocal", "list")) {
+        Arena A;
+        const uint64_t o_first = A.take(N * 4);
+        rc = arena_reserve(c, &A);
+        if (rc != BSK_OK) return rc;
+        HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_dist_first(c->x_send, c->x_reply, c->x_surv, N, c->x_base, A.at<uint32_t>(o_first), d_nloc, st));
+        {
+            Timed t(c, "k_rmdup_verify", st);
+            HIP_TRYX(c, launch_rmdup_verify_fastq(c->dist_buf, c->table, P, A.at<uint32_t>(o_first), nullptr, c->d_status, st));
+        }
+        rc = ctl_readback(c, st);
+        if (rc != BSK_OK) return rc;
+        c->dist_local_pairs = c->fin(bsk_ctx::FIN_AUX0);
+        const uint64_t status = c->status_word();
+        if (status & ERR_HASH_COLLISION) {
+            uint64_t rest = status & ~(uint64_t)ERR_HASH_COLLISION;
+            HIP_TRYX(c, hipMemcpyAsync(c->d_status, &rest, sizeof rest, hipMemcpyHostToDevice, st));
+            HIP_TRYX(c, hipStreamSynchronize(st));
+            if (rest) return kernel_error_to_status(c, rest);
+        } else {
+            rc = kernel_error_to_status(c, status);
+            if (rc != BSK_OK) return rc;
+            listed = true;  // (nothing to list)
+        }
+    }
+    if (!listed) {
+        HIP_TRYX(c, hipMemsetAsync(d_nloc, 0, sizeof(uint64_t), st));
+        HIP_TRYX(c, launch_x_local_list(c->dist_buf, c->table, tt, P, c->x_send, c->x_reply, c->x_surv, N, c->x_base, c->d_xflag,
+                                        (uint32_t)XFLAG_MAX, d_nloc, st));
+        rc = ctl_readback(c, st);
+        if (rc != BSK_OK) return rc;
+        c->dist_local_pairs = c->fin(bsk_ctx::FIN_AUX0);
+    }
+    rc = xflag_fetch(c, st);
+    if (rc != BSK_OK) return rc;
+    *n_flagged = c->x_flag_host.size();
+    if (pairs_compared) *pairs_compared = c->dist_local_pairs + c->x_m_req;
+    return BSK_OK;
+}
+
+// the flagged records of c->x_flag_host with their subject text: entries {u64 global index, u64 length, bytes padded to 8}
+static int xflag_serialise(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint64_t base, hipStream_t st,
+                           std::string* blob) {
+    blob->clear();
+    const uint32_t m = (uint32_t)c->x_flag_host.size();
+    if (m == 0) return BSK_OK;
+    uint32_t *d_list = nullptr, *d_len = nullptr;
+    uint64_t* d_off = nullptr;
+    uint8_t* d_txt = nullptr;
+    auto cleanup = [&] { for (void* p : {(void*)d_list, (void*)d_len, (void*)d_off, (void*)d_txt}) if (p) hipFree(p); };
+    int rc = BSK_OK;
+    do {
+        if (hipMalloc((void**)&d_list, (size_t)m * 4) != hipSuccess || hipMalloc((void**)&d_len, (size_t)m * 4) != hipSuccess ||
+            hipMalloc((void**)&d_off, (size_t)m * 8) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+        std::vector<uint32_t> len(m);
+        std::vector<uint64_t> off(m);
+        if (hipMemcpyAsync(d_list, c->x_flag_host.data(), (size_t)m * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            launch_x_subject_len(d_buf, c->table, tt, P, d_list, m, d_len, st) != hipSuccess ||
+            hipMemcpyAsync(len.data(), d_len, (size_t)m * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < m; ++j) { off[j] = total; total += len[j]; }
+        std::string txt(total, '\0');
+        if (total) {
+            if (hipMalloc((void**)&d_txt, total) != hipSuccess ||
+                hipMemcpyAsync(d_off, off.data(), (size_t)m * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+                launch_x_subject_copy(d_buf, c->table, tt, P, d_list, d_off, m, d_txt, st) != hipSuccess ||
+                hipMemcpyAsync(&txt[0], d_txt, total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { rc = BSK_ERR_HIP; break; }
+        }
+        blob->reserve(16 * (size_t)m + total + 8 * (size_t)m);
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint64_t g = base + c->x_flag_host[j], l = len[j];
+            blob->append((const char*)&g, 8);
+            blob->append((const char*)&l, 8);
+            blob->append(txt, off[j], l);
+            blob->append((8 - l % 8) % 8, '\0');
+        }
+    } while (false);
+    cleanup();
+    if (rc != BSK_OK) c->set_error("libbsk: rmdup: fetching the subjects of the flagged records failed on the device");
+    return rc;
+}
+
+// groups the entries of `all` by text (-i: case-folded) and returns, per text, the lowest global index
+static bool xflag_group(const bsk_ctx* c, const uint8_t* all, size_t n, std::unordered_map<std::string, uint64_t>* lowest,
+                        std::vector<std::pair<uint64_t, std::string>>* entries) {
+    const bool fold = c->opts.b("IgnoreCase");
+    size_t p = 0;
+    while (p < n) {
+        if (p + 16 > n) return false;
+        uint64_t g, l;
+        memcpy(&g, all + p, 8);
+        memcpy(&l, all + p + 8, 8);
+        p += 16;
+        const uint64_t padded = l + (8 - l % 8) % 8;
+        if (l > n || p + padded > n) return false;
+        std::string t((const char*)all + p, (size_t)l);
+        p += (size_t)padded;
+        if (fold)
+            for (auto& ch : t) if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32);  // (bytes.ToLower on ASCII letters, as the kernels fold)
+        auto it = lowest->find(t);
+        if (it == lowest->end()) lowest->emplace(t, g);
+        else if (g < it->second) it->second = g;
+        entries->emplace_back(g, std::move(t));
+    }
+    return true;
+}
+
+int rmdup_dist_flagged_get(bsk_ctx* c, void* buf, size_t cap, size_t* need, hipStream_t st) {
+    if (c->x_flag_blob.empty() && !c->x_flag_host.empty()) {
+        const bool fastq = c->dist_format == BSK_FORMAT_FASTQ;
+        const int rc = xflag_serialise(c, c->dist_buf, dist_text(c, fastq), rmdup_params(c, fastq), c->x_base, st, &c->x_flag_blob);
+        if (rc != BSK_OK) return rc;
+    }
+    *need = c->x_flag_blob.size();
+    if (buf && cap >= c->x_flag_blob.size() && !c->x_flag_blob.empty()) memcpy(buf, c->x_flag_blob.data(), c->x_flag_blob.size());
+    return BSK_OK;
+}
+
+int rmdup_dist_flagged_settle(bsk_ctx* c, const void* all, size_t n, hipStream_t st) {
+    std::unordered_map<std::string, uint64_t> lowest;
+    std::vector<std::pair<uint64_t, std::string>> entries;
+    if (!xflag_group(c, (const uint8_t*)all, n, &lowest, &entries)) {
+        c->set_error("libbsk: rmdup: the flagged-record lists of the ranks are malformed");
+        return BSK_ERR_INVALID_ARG;
+    }
+    std::vector<uint32_t> res;
+    const uint64_t base = c->x_base, N = c->table.n;
+    for (auto& e : entries)
+        if (e.first >= base && e.first - base < N && lowest[e.second] == e.first) res.push_back((uint32_t)(e.first - base));
+    std::sort(res.begin(), res.end());
+    res.erase(std::unique(res.begin(), res.end()), res.end());
+    c->xres_n = 0;
+    if (res.empty()) return BSK_OK;
+    int rc = grow(c, &c->d_xres, &c->xres_cap, res.size(), 64);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, hipMemcpyAsync(c->d_xres, res.data(), res.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRYX(c, hipStreamSynchronize(st));
+    c->xres_n = (uint32_t)res.size();
+    return BSK_OK;
+}
+
+// The single-GPU twin (rmdup_run_device): the key groups are in first[]; records whose text differs from the record their
+// group names (two subjects under one pair of keys) are regrouped by text on the host and first[] is put right -- the
+// first of every text names itself, the later ones name it.
+static int rmdup_settle_first(bsk_ctx* c, const uint8_t* d_buf, const TextTableH& tt, const RmDupParams& P, uint32_t* d_first, hipStream_t st) {
+    int rc = xflag_reset(c, st);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_x_first_list(d_buf, c->table, tt, P, d_first, c->d_xflag, (uint32_t)XFLAG_MAX, st));
+    rc = xflag_fetch(c, st);
+    if (rc != BSK_OK) return rc;
+    if (c->x_flag_host.empty()) return BSK_OK;
+    std::string blob;
+    rc = xflag_serialise(c, d_buf, tt, P, 0, st, &blob);
+    if (rc != BSK_OK) return rc;
+    std::unordered_map<std::string, uint64_t> lowest;
+    std::vector<std::pair<uint64_t, std::string>> entries;
+    if (!xflag_group(c, (const uint8_t*)blob.data(), blob.size(), &lowest, &entries)) { c->set_error("libbsk: rmdup: internal list malformed"); return BSK_ERR_INVALID_ARG; }
+    std::vector<uint32_t> pi, pv;
+    for (auto& e : entries) { pi.push_back((uint32_t)e.first); pv.push_back((uint32_t)lowest[e.second]); }
+    uint32_t* d_patch = nullptr;
+    const size_t pm = pi.size();
+    HIP_TRYX(c, hipMalloc((void**)&d_patch, pm * 8));
+    const bool ok = hipMemcpyAsync(d_patch, pi.data(), pm * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+                    hipMemcpyAsync(d_patch + pm, pv.data(), pm * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+                    launch_scatter_u32(d_patch, d_patch + pm, (uint32_t)pm, d_first, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    hipFree(d_patch);
+    if (!ok) { c->set_error("libbsk: rmdup: settling the records that differ from their key group failed on the device"); return BSK_ERR_HIP; }
+    c->x_flag_host.clear();
     return BSK_OK;
 }
 

@@ -252,8 +252,19 @@ class DeviceText:
 # The reference shuffles whole records (GroupByKey, bigseqkit/rmdup.go:97); here 24-byte tuples travel to
 # owner = key % world and one keep byte per tuple travels back (include/bsk.h, "rmdup across ranks").
 # ---------------------------------------------------------------------------
+def _device_view(ptr, shape, typestr, device):
+    """torch view of context-owned device memory (no copy; valid until the context's next phase)"""
+    import torch
+
+    class _Arr:  # __cuda_array_interface__ works for HIP pointers in torch-rocm
+        pass
+    a = _Arr()
+    a.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(a, device=device)
+
+
 class HipRmDupBackend:
-    """The four device phases of libbsk for one rank's HBM-resident shard (a torch uint8 CUDA tensor)."""
+    """The device phases of libbsk for one rank's HBM-resident shard (a torch uint8 CUDA tensor)."""
 
     def __init__(self, opts_json, device=0):
         from .api import Operator
@@ -295,11 +306,61 @@ class HipRmDupBackend:
                                             C.c_void_p(surv.data_ptr()), None), self.op.ctx)
         return keep, surv
 
+    # ---- round 6: RmDupCheck's text comparison for the duplicates whose survivor lives on another rank (include/bsk.h)
+    def xpack(self, send, reply, surv_reply, base, rank_base):
+        """-> (requests [m, 3] int64, text uint8, requests per destination, text bytes per destination); the tensors are
+        views of the context's send buffers"""
+        import torch
+        world = len(rank_base) - 1
+        rb = (C.c_uint64 * (world + 1))(*[int(x) for x in rank_base])
+        rc_, bc_ = (C.c_uint64 * world)(), (C.c_uint64 * world)()
+        d_req, d_text = C.c_void_p(), C.c_void_p()
+        check(lib.bsk_rmdup_dist_xpack(self.op.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(reply.data_ptr()), C.c_void_p(surv_reply.data_ptr()),
+                                       base, rb, world, rc_, bc_, C.byref(d_req), C.byref(d_text), None), self.op.ctx)
+        req_cnt, byte_cnt = [int(x) for x in rc_], [int(x) for x in bc_]
+        dev = self._keep.device
+        m, nb = sum(req_cnt), sum(byte_cnt)
+        req = _device_view(d_req.value, (m, 3), "<i8", dev) if m else torch.empty((0, 3), dtype=torch.int64, device=dev)
+        text = _device_view(d_text.value, (nb,), "|u1", dev) if nb else torch.empty(0, dtype=torch.uint8, device=dev)
+        return req, text, req_cnt, byte_cnt
+
+    def xcompare(self, req_in, req_from, text_in, bytes_from):
+        import torch
+        world = len(req_from)
+        verdict = torch.empty(req_in.shape[0], dtype=torch.uint8, device=req_in.device)
+        check(lib.bsk_rmdup_dist_xcompare(self.op.ctx, C.c_void_p(req_in.data_ptr()), (C.c_uint64 * world)(*req_from), C.c_void_p(text_in.data_ptr()),
+                                          (C.c_uint64 * world)(*bytes_from), world, C.c_void_p(verdict.data_ptr()), None), self.op.ctx)
+        return verdict
+
+    def xapply(self, verdict_back):
+        """-> number of records of this shard whose text differs from their survivor's; self.pairs_compared"""
+        nf, pairs = C.c_uint64(), C.c_uint64()
+        check(lib.bsk_rmdup_dist_xapply(self.op.ctx, C.c_void_p(verdict_back.data_ptr()), C.byref(nf), C.byref(pairs), None), self.op.ctx)
+        self.pairs_compared = pairs.value
+        return nf.value
+
+    def flagged(self):
+        need = C.c_size_t()
+        check(lib.bsk_rmdup_dist_flagged_get(self.op.ctx, None, 0, C.byref(need)), self.op.ctx)
+        buf = C.create_string_buffer(max(1, need.value))
+        check(lib.bsk_rmdup_dist_flagged_get(self.op.ctx, buf, need.value, C.byref(need)), self.op.ctx)
+        return buf.raw[:need.value]
+
+    def settle(self, all_lists):
+        check(lib.bsk_rmdup_dist_flagged_settle(self.op.ctx, all_lists, len(all_lists)), self.op.ctx)
+
+    def pair_stats(self):
+        """(pairs compared inside the shard, pairs whose survivor lives on another rank, flagged records) of the last exchange"""
+        a, b, f = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.bsk_rmdup_dist_stats(self.op.ctx, C.byref(a), C.byref(b), C.byref(f)), self.op.ctx)
+        return a.value, b.value, f.value
+
     def emit(self, send, reply, base, to_host=True, surv_reply=None):
         """survivors of this rank's shard: host bytes (tests), or with to_host=False a DeviceText -- the text stays in the
         context's output buffer in HBM (20 GB per rank at C5 do not belong on the host).  surv_reply (the survivors' global
-        indices, routed back like the keep bytes): the duplicates whose survivor lives in this shard are byte-compared with
-        it (bsk_rmdup_dist_emit_ex); self.local_pairs = how many"""
+        indices, routed back like the keep bytes): without the cross-rank check (xpack .. xapply) before it, the duplicates
+        whose survivor lives in this shard are byte-compared with it here (bsk_rmdup_dist_emit_ex); self.local_pairs = how
+        many pairs inside the shard were compared"""
         from . import _lib
         out = _lib.Out()
         if surv_reply is None:
@@ -334,13 +395,70 @@ class _Phases:
         self.t = now
 
 
+def _xcheck(backend, send, reply, surv_reply, base, counts_all, world, rank, dev, group, multi, ph, phases):
+    """Round 6: RmDupCheck's text comparison (bigseqkit-lib/rmdup.go:193-211) for EVERY duplicate.  The duplicates whose
+    survivor lives on another rank send their subject there (24-byte requests + the text, two all_to_alls), the survivor's
+    rank answers one byte per request (one all_to_all back); the pairs inside a shard are compared where they are.  Records
+    whose text differs from their survivor's (two subjects under one pair of keys; the tests mask the keys) are handed to
+    every rank -- only when there are any -- and regrouped by text."""
+    import torch
+    rank_base = [0]
+    for c in counts_all:
+        rank_base.append(rank_base[-1] + int(c))
+    req, text, req_cnt, byte_cnt = backend.xpack(send, reply, surv_reply, base, rank_base)
+    ph.mark("xpack")
+    if phases is not None:
+        phases["xcheck_requests"] = int(sum(req_cnt))
+        phases["xcheck_text_bytes_sent"] = int(sum(byte_cnt))
+    if multi:
+        t_in = torch.tensor([v for p in range(world) for v in (req_cnt[p], byte_cnt[p])], dtype=torch.int64, device=dev)
+        t_out = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        _all_to_all_single(t_out, t_in, None, None, group)
+        got = [int(x) for x in t_out.tolist()]
+        req_from, bytes_from = got[0::2], got[1::2]
+        req_in = torch.empty((sum(req_from), 3), dtype=torch.int64, device=dev)
+        _all_to_all_single(req_in, req, req_from, req_cnt, group)
+        text_in = torch.empty(sum(bytes_from), dtype=torch.uint8, device=dev)
+        _all_to_all_single(text_in, text, bytes_from, byte_cnt, group)
+        ph.mark("xchange")
+        verdict = backend.xcompare(req_in, req_from, text_in, bytes_from)
+        ph.mark("xcompare")
+        vback = torch.empty(sum(req_cnt), dtype=torch.uint8, device=dev)
+        _all_to_all_single(vback, verdict, req_cnt, req_from, group)
+        ph.mark("xreply")
+    else:
+        vback = torch.empty(0, dtype=torch.uint8, device=dev)
+    n_flagged = backend.xapply(vback)
+    blob = backend.flagged() if n_flagged else b""
+    if multi:
+        sizes, _ = _all_gather_int(len(blob), dev, group)
+    else:
+        sizes = [len(blob)]
+    if sum(sizes):
+        if multi:
+            cd = coll_device(dev, group)
+            width = max(sizes)
+            pad = torch.zeros(width, dtype=torch.uint8, device=cd)
+            if blob:
+                pad[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(cd)
+            parts = [torch.zeros_like(pad) for _ in range(world)]
+            _all_gather(parts, pad, group)
+            blob = b"".join(bytes(parts[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world))
+        backend.settle(blob)
+    ph.mark("xapply")
+    if phases is not None:
+        phases["xcheck_flagged"] = int(sum(sizes) != 0)
+
+
 def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None):
     """RmDup over the shards of all ranks of `group`; returns the survivors of THIS rank's shard (file order), so that the
     concatenation over ranks equals the single-GPU output: host bytes, or with to_host=False whatever the backend's emit
     leaves on the device (HipRmDupBackend: a DeviceText).  Collectives: one all_gather of the record counts, one
-    all_to_all of split sizes, one all_to_all of tuples, one all_to_all of keep bytes.
-    `phases` (a dict) receives milliseconds per phase -- keys / pack / all_to_all / resolve / reply / emit -- and
-    `tuple_bytes_sent` / `tuple_bytes_sent_off_rank`."""
+    all_to_all of split sizes, one all_to_all of tuples, one all_to_all of keep bytes and one of survivor indices, then the
+    text comparison of the duplicates whose survivor lives on another rank (_xcheck; BSK_RMDUP_XCHECK=off leaves them to
+    their two keys, as round 5 did).
+    `phases` (a dict) receives milliseconds per phase -- keys / pack / all_to_all / resolve / reply / x* / emit -- and
+    `tuple_bytes_sent` / `tuple_bytes_sent_off_rank` / `xcheck_*`."""
     import torch
     import torch.distributed as dist
     # (BSK_DIST_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank still takes the exchange -- every collective of the
@@ -365,9 +483,12 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
         phases["tuple_bytes_sent"] = 24 * int(sum(in_splits))
         phases["tuple_bytes_sent_off_rank"] = 24 * int(sum(c for r, c in enumerate(in_splits) if r != rank))
     ex = hasattr(backend, "resolve_ex")   # (round 5: the owner also names the survivor, local pairs are byte-compared)
+    xc = ex and hasattr(backend, "xpack") and os.environ.get("BSK_RMDUP_XCHECK") != "off"
     if not multi:
         keep, surv = backend.resolve_ex(send) if ex else (backend.resolve(send), None)
         ph.mark("resolve")
+        if xc:
+            _xcheck(backend, send, keep, surv, base, [n], 1, 0, dev, group, False, ph, phases)
         kw = {"surv_reply": surv} if ex else {}
         out = backend.emit(send, keep, base, **kw) if to_host else backend.emit(send, keep, base, to_host=False, **kw)
         ph.mark("emit")
@@ -389,6 +510,8 @@ def rmdup_distributed(shard, fmt, backend, group=None, to_host=True, phases=None
         _all_to_all_single(surv_reply, surv, in_splits, out_splits, group)
         kw = {"surv_reply": surv_reply}
     ph.mark("reply")
+    if xc:
+        _xcheck(backend, send, reply, surv_reply, base, counts_all, world, rank, dev, group, True, ph, phases)
     out = backend.emit(send, reply, base, **kw) if to_host else backend.emit(send, reply, base, to_host=False, **kw)
     ph.mark("emit")
     return out

@@ -1007,7 +1007,8 @@ int run_devices(const Invocation& inv) {
             if (W[(size_t)r].out_bytes == 0) {
                 char nm[64];
                 snprintf(nm, sizeof nm, "/part%05d", r);
-                const int e = open((out_file + nm).c_str(), O_CREAT | O_WRONLY, 0644);
+                // (O_TRUNC: a non-empty part of an earlier run into the same directory must not pass for this run's -- ADVICE r05)
+                const int e = open((out_file + nm).c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
                 if (e >= 0) close(e);
             }
         return 0;

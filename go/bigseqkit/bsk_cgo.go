@@ -446,6 +446,9 @@ func StoreFASTXN(r *Result, path string) error {
 type Comms struct{ c []*C.bsk_comm }
 
 func NewComms(devices []int) (*Comms, error) {
+	if len(devices) == 0 {
+		return nil, errors.New("bigseqkit: NewComms needs at least one device")
+	}
 	devs := make([]C.int, len(devices))
 	for i, d := range devices {
 		devs[i] = C.int(d)
@@ -464,7 +467,8 @@ func (g *Comms) Close() {
 }
 
 // onEveryDevice runs f(rank) on one locked goroutine per device and returns the first error.  EVERY rank must enter every
-// collective f reaches, also after a failure of its own (the C entry points are written that way).
+// collective f reaches, also after a failure of its own: f keeps its own error in a variable and calls g.agree before the
+// collective that carries data (the way run_devices of cli/bigseqkit.cpp does it).
 func onEveryDevice(n int, f func(rank int) error) error {
 	errs := make([]error, n)
 	var wg sync.WaitGroup
@@ -486,6 +490,33 @@ func onEveryDevice(n int, f func(rank int) error) error {
 	return nil
 }
 
+var errOtherRank = errors.New("bigseqkit: another rank failed before the collective (its own error says why)")
+
+// agree is the collective every rank enters before one that carries data: the sum over the ranks of "I have failed"
+// (bsk_count_allreduce on one word).  It returns nil when nobody has -- the ranks go on together --, the rank's own error
+// when it has one, errOtherRank when only a peer failed, and the communicator's error when the reduction itself failed
+// (then nobody may enter another collective on g).  A rank that returned BEFORE this call would leave its peers waiting
+// in ncclAllReduce for ever (ADVICE r05).
+func (g *Comms) agree(rank int, own error) error {
+	var bad C.uint64_t
+	if own != nil {
+		bad = 1
+	}
+	if rc := C.bsk_count_allreduce(g.c[rank], &bad, nil); rc != C.BSK_OK {
+		if own != nil {
+			return own
+		}
+		return errors.New(C.GoString(C.bsk_comm_error(g.c[rank])))
+	}
+	if own != nil {
+		return own
+	}
+	if bad != 0 {
+		return errOtherRank
+	}
+	return nil
+}
+
 // StatsN: Stats over the shards of `input` on the devices of `g`, shard k on device k (len(input.Shards) == len(devices)):
 // bsk_stats_run per rank, then StatsReduce + collect in ONE call (bsk_stats_collect_reduced: a single ncclAllReduce of the
 // dense vector; the overflow lists of chromosome-sized records are exchanged only when the reduced vector counts any).
@@ -494,16 +525,19 @@ func StatsN(name, format string, input *SeqFrame, o *SeqKitStatsOptions, g *Comm
 	js := OptionsToString(o)
 	var result *StatInfo
 	err := onEveryDevice(len(devices), func(rank int) error {
-		op, err := newBskOp("Stats", js, devices[rank])
-		if err != nil {
-			return err
-		}
-		defer op.Close()
-		d := input.Shards[rank].Data
-		if len(d) > 0 {
-			if rc := C.bsk_stats_run(op.ctx, unsafe.Pointer(&d[0]), C.size_t(len(d)), 0, C.int(input.Format), C.int64_t(rank), nil, nil); rc != C.BSK_OK {
-				return op.err()
+		// (everything that can fail on this rank alone happens before g.agree; its error travels with that reduction)
+		op, own := newBskOp("Stats", js, devices[rank])
+		if own == nil {
+			defer op.Close()
+			d := input.Shards[rank].Data
+			if len(d) > 0 {
+				if rc := C.bsk_stats_run(op.ctx, unsafe.Pointer(&d[0]), C.size_t(len(d)), 0, C.int(input.Format), C.int64_t(rank), nil, nil); rc != C.BSK_OK {
+					own = op.err()
+				}
 			}
+		}
+		if e := g.agree(rank, own); e != nil {
+			return e
 		}
 		capN := 1 << 20
 		keys := make([]C.int64_t, capN)
@@ -536,64 +570,71 @@ func GrepCountN(input *SeqFrame, o *SeqKitGrepOptions, g *Comms, devices []int) 
 	js := OptionsToString(o)
 	var total uint64
 	err := onEveryDevice(len(devices), func(rank int) error {
-		op, err := newBskOp("Grep", js, devices[rank])
-		if err != nil {
-			return err
-		}
-		defer op.Close()
-		d := input.Shards[rank].Data
-		var ptr unsafe.Pointer
-		if len(d) > 0 {
-			ptr = unsafe.Pointer(&d[0])
-		}
-		var out C.bsk_out
 		var cnt C.uint64_t
-		rc := C.bsk_grep_run(op.ctx, ptr, C.size_t(len(d)), 0, C.int(input.Format), C.int64_t(rank), nil, &out)
-		if rc == C.BSK_OK {
-			rc = C.bsk_grep_last_count(op.ctx, &cnt)
+		op, own := newBskOp("Grep", js, devices[rank])
+		if own == nil {
+			defer op.Close()
+			d := input.Shards[rank].Data
+			var ptr unsafe.Pointer
+			if len(d) > 0 {
+				ptr = unsafe.Pointer(&d[0])
+			}
+			var out C.bsk_out
+			rc := C.bsk_grep_run(op.ctx, ptr, C.size_t(len(d)), 0, C.int(input.Format), C.int64_t(rank), nil, &out)
+			if rc == C.BSK_OK {
+				rc = C.bsk_grep_last_count(op.ctx, &cnt)
+			}
+			if rc != C.BSK_OK {
+				own = op.err()
+				cnt = 0
+			}
 		}
-		var e error
-		if rc != C.BSK_OK {
-			e = op.err()
-			cnt = 0
+		if e := g.agree(rank, own); e != nil {
+			return e
 		}
-		if rc2 := C.bsk_count_allreduce(g.c[rank], &cnt, nil); rc2 != C.BSK_OK && e == nil {
-			e = errors.New(C.GoString(C.bsk_comm_error(g.c[rank])))
+		if rc := C.bsk_count_allreduce(g.c[rank], &cnt, nil); rc != C.BSK_OK {
+			return errors.New(C.GoString(C.bsk_comm_error(g.c[rank])))
 		}
 		if rank == 0 {
 			total = uint64(cnt)
 		}
-		return e
+		return nil
 	})
 	return total, err
 }
 
 // RmDupN: the survivors of every rank's shard (file order; their concatenation equals the single-GPU output), duplicates
 // found across ranks by bsk_rmdup_dist_run (24-byte tuples to owner = key % N by grouped ncclSend / ncclRecv, keep bytes
-// back; GroupByKey + RmDupCheck, bigseqkit/rmdup.go:97).
+// back, and the byte comparison of every duplicate with its survivor -- also one on another rank; GroupByKey + RmDupCheck,
+// bigseqkit/rmdup.go:97, bigseqkit-lib/rmdup.go:193-211).
 func RmDupN(input *SeqFrame, o *SeqKitRmDupOptions, g *Comms, devices []int) (*Result, error) {
 	o.setDefaults()
 	js := OptionsToString(o)
 	res := &Result{Parts: make([][]byte, len(devices))}
 	var mu sync.Mutex
 	err := onEveryDevice(len(devices), func(rank int) error {
-		op, err := newBskOp("RmDup", js, devices[rank])
-		if err != nil {
-			return err
-		}
-		defer op.Close()
 		d := input.Shards[rank].Data
-		C.bsk_device_select(C.int(devices[rank]))
-		dev := C.bsk_device_alloc(C.size_t(len(d) + 1))
-		if dev == nil {
-			return errors.New(C.GoString(C.bsk_global_error()))
-		}
-		defer C.bsk_device_free(dev)
-		if len(d) > 0 {
-			if rc := C.bsk_device_copy(dev, unsafe.Pointer(&d[0]), C.size_t(len(d)), C.BSK_COPY_H2D); rc != C.BSK_OK {
-				return errors.New(C.GoString(C.bsk_global_error()))
+		var dev unsafe.Pointer
+		op, own := newBskOp("RmDup", js, devices[rank])
+		if own == nil {
+			defer op.Close()
+			C.bsk_device_select(C.int(devices[rank]))
+			dev = C.bsk_device_alloc(C.size_t(len(d) + 1))
+			if dev == nil {
+				own = errors.New(C.GoString(C.bsk_global_error()))
+			} else {
+				defer C.bsk_device_free(dev)
+				if len(d) > 0 {
+					if rc := C.bsk_device_copy(dev, unsafe.Pointer(&d[0]), C.size_t(len(d)), C.BSK_COPY_H2D); rc != C.BSK_OK {
+						own = errors.New(C.GoString(C.bsk_global_error()))
+					}
+				}
 			}
 		}
+		if e := g.agree(rank, own); e != nil {
+			return e
+		}
+		// (from here on bsk_rmdup_dist_run carries every phase's outcome with its next collective itself: csrc/comm.cpp)
 		var out C.bsk_out
 		if rc := C.bsk_rmdup_dist_run(op.ctx, g.c[rank], dev, C.size_t(len(d)), C.int(input.Format), nil, &out); rc != C.BSK_OK {
 			return op.err()

@@ -360,12 +360,42 @@ int bsk_rmdup_dist_emit(bsk_ctx* ctx, const void* d_send, const void* d_reply, u
 /* The same two phases with the survivor's identity (round 5): _resolve_ex also writes d_survivor (u64[m]: the global index of
  * the record that survives for every tuple's subject); routed back like the keep bytes (d_survivor_reply, u64[n_records] in
  * the order of d_send) it lets _emit_ex compare the BYTES of every duplicate whose survivor lives in the same shard with that
- * survivor's (RmDupCheck's own test, bigseqkit-lib/rmdup.go:193-199; `-s` on FASTQ) -- a difference fails the call, as in
- * the single-GPU run.  Pairs that cross ranks are decided by the two keys alone (PARITY.md KEYS).  Either pointer NULL:
- * the plain phases.  *local_pairs_verified (may be NULL): how many pairs were compared. */
+ * survivor's (RmDupCheck's own test, bigseqkit-lib/rmdup.go:193-199; `-s` on FASTQ) -- without the cross-rank check below a
+ * difference fails the call and pairs that cross ranks rest on the two keys; with it (bsk_rmdup_dist_x*, which
+ * bsk_rmdup_dist_run runs) every pair is compared and _emit_ex only emits.  Either pointer NULL: the plain phases.
+ * *local_pairs_verified (may be NULL): how many pairs inside the shard were compared. */
 int bsk_rmdup_dist_resolve_ex(bsk_ctx* ctx, const void* d_tuples, uint64_t m, void* d_keep, void* d_survivor, void* stream);
 int bsk_rmdup_dist_emit_ex(bsk_ctx* ctx, const void* d_send, const void* d_reply, const void* d_survivor_reply, uint64_t base_index,
                            void* stream, bsk_out* out, uint64_t* local_pairs_verified);
+
+/* ---- RmDupCheck's text comparison across ranks (round 6; bigseqkit-lib/rmdup.go:193-211 compares the subject text of every
+ * member of a hash group -- the reference has the text there because GroupByKey, bigseqkit/rmdup.go:97, shuffles whole
+ * records).  After the replies of _resolve_ex are back, every duplicate whose survivor lives on ANOTHER rank sends its
+ * subject to that rank: a 24-byte request {survivor's global index, offset of the text in the destination's segment,
+ * length | local record << 32} and the bytes.  Between the phases the caller runs three all-to-all exchanges:
+ *   _xpack    : rank_base[r] = global index of rank r's first record (world + 1 entries); req_counts[r] / byte_counts[r] =
+ *               requests / text bytes for rank r; *d_requests / *d_text = the context's send buffers, grouped by destination
+ *               [requests, 24 B each, and text to their destinations]
+ *   _xcompare : survivor side.  req_from[r] / bytes_from[r] = what arrived from rank r (buffers in rank order);
+ *               d_verdict[j] = 1 equal, 0 differs (-i: case-folded)        [verdicts back, the same routes reversed]
+ *   _xapply   : d_verdict_back in the order of *d_requests.  Also compares the pairs INSIDE the shard.  *n_flagged = records
+ *               of this shard whose text differs from their survivor's (two subjects under one pair of keys); *pairs_compared
+ *               = local + cross-rank pairs.  bsk_rmdup_dist_emit[_ex] after it does not compare again.
+ * Only when the SUM of n_flagged over the ranks is not zero (about N^2 / 2^129; the tests mask the keys): every rank hands
+ * its list (_flagged_get: entries {u64 global index, u64 length, text padded to 8}; call with buf NULL for the size) to
+ * every other, and _flagged_settle(concatenation of all ranks' lists, any order) regroups them by TEXT -- the lowest global
+ * index of every text survives, as RmDupCheck's map keyed by the subject decides.  bsk_rmdup_dist_run does all of this. */
+int bsk_rmdup_dist_xpack(bsk_ctx* ctx, const void* d_send, const void* d_reply, const void* d_survivor_reply, uint64_t base_index,
+                         const uint64_t* rank_base, int world, uint64_t* req_counts, uint64_t* byte_counts, void** d_requests, void** d_text,
+                         void* stream);
+int bsk_rmdup_dist_xcompare(bsk_ctx* ctx, const void* d_requests_in, const uint64_t* req_from, const void* d_text_in,
+                            const uint64_t* bytes_from, int world, void* d_verdict, void* stream);
+int bsk_rmdup_dist_xapply(bsk_ctx* ctx, const void* d_verdict_back, uint64_t* n_flagged, uint64_t* pairs_compared, void* stream);
+int bsk_rmdup_dist_flagged_get(bsk_ctx* ctx, void* buf, size_t cap, size_t* need);
+int bsk_rmdup_dist_flagged_settle(bsk_ctx* ctx, const void* all_lists, size_t n_bytes);
+/* what the last exchange of this context compared: pairs inside the shard, pairs whose survivor lives on another rank (their
+ * text went there), and the records of this shard that were flagged (any pointer may be NULL) */
+int bsk_rmdup_dist_stats(const bsk_ctx* ctx, uint64_t* local_pairs, uint64_t* cross_pairs, uint64_t* flagged);
 
 /* ---- collectives behind the C ABI (round 5): RCCL over xGMI, no Python, no torch -----------------------------------------
  * In the reference the driver gets Reduce and GroupByKey from IgnisHPC, in the same binary (bigseqkit/stats.go:91,

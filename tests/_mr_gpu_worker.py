@@ -60,6 +60,15 @@ def main():
     # rmdup: tuple exchange
     be = bdist.HipRmDupBackend(json.dumps({"BySeq": True}), devi)
     put("rmdup", bdist.rmdup_distributed(shard, fmt, be))
+    put("rmdup_pairs", json.dumps(list(be.pair_stats()) + [be.n]).encode())   # (local pairs, cross-rank pairs, flagged, records)
+    be.close()
+    # the same with 16 bits of k1 and 2 bits of k2: DIFFERENT sequences share a pair of keys, also across ranks -- the text
+    # comparison of round 6 (bsk_rmdup_dist_x*) flags them and the settlement by text lets the first of every text survive
+    be = bdist.HipRmDupBackend(json.dumps({"BySeq": True}), devi)
+    check(lib.bsk_ctx_set(be.op.ctx, b"rmdup_k1_bits", b"16"), be.op.ctx)
+    check(lib.bsk_ctx_set(be.op.ctx, b"rmdup_k2_bits", b"2"), be.op.ctx)
+    put("rmdupx", bdist.rmdup_distributed(shard, fmt, be))
+    put("rmdupx_pairs", json.dumps(list(be.pair_stats()) + [be.n]).encode())
     be.close()
     # range with negative positions: needs the global count
     rb = bdist.HipRangeBackend("Range", json.dumps({"Range": "3:-3"}), devi)

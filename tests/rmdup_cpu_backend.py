@@ -14,9 +14,12 @@ def _s64(u):
 
 
 class OracleRmDupBackend:
-    def __init__(self, opts):
+    def __init__(self, opts, key_bits=64):
+        """key_bits < 64: only the low bits of BOTH keys are kept (what libbsk's test switches rmdup_k1_bits / rmdup_k2_bits
+        do): different subjects then share a pair of keys and the text comparison has to tell them apart"""
         self.by_seq = bool(opts.get("BySeq"))
         self.fold = bool(opts.get("IgnoreCase"))
+        self.mask = (1 << key_bits) - 1
 
     def keys(self, shard, fmt):
         import xxhash
@@ -32,8 +35,8 @@ class OracleRmDupBackend:
             if self.fold:
                 subject = subject.lower()
             self.subjects.append(subject)
-            self.k1.append(oracle.xxh64(subject))
-            self.k2.append(xxhash.xxh64(subject, seed=SEED2).intdigest())
+            self.k1.append(oracle.xxh64(subject) & self.mask)
+            self.k2.append(xxhash.xxh64(subject, seed=SEED2).intdigest() & self.mask)
         return len(self.records)
 
     def pack(self, base, world):
@@ -45,35 +48,104 @@ class OracleRmDupBackend:
         return send, [len(b) for b in buckets]
 
     def resolve(self, tuples):
-        first = {}
-        rows = tuples.tolist()
-        for k, k2, g in rows:
-            cur = first.get(k)
-            if cur is None or g < cur[0]:
-                first[k] = (g, k2)
-            assert first[k][1] == k2 or cur is None or cur[1] == k2
-        return torch.tensor([1 if first[k][0] == g else 0 for k, k2, g in rows], dtype=torch.uint8)
+        return self.resolve_ex(tuples)[0]
 
     def resolve_ex(self, tuples):
-        """resolve + the global index of every tuple's survivor (what bsk_rmdup_dist_resolve_ex answers)"""
-        keep = self.resolve(tuples)
+        """one keep byte per tuple + the global index of every tuple's survivor (what bsk_rmdup_dist_resolve_ex answers):
+        the owner groups by the PAIR of keys, the lowest global index of a group survives"""
         first = {}
         rows = tuples.tolist()
         for k, k2, g in rows:
-            first[k] = min(first.get(k, g), g)
-        return keep, torch.tensor([first[k] for k, k2, g in rows], dtype=torch.int64)
+            first[(k, k2)] = min(first.get((k, k2), g), g)
+        keep = torch.tensor([1 if first[(k, k2)] == g else 0 for k, k2, g in rows], dtype=torch.uint8)
+        return keep, torch.tensor([first[(k, k2)] for k, k2, g in rows], dtype=torch.int64)
+
+    # ---- round 6: the text comparison across ranks, in the layout of include/bsk.h (bsk_rmdup_dist_x*) ----
+    def xpack(self, send, reply, surv_reply, base, rank_base):
+        world = len(rank_base) - 1
+        n = len(self.records)
+        self.base, self.send, self.reply, self.surv = base, send.tolist(), reply.tolist(), surv_reply.tolist()
+        per = [[] for _ in range(world)]
+        for p, ((k, k2, g), r) in enumerate(zip(self.send, self.reply)):
+            s = int(self.surv[p])
+            if not r and not (base <= s < base + n):
+                d = max(q for q in range(world) if rank_base[q] <= s)
+                per[d].append((s, g - base))
+        reqs, text = [], bytearray()
+        self.x_local = []
+        for d in range(world):
+            off = 0
+            for s, i in per[d]:
+                t = self.subjects[i]   # (already folded with -i: the comparison folds both sides anyway)
+                reqs.append((s, off, len(t) | (i << 32)))
+                text += t
+                off += len(t)
+                self.x_local.append(i)
+        req = torch.tensor(reqs, dtype=torch.int64).reshape(len(reqs), 3)
+        return req, torch.frombuffer(bytearray(text) or bytearray(1), dtype=torch.uint8)[:len(text)], [len(x) for x in per], \
+            [sum(len(self.subjects[i]) for _, i in x) for x in per]
+
+    def xcompare(self, req_in, req_from, text_in, bytes_from):
+        rows, blob = req_in.tolist(), bytes(text_in.numpy().tobytes())
+        verdict, j = [], 0
+        seg = 0
+        for p, cnt in enumerate(req_from):
+            for _ in range(cnt):
+                s, off, w = rows[j]
+                ln = w & 0xFFFFFFFF
+                verdict.append(1 if blob[seg + off: seg + off + ln] == self.subjects[s - self.base] else 0)
+                j += 1
+            seg += bytes_from[p]
+        return torch.tensor(verdict, dtype=torch.uint8)
+
+    def xapply(self, verdict_back):
+        n = len(self.records)
+        flagged = {self.x_local[j] for j, v in enumerate(verdict_back.tolist()) if v != 1}
+        self.pairs_compared = len(self.x_local)
+        for p, ((k, k2, g), r) in enumerate(zip(self.send, self.reply)):
+            s = int(self.surv[p])
+            if not r and self.base <= s < self.base + n and s != g:
+                self.pairs_compared += 1
+                if self.subjects[s - self.base] != self.subjects[g - self.base]:
+                    flagged.add(g - self.base)
+        self.flagged_records = sorted(flagged)
+        self.xchecked, self.resurrect = True, set()
+        return len(self.flagged_records)
+
+    def flagged(self):
+        out = bytearray()
+        for i in self.flagged_records:
+            t = self.subjects[i]
+            out += (self.base + i).to_bytes(8, "little") + len(t).to_bytes(8, "little") + t + b"\0" * ((8 - len(t) % 8) % 8)
+        return bytes(out)
+
+    def settle(self, blob):
+        lowest, entries, p = {}, [], 0
+        while p < len(blob):
+            g, ln = int.from_bytes(blob[p:p + 8], "little"), int.from_bytes(blob[p + 8:p + 16], "little")
+            t = blob[p + 16:p + 16 + ln]
+            p += 16 + ln + (8 - ln % 8) % 8
+            lowest[t] = min(lowest.get(t, g), g)
+            entries.append((g, t))
+        n = len(self.records)
+        self.resurrect = {g - self.base for g, t in entries if self.base <= g < self.base + n and lowest[t] == g}
 
     def emit(self, send, reply, base, to_host=True, surv_reply=None):
         keep = {}
         self.local_pairs = 0
+        xchecked = getattr(self, "xchecked", False)
+        self.xchecked = False
         for p, ((k, k2, g), r) in enumerate(zip(send.tolist(), reply.tolist())):
             keep[g - base] = r
             if surv_reply is not None:
                 s = int(surv_reply[p])
                 assert (s == g) == bool(r)
                 if not r and base <= s < base + len(self.records):   # the survivor lives in this shard: the bytes must agree
-                    assert self.subjects[s - base] == self.subjects[g - base]
+                    assert xchecked or self.subjects[s - base] == self.subjects[g - base]
                     self.local_pairs += 1
+        if xchecked:
+            for i in self.resurrect:
+                keep[i] = 1
         text = b"".join(rec for i, rec in enumerate(self.records) if keep[i])
         if to_host:
             return text

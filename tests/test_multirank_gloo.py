@@ -114,7 +114,7 @@ def test_shard_bounds_are_record_aligned_and_cover_the_file():
 
 
 # ---------------------------------------------------------------- rmdup: the one command with an exchange step
-def _rmdup_worker(rank, world, port, data, opts, q, store=None):
+def _rmdup_worker(rank, world, port, data, opts, q, store=None, key_bits=64):
     import torch
     import torch.distributed as dist
     from rmdup_cpu_backend import OracleRmDupBackend
@@ -124,12 +124,13 @@ def _rmdup_worker(rank, world, port, data, opts, q, store=None):
     try:
         lo, hi = bdist.shard_bounds(data, world, bsk.FORMAT_FASTQ)[rank]
         shard = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.empty(0, dtype=torch.uint8)
-        out = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts))
+        out = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts, key_bits))
         # the resident form (bench.py's N > 1 leg: survivors stay with the backend) and the per-phase clock
         phases = {}
-        res = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts), to_host=False, phases=phases)
+        res = bdist.rmdup_distributed(shard, bsk.FORMAT_FASTQ, OracleRmDupBackend(opts, key_bits), to_host=False, phases=phases)
         assert bytes(res) == out and res.len == len(out) and res.records == out.count(b"\n") // 4
-        assert set(phases) >= {"keys", "pack", "all_to_all", "resolve", "reply", "emit", "tuple_bytes_sent"}
+        assert set(phases) >= {"keys", "pack", "all_to_all", "resolve", "reply", "emit", "tuple_bytes_sent", "xpack", "xapply", "xcheck_requests"}
+        assert phases["xcheck_flagged"] == (1 if key_bits < 64 else 0)   # (masked keys: different subjects under one pair -- settled by text)
         assert phases["tuple_bytes_sent"] == 24 * (shard.numpy().tobytes().count(b"\n") // 4)
         assert 0 <= phases["tuple_bytes_sent_off_rank"] <= phases["tuple_bytes_sent"]
         if store:
@@ -139,11 +140,15 @@ def _rmdup_worker(rank, world, port, data, opts, q, store=None):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("key_bits", [64, 5])
 @pytest.mark.parametrize("a2a_max_bytes", [None, 240])
 @pytest.mark.parametrize("opts", [{"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}])
-def test_two_ranks_gloo_rmdup_exchange(opts, a2a_max_bytes, tmp_path, monkeypatch):
+def test_two_ranks_gloo_rmdup_exchange(opts, a2a_max_bytes, key_bits, tmp_path, monkeypatch):
     """all_gather(counts) + all_to_all(tuples) + all_to_all(keep bytes): the concatenated per-rank survivors equal the
     single-shard result, i.e. the first occurrence in FILE order survives even when it lives on the other rank.
+    Round 6: the subject text of every duplicate whose survivor lives on the other rank travels there and is compared
+    (dist._xcheck); key_bits = 5 keeps five bits of either key, so that DIFFERENT subjects share a pair of keys on both
+    ranks -- the comparison flags them and the settlement by text lets every first-of-its-text survive, as the oracle does.
     a2a_max_bytes = 240: ten tuples per message, the exchange runs in rounds (dist._all_to_all_single: RCCL on this image
     delivers only the first half of a message beyond 1 GiB, so large exchanges are cut)."""
     import torch.multiprocessing as mp
@@ -162,7 +167,7 @@ def test_two_ranks_gloo_rmdup_exchange(opts, a2a_max_bytes, tmp_path, monkeypatc
     q = ctx.Queue()
     port = _free_port()
     merged = str(tmp_path / "merged.fq")
-    procs = [ctx.Process(target=_rmdup_worker, args=(r, 2, port, data, opts, q, merged)) for r in range(2)]
+    procs = [ctx.Process(target=_rmdup_worker, args=(r, 2, port, data, opts, q, merged, key_bits)) for r in range(2)]
     for p in procs:
         p.start()
     outs = dict(q.get(timeout=120) for _ in range(2))

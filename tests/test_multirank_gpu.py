@@ -48,7 +48,17 @@ def test_ranks_on_the_gpu_box(world, tmp_path, record_property):
     assert got_stats == want_stats
     for r in range(world):
         assert int((tmp_path / ("grepc.%d" % r)).read_bytes()) == oracle.grep(data, True, '{"Pattern": ["ACG"], "BySeq": true}').count(b"\n") // 4
-    assert cat("rmdup") == oracle.rmdup(data, True, '{"BySeq": true}')
+    want_rmdup = oracle.rmdup(data, True, '{"BySeq": true}')
+    assert cat("rmdup") == want_rmdup
+    # round 6: EVERY duplicate was byte-compared with its survivor -- inside its shard or on the survivor's rank
+    pairs = [json.loads((tmp_path / ("rmdup_pairs.%d" % r)).read_bytes()) for r in range(world)]
+    n_records = data.count(b"\n") // 4
+    assert sum(p[3] for p in pairs) == n_records
+    assert sum(p[0] + p[1] for p in pairs) == n_records - want_rmdup.count(b"\n") // 4 > 0
+    assert sum(p[1] for p in pairs) > 0 and sum(p[2] for p in pairs) == 0           # pairs crossed ranks; none differed
+    # ... and with masked keys different sequences under one pair of keys are told apart by their text, across ranks too
+    assert cat("rmdupx") == want_rmdup
+    assert sum(json.loads((tmp_path / ("rmdupx_pairs.%d" % r)).read_bytes())[2] for r in range(world)) > 0
     assert cat("range") == oracle.range_(data, True, '{"Range": "3:-3"}')
     assert (tmp_path / "merged.fq").read_bytes() == oracle.seq(data, True, '{"Reverse": true}')
     # which collectives carried this run: RCCL when the box gave every rank a GPU, gloo through the host otherwise --
