@@ -91,6 +91,26 @@ class _Helpers:
         lib.bsk_profile_enable(op.ctx, 0)
         return op, out, sum(times) / calls, min(times), self.kernels(op, calls)
 
+    def both_outputs(self, name, fn, opts, buf, nbytes, fmt):
+        """The operators that can leave their result as ORDERED SLICES (round 6; include/bsk.h bsk_out.d_seg_*: the reference's
+        Call returns []string whose elements share the partition's bytes): the same call timed with the switch "out" =
+        "slices" -- the figure of the entry -- and as one block (round 5's contract: "contiguous" inside the entry).  The
+        result handed back is the slices call's, made one block AFTER the clock stopped (bsk_out_materialize) so that `exact`
+        compares the concatenation of the slices byte for byte."""
+        lib, check = self.lib, self.check
+        op_c, out_c, mean_c, min_c, kern_c = self.timed_calls(name, fn, opts, buf, nbytes, fmt)
+        contiguous = {"ms": round(mean_c * 1e3, 4), "ms_min": round(min_c * 1e3, 4), "kernels_ms_per_call": kern_c,
+                      "out_bytes": int(out_c.len), "out_records": int(out_c.records)}
+        op_c.close()
+        self.torch.cuda.empty_cache()
+        op, out, mean_s, min_s, kern = self.timed_calls(name, fn, opts, buf, nbytes, fmt, sets=((b"out", b"slices"),))
+        info = {"output": "ordered slices (bsk_ctx_set(ctx, 'out', 'slices')): %d segments, d_data NULL" % int(out.n_segments)
+                if out.n_segments else "one block (the call did not qualify for slices)",
+                "contiguous": contiguous}
+        check(lib.bsk_out_materialize(op.ctx, C.byref(out), None), op.ctx)   # (untimed: for the comparison below)
+        self.torch.cuda.synchronize()
+        return op, out, mean_s, min_s, kern, info
+
     def entry(self, cmd, workload, nrec, in_bytes, alg_bytes, out, mean_s, min_s, kern, exact, how, extra=None):
         e = {"command": cmd, "workload": workload, "records": int(nrec), "in_bytes": int(in_bytes),
              "out_bytes": int(out.len), "out_records": int(out.records), "calls": self.calls,
@@ -450,7 +470,7 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
 
     # ---- seq -n @ C2: the names of the 100 GB file -----------------------------------------------------------------
     nbytes = total_rec * REC
-    op, out, mean_s, min_s, kern = timed_calls("SeqTransform", lib.bsk_seq_run, {"Name": True}, shard, nbytes, bsk.FORMAT_FASTQ)
+    op, out, mean_s, min_s, kern, both = H.both_outputs("SeqTransform", lib.bsk_seq_run, {"Name": True}, shard, nbytes, bsk.FORMAT_FASTQ)
     names = dev_bytes(out.d_data, out.len)
     view = shard.view(total_rec, REC)
     ok = out.len == 12 * total_rec and out.records == total_rec
@@ -462,7 +482,7 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
                                nbytes + 12 * total_rec, out, mean_s, min_s, kern, ok,
                                "output == columns [1, 13) of every 317-byte record (torch.equal over all %d names), "
                                "12 x N bytes, first / last name" % total_rec,
-                               None if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "seq", {"Name": True}, shard, REC, True)})
+                               dict(both, **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "seq", {"Name": True}, shard, REC, True)})))
     del names
     op.close()
 
@@ -470,8 +490,8 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     # (not a BASELINE config of its own: north_star lists subseq among the hot-path commands, VERDICT r02 named it the
     # kernel furthest from its roof after rmdup)
     nsub = total_rec // 4
-    op, out, mean_s, min_s, kern = timed_calls("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, shard, nsub * REC,
-                                               bsk.FORMAT_FASTQ)
+    op, out, mean_s, min_s, kern, both = H.both_outputs("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, shard, nsub * REC,
+                                                      bsk.FORMAT_FASTQ)
     got = dev_bytes(out.d_data, out.len)
     ok = out.len == 117 * nsub and out.records == nsub
     if ok:
@@ -488,7 +508,7 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
         nsub * REC, nsub * REC + 117 * nsub, out, mean_s, min_s, kern, ok,
         "output == columns [0, 63) ++ '\\n+\\n' ++ columns [166, 216) ++ '\\n' of every 317-byte record (torch.equal over all "
         "%d records)" % nsub,
-        None if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "subseq", {"Region": "1:50"}, shard, REC, True)})
+        dict(both, **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_op(H, "subseq", {"Region": "1:50"}, shard, REC, True)})))
     del got, view
     op.close()
     shard.data = torch.empty(0, dtype=torch.uint8, device=dev)  # the 100 GB file is not needed any more
@@ -695,7 +715,7 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
 
     # ---- rmdup -s @ C5: one GPU's 25 GB shard, every fifth record repeats the bases of an earlier one -------------------
     t, nrec = synth(_lib.SYNTH_FASTQ150, _lib.SYNTH_FLAG_DUPS, 25e9 * args.ops_scale)
-    op, out, mean_s, min_s, kern = timed_calls("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, t.numel(), bsk.FORMAT_FASTQ)
+    op, out, mean_s, min_s, kern, both = H.both_outputs("RmDup", lib.bsk_rmdup_run, {"BySeq": True}, t, t.numel(), bsk.FORMAT_FASTQ)
     view = t.view(nrec, REC)
     got = dev_bytes(out.d_data, out.len)
     keep = nrec - nrec // 5
@@ -715,19 +735,25 @@ def run_ops(args, torch, bsk, _lib, lib, check, dev, local, shard, total_rec):
     if ok_k:
         ok_k, _ = rows_equal(dev_bytes(out_k.d_data, out_k.len), view, lambda i0, i1: (torch.arange(i0, i1, device=dev) % 5) != 4, REC)
     op_k.close()
-    extra = {"survivors": int(out.records),
+    extra = dict(both)
+    extra["algorithmic_bytes_note"] = ("slices: the input once + 16 table bytes per record; the survivors are slices of the shard and are not "
+                                       "moved (RmDupCheck's result elements are the strings it was handed, rmdup.go:200-222).  contiguous: + "
+                                       "the output written once")
+    extra["contiguous"]["algorithmic_bytes"] = int(t.numel() + 16 * nrec + out.len)
+    extra["contiguous"]["frac"] = round(extra["contiguous"]["algorithmic_bytes"] / (extra["contiguous"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    extra.update({"survivors": int(out.records),
              "rmdup_keys": "verify (default): ONE 64-bit key groups the records -- the chain-free grouping key of csrc/hash_dev.hpp, whose "
                            "value nothing but the grouping sees -- and the sequence bytes of every duplicate are compared with its "
                            "survivor's (RmDupCheck, rmdup.go:193-199); a shard whose comparison meets two sequences under one key "
                            "runs again with XXH64 + the second key",
              "rmdup_keys_two_key": {"ms": round(mean_k * 1e3, 4), "ms_min": round(min_k * 1e3, 4), "kernels_ms_per_call": kern_k,
-                                    "exact": bool(ok_k), "note": "bsk_ctx_set(ctx, 'rmdup_keys', 'two-key'): no byte comparison"}}
+                                    "exact": bool(ok_k), "note": "bsk_ctx_set(ctx, 'rmdup_keys', 'two-key'): no byte comparison; one block"}})
     if not args.no_cpu_baseline:
         extra["cpu_baseline"] = cpu_baseline_op(H, "rmdup", {"BySeq": True}, t, REC, True, all_cores=False)
         extra["cpu_baseline"]["sample"] += " (duplicates are global: one thread, one group table)"
     ops["rmdup -s @ C5 shard"] = entry(
         "rmdup -s", "%.1f GB FASTQ-150, one GPU's shard of C5, record i with i %% 5 == 4 repeats the bases of an earlier record"
-        % (t.numel() / 1e9), nrec, t.numel(), t.numel() + 16 * nrec + out.len, out, mean_s, min_s, kern, ok,
+        % (t.numel() / 1e9), nrec, t.numel(), t.numel() + 16 * nrec + (0 if "slices" in both["output"] else out.len), out, mean_s, min_s, kern, ok,
         "output == the records with i % 5 != 4, byte for byte in file order (N - N // 5 survivors); rmdup of the output keeps "
         "every record", extra)
     del got, view, t

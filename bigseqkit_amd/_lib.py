@@ -79,7 +79,9 @@ class StatInfo(C.Structure):
 
 
 class Out(C.Structure):
-    _fields_ = [("d_data", C.c_void_p), ("len", C.c_size_t), ("records", C.c_uint64)]
+    # (d_seg_*: the result as ordered slices -- switch "out" = "slices", include/bsk.h; n_segments == 0: d_data holds the text)
+    _fields_ = [("d_data", C.c_void_p), ("len", C.c_size_t), ("records", C.c_uint64),
+                ("d_seg_src", C.c_void_p), ("d_seg_off", C.c_void_p), ("n_segments", C.c_uint64)]
 
 
 _vp, _sz, _i, _i64, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_uint64
@@ -109,6 +111,7 @@ SIGNATURES = {
     "bsk_stats_finalize": (_i, [_vp, _p(_i64), _p(_i64), _sz, _p(StatInfo)]),
     "bsk_stats_string": (_i, [_vp, C.c_char_p, C.c_char_p, _p(StatInfo), C.c_char_p, _sz]),
     "bsk_out_to_host": (_i, [_vp, _p(Out), _vp, _sz]),
+    "bsk_out_materialize": (_i, [_vp, _p(Out), _vp]),
     "bsk_index_build": (_i, [_vp, _vp, _sz, _i, _i, _vp, _p(_u64)]),
     "bsk_index_copy": (_i, [_vp, _p(_u64), _p(C.c_uint32), _p(C.c_uint32), _p(C.c_uint32), _sz]),
     "bsk_seq_run": (_i, [_vp, _vp, _sz, _i, _i, _i64, _vp, _p(Out)]),

@@ -12,6 +12,8 @@
 #include "anchor.hpp"
 #include "ctx.hpp"
 #include "ops_host.hpp"
+#include "ops_host_internal.hpp"
+#include "ops_segcopy.hpp"
 #include "stats_host.hpp"
 #include "stream_stats.hpp"
 #include "regex_vm.hpp"
@@ -90,6 +92,7 @@ static void apply_tuning(bsk_ctx* c) {
     c->use_dpp = !c->tune.is("scan", "shfl");
     c->stats_a_dense = c->tune.is("stats_a", "dense");
     c->min_range_bytes = (uint64_t)c->tune.num("min_range_bytes", (long long)MIN_RANGE_BYTES);
+    c->out_slices = c->tune.is("out", "slices");
 }
 
 int init_device(bsk_ctx* c) {
@@ -273,7 +276,7 @@ void bsk_destroy(bsk_ctx* c) {
         if (c->d_keys_sparse) hipFree(c->d_keys_sparse);
         if (c->d_ovf) hipFree(c->d_ovf);
         if (c->d_own) hipFree(c->d_own);
-        for (void* p : {(void*)c->d_xreq, (void*)c->d_xtext, (void*)c->d_xflag, (void*)c->d_xres})
+        for (void* p : {(void*)c->d_xreq, (void*)c->d_xtext, (void*)c->d_xflag, (void*)c->d_xres, (void*)c->d_slice_src})
             if (p) hipFree(p);
         if (c->d_set_keys) hipFree(c->d_set_keys);
         if (c->d_set_idx) hipFree(c->d_set_idx);
@@ -786,6 +789,7 @@ static int check_run_args(bsk_ctx* c, const void* shard, size_t n, int format) {
     if (format != BSK_FORMAT_FASTA && format != BSK_FORMAT_FASTQ)
         return fail(c, BSK_ERR_INVALID_ARG, "libbsk: format must be BSK_FORMAT_FASTA or BSK_FORMAT_FASTQ");
     if (n && !shard) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null shard");
+    c->pend_out.kind = 0;  // (a run begins: a result of an earlier run that is still a list of slices dies here, like its d_data would)
     return BSK_OK;
 }
 
@@ -794,8 +798,38 @@ int bsk_out_to_host(bsk_ctx* c, const bsk_out* out, void* dst, size_t cap) {
     if (out->len > cap) return fail(c, BSK_ERR_CAPACITY, "libbsk: output buffer too small");
     BSK_ENTER(c);
     HIP_TRY(c, hipDeviceSynchronize());
-    if (out->len) HIP_TRY(c, hipMemcpy(dst, out->d_data, out->len, hipMemcpyDeviceToHost));
+    if (out->len == 0) return BSK_OK;
+    if (out->n_segments == 0) {
+        HIP_TRY(c, hipMemcpy(dst, out->d_data, out->len, hipMemcpyDeviceToHost));
+        return BSK_OK;
+    }
+    // a list of slices: gathered piece by piece into one staging buffer of the device and copied from there (the context
+    // keeps the slices: the caller's bsk_out stays what it was)
+    const bsk_ctx::PendingOut& P = c->pend_out;
+    if (P.kind == 0 || out->d_seg_src != P.seg_src || out->d_seg_off != P.seg_off || out->n_segments != P.nseg || out->len != P.total)
+        return fail(c, BSK_ERR_INVALID_ARG, "libbsk: this result is not the one the context holds as slices (a later run replaced it)");
+    int rc = pending_first4k(c, nullptr);
+    if (rc != BSK_OK) return rc;
+    constexpr uint64_t PIECE = 64ull << 20;
+    uint8_t* d_piece = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_piece, (size_t)std::min<uint64_t>(PIECE, (P.total + 4095) & ~4095ull)));
+    hipError_t e = hipSuccess;
+    for (uint64_t at = 0; at < P.total && e == hipSuccess; at += PIECE) {
+        const uint64_t to = std::min<uint64_t>(P.total, at + PIECE);
+        e = launch_seg_copy_range(P.seg_src, P.seg_off, P.nseg, P.first4k, d_piece, at, to, P.total, P.lo, P.hi, nullptr);
+        if (e == hipSuccess) e = hipMemcpy((uint8_t*)dst + at, d_piece, (size_t)(to - at), hipMemcpyDeviceToHost);
+    }
+    hipFree(d_piece);
+    if (e != hipSuccess) return fail(c, BSK_ERR_HIP, std::string("libbsk: gathering the slices of the result failed: ") + hipGetErrorString(e));
     return BSK_OK;
+}
+
+int bsk_out_materialize(bsk_ctx* c, bsk_out* out, void* stream) {
+    if (!c || !out) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: null argument");
+    if (out->n_segments == 0) return BSK_OK;
+    if (c->device < 0) return fail(c, BSK_ERR_NO_DEVICE, "libbsk: context was created without a device");
+    BSK_ENTER(c);
+    return materialize_out(c, out, (hipStream_t)stream);
 }
 
 typedef int (*run_fn)(bsk_ctx*, const uint8_t*, size_t, int, hipStream_t, bsk_out*);
@@ -937,6 +971,7 @@ int bsk_index_copy(bsk_ctx* c, uint64_t* starts, uint32_t* head_len, uint32_t* s
 
 int bsk_seq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                 bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
@@ -976,6 +1011,7 @@ static int run_record_op(bsk_ctx* c, Op want, const char* what, run_fn fn, const
 
 int bsk_grep_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                  bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Grep, "Grep", grep_run_device, shard, n, on_device, format, stream, out);
 }
@@ -988,12 +1024,14 @@ int bsk_grep_last_count(const bsk_ctx* c, uint64_t* count) {
 
 int bsk_subseq_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                    bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Subseq, "SubseqTransform", subseq_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_faidx_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t base_offset,
                   void* stream, bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     if (!c) return BSK_ERR_INVALID_ARG;
     CallValues cv;
@@ -1003,6 +1041,7 @@ int bsk_faidx_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
 
 int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
                    bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Concat || !out || n_first > n) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Concat context / bad argument");
@@ -1028,6 +1067,7 @@ int bsk_concat_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int 
 
 int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file_ends, uint32_t n_files, int on_device,
                    int format, void* stream, bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Common || !out || !file_ends || n_files < 2 || n_files > 64 || file_ends[n_files - 1] != n)
@@ -1054,6 +1094,7 @@ int bsk_common_run(bsk_ctx* c, const void* shard, size_t n, const uint64_t* file
 
 int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on_device, int format, void* stream,
                  bsk_out* outs) {
+    if (outs) for (int k__ = 0; k__ < 4; ++k__) { outs[k__].d_seg_src = nullptr; outs[k__].d_seg_off = nullptr; outs[k__].n_segments = 0; }
     int rc = check_run_args(c, shard, n, format);
     if (rc != BSK_OK) return rc;
     if (c->op != Op::Pair || !outs || n_first > n) return fail(c, BSK_ERR_INVALID_ARG, "libbsk: not a Pair context / bad argument");
@@ -1079,24 +1120,28 @@ int bsk_pair_run(bsk_ctx* c, const void* shard, size_t n, size_t n_first, int on
 
 int bsk_faidx_query_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                         bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Faidx, "Faidx", faidx_query_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_sort_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                  bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Sort, "Sort", sort_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_rename_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                    bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Rename, "Rename", rename_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_fq2fa_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                   bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Fq2Fa, "Fq2Fa", fq2fa_run_device, shard, n, on_device, format, stream, out);
 }
@@ -1121,6 +1166,7 @@ int bsk_range_bounds(const bsk_ctx* c, int64_t* start, int64_t* end) {
 
 int bsk_range_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, uint64_t first_record,
                   void* stream, bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     if (!c) return BSK_ERR_INVALID_ARG;
     const int64_t fr = (int64_t)first_record;
@@ -1132,12 +1178,14 @@ int bsk_range_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int fo
 
 int bsk_duplicate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Duplicate, "Duplicate", records_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_locate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                    bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     CallValues cv;
     cv.pid = &pid;
     return run_record_op(c, Op::Locate, "Locate", locate_run_device, shard, n, on_device, format, stream, out, cv);
@@ -1145,12 +1193,14 @@ int bsk_locate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int f
 
 int bsk_translate_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                       bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::Translate, "Translate", translate_run_device, shard, n, on_device, format, stream, out);
 }
 
 int bsk_rmdup_run(bsk_ctx* c, const void* shard, size_t n, int on_device, int format, int64_t pid, void* stream,
                   bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     (void)pid;
     return run_record_op(c, Op::RmDup, "RmDup", rmdup_run_device, shard, n, on_device, format, stream, out);
 }
@@ -1237,6 +1287,7 @@ int bsk_rmdup_dist_resolve_ex(bsk_ctx* c, const void* d_tuples, uint64_t m, void
 
 int bsk_rmdup_dist_emit_ex(bsk_ctx* c, const void* d_send, const void* d_reply, const void* d_survivor_reply, uint64_t base_index,
                            void* stream, bsk_out* out, uint64_t* local_pairs_verified) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     int rc = dist_enter(c, "bsk_rmdup_dist_emit_ex");
     if (rc != BSK_OK) return rc;
     BSK_ENTER(c);
@@ -1306,6 +1357,7 @@ int bsk_rmdup_dist_stats(const bsk_ctx* c, uint64_t* local_pairs, uint64_t* cros
 
 int bsk_rmdup_dist_emit(bsk_ctx* c, const void* d_send, const void* d_reply, uint64_t base_index, void* stream,
                         bsk_out* out) {
+    if (out) { out->d_seg_src = nullptr; out->d_seg_off = nullptr; out->n_segments = 0; }
     int rc = dist_enter(c, "bsk_rmdup_dist_emit");
     if (rc != BSK_OK) return rc;
     BSK_ENTER(c);

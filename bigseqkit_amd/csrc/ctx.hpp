@@ -28,7 +28,7 @@
 struct bsk_tuning {
     static const char* const* names() {
         static const char* const N[] = {"filter", "grep_shiftand", "index", "locate_nopre", "long_bytes", "min_range_bytes", "names",
-                                        "names_scale", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_k2_bits", "rmdup_keys", "rmdup_place", "rmdup_xcheck", "rmdup_xlocal", "scan", "segcopy",
+                                        "names_scale", "out", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_k2_bits", "rmdup_keys", "rmdup_place", "rmdup_xcheck", "rmdup_xlocal", "scan", "segcopy",
                                         "sort", "stage_bytes", "stats_a", "stats_fasta", "subseq", "subseq_scale", "text", "translate", "translate_index", "translate_stream", "tr_lanes", nullptr};
         return N;
     }
@@ -287,6 +287,22 @@ struct bsk_ctx {
     int region_start = 0, region_end = 0;  // parsed -R / -r
     bool region_on = false;
     uint64_t last_count = 0;               // grep -C result of the last run
+
+    // ---- round 6: a result that is still a list of slices (bsk_out.d_seg_*; include/bsk.h) and what makes it one block
+    struct PendingOut {
+        int kind = 0;              // 0: none; 1: segments of the shard (k_seg_copy); 2: per-range slices of a streaming pass (k_names_compact)
+        uint64_t total = 0, records = 0, nseg = 0;
+        const uint64_t* seg_src = nullptr;
+        const uint64_t* seg_off = nullptr;
+        const uint32_t* first4k = nullptr;  // kind 1 (kind 2: built when a consumer gathers pieces)
+        const uint8_t *lo = nullptr, *hi = nullptr;
+        uint64_t slice_cap = 0;             // kind 2
+        uint64_t gen = 0;                   // the run that produced it (call_gen of the producing call's scope)
+    } pend_out;
+    bool out_slices = false;                // switch "out" = "slices"
+    bool force_contiguous = false;          // the running call needs one block whatever the switch says (bsk_run_to_store's chunks, operators that read the output again)
+    uint64_t* d_slice_src = nullptr;        // kind 2: source address per range
+    uint64_t slice_src_cap = 0;
 
     // ---- staging for host-resident shards ------------------------------------
     void* drainer = nullptr;   // pinned staging + events of the output drain (store.cpp: Drainer)

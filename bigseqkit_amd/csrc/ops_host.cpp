@@ -722,6 +722,78 @@ void apply_long(const bsk_ctx* c, SeqParams* P) {
     P->long_thresh = c->long_count ? c->long_thresh : 0u;
 }
 
+void out_as_segments(bsk_ctx* c, bsk_out* out, const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
+                     const uint8_t* lo, const uint8_t* hi, uint64_t total, uint64_t records) {
+    bsk_ctx::PendingOut& P = c->pend_out;
+    P = bsk_ctx::PendingOut();
+    P.kind = 1;
+    P.total = total; P.records = records; P.nseg = nseg;
+    P.seg_src = seg_src; P.seg_off = seg_off; P.first4k = first4k;
+    P.lo = lo; P.hi = hi;
+    P.gen = c->call_gen;
+    out->d_data = nullptr;
+    out->len = total;
+    out->records = records;
+    out->d_seg_src = seg_src;
+    out->d_seg_off = seg_off;
+    out->n_segments = nseg;
+}
+
+int out_as_slices(bsk_ctx* c, bsk_out* out, const uint8_t* slices, uint64_t slice_cap, const uint64_t* range_base, uint32_t nranges,
+                  uint64_t total, uint64_t records, hipStream_t st) {
+    int rc = grow(c, &c->d_slice_src, &c->slice_src_cap, (uint64_t)nranges + 1, 64);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_slice_srcs(slices, slice_cap, nranges, c->d_slice_src, st));
+    bsk_ctx::PendingOut& P = c->pend_out;
+    P = bsk_ctx::PendingOut();
+    P.kind = 2;
+    P.total = total; P.records = records; P.nseg = nranges;
+    P.seg_src = c->d_slice_src; P.seg_off = range_base; P.first4k = nullptr;
+    P.lo = slices; P.hi = slices + slice_cap * (uint64_t)nranges;
+    P.slice_cap = slice_cap;
+    P.gen = c->call_gen;
+    out->d_data = nullptr;
+    out->len = total;
+    out->records = records;
+    out->d_seg_src = P.seg_src;
+    out->d_seg_off = P.seg_off;
+    out->n_segments = nranges;
+    return BSK_OK;
+}
+
+int pending_first4k(bsk_ctx* c, hipStream_t st) {
+    bsk_ctx::PendingOut& P = c->pend_out;
+    if (P.first4k || P.total == 0) return BSK_OK;
+    int rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(P.total) + 1, 64);
+    if (rc != BSK_OK) return rc;
+    HIP_TRYX(c, launch_seg_first(P.seg_off, P.nseg, c->d_seg_first, st));
+    P.first4k = c->d_seg_first;
+    return BSK_OK;
+}
+
+int materialize_out(bsk_ctx* c, bsk_out* out, hipStream_t st) {
+    if (out->n_segments == 0) return BSK_OK;
+    bsk_ctx::PendingOut& P = c->pend_out;
+    if (P.kind == 0 || out->d_seg_src != P.seg_src || out->d_seg_off != P.seg_off || out->n_segments != P.nseg || out->len != P.total) {
+        c->set_error("libbsk: this result is not the one the context holds as slices (a later run replaced it)");
+        return BSK_ERR_INVALID_ARG;
+    }
+    int rc = ensure_out(c, P.total);
+    if (rc != BSK_OK) return rc;
+    if (P.total) {
+        rc = pending_first4k(c, st);
+        if (rc != BSK_OK) return rc;
+        Timed tm(c, P.kind == 1 ? "k_seg_copy" : "k_slices_compact", st);
+        HIP_TRYX(c, launch_seg_copy(P.seg_src, P.seg_off, P.nseg, P.first4k, c->d_out, P.total, P.lo, P.hi, st));
+    }
+    out->d_data = c->d_out;
+    out->d_seg_src = nullptr;
+    out->d_seg_off = nullptr;
+    out->n_segments = 0;
+    P.kind = 0;
+    return BSK_OK;
+}
+
 int empty_result(bsk_ctx* c, bsk_out* out) {
     out->d_data = nullptr;
     out->len = 0;

@@ -86,6 +86,18 @@ int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P,
 int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, const uint32_t* d_len, const uint64_t* d_off,
                     uint8_t* d_out, uint64_t total, uint64_t kept, hipStream_t st);
 int empty_result(bsk_ctx* c, bsk_out* out);
+// Round 6, results as ordered slices (include/bsk.h bsk_out.d_seg_*): does the running call leave its text where it is?
+inline bool slices_wanted(const bsk_ctx* c) { return c->out_slices && !c->force_contiguous; }
+// ... the text as segments of the shard (kind 1: what launch_seg_copy would move) / as the per-range slices of a streaming
+// pass (kind 2: what launch_names_compact would gather; range_base = [nranges + 1] scanned bytes)
+void out_as_segments(bsk_ctx* c, bsk_out* out, const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
+                     const uint8_t* lo, const uint8_t* hi, uint64_t total, uint64_t records);
+int out_as_slices(bsk_ctx* c, bsk_out* out, const uint8_t* slices, uint64_t slice_cap, const uint64_t* range_base, uint32_t nranges,
+                  uint64_t total, uint64_t records, hipStream_t st);
+// one block in c->d_out after all (out->d_data set, slice fields cleared); no-op on a contiguous result
+int materialize_out(bsk_ctx* c, bsk_out* out, hipStream_t st);
+// first4k of the pending result (kind 2 builds it on first use)
+int pending_first4k(bsk_ctx* c, hipStream_t st);
 // SeqParams that print the whole record unchanged == fastx.Record.Format(lineWidth)
 SeqParams format_params(bsk_ctx* c, bool fastq);
 void set_bits(uint32_t* set, const std::string& letters);

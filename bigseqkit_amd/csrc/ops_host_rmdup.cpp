@@ -356,6 +356,14 @@ int rmdup_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hip
         rc = finish_sizes(c, st, &total, &kept);
     }
     if (rc != BSK_OK) return rc;
+    // Round 6: the survivors ARE text of the shard, in output order -- with the switch "out" = "slices" the result is the
+    // list of them (segment i = record i, empty for a duplicate) and nothing is copied: RmDupCheck's result elements are the
+    // strings it was handed (rmdup.go:200-222).  Not with side files (-d / -D read the scratch arrays again) and not when
+    // some record must be re-formatted ('+' lines that repeat the name: FIN_OTHER).
+    if (placed && total && slices_wanted(c) && c->fin(bsk_ctx::FIN_OTHER) == 0 && o.s("DupSeqsFile").empty() && o.s("DupNumFile").empty()) {
+        out_as_segments(c, out, c->d_seg_src, c->d_out_off, N, c->d_seg_first, d_buf, d_buf + n, total, kept);
+        return BSK_OK;
+    }
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     F = format_params(c, fastq);

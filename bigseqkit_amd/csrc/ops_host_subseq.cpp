@@ -327,6 +327,10 @@ static int subseq_stream_run(bsk_ctx* c, const uint8_t* d_buf, size_t n, hipStre
         if (status == 0) return BSK_ERR_FILTER_FALLBACK;
     }
     if (status) return kernel_error_to_status(c, status);
+    if (total && slices_wanted(c)) {  // round 6: the per-range slices ARE the result, in order (include/bsk.h bsk_out.d_seg_*)
+        c->table.n = 0;
+        return out_as_slices(c, out, D.slices, D.slice_cap, c->d_range_base, nranges, total, records, st);
+    }
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     if (total) {

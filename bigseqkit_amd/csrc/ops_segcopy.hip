@@ -133,18 +133,21 @@ __device__ __forceinline__ uint32_t incl_scan64(uint32_t v) {  // inclusive sum 
 
 constexpr int32_t REL_MIN = -(1 << 30), REL_MAX = (1 << 30);
 
+// The output bytes [tile0 * SEG_TILE, total) of the text whose whole length is `whole`; `out` is the address output byte 0
+// WOULD have (a piece of the text gathered into a staging buffer: buffer - tile0 * SEG_TILE).  The whole text: tile0 = 0,
+// total = whole.
 __global__ __launch_bounds__(256) void k_seg_copy(const uint64_t* __restrict__ seg_src, const uint64_t* __restrict__ seg_off,
                                                   uint64_t nseg, const uint32_t* __restrict__ first4k, uint8_t* __restrict__ out,
-                                                  uint64_t total, const uint8_t* lo, const uint8_t* hi) {
+                                                  uint64_t total, const uint8_t* lo, const uint8_t* hi, uint64_t tile0, uint64_t whole) {
     __shared__ int32_t s_rel[4][66];     // begin of the wave's segments relative to its tile (clamped); [m] = end of the last
     __shared__ uint64_t s_delta[4][64];  // source address of output byte x = delta + x
     __shared__ uint32_t s_hist[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4u + wv;
+    const uint64_t tile = tile0 + (uint64_t)blockIdx.x * 4u + wv;
     const uint64_t T0 = tile * SEG_TILE;
     if (T0 >= total) return;
     const uint64_t k0 = first4k[tile];
-    const uint64_t k1 = (T0 + SEG_TILE < total) ? first4k[tile + 1] : nseg - 1;  // last segment that can begin in the tile
+    const uint64_t k1 = (T0 + SEG_TILE < whole) ? first4k[tile + 1] : nseg - 1;  // last segment that can begin in the tile
     const uint64_t m64 = k1 - k0 + 1;
     if (m64 <= 64) {
         const uint32_t m = (uint32_t)m64;
@@ -325,7 +328,30 @@ hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uin
     if (nseg == 0 || total == 0) return hipSuccess;
     const uint64_t tiles = seg_tiles(total);
     hipLaunchKernelGGL(k_seg_copy, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, seg_src, seg_off, nseg, first4k, out, total,
-                       lo, hi);
+                       lo, hi, (uint64_t)0, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_copy_range(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k, uint8_t* dst,
+                                 uint64_t from, uint64_t to, uint64_t whole, const uint8_t* lo, const uint8_t* hi, hipStream_t st) {
+    if (nseg == 0 || to <= from) return hipSuccess;
+    if (from % SEG_TILE || ((uintptr_t)dst & 15u)) return hipErrorInvalidValue;
+    const uint64_t tiles = seg_tiles(to) - from / SEG_TILE;
+    hipLaunchKernelGGL(k_seg_copy, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, seg_src, seg_off, nseg, first4k, dst - from, to,
+                       lo, hi, from / SEG_TILE, whole);
+    return hipGetLastError();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_slice_srcs(const uint8_t* slices, uint64_t slice_cap, uint32_t nranges, uint64_t* __restrict__ src) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nranges) src[r] = (uint64_t)(uintptr_t)(slices + (uint64_t)r * slice_cap);
+}
+}  // namespace
+
+hipError_t launch_slice_srcs(const uint8_t* slices, uint64_t slice_cap, uint32_t nranges, uint64_t* src, hipStream_t st) {
+    if (nranges == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_slice_srcs, dim3((nranges + 255) / 256), dim3(256), 0, st, slices, slice_cap, nranges, src);
     return hipGetLastError();
 }
 

@@ -43,4 +43,11 @@ hipError_t launch_seg_first(const uint64_t* seg_off, uint64_t nseg, uint32_t* fi
 hipError_t launch_seg_copy(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k,
                            uint8_t* out, uint64_t total, const uint8_t* lo, const uint8_t* hi, hipStream_t st);
 
+// the output bytes [from, to) of the text of `whole` bytes into dst[0, to - from) (from: a multiple of SEG_TILE, dst 16-byte
+// aligned): how a consumer gathers a result that is still a list of slices piece by piece (store.cpp)
+hipError_t launch_seg_copy_range(const uint64_t* seg_src, const uint64_t* seg_off, uint64_t nseg, const uint32_t* first4k, uint8_t* dst,
+                                 uint64_t from, uint64_t to, uint64_t whole, const uint8_t* lo, const uint8_t* hi, hipStream_t st);
+// src[r] = address of slice r of a per-range slice buffer (the segment form of the streaming passes' slices)
+hipError_t launch_slice_srcs(const uint8_t* slices, uint64_t slice_cap, uint32_t nranges, uint64_t* src, hipStream_t st);
+
 }  // namespace bsk

@@ -41,6 +41,8 @@
 #include "anchor.hpp"
 #include "ctx.hpp"
 #include "ops_host.hpp"
+#include "ops_host_internal.hpp"
+#include "ops_segcopy.hpp"
 
 using namespace bsk;
 
@@ -155,6 +157,7 @@ constexpr int DRAIN_NBUF = 3;
 struct Drainer {
     uint8_t* pin[DRAIN_NBUF] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[DRAIN_NBUF] = {nullptr, nullptr, nullptr};
+    uint8_t* dev[DRAIN_NBUF] = {nullptr, nullptr, nullptr};  // round 6: a result that is a list of slices is gathered piece by piece into these
 };
 
 int drainer_prepare(bsk_ctx* c) {
@@ -228,7 +231,8 @@ int finish_part(bsk_store* s, uint64_t part) {
 
 // device bytes -> store.  Returns a status and, on failure, the message in *err (the caller owns the context's error
 // text: this function also runs on the writer thread of bsk_run_to_store, next to the thread that computes).
-int drain_to_store(bsk_ctx* c, bsk_store* s, uint64_t part, const uint8_t* d, size_t n, bool last, hipStream_t d2h, std::string* err) {
+int drain_to_store(bsk_ctx* c, bsk_store* s, uint64_t part, const uint8_t* d, size_t n, bool last, hipStream_t d2h, std::string* err,
+                   const bsk_ctx::PendingOut* seg = nullptr /* the n bytes are this list of slices (d is null) */) {
     auto hipfail = [&](hipError_t e, const char* what) { *err = std::string(what) + ": " + hipGetErrorString(e); return BSK_ERR_HIP; };
 #define DR_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return hipfail(e__, #expr); } while (0)
     DR_TRY(hipSetDevice(c->device));
@@ -241,9 +245,17 @@ int drain_to_store(bsk_ctx* c, bsk_store* s, uint64_t part, const uint8_t* d, si
         if (rc != BSK_OK) { *err = s->err; return rc; }
         const size_t npieces = (n + DRAIN_PIECE - 1) / DRAIN_PIECE;
         auto piece_len = [&](size_t k) { return std::min(DRAIN_PIECE, n - k * DRAIN_PIECE); };
+        if (seg)
+            for (int b = 0; b < DRAIN_NBUF; ++b)
+                if (!D->dev[b]) DR_TRY(hipMalloc((void**)&D->dev[b], DRAIN_PIECE));
         auto issue = [&](size_t k) -> hipError_t {
             const int b = (int)(k % DRAIN_NBUF);
-            hipError_t e = hipMemcpyAsync(D->pin[b], d + k * DRAIN_PIECE, piece_len(k), hipMemcpyDeviceToHost, d2h);
+            const uint8_t* from = d ? d + k * DRAIN_PIECE : D->dev[b];
+            hipError_t e = hipSuccess;
+            if (seg)  // the piece of the text out of its slices (the buffer is free: the D2H copy that read it was waited for before its piece was written)
+                e = launch_seg_copy_range(seg->seg_src, seg->seg_off, seg->nseg, seg->first4k, D->dev[b], k * DRAIN_PIECE,
+                                          k * DRAIN_PIECE + piece_len(k), seg->total, seg->lo, seg->hi, d2h);
+            if (e == hipSuccess) e = hipMemcpyAsync(D->pin[b], from, piece_len(k), hipMemcpyDeviceToHost, d2h);
             return e == hipSuccess ? hipEventRecord(D->ev[b], d2h) : e;
         };
         // two copies in flight ahead of the piece being written (a buffer is free again once its piece has been written)
@@ -286,7 +298,7 @@ namespace bsk {
 void store_drainer_free(bsk_ctx* c) {
     Drainer* d = (Drainer*)c->drainer;
     if (!d) return;
-    for (int b = 0; b < DRAIN_NBUF; ++b) { if (d->pin[b]) hipHostFree(d->pin[b]); if (d->ev[b]) hipEventDestroy(d->ev[b]); }
+    for (int b = 0; b < DRAIN_NBUF; ++b) { if (d->pin[b]) hipHostFree(d->pin[b]); if (d->ev[b]) hipEventDestroy(d->ev[b]); if (d->dev[b]) hipFree(d->dev[b]); }
     delete d;
     c->drainer = nullptr;
 }
@@ -328,7 +340,21 @@ int bsk_store_put(bsk_store* s, bsk_ctx* c, uint64_t part, const bsk_out* o) {
     int rc = drainer_prepare(c);
     if (rc != BSK_OK) return rc;
     std::string err;
-    rc = drain_to_store(c, s, part, (const uint8_t*)o->d_data, o->len, true, c->copy_stream[1], &err);
+    if (o->n_segments && o->len) {
+        // round 6: the result is a list of slices (include/bsk.h): every 32 MiB piece of the text is gathered out of them into
+        // a staging buffer of the device and leaves from there -- the one block is never made
+        const bsk_ctx::PendingOut& P = c->pend_out;
+        if (P.kind == 0 || o->d_seg_src != P.seg_src || o->d_seg_off != P.seg_off || o->n_segments != P.nseg || o->len != P.total) {
+            c->set_error("libbsk: this result is not the one the context holds as slices (a later run replaced it)");
+            return BSK_ERR_INVALID_ARG;
+        }
+        rc = pending_first4k(c, nullptr);
+        if (rc != BSK_OK) return rc;
+        ST_TRY(c, hipDeviceSynchronize());
+        rc = drain_to_store(c, s, part, nullptr, o->len, true, c->copy_stream[1], &err, &P);
+    } else {
+        rc = drain_to_store(c, s, part, (const uint8_t*)o->d_data, o->len, true, c->copy_stream[1], &err);
+    }
     if (rc != BSK_OK) c->set_error(err);
     return rc;
 }
@@ -370,6 +396,11 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
     if (out_records) *out_records = 0;
     bsk_call_scope scope(c);
     if (!scope.owns) { c->set_error(BSK_BUSY_TEXT); return BSK_ERR_INVALID_ARG; }
+    // (the chunks' outputs are drained from the two output buffers while the next chunk computes: one block each, whatever
+    // the switch "out" says)
+    struct Contig { bsk_ctx* c; bool was; ~Contig() { c->force_contiguous = was; } } contig{c, c->force_contiguous};
+    c->force_contiguous = true;
+    c->pend_out.kind = 0;
     ST_TRY(c, hipSetDevice(c->device));
     for (int b = 0; b < 2; ++b)
         if (!c->copy_stream[b]) ST_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[b], hipStreamNonBlocking));

@@ -223,15 +223,20 @@ class DeviceText:
 
     def __init__(self, op, out, device):
         self.op, self.ptr, self.len, self.records, self.device = op, int(out.d_data or 0), int(out.len), int(out.records), device
+        self.out = out   # (with the switch "out" = "slices" the text may still be a list of slices: include/bsk.h bsk_out.d_seg_*)
 
     def __len__(self):
         return self.len
 
     def tensor(self):
-        """torch uint8 view of the bytes (no copy; valid until the context's next run)"""
+        """torch uint8 view of the bytes (no copy; valid until the context's next run).  A result that is still a list of
+        slices is made one block first (bsk_out_materialize)."""
         import torch
         if self.len == 0:
             return torch.empty(0, dtype=torch.uint8, device=self.device)
+        if self.out.n_segments:
+            check(lib.bsk_out_materialize(self.op.ctx, C.byref(self.out), None), self.op.ctx)
+            self.ptr = int(self.out.d_data or 0)
 
         class _Arr:  # __cuda_array_interface__ works for HIP pointers in torch-rocm
             pass
@@ -240,10 +245,8 @@ class DeviceText:
         return torch.as_tensor(a, device=self.device)
 
     def __bytes__(self):
-        from . import _lib
-        out = _lib.Out(self.ptr, self.len, self.records)
         buf = C.create_string_buffer(max(1, self.len))
-        check(lib.bsk_out_to_host(self.op.ctx, C.byref(out), buf, self.len), self.op.ctx)
+        check(lib.bsk_out_to_host(self.op.ctx, C.byref(self.out), buf, self.len), self.op.ctx)
         return buf.raw[:self.len]
 
 

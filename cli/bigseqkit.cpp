@@ -551,7 +551,12 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
         if (bsk_create(inv.cmd->op, js.c_str(), device, &c) != BSK_OK) die(bsk_global_error());
         return c;
     };
-    if (!(keep_on_device && records_out)) ctx = fresh();
+    if (!(keep_on_device && records_out)) {
+        ctx = fresh();
+        // the result goes to the host right after the run, while the input is still there: the operators that can leave their
+        // text as ordered slices (rmdup, seq -n, subseq -r: include/bsk.h bsk_out.d_seg_*) do, and bsk_out_to_host gathers them
+        bsk_ctx_set(ctx, "out", "slices");
+    }
     // range / head: the record index runs over the union of the inputs (cli/helper.go unions the files into one
     // dataframe); negative positions need the total (bigseqkit/range.go:69-80)
     std::vector<uint64_t> first(inputs.size(), 0);
@@ -873,6 +878,7 @@ int run_devices(const Invocation& inv) {
         auto give_up = [&](const std::string& m) { if (me.error.empty()) me.error = m.empty() ? "failed" : m; failed.fetch_add(1); };
         do {
             if (bsk_create(inv.cmd->op, inv.js.c_str(), device, &ctx) != BSK_OK) { give_up(bsk_global_error()); break; }
+            bsk_ctx_set(ctx, "out", "slices");  // (the shard stays on the device until bsk_store_put has drained the result)
             mark("context", rank);
             // this worker's bytes, and only they: from the file to the device in pieces, several readers (bsk_shard_load).
             // A record operator whose shard AND output may not fit the GPU side by side keeps the chunked host pipeline

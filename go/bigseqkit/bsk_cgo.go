@@ -187,6 +187,13 @@ func mapPartitions(name string, fn C.bsk_run_fn, optsJSON string, in *SeqFrame, 
 				return
 			}
 			defer op.Close()
+			// a result is copied to Go memory right after its run (bsk_out_to_host), while the staged shard is still the
+			// context's: the operators that can leave their text as ordered slices do (include/bsk.h bsk_out.d_seg_*) --
+			// the reference's []string elements share the partition's bytes just so
+			cOut, cSlices := C.CString("out"), C.CString("slices")
+			C.bsk_ctx_set(op.ctx, cOut, cSlices)
+			C.free(unsafe.Pointer(cOut))
+			C.free(unsafe.Pointer(cSlices))
 			for {
 				mu.Lock()
 				pid := next

@@ -210,12 +210,29 @@ int bsk_stats_string(const bsk_ctx* ctx, const char* name, const char* format, c
  * Here the result of one Call() is that byte stream, left in a ctx-owned DEVICE
  * buffer (valid until the next run on the same ctx or bsk_destroy). */
 typedef struct {
-    void* d_data;     /* device pointer, `len` bytes */
+    void* d_data;     /* device pointer, `len` bytes -- or NULL while the text is an ordered list of slices (below) */
     size_t len;
     uint64_t records; /* number of elements (output records) */
+    /* Round 6 -- the result as ORDERED SLICES (switch "out" = "slices", bsk_ctx_set; default "contiguous": these are 0).
+     * The reference's Call returns []string whose elements are (for seq -n, subseq, rmdup ...) Go strings that share the
+     * bytes of the partition or of per-goroutine buffers: nothing is moved into one block
+     * (bigseqkit-lib/subseq.go:167-225, seq.go:81-269, rmdup.go:200-222).  With "slices" an operator whose output text
+     * already sits somewhere in HBM in output order -- the survivors of rmdup inside the input shard, the per-range
+     * buffers the streaming passes of `seq -n` and `subseq -r` write -- returns that: segment k is the
+     * d_seg_off[k + 1] - d_seg_off[k] bytes at device address d_seg_src[k]; the text is their concatenation (len bytes).
+     * bsk_out_to_host, bsk_store_put and the Go shim consume slices as they are (gathered piece by piece into the
+     * staging buffers of the drain); bsk_out_materialize makes the one block for a consumer that needs it (the next
+     * operator of a pipe).  LIFETIME: slices of rmdup point into the caller's SHARD -- it must stay until the output is
+     * consumed (with "contiguous" it may go as soon as the run returns); like d_data they die with the context's next run. */
+    const uint64_t* d_seg_src; /* device: [n_segments] source addresses */
+    const uint64_t* d_seg_off; /* device: [n_segments + 1] offsets in the output text */
+    uint64_t n_segments;       /* 0: d_data holds the text */
 } bsk_out;
 /* copy an operator result to host memory (synchronises) */
 int bsk_out_to_host(bsk_ctx* ctx, const bsk_out* out, void* dst, size_t cap);
+/* a result that is still a list of slices becomes ONE block in the context's output buffer (today's second move of the
+ * text: k_seg_copy / k_names_compact); out->d_data is set, the slice fields are cleared.  No-op on a contiguous result. */
+int bsk_out_materialize(bsk_ctx* ctx, bsk_out* out, void* stream);
 
 /* ---- record table: SeqParser.Read (bigseqkit-lib/helper.go:219-325) --------
  * Builds, for a device- or host-resident shard, the SoA table of record slices the

@@ -171,6 +171,8 @@ def test_fuzz_every_command(seed, monkeypatch):
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
     if seed % 2:   # (round 5) every FASTA translate that qualifies through the one-pass kernel, whatever its record size
         monkeypatch.setenv("BSK_TRANSLATE_STREAM", "force")
+    if seed % 3 == 0:   # (round 6) results as ordered slices where an operator can leave them (rmdup -s, seq -n, subseq -r on FASTQ)
+        monkeypatch.setenv("BSK_OUT", "slices")
     rng = random.Random(5000 + seed)
     agree = errors = 0
     for it in range(90):
