@@ -931,31 +931,51 @@ def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, b
     surv_all = bdist.all_reduce_count(text.records, dev)
     out_bytes_all = bdist.all_reduce_count(text.len, dev)
     ok = all_ok(ok and text.len == REC * text.records) and surv_all == N - N // 5
-    names = ["keys", "pack", "all_to_all", "resolve", "reply", "emit"]
+    names = ["keys", "pack", "all_to_all", "resolve", "reply", "xpack", "xchange", "xcompare", "xreply", "xapply", "emit"]
     rows = bdist.all_gather_floats([own * 1e3] + [phases.get(k, 0.0) for k in names]
                                    + [phases.get("tuple_bytes_sent", 0), phases.get("tuple_bytes_sent_off_rank", 0)], dev)
     alg = N * REC + 16 * N + out_bytes_all
-    lp_rows = bdist.all_gather_floats([float(getattr(be, "local_pairs", 0))], dev)
+    # round 6: every duplicate is byte-compared with its survivor, the ones whose survivor lives on another rank through the
+    # text exchange of dist._xcheck: (pairs inside the shard, pairs across ranks, flagged records, subject bytes sent) per rank
+    lp, xp, fl = be.pair_stats()
+    lp_rows = bdist.all_gather_floats([float(lp), float(xp), float(fl), float(phases.get("xcheck_text_bytes_sent", 0)), float(nrec - text.records)], dev)
+    compared_all, dups_all = sum(int(r[0] + r[1]) for r in lp_rows), sum(int(r[4]) for r in lp_rows)
+    ok = ok and compared_all == dups_all == N // 5 and sum(int(r[2]) for r in lp_rows) == 0
+    # the same job with the cross-rank comparison switched off (round 5's decision rule: pairs that cross ranks rest on their
+    # two keys): what the text exchange costs
+    os.environ["BSK_RMDUP_XCHECK"] = "off"
+    try:
+        text_k, per_call_k, _ = job_time(lambda: bdist.rmdup_distributed(t, bsk.FORMAT_FASTQ, be, to_host=False))
+        ok_k = all_ok(text_k.len == text.len and text_k.records == text.records)
+    finally:
+        del os.environ["BSK_RMDUP_XCHECK"]
     ops["rmdup -s @ C5"] = {
         "command": "rmdup -s", "n_gpus": world, "backend": backend_name, "scaling": "weak",
         "workload": "%.1f GB FASTQ-150 per rank x %d ranks (C5 is 8 x 25 GB), record i with i %% 5 == 4 repeats the bases of a "
                     "record up to 1 001 places earlier (possibly on the rank before)" % (per * REC / 1e9, world),
         "records": N, "in_bytes": N * REC, "out_bytes": out_bytes_all, "survivors": int(surv_all), "calls": calls,
-        "collective": "all_gather(record counts) + all_to_all_single(24-byte tuples to owner = key %% N) + "
-                      "all_to_all_single(keep bytes)",
+        "collective": "all_gather(record counts) + all_to_all_single(24-byte tuples to owner = key %% N) + all_to_all_single(keep bytes, "
+                      "survivor indices) + the text of every duplicate whose survivor lives on another rank to that rank "
+                      "(24-byte requests + the bases) and one verdict byte back",
         "ms": round(per_call * 1e3, 4), "M_records_per_s": round(N / per_call / 1e6, 2),
         "algorithmic_bytes": int(alg), "achieved_GBps": round(alg / per_call / 1e9, 1),
         "frac": round(alg / per_call / 1e9 / (HBM_PEAK_GBS * world), 4),
         "per_rank_own_ms": [round(r[0], 4) for r in rows],
         "phases_ms_per_rank": {k: [round(r[1 + i], 4) for r in rows] for i, k in enumerate(names)},
-        "tuple_bytes_sent_per_rank": [int(r[7]) for r in rows], "tuple_bytes_sent_off_rank_per_rank": [int(r[8]) for r in rows],
+        "tuple_bytes_sent_per_rank": [int(r[1 + len(names)]) for r in rows], "tuple_bytes_sent_off_rank_per_rank": [int(r[2 + len(names)]) for r in rows],
         "survivors_resident": "HBM (DeviceText: the context's output buffer; no host copy)",
-        "rmdup_keys": "across ranks a record travels as (XXH64, second 64-bit key, global index) to owner = key % N and equal (k1, k2) "
-                      "decide there -- the owner does not hold the text; equal k1 with different k2 are kept apart through the overflow "
-                      "list.  The owner's reply names the survivor: a duplicate whose survivor lives in the SAME shard is byte-compared "
-                      "with it on its rank (RmDupCheck's test, as the single-GPU call does for every duplicate); pairs that cross "
-                      "ranks stay with the two keys (PARITY.md KEYS)",
+        "rmdup_keys": "across ranks a record travels as (XXH64, second 64-bit key, global index) to owner = key % N, where equal (k1, k2) "
+                      "GROUP -- the owner holds no text.  The owner's reply names the survivor, and EVERY duplicate is then byte-compared "
+                      "with it (RmDupCheck's test, bigseqkit-lib/rmdup.go:193-211): inside its shard when the survivor lives there, else "
+                      "its bases travel to the survivor's rank, which answers one byte.  Records whose text differs from their "
+                      "survivor's are regrouped by text over all ranks (none here: real keys)",
         "pairs_byte_compared_per_rank": [int(r[0]) for r in lp_rows],
+        "pairs_byte_compared_across_ranks_per_rank": [int(r[1]) for r in lp_rows],
+        "compared_pairs": int(compared_all), "duplicates": int(dups_all), "flagged_records": int(sum(int(r[2]) for r in lp_rows)),
+        "subject_bytes_sent_per_rank": [int(r[3]) for r in lp_rows],
+        "without_cross_rank_comparison": {"ms": round(per_call_k * 1e3, 4), "exact": bool(ok_k),
+                                          "note": "BSK_RMDUP_XCHECK=off: pairs that cross ranks rest on their two keys (round 5); "
+                                                  "the difference to `ms` is what the text exchange costs"},
         "exact": bool(ok),
         "exact_how": "every rank: output == the records of its shard with GLOBAL index %% 5 != 4, byte for byte in file order; "
                      "survivors over all ranks == N - N // 5"}

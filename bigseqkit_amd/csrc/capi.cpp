@@ -1463,6 +1463,11 @@ int bsk_profile_dump(bsk_ctx* c, char* buf, size_t cap) {
         out += kv.first;
         out += num;
     }
+    if (c->translate_stream_fallbacks) {  // (not a stage: how often the one-pass translate did not fit and the tables ran instead)
+        char num[96];
+        snprintf(num, sizeof num, "translate_stream_fallback=0.000000/%llu;", (unsigned long long)c->translate_stream_fallbacks);
+        out += num;
+    }
     if (out.size() + 1 > cap) { c->set_error("libbsk: bsk_profile_dump: buffer too small"); return BSK_ERR_CAPACITY; }
     memcpy(buf, out.c_str(), out.size() + 1);
     return BSK_OK;

@@ -173,6 +173,13 @@ struct bsk_ctx {
     bool codon_ready = false;        // d_codon holds the tables of this context's options
     bool translate_uniform_ok = true;  // FASTA: try the table-free pass on records that all look alike first (UniformLayout)
     bool translate_stream_ok = true;  // FASTA of long records: try the one-pass translation (k_translate_stream) before any table
+    // (round 6, ADVICE r05: a misfit -- one chromosome-sized record, one range with more than 512 records -- used to send
+    // the context to the table paths FOR GOOD, and long-lived contexts, the pipe pool or bsk_run_to_store's chunks, lost the
+    // fast path silently.  Now the next `translate_stream_skip` calls take the tables, then the one-pass kernel is tried
+    // again; the back-off doubles with every misfit in a row (8, 16, ... 1 024 calls) so that a file of chromosomes does
+    // not pay the wasted pass more than a few times.  bsk_profile_dump reports the misfits as "translate_stream_fallback".)
+    uint32_t translate_stream_skip = 0, translate_stream_backoff = 8;
+    uint64_t translate_stream_fallbacks = 0;
     bool translate_light_ok = true;  // FASTA: try the record table from the '>' bytes alone first (stream_fasta_light.hip)
     uint8_t* d_redo = nullptr;    // one byte per record: left by k_translate_wide to k_translate_frames4
     uint64_t redo_cap = 0;

@@ -331,7 +331,8 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     // ---- FASTA of long records that do NOT all look alike (round 5): one pass -- record starts, sizes, output offsets and the
     // translation itself (k_translate_stream), every window verified; anything that does not fit and the call goes on below
     // with the tables, and the context stays with them.  translate_stream = off skips it, = force takes it for short records too.
-    if (format == BSK_FORMAT_FASTA && n > 0 && c->translate_stream_ok && !c->tune.get("translate_index") && !c->tune.get("translate") &&
+    if (c->translate_stream_skip) --c->translate_stream_skip;  // (backing off after a misfit: this call takes the tables)
+    else if (format == BSK_FORMAT_FASTA && n > 0 && c->translate_stream_ok && !c->tune.get("translate_index") && !c->tune.get("translate") &&
         !c->tune.is("translate_stream", "off") && !P.init_m && !P.trim && !P.append_frame && !c->id_custom && (P.line_width == 0 || P.line_width >= 16)) {
         rc = sample_head(c, d_buf, n, st);
         if (rc != BSK_OK) return rc;
@@ -386,9 +387,13 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
                 out->d_data = c->d_out;
                 out->len = c->fin(bsk_ctx::FIN_TOTAL);
                 out->records = c->fin(bsk_ctx::FIN_KEPT) * (uint64_t)P.nframes;
+                c->translate_stream_backoff = 8;
                 return BSK_OK;
             }
-            c->translate_stream_ok = false;  // something did not fit: the table paths, from now on
+            // something did not fit: this call and the next few take the table paths, then the pass is tried again
+            ++c->translate_stream_fallbacks;
+            c->translate_stream_skip = c->translate_stream_backoff;
+            c->translate_stream_backoff = std::min<uint32_t>(1024, c->translate_stream_backoff * 2);
             HIP_TRYX(c, hipMemsetAsync(c->d_status, 0, 8 * sizeof(uint64_t), st));
         }
     }

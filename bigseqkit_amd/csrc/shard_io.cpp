@@ -141,7 +141,8 @@ extern "C" int bsk_shard_load(int fd, uint64_t offset, size_t n, int device, int
     if (device < 0 || device >= have) return bsk::global_error_set(BSK_ERR_NO_DEVICE, "libbsk: device " + std::to_string(device) + " is not visible");
     if (hipSetDevice(device) != hipSuccess) return bsk::global_error_set(BSK_ERR_NO_DEVICE, "libbsk: no such HIP device");
     void* d = nullptr;
-    if (hipMalloc(&d, n ? n : 1) != hipSuccess) return bsk::global_error_set(BSK_ERR_HIP, "libbsk: device allocation of the shard (" + std::to_string(n) + " bytes) failed");
+    // (BSK_SHARD_FAIL_ALLOC: the tests' stand-in for a shard larger than the free HBM -- the callers' fall-back and messages)
+    if (getenv("BSK_SHARD_FAIL_ALLOC") || hipMalloc(&d, n ? n : 1) != hipSuccess) return bsk::global_error_set(BSK_ERR_HIP, "libbsk: device allocation of the shard (" + std::to_string(n) + " bytes) failed");
     if (n) {
         LoadJob J;
         J.fd = fd; J.offset = offset; J.n = n; J.device = device; J.d = (char*)d;

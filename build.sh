@@ -44,5 +44,13 @@ if [ ! -f bigseqkit_amd/bin/bigseqkit ] || [ ! -f bigseqkit_amd/bin/bigseqkit.ke
   $CXX $FLAGS -pthread -o bigseqkit_amd/bin/bigseqkit cli/bigseqkit.cpp -L"$OUT" -lbsk -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
   printf '%s' "$CLIKEY" > bigseqkit_amd/bin/bigseqkit.key
 fi
+# the Go shim's twin in plain C (tests/host_c/ranks.c: bsk_comm_init_all + one pthread per rank through include/bsk.h alone) --
+# built here so that it travels to the GPU box with the library, and so that every build checks that bsk.h is C, not C++
+HCKEY="$(hash_of tests/host_c/ranks.c include/bsk.h) $LIBKEY"
+if [ ! -f bigseqkit_amd/bin/host_c_ranks ] || [ ! -f bigseqkit_amd/bin/host_c_ranks.key ] || [ "$(cat bigseqkit_amd/bin/host_c_ranks.key)" != "$HCKEY" ]; then
+  rm -f bigseqkit_amd/bin/host_c_ranks.key
+  gcc -O2 -Wall -std=c11 -Iinclude -pthread -o bigseqkit_amd/bin/host_c_ranks tests/host_c/ranks.c -L"$OUT" -lbsk -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
+  printf '%s' "$HCKEY" > bigseqkit_amd/bin/host_c_ranks.key
+fi
 make -s -C oracle
 echo "built $OUT/libbsk.so and oracle/_build/liboracle.so"

@@ -28,6 +28,7 @@
 #include <iostream>
 #include <map>
 #include <atomic>
+#include <future>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -437,8 +438,13 @@ struct Part {
     size_t n = 0;
     bsk_ctx* owner = nullptr;  // context whose output buffer dptr is (destroyed with the part)
     bool owned_alloc = false;  // dptr came from bsk_device_alloc
-    const void* ptr() const { return dptr ? dptr : (const void*)host.data(); }
-    size_t size() const { return dptr ? n : host.size(); }
+    // a file that does not fit the GPU (round 6; the reference takes any file size through its partitions,
+    // bigseqkit/helper.go:148-178): its read-only mapping -- `stats` streams it through the library's double-buffered
+    // host-shard path (bsk_stats_run with on_device = 0: record-aligned 256 MiB chunks, H2D of chunk i + 1 under the kernels of i)
+    const void* map = nullptr;
+    size_t map_n = 0;
+    const void* ptr() const { return dptr ? dptr : (map ? map : (const void*)host.data()); }
+    size_t size() const { return dptr ? n : (map ? map_n : host.size()); }
     int on_device() const { return dptr ? 1 : 0; }
 };
 
@@ -446,7 +452,8 @@ void release(std::vector<Part>& parts) {
     for (auto& p : parts) {
         if (p.owner) bsk_destroy(p.owner);
         else if (p.owned_alloc && p.dptr) bsk_device_free(p.dptr);
-        p.owner = nullptr; p.dptr = nullptr;
+        if (p.map) munmap(const_cast<void*>(p.map), p.map_n);
+        p.owner = nullptr; p.dptr = nullptr; p.map = nullptr;
     }
     parts.clear();
 }
@@ -614,7 +621,15 @@ Output execute(const Invocation& inv, std::vector<Part>& inputs, bool keep_on_de
 
 // device >= 0: the files go straight to that GPU (bsk_shard_load: several readers, pread || H2D) -- what every command but
 // the ones that join their inputs on the host (concat, common, pair) takes; device < 0: host strings
-std::vector<Part> read_parts(const std::vector<std::string>& files, int device = -1) {
+// files of at least this many bytes do not go to the GPU as one shard: `stats` streams them from the host, the other
+// commands say what to do.  BSK_HOST_PIPELINE_FROM moves the line (tests: 0)
+static size_t whole_file_limit() {
+    size_t lim = (size_t)200 << 30;  // (288 GB of HBM: the shard, the stats vector and nothing else)
+    if (const char* e = getenv("BSK_HOST_PIPELINE_FROM")) lim = (size_t)strtoull(e, nullptr, 10);
+    return lim;
+}
+
+std::vector<Part> read_parts(const std::vector<std::string>& files, int device = -1, const std::string& use = "") {
     std::vector<Part> parts;
     for (auto& f : files) {
         Part p;
@@ -636,7 +651,23 @@ std::vector<Part> read_parts(const std::vector<std::string>& files, int device =
             const ssize_t got = pread(fd, &first, 1, 0);
             p.fmt = sniff_format(f, got == 1 ? std::string(1, first) : std::string());
             p.n = (size_t)sb.st_size;
-            if (bsk_shard_load(fd, 0, p.n, device, 0, &p.dptr) != BSK_OK) die(bsk_global_error());
+            const bool too_big = use == "stats" && p.n > 0 && p.n >= whole_file_limit();
+            if (too_big || bsk_shard_load(fd, 0, p.n, device, 0, &p.dptr) != BSK_OK) {
+                p.dptr = nullptr;
+                if (use != "stats") {
+                    close(fd);
+                    die(std::string(bsk_global_error()) + " -- '" + use + "': " + f + " (" + std::to_string(p.n) + " bytes) must fit one GPU next to its "
+                        "result; cut it over several GPUs (--devices 0-7: fq2fa, grep, locate, rmdup, seq, stats, subseq, translate)");
+                }
+                // stats: the file stays on the host, its mapping is streamed in record-aligned chunks
+                p.map = mmap(nullptr, p.n, PROT_READ, MAP_SHARED, fd, 0);
+                if (p.map == MAP_FAILED) die("mmap " + f + " failed");
+                p.map_n = p.n;
+                p.n = 0;
+                close(fd);
+                parts.push_back(std::move(p));
+                continue;
+            }
             p.owned_alloc = true;
             close(fd);
         }
@@ -662,7 +693,7 @@ Output run_job(const bsk::json::Value& j, bool root) {
     std::vector<std::string> args;
     for (auto& a : cmd->arr) args.push_back(a->str);
     Invocation inv = parse_invocation(args);
-    for (auto& p : read_parts(inv.files, (int)strtol(inv.pget("device").c_str(), nullptr, 10))) inputs.push_back(std::move(p));
+    for (auto& p : read_parts(inv.files, (int)strtol(inv.pget("device").c_str(), nullptr, 10), inv.cmd->use)) inputs.push_back(std::move(p));
     if (inputs.empty()) die("no input for job command " + args[0]);
     Output o = execute(inv, inputs, !root);
     release(inputs);
@@ -873,8 +904,11 @@ int run_devices(const Invocation& inv) {
         bsk_ctx* ctx = nullptr;
         void* d_shard = nullptr;
         void* h = nullptr;
+        // stats: a shard that does not fit (or whose allocation fails) is streamed from the file in pinned pieces (below)
+        const bool stats_stream = use == "stats" && n > 0 && n >= std::min(host_pipeline_from * 4, whole_file_limit());
         const bool via_host = streamed && n > host_pipeline_from;
         bsk_store* own = nullptr;
+        bool stream_stats = stats_stream;
         auto give_up = [&](const std::string& m) { if (me.error.empty()) me.error = m.empty() ? "failed" : m; failed.fetch_add(1); };
         do {
             if (bsk_create(inv.cmd->op, inv.js.c_str(), device, &ctx) != BSK_OK) { give_up(bsk_global_error()); break; }
@@ -883,8 +917,16 @@ int run_devices(const Invocation& inv) {
             // this worker's bytes, and only they: from the file to the device in pieces, several readers (bsk_shard_load).
             // A record operator whose shard AND output may not fit the GPU side by side keeps the chunked host pipeline
             // (bsk_run_to_store: pinned shard, 256 MiB chunks through two device buffers).
+            if (stats_stream) break;
             if (!via_host) {
-                if (bsk_shard_load(fd, (uint64_t)lo, n, device, 0, &d_shard) != BSK_OK) { give_up(bsk_global_error()); break; }
+                if (bsk_shard_load(fd, (uint64_t)lo, n, device, 0, &d_shard) != BSK_OK) {
+                    if (use == "stats") { d_shard = nullptr; stream_stats = true; break; }  // (no room: streamed below)
+                    if (use == "rmdup")
+                        give_up(std::string(bsk_global_error()) + " -- rmdup needs every worker's shard (" + std::to_string(n) +
+                                " bytes here) in HBM next to its tables: more devices make smaller shards");
+                    else give_up(bsk_global_error());
+                    break;
+                }
                 mark("shard on the device", rank);
                 break;
             }
@@ -906,7 +948,49 @@ int run_devices(const Invocation& inv) {
             std::vector<int64_t> keys(1 << 20), vals(1 << 20);
             size_t cnt = 0;
             int rc = ok0 ? bsk_stats_reset(ctx, nullptr) : BSK_ERR_INVALID_ARG;
-            if (rc == BSK_OK && n) rc = bsk_stats_run(ctx, d_shard, n, 1, fmt, rank, nullptr, nullptr);
+            if (rc == BSK_OK && n && !stream_stats) rc = bsk_stats_run(ctx, d_shard, n, 1, fmt, rank, nullptr, nullptr);
+            if (rc == BSK_OK && n && stream_stats) {
+                // Round 6: a shard larger than the GPU's memory (the reference takes any file size through its partitions,
+                // bigseqkit/helper.go:148-178).  Pieces of ~1 GiB that end on record starts are read into two pinned buffers
+                // -- the pread of piece i + 1 runs while piece i crosses PCIe under the kernels (bsk_stats_run with a host
+                // pointer: record-aligned chunks through two device buffers) -- and accumulate into the one stats vector.
+                const size_t piece = std::max<size_t>(1 << 16, getenv("BSK_STATS_PIECE_BYTES") ? (size_t)strtoull(getenv("BSK_STATS_PIECE_BYTES"), nullptr, 10) : ((size_t)1 << 30));
+                const uint8_t* fmap = (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);  // (only the pages around the cuts are touched)
+                uint8_t* pin[2] = {(uint8_t*)bsk_host_alloc(piece + (64 << 20)), (uint8_t*)bsk_host_alloc(piece + (64 << 20))};
+                if (fmap == MAP_FAILED || !pin[0] || !pin[1]) { rc = BSK_ERR_HIP; give_up("stats: no pinned memory / mapping for the streamed shard"); }
+                else {
+                    std::vector<size_t> pc{lo};
+                    while (pc.back() < lo + n) {
+                        size_t nxt = lo + n;
+                        if (lo + n - pc.back() > piece) {
+                            size_t at = 0;
+                            if (bsk_find_record_start(fmap, lo + n, pc.back() + piece, fmt, &at) == BSK_OK && at > pc.back() && at < lo + n && at - pc.back() <= piece + (64u << 20)) nxt = at;
+                        }
+                        pc.push_back(nxt);
+                    }
+                    auto read_piece = [&](size_t k) -> bool {
+                        size_t done = 0;
+                        const size_t len = pc[k + 1] - pc[k];
+                        while (done < len) {
+                            const ssize_t got = pread(fd, pin[k & 1] + done, std::min<size_t>(len - done, 256u << 20), (off_t)(pc[k] + done));
+                            if (got <= 0) return false;
+                            done += (size_t)got;
+                        }
+                        return true;
+                    };
+                    bool okr = read_piece(0);
+                    for (size_t k = 0; k + 1 < pc.size() && okr && rc == BSK_OK; ++k) {
+                        std::future<bool> next;
+                        if (k + 2 < pc.size()) next = std::async(std::launch::async, read_piece, k + 1);
+                        rc = bsk_stats_run(ctx, pin[k & 1], pc[k + 1] - pc[k], 0, fmt, (int64_t)rank * 1000000 + (int64_t)k, nullptr, nullptr);
+                        if (next.valid()) okr = next.get();
+                    }
+                    if (!okr && rc == BSK_OK) { rc = BSK_ERR_INVALID_ARG; give_up("short read of " + path); }
+                    mark("shard streamed from the file", rank);
+                }
+                if (fmap != MAP_FAILED) munmap((void*)fmap, size);
+                for (uint8_t* q : pin) if (q) bsk_host_free(q);
+            }
             if (ok0 && rc != BSK_OK) give_up(bsk_last_error(ctx));
             uint64_t bad = (uint64_t)failed.load();
             if (bsk_count_allreduce(comm, &bad, nullptr) != BSK_OK) { give_up(bsk_comm_error(comm)); return; }
@@ -1101,7 +1185,7 @@ static int run_main(int argc, char** argv) {
     const std::string use_cmd = inv.cmd->use;
     const bool joins_on_host = use_cmd == "concat" || use_cmd == "common" || use_cmd == "pair";
     if (!joins_on_host && bsk_device_count() <= 0) die("no HIP device visible (the hot path has no CPU fallback)");
-    std::vector<Part> inputs = read_parts(inv.files, joins_on_host ? -1 : (int)strtol(inv.pget("device").c_str(), nullptr, 10));
+    std::vector<Part> inputs = read_parts(inv.files, joins_on_host ? -1 : (int)strtol(inv.pget("device").c_str(), nullptr, 10), use_cmd);
     if (std::string(inv.cmd->use) == "concat") {
         if (inputs.size() != 2) die("2 files needed");
         if (inputs[0].fmt != inputs[1].fmt) die("concat: inputs of different formats");

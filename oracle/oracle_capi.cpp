@@ -547,6 +547,23 @@ int orc_genetic_code(int id, int which, char* out65) {
     return 1;
 }
 
+// every triple over the 15 IUPAC letters + one invalid byte, in both cases, for table `id`: number of triples on which the
+// lookup table of translate_seq disagrees with codon_aa (0 expected); -1: unknown id
+int orc_codon_table_mismatches(int id) {
+    static const char L[] = "ACGTRYSWKMBDHVNacgturyswkmbdhvnU?";
+    const int n = (int)sizeof(L) - 1;
+    int bad = 0;
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            for (int c = 0; c < n; ++c) {
+                const char c3[3] = {L[a], L[b], L[c]};
+                char s = 0, f = 0;
+                if (codon_aa_pair(id, c3, &s, &f) != 0) return -1;
+                bad += s != f;
+            }
+    return bad;
+}
+
 int orc_translate_seq(const char* seq, int table, int frame, int trim, int clean, int allow_unknown, int init_m,
                       char* out, size_t cap) {
     try {

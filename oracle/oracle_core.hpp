@@ -195,6 +195,8 @@ std::vector<std::string> translate_call(const std::vector<std::string_view>& par
 // CodonTable.Translate [upstream-memory, shenwei356/bio v0.7.0 seq/codon_table.go]
 // ncbieaa (which = 0) / sncbieaa (which = 1) line of a table, derived from genetic_codes_diff.inc; null: unknown id
 const char* genetic_code_strings(int id, int which);
+// tests: codon_aa (the definition) and the 4 096-entry table translate_seq looks up, for one codon; -1: unknown table id
+int codon_aa_pair(int table_id, const char* c3, char* slow, char* fast);
 std::string translate_seq(const std::string& seq, int table, int frame, bool trim, bool clean, bool allow_unknown,
                           bool init_m, bool* unknown);
 

@@ -51,7 +51,12 @@ def test_bench_n_ranks_sharing_one_gpu(n):
     g, r = ops["grep -s -p @ C3"], ops["rmdup -s @ C5"]
     assert g["exact"] is True and g["n_gpus"] == n and g["hits"] >= g["planted"] > 0 and g["out_bytes"] == 317 * g["hits"], g
     assert r["exact"] is True and r["n_gpus"] == n and r["survivors"] == r["records"] - r["records"] // 5, r
-    assert set(r["phases_ms_per_rank"]) == {"keys", "pack", "all_to_all", "resolve", "reply", "emit"}
+    assert set(r["phases_ms_per_rank"]) == {"keys", "pack", "all_to_all", "resolve", "reply", "xpack", "xchange", "xcompare", "xreply", "xapply", "emit"}
+    # round 6: every duplicate was byte-compared with its survivor, most of them across ranks (a duplicate's original is up to
+    # 1 001 records earlier: with shards this small that is often the rank before)
+    assert r["compared_pairs"] == r["duplicates"] == r["records"] // 5 and r["flagged_records"] == 0
+    assert sum(r["pairs_byte_compared_across_ranks_per_rank"]) > 0 and sum(r["subject_bytes_sent_per_rank"]) == 150 * sum(r["pairs_byte_compared_across_ranks_per_rank"])
+    assert r["without_cross_rank_comparison"]["exact"] is True
     assert len(r["per_rank_own_ms"]) == n and all(b > 0 for b in r["tuple_bytes_sent_per_rank"])
     assert sum(r["tuple_bytes_sent_per_rank"]) == 24 * r["records"]
 

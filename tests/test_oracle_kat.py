@@ -186,3 +186,17 @@ def test_rmdup_hand_cases():
     assert oracle.rmdup(fa, False, '{"BySeq": true, "IgnoreCase": true}') == b">a\nACGT\n>d\nTTTT\n"
     assert oracle.rmdup(b">a x\nA\n>a y\nC\n>b\nG\n", False, "{}") == b">a x\nA\n>b\nG\n"
     assert oracle.rmdup(b">a x\nA\n>a y\nC\n>a x\nG\n", False, '{"ByName": true}') == b">a x\nA\n>a y\nC\n"
+
+
+def test_codon_lookup_table_equals_the_definition_on_every_triple():
+    """translate_seq looks amino acids up in a 4 096-entry table per genetic code (round 6: the CPU baseline of `translate`);
+    the table is codon_aa -- the cited definition, bio's ambiguous-codon rule -- evaluated on every triple: held to it here
+    on all 33^3 triples over both cases of the 15 IUPAC letters, U / u and an invalid byte, for every NCBI table"""
+    checked = 0
+    for table in range(1, 34):
+        bad = oracle._lib.orc_codon_table_mismatches(table)
+        if bad < 0:
+            continue
+        assert bad == 0, table
+        checked += 1
+    assert checked >= 24
