@@ -374,8 +374,11 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
             }
             {
                 Timed t(c, "k_translate_stream", st);
+                // (round 6: the record starts of a range are predicted from the starts at its head and verified in 128-byte
+                // windows; translate_probe = off searches every range in full, as round 5 did)
+                const uint32_t span_hint = c->tune.is("translate_probe", "off") ? 0u : (uint32_t)std::min<uint64_t>(avg, 1u << 20);
                 HIP_TRYX(c, launch_translate_stream(blocks, d_buf, n, c->d_anchors, nranges, queue, P, c->d_out, out_cap, c->d_scan_tmp, c->d_fin,
-                                                    d_redo_count, c->d_status, st));
+                                                    d_redo_count, c->d_status, st, span_hint));
             }
             P.long_thresh = 0;
             rc = ctl_readback(c, st);

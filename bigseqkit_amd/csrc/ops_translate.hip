@@ -1439,8 +1439,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSK_TRS_WAV
                                                           const uint64_t* __restrict__ anchors, uint32_t nranges,
                                                           uint32_t* __restrict__ queue, TranslateParams P, uint8_t* __restrict__ out,
                                                           uint64_t out_cap, uint64_t* __restrict__ chain, uint64_t* __restrict__ fin,
-                                                          uint64_t* __restrict__ redo_count, uint64_t* __restrict__ status) {
+                                                          uint64_t* __restrict__ redo_count, uint64_t* __restrict__ status, uint32_t span_hint) {
     __shared__ __attribute__((aligned(16))) uint8_t s_pair[16384];
+    __shared__ uint32_t s_probe_bad;
+    __shared__ uint64_t s_probe_first, s_probe_span;
     __shared__ uint8_t s_iu[256];
     __shared__ uint2 s_ins[6];
     __shared__ uint64_t s_pos[TS_MAXR], s_start[TS_MAXR + 1], s_off[TS_MAXR];
@@ -1507,15 +1509,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSK_TRS_WAV
                 return v;
             };
             constexpr uint64_t STRIDE = 16ull * 256ull;
-            uint64_t at = rs + 16ull * threadIdx.x;
-            for (; at + (BSK_TRS_INFLIGHT - 1) * STRIDE < re; at += BSK_TRS_INFLIGHT * STRIDE) {
-                uint4 v[BSK_TRS_INFLIGHT];
+            // the search of [from, re): every 16-byte piece of it, BSK_TRS_INFLIGHT loads per thread in flight
+            auto scan = [&](uint64_t from, uint64_t to) {
+                uint64_t at = from + 16ull * threadIdx.x;
+                const uint64_t re_saved = re;
+                re = to;   // (`take` clips at re)
+                for (; at + (BSK_TRS_INFLIGHT - 1) * STRIDE < to; at += BSK_TRS_INFLIGHT * STRIDE) {
+                    uint4 v[BSK_TRS_INFLIGHT];
 #pragma unroll
-                for (int k = 0; k < BSK_TRS_INFLIGHT; ++k) v[k] = load(at + (uint64_t)k * STRIDE);
+                    for (int k = 0; k < BSK_TRS_INFLIGHT; ++k) v[k] = load(at + (uint64_t)k * STRIDE);
 #pragma unroll
-                for (int k = 0; k < BSK_TRS_INFLIGHT; ++k) take(at + (uint64_t)k * STRIDE, v[k]);
+                    for (int k = 0; k < BSK_TRS_INFLIGHT; ++k) take(at + (uint64_t)k * STRIDE, v[k]);
+                }
+                for (; at < to; at += STRIDE) take(at, load(at));
+                re = re_saved;
+            };
+            // Round 6: PREDICT the record starts, then verify them (searching the whole range and then
+            // translating it read the input 2.07 times -- the megabyte a block searched has left every cache when its records are
+            // translated a millisecond later).  Records of one file tend to be of one size (reads, amplicons, CDS sets): the
+            // head of the range is searched as before, the starts found there give a stride, and every further start of the
+            // range is looked for in a 128-byte window around its predicted place only -- one '>' at a line start in every
+            // window, or the range is searched in full after all (as is every range of a file whose records vary: the attempt
+            // costs ~7 % of the range's bytes).  A start that is MISSED this way -- a short record between two windows -- makes
+            // its neighbour's "sequence" hold a header line, which the window check of the translation refuses (redo_count: the
+            // call takes the table path).  translate_probe = off keeps the full search.
+            bool probed = false;
+            if (span_hint) {
+                const uint64_t head = rs + (((uint64_t)span_hint * 3u + 4095u) & ~4095ull);
+                if (head + 2ull * span_hint < re) {
+                    scan(rs, head);
+                    if (threadIdx.x == 0) s_probe_bad = 0;
+                    __syncthreads();
+                    const uint32_t n0 = s_n;
+                    if (threadIdx.x == 0) {
+                        uint64_t lo = ~0ull, hi = 0;
+                        for (uint32_t i = 0; i < n0 && i < TS_MAXR; ++i) { lo = s_pos[i] < lo ? s_pos[i] : lo; hi = s_pos[i] > hi ? s_pos[i] : hi; }
+                        s_probe_first = hi;                                                 // the last start of the head
+                        s_probe_span = n0 >= 2u && n0 <= 64u ? (hi - lo) / (n0 - 1u) : 0ull;  // mean distance of the head's starts
+                    }
+                    __syncthreads();
+                    const uint64_t span = s_probe_span, last = s_probe_first;
+                    if (span >= 256u) {
+                        const uint64_t K = last + span < re ? (re - 1 - last) / span : 0;  // predicted starts last + k span < re, k = 1 .. K
+                        if (n0 + K + 2 <= TS_MAXR) {
+                            for (uint64_t k = 1 + threadIdx.x; k <= K + 1; k += 256u) {
+                                // (k = K + 1: a start just below re that the drift moved there would else be lost)
+                                const uint64_t pk = last + k * span;
+                                const uint64_t w0 = (pk - 56) & ~15ull;   // [w0, w0 + 128) holds pk - 56 .. pk + 56
+                                uint32_t found = 0;
+#pragma unroll
+                                for (int half = 0; half < 2; ++half) {  // (four loads in flight, twice: the registers of the search)
+                                    uint4 v[4];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) v[q] = load(w0 + 64ull * half + 16ull * q);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const uint64_t at = w0 + 64ull * half + 16ull * q;
+                                        uint32_t m = ts_eq_mask16(v[q], 0x3E3E3E3Eu);
+                                        while (m) {
+                                            const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+                                            m &= m - 1u;
+                                            const uint64_t pp = at + b;
+                                            if (pp < n_eff && buf[pp - 1] == (uint8_t)'\n') {
+                                                ++found;
+                                                if (pp < re) {
+                                                    const uint32_t slot = atomicAdd(&s_n, 1u);
+                                                    if (slot < TS_MAXR) s_pos[slot] = pp;
+                                                }
+                                            }
+                                        }
+                                    }
+                                }
+                                // exactly one start per window; only the window behind the range's last start may lie behind the file
+                                if (found != 1u && !(found == 0u && k == K + 1 && w0 + 128 >= n_eff)) atomicAdd(&s_probe_bad, 1u);
+                            }
+                            __syncthreads();
+                            probed = s_probe_bad == 0u && s_n <= TS_MAXR;
+                        }
+                    }
+                    if (!probed) {  // the starts of the head stay; the rest of the range in full
+                        __syncthreads();
+                        if (threadIdx.x == 0) s_n = n0;
+                        __syncthreads();
+                        scan(head, re);
+                        probed = true;
+                    }
+                }
             }
-            for (; at < re; at += STRIDE) take(at, load(at));
+            if (!probed) scan(rs, re);
         }
         __syncthreads();
         uint32_t nrec = s_n;
@@ -1669,9 +1750,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSK_TRS_WAV
 
 hipError_t launch_translate_stream(int blocks, const uint8_t* buf, uint64_t buf_n, const uint64_t* anchors, uint32_t nranges, uint32_t* queue,
                                    const TranslateParams& P, uint8_t* out, uint64_t out_cap, uint64_t* chain, uint64_t* fin,
-                                   uint64_t* redo_count, uint64_t* status, hipStream_t st) {
+                                   uint64_t* redo_count, uint64_t* status, hipStream_t st, uint32_t span_hint) {
     hipLaunchKernelGGL(k_translate_stream, dim3(blocks), dim3(256), 0, st, buf, buf_n, anchors, nranges, queue, P, out, out_cap, chain, fin,
-                       redo_count, status);
+                       redo_count, status, span_hint);
     return hipGetLastError();
 }
 int translate_stream_max_blocks_per_cu() {

@@ -68,7 +68,8 @@ constexpr uint32_t ERR_UNKNOWN_CODON = 256u;
 // *redo_count != 0: something did not fit, the output is to be discarded and the table paths take the call
 hipError_t launch_translate_stream(int blocks, const uint8_t* buf, uint64_t buf_n, const uint64_t* anchors, uint32_t nranges, uint32_t* queue,
                                    const TranslateParams& P, uint8_t* out, uint64_t out_cap, uint64_t* chain, uint64_t* fin,
-                                   uint64_t* redo_count, uint64_t* status, hipStream_t st);
+                                   uint64_t* redo_count, uint64_t* status, hipStream_t st,
+                                   uint32_t span_hint = 0 /* mean record bytes of the head sample: predict-and-verify the record starts; 0: search every range in full */);
 int translate_stream_max_blocks_per_cu();
 // elements are numbered record * nframes + f
 hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const TextTableH& tt,

@@ -72,6 +72,32 @@ __global__ __launch_bounds__(256) void calib_seg_read(const uint8_t* __restrict_
     if (acc == 0x9E3779B9u) sink[0] = acc;
 }
 
+// Round 6: the round-5 run could not tell "a request moves the touched 64-byte sector" from "a request
+// moves the whole 128-byte line" -- calib_header16 counted one 64-byte unit per distinct LINE, which fits both.  These probes
+// do: ONE sector of every line is asked for (16 bytes at offset `off` of every 128-byte line, lane i takes line i), and the
+// kernel is TIMED next to the streaming read of the same buffer.  If a request moved only its sector the probe would move
+// half the bytes of the stream and -- both are bound by the memory system, not by request issue -- take about half its
+// time; if it moves the line it takes the stream's time.  calib_two_sectors_apart asks for the OTHER sector of every line in
+// a second sweep of the same launch, 8 GB later (nothing of the first sweep is in a cache any more).
+__global__ __launch_bounds__(256) void calib_one_sector(const uint8_t* __restrict__ buf, uint64_t n, uint32_t off, uint32_t* sink) {
+    uint32_t acc = 0;
+    for (uint64_t l = blockIdx.x * 256ull + threadIdx.x; l * 128 + 128 <= n; l += (uint64_t)gridDim.x * 256ull) acc ^= fold(*reinterpret_cast<const uint4*>(buf + l * 128 + off));
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void calib_two_sectors_apart(const uint8_t* __restrict__ buf, uint64_t n, uint32_t* sink) {
+    uint32_t acc = 0;
+    for (uint32_t off = 0; off < 128u; off += 64u)
+        for (uint64_t l = blockIdx.x * 256ull + threadIdx.x; l * 128 + 128 <= n; l += (uint64_t)gridDim.x * 256ull) acc ^= fold(*reinterpret_cast<const uint4*>(buf + l * 128 + off));
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+// both sectors of a line by the same lane, back to back (two requests per line, or one?)
+__global__ __launch_bounds__(256) void calib_two_sectors_together(const uint8_t* __restrict__ buf, uint64_t n, uint32_t* sink) {
+    uint32_t acc = 0;
+    for (uint64_t l = blockIdx.x * 256ull + threadIdx.x; l * 128 + 128 <= n; l += (uint64_t)gridDim.x * 256ull)
+        acc ^= fold(*reinterpret_cast<const uint4*>(buf + l * 128)) ^ fold(*reinterpret_cast<const uint4*>(buf + l * 128 + 64));
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
 // distinct units of `unit` bytes touched by the ranges (start, len), merged on a bitmap
 struct Touch {
     std::vector<uint64_t> bits;
@@ -89,12 +115,30 @@ int main(int argc, char** argv) {
     CK(hipMalloc((void**)&d, n + 4096));
     CK(hipMalloc((void**)&sink, 64));
     CK(hipMemset(d, 0x41, n + 4096));
-    for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(calib_stream16, dim3(8192), dim3(256), 0, 0, d, n, sink);
-        hipLaunchKernelGGL(calib_header16, dim3(8192), dim3(256), 0, 0, d, nrec, sink);
-        hipLaunchKernelGGL(calib_quad_gather, dim3(8192), dim3(256), 0, 0, d, nrec, sink);
-        hipLaunchKernelGGL(calib_seg_read, dim3(8192), dim3(256), 0, 0, d, nrec, sink);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms[8] = {0};
+    auto timed = [&](int k, auto launch) {
+        CK(hipEventRecord(e0, 0));
+        launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms[k], e0, e1));
+    };
+    for (int rep = 0; rep < 2; ++rep) {  // (the second launch of every kernel is the one reported)
+        timed(0, [&] { hipLaunchKernelGGL(calib_stream16, dim3(8192), dim3(256), 0, 0, d, n, sink); });
+        timed(1, [&] { hipLaunchKernelGGL(calib_header16, dim3(8192), dim3(256), 0, 0, d, nrec, sink); });
+        timed(2, [&] { hipLaunchKernelGGL(calib_quad_gather, dim3(8192), dim3(256), 0, 0, d, nrec, sink); });
+        timed(3, [&] { hipLaunchKernelGGL(calib_seg_read, dim3(8192), dim3(256), 0, 0, d, nrec, sink); });
+        timed(4, [&] { hipLaunchKernelGGL(calib_one_sector, dim3(8192), dim3(256), 0, 0, d, n, 0u, sink); });
+        timed(5, [&] { hipLaunchKernelGGL(calib_two_sectors_apart, dim3(8192), dim3(256), 0, 0, d, n, sink); });
+        timed(6, [&] { hipLaunchKernelGGL(calib_two_sectors_together, dim3(8192), dim3(256), 0, 0, d, n, sink); });
         CK(hipDeviceSynchronize());
+    }
+    {
+        const char* names[7] = {"calib_stream16", "calib_header16", "calib_quad_gather", "calib_seg_read", "calib_one_sector", "calib_two_sectors_apart", "calib_two_sectors_together"};
+        for (int k = 0; k < 7; ++k) printf("{\"timing\": \"%s\", \"ms\": %.4f}\n", names[k], ms[k]);
     }
     // what the kernels asked for, counted on the host
     auto report = [&](const char* name, uint64_t requested, const Touch& t64, const Touch& t128) {
@@ -112,6 +156,15 @@ int main(int argc, char** argv) {
             req += 2 * 160;   // nine whole 16-byte steps + the last 16 bytes once more, from either text
         }
         report("calib_quad_gather", req, a, b);
+    }
+    {
+        const uint64_t lines = n / 128;
+        printf("{\"kernel\": \"calib_one_sector\", \"requested_bytes\": %llu, \"sectors64_bytes\": %llu, \"lines128_bytes\": %llu}\n",
+               (unsigned long long)(lines * 16), (unsigned long long)(lines * 64), (unsigned long long)(lines * 128));
+        printf("{\"kernel\": \"calib_two_sectors_apart\", \"requested_bytes\": %llu, \"sectors64_bytes\": %llu, \"lines128_bytes\": %llu, \"line_visits_bytes\": %llu}\n",
+               (unsigned long long)(lines * 32), (unsigned long long)(lines * 128), (unsigned long long)(lines * 128), (unsigned long long)(lines * 256));
+        printf("{\"kernel\": \"calib_two_sectors_together\", \"requested_bytes\": %llu, \"sectors64_bytes\": %llu, \"lines128_bytes\": %llu}\n",
+               (unsigned long long)(lines * 32), (unsigned long long)(lines * 128), (unsigned long long)(lines * 128));
     }
     {
         Touch a(n + 4096, 64), b(n + 4096, 128);

@@ -118,7 +118,8 @@ def test_a_result_dies_with_the_next_run_and_exceptions_keep_one_block():
     op, out = run("RmDup", {"BySeq": True}, t, "slices")
     first = _lib.Out.from_buffer_copy(out)
     out2 = _lib.Out()
-    check(lib.bsk_rmdup_run(op.ctx, C.c_void_p(t.data_ptr()), 317, 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out2)), op.ctx)
+    t2 = torch.frombuffer(bytearray(fastq(6, 10)), dtype=torch.uint8).cuda()
+    check(lib.bsk_rmdup_run(op.ctx, C.c_void_p(t2.data_ptr()), t2.numel(), 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out2)), op.ctx)
     buf = C.create_string_buffer(max(1, first.len))
     assert lib.bsk_out_to_host(op.ctx, C.byref(first), buf, first.len) != 0          # refused, not answered with other bytes
     assert b"slices" in lib.bsk_last_error(op.ctx)
