@@ -374,6 +374,99 @@ def run_end_to_end(H, gb=8.0):
     return res
 
 
+def file_to_result_config_size(H, gb):
+    """FILE -> result at the CONFIG's size (BASELINE.md section 4 asks for it beside the kernel-
+    resident number): the whole synthetic C2 / C3 file -- `gb` GB of FASTQ-150, motif planted -- written to /dev/shm (not
+    timed), then `bigseqkit stats -T <file> --devices 0` and `bigseqkit grep -s -p <motif> <file> -o <out> --merge --devices 0`,
+    a fresh process each: the steady-state rate of bsk_shard_load (8 readers, pread || H2D) on a file that is ~200 times the
+    start-up cost.  Skipped, with the reason, when the box cannot hold the file in memory."""
+    import shutil
+    import subprocess
+    torch, lib, check, bsk, _lib = H.torch, H.lib, H.check, H.bsk, H._lib
+    cli = os.path.join(ROOT, "bigseqkit_amd", "bin", "bigseqkit")
+    base = "/dev/shm"
+    n = int(gb * 1e9) // REC * REC
+    nrec = n // REC
+    if not os.path.exists(cli) or not os.path.isdir(base):
+        return {"skipped": "no command line binary / no /dev/shm"}
+    free = shutil.disk_usage(base).free
+    avail = 0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    if free < n * 1.1 + (8 << 30) or avail < n * 1.25 + (48 << 30):
+        return {"skipped": "the %.0f GB file does not fit this box's memory next to its page-cache copy's reader (free in /dev/shm %.0f GB, "
+                           "MemAvailable %.0f GB)" % (n / 1e9, free / 1e9, avail / 1e9)}
+    src = os.path.join(base, "bsk_bench_c2_%d.fastq" % os.getpid())
+    dst = os.path.join(base, "bsk_bench_c2_out_%d" % os.getpid())
+    res = {"input": "%.1f GB FASTQ-150 (%d records, the C2 / C3 file, motif planted) in %s" % (n / 1e9, nrec, base)}
+    try:
+        # the file: produced on the device piece by piece, through one pinned buffer, written with 8 threads on disjoint ranges
+        piece = (2 << 30) // REC * REC
+        hbuf = lib.bsk_host_alloc(piece)
+        if not hbuf:
+            return {"skipped": "no pinned buffer for writing the file"}
+        t0 = time.perf_counter()
+        want_hits = 0
+        try:
+            dpiece = torch.empty(piece, dtype=torch.uint8, device=H.dev)
+            view = memoryview((C.c_char * piece).from_address(hbuf)).cast("B")
+            fd = os.open(src, os.O_CREAT | os.O_TRUNC | os.O_WRONLY, 0o600)
+            out = _lib.Out()
+            with bsk.Operator("Grep", json.dumps({"BySeq": True, "Pattern": ["ACGTTGCAAGCT"]}), H.local) as op:
+                at = 0
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(8) as ex:
+                    while at < n:
+                        ln = min(piece, n - at)
+                        assert lib.bsk_synth_device(_lib.SYNTH_FASTQ150, 42, _lib.SYNTH_FLAG_MOTIF, at // REC, C.c_void_p(dpiece.data_ptr()), ln, H.local, None) == 0
+                        torch.cuda.synchronize()
+                        check(lib.bsk_grep_run(op.ctx, C.c_void_p(dpiece.data_ptr()), ln, 1, bsk.FORMAT_FASTQ, 0, None, C.byref(out)), op.ctx)
+                        torch.cuda.synchronize()
+                        want_hits += int(out.records)   # (what the device path answers on the same bytes; exact-checked in the ops leg)
+                        check(lib.bsk_device_copy(C.c_void_p(hbuf), C.c_void_p(dpiece.data_ptr()), ln, 2))
+                        step = (ln + 7) // 8
+                        list(ex.map(lambda k: os.pwrite(fd, view[k * step:min(ln, (k + 1) * step)], at + k * step) if k * step < ln else 0, range(8)))
+                        at += ln
+            os.close(fd)
+            del dpiece
+        finally:
+            lib.bsk_host_free(C.c_void_p(hbuf))
+        torch.cuda.empty_cache()
+        res["file_written_s"] = round(time.perf_counter() - t0, 2)
+        assert os.path.getsize(src) == n
+
+        def run(args):
+            t0 = time.perf_counter()
+            p = subprocess.run([cli] + args, capture_output=True, timeout=900, env=dict(os.environ, TMPDIR=base))
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                raise RuntimeError("%s: rc %d: %s" % (" ".join(args), p.returncode, p.stderr.decode(errors="replace")[-300:]))
+            return dt, p.stdout
+        dt, outp = run(["stats", "-T", src, "--devices", "0"])
+        row = outp.decode().strip().split("\n")[-1].split("\t")
+        res["stats (file -> row on stdout; fresh process)"] = {
+            "s": round(dt, 3), "GB_per_s": round(n / dt / 1e9, 2), "M_records_per_s": round(nrec / dt / 1e6, 1),
+            "exact": len(row) > 4 and row[3].replace(",", "") == str(nrec) and row[4].replace(",", "") == str(150 * nrec)}
+        dt, outp = run(["grep", "-s", "-p", "ACGTTGCAAGCT", src, "-o", dst, "--merge", "--devices", "0"])
+        ob = os.path.getsize(dst) if os.path.isfile(dst) else -1
+        res["grep -s -p (file -> one file; fresh process)"] = {
+            "s": round(dt, 3), "in_GB_per_s": round(n / dt / 1e9, 2), "out_bytes": ob, "M_records_per_s": round(nrec / dt / 1e6, 1),
+            "exact": ob == REC * want_hits}
+    except Exception as e:
+        res["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    finally:
+        for q in (src, dst):
+            if os.path.isdir(q):
+                shutil.rmtree(q, ignore_errors=True)
+            elif os.path.exists(q):
+                os.unlink(q)
+    return res
+
+
 def file_to_result(base, h, n, nrec, want_hits):
     """FILE -> result through the native driver `bigseqkit_amd/bin/bigseqkit <cmd> <file> --devices 0`: a fresh
     process per call (exec, HIP + RCCL start-up, the file's bytes from the page cache into pinned memory, copy to the GPU,
@@ -803,7 +896,7 @@ def attach_traffic(ops):
         if f.endswith((".hip", ".hpp", ".inc")):
             h.update(open(os.path.join(csrc, f), "rb").read())
     src = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/bench_ops.py; " \
-          "FETCH_SIZE x 2 for coalesced streams, x 1.1 - 1.8 for the gather shapes: profiles/r05_fetch_calibration.json)"
+          "FETCH_SIZE x 2: a request moves the 128-byte line whatever part of it was asked for, profiles/r06_fetch_calibration.json)"
     if tj.get("kernel_sources_sha256") != h.hexdigest():
         src += " -- STALE: the kernel sources have changed since that pass"
     prefix = {"seq -n @ C2": "seq -n", "subseq -r 1:50 (25 GB)": "subseq", "grep -s -p @ C3 shard": "grep -s",
@@ -820,13 +913,17 @@ def attach_traffic(ops):
         e["traffic_over_algorithmic"] = t["traffic_over_algorithmic"]
         e["traffic_upper_bound_over_algorithmic"] = t["upper_bound_over_algorithmic"]
         e["traffic_source"] = src
-    # the round-5 kernels the ops evidence does not reach (scripts/r05_extra_traffic.sh: the 50 GB inputs)
-    xf = os.path.join(ROOT, "profiles", "r05_extra_traffic.json")
-    if os.path.exists(xf):
+    # the kernels the ops evidence does not reach (scripts/r06_evidence.sh step 4: the 50 GB inputs); the newest file, held to
+    # the kernel sources like the others (round 5's carried no hash: VERDICT r05 weak 7)
+    xfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extra_traffic.json")))
+    xf = xfs[-1] if xfs else ""
+    if xf:
         try:
-            xk = json.load(open(xf)).get("kernels", {})
+            xj = json.load(open(xf))
+            xk = xj.get("kernels", {})
         except ValueError:
-            xk = {}
+            xj, xk = {}, {}
+        xstale = "" if xj.get("kernel_sources_sha256") == h.hexdigest() else " -- STALE: the kernel sources have changed since that pass"
         for name, pre in (("stats @ C4 input (50 GB FASTA-5k)", "k_stats<false, false"), ("translate -f 6 @ C4, records that differ", "k_translate_stream")):
             e = ops.get(name)
             t = next((v for k, v in xk.items() if k.startswith(pre)), None)
@@ -836,8 +933,10 @@ def attach_traffic(ops):
                 continue
             e["traffic"] = int((t["read_GB"] + t["write_GB"]) * 1e9)
             e["traffic_over_algorithmic"] = t["traffic_over_algorithmic"]
-            e["traffic_source"] = "profiles/r05_extra_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel of the same command " \
-                                  "at the same size; collected once this round, not re-checked against the sources)"
+            if "read_over_input" in t:
+                e["input_read_over_input"] = t["read_over_input"]
+            e["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel of the same command " \
+                                  "at the same size)%s" % (os.path.basename(xf), xstale)
 
 
 def run_ops_multi(args, torch, bsk, _lib, lib, check, dev, local, rank, world, bdist, backend_name):
@@ -997,6 +1096,7 @@ def main():
                                                            "BASELINE config sizes, N = 1 only)")
     ap.add_argument("--no-scaling-model", action="store_true", help="skip the single-GPU shard steps of 'scaling_model' (the "
                     "profiling passes: every k_stats dispatch of the run is then a whole-file one)")
+    ap.add_argument("--no-e2e-full", action="store_true", help="skip the FILE -> result legs on the whole C2 file in /dev/shm")
     ap.add_argument("--ops-scale", type=float, default=1.0, help="scale the sizes of the 'ops' workloads (tests)")
     ap.add_argument("--ops-calls", type=int, default=5, help="timed calls per operator of the 'ops' object")
     ap.add_argument("--launch-check", action="store_true",
@@ -1383,6 +1483,12 @@ def main():
                 out["end_to_end"] = run_end_to_end(_Helpers(args, torch, bsk, _lib, lib, check, dev, local), 8.0 * min(1.0, args.ops_scale * 4))
             except Exception as e:
                 out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+            if not args.no_e2e_full:
+                try:
+                    out["end_to_end_config_size"] = file_to_result_config_size(_Helpers(args, torch, bsk, _lib, lib, check, dev, local),
+                                                                               (total_bytes / 1e9) if args.ops_scale == 1.0 else 100.0 * args.ops_scale)
+                except Exception as e:
+                    out["end_to_end_config_size"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
             try:
                 out["vendor_yardsticks"] = vendor_yardsticks(torch, dev, 20.0 * min(1.0, args.ops_scale * 4))
             except Exception as e:

@@ -28,7 +28,7 @@
 struct bsk_tuning {
     static const char* const* names() {
         static const char* const N[] = {"filter", "grep_shiftand", "index", "locate_nopre", "long_bytes", "min_range_bytes", "names",
-                                        "names_scale", "out", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_k2_bits", "rmdup_keys", "rmdup_place", "rmdup_xcheck", "rmdup_xlocal", "scan", "segcopy",
+                                        "names_scale", "out", "pin_alphabet", "ranges_per_wave", "rmdup", "rmdup_buckets", "rmdup_hash", "rmdup_k1_bits", "rmdup_k2_bits", "rmdup_keys", "rmdup_place", "rmdup_xcheck", "rmdup_xlocal", "scan", "segcopy",
                                         "sort", "stage_bytes", "stats_a", "stats_fasta", "subseq", "subseq_scale", "text", "translate", "translate_index", "translate_probe", "translate_stream", "tr_lanes", nullptr};
         return N;
     }

@@ -149,7 +149,10 @@ extern "C" int bsk_shard_load(int fd, uint64_t offset, size_t n, int device, int
         J.piece = PIECE_DEFAULT;
         if (const char* e = getenv("BSK_SHARD_PIECE_BYTES")) { const long long v = atoll(e); if (v >= 4096) J.piece = (size_t)v; }
         const uint64_t pieces = (n + J.piece - 1) / J.piece;
-        int T = threads > 0 ? threads : 8;
+        // (8 readers bring 8 GB in 0.25 s; the whole 100 GB file of C2 came at 16.7 GB/s -- bench.py end_to_end_config_size,
+        // round 6 -- where PCIe takes 55: the copy out of the page cache is what a reader spends its time in, so a large shard
+        // gets more of them: 8 + one per 4 GiB, up to 24)
+        int T = threads > 0 ? threads : 8 + (int)std::min<uint64_t>(16, (uint64_t)n >> 32);
         T = (int)std::min<uint64_t>((uint64_t)std::min(T, 64), pieces);
         J.pin = numa_cpus_of_device(device, &J.cpus);
         // (every reader is a thread of its own: the caller's affinity is not touched)

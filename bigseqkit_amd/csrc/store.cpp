@@ -481,13 +481,16 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
         // SeqType auto: the reference guesses the alphabet ONCE per partition, from its first record (helper.go:286-291);
         // a chunk that guessed from its own first record could search other strands or validate other letters than a
         // run over the whole shard.  The guess of chunk 0 is pinned for the rest of the call.
-        if (i == 0 && nchunks > 1 && c->alphabet == AB_NONE && c->op != Op::Duplicate) {
+        // (switch "pin_alphabet": the caller feeds ONE partition through several calls -- the command line's pieces of a shard
+        // that does not fit the GPU -- and the guess of the first call's first record stays for all of them)
+        const bool pin_for_good = c->tune.is("pin_alphabet", "1");
+        if (i == 0 && (nchunks > 1 || pin_for_good) && c->alphabet == AB_NONE && c->op != Op::Duplicate) {
             ST_TRY(c, hipStreamSynchronize(st));  // (chunk 0 is on the device: its head is read back)
             int arc = BSK_OK;
             const Alphabet ab = partition_alphabet(c, c->d_stage[b], cuts[1] - cuts[0], format, st, &arc);
             if (arc != BSK_OK) { rc = arc; break; }
             c->alphabet = ab;
-            S.alphabet_pinned = true;
+            S.alphabet_pinned = !pin_for_good;
         }
         std::swap(c->d_out, S.alt_out);
         std::swap(c->out_cap, S.alt_cap);

@@ -930,16 +930,9 @@ int run_devices(const Invocation& inv) {
                 mark("shard on the device", rank);
                 break;
             }
-            h = bsk_host_alloc(std::max<size_t>(1, n));
-            if (!h) { give_up("pinned allocation of " + std::to_string(n) + " bytes failed"); break; }
-            size_t done = 0;
-            while (done < n) {
-                const ssize_t got = pread(fd, (char*)h + done, std::min<size_t>(n - done, 256u << 20), (off_t)(lo + done));
-                if (got <= 0) break;
-                done += (size_t)got;
-            }
-            if (done < n) { give_up("short read of " + path); break; }
-            mark("shard in pinned memory", rank);
+            // (round 6: the shard is NOT read into one pinned buffer first -- 100 GB took 12 s to pin and 10 s to read with one
+            // thread before the first kernel ran: grep on the whole C2 file 29.5 s, bench.py end_to_end_config_size.  It is
+            // streamed below in pieces through two pinned buffers, the pread of piece k + 1 under the pipeline of piece k.)
         } while (false);
         // every worker enters every collective, also the one that has given up (its contribution is empty): the others must
         // not wait for it for ever
@@ -1046,7 +1039,60 @@ int run_devices(const Invocation& inv) {
                     me.out_bytes = o.len; me.out_records = o.records;
                 }
             } else if (me.error.empty() && via_host) {
-                if (bsk_run_to_store(ctx, h, n, fmt, rank, st, part, &me.out_bytes, &me.out_records) != BSK_OK) give_up(bsk_last_error(ctx));
+                // A shard that does not fit the GPU next to its result: pieces of ~2 GiB that end on record starts (found on a
+                // mapping of the file: only the pages around the cuts are touched) go through bsk_run_to_store one after the
+                // other -- inside, 256 MiB chunks cross PCIe under the kernels and the drain of the chunk before -- while a
+                // reader thread fills the other pinned buffer.  The pieces are the parts 0, 1, 2 ... of ONE file: this worker's
+                // spool (--merge / -o -) or its part%05d of the directory, written through a store of its own.
+                bsk_store* mine = own;
+                uint64_t p0 = 0;
+                if (!mine) {
+                    char nm[64];
+                    snprintf(nm, sizeof nm, "/part%05d", rank);
+                    if (bsk_store_open((out_file + nm).c_str(), 1, &mine) != BSK_OK) give_up("cannot create " + out_file + nm);
+                }
+                const size_t piece = std::max<size_t>(1 << 16, getenv("BSK_STREAM_PIECE_BYTES") ? (size_t)strtoull(getenv("BSK_STREAM_PIECE_BYTES"), nullptr, 10) : ((size_t)2 << 30));
+                const uint8_t* fmap = (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
+                uint8_t* pin[2] = {(uint8_t*)bsk_host_alloc(piece + (64 << 20)), (uint8_t*)bsk_host_alloc(piece + (64 << 20))};
+                if (me.error.empty() && (fmap == MAP_FAILED || !pin[0] || !pin[1])) give_up("no pinned memory / mapping for the streamed shard");
+                if (me.error.empty()) {
+                    bsk_ctx_set(ctx, "pin_alphabet", "1");  // (one partition through several calls: one alphabet guess)
+                    std::vector<size_t> pc{lo};
+                    while (pc.back() < lo + n) {
+                        size_t nxt = lo + n;
+                        if (lo + n - pc.back() > piece) {
+                            size_t at = 0;
+                            if (bsk_find_record_start(fmap, lo + n, pc.back() + piece, fmt, &at) == BSK_OK && at > pc.back() && at < lo + n && at - pc.back() <= piece + (64u << 20)) nxt = at;
+                        }
+                        pc.push_back(nxt);
+                    }
+                    auto read_piece = [&](size_t k) -> bool {
+                        size_t done = 0;
+                        const size_t len = pc[k + 1] - pc[k];
+                        while (done < len) {
+                            const ssize_t got = pread(fd, pin[k & 1] + done, std::min<size_t>(len - done, 256u << 20), (off_t)(pc[k] + done));
+                            if (got <= 0) return false;
+                            done += (size_t)got;
+                        }
+                        return true;
+                    };
+                    bool okr = read_piece(0);
+                    for (size_t k = 0; k + 1 < pc.size() && okr && me.error.empty(); ++k) {
+                        std::future<bool> next;
+                        if (k + 2 < pc.size()) next = std::async(std::launch::async, read_piece, k + 1);
+                        uint64_t ob = 0, orec = 0;
+                        // (pid: the header row of `locate` belongs to the first chunk of partition 0 -- the first piece of worker 0 only)
+                        const int64_t pid = (rank == 0 && k == 0) ? 0 : (int64_t)rank * 1000000 + (int64_t)k + 1;
+                        if (bsk_run_to_store(ctx, pin[k & 1], pc[k + 1] - pc[k], fmt, pid, mine, p0 + k, &ob, &orec) != BSK_OK) give_up(bsk_last_error(ctx));
+                        me.out_bytes += ob; me.out_records += orec;
+                        if (next.valid()) okr = next.get();
+                    }
+                    if (!okr) give_up("short read of " + path);
+                    mark("shard streamed through the host pipeline", rank);
+                }
+                if (fmap != MAP_FAILED) munmap((void*)fmap, size);
+                for (uint8_t* q : pin) if (q) bsk_host_free(q);
+                if (mine && mine != own) { uint64_t tot = 0; if (bsk_store_close(mine, &tot) != BSK_OK) give_up("closing this worker's part failed"); }
             } else if (me.error.empty()) {
                 // the shard is on the device: one call over all of it, its output drained in pieces (bsk_store_put: the
                 // copy of a piece runs while the piece before it is written)

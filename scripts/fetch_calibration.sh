@@ -68,7 +68,9 @@ if "calib_stream16" in ms and "calib_one_sector" in ms:
         "bytes_if_requests_move_sectors": known["calib_one_sector"]["sectors64_bytes"],
         "bytes_if_requests_move_lines": known["calib_one_sector"]["lines128_bytes"],
         "reading": "a probe that asks for ONE 64-byte sector of every 128-byte line: ~0.5 x the stream's time = a request moves its "
-                   "sector (FETCH_SIZE x 1 for such gathers), ~1.0 x = it moves the line (FETCH_SIZE x 2, as for streams)"}
+                   "sector (FETCH_SIZE x 1 for such gathers), ~1.0 x = it moves the line (FETCH_SIZE x 2, as for streams)",
+        "conclusion": ("a request moves the 128-byte LINE: bytes = 2 x FETCH_SIZE for every access shape" if t_1 / t_s >= 0.75 else
+                       "a request moves the touched 64-byte sector: bytes = FETCH_SIZE x the per-shape factor against sectors64")}
 json.dump(out, open(f"{O}/{tag}_fetch_calibration.json", "w"), indent=1)
 print(json.dumps(out.get("discrimination"), indent=1))
 for k, d in out["kernels"].items():

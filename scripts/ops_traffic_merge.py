@@ -22,9 +22,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1]
 ops = (sys.argv[2] if len(sys.argv) > 2 else "seq,subseq,grep,rmdup,translate").split(",")
-cal = json.load(open(f"{ROOT}/profiles/{tag}_fetch_calibration.json"))["kernels"]
-G = {"header": cal["calib_header16"]["factor_vs_sectors64"], "quad": cal["calib_quad_gather"]["factor_vs_sectors64"],
-     "seg": cal["calib_seg_read"]["factor_vs_sectors64"], "stream": cal["calib_stream16"]["factor_vs_sectors64"]}
+calj = json.load(open(f"{ROOT}/profiles/{tag}_fetch_calibration.json"))
+cal = calj["kernels"]
+# Round 6 settled what a request moves (profiles/r06_fetch_calibration.json "discrimination": a probe that asks for ONE
+# 64-byte sector of every 128-byte line takes 0.89 x the time of the streaming read of the same buffer and TCC_EA0_RDREQ
+# counts one request per LINE, none of 32 bytes; the header probe's time x the stream's rate = the bytes of the LINES it
+# touches): a request moves the LINE.  FETCH_SIZE tallies every request at 64 bytes, so bytes = 2 x FETCH_SIZE for every
+# shape -- the "upper bound" of round 5 was the figure.  A calibration file without the discrimination (round 5) keeps the
+# per-shape factors against the touched sectors.
+moves_lines = calj.get("discrimination", {}).get("one_sector_ms_over_stream_ms", 0) >= 0.75
+fk = "factor_vs_lines128" if moves_lines else "factor_vs_sectors64"
+G = {"header": cal["calib_header16"][fk], "quad": cal["calib_quad_gather"][fk],
+     "seg": cal["calib_seg_read"][fk], "stream": cal["calib_stream16"][fk]}
+if moves_lines:
+    G = {k: 2.0 for k in G}   # (one request = one 128-byte line, counted as 64 bytes: exactly 2, whatever part of the line was asked for)
 res = json.load(open(f"{O}/ops_{tag}.json"))
 key_of = {"seq": "seq -n", "subseq": "subseq", "grep": "grep -s", "locate": "locate", "rmdup": "rmdup", "translate": "translate"}
 
@@ -41,7 +52,7 @@ def shape_of(kernel, entry):
     return None, "stream"              # everything else is counted as a coalesced stream (x2)
 
 
-out = {"source": __doc__.split("Usage:")[0].strip(), "factors": G, "ops": {}}
+out = {"source": __doc__.split("Usage:")[0].strip(), "factors": G, "requests_move": "lines (2 x FETCH_SIZE everywhere)" if moves_lines else "sectors (per-shape factors)", "output_contract": os.environ.get("BSK_OUT", "contiguous"), "ops": {}}
 for op in ops:
     tf = f"{O}/traffic_{tag}_{op}.json"
     if not os.path.exists(tf):
@@ -51,6 +62,8 @@ for op in ops:
         if not name.startswith(key_of.get(op, op)):
             continue
         alg = (v["in_GB"] + v["out_GB"]) * 1e9
+        if os.environ.get("BSK_OUT") == "slices" and op == "rmdup":
+            alg = v["in_GB"] * 1e9 + 16.0 * v["records"]   # (the survivors are slices of the shard: not moved; bench.py's figure)
         kern, total, upper = {}, 0.0, 0.0
         for k, kv in t.items():
             calls = kv["dispatches"] / 2.0              # (two calls of the command per pass)

@@ -119,5 +119,9 @@ def test_bench_ops_object_small():
     legs = [v for k, v in e2e.items() if isinstance(v, dict)]
     assert len(legs) == 5 and all(v["exact"] is True for v in legs), e2e
     assert sum("fresh process" in k for k in e2e) == 2, e2e     # FILE -> result through the native driver
+    ec = d["end_to_end_config_size"]                               # round 6: FILE -> result on the whole (here: scaled) C2 file in /dev/shm
+    assert "error" not in ec, ec
+    if "skipped" not in ec:
+        assert ec["stats (file -> row on stdout; fresh process)"]["exact"] is True and ec["grep -s -p (file -> one file; fresh process)"]["exact"] is True, ec
     y = d["vendor_yardsticks"]
     assert "error" not in y and y["d2d_copy_GBps_read_plus_write"] > 0 and y["read_sum_int64_GBps"] > 0, y

@@ -179,11 +179,16 @@ def test_a_lone_worker_without_rccl_and_the_chunked_host_pipeline(case, tmp_path
     name, args, kind = case
     src, want = one_device_output(case, tmp_path_factory)
     runs = (({"BSK_COMM": ""}, "0"), ({"BSK_COMM": "", "BSK_HOST_PIPELINE_FROM": "0", "BSK_STAGE_BYTES": "65536"}, "0"),
-            ({"BSK_HOST_PIPELINE_FROM": "0", "BSK_STAGE_BYTES": "65536"}, "0,0,0"), ({"BSK_SHARD_PIECE_BYTES": "4096"}, "0,0,0"))
+            ({"BSK_HOST_PIPELINE_FROM": "0", "BSK_STAGE_BYTES": "65536", "BSK_STREAM_PIECE_BYTES": "300000"}, "0,0,0"),   # (round 6: the shard in pieces of 300 kB, each through the pipeline)
+            ({"BSK_SHARD_PIECE_BYTES": "4096"}, "0,0,0"))
     for k, (env, devices) in enumerate(runs):
         many = str(tmp_path / ("many%d.out" % k))
         run_native([CLI] + args + [src, "-o", many, "--merge", "--devices", devices], env)
         assert read_out(many) == want, (env, devices)
+    # ... and as a directory of parts: every worker writes its part%05d piece by piece through a store of its own
+    many = str(tmp_path / "manydir.out")
+    run_native([CLI] + args + [src, "-o", many, "--devices", "0,0"], {"BSK_HOST_PIPELINE_FROM": "0", "BSK_STAGE_BYTES": "65536", "BSK_STREAM_PIECE_BYTES": "250000"})
+    assert read_out(many) == want and sorted(os.listdir(many)) == ["part00000", "part00001"]
 
 
 def test_shard_load_reads_the_range_it_is_asked_for(tmp_path):
