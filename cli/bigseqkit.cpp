@@ -834,6 +834,30 @@ struct Worker {
     std::string text;             // worker 0: what goes to stdout (stats table, grep -C count)
 };
 
+// len bytes of the file at `off` into buf with several readers (a copy out of the page cache is one core's work: ~9 GB/s with
+// one thread on the box of round 6, where PCIe takes 55)
+static bool parallel_pread(int fd, uint8_t* buf, size_t len, size_t off, int threads = 8) {
+    if (len < ((size_t)64 << 20)) threads = 1;
+    std::vector<std::future<bool>> jobs;
+    const size_t per = (len + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        const size_t a = std::min(len, per * (size_t)t), b = std::min(len, a + per);
+        if (a >= b) break;
+        jobs.push_back(std::async(std::launch::async, [=]() {
+            size_t done = a;
+            while (done < b) {
+                const ssize_t got = pread(fd, buf + done, std::min<size_t>(b - done, 64u << 20), (off_t)(off + done));
+                if (got <= 0) return false;
+                done += (size_t)got;
+            }
+            return true;
+        }));
+    }
+    bool ok = true;
+    for (auto& j : jobs) ok = j.get() && ok;
+    return ok;
+}
+
 int run_devices(const Invocation& inv) {
     const std::string use = inv.cmd->use;
     static const char* const kStreamed[] = {"seq", "grep", "locate", "subseq", "translate", "fq2fa"};
@@ -961,16 +985,7 @@ int run_devices(const Invocation& inv) {
                         }
                         pc.push_back(nxt);
                     }
-                    auto read_piece = [&](size_t k) -> bool {
-                        size_t done = 0;
-                        const size_t len = pc[k + 1] - pc[k];
-                        while (done < len) {
-                            const ssize_t got = pread(fd, pin[k & 1] + done, std::min<size_t>(len - done, 256u << 20), (off_t)(pc[k] + done));
-                            if (got <= 0) return false;
-                            done += (size_t)got;
-                        }
-                        return true;
-                    };
+                    auto read_piece = [&](size_t k) -> bool { return parallel_pread(fd, pin[k & 1], pc[k + 1] - pc[k], pc[k]); };
                     bool okr = read_piece(0);
                     for (size_t k = 0; k + 1 < pc.size() && okr && rc == BSK_OK; ++k) {
                         std::future<bool> next;
@@ -1066,16 +1081,7 @@ int run_devices(const Invocation& inv) {
                         }
                         pc.push_back(nxt);
                     }
-                    auto read_piece = [&](size_t k) -> bool {
-                        size_t done = 0;
-                        const size_t len = pc[k + 1] - pc[k];
-                        while (done < len) {
-                            const ssize_t got = pread(fd, pin[k & 1] + done, std::min<size_t>(len - done, 256u << 20), (off_t)(pc[k] + done));
-                            if (got <= 0) return false;
-                            done += (size_t)got;
-                        }
-                        return true;
-                    };
+                    auto read_piece = [&](size_t k) -> bool { return parallel_pread(fd, pin[k & 1], pc[k + 1] - pc[k], pc[k]); };
                     bool okr = read_piece(0);
                     for (size_t k = 0; k + 1 < pc.size() && okr && me.error.empty(); ++k) {
                         std::future<bool> next;

@@ -518,6 +518,15 @@ int orc_rmdup(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, 
     return run_parts(buf, n, fastq, so, 1, rmdup_call, false, out, cap, nout, nrec, err, errcap);
 }
 
+// rmdup on `threads` host threads (bench.py's all-cores CPU baseline)
+int orc_rmdup_mt(const uint8_t* buf, size_t n, int fastq, const orc_rmdup_opts* o, int threads, uint8_t* out, size_t cap,
+                 size_t* nout, uint64_t* nrec, char* err, size_t errcap) {
+    try {
+        auto recs = split_records(std::string_view((const char*)buf, n), fastq != 0);
+        return emit(rmdup_call_mt(recs, conv(*o), threads), out, cap, nout, nrec);
+    } catch (const std::exception& e) { return fail(err, errcap, e); }
+}
+
 // Locate over nparts partitions: MapPartitionsWithIndex, the header row comes from partition 0
 int orc_locate(const uint8_t* buf, size_t n, int fastq, const orc_locate_opts* o, int nparts, uint8_t* out, size_t cap,
                size_t* nout, uint64_t* nrec, char* err, size_t errcap) {

@@ -6,6 +6,8 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <unordered_map>
 
 #include <algorithm>
 #include <set>
@@ -1606,6 +1608,84 @@ uint64_t xxh64(const void* data, size_t len, uint64_t seed) {
 // ---------------------------------------------------------------------------
 std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, const RmDupOptions& o) {
     return rmdup_call_side(all, o, nullptr, nullptr);
+}
+
+// The same result with `threads` host threads -- bench.py's all-cores CPU baseline of `rmdup` (a labelled
+// baseline, nothing the product runs).  The reference gets its parallelism from IgnisHPC: RmDupPrepare keys the records of
+// every partition on its executor, GroupByKey brings equal keys together, RmDupCheck settles every key group on its own
+// (bigseqkit/rmdup.go:88-105).  Restated with threads: phase 1, every thread parses a contiguous run of records (subject,
+// XXH64 key, Format() text); phase 2, thread t owns the keys with key % threads == t, collects their records in file order
+// and settles every group with rmdup_call_side's rule (a map keyed by the subject text, the reverse complement looked up
+// inside the group).  tests/test_oracle_kat.py holds it to rmdup_call on random inputs.
+std::vector<std::string> rmdup_call_mt(const std::vector<std::string_view>& all, const RmDupOptions& o, int threads) {
+    Alphabet ab = alphabet_from_seqtype(o.Config.SeqType);
+    if (o.BySeq && o.ByName) throw Error("only one/none of the flags -s (--by-seq) and -n (--by-name) is allowed");
+    if (o.OnlyPositiveStrand && !o.BySeq) throw Error("flag -s (--by-seq) needed when using -P (--only-positive-strand)");
+    if (threads < 1) threads = 1;
+    struct Item { std::string subject, text, seq; uint64_t key; };
+    const size_t N = all.size();
+    std::vector<Item> items(N);
+    std::vector<std::string> errors((size_t)threads);
+    Alphabet fa = AB_NONE;
+    {
+        // (the alphabet of the partition is the one the FIRST record yields, as in the sequential reader)
+        std::vector<std::string_view> head(all.begin(), all.begin() + std::min<size_t>(N, 1));
+        SeqParser rd(ab, &head, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+        while (rd.Read()) {}
+        fa = rd.GetAlphabet();
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            try {
+                const size_t a = N * (size_t)t / (size_t)threads, b = N * (size_t)(t + 1) / (size_t)threads;
+                std::vector<std::string_view> part(all.begin() + a, all.begin() + b);
+                SeqParser rd(ab, &part, o.Config.IDRegexp, o.Config.AlphabetGuessSeqLength);
+                int lineWidth = o.Config.LineWidth;
+                size_t i = a;
+                while (rd.Read()) {
+                    Record& r = rd.rec;
+                    if (rd.IsFastq) lineWidth = 0;
+                    Item& it = items[i++];
+                    it.subject = o.BySeq ? r.seq : (o.ByName ? r.name : r.id);
+                    if (o.IgnoreCase) it.subject = lower(it.subject);
+                    it.key = xxh64(it.subject.data(), it.subject.size(), 0);
+                    it.text = record_format(r, rd.IsFastq, lineWidth);
+                    it.seq = r.seq;
+                }
+            } catch (const std::exception& e) { errors[(size_t)t] = e.what(); }
+        });
+    for (auto& th : pool) th.join();
+    for (auto& e : errors) if (!e.empty()) throw Error(e);
+    const bool revcom = o.BySeq && !o.OnlyPositiveStrand;
+    std::vector<char> keep(N, 0);
+    pool.clear();
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            std::unordered_map<uint64_t, std::vector<size_t>> groups;
+            for (size_t i = 0; i < N; ++i)
+                if (items[i].key % (uint64_t)threads == (uint64_t)t) groups[items[i].key].push_back(i);
+            for (auto& kv : groups) {
+                auto& g = kv.second;  // (file order: i ascends)
+                if (g.size() == 1) { keep[g[0]] = 1; continue; }
+                std::map<std::string, size_t> counter;
+                for (size_t i : g) {
+                    if (counter.count(items[i].subject)) continue;
+                    if (revcom) {
+                        std::string rc = rev_com(items[i].seq, fa);
+                        if (o.IgnoreCase) rc = lower(rc);
+                        if (counter.count(rc)) continue;
+                    }
+                    counter[items[i].subject] = i;
+                    keep[i] = 1;
+                }
+            }
+        });
+    for (auto& th : pool) th.join();
+    std::vector<std::string> result;
+    for (size_t i = 0; i < N; ++i)
+        if (keep[i]) { std::string tx = std::move(items[i].text); tx.pop_back(); result.push_back(std::move(tx)); }
+    return result;
 }
 
 // dup_seqs: Format() text of every removed record (rmdup.go:181-183, written by After() :246-261);

@@ -222,6 +222,8 @@ struct RmDupOptions {  // bigseqkit/rmdup.go:13-33
 // RmDupPrepare + GroupByKey + RmDupCheck over the WHOLE input (bigseqkit-lib/rmdup.go:43-242);
 // survivor = first record in file order (PARITY.md Q10)
 std::vector<std::string> rmdup_call(const std::vector<std::string_view>& all, const RmDupOptions& o);
+// the same result on `threads` host threads (bench.py's all-cores baseline; held to rmdup_call by tests/test_oracle_kat.py)
+std::vector<std::string> rmdup_call_mt(const std::vector<std::string_view>& all, const RmDupOptions& o, int threads);
 std::vector<std::string> rmdup_call_side(const std::vector<std::string_view>& all, const RmDupOptions& o,
                                          std::string* dup_seqs, std::string* dup_nums);
 uint64_t xxh64(const void* data, size_t len, uint64_t seed);  // cespare/xxhash Sum64 == XXH64 seed 0

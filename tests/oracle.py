@@ -203,6 +203,11 @@ def rmdup(data, fastq, opts_json="{}"):
     return _run_text(_lib.orc_rmdup, data, fastq, rmdup_opts(opts_json), 1)[0]
 
 
+def rmdup_mt(data, fastq, opts_json="{}", threads=4):
+    """rmdup on `threads` host threads (rmdup_call_mt: bench.py's all-cores baseline); the nparts slot carries the thread count"""
+    return _run_text(_lib.orc_rmdup_mt, data, fastq, rmdup_opts(opts_json), threads)[0]
+
+
 def rmdup_side(data, fastq, opts_json="{}", which=1):
     """which=1: text of the removed records (-d); which=2: the duplicate-number lines (-D)"""
     o = rmdup_opts(opts_json)
@@ -228,7 +233,7 @@ def sub_location(length, start, end):
     return b.value, e.value
 
 
-def run_ptr(name, ptr, n, fastq, opts_json, out_cap):
+def run_ptr(name, ptr, n, fastq, opts_json, out_cap, threads=1):
     """Timing entry of bench.py's cpu_baseline legs: operator `name` ("seq", "grep", "subseq", "translate", "rmdup") on the n
     bytes at address `ptr` -- no copy of the input, the output written into an UNINITIALISED buffer of out_cap bytes (grown
     once if the operator needs more) and discarded.  Returns (output bytes, output records).  The test entries above copy
@@ -236,13 +241,14 @@ def run_ptr(name, ptr, n, fastq, opts_json, out_cap):
     callers at once the page faults of those buffers, not the restatement, were what got timed."""
     import numpy as np
     fn, mk = {"seq": (_lib.orc_seq, seq_opts), "grep": (_lib.orc_grep, grep_opts), "subseq": (_lib.orc_subseq, subseq_opts),
-              "translate": (_lib.orc_translate, translate_opts), "rmdup": (_lib.orc_rmdup, rmdup_opts)}[name]
+              "translate": (_lib.orc_translate, translate_opts), "rmdup": (_lib.orc_rmdup, rmdup_opts),
+              "rmdup_mt": (_lib.orc_rmdup_mt, rmdup_opts)}[name]
     o = mk(opts_json)
     cap = int(out_cap)
     while True:
         out = np.empty(max(16, cap), dtype=np.uint8)
         nout, nrec, err = C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
-        rc = fn(C.c_void_p(ptr), C.c_size_t(n), int(fastq), C.byref(o), 1, C.c_void_p(out.ctypes.data), C.c_size_t(out.size), C.byref(nout),
+        rc = fn(C.c_void_p(ptr), C.c_size_t(n), int(fastq), C.byref(o), int(threads), C.c_void_p(out.ctypes.data), C.c_size_t(out.size), C.byref(nout),
                 C.byref(nrec), err, _ERR)
         if rc == 2:
             cap = nout.value + 16

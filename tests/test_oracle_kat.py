@@ -200,3 +200,23 @@ def test_codon_lookup_table_equals_the_definition_on_every_triple():
         assert bad == 0, table
         checked += 1
     assert checked >= 24
+
+
+def test_rmdup_on_several_threads_equals_the_sequential_restatement():
+    """rmdup_call_mt (bench.py's all-cores CPU baseline of `rmdup`: per-thread parsing, key groups settled by the thread that
+    owns key % threads) against rmdup_call on random inputs, every subject kind, FASTA and FASTQ"""
+    import random
+    import seqgen
+    rng = random.Random(606)
+    for it in range(30):
+        fastq = rng.random() < 0.5
+        gen = (lambda r, k: seqgen.random_fastq(r, k, 0, 40)) if fastq else (lambda r, k: seqgen.random_fasta(r, k, 0, 90))
+        seed, k = rng.randrange(1 << 30), rng.randint(0, 200)
+        first, again, other = gen(random.Random(seed), k), gen(random.Random(seed), k), gen(random.Random(seed + 1), rng.randint(0, 100))
+        assert first == again
+        data = first + other + (again.lower() if (rng.random() < 0.3 and not fastq) else again)   # every record of `first` once more
+        for opts in ({"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}, {"ByName": True}, {"BySeq": True, "OnlyPositiveStrand": True}):
+            import json as _json
+            want = oracle.rmdup(data, fastq, _json.dumps(opts))
+            for threads in (1, 3, 8):
+                assert oracle.rmdup_mt(data, fastq, _json.dumps(opts), threads) == want, (it, opts, threads)
