@@ -292,6 +292,22 @@ struct sink_tile_nt { static constexpr bool value = false; };
 template <class S>
 struct sink_tile_nt<S, decltype((void)S::TILE_NT)> { static constexpr bool value = S::TILE_NT; };
 
+// A RECORDS4 sink with `static constexpr bool HEAD16 = true` is handed the 16 bytes BEHIND every record-end newline while
+// they are in LDS -- the marker and the first 15 bytes of the NEXT record's header line (round 6, k_names):
+//     sink.head16(s, p, valid)          s = window slot of the record-end event; p = the byte behind the newline inside the
+//                                       compacted flagged pieces (L.sdata, LDS: consecutive slots are consecutive 16-byte
+//                                       pieces of the tile when they are neighbours in it; an unaligned ds_read_b128 is fine
+//                                       on gfx950); valid = what the sink may use of the 16 bytes at p is the text (the header
+//                                       line ends inside this piece, or the next slot holds the tile's next piece)
+//     sink.shift16(done, keep)          the window moved: slots [done, done + HISTORY + keep) are now [0, HISTORY + keep)
+// `seq -n` fetched 1.43 x its input (profiles/r06_ops_traffic.json): one more 128-byte line per record for a 12-byte header
+// that had gone through the wave's registers ~5 tiles earlier -- a wave's tiles are long out of L2 by then (28 waves x 8 KiB
+// in flight per CU and 32 CUs share 4 MiB).
+template <class S, class = void>
+struct sink_head16 { static constexpr bool value = false; };
+template <class S>
+struct sink_head16<S, decltype((void)S::HEAD16)> { static constexpr bool value = S::HEAD16; };
+
 // WHEN the deferred sink runs.  REC_TILE_END = true (default): at the end of a tile once the window is half full -- the 16
 // data registers of the tile are dead there, which is what lets k_index / k_names keep 72 registers without a spill.
 // false: inside the rounds, when the window is full (64 records of a 256 window) -- what k_stats' default row needs: it
@@ -356,6 +372,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
     constexpr bool ROLES = FASTQ && !ALL && sink_role_counts<Sink>::value;
     constexpr bool REC4 = FASTQ && !ALL && sink_records4<Sink>::value;  // whole records, deferred (see sink_records4)
     constexpr bool REC_TE = REC4 && sink_rec_tile_end<Sink>::value;     // ... at the end of a tile / when the window is full
+    constexpr bool HEAD16 = REC4 && sink_head16<Sink>::value;           // ... and is handed the 16 bytes behind every record end
     constexpr uint32_t CAPW = (uint32_t)CV;
     static_assert(!REC4 || (CV % 4 == 0 && CV >= 256), "a window of whole records with room for a tile behind the ones that wait");
     uint32_t pend_base = 0;  // REC4: rank of the event in slot HISTORY (a multiple of 4)
@@ -541,6 +558,12 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                         }
                     }
                 }
+                // HEAD16: is the piece in the next slot the tile's next piece?  (lane l + 1's offset over DPP wave_shl:1)
+                bool next_adjacent = false;
+                if constexpr (HEAD16) {
+                    const uint32_t offn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(have ? off0 + 1u : 0u), 0x130, 0xf, 0xf, true);
+                    next_adjacent = have && lane != 63 && offn == off0 + 16u + 1u;
+                }
                 // this lane's newlines -> events in the window whose first slot is the event of rank `wb`
                 auto emit_events = [&](uint32_t wb) {
                     uint32_t m = nl, k = 0;
@@ -553,6 +576,12 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                             const uint32_t s = HISTORY + w;
                             const uint32_t off = off0 + bpos;
                             L.pos[s] = tile_rel + off;
+                            if constexpr (HEAD16) {
+                                if (((rank0 + k - 1u) & 3u) == 3u) {  // a record ends here: what follows is the next record's header
+                                    sink.head16(s, reinterpret_cast<const uint8_t*>(&L.sdata[0]) + (uint32_t)lane * 16u + bpos + 1u,
+                                                m != 0u || next_adjacent);
+                                }
+                            }
                             // the byte after the newline sits in the same 16 bytes 15 times out of 16
                             uint32_t nc16 = 0;
                             if (bpos < 15u) {
@@ -586,6 +615,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                         if constexpr (REC_TE) sink.template batch<FASTQ, ALL>(L, CAPW, pend_base, rs, 0u, re, buf);
                         else sink.template records<Lds<FASTQ, ALL, CV>>(L, CAPW / 4u, pend_base, tile_idx, tile_rel, rs, re, buf);
                         shift_window(L, CAPW, 0u);
+                        if constexpr (HEAD16) sink.shift16(CAPW, 0u);
                         pend_base += CAPW;
                     }
                 } else {
@@ -663,6 +693,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
                     wave_lds_fence();
                     if (R) sink.template records<Lds<FASTQ, ALL, CV>>(L, R, pend_base, tile_idx, tile_rel, rs, re, buf);
                     shift_window(L, 4u * R, pending & 3u);
+                    if constexpr (HEAD16) sink.shift16(4u * R, pending & 3u);
                     pend_base += 4u * R;
                 }
             }
@@ -856,6 +887,7 @@ __device__ __forceinline__ uint32_t stream_range(Lds<FASTQ, ALL, CV>& L, const u
             const uint32_t R = pending >> 2;
             if (R) sink.template records<Lds<FASTQ, ALL, CV>>(L, R, pend_base, end_tile, (uint32_t)(end_tile - rs), rs, re, buf);
             shift_window(L, 4u * R, pending & 3u);
+            if constexpr (HEAD16) sink.shift16(4u * R, pending & 3u);
             pend_base += 4u * R;
         }
         // the whole records have gone to the sink (tile-end sinks: at the end of the last tile, virtual newline included);

@@ -24,11 +24,25 @@
 #define BSK_NAMES_EXP 0
 #endif
 #ifndef BSK_NAMES_WINDOW
-#define BSK_NAMES_WINDOW 384  // events the deferred window holds: 384 / tile end 20.25 ms, 256 / window full 20.38, 512 / tile end 22.07 at C2
-                              // (scripts/history/r04_names.sh: the later the sink runs, the colder the header lines it loads)
+#define BSK_NAMES_WINDOW 320  // events the deferred window holds.  Round 4 (header bytes loaded again per record): 384 / tile end
+                              // 20.25 ms, 256 / window full 20.38, 512 / tile end 22.07 at C2 (scripts/history/r04_names.sh: the
+                              // later the sink ran, the colder the header lines it loaded).  Round 6 (header bytes from LDS):
+                              // 256 .. 384 are one figure, 18.7 .. 20.7 ms from box to box (scripts/r06_ab4e.sh, r06_ab4f.sh);
+                              // 320 is the least LDS that still hands the sink 48 records at a time
 #endif
 #ifndef BSK_NAMES_TE
 #define BSK_NAMES_TE 1               // the sink runs at the end of a tile (1) / when the window is full (0)
+#endif
+#ifndef BSK_NAMES_HEAD16
+#define BSK_NAMES_HEAD16 1           // header bytes from the pass's LDS (stream_core_dev.hpp sink_head16) instead of a load per record:
+                                     // FETCH_SIZE x 2 of the pass 144.8 -> 103.1 GB per 100 GB (scripts/r06_ab4.sh)
+#endif
+#ifndef BSK_NAMES_NT
+#define BSK_NAMES_NT 0               // non-temporal tile loads: no gain once the header bytes come from LDS, and a wider spread
+                                     // (19.3 .. 21.2 ms against 18.7 .. 19.6, scripts/r06_ab4e.sh)
+#endif
+#ifndef BSK_NAMES_DIAG
+#define BSK_NAMES_DIAG 0             // experiments (wrong results): 1 no scan / stores, 2 no sink at all, 3 no stores
 #endif
 #ifndef BSK_NAMES_WAVES
 #define BSK_NAMES_WAVES 7
@@ -45,52 +59,92 @@ struct NamesSink {
     static constexpr bool TILE_HOOK = false;
     static constexpr bool RECORDS4 = true;  // whole records, 64 at a time (records() below)
     static constexpr bool REC_TILE_END = BSK_NAMES_TE != 0;
+    static constexpr bool TILE_NT = BSK_NAMES_NT != 0 && BSK_NAMES_HEAD16 != 0;
     NamesDev D;
     uint8_t* slice = nullptr;  // this range's output slice
     uint32_t cursor = 0;       // bytes written to it so far (wave-uniform)
     uint32_t nrec = 0;         // records seen in this range (wave-uniform)
     uint32_t err = 0;
     const uint8_t* lim = nullptr;  // one past the last byte of the shard
+    // HEAD16: entry j = the 16 bytes behind the newline in window slot HISTORY + 4 j - 1 -- '@' and the first 15 bytes of the
+    // header of record j of the window (entry 0: the record whose header began before the window did); zeros = not known
+    static constexpr bool HEAD16 = BSK_NAMES_HEAD16 != 0;
+    uint4* h16 = nullptr;
+
+    __device__ __forceinline__ void head16(uint32_t s, const uint8_t* p, bool valid) {
+        uint4* e = &h16[(s - (uint32_t)HISTORY + 1u) >> 2];
+        if (valid) {
+            uint4 v;
+            __builtin_memcpy(&v, p, 16);
+            *e = v;
+        } else {
+            e->x = 0;  // (no '@' in its first byte: not known)
+        }
+    }
+    __device__ __forceinline__ void shift16(uint32_t done, uint32_t) {
+        // (the events that stay pending are the first three of a record at most: only the header of THAT record moves)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const bool mine = (threadIdx.x & 63) == 0;
+        if (mine) v = h16[done >> 2];
+        wave_lds_fence();
+        if (mine) h16[0] = v;
+        wave_lds_fence();
+    }
 
     __device__ __forceinline__ void begin_range(uint32_t r) {
         slice = D.slices + (uint64_t)r * D.slice_cap;
         cursor = 0;
         nrec = 0;
+        if constexpr (HEAD16) {
+            if ((threadIdx.x & 63) == 0) h16[0] = make_uint4(0, 0, 0, 0);  // (the range's first header has no record end before it)
+            wave_lds_fence();
+        }
+    }
+
+    // exactly olen <= 16 bytes of w to dst: 16 / 8 / 4 / 2 / 1-byte stores (neighbouring lanes own the bytes around them).
+    // (Four dwords by value and selects, not an array: indexed by "dwords consumed" the array went to scratch memory -- a
+    // 16-byte scratch store and two scratch loads per record, most of the 10.4 GB k_names wrote for 3.8 GB of names at C2.)
+    __device__ __forceinline__ void store_small(uint8_t* dst, uint4 w, uint32_t olen) {
+        if (olen & 16u) { __builtin_memcpy(dst, &w, 16); return; }
+        uint32_t a = w.x, b = w.y, c = w.z, d = w.w;  // what is left to write begins at a
+        if (olen & 8u) {
+            const uint2 v = make_uint2(a, b);
+            __builtin_memcpy(dst, &v, 8);
+            dst += 8;
+            a = c; b = d;
+        }
+        if (olen & 4u) {
+            __builtin_memcpy(dst, &a, 4);
+            dst += 4;
+            a = b;
+        }
+        if (olen & 2u) {
+            const uint16_t h2 = (uint16_t)a;
+            __builtin_memcpy(dst, &h2, 2);
+            dst += 2;
+            a >>= 16;
+        }
+        if (olen & 1u) dst[0] = (uint8_t)a;
+    }
+    // byte m (< 16) of w becomes '\n'
+    __device__ __forceinline__ uint4 newline_at(uint4 w, uint32_t m) {
+        const uint32_t sh = (m & 3u) * 8u, d = m >> 2;
+        const uint32_t keep = ~(0xFFu << sh), nl = 0x0Au << sh;
+        w.x = d == 0u ? (w.x & keep) | nl : w.x;
+        w.y = d == 1u ? (w.y & keep) | nl : w.y;
+        w.z = d == 2u ? (w.z & keep) | nl : w.z;
+        w.w = d == 3u ? (w.w & keep) | nl : w.w;
+        return w;
     }
 
     // olen = m + 1 bytes of a name (m from src, then '\n') to dst
     __device__ __forceinline__ void copy_name(uint8_t* dst, const uint8_t* src, uint32_t m, uint32_t olen) {
-                    if (olen <= 16u && src + 16 <= lim) {
-            // one 16-byte load; the '\n' is put at byte m in registers (it IS byte m of the text for a whole
-            // head), then 8 / 4 / 2 / 1-byte stores of exactly olen bytes (neighbouring lanes own the rest)
-            uint32_t w[4];
-            __builtin_memcpy(w, src, 16);
-            if (D.only_id) {
-                const uint32_t sh = (m & 3u) * 8u;
-                const uint32_t d = m >> 2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (d == (uint32_t)q) w[q] = (w[q] & ~(0xFFu << sh)) | (0x0Au << sh);
-            }
-            uint32_t q = 0;  // dwords consumed
-            if (olen & 16u) { __builtin_memcpy(dst, w, 16); }
-            if (olen & 8u) { __builtin_memcpy(dst, w, 8); q = 2; }
-            if (olen & 4u) {
-                const uint32_t v = q ? w[2] : w[0];
-                __builtin_memcpy(dst + 4u * q, &v, 4);
-                q += 1;
-            }
-            if (olen & 3u) {
-                const uint32_t v = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
-                uint8_t* d2 = dst + 4u * q;
-                if (olen & 2u) {
-                    const uint16_t h2 = (uint16_t)v;
-                    __builtin_memcpy(d2, &h2, 2);
-                    if (olen & 1u) d2[2] = (uint8_t)(v >> 16);
-                } else {
-                    d2[0] = (uint8_t)v;
-                }
-            }
+        if (olen <= 16u && src + 16 <= lim) {
+            // one 16-byte load; the '\n' is put at byte m in registers (it IS byte m of the text for a whole head)
+            uint4 w;
+            __builtin_memcpy(&w, src, 16);
+            if (D.only_id) w = newline_at(w, m);
+            store_small(dst, w, olen);
         } else {
             uint32_t i = 0;
             for (; i + 16u <= m; i += 16u) {
@@ -134,6 +188,9 @@ struct NamesSink {
             if (v16 & 0x100u) return v16 & 0xFFu;
             return buf[rs + p + 1u];
         };
+#if BSK_NAMES_DIAG == 2
+        nrec += R; return;
+#endif
         for (uint32_t r0 = 0; r0 < R; r0 += WAVE) {
             const uint32_t j = r0 + lane;
             const bool on = j < R;
@@ -158,12 +215,32 @@ struct NamesSink {
                 }
                 olen = m + 1u;
             }
+            // HEAD16: a whole head of up to 15 bytes sits behind its '@' in the 16 bytes the pass kept in LDS
+            bool in_lds = false;
+            uint4 hw = make_uint4(0, 0, 0, 0);
+            if constexpr (HEAD16) {
+                if (on && !D.only_id && olen <= 16u) {
+                    const uint4 hd = h16[j];
+                    if ((hd.x & 0xFFu) == (uint32_t)'@') {
+                        in_lds = true;
+                        hw = newline_at(make_uint4(__builtin_amdgcn_alignbyte(hd.y, hd.x, 1), __builtin_amdgcn_alignbyte(hd.z, hd.y, 1),
+                                                   __builtin_amdgcn_alignbyte(hd.w, hd.z, 1), hd.w >> 8), m);
+                    }
+                }
+            }
+#if BSK_NAMES_DIAG == 1
+            err |= (olen + (uint32_t)(uintptr_t)src) == 0x12345678u; nrec += (uint32_t)__popcll(__ballot(on)); continue;
+#endif
             const uint32_t incl = wave_incl_scan<DPP>(olen);
             const uint32_t tot = wave_last(incl);
+#if BSK_NAMES_DIAG == 3
+            cursor += tot; err |= (hw.x ^ hw.y ^ hw.z ^ hw.w) == 0x12345678u; nrec += (uint32_t)__popcll(__ballot(on)); continue;
+#endif
             if (olen) {
                 const uint32_t at = cursor + incl - olen;
-                if ((uint64_t)at + olen <= D.slice_cap) copy_name(slice + at, src, m, olen);
-                else err |= ERR_CAPACITY;
+                if ((uint64_t)at + olen > D.slice_cap) err |= ERR_CAPACITY;
+                else if (in_lds) store_small(slice + at, hw, olen);
+                else copy_name(slice + at, src, m, olen);
             }
             cursor += tot;
             nrec += (uint32_t)__popcll(__ballot(olen != 0u));
@@ -235,6 +312,10 @@ void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __rest
     const int wave = threadIdx.x >> 6;
     Lds<true, false, BSK_NAMES_WINDOW>& L = s_l[wave];
     NamesSink<DPP> sink;
+    if constexpr (NamesSink<DPP>::HEAD16) {
+        __shared__ uint4 s_h16[WAVES_PER_BLOCK][BSK_NAMES_WINDOW / 4 + 1];
+        sink.h16 = s_h16[wave];
+    }
     sink.D = D;
     sink.lim = buf + n;
     PredConsts P;  // unused (sparse path)

@@ -80,7 +80,7 @@ if want("seq") or want("subseq"):
     t, nrec = synth(0, 0, 100e9 * scale)
     if want("seq"):
         dt, ol, k = run("SeqTransform", lib.bsk_seq_run, {"Name": True}, t, 1)
-        assert ol == 12 * nrec
+        assert ol == 12 * nrec or os.environ.get("BSK_DIAG")  # (BSK_DIAG: experiment builds with parts of a kernel removed)
         report("seq -n (C2, 100 GB FASTQ)", nrec, t.numel(), dt, ol)
     if want("subseq"):
         dt, ol, k = run("SubseqTransform", lib.bsk_subseq_run, {"Region": "1:50"}, t[:317 * (nrec // 4)], 1)
