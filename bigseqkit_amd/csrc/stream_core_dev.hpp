@@ -112,6 +112,25 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ---------------------------------------------------------------------------
+// A kernel argument that is needed once per range, read from the kernel's argument block WHEN it is needed instead of
+// living in a scalar register through the pass.  Round 6: every streaming pass wants ~150 scalar registers (the arguments,
+// the state of range / tile / round, four ballots, one exec mask per level of divergent control flow) where a wave has
+// 94 - 102, and the compiler keeps the rest in lanes of a vector register: a v_writelane per definition and a v_readlane
+// per use -- VALU instructions in passes that are bound by VALU issue.  The kernel takes ONE struct; BSK_KARG(Args, member)
+// is a scalar load from the argument block behind an opaque copy of its address (so that the load is neither hoisted out of
+// the loop nor merged with the loads at kernel entry).  Measured on k_names (scripts/r06_ab5.sh): 68 -> 55 spilled scalar
+// registers, 410 -> 404 VALU per tile -- the spills that cost are those of the tile / round state, not of the arguments;
+// kept there, not worth carrying to the other passes.
+template <class T>
+__device__ __forceinline__ T karg_load(uint32_t offset) {
+    using cptr = __attribute__((address_space(4))) const char*;
+    cptr p = (cptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<__attribute__((address_space(4))) const T*>(p + offset);
+}
+#define BSK_KARG(ARGS, member) (::bsk::stream::karg_load<decltype(ARGS::member)>((uint32_t)offsetof(ARGS, member)))
+
+// ---------------------------------------------------------------------------
 // SWAR byte predicates on a dword -> 4-bit mask (bit b = byte b matches)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {  // exact: 0x80 in every zero byte

@@ -60,8 +60,9 @@ struct NamesSink {
     static constexpr bool RECORDS4 = true;  // whole records, 64 at a time (records() below)
     static constexpr bool REC_TILE_END = BSK_NAMES_TE != 0;
     static constexpr bool TILE_NT = BSK_NAMES_NT != 0 && BSK_NAMES_HEAD16 != 0;
-    NamesDev D;
-    uint8_t* slice = nullptr;  // this range's output slice
+    int only_id = 0, id_mode = 0;  // (NamesDev)
+    uint32_t slice_cap = 0;        // bytes of a slice (< 2^32)
+    uint8_t* slice = nullptr;      // this range's output slice
     uint32_t cursor = 0;       // bytes written to it so far (wave-uniform)
     uint32_t nrec = 0;         // records seen in this range (wave-uniform)
     uint32_t err = 0;
@@ -91,8 +92,8 @@ struct NamesSink {
         wave_lds_fence();
     }
 
-    __device__ __forceinline__ void begin_range(uint32_t r) {
-        slice = D.slices + (uint64_t)r * D.slice_cap;
+    __device__ __forceinline__ void begin_range(uint8_t* slice_of_range) {
+        slice = slice_of_range;
         cursor = 0;
         nrec = 0;
         if constexpr (HEAD16) {
@@ -143,7 +144,7 @@ struct NamesSink {
             // one 16-byte load; the '\n' is put at byte m in registers (it IS byte m of the text for a whole head)
             uint4 w;
             __builtin_memcpy(&w, src, 16);
-            if (D.only_id) w = newline_at(w, m);
+            if (only_id) w = newline_at(w, m);
             store_small(dst, w, olen);
         } else {
             uint32_t i = 0;
@@ -208,9 +209,9 @@ struct NamesSink {
                 const uint8_t* h = buf + rs + (uint64_t)(p0 + 1u) + 1u;  // the header without its marker (p0 + 1 wraps to 0 at the range start)
                 m = lh ? lh - 1u : 0u;
                 src = h;
-                if (D.only_id) {
+                if (only_id) {
                     uint32_t off = 0;
-                    m = id_span_of(h, m, D.id_mode, &off, lim);
+                    m = id_span_of(h, m, id_mode, &off, lim);
                     src = h + off;
                 }
                 olen = m + 1u;
@@ -219,7 +220,7 @@ struct NamesSink {
             bool in_lds = false;
             uint4 hw = make_uint4(0, 0, 0, 0);
             if constexpr (HEAD16) {
-                if (on && !D.only_id && olen <= 16u) {
+                if (on && !only_id && olen <= 16u) {
                     const uint4 hd = h16[j];
                     if ((hd.x & 0xFFu) == (uint32_t)'@') {
                         in_lds = true;
@@ -238,7 +239,7 @@ struct NamesSink {
 #endif
             if (olen) {
                 const uint32_t at = cursor + incl - olen;
-                if ((uint64_t)at + olen > D.slice_cap) err |= ERR_CAPACITY;
+                if ((uint64_t)at + olen > slice_cap) err |= ERR_CAPACITY;
                 else if (in_lds) store_small(slice + at, hw, olen);
                 else copy_name(slice + at, src, m, olen);
             }
@@ -278,9 +279,9 @@ struct NamesSink {
                     const uint8_t* h = buf + abs_of(p4, tile_idx, tile_rel) + 2;  // the header without its marker
                     m = lh ? lh - 1u : 0u;
                     src = h;
-                    if (D.only_id) {
+                    if (only_id) {
                         uint32_t off = 0;
-                        m = id_span_of(h, m, D.id_mode, &off, lim);
+                        m = id_span_of(h, m, id_mode, &off, lim);
                         src = h + off;
                     }
                     olen = m + 1u;
@@ -290,7 +291,7 @@ struct NamesSink {
             const uint32_t tot = wave_last(incl);
             if (olen) {
                 const uint32_t at = cursor + incl - olen;
-                if ((uint64_t)at + olen <= D.slice_cap) {
+                if ((uint64_t)at + olen <= slice_cap) {
                     uint8_t* dst = slice + at;
                     copy_name(dst, src, m, olen);
                 } else {
@@ -303,10 +304,19 @@ struct NamesSink {
     }
 };
 
+// (one argument struct: what a wave needs once per range is read from it there -- BSK_KARG, stream_core_dev.hpp)
+struct NamesArgs {
+    const uint8_t* buf;
+    uint64_t n;
+    const uint64_t* anchors;
+    uint32_t nranges;
+    uint32_t* queue;
+    NamesDev D;
+};
+
 template <bool DPP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) __attribute__((amdgpu_waves_per_eu(BSK_NAMES_WAVES, 8)))
-void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __restrict__ anchors, uint32_t nranges,
-             uint32_t* __restrict__ queue, NamesDev D) {
+void k_names(NamesArgs a) {
     __shared__ Lds<true, false, BSK_NAMES_WINDOW> s_l[WAVES_PER_BLOCK];  // 64 whole records per sink call (NamesSink::records)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -316,30 +326,36 @@ void k_names(const uint8_t* __restrict__ buf, uint64_t n, const uint64_t* __rest
         __shared__ uint4 s_h16[WAVES_PER_BLOCK][BSK_NAMES_WINDOW / 4 + 1];
         sink.h16 = s_h16[wave];
     }
-    sink.D = D;
+    const uint8_t* __restrict__ buf = a.buf;
+    const uint64_t n = a.n;
+    sink.only_id = a.D.only_id;
+    sink.id_mode = a.D.id_mode;
     sink.lim = buf + n;
     PredConsts P;  // unused (sparse path)
     P.k20 = P.k30 = 0;
     P.ngap = 0;
-    const uint64_t n_eff = anchors[nranges];
     for (;;) {
         uint32_t r = 0;
-        if (lane == 0) r = atomicAdd(queue, 1u);
+        if (lane == 0) r = atomicAdd(BSK_KARG(NamesArgs, queue), 1u);
         r = wave_first(r);
+        const uint32_t nranges = BSK_KARG(NamesArgs, nranges);
         if (r >= nranges) break;
+        const uint64_t* anchors = BSK_KARG(NamesArgs, anchors);
+        const uint64_t n_eff = anchors[nranges];
         uint64_t rs = anchors[r], re = anchors[r + 1];
         rs = rs < n_eff ? rs : n_eff;
         re = re < n_eff ? re : n_eff;
         if (rs >= re) {
-            if (lane == 0) { D.range_bytes[r] = 0; D.range_count[r] = 0; }
+            if (lane == 0) { BSK_KARG(NamesArgs, D.range_bytes)[r] = 0; BSK_KARG(NamesArgs, D.range_count)[r] = 0; }
             continue;
         }
-        sink.begin_range(r);
+        sink.slice_cap = (uint32_t)BSK_KARG(NamesArgs, D.slice_cap);
+        sink.begin_range(BSK_KARG(NamesArgs, D.slices) + (uint64_t)r * sink.slice_cap);
         stream_range<true, false, DPP>(L, buf, n, rs, re, re == n_eff, P, sink);
-        if (lane == 0) { D.range_bytes[r] = sink.cursor; D.range_count[r] = sink.nrec; }
+        if (lane == 0) { BSK_KARG(NamesArgs, D.range_bytes)[r] = sink.cursor; BSK_KARG(NamesArgs, D.range_count)[r] = sink.nrec; }
     }
     const uint32_t err = wave_or_u32(sink.err);
-    if (lane == 0 && err) atomicOr((unsigned long long*)&D.status[0], (unsigned long long)err);
+    if (lane == 0 && err) atomicOr((unsigned long long*)&BSK_KARG(NamesArgs, D.status)[0], (unsigned long long)err);
 }
 
 // slices -> one text: block (r, k) copies the k-th 16 KiB of range r's slice to its place.  A slice begins 16-byte
@@ -373,8 +389,9 @@ __global__ __launch_bounds__(256) void k_names_compact(const uint8_t* __restrict
 hipError_t launch_names(bool dpp, int blocks, const uint8_t* buf, uint64_t n, const uint64_t* anchors, uint32_t nranges,
                         uint32_t* queue, const NamesDev& D, hipStream_t st) {
     const dim3 b(WAVES_PER_BLOCK * WAVE);
-    if (dpp) hipLaunchKernelGGL((k_names<true>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
-    else hipLaunchKernelGGL((k_names<false>), dim3(blocks), b, 0, st, buf, n, anchors, nranges, queue, D);
+    const NamesArgs a{buf, n, anchors, nranges, queue, D};
+    if (dpp) hipLaunchKernelGGL((k_names<true>), dim3(blocks), b, 0, st, a);
+    else hipLaunchKernelGGL((k_names<false>), dim3(blocks), b, 0, st, a);
     return hipGetLastError();
 }
 
