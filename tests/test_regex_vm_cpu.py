@@ -3,6 +3,7 @@ Python's `re` on the syntax both share: bounds of the match and of capture group
 Host build of the same routine the device runs."""
 import ctypes as C
 import random
+import zlib
 import re
 
 import pytest
@@ -49,7 +50,7 @@ EXPRS = [r"^(\S+)\s?", r"\|([^\|]+)\| ", r"^([^ ]+) ", r"(\d+)$", r"id=(\w+)", r
 
 @pytest.mark.parametrize("expr", EXPRS)
 def test_same_spans_as_python_re(expr):
-    rng = random.Random(hash(expr) & 0xFFFF)
+    rng = random.Random(zlib.crc32(repr(expr).encode()) & 0xFFFF)  # (str hashes differ from process to process)
     alpha = "ACGTNacgt|_ .=xyab01239d-"
     texts = [b"", b"a", b"aaa", b"gi|110645304|ref|NC_002516.2| Pseudomonas", b"seq1 desc id=ab_9 end", b"ACGTACGT", b"xxxy", b"abcd",
              b"read_12_x 77", b"AAAAC", b"GAAT", b"TAA TGA"]

@@ -5,6 +5,7 @@ the oracle's (Translate.Call, /root/reference/bigseqkit-lib/translate.go:104-145
 import ctypes as C
 import json
 import random
+import zlib
 
 import pytest
 
@@ -55,7 +56,7 @@ OPTS = [{"Frame": ["6"]}, {"Frame": ["1"], "Trim": True}, {"Frame": ["-2", "3"],
 @pytest.mark.parametrize("shape", ["w60", "w70", "one_line", "own_width", "no_final_newline", "lower"])
 def test_regular_text_takes_the_light_table(shape, o, monkeypatch):
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
-    rng = random.Random(hash(shape) % 1000 + o)
+    rng = random.Random(zlib.crc32(shape.encode()) % 1000 + o)  # (str hashes differ from process to process)
     if shape == "w60": data = fasta(rng, 400, 60)
     elif shape == "w70": data = fasta(rng, 300, 70, lens=(0, 500))
     elif shape == "one_line": data = fasta(rng, 300, 0, lens=(1, 700))
