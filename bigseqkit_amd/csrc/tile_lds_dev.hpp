@@ -18,7 +18,11 @@
 namespace bsk {
 namespace tilelds {
 
-constexpr uint32_t CARRY = 512;                       // bytes of the previous tile kept in front of the current one
+#ifndef BSK_TILE_CARRY
+#define BSK_TILE_CARRY 512  // (a source may choose: LDS per block decides the blocks per CU -- stream_subseq.hip)
+#endif
+constexpr uint32_t CARRY = BSK_TILE_CARRY;            // bytes of the previous tile kept in front of the current one
+static_assert(CARRY % 16 == 0 && CARRY >= 64 && CARRY <= 1024, "the carry is copied by lanes, 16 bytes each");
 constexpr uint32_t TBUF = CARRY + stream::TILE + 16;  // + 16: a word that ends on the last tile byte is read as whole dwords
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

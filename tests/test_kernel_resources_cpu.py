@@ -56,3 +56,35 @@ def test_translate_wide_keeps_its_registers(tmp_path):
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
         assert (scratch, spill) == (0, 0) and occ >= 4, (b.split(" ", 1)[0], scratch, spill, occ)
     assert seen == 6   # G = 4, 16, 64, each with the record table and with the uniform layout (UNI)
+
+
+def _blocks(src, tmp_path):
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o",
+                        str(tmp_path / "o.o")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr.split("Function Name: ")[1:]
+
+
+def _num(b, what):
+    return int(re.search(re.escape(what) + r": (\d+)", b).group(1))
+
+
+def test_streaming_passes_keep_no_array_in_scratch(tmp_path):
+    """Scratch memory beyond what the spilled registers need is an ARRAY that the compiler could not keep in registers (one
+    that is indexed at run time): `k_names` wrote 10.4 GB for 3.8 GB of names that way until round 6 (HISTORY section 10) --
+    the resource report had said "ScratchSize 32, VGPRs Spill 0" all along.  `k_subseq_stream`: 6 waves per SIMD needs
+    26.1 KB of LDS per block (6 blocks of 4 waves in 160 KB) and at most 80 registers, none spilled."""
+    seen = set()
+    for name in ("stream_names.hip", "stream_subseq.hip", "stream_filter.hip", "stream_index.hip", "stream_rmdup.hip"):
+        for b in _blocks(os.path.join(ROOT, "bigseqkit_amd", "csrc", name), tmp_path):
+            sym = b.split(" ", 1)[0]
+            if not any(k in sym for k in ("k_names", "k_subseq_stream", "k_filter", "k_index", "k_rmdup_stream")) or "compact" in sym:
+                continue
+            seen.add(re.sub(r"I.*", "", sym.split("N_1")[-1]))
+            scratch, spilled = _num(b, "ScratchSize [bytes/lane]"), _num(b, "VGPRs Spill")
+            assert scratch <= 4 * spilled + 4, (sym, scratch, spilled)
+            if "k_subseq_streamILb1E" in sym:
+                assert _num(b, "Occupancy [waves/SIMD]") == 6 and spilled == 0 and _num(b, "LDS Size [bytes/block]") * 6 <= 160 * 1024, b[:900]
+            if "k_namesILb1E" in sym:
+                assert _num(b, "Occupancy [waves/SIMD]") == 7 and _num(b, "LDS Size [bytes/block]") * 7 <= 160 * 1024, b[:900]
+    assert len(seen) >= 5, seen
