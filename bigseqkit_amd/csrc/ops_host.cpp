@@ -672,6 +672,39 @@ int finish_sizes(bsk_ctx* c, hipStream_t st, uint64_t* total, uint64_t* kept) {
     return kernel_error_to_status(c, c->status_word());
 }
 
+// records that leave exactly as they stand in the shard (4-line FASTQ, everything printed, nothing rewritten)
+static bool records_verbatim(const SeqParams& P) {
+    return P.fastq && !P.fasta_out && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id && !P.reverse && !P.use_lut &&
+           !P.region_on && !P.feat_on && !P.remove_gaps;  // (rename: per record, k_seg_build)
+}
+
+// Round 6 (results as ordered slices, include/bsk.h bsk_out.d_seg_*): the records an operator KEEPS, verbatim, are segments of
+// the shard -- `seq` with its length / quality filters, `grep`, whatever selects whole FASTQ records.  With out=slices the
+// segment list that k_seg_copy would be driven by IS the result (a record that was dropped is a segment of no bytes) and the
+// output block is neither allocated nor written.  1: `out` describes the result; 0: not this call (the caller emits as
+// before); < 0: error.  Sizes and offsets are the call's d_out_len / d_out_off (finish_sizes).
+int try_records_as_slices(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, uint64_t total, uint64_t kept, hipStream_t st,
+                          bsk_out* out) {
+    const RecordTable& t = c->table;
+    if (!slices_wanted(c) || !records_verbatim(P) || t.n == 0 || total == 0 || c->tune.is("segcopy", "off")) return 0;
+    int rc = grow(c, &c->d_seg_src, &c->seg_src_cap, t.n + 1, t.n / 8 + 16);
+    if (rc != BSK_OK) return rc > 0 ? -rc : rc;
+    rc = grow(c, &c->d_seg_first, &c->seg_first_cap, seg_tiles(total) + 1, 64);
+    if (rc != BSK_OK) return rc > 0 ? -rc : rc;
+    uint64_t* d_other = c->d_fin + bsk_ctx::FIN_OTHER;
+    if (hipMemsetAsync(d_other, 0, sizeof(uint64_t), st) != hipSuccess) { c->set_error("hipMemsetAsync failed"); return -BSK_ERR_HIP; }
+    {
+        Timed tm(c, "k_seg_prep", st);
+        if (launch_seg_build_fastq(d_buf, n, t, c->d_out_len, c->d_seg_src, d_other, st, P.ren_ord) != hipSuccess ||
+            launch_seg_first(c->d_out_off, t.n, c->d_seg_first, st) != hipSuccess) { c->set_error("k_seg_prep launch failed"); return -BSK_ERR_HIP; }
+    }
+    rc = ctl_readback(c, st);
+    if (rc != BSK_OK) return rc > 0 ? -rc : rc;
+    if (c->fin(bsk_ctx::FIN_OTHER) != 0) return 0;  // (records that are not four plain lines: the emit kernel writes those)
+    out_as_segments(c, out, c->d_seg_src, c->d_out_off, t.n, c->d_seg_first, d_buf, d_buf + n, total, kept);
+    return 1;
+}
+
 // tell the emit kernel which records it must leave to the block-per-chunk launch
 int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& Pin, const uint32_t* d_len, const uint64_t* d_off,
                     uint8_t* d_out, uint64_t total, uint64_t kept, hipStream_t st) {
@@ -679,8 +712,7 @@ int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams&
     P.seg_src = nullptr;
     const RecordTable& t = c->table;
     const char* env = c->tune.get("segcopy");  // off: never; force: whenever the records qualify (tests)
-    const bool verbatim = P.fastq && !P.fasta_out && P.print_name && P.print_seq && P.print_qual && !P.qual_only && !P.only_id &&
-                          !P.reverse && !P.use_lut && !P.region_on && !P.feat_on && !P.remove_gaps;  // (rename: per record, below)
+    const bool verbatim = records_verbatim(P);
     bool seg = verbatim && t.n > 0 && total > 0 && ((uintptr_t)d_out & 15u) == 0 && !(env && strcmp(env, "off") == 0);
     if (seg && !(env && strcmp(env, "force") == 0)) seg = kept * 2 >= t.n && total >= (4u << 20);
     if (seg) {

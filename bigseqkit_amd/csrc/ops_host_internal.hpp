@@ -85,6 +85,10 @@ int emit_records(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P,
 // the same with the caller's size / offset arrays (offsets in RECORD order) and output place
 int emit_records_at(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, const uint32_t* d_len, const uint64_t* d_off,
                     uint8_t* d_out, uint64_t total, uint64_t kept, hipStream_t st);
+// out=slices: kept records that leave verbatim as segments of the shard (1: `out` is the result, nothing to emit; 0: emit as
+// usual; < 0: -status).  Call after finish_sizes and BEFORE ensure_out: the block is not needed then.
+int try_records_as_slices(bsk_ctx* c, const uint8_t* d_buf, size_t n, const SeqParams& P, uint64_t total, uint64_t kept, hipStream_t st,
+                          bsk_out* out);
 int empty_result(bsk_ctx* c, bsk_out* out);
 // Round 6, results as ordered slices (include/bsk.h bsk_out.d_seg_*): does the running call leave its text where it is?
 inline bool slices_wanted(const bsk_ctx* c) { return c->out_slices && !c->force_contiguous; }

@@ -696,9 +696,14 @@ int grep_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipS
     out->len = 0;
     out->records = 0;
     if (total == 0) return BSK_OK;
+    SeqParams P = format_params(c, fastq);
+    if (fastq) {
+        const int rs = try_records_as_slices(c, d_buf, n, P, total, kept, st, out);
+        if (rs < 0) return -rs;
+        if (rs == 1) return BSK_OK;
+    }
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
-    SeqParams P = format_params(c, fastq);
     if (!fastq && tt.text_w == c->d_text_w) {  // the search ran on linear copies: the emit reads the wrapped text in place
         rc = prepare_text(c, d_buf, format, st, &tt, false, /*keep_out_len=*/true);
         if (rc != BSK_OK) return rc;

@@ -221,6 +221,11 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     uint64_t total = 0, kept = 0;
     rc = finish_sizes(c, st, &total, &kept);
     if (rc != BSK_OK) return rc;
+    {
+        const int rs = try_records_as_slices(c, d_buf, n, P, total, kept, st, out);
+        if (rs < 0) return -rs;
+        if (rs == 1) return BSK_OK;
+    }
     rc = ensure_out(c, total);
     if (rc != BSK_OK) return rc;
     apply_long(c, &P);

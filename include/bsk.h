@@ -218,11 +218,12 @@ typedef struct {
      * bytes of the partition or of per-goroutine buffers: nothing is moved into one block
      * (bigseqkit-lib/subseq.go:167-225, seq.go:81-269, rmdup.go:200-222).  With "slices" an operator whose output text
      * already sits somewhere in HBM in output order -- the survivors of rmdup inside the input shard, the per-range
-     * buffers the streaming passes of `seq -n` and `subseq -r` write -- returns that: segment k is the
+     * buffers the streaming passes of `seq -n` and `subseq -r` write, the whole FASTQ records that `seq` (length / quality
+     * filters) and `grep` KEEP (segments of the shard; a dropped record is a segment of no bytes) -- returns that: segment k is the
      * d_seg_off[k + 1] - d_seg_off[k] bytes at device address d_seg_src[k]; the text is their concatenation (len bytes).
      * bsk_out_to_host, bsk_store_put and the Go shim consume slices as they are (gathered piece by piece into the
      * staging buffers of the drain); bsk_out_materialize makes the one block for a consumer that needs it (the next
-     * operator of a pipe).  LIFETIME: slices of rmdup point into the caller's SHARD -- it must stay until the output is
+     * operator of a pipe).  LIFETIME: slices of rmdup / seq / grep point into the caller's SHARD -- it must stay until the output is
      * consumed (with "contiguous" it may go as soon as the run returns); like d_data they die with the context's next run. */
     const uint64_t* d_seg_src; /* device: [n_segments] source addresses */
     const uint64_t* d_seg_off; /* device: [n_segments + 1] offsets in the output text */

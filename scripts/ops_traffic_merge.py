@@ -64,6 +64,11 @@ for op in ops:
         alg = (v["in_GB"] + v["out_GB"]) * 1e9
         if os.environ.get("BSK_OUT") == "slices" and op == "rmdup":
             alg = v["in_GB"] * 1e9 + 16.0 * v["records"]   # (the survivors are slices of the shard: not moved; bench.py's figure)
+        if os.environ.get("BSK_OUT") == "slices" and op == "grep":
+            import re
+            m = re.search(r"hits=(\d+)", v.get("note", ""))
+            if m:
+                alg = v["in_GB"] * 1e9 + 16.0 * int(m.group(1))   # (the hits stay in the shard: 16 bytes of slice list each)
         kern, total, upper = {}, 0.0, 0.0
         for k, kv in t.items():
             calls = kv["dispatches"] / 2.0              # (two calls of the command per pass)

@@ -18,10 +18,14 @@ from bigseqkit_amd._lib import lib, check
 
 pytestmark = pytest.mark.gpu
 
-RUN = {"RmDup": lib.bsk_rmdup_run, "SeqTransform": lib.bsk_seq_run, "SubseqTransform": lib.bsk_subseq_run}
+RUN = {"RmDup": lib.bsk_rmdup_run, "SeqTransform": lib.bsk_seq_run, "SubseqTransform": lib.bsk_subseq_run, "Grep": lib.bsk_grep_run}
+# (the last four: records an operator KEEPS verbatim are segments of the shard too -- `seq` with its filters, `grep`)
 CASES = [("RmDup", {"BySeq": True}, oracle.rmdup), ("RmDup", {"BySeq": True, "IgnoreCase": True}, oracle.rmdup),
          ("SeqTransform", {"Name": True}, oracle.seq), ("SeqTransform", {"Name": True, "OnlyId": True}, oracle.seq),
-         ("SubseqTransform", {"Region": "1:50"}, oracle.subseq), ("SubseqTransform", {"Region": "-30:-2"}, oracle.subseq)]
+         ("SubseqTransform", {"Region": "1:50"}, oracle.subseq), ("SubseqTransform", {"Region": "-30:-2"}, oracle.subseq),
+         ("SeqTransform", {"MinLen": 100}, oracle.seq), ("SeqTransform", {"MinQual": 19.5, "MaxLen": 150}, oracle.seq),
+         ("Grep", {"Pattern": ["ACG"], "BySeq": True, "OnlyPositiveStrand": True}, oracle.grep),
+         ("Grep", {"Pattern": ["lane=3"], "ByName": True, "UseRegexp": True, "InvertMatch": True}, oracle.grep)]
 
 
 def fastq(seed, n, dup=0.3):
@@ -63,7 +67,8 @@ def test_slices_hold_the_same_text(case, n, tmp_path):
     assert out_c.n_segments == 0 and host(op_c, out_c) == want
     op, out = run(name, opts, t, "slices")
     assert out.len == len(want) and out.records == out_c.records
-    assert out.n_segments > 0 and not out.d_data and out.d_seg_src and out.d_seg_off     # nothing was gathered
+    if want:   # (a filter that keeps nothing has nothing to leave in place)
+        assert out.n_segments > 0 and not out.d_data and out.d_seg_src and out.d_seg_off     # nothing was gathered
     # 1. to the host, the context keeps the slices ...
     assert host(op, out) == want
     # 2. ... the writer drains them ...
@@ -76,7 +81,7 @@ def test_slices_hold_the_same_text(case, n, tmp_path):
     assert tot.value == len(want) and open(path, "rb").read() == want
     # 3. ... and one block is made when somebody asks for it (the next operator of a pipe)
     check(lib.bsk_out_materialize(op.ctx, C.byref(out), None), op.ctx)
-    assert out.n_segments == 0 and out.d_data and host(op, out) == want
+    assert out.n_segments == 0 and (out.d_data or not want) and host(op, out) == want
     got = torch.empty(out.len, dtype=torch.uint8, device="cuda")
     check(lib.bsk_device_copy(C.c_void_p(got.data_ptr()), C.c_void_p(out.d_data), out.len, 3))
     torch.cuda.synchronize()
