@@ -21,15 +21,11 @@
 
 #include <cstdint>
 
-// Round 6: a sixth wave per SIMD.  The pass is bound by neither memory nor instruction issue (476 VALU per tile = 4.7 ms of
-// issue under an 8.4 ms pass that moves 34 GB) but by how many tiles are in flight: 27.1 KB of LDS per block and 81 registers
-// held it at 5 waves.  A 256-byte carry in front of the LDS tile (a line of up to 256 bytes that ends in a tile is still
-// contiguous there -- 150- and 250-base reads; longer lines take the memory path more often) makes it 26.1 KB = 6 blocks per
-// CU, and the compiler fits the loop into 78 registers without a spill: 9.06 / 9.20 -> 8.86 / 8.71 ms on one box
-// (scripts/r06_ab6.sh; a 128-byte carry the same).
-#ifndef BSK_TILE_CARRY
-#define BSK_TILE_CARRY 256
-#endif
+// Round 6 tried a sixth wave per SIMD: the pass is bound by neither memory nor instruction issue (476 VALU per tile = 4.7 ms of
+// issue under an 8.4 ms pass that moves 34 GB), 27.1 KB of LDS per block and 81 registers hold it at 5 waves; a 256-byte carry
+// in front of the LDS tile (-DBSK_TILE_CARRY=256: 26.1 KB = 6 blocks per CU) and -DBSK_SUBSEQ_WAVES=6 (78 registers, no spill)
+// give it the sixth.  One box: 9.06 / 9.20 -> 8.86 / 8.71 ms; another, five alternations: 8.44 +- 0.04 -> 8.53 +- 0.07 ms, and
+// 9.03 in the bench run of a third (scripts/r06_ab6.sh).  Not a gain that survives a change of box: the round-5 shape stays.
 #include "anchor.hpp"
 #include "ops_seq.hpp"
 #include "stream_core_dev.hpp"
@@ -37,7 +33,7 @@
 #include "tile_lds_dev.hpp"
 
 #ifndef BSK_SUBSEQ_WAVES
-#define BSK_SUBSEQ_WAVES 6
+#define BSK_SUBSEQ_WAVES 0
 #endif
 #if BSK_SUBSEQ_WAVES
 #define BSK_SUBSEQ_ATTR __attribute__((amdgpu_waves_per_eu(BSK_SUBSEQ_WAVES, 8)))

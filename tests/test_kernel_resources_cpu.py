@@ -72,8 +72,8 @@ def _num(b, what):
 def test_streaming_passes_keep_no_array_in_scratch(tmp_path):
     """Scratch memory beyond what the spilled registers need is an ARRAY that the compiler could not keep in registers (one
     that is indexed at run time): `k_names` wrote 10.4 GB for 3.8 GB of names that way until round 6 (HISTORY section 10) --
-    the resource report had said "ScratchSize 32, VGPRs Spill 0" all along.  `k_subseq_stream`: 6 waves per SIMD needs
-    26.1 KB of LDS per block (6 blocks of 4 waves in 160 KB) and at most 80 registers, none spilled."""
+    the resource report had said "ScratchSize 32, VGPRs Spill 0" all along.  `k_subseq_stream` / `k_names`: the occupancy
+    they were tuned at (5 / 7 waves per SIMD: LDS per block x blocks per CU within 160 KB, no spilled register in the former)."""
     seen = set()
     for name in ("stream_names.hip", "stream_subseq.hip", "stream_filter.hip", "stream_index.hip", "stream_rmdup.hip"):
         for b in _blocks(os.path.join(ROOT, "bigseqkit_amd", "csrc", name), tmp_path):
@@ -84,7 +84,7 @@ def test_streaming_passes_keep_no_array_in_scratch(tmp_path):
             scratch, spilled = _num(b, "ScratchSize [bytes/lane]"), _num(b, "VGPRs Spill")
             assert scratch <= 4 * spilled + 4, (sym, scratch, spilled)
             if "k_subseq_streamILb1E" in sym:
-                assert _num(b, "Occupancy [waves/SIMD]") == 6 and spilled == 0 and _num(b, "LDS Size [bytes/block]") * 6 <= 160 * 1024, b[:900]
+                assert _num(b, "Occupancy [waves/SIMD]") >= 5 and spilled == 0 and _num(b, "LDS Size [bytes/block]") * 5 <= 160 * 1024, b[:900]
             if "k_namesILb1E" in sym:
                 assert _num(b, "Occupancy [waves/SIMD]") == 7 and _num(b, "LDS Size [bytes/block]") * 7 <= 160 * 1024, b[:900]
     assert len(seen) >= 5, seen
