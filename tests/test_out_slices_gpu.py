@@ -136,3 +136,33 @@ def test_a_result_dies_with_the_next_run_and_exceptions_keep_one_block():
         op, out = run("RmDup", o, tt, "slices")
         assert out.n_segments == 0 and host(op, out) == oracle.rmdup(d, True, json.dumps({"BySeq": True}))
         op.close()
+
+
+@pytest.mark.parametrize("name,opts,ofn", [("SeqTransform", {"MinLen": 40}, oracle.seq), ("Grep", {"Pattern": ["AC"], "BySeq": True}, oracle.grep)])
+def test_kept_records_that_are_not_four_plain_lines_take_the_one_block(name, opts, ofn):
+    """the records `seq` / `grep` keep are slices of the shard only while they leave exactly as they stand: a '+' line that
+    repeats the name is re-written (SeqParser.Read + Format, helper.go:252-311) -- one block then, whatever the switch says;
+    bases wrapped over several lines likewise leave as four lines.  The reference's text either way"""
+    import torch
+    base = fastq(21, 400, dup=0.0)
+    plus = base.replace(b"\n+\n", b"\n+read7/1 again\n", 3)
+    recs = base.decode().split("\n")
+    wrapped = []
+    for i in range(0, len(recs) - 1, 4):   # bases and qualities over lines of 50
+        h, s, p, q = recs[i:i + 4]
+        q = q.replace("@", "A").replace("+", "B")   # (a wrapped quality line must not look like a header or a separator)
+        wrapped += [h] + [s[j:j + 50] for j in range(0, len(s), 50)] + [p] + [q[j:j + 50] for j in range(0, len(q), 50)]
+    wrapped = ("\n".join(wrapped) + "\n").encode()
+    # (wrapped records are first made four-line text in a buffer of the context: what is kept may be slices of THAT)
+    for label, data, one_block in (("plus", plus, True), ("wrapped", wrapped, False)):
+        want = ofn(data, True, json.dumps(opts))
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        op, out = run(name, opts, t, "slices")
+        assert host(op, out) == want and len(want) > 0, label
+        assert out.n_segments == 0 or not one_block, label
+        op.close()
+    # ... and the same call on the plain records leaves slices
+    t = torch.frombuffer(bytearray(base), dtype=torch.uint8).cuda()
+    op, out = run(name, opts, t, "slices")
+    assert out.n_segments > 0 and host(op, out) == ofn(base, True, json.dumps(opts))
+    op.close()
