@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -141,18 +142,24 @@ extern "C" int bsk_shard_load(int fd, uint64_t offset, size_t n, int device, int
     if (device < 0 || device >= have) return bsk::global_error_set(BSK_ERR_NO_DEVICE, "libbsk: device " + std::to_string(device) + " is not visible");
     if (hipSetDevice(device) != hipSuccess) return bsk::global_error_set(BSK_ERR_NO_DEVICE, "libbsk: no such HIP device");
     void* d = nullptr;
+    const bool timing = getenv("BSK_SHARD_TIMING") != nullptr;  // (stderr: allocation / readers, scripts/r06_load_sweep.py)
+    const auto t_begin = std::chrono::steady_clock::now();
     // (BSK_SHARD_FAIL_ALLOC: the tests' stand-in for a shard larger than the free HBM -- the callers' fall-back and messages)
     if (getenv("BSK_SHARD_FAIL_ALLOC") || hipMalloc(&d, n ? n : 1) != hipSuccess) return bsk::global_error_set(BSK_ERR_HIP, "libbsk: device allocation of the shard (" + std::to_string(n) + " bytes) failed");
+    const auto t_alloc = std::chrono::steady_clock::now();
     if (n) {
         LoadJob J;
         J.fd = fd; J.offset = offset; J.n = n; J.device = device; J.d = (char*)d;
         J.piece = PIECE_DEFAULT;
         if (const char* e = getenv("BSK_SHARD_PIECE_BYTES")) { const long long v = atoll(e); if (v >= 4096) J.piece = (size_t)v; }
         const uint64_t pieces = (n + J.piece - 1) / J.piece;
-        // (8 readers bring 8 GB in 0.25 s; the whole 100 GB file of C2 came at 16.7 GB/s -- bench.py end_to_end_config_size,
-        // round 6 -- where PCIe takes 55: the copy out of the page cache is what a reader spends its time in, so a large shard
-        // gets more of them: 8 + one per 4 GiB, up to 24)
-        int T = threads > 0 ? threads : 8 + (int)std::min<uint64_t>(16, (uint64_t)n >> 32);
+        // (8 readers: the whole 100 GB file of C2 is on the device 1.87 - 2.0 s after the allocation = 50 - 53 GB/s, what PCIe
+        // Gen5 x16 gives; 4: 2.0 - 2.2, 12: 2.0, 16: 2.0 - 2.15, 24: 2.5 -- more readers only get in each other's way in the
+        // page cache (scripts/r06_load_sweep.py with BSK_SHARD_TIMING=1).  What made round 6's first measurements spread
+        // from 2.3 to 8.9 s per call was not the readers: every SECOND fresh process pays 3.5 - 5.8 s for its hipMalloc of
+        // 100 GB -- the memory the process before it released is cleared first -- and the others 0.001 s.)
+        int T = threads > 0 ? threads : 8;
+        if (threads <= 0) { if (const char* e = getenv("BSK_SHARD_READERS")) { const int v = atoi(e); if (v > 0) T = v; } }  // (scripts/r06_load_sweep.py)
         T = (int)std::min<uint64_t>((uint64_t)std::min(T, 64), pieces);
         J.pin = numa_cpus_of_device(device, &J.cpus);
         // (every reader is a thread of its own: the caller's affinity is not touched)
@@ -163,6 +170,11 @@ extern "C" int bsk_shard_load(int fd, uint64_t offset, size_t n, int device, int
             hipFree(d);
             return bsk::global_error_set(BSK_ERR_HIP, J.error);
         }
+    }
+    if (timing) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[shard] %zu bytes: allocation %.3f s, readers %.3f s\n", n, std::chrono::duration<double>(t_alloc - t_begin).count(),
+                std::chrono::duration<double>(t_end - t_alloc).count());
     }
     *d_shard = d;
     return BSK_OK;
