@@ -404,8 +404,9 @@ int translate_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format,
     // FASTA: first with the record table from the '>' bytes alone (stream_fasta_light.hip) -- k_translate_wide validates the
     // whole text against the layout that table assumes; whatever does not fit (a record flagged by the wide kernel, a
     // chromosome-sized one, ...) sends the call through the full index pass below, and the context remembers it
+    // (... which is why the light table is not used where the wide kernel does not run: a shard below its minimum size)
     bool light = format == BSK_FORMAT_FASTA && c->translate_light_ok && !c->tune.is("translate_index", "full") &&
-                 !c->tune.get("translate") && !o.b("InitCodonAsM");
+                 !c->tune.get("translate") && !o.b("InitCodonAsM") && (uint64_t)n >= TRANSLATE_WIDE_MIN_BYTES;
     rc = BSK_ERR_FILTER_FALLBACK;
     if (light) {
         rc = build_index_light(c, d_buf, n, st);

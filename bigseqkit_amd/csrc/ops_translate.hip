@@ -1780,7 +1780,7 @@ hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, con
     if (!v3) {
         // the wide kernel first (plain A/C/G/T text in ordinary layouts), then frames4 for the records it flagged
         const uint8_t* only = nullptr;
-        if (redo && !nowide && buf_n >= 64) {  // (k_translate_wide asks for 52 bytes at `buf` on behalf of idle lanes)
+        if (redo && !nowide && buf_n >= TRANSLATE_WIDE_MIN_BYTES) {  // (k_translate_wide asks for 52 bytes at `buf` on behalf of idle lanes)
             if (wide_lanes == 64)
                 hipLaunchKernelGGL((k_translate_wide<64, false>), dim3((unsigned)((t.n * 64 + 255) / 256)), dim3(256), 0, st, buf, buf_n, t, d,
                                    P, out_len, out_off, out, redo, redo_count, status);

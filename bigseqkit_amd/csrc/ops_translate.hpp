@@ -77,6 +77,10 @@ hipError_t launch_translate_size(const uint8_t* buf, const RecordTable& t, const
 // all requested frames of a record from ONE read of its bases (G lanes per record).  With `redo` (one zeroed byte per
 // record) k_translate_wide<wide_lanes> translates the records of plain A/C/G/T text first and k_translate_frames4 the ones
 // it flags; buf_n = bytes in the shard (the wide kernel reads 64 bytes at a time and must not pass the end)
+// k_translate_wide asks for 52 bytes at `buf` on behalf of idle lanes: shards smaller than this go to k_translate_frames4
+// alone -- which validates nothing, so a record table whose lengths are DERIVED (the light table) needs the full pass there
+// (a 62-byte shard with lines of 46, 5 and 1 letters came out as 53 bases with a line break among them: fuzz seed 1414, round 6)
+constexpr uint64_t TRANSLATE_WIDE_MIN_BYTES = 64;
 hipError_t launch_translate_frames(int lanes_per_record, const uint8_t* buf, const RecordTable& t, const TextTableH& tt,
                                    const TranslateParams& P, const uint32_t* out_len, const uint64_t* out_off,
                                    uint8_t* out, uint64_t* status, hipStream_t st, uint64_t buf_n = 0, uint8_t* redo = nullptr,

@@ -130,3 +130,26 @@ def test_a_break_in_the_right_window_but_the_wrong_place_is_not_trusted(lines_of
     assert outs[0][0] == want and outs[1][0] == want
     assert "k_fasta_starts" in outs[0][1] and "k_index=" in outs[0][1]   # tried light, fell back
     assert "k_fasta_starts" not in outs[1][1]
+
+
+def test_a_shard_below_the_wide_kernels_minimum_is_not_left_to_the_light_table():
+    """fuzz seed 1414 (round 6): 62 bytes, lines of 46, 5 and 1 letters, no final line break.  The light table derives 53
+    bases from "every line but the last is as long as the first"; k_translate_wide, which would have found the line break
+    among them, does not run on shards below 64 bytes -- and k_translate_frames4 validates nothing.  Such a shard takes the
+    full index pass."""
+    data = b">s0 a>b\ntgCCtCggaTtTCgAggcGGgcTAtTattAacAGTAccTggGcTGg\ngaGTt\nt"
+    assert len(data) == 62
+    for opts in ({"Config": {"LineWidth": 1}, "Frame": ["-3"], "TranslTable": 4, "AllowUnknownCodon": True, "Clean": True, "AppendFrame": True},
+                 {"Frame": ["6"]}, {"Frame": ["1"], "Config": {"LineWidth": 0}}):
+        want = oracle.translate(data, False, json.dumps(opts))
+        for sets in ((), ((b"translate_index", b"light"),)):
+            for got, _ in translate(data, opts, sets):
+                assert got == want, (opts, sets)
+    # ... and irregular lines in shards just above the minimum are caught by the wide kernel as before
+    rng = random.Random(1414)
+    for k in range(40):
+        lines = ["".join(rng.choice("ACGTacgt") for _ in range(rng.choice((46, 30, 5, 1, 60)))) for _ in range(rng.randint(1, 4))]
+        d = (">r x\n" + "\n".join(lines) + rng.choice(("", "\n"))).encode()
+        want = oracle.translate(d, False, json.dumps({"Frame": ["6"]}))
+        for got, _ in translate(d, {"Frame": ["6"]}):
+            assert got == want, d
