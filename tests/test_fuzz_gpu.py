@@ -209,6 +209,63 @@ def test_fuzz_every_command(seed, monkeypatch):
     assert agree > 45
 
 
+def one_case(op, fastq, data, opts):
+    """both sides on one input: the same bytes, or both fail (the HIP path may decline what it documents as unsupported)"""
+    fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+    ofn, gfn = OPS[op]
+    try:
+        want, werr = ofn(data, fastq, json.dumps(opts)), None
+    except oracle.OracleError as e:
+        want, werr = None, str(e)
+    try:
+        got, gerr = gfn(bsk.SeqFrame(fmt, [dev(data)]), _Opts(opts)), None
+    except bsk.BskError as e:
+        got, gerr = None, str(e)
+    ctx = (op, fastq, opts, data[:300])
+    if werr is not None or gerr is not None:
+        assert gerr is not None, ("oracle failed, HIP path answered", werr, ctx)
+        if werr is None:
+            assert "not supported" in gerr or "not accepted" in gerr or "libbsk" in gerr, (gerr, ctx)
+        return False
+    assert got == want, ctx
+    return True
+
+
+@pytest.mark.parametrize("seed", range(max(2, int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24")) // 4)))
+def test_fuzz_tiny_inputs(seed, monkeypatch):
+    """shards of a few dozen bytes: one to three short records with awkward line shapes.  Kernels that fetch a window on
+    behalf of idle lanes, tables whose lengths are derived and validated by a pass that needs a minimum size, ranges cut
+    from nearly nothing -- seed 1414 of the test above met the one such case among 130 000 (a 62-byte FASTA whose `translate`
+    trusted a record table nothing had validated); here every input is that small."""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    if seed % 3 == 0:
+        monkeypatch.setenv("BSK_OUT", "slices")
+    rng = random.Random(77000 + seed)
+    agree = 0
+    for it in range(150):
+        op = rng.choice(list(OPS))
+        fastq = rng.random() < 0.5
+        recs = []
+        for k in range(rng.randint(1, 3)):
+            L = rng.choice([0, 1, 2, 3, 5, 16, 17, rng.randint(0, 60)])
+            s = rand_seq(rng, L, rng.choice(["ACGT", "ACGTacgt", "ACGTN"]))
+            name = f"s{k}" + rng.choice(["", " d", " a>b"])
+            if fastq:
+                recs.append(f"@{name}\n{s}\n+\n{''.join(chr(rng.randint(35, 73)) for _ in range(L))}\n")
+            else:
+                lines, j = [], 0
+                while j < L:
+                    w = rng.choice([1, 5, 16, 46, 60, rng.randint(1, 50)])
+                    lines.append(s[j:j + w])
+                    j += w
+                recs.append(f">{name}\n" + "".join(l + "\n" for l in lines))
+        data = "".join(recs)
+        if rng.random() < 0.4 and data.endswith("\n"):
+            data = data[:-1]
+        agree += one_case(op, fastq, data.encode(), rand_opts(rng, op, fastq))
+    assert agree > 60
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24")) // 2))
 def test_fuzz_two_input_commands(seed, monkeypatch):
     """pair / common / concat on random pairs of files that share part of their IDs (one GPU call sees both files)"""
