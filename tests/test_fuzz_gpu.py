@@ -209,6 +209,13 @@ def test_fuzz_every_command(seed, monkeypatch):
     assert agree > 45
 
 
+def extra_env(monkeypatch):
+    """BSK_FUZZ_ENV="BSK_SEGCOPY=force,BSK_TEXT=view": one more selection of the run-time switches for a soak of many seeds"""
+    for kv in filter(None, __import__("os").environ.get("BSK_FUZZ_ENV", "").split(",")):
+        k, v = kv.split("=", 1)
+        monkeypatch.setenv(k, v)
+
+
 def one_case(op, fastq, data, opts):
     """both sides on one input: the same bytes, or both fail (the HIP path may decline what it documents as unsupported)"""
     fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
@@ -240,6 +247,7 @@ def test_fuzz_tiny_inputs(seed, monkeypatch):
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
     if seed % 3 == 0:
         monkeypatch.setenv("BSK_OUT", "slices")
+    extra_env(monkeypatch)
     rng = random.Random(77000 + seed)
     agree = 0
     for it in range(150):
@@ -270,6 +278,7 @@ def test_fuzz_tiny_inputs(seed, monkeypatch):
 def test_fuzz_two_input_commands(seed, monkeypatch):
     """pair / common / concat on random pairs of files that share part of their IDs (one GPU call sees both files)"""
     monkeypatch.setenv("BSK_MIN_RANGE_BYTES", "4096")
+    extra_env(monkeypatch)
     rng = random.Random(9000 + seed)
     for it in range(20):
         fastq = rng.random() < 0.5

@@ -170,3 +170,44 @@ def test_a_rank_without_records_and_a_rank_that_fails():
     bad = good[:len(good) // 2] + b"@x\nAC\n+\nIII\n" + good[len(good) // 2:]
     outs, stats, errs = run_ranks(bad, bsk.FORMAT_FASTQ, {"BySeq": True}, [0, 0])
     assert all(e for e in errs), errs     # every rank leaves with an error; nobody waits in a collective
+
+
+@pytest.mark.parametrize("seed", range(max(2, int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24")) // 8)))
+def test_fuzz_ranks(seed):
+    """random worlds, record counts (ranks without a record among them), subjects, formats and key widths: the ranks' outputs
+    joined in rank order are the oracle's -- RmDupCheck over the whole file"""
+    rng = random.Random(31000 + seed)
+    for it in range(6):
+        world = rng.choice([1, 2, 2, 3, 4, 5])
+        fastq = rng.random() < 0.7
+        n = rng.choice([0, 1, 2, world - 1, world, 7, rng.randint(0, 60), rng.randint(100, 4000)])
+        opts = rng.choice([{"BySeq": True}, {"BySeq": True, "IgnoreCase": True}, {}, {"ByName": True}, {"ByName": True, "IgnoreCase": True},
+                           {"BySeq": True, "OnlyPositiveStrand": True}])
+        lens = rng.choice([(20, 36, 150, 151, 7), (1, 2, 3), (150,), (0, 5, 33), (300, 301, 64)])
+        alphabet = rng.choice(["ACGT", "ACGTacgt", "ACGTN"])
+        uniq = ["".join(rng.choice(alphabet) for _ in range(rng.choice(lens))) for _ in range(max(1, int(n * rng.choice([0.2, 0.6, 1.0]))))]
+        recs = []
+        for i in range(n):
+            s = rng.choice(uniq)
+            name = "r%d id%d%s" % (i, i % max(1, n // rng.choice([1, 3, 10])), rng.choice(["", " desc", "\tx"]))
+            if fastq:
+                recs.append("@%s\n%s\n+\n%s\n" % (name, s, "".join(chr(rng.randint(35, 73)) for _ in s)))
+            else:
+                w = rng.choice([60, 0, 7, 70])
+                body = s + "\n" if (w == 0 and s) else "".join(s[k:k + w] + "\n" for k in range(0, len(s), w)) if w else ""
+                recs.append(">%s\n%s" % (name, body))
+        data = "".join(recs).encode()
+        fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+        sw = rng.choice([None, None, {"rmdup_k1_bits": 16, "rmdup_k2_bits": rng.choice([1, 2, 3])}, {"rmdup_k1_bits": 20, "rmdup_k2_bits": 1},
+                         {"rmdup_xcheck": "off"}])
+        ctx = (seed, it, world, fastq, n, opts, lens, sw)
+        try:
+            want, werr = oracle.rmdup(data, fastq, json.dumps(opts)), None
+        except oracle.OracleError as e:
+            want, werr = None, str(e)
+        outs, stats, errs = run_ranks(data, fmt, opts, [0] * world, sw)
+        if werr is not None:
+            assert any(errs), (werr, ctx)
+            continue
+        assert errs == [None] * world, (errs, ctx)
+        assert b"".join(outs) == want, ctx
