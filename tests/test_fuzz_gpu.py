@@ -209,6 +209,28 @@ def test_fuzz_every_command(seed, monkeypatch):
     assert agree > 45
 
 
+def rand_tiny(rng, fastq):
+    """one to three short records with awkward line shapes: a shard of a few dozen bytes"""
+    recs = []
+    for k in range(rng.randint(1, 3)):
+        L = rng.choice([0, 1, 2, 3, 5, 16, 17, rng.randint(0, 60)])
+        s = rand_seq(rng, L, rng.choice(["ACGT", "ACGTacgt", "ACGTN"]))
+        name = f"s{k}" + rng.choice(["", " d", " a>b"])
+        if fastq:
+            recs.append(f"@{name}\n{s}\n+\n{''.join(chr(rng.randint(35, 73)) for _ in range(L))}\n")
+        else:
+            lines, j = [], 0
+            while j < L:
+                w = rng.choice([1, 5, 16, 46, 60, rng.randint(1, 50)])
+                lines.append(s[j:j + w])
+                j += w
+            recs.append(f">{name}\n" + "".join(l + "\n" for l in lines))
+    data = "".join(recs)
+    if rng.random() < 0.4 and data.endswith("\n"):
+        data = data[:-1]
+    return data.encode()
+
+
 def extra_env(monkeypatch):
     """BSK_FUZZ_ENV="BSK_SEGCOPY=force,BSK_TEXT=view": one more selection of the run-time switches for a soak of many seeds"""
     for kv in filter(None, __import__("os").environ.get("BSK_FUZZ_ENV", "").split(",")):
@@ -253,25 +275,79 @@ def test_fuzz_tiny_inputs(seed, monkeypatch):
     for it in range(150):
         op = rng.choice(list(OPS))
         fastq = rng.random() < 0.5
-        recs = []
-        for k in range(rng.randint(1, 3)):
-            L = rng.choice([0, 1, 2, 3, 5, 16, 17, rng.randint(0, 60)])
-            s = rand_seq(rng, L, rng.choice(["ACGT", "ACGTacgt", "ACGTN"]))
-            name = f"s{k}" + rng.choice(["", " d", " a>b"])
-            if fastq:
-                recs.append(f"@{name}\n{s}\n+\n{''.join(chr(rng.randint(35, 73)) for _ in range(L))}\n")
-            else:
-                lines, j = [], 0
-                while j < L:
-                    w = rng.choice([1, 5, 16, 46, 60, rng.randint(1, 50)])
-                    lines.append(s[j:j + w])
-                    j += w
-                recs.append(f">{name}\n" + "".join(l + "\n" for l in lines))
-        data = "".join(recs)
-        if rng.random() < 0.4 and data.endswith("\n"):
-            data = data[:-1]
-        agree += one_case(op, fastq, data.encode(), rand_opts(rng, op, fastq))
+        data = rand_tiny(rng, fastq)
+        agree += one_case(op, fastq, data, rand_opts(rng, op, fastq))
     assert agree > 60
+
+
+@pytest.mark.parametrize("seed", range(max(2, int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24")) // 4)))
+def test_fuzz_stats(seed, monkeypatch):
+    """the headline command: the merged map (Stats.Call + StatsReduce, bigseqkit-lib/stats.go:48-137) and the printed row
+    (bigseqkit/stats.go:75-288) on random inputs x `-a`, gap letters, quality encodings, tabular -- input cut into several
+    partitions some of the time (the map is additive, the type column comes from the first record)"""
+    monkeypatch.setenv("BSK_MIN_RANGE_BYTES", rng_choice(seed, ["4096", "1024", "65536"]))
+    extra_env(monkeypatch)
+    rng = random.Random(41000 + seed)
+    for it in range(60):
+        fastq = rng.random() < 0.5
+        if rng.random() < 0.3:
+            data = rand_tiny(rng, fastq)
+        elif fastq:
+            data = rand_fastq(rng)
+        else:
+            data = rand_fasta(rng)
+            if rng.random() < 0.5:   # gap letters among the bases
+                gaps = rng.choice([b"-", b".", b" ", b"-.", b"*"])
+                b = bytearray(data)
+                for _ in range(rng.randint(1, 40)):
+                    k = rng.randrange(len(b))
+                    if b[k] in b"ACGTacgtN":
+                        b[k] = rng.choice(gaps)
+                data = bytes(b)
+        opts = {}
+        if rng.random() < 0.6: opts["All"] = True
+        if rng.random() < 0.4: opts["GapLetters"] = rng.choice(["- .", "-", ".N", "-*.", "", "ACGT"])
+        if rng.random() < 0.4: opts["FqEncoding"] = rng.choice(["sanger", "solexa", "illumina-1.3+", "illumina-1.5+", "illumina-1.8+"])
+        if rng.random() < 0.3: opts["Tabular"] = True
+        if rng.random() < 0.2: opts["Basename"] = True
+        ctx = (seed, it, fastq, opts, data[:200])
+        try:
+            want_m, werr = oracle.stats_map(data, fastq, json.dumps(opts)), None
+            want_s = oracle.stats_string(data, fastq, json.dumps(opts), name="dir/in.fq", fmt="FASTQ" if fastq else "FASTA")
+        except oracle.OracleError as e:
+            want_m, werr = None, str(e)
+        fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
+        parts = [dev(data)]
+        if len(data) > 200 and rng.random() < 0.4:   # two partitions cut at a record start
+            cut = data.find(b"\n@" if fastq else b"\n>", len(data) // 2)
+            if fastq and cut >= 0:   # ('@' may open a quality line: take the cut only if the oracle reads both halves alike)
+                try:
+                    a, b2 = oracle.stats_map(data[:cut + 1], True, json.dumps(opts)), oracle.stats_map(data[cut + 1:], True, json.dumps(opts))
+                    merged = dict(a)
+                    for k, v in b2.items():
+                        merged[k] = merged.get(k, 0) + v
+                    if merged != want_m:
+                        cut = -1
+                except oracle.OracleError:
+                    cut = -1
+            if cut >= 0:
+                parts = [dev(data[:cut + 1]), dev(data[cut + 1:])]
+        try:
+            got_m, op = bsk.stats_map(bsk.SeqFrame(fmt, parts), _Opts(opts))
+            op.close()
+            got_s = bsk.StatsString("dir/in.fq", "FASTQ" if fastq else "FASTA", bsk.SeqFrame(fmt, parts), _Opts(opts))
+            gerr = None
+        except bsk.BskError as e:
+            got_m, gerr = None, str(e)
+        if werr is not None or gerr is not None:
+            assert werr is not None and gerr is not None, (werr, gerr, ctx)
+            continue
+        assert got_m == want_m, ctx
+        assert got_s == want_s, ctx
+
+
+def rng_choice(seed, xs):
+    return xs[seed % len(xs)]
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSK_FUZZ_SEEDS", "24")) // 2))
