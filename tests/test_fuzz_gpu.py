@@ -35,8 +35,9 @@ def rand_fasta(rng):
     alphabet = rng.choice(["ACGT", "ACGTN", "ACGTacgt", "ACGTRYKMSWN", "ACGUacgu"])
     style = rng.choice(["w60", "w1line", "w17", "w7", "irregular", "mixed"])
     recs = []
-    for k in range(rng.randint(1, 60)):
-        L = rng.choice([0, 1, 2, 3, 15, 16, 17, 59, 60, 61, 120, rng.randint(0, 400), rng.randint(0, 2000)])
+    dense = rng.random() < 0.125   # (as in rand_fastq below: hundreds of records of a few bytes)
+    for k in range(rng.randint(300, 1500) if dense else rng.randint(1, 60)):
+        L = rng.choice([0, 0, 1, 2, 3, 7]) if dense else rng.choice([0, 1, 2, 3, 15, 16, 17, 59, 60, 61, 120, rng.randint(0, 400), rng.randint(0, 2000)])
         s = rand_seq(rng, L, alphabet)
         st = style if style != "mixed" else rng.choice(["w60", "w1line", "w17", "w7", "irregular"])
         if st == "irregular":
@@ -59,8 +60,11 @@ def rand_fasta(rng):
 def rand_fastq(rng):
     alphabet = rng.choice(["ACGT", "ACGTN", "ACGTacgtN"])
     recs = []
-    for k in range(rng.randint(1, 80)):
-        L = rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 150, rng.randint(0, 300)])
+    # one input in eight: hundreds of records of a few bytes each -- more newlines per 4 KiB tile than a sink's window holds
+    # (the overflow paths of the streaming passes: stream_core_dev.hpp "a tile with more newlines than that")
+    dense = rng.random() < 0.125
+    for k in range(rng.randint(300, 1500) if dense else rng.randint(1, 80)):
+        L = rng.choice([0, 1, 1, 2, 3]) if dense else rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 150, rng.randint(0, 300)])
         s = rand_seq(rng, L, alphabet)
         q = "".join(chr(rng.randint(33, 74)) for _ in range(L))
         if L and rng.random() < 0.3:
