@@ -88,12 +88,39 @@ def seq_opts(opts_json):
                    g("QualAsciiBase", 33), float(g("MinQual", -1)), float(g("MaxQual", -1)))
 
 
+def _deep(call):
+    """run `call` on a thread with a 1 GiB stack: libstdc++'s std::regex (the stand-in for Go's regexp in `grep -r` /
+    `locate -r` / --id-regexp) matches recursively -- `^A.*T$` on a read of 17 821 bases overflowed the 8 MiB of the main
+    thread (fuzz seed 423, round 6: the CHECKER crashed, not the product)"""
+    import threading
+    res = []
+
+    def body():
+        try:
+            res.append((True, call()))
+        except BaseException as e:  # noqa: BLE001 -- handed to the caller's thread
+            res.append((False, e))
+
+    old = threading.stack_size(1 << 30)
+    try:
+        t = threading.Thread(target=body)
+        t.start()
+    finally:
+        threading.stack_size(old)
+    t.join()
+    ok, v = res[0]
+    if not ok:
+        raise v
+    return v
+
+
 def _run_text(fn, data, fastq, o, nparts):
     cap = 4 * len(data) + 4096
     while True:
         out, n, nrec, err = C.create_string_buffer(cap), C.c_size_t(), C.c_uint64(), C.create_string_buffer(_ERR)
-        rc = fn(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), nparts, out, C.c_size_t(cap), C.byref(n),
-                C.byref(nrec), err, _ERR)
+        call = lambda: fn(_buf(data), C.c_size_t(len(data)), int(fastq), C.byref(o), nparts, out, C.c_size_t(cap), C.byref(n),
+                          C.byref(nrec), err, _ERR)
+        rc = _deep(call) if len(data) > 2000 else call()
         if rc == 2:
             cap = n.value + 16
             continue

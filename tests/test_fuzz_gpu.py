@@ -36,8 +36,12 @@ def rand_fasta(rng):
     style = rng.choice(["w60", "w1line", "w17", "w7", "irregular", "mixed"])
     recs = []
     dense = rng.random() < 0.125   # (as in rand_fastq below: hundreds of records of a few bytes)
+    # one input in ten: a few records of 5 - 60 kb among the others -- lines and records longer than a range of 4 KiB
+    long_at = set(rng.sample(range(60), rng.randint(1, 3))) if (not dense and rng.random() < 0.1) else set()
     for k in range(rng.randint(300, 1500) if dense else rng.randint(1, 60)):
         L = rng.choice([0, 0, 1, 2, 3, 7]) if dense else rng.choice([0, 1, 2, 3, 15, 16, 17, 59, 60, 61, 120, rng.randint(0, 400), rng.randint(0, 2000)])
+        if k in long_at:
+            L = rng.randint(5000, 60000)
         s = rand_seq(rng, L, alphabet)
         st = style if style != "mixed" else rng.choice(["w60", "w1line", "w17", "w7", "irregular"])
         if st == "irregular":
@@ -65,6 +69,8 @@ def rand_fastq(rng):
     dense = rng.random() < 0.125
     for k in range(rng.randint(300, 1500) if dense else rng.randint(1, 80)):
         L = rng.choice([0, 1, 1, 2, 3]) if dense else rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 150, rng.randint(0, 300)])
+        if not dense and rng.random() < 0.004:
+            L = rng.randint(4000, 30000)   # (a long read now and then: lines longer than a range of 4 KiB)
         s = rand_seq(rng, L, alphabet)
         q = "".join(chr(rng.randint(33, 74)) for _ in range(L))
         if L and rng.random() < 0.3:
