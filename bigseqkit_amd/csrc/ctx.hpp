@@ -82,6 +82,11 @@ struct bsk_ctx {
 
     // ---- Stats ----------------------------------------------------------------
     bsk::Alphabet alphabet = bsk::AB_NONE;  // forced by -t, else AB_NONE
+    // ... or the GUESS of a partition's first record, held for the calls that feed that partition piece by piece
+    // (bsk_run_to_store, switch pin_alphabet): that is not a -t -- SeqTransform.Before switches validation on for a GIVEN
+    // type only (seq.go:66-72).  Round 6: `seq` on a streamed shard whose first record read as DNA refused the RNA behind it.
+    bool alphabet_guessed = false;
+    bool alphabet_given() const { return !alphabet_guessed && !(alphabet == bsk::AB_NONE || alphabet == bsk::AB_UNLIMIT); }
     uint32_t hist_cap = 1u << 16;
     uint64_t* d_vec = nullptr;       // ctx-owned stats vector
     uint64_t* d_status = nullptr;    // [0] err flags [1] overflow count            (= d_ctl)

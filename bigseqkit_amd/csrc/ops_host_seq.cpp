@@ -126,7 +126,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
         // names only, nothing that needs the sequence (length / quality filters, gap removal, letter validation): the
         // streaming pass writes them (BSK_NAMES=off keeps the record-table path)
         const char* nm = c->tune.get("names");
-        const bool explicit_alphabet = !(c->alphabet == AB_NONE || c->alphabet == AB_UNLIMIT);
+        const bool explicit_alphabet = c->alphabet_given();
         if (fastq && n > 0 && o.b("Name") && !o.b("Seq") && !o.b("RemoveGaps") && o.i("MinLen") <= 0 && o.i("MaxLen") <= 0 &&
             !(o.f("MinQual") > 0) && !(o.f("MaxQual") > 0) && !o.b("ValidateSeq") && !explicit_alphabet &&
             (!o.b("OnlyId") || id_mode_of(c) != 2) && !(nm && strcmp(nm, "off") == 0)) {
@@ -169,7 +169,7 @@ int seq_run_device(bsk_ctx* c, const uint8_t* d_buf, size_t n, int format, hipSt
     P.min_qual = o.f("MinQual"); P.max_qual = o.f("MaxQual");
     P.qual_base = (int)o.i("QualAsciiBase");
     bool validate = o.b("ValidateSeq");
-    if (!validate && !(c->alphabet == AB_NONE || c->alphabet == AB_UNLIMIT)) validate = true;  // seq.go:66-72
+    if (!validate && c->alphabet_given()) validate = true;  // seq.go:66-72 (a type that was GIVEN: not a partition's pinned guess)
     const char* letters = alphabet_letters(ab);
     P.validate = validate && letters != nullptr;
     P.validate_len = (int)o.i("ValidateSeqLength");

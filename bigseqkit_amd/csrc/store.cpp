@@ -425,7 +425,7 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
             if (swapped) { std::swap(c->d_out, alt_out); std::swap(c->out_cap, alt_cap); }
             c->d_out_alt = alt_out;
             c->out_alt_cap = alt_cap;
-            if (alphabet_pinned) c->alphabet = saved_alphabet;
+            if (alphabet_pinned) { c->alphabet = saved_alphabet; c->alphabet_guessed = false; }
             for (int b = 0; b < 2; ++b) { if (in_done[b]) hipEventDestroy(in_done[b]); if (in_free[b]) hipEventDestroy(in_free[b]); }
         }
     } S{c, c->d_out_alt, c->out_alt_cap};
@@ -490,6 +490,7 @@ int bsk_run_to_store(bsk_ctx* c, const void* host_shard, size_t n, int format, i
             const Alphabet ab = partition_alphabet(c, c->d_stage[b], cuts[1] - cuts[0], format, st, &arc);
             if (arc != BSK_OK) { rc = arc; break; }
             c->alphabet = ab;
+            c->alphabet_guessed = true;
             S.alphabet_pinned = !pin_for_good;
         }
         std::swap(c->d_out, S.alt_out);
