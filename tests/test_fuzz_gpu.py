@@ -83,7 +83,25 @@ def rand_fastq(rng):
     return data.encode()
 
 
-def rand_opts(rng, op, fastq):
+def planted(rng, data, fastq):
+    """a pattern of 11 - 40 letters cut out of the input (or its reverse complement), so that it occurs: patterns of 11 to 64
+    letters on FASTQ take the search INSIDE the streaming pass (k_filter, stream_filter.hpp FILTER_MIN_LEN) -- with random
+    patterns of up to 8 letters this test never went there"""
+    lines = data.split(b"\n")
+    seqs = [l for i, l in enumerate(lines) if (i % 4 == 1 if fastq else (l and not l.startswith(b">")))]
+    seqs = [l for l in seqs if len(l) >= 11 and all(c in b"ACGTacgtN" for c in l)]
+    if not seqs:
+        return None
+    l = rng.choice(seqs)
+    n = rng.randint(11, min(40, len(l)))
+    at = rng.randrange(len(l) - n + 1)
+    p = l[at:at + n].decode()
+    if rng.random() < 0.3:
+        p = p[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+    return p
+
+
+def rand_opts(rng, op, fastq, data=None):
     cfg = {"LineWidth": rng.choice([60, 0, 1, 13, 70])}
     if rng.random() < 0.15:
         cfg["IDNCBI"] = True
@@ -104,7 +122,12 @@ def rand_opts(rng, op, fastq):
         mode = rng.choice(["id", "name", "seq", "seq", "deg", "mm", "re", "re_seq"])
         if mode == "id": o["Pattern"] = [f"s{rng.randint(0, 30)}", f"r{rng.randint(0, 30)}"]
         elif mode == "name": o.update(Pattern=[f"s{rng.randint(0, 9)} desc", f"r{rng.randint(0, 9)} d"], ByName=True)
-        elif mode == "seq": o.update(Pattern=[pat(), pat()], BySeq=True)
+        elif mode == "seq":
+            o.update(Pattern=[pat(), pat()], BySeq=True)
+            if data is not None and rng.random() < 0.6:
+                ps = [p for p in (planted(rng, data, fastq) for _ in range(rng.randint(1, 3))) if p]
+                if ps:
+                    o["Pattern"] = ps
         elif mode == "deg": o.update(Pattern=[rand_seq(rng, rng.randint(2, 7), "ACGTNRY")], Degenerate=True)
         elif mode == "mm": o.update(Pattern=[rand_seq(rng, rng.randint(4, 9), "ACGT")], MaxMismatch=rng.randint(1, 2))
         elif mode == "re": o.update(Pattern=[rng.choice(["^s[0-9]$", "1$", "^r\\d\\d", "s(1|2)+"])], UseRegexp=True, ByName=rng.random() < 0.5)
@@ -123,6 +146,10 @@ def rand_opts(rng, op, fastq):
     elif op == "locate":
         mode = rng.choice(["exact", "exact", "deg", "mm", "fmi", "re"])
         o["Pattern"] = [rand_seq(rng, rng.randint(1, 6), "ACGT") for _ in range(rng.randint(1, 3))]
+        if mode == "exact" and data is not None and rng.random() < 0.6:
+            ps = [p for p in (planted(rng, data, fastq) for _ in range(rng.randint(1, 2))) if p]
+            if ps:
+                o["Pattern"] = ps
         if mode == "deg": o.update(Pattern=[rand_seq(rng, rng.randint(2, 6), "ACGTNRYW")], Degenerate=True)
         elif mode == "mm": o.update(Pattern=[rand_seq(rng, rng.randint(4, 8), "ACGT")], MaxMismatch=1)
         elif mode == "fmi": o["UseFmi"] = True
@@ -191,7 +218,7 @@ def test_fuzz_every_command(seed, monkeypatch):
         data = rand_fastq(rng) if fastq else rand_fasta(rng)
         if op == "translate" and rng.random() < 0.8:
             data = data.replace(b"-", b"A")
-        opts = rand_opts(rng, op, fastq)
+        opts = rand_opts(rng, op, fastq, data)
         fmt = bsk.FORMAT_FASTQ if fastq else bsk.FORMAT_FASTA
         ofn, gfn = OPS[op]
         try:
@@ -286,7 +313,7 @@ def test_fuzz_tiny_inputs(seed, monkeypatch):
         op = rng.choice(list(OPS))
         fastq = rng.random() < 0.5
         data = rand_tiny(rng, fastq)
-        agree += one_case(op, fastq, data, rand_opts(rng, op, fastq))
+        agree += one_case(op, fastq, data, rand_opts(rng, op, fastq, data))
     assert agree > 60
 
 
